@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz|json by RUNNING the reference's own pure-Python
+hot-path code (utils/sampler.py, utils/metrics.py, model/RankingPreprocess.py).
+
+Run in the build container only (needs /root/reference); the outputs are data
+(inputs + expected outputs) and are committed, the reference code is not.
+
+utils/tools.py imports tensorflow and gensim at module top although the
+sampler / preprocess only use its `timer` and `re_index`; both packages are
+absent here, so inert empty modules are registered under those names before the
+import.  No reference file is modified or copied.
+
+    python tools/make_golden.py [--ref /root/reference] [--out tests/golden]
+"""
+import argparse
+import hashlib
+import json
+import logging
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+
+def _import_reference(ref):
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, ref)
+    for name in ("tensorflow", "gensim", "gensim.models", "gensim.models.word2vec"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["gensim"].models = sys.modules["gensim.models"]
+    sys.modules["gensim.models"].word2vec = sys.modules["gensim.models.word2vec"]
+    import utils.metrics as metrics
+    import utils.sampler as sampler
+    return sampler, metrics
+
+
+class Data:
+    pass
+
+
+def synth_ui(seed, n_users, n_items, lo, hi, skip_every=0):
+    """Small synthetic ui_train in the reference's protocol: dict[int -> list[int]],
+    keys ascending, item lists unsorted without duplicates."""
+    g = np.random.Generator(np.random.PCG64(seed))
+    pop = 1.0 / np.arange(1, n_items + 1)
+    pop /= pop.sum()
+    ui = {}
+    for u in range(n_users):
+        if skip_every and u % skip_every == skip_every - 1:
+            continue  # users without train rows exist in the reference protocol
+        k = int(g.integers(lo, hi + 1))
+        ui[u] = [int(x) for x in g.choice(n_items, size=k, replace=False, p=pop)]
+    return ui
+
+
+def csr(ui):
+    keys = np.array(list(ui.keys()), dtype=np.int32)
+    ptr = np.zeros(len(ui) + 1, dtype=np.int64)
+    ptr[1:] = np.cumsum([len(v) for v in ui.values()])
+    items = np.array([x for v in ui.values() for x in v], dtype=np.int32)
+    return keys, ptr, items
+
+
+def sampler_case(sampler, name, ui, item_nums, seed, neg_ratio, batch):
+    d = Data()
+    d.ui_train, d.item_nums = ui, item_nums
+    out = {}
+    keys, ptr, items = csr(ui)
+    out.update(keys=keys, ptr=ptr, items=items, item_nums=item_nums, seed=seed, neg_ratio=neg_ratio, batch=batch)
+    np.random.seed(seed)
+    nb, u, i, j = sampler.pairwise_ranking_sampler(d, neg_ratio, batch)
+    out.update(pw_batches=nb, pw_u=u.astype(np.int64), pw_i=i.astype(np.int64), pw_j=j.astype(np.int64),
+               pw_next=np.random.randint(2 ** 30))
+    np.random.seed(seed)
+    nb, u, i, y = sampler.pointwise_ranking_sampler(d, neg_ratio, batch)
+    out.update(pt_batches=nb, pt_u=u.astype(np.int64), pt_i=i.astype(np.int64), pt_y=y.astype(np.float64),
+               pt_next=np.random.randint(2 ** 30))
+    np.random.seed(seed)
+    nb, u, i, neg = sampler.ranking_sampler_cml(d, neg_ratio, batch)
+    out.update(cml_batches=nb, cml_u=u.astype(np.int64), cml_i=i.astype(np.int64), cml_neg=neg.astype(np.int64),
+               cml_next=np.random.randint(2 ** 30))
+    return name, out
+
+
+def metrics_cases(metrics, n=400):
+    g = np.random.Generator(np.random.PCG64(7))
+    cases = [([5], [1, 5, 3], 3), ([5, 8, 9], [9, 2, 5, 7, 1, 0, 3, 4, 6, 10], 10), ([1, 2], [7, 8], 2),
+             ([3, 7], [7, 1, 3, 9], 4)]
+    for _ in range(n):
+        n_items = int(g.integers(5, 60))
+        K = int(g.integers(1, min(20, n_items) + 1))
+        n_real = int(g.integers(1, min(15, n_items) + 1))
+        real = [int(x) for x in g.choice(n_items, size=n_real, replace=False)]
+        rec = [int(x) for x in g.choice(n_items, size=K, replace=False)]
+        cases.append((real, rec, K))
+    out = []
+    for real, rec, K in cases:
+        # the reference hands rec_items over as a float64 ndarray slice (RankingRecommender.py:229,242)
+        hr, mrr, ndcg = metrics.cal_ranking_metrics(real, np.array(rec, dtype=np.float64), K)
+        out.append({"real": real, "rec": rec, "K": K, "hr": float(hr), "mrr": float(mrr), "ndcg": float(ndcg)})
+    rm = metrics.cal_rmse_mae([1, 2, 3], [1.5, 2, 1])
+    return {"ranking": out, "rmse_mae": {"y": [1, 2, 3], "y_pre": [1.5, 2, 1], "rmse": rm[0], "mae": rm[1]}}
+
+
+def preprocess_case(ref, seed=0):
+    """RankingPreprocess on a synthetic UI csv (first row is swallowed as a header,
+    SURVEY 2.3) -> the `data` protocol the hot path consumes."""
+    from model.RankingPreprocess import RankingPreprocess
+    g = np.random.Generator(np.random.PCG64(11))
+    rows = set()
+    while len(rows) < 3000:
+        rows.add((int(g.integers(100, 260)), int(g.zipf(1.3)) % 400 + 1000))
+    rows = sorted(rows, key=lambda r: (r[0] * 7919 + r[1] * 104729) % 65521)
+    tmp = tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp, "syn"))
+    with open(os.path.join(tmp, "syn", "ratings.csv"), "w") as f:
+        for a, b in rows:
+            f.write("%d,%d\n" % (a, b))
+    cfg = {"data.root_dir": tmp, "data.dataset": "syn", "data.file_name": "ratings.csv", "data.sep": ",",
+           "data.format": "UI", "data.split_way": "rs", "data.split_ratio": "[0.7,0.2,0.1]",
+           "data.split_by_time": "False", "data.user_min": "0", "data.item_min": "5", "test.neg_samples": "0",
+           "recommender": "BPR"}
+    logger = logging.getLogger("golden")
+    np.random.seed(seed)
+    d = RankingPreprocess(cfg, logger)
+    tk, tp, ti = csr(d.ui_train)
+    sk, sp, si = csr(d.ui_test)
+    return {"csv_u": np.array([r[0] for r in rows], dtype=np.int64), "csv_i": np.array([r[1] for r in rows], dtype=np.int64),
+            "seed": seed, "user_nums": d.user_nums, "item_nums": d.item_nums, "train_keys": tk, "train_ptr": tp,
+            "train_items": ti, "test_keys": sk, "test_ptr": sp, "test_items": si}
+
+
+def ml100k_anchor(ref, sampler):
+    """Hashes only (MovieLens data may not be redistributed): seed(0) -> RankingPreprocess(ml-100k
+    defaults) -> seed(1) -> samplers.  Re-checkable wherever the dataset file exists."""
+    path = os.path.join(ref, "dataset", "ml-100k", "u.data")
+    if not os.path.exists(path):
+        return None
+    from model.RankingPreprocess import RankingPreprocess
+    cfg = {"data.root_dir": os.path.join(ref, "dataset"), "data.dataset": "ml-100k", "data.file_name": "u.data",
+           "data.sep": "\t", "data.format": "UI", "data.split_way": "rs", "data.split_ratio": "[0.7,0.2,0.1]",
+           "data.split_by_time": "False", "data.user_min": "0", "data.item_min": "5", "test.neg_samples": "0",
+           "recommender": "BPR"}
+    np.random.seed(0)
+    d = RankingPreprocess(cfg, logging.getLogger("golden"))
+
+    def h(a):
+        return hashlib.sha256(np.ascontiguousarray(a).astype("<i8").tobytes()).hexdigest()[:16]
+
+    out = {"user_nums": d.user_nums, "item_nums": d.item_nums, "n_train": sum(len(v) for v in d.ui_train.values()),
+           "n_test": sum(len(v) for v in d.ui_test.values()), "n_test_users": len(d.ui_test)}
+    tk, tp, ti = csr(d.ui_train)
+    out["train_hash"] = [h(tk), h(tp), h(ti)]
+    np.random.seed(1)
+    nb, u, i, j = sampler.pairwise_ranking_sampler(d, 4, 6144)
+    out["pairwise"] = {"batches": nb, "n": len(u), "first": [[int(u[k]), int(i[k]), int(j[k])] for k in range(4)],
+                       "hash": [h(u), h(i), h(j)], "next": int(np.random.randint(2 ** 30))}
+    np.random.seed(1)
+    nb, u, i, y = sampler.pointwise_ranking_sampler(d, 4, 6144)
+    out["pointwise"] = {"batches": nb, "n": len(u), "hash": [h(u), h(i)], "ysum": float(y.sum())}
+    np.random.seed(1)
+    nb, u, i, neg = sampler.ranking_sampler_cml(d, 20, 6144)
+    out["cml"] = {"batches": nb, "n": len(u), "hash": [h(u), h(i), h(neg)]}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden"))
+    a = ap.parse_args()
+    os.makedirs(a.out, exist_ok=True)
+    sampler, metrics = _import_reference(a.ref)
+
+    toy = {0: [1, 2, 3], 1: [4, 5], 2: [0, 9]}
+    cases = [
+        sampler_case(sampler, "toy", toy, 10, 123, 2, 4),
+        sampler_case(sampler, "syn200", synth_ui(1, 200, 300, 3, 40, skip_every=17), 300, 5, 4, 512),
+        # dense users: heavy seen-set rejection and frequent in-group duplicates
+        sampler_case(sampler, "dense", synth_ui(2, 24, 16, 8, 11), 16, 2 ** 32 - 1, 4, 64),
+        # item_nums a power of two (mask == max: no masked rejections) and neg_ratio 20 (CML conf)
+        sampler_case(sampler, "pow2", synth_ui(3, 60, 64, 2, 12), 64, 0, 20, 256),
+    ]
+    for name, out in cases:
+        np.savez_compressed(os.path.join(a.out, "sampler_%s.npz" % name), **out)
+    with open(os.path.join(a.out, "metrics.json"), "w") as f:
+        json.dump(metrics_cases(metrics), f)
+    np.savez_compressed(os.path.join(a.out, "preprocess_syn.npz"), **preprocess_case(a.ref))
+    anchor = ml100k_anchor(a.ref, sampler)
+    if anchor is not None:
+        with open(os.path.join(a.out, "ml100k_anchor.json"), "w") as f:
+            json.dump(anchor, f, indent=1)
+    print("golden vectors written to", os.path.abspath(a.out))
+
+
+if __name__ == "__main__":
+    main()
