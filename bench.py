@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py -- BPR triples/sec on the ml-1m-shaped workload (BASELINE.json configs[1]).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One "step" = one batch (6144 triples) through the hot path: the fused gather -> BPR loss ->
+per-row gradient sums -> TF1-semantics Adam (bpr_user_side + bpr_item_side), including the
+per-epoch-chunk index build and the loss reduction that the library launches around them.
+The sampled index stream (bit-exact host sampler, seed 1) and the tables are resident in HBM
+when the timed region starts.  Prints ONE JSON line (rank 0).
+
+Extra objects in the line:
+  roofline      dominant kernel (bpr_user_side): algorithmic bytes per launch / its average
+                duration from HIP events on the launch stream, against the 8 TB/s HBM peak
+  cpu_baseline  the CPU oracle (oracle/crec_oracle.c, one core) on a bounded sample of the
+                same workload -- a reported baseline, not the target
+  eval          full-catalogue top-20 evaluation of all test users (users/s)
+  sampler       the bit-exact host sampler's rate and the sampler-inclusive epoch rate
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+D, B, NEG, LR, REG = 64, 6144, 4, 1e-3, 0.01
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=912)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--cpu-steps", type=int, default=600, help="steps of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the roofline/eval/sampler/cpu legs")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from cleverrec_amd import runtime
+    from cleverrec_amd.data import synthetic
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == a.gpus, "--gpus %d but WORLD_SIZE=%d" % (a.gpus, world)
+
+    sess = runtime.Session(local_rank)
+    # every rank holds one ml-1m-shaped shard (its own users, its own sampled stream): weak scaling
+    data = synthetic("S-ml1m", seed=20240601 + rank)
+    gen = torch.Generator().manual_seed(rank)
+    P0 = torch.empty(data.user_nums, D).normal_(0, 0.01, generator=gen).numpy()
+    Q0 = torch.empty(data.item_nums, D).normal_(0, 0.01, generator=gen).numpy()
+    st = runtime.BprState(sess, P0, Q0, lr=LR, reg=REG, adam_mode="tf1")
+
+    sess.ctx.seed(1 + rank)
+    t0 = time.perf_counter()
+    u, i, j = sess.ctx.sample_pairwise(data.train_csr, data.item_nums, NEG)
+    t_sample = time.perf_counter() - t0
+    n_epoch = len(u)
+    du, di, dj = (sess.to_dev(x) for x in (u, i, j))
+
+    def run_steps(k):
+        """k consecutive batches, wrapping around the sampled epoch."""
+        done = 0
+        nb_epoch = n_epoch // B  # full batches only, so every step is 6144 triples
+        while done < k:
+            take = min(k - done, nb_epoch)
+            st.train_epoch(du[:take * B], di[:take * B], dj[:take * B], B)
+            done += take
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run_steps(a.warmup)
+    fence()
+    t0 = time.perf_counter()
+    run_steps(a.steps)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=sess.device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    value = a.steps * B * world / dt
+
+    out = {
+        "metric": "BPR triples/sec (train)", "value": value, "unit": "triples/s", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BPR on S-ml1m (6040x3706, 1,000,208 interactions, ml-1m marginals), d=64 fp32, "
+                               "batch 6144, neg_ratio 4, Adam tf1 semantics (BASELINE.json configs[1])",
+                   "users": data.user_nums, "items": data.item_nums, "embed_size": D, "batch_size": B,
+                   "neg_ratio": NEG, "adam_mode": "tf1", "sharding": "one shard (model + stream) per GPU" if world > 1 else "none"},
+    }
+
+    if rank == 0 and not a.no_extras:
+        # ---- roofline: per-kernel durations from HIP events on the launch stream ----------------
+        sess.ctx.profile(True)
+        run_steps(min(a.steps, n_epoch // B))
+        torch.cuda.synchronize()
+        prof = sess.ctx.profile_read()
+        sess.ctx.profile(False)
+        U, I = data.user_nums, data.item_nums
+        # algorithmic bytes per launch (DESIGN.md "Algorithmic bytes"): SURVEY 8(d)'s 24d+12 per triple
+        # split by which kernel owns the access, plus the tf1 Adam sweep 24*d*rows
+        alg = {"bpr_user_side": B * (16 * D + 12) + 24 * D * U, "bpr_item_side": B * 8 * D + 24 * D * I}
+        kern = {}
+        for name in ("bpr_user_side", "bpr_item_side", "bpr_index_batches", "bpr_row_words", "bpr_reduce_loss"):
+            ms, n = prof[name]
+            if n:
+                kern[name] = {"avg_us": ms / n * 1e3, "launches": n}
+        dom = max(("bpr_user_side", "bpr_item_side"), key=lambda k: prof[k][0])
+        avg_s = prof[dom][0] / prof[dom][1] * 1e-3
+        ach = alg[dom] / avg_s / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg[dom],
+                           "avg_launch_us": avg_s * 1e6,
+                           "note": "tables+slots 7.5 MB: Infinity-Cache resident, HBM fraction is nominal"}
+        step_bytes = alg["bpr_user_side"] + alg["bpr_item_side"]
+        out["kernels"] = kern
+        out["step_algorithmic_GBs"] = step_bytes / (dt / a.steps) / 1e9
+
+        # ---- eval: all test users, full catalogue, K = 20 ---------------------------------------
+        users = sess.to_dev(data.test_users)
+        sp, si = sess.to_dev(data.seen_csr[0]), sess.to_dev(data.seen_csr[1])
+        tp, ti = sess.to_dev(data.test_csr[0]), sess.to_dev(data.test_csr[1])
+
+        def eval_once():
+            ids, _ = runtime.eval_topk(sess, st.P, st.Q, users, sp, si, 20)
+            return runtime.rank_metrics(sess, ids, users, [10, 20], tp, ti)
+        eval_once()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 20
+        for _ in range(reps):
+            hr, mrr, ndcg = eval_once()
+        torch.cuda.synchronize()
+        te = (time.perf_counter() - t0) / reps
+        out["eval"] = {"metric": "eval users/sec@top-20 (full catalogue + HR/MRR/NDCG@10,20)", "value": len(data.test_users) / te,
+                       "unit": "users/s", "ms": te * 1e3, "users": int(len(data.test_users)), "items": I,
+                       "gemm_TFLOPs": 2.0 * len(data.test_users) * I * D / te / 1e12, "ndcg@10": float(ndcg[0].mean())}
+
+        # ---- sampler ---------------------------------------------------------------------------------
+        epoch_gpu_s = (n_epoch / B) * (dt / a.steps)
+        out["sampler"] = {"mode": "mt19937 bit-exact (host, 1 core)", "triples_per_s": n_epoch / t_sample,
+                          "epoch_triples": n_epoch, "epoch_inclusive_triples_per_s_serial": n_epoch / (t_sample + epoch_gpu_s),
+                          "epoch_inclusive_triples_per_s_overlapped": n_epoch / max(t_sample, epoch_gpu_s)}
+
+        # ---- CPU baseline: the oracle on a bounded sample of the same workload --------------------
+        if a.cpu_steps > 0:
+            import oracle
+            om = oracle.BprModel(P0, Q0, lr=LR, reg=REG, adam_mode=0)
+            k = min(a.cpu_steps, n_epoch // B)
+            t0 = time.perf_counter()
+            for b in range(k):
+                om.step(u[b * B:(b + 1) * B], i[b * B:(b + 1) * B], j[b * B:(b + 1) * B])
+            tc = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": k * B / tc, "unit": "triples/s", "cores": 1, "kind": "port",
+                                   "sample": "first %d batches of the same sampled epoch, oracle/crec_oracle.c "
+                                             "orc_bpr_step (scalar C, tf1 Adam), %.1f s; host has %d cores"
+                                             % (k, tc, os.cpu_count())}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

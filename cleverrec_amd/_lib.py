@@ -1,0 +1,167 @@
+"""ctypes binding of libcrec.so (include/crec.h).  No CPU fallback: if the library or a
+symbol is missing this module raises, and device entry points fail with the library's own
+error text when no gfx950 is present."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcrec.so")
+
+OK, EINVAL, EHIP, ENOMEM, EUNSUPPORTED, ENODEVICE = 0, -1, -2, -3, -4, -5
+ADAM_TF1, ADAM_LAZY = 0, 1
+_CODES = {EINVAL: "CREC_EINVAL", EHIP: "CREC_EHIP", ENOMEM: "CREC_ENOMEM", EUNSUPPORTED: "CREC_EUNSUPPORTED",
+          ENODEVICE: "CREC_ENODEVICE"}
+
+
+class CrecError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("%s: %s" % (_CODES.get(code, code), text))
+        self.code = code
+
+
+class BprTables(C.Structure):
+    _fields_ = [("P", C.c_void_p), ("Q", C.c_void_p), ("mP", C.c_void_p), ("vP", C.c_void_p), ("mQ", C.c_void_p),
+                ("vQ", C.c_void_p), ("U", C.c_int64), ("I", C.c_int64), ("d", C.c_int32)]
+
+
+class Adam(C.Structure):
+    _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("reg", C.c_float),
+                ("adam_mode", C.c_int32), ("beta1_power", C.c_float), ("beta2_power", C.c_float), ("step", C.c_int64)]
+
+
+_vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+_SIGNATURES = {
+    "crec_version": (C.c_int, []),
+    "crec_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "crec_ctx_destroy": (None, [_vp]),
+    "crec_last_error": (C.c_char_p, [_vp]),
+    "crec_profile_enable": (C.c_int, [_vp, C.c_int]),
+    "crec_profile_read": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(_i64)]),
+    "crec_rng_seed": (C.c_int, [_vp, C.c_uint32]),
+    "crec_rng_set_state": (C.c_int, [_vp, _vp, _i32]),
+    "crec_rng_get_state": (C.c_int, [_vp, _vp, C.POINTER(_i32)]),
+    "crec_rng_randint": (C.c_int, [_vp, _i64, C.POINTER(_i64)]),
+    "crec_rng_permutation": (C.c_int, [_vp, _i64, _vp]),
+    "crec_sample_pairwise": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, C.c_int, _vp, _vp, _vp, C.POINTER(_i64)]),
+    "crec_sample_pointwise": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, C.c_int, _vp, _vp, _vp, C.POINTER(_i64)]),
+    "crec_sample_cml": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, C.c_int, _vp, _vp, _vp, C.POINTER(_i64)]),
+    "crec_bpr_train_epoch": (C.c_int, [_vp, C.POINTER(BprTables), C.POINTER(Adam), _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
+    "crec_eval_topk": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
+    "crec_rank_metrics": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen libcrec.so and bind every symbol of include/crec.h (raises if any is missing)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s not built: run `python -m cleverrec_amd.build` (needs hipcc)" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the export is missing
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def _np(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One crec_ctx.  device=None -> host-only (RNG + samplers)."""
+
+    def __init__(self, device=None):
+        self.lib = load()
+        h = C.c_void_p()
+        rc = self.lib.crec_ctx_create(-1 if device is None else int(device), C.byref(h))
+        if rc != OK:
+            raise CrecError(rc, "crec_ctx_create(device=%r) failed (no MI355X / gfx950 visible?)" % (device,))
+        self.h, self.device = h, device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.crec_ctx_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def check(self, rc):
+        if rc != OK:
+            raise CrecError(rc, self.lib.crec_last_error(self.h).decode())
+
+    # ---- measurement ---------------------------------------------------------------------------
+    KERNELS = ("bpr_index_batches", "bpr_row_words", "bpr_user_side", "bpr_item_side", "bpr_reduce_loss", "eval_sweep",
+               "eval_merge", "rank_metrics")
+
+    def profile(self, on):
+        self.check(self.lib.crec_profile_enable(self.h, int(bool(on))))
+
+    def profile_read(self):
+        """{kernel: (total_ms, launches)} accumulated since profile(True)."""
+        out = {}
+        for k, name in enumerate(self.KERNELS):
+            ms, n = C.c_double(), C.c_int64()
+            self.check(self.lib.crec_profile_read(self.h, k, C.byref(ms), C.byref(n)))
+            out[name] = (ms.value, n.value)
+        return out
+
+    # ---- RNG ----------------------------------------------------------------------------------
+    def seed(self, s):
+        self.check(self.lib.crec_rng_seed(self.h, int(s) & 0xFFFFFFFF))
+
+    def set_state(self, key, pos):
+        key = np.ascontiguousarray(key, dtype=np.uint32)
+        assert key.shape == (624,)
+        self.check(self.lib.crec_rng_set_state(self.h, _np(key), int(pos)))
+
+    def get_state(self):
+        key, pos = np.empty(624, dtype=np.uint32), C.c_int32()
+        self.check(self.lib.crec_rng_get_state(self.h, _np(key), C.byref(pos)))
+        return key, pos.value
+
+    def randint(self, n):
+        out = C.c_int64()
+        self.check(self.lib.crec_rng_randint(self.h, int(n), C.byref(out)))
+        return out.value
+
+    def permutation(self, n):
+        out = np.empty(int(n), dtype=np.int64)
+        self.check(self.lib.crec_rng_permutation(self.h, int(n), _np(out)))
+        return out
+
+    # ---- samplers (host) ------------------------------------------------------------------------
+    def _sample(self, fn, csr, item_nums, neg_ratio, cap, third):
+        keys, ptr, items = csr
+        u, i = np.empty(max(cap, 1), np.int32), np.empty(max(cap, 1), np.int32)
+        n = C.c_int64()
+        self.check(fn(self.h, _np(ptr), _np(items), len(keys), _np(keys), int(item_nums), int(neg_ratio), _np(u), _np(i),
+                      _np(third), C.byref(n)))
+        return n.value, u, i
+
+    def sample_pairwise(self, csr, item_nums, neg_ratio):
+        cap = int(csr[1][-1]) * neg_ratio
+        j = np.empty(max(cap, 1), np.int32)
+        n, u, i = self._sample(self.lib.crec_sample_pairwise, csr, item_nums, neg_ratio, cap, j)
+        return u[:n], i[:n], j[:n]
+
+    def sample_pointwise(self, csr, item_nums, neg_ratio):
+        cap = int(csr[1][-1]) * (1 + neg_ratio)
+        y = np.empty(max(cap, 1), np.float32)
+        n, u, i = self._sample(self.lib.crec_sample_pointwise, csr, item_nums, neg_ratio, cap, y)
+        return u[:n], i[:n], y[:n]
+
+    def sample_cml(self, csr, item_nums, neg_ratio):
+        cap = int(csr[1][-1])
+        neg = np.empty(max(cap * neg_ratio, 1), np.int32)
+        n, u, i = self._sample(self.lib.crec_sample_cml, csr, item_nums, neg_ratio, cap, neg)
+        return u[:n], i[:n], neg[:n * neg_ratio].reshape(n, neg_ratio)

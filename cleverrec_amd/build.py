@@ -1,0 +1,67 @@
+"""Builds cleverrec_amd/lib/libcrec.so (gfx950 only) with hipcc, in-tree.
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the .so travels
+to the GPU box with the repo snapshot.  `python -m cleverrec_amd.build [--force]`.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libcrec.so")
+
+ARCH = "gfx950"
+COMMON = ["-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+# per-file extra flags.  bpr_train keeps every fp32 mul/add separately rounded (TF1 / Eigen
+# element-wise semantics; makes the Adam arithmetic bit-reproducible against the oracle).
+SOURCES = {
+    "crec_ctx.cpp": [],
+    "crec_sampler.cpp": ["-fno-math-errno"],
+    "bpr_train.hip": ["-ffp-contract=off"],
+    "eval_topk.hip": [],
+}
+
+
+def hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def _stale(out, deps):
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(HERE, "..", "include", "crec.h"))
+    cc = hipcc()
+    objs = []
+    for src, extra in SOURCES.items():
+        path = os.path.join(CSRC, src)
+        obj = os.path.join(objdir, src.rsplit(".", 1)[0] + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [path] + headers + [os.path.abspath(__file__)]):
+            cmd = [cc, "--offload-arch=" + ARCH, "-x", "hip"] + COMMON + extra + ["-c", path, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+    if force or _stale(LIB, objs):
+        cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,38 @@
+"""Configuration: the reference's two .properties files merged into one flat dict of strings
+(main.py:19-26: ConfigParser lower-cases keys, strips values, '#' starts a full-line comment).
+Consumers re-parse the strings exactly like the reference does (model/Recommender.py:16-28);
+keys this core adds (adam_mode, sampler_mode, seed) default so that old files keep working."""
+import configparser as cp
+import os
+
+DEFAULTS = {
+    "adam_mode": "tf1",        # tf1 | lazy  (include/crec.h CREC_ADAM_*)
+    "sampler_mode": "mt19937",  # bit-exact host sampler
+}
+
+
+def read_configs(project_file="./CleverRec.properties", conf_dir=None, recommender=None):
+    conf = cp.ConfigParser()
+    if not conf.read(project_file, encoding="utf-8"):
+        raise FileNotFoundError(project_file)
+    configs = dict(conf.items("default"))
+    recommender = recommender or configs["recommender"]
+    configs["recommender"] = recommender
+    conf_dir = conf_dir or configs.get("config_dir", "./conf")
+    model_file = os.path.join(conf_dir, recommender + ".properties")
+    if not conf.read(model_file, encoding="utf-8"):
+        raise FileNotFoundError(model_file)
+    configs.update(dict(conf.items("parameters")))
+    for k, v in DEFAULTS.items():
+        configs.setdefault(k, v)
+    return configs
+
+
+def parse_list(s, typ=float):
+    """'[0.7,0.2,0.1]' -> [0.7, 0.2, 0.1]   (the reference's s[1:-1].split(','))"""
+    return [typ(x) for x in s.strip()[1:-1].split(",") if x.strip() != ""]
+
+
+def is_true(s):
+    """The reference compares strings to 'True' (RankingRecommender.py:35)."""
+    return str(s).strip() == "True"

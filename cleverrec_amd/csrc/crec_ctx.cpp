@@ -1,0 +1,164 @@
+// Context, error reporting and workspace management of libcrec.so.
+#include "crec_internal.h"
+
+int crec_fail(crec_ctx *ctx, int code, const char *fmt, ...)
+{
+    if (ctx) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(ctx->err, sizeof(ctx->err), fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+int crec_reserve(crec_ctx *ctx, crec_devbuf *b, size_t bytes)
+{
+    if (bytes <= b->bytes)
+        return CREC_OK;
+    if (b->ptr) {
+        // buffers may still be referenced by work in flight on a caller stream
+        CREC_HIP(ctx, hipDeviceSynchronize());
+        CREC_HIP(ctx, hipFree(b->ptr));
+        b->ptr = nullptr;
+        b->bytes = 0;
+    }
+    size_t want = bytes + bytes / 8;
+    hipError_t e = hipMalloc(&b->ptr, want);
+    if (e != hipSuccess) {
+        b->ptr = nullptr;
+        return crec_fail(ctx, CREC_ENOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    }
+    b->bytes = want;
+    return CREC_OK;
+}
+
+static hipEvent_t prof_event(crec_ctx *ctx)
+{
+    if (!ctx->prof.pool.empty()) {
+        hipEvent_t e = ctx->prof.pool.back();
+        ctx->prof.pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+void crec_prof_begin(crec_ctx *ctx, int cls, hipStream_t st)
+{
+    if (!ctx->prof.on)
+        return;
+    crec_profile::rec r{cls, prof_event(ctx), prof_event(ctx)};
+    (void)hipEventRecord(r.a, st);
+    ctx->prof.pending.push_back(r);
+}
+
+void crec_prof_end(crec_ctx *ctx, hipStream_t st)
+{
+    if (!ctx->prof.on || ctx->prof.pending.empty())
+        return;
+    (void)hipEventRecord(ctx->prof.pending.back().b, st);
+}
+
+int crec_prof_flush(crec_ctx *ctx, hipStream_t st)
+{
+    if (!ctx->prof.on || ctx->prof.pending.empty())
+        return CREC_OK;
+    CREC_HIP(ctx, hipStreamSynchronize(st));
+    for (auto &r : ctx->prof.pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            ctx->prof.total_ms[r.cls] += ms;
+            ctx->prof.launches[r.cls] += 1;
+        }
+        ctx->prof.pool.push_back(r.a);
+        ctx->prof.pool.push_back(r.b);
+    }
+    ctx->prof.pending.clear();
+    return CREC_OK;
+}
+
+extern "C" {
+
+int crec_profile_enable(crec_ctx *ctx, int on)
+{
+    if (!ctx)
+        return CREC_EINVAL;
+    ctx->prof.on = on != 0;
+    for (int k = 0; k < CREC_K_COUNT; ++k) {
+        ctx->prof.total_ms[k] = 0;
+        ctx->prof.launches[k] = 0;
+    }
+    return CREC_OK;
+}
+
+int crec_profile_read(const crec_ctx *ctx, int kernel_class, double *total_ms, int64_t *launches)
+{
+    if (!ctx || kernel_class < 0 || kernel_class >= CREC_K_COUNT || !total_ms || !launches)
+        return CREC_EINVAL;
+    *total_ms = ctx->prof.total_ms[kernel_class];
+    *launches = ctx->prof.launches[kernel_class];
+    return CREC_OK;
+}
+
+int crec_version(void) { return CREC_VERSION; }
+
+int crec_ctx_create(int device, crec_ctx **out)
+{
+    if (!out)
+        return CREC_EINVAL;
+    *out = nullptr;
+    crec_ctx *ctx = new (std::nothrow) crec_ctx();
+    if (!ctx)
+        return CREC_ENOMEM;
+    ctx->device = device;
+    crec_rng_seed(ctx, 5489u);
+    if (device >= 0) {
+        int n = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        if (e != hipSuccess || device >= n) {
+            delete ctx;
+            return CREC_ENODEVICE;
+        }
+        hipDeviceProp_t prop;
+        if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) {
+            delete ctx;
+            return CREC_ENODEVICE;
+        }
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            // the code object is gfx950-only: say so now rather than at the first launch
+            delete ctx;
+            return CREC_ENODEVICE;
+        }
+        ctx->num_cus = prop.multiProcessorCount;
+    }
+    *out = ctx;
+    return CREC_OK;
+}
+
+void crec_ctx_destroy(crec_ctx *ctx)
+{
+    if (!ctx)
+        return;
+    if (ctx->device >= 0) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipDeviceSynchronize();
+        crec_devbuf *bufs[] = {&ctx->idx_ws, &ctx->contrib, &ctx->loss_ws, &ctx->lr_table,
+                               &ctx->misc,   &ctx->eval_ws, &ctx->ks_dev};
+        for (crec_devbuf *b : bufs)
+            if (b->ptr)
+                (void)hipFree(b->ptr);
+        for (auto &r : ctx->prof.pending) {
+            (void)hipEventDestroy(r.a);
+            (void)hipEventDestroy(r.b);
+        }
+        for (hipEvent_t e : ctx->prof.pool)
+            (void)hipEventDestroy(e);
+    }
+    delete ctx;
+}
+
+const char *crec_last_error(const crec_ctx *ctx) { return ctx ? ctx->err : "null ctx"; }
+
+} // extern "C"

@@ -1,0 +1,90 @@
+// Internal declarations shared by the translation units of libcrec.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/crec.h"
+
+#define CREC_VERSION 100
+
+struct crec_mt19937 {
+    uint32_t key[624];
+    int32_t pos;
+};
+
+// A device buffer the ctx grows on demand and keeps across calls.
+struct crec_devbuf {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+};
+
+// Optional per-kernel timing with HIP events on the launch stream (crec_profile_*).
+enum crec_kernel_class {
+    CREC_K_INDEX = 0,
+    CREC_K_WORDS,
+    CREC_K_USER_SIDE,
+    CREC_K_ITEM_SIDE,
+    CREC_K_REDUCE_LOSS,
+    CREC_K_EVAL_SWEEP,
+    CREC_K_EVAL_MERGE,
+    CREC_K_METRICS,
+    CREC_K_COUNT
+};
+
+struct crec_profile {
+    bool on = false;
+    struct rec {
+        int cls;
+        hipEvent_t a, b;
+    };
+    std::vector<rec> pending;
+    std::vector<hipEvent_t> pool;
+    double total_ms[CREC_K_COUNT] = {0};
+    int64_t launches[CREC_K_COUNT] = {0};
+};
+
+struct crec_ctx {
+    int device = -1;
+    crec_profile prof;
+    char err[512] = {0};
+    crec_mt19937 rng;
+    // BPR training workspace (bpr_train.hip)
+    crec_devbuf idx_ws;   // per-batch inverted indices of one chunk of batches
+    crec_devbuf contrib;  // [B, d] per-triple contribution rows s_b * p_u
+    crec_devbuf loss_ws;  // per-triple loss terms of one chunk
+    crec_devbuf lr_table; // per-step lr_t of one chunk
+    crec_devbuf misc;     // small counters
+    // eval workspace (eval_topk.hip)
+    crec_devbuf eval_ws;
+    crec_devbuf ks_dev;
+    int num_cus = 0;
+};
+
+int crec_fail(crec_ctx *ctx, int code, const char *fmt, ...);
+// profiling brackets: no-ops unless crec_profile_enable(ctx, 1)
+void crec_prof_begin(crec_ctx *ctx, int cls, hipStream_t st);
+void crec_prof_end(crec_ctx *ctx, hipStream_t st);
+int crec_prof_flush(crec_ctx *ctx, hipStream_t st);
+int crec_reserve(crec_ctx *ctx, crec_devbuf *b, size_t bytes);
+
+#define CREC_HIP(ctx, call)                                                                            \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return crec_fail((ctx), CREC_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                             __FILE__, __LINE__);                                                      \
+    } while (0)
+
+#define CREC_REQUIRE(ctx, cond, ...)                      \
+    do {                                                  \
+        if (!(cond))                                      \
+            return crec_fail((ctx), CREC_EINVAL, __VA_ARGS__); \
+    } while (0)
+
+static inline int64_t crec_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }

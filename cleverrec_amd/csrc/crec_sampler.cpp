@@ -1,0 +1,326 @@
+// Host side of the hot path: the NumPy-legacy MT19937 stream and the three epoch samplers,
+// bit-exact with the reference on the same RNG state.
+//
+// Why this part stays on the host: one MT19937 stream feeds data-dependent rejection loops
+// (redraw while j is a seen item or repeats inside the positive's group) and a Fisher-Yates
+// shuffle whose accept test changes every step, so which stream word lands in which slot
+// depends on every earlier accept/reject.  That chain is strictly serial; a single CPU core
+// walks it at a few ns per draw, a GPU lane at tens.  Everything after the draws (expanding
+// u/i, applying the permutation) is a gather and is done here in one fused pass.
+//
+// Reference: utils/sampler.py:10-99 (samplers), numpy RandomState (randint / permutation).
+#include <cstdlib>
+#include <memory>
+#include <new>
+
+#include "crec_internal.h"
+
+namespace {
+
+constexpr int MT_N = 624, MT_M = 397;
+
+inline void mt_refill(crec_mt19937 &r)
+{
+    uint32_t *mt = r.key;
+    auto twist = [](uint32_t a, uint32_t b, uint32_t c) {
+        uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+        return c ^ (y >> 1) ^ ((0u - (y & 1u)) & 0x9908b0dfu);
+    };
+    int k = 0;
+    for (; k < MT_N - MT_M; ++k)
+        mt[k] = twist(mt[k], mt[k + 1], mt[k + MT_M]);
+    for (; k < MT_N - 1; ++k)
+        mt[k] = twist(mt[k], mt[k + 1], mt[k + MT_M - MT_N]);
+    mt[MT_N - 1] = twist(mt[MT_N - 1], mt[0], mt[MT_M - 1]);
+    r.pos = 0;
+}
+
+inline uint32_t mt_next(crec_mt19937 &r)
+{
+    if (__builtin_expect(r.pos >= MT_N, 0))
+        mt_refill(r);
+    uint32_t y = r.key[r.pos++];
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+
+inline uint32_t mask_of(uint32_t max)
+{
+    uint32_t m = max;
+    m |= m >> 1;
+    m |= m >> 2;
+    m |= m >> 4;
+    m |= m >> 8;
+    m |= m >> 16;
+    return m;
+}
+
+// masked rejection draw in [0, max]; consumes no word when max == 0
+inline uint32_t draw(crec_mt19937 &r, uint32_t max, uint32_t mask)
+{
+    if (max == 0)
+        return 0;
+    uint32_t v;
+    do {
+        v = mt_next(r) & mask;
+    } while (v > max);
+    return v;
+}
+
+// legacy shuffle of arange(n): for k = n-1 .. 1: swap(a[k], a[draw in [0, k]]).
+// The swap targets depend only on the RNG stream, never on the array, so they are drawn a
+// block ahead and prefetched: the swaps themselves still run strictly in order, but on
+// lines that are already on their way (the array is far larger than the host caches).
+template <typename T> void permutation(crec_mt19937 &r, int64_t n, T *a)
+{
+    for (int64_t k = 0; k < n; ++k)
+        a[k] = (T)k;
+    constexpr int BLK = 64;
+    uint32_t jb[BLK];
+    for (int64_t k = n - 1; k >= 1;) {
+        const int m = (int)(k < BLK ? k : BLK);
+        for (int t = 0; t < m; ++t) {
+            uint32_t kk = (uint32_t)(k - t);
+            jb[t] = draw(r, kk, mask_of(kk));
+            __builtin_prefetch(&a[jb[t]], 1, 1);
+        }
+        for (int t = 0; t < m; ++t) {
+            T *x = &a[k - t], *y = &a[jb[t]];
+            T tmp = *x;
+            *x = *y;
+            *y = tmp;
+        }
+        k -= m;
+    }
+}
+
+struct Csr {
+    const int64_t *ptr;
+    const int32_t *items;
+    int64_t n_users;
+    const int32_t *user_ids;
+    int32_t item_nums;
+};
+
+// Draws the negatives of every positive in reference order.  neg[e*neg_ratio + t] is the
+// t-th negative of positive e.  Returns false if some user cannot supply neg_ratio negatives.
+bool draw_negatives(crec_mt19937 &r, const Csr &c, int neg_ratio, int32_t *neg, int32_t *stamp)
+{
+    const uint32_t max = (uint32_t)(c.item_nums - 1), mask = mask_of(max);
+    int64_t out = 0;
+    for (int64_t k = 0; k < c.n_users; ++k) {
+        const int32_t tag = (int32_t)(k + 1);
+        int64_t uniq = 0;
+        for (int64_t e = c.ptr[k]; e < c.ptr[k + 1]; ++e) {
+            uniq += (stamp[c.items[e]] != tag);
+            stamp[c.items[e]] = tag; // seen_items = set(ui_train[u])
+        }
+        if (c.ptr[k + 1] > c.ptr[k] && uniq + neg_ratio > c.item_nums)
+            return false;
+        for (int64_t e = c.ptr[k]; e < c.ptr[k + 1]; ++e) {
+            int32_t *grp = neg + out; // random_j of this positive
+            for (int t = 0; t < neg_ratio; ++t) {
+                for (;;) {
+                    int32_t j = (int32_t)draw(r, max, mask);
+                    bool bad = stamp[j] == tag;
+                    for (int q = 0; q < t; ++q)
+                        bad |= (grp[q] == j);
+                    if (!bad) {
+                        grp[t] = j;
+                        break;
+                    }
+                }
+            }
+            out += neg_ratio;
+        }
+    }
+    return true;
+}
+
+template <typename T> struct Free {
+    void operator()(T *p) const { std::free(p); }
+};
+template <typename T> using buf = std::unique_ptr<T[], Free<T>>;
+template <typename T> buf<T> alloc(int64_t n, bool zero = false)
+{
+    size_t bytes = sizeof(T) * (size_t)(n > 0 ? n : 1);
+    return buf<T>((T *)(zero ? std::calloc(bytes, 1) : std::malloc(bytes)));
+}
+
+int check_csr(crec_ctx *ctx, const Csr &c, int neg_ratio, const void *a, const void *b, const void *d, int64_t *n_out)
+{
+    CREC_REQUIRE(ctx, c.ptr && c.user_ids && a && b && d && n_out, "null argument");
+    CREC_REQUIRE(ctx, c.n_users >= 0 && c.item_nums >= 1 && neg_ratio >= 0, "bad sizes");
+    CREC_REQUIRE(ctx, c.items || c.ptr[c.n_users] == 0, "null items");
+    for (int64_t k = 0; k < c.n_users; ++k)
+        CREC_REQUIRE(ctx, c.ptr[k + 1] >= c.ptr[k], "ptr not monotone at %lld", (long long)k);
+    for (int64_t e = 0; e < c.ptr[c.n_users]; ++e)
+        CREC_REQUIRE(ctx, c.items[e] >= 0 && c.items[e] < c.item_nums, "item id %d out of range", c.items[e]);
+    return CREC_OK;
+}
+
+// edge -> user id, so the shuffled u column is one gather
+buf<int32_t> edge_users(const Csr &c)
+{
+    auto eu = alloc<int32_t>(c.ptr[c.n_users]);
+    if (eu)
+        for (int64_t k = 0; k < c.n_users; ++k)
+            for (int64_t e = c.ptr[k]; e < c.ptr[k + 1]; ++e)
+                eu[e] = c.user_ids[k];
+    return eu;
+}
+
+} // namespace
+
+extern "C" {
+
+int crec_rng_seed(crec_ctx *ctx, uint32_t seed)
+{
+    if (!ctx)
+        return CREC_EINVAL;
+    uint32_t *mt = ctx->rng.key;
+    mt[0] = seed;
+    for (int k = 1; k < MT_N; ++k)
+        mt[k] = 1812433253u * (mt[k - 1] ^ (mt[k - 1] >> 30)) + (uint32_t)k;
+    ctx->rng.pos = MT_N;
+    return CREC_OK;
+}
+
+int crec_rng_set_state(crec_ctx *ctx, const uint32_t key[624], int32_t pos)
+{
+    if (!ctx)
+        return CREC_EINVAL;
+    CREC_REQUIRE(ctx, key && pos >= 0 && pos <= MT_N, "bad MT19937 state");
+    std::memcpy(ctx->rng.key, key, sizeof(ctx->rng.key));
+    ctx->rng.pos = pos;
+    return CREC_OK;
+}
+
+int crec_rng_get_state(const crec_ctx *ctx, uint32_t key[624], int32_t *pos)
+{
+    if (!ctx || !key || !pos)
+        return CREC_EINVAL;
+    std::memcpy(key, ctx->rng.key, sizeof(ctx->rng.key));
+    *pos = ctx->rng.pos;
+    return CREC_OK;
+}
+
+int crec_rng_randint(crec_ctx *ctx, int64_t n, int64_t *out)
+{
+    if (!ctx)
+        return CREC_EINVAL;
+    CREC_REQUIRE(ctx, out && n >= 1 && n <= (int64_t)1 << 32, "randint range");
+    uint32_t max = (uint32_t)(n - 1);
+    *out = max == 0xffffffffu ? (int64_t)mt_next(ctx->rng) : (int64_t)draw(ctx->rng, max, mask_of(max));
+    return CREC_OK;
+}
+
+int crec_rng_permutation(crec_ctx *ctx, int64_t n, int64_t *out)
+{
+    if (!ctx)
+        return CREC_EINVAL;
+    CREC_REQUIRE(ctx, n >= 0 && n <= 0xffffffffLL && (out || n == 0), "permutation size");
+    permutation(ctx->rng, n, out);
+    return CREC_OK;
+}
+
+int crec_sample_pairwise(crec_ctx *ctx, const int64_t *ptr, const int32_t *items, int64_t n_users,
+                         const int32_t *user_ids, int32_t item_nums, int neg_ratio, int32_t *u, int32_t *i, int32_t *j,
+                         int64_t *n_out)
+{
+    if (!ctx)
+        return CREC_EINVAL;
+    Csr c{ptr, items, n_users, user_ids, item_nums};
+    if (int rc = check_csr(ctx, c, neg_ratio, u, i, j, n_out))
+        return rc;
+    const int64_t n_pos = ptr[n_users], n = n_pos * neg_ratio;
+    CREC_REQUIRE(ctx, n <= 0xffffffffLL, "epoch too large for a 32-bit permutation");
+    auto stamp = alloc<int32_t>(item_nums, true);
+    auto neg = alloc<int32_t>(n);
+    auto perm = alloc<uint32_t>(n);
+    auto eu = edge_users(c);
+    if (!stamp || !neg || !perm || !eu)
+        return crec_fail(ctx, CREC_ENOMEM, "host allocation failed");
+    if (!draw_negatives(ctx->rng, c, neg_ratio, neg.get(), stamp.get()))
+        return crec_fail(ctx, CREC_EINVAL, "a user has fewer than neg_ratio unseen items");
+    permutation(ctx->rng, n, perm.get()); // sampler.py:68
+    for (int64_t k = 0; k < n; ++k) {     // np.array(x)[s_idx] for the three columns at once
+        if (k + 32 < n) {
+            uint32_t sp = perm[k + 32], ep = sp / (uint32_t)neg_ratio;
+            __builtin_prefetch(&neg[sp], 0, 1);
+            __builtin_prefetch(&eu[ep], 0, 1);
+            __builtin_prefetch(&items[ep], 0, 1);
+        }
+        uint32_t s = perm[k], e = s / (uint32_t)neg_ratio;
+        u[k] = eu[e];
+        i[k] = items[e];
+        j[k] = neg[s];
+    }
+    *n_out = n;
+    return CREC_OK;
+}
+
+int crec_sample_pointwise(crec_ctx *ctx, const int64_t *ptr, const int32_t *items, int64_t n_users,
+                          const int32_t *user_ids, int32_t item_nums, int neg_ratio, int32_t *u, int32_t *i, float *y,
+                          int64_t *n_out)
+{
+    if (!ctx)
+        return CREC_EINVAL;
+    Csr c{ptr, items, n_users, user_ids, item_nums};
+    if (int rc = check_csr(ctx, c, neg_ratio, u, i, y, n_out))
+        return rc;
+    const int64_t n_pos = ptr[n_users], w = 1 + (int64_t)neg_ratio, n = n_pos * w;
+    CREC_REQUIRE(ctx, n <= 0xffffffffLL, "epoch too large for a 32-bit permutation");
+    auto stamp = alloc<int32_t>(item_nums, true);
+    auto neg = alloc<int32_t>(n_pos * neg_ratio);
+    auto perm = alloc<uint32_t>(n);
+    auto eu = edge_users(c);
+    if (!stamp || !neg || !perm || !eu)
+        return crec_fail(ctx, CREC_ENOMEM, "host allocation failed");
+    if (!draw_negatives(ctx->rng, c, neg_ratio, neg.get(), stamp.get()))
+        return crec_fail(ctx, CREC_EINVAL, "a user has fewer than neg_ratio unseen items");
+    permutation(ctx->rng, n, perm.get()); // sampler.py:37
+    for (int64_t k = 0; k < n; ++k) {
+        // instance s = e*(1+neg_ratio) + t: t == 0 the positive, t >= 1 its (t-1)-th negative (sampler.py:18-31)
+        uint32_t s = perm[k], e = s / (uint32_t)w, t = s - e * (uint32_t)w;
+        u[k] = eu[e];
+        i[k] = t == 0 ? items[e] : neg[(int64_t)e * neg_ratio + (t - 1)];
+        y[k] = t == 0 ? 1.0f : 0.0f;
+    }
+    *n_out = n;
+    return CREC_OK;
+}
+
+int crec_sample_cml(crec_ctx *ctx, const int64_t *ptr, const int32_t *items, int64_t n_users, const int32_t *user_ids,
+                    int32_t item_nums, int neg_ratio, int32_t *u, int32_t *i, int32_t *neg_out, int64_t *n_out)
+{
+    if (!ctx)
+        return CREC_EINVAL;
+    Csr c{ptr, items, n_users, user_ids, item_nums};
+    if (int rc = check_csr(ctx, c, neg_ratio, u, i, neg_out, n_out))
+        return rc;
+    const int64_t n = ptr[n_users];
+    CREC_REQUIRE(ctx, n <= 0xffffffffLL, "epoch too large for a 32-bit permutation");
+    auto stamp = alloc<int32_t>(item_nums, true);
+    auto neg = alloc<int32_t>(n * neg_ratio);
+    auto perm = alloc<uint32_t>(n);
+    auto eu = edge_users(c);
+    if (!stamp || !neg || !perm || !eu)
+        return crec_fail(ctx, CREC_ENOMEM, "host allocation failed");
+    if (!draw_negatives(ctx->rng, c, neg_ratio, neg.get(), stamp.get()))
+        return crec_fail(ctx, CREC_EINVAL, "a user has fewer than neg_ratio unseen items");
+    permutation(ctx->rng, n, perm.get()); // sampler.py:97
+    for (int64_t k = 0; k < n; ++k) {
+        uint32_t e = perm[k];
+        u[k] = eu[e];
+        i[k] = items[e];
+        std::memcpy(neg_out + k * neg_ratio, neg.get() + (int64_t)e * neg_ratio, sizeof(int32_t) * (size_t)neg_ratio);
+    }
+    *n_out = n;
+    return CREC_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,437 @@
+// Full-catalogue evaluation for gfx950: scores = P[users] . Q^T on the fp32 matrix cores with
+// the seen-item filter and the top-K selection fused behind the accumulators, so the
+// [users, items] score matrix never exists in memory.
+//
+// Replaces sess.run(pre_scores) (model/ranking/BPR.py:51) + np.argsort + the seen-item loop of
+// RankingRecommender.test_model_rs (model/RankingRecommender.py:221-240) and cal_ranking_metrics
+// (utils/metrics.py:9-19); see include/crec.h.
+//
+// eval_sweep<DMAX, TI>: a workgroup = 4 waves; wave w owns 32 users (the rows of a
+//   v_mfma_f32_32x32x2_f32 tile) and keeps their embeddings in DMAX/2 registers per lane for
+//   the whole sweep; the 4 waves share item tiles of TI rows staged global -> registers -> LDS
+//   (rows padded by 16 B: conflict-free ds_read_b128), double buffered.  MFMA step s multiplies
+//   k = s (lanes 0-31) and k = DMAX/2 + s (lanes 32-63), so a lane reads its B operands as
+//   contiguous float4s; the CPU oracle's order == 1 folds products in that same order, which
+//   makes the fp32 scores bit-identical.
+//   Behind each 32x32 accumulator tile: score > the user's current K-th best (16 compares per
+//   lane, the thresholds live in registers) -> rare candidates are appended to a per-user
+//   64-slot buffer in LDS; a full buffer is pruned by the wave: binary search of each new
+//   candidate in the user's sorted seen list, rank by all-pairs compare, keep the K best,
+//   raise the threshold.  Keys are (ordered score bits, ~item id) so ties go to the lower id.
+//   grid.y splits the catalogue; each split writes K keys per user.
+// eval_merge: one wave per user ranks the splits' keys and writes ids / scores.
+// rank_metrics: HR / MRR / NDCG per (K, user) in float64.
+#include "crec_internal.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned long long u64;
+
+constexpr int CAP = 64;        // candidate slots per user
+constexpr int K_MAX = 32;      // CAP - K_MAX >= 32: one half-wave of candidates always fits after a prune
+constexpr int USERS_PER_WG = 128;
+constexpr int MAX_SPLITS = 16;
+
+__device__ inline uint32_t ordered_bits(float f)
+{
+    uint32_t u = __float_as_uint(f);
+    return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
+}
+__device__ inline float from_ordered(uint32_t o)
+{
+    uint32_t u = o ^ ((o >> 31) ? 0x80000000u : 0xffffffffu);
+    return __uint_as_float(u);
+}
+__device__ inline u64 make_key(float score, int item) { return ((u64)ordered_bits(score) << 32) | (0xffffffffu - (uint32_t)item); }
+__device__ inline int key_item(u64 k) { return (int)(0xffffffffu - (uint32_t)k); }
+__device__ inline float key_score(u64 k) { return from_ordered((uint32_t)(k >> 32)); }
+
+__device__ inline void lds_fence()
+{
+    // LDS operations of one wave execute in issue order; this only stops the compiler from
+    // caching or reordering the cross-lane traffic below.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+struct WaveState {
+    u64 *cand;   // [32][CAP]
+    int *cnt;    // [32] entries in the buffer
+    int *clean;  // [32] leading entries already checked against the seen list
+    float *thr;  // [32] score a candidate must beat
+    int *uid;    // [32] global user id, -1 for padding rows
+};
+
+// Keep the K best unseen entries of user row `ul`, sorted best first.  Whole wave.
+__device__ void prune(const WaveState &ws, int ul, int K, const int64_t *__restrict__ seen_ptr,
+                      const int32_t *__restrict__ seen_items)
+{
+    const int lane = threadIdx.x & 63;
+    u64 *buf = ws.cand + ul * CAP;
+    const int n = ws.cnt[ul], clean = ws.clean[ul], uid = ws.uid[ul];
+    u64 mine = lane < n ? buf[lane] : 0;
+    if (lane >= clean && lane < n) {
+        const int item = key_item(mine);
+        int64_t lo = seen_ptr[uid], hi = seen_ptr[uid + 1];
+        const int64_t end = hi;
+        while (lo < hi) {
+            int64_t mid = (lo + hi) >> 1;
+            if (seen_items[mid] < item)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        if (lo < end && seen_items[lo] == item)
+            mine = 0; // seen in training: never recommended (RankingRecommender.py:236)
+    }
+    buf[lane] = mine;
+    lds_fence();
+    int rank = 0;
+    for (int t = 0; t < n; ++t)
+        rank += buf[t] > mine;
+    lds_fence();
+    const bool valid = mine != 0;
+    const int n_valid = __popcll(__ballot(valid));
+    if (valid && rank < K)
+        buf[rank] = mine;
+    const int kept = n_valid < K ? n_valid : K;
+    if (n_valid >= K) {
+        if (valid && rank == K - 1)
+            ws.thr[ul] = key_score(mine);
+    }
+    if (lane == 0) {
+        ws.cnt[ul] = kept;
+        ws.clean[ul] = kept;
+    }
+    lds_fence();
+}
+
+template <int DMAX, int TI>
+__global__ __launch_bounds__(256) void eval_sweep(const float *__restrict__ P, const float *__restrict__ Q, int64_t I,
+                                                  int d, const int32_t *__restrict__ users, int Bt,
+                                                  const int64_t *__restrict__ seen_ptr,
+                                                  const int32_t *__restrict__ seen_items, int K, float sign,
+                                                  int64_t items_per_split, u64 *__restrict__ part /*[Bt][S][K]*/)
+{
+    constexpr int HS = DMAX / 2;          // MFMA steps
+    constexpr int LDQ = DMAX + 4;         // padded LDS row (floats)
+    constexpr int CPR = DMAX / 4;         // float4 chunks per item row
+    constexpr int NCH = TI * CPR / 256;   // chunks staged per thread
+    constexpr int NBLK = TI / 32;
+    static_assert(NCH >= 1, "tile too small");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *qt = (float *)smem;                                  // [2][TI*LDQ]
+    u64 *cand_all = (u64 *)(qt + 2 * TI * LDQ);                 // [4][32][CAP]
+    int *cnt_all = (int *)(cand_all + 4 * 32 * CAP);            // [4][32]
+    int *clean_all = cnt_all + 4 * 32;
+    float *thr_all = (float *)(clean_all + 4 * 32);
+    int *uid_all = (int *)(thr_all + 4 * 32);
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int row = lane & 31, h = lane >> 5;
+    WaveState ws{cand_all + wv * 32 * CAP, cnt_all + wv * 32, clean_all + wv * 32, thr_all + wv * 32, uid_all + wv * 32};
+
+    const int S = gridDim.y, sp = blockIdx.y;
+    const int64_t i0 = (int64_t)sp * items_per_split;
+    const int64_t i1 = (i0 + items_per_split) < I ? (i0 + items_per_split) : I;
+
+    // ---- per-wave state + the A operand (this wave's 32 users) --------------------------
+    const int urow = blockIdx.x * USERS_PER_WG + wv * 32 + row;
+    const int uid = urow < Bt ? users[urow] : -1;
+    if (h == 0) {
+        ws.cnt[row] = 0;
+        ws.clean[row] = 0;
+        ws.thr[row] = uid >= 0 ? -INFINITY : INFINITY; // padding rows never produce candidates
+        ws.uid[row] = uid;
+    }
+    float a[HS];
+#pragma unroll
+    for (int q = 0; q < HS / 4; ++q) {
+        const int k = h * HS + 4 * q;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (uid >= 0 && k < d)
+            v = *reinterpret_cast<const float4 *>(P + (int64_t)uid * d + k);
+        a[4 * q + 0] = sign * v.x;
+        a[4 * q + 1] = sign * v.y;
+        a[4 * q + 2] = sign * v.z;
+        a[4 * q + 3] = sign * v.w;
+    }
+    // zero both tile buffers once: the k >= d padding columns are never written again
+    for (int k = tid; k < 2 * TI * LDQ; k += 256)
+        qt[k] = 0.f;
+    __syncthreads();
+
+    // ---- staging helpers --------------------------------------------------------------------
+    float4 stage[NCH];
+    auto stage_load = [&](int64_t tile_base) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int ch = tid + c * 256, r = ch / CPR, k = (ch % CPR) * 4;
+            const int64_t item = tile_base + r;
+            stage[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (item < i1 && k < d)
+                stage[c] = *reinterpret_cast<const float4 *>(Q + item * d + k);
+        }
+    };
+    auto stage_store = [&](int bufi) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int ch = tid + c * 256, r = ch / CPR, k = (ch % CPR) * 4;
+            if (k < d)
+                *reinterpret_cast<float4 *>(qt + bufi * TI * LDQ + r * LDQ + k) = stage[c];
+        }
+    };
+
+    float thr_r[16];
+    auto reload_thr = [&]() {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            thr_r[r] = ws.thr[(r & 3) + 8 * (r >> 2) + 4 * h];
+    };
+    lds_fence();
+    reload_thr();
+
+    const int64_t n_tiles = i1 > i0 ? (i1 - i0 + TI - 1) / TI : 0;
+    if (n_tiles > 0) {
+        stage_load(i0);
+        stage_store(0);
+    }
+    __syncthreads();
+
+    for (int64_t t = 0; t < n_tiles; ++t) {
+        const int cur = (int)(t & 1);
+        const int64_t tile_base = i0 + t * TI;
+        if (t + 1 < n_tiles)
+            stage_load(tile_base + TI); // in flight while this tile is multiplied
+
+        const float *qb = qt + cur * TI * LDQ;
+#pragma unroll
+        for (int blk = 0; blk < NBLK; ++blk) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc[r] = 0.f;
+            const float *bp = qb + (blk * 32 + row) * LDQ + h * HS;
+#pragma unroll
+            for (int q = 0; q < HS / 4; ++q) {
+                const float4 b = *reinterpret_cast<const float4 *>(bp + 4 * q);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * q + 0], b.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * q + 1], b.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * q + 2], b.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * q + 3], b.w, acc, 0, 0, 0);
+            }
+            // ---- epilogue: accumulator register r of lane (row, h) is
+            //      score[user (r&3) + 8*(r>>2) + 4*h][item tile_base + blk*32 + row]
+            const int64_t item = tile_base + blk * 32 + row;
+            const bool item_ok = item < i1;
+            bool pruned = false;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float sc = acc[r];
+                const bool is_cand = item_ok && sc > thr_r[r];
+                const u64 bal = __ballot(is_cand);
+                if (bal) {
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const uint32_t m = hh ? (uint32_t)(bal >> 32) : (uint32_t)bal;
+                        if (m) {
+                            const int ul = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                            const int c = __popc(m);
+                            int base = ws.cnt[ul];
+                            if (base + c > CAP) {
+                                prune(ws, ul, K, seen_ptr, seen_items);
+                                pruned = true;
+                                base = ws.cnt[ul];
+                            }
+                            if (h == hh && is_cand)
+                                ws.cand[ul * CAP + base + __popc(m & ((1u << row) - 1u))] = make_key(sc, (int)item);
+                            if (lane == 0)
+                                ws.cnt[ul] = base + c;
+                            lds_fence();
+                        }
+                    }
+                }
+            }
+            if (pruned)
+                reload_thr();
+        }
+
+        if (t + 1 < n_tiles)
+            stage_store(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- final prune + hand the K best keys of this split to the merge -------------------------
+    for (int ul = 0; ul < 32; ++ul) {
+        const int gu = blockIdx.x * USERS_PER_WG + wv * 32 + ul;
+        if (gu >= Bt)
+            break;
+        prune(ws, ul, K, seen_ptr, seen_items);
+        const int n = ws.cnt[ul];
+        if (lane < K)
+            part[((int64_t)gu * S + sp) * K + lane] = lane < n ? ws.cand[ul * CAP + lane] : 0;
+    }
+}
+
+// one wave per user: rank the S*K keys, best first
+__global__ __launch_bounds__(64) void eval_merge(const u64 *__restrict__ part, int S, int K, float sign,
+                                                 int32_t *__restrict__ topk_ids, float *__restrict__ topk_scores)
+{
+    __shared__ u64 keys[MAX_SPLITS * K_MAX];
+    const int lane = threadIdx.x, n = S * K;
+    const int64_t user = blockIdx.x;
+    for (int k = lane; k < n; k += 64)
+        keys[k] = part[user * n + k];
+    if (lane < K) {
+        topk_ids[user * K + lane] = -1;
+        topk_scores[user * K + lane] = sign * -INFINITY;
+    }
+    __syncthreads();
+    for (int k = lane; k < n; k += 64) {
+        const u64 mine = keys[k];
+        if (mine == 0)
+            continue;
+        int rank = 0;
+        for (int t = 0; t < n; ++t)
+            rank += keys[t] > mine;
+        if (rank < K) {
+            topk_ids[user * K + rank] = key_item(mine);
+            topk_scores[user * K + rank] = sign * key_score(mine);
+        }
+    }
+}
+
+// cal_ranking_metrics (utils/metrics.py:9-19): thread per (k index, user), float64
+__global__ void rank_metrics_kernel(const int32_t *__restrict__ topk_ids, const int32_t *__restrict__ users, int Bt,
+                                    int Kmax, const int32_t *__restrict__ ks, int nk,
+                                    const int64_t *__restrict__ test_ptr, const int32_t *__restrict__ test_items,
+                                    double *__restrict__ hr, double *__restrict__ mrr, double *__restrict__ ndcg)
+{
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (int64_t)nk * Bt)
+        return;
+    const int q = (int)(gid / Bt), r = (int)(gid % Bt);
+    const int K = ks[q];
+    const int32_t *rec = topk_ids + (int64_t)r * Kmax;
+    const int32_t uu = users[r];
+    const int64_t t0 = test_ptr[uu], n_real = test_ptr[uu + 1] - t0;
+    double hit = 0, rr = 0, dcg = 0, idcg = 0;
+    for (int64_t id = 0; id < n_real; ++id) {
+        const int32_t item = test_items[t0 + id];
+        for (int idx = 0; idx < K; ++idx) {
+            if (rec[idx] == item) {
+                hit += 1.0;
+                rr += 1.0 / (double)(idx + 1);
+                dcg += 1.0 / log2((double)(idx + 2));
+                break;
+            }
+        }
+        idcg += 1.0 / log2((double)(id + 2));
+    }
+    const double denom = (double)(K < n_real ? (int64_t)K : n_real);
+    hr[gid] = hit / denom;
+    mrr[gid] = rr;
+    ndcg[gid] = dcg / idcg;
+}
+
+template <int DMAX, int TI> size_t sweep_lds()
+{
+    return sizeof(float) * 2 * TI * (DMAX + 4) + sizeof(u64) * 4 * 32 * CAP + sizeof(int) * 4 * 32 * 4;
+}
+
+template <int DMAX, int TI>
+int launch_sweep(crec_ctx *ctx, dim3 grid, hipStream_t st, const float *P, const float *Q, int64_t I, int d,
+                 const int32_t *users, int Bt, const int64_t *seen_ptr, const int32_t *seen_items, int K, float sign,
+                 int64_t per_split, u64 *part)
+{
+    const size_t lds = sweep_lds<DMAX, TI>();
+    CREC_HIP(ctx, hipFuncSetAttribute((const void *)eval_sweep<DMAX, TI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds));
+    crec_prof_begin(ctx, CREC_K_EVAL_SWEEP, st);
+    hipLaunchKernelGGL((eval_sweep<DMAX, TI>), grid, dim3(256), lds, st, P, Q, I, d, users, Bt, seen_ptr, seen_items, K,
+                       sign, per_split, part);
+    crec_prof_end(ctx, st);
+    return CREC_OK;
+}
+
+} // namespace
+
+extern "C" int crec_eval_topk(crec_ctx *ctx, const float *P, const float *Q, int64_t I, int32_t d,
+                              const int32_t *users, int32_t Bt, const int64_t *seen_ptr, const int32_t *seen_items,
+                              int32_t K, int32_t ascending, int32_t *topk_ids, float *topk_scores, void *stream)
+{
+    if (!ctx)
+        return CREC_EINVAL;
+    CREC_REQUIRE(ctx, ctx->device >= 0, "host-only ctx: no device bound");
+    CREC_REQUIRE(ctx, P && Q && users && seen_ptr && topk_ids && topk_scores, "null argument");
+    CREC_REQUIRE(ctx, d >= 4 && d <= 256 && d % 4 == 0, "embed_size %d: need a multiple of 4 in [4, 256]", d);
+    CREC_REQUIRE(ctx, K >= 1 && K <= K_MAX, "K = %d: this build keeps at most %d per user", K, K_MAX);
+    CREC_REQUIRE(ctx, I >= 1 && I < ((int64_t)1 << 31) && Bt >= 0, "bad sizes");
+    CREC_REQUIRE(ctx, (((uintptr_t)P | (uintptr_t)Q) & 15) == 0, "table base not 16-byte aligned");
+    if (Bt == 0)
+        return CREC_OK;
+    CREC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+
+    const int tile = d > 128 ? 32 : 64;
+    const int user_tiles = (int)crec_ceil_div(Bt, USERS_PER_WG);
+    const int64_t n_item_tiles = crec_ceil_div(I, tile);
+    int64_t S = crec_ceil_div(2 * (int64_t)(ctx->num_cus > 0 ? ctx->num_cus : 256), user_tiles);
+    S = S < 1 ? 1 : (S > MAX_SPLITS ? MAX_SPLITS : S);
+    S = S > n_item_tiles ? n_item_tiles : S;
+    const int64_t per_split = crec_ceil_div(n_item_tiles, S) * tile;
+    S = crec_ceil_div(I, per_split);
+
+    if (int rc = crec_reserve(ctx, &ctx->eval_ws, sizeof(u64) * (size_t)Bt * S * K))
+        return rc;
+    u64 *part = (u64 *)ctx->eval_ws.ptr;
+    const float sign = ascending ? -1.0f : 1.0f;
+    dim3 grid((unsigned)user_tiles, (unsigned)S);
+    int rc;
+    if (d <= 32)
+        rc = launch_sweep<32, 64>(ctx, grid, st, P, Q, I, d, users, Bt, seen_ptr, seen_items, K, sign, per_split, part);
+    else if (d <= 64)
+        rc = launch_sweep<64, 64>(ctx, grid, st, P, Q, I, d, users, Bt, seen_ptr, seen_items, K, sign, per_split, part);
+    else if (d <= 128)
+        rc = launch_sweep<128, 64>(ctx, grid, st, P, Q, I, d, users, Bt, seen_ptr, seen_items, K, sign, per_split, part);
+    else
+        rc = launch_sweep<256, 32>(ctx, grid, st, P, Q, I, d, users, Bt, seen_ptr, seen_items, K, sign, per_split, part);
+    if (rc)
+        return rc;
+    crec_prof_begin(ctx, CREC_K_EVAL_MERGE, st);
+    hipLaunchKernelGGL(eval_merge, dim3((unsigned)Bt), dim3(64), 0, st, (const u64 *)part, (int)S, (int)K, sign,
+                       topk_ids, topk_scores);
+    crec_prof_end(ctx, st);
+    CREC_HIP(ctx, hipGetLastError());
+    return crec_prof_flush(ctx, st);
+}
+
+extern "C" int crec_rank_metrics(crec_ctx *ctx, const int32_t *topk_ids, const int32_t *users, int32_t Bt, int32_t K,
+                                 const int32_t *ks, int32_t nk, const int64_t *test_ptr, const int32_t *test_items,
+                                 double *hr, double *mrr, double *ndcg, void *stream)
+{
+    if (!ctx)
+        return CREC_EINVAL;
+    CREC_REQUIRE(ctx, ctx->device >= 0, "host-only ctx: no device bound");
+    CREC_REQUIRE(ctx, topk_ids && users && ks && test_ptr && hr && mrr && ndcg, "null argument");
+    CREC_REQUIRE(ctx, nk >= 1 && nk <= 64 && Bt >= 0 && K >= 1, "bad sizes");
+    for (int q = 0; q < nk; ++q)
+        CREC_REQUIRE(ctx, ks[q] >= 1 && ks[q] <= K, "ks[%d] = %d outside [1, K]", q, ks[q]);
+    if (Bt == 0)
+        return CREC_OK;
+    CREC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    if (int rc = crec_reserve(ctx, &ctx->ks_dev, sizeof(int32_t) * 64))
+        return rc;
+    CREC_HIP(ctx, hipMemcpyAsync(ctx->ks_dev.ptr, ks, sizeof(int32_t) * nk, hipMemcpyHostToDevice, st));
+    const int64_t total = (int64_t)nk * Bt;
+    crec_prof_begin(ctx, CREC_K_METRICS, st);
+    hipLaunchKernelGGL(rank_metrics_kernel, dim3((unsigned)crec_ceil_div(total, 256)), dim3(256), 0, st, topk_ids, users,
+                       Bt, K, (const int32_t *)ctx->ks_dev.ptr, nk, test_ptr, test_items, hr, mrr, ndcg);
+    crec_prof_end(ctx, st);
+    CREC_HIP(ctx, hipGetLastError());
+    return crec_prof_flush(ctx, st);
+}

@@ -1,0 +1,113 @@
+"""Trainer base for ranking models (reference model/RankingRecommender.py): same methods and
+return shapes -- train_model() -> mean of per-batch summed losses (:33-61), test_model_rs() ->
+(HR, MRR, NDCG) dicts of per-user lists keyed by topk index (:198-247), run_model() with the
+reference's log lines and best-NDCG@topk[0] bookkeeping (:395-440) -- with the per-batch
+sess.run, the numpy argsort and the Python filter/metric loops replaced by libcrec.so calls."""
+import math
+import time
+from collections import defaultdict
+
+import numpy as np
+import torch
+
+from .. import runtime
+from ..utils.sampler import pairwise_ranking_sampler
+from ..utils.tools import timer
+from .Recommender import Recommender
+
+
+class RankingRecommender(Recommender):
+    def __init__(self, sess, data, configs, logger):
+        super(RankingRecommender, self).__init__(sess, data, configs, logger)
+        self.neg_ratio = int(configs['neg_ratio'])
+        self.model_params += ', neg_ratio=%d' % self.neg_ratio
+        self.test_users = [int(u) for u in (data.test_users if hasattr(data, 'test_users') else data.ui_test.keys())]
+        self.test_batches = math.ceil(len(self.test_users) / self.batch_size_t)
+        self._eval_cache = None
+
+    # -- hooks a model class fills in ---------------------------------------------------------
+    def _train_epoch_device(self, u, i, j):
+        """Run all batches of one sampled epoch; return per-batch losses (device tensor)."""
+        raise NotImplementedError
+
+    def _eval_tables(self):
+        """(P_like, Q_like) such that score(u, item) = P_like[u] . Q_like[item]."""
+        raise NotImplementedError
+
+    # -- one epoch (RankingRecommender.py:33-61) -------------------------------------------------
+    def train_model(self):
+        if self.is_pairwise != 'True':
+            raise NotImplementedError("pointwise training belongs to the GMF/MLP/NeuMF kernels (next tier)")
+        train_ = pairwise_ranking_sampler(self.data, self.neg_ratio, self.batch_size, fism_like=self.fism_like)
+        s = self.sess
+        u, i, j = (s.to_dev(a) for a in train_[1:4])
+        losses = self._train_epoch_device(u, i, j)
+        total_loss = float(losses.double().sum().item())  # total_loss += loss_val over the batches
+        return total_loss / train_[0]
+
+    # -- full-catalogue evaluation (RankingRecommender.py:198-247) -------------------------------
+    def _eval_inputs(self):
+        if self._eval_cache is None:
+            s, d = self.sess, self.data
+            if not hasattr(d, 'seen_csr'):
+                from ..data import RankingData
+                d = RankingData(d.user_nums, d.item_nums, d.ui_train, d.ui_test)
+            self._eval_cache = dict(
+                users=s.to_dev(np.asarray(self.test_users, dtype=np.int32)),
+                seen_ptr=s.to_dev(d.seen_csr[0]), seen_items=s.to_dev(d.seen_csr[1] if len(d.seen_csr[1]) else np.zeros(1, np.int32)),
+                test_ptr=s.to_dev(d.test_csr[0]), test_items=s.to_dev(d.test_csr[1]))
+        return self._eval_cache
+
+    def test_model_rs(self):
+        HR, MRR, NDCG = defaultdict(list), defaultdict(list), defaultdict(list)
+        e = self._eval_inputs()
+        P, Q = self._eval_tables()
+        Kmax = self.topk[-1]
+        for t_id in range(self.test_batches):
+            cur = e['users'][t_id * self.batch_size_t:(t_id + 1) * self.batch_size_t]
+            ids, _ = runtime.eval_topk(self.sess, P, Q, cur, e['seen_ptr'], e['seen_items'], Kmax, self.cml_like)
+            hr, mrr, ndcg = runtime.rank_metrics(self.sess, ids, cur, self.topk, e['test_ptr'], e['test_items'])
+            hr, mrr, ndcg = hr.cpu().numpy(), mrr.cpu().numpy(), ndcg.cpu().numpy()
+            for kid in range(len(self.topk)):
+                HR[kid].extend(hr[kid].tolist())
+                MRR[kid].extend(mrr[kid].tolist())
+                NDCG[kid].extend(ndcg[kid].tolist())
+        return HR, MRR, NDCG
+
+    def test_model_loo(self):
+        raise NotImplementedError("leave-one-out / sampled-negative evaluation is the next tier (SURVEY.md 8 f1)")
+
+    # -- driver (RankingRecommender.py:395-440) ---------------------------------------------------
+    @timer('run_model')
+    def run_model(self):
+        self.build_model()
+        best_ndcg10, best_epoch = 0, 0
+        best_metrics = {}
+        for epoch in range(self.epoches):
+            t1 = time.time()
+            avg_loss = self.train_model()
+            self.logger.info(' epoch %d\n  Training loss: %.4f, time: %s' % (epoch + 1, avg_loss, time.strftime('%H:%M:%S', time.gmtime(time.time() - t1))))
+            t2 = time.time()
+            if (epoch + 1) % self.T:
+                continue
+            if self.configs['data.split_way'] == 'loo' or self.neg_samples > 0:
+                HR, MRR, NDCG = self.test_model_loo()
+            else:
+                HR, MRR, NDCG = self.test_model_rs()
+            self.logger.info('  Testing time: %s' % time.strftime('%H:%M:%S', time.gmtime(time.time() - t2)))
+            best_flag = False
+            for id in range(len(self.topk)):
+                hr, mrr, ndcg = np.mean(HR[id]), np.mean(MRR[id]), np.mean(NDCG[id])
+                self.logger.info('  (k=%d) HR=%.4f, MRR=%.4f, NDCG=%.4f' % (self.topk[id], hr, mrr, ndcg))
+                if id == 0 and ndcg > best_ndcg10:
+                    best_flag = True
+                    best_ndcg10 = ndcg
+                if best_flag:
+                    best_metrics[id] = (hr, mrr, ndcg)
+                    best_epoch = epoch + 1
+        self.logger.info('best_epoch: %d' % best_epoch)
+        for id in range(len(self.topk)):
+            if id in best_metrics:  # the reference raises KeyError when NDCG never rose above 0
+                hr, mrr, ndcg = best_metrics[id]
+                self.logger.info('  (k=%d) HR=%.4f, MRR=%.4f, NDCG=%.4f' % (self.topk[id], hr, mrr, ndcg))
+        return best_epoch, best_metrics

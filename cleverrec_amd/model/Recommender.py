@@ -1,0 +1,46 @@
+"""Base Recommender (reference model/Recommender.py:9-40): same constructor, same parsed
+attributes; `sess` is a cleverrec_amd.runtime.Session (or None: one is opened on gpu.id)."""
+from ..config import parse_list
+from ..runtime import Session
+from ..utils.tools import get_initializer
+
+
+class Recommender(object):
+    def __init__(self, sess, data, configs, logger):
+        self.model = configs['recommender']
+        if sess is None:
+            sess = Session(int(configs.get('gpu.id', 0)))
+        self.sess, self.data, self.configs, self.logger = sess, data, configs, logger
+        self._get_common_params()
+
+    def _get_common_params(self):
+        c = self.configs
+        self.epoches, self.batch_size, self.batch_size_t = int(c['epoches']), int(c['batch_size']), int(c['test.batch_size'])
+        self.lr, self.neg_samples = float(c['lr']), int(c['test.neg_samples'])
+        # presence flags, as in the reference (Recommender.py:19)
+        self.fism_like, self.cml_like = 'fism_like' in c, 'cml_like' in c
+        self.is_pairwise = c['is_pairwise']  # the *string* 'True'/'False' (RankingRecommender.py:35)
+        self.initializer = get_initializer(c['init_method'], float(c['stddev']))
+        # the reference attaches l2_regularizer(0.001) to every variable but never adds
+        # REGULARIZATION_LOSSES to the loss, so it has no effect: nothing to carry.
+        self.loss_func = c['loss_func']
+        self.optimizer = c['optimizer']
+        if self.optimizer != 'Adam':
+            raise NotImplementedError("optimizer=%s: this core implements Adam (the shipped confs' choice)" % self.optimizer)
+        self.adam_mode = c.get('adam_mode', 'tf1')
+        self.saved_model_dir = c['saved_dir']
+        self.T = int(c['test.interval'])
+        self.topk = parse_list(c['topk'], int)
+        self.model_params = 'lr=%s, loss_func=%s' % (self.lr, c['loss_func'])
+
+    def build_model(self):
+        raise NotImplementedError
+
+    def train_model(self):
+        raise NotImplementedError
+
+    def test_model(self):
+        raise NotImplementedError
+
+    def run_model(self):
+        raise NotImplementedError

@@ -1,0 +1,77 @@
+"""Host helpers with the reference's names (utils/tools.py:9-87): re_index, timer, get_logger,
+get_initializer.  get_loss / get_optimizer have no host object here: loss_func and optimizer
+are parsed by the model class and carried out inside the HIP kernels."""
+import functools
+import logging
+import math
+import os
+import sys
+import time
+
+import torch
+
+
+def re_index(data_set):
+    """utils/tools.py:9-15: ids in iteration order -> 0..n-1."""
+    return {d: n for n, d in enumerate(data_set)}
+
+
+def timer(text):
+    """utils/tools.py:18-28 (same console lines)."""
+    def decorator(func):
+        @functools.wraps(func)
+        def wrapper(*args, **kwargs):
+            t1 = time.time()
+            print("Start %s..." % text)
+            res = func(*args, **kwargs)
+            print("%s done, time: %s" % (text, time.strftime("%H:%M:%S", time.gmtime(time.time() - t1))))
+            return res
+        return wrapper
+    return decorator
+
+
+def get_logger(log_dir, model):
+    """utils/tools.py:31-48: root logger -> <log_dir>/<model>.log + stdout, same format."""
+    os.makedirs(log_dir, exist_ok=True)
+    logger = logging.getLogger()
+    logger.setLevel(logging.DEBUG)
+    fmt = logging.Formatter("%(asctime)s  %(message)s", datefmt="%Y-%m-%d %H:%M:%S")
+    for h in (logging.FileHandler(os.path.join(log_dir, model + ".log")), logging.StreamHandler(sys.stdout)):
+        h.setLevel(logging.DEBUG)
+        h.setFormatter(fmt)
+        logger.addHandler(h)
+    return logger
+
+
+def get_initializer(init_method, stddev=None, generator=None):
+    """utils/tools.py:51-63.  Returns f(shape) -> fp32 CPU tensor.  'xavier_uniform' (used by the
+    shipped GMF/MLP/NeuMF confs but unhandled by the reference) is Glorot-uniform.
+    TF's own Philox stream is not reproducible (and the reference never seeds it); parity tests
+    inject tables instead."""
+    init_method = init_method.strip()
+
+    def fans(shape):
+        if len(shape) < 1:
+            return 1, 1
+        if len(shape) == 1:
+            return shape[0], shape[0]
+        return shape[-2], shape[-1]
+
+    def f(shape):
+        shape = tuple(int(s) for s in shape)
+        g = generator
+        if init_method == "normal":
+            return torch.empty(shape).normal_(0.0, stddev, generator=g)
+        if init_method == "tnormal":  # truncated at 2 sigma, redrawn
+            return torch.nn.init.trunc_normal_(torch.empty(shape), 0.0, stddev, -2 * stddev, 2 * stddev, generator=g)
+        if init_method == "uniform":
+            return torch.empty(shape).uniform_(-stddev, stddev, generator=g)
+        fi, fo = fans(shape)
+        if init_method in ("xavier", "xavier_uniform"):
+            lim = math.sqrt(6.0 / (fi + fo))
+            return torch.empty(shape).uniform_(-lim, lim, generator=g)
+        if init_method == "xavier_normal":
+            sd = math.sqrt(2.0 / (fi + fo))
+            return torch.nn.init.trunc_normal_(torch.empty(shape), 0.0, sd, -2 * sd, 2 * sd, generator=g)
+        raise ValueError("init_method=%r" % init_method)
+    return f

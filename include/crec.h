@@ -1,0 +1,142 @@
+/*
+ * crec.h -- C ABI of libcrec.so, the MI355X (gfx950) embedding-training core that
+ * sits under CleverRec's Recommender / RankingRecommender classes.
+ *
+ * The reference has no FFI of its own: its "operator API" for this path is the
+ * per-batch `sess.run` into a TF1 graph plus three pure-Python helpers.  Each entry
+ * point below names the reference interface it replaces (paths relative to the
+ * reference root); INTEGRATION.md shows the ctypes stub a reference maintainer adds.
+ *
+ * Conventions
+ *   - every function returns CREC_OK (0) or a negative CREC_E* code and never throws;
+ *     crec_last_error(ctx) holds the text of the last failure on that ctx.
+ *   - the caller owns every buffer it passes; the library owns only the opaque ctx
+ *     (index workspace, contribution rows, graphs).  No ownership is transferred.
+ *   - pointers marked [dev] are device (HBM) addresses on the ctx's GPU, [host] are
+ *     host addresses.  `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *     device work is enqueued on it and not synchronised unless stated.
+ *   - one ctx per (device, host thread); a ctx is not thread-safe, distinct ctxs are
+ *     independent.
+ *   - embedding tables are dense row-major fp32 [rows, d]; d % 4 == 0, 4 <= d <= 256;
+ *     table base addresses 16-byte aligned.
+ */
+#ifndef CREC_H
+#define CREC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CREC_OK 0
+#define CREC_EINVAL (-1)       /* bad argument (shape, alignment, null pointer, range) */
+#define CREC_EHIP (-2)         /* a HIP runtime call or kernel launch failed */
+#define CREC_ENOMEM (-3)       /* host or device allocation failed */
+#define CREC_EUNSUPPORTED (-4) /* valid request this build does not implement */
+#define CREC_ENODEVICE (-5)    /* no usable gfx950 device */
+
+#define CREC_ADAM_TF1 0  /* TF1 AdamOptimizer on IndexedSlices: every row decays and moves each step */
+#define CREC_ADAM_LAZY 1 /* only rows touched by the batch are updated */
+
+typedef struct crec_ctx crec_ctx;
+
+int crec_version(void);
+
+/* device >= 0: bind to that HIP device (replaces tf.Session + CUDA_VISIBLE_DEVICES=gpu.id,
+ * main.py:40-47).  device < 0: host-only ctx (RNG + samplers), usable without a GPU. */
+int crec_ctx_create(int device, crec_ctx **out);
+void crec_ctx_destroy(crec_ctx *ctx);
+const char *crec_last_error(const crec_ctx *ctx);
+
+/* ---- measurement: per-kernel time from HIP events recorded on the launch stream ------------
+ * While enabled, every kernel launch of this ctx is bracketed by two events and each API call
+ * ends with a stream synchronise (so do not time whole-job throughput with it on).
+ * kernel_class: 0 bpr_index_batches, 1 bpr_row_words, 2 bpr_user_side, 3 bpr_item_side,
+ *               4 bpr_reduce_loss, 5 eval_sweep, 6 eval_merge, 7 rank_metrics.
+ * enable(.., 1) also clears the accumulated totals. */
+int crec_profile_enable(crec_ctx *ctx, int on);
+int crec_profile_read(const crec_ctx *ctx, int kernel_class, double *total_ms, int64_t *launches);
+
+/* ---- RNG: the NumPy legacy global MT19937 stream the samplers draw from -------------
+ * replaces np.random.seed / get_state / set_state as used around utils/sampler.py. */
+int crec_rng_seed(crec_ctx *ctx, uint32_t seed);
+int crec_rng_set_state(crec_ctx *ctx, const uint32_t key[624], int32_t pos);
+int crec_rng_get_state(const crec_ctx *ctx, uint32_t key[624], int32_t *pos);
+/* np.random.randint(n), 1 <= n <= 2^32 (exposed for tests and for callers that interleave draws) */
+int crec_rng_randint(crec_ctx *ctx, int64_t n, int64_t *out);
+/* np.random.permutation(n) -> out[n] [host] */
+int crec_rng_permutation(crec_ctx *ctx, int64_t n, int64_t *out);
+
+/* ---- samplers (host, bit-exact with the reference on the same RNG state) -------------
+ * ui_train is a CSR in the dict's iteration order: user_ids[k] owns
+ * items[ptr[k] .. ptr[k+1]) in list order.  Outputs [host], already shuffled by the
+ * epoch permutation; *n_out = number of instances written.
+ *   pairwise : utils/sampler.py:46-74   capacity n_pos*neg_ratio      each of u, i, j
+ *   pointwise: utils/sampler.py:10-43   capacity n_pos*(1+neg_ratio)  each of u, i, y
+ *   cml      : utils/sampler.py:77-99   capacity n_pos for u, i; n_pos*neg_ratio for neg
+ * Fails with CREC_EINVAL when some user has fewer than neg_ratio unseen items (the
+ * reference would loop forever there). */
+int crec_sample_pairwise(crec_ctx *ctx, const int64_t *ptr, const int32_t *items, int64_t n_users,
+                         const int32_t *user_ids, int32_t item_nums, int neg_ratio, int32_t *u, int32_t *i, int32_t *j,
+                         int64_t *n_out);
+int crec_sample_pointwise(crec_ctx *ctx, const int64_t *ptr, const int32_t *items, int64_t n_users,
+                          const int32_t *user_ids, int32_t item_nums, int neg_ratio, int32_t *u, int32_t *i, float *y,
+                          int64_t *n_out);
+int crec_sample_cml(crec_ctx *ctx, const int64_t *ptr, const int32_t *items, int64_t n_users, const int32_t *user_ids,
+                    int32_t item_nums, int neg_ratio, int32_t *u, int32_t *i, int32_t *neg, int64_t *n_out);
+
+/* ---- BPR training (device) ------------------------------------------------------------
+ * replaces, per batch, sess.run([self.train, self.loss], {u_idx, i_idx, j_idx})
+ * (model/RankingRecommender.py:46) on the graph of model/ranking/BPR.py:31-44 with
+ * tf.train.AdamOptimizer (utils/tools.py:83-84). */
+typedef struct {
+    float *P, *Q;     /* [dev] [U,d], [I,d] parameters ('BPR_params/P', 'BPR_params/Q', BPR.py:28-29) */
+    float *mP, *vP;   /* [dev] Adam slots of P */
+    float *mQ, *vQ;   /* [dev] Adam slots of Q */
+    int64_t U, I;
+    int32_t d;
+} crec_bpr_tables;
+
+typedef struct {
+    float lr, beta1, beta2, eps; /* AdamOptimizer(lr) defaults: 0.9, 0.999, 1e-8 */
+    float reg;                   /* configs['reg'] (BPR.py:13) */
+    int32_t adam_mode;           /* CREC_ADAM_* */
+    /* optimizer state, updated by the call: fp32 running products like TF's beta1_power /
+     * beta2_power slot variables.  Initialise to beta1, beta2 and step = 0. */
+    float beta1_power, beta2_power;
+    int64_t step;
+} crec_adam;
+
+/* One epoch's batches: contiguous slices [b*B, (b+1)*B) of the sampled triples (last one
+ * partial), exactly the slicing of RankingRecommender.train_model (:39-47).
+ *   u, i, j        [dev] int32 [N]
+ *   loss_per_batch [dev] float [ceil(N/B)]: loss_b = sum softplus(-x) + reg*(l2 terms)
+ * train_model's return value is mean(loss_per_batch) (:61).  B <= 8192. */
+int crec_bpr_train_epoch(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, const int32_t *u, const int32_t *i,
+                         const int32_t *j, int64_t N, int32_t B, float *loss_per_batch, void *stream);
+
+/* ---- full-catalogue evaluation (device) -------------------------------------------------
+ * replaces sess.run(self.pre_scores) (BPR._predict rs branch, BPR.py:51) + np.argsort +
+ * the seen-item filter loop (model/RankingRecommender.py:221-240).
+ *   users        [dev] int32 [Bt] row ids into P
+ *   seen_ptr     [dev] int64 [U+1], seen_items [dev] int32: CSR of ui_train by user id, each
+ *                user's items sorted ascending (empty row = user absent from ui_train)
+ *   topk_ids     [dev] int32 [Bt,K], topk_scores [dev] float [Bt,K]: best first; ties by
+ *                lower item id; -1 / -inf padding when fewer than K unseen items exist
+ *   ascending    0: larger score is better; 1: smaller is better (cml_like, :222-223) */
+int crec_eval_topk(crec_ctx *ctx, const float *P, const float *Q, int64_t I, int32_t d, const int32_t *users,
+                   int32_t Bt, const int64_t *seen_ptr, const int32_t *seen_items, int32_t K, int32_t ascending,
+                   int32_t *topk_ids, float *topk_scores, void *stream);
+
+/* replaces cal_ranking_metrics (utils/metrics.py:9-19) over a user batch, float64.
+ *   ks [host] int32 [nk] (each <= K); test CSR by user id [dev]
+ *   hr, mrr, ndcg [dev] double [nk, Bt] */
+int crec_rank_metrics(crec_ctx *ctx, const int32_t *topk_ids, const int32_t *users, int32_t Bt, int32_t K,
+                      const int32_t *ks, int32_t nk, const int64_t *test_ptr, const int32_t *test_items, double *hr,
+                      double *mrr, double *ndcg, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CREC_H */

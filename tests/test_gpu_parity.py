@@ -1,0 +1,257 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle.  Needs an MI355X.
+
+Tolerances: index/id work bit-exact; fp32 losses rtol 1e-5 (north_star); parameters after a
+step: |delta| <= 2e-6 absolute on values of order 1e-2..1 where the Adam step itself is 1e-3
+(fp32 dot products are summed in a different order on the GPU, and Adam divides by sqrt(v));
+top-K ids and scores bit-exact against the oracle's MFMA-ordered fp32 chain."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from cleverrec_amd import _lib, runtime
+from cleverrec_amd.data import RankingData, synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sess():
+    s = runtime.Session(0)
+    yield s
+    s.close()
+
+
+def _toy_data(seed, U, I, lo, hi, test_every=2):
+    g = np.random.Generator(np.random.PCG64(seed))
+    ui_train = {u: [int(x) for x in g.choice(I, size=int(g.integers(lo, hi + 1)), replace=False)] for u in range(U) if u % 7 != 6}
+    ui_test = {u: [int(x) for x in g.choice(I, size=int(g.integers(1, 5)), replace=False)] for u in range(0, U, test_every)}
+    return RankingData(U, I, ui_train, ui_test)
+
+
+def _tables(seed, U, I, d, scale=0.01):
+    g = np.random.Generator(np.random.PCG64(seed))
+    return (g.standard_normal((U, d)) * scale).astype(np.float32), (g.standard_normal((I, d)) * scale).astype(np.float32)
+
+
+def _run_both(sess, data, d, B, epochs, mode, neg_ratio=4, seed=1, scale=0.01, lr=1e-3, reg=0.01):
+    P0, Q0 = _tables(7, data.user_nums, data.item_nums, d, scale)
+    st = runtime.BprState(sess, P0, Q0, lr=lr, reg=reg, adam_mode=mode)
+    om = oracle.BprModel(P0, Q0, lr=lr, reg=reg, adam_mode={"tf1": 0, "lazy": 1}[mode])
+    sess.ctx.seed(seed)
+    rng = oracle.Rng(seed)
+    losses, olosses = [], []
+    for _ in range(epochs):
+        u, i, j = sess.ctx.sample_pairwise(data.train_csr, data.item_nums, neg_ratio)
+        nb, ou, oi, oj = oracle.sample_pairwise(rng, data.ui_train, data.item_nums, neg_ratio, B)
+        assert np.array_equal(u, ou) and np.array_equal(i, oi) and np.array_equal(j, oj)  # bit-exact index stream
+        losses.append(st.train_epoch(sess.to_dev(u), sess.to_dev(i), sess.to_dev(j), B).cpu().numpy())
+        olosses.append(oracle.train_model_py(om, nb, ou, oi, oj, B)[1])
+    return st, om, np.concatenate(losses), np.concatenate(olosses)
+
+
+def _assert_state_close(st, om, atol):
+    for name in ("P", "Q", "mP", "mQ"):
+        np.testing.assert_allclose(getattr(st, name).cpu().numpy(), getattr(om, name), rtol=0, atol=atol, err_msg=name)
+    for name in ("vP", "vQ"):
+        np.testing.assert_allclose(getattr(st, name).cpu().numpy(), getattr(om, name), rtol=1e-4, atol=1e-12, err_msg=name)
+
+
+@pytest.mark.parametrize("mode", ["tf1", "lazy"])
+@pytest.mark.parametrize("d", [4, 16, 20, 32, 64, 128, 256])
+def test_bpr_epochs_match_oracle(sess, mode, d):
+    data = _toy_data(1, 150, 90, 2, 25)
+    st, om, loss, oloss = _run_both(sess, data, d, B=256, epochs=2, mode=mode)
+    assert st.adam.step == len(loss) and len(loss) == len(oloss)
+    np.testing.assert_allclose(loss, oloss, rtol=1e-5)
+    _assert_state_close(st, om, atol=2e-6)
+
+
+@pytest.mark.parametrize("B", [1, 63, 64, 1000, 6144, 8192])
+def test_bpr_batch_sizes_and_ragged_tail(sess, B):
+    data = _toy_data(2, 80, 50, 1, 20)
+    st, om, loss, oloss = _run_both(sess, data, 32, B=B, epochs=1, mode="tf1", neg_ratio=3)
+    np.testing.assert_allclose(loss, oloss, rtol=1e-5)
+    _assert_state_close(st, om, atol=2e-6)
+
+
+def test_bpr_heavy_duplicates_and_large_scores(sess):
+    # 3 users x 6 items: every row is hit hundreds of times per batch; scale 1.0 drives x far from 0
+    # (softplus branches, saturated sigmoid)
+    data = RankingData(3, 6, {0: [0, 1], 1: [2, 3, 4], 2: [5]}, {0: [2]})
+    st, om, loss, oloss = _run_both(sess, data, 16, B=512, epochs=3, mode="tf1", neg_ratio=3, scale=1.5, lr=0.05)
+    np.testing.assert_allclose(loss, oloss, rtol=1e-5)
+    _assert_state_close(st, om, atol=5e-5)
+
+
+def test_bpr_ml100k_shape_full_epoch(sess):
+    """BASELINE config C1 shape (943 x 1349, d=32, B=6144, neg_ratio 4) on synthetic data."""
+    data = synthetic("S-ml100k")
+    st, om, loss, oloss = _run_both(sess, data, 32, B=6144, epochs=1, mode="tf1")
+    assert len(loss) == -(-data.n_train * 4 // 6144)
+    np.testing.assert_allclose(loss, oloss, rtol=1e-5)
+    _assert_state_close(st, om, atol=2e-6)
+    # train_model's return value: mean of the per-batch sums (RankingRecommender.py:61)
+    assert float(loss.astype(np.float64).mean()) == pytest.approx(float(oloss.mean()), rel=1e-6)
+
+
+def test_bpr_is_deterministic_at_full_size(sess):
+    """ml-1m shape (C2): two runs from the same state are bitwise identical (no atomics), and the
+    tf1 / lazy modes agree on every row the epoch touches in every batch-free sense: lazy leaves
+    untouched rows' slots at zero while tf1 keeps them at zero too when m == 0."""
+    data = synthetic("S-ml1m")
+    P0, Q0 = _tables(3, data.user_nums, data.item_nums, 64)
+    sess.ctx.seed(1)
+    u, i, j = (sess.to_dev(a) for a in sess.ctx.sample_pairwise(data.train_csr, data.item_nums, 4))
+    n = 40 * 6144
+    outs = []
+    for _ in range(2):
+        st = runtime.BprState(sess, P0, Q0, lr=1e-3, reg=0.01, adam_mode="tf1")
+        loss = st.train_epoch(u[:n], i[:n], j[:n], 6144)
+        outs.append((loss.cpu().numpy(), st.P.cpu().numpy(), st.Q.cpu().numpy(), st.vQ.cpu().numpy()))
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    # loss of an untrained model ~ B*ln2 + reg terms, and it must go down
+    assert outs[0][0][0] == pytest.approx(6144 * np.log(2), rel=1e-3)
+    assert outs[0][0][-1] < outs[0][0][0]
+    # first 3 batches against the oracle at full size
+    om = oracle.BprModel(P0, Q0, lr=1e-3, reg=0.01, adam_mode=0)
+    un, inn, jn = (t[:3 * 6144].cpu().numpy() for t in (u, i, j))
+    _, ol = oracle.train_model_py(om, 3, un, inn, jn, 6144)
+    np.testing.assert_allclose(outs[0][0][:3], ol, rtol=1e-5)
+
+
+def test_bpr_argument_checks(sess):
+    P0, Q0 = _tables(0, 10, 10, 6)  # d = 6 is not a multiple of 4
+    st = runtime.BprState(sess, P0, Q0, 1e-3, 0.01)
+    z = sess.zeros((8,), torch.int32)
+    with pytest.raises(_lib.CrecError, match="embed_size"):
+        st.train_epoch(z, z, z, 4)
+    P0, Q0 = _tables(0, 10, 10, 8)
+    st = runtime.BprState(sess, P0, Q0, 1e-3, 0.01)
+    with pytest.raises(_lib.CrecError, match="batch_size"):
+        st.train_epoch(z, z, z, 10000)
+    loss = st.train_epoch(z[:0], z[:0], z[:0], 4)  # empty epoch: nothing happens
+    assert loss.numel() == 0 and st.adam.step == 0
+
+
+# ---------------------------------------------------------------------------------------------
+# evaluation
+# ---------------------------------------------------------------------------------------------
+def _eval_both(sess, data, P, Q, K, ascending=False, users=None):
+    users = data.test_users if users is None else np.asarray(users, dtype=np.int32)
+    seen_items = data.seen_csr[1] if len(data.seen_csr[1]) else np.zeros(1, np.int32)
+    ids, sc = runtime.eval_topk(sess, sess.to_dev(P), sess.to_dev(Q), sess.to_dev(users), sess.to_dev(data.seen_csr[0]),
+                                sess.to_dev(seen_items), K, ascending)
+    osc = oracle.scores(P, Q, users, order=1)
+    oids, oval = oracle.topk(osc, users, data.seen_csr[0], data.seen_csr[1], K, ascending)
+    return ids, sc, oids, oval, users
+
+
+@pytest.mark.parametrize("d", [4, 32, 64, 128, 256])
+@pytest.mark.parametrize("ascending", [False, True])
+def test_eval_topk_bit_exact(sess, d, ascending):
+    data = _toy_data(5, 333, 700, 1, 120, test_every=1)
+    P, Q = _tables(11, data.user_nums, data.item_nums, d, scale=1.0)
+    Q[10] = Q[9]
+    Q[500] = Q[9]  # exact score ties across tiles -> lower id first
+    ids, sc, oids, oval, _ = _eval_both(sess, data, P, Q, 20, ascending)
+    assert np.array_equal(ids.cpu().numpy(), oids)
+    assert np.array_equal(sc.cpu().numpy(), oval)
+
+
+def test_eval_topk_edges(sess):
+    # fewer than K unseen items -> -1 padding; users absent from ui_train skip the filter;
+    # a single user; K = 1 and K = 32
+    I = 40
+    ui_train = {0: list(range(0, 35)), 1: list(range(I)), 3: [7]}
+    data = RankingData(5, I, ui_train, {0: [36], 1: [0], 2: [5], 3: [1], 4: [2]})
+    P, Q = _tables(12, 5, I, 16, scale=1.0)
+    for K in (1, 20, 32):
+        ids, sc, oids, oval, _ = _eval_both(sess, data, P, Q, K)
+        assert np.array_equal(ids.cpu().numpy(), oids) and np.array_equal(sc.cpu().numpy(), oval)
+    ids = ids.cpu().numpy()
+    assert (ids[0] >= 0).sum() == 5 and (ids[1] == -1).all() and (ids[2] >= 0).all()
+    ids1, sc1, oids1, _, _ = _eval_both(sess, data, P, Q, 20, users=[4])
+    assert np.array_equal(ids1.cpu().numpy(), oids1)
+
+
+def test_eval_metrics_match_oracle_and_reference_semantics(sess):
+    data = _toy_data(6, 500, 900, 1, 200, test_every=1)
+    P, Q = _tables(13, data.user_nums, data.item_nums, 64, scale=1.0)
+    ids, sc, oids, _, users = _eval_both(sess, data, P, Q, 20)
+    du = sess.to_dev(users)
+    hr, mrr, ndcg = runtime.rank_metrics(sess, ids, du, [10, 20], sess.to_dev(data.test_csr[0]), sess.to_dev(data.test_csr[1]))
+    ohr, omrr, ondcg = oracle.rank_metrics(oids, users, [10, 20], data.test_csr[0], data.test_csr[1])
+    np.testing.assert_allclose(hr.cpu().numpy(), ohr, rtol=0, atol=0)
+    np.testing.assert_allclose(mrr.cpu().numpy(), omrr, rtol=1e-14)
+    np.testing.assert_allclose(ndcg.cpu().numpy(), ondcg, rtol=1e-12)
+    # and against the statement-for-statement Python restatement of test_model_rs
+    H, M, N = oracle.test_model_rs_py(lambda cur: oracle.scores(P, Q, cur, 1), [int(x) for x in users], data.ui_train,
+                                      data.ui_test, [10, 20], 128)
+    np.testing.assert_allclose(ndcg.cpu().numpy()[0], N[0], rtol=1e-12)
+    np.testing.assert_allclose(hr.cpu().numpy()[1], H[1], rtol=0)
+
+
+def test_eval_full_size_properties(sess):
+    """ml-1m shape (C2): size-independent properties of the fused GEMM + top-K at full size."""
+    data = synthetic("S-ml1m")
+    P, Q = _tables(14, data.user_nums, data.item_nums, 64, scale=0.3)
+    K = 20
+    ids, sc = runtime.eval_topk(sess, sess.to_dev(P), sess.to_dev(Q), sess.to_dev(data.test_users),
+                                sess.to_dev(data.seen_csr[0]), sess.to_dev(data.seen_csr[1]), K)
+    ids, sc = ids.cpu().numpy(), sc.cpu().numpy()
+    assert ids.shape == (len(data.test_users), K) and (ids >= 0).all() and (ids < data.item_nums).all()
+    assert (np.diff(sc, axis=1) <= 0).all()  # best first
+    assert all(len(set(r)) == K for r in ids[::97])  # no repeats
+    ptr, items = data.seen_csr
+    for r in range(0, len(ids), 53):  # never a training item
+        uu = data.test_users[r]
+        assert not set(ids[r]) & set(items[ptr[uu]:ptr[uu + 1]])
+    # returned scores are the dot products, and nothing outside the list beats its last entry
+    full = P[data.test_users[::211]].astype(np.float64) @ Q.T.astype(np.float64)
+    for n, r in enumerate(range(0, len(ids), 211)):
+        np.testing.assert_allclose(sc[r], full[n][ids[r]], rtol=1e-5, atol=1e-6)
+        uu = data.test_users[r]
+        mask = np.ones(data.item_nums, bool)
+        mask[items[ptr[uu]:ptr[uu + 1]]] = False
+        mask[ids[r]] = False
+        assert full[n][mask].max() <= sc[r][-1] + 1e-5
+    # a spot check of whole rows against the oracle, bit for bit
+    sub = data.test_users[:256]
+    oids, oval = oracle.topk(oracle.scores(P, Q, sub, 1), sub, ptr, items, K)
+    assert np.array_equal(ids[:256], oids) and np.array_equal(sc[:256], oval)
+
+
+def test_model_class_end_to_end(sess, tmp_path):
+    """The reference-shaped surface: BPR(sess, data, configs, logger).run_model() on a small
+    dataset, against an oracle run of the same protocol (sampler stream from np.random)."""
+    import logging
+    from cleverrec_amd.model.ranking.BPR import BPR
+    data = _toy_data(8, 200, 120, 3, 30)
+    configs = {"recommender": "BPR", "epoches": "3", "batch_size": "512", "test.batch_size": "64", "lr": "0.001",
+               "test.neg_samples": "0", "is_pairwise": "True", "init_method": "normal", "stddev": "0.01",
+               "loss_func": "bpr", "optimizer": "Adam", "saved_dir": str(tmp_path), "test.interval": "1",
+               "topk": "[10,20]", "neg_ratio": "4", "embed_size": "32", "reg": "0.01", "data.split_way": "rs"}
+    m = BPR(sess, data, configs, logging.getLogger("t"))
+    P0, Q0 = _tables(9, data.user_nums, data.item_nums, 32)
+    m.build_model(P0, Q0)
+    om = oracle.BprModel(P0, Q0, lr=1e-3, reg=0.01)
+    np.random.seed(4)
+    rng = oracle.Rng(4)
+    for _ in range(2):
+        avg = m.train_model()
+        nb, ou, oi, oj = oracle.sample_pairwise(rng, data.ui_train, data.item_nums, 4, 512)
+        oavg, _ = oracle.train_model_py(om, nb, ou, oi, oj, 512)
+        assert avg == pytest.approx(oavg, rel=1e-5)
+    HR, MRR, NDCG = m.test_model_rs()
+    Pn, Qn = m.P.cpu().numpy(), m.Q.cpu().numpy()
+    H, M, N = oracle.test_model_rs_py(lambda cur: oracle.scores(Pn, Qn, cur, 1), m.test_users, data.ui_train, data.ui_test,
+                                      [10, 20], 64)
+    for kid in range(2):
+        np.testing.assert_allclose(HR[kid], H[kid], rtol=0)
+        np.testing.assert_allclose(NDCG[kid], N[kid], rtol=1e-12)
+        np.testing.assert_allclose(MRR[kid], M[kid], rtol=1e-12)
+    assert os.path.exists(m.save())

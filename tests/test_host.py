@@ -1,0 +1,132 @@
+"""CPU-side checks of the product: the C-ABI library loads and exports every symbol of
+include/crec.h, the host RNG + samplers are bit-exact against the reference's golden vectors
+and numpy, and device entry points fail loudly without a GPU.  No compute on a GPU here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from cleverrec_amd import _lib, build as crec_build
+from cleverrec_amd.data import RankingData, csr_from_dict
+from cleverrec_amd.utils import sampler as S
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    crec_build.build()
+    c = _lib.Context(None)
+    yield c
+    c.close()
+
+
+def test_library_exports_every_declared_symbol():
+    crec_build.build()
+    hdr = open(os.path.join(ROOT, "include", "crec.h")).read()
+    declared = set(re.findall(r"\b(crec_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    lib = C.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libcrec.so does not export %s" % name
+    assert declared == set(_lib.exported_symbols()), "ctypes table out of step with crec.h"
+    assert _lib.load().crec_version() >= 100
+
+
+def test_rng_matches_numpy(ctx):
+    for seed in (0, 123, 2 ** 32 - 1):
+        ctx.seed(seed)
+        np.random.seed(seed)
+        for n in [1, 2, 3, 10, 1349, 3706, 4096, 4097, 2 ** 31, 2 ** 32, 1, 7] * 30:
+            assert ctx.randint(n) == int(np.random.randint(n))
+        for n in (0, 1, 2, 63, 64, 65, 1000, 5000):
+            assert np.array_equal(ctx.permutation(n), np.random.permutation(n))
+
+
+@pytest.mark.parametrize("name", ["toy", "syn200", "dense", "pow2"])
+def test_samplers_bit_exact_vs_reference(ctx, golden_dir, name):
+    g = np.load(os.path.join(golden_dir, "sampler_%s.npz" % name))
+    csr = (g["keys"], g["ptr"], g["items"])
+    item_nums, seed, nr = int(g["item_nums"]), int(g["seed"]), int(g["neg_ratio"])
+    ctx.seed(seed)
+    u, i, j = ctx.sample_pairwise(csr, item_nums, nr)
+    assert np.array_equal(u, g["pw_u"]) and np.array_equal(i, g["pw_i"]) and np.array_equal(j, g["pw_j"])
+    assert ctx.randint(2 ** 30) == int(g["pw_next"])
+    ctx.seed(seed)
+    u, i, y = ctx.sample_pointwise(csr, item_nums, nr)
+    assert np.array_equal(u, g["pt_u"]) and np.array_equal(i, g["pt_i"]) and np.array_equal(y, g["pt_y"])
+    assert ctx.randint(2 ** 30) == int(g["pt_next"])
+    ctx.seed(seed)
+    u, i, neg = ctx.sample_cml(csr, item_nums, nr)
+    assert np.array_equal(u, g["cml_u"]) and np.array_equal(i, g["cml_i"]) and np.array_equal(neg, g["cml_neg"])
+    assert ctx.randint(2 ** 30) == int(g["cml_next"])
+
+
+def test_sampler_wrappers_keep_numpy_global_stream_in_step(golden_dir):
+    """Drop-in behaviour: np.random.seed(s); sampler(...) leaves np.random exactly where the
+    reference's sampler would (pw_next was drawn from np.random after the reference call)."""
+    g = np.load(os.path.join(golden_dir, "sampler_syn200.npz"))
+
+    class D:
+        pass
+    d = D()
+    d.ui_train = {int(k): g["items"][g["ptr"][n]:g["ptr"][n + 1]].tolist() for n, k in enumerate(g["keys"])}
+    d.item_nums = int(g["item_nums"])
+    np.random.seed(int(g["seed"]))
+    nb, u, i, j = S.pairwise_ranking_sampler(d, int(g["neg_ratio"]), int(g["batch"]))
+    assert nb == int(g["pw_batches"]) and np.array_equal(j, g["pw_j"])
+    assert int(np.random.randint(2 ** 30)) == int(g["pw_next"])
+    np.random.seed(int(g["seed"]))
+    nb, u, i, y = S.pointwise_ranking_sampler(d, int(g["neg_ratio"]), int(g["batch"]))
+    assert nb == int(g["pt_batches"]) and np.array_equal(i, g["pt_i"])
+    assert int(np.random.randint(2 ** 30)) == int(g["pt_next"])
+    np.random.seed(int(g["seed"]))
+    nb, u, i, neg = S.ranking_sampler_cml(d, int(g["neg_ratio"]), int(g["batch"]))
+    assert nb == int(g["cml_batches"]) and np.array_equal(neg, g["cml_neg"])
+    assert int(np.random.randint(2 ** 30)) == int(g["cml_next"])
+
+
+def test_sampler_edge_cases(ctx):
+    # empty ui_train
+    e = (np.zeros(0, np.int32), np.zeros(1, np.int64), np.zeros(0, np.int32))
+    u, i, j = ctx.sample_pairwise(e, 10, 4)
+    assert len(u) == 0
+    # a user without rows between users with rows, and neg_ratio 0
+    csr = csr_from_dict({0: [1], 1: [], 2: [0, 3]})
+    u, i, j = ctx.sample_pairwise(csr, 5, 0)
+    assert len(u) == 0
+    # a user who cannot supply neg_ratio distinct unseen items: the reference would spin forever
+    with pytest.raises(_lib.CrecError):
+        ctx.sample_pairwise(csr_from_dict({0: [0, 1, 2]}), 4, 2)
+    # item id out of range
+    with pytest.raises(_lib.CrecError):
+        ctx.sample_pairwise(csr_from_dict({0: [7]}), 4, 1)
+    # item_nums == 1 and the only item unseen is impossible; item_nums 2 with one seen: always the other
+    ctx.seed(3)
+    u, i, j = ctx.sample_pairwise(csr_from_dict({5: [1]}), 2, 1)
+    assert u.tolist() == [5] and i.tolist() == [1] and j.tolist() == [0]
+
+
+def test_device_entry_points_fail_loudly_without_gpu(ctx):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    t = _lib.BprTables()
+    a = _lib.Adam()
+    rc = ctx.lib.crec_bpr_train_epoch(ctx.h, C.byref(t), C.byref(a), None, None, None, 0, 1, None, None)
+    assert rc == _lib.EINVAL and b"host-only" in ctx.lib.crec_last_error(ctx.h)
+    with pytest.raises(_lib.CrecError):
+        _lib.Context(0)  # no device: ENODEVICE, never a silent CPU path
+    from cleverrec_amd.runtime import Session
+    with pytest.raises(RuntimeError):
+        Session(0)
+
+
+def test_ranking_data_protocol():
+    d = RankingData(5, 6, {0: [3, 1], 2: [5], 4: [0, 2, 4]}, {0: [2], 4: [1, 5]})
+    assert d.test_users.tolist() == [0, 4] and d.n_train == 6
+    assert d.seen_csr[0].tolist() == [0, 2, 2, 3, 3, 6] and d.seen_csr[1].tolist() == [1, 3, 5, 0, 2, 4]
+    assert d.test_csr[0].tolist() == [0, 1, 1, 1, 1, 3] and d.test_csr[1].tolist() == [2, 1, 5]
+    assert d.ui_train == {0: [3, 1], 2: [5], 4: [0, 2, 4]}
