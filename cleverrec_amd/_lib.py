@@ -61,6 +61,10 @@ def load():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise ImportError("%s not built: run `python -m cleverrec_amd.build` (needs hipcc)" % LIB_PATH)
+        # torch first: its wheel bundles its own libamdhip64.so.7 / libhsa-runtime64; libcrec.so must
+        # bind to that already-loaded runtime (device pointers and streams are shared with torch).
+        # Loaded the other way round the process ends up with two HSA runtimes and no visible GPU.
+        import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the export is missing
@@ -85,7 +89,7 @@ class Context:
         h = C.c_void_p()
         rc = self.lib.crec_ctx_create(-1 if device is None else int(device), C.byref(h))
         if rc != OK:
-            raise CrecError(rc, "crec_ctx_create(device=%r) failed (no MI355X / gfx950 visible?)" % (device,))
+            raise CrecError(rc, "crec_ctx_create(device=%r): %s" % (device, self.lib.crec_last_error(None).decode()))
         self.h, self.device = h, device
 
     def close(self):

@@ -515,12 +515,13 @@ extern "C" int crec_bpr_train_epoch(crec_ctx *ctx, const crec_bpr_tables *t, cre
     if (!ctx)
         return CREC_EINVAL;
     CREC_REQUIRE(ctx, ctx->device >= 0, "host-only ctx: no device bound");
-    CREC_REQUIRE(ctx, t && opt && u && i && j && loss_per_batch, "null argument");
+    CREC_REQUIRE(ctx, t && opt, "null argument");
+    CREC_REQUIRE(ctx, N >= 0, "negative N");
+    CREC_REQUIRE(ctx, N == 0 || (u && i && j && loss_per_batch), "null argument");
     CREC_REQUIRE(ctx, t->P && t->Q && t->mP && t->vP && t->mQ && t->vQ, "null table pointer");
     CREC_REQUIRE(ctx, t->d >= 4 && t->d <= 256 && t->d % 4 == 0, "embed_size %d: need a multiple of 4 in [4, 256]", t->d);
     CREC_REQUIRE(ctx, t->U >= 1 && t->I >= 1 && t->U < ((int64_t)1 << 31) && t->I < ((int64_t)1 << 31), "table rows");
     CREC_REQUIRE(ctx, B >= 1 && B <= MAX_B, "batch_size %d: this build indexes batches of at most %d in LDS", B, MAX_B);
-    CREC_REQUIRE(ctx, N >= 0, "negative N");
     CREC_REQUIRE(ctx, opt->adam_mode == CREC_ADAM_TF1 || opt->adam_mode == CREC_ADAM_LAZY, "adam_mode");
     const float *tabs[] = {t->P, t->Q, t->mP, t->vP, t->mQ, t->vQ};
     for (const float *p : tabs)

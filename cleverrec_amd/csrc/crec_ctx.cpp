@@ -33,6 +33,8 @@ int crec_reserve(crec_ctx *ctx, crec_devbuf *b, size_t bytes)
     return CREC_OK;
 }
 
+static char g_create_err[256] = "no error";
+
 static hipEvent_t prof_event(crec_ctx *ctx)
 {
     if (!ctx->prof.pool.empty()) {
@@ -118,16 +120,22 @@ int crec_ctx_create(int device, crec_ctx **out)
         int n = 0;
         hipError_t e = hipGetDeviceCount(&n);
         if (e != hipSuccess || device >= n) {
+            snprintf(g_create_err, sizeof(g_create_err), "hipGetDeviceCount -> %s, %d device(s), asked for %d",
+                     hipGetErrorString(e), n, device);
             delete ctx;
             return CREC_ENODEVICE;
         }
         hipDeviceProp_t prop;
-        if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) {
+        if ((e = hipSetDevice(device)) != hipSuccess || (e = hipGetDeviceProperties(&prop, device)) != hipSuccess) {
+            snprintf(g_create_err, sizeof(g_create_err), "hipSetDevice/hipGetDeviceProperties(%d) -> %s", device,
+                     hipGetErrorString(e));
             delete ctx;
             return CREC_ENODEVICE;
         }
         if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
             // the code object is gfx950-only: say so now rather than at the first launch
+            snprintf(g_create_err, sizeof(g_create_err), "device %d is %s; this library is built for gfx950 only", device,
+                     prop.gcnArchName);
             delete ctx;
             return CREC_ENODEVICE;
         }
@@ -159,6 +167,7 @@ void crec_ctx_destroy(crec_ctx *ctx)
     delete ctx;
 }
 
-const char *crec_last_error(const crec_ctx *ctx) { return ctx ? ctx->err : "null ctx"; }
+// ctx == NULL: why the last crec_ctx_create failed
+const char *crec_last_error(const crec_ctx *ctx) { return ctx ? ctx->err : g_create_err; }
 
 } // extern "C"

@@ -47,6 +47,7 @@ int crec_version(void);
  * main.py:40-47).  device < 0: host-only ctx (RNG + samplers), usable without a GPU. */
 int crec_ctx_create(int device, crec_ctx **out);
 void crec_ctx_destroy(crec_ctx *ctx);
+/* ctx == NULL: the reason the last crec_ctx_create on this process failed */
 const char *crec_last_error(const crec_ctx *ctx);
 
 /* ---- measurement: per-kernel time from HIP events recorded on the launch stream ------------

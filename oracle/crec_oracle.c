@@ -399,7 +399,7 @@ void orc_bpr_step(float *P, float *Q, float *mP, float *vP, float *mQ, float *vQ
  *      (model/RankingRecommender.py:198-247, model/ranking/BPR.py:51).
  * order == 0: plain k = 0..d-1 fp32 chain.
  * order == 1: the k order of the gfx950 v_mfma_f32_32x32x2_f32 chain the HIP
- *             kernel issues (step s uses k = s and k = d/2 + s, in that order),
+ *             kernel issues (step s uses k = s and k = DMAX/2 + s, in that order),
  *             each product folded in with one fmaf rounding.
  * Ranking: descending score (ascending when `ascending`), ties -> lower item id
  * (the reference's np.argsort is not stable, so its tie order is unspecified).
@@ -419,10 +419,16 @@ void orc_scores(const float *P, const float *Q, int64_t I, int d, const int32_t 
                 for (int k = 0; k < d; k++)
                     acc = acc + pu[k] * q[k];
             } else {
-                int h = d / 2;
+                /* the kernel pads d up to DMAX in {32, 64, 128, 256}: lanes 0-31 take k = s,
+                 * lanes 32-63 take k = DMAX/2 + s; products with k >= d are 0*0 and leave the
+                 * chain unchanged, so they are skipped here */
+                int dmax = d <= 32 ? 32 : d <= 64 ? 64 : d <= 128 ? 128 : 256;
+                int h = dmax / 2;
                 for (int s = 0; s < h; s++) {
-                    acc = fmaf(pu[s], q[s], acc);
-                    acc = fmaf(pu[h + s], q[h + s], acc);
+                    if (s < d)
+                        acc = fmaf(pu[s], q[s], acc);
+                    if (h + s < d)
+                        acc = fmaf(pu[h + s], q[h + s], acc);
                 }
             }
             scores[r * I + c] = acc;
