@@ -4,13 +4,13 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
 One "step" = one batch (6144 triples) through the hot path: the fused gather -> BPR loss ->
-per-row gradient sums -> TF1-semantics Adam (bpr_user_side + bpr_item_side), including the
+per-row gradient sums -> TF1-semantics Adam (bpr_step_fused, one launch per batch), including the
 per-epoch-chunk index build and the loss reduction that the library launches around them.
 The sampled index stream (bit-exact host sampler, seed 1) and the tables are resident in HBM
 when the timed region starts.  Prints ONE JSON line (rank 0).
 
 Extra objects in the line:
-  roofline      dominant kernel (bpr_user_side): algorithmic bytes per launch / its average
+  roofline      dominant kernel (bpr_step_fused): algorithmic bytes per launch / its average
                 duration from HIP events on the launch stream, against the 8 TB/s HBM peak
   cpu_baseline  the CPU oracle (oracle/crec_oracle.c, one core) on a bounded sample of the
                 same workload -- a reported baseline, not the target
@@ -116,20 +116,19 @@ def main():
         U, I = data.user_nums, data.item_nums
         # algorithmic bytes per launch (DESIGN.md "Algorithmic bytes"): SURVEY 8(d)'s 24d+12 per triple
         # split by which kernel owns the access, plus the tf1 Adam sweep 24*d*rows
-        alg = {"bpr_user_side": B * (16 * D + 12) + 24 * D * U, "bpr_item_side": B * 8 * D + 24 * D * I}
+        alg = {"bpr_step_fused": B * (24 * D + 12) + 24 * D * (U + I)}
         kern = {}
-        for name in ("bpr_user_side", "bpr_item_side", "bpr_index_batches", "bpr_row_words", "bpr_reduce_loss"):
-            ms, n = prof[name]
+        for name, (ms, n) in prof.items():
             if n:
                 kern[name] = {"avg_us": ms / n * 1e3, "launches": n}
-        dom = max(("bpr_user_side", "bpr_item_side"), key=lambda k: prof[k][0])
+        dom = "bpr_step_fused"
         avg_s = prof[dom][0] / prof[dom][1] * 1e-3
         ach = alg[dom] / avg_s / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg[dom],
                            "avg_launch_us": avg_s * 1e6,
                            "note": "tables+slots 7.5 MB: Infinity-Cache resident, HBM fraction is nominal"}
-        step_bytes = alg["bpr_user_side"] + alg["bpr_item_side"]
+        step_bytes = alg[dom]
         out["kernels"] = kern
         out["step_algorithmic_GBs"] = step_bytes / (dt / a.steps) / 1e9
 

@@ -104,7 +104,7 @@ class Context:
             raise CrecError(rc, self.lib.crec_last_error(self.h).decode())
 
     # ---- measurement ---------------------------------------------------------------------------
-    KERNELS = ("bpr_index_batches", "bpr_row_words", "bpr_user_side", "bpr_item_side", "bpr_reduce_loss", "eval_sweep",
+    KERNELS = ("bpr_index_batches", "bpr_step_fused", "bpr_user_side", "bpr_item_side", "bpr_reduce_loss", "eval_sweep",
                "eval_merge", "rank_metrics")
 
     def profile(self, on):

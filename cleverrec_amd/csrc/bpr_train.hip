@@ -6,24 +6,30 @@
 //
 // Per chunk of batches, one launch:
 //   bpr_index_batches  one workgroup per (batch, side): bitonic sort in LDS of (row, position)
-//                      keys -> unique rows, segment starts, occurrence records.  This is the
-//                      "unique + unsorted_segment_sum" bookkeeping of TF1's sparse Adam, done
-//                      once for the whole chunk and in batch position order, i-slices before
-//                      j-slices, so row sums are deterministic.
-//   bpr_row_words      (tf1 mode) per 32 table rows: {touched bitmap, rank of first} so the
-//                      dense sweep finds a row's segment with one 8-byte load.
-// Per batch, two launches (a step's row updates must not be seen by that step's gathers):
-//   bpr_user_side      one wave per user row: for every triple of that user gather q_i, q_j,
-//                      x = p.q_i - p.q_j, s = sigmoid(-x), loss term, contribution row
-//                      c_b = s*p_u (plain coalesced store), sum of dL/dp; then Adam on the row
-//                      in place.  P rows are read only by their own wave, so in place is safe.
-//   bpr_item_side      one wave per item row: sum of -/+ c_b over the row's i-/j-occurrences
-//                      plus reg*q; Adam in place.  Reads no other Q row.
+//                      keys -> unique rows, segment starts, occurrence records {u, i, j, pos}.
+//                      This is the "unique + unsorted_segment_sum" bookkeeping of TF1's sparse
+//                      Adam, done once for the whole chunk, in batch position order, i-slices
+//                      before j-slices, so every row sum has one fixed order (deterministic).
+//                      tf1 mode also writes row -> {segment start, length} for every table row.
+// Per batch:
+//   tf1 mode   ONE launch, bpr_step_fused: every row of P and Q moves every step (TF1 decays
+//              m, v and applies var -= lr_t*m/(sqrt(v)+eps) on all rows), so the step reads
+//              the tables from one buffer set and writes the other (ping-pong): no gather can
+//              see a row updated by the same step, and user-row and item-row waves run side by
+//              side.  An item wave recomputes s_b = sigmoid(-x_b) of its occurrences from
+//              p_u, q_i, q_j with the very instruction sequence the user wave uses, so both
+//              sides use bit-identical s_b.
+//   lazy mode  two launches in place: bpr_user_side (stores the contribution row c_b = s_b*p_u
+//              of each triple, plain coalesced stores, then Adam on the user's row) and
+//              bpr_item_side (sums -/+ c_b over the row's occurrences, Adam on the row).
+//              Rows are read only by their own wave inside a launch, so in place is safe.
 // Per chunk: bpr_reduce_loss sums the per-triple loss terms of each batch in a fixed order.
 //
-// A wave splits into G = 64/LPR groups of LPR lanes, each lane holding a float4 of a row
-// (LPR*4 >= d), so G occurrences are in flight per wave and every row access is one
-// coalesced 16-byte-per-lane load.  Dots reduce with xor-shuffles inside a group.
+// A wave owns one table row.  It splits into G = 64/LPR groups of LPR lanes, each lane holding
+// a float4 of a row (LPR*4 >= d): G occurrences are processed at once and every row access is
+// one coalesced 16-byte-per-lane load.  The wave fetches up to 64 occurrence records with one
+// coalesced load and hands them to its groups by cross-lane reads; row gathers of up to UNR
+// sub-iterations are issued before the first is consumed.  Dots reduce with DPP adds.
 //
 // Compiled with -ffp-contract=off: each fp32 multiply/add is rounded separately, like the
 // element-wise Eigen kernels TF1 runs (and like the CPU oracle), so the Adam arithmetic is
@@ -34,18 +40,19 @@ namespace {
 
 constexpr int PREP_THREADS = 1024;
 constexpr int MAX_B = 8192;
+constexpr int UNR = 4; // sub-iterations whose gathers are in flight together
 
 // ------------------------------------------------------------------------------------
 // index workspace layout for one chunk of nbc batches
 // ------------------------------------------------------------------------------------
 struct IndexWs {
-    int32_t *n_u, *n_q;       // [nbc] unique rows per batch
-    int32_t *u_rows, *u_seg;  // [nbc][B], [nbc][B+1]
-    int4 *u_occ;              // [nbc][B]   {i, j, position in batch, user row}
-    int32_t *q_rows, *q_seg;  // [nbc][2B], [nbc][2B+1]
-    int32_t *q_occ;           // [nbc][2B]  position | sign<<31  (sign 1 = the triple's j)
-    int2 *u_words, *q_words;  // [nbc][WU], [nbc][WI]  {bitmap of 32 rows, rank of the first}
-    int64_t B, WU, WI;
+    int32_t *n_u, *n_q;        // [nbc] unique rows per batch
+    int32_t *u_rows, *u_seg;   // [nbc][B], [nbc][B+1]
+    int4 *u_occ;               // [nbc][B]   {u, i, j, position in batch}
+    int32_t *q_rows, *q_seg;   // [nbc][2B], [nbc][2B+1]
+    int4 *q_occ;               // [nbc][2B]  {u, i, j, position | side<<31}  (side 1: row is the triple's j)
+    int2 *u_rowseg, *q_rowseg; // tf1 mode: [nbc][U], [nbc][I]  {segment start, length} of every table row
+    int64_t B, U, I;
     size_t bytes;
 };
 
@@ -55,8 +62,8 @@ IndexWs layout_index(void *base, int64_t nbc, int64_t B, int64_t U, int64_t I, b
 {
     IndexWs w{};
     w.B = B;
-    w.WU = dense ? crec_ceil_div(U, 32) : 0;
-    w.WI = dense ? crec_ceil_div(I, 32) : 0;
+    w.U = dense ? U : 0;
+    w.I = dense ? I : 0;
     size_t off = 0;
     auto take = [&](size_t bytes) {
         char *p = base ? (char *)base + off : nullptr;
@@ -70,9 +77,9 @@ IndexWs layout_index(void *base, int64_t nbc, int64_t B, int64_t U, int64_t I, b
     w.u_occ = (int4 *)take(sizeof(int4) * nbc * B);
     w.q_rows = (int32_t *)take(sizeof(int32_t) * nbc * 2 * B);
     w.q_seg = (int32_t *)take(sizeof(int32_t) * nbc * (2 * B + 1));
-    w.q_occ = (int32_t *)take(sizeof(int32_t) * nbc * 2 * B);
-    w.u_words = (int2 *)take(sizeof(int2) * nbc * w.WU);
-    w.q_words = (int2 *)take(sizeof(int2) * nbc * w.WI);
+    w.q_occ = (int4 *)take(sizeof(int4) * nbc * 2 * B);
+    w.u_rowseg = (int2 *)take(sizeof(int2) * nbc * w.U);
+    w.q_rowseg = (int2 *)take(sizeof(int2) * nbc * w.I);
     w.bytes = off;
     return w;
 }
@@ -112,6 +119,19 @@ __device__ inline int block_excl_scan(int v, int *wave_sums /* [PREP_THREADS/64 
     return wave_sums[wave] + incl - v;
 }
 
+__device__ inline int lower_bound_key(const unsigned long long *keys, int n, unsigned long long key)
+{
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (keys[mid] < key)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
 // ------------------------------------------------------------------------------------
 // bpr_index_batches: grid = 2*nbc workgroups; block b>>1 = batch, b&1 = side (0 user, 1 item)
 // ------------------------------------------------------------------------------------
@@ -136,11 +156,11 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
         if (k < n) {
             if (side == 0) {
                 key = ((unsigned long long)(uint32_t)u[t0 + k] << 32) | (uint32_t)k;
-            } else { // i-slices first, then j-slices: sign is the high payload bit
+            } else { // i-slices first, then j-slices: the side flag is the high payload bit
                 int pos = k < nb ? k : k - nb;
-                uint32_t sign = k < nb ? 0u : 1u;
-                int32_t row = sign ? j[t0 + pos] : i[t0 + pos];
-                key = ((unsigned long long)(uint32_t)row << 32) | (sign << 31) | (uint32_t)pos;
+                uint32_t sd = k < nb ? 0u : 1u;
+                int32_t row = sd ? j[t0 + pos] : i[t0 + pos];
+                key = ((unsigned long long)(uint32_t)row << 32) | (sd << 31) | (uint32_t)pos;
             }
         }
         keys[k] = key;
@@ -177,6 +197,7 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
 
     int32_t *rows_out = side ? w.q_rows + (int64_t)batch * 2 * B : w.u_rows + (int64_t)batch * B;
     int32_t *seg_out = side ? w.q_seg + (int64_t)batch * (2 * B + 1) : w.u_seg + (int64_t)batch * (B + 1);
+    int4 *occ_out = side ? w.q_occ + (int64_t)batch * 2 * B : w.u_occ + (int64_t)batch * B;
     for (int k = k0; k < k0 + per && k < n; ++k) {
         unsigned long long key = keys[k];
         uint32_t row = (uint32_t)(key >> 32);
@@ -185,76 +206,83 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
             seg_out[rank] = k;
             ++rank;
         }
-        uint32_t payload = (uint32_t)key;
-        if (side == 0) {
-            int pos = (int)payload;
-            w.u_occ[(int64_t)batch * B + k] = make_int4(i[t0 + pos], j[t0 + pos], pos, (int32_t)row);
-        } else {
-            w.q_occ[(int64_t)batch * 2 * B + k] = (int32_t)payload;
-        }
+        const uint32_t payload = (uint32_t)key;
+        const int pos = (int)(payload & 0x7fffffffu);
+        occ_out[k] = make_int4(u[t0 + pos], i[t0 + pos], j[t0 + pos], (int)payload);
     }
     if (tid == 0) {
         seg_out[total] = n;
         (side ? w.n_q : w.n_u)[batch] = total;
     }
-}
 
-// ------------------------------------------------------------------------------------
-// bpr_row_words (tf1 mode): grid = 2*nbc, one workgroup per (batch, side)
-// ------------------------------------------------------------------------------------
-__global__ void bpr_row_words(IndexWs w, int64_t U, int64_t I)
-{
-    const int batch = blockIdx.x >> 1, side = blockIdx.x & 1;
-    const int32_t *rows = side ? w.q_rows + (int64_t)batch * 2 * w.B : w.u_rows + (int64_t)batch * w.B;
-    const int n = (side ? w.n_q : w.n_u)[batch];
-    const int64_t W = side ? w.WI : w.WU;
-    int2 *words = side ? w.q_words + (int64_t)batch * W : w.u_words + (int64_t)batch * W;
-    (void)U;
-    (void)I;
-    for (int64_t wd = threadIdx.x; wd < W; wd += blockDim.x) {
-        const int64_t first = wd * 32;
-        int lo = 0, hi = n; // lower_bound(rows, first)
-        while (lo < hi) {
-            int mid = (lo + hi) >> 1;
-            if (rows[mid] < first)
-                lo = mid + 1;
-            else
-                hi = mid;
+    // tf1 mode: every table row's {segment start, length} by two binary searches in the sorted keys
+    const int64_t n_rows = side ? w.I : w.U;
+    if (n_rows > 0) {
+        int2 *rs = side ? w.q_rowseg + (int64_t)batch * w.I : w.u_rowseg + (int64_t)batch * w.U;
+        for (int64_t r = tid; r < n_rows; r += PREP_THREADS) {
+            const int a = lower_bound_key(keys, n, (unsigned long long)r << 32);
+            const int b = lower_bound_key(keys, n, (unsigned long long)(r + 1) << 32);
+            rs[r] = make_int2(a, b - a);
         }
-        uint32_t bits = 0;
-        for (int k = lo; k < n && rows[k] < first + 32; ++k)
-            bits |= 1u << (rows[k] - first);
-        words[wd] = make_int2((int)bits, lo);
     }
 }
 
 // ------------------------------------------------------------------------------------
-// shared pieces of the two row kernels
+// shared device pieces
 // ------------------------------------------------------------------------------------
 struct Hyper {
     float lr_t, beta1, beta2, eps, reg;
+};
+
+struct Tables { // one buffer set
+    float *P, *mP, *vP, *Q, *mQ, *vQ;
 };
 
 __device__ inline float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ inline void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
 __device__ inline float dot4(float4 a, float4 b) { return ((a.x * b.x + a.y * b.y) + a.z * b.z) + a.w * b.w; }
 
+template <int CTRL> __device__ inline float dpp_add(float v)
+{
+    // v + (v read through the DPP lane pattern CTRL); all lanes active
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+
+// all-reduce over the LPR lanes of a group; every lane ends with the bit-identical sum.
+// xor-1 / xor-2 inside quads, then mirror patterns (a quad, then an 8-lane half, already holds one
+// value, so a mirror is as good as an xor), then real cross-row shuffles above 16 lanes.
 template <int LPR> __device__ inline float group_sum(float v)
 {
-#pragma unroll
-    for (int off = LPR >> 1; off > 0; off >>= 1)
-        v += __shfl_xor(v, off, 64);
+    if (LPR >= 2)
+        v = dpp_add<0xB1>(v); // quad_perm [1,0,3,2]
+    if (LPR >= 4)
+        v = dpp_add<0x4E>(v); // quad_perm [2,3,0,1]
+    if (LPR >= 8)
+        v = dpp_add<0x141>(v); // row_half_mirror
+    if (LPR >= 16)
+        v = dpp_add<0x140>(v); // row_mirror
+    if (LPR >= 32)
+        v += __shfl_xor(v, 16, 64);
+    if (LPR >= 64)
+        v += __shfl_xor(v, 32, 64);
     return v;
 }
 
+// sum over the G groups of a wave (same lane position in each group)
 template <int LPR> __device__ inline float4 cross_group_sum(float4 g)
 {
 #pragma unroll
     for (int off = LPR; off < 64; off <<= 1) {
-        g.x += __shfl_xor(g.x, off, 64);
-        g.y += __shfl_xor(g.y, off, 64);
-        g.z += __shfl_xor(g.z, off, 64);
-        g.w += __shfl_xor(g.w, off, 64);
+        if (off == 1) {
+            g.x = dpp_add<0xB1>(g.x), g.y = dpp_add<0xB1>(g.y), g.z = dpp_add<0xB1>(g.z), g.w = dpp_add<0xB1>(g.w);
+        } else if (off == 2) {
+            g.x = dpp_add<0x4E>(g.x), g.y = dpp_add<0x4E>(g.y), g.z = dpp_add<0x4E>(g.z), g.w = dpp_add<0x4E>(g.w);
+        } else {
+            g.x += __shfl_xor(g.x, off, 64);
+            g.y += __shfl_xor(g.y, off, 64);
+            g.z += __shfl_xor(g.z, off, 64);
+            g.w += __shfl_xor(g.w, off, 64);
+        }
     }
     return g;
 }
@@ -291,150 +319,256 @@ __device__ inline void adam4(float4 &var, float4 &m, float4 &v, float4 g, bool t
     }
 }
 
-// wave -> (row, segment) for both modes
-template <bool DENSE>
-__device__ inline bool locate_row(int64_t wave_id, int64_t n_table_rows, const int32_t *n_rows, const int32_t *rows,
-                                  const int32_t *seg, const int2 *words, int64_t *row, int *s0, int *s1)
+__device__ inline int4 shfl4(int4 v, int src)
 {
-    if (DENSE) {
-        if (wave_id >= n_table_rows)
-            return false;
-        *row = wave_id;
-        int2 wd = words[wave_id >> 5];
-        uint32_t bits = (uint32_t)wd.x, bit = 1u << (wave_id & 31);
-        if (bits & bit) {
-            int rank = wd.y + __popc(bits & (bit - 1));
-            *s0 = seg[rank];
-            *s1 = seg[rank + 1];
-        } else {
-            *s0 = *s1 = 0;
-        }
-        return true;
-    }
-    if (wave_id >= *n_rows)
-        return false;
-    *row = rows[wave_id];
-    *s0 = seg[wave_id];
-    *s1 = seg[wave_id + 1];
-    return true;
+    return make_int4(__shfl(v.x, src, 64), __shfl(v.y, src, 64), __shfl(v.z, src, 64), __shfl(v.w, src, 64));
+}
+
+// x_b and s_b of one triple from the group's float4 slices: the ONE place this arithmetic lives,
+// so user-row and item-row waves agree bit for bit.
+template <int LPR> __device__ inline float triple_s(float4 p, float4 qi, float4 qj, float *x_out)
+{
+    const float di = group_sum<LPR>(dot4(p, qi));
+    const float dj = group_sum<LPR>(dot4(p, qj));
+    const float x = di - dj; // ui_scores - uj_scores (BPR.py:39-42)
+    *x_out = x;
+    return 1.0f / (1.0f + expf(x)); // sigmoid(-x) = -d softplus(-x)/dx
 }
 
 // ------------------------------------------------------------------------------------
-// bpr_user_side
+// one user row: sum over its triples of dL/dp, loss terms, (lazy mode) contribution rows
 // ------------------------------------------------------------------------------------
-template <int LPR, bool DENSE>
-__global__ __launch_bounds__(256) void bpr_user_side(float *__restrict__ P, float *__restrict__ mP,
-                                                     float *__restrict__ vP, const float *__restrict__ Q, int d,
-                                                     int64_t U, const int32_t *__restrict__ n_rows,
-                                                     const int32_t *__restrict__ rows, const int32_t *__restrict__ seg,
-                                                     const int4 *__restrict__ occ, const int2 *__restrict__ words,
-                                                     float *__restrict__ contrib, float *__restrict__ loss_triple,
-                                                     Hyper h)
+template <int LPR, bool STORE_CONTRIB>
+__device__ inline float4 user_row_grad(float4 p, const float *__restrict__ Q, int d, const int4 *__restrict__ occ,
+                                       int s0, int n, float *__restrict__ contrib, float *__restrict__ loss_triple,
+                                       const Hyper &h)
 {
     constexpr int G = 64 / LPR;
-    const int lane = threadIdx.x & 63;
-    const int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    int64_t r;
-    int s0, s1;
-    if (!locate_row<DENSE>(wave_id, U, n_rows, rows, seg, words, &r, &s0, &s1))
-        return;
-    const int g = lane / LPR, l = lane % LPR;
+    const int lane = threadIdx.x & 63, g = lane / LPR, l = lane % LPR;
     const bool act = 4 * l < d;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int64_t ro = r * d + 4 * l;
-    float4 p = act ? ld4(P + ro) : zero;
-    float4 m = zero, v = zero;
-    if (g == 0 && act) {
-        m = ld4(mP + ro);
-        v = ld4(vP + ro);
-    }
     const float np = group_sum<LPR>(dot4(p, p));
     float4 acc = zero;
-    for (int base = s0; base < s1; base += G) {
-        const int k = base + g;
-        const bool has = k < s1;
-        int4 rec = has ? occ[k] : make_int4(0, 0, 0, 0);
-        float4 qi = zero, qj = zero;
-        if (has && act) {
-            qi = ld4(Q + (int64_t)rec.x * d + 4 * l);
-            qj = ld4(Q + (int64_t)rec.y * d + 4 * l);
-        }
-        const float di = group_sum<LPR>(dot4(p, qi));
-        const float dj = group_sum<LPR>(dot4(p, qj));
-        const float ni = group_sum<LPR>(dot4(qi, qi));
-        const float nj = group_sum<LPR>(dot4(qj, qj));
-        const float x = di - dj;
-        const float s = 1.0f / (1.0f + expf(x)); // sigmoid(-x)
-        if (has) {
-            if (l == 0)
-                loss_triple[rec.z] = tf_softplus(-x) + h.reg * ((0.5f * np + 0.5f * ni) + 0.5f * nj);
-            if (act) {
-                st4(contrib + (int64_t)rec.z * d + 4 * l, make_float4(s * p.x, s * p.y, s * p.z, s * p.w));
-                const float ns = -s;
-                acc.x = acc.x + (ns * (qi.x - qj.x) + h.reg * p.x);
-                acc.y = acc.y + (ns * (qi.y - qj.y) + h.reg * p.y);
-                acc.z = acc.z + (ns * (qi.z - qj.z) + h.reg * p.z);
-                acc.w = acc.w + (ns * (qi.w - qj.w) + h.reg * p.w);
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const int nc = (n - c0) < 64 ? (n - c0) : 64;
+        const int4 mine = lane < nc ? occ[s0 + c0 + lane] : make_int4(0, 0, 0, 0);
+        const int n_sub = (nc + G - 1) / G;
+        for (int t0 = 0; t0 < n_sub; t0 += UNR) {
+            int4 rec[UNR];
+            float4 qi[UNR], qj[UNR];
+            bool has[UNR];
+#pragma unroll
+            for (int t = 0; t < UNR; ++t) {
+                const int k = (t0 + t) * G + g;
+                rec[t] = shfl4(mine, k & 63);
+                has[t] = (t0 + t) < n_sub && k < nc;
+                qi[t] = qj[t] = zero;
+                if (has[t] && act) {
+                    qi[t] = ld4(Q + (int64_t)rec[t].y * d + 4 * l);
+                    qj[t] = ld4(Q + (int64_t)rec[t].z * d + 4 * l);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < UNR; ++t) {
+                if ((t0 + t) >= n_sub)
+                    break; // wave-uniform
+                float x;
+                const float s = triple_s<LPR>(p, qi[t], qj[t], &x);
+                const float ni = group_sum<LPR>(dot4(qi[t], qi[t]));
+                const float nj = group_sum<LPR>(dot4(qj[t], qj[t]));
+                if (has[t]) {
+                    const int pos = rec[t].w & 0x7fffffff;
+                    if (l == 0)
+                        loss_triple[pos] = tf_softplus(-x) + h.reg * ((0.5f * np + 0.5f * ni) + 0.5f * nj);
+                    if (act) {
+                        if (STORE_CONTRIB)
+                            st4(contrib + (int64_t)pos * d + 4 * l, make_float4(s * p.x, s * p.y, s * p.z, s * p.w));
+                        const float ns = -s;
+                        acc.x = acc.x + (ns * (qi[t].x - qj[t].x) + h.reg * p.x);
+                        acc.y = acc.y + (ns * (qi[t].y - qj[t].y) + h.reg * p.y);
+                        acc.z = acc.z + (ns * (qi[t].z - qj[t].z) + h.reg * p.z);
+                        acc.w = acc.w + (ns * (qi[t].w - qj[t].w) + h.reg * p.w);
+                    }
+                }
             }
         }
     }
-    acc = cross_group_sum<LPR>(acc);
-    if (g == 0 && act) {
-        adam4(p, m, v, acc, s1 > s0, h);
-        st4(P + ro, p);
-        st4(mP + ro, m);
-        st4(vP + ro, v);
-    }
+    return cross_group_sum<LPR>(acc);
 }
 
 // ------------------------------------------------------------------------------------
-// bpr_item_side
+// one item row: sum over its occurrences of dL/dq.
+//   FROM_CONTRIB: c_b is read back (lazy mode).  Otherwise s_b is recomputed from the
+//   read-side tables (fused tf1 step).
 // ------------------------------------------------------------------------------------
-template <int LPR, bool DENSE>
-__global__ __launch_bounds__(256) void bpr_item_side(float *__restrict__ Q, float *__restrict__ mQ,
-                                                     float *__restrict__ vQ, int d, int64_t I,
-                                                     const int32_t *__restrict__ n_rows,
-                                                     const int32_t *__restrict__ rows, const int32_t *__restrict__ seg,
-                                                     const int32_t *__restrict__ occ, const int2 *__restrict__ words,
-                                                     const float *__restrict__ contrib, Hyper h)
+template <int LPR, bool FROM_CONTRIB>
+__device__ inline float4 item_row_grad(float4 q, int32_t row, const float *__restrict__ P, const float *__restrict__ Q,
+                                       int d, const int4 *__restrict__ occ, int s0, int n,
+                                       const float *__restrict__ contrib, const Hyper &h)
 {
     constexpr int G = 64 / LPR;
+    const int lane = threadIdx.x & 63, g = lane / LPR, l = lane % LPR;
+    const bool act = 4 * l < d;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 acc = zero;
+    (void)row;
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const int nc = (n - c0) < 64 ? (n - c0) : 64;
+        const int4 mine = lane < nc ? occ[s0 + c0 + lane] : make_int4(0, 0, 0, 0);
+        const int n_sub = (nc + G - 1) / G;
+        for (int t0 = 0; t0 < n_sub; t0 += UNR) {
+            int4 rec[UNR];
+            float4 a[UNR], b[UNR]; // FROM_CONTRIB: a = c_b.  else a = p_u, b = the triple's other item row
+            bool has[UNR];
+#pragma unroll
+            for (int t = 0; t < UNR; ++t) {
+                const int k = (t0 + t) * G + g;
+                rec[t] = shfl4(mine, k & 63);
+                has[t] = (t0 + t) < n_sub && k < nc;
+                a[t] = b[t] = zero;
+                if (has[t] && act) {
+                    if (FROM_CONTRIB) {
+                        a[t] = ld4(contrib + (int64_t)(rec[t].w & 0x7fffffff) * d + 4 * l);
+                    } else {
+                        a[t] = ld4(P + (int64_t)rec[t].x * d + 4 * l);
+                        const int other = rec[t].w < 0 ? rec[t].y : rec[t].z;
+                        b[t] = ld4(Q + (int64_t)other * d + 4 * l);
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < UNR; ++t) {
+                if ((t0 + t) >= n_sub)
+                    break; // wave-uniform
+                float4 c = a[t];
+                const bool is_j = rec[t].w < 0;
+                if (!FROM_CONTRIB) {
+                    // operands selected, not branched: the cross-lane sums below run with every lane active
+                    const float4 qi = is_j ? b[t] : q, qj = is_j ? q : b[t];
+                    float x;
+                    const float s = triple_s<LPR>(a[t], qi, qj, &x);
+                    c = make_float4(s * a[t].x, s * a[t].y, s * a[t].z, s * a[t].w);
+                }
+                if (has[t] && act) {
+                    const float sg = is_j ? 1.0f : -1.0f; // j-slices get +s*p, i-slices -s*p
+                    acc.x = acc.x + (sg * c.x + h.reg * q.x);
+                    acc.y = acc.y + (sg * c.y + h.reg * q.y);
+                    acc.z = acc.z + (sg * c.z + h.reg * q.z);
+                    acc.w = acc.w + (sg * c.w + h.reg * q.w);
+                }
+            }
+        }
+    }
+    return cross_group_sum<LPR>(acc);
+}
+
+// ------------------------------------------------------------------------------------
+// tf1 mode: the whole step in one launch, tables read from `src`, written to `dst`
+// ------------------------------------------------------------------------------------
+template <int LPR>
+__global__ __launch_bounds__(256) void bpr_step_fused(Tables src, Tables dst, int d, int64_t U, int64_t I,
+                                                      const int2 *__restrict__ u_rowseg,
+                                                      const int4 *__restrict__ u_occ,
+                                                      const int2 *__restrict__ q_rowseg,
+                                                      const int4 *__restrict__ q_occ, float *__restrict__ loss_triple,
+                                                      Hyper h)
+{
     const int lane = threadIdx.x & 63;
     const int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    int64_t r;
-    int s0, s1;
-    if (!locate_row<DENSE>(wave_id, I, n_rows, rows, seg, words, &r, &s0, &s1))
+    if (wave_id >= U + I)
         return;
+    const bool is_user = wave_id < U;
+    const int64_t r = is_user ? wave_id : wave_id - U;
     const int g = lane / LPR, l = lane % LPR;
     const bool act = 4 * l < d;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     const int64_t ro = r * d + 4 * l;
-    float4 q = act ? ld4(Q + ro) : zero;
+    const int2 rs = is_user ? u_rowseg[r] : q_rowseg[r];
+    const float *sv = is_user ? src.P : src.Q, *sm = is_user ? src.mP : src.mQ, *sw = is_user ? src.vP : src.vQ;
+    float4 var = act ? ld4(sv + ro) : zero;
     float4 m = zero, v = zero;
     if (g == 0 && act) {
-        m = ld4(mQ + ro);
-        v = ld4(vQ + ro);
+        m = ld4(sm + ro);
+        v = ld4(sw + ro);
     }
-    float4 acc = zero;
-    for (int base = s0; base < s1; base += G) {
-        const int k = base + g;
-        if (k < s1 && act) {
-            const int32_t rec = occ[k];
-            const int pos = rec & 0x7fffffff;
-            float4 c = ld4(contrib + (int64_t)pos * d + 4 * l);
-            const float sg = rec < 0 ? 1.0f : -1.0f; // j-slices get +s*p, i-slices -s*p
-            acc.x = acc.x + (sg * c.x + h.reg * q.x);
-            acc.y = acc.y + (sg * c.y + h.reg * q.y);
-            acc.z = acc.z + (sg * c.z + h.reg * q.z);
-            acc.w = acc.w + (sg * c.w + h.reg * q.w);
-        }
+    float4 grad = zero;
+    if (rs.y > 0) { // wave-uniform
+        if (is_user)
+            grad = user_row_grad<LPR, false>(var, src.Q, d, u_occ, rs.x, rs.y, nullptr, loss_triple, h);
+        else
+            grad = item_row_grad<LPR, false>(var, (int32_t)r, src.P, src.Q, d, q_occ, rs.x, rs.y, nullptr, h);
     }
-    acc = cross_group_sum<LPR>(acc);
     if (g == 0 && act) {
-        adam4(q, m, v, acc, s1 > s0, h);
-        st4(Q + ro, q);
-        st4(mQ + ro, m);
-        st4(vQ + ro, v);
+        adam4(var, m, v, grad, rs.y > 0, h);
+        float *dv = is_user ? dst.P : dst.Q, *dm = is_user ? dst.mP : dst.mQ, *dw = is_user ? dst.vP : dst.vQ;
+        st4(dv + ro, var);
+        st4(dm + ro, m);
+        st4(dw + ro, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// lazy mode: touched rows only, in place, two launches
+// ------------------------------------------------------------------------------------
+template <int LPR>
+__global__ __launch_bounds__(256) void bpr_user_side(Tables t, int d, const int32_t *__restrict__ n_rows,
+                                                     const int32_t *__restrict__ rows, const int32_t *__restrict__ seg,
+                                                     const int4 *__restrict__ occ, float *__restrict__ contrib,
+                                                     float *__restrict__ loss_triple, Hyper h)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (wave_id >= *n_rows)
+        return;
+    const int64_t r = rows[wave_id];
+    const int s0 = seg[wave_id], n = seg[wave_id + 1] - s0;
+    const int g = lane / LPR, l = lane % LPR;
+    const bool act = 4 * l < d;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t ro = r * d + 4 * l;
+    float4 p = act ? ld4(t.P + ro) : zero;
+    float4 m = zero, v = zero;
+    if (g == 0 && act) {
+        m = ld4(t.mP + ro);
+        v = ld4(t.vP + ro);
+    }
+    const float4 grad = user_row_grad<LPR, true>(p, t.Q, d, occ, s0, n, contrib, loss_triple, h);
+    if (g == 0 && act) {
+        adam4(p, m, v, grad, true, h);
+        st4(t.P + ro, p);
+        st4(t.mP + ro, m);
+        st4(t.vP + ro, v);
+    }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void bpr_item_side(Tables t, int d, const int32_t *__restrict__ n_rows,
+                                                     const int32_t *__restrict__ rows, const int32_t *__restrict__ seg,
+                                                     const int4 *__restrict__ occ, const float *__restrict__ contrib,
+                                                     Hyper h)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (wave_id >= *n_rows)
+        return;
+    const int64_t r = rows[wave_id];
+    const int s0 = seg[wave_id], n = seg[wave_id + 1] - s0;
+    const int g = lane / LPR, l = lane % LPR;
+    const bool act = 4 * l < d;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t ro = r * d + 4 * l;
+    float4 q = act ? ld4(t.Q + ro) : zero;
+    float4 m = zero, v = zero;
+    if (g == 0 && act) {
+        m = ld4(t.mQ + ro);
+        v = ld4(t.vQ + ro);
+    }
+    const float4 grad = item_row_grad<LPR, true>(q, (int32_t)r, nullptr, nullptr, d, occ, s0, n, contrib, h);
+    if (g == 0 && act) {
+        adam4(q, m, v, grad, true, h);
+        st4(t.Q + ro, q);
+        st4(t.mQ + ro, m);
+        st4(t.vQ + ro, v);
     }
 }
 
@@ -464,26 +598,44 @@ __global__ __launch_bounds__(256) void bpr_reduce_loss(const float *__restrict__
 // ------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------
-template <int LPR, bool DENSE>
-void launch_step(crec_ctx *ctx, const crec_bpr_tables &t, const IndexWs &w, int64_t b, float *contrib,
-                 float *loss_triple, const Hyper &h, int32_t B, hipStream_t st)
+struct StepArgs {
+    crec_ctx *ctx;
+    Tables cur, other; // tf1: read `cur`, write `other`.  lazy: `cur` in place.
+    int d;
+    int64_t U, I;
+    int32_t B;
+    float *contrib, *loss_triple;
+    Hyper h;
+    hipStream_t st;
+};
+
+template <int LPR> void launch_fused(const StepArgs &a, const IndexWs &w, int64_t b)
 {
-    const int64_t u_waves = DENSE ? t.U : (t.U < B ? t.U : B);
-    const int64_t q_waves = DENSE ? t.I : (t.I < 2 * (int64_t)B ? t.I : 2 * (int64_t)B);
-    crec_prof_begin(ctx, CREC_K_USER_SIDE, st);
-    hipLaunchKernelGGL((bpr_user_side<LPR, DENSE>), dim3((unsigned)crec_ceil_div(u_waves, 4)), dim3(256), 0, st, t.P,
-                       t.mP, t.vP, t.Q, t.d, t.U, w.n_u + b, w.u_rows + b * w.B, w.u_seg + b * (w.B + 1),
-                       w.u_occ + b * w.B, w.u_words + b * w.WU, contrib, loss_triple, h);
-    crec_prof_end(ctx, st);
-    crec_prof_begin(ctx, CREC_K_ITEM_SIDE, st);
-    hipLaunchKernelGGL((bpr_item_side<LPR, DENSE>), dim3((unsigned)crec_ceil_div(q_waves, 4)), dim3(256), 0, st, t.Q,
-                       t.mQ, t.vQ, t.d, t.I, w.n_q + b, w.q_rows + b * 2 * w.B, w.q_seg + b * (2 * w.B + 1),
-                       w.q_occ + b * 2 * w.B, w.q_words + b * w.WI, contrib, h);
-    crec_prof_end(ctx, st);
+    const int64_t waves = a.U + a.I;
+    crec_prof_begin(a.ctx, CREC_K_STEP_FUSED, a.st);
+    hipLaunchKernelGGL((bpr_step_fused<LPR>), dim3((unsigned)crec_ceil_div(waves, 4)), dim3(256), 0, a.st, a.cur, a.other,
+                       a.d, a.U, a.I, w.u_rowseg + b * w.U, w.u_occ + b * w.B, w.q_rowseg + b * w.I,
+                       w.q_occ + b * 2 * w.B, a.loss_triple, a.h);
+    crec_prof_end(a.ctx, a.st);
 }
 
-using StepFn = void (*)(crec_ctx *, const crec_bpr_tables &, const IndexWs &, int64_t, float *, float *, const Hyper &,
-                        int32_t, hipStream_t);
+template <int LPR> void launch_lazy(const StepArgs &a, const IndexWs &w, int64_t b)
+{
+    const int64_t u_waves = a.U < a.B ? a.U : a.B;
+    const int64_t q_waves = a.I < 2 * (int64_t)a.B ? a.I : 2 * (int64_t)a.B;
+    crec_prof_begin(a.ctx, CREC_K_USER_SIDE, a.st);
+    hipLaunchKernelGGL((bpr_user_side<LPR>), dim3((unsigned)crec_ceil_div(u_waves, 4)), dim3(256), 0, a.st, a.cur, a.d,
+                       w.n_u + b, w.u_rows + b * w.B, w.u_seg + b * (w.B + 1), w.u_occ + b * w.B, a.contrib,
+                       a.loss_triple, a.h);
+    crec_prof_end(a.ctx, a.st);
+    crec_prof_begin(a.ctx, CREC_K_ITEM_SIDE, a.st);
+    hipLaunchKernelGGL((bpr_item_side<LPR>), dim3((unsigned)crec_ceil_div(q_waves, 4)), dim3(256), 0, a.st, a.cur, a.d,
+                       w.n_q + b, w.q_rows + b * 2 * w.B, w.q_seg + b * (2 * w.B + 1), w.q_occ + b * 2 * w.B,
+                       (const float *)a.contrib, a.h);
+    crec_prof_end(a.ctx, a.st);
+}
+
+using StepFn = void (*)(const StepArgs &, const IndexWs &, int64_t);
 
 StepFn pick_step(int d, bool dense)
 {
@@ -492,7 +644,7 @@ StepFn pick_step(int d, bool dense)
         lpr <<= 1;
 #define CREC_PICK(L) \
     case L:          \
-        return dense ? launch_step<L, true> : launch_step<L, false>;
+        return dense ? launch_fused<L> : launch_lazy<L>;
     switch (lpr) {
         CREC_PICK(1)
         CREC_PICK(2)
@@ -540,10 +692,30 @@ extern "C" int crec_bpr_train_epoch(crec_ctx *ctx, const crec_bpr_tables *t, cre
     chunk = chunk < 1 ? 1 : (chunk > nb ? nb : chunk);
     if (int rc = crec_reserve(ctx, &ctx->idx_ws, layout_index(nullptr, chunk, B, t->U, t->I, dense).bytes))
         return rc;
-    if (int rc = crec_reserve(ctx, &ctx->contrib, sizeof(float) * (size_t)B * t->d))
-        return rc;
     if (int rc = crec_reserve(ctx, &ctx->loss_ws, sizeof(float) * (size_t)chunk * B))
         return rc;
+
+    StepArgs a{};
+    a.ctx = ctx;
+    a.cur = Tables{t->P, t->mP, t->vP, t->Q, t->mQ, t->vQ};
+    a.d = t->d;
+    a.U = t->U;
+    a.I = t->I;
+    a.B = B;
+    a.st = st;
+    const size_t bytesP = sizeof(float) * (size_t)t->U * t->d, bytesQ = sizeof(float) * (size_t)t->I * t->d;
+    if (dense) { // the second buffer set of the ping-pong
+        const size_t aP = align_up(bytesP, 256), aQ = align_up(bytesQ, 256);
+        if (int rc = crec_reserve(ctx, &ctx->shadow, 3 * aP + 3 * aQ))
+            return rc;
+        char *s = (char *)ctx->shadow.ptr;
+        a.other = Tables{(float *)s, (float *)(s + aP), (float *)(s + 2 * aP), (float *)(s + 3 * aP),
+                         (float *)(s + 3 * aP + aQ), (float *)(s + 3 * aP + 2 * aQ)};
+    } else {
+        if (int rc = crec_reserve(ctx, &ctx->contrib, sizeof(float) * (size_t)B * t->d))
+            return rc;
+        a.contrib = (float *)ctx->contrib.ptr;
+    }
 
     // dynamic LDS of the index kernel: padded key array + scan scratch
     int n_pad = 64;
@@ -553,6 +725,7 @@ extern "C" int crec_bpr_train_epoch(crec_ctx *ctx, const crec_bpr_tables *t, cre
     CREC_HIP(ctx, hipFuncSetAttribute((const void *)bpr_index_batches, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds));
 
+    bool in_shadow = false; // tf1: which buffer set holds the current tables
     for (int64_t b0 = 0; b0 < nb; b0 += chunk) {
         const int64_t nbc = (nb - b0) < chunk ? (nb - b0) : chunk;
         const int64_t t0 = b0 * B, n_chunk = (N - t0) < nbc * B ? (N - t0) : nbc * B;
@@ -561,20 +734,21 @@ extern "C" int crec_bpr_train_epoch(crec_ctx *ctx, const crec_bpr_tables *t, cre
         hipLaunchKernelGGL(bpr_index_batches, dim3((unsigned)(2 * nbc)), dim3(PREP_THREADS), lds, st, u + t0, i + t0,
                            j + t0, n_chunk, B, w);
         crec_prof_end(ctx, st);
-        if (dense) {
-            crec_prof_begin(ctx, CREC_K_WORDS, st);
-            hipLaunchKernelGGL(bpr_row_words, dim3((unsigned)(2 * nbc)), dim3(256), 0, st, w, t->U, t->I);
-            crec_prof_end(ctx, st);
-        }
         for (int64_t b = 0; b < nbc; ++b) {
-            Hyper h;
             // lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t) with fp32 running powers (TF1 _prepare/_finish)
-            h.lr_t = (opt->lr * sqrtf(1.0f - opt->beta2_power)) / (1.0f - opt->beta1_power);
-            h.beta1 = opt->beta1;
-            h.beta2 = opt->beta2;
-            h.eps = opt->eps;
-            h.reg = opt->reg;
-            step(ctx, *t, w, b, (float *)ctx->contrib.ptr, (float *)ctx->loss_ws.ptr + b * B, h, B, st);
+            a.h.lr_t = (opt->lr * sqrtf(1.0f - opt->beta2_power)) / (1.0f - opt->beta1_power);
+            a.h.beta1 = opt->beta1;
+            a.h.beta2 = opt->beta2;
+            a.h.eps = opt->eps;
+            a.h.reg = opt->reg;
+            a.loss_triple = (float *)ctx->loss_ws.ptr + b * B;
+            step(a, w, b);
+            if (dense) {
+                Tables tmp = a.cur;
+                a.cur = a.other;
+                a.other = tmp;
+                in_shadow = !in_shadow;
+            }
             opt->beta1_power = opt->beta1_power * opt->beta1;
             opt->beta2_power = opt->beta2_power * opt->beta2;
             opt->step += 1;
@@ -586,6 +760,15 @@ extern "C" int crec_bpr_train_epoch(crec_ctx *ctx, const crec_bpr_tables *t, cre
         CREC_HIP(ctx, hipGetLastError());
         if (int rc = crec_prof_flush(ctx, st))
             return rc;
+    }
+    if (in_shadow) { // an odd number of steps: bring the result home to the caller's buffers
+        const Tables &s = a.cur;
+        CREC_HIP(ctx, hipMemcpyAsync(t->P, s.P, bytesP, hipMemcpyDeviceToDevice, st));
+        CREC_HIP(ctx, hipMemcpyAsync(t->mP, s.mP, bytesP, hipMemcpyDeviceToDevice, st));
+        CREC_HIP(ctx, hipMemcpyAsync(t->vP, s.vP, bytesP, hipMemcpyDeviceToDevice, st));
+        CREC_HIP(ctx, hipMemcpyAsync(t->Q, s.Q, bytesQ, hipMemcpyDeviceToDevice, st));
+        CREC_HIP(ctx, hipMemcpyAsync(t->mQ, s.mQ, bytesQ, hipMemcpyDeviceToDevice, st));
+        CREC_HIP(ctx, hipMemcpyAsync(t->vQ, s.vQ, bytesQ, hipMemcpyDeviceToDevice, st));
     }
     return CREC_OK;
 }

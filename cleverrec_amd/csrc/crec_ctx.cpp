@@ -153,7 +153,7 @@ void crec_ctx_destroy(crec_ctx *ctx)
         (void)hipSetDevice(ctx->device);
         (void)hipDeviceSynchronize();
         crec_devbuf *bufs[] = {&ctx->idx_ws, &ctx->contrib, &ctx->loss_ws, &ctx->lr_table,
-                               &ctx->misc,   &ctx->eval_ws, &ctx->ks_dev};
+                               &ctx->misc,   &ctx->eval_ws, &ctx->ks_dev, &ctx->shadow};
         for (crec_devbuf *b : bufs)
             if (b->ptr)
                 (void)hipFree(b->ptr);

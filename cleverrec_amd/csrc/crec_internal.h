@@ -27,7 +27,7 @@ struct crec_devbuf {
 // Optional per-kernel timing with HIP events on the launch stream (crec_profile_*).
 enum crec_kernel_class {
     CREC_K_INDEX = 0,
-    CREC_K_WORDS,
+    CREC_K_STEP_FUSED,
     CREC_K_USER_SIDE,
     CREC_K_ITEM_SIDE,
     CREC_K_REDUCE_LOSS,
@@ -56,7 +56,8 @@ struct crec_ctx {
     crec_mt19937 rng;
     // BPR training workspace (bpr_train.hip)
     crec_devbuf idx_ws;   // per-batch inverted indices of one chunk of batches
-    crec_devbuf contrib;  // [B, d] per-triple contribution rows s_b * p_u
+    crec_devbuf contrib;  // [B, d] per-triple contribution rows s_b * p_u (lazy mode)
+    crec_devbuf shadow;   // second buffer set of the tf1-mode ping-pong: P, mP, vP, Q, mQ, vQ
     crec_devbuf loss_ws;  // per-triple loss terms of one chunk
     crec_devbuf lr_table; // per-step lr_t of one chunk
     crec_devbuf misc;     // small counters
