@@ -40,7 +40,7 @@ namespace {
 
 constexpr int PREP_THREADS = 1024;
 constexpr int MAX_B = 8192;
-constexpr int UNR = 4; // sub-iterations whose gathers are in flight together
+constexpr int UNR = 2; // sub-iterations whose gathers are in flight together
 
 // ------------------------------------------------------------------------------------
 // index workspace layout for one chunk of nbc batches
@@ -298,8 +298,8 @@ __device__ inline float tf_softplus(float z)
     return log1pf(expf(z));
 }
 
-// TF1 Adam on one float4 of a row.  touched == false: the g = 0 sweep of a row the batch
-// does not index (m, v still decay and var still moves: _apply_sparse_shared).
+// TF1 Adam on one float4 of a row.  touched == false: the g = 0 sweep of a row the batch does not
+// index (m, v still decay and var still moves: _apply_sparse_shared).
 __device__ inline void adam4(float4 &var, float4 &m, float4 &v, float4 g, bool touched, const Hyper &h)
 {
     const float omb1 = 1.0f - h.beta1, omb2 = 1.0f - h.beta2;
@@ -323,6 +323,22 @@ __device__ inline int4 shfl4(int4 v, int src)
 {
     return make_int4(__shfl(v.x, src, 64), __shfl(v.y, src, 64), __shfl(v.z, src, 64), __shfl(v.w, src, 64));
 }
+__device__ inline float4 shfl4f(float4 v, int src)
+{
+    return make_float4(__shfl(v.x, src, 64), __shfl(v.y, src, 64), __shfl(v.z, src, 64), __shfl(v.w, src, 64));
+}
+__device__ inline float4 shfl4f_xor(float4 v, int mask)
+{
+    return make_float4(__shfl_xor(v.x, mask, 64), __shfl_xor(v.y, mask, 64), __shfl_xor(v.z, mask, 64),
+                       __shfl_xor(v.w, mask, 64));
+}
+__device__ inline void add4(float4 &a, float4 b)
+{
+    a.x = a.x + b.x;
+    a.y = a.y + b.y;
+    a.z = a.z + b.z;
+    a.w = a.w + b.w;
+}
 
 // x_b and s_b of one triple from the group's float4 slices: the ONE place this arithmetic lives,
 // so user-row and item-row waves agree bit for bit.
@@ -336,255 +352,348 @@ template <int LPR> __device__ inline float triple_s(float4 p, float4 qi, float4 
 }
 
 // ------------------------------------------------------------------------------------
-// one user row: sum over its triples of dL/dp, loss terms, (lazy mode) contribution rows
+// A wave owns R = min(G, 4) consecutive table rows ("slots"), one per lane group: group g holds
+// slot g's row, m and v slices as float4s (every row byte is loaded and stored exactly once, all
+// lanes busy in the Adam arithmetic).  The occurrences of consecutive rows are consecutive in the
+// sorted occurrence list, so the wave walks ONE contiguous range of records, G at a time: the
+// group that draws occurrence k finds its slot from the slots' segment ends, borrows that slot's
+// row slice with a cross-lane read, gathers the other rows, and adds the result into a per-slot
+// accumulator.  A reduce-scatter over the groups then hands slot g's gradient to group g.
 // ------------------------------------------------------------------------------------
-template <int LPR, bool STORE_CONTRIB>
-__device__ inline float4 user_row_grad(float4 p, const float *__restrict__ Q, int d, const int4 *__restrict__ occ,
-                                       int s0, int n, float *__restrict__ contrib, float *__restrict__ loss_triple,
-                                       const Hyper &h)
+template <int LPR> struct Geo {
+    static constexpr int G = 64 / LPR;
+    static constexpr int R = G < 4 ? G : 4;
+};
+
+struct Slot { // per lane: the slot of this lane's group (valid when g < R and row >= 0)
+    int64_t row;
+    int start, cnt;
+};
+
+// sum over groups of acc[s], delivered to group s (slot owner); other groups' return value is unused
+template <int LPR> __device__ inline float4 reduce_to_owner(float4 (&acc)[Geo<LPR>::R])
 {
-    constexpr int G = 64 / LPR;
-    const int lane = threadIdx.x & 63, g = lane / LPR, l = lane % LPR;
-    const bool act = 4 * l < d;
+    constexpr int G = Geo<LPR>::G, R = Geo<LPR>::R;
+    const int g = (threadIdx.x & 63) / LPR;
+    if (G == 1)
+        return acc[0];
+    if (G == 2) { // partner = other group: keep my slot, add the partner's partial of it
+        const float4 give = g == 0 ? acc[1] : acc[0];
+        float4 mine = g == 0 ? acc[0] : acc[1];
+        add4(mine, shfl4f_xor(give, LPR));
+        return mine;
+    }
+    if (G == 4) {
+        // step 1, partner g^2: keep the slot pair {g&2, (g&2)+1}, hand over the other pair
+        const bool hi = (g & 2) != 0;
+        float4 k0 = hi ? acc[2] : acc[0], k1 = hi ? acc[3] : acc[1];
+        const float4 s0 = hi ? acc[0] : acc[2], s1 = hi ? acc[1] : acc[3];
+        add4(k0, shfl4f_xor(s0, 2 * LPR));
+        add4(k1, shfl4f_xor(s1, 2 * LPR));
+        // step 2, partner g^1: keep slot g, hand over the pair's other slot
+        const bool odd = (g & 1) != 0;
+        float4 mine = odd ? k1 : k0;
+        const float4 give = odd ? k0 : k1;
+        add4(mine, shfl4f_xor(give, LPR));
+        return mine;
+    }
+    // G > 4 (d < 64): all-reduce every slot over all groups, then pick
+    float4 out = acc[0];
+#pragma unroll
+    for (int s = 0; s < R; ++s) {
+        float4 a = acc[s];
+#pragma unroll
+        for (int off = LPR; off < 64; off <<= 1)
+            add4(a, shfl4f_xor(a, off));
+        if (g == s)
+            out = a;
+    }
+    return out;
+}
+
+// MODE 0: user rows (gathers q_i, q_j; stores x_b; lazy mode also stores c_b = s_b * p_u)
+// MODE 1: item rows, fused step (gathers p_u and the triple's other item row; recomputes s_b)
+// MODE 2: item rows, lazy mode (reads c_b back)
+//
+// One "trip" = UNR sub-iterations of G occurrences.  Trips are software-pipelined two deep: the
+// gathers of trip n+1 are issued before trip n is consumed, so the loop runs at the pace of the
+// arithmetic, not of a memory round trip per trip.
+template <int LPR> struct Trip {
+    int4 rec[UNR];
+    float4 a[UNR], b[UNR];
+    bool has[UNR];
+    int slot[UNR];
+};
+
+template <int LPR> struct WaveCtx {
+    static constexpr int R = Geo<LPR>::R;
+    const float *P, *Q;
+    float *contrib, *xb;
+    int d, g, l;
+    bool act;
+    int e[R]; // wave-uniform segment ends of the slots
+    float reg;
+};
+
+template <int LPR, int MODE>
+__device__ __forceinline__ void trip_issue(Trip<LPR> &tr, const WaveCtx<LPR> &w, const int4 &mine, int c0, int nc,
+                                           int n_sub, int t0)
+{
+    constexpr int G = Geo<LPR>::G, R = Geo<LPR>::R;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float np = group_sum<LPR>(dot4(p, p));
-    float4 acc = zero;
-    for (int c0 = 0; c0 < n; c0 += 64) {
-        const int nc = (n - c0) < 64 ? (n - c0) : 64;
-        const int4 mine = lane < nc ? occ[s0 + c0 + lane] : make_int4(0, 0, 0, 0);
-        const int n_sub = (nc + G - 1) / G;
-        for (int t0 = 0; t0 < n_sub; t0 += UNR) {
-            int4 rec[UNR];
-            float4 qi[UNR], qj[UNR];
-            bool has[UNR];
 #pragma unroll
-            for (int t = 0; t < UNR; ++t) {
-                const int k = (t0 + t) * G + g;
-                rec[t] = shfl4(mine, k & 63);
-                has[t] = (t0 + t) < n_sub && k < nc;
-                qi[t] = qj[t] = zero;
-                if (has[t] && act) {
-                    qi[t] = ld4(Q + (int64_t)rec[t].y * d + 4 * l);
-                    qj[t] = ld4(Q + (int64_t)rec[t].z * d + 4 * l);
-                }
+    for (int t = 0; t < UNR; ++t) {
+        const int kk = (t0 + t) * G + w.g;
+        tr.rec[t] = shfl4(mine, kk & 63);
+        tr.has[t] = (t0 + t) < n_sub && kk < nc;
+        const int k = c0 + kk;
+        int s = 0;
+#pragma unroll
+        for (int q = 0; q + 1 < R; ++q)
+            s += k >= w.e[q];
+        tr.slot[t] = s;
+        tr.a[t] = tr.b[t] = zero;
+        if (tr.has[t] && w.act) {
+            if (MODE == 0) {
+                tr.a[t] = ld4(w.Q + (int64_t)tr.rec[t].y * w.d + 4 * w.l);
+                tr.b[t] = ld4(w.Q + (int64_t)tr.rec[t].z * w.d + 4 * w.l);
+            } else if (MODE == 1) {
+                tr.a[t] = ld4(w.P + (int64_t)tr.rec[t].x * w.d + 4 * w.l);
+                const int other = tr.rec[t].w < 0 ? tr.rec[t].y : tr.rec[t].z;
+                tr.b[t] = ld4(w.Q + (int64_t)other * w.d + 4 * w.l);
+            } else {
+                tr.a[t] = ld4(w.contrib + (int64_t)(tr.rec[t].w & 0x7fffffff) * w.d + 4 * w.l);
             }
+        }
+    }
+}
+
+template <int LPR, int MODE, bool STORE_CONTRIB>
+__device__ __forceinline__ void trip_consume(const Trip<LPR> &tr, const WaveCtx<LPR> &w, float4 var,
+                                             float4 (&acc)[Geo<LPR>::R], int n_sub, int t0)
+{
+    constexpr int R = Geo<LPR>::R;
 #pragma unroll
-            for (int t = 0; t < UNR; ++t) {
-                if ((t0 + t) >= n_sub)
-                    break; // wave-uniform
+    for (int t = 0; t < UNR; ++t) {
+        const bool live = (t0 + t) < n_sub; // wave-uniform; dead sub-iterations have has == false everywhere
+        (void)live;
+        const float4 own = R == 1 ? var : shfl4f(var, tr.slot[t] * LPR + w.l); // the slot's row slice
+        float4 c;
+        if (MODE == 0) {
+            float x;
+            const float s = triple_s<LPR>(own, tr.a[t], tr.b[t], &x);
+            const int pos = tr.rec[t].w & 0x7fffffff;
+            if (tr.has[t] && w.l == 0)
+                w.xb[pos] = x; // softplus(-x) is taken in bpr_reduce_loss
+            if (STORE_CONTRIB && tr.has[t] && w.act)
+                st4(w.contrib + (int64_t)pos * w.d + 4 * w.l, make_float4(s * own.x, s * own.y, s * own.z, s * own.w));
+            const float ns = -s;
+            c.x = ns * (tr.a[t].x - tr.b[t].x) + w.reg * own.x;
+            c.y = ns * (tr.a[t].y - tr.b[t].y) + w.reg * own.y;
+            c.z = ns * (tr.a[t].z - tr.b[t].z) + w.reg * own.z;
+            c.w = ns * (tr.a[t].w - tr.b[t].w) + w.reg * own.w;
+        } else {
+            const bool is_j = tr.rec[t].w < 0;
+            float4 sp = tr.a[t];
+            if (MODE == 1) {
+                // operands selected, not branched: the cross-lane sums run with every lane active
+                const float4 qi = is_j ? tr.b[t] : own, qj = is_j ? own : tr.b[t];
                 float x;
-                const float s = triple_s<LPR>(p, qi[t], qj[t], &x);
-                const float ni = group_sum<LPR>(dot4(qi[t], qi[t]));
-                const float nj = group_sum<LPR>(dot4(qj[t], qj[t]));
-                if (has[t]) {
-                    const int pos = rec[t].w & 0x7fffffff;
-                    if (l == 0)
-                        loss_triple[pos] = tf_softplus(-x) + h.reg * ((0.5f * np + 0.5f * ni) + 0.5f * nj);
-                    if (act) {
-                        if (STORE_CONTRIB)
-                            st4(contrib + (int64_t)pos * d + 4 * l, make_float4(s * p.x, s * p.y, s * p.z, s * p.w));
-                        const float ns = -s;
-                        acc.x = acc.x + (ns * (qi[t].x - qj[t].x) + h.reg * p.x);
-                        acc.y = acc.y + (ns * (qi[t].y - qj[t].y) + h.reg * p.y);
-                        acc.z = acc.z + (ns * (qi[t].z - qj[t].z) + h.reg * p.z);
-                        acc.w = acc.w + (ns * (qi[t].w - qj[t].w) + h.reg * p.w);
-                    }
-                }
+                const float s = triple_s<LPR>(tr.a[t], qi, qj, &x);
+                sp = make_float4(s * tr.a[t].x, s * tr.a[t].y, s * tr.a[t].z, s * tr.a[t].w);
             }
+            const float sg = is_j ? 1.0f : -1.0f; // j-slices get +s*p, i-slices -s*p
+            c.x = sg * sp.x + w.reg * own.x;
+            c.y = sg * sp.y + w.reg * own.y;
+            c.z = sg * sp.z + w.reg * own.z;
+            c.w = sg * sp.w + w.reg * own.w;
         }
+        const bool take = tr.has[t] && w.act;
+#pragma unroll
+        for (int s = 0; s < R; ++s)
+            if (take && tr.slot[t] == s)
+                add4(acc[s], c);
     }
-    return cross_group_sum<LPR>(acc);
 }
 
-// ------------------------------------------------------------------------------------
-// one item row: sum over its occurrences of dL/dq.
-//   FROM_CONTRIB: c_b is read back (lazy mode).  Otherwise s_b is recomputed from the
-//   read-side tables (fused tf1 step).
-// ------------------------------------------------------------------------------------
-template <int LPR, bool FROM_CONTRIB>
-__device__ inline float4 item_row_grad(float4 q, int32_t row, const float *__restrict__ P, const float *__restrict__ Q,
-                                       int d, const int4 *__restrict__ occ, int s0, int n,
-                                       const float *__restrict__ contrib, const Hyper &h)
+template <int LPR, int MODE, bool STORE_CONTRIB>
+__device__ inline float4 slots_grad(float4 var, const Slot &sl, int n_valid, const float *__restrict__ P,
+                                    const float *__restrict__ Q, int d, const int4 *__restrict__ occ,
+                                    float *__restrict__ contrib, float *__restrict__ xb, const Hyper &h)
 {
-    constexpr int G = 64 / LPR;
-    const int lane = threadIdx.x & 63, g = lane / LPR, l = lane % LPR;
-    const bool act = 4 * l < d;
+    constexpr int G = Geo<LPR>::G, R = Geo<LPR>::R;
+    const int lane = threadIdx.x & 63;
+    WaveCtx<LPR> w;
+    w.P = P;
+    w.Q = Q;
+    w.contrib = contrib;
+    w.xb = xb;
+    w.d = d;
+    w.g = lane / LPR;
+    w.l = lane % LPR;
+    w.act = 4 * w.l < d;
+    w.reg = h.reg;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 acc = zero;
-    (void)row;
-    for (int c0 = 0; c0 < n; c0 += 64) {
-        const int nc = (n - c0) < 64 ? (n - c0) : 64;
-        const int4 mine = lane < nc ? occ[s0 + c0 + lane] : make_int4(0, 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < R; ++s) { // INT_MAX for slots beyond the table
+        const int end_s = __shfl(sl.start + sl.cnt, s * LPR, 64);
+        w.e[s] = s < n_valid ? end_s : 0x7fffffff;
+    }
+    const int w_start = __shfl(sl.start, 0, 64);
+    int w_end = w_start;
+#pragma unroll
+    for (int s = 0; s < R; ++s)
+        w_end = s < n_valid ? w.e[s] : w_end;
+    float4 acc[R];
+#pragma unroll
+    for (int s = 0; s < R; ++s)
+        acc[s] = zero;
+
+    for (int c0 = w_start; c0 < w_end; c0 += 64) {
+        const int nc = (w_end - c0) < 64 ? (w_end - c0) : 64;
+        const int4 mine = lane < nc ? occ[c0 + lane] : make_int4(0, 0, 0, 0);
         const int n_sub = (nc + G - 1) / G;
-        for (int t0 = 0; t0 < n_sub; t0 += UNR) {
-            int4 rec[UNR];
-            float4 a[UNR], b[UNR]; // FROM_CONTRIB: a = c_b.  else a = p_u, b = the triple's other item row
-            bool has[UNR];
-#pragma unroll
-            for (int t = 0; t < UNR; ++t) {
-                const int k = (t0 + t) * G + g;
-                rec[t] = shfl4(mine, k & 63);
-                has[t] = (t0 + t) < n_sub && k < nc;
-                a[t] = b[t] = zero;
-                if (has[t] && act) {
-                    if (FROM_CONTRIB) {
-                        a[t] = ld4(contrib + (int64_t)(rec[t].w & 0x7fffffff) * d + 4 * l);
-                    } else {
-                        a[t] = ld4(P + (int64_t)rec[t].x * d + 4 * l);
-                        const int other = rec[t].w < 0 ? rec[t].y : rec[t].z;
-                        b[t] = ld4(Q + (int64_t)other * d + 4 * l);
-                    }
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < UNR; ++t) {
-                if ((t0 + t) >= n_sub)
-                    break; // wave-uniform
-                float4 c = a[t];
-                const bool is_j = rec[t].w < 0;
-                if (!FROM_CONTRIB) {
-                    // operands selected, not branched: the cross-lane sums below run with every lane active
-                    const float4 qi = is_j ? b[t] : q, qj = is_j ? q : b[t];
-                    float x;
-                    const float s = triple_s<LPR>(a[t], qi, qj, &x);
-                    c = make_float4(s * a[t].x, s * a[t].y, s * a[t].z, s * a[t].w);
-                }
-                if (has[t] && act) {
-                    const float sg = is_j ? 1.0f : -1.0f; // j-slices get +s*p, i-slices -s*p
-                    acc.x = acc.x + (sg * c.x + h.reg * q.x);
-                    acc.y = acc.y + (sg * c.y + h.reg * q.y);
-                    acc.z = acc.z + (sg * c.z + h.reg * q.z);
-                    acc.w = acc.w + (sg * c.w + h.reg * q.w);
-                }
-            }
+        Trip<LPR> ta, tb;
+        trip_issue<LPR, MODE>(ta, w, mine, c0, nc, n_sub, 0);
+        for (int t0 = 0; t0 < n_sub; t0 += 2 * UNR) {
+            if (t0 + UNR < n_sub)
+                trip_issue<LPR, MODE>(tb, w, mine, c0, nc, n_sub, t0 + UNR);
+            trip_consume<LPR, MODE, STORE_CONTRIB>(ta, w, var, acc, n_sub, t0);
+            if (t0 + UNR >= n_sub)
+                break;
+            if (t0 + 2 * UNR < n_sub)
+                trip_issue<LPR, MODE>(ta, w, mine, c0, nc, n_sub, t0 + 2 * UNR);
+            trip_consume<LPR, MODE, STORE_CONTRIB>(tb, w, var, acc, n_sub, t0 + UNR);
         }
     }
-    return cross_group_sum<LPR>(acc);
+    return reduce_to_owner<LPR>(acc);
 }
 
 // ------------------------------------------------------------------------------------
-// tf1 mode: the whole step in one launch, tables read from `src`, written to `dst`
+// Loss bookkeeping.  loss_b = sum_triples softplus(-x_b) + reg * sum_rows cnt_row * |row|^2 / 2:
+// the l2 part of BPR.py:42-43 regrouped by table row (each row's norm is taken once by the group
+// that owns the row, times the number of batch slots that index it).  User waves store x_b per
+// triple, every owner group stores its row term; bpr_reduce_loss does the softplus and the sums.
+// Per batch the workspace holds xb[B] then rowterm[RT] (RT = U + I in tf1 mode, 3B in lazy mode).
+// ------------------------------------------------------------------------------------
+template <int LPR, int MODE, bool STORE_CONTRIB>
+__device__ inline void row_wave(const Tables &src, const Tables &dst, int d, const Slot &sl, int n_valid,
+                                const int4 *__restrict__ occ, float *__restrict__ contrib, float *__restrict__ xb,
+                                float *__restrict__ rowterm_slot, bool dense, const Hyper &h)
+{
+    constexpr int R = Geo<LPR>::R;
+    const int lane = threadIdx.x & 63, g = lane / LPR, l = lane % LPR;
+    const bool owner = g < R && g < n_valid && 4 * l < d;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool user = MODE == 0;
+    const int64_t ro = sl.row * d + 4 * l;
+    float4 var = zero, m = zero, v = zero;
+    if (owner) {
+        var = ld4((user ? src.P : src.Q) + ro);
+        m = ld4((user ? src.mP : src.mQ) + ro);
+        v = ld4((user ? src.vP : src.vQ) + ro);
+    }
+    const int total = __shfl(sl.start + sl.cnt, (n_valid - 1) * LPR, 64) - __shfl(sl.start, 0, 64);
+    float4 grad = zero;
+    if (total > 0) // wave-uniform
+        grad = slots_grad<LPR, MODE, STORE_CONTRIB>(var, sl, n_valid, src.P, src.Q, d, occ, contrib, xb, h);
+    const float nr = group_sum<LPR>(dot4(var, var));
+    if (owner) {
+        if (l == 0 && (dense || sl.cnt > 0))
+            *rowterm_slot = (0.5f * nr) * (float)sl.cnt;
+        adam4(var, m, v, grad, sl.cnt > 0, h);
+        st4((user ? dst.P : dst.Q) + ro, var);
+        st4((user ? dst.mP : dst.mQ) + ro, m);
+        st4((user ? dst.vP : dst.vQ) + ro, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// tf1 mode: the whole step in one launch, tables read from `src`, written to `dst`.
+// Waves [0, WU) own user rows, waves [WU, WU + WI) item rows, R rows each.
 // ------------------------------------------------------------------------------------
 template <int LPR>
 __global__ __launch_bounds__(256) void bpr_step_fused(Tables src, Tables dst, int d, int64_t U, int64_t I,
                                                       const int2 *__restrict__ u_rowseg,
                                                       const int4 *__restrict__ u_occ,
                                                       const int2 *__restrict__ q_rowseg,
-                                                      const int4 *__restrict__ q_occ, float *__restrict__ loss_triple,
-                                                      Hyper h)
+                                                      const int4 *__restrict__ q_occ, float *__restrict__ xb,
+                                                      float *__restrict__ rowterm, Hyper h)
 {
-    const int lane = threadIdx.x & 63;
+    constexpr int R = Geo<LPR>::R;
+    const int lane = threadIdx.x & 63, g = lane / LPR;
     const int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (wave_id >= U + I)
+    const int64_t WU = (U + R - 1) / R, WI = (I + R - 1) / R;
+    if (wave_id >= WU + WI)
         return;
-    const bool is_user = wave_id < U;
-    const int64_t r = is_user ? wave_id : wave_id - U;
-    const int g = lane / LPR, l = lane % LPR;
-    const bool act = 4 * l < d;
-    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int64_t ro = r * d + 4 * l;
-    const int2 rs = is_user ? u_rowseg[r] : q_rowseg[r];
-    const float *sv = is_user ? src.P : src.Q, *sm = is_user ? src.mP : src.mQ, *sw = is_user ? src.vP : src.vQ;
-    float4 var = act ? ld4(sv + ro) : zero;
-    float4 m = zero, v = zero;
-    if (g == 0 && act) {
-        m = ld4(sm + ro);
-        v = ld4(sw + ro);
-    }
-    float4 grad = zero;
-    if (rs.y > 0) { // wave-uniform
-        if (is_user)
-            grad = user_row_grad<LPR, false>(var, src.Q, d, u_occ, rs.x, rs.y, nullptr, loss_triple, h);
-        else
-            grad = item_row_grad<LPR, false>(var, (int32_t)r, src.P, src.Q, d, q_occ, rs.x, rs.y, nullptr, h);
-    }
-    if (g == 0 && act) {
-        adam4(var, m, v, grad, rs.y > 0, h);
-        float *dv = is_user ? dst.P : dst.Q, *dm = is_user ? dst.mP : dst.mQ, *dw = is_user ? dst.vP : dst.vQ;
-        st4(dv + ro, var);
-        st4(dm + ro, m);
-        st4(dw + ro, v);
-    }
+    const bool is_user = wave_id < WU;
+    const int64_t n_rows = is_user ? U : I;
+    const int64_t base = (is_user ? wave_id : wave_id - WU) * R;
+    const int n_valid = (int)((n_rows - base) < R ? (n_rows - base) : R);
+    Slot sl;
+    sl.row = base + (g < n_valid ? g : 0);
+    const int2 rs = (is_user ? u_rowseg : q_rowseg)[sl.row];
+    sl.start = rs.x;
+    sl.cnt = g < n_valid ? rs.y : 0;
+    float *rt = rowterm + (is_user ? 0 : U) + sl.row;
+    if (is_user)
+        row_wave<LPR, 0, false>(src, dst, d, sl, n_valid, u_occ, nullptr, xb, rt, true, h);
+    else
+        row_wave<LPR, 1, false>(src, dst, d, sl, n_valid, q_occ, nullptr, xb, rt, true, h);
 }
 
 // ------------------------------------------------------------------------------------
 // lazy mode: touched rows only, in place, two launches
 // ------------------------------------------------------------------------------------
-template <int LPR>
-__global__ __launch_bounds__(256) void bpr_user_side(Tables t, int d, const int32_t *__restrict__ n_rows,
+template <int LPR, int MODE>
+__global__ __launch_bounds__(256) void bpr_side_lazy(Tables t, int d, const int32_t *__restrict__ n_rows_p,
                                                      const int32_t *__restrict__ rows, const int32_t *__restrict__ seg,
                                                      const int4 *__restrict__ occ, float *__restrict__ contrib,
-                                                     float *__restrict__ loss_triple, Hyper h)
+                                                     float *__restrict__ xb, float *__restrict__ rowterm, Hyper h)
 {
-    const int lane = threadIdx.x & 63;
+    constexpr int R = Geo<LPR>::R;
+    const int lane = threadIdx.x & 63, g = lane / LPR;
     const int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (wave_id >= *n_rows)
+    const int n_rows = *n_rows_p;
+    const int64_t base = wave_id * R;
+    if (base >= n_rows)
         return;
-    const int64_t r = rows[wave_id];
-    const int s0 = seg[wave_id], n = seg[wave_id + 1] - s0;
-    const int g = lane / LPR, l = lane % LPR;
-    const bool act = 4 * l < d;
-    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int64_t ro = r * d + 4 * l;
-    float4 p = act ? ld4(t.P + ro) : zero;
-    float4 m = zero, v = zero;
-    if (g == 0 && act) {
-        m = ld4(t.mP + ro);
-        v = ld4(t.vP + ro);
-    }
-    const float4 grad = user_row_grad<LPR, true>(p, t.Q, d, occ, s0, n, contrib, loss_triple, h);
-    if (g == 0 && act) {
-        adam4(p, m, v, grad, true, h);
-        st4(t.P + ro, p);
-        st4(t.mP + ro, m);
-        st4(t.vP + ro, v);
-    }
-}
-
-template <int LPR>
-__global__ __launch_bounds__(256) void bpr_item_side(Tables t, int d, const int32_t *__restrict__ n_rows,
-                                                     const int32_t *__restrict__ rows, const int32_t *__restrict__ seg,
-                                                     const int4 *__restrict__ occ, const float *__restrict__ contrib,
-                                                     Hyper h)
-{
-    const int lane = threadIdx.x & 63;
-    const int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (wave_id >= *n_rows)
-        return;
-    const int64_t r = rows[wave_id];
-    const int s0 = seg[wave_id], n = seg[wave_id + 1] - s0;
-    const int g = lane / LPR, l = lane % LPR;
-    const bool act = 4 * l < d;
-    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int64_t ro = r * d + 4 * l;
-    float4 q = act ? ld4(t.Q + ro) : zero;
-    float4 m = zero, v = zero;
-    if (g == 0 && act) {
-        m = ld4(t.mQ + ro);
-        v = ld4(t.vQ + ro);
-    }
-    const float4 grad = item_row_grad<LPR, true>(q, (int32_t)r, nullptr, nullptr, d, occ, s0, n, contrib, h);
-    if (g == 0 && act) {
-        adam4(q, m, v, grad, true, h);
-        st4(t.Q + ro, q);
-        st4(t.mQ + ro, m);
-        st4(t.vQ + ro, v);
-    }
+    const int n_valid = (int)((n_rows - base) < R ? (n_rows - base) : R);
+    const int64_t idx = base + (g < n_valid ? g : 0);
+    Slot sl;
+    sl.row = rows[idx];
+    sl.start = seg[idx];
+    sl.cnt = g < n_valid ? seg[idx + 1] - sl.start : 0;
+    row_wave<LPR, MODE, MODE == 0>(t, t, d, sl, n_valid, occ, contrib, xb, rowterm + idx, false, h);
 }
 
 // ------------------------------------------------------------------------------------
-// bpr_reduce_loss: one workgroup per batch, fixed summation order, float64 accumulation
+// bpr_reduce_loss: one workgroup per batch, fixed summation order, float64 accumulation.
+//   dense: rowterm[0 .. n_dense).  lazy (n_dense == 0): rowterm[0 .. n_u) and rowterm[B .. B + n_q).
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bpr_reduce_loss(const float *__restrict__ loss_triple, int64_t n_total,
-                                                       int32_t B, float *__restrict__ loss_per_batch)
+__global__ __launch_bounds__(256) void bpr_reduce_loss(const float *__restrict__ ws, int64_t stride, int64_t n_total,
+                                                       int32_t B, int64_t n_dense, const int32_t *__restrict__ n_u,
+                                                       const int32_t *__restrict__ n_q, float reg,
+                                                       float *__restrict__ loss_per_batch)
 {
     __shared__ double part[256];
     const int64_t t0 = (int64_t)blockIdx.x * B;
     const int nb = (int)((n_total - t0) < B ? (n_total - t0) : B);
-    double s = 0.0;
+    const float *xb = ws + blockIdx.x * stride, *rowterm = xb + B;
+    double s = 0.0, l2 = 0.0;
     for (int k = threadIdx.x; k < nb; k += 256)
-        s += (double)loss_triple[t0 + k];
-    part[threadIdx.x] = s;
+        s += (double)tf_softplus(-xb[k]);
+    if (n_dense > 0) {
+        for (int64_t k = threadIdx.x; k < n_dense; k += 256)
+            l2 += (double)rowterm[k];
+    } else {
+        const int nu = n_u[blockIdx.x], nq = n_q[blockIdx.x];
+        for (int k = threadIdx.x; k < nu; k += 256)
+            l2 += (double)rowterm[k];
+        for (int k = threadIdx.x; k < nq; k += 256)
+            l2 += (double)rowterm[B + k];
+    }
+    part[threadIdx.x] = s + (double)reg * l2;
     __syncthreads();
     for (int off = 128; off > 0; off >>= 1) {
         if ((int)threadIdx.x < off)
@@ -604,34 +713,36 @@ struct StepArgs {
     int d;
     int64_t U, I;
     int32_t B;
-    float *contrib, *loss_triple;
+    float *contrib, *xb, *rowterm;
     Hyper h;
     hipStream_t st;
 };
 
 template <int LPR> void launch_fused(const StepArgs &a, const IndexWs &w, int64_t b)
 {
-    const int64_t waves = a.U + a.I;
+    constexpr int R = Geo<LPR>::R;
+    const int64_t waves = crec_ceil_div(a.U, R) + crec_ceil_div(a.I, R);
     crec_prof_begin(a.ctx, CREC_K_STEP_FUSED, a.st);
     hipLaunchKernelGGL((bpr_step_fused<LPR>), dim3((unsigned)crec_ceil_div(waves, 4)), dim3(256), 0, a.st, a.cur, a.other,
                        a.d, a.U, a.I, w.u_rowseg + b * w.U, w.u_occ + b * w.B, w.q_rowseg + b * w.I,
-                       w.q_occ + b * 2 * w.B, a.loss_triple, a.h);
+                       w.q_occ + b * 2 * w.B, a.xb, a.rowterm, a.h);
     crec_prof_end(a.ctx, a.st);
 }
 
 template <int LPR> void launch_lazy(const StepArgs &a, const IndexWs &w, int64_t b)
 {
-    const int64_t u_waves = a.U < a.B ? a.U : a.B;
-    const int64_t q_waves = a.I < 2 * (int64_t)a.B ? a.I : 2 * (int64_t)a.B;
+    constexpr int R = Geo<LPR>::R;
+    const int64_t u_waves = crec_ceil_div(a.U < a.B ? a.U : a.B, R);
+    const int64_t q_waves = crec_ceil_div(a.I < 2 * (int64_t)a.B ? a.I : 2 * (int64_t)a.B, R);
     crec_prof_begin(a.ctx, CREC_K_USER_SIDE, a.st);
-    hipLaunchKernelGGL((bpr_user_side<LPR>), dim3((unsigned)crec_ceil_div(u_waves, 4)), dim3(256), 0, a.st, a.cur, a.d,
-                       w.n_u + b, w.u_rows + b * w.B, w.u_seg + b * (w.B + 1), w.u_occ + b * w.B, a.contrib,
-                       a.loss_triple, a.h);
+    hipLaunchKernelGGL((bpr_side_lazy<LPR, 0>), dim3((unsigned)crec_ceil_div(u_waves, 4)), dim3(256), 0, a.st, a.cur, a.d,
+                       w.n_u + b, w.u_rows + b * w.B, w.u_seg + b * (w.B + 1), w.u_occ + b * w.B, a.contrib, a.xb,
+                       a.rowterm, a.h);
     crec_prof_end(a.ctx, a.st);
     crec_prof_begin(a.ctx, CREC_K_ITEM_SIDE, a.st);
-    hipLaunchKernelGGL((bpr_item_side<LPR>), dim3((unsigned)crec_ceil_div(q_waves, 4)), dim3(256), 0, a.st, a.cur, a.d,
-                       w.n_q + b, w.q_rows + b * 2 * w.B, w.q_seg + b * (2 * w.B + 1), w.q_occ + b * 2 * w.B,
-                       (const float *)a.contrib, a.h);
+    hipLaunchKernelGGL((bpr_side_lazy<LPR, 2>), dim3((unsigned)crec_ceil_div(q_waves, 4)), dim3(256), 0, a.st, a.cur, a.d,
+                       w.n_q + b, w.q_rows + b * 2 * w.B, w.q_seg + b * (2 * w.B + 1), w.q_occ + b * 2 * w.B, a.contrib,
+                       a.xb, a.rowterm + a.B, a.h);
     crec_prof_end(a.ctx, a.st);
 }
 
@@ -692,7 +803,9 @@ extern "C" int crec_bpr_train_epoch(crec_ctx *ctx, const crec_bpr_tables *t, cre
     chunk = chunk < 1 ? 1 : (chunk > nb ? nb : chunk);
     if (int rc = crec_reserve(ctx, &ctx->idx_ws, layout_index(nullptr, chunk, B, t->U, t->I, dense).bytes))
         return rc;
-    if (int rc = crec_reserve(ctx, &ctx->loss_ws, sizeof(float) * (size_t)chunk * B))
+    // per batch: x_b of every triple, then one l2 term per row wave
+    const int64_t loss_stride = B + (dense ? t->U + t->I : 3 * (int64_t)B);
+    if (int rc = crec_reserve(ctx, &ctx->loss_ws, sizeof(float) * (size_t)chunk * loss_stride))
         return rc;
 
     StepArgs a{};
@@ -741,7 +854,8 @@ extern "C" int crec_bpr_train_epoch(crec_ctx *ctx, const crec_bpr_tables *t, cre
             a.h.beta2 = opt->beta2;
             a.h.eps = opt->eps;
             a.h.reg = opt->reg;
-            a.loss_triple = (float *)ctx->loss_ws.ptr + b * B;
+            a.xb = (float *)ctx->loss_ws.ptr + b * loss_stride;
+            a.rowterm = a.xb + B;
             step(a, w, b);
             if (dense) {
                 Tables tmp = a.cur;
@@ -755,7 +869,8 @@ extern "C" int crec_bpr_train_epoch(crec_ctx *ctx, const crec_bpr_tables *t, cre
         }
         crec_prof_begin(ctx, CREC_K_REDUCE_LOSS, st);
         hipLaunchKernelGGL(bpr_reduce_loss, dim3((unsigned)nbc), dim3(256), 0, st, (const float *)ctx->loss_ws.ptr,
-                           n_chunk, B, loss_per_batch + b0);
+                           loss_stride, n_chunk, B, dense ? t->U + t->I : (int64_t)0, (const int32_t *)w.n_u,
+                           (const int32_t *)w.n_q, opt->reg, loss_per_batch + b0);
         crec_prof_end(ctx, st);
         CREC_HIP(ctx, hipGetLastError());
         if (int rc = crec_prof_flush(ctx, st))
