@@ -7,7 +7,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcrec.so")
+LIB_PATH = os.environ.get("CREC_LIB") or os.path.join(_HERE, "lib", "libcrec.so")  # CREC_LIB: an alternative build
 
 OK, EINVAL, EHIP, ENOMEM, EUNSUPPORTED, ENODEVICE = 0, -1, -2, -3, -4, -5
 ADAM_TF1, ADAM_LAZY = 0, 1
@@ -105,7 +105,7 @@ class Context:
 
     # ---- measurement ---------------------------------------------------------------------------
     KERNELS = ("bpr_index_batches", "bpr_step_fused", "bpr_user_side", "bpr_item_side", "bpr_reduce_loss", "eval_sweep",
-               "eval_merge", "rank_metrics")
+               "eval_merge", "rank_metrics", "bpr_finish_heavy")
 
     def profile(self, on):
         self.check(self.lib.crec_profile_enable(self.h, int(bool(on))))

@@ -40,30 +40,53 @@ namespace {
 
 constexpr int PREP_THREADS = 1024;
 constexpr int MAX_B = 8192;
-constexpr int UNR = 2; // sub-iterations whose gathers are in flight together
+#ifndef CREC_UNR
+#define CREC_UNR 2
+#endif
+#ifndef CREC_RPW
+#define CREC_RPW 2
+#endif
+#ifndef CREC_PIPE
+#define CREC_PIPE 0
+#endif
+constexpr int UNR = CREC_UNR;           // sub-iterations per trip
+constexpr int ROWS_PER_WAVE = CREC_RPW; // table rows a normal wave owns (capped by the groups per wave)
+constexpr bool PIPELINED = CREC_PIPE;   // two trips in flight
+#ifndef CREC_ABL
+#define CREC_ABL 0
+#endif
 
 // ------------------------------------------------------------------------------------
 // index workspace layout for one chunk of nbc batches
 // ------------------------------------------------------------------------------------
 struct IndexWs {
     int32_t *n_u, *n_q;        // [nbc] unique rows per batch
-    int32_t *u_rows, *u_seg;   // [nbc][B], [nbc][B+1]
+    int32_t *u_rows, *u_seg;   // [nbc][B], [nbc][B+1]   row id | heavy<<31 ; segment starts
     int4 *u_occ;               // [nbc][B]   {u, i, j, position in batch}
     int32_t *q_rows, *q_seg;   // [nbc][2B], [nbc][2B+1]
     int4 *q_occ;               // [nbc][2B]  {u, i, j, position | side<<31}  (side 1: row is the triple's j)
-    int2 *u_rowseg, *q_rowseg; // tf1 mode: [nbc][U], [nbc][I]  {segment start, length} of every table row
-    int64_t B, U, I;
+    int2 *u_rowseg, *q_rowseg; // tf1 mode: [nbc][U], [nbc][I]  {segment start, length (negative: heavy row)}
+    int32_t *hn;               // [nbc][4]   {user heavy rows, user chunks, item heavy rows, item chunks}
+    int4 *u_hrows, *q_hrows;   // [nbc][HRu|HRq]  {row, first chunk, chunks<<16 | length, rank among unique rows}
+    int4 *u_hitems, *q_hitems; // [nbc][HIu|HIq]  {row, segment start, length, chunk index}
+    int64_t B, U, I, HRu, HRq, HIu, HIq;
+    int32_t CH;                // rows with more than CH occurrences are split into chunks of CH
     size_t bytes;
 };
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-IndexWs layout_index(void *base, int64_t nbc, int64_t B, int64_t U, int64_t I, bool dense)
+IndexWs layout_index(void *base, int64_t nbc, int64_t B, int64_t U, int64_t I, bool dense, int CH)
 {
     IndexWs w{};
     w.B = B;
     w.U = dense ? U : 0;
     w.I = dense ? I : 0;
+    w.CH = CH;
+    w.HRu = B / (CH + 1) + 1;
+    w.HRq = 2 * B / (CH + 1) + 1;
+    w.HIu = B / CH + w.HRu + 1;
+    w.HIq = 2 * B / CH + w.HRq + 1;
     size_t off = 0;
     auto take = [&](size_t bytes) {
         char *p = base ? (char *)base + off : nullptr;
@@ -80,6 +103,11 @@ IndexWs layout_index(void *base, int64_t nbc, int64_t B, int64_t U, int64_t I, b
     w.q_occ = (int4 *)take(sizeof(int4) * nbc * 2 * B);
     w.u_rowseg = (int2 *)take(sizeof(int2) * nbc * w.U);
     w.q_rowseg = (int2 *)take(sizeof(int2) * nbc * w.I);
+    w.hn = (int32_t *)take(sizeof(int32_t) * nbc * 4);
+    w.u_hrows = (int4 *)take(sizeof(int4) * nbc * w.HRu);
+    w.q_hrows = (int4 *)take(sizeof(int4) * nbc * w.HRq);
+    w.u_hitems = (int4 *)take(sizeof(int4) * nbc * w.HIu);
+    w.q_hitems = (int4 *)take(sizeof(int4) * nbc * w.HIq);
     w.bytes = off;
     return w;
 }
@@ -146,6 +174,7 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
     const int64_t t0 = (int64_t)batch * B;
     const int nb = (int)((n_total - t0) < B ? (n_total - t0) : B); // triples in this batch
     const int n = side ? 2 * nb : nb;
+    const int CH = w.CH;
     int n_pad = 64;
     while (n_pad < n)
         n_pad <<= 1;
@@ -184,26 +213,47 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
         }
     }
 
-    // heads of equal-row runs -> rank of each unique row
+    // pass 1: heads of equal-row runs; heavy rows (more than CH occurrences) and their chunk counts
     const int per = n_pad / PREP_THREADS > 0 ? n_pad / PREP_THREADS : 1;
     const int k0 = tid * per;
-    int heads = 0;
+    int heads = 0, hv = 0; // hv = heavy rows << 16 | chunks
     for (int k = k0; k < k0 + per && k < n; ++k) {
-        uint32_t row = (uint32_t)(keys[k] >> 32);
-        heads += (k == 0) || (row != (uint32_t)(keys[k - 1] >> 32));
+        const uint32_t row = (uint32_t)(keys[k] >> 32);
+        if (k == 0 || row != (uint32_t)(keys[k - 1] >> 32)) {
+            ++heads;
+            const int cnt = lower_bound_key(keys, n, (unsigned long long)(row + 1) << 32) - k;
+            if (cnt > CH)
+                hv += (1 << 16) + (cnt + CH - 1) / CH;
+        }
     }
-    int total = 0;
+    int total = 0, hv_total = 0;
     int rank = block_excl_scan(heads, scratch, &total);
+    __syncthreads();
+    const int hv_before = block_excl_scan(hv, scratch, &hv_total);
+    int hrow = hv_before >> 16, hitem = hv_before & 0xffff;
 
     int32_t *rows_out = side ? w.q_rows + (int64_t)batch * 2 * B : w.u_rows + (int64_t)batch * B;
     int32_t *seg_out = side ? w.q_seg + (int64_t)batch * (2 * B + 1) : w.u_seg + (int64_t)batch * (B + 1);
     int4 *occ_out = side ? w.q_occ + (int64_t)batch * 2 * B : w.u_occ + (int64_t)batch * B;
+    int4 *hrows_out = side ? w.q_hrows + (int64_t)batch * w.HRq : w.u_hrows + (int64_t)batch * w.HRu;
+    int4 *hitems_out = side ? w.q_hitems + (int64_t)batch * w.HIq : w.u_hitems + (int64_t)batch * w.HIu;
     for (int k = k0; k < k0 + per && k < n; ++k) {
         unsigned long long key = keys[k];
         uint32_t row = (uint32_t)(key >> 32);
         if (k == 0 || row != (uint32_t)(keys[k - 1] >> 32)) {
-            rows_out[rank] = (int32_t)row;
+            const int cnt = lower_bound_key(keys, n, (unsigned long long)(row + 1) << 32) - k;
+            const bool heavy = cnt > CH;
+            rows_out[rank] = (int32_t)(row | (heavy ? 0x80000000u : 0u));
             seg_out[rank] = k;
+            if (heavy) {
+                const int parts = (cnt + CH - 1) / CH;
+                hrows_out[hrow++] = make_int4((int)row, hitem, (parts << 16) | cnt, rank);
+                for (int p = 0; p < parts; ++p) {
+                    const int len = (cnt - p * CH) < CH ? (cnt - p * CH) : CH;
+                    hitems_out[hitem] = make_int4((int)row, k + p * CH, len, hitem);
+                    ++hitem;
+                }
+            }
             ++rank;
         }
         const uint32_t payload = (uint32_t)key;
@@ -213,6 +263,8 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
     if (tid == 0) {
         seg_out[total] = n;
         (side ? w.n_q : w.n_u)[batch] = total;
+        w.hn[batch * 4 + side * 2 + 0] = hv_total >> 16;
+        w.hn[batch * 4 + side * 2 + 1] = hv_total & 0xffff;
     }
 
     // tf1 mode: every table row's {segment start, length} by two binary searches in the sorted keys
@@ -222,7 +274,8 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
         for (int64_t r = tid; r < n_rows; r += PREP_THREADS) {
             const int a = lower_bound_key(keys, n, (unsigned long long)r << 32);
             const int b = lower_bound_key(keys, n, (unsigned long long)(r + 1) << 32);
-            rs[r] = make_int2(a, b - a);
+            const int cnt = b - a;
+            rs[r] = make_int2(a, cnt > CH ? -cnt : cnt);
         }
     }
 }
@@ -344,6 +397,10 @@ __device__ inline void add4(float4 &a, float4 b)
 // so user-row and item-row waves agree bit for bit.
 template <int LPR> __device__ inline float triple_s(float4 p, float4 qi, float4 qj, float *x_out)
 {
+    if (CREC_ABL & 2) {
+        *x_out = p.x + qi.x + qj.x;
+        return *x_out;
+    }
     const float di = group_sum<LPR>(dot4(p, qi));
     const float dj = group_sum<LPR>(dot4(p, qj));
     const float x = di - dj; // ui_scores - uj_scores (BPR.py:39-42)
@@ -351,43 +408,51 @@ template <int LPR> __device__ inline float triple_s(float4 p, float4 qi, float4 
     return 1.0f / (1.0f + expf(x)); // sigmoid(-x) = -d softplus(-x)/dx
 }
 
+
 // ------------------------------------------------------------------------------------
-// A wave owns R = min(G, 4) consecutive table rows ("slots"), one per lane group: group g holds
-// slot g's row, m and v slices as float4s (every row byte is loaded and stored exactly once, all
-// lanes busy in the Adam arithmetic).  The occurrences of consecutive rows are consecutive in the
-// sorted occurrence list, so the wave walks ONE contiguous range of records, G at a time: the
-// group that draws occurrence k finds its slot from the slots' segment ends, borrows that slot's
-// row slice with a cross-lane read, gathers the other rows, and adds the result into a per-slot
-// accumulator.  A reduce-scatter over the groups then hands slot g's gradient to group g.
+// A normal wave owns R = min(G, ROWS_PER_WAVE) consecutive table rows ("slots"), one per lane
+// group: group g holds slot g's row, m and v slices as float4s (every row byte is loaded and stored
+// exactly once, all lanes busy in the Adam arithmetic).  The occurrences of consecutive rows are
+// consecutive in the sorted occurrence list, so the wave walks contiguous ranges of records, G at
+// a time: the group that draws occurrence k finds its slot from the slots' segment ends, borrows
+// that slot's row slice with a cross-lane read, gathers the other rows, and adds the result into a
+// per-slot accumulator.  A reduce-scatter over the groups then hands slot g's gradient to group g.
+//
+// Heavy rows (more than CH occurrences in the batch: popular items) would make their wave the
+// kernel's critical path, so the index kernel cuts them into chunks of CH: chunk waves (R = 1, all
+// G groups on one row) write partial gradients, normal waves skip such a slot, and bpr_finish_heavy
+// adds the partials in chunk order and applies Adam.  Every sum keeps one fixed order.
 // ------------------------------------------------------------------------------------
-template <int LPR> struct Geo {
+template <int LPR, int RW> struct Geo {
     static constexpr int G = 64 / LPR;
-    static constexpr int R = G < 4 ? G : 4;
+    static constexpr int R = G < RW ? G : RW;
 };
 
-struct Slot { // per lane: the slot of this lane's group (valid when g < R and row >= 0)
+template <int LPR, int RW> using AccArr = float4[Geo<LPR, RW>::R];
+
+struct Slot { // per lane: the slot of this lane's group (meaningful when g < n_valid)
     int64_t row;
-    int start, cnt;
+    int start, cnt; // cnt < 0: heavy row, handled by chunk waves + bpr_finish_heavy
 };
 
 // sum over groups of acc[s], delivered to group s (slot owner); other groups' return value is unused
-template <int LPR> __device__ inline float4 reduce_to_owner(float4 (&acc)[Geo<LPR>::R])
+template <int LPR, int RW> __device__ inline float4 reduce_to_owner(AccArr<LPR, RW> &acc)
 {
-    constexpr int G = Geo<LPR>::G, R = Geo<LPR>::R;
+    constexpr int G = Geo<LPR, RW>::G, R = Geo<LPR, RW>::R;
     const int g = (threadIdx.x & 63) / LPR;
     if (G == 1)
         return acc[0];
-    if (G == 2) { // partner = other group: keep my slot, add the partner's partial of it
-        const float4 give = g == 0 ? acc[1] : acc[0];
-        float4 mine = g == 0 ? acc[0] : acc[1];
+    if (R == G && G == 2) { // partner = other group: keep my slot, add the partner's partial of it
+        const float4 give = g == 0 ? acc[R - 1] : acc[0];
+        float4 mine = g == 0 ? acc[0] : acc[R - 1];
         add4(mine, shfl4f_xor(give, LPR));
         return mine;
     }
-    if (G == 4) {
+    if (R == G && G == 4) {
         // step 1, partner g^2: keep the slot pair {g&2, (g&2)+1}, hand over the other pair
         const bool hi = (g & 2) != 0;
-        float4 k0 = hi ? acc[2] : acc[0], k1 = hi ? acc[3] : acc[1];
-        const float4 s0 = hi ? acc[0] : acc[2], s1 = hi ? acc[1] : acc[3];
+        float4 k0 = hi ? acc[2 % R] : acc[0], k1 = hi ? acc[3 % R] : acc[1 % R];
+        const float4 s0 = hi ? acc[0] : acc[2 % R], s1 = hi ? acc[1 % R] : acc[3 % R];
         add4(k0, shfl4f_xor(s0, 2 * LPR));
         add4(k1, shfl4f_xor(s1, 2 * LPR));
         // step 2, partner g^1: keep slot g, hand over the pair's other slot
@@ -397,7 +462,7 @@ template <int LPR> __device__ inline float4 reduce_to_owner(float4 (&acc)[Geo<LP
         add4(mine, shfl4f_xor(give, LPR));
         return mine;
     }
-    // G > 4 (d < 64): all-reduce every slot over all groups, then pick
+    // general: all-reduce every slot over all groups, then pick
     float4 out = acc[0];
 #pragma unroll
     for (int s = 0; s < R; ++s) {
@@ -416,17 +481,15 @@ template <int LPR> __device__ inline float4 reduce_to_owner(float4 (&acc)[Geo<LP
 // MODE 2: item rows, lazy mode (reads c_b back)
 //
 // One "trip" = UNR sub-iterations of G occurrences.  Trips are software-pipelined two deep: the
-// gathers of trip n+1 are issued before trip n is consumed, so the loop runs at the pace of the
-// arithmetic, not of a memory round trip per trip.
-template <int LPR> struct Trip {
+// gathers of trip n+1 are issued before trip n is consumed.
+struct Trip {
     int4 rec[UNR];
     float4 a[UNR], b[UNR];
     bool has[UNR];
     int slot[UNR];
 };
 
-template <int LPR> struct WaveCtx {
-    static constexpr int R = Geo<LPR>::R;
+template <int R> struct WaveCtx {
     const float *P, *Q;
     float *contrib, *xb;
     int d, g, l;
@@ -435,11 +498,11 @@ template <int LPR> struct WaveCtx {
     float reg;
 };
 
-template <int LPR, int MODE>
-__device__ __forceinline__ void trip_issue(Trip<LPR> &tr, const WaveCtx<LPR> &w, const int4 &mine, int c0, int nc,
+template <int LPR, int RW, int MODE>
+__device__ __forceinline__ void trip_issue(Trip &tr, const WaveCtx<Geo<LPR, RW>::R> &w, const int4 &mine, int c0, int nc,
                                            int n_sub, int t0)
 {
-    constexpr int G = Geo<LPR>::G, R = Geo<LPR>::R;
+    constexpr int G = Geo<LPR, RW>::G, R = Geo<LPR, RW>::R;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int t = 0; t < UNR; ++t) {
@@ -454,7 +517,10 @@ __device__ __forceinline__ void trip_issue(Trip<LPR> &tr, const WaveCtx<LPR> &w,
         tr.slot[t] = s;
         tr.a[t] = tr.b[t] = zero;
         if (tr.has[t] && w.act) {
-            if (MODE == 0) {
+            if (CREC_ABL & 1) {
+                tr.a[t] = ld4(w.Q + (int64_t)(tr.rec[t].y & 3) * w.d + 4 * w.l);
+                tr.b[t] = ld4(w.Q + (int64_t)(tr.rec[t].z & 3) * w.d + 4 * w.l);
+            } else if (MODE == 0) {
                 tr.a[t] = ld4(w.Q + (int64_t)tr.rec[t].y * w.d + 4 * w.l);
                 tr.b[t] = ld4(w.Q + (int64_t)tr.rec[t].z * w.d + 4 * w.l);
             } else if (MODE == 1) {
@@ -468,15 +534,14 @@ __device__ __forceinline__ void trip_issue(Trip<LPR> &tr, const WaveCtx<LPR> &w,
     }
 }
 
-template <int LPR, int MODE, bool STORE_CONTRIB>
-__device__ __forceinline__ void trip_consume(const Trip<LPR> &tr, const WaveCtx<LPR> &w, float4 var,
-                                             float4 (&acc)[Geo<LPR>::R], int n_sub, int t0)
+template <int LPR, int RW, int MODE, bool STORE_CONTRIB>
+__device__ __forceinline__ void trip_consume(const Trip &tr, const WaveCtx<Geo<LPR, RW>::R> &w, float4 var,
+                                             AccArr<LPR, RW> &acc)
 {
-    constexpr int R = Geo<LPR>::R;
+    constexpr int R = Geo<LPR, RW>::R;
 #pragma unroll
     for (int t = 0; t < UNR; ++t) {
-        const bool live = (t0 + t) < n_sub; // wave-uniform; dead sub-iterations have has == false everywhere
-        (void)live;
+        // dead sub-iterations (past the end of the range) have has == false in every lane
         const float4 own = R == 1 ? var : shfl4f(var, tr.slot[t] * LPR + w.l); // the slot's row slice
         float4 c;
         if (MODE == 0) {
@@ -516,14 +581,48 @@ __device__ __forceinline__ void trip_consume(const Trip<LPR> &tr, const WaveCtx<
     }
 }
 
-template <int LPR, int MODE, bool STORE_CONTRIB>
+// walk the occurrence records [k_begin, k_end) of this wave
+template <int LPR, int RW, int MODE, bool STORE_CONTRIB>
+__device__ __forceinline__ void walk_range(const WaveCtx<Geo<LPR, RW>::R> &w, float4 var, AccArr<LPR, RW> &acc,
+                                           const int4 *__restrict__ occ, int k_begin, int k_end)
+{
+    constexpr int G = Geo<LPR, RW>::G;
+    const int lane = threadIdx.x & 63;
+    for (int c0 = k_begin; c0 < k_end; c0 += 64) {
+        const int nc = (k_end - c0) < 64 ? (k_end - c0) : 64;
+        const int4 mine = lane < nc ? occ[c0 + lane] : make_int4(0, 0, 0, 0);
+        const int n_sub = (nc + G - 1) / G;
+        if (PIPELINED) {
+            Trip ta, tb;
+            trip_issue<LPR, RW, MODE>(ta, w, mine, c0, nc, n_sub, 0);
+            for (int t0 = 0; t0 < n_sub; t0 += 2 * UNR) {
+                if (t0 + UNR < n_sub)
+                    trip_issue<LPR, RW, MODE>(tb, w, mine, c0, nc, n_sub, t0 + UNR);
+                trip_consume<LPR, RW, MODE, STORE_CONTRIB>(ta, w, var, acc);
+                if (t0 + UNR >= n_sub)
+                    break;
+                if (t0 + 2 * UNR < n_sub)
+                    trip_issue<LPR, RW, MODE>(ta, w, mine, c0, nc, n_sub, t0 + 2 * UNR);
+                trip_consume<LPR, RW, MODE, STORE_CONTRIB>(tb, w, var, acc);
+            }
+        } else {
+            for (int t0 = 0; t0 < n_sub; t0 += UNR) {
+                Trip ta;
+                trip_issue<LPR, RW, MODE>(ta, w, mine, c0, nc, n_sub, t0);
+                trip_consume<LPR, RW, MODE, STORE_CONTRIB>(ta, w, var, acc);
+            }
+        }
+    }
+}
+
+template <int LPR, int RW, int MODE, bool STORE_CONTRIB>
 __device__ inline float4 slots_grad(float4 var, const Slot &sl, int n_valid, const float *__restrict__ P,
                                     const float *__restrict__ Q, int d, const int4 *__restrict__ occ,
                                     float *__restrict__ contrib, float *__restrict__ xb, const Hyper &h)
 {
-    constexpr int G = Geo<LPR>::G, R = Geo<LPR>::R;
+    constexpr int R = Geo<LPR, RW>::R;
     const int lane = threadIdx.x & 63;
-    WaveCtx<LPR> w;
+    WaveCtx<R> w;
     w.P = P;
     w.Q = Q;
     w.contrib = contrib;
@@ -534,39 +633,39 @@ __device__ inline float4 slots_grad(float4 var, const Slot &sl, int n_valid, con
     w.act = 4 * w.l < d;
     w.reg = h.reg;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    int st[R], cn[R]; // wave-uniform copies of the slots' segments
 #pragma unroll
-    for (int s = 0; s < R; ++s) { // INT_MAX for slots beyond the table
-        const int end_s = __shfl(sl.start + sl.cnt, s * LPR, 64);
-        w.e[s] = s < n_valid ? end_s : 0x7fffffff;
+    for (int s = 0; s < R; ++s) {
+        st[s] = __shfl(sl.start, s * LPR, 64);
+        cn[s] = s < n_valid ? __shfl(sl.cnt, s * LPR, 64) : 0;
+        const int len = cn[s] < 0 ? -cn[s] : cn[s];
+        w.e[s] = s < n_valid ? st[s] + len : 0x7fffffff; // INT_MAX for slots beyond the table
     }
-    const int w_start = __shfl(sl.start, 0, 64);
-    int w_end = w_start;
-#pragma unroll
-    for (int s = 0; s < R; ++s)
-        w_end = s < n_valid ? w.e[s] : w_end;
     float4 acc[R];
 #pragma unroll
     for (int s = 0; s < R; ++s)
         acc[s] = zero;
-
-    for (int c0 = w_start; c0 < w_end; c0 += 64) {
-        const int nc = (w_end - c0) < 64 ? (w_end - c0) : 64;
-        const int4 mine = lane < nc ? occ[c0 + lane] : make_int4(0, 0, 0, 0);
-        const int n_sub = (nc + G - 1) / G;
-        Trip<LPR> ta, tb;
-        trip_issue<LPR, MODE>(ta, w, mine, c0, nc, n_sub, 0);
-        for (int t0 = 0; t0 < n_sub; t0 += 2 * UNR) {
-            if (t0 + UNR < n_sub)
-                trip_issue<LPR, MODE>(tb, w, mine, c0, nc, n_sub, t0 + UNR);
-            trip_consume<LPR, MODE, STORE_CONTRIB>(ta, w, var, acc, n_sub, t0);
-            if (t0 + UNR >= n_sub)
-                break;
-            if (t0 + 2 * UNR < n_sub)
-                trip_issue<LPR, MODE>(ta, w, mine, c0, nc, n_sub, t0 + 2 * UNR);
-            trip_consume<LPR, MODE, STORE_CONTRIB>(tb, w, var, acc, n_sub, t0 + UNR);
+    bool any_heavy = false;
+    int first = 0x7fffffff, last = 0;
+#pragma unroll
+    for (int s = 0; s < R; ++s) {
+        any_heavy |= cn[s] < 0;
+        if (s < n_valid) {
+            first = st[s] < first ? st[s] : first;
+            last = w.e[s];
         }
     }
-    return reduce_to_owner<LPR>(acc);
+    if (!any_heavy) { // the usual case: the slots' segments are one contiguous range
+        if (last > first)
+            walk_range<LPR, RW, MODE, STORE_CONTRIB>(w, var, acc, occ, first, last);
+    } else { // a heavy slot sits in the middle: walk the other slots one by one
+        for (int s = 0; s < n_valid; ++s) {
+            const int b = __shfl(sl.start, s * LPR, 64), c = __shfl(sl.cnt, s * LPR, 64);
+            if (c > 0)
+                walk_range<LPR, RW, MODE, STORE_CONTRIB>(w, var, acc, occ, b, b + c);
+        }
+    }
+    return reduce_to_owner<LPR, RW>(acc);
 }
 
 // ------------------------------------------------------------------------------------
@@ -581,9 +680,11 @@ __device__ inline void row_wave(const Tables &src, const Tables &dst, int d, con
                                 const int4 *__restrict__ occ, float *__restrict__ contrib, float *__restrict__ xb,
                                 float *__restrict__ rowterm_slot, bool dense, const Hyper &h)
 {
-    constexpr int R = Geo<LPR>::R;
+    constexpr int RW = ROWS_PER_WAVE, R = Geo<LPR, RW>::R;
     const int lane = threadIdx.x & 63, g = lane / LPR, l = lane % LPR;
-    const bool owner = g < R && g < n_valid && 4 * l < d;
+    const bool heavy = sl.cnt < 0;
+    const bool in_slot = g < R && g < n_valid && 4 * l < d;
+    const bool owner = in_slot && !heavy; // heavy rows are finished by bpr_finish_heavy
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool user = MODE == 0;
     const int64_t ro = sl.row * d + 4 * l;
@@ -593,10 +694,7 @@ __device__ inline void row_wave(const Tables &src, const Tables &dst, int d, con
         m = ld4((user ? src.mP : src.mQ) + ro);
         v = ld4((user ? src.vP : src.vQ) + ro);
     }
-    const int total = __shfl(sl.start + sl.cnt, (n_valid - 1) * LPR, 64) - __shfl(sl.start, 0, 64);
-    float4 grad = zero;
-    if (total > 0) // wave-uniform
-        grad = slots_grad<LPR, MODE, STORE_CONTRIB>(var, sl, n_valid, src.P, src.Q, d, occ, contrib, xb, h);
+    const float4 grad = slots_grad<LPR, RW, MODE, STORE_CONTRIB>(var, sl, n_valid, src.P, src.Q, d, occ, contrib, xb, h);
     const float nr = group_sum<LPR>(dot4(var, var));
     if (owner) {
         if (l == 0 && (dense || sl.cnt > 0))
@@ -608,21 +706,60 @@ __device__ inline void row_wave(const Tables &src, const Tables &dst, int d, con
     }
 }
 
+// one chunk (<= CH occurrences) of a heavy row: all G groups on the row, partial gradient out
+template <int LPR, int MODE, bool STORE_CONTRIB>
+__device__ inline void chunk_wave(const Tables &src, int d, int4 item, const int4 *__restrict__ occ,
+                                  float *__restrict__ contrib, float *__restrict__ xb, float *__restrict__ partial,
+                                  const Hyper &h)
+{
+    const int lane = threadIdx.x & 63, g = lane / LPR, l = lane % LPR;
+    const bool act = 4 * l < d;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    Slot sl;
+    sl.row = item.x;
+    sl.start = item.y;
+    sl.cnt = item.z;
+    const float4 var = act ? ld4((MODE == 0 ? src.P : src.Q) + sl.row * d + 4 * l) : zero; // every group: R == 1
+    const float4 grad = slots_grad<LPR, 1, MODE, STORE_CONTRIB>(var, sl, 1, src.P, src.Q, d, occ, contrib, xb, h);
+    if (g == 0 && act)
+        st4(partial + (int64_t)item.w * d + 4 * l, grad);
+}
+
 // ------------------------------------------------------------------------------------
 // tf1 mode: the whole step in one launch, tables read from `src`, written to `dst`.
-// Waves [0, WU) own user rows, waves [WU, WU + WI) item rows, R rows each.
+// Wave ids: [0, HIu) user chunk waves, [HIu, HIu+HIq) item chunk waves (first, so that the longest
+// work starts first), then WU waves owning user rows, then WI waves owning item rows.
 // ------------------------------------------------------------------------------------
+struct HeavyArgs {
+    const int32_t *hn;               // {user heavy rows, user chunks, item heavy rows, item chunks}
+    const int4 *u_hitems, *q_hitems; // chunk descriptors
+    const int4 *u_hrows, *q_hrows;   // heavy row descriptors
+    float *partial;                  // [HIu + HIq][d]
+    int HIu, HIq, HRu, HRq;
+};
+
 template <int LPR>
 __global__ __launch_bounds__(256) void bpr_step_fused(Tables src, Tables dst, int d, int64_t U, int64_t I,
                                                       const int2 *__restrict__ u_rowseg,
                                                       const int4 *__restrict__ u_occ,
                                                       const int2 *__restrict__ q_rowseg,
-                                                      const int4 *__restrict__ q_occ, float *__restrict__ xb,
-                                                      float *__restrict__ rowterm, Hyper h)
+                                                      const int4 *__restrict__ q_occ, HeavyArgs hv,
+                                                      float *__restrict__ xb, float *__restrict__ rowterm, Hyper h)
 {
-    constexpr int R = Geo<LPR>::R;
+    constexpr int R = Geo<LPR, ROWS_PER_WAVE>::R;
     const int lane = threadIdx.x & 63, g = lane / LPR;
-    const int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (wave_id < hv.HIu) {
+        chunk_wave<LPR, 0, false>(src, d, hv.u_hitems[wave_id], u_occ, nullptr, xb, hv.partial, h);
+        return;
+    }
+    wave_id -= hv.HIu;
+    if (wave_id < hv.HIq) {
+        chunk_wave<LPR, 1, false>(src, d, hv.q_hitems[wave_id], q_occ, nullptr, xb,
+                                      hv.partial + (int64_t)hv.HIu * d, h);
+        return;
+    }
+    wave_id -= hv.HIq;
     const int64_t WU = (U + R - 1) / R, WI = (I + R - 1) / R;
     if (wave_id >= WU + WI)
         return;
@@ -643,28 +780,81 @@ __global__ __launch_bounds__(256) void bpr_step_fused(Tables src, Tables dst, in
 }
 
 // ------------------------------------------------------------------------------------
-// lazy mode: touched rows only, in place, two launches
+// lazy mode: touched rows only, in place, two launches (MODE 0 users, MODE 2 items)
 // ------------------------------------------------------------------------------------
 template <int LPR, int MODE>
 __global__ __launch_bounds__(256) void bpr_side_lazy(Tables t, int d, const int32_t *__restrict__ n_rows_p,
                                                      const int32_t *__restrict__ rows, const int32_t *__restrict__ seg,
-                                                     const int4 *__restrict__ occ, float *__restrict__ contrib,
+                                                     const int4 *__restrict__ occ, const int32_t *__restrict__ n_chunks_p,
+                                                     const int4 *__restrict__ hitems, int HI,
+                                                     float *__restrict__ partial, float *__restrict__ contrib,
                                                      float *__restrict__ xb, float *__restrict__ rowterm, Hyper h)
 {
-    constexpr int R = Geo<LPR>::R;
+    constexpr int R = Geo<LPR, ROWS_PER_WAVE>::R;
     const int lane = threadIdx.x & 63, g = lane / LPR;
-    const int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (wave_id < HI) {
+        chunk_wave<LPR, MODE, MODE == 0>(t, d, hitems[wave_id], occ, contrib, xb, partial, h);
+        return;
+    }
+    wave_id -= HI;
     const int n_rows = *n_rows_p;
     const int64_t base = wave_id * R;
     if (base >= n_rows)
         return;
     const int n_valid = (int)((n_rows - base) < R ? (n_rows - base) : R);
     const int64_t idx = base + (g < n_valid ? g : 0);
+    const int32_t rw = rows[idx];
     Slot sl;
-    sl.row = rows[idx];
+    sl.row = rw & 0x7fffffff;
     sl.start = seg[idx];
-    sl.cnt = g < n_valid ? seg[idx + 1] - sl.start : 0;
+    const int cnt = seg[idx + 1] - sl.start;
+    sl.cnt = g < n_valid ? (rw < 0 ? -cnt : cnt) : 0;
     row_wave<LPR, MODE, MODE == 0>(t, t, d, sl, n_valid, occ, contrib, xb, rowterm + idx, false, h);
+}
+
+// ------------------------------------------------------------------------------------
+// bpr_finish_heavy: one wave per heavy row: partials summed in chunk order, Adam, row term.
+// Waves [0, HRu) user rows, [HRu, HRu + HRq) item rows.  tf1: src -> dst; lazy: in place.
+// ------------------------------------------------------------------------------------
+template <int LPR>
+__global__ __launch_bounds__(256) void bpr_finish_heavy(Tables src, Tables dst, int d, HeavyArgs hv,
+                                                        float *__restrict__ rowterm, int64_t rt_item_base, int dense,
+                                                        Hyper h)
+{
+    const int lane = threadIdx.x & 63, g = lane / LPR, l = lane % LPR;
+    int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    bool user = true;
+    if (wave_id >= hv.HRu) {
+        user = false;
+        wave_id -= hv.HRu;
+        if (wave_id >= hv.HRq)
+            return;
+    }
+    const int4 rec = user ? hv.u_hrows[wave_id] : hv.q_hrows[wave_id];
+    const int64_t row = rec.x;
+    const int first = rec.y, parts = rec.z >> 16, cnt = rec.z & 0xffff;
+    const bool on = g == 0 && 4 * l < d;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t ro = row * d + 4 * l;
+    float4 var = zero, m = zero, v = zero, grad = zero;
+    if (on) {
+        var = ld4((user ? src.P : src.Q) + ro);
+        m = ld4((user ? src.mP : src.mQ) + ro);
+        v = ld4((user ? src.vP : src.vQ) + ro);
+        const float *part = hv.partial + (int64_t)(user ? 0 : hv.HIu) * d;
+        for (int p = 0; p < parts; ++p)
+            add4(grad, ld4(part + (int64_t)(first + p) * d + 4 * l));
+    }
+    const float nr = group_sum<LPR>(dot4(var, var));
+    if (on) {
+        if (l == 0)
+            rowterm[(user ? 0 : rt_item_base) + (dense ? row : (int64_t)rec.w)] = (0.5f * nr) * (float)cnt;
+        adam4(var, m, v, grad, true, h);
+        st4((user ? dst.P : dst.Q) + ro, var);
+        st4((user ? dst.mP : dst.mQ) + ro, m);
+        st4((user ? dst.vP : dst.vQ) + ro, v);
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -713,40 +903,73 @@ struct StepArgs {
     int d;
     int64_t U, I;
     int32_t B;
-    float *contrib, *xb, *rowterm;
+    float *contrib, *xb, *rowterm, *partial;
     Hyper h;
     hipStream_t st;
 };
 
-template <int LPR> void launch_fused(const StepArgs &a, const IndexWs &w, int64_t b)
+// hn: this batch's {user heavy rows, user chunks, item heavy rows, item chunks}, read back by the host
+// once per chunk of batches, so grids are sized to the real counts and the finish launch is skipped
+// when a batch has no heavy row at all.
+HeavyArgs heavy_args(const StepArgs &a, const IndexWs &w, int64_t b, const int32_t *hn)
 {
-    constexpr int R = Geo<LPR>::R;
-    const int64_t waves = crec_ceil_div(a.U, R) + crec_ceil_div(a.I, R);
+    HeavyArgs hv;
+    hv.hn = w.hn + b * 4;
+    hv.u_hitems = w.u_hitems + b * w.HIu;
+    hv.q_hitems = w.q_hitems + b * w.HIq;
+    hv.u_hrows = w.u_hrows + b * w.HRu;
+    hv.q_hrows = w.q_hrows + b * w.HRq;
+    hv.partial = a.partial;
+    hv.HRu = hn[0];
+    hv.HIu = hn[1];
+    hv.HRq = hn[2];
+    hv.HIq = hn[3];
+    return hv;
+}
+
+template <int LPR> void launch_fused(const StepArgs &a, const IndexWs &w, int64_t b, const int32_t *hn)
+{
+    constexpr int R = Geo<LPR, ROWS_PER_WAVE>::R;
+    const HeavyArgs hv = heavy_args(a, w, b, hn);
+    const int64_t waves = hv.HIu + hv.HIq + crec_ceil_div(a.U, R) + crec_ceil_div(a.I, R);
     crec_prof_begin(a.ctx, CREC_K_STEP_FUSED, a.st);
     hipLaunchKernelGGL((bpr_step_fused<LPR>), dim3((unsigned)crec_ceil_div(waves, 4)), dim3(256), 0, a.st, a.cur, a.other,
                        a.d, a.U, a.I, w.u_rowseg + b * w.U, w.u_occ + b * w.B, w.q_rowseg + b * w.I,
-                       w.q_occ + b * 2 * w.B, a.xb, a.rowterm, a.h);
+                       w.q_occ + b * 2 * w.B, hv, a.xb, a.rowterm, a.h);
     crec_prof_end(a.ctx, a.st);
+    if (hv.HRu + hv.HRq > 0) {
+        crec_prof_begin(a.ctx, CREC_K_FINISH, a.st);
+        hipLaunchKernelGGL((bpr_finish_heavy<LPR>), dim3((unsigned)crec_ceil_div(hv.HRu + hv.HRq, 4)), dim3(256), 0, a.st,
+                           a.cur, a.other, a.d, hv, a.rowterm, a.U, 1, a.h);
+        crec_prof_end(a.ctx, a.st);
+    }
 }
 
-template <int LPR> void launch_lazy(const StepArgs &a, const IndexWs &w, int64_t b)
+template <int LPR> void launch_lazy(const StepArgs &a, const IndexWs &w, int64_t b, const int32_t *hn)
 {
-    constexpr int R = Geo<LPR>::R;
-    const int64_t u_waves = crec_ceil_div(a.U < a.B ? a.U : a.B, R);
-    const int64_t q_waves = crec_ceil_div(a.I < 2 * (int64_t)a.B ? a.I : 2 * (int64_t)a.B, R);
+    constexpr int R = Geo<LPR, ROWS_PER_WAVE>::R;
+    const HeavyArgs hv = heavy_args(a, w, b, hn);
+    const int64_t u_waves = hv.HIu + crec_ceil_div(a.U < a.B ? a.U : a.B, R);
+    const int64_t q_waves = hv.HIq + crec_ceil_div(a.I < 2 * (int64_t)a.B ? a.I : 2 * (int64_t)a.B, R);
     crec_prof_begin(a.ctx, CREC_K_USER_SIDE, a.st);
     hipLaunchKernelGGL((bpr_side_lazy<LPR, 0>), dim3((unsigned)crec_ceil_div(u_waves, 4)), dim3(256), 0, a.st, a.cur, a.d,
-                       w.n_u + b, w.u_rows + b * w.B, w.u_seg + b * (w.B + 1), w.u_occ + b * w.B, a.contrib, a.xb,
-                       a.rowterm, a.h);
+                       w.n_u + b, w.u_rows + b * w.B, w.u_seg + b * (w.B + 1), w.u_occ + b * w.B, hv.hn + 1, hv.u_hitems,
+                       hv.HIu, a.partial, a.contrib, a.xb, a.rowterm, a.h);
     crec_prof_end(a.ctx, a.st);
     crec_prof_begin(a.ctx, CREC_K_ITEM_SIDE, a.st);
     hipLaunchKernelGGL((bpr_side_lazy<LPR, 2>), dim3((unsigned)crec_ceil_div(q_waves, 4)), dim3(256), 0, a.st, a.cur, a.d,
-                       w.n_q + b, w.q_rows + b * 2 * w.B, w.q_seg + b * (2 * w.B + 1), w.q_occ + b * 2 * w.B, a.contrib,
-                       a.xb, a.rowterm + a.B, a.h);
+                       w.n_q + b, w.q_rows + b * 2 * w.B, w.q_seg + b * (2 * w.B + 1), w.q_occ + b * 2 * w.B, hv.hn + 3,
+                       hv.q_hitems, hv.HIq, a.partial + (int64_t)hv.HIu * a.d, a.contrib, a.xb, a.rowterm + a.B, a.h);
     crec_prof_end(a.ctx, a.st);
+    if (hv.HRu + hv.HRq > 0) {
+        crec_prof_begin(a.ctx, CREC_K_FINISH, a.st);
+        hipLaunchKernelGGL((bpr_finish_heavy<LPR>), dim3((unsigned)crec_ceil_div(hv.HRu + hv.HRq, 4)), dim3(256), 0, a.st,
+                           a.cur, a.cur, a.d, hv, a.rowterm, (int64_t)a.B, 0, a.h);
+        crec_prof_end(a.ctx, a.st);
+    }
 }
 
-using StepFn = void (*)(const StepArgs &, const IndexWs &, int64_t);
+using StepFn = void (*)(const StepArgs &, const IndexWs &, int64_t, const int32_t *);
 
 StepFn pick_step(int d, bool dense)
 {
@@ -796,16 +1019,24 @@ extern "C" int crec_bpr_train_epoch(crec_ctx *ctx, const crec_bpr_tables *t, cre
     const bool dense = opt->adam_mode == CREC_ADAM_TF1;
     StepFn step = pick_step(t->d, dense);
     const int64_t nb = crec_ceil_div(N, B);
+    // occurrences per heavy-row chunk.  tf1 mode pays a second launch per step for split rows, so it
+    // only splits rows that would dominate the step; lazy mode (large catalogues, Zipf heads) splits early.
+    static const int ch_env = getenv("CREC_CH") ? atoi(getenv("CREC_CH")) : 0;
+    const int CH = ch_env > 0 ? ch_env : (dense ? 64 : 16);
+    CREC_REQUIRE(ctx, CH >= 1, "CREC_CH");
 
     // chunk the epoch so the inverted indices of a chunk stay under ~1 GiB
-    const size_t per_batch = layout_index(nullptr, 1, B, t->U, t->I, dense).bytes;
+    const size_t per_batch = layout_index(nullptr, 1, B, t->U, t->I, dense, CH).bytes;
     int64_t chunk = (int64_t)((size_t)1 << 30) / (int64_t)per_batch;
     chunk = chunk < 1 ? 1 : (chunk > nb ? nb : chunk);
-    if (int rc = crec_reserve(ctx, &ctx->idx_ws, layout_index(nullptr, chunk, B, t->U, t->I, dense).bytes))
+    if (int rc = crec_reserve(ctx, &ctx->idx_ws, layout_index(nullptr, chunk, B, t->U, t->I, dense, CH).bytes))
         return rc;
     // per batch: x_b of every triple, then one l2 term per row wave
     const int64_t loss_stride = B + (dense ? t->U + t->I : 3 * (int64_t)B);
     if (int rc = crec_reserve(ctx, &ctx->loss_ws, sizeof(float) * (size_t)chunk * loss_stride))
+        return rc;
+    const IndexWs w0 = layout_index(nullptr, 1, B, t->U, t->I, dense, CH);
+    if (int rc = crec_reserve(ctx, &ctx->misc, sizeof(float) * (size_t)(w0.HIu + w0.HIq) * t->d))
         return rc;
 
     StepArgs a{};
@@ -816,6 +1047,7 @@ extern "C" int crec_bpr_train_epoch(crec_ctx *ctx, const crec_bpr_tables *t, cre
     a.I = t->I;
     a.B = B;
     a.st = st;
+    a.partial = (float *)ctx->misc.ptr;
     const size_t bytesP = sizeof(float) * (size_t)t->U * t->d, bytesQ = sizeof(float) * (size_t)t->I * t->d;
     if (dense) { // the second buffer set of the ping-pong
         const size_t aP = align_up(bytesP, 256), aQ = align_up(bytesQ, 256);
@@ -842,11 +1074,14 @@ extern "C" int crec_bpr_train_epoch(crec_ctx *ctx, const crec_bpr_tables *t, cre
     for (int64_t b0 = 0; b0 < nb; b0 += chunk) {
         const int64_t nbc = (nb - b0) < chunk ? (nb - b0) : chunk;
         const int64_t t0 = b0 * B, n_chunk = (N - t0) < nbc * B ? (N - t0) : nbc * B;
-        IndexWs w = layout_index(ctx->idx_ws.ptr, nbc, B, t->U, t->I, dense);
+        IndexWs w = layout_index(ctx->idx_ws.ptr, nbc, B, t->U, t->I, dense, CH);
         crec_prof_begin(ctx, CREC_K_INDEX, st);
         hipLaunchKernelGGL(bpr_index_batches, dim3((unsigned)(2 * nbc)), dim3(PREP_THREADS), lds, st, u + t0, i + t0,
                            j + t0, n_chunk, B, w);
         crec_prof_end(ctx, st);
+        std::vector<int32_t> hn((size_t)nbc * 4);
+        CREC_HIP(ctx, hipMemcpyAsync(hn.data(), w.hn, sizeof(int32_t) * hn.size(), hipMemcpyDeviceToHost, st));
+        CREC_HIP(ctx, hipStreamSynchronize(st));
         for (int64_t b = 0; b < nbc; ++b) {
             // lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t) with fp32 running powers (TF1 _prepare/_finish)
             a.h.lr_t = (opt->lr * sqrtf(1.0f - opt->beta2_power)) / (1.0f - opt->beta1_power);
@@ -856,7 +1091,7 @@ extern "C" int crec_bpr_train_epoch(crec_ctx *ctx, const crec_bpr_tables *t, cre
             a.h.reg = opt->reg;
             a.xb = (float *)ctx->loss_ws.ptr + b * loss_stride;
             a.rowterm = a.xb + B;
-            step(a, w, b);
+            step(a, w, b, hn.data() + b * 4);
             if (dense) {
                 Tables tmp = a.cur;
                 a.cur = a.other;

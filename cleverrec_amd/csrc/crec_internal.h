@@ -34,6 +34,7 @@ enum crec_kernel_class {
     CREC_K_EVAL_SWEEP,
     CREC_K_EVAL_MERGE,
     CREC_K_METRICS,
+    CREC_K_FINISH,
     CREC_K_COUNT
 };
 

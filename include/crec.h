@@ -54,7 +54,7 @@ const char *crec_last_error(const crec_ctx *ctx);
  * While enabled, every kernel launch of this ctx is bracketed by two events and each API call
  * ends with a stream synchronise (so do not time whole-job throughput with it on).
  * kernel_class: 0 bpr_index_batches, 1 bpr_step_fused, 2 bpr_user_side, 3 bpr_item_side,
- *               4 bpr_reduce_loss, 5 eval_sweep, 6 eval_merge, 7 rank_metrics.
+ *               4 bpr_reduce_loss, 5 eval_sweep, 6 eval_merge, 7 rank_metrics, 8 bpr_finish_heavy.
  * enable(.., 1) also clears the accumulated totals. */
 int crec_profile_enable(crec_ctx *ctx, int on);
 int crec_profile_read(const crec_ctx *ctx, int kernel_class, double *total_ms, int64_t *launches);

@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""S-big: the HBM-bound form of the BPR hot path (BASELINE.json configs[4] on one GPU).
+
+Synthetic U = 10 M users x I = 1 M items, d = 128 fp32 (tables + Adam slots = 16.9 GB, far
+beyond the 256 MiB Infinity Cache), batch 6144, lazy Adam (only touched rows move; a TF1-exact
+dense sweep would stream all 16.9 GB per step).  Users uniform, positives Zipf(1.0), negatives
+uniform.  Measures the two kernels of the lazy step with HIP events and prices them against
+SURVEY.md 8(d)'s algorithmic bytes: (24d+12) per triple + 28d per unique touched row.
+
+    python tools/bench_big.py [--users 10000000] [--items 1000000] [--dim 128] [--steps 300]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def run(users=10_000_000, items=1_000_000, dim=128, steps=300, warmup=30, batch=6144, sess=None, seed=0):
+    import torch
+    from cleverrec_amd import _lib, runtime
+    sess = sess or runtime.Session(0)
+    dev = sess.device
+    g = torch.Generator(device=dev).manual_seed(seed)
+    st = runtime.BprState.__new__(runtime.BprState)
+    st.sess = sess
+    f32 = torch.float32
+    st.P = torch.empty((users, dim), dtype=f32, device=dev).normal_(0, 0.01, generator=g)
+    st.Q = torch.empty((items, dim), dtype=f32, device=dev).normal_(0, 0.01, generator=g)
+    st.mP, st.vP = torch.zeros_like(st.P), torch.zeros_like(st.P)
+    st.mQ, st.vQ = torch.zeros_like(st.Q), torch.zeros_like(st.Q)
+    st.tables = _lib.BprTables(*(t.data_ptr() for t in (st.P, st.Q, st.mP, st.vP, st.mQ, st.vQ)), users, items, dim)
+    st.adam = _lib.Adam(1e-3, 0.9, 0.999, 1e-8, 0.01, _lib.ADAM_LAZY, 0.9, 0.999, 0)
+
+    n = (steps + warmup) * batch
+    u = torch.randint(0, users, (n,), generator=g, device=dev, dtype=torch.int64).to(torch.int32)
+    w = 1.0 / torch.arange(1, items + 1, dtype=torch.float64, device=dev)
+    cdf = torch.cumsum(w / w.sum(), 0)
+    i = torch.searchsorted(cdf, torch.rand(n, generator=g, device=dev, dtype=torch.float64)).clamp_(max=items - 1).to(torch.int32)
+    j = torch.randint(0, items, (n,), generator=g, device=dev, dtype=torch.int64).to(torch.int32)
+    del cdf, w
+
+    nw = warmup * batch
+    st.train_epoch(u[:nw], i[:nw], j[:nw], batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loss = st.train_epoch(u[nw:], i[nw:], j[nw:], batch)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+
+    sess.ctx.profile(True)
+    st.train_epoch(u[nw:], i[nw:], j[nw:], batch)
+    torch.cuda.synchronize()
+    prof = sess.ctx.profile_read()
+    sess.ctx.profile(False)
+
+    # unique touched rows per batch (sampled) for the 28d Adam term
+    uq_u = uq_q = 0
+    sample = range(0, steps, max(1, steps // 16))
+    for b in sample:
+        sl = slice(nw + b * batch, nw + (b + 1) * batch)
+        uq_u += int(torch.unique(u[sl]).numel())
+        uq_q += int(torch.unique(torch.cat([i[sl], j[sl]])).numel())
+    uq_u /= len(sample)
+    uq_q /= len(sample)
+    d = dim
+    alg_user = batch * (16 * d + 12) + uq_u * 28 * d   # indices + 3 row reads + dL/dp, + Adam on the user rows
+    alg_item = batch * 8 * d + uq_q * 28 * d           # dL/dq_i, dL/dq_j, + Adam on the item rows
+    us = prof["bpr_user_side"][0] / prof["bpr_user_side"][1] * 1e3
+    it = prof["bpr_item_side"][0] / prof["bpr_item_side"][1] * 1e3
+    out = {
+        "workload": "S-big: %d users x %d items, d=%d fp32, batch %d, lazy Adam, Zipf(1.0) positives" % (users, items, dim, batch),
+        "state_GB": (users + items) * dim * 4 * 3 / 1e9,
+        "triples_per_s": steps * batch / dt, "us_per_step": dt / steps * 1e6,
+        "unique_user_rows_per_batch": uq_u, "unique_item_rows_per_batch": uq_q,
+        "bpr_user_side": {"avg_us": us, "algorithmic_bytes": alg_user, "GBs": alg_user / us / 1e3, "frac_of_8TBs": alg_user / us / 1e3 / 8000},
+        "bpr_item_side": {"avg_us": it, "algorithmic_bytes": alg_item, "GBs": alg_item / it / 1e3, "frac_of_8TBs": alg_item / it / 1e3 / 8000},
+        "step_algorithmic_GBs": (alg_user + alg_item) / (dt / steps) / 1e9,
+        "bpr_index_batches_us_per_step": prof["bpr_index_batches"][0] * 1e3 / steps,
+        "loss_first_last": [float(loss[0]), float(loss[-1])],
+    }
+    del st
+    torch.cuda.empty_cache()
+    return out
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--users", type=int, default=10_000_000)
+    ap.add_argument("--items", type=int, default=1_000_000)
+    ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--batch", type=int, default=6144)
+    a = ap.parse_args()
+    print(json.dumps(run(a.users, a.items, a.dim, a.steps, batch=a.batch)))
