@@ -49,24 +49,36 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    force_dp = os.environ.get("CREC_FORCE_DP") == "1"  # rehearse the N > 1 code path on one GPU
+    if world > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     assert world == a.gpus, "--gpus %d but WORLD_SIZE=%d" % (a.gpus, world)
 
     sess = runtime.Session(local_rank)
-    # every rank holds one ml-1m-shaped shard (its own users, its own sampled stream): weak scaling
+    # N > 1 (weak scaling): users are sharded, every rank holds one ml-1m-shaped shard of users (its own
+    # P rows, its own sampled stream of 6144 triples per step); Q is replicated and kept identical by one
+    # RCCL all-reduce of the per-item gradient sums per step (cleverrec_amd/parallel.py).
     data = synthetic("S-ml1m", seed=20240601 + rank)
-    gen = torch.Generator().manual_seed(rank)
-    P0 = torch.empty(data.user_nums, D).normal_(0, 0.01, generator=gen).numpy()
-    Q0 = torch.empty(data.item_nums, D).normal_(0, 0.01, generator=gen).numpy()
-    st = runtime.BprState(sess, P0, Q0, lr=LR, reg=REG, adam_mode="tf1")
+    P0 = torch.empty(data.user_nums, D).normal_(0, 0.01, generator=torch.Generator().manual_seed(1000 + rank)).numpy()
+    Q0 = torch.empty(3706, D).normal_(0, 0.01, generator=torch.Generator().manual_seed(0)).numpy()[:data.item_nums]
+    dp = world > 1 or force_dp
+    if dp:
+        from cleverrec_amd.parallel import DpBprState, agree_min
+        assert agree_min(data.item_nums) == data.item_nums == -agree_min(-data.item_nums), "replicas need one catalogue"
+        st = DpBprState(sess, P0, Q0, lr=LR, reg=REG)
+    else:
+        st = runtime.BprState(sess, P0, Q0, lr=LR, reg=REG, adam_mode="tf1")
 
     sess.ctx.seed(1 + rank)
     t0 = time.perf_counter()
     u, i, j = sess.ctx.sample_pairwise(data.train_csr, data.item_nums, NEG)
     t_sample = time.perf_counter() - t0
     n_epoch = len(u)
+    if dp:
+        n_epoch = agree_min(n_epoch // B) * B  # the dp epoch is collective: same batch count everywhere
+        u, i, j = u[:n_epoch], i[:n_epoch], j[:n_epoch]
     du, di, dj = (sess.to_dev(x) for x in (u, i, j))
 
     def run_steps(k):
@@ -80,7 +92,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dp:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -90,7 +102,7 @@ def main():
     run_steps(a.steps)
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dp:
         tt = torch.tensor([dt], dtype=torch.float64, device=sess.device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -103,7 +115,7 @@ def main():
         "config": {"workload": "BPR on S-ml1m (6040x3706, 1,000,208 interactions, ml-1m marginals), d=64 fp32, "
                                "batch 6144, neg_ratio 4, Adam tf1 semantics (BASELINE.json configs[1])",
                    "users": data.user_nums, "items": data.item_nums, "embed_size": D, "batch_size": B,
-                   "neg_ratio": NEG, "adam_mode": "tf1", "sharding": "one shard (model + stream) per GPU" if world > 1 else "none"},
+                   "neg_ratio": NEG, "adam_mode": "tf1", "sharding": "users sharded (one S-ml1m user shard per GPU), Q replicated, 1 RCCL all-reduce of dQ per step" if world > 1 else "none"},
     }
 
     if rank == 0 and not a.no_extras:
@@ -122,6 +134,8 @@ def main():
             if n:
                 kern[name] = {"avg_us": ms / n * 1e3, "launches": n}
         dom = "bpr_step_fused"
+        if dp:
+            alg[dom] = B * (24 * D + 12) + 24 * D * U + 4 * D * I  # P swept, dQ written; Q is swept by bpr_adam_dense
         avg_s = prof[dom][0] / prof[dom][1] * 1e-3
         ach = alg[dom] / avg_s / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -173,7 +187,7 @@ def main():
                                              % (k, tc, os.cpu_count())}
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if dp:
         dist.destroy_process_group()
 
 

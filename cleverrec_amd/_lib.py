@@ -48,6 +48,10 @@ _SIGNATURES = {
     "crec_sample_pointwise": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, C.c_int, _vp, _vp, _vp, C.POINTER(_i64)]),
     "crec_sample_cml": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, C.c_int, _vp, _vp, _vp, C.POINTER(_i64)]),
     "crec_bpr_train_epoch": (C.c_int, [_vp, C.POINTER(BprTables), C.POINTER(Adam), _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
+    "crec_bpr_train_epoch_dp": (C.c_int, [_vp, C.POINTER(BprTables), C.POINTER(Adam), _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
+    "crec_comm_unique_id": (C.c_int, [_vp, _vp]),
+    "crec_comm_init": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
+    "crec_comm_destroy": (C.c_int, [_vp]),
     "crec_eval_topk": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "crec_rank_metrics": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
@@ -105,7 +109,7 @@ class Context:
 
     # ---- measurement ---------------------------------------------------------------------------
     KERNELS = ("bpr_index_batches", "bpr_step_fused", "bpr_user_side", "bpr_item_side", "bpr_reduce_loss", "eval_sweep",
-               "eval_merge", "rank_metrics", "bpr_finish_heavy")
+               "eval_merge", "rank_metrics", "bpr_finish_heavy", "bpr_adam_dense")
 
     def profile(self, on):
         self.check(self.lib.crec_profile_enable(self.h, int(bool(on))))

@@ -36,6 +36,8 @@
 // bit-reproducible.
 #include "crec_internal.h"
 
+#include <rccl/rccl.h>
+
 namespace {
 
 constexpr int PREP_THREADS = 1024;
@@ -285,6 +287,7 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
 // ------------------------------------------------------------------------------------
 struct Hyper {
     float lr_t, beta1, beta2, eps, reg;
+    float *dQ; // data-parallel step: item rows' gradient sums go here ([I,d], every row written) instead of Adam
 };
 
 struct Tables { // one buffer set
@@ -699,10 +702,14 @@ __device__ inline void row_wave(const Tables &src, const Tables &dst, int d, con
     if (owner) {
         if (l == 0 && (dense || sl.cnt > 0))
             *rowterm_slot = (0.5f * nr) * (float)sl.cnt;
-        adam4(var, m, v, grad, sl.cnt > 0, h);
-        st4((user ? dst.P : dst.Q) + ro, var);
-        st4((user ? dst.mP : dst.mQ) + ro, m);
-        st4((user ? dst.vP : dst.vQ) + ro, v);
+        if (!user && h.dQ) { // the all-reduce + bpr_adam_dense finish this row
+            st4(h.dQ + ro, grad);
+        } else {
+            adam4(var, m, v, grad, sl.cnt > 0, h);
+            st4((user ? dst.P : dst.Q) + ro, var);
+            st4((user ? dst.mP : dst.mQ) + ro, m);
+            st4((user ? dst.vP : dst.vQ) + ro, v);
+        }
     }
 }
 
@@ -850,10 +857,31 @@ __global__ __launch_bounds__(256) void bpr_finish_heavy(Tables src, Tables dst, 
     if (on) {
         if (l == 0)
             rowterm[(user ? 0 : rt_item_base) + (dense ? row : (int64_t)rec.w)] = (0.5f * nr) * (float)cnt;
-        adam4(var, m, v, grad, true, h);
-        st4((user ? dst.P : dst.Q) + ro, var);
-        st4((user ? dst.mP : dst.mQ) + ro, m);
-        st4((user ? dst.vP : dst.vQ) + ro, v);
+        if (!user && h.dQ) {
+            st4(h.dQ + ro, grad);
+        } else {
+            adam4(var, m, v, grad, true, h);
+            st4((user ? dst.P : dst.Q) + ro, var);
+            st4((user ? dst.mP : dst.mQ) + ro, m);
+            st4((user ? dst.vP : dst.vQ) + ro, v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// bpr_adam_dense (data-parallel step): TF1 Adam of every row of Q from the all-reduced gradient.
+// A row no rank touched has g == 0, which is exactly the untouched sweep (m*b1 + 0 == m*b1).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bpr_adam_dense(float *__restrict__ var, float *__restrict__ m,
+                                                      float *__restrict__ v, const float *__restrict__ g, int64_t n4,
+                                                      Hyper h)
+{
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n4; k += (int64_t)gridDim.x * blockDim.x) {
+        float4 a = ld4(var + 4 * k), b = ld4(m + 4 * k), c = ld4(v + 4 * k);
+        adam4(a, b, c, ld4(g + 4 * k), true, h);
+        st4(var + 4 * k, a);
+        st4(m + 4 * k, b);
+        st4(v + 4 * k, c);
     }
 }
 
@@ -994,9 +1022,9 @@ StepFn pick_step(int d, bool dense)
 
 } // namespace
 
-extern "C" int crec_bpr_train_epoch(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, const int32_t *u,
-                                    const int32_t *i, const int32_t *j, int64_t N, int32_t B, float *loss_per_batch,
-                                    void *stream)
+namespace {
+int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, const int32_t *u, const int32_t *i,
+                     const int32_t *j, int64_t N, int32_t B, float *loss_per_batch, void *stream, bool dp)
 {
     if (!ctx)
         return CREC_EINVAL;
@@ -1017,6 +1045,11 @@ extern "C" int crec_bpr_train_epoch(crec_ctx *ctx, const crec_bpr_tables *t, cre
     CREC_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
     const bool dense = opt->adam_mode == CREC_ADAM_TF1;
+    ncclComm_t comm = (ncclComm_t)ctx->comm;
+    if (dp) {
+        CREC_REQUIRE(ctx, comm != nullptr, "crec_comm_init has not been called on this ctx");
+        CREC_REQUIRE(ctx, dense, "the data-parallel step is built for adam_mode tf1");
+    }
     StepFn step = pick_step(t->d, dense);
     const int64_t nb = crec_ceil_div(N, B);
     // occurrences per heavy-row chunk.  tf1 mode pays a second launch per step for split rows, so it
@@ -1056,6 +1089,13 @@ extern "C" int crec_bpr_train_epoch(crec_ctx *ctx, const crec_bpr_tables *t, cre
         char *s = (char *)ctx->shadow.ptr;
         a.other = Tables{(float *)s, (float *)(s + aP), (float *)(s + 2 * aP), (float *)(s + 3 * aP),
                          (float *)(s + 3 * aP + aQ), (float *)(s + 3 * aP + 2 * aQ)};
+        if (dp) { // Q does not ping-pong: the fused launch only emits dQ, bpr_adam_dense updates Q in place
+            a.other.Q = a.cur.Q;
+            a.other.mQ = a.cur.mQ;
+            a.other.vQ = a.cur.vQ;
+            if (int rc = crec_reserve(ctx, &ctx->dq, bytesQ))
+                return rc;
+        }
     } else {
         if (int rc = crec_reserve(ctx, &ctx->contrib, sizeof(float) * (size_t)B * t->d))
             return rc;
@@ -1089,9 +1129,23 @@ extern "C" int crec_bpr_train_epoch(crec_ctx *ctx, const crec_bpr_tables *t, cre
             a.h.beta2 = opt->beta2;
             a.h.eps = opt->eps;
             a.h.reg = opt->reg;
+            a.h.dQ = dp ? (float *)ctx->dq.ptr : nullptr;
             a.xb = (float *)ctx->loss_ws.ptr + b * loss_stride;
             a.rowterm = a.xb + B;
             step(a, w, b, hn.data() + b * 4);
+            if (dp) {
+                // the one exchange of the path: per-item gradient sums over all ranks' triples
+                float *dq = (float *)ctx->dq.ptr;
+                const size_t nq = (size_t)t->I * t->d;
+                if (ncclAllReduce(dq, dq, nq, ncclFloat, ncclSum, comm, st) != ncclSuccess)
+                    return crec_fail(ctx, CREC_EHIP, "ncclAllReduce(dQ) failed");
+                crec_prof_begin(ctx, CREC_K_ADAM_DENSE, st);
+                const int64_t n4 = (int64_t)nq / 4;
+                const unsigned blocks = (unsigned)(crec_ceil_div(n4, 256) < 2048 ? crec_ceil_div(n4, 256) : 2048);
+                hipLaunchKernelGGL(bpr_adam_dense, dim3(blocks), dim3(256), 0, st, t->Q, t->mQ, t->vQ, (const float *)dq, n4,
+                                   a.h);
+                crec_prof_end(ctx, st);
+            }
             if (dense) {
                 Tables tmp = a.cur;
                 a.cur = a.other;
@@ -1107,6 +1161,9 @@ extern "C" int crec_bpr_train_epoch(crec_ctx *ctx, const crec_bpr_tables *t, cre
                            loss_stride, n_chunk, B, dense ? t->U + t->I : (int64_t)0, (const int32_t *)w.n_u,
                            (const int32_t *)w.n_q, opt->reg, loss_per_batch + b0);
         crec_prof_end(ctx, st);
+        if (dp && ncclAllReduce(loss_per_batch + b0, loss_per_batch + b0, (size_t)nbc, ncclFloat, ncclSum, comm, st) !=
+                      ncclSuccess)
+            return crec_fail(ctx, CREC_EHIP, "ncclAllReduce(loss) failed");
         CREC_HIP(ctx, hipGetLastError());
         if (int rc = crec_prof_flush(ctx, st))
             return rc;
@@ -1116,9 +1173,70 @@ extern "C" int crec_bpr_train_epoch(crec_ctx *ctx, const crec_bpr_tables *t, cre
         CREC_HIP(ctx, hipMemcpyAsync(t->P, s.P, bytesP, hipMemcpyDeviceToDevice, st));
         CREC_HIP(ctx, hipMemcpyAsync(t->mP, s.mP, bytesP, hipMemcpyDeviceToDevice, st));
         CREC_HIP(ctx, hipMemcpyAsync(t->vP, s.vP, bytesP, hipMemcpyDeviceToDevice, st));
-        CREC_HIP(ctx, hipMemcpyAsync(t->Q, s.Q, bytesQ, hipMemcpyDeviceToDevice, st));
-        CREC_HIP(ctx, hipMemcpyAsync(t->mQ, s.mQ, bytesQ, hipMemcpyDeviceToDevice, st));
-        CREC_HIP(ctx, hipMemcpyAsync(t->vQ, s.vQ, bytesQ, hipMemcpyDeviceToDevice, st));
+        if (s.Q != t->Q) {
+            CREC_HIP(ctx, hipMemcpyAsync(t->Q, s.Q, bytesQ, hipMemcpyDeviceToDevice, st));
+            CREC_HIP(ctx, hipMemcpyAsync(t->mQ, s.mQ, bytesQ, hipMemcpyDeviceToDevice, st));
+            CREC_HIP(ctx, hipMemcpyAsync(t->vQ, s.vQ, bytesQ, hipMemcpyDeviceToDevice, st));
+        }
     }
     return CREC_OK;
 }
+} // namespace
+
+extern "C" {
+
+int crec_bpr_train_epoch(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, const int32_t *u, const int32_t *i,
+                         const int32_t *j, int64_t N, int32_t B, float *loss_per_batch, void *stream)
+{
+    return train_epoch_impl(ctx, t, opt, u, i, j, N, B, loss_per_batch, stream, false);
+}
+
+int crec_bpr_train_epoch_dp(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, const int32_t *u,
+                            const int32_t *i, const int32_t *j, int64_t N, int32_t B, float *loss_per_batch,
+                            void *stream)
+{
+    return train_epoch_impl(ctx, t, opt, u, i, j, N, B, loss_per_batch, stream, true);
+}
+
+int crec_comm_unique_id(crec_ctx *ctx, void *id_out)
+{
+    if (!ctx || !id_out)
+        return CREC_EINVAL;
+    static_assert(sizeof(ncclUniqueId) == CREC_UNIQUE_ID_BYTES, "unique id size");
+    if (ncclGetUniqueId((ncclUniqueId *)id_out) != ncclSuccess)
+        return crec_fail(ctx, CREC_EHIP, "ncclGetUniqueId failed");
+    return CREC_OK;
+}
+
+int crec_comm_init(crec_ctx *ctx, int rank, int world, const void *id)
+{
+    if (!ctx)
+        return CREC_EINVAL;
+    CREC_REQUIRE(ctx, ctx->device >= 0, "host-only ctx: no device bound");
+    CREC_REQUIRE(ctx, id && world >= 1 && rank >= 0 && rank < world, "bad rank/world");
+    CREC_REQUIRE(ctx, ctx->comm == nullptr, "communicator already initialised");
+    CREC_HIP(ctx, hipSetDevice(ctx->device));
+    ncclUniqueId uid;
+    std::memcpy(&uid, id, sizeof(uid));
+    ncclComm_t comm = nullptr;
+    ncclResult_t r = ncclCommInitRank(&comm, world, uid, rank);
+    if (r != ncclSuccess)
+        return crec_fail(ctx, CREC_EHIP, "ncclCommInitRank failed: %s", ncclGetErrorString(r));
+    ctx->comm = comm;
+    ctx->rank = rank;
+    ctx->world = world;
+    return CREC_OK;
+}
+
+int crec_comm_destroy(crec_ctx *ctx)
+{
+    if (!ctx)
+        return CREC_EINVAL;
+    if (ctx->comm) {
+        ncclCommDestroy((ncclComm_t)ctx->comm);
+        ctx->comm = nullptr;
+    }
+    return CREC_OK;
+}
+
+} // extern "C"

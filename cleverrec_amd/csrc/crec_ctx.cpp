@@ -152,8 +152,9 @@ void crec_ctx_destroy(crec_ctx *ctx)
     if (ctx->device >= 0) {
         (void)hipSetDevice(ctx->device);
         (void)hipDeviceSynchronize();
+        (void)crec_comm_destroy(ctx);
         crec_devbuf *bufs[] = {&ctx->idx_ws, &ctx->contrib, &ctx->loss_ws, &ctx->lr_table,
-                               &ctx->misc,   &ctx->eval_ws, &ctx->ks_dev, &ctx->shadow};
+                               &ctx->misc,   &ctx->eval_ws, &ctx->ks_dev, &ctx->shadow, &ctx->dq};
         for (crec_devbuf *b : bufs)
             if (b->ptr)
                 (void)hipFree(b->ptr);

@@ -35,6 +35,7 @@ enum crec_kernel_class {
     CREC_K_EVAL_MERGE,
     CREC_K_METRICS,
     CREC_K_FINISH,
+    CREC_K_ADAM_DENSE,
     CREC_K_COUNT
 };
 
@@ -58,6 +59,9 @@ struct crec_ctx {
     // BPR training workspace (bpr_train.hip)
     crec_devbuf idx_ws;   // per-batch inverted indices of one chunk of batches
     crec_devbuf contrib;  // [B, d] per-triple contribution rows s_b * p_u (lazy mode)
+    crec_devbuf dq;       // data-parallel step: dense per-item gradient sums [I, d]
+    void *comm = nullptr; // ncclComm_t (RCCL), set by crec_comm_init
+    int rank = 0, world = 1;
     crec_devbuf shadow;   // second buffer set of the tf1-mode ping-pong: P, mP, vP, Q, mQ, vQ
     crec_devbuf loss_ws;  // per-triple loss terms of one chunk
     crec_devbuf lr_table; // per-step lr_t of one chunk

@@ -54,7 +54,7 @@ const char *crec_last_error(const crec_ctx *ctx);
  * While enabled, every kernel launch of this ctx is bracketed by two events and each API call
  * ends with a stream synchronise (so do not time whole-job throughput with it on).
  * kernel_class: 0 bpr_index_batches, 1 bpr_step_fused, 2 bpr_user_side, 3 bpr_item_side,
- *               4 bpr_reduce_loss, 5 eval_sweep, 6 eval_merge, 7 rank_metrics, 8 bpr_finish_heavy.
+ *               4 bpr_reduce_loss, 5 eval_sweep, 6 eval_merge, 7 rank_metrics, 8 bpr_finish_heavy, 9 bpr_adam_dense.
  * enable(.., 1) also clears the accumulated totals. */
 int crec_profile_enable(crec_ctx *ctx, int on);
 int crec_profile_read(const crec_ctx *ctx, int kernel_class, double *total_ms, int64_t *launches);
@@ -116,6 +116,23 @@ typedef struct {
  * train_model's return value is mean(loss_per_batch) (:61).  B <= 8192. */
 int crec_bpr_train_epoch(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, const int32_t *u, const int32_t *i,
                          const int32_t *j, int64_t N, int32_t B, float *loss_per_batch, void *stream);
+
+/* ---- data-parallel training over RCCL (one process per GPU of one node) -----------------------
+ * The path shards with one real exchange: gradients of the same Q row must be summed over all ranks'
+ * triples before Adam.  Users (rows of P, their slots, their triples) are sharded over ranks, Q and its
+ * slots are replicated; every step each rank emits its dense partial dQ, one ncclAllReduce sums it,
+ * and every replica applies the identical tf1 Adam update (replicas stay bit-identical).
+ *   crec_comm_unique_id : rank 0 creates the 128-byte RCCL id; the caller ships it to the other ranks
+ *   crec_comm_init      : collective over all ranks (ncclCommInitRank on the ctx's device)
+ *   crec_bpr_train_epoch_dp : like crec_bpr_train_epoch on this rank's shard (t->P = this rank's user
+ *       rows, u = row ids inside the shard, t->Q = the replica).  Collective: every rank must pass the
+ *       same number of batches ceil(N/B).  loss_per_batch receives the sum over ranks.  adam_mode tf1. */
+#define CREC_UNIQUE_ID_BYTES 128
+int crec_comm_unique_id(crec_ctx *ctx, void *id_out);
+int crec_comm_init(crec_ctx *ctx, int rank, int world, const void *id);
+int crec_comm_destroy(crec_ctx *ctx);
+int crec_bpr_train_epoch_dp(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, const int32_t *u, const int32_t *i,
+                            const int32_t *j, int64_t N, int32_t B, float *loss_per_batch, void *stream);
 
 /* ---- full-catalogue evaluation (device) -------------------------------------------------
  * replaces sess.run(self.pre_scores) (BPR._predict rs branch, BPR.py:51) + np.argsort +

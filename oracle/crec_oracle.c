@@ -517,3 +517,58 @@ void orc_rank_metrics(const int32_t *topk_ids, const int32_t *users, int64_t Bt,
         }
     }
 }
+
+/* ------------------------------------------------------------------------
+ * Data-parallel form of the same step: users sharded over ranks, Q replicated.
+ * orc_bpr_dp_local: this rank's triples -> tf1 Adam on its P shard, dense partial dQ [I,d]
+ *                   (i-slices then j-slices, position order), local loss.
+ * orc_adam_dense  : tf1 Adam of every Q row from the rank-summed gradient (a row nobody touched has
+ *                   g == 0, which is exactly the untouched sweep).
+ * Summing dQ over ranks and applying orc_adam_dense on every replica equals orc_bpr_step on the
+ * concatenated batch up to fp32 add order.
+ * --------------------------------------------------------------------- */
+void orc_bpr_dp_local(float *P, const float *Q, float *mP, float *vP, int64_t U, int64_t I, int d, const int32_t *u,
+                      const int32_t *i, const int32_t *j, int64_t B, float reg, float lr_t, float beta1, float beta2,
+                      float eps, float *gP, int32_t *cntP, float *dQ, double *loss_out)
+{
+    memset(gP, 0, sizeof(float) * (size_t)U * d);
+    memset(cntP, 0, sizeof(int32_t) * (size_t)U);
+    memset(dQ, 0, sizeof(float) * (size_t)I * d);
+    double loss = 0.0;
+    float *sb = (float *)malloc(sizeof(float) * (size_t)(B > 0 ? B : 1));
+    for (int64_t b = 0; b < B; b++) {
+        const float *pu = P + (int64_t)u[b] * d, *qi = Q + (int64_t)i[b] * d, *qj = Q + (int64_t)j[b] * d;
+        float x = dotf(pu, qi, d) - dotf(pu, qj, d);
+        float s = 1.0f / (1.0f + expf(x));
+        sb[b] = s;
+        float l2 = 0.5f * dotf(pu, pu, d) + 0.5f * dotf(qi, qi, d) + 0.5f * dotf(qj, qj, d);
+        loss += (double)tf_softplus(-x) + (double)(reg * l2);
+        float *g = gP + (int64_t)u[b] * d;
+        for (int k = 0; k < d; k++)
+            g[k] = g[k] + ((-s) * (qi[k] - qj[k]) + reg * pu[k]);
+        cntP[u[b]]++;
+    }
+    for (int64_t b = 0; b < B; b++) {
+        const float *pu = P + (int64_t)u[b] * d, *qi = Q + (int64_t)i[b] * d;
+        float *g = dQ + (int64_t)i[b] * d;
+        for (int k = 0; k < d; k++)
+            g[k] = g[k] + ((-sb[b]) * pu[k] + reg * qi[k]);
+    }
+    for (int64_t b = 0; b < B; b++) {
+        const float *pu = P + (int64_t)u[b] * d, *qj = Q + (int64_t)j[b] * d;
+        float *g = dQ + (int64_t)j[b] * d;
+        for (int k = 0; k < d; k++)
+            g[k] = g[k] + (sb[b] * pu[k] + reg * qj[k]);
+    }
+    for (int64_t r = 0; r < U; r++)
+        adam_row(P + r * d, mP + r * d, vP + r * d, cntP[r] ? gP + r * d : NULL, d, lr_t, beta1, beta2, eps);
+    free(sb);
+    *loss_out = loss;
+}
+
+void orc_adam_dense(float *var, float *m, float *v, const float *g, int64_t rows, int d, float lr_t, float beta1,
+                    float beta2, float eps)
+{
+    for (int64_t r = 0; r < rows; r++)
+        adam_row(var + r * d, m + r * d, v + r * d, g + r * d, d, lr_t, beta1, beta2, eps);
+}

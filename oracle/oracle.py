@@ -16,7 +16,7 @@ _SO = os.path.join(_HERE, "liboracle.so")
 __all__ = [
     "build", "Rng", "to_csr", "dict_from_csr", "sample_pairwise", "sample_pointwise", "sample_cml",
     "AdamSchedule", "BprModel", "bpr_step", "scores", "topk", "rank_metrics",
-    "cal_ranking_metrics_py", "test_model_rs_py", "train_model_py", "tf_softplus_np",
+    "cal_ranking_metrics_py", "test_model_rs_py", "train_model_py", "tf_softplus_np", "bpr_dp_local", "adam_dense",
 ]
 
 
@@ -290,3 +290,22 @@ def tf_softplus_np(z):
     z = np.asarray(z, dtype=np.float32)
     thr = np.float32(np.log(np.float32(1.1920929e-07)) + 2.0)
     return np.where(z > -thr, z, np.where(z < thr, np.exp(z), np.log1p(np.exp(z)))).astype(np.float32)
+
+
+def bpr_dp_local(m, u, i, j, lr_t):
+    """Data-parallel local half of a step (orc_bpr_dp_local): updates m.P in place, returns (dQ, loss)."""
+    u, i, j = (np.ascontiguousarray(x, dtype=np.int32) for x in (u, i, j))
+    dQ = np.empty_like(m.Q)
+    loss = C.c_double()
+    U, d = m.P.shape
+    lib().orc_bpr_dp_local(_p(m.P), _p(m.Q), _p(m.mP), _p(m.vP), C.c_int64(U), C.c_int64(len(m.Q)), C.c_int(d), _p(u),
+                           _p(i), _p(j), C.c_int64(len(u)), C.c_float(m.reg), C.c_float(lr_t), C.c_float(m.sched.beta1),
+                           C.c_float(m.sched.beta2), C.c_float(m.sched.eps), _p(m._gP), _p(m._cP), _p(dQ), C.byref(loss))
+    return dQ, loss.value
+
+
+def adam_dense(m, g, lr_t):
+    """tf1 Adam of every Q row from the summed gradient (orc_adam_dense)."""
+    g = np.ascontiguousarray(g, dtype=np.float32)
+    lib().orc_adam_dense(_p(m.Q), _p(m.mQ), _p(m.vQ), _p(g), C.c_int64(len(m.Q)), C.c_int(m.Q.shape[1]), C.c_float(lr_t),
+                         C.c_float(m.sched.beta1), C.c_float(m.sched.beta2), C.c_float(m.sched.eps))

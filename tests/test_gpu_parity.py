@@ -255,3 +255,35 @@ def test_model_class_end_to_end(sess, tmp_path):
         np.testing.assert_allclose(NDCG[kid], N[kid], rtol=1e-12)
         np.testing.assert_allclose(MRR[kid], M[kid], rtol=1e-12)
     assert os.path.exists(m.save())
+
+
+def test_data_parallel_epoch_world1_matches_oracle(sess):
+    """crec_bpr_train_epoch_dp with a 1-rank RCCL communicator: the same kernels, collectives and dense
+    Adam the multi-GPU bench runs, against the oracle's data-parallel restatement and the fused step."""
+    from cleverrec_amd.parallel import DpBprState
+    data = _toy_data(21, 260, 140, 2, 30)
+    d, B = 64, 512
+    P0, Q0 = _tables(22, data.user_nums, data.item_nums, d)
+    s2 = runtime.Session(0)  # its own ctx: a communicator is bound to a ctx for life
+    try:
+        st = DpBprState(s2, P0, Q0, lr=1e-3, reg=0.01, rank=0, world=1)
+        ref = runtime.BprState(sess, P0, Q0, lr=1e-3, reg=0.01, adam_mode="tf1")
+        om = oracle.BprModel(P0, Q0, lr=1e-3, reg=0.01)
+        s2.ctx.seed(3)
+        u, i, j = s2.ctx.sample_pairwise(data.train_csr, data.item_nums, 4)
+        loss = st.train_epoch(s2.to_dev(u), s2.to_dev(i), s2.to_dev(j), B).cpu().numpy()
+        rloss = ref.train_epoch(sess.to_dev(u), sess.to_dev(i), sess.to_dev(j), B).cpu().numpy()
+        ol = []
+        for b in range(len(loss)):
+            sl = slice(b * B, (b + 1) * B)
+            lr_t = float(om.sched.next(1)[0])
+            dQ, l = oracle.bpr_dp_local(om, u[sl], i[sl], j[sl], lr_t)
+            oracle.adam_dense(om, dQ, lr_t)
+            ol.append(l)
+        np.testing.assert_allclose(loss, ol, rtol=1e-5)
+        np.testing.assert_allclose(loss, rloss, rtol=1e-6)
+        for name in ("P", "Q", "mQ"):
+            np.testing.assert_allclose(getattr(st, name).cpu().numpy(), getattr(om, name), rtol=0, atol=2e-6, err_msg=name)
+            np.testing.assert_allclose(getattr(st, name).cpu().numpy(), getattr(ref, name).cpu().numpy(), rtol=0, atol=2e-6)
+    finally:
+        s2.close()
