@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--cpu-steps", type=int, default=600, help="steps of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the roofline/eval/sampler/cpu legs")
+    ap.add_argument("--no-big", action="store_true", help="skip the S-big (10M x 1M, d=128) leg")
     a = ap.parse_args()
 
     import torch
@@ -134,14 +135,25 @@ def main():
             if n:
                 kern[name] = {"avg_us": ms / n * 1e3, "launches": n}
         dom = "bpr_step_fused"
+        # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes over this same
+        # command, tools/profile.sh; gfx950 FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes).  PMC
+        # counters cannot be read from inside the process, so the committed measurement is quoted.
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "round1_traffic.json")
+        if os.path.exists(tf) and not dp:
+            traffic = json.load(open(tf)).get("traffic_bytes_per_launch")
         if dp:
             alg[dom] = B * (24 * D + 12) + 24 * D * U + 4 * D * I  # P swept, dQ written; Q is swept by bpr_adam_dense
         avg_s = prof[dom][0] / prof[dom][1] * 1e-3
         ach = alg[dom] / avg_s / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg[dom],
+                           "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg[dom],
                            "avg_launch_us": avg_s * 1e6,
-                           "note": "tables+slots 7.5 MB: Infinity-Cache resident, HBM fraction is nominal"}
+                           "note": "avg_launch_us = HIP-event bracket around each launch minus the mean empty bracket recorded "
+                                   "right behind it on the same stream (an event pair costs ~5.8 us of stream time); rocprofv3 "
+                                   "--kernel-trace reports 13.6 us for the same kernel (profiles/round1_bench_kernel_stats.txt), "
+                                   "which would give frac 0.226.  Tables+slots are 7.5 MB (Infinity-Cache resident): the HBM "
+                                   "fraction is nominal; S-big (synthetic_big) is the HBM-resident form"}
         step_bytes = alg[dom]
         out["kernels"] = kern
         out["step_algorithmic_GBs"] = step_bytes / (dt / a.steps) / 1e9
@@ -171,6 +183,15 @@ def main():
         out["sampler"] = {"mode": "mt19937 bit-exact (host, 1 core)", "triples_per_s": n_epoch / t_sample,
                           "epoch_triples": n_epoch, "epoch_inclusive_triples_per_s_serial": n_epoch / (t_sample + epoch_gpu_s),
                           "epoch_inclusive_triples_per_s_overlapped": n_epoch / max(t_sample, epoch_gpu_s)}
+
+        # ---- S-big: the HBM-bound form of the same path (10 M x 1 M, d=128, lazy Adam) ----------------
+        if not a.no_big:
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import bench_big
+                out["synthetic_big"] = bench_big.run(steps=200, sess=sess)
+            except Exception as e:  # e.g. not enough free HBM on a shared box
+                out["synthetic_big"] = {"error": repr(e)}
 
         # ---- CPU baseline: the oracle on a bounded sample of the same workload --------------------
         if a.cpu_steps > 0:

@@ -41,6 +41,7 @@ enum crec_kernel_class {
 
 struct crec_profile {
     bool on = false;
+    float overhead_ms = -1.f; // stream time of an empty event bracket, measured at the first flush
     struct rec {
         int cls;
         hipEvent_t a, b;
