@@ -190,6 +190,8 @@ def main():
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import bench_big
                 out["synthetic_big"] = bench_big.run(steps=200, sess=sess)
+                import bench_eval_big
+                out["eval_big"] = bench_eval_big.run(sess=sess, reps=2)  # 65536 users x 1 M items: MFMA utilisation
             except Exception as e:  # e.g. not enough free HBM on a shared box
                 out["synthetic_big"] = {"error": repr(e)}
 
