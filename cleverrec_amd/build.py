@@ -21,6 +21,8 @@ SOURCES = {
     "crec_sampler.cpp": ["-fno-math-errno"],
     "bpr_train.hip": ["-ffp-contract=off"],
     "eval_topk.hip": [],
+    "rows_adam.hip": ["-ffp-contract=off"],
+    "ncf.hip": ["-ffp-contract=off"],
 }
 
 

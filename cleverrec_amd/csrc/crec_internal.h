@@ -36,6 +36,10 @@ enum crec_kernel_class {
     CREC_K_METRICS,
     CREC_K_FINISH,
     CREC_K_ADAM_DENSE,
+    CREC_K_ROWS_INDEX,
+    CREC_K_ROWS_APPLY,
+    CREC_K_SMALL_ADAM,
+    CREC_K_NCF_TILE,
     CREC_K_COUNT
 };
 

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from .. import runtime
-from ..utils.sampler import pairwise_ranking_sampler
+from ..utils.sampler import pairwise_ranking_sampler, pointwise_ranking_sampler
 from ..utils.tools import timer
 from .Recommender import Recommender
 
@@ -36,12 +36,16 @@ class RankingRecommender(Recommender):
 
     # -- one epoch (RankingRecommender.py:33-61) -------------------------------------------------
     def train_model(self):
-        if self.is_pairwise != 'True':
-            raise NotImplementedError("pointwise training belongs to the GMF/MLP/NeuMF kernels (next tier)")
-        train_ = pairwise_ranking_sampler(self.data, self.neg_ratio, self.batch_size, fism_like=self.fism_like)
         s = self.sess
-        u, i, j = (s.to_dev(a) for a in train_[1:4])
-        losses = self._train_epoch_device(u, i, j)
+        if self.is_pairwise == 'True':
+            train_ = pairwise_ranking_sampler(self.data, self.neg_ratio, self.batch_size, fism_like=self.fism_like)
+            u, i, j = (s.to_dev(a) for a in train_[1:4])
+            losses = self._train_epoch_device(u, i, j)
+        else:  # pointwise: (u, i, label) instances (RankingRecommender.py:48-58)
+            train_ = pointwise_ranking_sampler(self.data, self.neg_ratio, self.batch_size, fism_like=self.fism_like)
+            u, i = s.to_dev(train_[1]), s.to_dev(train_[2])
+            y = s.to_dev(np.asarray(train_[3], dtype=np.float32))
+            losses = self._train_epoch_device(u, i, y)
         total_loss = float(losses.double().sum().item())  # total_loss += loss_val over the batches
         return total_loss / train_[0]
 

@@ -92,3 +92,53 @@ def rank_metrics(sess, topk_ids, users, ks, test_ptr, test_items):
                                               sess.stream_ptr()))
     torch.cuda.current_stream(sess.device).synchronize()  # ks_h is read by an async copy
     return out
+
+
+class NcfState:
+    """Variables of GMF / MLP / NeuMF in HBM (crec_ncf): embedding tables + ONE flat block holding
+    W_0|b_0|...|h with named views, Adam slots for all, and the optimizer scalars.
+
+    kind: 'GMF' | 'MLP' | 'NeuMF'.  tables: dict with 'P_gmf','Q_gmf' and/or 'P_mlp','Q_mlp' (numpy/torch).
+    Ws, bs: lists of tower weights/biases (MLP, NeuMF); h: head vector."""
+
+    KINDS = {"GMF": _lib.NCF_GMF, "MLP": _lib.NCF_MLP, "NeuMF": _lib.NCF_NEUMF}
+
+    def __init__(self, sess, kind, tables, Ws, bs, h, lr, reg_gmf=0.0, reg_mlp=0.0, beta1=0.9, beta2=0.999, eps=1e-8):
+        self.sess, self.kind = sess, kind
+        f32 = torch.float32
+        self.t, self.slots = {}, {}
+        for k, a in tables.items():
+            self.t[k] = sess.to_dev(a, f32).contiguous()
+            self.slots[k] = (torch.zeros_like(self.t[k]), torch.zeros_like(self.t[k]))
+        flat = [np.asarray(x, dtype=np.float32).reshape(-1) for pair in zip(Ws, bs) for x in pair] + \
+               [np.asarray(h, dtype=np.float32).reshape(-1)]
+        self.small = sess.to_dev(np.concatenate(flat), f32)
+        self.small_m, self.small_v = torch.zeros_like(self.small), torch.zeros_like(self.small)
+        # named views into the flat block
+        self.W, self.b, off = [], [], 0
+        for W, b in zip(Ws, bs):
+            W, b = np.asarray(W), np.asarray(b)
+            self.W.append(self.small[off:off + W.size].view(*W.shape))
+            off += W.size
+            self.b.append(self.small[off:off + b.size])
+            off += b.size
+        self.h = self.small[off:]
+
+        def param(name):
+            if name not in self.t:
+                return _lib.Param(None, None, None, 0, 0)
+            t, (m, v) = self.t[name], self.slots[name]
+            return _lib.Param(t.data_ptr(), m.data_ptr(), v.data_ptr(), t.shape[0], t.shape[1])
+        small = _lib.Param(self.small.data_ptr(), self.small_m.data_ptr(), self.small_v.data_ptr(), 1, self.small.numel())
+        self.model = _lib.Ncf(self.KINDS[kind], param("P_gmf"), param("Q_gmf"), param("P_mlp"), param("Q_mlp"), len(Ws), small,
+                              reg_gmf, reg_mlp)
+        self.adam = _lib.Adam(lr, beta1, beta2, eps, 0.0, _lib.ADAM_TF1, beta1, beta2, 0)
+
+    def train_epoch(self, u, i, y, batch_size):
+        """u, i int32, y float32 device tensors [N] -> per-batch summed losses (device fp32)."""
+        s = self.sess
+        n = int(u.numel())
+        loss = s.empty((-(-n // batch_size),), torch.float32)
+        s.ctx.check(s.lib.crec_ncf_train_epoch(s.ctx.h, C.byref(self.model), C.byref(self.adam), s.ptr(u), s.ptr(i), s.ptr(y),
+                                               n, int(batch_size), s.ptr(loss), s.stream_ptr()))
+        return loss

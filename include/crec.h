@@ -54,7 +54,8 @@ const char *crec_last_error(const crec_ctx *ctx);
  * While enabled, every kernel launch of this ctx is bracketed by two events and each API call
  * ends with a stream synchronise (so do not time whole-job throughput with it on).
  * kernel_class: 0 bpr_index_batches, 1 bpr_step_fused, 2 bpr_user_side, 3 bpr_item_side,
- *               4 bpr_reduce_loss, 5 eval_sweep, 6 eval_merge, 7 rank_metrics, 8 bpr_finish_heavy, 9 bpr_adam_dense.
+ *               4 bpr_reduce_loss, 5 eval_sweep, 6 eval_merge, 7 rank_metrics, 8 bpr_finish_heavy, 9 bpr_adam_dense,
+ *               10 rows_index_batches, 11 rows_apply, 12 small_adam_dense, 13 ncf_tile.
  * enable(.., 1) also clears the accumulated totals. */
 int crec_profile_enable(crec_ctx *ctx, int on);
 int crec_profile_read(const crec_ctx *ctx, int kernel_class, double *total_ms, int64_t *launches);
@@ -116,6 +117,37 @@ typedef struct {
  * train_model's return value is mean(loss_per_batch) (:61).  B <= 8192. */
 int crec_bpr_train_epoch(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, const int32_t *u, const int32_t *i,
                          const int32_t *j, int64_t N, int32_t B, float *loss_per_batch, void *stream);
+
+/* ---- pointwise NCF family: GMF / MLP / NeuMF (device) --------------------------------------------
+ * replaces, per batch, sess.run([self.train, self.loss], {u_idx, i_idx, y}) (model/RankingRecommender.py:52-58)
+ * on the graphs of model/ranking/GMF.py:29-57, MLP.py:31-77, NeuMF.py:33-105 (sigmoid cross-entropy,
+ * utils/tools.py:68-69; l2 on the gathered rows; AdamOptimizer: embedding tables take the IndexedSlices
+ * path and are swept on every row, the small parameters take dense ApplyAdam).
+ * A crec_param is a dense row-major fp32 variable with its Adam slots, all caller-owned [dev]. */
+typedef struct {
+    float *var, *m, *v;
+    int64_t rows;
+    int32_t cols;
+} crec_param;
+
+#define CREC_NCF_GMF 0
+#define CREC_NCF_MLP 1
+#define CREC_NCF_NEUMF 2
+
+typedef struct {
+    int32_t kind;            /* CREC_NCF_* */
+    crec_param P_gmf, Q_gmf; /* [U,d], [I,d]: 'GMF_params/P','Q' or 'NeuMF_params/P_gmf','Q_gmf' (unused for MLP) */
+    crec_param P_mlp, Q_mlp; /* [U,L0/2], [I,L0/2]: 'MLP_params/P','Q' or 'NeuMF_params/P_mlp','Q_mlp' (unused for GMF) */
+    int32_t n_layers;        /* tower depth (<= 4); layer k maps width w_k = L0 / 2^k to w_k / 2 (MLP.py:34-37) */
+    crec_param small;        /* ONE flat block [1, n]: W_0 | b_0 | W_1 | b_1 | ... | h, W_k row-major [w_k, w_k/2];
+                                h = h_gmf [d] (GMF), h_mlp [last] (MLP), h_neumf [d + last] (NeuMF) */
+    float reg_gmf, reg_mlp;  /* l2 weights of the gmf / mlp rows (configs 'reg' | 'reg_gmf' | 'reg1', 'reg_mlp' | 'reg2') */
+} crec_ncf;
+
+/* u, i int32 [N], y float [N] [dev]: the shuffled instances of pointwise_ranking_sampler; batches are the
+ * contiguous slices of RankingRecommender.train_model (:51-58); loss_per_batch [ceil(N/B)] [dev]. */
+int crec_ncf_train_epoch(crec_ctx *ctx, const crec_ncf *model, crec_adam *opt, const int32_t *u, const int32_t *i,
+                         const float *y, int64_t N, int32_t B, float *loss_per_batch, void *stream);
 
 /* ---- data-parallel training over RCCL (one process per GPU of one node) -----------------------
  * The path shards with one real exchange: gradients of the same Q row must be summed over all ranks'

@@ -1,0 +1,210 @@
+"""CPU restatement (PyTorch fp32 autograd) of the reference's other hot-path graphs:
+GMF / MLP / NeuMF (pointwise, sigmoid cross-entropy), CML, FM -- TEST INFRASTRUCTURE ONLY.
+
+Each forward follows the reference's graph definition line by line (citations per function); the
+backward is autograd; the optimizer is a restatement of TF1's AdamOptimizer with its two code paths:
+
+  * 'sparse' (variables reached only through embedding_lookup / gather: IndexedSlices gradients ->
+    _apply_sparse_shared):  m = m*b1 + g*(1-b1);  v = v*b2 + g*g*(1-b2);  var -= lr_t*m/(sqrt(v)+eps),
+    m, v and var swept on EVERY row (an untouched row is the g = 0 case of the same formula);
+  * 'dense' (ApplyAdam kernel):  m += (g-m)*(1-b1);  v += (g*g-v)*(1-b2);  var -= (m*lr_t)/(sqrt(v)+eps).
+
+lr_t = lr*sqrt(1-b2^t)/(1-b1^t) with fp32 running powers.  Parity is unpinned at the TF boundary
+(TensorFlow is absent, reference README.md:57); see DESIGN.md 2.
+"""
+import numpy as np
+import torch
+
+f32 = torch.float32
+
+
+class TF1Adam:
+    def __init__(self, params, kinds, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+        """params: dict name -> tensor (updated in place); kinds: dict name -> 'sparse' | 'dense'."""
+        self.p, self.kinds = params, kinds
+        self.lr, self.b1, self.b2, self.eps = (np.float32(x) for x in (lr, beta1, beta2, eps))
+        self.b1p, self.b2p = np.float32(beta1), np.float32(beta2)
+        self.m = {k: torch.zeros_like(v) for k, v in params.items()}
+        self.v = {k: torch.zeros_like(v) for k, v in params.items()}
+
+    def step(self, grads):
+        lr_t = np.float32(np.float32(self.lr * np.sqrt(np.float32(1) - self.b2p)) / (np.float32(1) - self.b1p))
+        omb1, omb2 = np.float32(1) - self.b1, np.float32(1) - self.b2
+        for k, g in grads.items():
+            if g is None:
+                continue  # minimize() skips variables without a gradient
+            var, m, v = self.p[k], self.m[k], self.v[k]
+            if self.kinds[k] == "sparse":
+                m.mul_(float(self.b1)).add_(g * float(omb1))
+                v.mul_(float(self.b2)).add_((g * g) * float(omb2))
+                var.sub_((float(lr_t) * m) / (v.sqrt() + float(self.eps)))
+            else:
+                m.add_((g - m) * float(omb1))
+                v.add_((g * g - v) * float(omb2))
+                var.sub_((m * float(lr_t)) / (v.sqrt() + float(self.eps)))
+        self.b1p = np.float32(self.b1p * self.b1)
+        self.b2p = np.float32(self.b2p * self.b2)
+        return float(lr_t)
+
+
+def _l2(t):  # tf.nn.l2_loss
+    return (t * t).sum() / 2
+
+
+def _ce_sum(labels, logits):  # utils/tools.py:68-69: reduce_sum(sigmoid_cross_entropy_with_logits)
+    return (torch.clamp(logits, min=0) - logits * labels + torch.log1p(torch.exp(-logits.abs()))).sum()
+
+
+class Model:
+    """params (fp32 tensors), kinds, loss(batch) -> scalar.  step(batch) runs one sess.run([train, loss])."""
+
+    def __init__(self, params, kinds, lr):
+        self.params = {k: torch.tensor(np.array(v, dtype=np.float32)) for k, v in params.items()}
+        self.opt = TF1Adam(self.params, kinds, lr)
+
+    def step(self, *batch):
+        leaves = {k: v.clone().requires_grad_(True) for k, v in self.params.items()}
+        loss = self.loss(leaves, *batch)
+        grads = torch.autograd.grad(loss, list(leaves.values()), allow_unused=True)
+        self.opt.step(dict(zip(leaves.keys(), grads)))
+        return float(loss.detach())
+
+    def numpy(self, k):
+        return self.params[k].numpy()
+
+
+class GMF(Model):
+    """model/ranking/GMF.py:29-57: logit = sum_d pu*qi*h (:42); loss = sum CE + reg*(l2(pu)+l2(qi)) (:48)."""
+
+    def __init__(self, P, Q, h, lr, reg):
+        super().__init__({"P": P, "Q": Q, "h_gmf": h}, {"P": "sparse", "Q": "sparse", "h_gmf": "dense"}, lr)
+        self.reg = reg
+
+    def loss(self, w, u, i, y):
+        u, i = torch.as_tensor(u, dtype=torch.long), torch.as_tensor(i, dtype=torch.long)
+        y = torch.as_tensor(np.asarray(y, dtype=np.float32))
+        pu, qi = w["P"][u], w["Q"][i]
+        logits = ((pu * qi) * w["h_gmf"]).sum(1)
+        return _ce_sum(y, logits) + self.reg * (_l2(pu) + _l2(qi))
+
+    def predict(self, users):  # GMF.py:40,57: sigmoid((pu * Q) . h) for every item
+        P, Q, h = (self.params[k] for k in ("P", "Q", "h_gmf"))
+        return torch.sigmoid((P[torch.as_tensor(users, dtype=torch.long)] * h) @ Q.T).numpy()
+
+
+def _tower(y, w, n_layers, prefix=""):
+    for k in range(n_layers):  # MLP.py:49-53: relu(y W_k + b_k) for every layer
+        y = torch.relu(y @ w[prefix + "W_%d" % k] + w[prefix + "b_%d" % k])
+    return y
+
+
+class MLP(Model):
+    """model/ranking/MLP.py:31-77: P,Q of width layers[0]//2, W_k [layers[k], layers[k]//2], b_k, h_mlp;
+    logit = tower(concat(pu, qi)) . h_mlp (:59); loss = sum CE + reg*(l2(pu)+l2(qi)) (:66)."""
+
+    def __init__(self, P, Q, Ws, bs, h, lr, reg):
+        params, kinds = {"P": P, "Q": Q, "h_mlp": h}, {"P": "sparse", "Q": "sparse", "h_mlp": "dense"}
+        for k, (W, b) in enumerate(zip(Ws, bs)):
+            params["W_%d" % k], params["b_%d" % k] = W, b
+            kinds["W_%d" % k] = kinds["b_%d" % k] = "dense"
+        super().__init__(params, kinds, lr)
+        self.reg, self.n_layers = reg, len(Ws)
+
+    def loss(self, w, u, i, y):
+        u, i = torch.as_tensor(u, dtype=torch.long), torch.as_tensor(i, dtype=torch.long)
+        y = torch.as_tensor(np.asarray(y, dtype=np.float32))
+        pu, qi = w["P"][u], w["Q"][i]
+        logits = _tower(torch.cat([pu, qi], 1), w, self.n_layers) @ w["h_mlp"]
+        return _ce_sum(y, logits) + self.reg * (_l2(pu) + _l2(qi))
+
+
+class NeuMF(Model):
+    """model/ranking/NeuMF.py:33-105: four tables; logit = concat(pg*qg, tower(concat(pm, qm))) . h_neumf (:84);
+    loss = sum CE + reg1*(l2(pg)+l2(qg)) + reg2*(l2(pm)+l2(qm)) (:93-94).  h_gmf / h_mlp exist as variables but
+    receive no gradient."""
+
+    def __init__(self, Pg, Qg, Pm, Qm, Ws, bs, h, lr, reg1, reg2):
+        params = {"P_gmf": Pg, "Q_gmf": Qg, "P_mlp": Pm, "Q_mlp": Qm, "h_neumf": h}
+        kinds = {"P_gmf": "sparse", "Q_gmf": "sparse", "P_mlp": "sparse", "Q_mlp": "sparse", "h_neumf": "dense"}
+        for k, (W, b) in enumerate(zip(Ws, bs)):
+            params["W_%d" % k], params["b_%d" % k] = W, b
+            kinds["W_%d" % k] = kinds["b_%d" % k] = "dense"
+        super().__init__(params, kinds, lr)
+        self.reg1, self.reg2, self.n_layers = reg1, reg2, len(Ws)
+
+    def loss(self, w, u, i, y):
+        u, i = torch.as_tensor(u, dtype=torch.long), torch.as_tensor(i, dtype=torch.long)
+        y = torch.as_tensor(np.asarray(y, dtype=np.float32))
+        pg, qg, pm, qm = w["P_gmf"][u], w["Q_gmf"][i], w["P_mlp"][u], w["Q_mlp"][i]
+        y_mlp = _tower(torch.cat([pm, qm], 1), w, self.n_layers)
+        logits = torch.cat([pg * qg, y_mlp], 1) @ w["h_neumf"]
+        return _ce_sum(y, logits) + self.reg1 * (_l2(pg) + _l2(qg)) + self.reg2 * (_l2(pm) + _l2(qm))
+
+    def predict(self, users):  # NeuMF.py:66,73,84,105 for every item
+        w = self.params
+        users = torch.as_tensor(users, dtype=torch.long)
+        out = []
+        for uu in users:
+            pg, pm = w["P_gmf"][uu], w["P_mlp"][uu]
+            y_mlp = _tower(torch.cat([pm.expand(len(w["Q_mlp"]), -1), w["Q_mlp"]], 1), w, self.n_layers)
+            out.append(torch.sigmoid(torch.cat([pg * w["Q_gmf"], y_mlp], 1) @ w["h_neumf"]))
+        return torch.stack(out).numpy()
+
+
+class CML(Model):
+    """model/ranking/CML.py:34-84.  d_ui = |pu-qi|^2 (:42), d_un[b,k] = |pu-q_neg|^2 (:43),
+    loss_b = max(d_ui + margin - min_k d_un, 0) * log(rank+1), rank = mean_k(impostor)*I/neg_ratio without
+    gradient (:45-53), + reg * sum offdiag(cov([Q;P])) (:63-70).  Both tables get dense gradients (the
+    covariance term reads the full tables) -> dense Adam."""
+
+    def __init__(self, P, Q, lr, reg, margin, item_nums):
+        super().__init__({"P": P, "Q": Q}, {"P": "dense", "Q": "dense"}, lr)
+        self.reg, self.margin, self.item_nums = reg, margin, item_nums
+
+    def loss(self, w, u, i, neg):
+        u, i = torch.as_tensor(u, dtype=torch.long), torch.as_tensor(i, dtype=torch.long)
+        neg = torch.as_tensor(np.asarray(neg), dtype=torch.long)
+        pu, qi, qn = w["P"][u], w["Q"][i], w["Q"][neg]  # qn [B, K, d]
+        d_ui = ((pu - qi) ** 2).sum(1)
+        d_un = ((pu[:, None, :] - qn) ** 2).sum(2)
+        base = torch.clamp(d_ui + self.margin - d_un.min(1).values, min=0)
+        imp = ((d_ui[:, None] + self.margin - d_un) > 0).to(f32)
+        rank = imp.mean(1) * self.item_nums / neg.shape[1]
+        per_pair = base * torch.log(rank + 1).detach()
+        X = torch.cat([w["Q"], w["P"]], 0)
+        n_rows = X.shape[0]
+        Xc = X - X.mean(0)
+        cov = (Xc.T @ Xc) / n_rows
+        cov_loss = self.reg * (cov.sum() - torch.diagonal(cov).sum())
+        return per_pair.sum() + cov_loss
+
+    def predict(self, users):  # CML.py:76,84: |clip_1(pu) - Q_i|^2, smaller is better
+        P, Q = self.params["P"], self.params["Q"]
+        pu = P[torch.as_tensor(users, dtype=torch.long)]
+        nrm = pu.norm(dim=1, keepdim=True)
+        pu = torch.where(nrm > 1.0, pu / nrm, pu)  # tf.clip_by_norm(.., 1.0, axes=[1])
+        return ((pu[:, None, :] - Q[None]) ** 2).sum(2).numpy()
+
+
+class FM(Model):
+    """model/rating/FM.py:20-53: y = w0 + sum_f wi[x_f] + 0.5*sum_k[(sum_f x v)^2 - sum_f x^2 v^2] (the linear
+    term ignores x_value, :35,49); loss = sum (y - y_pre)^2 + reg*(l2(wi) + l2(vif)) over the FULL tables (:52)
+    -> dense Adam for wi and vif; w0 dense."""
+
+    def __init__(self, w0, wi, vif, lr, reg):
+        super().__init__({"w0": w0, "wi": wi, "vif": vif}, {"w0": "dense", "wi": "dense", "vif": "dense"}, lr)
+        self.reg = reg
+
+    def y_pre(self, w, x_idx, x_val):
+        x_idx = torch.as_tensor(np.asarray(x_idx), dtype=torch.long)
+        x_val = torch.as_tensor(np.asarray(x_val, dtype=np.float32))
+        wi_e, v_e = w["wi"][x_idx], w["vif"][x_idx]  # [B,F], [B,F,d]
+        sq_sum = ((x_val[:, :, None] * v_e).sum(1)) ** 2
+        sum_sq = ((x_val ** 2)[:, :, None] * (v_e ** 2)).sum(1)
+        return w["w0"] + wi_e.sum(1) + 0.5 * (sq_sum - sum_sq).sum(1)
+
+    def loss(self, w, x_idx, x_val, y):
+        y = torch.as_tensor(np.asarray(y, dtype=np.float32))
+        yp = self.y_pre(w, x_idx, x_val)
+        self.last_y_pre = yp.detach().numpy()
+        return ((y - yp) ** 2).sum() + self.reg * (_l2(w["wi"]) + _l2(w["vif"]))

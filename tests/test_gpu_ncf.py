@@ -1,0 +1,129 @@
+"""GMF / MLP / NeuMF training steps (HIP, through the C ABI) against the torch-autograd restatement of the
+reference graphs with TF1 Adam semantics (oracle/models_torch.py).  Needs an MI355X.
+fp32; losses rtol 1e-5, parameters |delta| <= 1e-5 = 1% of one Adam step of 1e-3 (different fp32 summation order; Adam divides by sqrt(v))."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import models_torch as MT
+from cleverrec_amd import runtime
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sess():
+    s = runtime.Session(0)
+    yield s
+    s.close()
+
+
+def _instances(seed, U, I, n):
+    g = np.random.Generator(np.random.PCG64(seed))
+    return (g.integers(0, U, n).astype(np.int32), g.integers(0, I, n).astype(np.int32),
+            (g.random(n) < 0.2).astype(np.float32))
+
+
+def _rand(g, *shape, scale=0.1):
+    return (g.standard_normal(shape) * scale).astype(np.float32)
+
+
+def _tower(g, L0, n_layers):
+    Ws, bs, w = [], [], L0
+    for _ in range(n_layers):
+        Ws.append(_rand(g, w, w // 2, scale=0.2))
+        bs.append(_rand(g, w // 2, scale=0.05))
+        w //= 2
+    return Ws, bs, w
+
+
+def _compare(st, om, names, atol=1e-5):  # 1% of one Adam step: where a gradient sum cancels to ~0, g/sqrt(v) amplifies fp32 order noise
+    for dev, ref in names:
+        np.testing.assert_allclose(dev.cpu().numpy().reshape(-1), om.numpy(ref).reshape(-1), rtol=0, atol=atol, err_msg=ref)
+
+
+@pytest.mark.parametrize("d", [8, 32, 64])
+def test_gmf_steps_match_oracle(sess, d):
+    U, I, B = 120, 70, 500
+    g = np.random.Generator(np.random.PCG64(d))
+    P, Q, h = _rand(g, U, d), _rand(g, I, d), _rand(g, d, scale=0.5)
+    u, i, y = _instances(1, U, I, 3 * B + 77)
+    st = runtime.NcfState(sess, "GMF", {"P_gmf": P, "Q_gmf": Q}, [], [], h, lr=1e-3, reg_gmf=0.01)
+    om = MT.GMF(P, Q, h, lr=1e-3, reg=0.01)
+    loss = st.train_epoch(sess.to_dev(u), sess.to_dev(i), sess.to_dev(y), B).cpu().numpy()
+    ol = [om.step(u[b * B:(b + 1) * B], i[b * B:(b + 1) * B], y[b * B:(b + 1) * B]) for b in range(len(loss))]
+    np.testing.assert_allclose(loss, ol, rtol=1e-5)
+    _compare(st, om, [(st.t["P_gmf"], "P"), (st.t["Q_gmf"], "Q"), (st.h, "h_gmf")])
+
+
+@pytest.mark.parametrize("layers", [[16, 8], [128, 64, 32], [64, 32, 16, 8]])
+def test_mlp_steps_match_oracle(sess, layers):
+    U, I, B = 90, 60, 300
+    g = np.random.Generator(np.random.PCG64(len(layers)))
+    L0 = layers[0]
+    P, Q = _rand(g, U, L0 // 2), _rand(g, I, L0 // 2)
+    Ws, bs, last = _tower(g, L0, len(layers))
+    h = _rand(g, last, scale=0.5)
+    u, i, y = _instances(2, U, I, 2 * B + 31)
+    st = runtime.NcfState(sess, "MLP", {"P_mlp": P, "Q_mlp": Q}, Ws, bs, h, lr=1e-3, reg_mlp=0.01)
+    om = MT.MLP(P, Q, Ws, bs, h, lr=1e-3, reg=0.01)
+    loss = st.train_epoch(sess.to_dev(u), sess.to_dev(i), sess.to_dev(y), B).cpu().numpy()
+    ol = [om.step(u[b * B:(b + 1) * B], i[b * B:(b + 1) * B], y[b * B:(b + 1) * B]) for b in range(len(loss))]
+    np.testing.assert_allclose(loss, ol, rtol=1e-5)
+    names = [(st.t["P_mlp"], "P"), (st.t["Q_mlp"], "Q"), (st.h, "h_mlp")]
+    names += [(st.W[k], "W_%d" % k) for k in range(len(layers))] + [(st.b[k], "b_%d" % k) for k in range(len(layers))]
+    _compare(st, om, names)
+
+
+def test_neumf_config3_shape(sess):
+    """BASELINE config C3: NeuMF, d = 64, layers [128, 64, 32], batch 6144 (catalogue scaled down)."""
+    U, I, B, d, layers = 400, 300, 6144, 64, [128, 64, 32]
+    g = np.random.Generator(np.random.PCG64(9))
+    Pg, Qg, Pm, Qm = _rand(g, U, d), _rand(g, I, d), _rand(g, U, 64), _rand(g, I, 64)
+    Ws, bs, last = _tower(g, 128, 3)
+    h = _rand(g, d + last, scale=0.3)
+    u, i, y = _instances(3, U, I, 2 * B + 500)
+    st = runtime.NcfState(sess, "NeuMF", {"P_gmf": Pg, "Q_gmf": Qg, "P_mlp": Pm, "Q_mlp": Qm}, Ws, bs, h, lr=1e-3,
+                          reg_gmf=1e-2, reg_mlp=1e-3)
+    om = MT.NeuMF(Pg, Qg, Pm, Qm, Ws, bs, h, lr=1e-3, reg1=1e-2, reg2=1e-3)
+    loss = st.train_epoch(sess.to_dev(u), sess.to_dev(i), sess.to_dev(y), B).cpu().numpy()
+    ol = [om.step(u[b * B:(b + 1) * B], i[b * B:(b + 1) * B], y[b * B:(b + 1) * B]) for b in range(len(loss))]
+    np.testing.assert_allclose(loss, ol, rtol=1e-5)
+    names = [(st.t[k], k) for k in ("P_gmf", "Q_gmf", "P_mlp", "Q_mlp")] + [(st.h, "h_neumf")]
+    names += [(st.W[k], "W_%d" % k) for k in range(3)] + [(st.b[k], "b_%d" % k) for k in range(3)]
+    _compare(st, om, names)
+
+
+def test_gmf_class_surface_train_and_eval(sess, tmp_path):
+    """GMF(sess, data, configs, logger): pointwise train_model() on the np.random stream, then the
+    full-catalogue ranking (sigmoid((pu*h).q), GMF.py:40,57) against the oracle's predict()."""
+    import logging
+    from cleverrec_amd.data import RankingData
+    from cleverrec_amd.model.ranking.GMF import GMF
+    g = np.random.Generator(np.random.PCG64(4))
+    U, I, d = 150, 90, 32
+    ui_train = {uu: [int(x) for x in g.choice(I, size=int(g.integers(3, 20)), replace=False)] for uu in range(U)}
+    ui_test = {uu: [int(x) for x in g.choice(I, size=2, replace=False)] for uu in range(0, U, 2)}
+    data = RankingData(U, I, ui_train, ui_test)
+    configs = {"recommender": "GMF", "epoches": "2", "batch_size": "512", "test.batch_size": "64", "lr": "0.001",
+               "test.neg_samples": "0", "is_pairwise": "False", "init_method": "xavier_uniform", "stddev": "0.01",
+               "loss_func": "cross_entropy", "optimizer": "Adam", "saved_dir": str(tmp_path), "test.interval": "1",
+               "topk": "[10,20]", "neg_ratio": "4", "embed_size": str(d), "reg_gmf": "0.01", "data.split_way": "rs"}
+    m = GMF(sess, data, configs, logging.getLogger("t"))
+    init = {"P": _rand(g, U, d), "Q": _rand(g, I, d), "h_gmf": _rand(g, d, scale=0.5)}
+    m.build_model(init)
+    om = MT.GMF(init["P"], init["Q"], init["h_gmf"], lr=1e-3, reg=0.01)
+    np.random.seed(11)
+    rng = oracle.Rng(11)
+    for _ in range(2):
+        avg = m.train_model()
+        nb, ou, oi, oy = oracle.sample_pointwise(rng, data.ui_train, I, 4, 512)
+        tot = sum(om.step(ou[b * 512:(b + 1) * 512], oi[b * 512:(b + 1) * 512], oy[b * 512:(b + 1) * 512]) for b in range(nb))
+        assert avg == pytest.approx(tot / nb, rel=1e-5)
+    HR, MRR, NDCG = m.test_model_rs()
+    # same ranking as sorting the oracle's sigmoid scores of the DEVICE parameters (ties aside, none here)
+    dev = MT.GMF(m.P.cpu().numpy(), m.Q.cpu().numpy(), m.h_gmf.cpu().numpy(), lr=1e-3, reg=0.01)
+    H, M, N = oracle.test_model_rs_py(lambda cur: dev.predict(cur), m.test_users, data.ui_train, data.ui_test, [10, 20], 64)
+    np.testing.assert_allclose(np.mean(NDCG[0]), np.mean(N[0]), rtol=1e-6)
+    np.testing.assert_allclose(np.mean(HR[1]), np.mean(H[1]), rtol=1e-6)
