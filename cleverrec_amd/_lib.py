@@ -43,6 +43,10 @@ class Ncf(C.Structure):
                 ("n_layers", C.c_int32), ("small", Param), ("reg_gmf", C.c_float), ("reg_mlp", C.c_float)]
 
 
+class Fm(C.Structure):
+    _fields_ = [("w0", Param), ("wi", Param), ("vif", Param), ("reg", C.c_float)]
+
+
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 _SIGNATURES = {
     "crec_version": (C.c_int, []),
@@ -61,6 +65,9 @@ _SIGNATURES = {
     "crec_sample_cml": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, C.c_int, _vp, _vp, _vp, C.POINTER(_i64)]),
     "crec_bpr_train_epoch": (C.c_int, [_vp, C.POINTER(BprTables), C.POINTER(Adam), _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "crec_ncf_train_epoch": (C.c_int, [_vp, C.POINTER(Ncf), C.POINTER(Adam), _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
+    "crec_fm_train_epoch": (C.c_int, [_vp, C.POINTER(Fm), C.POINTER(Adam), _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
+    "crec_fm_predict": (C.c_int, [_vp, C.POINTER(Fm), _vp, _vp, _i64, _i32, _vp, _vp]),
+    "crec_rmse_mae": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "crec_bpr_train_epoch_dp": (C.c_int, [_vp, C.POINTER(BprTables), C.POINTER(Adam), _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "crec_comm_unique_id": (C.c_int, [_vp, _vp]),
     "crec_comm_init": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
@@ -122,7 +129,7 @@ class Context:
 
     # ---- measurement ---------------------------------------------------------------------------
     KERNELS = ("bpr_index_batches", "bpr_step_fused", "bpr_user_side", "bpr_item_side", "bpr_reduce_loss", "eval_sweep",
-               "eval_merge", "rank_metrics", "bpr_finish_heavy", "bpr_adam_dense", "rows_index_batches", "rows_apply", "small_adam_dense", "ncf_tile")
+               "eval_merge", "rank_metrics", "bpr_finish_heavy", "bpr_adam_dense", "rows_index_batches", "rows_apply", "small_adam_dense", "ncf_tile", "fm_instances")
 
     def profile(self, on):
         self.check(self.lib.crec_profile_enable(self.h, int(bool(on))))

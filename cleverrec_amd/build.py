@@ -23,6 +23,7 @@ SOURCES = {
     "eval_topk.hip": [],
     "rows_adam.hip": ["-ffp-contract=off"],
     "ncf.hip": ["-ffp-contract=off"],
+    "fm.hip": ["-ffp-contract=off"],
 }
 
 

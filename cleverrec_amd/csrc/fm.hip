@@ -1,0 +1,334 @@
+// Factorization Machine (rating path) for gfx950.
+//
+// Replaces sess.run([train, loss, y_pre]) / sess.run(y_pre) (model/RatingRecommender.py:50,73) on the graph
+// of model/rating/FM.py:20-53 and the Python RMSE/MAE loop (utils/metrics.py:22-29); see include/crec.h.
+//
+//   y_pre = w0 + sum_f wi[x_f] + 0.5 * sum_k [ (sum_f x_f v_fk)^2 - sum_f x_f^2 v_fk^2 ]   (FM.py:43-49;
+//           the linear term ignores x_value, FM.py:35,49)
+//   loss  = sum_b (y - y_pre)^2 + reg * 0.5 * (|wi|^2 + |vif|^2) over the FULL tables (FM.py:52)
+// so wi and vif receive dense gradients and take TF1's dense ApplyAdam on every row each step.
+//
+// Per batch: fm_instances (one lane group per instance: gathers, y_pre, residual, contribution rows for
+// vif and scalars for wi, per-wave partial of dL/dw0) -> rows_apply (vif, ROWS_DENSE + reg*table) ->
+// fm_linear_apply (wi, thread per row) -> small_adam_dense (w0).  Deterministic, no atomics.
+#include "crec_internal.h"
+#include "rows_adam.h"
+
+namespace {
+
+constexpr int FM_MAX_F = 8; // features per row held in registers
+
+// group = LPR lanes (float4 per lane) per instance; G = 64/LPR instances per wave
+template <int LPR, bool TRAIN>
+__global__ __launch_bounds__(256) void fm_instances(const float *__restrict__ w0, const float *__restrict__ wi,
+                                                    const float *__restrict__ vif, int d, const int32_t *__restrict__ x_idx,
+                                                    const float *__restrict__ x_val, const float *__restrict__ y, int n,
+                                                    int F, float *__restrict__ y_pre, float *__restrict__ c_v,
+                                                    float *__restrict__ c_w, float *__restrict__ sq_err,
+                                                    float *__restrict__ w0_partial)
+{
+    constexpr int G = 64 / LPR;
+    const int lane = threadIdx.x & 63, g = lane / LPR, l = lane % LPR;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t inst = wave * G + g;
+    const bool ok = inst < n, act = 4 * l < d;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 v[FM_MAX_F];
+    float xv[FM_MAX_F];
+    int xi[FM_MAX_F];
+    float4 S = zero, SS = zero; // sum_f x v, sum_f x^2 v^2  (this lane's 4 components)
+    float lin = 0.f;
+#pragma unroll
+    for (int f = 0; f < FM_MAX_F; ++f) {
+        v[f] = zero;
+        xv[f] = 0.f;
+        xi[f] = 0;
+        if (f < F && ok) {
+            xi[f] = x_idx[inst * F + f];
+            xv[f] = x_val[inst * F + f];
+            if (act)
+                v[f] = *reinterpret_cast<const float4 *>(vif + (int64_t)xi[f] * d + 4 * l);
+            lin = lin + wi[xi[f]];
+            const float x2 = xv[f] * xv[f];
+            S.x = S.x + xv[f] * v[f].x;
+            S.y = S.y + xv[f] * v[f].y;
+            S.z = S.z + xv[f] * v[f].z;
+            S.w = S.w + xv[f] * v[f].w;
+            SS.x = SS.x + x2 * (v[f].x * v[f].x);
+            SS.y = SS.y + x2 * (v[f].y * v[f].y);
+            SS.z = SS.z + x2 * (v[f].z * v[f].z);
+            SS.w = SS.w + x2 * (v[f].w * v[f].w);
+        }
+    }
+    float second = ((S.x * S.x - SS.x) + (S.y * S.y - SS.y)) + ((S.z * S.z - SS.z) + (S.w * S.w - SS.w));
+#pragma unroll
+    for (int off = LPR >> 1; off > 0; off >>= 1)
+        second += __shfl_xor(second, off, 64);
+    const float yp = (w0[0] + lin) + 0.5f * second;
+    if (ok && l == 0)
+        y_pre[inst] = yp;
+    if (!TRAIN)
+        return;
+    const float res = ok ? yp - y[inst] : 0.f; // dL/dy_pre = 2 * res
+    const float gy = 2.0f * res;
+    if (ok) {
+        if (l == 0)
+            sq_err[inst] = res * res;
+#pragma unroll
+        for (int f = 0; f < FM_MAX_F; ++f) {
+            if (f < F) {
+                if (act) { // d y / d v_fk = x_f * S_k - x_f^2 * v_fk
+                    const float x2 = xv[f] * xv[f];
+                    float4 c;
+                    c.x = gy * (xv[f] * S.x - x2 * v[f].x);
+                    c.y = gy * (xv[f] * S.y - x2 * v[f].y);
+                    c.z = gy * (xv[f] * S.z - x2 * v[f].z);
+                    c.w = gy * (xv[f] * S.w - x2 * v[f].w);
+                    *reinterpret_cast<float4 *>(c_v + (inst * F + f) * d + 4 * l) = c;
+                }
+                if (l == 0)
+                    c_w[inst * F + f] = gy;
+            }
+        }
+    }
+    // dL/dw0 partial of this wave: sum over its G instances in group order
+    float s = l == 0 ? gy : 0.f;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        s += __shfl_xor(s, off, 64);
+    if (lane == 0)
+        w0_partial[wave] = s;
+}
+
+// wi: a [rows] vector "table" (one float per row): sum of slot scalars per row + dense ApplyAdam with reg*wi
+__global__ void fm_linear_apply(float *__restrict__ var, float *__restrict__ m, float *__restrict__ v, int64_t rows,
+                                const int2 *__restrict__ rowseg, const int32_t *__restrict__ order,
+                                const float *__restrict__ c_w, float *__restrict__ rownorm, crec_rows_opt o)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows)
+        return;
+    const int2 rs = rowseg[r];
+    float g = 0.f;
+    for (int k = rs.x; k < rs.x + rs.y; ++k)
+        g = g + c_w[order[k]];
+    const float w = var[r];
+    rownorm[r] = w * w;
+    g = g + o.dense_reg * w;
+    const float omb1 = 1.0f - o.beta1, omb2 = 1.0f - o.beta2;
+    float mm = m[r], vv = v[r];
+    mm = mm + (g - mm) * omb1;
+    vv = vv + (g * g - vv) * omb2;
+    m[r] = mm;
+    v[r] = vv;
+    var[r] = w - (mm * o.lr_t) / (sqrtf(vv) + o.eps);
+}
+
+// |row|^2 of every vif row (before the update), one wave per 64 floats chunk ... simple thread-per-row
+__global__ void fm_row_sqnorm(const float *__restrict__ var, int64_t rows, int d, float *__restrict__ out)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows)
+        return;
+    float s = 0.f;
+    for (int c = 0; c < d; ++c)
+        s = s + var[r * d + c] * var[r * d + c];
+    out[r] = s;
+}
+
+// loss_b = sum_b (y - y_pre)^2 + reg * 0.5 * (sum rownorm_w + sum rownorm_v), float64, fixed order
+__global__ __launch_bounds__(256) void fm_reduce_loss(const float *__restrict__ sq_err, int nb, const float *__restrict__ nw,
+                                                      const float *__restrict__ nv, int64_t rows, float reg,
+                                                      float *__restrict__ out)
+{
+    __shared__ double part[256];
+    double s = 0.0, l2 = 0.0;
+    for (int k = threadIdx.x; k < nb; k += 256)
+        s += (double)sq_err[k];
+    for (int64_t k = threadIdx.x; k < rows; k += 256)
+        l2 += (double)nw[k] + (double)nv[k];
+    part[threadIdx.x] = s + (double)reg * 0.5 * l2;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off)
+            part[threadIdx.x] += part[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        *out = (float)part[0];
+}
+
+// utils/metrics.py:22-29 in float64: out = {sqrt(mean (y - y_pre)^2), mean |y - y_pre|}
+__global__ __launch_bounds__(1024) void rmse_mae_kernel(const float *__restrict__ y, const float *__restrict__ yp, int64_t n,
+                                                        double *__restrict__ out)
+{
+    __shared__ double sq[1024], ab[1024];
+    double a = 0.0, b = 0.0;
+    for (int64_t k = threadIdx.x; k < n; k += 1024) {
+        const double r = (double)y[k] - (double)yp[k];
+        a += r * r;
+        b += fabs(r);
+    }
+    sq[threadIdx.x] = a;
+    ab[threadIdx.x] = b;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            sq[threadIdx.x] += sq[threadIdx.x + off];
+            ab[threadIdx.x] += ab[threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[0] = sqrt(sq[0] / (double)n);
+        out[1] = ab[0] / (double)n;
+    }
+}
+
+template <bool TRAIN>
+void launch_instances(int lpr, dim3 grid, hipStream_t st, const float *w0, const float *wi, const float *vif, int d,
+                      const int32_t *x_idx, const float *x_val, const float *y, int n, int F, float *y_pre, float *c_v,
+                      float *c_w, float *sq_err, float *w0_partial)
+{
+#define CREC_FM(L)                                                                                                      \
+    case L:                                                                                                             \
+        hipLaunchKernelGGL((fm_instances<L, TRAIN>), grid, dim3(256), 0, st, w0, wi, vif, d, x_idx, x_val, y, n, F, y_pre, \
+                           c_v, c_w, sq_err, w0_partial);                                                               \
+        break;
+    switch (lpr) {
+        CREC_FM(1)
+        CREC_FM(2)
+        CREC_FM(4)
+        CREC_FM(8)
+        CREC_FM(16)
+        CREC_FM(32)
+        CREC_FM(64)
+    }
+#undef CREC_FM
+}
+
+int check_fm(crec_ctx *ctx, const crec_fm *m, int F)
+{
+    CREC_REQUIRE(ctx, m && m->w0.var && m->wi.var && m->vif.var, "null FM parameter");
+    CREC_REQUIRE(ctx, m->vif.cols % 4 == 0 && m->vif.cols >= 4 && m->vif.cols <= 256,
+                 "embed_size %d: need a multiple of 4 in [4, 256]", m->vif.cols);
+    CREC_REQUIRE(ctx, m->wi.rows * m->wi.cols == m->vif.rows, "wi and vif must have the same number of features");
+    CREC_REQUIRE(ctx, F >= 1 && F <= FM_MAX_F, "%d features per row: this build holds at most %d", F, FM_MAX_F);
+    return CREC_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int crec_fm_predict(crec_ctx *ctx, const crec_fm *m, const int32_t *x_idx, const float *x_val, int64_t N, int32_t F,
+                    float *y_pre, void *stream)
+{
+    if (!ctx)
+        return CREC_EINVAL;
+    CREC_REQUIRE(ctx, ctx->device >= 0, "host-only ctx: no device bound");
+    if (int rc = check_fm(ctx, m, F))
+        return rc;
+    CREC_REQUIRE(ctx, N >= 0 && (N == 0 || (x_idx && x_val && y_pre)), "null argument");
+    if (N == 0)
+        return CREC_OK;
+    CREC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int d = m->vif.cols;
+    int lpr = 1;
+    while (lpr * 4 < d)
+        lpr <<= 1;
+    const int G = 64 / lpr;
+    const int64_t waves = crec_ceil_div(N, G);
+    launch_instances<false>(lpr, dim3((unsigned)crec_ceil_div(waves, 4)), st, m->w0.var, m->wi.var, m->vif.var, d, x_idx, x_val,
+                            nullptr, (int)N, F, y_pre, nullptr, nullptr, nullptr, nullptr);
+    CREC_HIP(ctx, hipGetLastError());
+    return CREC_OK;
+}
+
+int crec_fm_train_epoch(crec_ctx *ctx, const crec_fm *m, crec_adam *opt, const int32_t *x_idx, const float *x_val,
+                        const float *y, int64_t N, int32_t F, int32_t B, float *y_pre, float *loss_per_batch,
+                        void *stream)
+{
+    if (!ctx)
+        return CREC_EINVAL;
+    CREC_REQUIRE(ctx, ctx->device >= 0, "host-only ctx: no device bound");
+    if (int rc = check_fm(ctx, m, F))
+        return rc;
+    CREC_REQUIRE(ctx, opt && N >= 0 && (N == 0 || (x_idx && x_val && y && y_pre && loss_per_batch)), "null argument");
+    CREC_REQUIRE(ctx, B >= 1 && (int64_t)B * F <= 16384, "batch_size * features = %lld: at most 16384", (long long)B * F);
+    if (N == 0)
+        return CREC_OK;
+    CREC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int d = m->vif.cols;
+    const int64_t rows = m->vif.rows, nb = crec_ceil_div(N, B);
+    int lpr = 1;
+    while (lpr * 4 < d)
+        lpr <<= 1;
+    const int G = 64 / lpr;
+    auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+    const size_t ixb = crec_rows_index_bytes(nb, B * F, rows);
+    const size_t cvb = sizeof(float) * (size_t)B * F * d, cwb = sizeof(float) * (size_t)B * F, seb = sizeof(float) * (size_t)B;
+    const int max_waves = (int)crec_ceil_div(B, G);
+    const size_t w0b = sizeof(float) * (size_t)max_waves, nrb = sizeof(float) * (size_t)rows;
+    if (int rc = crec_reserve(ctx, &ctx->idx_ws, up(ixb) + up(cvb) + up(cwb) + up(seb) + up(w0b) + 2 * up(nrb)))
+        return rc;
+    char *ws = (char *)ctx->idx_ws.ptr;
+    crec_rows_index_view vx;
+    if (int rc = crec_rows_index(ctx, x_idx, N * F, B * F, rows, ws, &vx, st))
+        return rc;
+    float *c_v = (float *)(ws + up(ixb));
+    float *c_w = (float *)((char *)c_v + up(cvb));
+    float *sq_err = (float *)((char *)c_w + up(cwb));
+    float *w0_partial = (float *)((char *)sq_err + up(seb));
+    float *nw = (float *)((char *)w0_partial + up(w0b));
+    float *nv = (float *)((char *)nw + up(nrb));
+
+    for (int64_t b = 0; b < nb; ++b) {
+        const int64_t t0 = b * B;
+        const int nbt = (int)((N - t0) < B ? (N - t0) : B);
+        crec_rows_opt o{};
+        o.kind = ROWS_DENSE;
+        o.reg_occ = 0.f;
+        o.dense_reg = m->reg;
+        o.lr_t = (opt->lr * sqrtf(1.0f - opt->beta2_power)) / (1.0f - opt->beta1_power);
+        o.beta1 = opt->beta1;
+        o.beta2 = opt->beta2;
+        o.eps = opt->eps;
+        const int waves = (int)crec_ceil_div(nbt, G);
+        crec_prof_begin(ctx, CREC_K_FM_INSTANCES, st);
+        launch_instances<true>(lpr, dim3((unsigned)crec_ceil_div(waves, 4)), st, m->w0.var, m->wi.var, m->vif.var, d,
+                               x_idx + t0 * F, x_val + t0 * F, y + t0, nbt, F, y_pre + t0, c_v, c_w, sq_err, w0_partial);
+        crec_prof_end(ctx, st);
+        hipLaunchKernelGGL(fm_row_sqnorm, dim3((unsigned)crec_ceil_div(rows, 256)), dim3(256), 0, st, (const float *)m->vif.var,
+                           rows, d, nv);
+        crec_rows_apply(ctx, crec_rows_table{m->vif.var, m->vif.m, m->vif.v, rows, d}, vx, b, c_v, nullptr, o, st);
+        hipLaunchKernelGGL(fm_linear_apply, dim3((unsigned)crec_ceil_div(rows, 256)), dim3(256), 0, st, m->wi.var, m->wi.m,
+                           m->wi.v, rows, (const int2 *)(vx.rowseg + b * vx.rows), (const int32_t *)(vx.order + b * vx.per_batch),
+                           (const float *)c_w, nw, o);
+        // waves beyond this batch's count were not written: pass the exact count
+        crec_small_adam_dense(ctx, m->w0.var, m->w0.m, m->w0.v, w0_partial, waves, 1, 1, o, st);
+        hipLaunchKernelGGL(fm_reduce_loss, dim3(1), dim3(256), 0, st, (const float *)sq_err, nbt, (const float *)nw,
+                           (const float *)nv, rows, m->reg, loss_per_batch + b);
+        opt->beta1_power = opt->beta1_power * opt->beta1;
+        opt->beta2_power = opt->beta2_power * opt->beta2;
+        opt->step += 1;
+    }
+    CREC_HIP(ctx, hipGetLastError());
+    return crec_prof_flush(ctx, st);
+}
+
+int crec_rmse_mae(crec_ctx *ctx, const float *y, const float *y_pre, int64_t n, double *out2, void *stream)
+{
+    if (!ctx)
+        return CREC_EINVAL;
+    CREC_REQUIRE(ctx, ctx->device >= 0, "host-only ctx: no device bound");
+    CREC_REQUIRE(ctx, y && y_pre && out2 && n >= 1, "bad argument");
+    CREC_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(rmse_mae_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, y, y_pre, n, out2);
+    CREC_HIP(ctx, hipGetLastError());
+    return CREC_OK;
+}
+
+} // extern "C"

@@ -142,3 +142,49 @@ class NcfState:
         s.ctx.check(s.lib.crec_ncf_train_epoch(s.ctx.h, C.byref(self.model), C.byref(self.adam), s.ptr(u), s.ptr(i), s.ptr(y),
                                                n, int(batch_size), s.ptr(loss), s.stream_ptr()))
         return loss
+
+
+class FmState:
+    """w0, wi, vif of model/rating/FM.py:27-31 with Adam slots in HBM (crec_fm)."""
+
+    def __init__(self, sess, w0, wi, vif, lr, reg, beta1=0.9, beta2=0.999, eps=1e-8):
+        self.sess = sess
+        f32 = torch.float32
+        self.w0 = sess.to_dev(np.asarray(w0, dtype=np.float32).reshape(1), f32)
+        self.wi = sess.to_dev(np.asarray(wi, dtype=np.float32).reshape(-1), f32)
+        self.vif = sess.to_dev(vif, f32).contiguous()
+        self.slots = {k: (torch.zeros_like(t), torch.zeros_like(t)) for k, t in (("w0", self.w0), ("wi", self.wi), ("vif", self.vif))}
+
+        def param(name, t, rows, cols):
+            m, v = self.slots[name]
+            return _lib.Param(t.data_ptr(), m.data_ptr(), v.data_ptr(), rows, cols)
+        self.model = _lib.Fm(param("w0", self.w0, 1, 1), param("wi", self.wi, self.wi.numel(), 1),
+                             param("vif", self.vif, self.vif.shape[0], self.vif.shape[1]), reg)
+        self.adam = _lib.Adam(lr, beta1, beta2, eps, 0.0, _lib.ADAM_TF1, beta1, beta2, 0)
+
+    def train_epoch(self, x_idx, x_val, y, batch_size):
+        """x_idx int32 [N,F], x_val fp32 [N,F], y fp32 [N] (device) -> (pre-update y_pre [N], per-batch losses)."""
+        s = self.sess
+        n, F = x_idx.shape
+        y_pre = s.empty((n,), torch.float32)
+        loss = s.empty((-(-n // batch_size),), torch.float32)
+        s.ctx.check(s.lib.crec_fm_train_epoch(s.ctx.h, C.byref(self.model), C.byref(self.adam), s.ptr(x_idx), s.ptr(x_val),
+                                              s.ptr(y), n, F, int(batch_size), s.ptr(y_pre), s.ptr(loss), s.stream_ptr()))
+        return y_pre, loss
+
+    def predict(self, x_idx, x_val):
+        s = self.sess
+        n, F = x_idx.shape
+        y_pre = s.empty((n,), torch.float32)
+        s.ctx.check(s.lib.crec_fm_predict(s.ctx.h, C.byref(self.model), s.ptr(x_idx), s.ptr(x_val), n, F, s.ptr(y_pre),
+                                          s.stream_ptr()))
+        return y_pre
+
+
+def rmse_mae(sess, y, y_pre):
+    """cal_rmse_mae (utils/metrics.py:22-29) on device tensors, float64 -> (rmse, mae) host floats."""
+    out = sess.empty((2,), torch.float64)
+    sess.ctx.check(sess.lib.crec_rmse_mae(sess.ctx.h, sess.ptr(y), sess.ptr(y_pre), int(y.numel()), sess.ptr(out),
+                                          sess.stream_ptr()))
+    r = out.cpu().numpy()
+    return float(r[0]), float(r[1])

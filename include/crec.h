@@ -55,7 +55,7 @@ const char *crec_last_error(const crec_ctx *ctx);
  * ends with a stream synchronise (so do not time whole-job throughput with it on).
  * kernel_class: 0 bpr_index_batches, 1 bpr_step_fused, 2 bpr_user_side, 3 bpr_item_side,
  *               4 bpr_reduce_loss, 5 eval_sweep, 6 eval_merge, 7 rank_metrics, 8 bpr_finish_heavy, 9 bpr_adam_dense,
- *               10 rows_index_batches, 11 rows_apply, 12 small_adam_dense, 13 ncf_tile.
+ *               10 rows_index_batches, 11 rows_apply, 12 small_adam_dense, 13 ncf_tile, 14 fm_instances.
  * enable(.., 1) also clears the accumulated totals. */
 int crec_profile_enable(crec_ctx *ctx, int on);
 int crec_profile_read(const crec_ctx *ctx, int kernel_class, double *total_ms, int64_t *launches);
@@ -148,6 +148,25 @@ typedef struct {
  * contiguous slices of RankingRecommender.train_model (:51-58); loss_per_batch [ceil(N/B)] [dev]. */
 int crec_ncf_train_epoch(crec_ctx *ctx, const crec_ncf *model, crec_adam *opt, const int32_t *u, const int32_t *i,
                          const float *y, int64_t N, int32_t B, float *loss_per_batch, void *stream);
+
+/* ---- Factorization Machine, rating path (device) ---------------------------------------------------
+ * replaces sess.run([self.train, self.loss, self.y_pre]) / sess.run(self.y_pre) (model/RatingRecommender.py:50,73)
+ * on the graph of model/rating/FM.py:20-53, and cal_rmse_mae (utils/metrics.py:22-29).
+ *   w0 [1,1] ('fm_params/w0'), wi [N+1,1] ('wi'), vif [N+1,d] ('vif'); reg = configs['reg'].
+ *   x_idx int32 [N,F], x_val float [N,F] (is_real_valued), y float [N]; F <= 8; B*F <= 16384.
+ *   The loss puts l2 on the FULL wi and vif tables (FM.py:52): both take dense ApplyAdam on every row. */
+typedef struct {
+    crec_param w0, wi, vif;
+    float reg;
+} crec_fm;
+/* y_pre [N]: the pre-update predictions train_fm collects for the training RMSE (RatingRecommender.py:50-54) */
+int crec_fm_train_epoch(crec_ctx *ctx, const crec_fm *model, crec_adam *opt, const int32_t *x_idx, const float *x_val,
+                        const float *y, int64_t N, int32_t F, int32_t B, float *y_pre, float *loss_per_batch,
+                        void *stream);
+int crec_fm_predict(crec_ctx *ctx, const crec_fm *model, const int32_t *x_idx, const float *x_val, int64_t N, int32_t F,
+                    float *y_pre, void *stream);
+/* out2 [dev] double[2] = {rmse, mae} in float64 */
+int crec_rmse_mae(crec_ctx *ctx, const float *y, const float *y_pre, int64_t n, double *out2, void *stream);
 
 /* ---- data-parallel training over RCCL (one process per GPU of one node) -----------------------
  * The path shards with one real exchange: gradients of the same Q row must be summed over all ranks'

@@ -1,0 +1,92 @@
+"""FM training / prediction / RMSE (HIP, through the C ABI) against the torch-autograd restatement of
+model/rating/FM.py with TF1 dense Adam (oracle/models_torch.py).  Needs an MI355X."""
+import numpy as np
+import pytest
+
+from oracle import models_torch as MT
+from cleverrec_amd import runtime
+from cleverrec_amd.utils.metrics import cal_rmse_mae
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sess():
+    s = runtime.Session(0)
+    yield s
+    s.close()
+
+
+@pytest.mark.parametrize("d,F", [(32, 2), (8, 3), (64, 5)])
+def test_fm_steps_match_oracle(sess, d, F):
+    g = np.random.Generator(np.random.PCG64(d + F))
+    n_feat, B, N = 300, 256, 3 * 256 + 100
+    w0, wi, vif = np.array([0.1], np.float32), (g.standard_normal(n_feat) * 0.1).astype(np.float32), \
+        (g.standard_normal((n_feat, d)) * 0.1).astype(np.float32)
+    x_idx = g.integers(0, n_feat, (N, F)).astype(np.int32)
+    x_val = np.where(g.random((N, F)) < 0.7, 1.0, g.random((N, F)) * 2).astype(np.float32)
+    y = g.integers(1, 6, N).astype(np.float32)
+    st = runtime.FmState(sess, w0, wi, vif, lr=1e-3, reg=1e-3)
+    om = MT.FM(w0.reshape(()), wi, vif, lr=1e-3, reg=1e-3)
+    y_pre, loss = st.train_epoch(sess.to_dev(x_idx), sess.to_dev(x_val), sess.to_dev(y), B)
+    ol, oy = [], []
+    for b in range(len(loss)):
+        sl = slice(b * B, (b + 1) * B)
+        ol.append(om.step(x_idx[sl], x_val[sl], y[sl]))
+        oy.append(om.last_y_pre)
+    np.testing.assert_allclose(loss.cpu().numpy(), ol, rtol=1e-5)
+    np.testing.assert_allclose(y_pre.cpu().numpy(), np.concatenate(oy), rtol=1e-5, atol=1e-6)
+    for dev, name in ((st.w0, "w0"), (st.wi, "wi"), (st.vif, "vif")):
+        np.testing.assert_allclose(dev.cpu().numpy().reshape(-1), om.numpy(name).reshape(-1), rtol=0, atol=1e-5, err_msg=name)
+    # prediction + RMSE/MAE against the reference-shaped Python loop
+    yp = st.predict(sess.to_dev(x_idx), sess.to_dev(x_val))
+    rm, ma = runtime.rmse_mae(sess, sess.to_dev(y), yp)
+    r2, m2 = cal_rmse_mae(y.astype(np.float64), yp.cpu().numpy().astype(np.float64))
+    assert rm == pytest.approx(r2, rel=1e-12) and ma == pytest.approx(m2, rel=1e-12)
+
+
+def test_fm_class_surface(sess, tmp_path):
+    """FM(sess, data, configs, logger) on a small libfm-ish dataset written to disk: RatingPreprocess reader,
+    train_fm()/test_fm() against the oracle on the same np.random.permutation stream."""
+    import logging
+    import torch
+    from cleverrec_amd.model.RatingPreprocess import RatingPreprocess
+    from cleverrec_amd.model.rating.FM import FM
+    g = np.random.Generator(np.random.PCG64(1))
+    U, I = 40, 25
+    root = tmp_path / "toy"
+    root.mkdir()
+    for name, n in (("toy.train.libfm", 900), ("toy.test.libfm", 200)):
+        with open(root / name, "w") as f:
+            for _ in range(n):
+                f.write("%d,%d:1,%d:1\n" % (g.integers(1, 6), g.integers(1, U + 1), U + g.integers(1, I + 1)))
+    configs = {"recommender": "FM", "data.root_dir": str(tmp_path), "data.dataset": "toy", "train": ".train.libfm",
+               "test": ".test.libfm", "is_real_valued": "True", "epoches": "2", "batch_size": "256",
+               "test.batch_size": "128", "lr": "0.01", "test.neg_samples": "0", "is_pairwise": "False",
+               "init_method": "normal", "stddev": "0.01", "loss_func": "square", "optimizer": "Adam",
+               "saved_dir": str(tmp_path), "test.interval": "1", "topk": "[10,20]", "embed_size": "32", "reg": "0.001"}
+    data = RatingPreprocess(configs, logging.getLogger("t"))
+    assert data.X_idx_tr.shape == (900, 2) and data.feature_nums == len(set(data.X_idx_tr.ravel()) | set(data.X_idx_t.ravel()))
+    m = FM(sess, data, configs, logging.getLogger("t"))
+    n = data.feature_nums + 1
+    init = {"w0": np.zeros(1, np.float32), "wi": (g.standard_normal(n) * 0.01).astype(np.float32),
+            "vif": (g.standard_normal((n, 32)) * 0.01).astype(np.float32)}
+    m.build_model(init)
+    om = MT.FM(np.float32(0.0), init["wi"], init["vif"], lr=0.01, reg=0.001)
+    np.random.seed(5)
+    rmse, mae, avg_loss = m.train_fm()
+    np.random.seed(5)
+    s_idx = np.random.permutation(900)
+    xi, xv, yy = data.X_idx_tr[s_idx], data.X_value_tr[s_idx], data.y_tr[s_idx]
+    tot, preds = 0.0, []
+    for b in range(4):
+        sl = slice(b * 256, (b + 1) * 256)
+        tot += om.step(xi[sl], xv[sl], yy[sl])
+        preds.append(om.last_y_pre)
+    r2, m2 = cal_rmse_mae(np.concatenate(preds).astype(np.float64), yy.astype(np.float64))
+    assert avg_loss == pytest.approx(tot / 4, rel=1e-5) and rmse == pytest.approx(r2, rel=1e-5) and mae == pytest.approx(m2, rel=1e-5)
+    rt, mt = m.test_fm()
+    w = {k: v for k, v in om.params.items()}
+    yp = om.y_pre(w, data.X_idx_t, data.X_value_t).numpy()
+    r3, m3 = cal_rmse_mae(data.y_t.astype(np.float64), yp.astype(np.float64))
+    assert rt == pytest.approx(r3, rel=1e-4) and mt == pytest.approx(m3, rel=1e-4)
