@@ -166,6 +166,40 @@ def ml100k_anchor(ref, sampler):
     return out
 
 
+def rating_case(ref):
+    """RatingPreprocess._read_file / _load_data on a small libfm-ish pair of files (the FM input contract)."""
+    from model.RatingPreprocess import RatingPreprocess
+    g = np.random.Generator(np.random.PCG64(21))
+    tmp = tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp, "syn"))
+    lines = {}
+    for name, n in (("syn.train.libfm", 300), ("syn.test.libfm", 80)):
+        rows = ["%d,%d:1,%d:1" % (g.integers(1, 6), g.integers(1, 60), 60 + g.integers(1, 40)) for _ in range(n)]
+        rows[3] = "4,7:0.5,%d:2" % (60 + 5)  # real-valued features
+        lines[name] = rows
+        with open(os.path.join(tmp, "syn", name), "w") as f:
+            f.write("\n".join(rows) + "\n")
+    cfg = {"recommender": "FM", "data.root_dir": tmp, "data.dataset": "syn", "train": ".train.libfm", "test": ".test.libfm",
+           "is_real_valued": "True"}
+    d = RatingPreprocess(cfg, logging.getLogger("golden"))
+    out = {"train_lines": np.array(lines["syn.train.libfm"]), "test_lines": np.array(lines["syn.test.libfm"]),
+           "feature_nums": d.feature_nums, "X_idx_tr": np.array(d.X_idx_tr, dtype=np.int64),
+           "X_value_tr": np.array(d.X_value_tr, dtype=np.float64), "y_tr": np.array(d.y_tr, dtype=np.float64),
+           "X_idx_t": np.array(d.X_idx_t, dtype=np.int64), "X_value_t": np.array(d.X_value_t, dtype=np.float64),
+           "y_t": np.array(d.y_t, dtype=np.float64)}
+    # anchor on the one real FM file in the checkout (hashes only)
+    real = os.path.join(ref, "dataset", "ml-1m", "ml-1m.test.libfm")
+    if os.path.exists(real):
+        o = RatingPreprocess.__new__(RatingPreprocess)
+        o.is_real_valued, o.all_features = True, {}
+        xi, xv, yy = o._read_file(real)
+        idx = np.array([[o.all_features[c] for c in r] for r in xi], dtype=np.int64)
+        h = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+        out.update(ml1m_rows=len(yy), ml1m_features=len(o.all_features), ml1m_idx_hash=h(idx),
+                   ml1m_val_hash=h(np.array(xv, dtype=np.float64)), ml1m_y_hash=h(np.array(yy, dtype=np.float64)))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -188,6 +222,7 @@ def main():
     with open(os.path.join(a.out, "metrics.json"), "w") as f:
         json.dump(metrics_cases(metrics), f)
     np.savez_compressed(os.path.join(a.out, "preprocess_syn.npz"), **preprocess_case(a.ref))
+    np.savez_compressed(os.path.join(a.out, "rating_syn.npz"), **rating_case(a.ref))
     anchor = ml100k_anchor(a.ref, sampler)
     if anchor is not None:
         with open(os.path.join(a.out, "ml100k_anchor.json"), "w") as f:
