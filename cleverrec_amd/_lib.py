@@ -47,6 +47,10 @@ class Fm(C.Structure):
     _fields_ = [("w0", Param), ("wi", Param), ("vif", Param), ("reg", C.c_float)]
 
 
+class Cml(C.Structure):
+    _fields_ = [("P", Param), ("Q", Param), ("reg", C.c_float), ("margin", C.c_float)]
+
+
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 _SIGNATURES = {
     "crec_version": (C.c_int, []),
@@ -68,6 +72,8 @@ _SIGNATURES = {
     "crec_fm_train_epoch": (C.c_int, [_vp, C.POINTER(Fm), C.POINTER(Adam), _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
     "crec_fm_predict": (C.c_int, [_vp, C.POINTER(Fm), _vp, _vp, _i64, _i32, _vp, _vp]),
     "crec_rmse_mae": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    "crec_cml_train_epoch": (C.c_int, [_vp, C.POINTER(Cml), C.POINTER(Adam), _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
+    "crec_cml_eval_tables": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp]),
     "crec_bpr_train_epoch_dp": (C.c_int, [_vp, C.POINTER(BprTables), C.POINTER(Adam), _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "crec_comm_unique_id": (C.c_int, [_vp, _vp]),
     "crec_comm_init": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
@@ -129,7 +135,7 @@ class Context:
 
     # ---- measurement ---------------------------------------------------------------------------
     KERNELS = ("bpr_index_batches", "bpr_step_fused", "bpr_user_side", "bpr_item_side", "bpr_reduce_loss", "eval_sweep",
-               "eval_merge", "rank_metrics", "bpr_finish_heavy", "bpr_adam_dense", "rows_index_batches", "rows_apply", "small_adam_dense", "ncf_tile", "fm_instances")
+               "eval_merge", "rank_metrics", "bpr_finish_heavy", "bpr_adam_dense", "rows_index_batches", "rows_apply", "small_adam_dense", "ncf_tile", "fm_instances", "cml_instances")
 
     def profile(self, on):
         self.check(self.lib.crec_profile_enable(self.h, int(bool(on))))

@@ -24,6 +24,7 @@ SOURCES = {
     "rows_adam.hip": ["-ffp-contract=off"],
     "ncf.hip": ["-ffp-contract=off"],
     "fm.hip": ["-ffp-contract=off"],
+    "cml.hip": ["-ffp-contract=off"],
 }
 
 

@@ -1,0 +1,289 @@
+// Collaborative Metric Learning for gfx950.
+//
+// Replaces sess.run([train, loss], {u_idx, i_idx, neg_items}) (model/RankingRecommender.py:90-100) on the
+// graph of model/ranking/CML.py:34-70; see include/crec.h (crec_cml).
+//
+//   d_ui = |p_u - q_i|^2, d_un[k] = |p_u - q_neg[k]|^2                                   (CML.py:42-43)
+//   loss_b = max(d_ui + margin - min_k d_un, 0) * log(rank + 1),
+//   rank   = mean_k[d_ui + margin - d_un[k] > 0] * item_nums / neg_ratio   (no gradient)  (CML.py:45-53)
+//   + reg * sum_{a != b} cov([Q;P])_ab                                                    (CML.py:63-70)
+// The covariance term reads the full tables, so P and Q get dense gradients -> TF1 dense ApplyAdam on
+// every row.  Its gradient needs no d x d product: with X centred by the column means mu,
+// dL/dX_ra = (2 reg / n)(s_r - Xc_ra), s_r = sum_b Xc_rb (rows_adam.hip).
+//
+// Per batch: cml_colsum x2 (mu) -> cml_instances (one lane group per instance: distances, arg-min negative,
+// WARP weight, contribution rows for p_u, q_i and the arg-min negative, whose row id is only known now) ->
+// rows_index (item slots of this batch) -> rows_apply P, rows_apply Q -> cml_reduce_loss.
+#include "crec_internal.h"
+#include "rows_adam.h"
+
+namespace {
+
+__device__ inline float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ inline void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+
+template <int LPR> __device__ inline float gsum(float v)
+{
+#pragma unroll
+    for (int off = LPR >> 1; off > 0; off >>= 1)
+        v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ inline float sqdist4(float4 a, float4 b)
+{
+    const float x = a.x - b.x, y = a.y - b.y, z = a.z - b.z, w = a.w - b.w;
+    return (x * x + y * y) + (z * z + w * w);
+}
+
+// stage 1: block b sums rows [b*rpb, (b+1)*rpb) of one table, column-wise; thread = column
+__global__ void cml_colsum(const float *__restrict__ X, int64_t rows, int d, int64_t rpb, float *__restrict__ partial)
+{
+    const int c = threadIdx.x;
+    if (c >= d)
+        return;
+    const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = (r0 + rpb) < rows ? (r0 + rpb) : rows;
+    float s = 0.f;
+    for (int64_t r = r0; r < r1; ++r)
+        s = s + X[r * d + c];
+    partial[(int64_t)blockIdx.x * d + c] = s;
+}
+
+// stage 2: mu[c] = (sum of all partials of both tables) / n
+__global__ void cml_colmean(const float *__restrict__ partial, int n_partials, int d, float n, float *__restrict__ mu)
+{
+    const int c = threadIdx.x;
+    if (c >= d)
+        return;
+    float s = 0.f;
+    for (int p = 0; p < n_partials; ++p)
+        s = s + partial[(int64_t)p * d + c];
+    mu[c] = s / n;
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void cml_instances(const float *__restrict__ P, const float *__restrict__ Q, int d,
+                                                     const int32_t *__restrict__ u, const int32_t *__restrict__ i,
+                                                     const int32_t *__restrict__ neg, int n, int K, float margin,
+                                                     float rank_scale /* item_nums / neg_ratio */, float *__restrict__ c_p,
+                                                     float *__restrict__ c_q, int32_t *__restrict__ item_slots,
+                                                     float *__restrict__ loss_inst)
+{
+    constexpr int G = 64 / LPR;
+    const int lane = threadIdx.x & 63, g = lane / LPR, l = lane % LPR;
+    const int64_t inst = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * G + g;
+    const bool ok = inst < n, act = 4 * l < d;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int uu = ok ? u[inst] : 0, ii = ok ? i[inst] : 0;
+    const float4 p = (ok && act) ? ld4(P + (int64_t)uu * d + 4 * l) : zero;
+    const float4 qi = (ok && act) ? ld4(Q + (int64_t)ii * d + 4 * l) : zero;
+    const float d_ui = gsum<LPR>(sqdist4(p, qi));
+    float dmin = INFINITY;
+    int kmin = 0, imp = 0;
+    for (int k = 0; k < K; ++k) { // wave-uniform trip count
+        const int nk = ok ? neg[inst * K + k] : 0;
+        const float4 qn = (ok && act) ? ld4(Q + (int64_t)nk * d + 4 * l) : zero;
+        const float dn = gsum<LPR>(sqdist4(p, qn));
+        if (dn < dmin) { // first minimum wins
+            dmin = dn;
+            kmin = nk;
+        }
+        imp += (d_ui + margin - dn) > 0.f;
+    }
+    const float base = fmaxf(d_ui + margin - dmin, 0.f);
+    const float rank = ((float)imp / (float)K) * rank_scale;
+    const float wgt = logf(rank + 1.0f);
+    if (!ok)
+        return;
+    if (l == 0) {
+        loss_inst[inst] = base * wgt;
+        item_slots[2 * inst] = ii;
+        item_slots[2 * inst + 1] = kmin;
+    }
+    if (act) {
+        const float4 qm = ld4(Q + (int64_t)kmin * d + 4 * l);
+        const float w2 = base > 0.f ? 2.0f * wgt : 0.f;
+        // d/dp = w2*((p-qi) - (p-qm)); d/dqi = -w2*(p-qi); d/dqm = +w2*(p-qm)
+        const float4 a = make_float4(p.x - qi.x, p.y - qi.y, p.z - qi.z, p.w - qi.w);
+        const float4 b = make_float4(p.x - qm.x, p.y - qm.y, p.z - qm.z, p.w - qm.w);
+        st4(c_p + inst * d + 4 * l, make_float4(w2 * (a.x - b.x), w2 * (a.y - b.y), w2 * (a.z - b.z), w2 * (a.w - b.w)));
+        st4(c_q + (2 * inst) * d + 4 * l, make_float4(-w2 * a.x, -w2 * a.y, -w2 * a.z, -w2 * a.w));
+        st4(c_q + (2 * inst + 1) * d + 4 * l, make_float4(w2 * b.x, w2 * b.y, w2 * b.z, w2 * b.w));
+    }
+}
+
+// loss_b = sum_b loss_inst + (reg / n) * (sum_r rowP + sum_r rowQ), float64, fixed order
+__global__ __launch_bounds__(256) void cml_reduce_loss(const float *__restrict__ loss_inst, int nb,
+                                                       const float *__restrict__ rowP, int64_t U,
+                                                       const float *__restrict__ rowQ, int64_t I, float reg_over_n,
+                                                       float *__restrict__ out)
+{
+    __shared__ double part[256];
+    double s = 0.0, c = 0.0;
+    for (int k = threadIdx.x; k < nb; k += 256)
+        s += (double)loss_inst[k];
+    for (int64_t k = threadIdx.x; k < U; k += 256)
+        c += (double)rowP[k];
+    for (int64_t k = threadIdx.x; k < I; k += 256)
+        c += (double)rowQ[k];
+    part[threadIdx.x] = s + (double)reg_over_n * c;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off)
+            part[threadIdx.x] += part[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        *out = (float)part[0];
+}
+
+// rs-evaluation tables (CML.py:76,84; RankingRecommender.py:222-223): |clip_1(p) - q|^2 ascending ==
+// (-2 clip_1(p)) . q + |q|^2 ascending, i.e. a dot product of vectors widened by one slot (padded to 4):
+//   P_aug = [-2 clip_1(p), 1, 0, 0, 0],  Q_aug = [q, |q|^2, 0, 0, 0]
+__global__ void cml_aug_tables(const float *__restrict__ P, const float *__restrict__ Q, int64_t U, int64_t I, int d,
+                               float *__restrict__ Pa, float *__restrict__ Qa)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int da = d + 4;
+    if (r < U) {
+        float nn = 0.f;
+        for (int c = 0; c < d; ++c)
+            nn = nn + P[r * d + c] * P[r * d + c];
+        const float nrm = sqrtf(nn), sc = nrm > 1.0f ? 1.0f / nrm : 1.0f; // tf.clip_by_norm(., 1.0, axes=[1])
+        for (int c = 0; c < d; ++c)
+            Pa[r * da + c] = -2.0f * (P[r * d + c] * sc);
+        Pa[r * da + d] = 1.0f;
+        Pa[r * da + d + 1] = Pa[r * da + d + 2] = Pa[r * da + d + 3] = 0.f;
+    } else if (r < U + I) {
+        const int64_t q = r - U;
+        float nn = 0.f;
+        for (int c = 0; c < d; ++c) {
+            const float v = Q[q * d + c];
+            Qa[q * da + c] = v;
+            nn = nn + v * v;
+        }
+        Qa[q * da + d] = nn;
+        Qa[q * da + d + 1] = Qa[q * da + d + 2] = Qa[q * da + d + 3] = 0.f;
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+int crec_cml_train_epoch(crec_ctx *ctx, const crec_cml *m, crec_adam *opt, const int32_t *u, const int32_t *i,
+                         const int32_t *neg, int64_t N, int32_t K, int32_t B, float *loss_per_batch, void *stream)
+{
+    if (!ctx)
+        return CREC_EINVAL;
+    CREC_REQUIRE(ctx, ctx->device >= 0, "host-only ctx: no device bound");
+    CREC_REQUIRE(ctx, m && opt && m->P.var && m->Q.var && m->P.cols == m->Q.cols, "CML tables");
+    const int d = m->P.cols;
+    CREC_REQUIRE(ctx, d % 4 == 0 && d >= 4 && d <= 256, "embed_size %d: need a multiple of 4 in [4, 256]", d);
+    CREC_REQUIRE(ctx, K >= 1 && B >= 1 && B <= 8192, "neg_ratio >= 1, batch_size <= 8192");
+    CREC_REQUIRE(ctx, N >= 0 && (N == 0 || (u && i && neg && loss_per_batch)), "null argument");
+    if (N == 0)
+        return CREC_OK;
+    CREC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t U = m->P.rows, I = m->Q.rows, nb = crec_ceil_div(N, B);
+    int lpr = 1;
+    while (lpr * 4 < d)
+        lpr <<= 1;
+    const int G = 64 / lpr;
+    auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+    const int64_t rpb = 256; // rows per column-sum block
+    const int nbP = (int)crec_ceil_div(U, rpb), nbQ = (int)crec_ceil_div(I, rpb);
+    const size_t ixu = crec_rows_index_bytes(nb, B, U), ixq = crec_rows_index_bytes(1, 2 * B, I);
+    const size_t cpb = sizeof(float) * (size_t)B * d, cqb = sizeof(float) * (size_t)2 * B * d;
+    const size_t sl = sizeof(int32_t) * (size_t)2 * B, li = sizeof(float) * (size_t)B;
+    const size_t pp = sizeof(float) * (size_t)(nbP + nbQ) * d, mub = sizeof(float) * 256;
+    const size_t rP = sizeof(float) * (size_t)U, rQ = sizeof(float) * (size_t)I;
+    if (int rc = crec_reserve(ctx, &ctx->idx_ws, up(ixu) + up(ixq) + up(cpb) + up(cqb) + up(sl) + up(li) + up(pp) + up(mub) + up(rP) + up(rQ)))
+        return rc;
+    char *ws = (char *)ctx->idx_ws.ptr;
+    crec_rows_index_view vu, vq;
+    if (int rc = crec_rows_index(ctx, u, N, B, U, ws, &vu, st))
+        return rc;
+    char *p = ws + up(ixu);
+    char *ixq_ws = p;
+    p += up(ixq);
+    float *c_p = (float *)p;
+    p += up(cpb);
+    float *c_q = (float *)p;
+    p += up(cqb);
+    int32_t *slots = (int32_t *)p;
+    p += up(sl);
+    float *loss_inst = (float *)p;
+    p += up(li);
+    float *partial = (float *)p;
+    p += up(pp);
+    float *mu = (float *)p;
+    p += up(mub);
+    float *rowP = (float *)p;
+    p += up(rP);
+    float *rowQ = (float *)p;
+    const float n_rows = (float)(U + I);
+
+    for (int64_t b = 0; b < nb; ++b) {
+        const int64_t t0 = b * B;
+        const int nbt = (int)((N - t0) < B ? (N - t0) : B);
+        crec_rows_opt o{};
+        o.kind = ROWS_DENSE;
+        o.cov_coef = 2.0f * m->reg / n_rows;
+        o.lr_t = (opt->lr * sqrtf(1.0f - opt->beta2_power)) / (1.0f - opt->beta1_power);
+        o.beta1 = opt->beta1;
+        o.beta2 = opt->beta2;
+        o.eps = opt->eps;
+        hipLaunchKernelGGL(cml_colsum, dim3(nbQ), dim3(256), 0, st, (const float *)m->Q.var, I, d, rpb, partial);
+        hipLaunchKernelGGL(cml_colsum, dim3(nbP), dim3(256), 0, st, (const float *)m->P.var, U, d, rpb, partial + (size_t)nbQ * d);
+        hipLaunchKernelGGL(cml_colmean, dim3(1), dim3(256), 0, st, (const float *)partial, nbP + nbQ, d, n_rows, mu);
+        const int waves = (int)crec_ceil_div(nbt, G);
+        const dim3 grid((unsigned)crec_ceil_div(waves, 4));
+        crec_prof_begin(ctx, CREC_K_CML_INSTANCES, st);
+#define CREC_CML(L)                                                                                                          \
+    case L:                                                                                                                  \
+        hipLaunchKernelGGL((cml_instances<L>), grid, dim3(256), 0, st, (const float *)m->P.var, (const float *)m->Q.var, d,  \
+                           u + t0, i + t0, neg + t0 * K, nbt, (int)K, m->margin, (float)I / (float)K, c_p, c_q, slots,        \
+                           loss_inst);                                                                                       \
+        break;
+        switch (lpr) {
+            CREC_CML(1)
+            CREC_CML(2)
+            CREC_CML(4)
+            CREC_CML(8)
+            CREC_CML(16)
+            CREC_CML(32)
+            CREC_CML(64)
+        }
+#undef CREC_CML
+        crec_prof_end(ctx, st);
+        if (int rc = crec_rows_index(ctx, slots, 2 * (int64_t)nbt, 2 * B, I, ixq_ws, &vq, st))
+            return rc;
+        crec_rows_apply(ctx, crec_rows_table{m->P.var, m->P.m, m->P.v, U, d}, vu, b, c_p, mu, o, st, rowP);
+        crec_rows_apply(ctx, crec_rows_table{m->Q.var, m->Q.m, m->Q.v, I, d}, vq, 0, c_q, mu, o, st, rowQ);
+        hipLaunchKernelGGL(cml_reduce_loss, dim3(1), dim3(256), 0, st, (const float *)loss_inst, nbt, (const float *)rowP, U,
+                           (const float *)rowQ, I, m->reg / n_rows, loss_per_batch + b);
+        opt->beta1_power = opt->beta1_power * opt->beta1;
+        opt->beta2_power = opt->beta2_power * opt->beta2;
+        opt->step += 1;
+    }
+    CREC_HIP(ctx, hipGetLastError());
+    return crec_prof_flush(ctx, st);
+}
+
+int crec_cml_eval_tables(crec_ctx *ctx, const float *P, const float *Q, int64_t U, int64_t I, int32_t d, float *P_aug,
+                         float *Q_aug, void *stream)
+{
+    if (!ctx)
+        return CREC_EINVAL;
+    CREC_REQUIRE(ctx, ctx->device >= 0, "host-only ctx: no device bound");
+    CREC_REQUIRE(ctx, P && Q && P_aug && Q_aug && U >= 1 && I >= 1 && d >= 1, "bad argument");
+    CREC_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(cml_aug_tables, dim3((unsigned)crec_ceil_div(U + I, 256)), dim3(256), 0, (hipStream_t)stream, P, Q, U, I,
+                       d, P_aug, Q_aug);
+    CREC_HIP(ctx, hipGetLastError());
+    return CREC_OK;
+}
+
+} // extern "C"

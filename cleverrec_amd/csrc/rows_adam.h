@@ -14,6 +14,7 @@ struct crec_rows_opt {
     int kind;         // ROWS_*
     float reg_occ;    // l2 weight applied once per occurrence of a row (tf.nn.l2_loss on gathered rows)
     float dense_reg;  // ROWS_DENSE: l2 weight on the whole table (FM.py:52)
+    float cov_coef;   // ROWS_DENSE, CML: 2*reg/n of the covariance term; dense_grad then holds the column means
     float lr_t, beta1, beta2, eps;
 };
 
@@ -28,6 +29,7 @@ size_t crec_rows_index_bytes(int64_t n_batches, int32_t per_batch, int64_t rows)
 int crec_rows_index(crec_ctx *ctx, const int32_t *idx, int64_t n_total, int32_t per_batch, int64_t rows, void *ws,
                     crec_rows_index_view *out, hipStream_t st);
 int crec_rows_apply(crec_ctx *ctx, const crec_rows_table &t, const crec_rows_index_view &ix, int64_t batch,
-                    const float *contrib, const float *dense_grad, const crec_rows_opt &o, hipStream_t st);
+                    const float *contrib, const float *dense_grad, const crec_rows_opt &o, hipStream_t st,
+                    float *row_out = nullptr);
 int crec_small_adam_dense(crec_ctx *ctx, float *var, float *m, float *v, const float *partial, int n_partials,
                           int64_t stride, int n, const crec_rows_opt &o, hipStream_t st);

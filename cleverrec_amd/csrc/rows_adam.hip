@@ -78,7 +78,8 @@ __device__ inline void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) 
 template <int LPR>
 __global__ __launch_bounds__(256) void rows_apply(crec_rows_table t, const int2 *__restrict__ rowseg,
                                                   const int32_t *__restrict__ order, const float *__restrict__ contrib,
-                                                  const float *__restrict__ dense_grad, crec_rows_opt o)
+                                                  const float *__restrict__ dense_grad, float *__restrict__ row_out,
+                                                  crec_rows_opt o)
 {
     constexpr int G = 64 / LPR;
     const int lane = threadIdx.x & 63, g = lane / LPR, l = lane % LPR;
@@ -112,14 +113,33 @@ __global__ __launch_bounds__(256) void rows_apply(crec_rows_table t, const int2 
         acc.z = acc.z + z;
         acc.w = acc.w + w;
     }
+    // CML covariance term (CML.py:63-70): with X = [Q;P] centred by the column means mu,
+    // d/dX_ra of reg * sum_{a != b} cov_ab = (2*reg/n) * (s_r - Xc_ra), s_r = sum_b Xc_rb; the loss itself is
+    // (reg/n) * sum_r (s_r^2 - sum_a Xc_ra^2).  dense_grad then carries mu [d] instead of a per-row gradient.
+    float4 dg = zero;
+    if (o.cov_coef != 0.f) {
+        float4 xc = zero;
+        if (act) {
+            const float4 mu = ld4(dense_grad + 4 * l);
+            xc = make_float4(var.x - mu.x, var.y - mu.y, var.z - mu.z, var.w - mu.w);
+        }
+        float sr = (xc.x + xc.y) + (xc.z + xc.w), sq = (xc.x * xc.x + xc.y * xc.y) + (xc.z * xc.z + xc.w * xc.w);
+#pragma unroll
+        for (int off = LPR >> 1; off > 0; off >>= 1) {
+            sr += __shfl_xor(sr, off, 64);
+            sq += __shfl_xor(sq, off, 64);
+        }
+        dg = make_float4(o.cov_coef * (sr - xc.x), o.cov_coef * (sr - xc.y), o.cov_coef * (sr - xc.z), o.cov_coef * (sr - xc.w));
+        if (row_out && lane == 0)
+            row_out[r] = sr * sr - sq;
+    } else if (dense_grad && act && g == 0) {
+        dg = ld4(dense_grad + ro);
+    }
     if (g != 0 || !act)
         return;
     float4 m = ld4(t.m + ro), v = ld4(t.v + ro), nv = var;
     float *pg = &acc.x, *pm = &m.x, *pv = &v.x, *pn = &nv.x;
     const float *pvar = &var.x;
-    float4 dg = zero;
-    if (dense_grad)
-        dg = ld4(dense_grad + ro);
     const float *pdg = &dg.x;
     const float omb1 = 1.0f - o.beta1, omb2 = 1.0f - o.beta2;
 #pragma unroll
@@ -190,7 +210,7 @@ int crec_rows_index(crec_ctx *ctx, const int32_t *idx, int64_t n_total, int32_t 
 }
 
 int crec_rows_apply(crec_ctx *ctx, const crec_rows_table &t, const crec_rows_index_view &ix, int64_t batch,
-                    const float *contrib, const float *dense_grad, const crec_rows_opt &o, hipStream_t st)
+                    const float *contrib, const float *dense_grad, const crec_rows_opt &o, hipStream_t st, float *row_out)
 {
     int lpr = 1;
     while (lpr * 4 < t.d)
@@ -201,7 +221,7 @@ int crec_rows_apply(crec_ctx *ctx, const crec_rows_table &t, const crec_rows_ind
     crec_prof_begin(ctx, CREC_K_ROWS_APPLY, st);
 #define CREC_RA(L)                                                                                   \
     case L:                                                                                          \
-        hipLaunchKernelGGL((rows_apply<L>), grid, block, 0, st, t, rs, ord, contrib, dense_grad, o); \
+        hipLaunchKernelGGL((rows_apply<L>), grid, block, 0, st, t, rs, ord, contrib, dense_grad, row_out, o); \
         break;
     switch (lpr) {
         CREC_RA(1)

@@ -188,3 +188,35 @@ def rmse_mae(sess, y, y_pre):
                                           sess.stream_ptr()))
     r = out.cpu().numpy()
     return float(r[0]), float(r[1])
+
+
+class CmlState:
+    """P, Q of model/ranking/CML.py:28-32 with Adam slots in HBM (crec_cml)."""
+
+    def __init__(self, sess, P0, Q0, lr, reg, margin, beta1=0.9, beta2=0.999, eps=1e-8):
+        self.sess = sess
+        f32 = torch.float32
+        self.P, self.Q = sess.to_dev(P0, f32).contiguous(), sess.to_dev(Q0, f32).contiguous()
+        self.mP, self.vP = torch.zeros_like(self.P), torch.zeros_like(self.P)
+        self.mQ, self.vQ = torch.zeros_like(self.Q), torch.zeros_like(self.Q)
+        par = lambda t, m, v: _lib.Param(t.data_ptr(), m.data_ptr(), v.data_ptr(), t.shape[0], t.shape[1])
+        self.model = _lib.Cml(par(self.P, self.mP, self.vP), par(self.Q, self.mQ, self.vQ), reg, margin)
+        self.adam = _lib.Adam(lr, beta1, beta2, eps, 0.0, _lib.ADAM_TF1, beta1, beta2, 0)
+
+    def train_epoch(self, u, i, neg, batch_size):
+        """u, i int32 [N], neg int32 [N, K] (device) -> per-batch losses (device fp32)."""
+        s = self.sess
+        n, K = neg.shape
+        loss = s.empty((-(-n // batch_size),), torch.float32)
+        s.ctx.check(s.lib.crec_cml_train_epoch(s.ctx.h, C.byref(self.model), C.byref(self.adam), s.ptr(u), s.ptr(i), s.ptr(neg),
+                                               n, K, int(batch_size), s.ptr(loss), s.stream_ptr()))
+        return loss
+
+    def eval_tables(self):
+        """(P_aug, Q_aug) for crec_eval_topk(ascending=1): CML._predict's distances as a dot product."""
+        s = self.sess
+        U, d = self.P.shape
+        I = self.Q.shape[0]
+        Pa, Qa = s.empty((U, d + 4), torch.float32), s.empty((I, d + 4), torch.float32)
+        s.ctx.check(s.lib.crec_cml_eval_tables(s.ctx.h, s.ptr(self.P), s.ptr(self.Q), U, I, d, s.ptr(Pa), s.ptr(Qa), s.stream_ptr()))
+        return Pa, Qa

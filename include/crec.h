@@ -55,7 +55,7 @@ const char *crec_last_error(const crec_ctx *ctx);
  * ends with a stream synchronise (so do not time whole-job throughput with it on).
  * kernel_class: 0 bpr_index_batches, 1 bpr_step_fused, 2 bpr_user_side, 3 bpr_item_side,
  *               4 bpr_reduce_loss, 5 eval_sweep, 6 eval_merge, 7 rank_metrics, 8 bpr_finish_heavy, 9 bpr_adam_dense,
- *               10 rows_index_batches, 11 rows_apply, 12 small_adam_dense, 13 ncf_tile, 14 fm_instances.
+ *               10 rows_index_batches, 11 rows_apply, 12 small_adam_dense, 13 ncf_tile, 14 fm_instances, 15 cml_instances.
  * enable(.., 1) also clears the accumulated totals. */
 int crec_profile_enable(crec_ctx *ctx, int on);
 int crec_profile_read(const crec_ctx *ctx, int kernel_class, double *total_ms, int64_t *launches);
@@ -167,6 +167,23 @@ int crec_fm_predict(crec_ctx *ctx, const crec_fm *model, const int32_t *x_idx, c
                     float *y_pre, void *stream);
 /* out2 [dev] double[2] = {rmse, mae} in float64 */
 int crec_rmse_mae(crec_ctx *ctx, const float *y, const float *y_pre, int64_t n, double *out2, void *stream);
+
+/* ---- Collaborative Metric Learning (device) ----------------------------------------------------------
+ * replaces sess.run([self.train, self.loss], {u_idx, i_idx, neg_items}) (model/RankingRecommender.py:90-100)
+ * on the graph of model/ranking/CML.py:34-70 (hinge on the closest sampled negative, WARP rank weight,
+ * covariance regulariser over [Q;P]).  P ('cml_params/P') and Q take dense ApplyAdam on every row.
+ *   u, i int32 [N]; neg int32 [N, K] (ranking_sampler_cml); B <= 8192. */
+typedef struct {
+    crec_param P, Q;
+    float reg, margin; /* configs['reg'], configs['margin'] */
+} crec_cml;
+int crec_cml_train_epoch(crec_ctx *ctx, const crec_cml *model, crec_adam *opt, const int32_t *u, const int32_t *i,
+                         const int32_t *neg, int64_t N, int32_t K, int32_t B, float *loss_per_batch, void *stream);
+/* rs-evaluation form of CML._predict (CML.py:76,84): |clip_1(p_u) - q_i|^2 ascending equals the ascending
+ * dot product of P_aug [U, d+4] = [-2 clip_1(p), 1, 0,0,0] and Q_aug [I, d+4] = [q, |q|^2, 0,0,0]; feed them to
+ * crec_eval_topk with ascending = 1 (cml_like, model/RankingRecommender.py:222-223). */
+int crec_cml_eval_tables(crec_ctx *ctx, const float *P, const float *Q, int64_t U, int64_t I, int32_t d, float *P_aug,
+                         float *Q_aug, void *stream);
 
 /* ---- data-parallel training over RCCL (one process per GPU of one node) -----------------------
  * The path shards with one real exchange: gradients of the same Q row must be summed over all ranks'

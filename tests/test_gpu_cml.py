@@ -1,0 +1,67 @@
+"""CML training / rs-evaluation (HIP, through the C ABI) against the torch-autograd restatement of
+model/ranking/CML.py with TF1 dense Adam (oracle/models_torch.py).  Needs an MI355X."""
+import logging
+
+import numpy as np
+import pytest
+
+import oracle
+from oracle import models_torch as MT
+from cleverrec_amd import runtime
+from cleverrec_amd.data import RankingData
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sess():
+    s = runtime.Session(0)
+    yield s
+    s.close()
+
+
+@pytest.mark.parametrize("d,K", [(16, 5), (128, 20)])
+def test_cml_steps_match_oracle(sess, d, K):
+    g = np.random.Generator(np.random.PCG64(d))
+    U, I, B, N = 70, 90, 200, 2 * 200 + 50
+    P = (g.standard_normal((U, d)) * 0.3).astype(np.float32)
+    Q = (g.standard_normal((I, d)) * 0.3).astype(np.float32)
+    u, i = g.integers(0, U, N).astype(np.int32), g.integers(0, I, N).astype(np.int32)
+    neg = g.integers(0, I, (N, K)).astype(np.int32)
+    st = runtime.CmlState(sess, P, Q, lr=1e-3, reg=10.0, margin=1.0)
+    om = MT.CML(P, Q, lr=1e-3, reg=10.0, margin=1.0, item_nums=I)
+    loss = st.train_epoch(sess.to_dev(u), sess.to_dev(i), sess.to_dev(neg), B).cpu().numpy()
+    ol = [om.step(u[b * B:(b + 1) * B], i[b * B:(b + 1) * B], neg[b * B:(b + 1) * B]) for b in range(len(loss))]
+    np.testing.assert_allclose(loss, ol, rtol=2e-5)
+    np.testing.assert_allclose(st.P.cpu().numpy(), om.numpy("P"), rtol=0, atol=1e-5)
+    np.testing.assert_allclose(st.Q.cpu().numpy(), om.numpy("Q"), rtol=0, atol=1e-5)
+
+
+def test_cml_class_surface_and_distance_ranking(sess, tmp_path):
+    from cleverrec_amd.model.ranking.CML import CML
+    g = np.random.Generator(np.random.PCG64(2))
+    U, I, d = 120, 100, 32
+    ui_train = {uu: [int(x) for x in g.choice(I, size=int(g.integers(3, 15)), replace=False)] for uu in range(U)}
+    ui_test = {uu: [int(x) for x in g.choice(I, size=2, replace=False)] for uu in range(0, U, 2)}
+    data = RankingData(U, I, ui_train, ui_test)
+    configs = {"recommender": "CML", "epoches": "2", "batch_size": "256", "test.batch_size": "64", "lr": "0.001",
+               "test.neg_samples": "0", "is_pairwise": "False", "init_method": "xavier", "stddev": "0.01",
+               "loss_func": "hinge", "optimizer": "Adam", "saved_dir": str(tmp_path), "test.interval": "1", "topk": "[10,20]",
+               "neg_ratio": "5", "embed_size": str(d), "reg": "10.0", "margin": "1.0", "cml_like": "True", "data.split_way": "rs"}
+    m = CML(sess, data, configs, logging.getLogger("t"))
+    assert m.cml_like
+    init = {"P": (g.standard_normal((U, d)) * 0.4).astype(np.float32), "Q": (g.standard_normal((I, d)) * 0.4).astype(np.float32)}
+    m.build_model(init)
+    om = MT.CML(init["P"], init["Q"], lr=1e-3, reg=10.0, margin=1.0, item_nums=I)
+    np.random.seed(3)
+    rng = oracle.Rng(3)
+    avg = m.train_model()
+    nb, ou, oi, oneg = oracle.sample_cml(rng, data.ui_train, I, 5, 256)
+    tot = sum(om.step(ou[b * 256:(b + 1) * 256], oi[b * 256:(b + 1) * 256], oneg[b * 256:(b + 1) * 256]) for b in range(nb))
+    assert avg == pytest.approx(tot / nb, rel=2e-5)
+    HR, MRR, NDCG = m.test_model_rs()
+    dev = MT.CML(m.P.cpu().numpy(), m.Q.cpu().numpy(), lr=1e-3, reg=10.0, margin=1.0, item_nums=I)
+    H, M, N = oracle.test_model_rs_py(lambda cur: dev.predict(cur), m.test_users, data.ui_train, data.ui_test, [10, 20], 64,
+                                      ascending=True)
+    np.testing.assert_allclose(np.mean(NDCG[0]), np.mean(N[0]), rtol=1e-6)
+    np.testing.assert_allclose(np.mean(HR[1]), np.mean(H[1]), rtol=1e-6)
