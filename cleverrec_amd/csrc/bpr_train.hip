@@ -354,6 +354,22 @@ __device__ inline float tf_softplus(float z)
     return log1pf(expf(z));
 }
 
+// The two quotients of the step.  An IEEE-exact fp32 divide or square root is a ~15-instruction software
+// sequence on gfx950 and these kernels are instruction-issue bound, so by default both use
+// the hardware v_rcp_f32 / v_sqrt_f32 / v_exp_f32 (<= 1 ulp each): the update differs from the exactly
+// rounded one by <= ~3e-7 of ITSELF (an update is ~lr = 1e-3), five orders below the 1e-5 parity bar.
+// -DCREC_EXACT_MATH restores the exactly rounded forms (bit-reproducible against the CPU oracle's Adam).
+#ifdef CREC_EXACT_MATH
+__device__ inline float adam_quot(float num, float v, float eps) { return num / (sqrtf(v) + eps); }
+__device__ inline float sigmoid_neg(float x) { return 1.0f / (1.0f + expf(x)); }
+#else
+__device__ inline float adam_quot(float num, float v, float eps)
+{
+    return num * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) + eps);
+}
+__device__ inline float sigmoid_neg(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(x)); }
+#endif
+
 // TF1 Adam on one float4 of a row.  touched == false: the g = 0 sweep of a row the batch does not
 // index (m, v still decay and var still moves: _apply_sparse_shared).
 __device__ inline void adam4(float4 &var, float4 &m, float4 &v, float4 g, bool touched, const Hyper &h)
@@ -371,7 +387,7 @@ __device__ inline void adam4(float4 &var, float4 &m, float4 &v, float4 g, bool t
         }
         pm[c] = mk;
         pw[c] = vk;
-        pv[c] = pv[c] - (h.lr_t * mk) / (sqrtf(vk) + h.eps);
+        pv[c] = pv[c] - adam_quot(h.lr_t * mk, vk, h.eps);
     }
 }
 
@@ -408,7 +424,7 @@ template <int LPR> __device__ inline float triple_s(float4 p, float4 qi, float4 
     const float dj = group_sum<LPR>(dot4(p, qj));
     const float x = di - dj; // ui_scores - uj_scores (BPR.py:39-42)
     *x_out = x;
-    return 1.0f / (1.0f + expf(x)); // sigmoid(-x) = -d softplus(-x)/dx
+    return sigmoid_neg(x); // sigmoid(-x) = -d softplus(-x)/dx
 }
 
 
@@ -426,9 +442,12 @@ template <int LPR> __device__ inline float triple_s(float4 p, float4 qi, float4 
 // G groups on one row) write partial gradients, normal waves skip such a slot, and bpr_finish_heavy
 // adds the partials in chunk order and applies Adam.  Every sum keeps one fixed order.
 // ------------------------------------------------------------------------------------
+// RW = rows per wave requested | (FULL << 8); FULL: d == 4 * LPR, every lane owns a live float4 (lets the
+// compiler drop the per-lane "inside the row" predicate and its exec-mask branches)
 template <int LPR, int RW> struct Geo {
     static constexpr int G = 64 / LPR;
-    static constexpr int R = G < RW ? G : RW;
+    static constexpr int R = G < (RW & 0xff) ? G : (RW & 0xff);
+    static constexpr bool FULL = ((RW >> 8) & 1) != 0;
 };
 
 template <int LPR, int RW> using AccArr = float4[Geo<LPR, RW>::R];
@@ -519,7 +538,8 @@ __device__ __forceinline__ void trip_issue(Trip &tr, const WaveCtx<Geo<LPR, RW>:
             s += k >= w.e[q];
         tr.slot[t] = s;
         tr.a[t] = tr.b[t] = zero;
-        if (tr.has[t] && w.act) {
+        // FULL: a dead slot's record is all zeros -> row 0, a harmless load, so no exec-mask branch is needed
+        if (Geo<LPR, RW>::FULL || (tr.has[t] && w.act)) {
             if (CREC_ABL & 1) {
                 tr.a[t] = ld4(w.Q + (int64_t)(tr.rec[t].y & 3) * w.d + 4 * w.l);
                 tr.b[t] = ld4(w.Q + (int64_t)(tr.rec[t].z & 3) * w.d + 4 * w.l);
@@ -576,11 +596,13 @@ __device__ __forceinline__ void trip_consume(const Trip &tr, const WaveCtx<Geo<L
             c.z = sg * sp.z + w.reg * own.z;
             c.w = sg * sp.w + w.reg * own.w;
         }
+        // branch-free: a contribution that is not taken is added as +0 (exact)
         const bool take = tr.has[t] && w.act;
 #pragma unroll
-        for (int s = 0; s < R; ++s)
-            if (take && tr.slot[t] == s)
-                add4(acc[s], c);
+        for (int s = 0; s < R; ++s) {
+            const float k = (take && tr.slot[t] == s) ? 1.0f : 0.0f;
+            add4(acc[s], make_float4(k * c.x, k * c.y, k * c.z, k * c.w));
+        }
     }
 }
 
@@ -633,7 +655,7 @@ __device__ inline float4 slots_grad(float4 var, const Slot &sl, int n_valid, con
     w.d = d;
     w.g = lane / LPR;
     w.l = lane % LPR;
-    w.act = 4 * w.l < d;
+    w.act = Geo<LPR, RW>::FULL ? true : 4 * w.l < d;
     w.reg = h.reg;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     int st[R], cn[R]; // wave-uniform copies of the slots' segments
@@ -678,15 +700,15 @@ __device__ inline float4 slots_grad(float4 var, const Slot &sl, int n_valid, con
 // triple, every owner group stores its row term; bpr_reduce_loss does the softplus and the sums.
 // Per batch the workspace holds xb[B] then rowterm[RT] (RT = U + I in tf1 mode, 3B in lazy mode).
 // ------------------------------------------------------------------------------------
-template <int LPR, int MODE, bool STORE_CONTRIB>
+template <int LPR, int MODE, bool STORE_CONTRIB, bool FULL>
 __device__ inline void row_wave(const Tables &src, const Tables &dst, int d, const Slot &sl, int n_valid,
                                 const int4 *__restrict__ occ, float *__restrict__ contrib, float *__restrict__ xb,
                                 float *__restrict__ rowterm_slot, bool dense, const Hyper &h)
 {
-    constexpr int RW = ROWS_PER_WAVE, R = Geo<LPR, RW>::R;
+    constexpr int RW = ROWS_PER_WAVE | (FULL ? 0x100 : 0), R = Geo<LPR, RW>::R;
     const int lane = threadIdx.x & 63, g = lane / LPR, l = lane % LPR;
     const bool heavy = sl.cnt < 0;
-    const bool in_slot = g < R && g < n_valid && 4 * l < d;
+    const bool in_slot = g < R && g < n_valid && (FULL || 4 * l < d);
     const bool owner = in_slot && !heavy; // heavy rows are finished by bpr_finish_heavy
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool user = MODE == 0;
@@ -714,20 +736,20 @@ __device__ inline void row_wave(const Tables &src, const Tables &dst, int d, con
 }
 
 // one chunk (<= CH occurrences) of a heavy row: all G groups on the row, partial gradient out
-template <int LPR, int MODE, bool STORE_CONTRIB>
+template <int LPR, int MODE, bool STORE_CONTRIB, bool FULL>
 __device__ inline void chunk_wave(const Tables &src, int d, int4 item, const int4 *__restrict__ occ,
                                   float *__restrict__ contrib, float *__restrict__ xb, float *__restrict__ partial,
                                   const Hyper &h)
 {
     const int lane = threadIdx.x & 63, g = lane / LPR, l = lane % LPR;
-    const bool act = 4 * l < d;
+    const bool act = FULL || 4 * l < d;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     Slot sl;
     sl.row = item.x;
     sl.start = item.y;
     sl.cnt = item.z;
     const float4 var = act ? ld4((MODE == 0 ? src.P : src.Q) + sl.row * d + 4 * l) : zero; // every group: R == 1
-    const float4 grad = slots_grad<LPR, 1, MODE, STORE_CONTRIB>(var, sl, 1, src.P, src.Q, d, occ, contrib, xb, h);
+    const float4 grad = slots_grad<LPR, 1 | (FULL ? 0x100 : 0), MODE, STORE_CONTRIB>(var, sl, 1, src.P, src.Q, d, occ, contrib, xb, h);
     if (g == 0 && act)
         st4(partial + (int64_t)item.w * d + 4 * l, grad);
 }
@@ -745,7 +767,7 @@ struct HeavyArgs {
     int HIu, HIq, HRu, HRq;
 };
 
-template <int LPR>
+template <int LPR, bool FULL>
 __global__ __launch_bounds__(256) void bpr_step_fused(Tables src, Tables dst, int d, int64_t U, int64_t I,
                                                       const int2 *__restrict__ u_rowseg,
                                                       const int4 *__restrict__ u_occ,
@@ -757,12 +779,12 @@ __global__ __launch_bounds__(256) void bpr_step_fused(Tables src, Tables dst, in
     const int lane = threadIdx.x & 63, g = lane / LPR;
     int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (wave_id < hv.HIu) {
-        chunk_wave<LPR, 0, false>(src, d, hv.u_hitems[wave_id], u_occ, nullptr, xb, hv.partial, h);
+        chunk_wave<LPR, 0, false, FULL>(src, d, hv.u_hitems[wave_id], u_occ, nullptr, xb, hv.partial, h);
         return;
     }
     wave_id -= hv.HIu;
     if (wave_id < hv.HIq) {
-        chunk_wave<LPR, 1, false>(src, d, hv.q_hitems[wave_id], q_occ, nullptr, xb,
+        chunk_wave<LPR, 1, false, FULL>(src, d, hv.q_hitems[wave_id], q_occ, nullptr, xb,
                                       hv.partial + (int64_t)hv.HIu * d, h);
         return;
     }
@@ -781,15 +803,15 @@ __global__ __launch_bounds__(256) void bpr_step_fused(Tables src, Tables dst, in
     sl.cnt = g < n_valid ? rs.y : 0;
     float *rt = rowterm + (is_user ? 0 : U) + sl.row;
     if (is_user)
-        row_wave<LPR, 0, false>(src, dst, d, sl, n_valid, u_occ, nullptr, xb, rt, true, h);
+        row_wave<LPR, 0, false, FULL>(src, dst, d, sl, n_valid, u_occ, nullptr, xb, rt, true, h);
     else
-        row_wave<LPR, 1, false>(src, dst, d, sl, n_valid, q_occ, nullptr, xb, rt, true, h);
+        row_wave<LPR, 1, false, FULL>(src, dst, d, sl, n_valid, q_occ, nullptr, xb, rt, true, h);
 }
 
 // ------------------------------------------------------------------------------------
 // lazy mode: touched rows only, in place, two launches (MODE 0 users, MODE 2 items)
 // ------------------------------------------------------------------------------------
-template <int LPR, int MODE>
+template <int LPR, int MODE, bool FULL>
 __global__ __launch_bounds__(256) void bpr_side_lazy(Tables t, int d, const int32_t *__restrict__ n_rows_p,
                                                      const int32_t *__restrict__ rows, const int32_t *__restrict__ seg,
                                                      const int4 *__restrict__ occ, const int32_t *__restrict__ n_chunks_p,
@@ -801,7 +823,7 @@ __global__ __launch_bounds__(256) void bpr_side_lazy(Tables t, int d, const int3
     const int lane = threadIdx.x & 63, g = lane / LPR;
     int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (wave_id < HI) {
-        chunk_wave<LPR, MODE, MODE == 0>(t, d, hitems[wave_id], occ, contrib, xb, partial, h);
+        chunk_wave<LPR, MODE, MODE == 0, FULL>(t, d, hitems[wave_id], occ, contrib, xb, partial, h);
         return;
     }
     wave_id -= HI;
@@ -817,7 +839,7 @@ __global__ __launch_bounds__(256) void bpr_side_lazy(Tables t, int d, const int3
     sl.start = seg[idx];
     const int cnt = seg[idx + 1] - sl.start;
     sl.cnt = g < n_valid ? (rw < 0 ? -cnt : cnt) : 0;
-    row_wave<LPR, MODE, MODE == 0>(t, t, d, sl, n_valid, occ, contrib, xb, rowterm + idx, false, h);
+    row_wave<LPR, MODE, MODE == 0, FULL>(t, t, d, sl, n_valid, occ, contrib, xb, rowterm + idx, false, h);
 }
 
 // ------------------------------------------------------------------------------------
@@ -955,13 +977,13 @@ HeavyArgs heavy_args(const StepArgs &a, const IndexWs &w, int64_t b, const int32
     return hv;
 }
 
-template <int LPR> void launch_fused(const StepArgs &a, const IndexWs &w, int64_t b, const int32_t *hn)
+template <int LPR, bool FULL> void launch_fused(const StepArgs &a, const IndexWs &w, int64_t b, const int32_t *hn)
 {
     constexpr int R = Geo<LPR, ROWS_PER_WAVE>::R;
     const HeavyArgs hv = heavy_args(a, w, b, hn);
     const int64_t waves = hv.HIu + hv.HIq + crec_ceil_div(a.U, R) + crec_ceil_div(a.I, R);
     crec_prof_begin(a.ctx, CREC_K_STEP_FUSED, a.st);
-    hipLaunchKernelGGL((bpr_step_fused<LPR>), dim3((unsigned)crec_ceil_div(waves, 4)), dim3(256), 0, a.st, a.cur, a.other,
+    hipLaunchKernelGGL((bpr_step_fused<LPR, FULL>), dim3((unsigned)crec_ceil_div(waves, 4)), dim3(256), 0, a.st, a.cur, a.other,
                        a.d, a.U, a.I, w.u_rowseg + b * w.U, w.u_occ + b * w.B, w.q_rowseg + b * w.I,
                        w.q_occ + b * 2 * w.B, hv, a.xb, a.rowterm, a.h);
     crec_prof_end(a.ctx, a.st);
@@ -973,19 +995,19 @@ template <int LPR> void launch_fused(const StepArgs &a, const IndexWs &w, int64_
     }
 }
 
-template <int LPR> void launch_lazy(const StepArgs &a, const IndexWs &w, int64_t b, const int32_t *hn)
+template <int LPR, bool FULL> void launch_lazy(const StepArgs &a, const IndexWs &w, int64_t b, const int32_t *hn)
 {
     constexpr int R = Geo<LPR, ROWS_PER_WAVE>::R;
     const HeavyArgs hv = heavy_args(a, w, b, hn);
     const int64_t u_waves = hv.HIu + crec_ceil_div(a.U < a.B ? a.U : a.B, R);
     const int64_t q_waves = hv.HIq + crec_ceil_div(a.I < 2 * (int64_t)a.B ? a.I : 2 * (int64_t)a.B, R);
     crec_prof_begin(a.ctx, CREC_K_USER_SIDE, a.st);
-    hipLaunchKernelGGL((bpr_side_lazy<LPR, 0>), dim3((unsigned)crec_ceil_div(u_waves, 4)), dim3(256), 0, a.st, a.cur, a.d,
+    hipLaunchKernelGGL((bpr_side_lazy<LPR, 0, FULL>), dim3((unsigned)crec_ceil_div(u_waves, 4)), dim3(256), 0, a.st, a.cur, a.d,
                        w.n_u + b, w.u_rows + b * w.B, w.u_seg + b * (w.B + 1), w.u_occ + b * w.B, hv.hn + 1, hv.u_hitems,
                        hv.HIu, a.partial, a.contrib, a.xb, a.rowterm, a.h);
     crec_prof_end(a.ctx, a.st);
     crec_prof_begin(a.ctx, CREC_K_ITEM_SIDE, a.st);
-    hipLaunchKernelGGL((bpr_side_lazy<LPR, 2>), dim3((unsigned)crec_ceil_div(q_waves, 4)), dim3(256), 0, a.st, a.cur, a.d,
+    hipLaunchKernelGGL((bpr_side_lazy<LPR, 2, FULL>), dim3((unsigned)crec_ceil_div(q_waves, 4)), dim3(256), 0, a.st, a.cur, a.d,
                        w.n_q + b, w.q_rows + b * 2 * w.B, w.q_seg + b * (2 * w.B + 1), w.q_occ + b * 2 * w.B, hv.hn + 3,
                        hv.q_hitems, hv.HIq, a.partial + (int64_t)hv.HIu * a.d, a.contrib, a.xb, a.rowterm + a.B, a.h);
     crec_prof_end(a.ctx, a.st);
@@ -1004,9 +1026,11 @@ StepFn pick_step(int d, bool dense)
     int lpr = 1;
     while (lpr * 4 < d)
         lpr <<= 1;
-#define CREC_PICK(L) \
-    case L:          \
-        return dense ? launch_fused<L> : launch_lazy<L>;
+    const bool full = d == 4 * lpr;
+#define CREC_PICK(L)                                                                                      \
+    case L:                                                                                               \
+        return dense ? (full ? launch_fused<L, true> : launch_fused<L, false>)                            \
+                     : (full ? launch_lazy<L, true> : launch_lazy<L, false>);
     switch (lpr) {
         CREC_PICK(1)
         CREC_PICK(2)
