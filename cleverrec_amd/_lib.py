@@ -69,6 +69,8 @@ _SIGNATURES = {
     "crec_sample_cml": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, C.c_int, _vp, _vp, _vp, C.POINTER(_i64)]),
     "crec_bpr_train_epoch": (C.c_int, [_vp, C.POINTER(BprTables), C.POINTER(Adam), _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "crec_ncf_train_epoch": (C.c_int, [_vp, C.POINTER(Ncf), C.POINTER(Adam), _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
+    "crec_ncf_scores": (C.c_int, [_vp, C.POINTER(Ncf), _vp, _i32, _vp, _vp]),
+    "crec_topk_scores": (C.c_int, [_vp, _vp, _i64, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "crec_fm_train_epoch": (C.c_int, [_vp, C.POINTER(Fm), C.POINTER(Adam), _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
     "crec_fm_predict": (C.c_int, [_vp, C.POINTER(Fm), _vp, _vp, _i64, _i32, _vp, _vp]),
     "crec_rmse_mae": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
@@ -135,7 +137,7 @@ class Context:
 
     # ---- measurement ---------------------------------------------------------------------------
     KERNELS = ("bpr_index_batches", "bpr_step_fused", "bpr_user_side", "bpr_item_side", "bpr_reduce_loss", "eval_sweep",
-               "eval_merge", "rank_metrics", "bpr_finish_heavy", "bpr_adam_dense", "rows_index_batches", "rows_apply", "small_adam_dense", "ncf_tile", "fm_instances", "cml_instances")
+               "eval_merge", "rank_metrics", "bpr_finish_heavy", "bpr_adam_dense", "rows_index_batches", "rows_apply", "small_adam_dense", "ncf_tile", "fm_instances", "cml_instances", "ncf_pair_logits")
 
     def profile(self, on):
         self.check(self.lib.crec_profile_enable(self.h, int(bool(on))))

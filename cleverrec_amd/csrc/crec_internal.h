@@ -42,6 +42,7 @@ enum crec_kernel_class {
     CREC_K_NCF_TILE,
     CREC_K_FM_INSTANCES,
     CREC_K_CML_INSTANCES,
+    CREC_K_NCF_SCORES,
     CREC_K_COUNT
 };
 

@@ -31,8 +31,12 @@ class RankingRecommender(Recommender):
         raise NotImplementedError
 
     def _eval_tables(self):
-        """(P_like, Q_like) such that score(u, item) = P_like[u] . Q_like[item]."""
+        """(P_like, Q_like) such that score(u, item) = P_like[u] . Q_like[item] (fused GEMM + top-K path)."""
         raise NotImplementedError
+
+    def _eval_scores(self, users):
+        """Models whose score is not a dot product (tower models): a [len(users), I] score matrix, or None."""
+        return None
 
     # -- one epoch (RankingRecommender.py:33-61) -------------------------------------------------
     def train_model(self):
@@ -65,11 +69,16 @@ class RankingRecommender(Recommender):
     def test_model_rs(self):
         HR, MRR, NDCG = defaultdict(list), defaultdict(list), defaultdict(list)
         e = self._eval_inputs()
-        P, Q = self._eval_tables()
         Kmax = self.topk[-1]
+        tables = None
         for t_id in range(self.test_batches):
             cur = e['users'][t_id * self.batch_size_t:(t_id + 1) * self.batch_size_t]
-            ids, _ = runtime.eval_topk(self.sess, P, Q, cur, e['seen_ptr'], e['seen_items'], Kmax, self.cml_like)
+            sc = self._eval_scores(cur)
+            if sc is not None:  # materialised pre_scores (MLP / NeuMF), then argsort + seen filter
+                ids, _ = runtime.topk_scores(self.sess, sc, cur, e['seen_ptr'], e['seen_items'], Kmax, self.cml_like)
+            else:
+                tables = tables or self._eval_tables()
+                ids, _ = runtime.eval_topk(self.sess, tables[0], tables[1], cur, e['seen_ptr'], e['seen_items'], Kmax, self.cml_like)
             hr, mrr, ndcg = runtime.rank_metrics(self.sess, ids, cur, self.topk, e['test_ptr'], e['test_items'])
             hr, mrr, ndcg = hr.cpu().numpy(), mrr.cpu().numpy(), ndcg.cpu().numpy()
             for kid in range(len(self.topk)):

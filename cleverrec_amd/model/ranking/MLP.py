@@ -69,6 +69,8 @@ class MLP(RankingRecommender):
     def _train_epoch_device(self, u, i, y):
         return self.state.train_epoch(u, i, y, self.batch_size)
 
-    def _eval_tables(self):
-        raise NotImplementedError("full-catalogue scoring through the MLP tower ([B_t*I, L0] x W, MLP.py:47-52) "
-                                  "is the next eval kernel (DESIGN.md 9)")
+    def _eval_scores(self, users):
+        # logits of every (test user, item) pair through the tower; sigmoid is monotone, so the ranking of
+        # pre_scores = sigmoid(logits) (MLP.py _predict, rs branch) is the ranking of the logits
+        from ... import runtime
+        return runtime.ncf_scores(self.sess, self.state, users)

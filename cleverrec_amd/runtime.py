@@ -220,3 +220,22 @@ class CmlState:
         Pa, Qa = s.empty((U, d + 4), torch.float32), s.empty((I, d + 4), torch.float32)
         s.ctx.check(s.lib.crec_cml_eval_tables(s.ctx.h, s.ptr(self.P), s.ptr(self.Q), U, I, d, s.ptr(Pa), s.ptr(Qa), s.stream_ptr()))
         return Pa, Qa
+
+
+def ncf_scores(sess, state, users):
+    """crec_ncf_scores -> logits [Bt, I] (device fp32); pre_scores = sigmoid(logits) ranks identically."""
+    Bt = int(users.numel())
+    I = (state.t["Q_mlp"] if "Q_mlp" in state.t else state.t["Q_gmf"]).shape[0]
+    out = sess.empty((Bt, I), torch.float32)
+    sess.ctx.check(sess.lib.crec_ncf_scores(sess.ctx.h, C.byref(state.model), sess.ptr(users), Bt, sess.ptr(out), sess.stream_ptr()))
+    return out
+
+
+def topk_scores(sess, scores, users, seen_ptr, seen_items, K, ascending=False):
+    """crec_topk_scores over a materialised [Bt, I] score matrix -> (ids int32 [Bt,K], scores fp32 [Bt,K])."""
+    Bt, I = scores.shape
+    ids, sc = sess.empty((Bt, K), torch.int32), sess.empty((Bt, K), torch.float32)
+    sess.ctx.check(sess.lib.crec_topk_scores(sess.ctx.h, sess.ptr(scores), I, sess.ptr(users), Bt, sess.ptr(seen_ptr),
+                                             sess.ptr(seen_items), int(K), int(bool(ascending)), sess.ptr(ids), sess.ptr(sc),
+                                             sess.stream_ptr()))
+    return ids, sc

@@ -55,7 +55,8 @@ const char *crec_last_error(const crec_ctx *ctx);
  * ends with a stream synchronise (so do not time whole-job throughput with it on).
  * kernel_class: 0 bpr_index_batches, 1 bpr_step_fused, 2 bpr_user_side, 3 bpr_item_side,
  *               4 bpr_reduce_loss, 5 eval_sweep, 6 eval_merge, 7 rank_metrics, 8 bpr_finish_heavy, 9 bpr_adam_dense,
- *               10 rows_index_batches, 11 rows_apply, 12 small_adam_dense, 13 ncf_tile, 14 fm_instances, 15 cml_instances.
+ *               10 rows_index_batches, 11 rows_apply, 12 small_adam_dense, 13 ncf_tile, 14 fm_instances, 15 cml_instances,
+ *               16 ncf_pair_logits.
  * enable(.., 1) also clears the accumulated totals. */
 int crec_profile_enable(crec_ctx *ctx, int on);
 int crec_profile_read(const crec_ctx *ctx, int kernel_class, double *total_ms, int64_t *launches);
@@ -148,6 +149,16 @@ typedef struct {
  * contiguous slices of RankingRecommender.train_model (:51-58); loss_per_batch [ceil(N/B)] [dev]. */
 int crec_ncf_train_epoch(crec_ctx *ctx, const crec_ncf *model, crec_adam *opt, const int32_t *u, const int32_t *i,
                          const float *y, int64_t N, int32_t B, float *loss_per_batch, void *stream);
+
+/* Full-catalogue logits of a GMF / MLP / NeuMF model: replaces sess.run(self.pre_scores) of the rs branch
+ * (GMF.py:40,57, MLP.py:45-52,71-77, NeuMF.py:62-78,96-105).  logits [dev] float [Bt, I]; pre_scores is
+ * sigmoid(logits), which ranks identically.  layers[0] <= 256. */
+int crec_ncf_scores(crec_ctx *ctx, const crec_ncf *model, const int32_t *users, int32_t Bt, float *logits, void *stream);
+/* np.argsort + seen filter (model/RankingRecommender.py:221-240) over a materialised score matrix
+ * scores [dev] float [Bt, I], I <= 40000; outputs as crec_eval_topk. */
+int crec_topk_scores(crec_ctx *ctx, const float *scores, int64_t I, const int32_t *users, int32_t Bt,
+                     const int64_t *seen_ptr, const int32_t *seen_items, int32_t K, int32_t ascending, int32_t *topk_ids,
+                     float *topk_scores, void *stream);
 
 /* ---- Factorization Machine, rating path (device) ---------------------------------------------------
  * replaces sess.run([self.train, self.loss, self.y_pre]) / sess.run(self.y_pre) (model/RatingRecommender.py:50,73)

@@ -127,3 +127,41 @@ def test_gmf_class_surface_train_and_eval(sess, tmp_path):
     H, M, N = oracle.test_model_rs_py(lambda cur: dev.predict(cur), m.test_users, data.ui_train, data.ui_test, [10, 20], 64)
     np.testing.assert_allclose(np.mean(NDCG[0]), np.mean(N[0]), rtol=1e-6)
     np.testing.assert_allclose(np.mean(HR[1]), np.mean(H[1]), rtol=1e-6)
+
+
+def test_neumf_full_catalogue_eval(sess, tmp_path):
+    """NeuMF(sess, data, configs, logger): test_model_rs() scores every test user against every item through
+    the tower (NeuMF.py:62-78) and ranks; compared with the oracle's predict() on the device parameters."""
+    import logging
+    from cleverrec_amd.data import RankingData
+    from cleverrec_amd.model.ranking.NeuMF import NeuMF
+    g = np.random.Generator(np.random.PCG64(8))
+    U, I, d, layers = 130, 200, 16, [32, 16]
+    ui_train = {uu: [int(x) for x in g.choice(I, size=int(g.integers(3, 20)), replace=False)] for uu in range(U)}
+    ui_test = {uu: [int(x) for x in g.choice(I, size=2, replace=False)] for uu in range(0, U, 2)}
+    data = RankingData(U, I, ui_train, ui_test)
+    configs = {"recommender": "NeuMF", "epoches": "1", "batch_size": "512", "test.batch_size": "50", "lr": "0.001",
+               "test.neg_samples": "0", "is_pairwise": "False", "init_method": "xavier_uniform", "stddev": "0.01",
+               "loss_func": "cross_entropy", "optimizer": "Adam", "saved_dir": str(tmp_path), "test.interval": "1",
+               "topk": "[10,20]", "neg_ratio": "4", "embed_size": str(d), "layers": str(layers).replace(" ", ""),
+               "reg_gmf": "0.01", "reg_mlp": "0.001", "data.split_way": "rs", "gmf_pretrain": "x", "mlp_pretrain": "y"}
+    m = NeuMF(sess, data, configs, logging.getLogger("t"))
+    Ws, bs, last = _tower(g, layers[0], len(layers))
+    init = {"P_gmf": _rand(g, U, d, scale=0.5), "Q_gmf": _rand(g, I, d, scale=0.5), "P_mlp": _rand(g, U, layers[0] // 2, scale=0.5),
+            "Q_mlp": _rand(g, I, layers[0] // 2, scale=0.5), "h_neumf": _rand(g, d + last, scale=0.5)}
+    for k in range(len(layers)):
+        init["W_%d" % k], init["b_%d" % k] = Ws[k], bs[k]
+    m.build_model(init)
+    np.random.seed(2)
+    m.train_model()
+    HR, MRR, NDCG = m.test_model_rs()
+    dev = MT.NeuMF(*(m.state.t[k].cpu().numpy() for k in ("P_gmf", "Q_gmf", "P_mlp", "Q_mlp")),
+                   [w.cpu().numpy() for w in m.state.W], [b.cpu().numpy() for b in m.state.b], m.h_neumf.cpu().numpy(),
+                   lr=1e-3, reg1=0.01, reg2=0.001)
+    # logits against the oracle's sigmoid scores (through logit = log(s/(1-s)) would lose bits: compare sigmoids)
+    users = sess.to_dev(np.asarray(m.test_users[:40], dtype=np.int32))
+    lg = runtime.ncf_scores(sess, m.state, users).cpu().numpy()
+    np.testing.assert_allclose(1.0 / (1.0 + np.exp(-lg)), dev.predict(m.test_users[:40]), rtol=2e-5, atol=1e-6)
+    H, M, N = oracle.test_model_rs_py(lambda cur: dev.predict(cur), m.test_users, data.ui_train, data.ui_test, [10, 20], 50)
+    np.testing.assert_allclose(np.mean(NDCG[0]), np.mean(N[0]), rtol=1e-6)
+    np.testing.assert_allclose(np.mean(HR[1]), np.mean(H[1]), rtol=1e-6)
