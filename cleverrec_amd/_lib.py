@@ -71,6 +71,8 @@ _SIGNATURES = {
     "crec_ncf_train_epoch": (C.c_int, [_vp, C.POINTER(Ncf), C.POINTER(Adam), _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "crec_ncf_scores": (C.c_int, [_vp, C.POINTER(Ncf), _vp, _i32, _vp, _vp]),
     "crec_topk_scores": (C.c_int, [_vp, _vp, _i64, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
+    "crec_eval_topk_candidates": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
+    "crec_topk_scores_candidates": (C.c_int, [_vp, _vp, _i64, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "crec_fm_train_epoch": (C.c_int, [_vp, C.POINTER(Fm), C.POINTER(Adam), _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
     "crec_fm_predict": (C.c_int, [_vp, C.POINTER(Fm), _vp, _vp, _i64, _i32, _vp, _vp]),
     "crec_rmse_mae": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp]),

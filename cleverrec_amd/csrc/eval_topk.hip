@@ -62,6 +62,7 @@ struct WaveState {
     int *clean;  // [32] leading entries already checked against the seen list
     float *thr;  // [32] score a candidate must beat
     int *uid;    // [32] global user id, -1 for padding rows
+    int keep_listed; // 0: drop items found in the user's list (seen filter); 1: keep only those (candidates)
 };
 
 // Keep the K best unseen entries of user row `ul`, sorted best first.  Whole wave.
@@ -83,8 +84,11 @@ __device__ void prune(const WaveState &ws, int ul, int K, const int64_t *__restr
             else
                 hi = mid;
         }
-        if (lo < end && seen_items[lo] == item)
-            mine = 0; // seen in training: never recommended (RankingRecommender.py:236)
+        // exclude mode: listed = seen in training, never recommended (RankingRecommender.py:236);
+        // keep mode: listed = the user's candidate items (leave-one-out / sampled-negative evaluation, :250-299)
+        const bool listed = lo < end && seen_items[lo] == item;
+        if (listed != (ws.keep_listed != 0))
+            mine = 0;
     }
     buf[lane] = mine;
     lds_fence();
@@ -132,7 +136,9 @@ __global__ __launch_bounds__(256) void eval_sweep(const float *__restrict__ P, c
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int row = lane & 31, h = lane >> 5;
-    WaveState ws{cand_all + wv * 32 * CAP, cnt_all + wv * 32, clean_all + wv * 32, thr_all + wv * 32, uid_all + wv * 32};
+    // the host packs the filter mode above K: K | keep_listed << 16
+    WaveState ws{cand_all + wv * 32 * CAP, cnt_all + wv * 32, clean_all + wv * 32, thr_all + wv * 32, uid_all + wv * 32, K >> 16};
+    K &= 0xffff;
 
     const int S = gridDim.y, sp = blockIdx.y;
     const int64_t i0 = (int64_t)sp * items_per_split;
@@ -359,9 +365,28 @@ int launch_sweep(crec_ctx *ctx, dim3 grid, hipStream_t st, const float *P, const
 
 } // namespace
 
+static int eval_topk_impl(crec_ctx *ctx, const float *P, const float *Q, int64_t I, int32_t d, const int32_t *users,
+                          int32_t Bt, const int64_t *seen_ptr, const int32_t *seen_items, int32_t K, int32_t ascending,
+                          int32_t *topk_ids, float *topk_scores, void *stream, int keep_listed);
+
 extern "C" int crec_eval_topk(crec_ctx *ctx, const float *P, const float *Q, int64_t I, int32_t d,
                               const int32_t *users, int32_t Bt, const int64_t *seen_ptr, const int32_t *seen_items,
                               int32_t K, int32_t ascending, int32_t *topk_ids, float *topk_scores, void *stream)
+{
+    return eval_topk_impl(ctx, P, Q, I, d, users, Bt, seen_ptr, seen_items, K, ascending, topk_ids, topk_scores, stream, 0);
+}
+
+extern "C" int crec_eval_topk_candidates(crec_ctx *ctx, const float *P, const float *Q, int64_t I, int32_t d,
+                                         const int32_t *users, int32_t Bt, const int64_t *cand_ptr,
+                                         const int32_t *cand_items, int32_t K, int32_t ascending, int32_t *topk_ids,
+                                         float *topk_scores, void *stream)
+{
+    return eval_topk_impl(ctx, P, Q, I, d, users, Bt, cand_ptr, cand_items, K, ascending, topk_ids, topk_scores, stream, 1);
+}
+
+static int eval_topk_impl(crec_ctx *ctx, const float *P, const float *Q, int64_t I, int32_t d, const int32_t *users,
+                          int32_t Bt, const int64_t *seen_ptr, const int32_t *seen_items, int32_t K, int32_t ascending,
+                          int32_t *topk_ids, float *topk_scores, void *stream, int keep_listed)
 {
     if (!ctx)
         return CREC_EINVAL;
@@ -392,13 +417,13 @@ extern "C" int crec_eval_topk(crec_ctx *ctx, const float *P, const float *Q, int
     dim3 grid((unsigned)user_tiles, (unsigned)S);
     int rc;
     if (d <= 32)
-        rc = launch_sweep<32, 64>(ctx, grid, st, P, Q, I, d, users, Bt, seen_ptr, seen_items, K, sign, per_split, part);
+        rc = launch_sweep<32, 64>(ctx, grid, st, P, Q, I, d, users, Bt, seen_ptr, seen_items, K | (keep_listed << 16), sign, per_split, part);
     else if (d <= 64)
-        rc = launch_sweep<64, 64>(ctx, grid, st, P, Q, I, d, users, Bt, seen_ptr, seen_items, K, sign, per_split, part);
+        rc = launch_sweep<64, 64>(ctx, grid, st, P, Q, I, d, users, Bt, seen_ptr, seen_items, K | (keep_listed << 16), sign, per_split, part);
     else if (d <= 128)
-        rc = launch_sweep<128, 64>(ctx, grid, st, P, Q, I, d, users, Bt, seen_ptr, seen_items, K, sign, per_split, part);
+        rc = launch_sweep<128, 64>(ctx, grid, st, P, Q, I, d, users, Bt, seen_ptr, seen_items, K | (keep_listed << 16), sign, per_split, part);
     else
-        rc = launch_sweep<256, 32>(ctx, grid, st, P, Q, I, d, users, Bt, seen_ptr, seen_items, K, sign, per_split, part);
+        rc = launch_sweep<256, 32>(ctx, grid, st, P, Q, I, d, users, Bt, seen_ptr, seen_items, K | (keep_listed << 16), sign, per_split, part);
     if (rc)
         return rc;
     crec_prof_begin(ctx, CREC_K_EVAL_MERGE, st);

@@ -99,12 +99,22 @@ __global__ __launch_bounds__(64) void topk_rows(const float *__restrict__ scores
     const int lane = threadIdx.x;
     const int64_t r = blockIdx.x;
     const float worst = -INFINITY;
-    for (int64_t c = lane; c < I; c += 64)
-        row[c] = sign * scores[r * I + c];
-    __syncthreads();
+    const bool keep_listed = K >> 16; // the host packs the filter mode above K
+    K &= 0xffff;
     const int32_t uu = users[r];
-    for (int64_t e = seen_ptr[uu] + lane; e < seen_ptr[uu + 1]; e += 64)
-        row[seen_items[e]] = worst;
+    if (!keep_listed) { // listed = seen in training: struck out
+        for (int64_t c = lane; c < I; c += 64)
+            row[c] = sign * scores[r * I + c];
+        __syncthreads();
+        for (int64_t e = seen_ptr[uu] + lane; e < seen_ptr[uu + 1]; e += 64)
+            row[seen_items[e]] = worst;
+    } else { // listed = the user's candidates: only they compete
+        for (int64_t c = lane; c < I; c += 64)
+            row[c] = worst;
+        __syncthreads();
+        for (int64_t e = seen_ptr[uu] + lane; e < seen_ptr[uu + 1]; e += 64)
+            row[seen_items[e]] = sign * scores[r * I + seen_items[e]];
+    }
     __syncthreads();
     for (int k = 0; k < K; ++k) {
         u64 best = 0; // (ordered score, ~item): larger is better, ties -> lower item id
@@ -186,9 +196,27 @@ int crec_ncf_scores(crec_ctx *ctx, const crec_ncf *mdl, const int32_t *users, in
     return crec_prof_flush(ctx, st);
 }
 
+static int topk_scores_impl(crec_ctx *ctx, const float *scores, int64_t I, const int32_t *users, int32_t Bt,
+                            const int64_t *seen_ptr, const int32_t *seen_items, int32_t K, int32_t ascending,
+                            int32_t *topk_ids, float *topk_scores, void *stream, int keep_listed);
+
 int crec_topk_scores(crec_ctx *ctx, const float *scores, int64_t I, const int32_t *users, int32_t Bt,
                      const int64_t *seen_ptr, const int32_t *seen_items, int32_t K, int32_t ascending, int32_t *topk_ids,
                      float *topk_scores, void *stream)
+{
+    return topk_scores_impl(ctx, scores, I, users, Bt, seen_ptr, seen_items, K, ascending, topk_ids, topk_scores, stream, 0);
+}
+
+int crec_topk_scores_candidates(crec_ctx *ctx, const float *scores, int64_t I, const int32_t *users, int32_t Bt,
+                                const int64_t *cand_ptr, const int32_t *cand_items, int32_t K, int32_t ascending,
+                                int32_t *topk_ids, float *topk_scores, void *stream)
+{
+    return topk_scores_impl(ctx, scores, I, users, Bt, cand_ptr, cand_items, K, ascending, topk_ids, topk_scores, stream, 1);
+}
+
+static int topk_scores_impl(crec_ctx *ctx, const float *scores, int64_t I, const int32_t *users, int32_t Bt,
+                            const int64_t *seen_ptr, const int32_t *seen_items, int32_t K, int32_t ascending,
+                            int32_t *topk_ids, float *topk_scores, void *stream, int keep_listed)
 {
     if (!ctx)
         return CREC_EINVAL;
@@ -201,7 +229,7 @@ int crec_topk_scores(crec_ctx *ctx, const float *scores, int64_t I, const int32_
     const size_t lds = sizeof(float) * (size_t)I;
     CREC_HIP(ctx, hipFuncSetAttribute((const void *)topk_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(topk_rows, dim3((unsigned)Bt), dim3(64), lds, (hipStream_t)stream, scores, I, users, seen_ptr, seen_items,
-                       (int)K, ascending ? -1.0f : 1.0f, topk_ids, topk_scores);
+                       (int)K | (keep_listed << 16), ascending ? -1.0f : 1.0f, topk_ids, topk_scores);
     CREC_HIP(ctx, hipGetLastError());
     return CREC_OK;
 }

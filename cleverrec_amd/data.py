@@ -71,6 +71,30 @@ class RankingData:
             out[full[k]:full[k + 1]] = np.sort(seg) if sort_rows else seg
         return full, out
 
+    def loo_csr(self, neg_samples):
+        """Views for test_model_loo (model/RankingRecommender.py:250-299), where ui_test[u] holds the sampled
+        negatives first and the held-out items after them (model/RankingPreprocess.py:121-129):
+          cand (ptr[U+1], items sorted per user): every listed item -- the only ones that compete;
+          real (ptr[U+1], items): ui_test[u][neg_samples:], the ground truth."""
+        keys, ptr, items = self._test_rows
+        cand, real = {}, {}
+        for n, k in enumerate(keys):
+            seg = items[ptr[n]:ptr[n + 1]]
+            cand[int(k)] = np.unique(seg)
+            real[int(k)] = seg[neg_samples:]
+        out = []
+        for d in (cand, real):
+            lens = np.zeros(self.user_nums, dtype=np.int64)
+            for k, v in d.items():
+                lens[k] = len(v)
+            full = np.zeros(self.user_nums + 1, dtype=np.int64)
+            np.cumsum(lens, out=full[1:])
+            flat = np.zeros(max(int(full[-1]), 1), dtype=np.int32)
+            for k, v in d.items():
+                flat[full[k]:full[k + 1]] = v
+            out.append((full, flat))
+        return out[0], out[1]
+
     @property
     def ui_train(self):
         if self._ui_train is None:

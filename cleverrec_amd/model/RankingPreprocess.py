@@ -1,0 +1,100 @@
+"""Ranking data pipeline (reference model/RankingPreprocess.py:12-134): same class name, config keys and
+published attributes (user_nums, item_nums, ui_train, ui_test), result-compatible with the reference on the
+same file and the same np.random state -- it goes through the same pandas / scikit-learn primitives in the
+same order, because the ids and the split depend on them:
+
+  * read_csv(header=0, names=...) swallows the first data row of header-less files;
+  * ids are re-indexed in the iteration order of a Python set of the unique raw ids (RankingPreprocess.py:42-47);
+  * the random split is two sklearn train_test_split calls on NumPy's global RandomState (:108-115);
+  * ui_train / ui_test are groupby(u_id) lists: users ascending, items in split row order (:117-118);
+  * loo / test.neg_samples > 0: negatives drawn with np.random.choice(list(item_set - seen), replace=False) are
+    put IN FRONT of the held-out items of each test user (:121-129).
+
+The object is also a cleverrec_amd.data.RankingData, so the CSR views the kernels read are available.
+Social files (trusts, SAMN padding) serve models outside this core and are not read."""
+import os
+
+import numpy as np
+import pandas as pd
+from sklearn.model_selection import train_test_split
+
+from ..config import parse_list
+from ..data import RankingData
+from ..utils.tools import re_index, timer
+
+
+class RankingPreprocess(RankingData):
+    def __init__(self, configs, logger):
+        self.configs, self.logger = configs, logger
+        self.file_path = os.path.join(configs['data.root_dir'], configs['data.dataset'])
+        ratings, item_set = self._load_data()
+        ui_train, ui_test = self._split_data(ratings, item_set)
+        RankingData.__init__(self, self.user_nums, self.item_nums, ui_train, ui_test)
+
+    @timer('Load data')
+    def _load_data(self):
+        c = self.configs
+        fmt = c['data.format']
+        cols = {'UI': ['u_id', 'i_id'], 'UIR': ['u_id', 'i_id', 'rating'], 'UIRT': ['u_id', 'i_id', 'rating', 'time']}[fmt]
+        ratings = pd.read_csv(os.path.join(self.file_path, c['data.file_name']), sep=c['data.sep'], header=0, names=cols,
+                              usecols=list(range(len(cols))))
+        if fmt == 'UIRT':
+            ratings.time = ratings.time.astype(int)
+        user_min, item_min = int(c['data.user_min']), int(c['data.item_min'])
+        if user_min > 0:
+            ratings = self._filter(ratings, 'u_id', user_min)
+        if item_min > 0:
+            ratings = self._filter(ratings, 'i_id', item_min)
+        user_set_, item_set_ = set(ratings.u_id.unique()), set(ratings.i_id.unique())
+        self.user_nums, self.item_nums = len(user_set_), len(item_set_)
+        user_map, item_map = re_index(user_set_), re_index(item_set_)
+        ratings.u_id = ratings.u_id.map(lambda x: user_map[x])
+        ratings.i_id = ratings.i_id.map(lambda x: item_map[x])
+        if 'social_file' in c:
+            raise NotImplementedError('social_file: the trust graph serves SBPR/SAMN-type models, outside this core')
+        return ratings, set(ratings.i_id.unique())
+
+    @staticmethod
+    def _filter(ratings, col, minimum):
+        sizes = ratings.groupby(col).size().to_dict()
+        dropped = {k for k, n in sizes.items() if n < minimum}
+        return ratings[~(ratings[col].isin(dropped))].reset_index(drop=True)
+
+    @timer('Split data')
+    def _split_data(self, ratings, item_set=None):
+        c = self.configs
+        split_way = c['data.split_way']
+        if c['data.split_by_time'] == 'True':
+            ratings.sort_values(['u_id', 'time'], inplace=True)
+        if split_way == 'loo':
+            train_parts, test_parts = [], []
+            for _, rows in ratings.groupby('u_id'):
+                if len(rows) <= 3:  # users with <= 3 interactions stay in training
+                    train_parts.append(rows)
+                else:
+                    train_parts.append(rows.iloc[:-1])
+                    test_parts.append(rows.iloc[-1:])
+            train_data = pd.concat(train_parts, ignore_index=True)
+            test_data = pd.concat(test_parts, ignore_index=True)
+        else:
+            r1, r2, r3 = parse_list(c['data.split_ratio'], float)
+            if r2 > 0:
+                train_data, tmp = train_test_split(ratings, test_size=1.0 - r1)
+                _, test_data = train_test_split(tmp, test_size=r3 / (r2 + r3))
+            else:
+                train_data, test_data = train_test_split(ratings, test_size=r3)
+            train_data, test_data = train_data.reset_index(drop=True), test_data.reset_index(drop=True)
+        ui_train = train_data.groupby('u_id').i_id.apply(list).to_dict()
+        ui_test = test_data.groupby('u_id').i_id.apply(list).to_dict()
+        neg_samples = int(c['test.neg_samples'])
+        if split_way == 'loo' or neg_samples > 0:
+            with_negs = {}
+            for u in ui_test:
+                seen = set(ui_train[u]) if u in ui_train else set()
+                negs = np.random.choice(list(item_set - seen), size=neg_samples, replace=False).tolist()
+                with_negs[u] = negs + ui_test[u]  # ground truth after the sampled negatives
+            ui_test = with_negs
+        extra = '' if split_way == 'loo' else ('split_ratio=%s, ' % c['data.split_ratio'])
+        self.logger.info(' Data: dataset=%s, split_way=%s, neg_samples=%d, %suser_nums=%d, item_nums=%d, ratings_num=%d'
+                         % (c['data.dataset'], split_way, neg_samples, extra, self.user_nums, self.item_nums, ratings.shape[0]))
+        return ui_train, ui_test

@@ -88,7 +88,36 @@ class RankingRecommender(Recommender):
         return HR, MRR, NDCG
 
     def test_model_loo(self):
-        raise NotImplementedError("leave-one-out / sampled-negative evaluation is the next tier (SURVEY.md 8 f1)")
+        """Leave-one-out / sampled-negative evaluation (RankingRecommender.py:250-299): only the items listed in
+        ui_test[u] (neg_samples negatives, then the held-out items) compete; the held-out ones are the truth."""
+        HR, MRR, NDCG = defaultdict(list), defaultdict(list), defaultdict(list)
+        e = self._eval_inputs()
+        if 'cand_ptr' not in e:
+            d = self.data
+            if not hasattr(d, 'loo_csr'):
+                from ..data import RankingData
+                d = RankingData(d.user_nums, d.item_nums, d.ui_train, d.ui_test)
+            (cp, ci), (rp, ri) = d.loo_csr(self.neg_samples)
+            s = self.sess
+            e.update(cand_ptr=s.to_dev(cp), cand_items=s.to_dev(ci), real_ptr=s.to_dev(rp), real_items=s.to_dev(ri))
+        Kmax = self.topk[-1]
+        tables = None
+        for t_id in range(self.test_batches):
+            cur = e['users'][t_id * self.batch_size_t:(t_id + 1) * self.batch_size_t]
+            sc = self._eval_scores(cur)
+            if sc is not None:
+                ids, _ = runtime.topk_scores(self.sess, sc, cur, e['cand_ptr'], e['cand_items'], Kmax, self.cml_like, candidates=True)
+            else:
+                tables = tables or self._eval_tables()
+                ids, _ = runtime.eval_topk(self.sess, tables[0], tables[1], cur, e['cand_ptr'], e['cand_items'], Kmax,
+                                           self.cml_like, candidates=True)
+            hr, mrr, ndcg = runtime.rank_metrics(self.sess, ids, cur, self.topk, e['real_ptr'], e['real_items'])
+            hr, mrr, ndcg = hr.cpu().numpy(), mrr.cpu().numpy(), ndcg.cpu().numpy()
+            for kid in range(len(self.topk)):
+                HR[kid].extend(hr[kid].tolist())
+                MRR[kid].extend(mrr[kid].tolist())
+                NDCG[kid].extend(ndcg[kid].tolist())
+        return HR, MRR, NDCG
 
     # -- driver (RankingRecommender.py:395-440) ---------------------------------------------------
     @timer('run_model')

@@ -70,12 +70,14 @@ class BprState:
         return loss
 
 
-def eval_topk(sess, P, Q, users, seen_ptr, seen_items, K, ascending=False):
-    """crec_eval_topk -> (ids int32 [Bt,K], scores fp32 [Bt,K]) device tensors."""
+def eval_topk(sess, P, Q, users, seen_ptr, seen_items, K, ascending=False, candidates=False):
+    """crec_eval_topk (list = seen items, excluded) or crec_eval_topk_candidates (list = the only items that
+    compete) -> (ids int32 [Bt,K], scores fp32 [Bt,K]) device tensors."""
     Bt = int(users.numel())
     ids = sess.empty((Bt, K), torch.int32)
     sc = sess.empty((Bt, K), torch.float32)
-    sess.ctx.check(sess.lib.crec_eval_topk(sess.ctx.h, sess.ptr(P), sess.ptr(Q), Q.shape[0], Q.shape[1], sess.ptr(users),
+    fn = sess.lib.crec_eval_topk_candidates if candidates else sess.lib.crec_eval_topk
+    sess.ctx.check(fn(sess.ctx.h, sess.ptr(P), sess.ptr(Q), Q.shape[0], Q.shape[1], sess.ptr(users),
                                            Bt, sess.ptr(seen_ptr), sess.ptr(seen_items), int(K), int(bool(ascending)),
                                            sess.ptr(ids), sess.ptr(sc), sess.stream_ptr()))
     return ids, sc
@@ -231,11 +233,12 @@ def ncf_scores(sess, state, users):
     return out
 
 
-def topk_scores(sess, scores, users, seen_ptr, seen_items, K, ascending=False):
-    """crec_topk_scores over a materialised [Bt, I] score matrix -> (ids int32 [Bt,K], scores fp32 [Bt,K])."""
+def topk_scores(sess, scores, users, seen_ptr, seen_items, K, ascending=False, candidates=False):
+    """crec_topk_scores[_candidates] over a materialised [Bt, I] score matrix -> (ids int32 [Bt,K], scores fp32 [Bt,K])."""
     Bt, I = scores.shape
     ids, sc = sess.empty((Bt, K), torch.int32), sess.empty((Bt, K), torch.float32)
-    sess.ctx.check(sess.lib.crec_topk_scores(sess.ctx.h, sess.ptr(scores), I, sess.ptr(users), Bt, sess.ptr(seen_ptr),
+    fn = sess.lib.crec_topk_scores_candidates if candidates else sess.lib.crec_topk_scores
+    sess.ctx.check(fn(sess.ctx.h, sess.ptr(scores), I, sess.ptr(users), Bt, sess.ptr(seen_ptr),
                                              sess.ptr(seen_items), int(K), int(bool(ascending)), sess.ptr(ids), sess.ptr(sc),
                                              sess.stream_ptr()))
     return ids, sc

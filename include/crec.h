@@ -160,6 +160,17 @@ int crec_topk_scores(crec_ctx *ctx, const float *scores, int64_t I, const int32_
                      const int64_t *seen_ptr, const int32_t *seen_items, int32_t K, int32_t ascending, int32_t *topk_ids,
                      float *topk_scores, void *stream);
 
+/* Leave-one-out / sampled-negative evaluation (RankingRecommender.test_model_loo, model/RankingRecommender.py:250-299):
+ * only the user's candidate items compete -- the sampled negatives plus the held-out items that RankingPreprocess
+ * stores in ui_test[u] (model/RankingPreprocess.py:121-129).  Same as crec_eval_topk / crec_topk_scores with the
+ * list's meaning inverted: cand CSR by user id, items sorted ascending; an item NOT listed is never returned. */
+int crec_eval_topk_candidates(crec_ctx *ctx, const float *P, const float *Q, int64_t I, int32_t d, const int32_t *users,
+                              int32_t Bt, const int64_t *cand_ptr, const int32_t *cand_items, int32_t K,
+                              int32_t ascending, int32_t *topk_ids, float *topk_scores, void *stream);
+int crec_topk_scores_candidates(crec_ctx *ctx, const float *scores, int64_t I, const int32_t *users, int32_t Bt,
+                                const int64_t *cand_ptr, const int32_t *cand_items, int32_t K, int32_t ascending,
+                                int32_t *topk_ids, float *topk_scores, void *stream);
+
 /* ---- Factorization Machine, rating path (device) ---------------------------------------------------
  * replaces sess.run([self.train, self.loss, self.y_pre]) / sess.run(self.y_pre) (model/RatingRecommender.py:50,73)
  * on the graph of model/rating/FM.py:20-53, and cal_rmse_mae (utils/metrics.py:22-29).

@@ -19,15 +19,17 @@ if __name__ == '__main__':
     logger.info('=' * 100)
     logger.info('Current model: %s' % recommender)
 
-    if configs['model_type'] != 'ranking':
-        raise NotImplementedError('rating models (FM) are the next tier (SURVEY.md 8, config C4)')
-    if configs['data.dataset'] in SHAPES:
-        data = synthetic(configs['data.dataset'])
+    if configs['model_type'] == 'ranking':
+        if configs['data.dataset'] in SHAPES:  # seeded synthetic data with MovieLens marginals
+            data = synthetic(configs['data.dataset'])
+            logger.info(' Data: dataset=%s, user_nums=%d, item_nums=%d, train=%d' % (configs['data.dataset'], data.user_nums,
+                                                                                        data.item_nums, data.n_train))
+        else:
+            from cleverrec_amd.model.RankingPreprocess import RankingPreprocess
+            data = RankingPreprocess(configs, logger)
     else:
-        raise NotImplementedError('on-disk datasets need the preprocess pipeline (SURVEY.md 8 f2); '
-                                  'use data.dataset=S-ml100k or S-ml1m')
-    logger.info(' Data: dataset=%s, user_nums=%d, item_nums=%d, train=%d' % (configs['data.dataset'], data.user_nums,
-                                                                                data.item_nums, data.n_train))
+        from cleverrec_amd.model.RatingPreprocess import RatingPreprocess
+        data = RatingPreprocess(configs, logger)
     if not is_true(configs['gpu.is_gpu']):
         raise RuntimeError('gpu.is_gpu=False: this core has no CPU path (the reference treats the string as truthy anyway)')
 

@@ -16,7 +16,7 @@ _SO = os.path.join(_HERE, "liboracle.so")
 __all__ = [
     "build", "Rng", "to_csr", "dict_from_csr", "sample_pairwise", "sample_pointwise", "sample_cml",
     "AdamSchedule", "BprModel", "bpr_step", "scores", "topk", "rank_metrics",
-    "cal_ranking_metrics_py", "test_model_rs_py", "train_model_py", "tf_softplus_np", "bpr_dp_local", "adam_dense",
+    "cal_ranking_metrics_py", "test_model_rs_py", "train_model_py", "tf_softplus_np", "bpr_dp_local", "adam_dense", "test_model_loo_py",
 ]
 
 
@@ -309,3 +309,22 @@ def adam_dense(m, g, lr_t):
     g = np.ascontiguousarray(g, dtype=np.float32)
     lib().orc_adam_dense(_p(m.Q), _p(m.mQ), _p(m.vQ), _p(g), C.c_int64(len(m.Q)), C.c_int(m.Q.shape[1]), C.c_float(lr_t),
                          C.c_float(m.sched.beta1), C.c_float(m.sched.beta2), C.c_float(m.sched.eps))
+
+
+def test_model_loo_py(pair_score_fn, test_users, ui_test, neg_samples, topk_list, batch_size_t, ascending=False):
+    """test_model_loo (model/RankingRecommender.py:250-299): pair_score_fn(u, items) -> fp32 scores of the
+    listed (u, item) pairs; a stable argsort stands in for np.argsort."""
+    HR, MRR, NDCG = ({k: [] for k in range(len(topk_list))} for _ in range(3))
+    Kmax = topk_list[-1]
+    for uu in test_users:
+        items = ui_test[uu]
+        sc = np.asarray(pair_score_fn(uu, items), dtype=np.float32)
+        args = np.argsort(sc if ascending else -sc, kind="stable")[:Kmax]
+        real = items[neg_samples:]
+        for kid, K in enumerate(topk_list):
+            rec = np.take(items, args[:K])
+            h, m, n = cal_ranking_metrics_py(real, rec, K)
+            HR[kid].append(h)
+            MRR[kid].append(m)
+            NDCG[kid].append(n)
+    return HR, MRR, NDCG

@@ -287,3 +287,33 @@ def test_data_parallel_epoch_world1_matches_oracle(sess):
             np.testing.assert_allclose(getattr(st, name).cpu().numpy(), getattr(ref, name).cpu().numpy(), rtol=0, atol=2e-6)
     finally:
         s2.close()
+
+
+@pytest.mark.parametrize("neg_samples", [0, 30])
+def test_model_loo_matches_reference_semantics(sess, tmp_path, neg_samples):
+    """test_model_loo: only ui_test[u] (sampled negatives + held-out items) competes (RankingRecommender.py:250-299)."""
+    import logging
+    from cleverrec_amd.model.ranking.BPR import BPR
+    g = np.random.Generator(np.random.PCG64(31))
+    U, I, d = 90, 400, 32
+    ui_train = {u: [int(x) for x in g.choice(I, size=int(g.integers(3, 20)), replace=False)] for u in range(U)}
+    ui_test = {}
+    for u in range(0, U, 2):  # negatives first, then the held-out item(s), like RankingPreprocess._split_data
+        rest = np.setdiff1d(np.arange(I), ui_train[u])
+        pick = g.choice(rest, size=neg_samples + (1 if neg_samples == 0 else 2), replace=False)
+        ui_test[u] = [int(x) for x in pick]
+    data = RankingData(U, I, ui_train, ui_test)
+    configs = {"recommender": "BPR", "epoches": "1", "batch_size": "512", "test.batch_size": "16", "lr": "0.001",
+               "test.neg_samples": str(neg_samples), "is_pairwise": "True", "init_method": "normal", "stddev": "0.01",
+               "loss_func": "bpr", "optimizer": "Adam", "saved_dir": str(tmp_path), "test.interval": "1", "topk": "[5,10]",
+               "neg_ratio": "4", "embed_size": str(d), "reg": "0.01", "data.split_way": "loo"}
+    m = BPR(sess, data, configs, logging.getLogger("t"))
+    P0, Q0 = _tables(33, U, I, d, scale=1.0)
+    m.build_model(P0, Q0)
+    HR, MRR, NDCG = m.test_model_loo()
+    H, M, N = oracle.test_model_loo_py(lambda u, items: oracle.scores(P0, Q0[items], [u], 1)[0], m.test_users, data.ui_test,
+                                       neg_samples, [5, 10], 16)
+    for kid in range(2):
+        np.testing.assert_allclose(HR[kid], H[kid], rtol=0)
+        np.testing.assert_allclose(MRR[kid], M[kid], rtol=1e-12)
+        np.testing.assert_allclose(NDCG[kid], N[kid], rtol=1e-12)
