@@ -99,18 +99,34 @@ __global__ __launch_bounds__(NT) void ncf_tile(NcfDev m, const int32_t *__restri
         }
     }
     // ---- tower forward: A[k+1] = relu(A[k] W_k + b_k) --------------------------------------------
+    // W_k is staged in LDS with rows padded by one float (the backward pass reads it column-wise); each
+    // thread produces 4 rows x 1 column, so a weight is read once per 4 FMAs
+    float *Wl = (float *)(si + T);
     for (int k = 0; k < L; ++k) {
-        const int kin = width[k], kout = width[k + 1];
+        const int kin = width[k], kout = width[k + 1], ws = kout + 1;
         const float *W = m.small + m.w_off[k], *b = m.small + m.b_off[k];
         __syncthreads();
-        for (int o = tid; o < T * kout; o += NT) {
-            const int r = o / kout, c = o % kout;
-            float s = 0.f;
-            const float *a = A[k] + r * kin;
-            for (int kk = 0; kk < kin; ++kk)
-                s = s + a[kk] * W[kk * kout + c];
-            s = s + b[c];
-            A[k + 1][o] = s > 0.f ? s : 0.f;
+        for (int o = tid; o < kin * kout; o += NT)
+            Wl[(o / kout) * ws + (o % kout)] = W[o];
+        __syncthreads();
+        for (int unit = tid; unit < (T / 4) * kout; unit += NT) {
+            const int rb = unit / kout, c = unit % kout;
+            const float *a = A[k] + (rb * 4) * kin;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            for (int kk = 0; kk < kin; ++kk) {
+                const float w = Wl[kk * ws + c];
+                s0 = s0 + a[kk] * w;
+                s1 = s1 + a[kin + kk] * w;
+                s2 = s2 + a[2 * kin + kk] * w;
+                s3 = s3 + a[3 * kin + kk] * w;
+            }
+            float *o4 = A[k + 1] + (rb * 4) * kout + c;
+            const float bb = b[c];
+            s0 += bb, s1 += bb, s2 += bb, s3 += bb;
+            o4[0] = s0 > 0.f ? s0 : 0.f;
+            o4[kout] = s1 > 0.f ? s1 : 0.f;
+            o4[2 * kout] = s2 > 0.f ? s2 : 0.f;
+            o4[3 * kout] = s3 > 0.f ? s3 : 0.f;
         }
     }
     __syncthreads();
@@ -182,18 +198,32 @@ __global__ __launch_bounds__(NT) void ncf_tile(NcfDev m, const int32_t *__restri
                     s = s + D[k + 1][r * kout + c];
                 part[m.b_off[k] + c] = s;
             }
-            // delta of the layer below (k > 0: through its ReLU; k == 0: dL/dX, written over A[0])
+            // delta of the layer below (k > 0: through its ReLU; k == 0: dL/dX, written over A[0]);
+            // W_k back in LDS (padded rows: lanes differ in kk), 4 rows per thread
+            const int ws = kout + 1;
+            for (int o = tid; o < kin * kout; o += NT)
+                Wl[(o / kout) * ws + (o % kout)] = W[o];
             __syncthreads();
-            for (int o = tid; o < T * kin; o += NT) {
-                const int r = o / kin, kk = o % kin;
-                float s = 0.f;
-                const float *dr = D[k + 1] + r * kout;
-                for (int c = 0; c < kout; ++c)
-                    s = s + dr[c] * W[kk * kout + c];
-                if (k > 0)
-                    D[k][o] = A[k][o] > 0.f ? s : 0.f;
-                else
-                    A[0][o] = s;
+            for (int unit = tid; unit < (T / 4) * kin; unit += NT) {
+                const int rb = unit / kin, kk = unit % kin;
+                const float *dr = D[k + 1] + (rb * 4) * kout, *wr = Wl + kk * ws;
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+                for (int c = 0; c < kout; ++c) {
+                    const float w = wr[c];
+                    s0 = s0 + dr[c] * w;
+                    s1 = s1 + dr[kout + c] * w;
+                    s2 = s2 + dr[2 * kout + c] * w;
+                    s3 = s3 + dr[3 * kout + c] * w;
+                }
+                const float sv[4] = {s0, s1, s2, s3};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int o = (rb * 4 + j) * kin + kk;
+                    if (k > 0)
+                        D[k][o] = A[k][o] > 0.f ? sv[j] : 0.f;
+                    else
+                        A[0][o] = sv[j];
+                }
             }
         }
         __syncthreads();
@@ -284,6 +314,8 @@ extern "C" int crec_ncf_train_epoch(crec_ctx *ctx, const crec_ncf *mdl, crec_ada
             lds_f += 2 * (size_t)T * w;
         }
         lds_f += 2 * (size_t)T * d.dg + 5 * T;
+        if (has_m)
+            lds_f += (size_t)d.L0 * (d.L0 / 2 + 1); // the widest layer's weights, rows padded by one float
     }
     const size_t lds = lds_f * sizeof(float);
     CREC_REQUIRE(ctx, lds <= 160 * 1024, "model too wide for the on-chip tile (%zu bytes of LDS)", lds);
