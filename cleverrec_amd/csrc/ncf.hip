@@ -21,12 +21,113 @@
 namespace {
 
 constexpr int T = 32;        // instances per tile
-constexpr int NT = 256;      // threads per workgroup
+#ifndef NCF_NT
+#define NCF_NT 512
+#endif
+constexpr int NT = NCF_NT;   // threads per workgroup
+constexpr int NW = NT / 64;  // waves per workgroup
+constexpr int RW = T / NW;   // tile rows owned by one wave in the row-wise phases
 
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 __device__ inline float sigmoidf_(float z) { return 1.0f / (1.0f + expf(-z)); }
 
-// dynamic LDS: activations A_0..A_L (A_0 = concat(pm, qm)), deltas D_1..D_L, gmf rows, per-instance scalars
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1)
+        v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// C[M x N] = A[M x K] * B[K x N] on v_mfma_f32_16x16x4_f32: 16x16 output blocks dealt round-robin to the waves.
+// fa(m, k) / fb(k, n) read the operands (LDS), fs(m, n, v) consumes an output; the edges of M / N / K are handled
+// here (fa / fb only ever see valid indices).
+// Lane l feeds A[l & 15][k_l] and B[k_l][l & 15] and the instruction sums over the four k_l of the quarter-waves
+// q = l >> 4; output register j of lane l is C[4 * q + j][l & 15].  Which four k an instruction covers is free as long
+// as A and B agree, so K is walked in chunks of 4*S columns with k_l = chunk + s + S*q in step s: with S = 16 and row
+// strides that are odd, a half-wave's 32 operand reads fall in 32 different LDS banks whether k runs along the row
+// (A of the forward pass) or down the column (B).  The order of the sum is fixed: chunks ascending, s ascending, q
+// ascending inside the instruction.
+template <int S, class FA, class FB>
+__device__ __forceinline__ f32x4 gemm_chunk(f32x4 acc, int k0, int mc, int nc, int q, FA fa, FB fb)
+{
+    float a[S], b[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) { // all 2*S operand reads in flight together
+        a[s] = fa(mc, k0 + s + S * q);
+        b[s] = fb(k0 + s + S * q, nc);
+    }
+    __builtin_amdgcn_sched_barrier(0); // keep the reads batched: the scheduler would otherwise pair each with its MFMA
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc, 0, 0, 0);
+    return acc;
+}
+
+template <class FA, class FB, class FS>
+__device__ __forceinline__ void tile_gemm(int M, int N, int K, FA fa, FB fb, FS fs)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l16 = lane & 15, q = lane >> 4;
+    const int nbn = (N + 15) >> 4, nblk = ((M + 15) >> 4) * nbn;
+    for (int blk = wave; blk < nblk; blk += NW) {
+        const int m0 = (blk / nbn) << 4, n0 = (blk % nbn) << 4;
+        // rows / columns past the edge read a clamped (valid) address: they only feed outputs that are dropped
+        // below, so no predicate -- a predicated LDS read costs a branch each
+        const int ni = n0 + l16;
+        const int mc = (m0 + l16) < M ? (m0 + l16) : M - 1, nc = ni < N ? ni : N - 1;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        int k = 0;
+        for (; k + 64 <= K; k += 64)
+            acc = gemm_chunk<16>(acc, k, mc, nc, q, fa, fb);
+        if (k + 32 <= K) {
+            acc = gemm_chunk<8>(acc, k, mc, nc, q, fa, fb);
+            k += 32;
+        }
+        if (k + 16 <= K) {
+            acc = gemm_chunk<4>(acc, k, mc, nc, q, fa, fb);
+            k += 16;
+        }
+        for (; k < K; k += 4) { // K tail: columns past the end contribute zeros
+            const bool kok = k + q < K;
+            const int kc = kok ? k + q : K - 1;
+            const float a = fa(mc, kc), b = fb(kc, nc);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kok ? a : 0.f, b, acc, 0, 0, 0);
+        }
+        if (ni < N) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (m0 + q * 4 + j < M)
+                    fs(m0 + q * 4 + j, ni, acc[j]);
+        }
+    }
+}
+
+// stage a row-major [rows x cols] weight matrix in LDS with row stride cols + 1
+__device__ __forceinline__ void stage_weights(float *__restrict__ Wl, const float *__restrict__ W, int rows, int cols)
+{
+    const int n = rows * cols, ws = cols + 1;
+    if ((cols & (cols - 1)) == 0 && cols >= 4 && ((uintptr_t)W & 15) == 0) { // the usual case: no division, 16 B loads
+        const int sh = __builtin_ctz(cols);
+        const float4 *W4 = (const float4 *)W;
+#pragma unroll 8
+        for (int o4 = threadIdx.x; o4 < n / 4; o4 += NT) {
+            const float4 w = W4[o4];
+            float *dst = Wl + ((o4 * 4) >> sh) * ws + ((o4 * 4) & (cols - 1));
+            dst[0] = w.x, dst[1] = w.y, dst[2] = w.z, dst[3] = w.w;
+        }
+    } else {
+#pragma unroll 4
+        for (int o = threadIdx.x; o < n; o += NT)
+            Wl[(o / cols) * ws + (o % cols)] = W[o];
+    }
+}
+
+// dynamic LDS (every 2-D array has its row stride padded by one float, so that the MFMA operand reads -- 16 rows at
+// one column -- spread over the banks): activations A_0..A_L (A_0 = concat(pm, qm)), deltas D_1..D_L, the gmf rows,
+// e / label / (u, i) per instance, the small vectors [b_0 | .. | b_{L-1} | h], and the weights of every layer.
+// Nothing in the phases below reads a parameter from global memory: with one workgroup per CU every such load
+// would be an exposed round trip.
 __global__ __launch_bounds__(NT) void ncf_tile(NcfDev m, const int32_t *__restrict__ u, const int32_t *__restrict__ i,
                                                const float *__restrict__ y, int nb, float *__restrict__ c_pg,
                                                float *__restrict__ c_qg, float *__restrict__ c_pm,
@@ -34,209 +135,302 @@ __global__ __launch_bounds__(NT) void ncf_tile(NcfDev m, const int32_t *__restri
                                                float *__restrict__ partial)
 {
     extern __shared__ float lds[];
-    const int tid = threadIdx.x, tile = blockIdx.x;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+#ifdef NCF_STAMPS // debug builds: core-clock and 100 MHz stamps of tile 7 at the phase boundaries
+    int stamp_n = 0;
+#define STAMP()                                                          \
+    do {                                                                 \
+        __syncthreads();                                                 \
+        if (m.dbg && blockIdx.x == 7 && tid == 0) {                          \
+            m.dbg[2 * stamp_n] = __builtin_amdgcn_s_memtime();           \
+            m.dbg[2 * stamp_n + 1] = __builtin_amdgcn_s_memrealtime();   \
+        }                                                                \
+        ++stamp_n;                                                       \
+    } while (0)
+#else
+#define STAMP()
+#endif
+    for (int tile = blockIdx.x; tile * T < nb; tile += gridDim.x) { // grid-stride over the batch's tiles
+    STAMP();
     const int r0 = tile * T;
     const int nr = (nb - r0) < T ? (nb - r0) : T;
     const bool has_g = m.kind != 1, has_m = m.kind != 0;
-    const int dg = has_g ? m.dg : 0, L = has_m ? m.n_layers : 0, hm = m.L0 / 2;
+    const int dg = has_g ? m.dg : 0, L = has_m ? m.n_layers : 0, hm = m.L0 / 2, ldg = dg + 1;
 
-    // carve LDS
-    float *p = lds;
-    float *A[MAX_LAYERS + 1], *D[MAX_LAYERS + 1];
-    int width[MAX_LAYERS + 1];
-    width[0] = has_m ? m.L0 : 0;
-    for (int k = 0; k < L; ++k)
-        width[k + 1] = width[k] / 2;
-    for (int k = 0; k <= L; ++k) {
-        A[k] = p;
-        p += T * width[k];
-    }
-    for (int k = 1; k <= L; ++k) {
-        D[k] = p;
-        p += T * width[k];
-    }
-    float *G_p = p;
-    p += T * dg;
-    float *G_q = p;
-    p += T * dg;
-    float *zg = p, *e = p + T, *yl = p + 2 * T;
-    int *su = (int *)(p + 3 * T), *si = su + T;
+    // carve LDS (ncf_tile_lds_floats below mirrors this).  Widths halve exactly (ncf_describe), so the offsets
+    // are closed-form scalar arithmetic: no pointer tables (they would live in scratch)
+    const auto width_of = [&](int k) { return has_m ? (m.L0 >> k) : 0; };
+    const auto off_of = [&](int k) { // floats before A_k when the A_j are laid out back to back
+        int o = 0;
+        for (int j = 0; j < k; ++j)
+            o += T * (width_of(j) + 1);
+        return o;
+    };
+    const auto woff_of = [&](int k) { // floats before W_k (rows padded by one float)
+        int o = 0;
+        for (int j = 0; j < k; ++j)
+            o += width_of(j) * (width_of(j + 1) + 1);
+        return o;
+    };
+    const auto boff_of = [&](int k) { // floats before b_k
+        int o = 0;
+        for (int j = 0; j < k; ++j)
+            o += width_of(j + 1);
+        return o;
+    };
+    const int last = has_m ? width_of(L) : 0;
+    float *const A_base = lds;
+    float *const D_base = lds + off_of(L + 1) - off_of(1); // D_k sits where an (L+1+k)-th activation would
+    float *p = lds + 2 * off_of(L + 1) - off_of(1);
+#define A_(k) (A_base + off_of(k))
+#define D_(k) (D_base + off_of(k))
+#define W_(k) width_of(k)
+#define LD_(k) (width_of(k) + 1)
+    float *const G_p = p;
+    p += T * ldg;
+    float *const G_q = p;
+    p += T * ldg;
+    float *const e = p, *const yl = p + T;
+    int *const su = (int *)(p + 2 * T), *const si = su + T;
+    float *const b_base = (float *)(si + T);
+    float *const hl = b_base + boff_of(L); // GMF: h_gmf[dg]; MLP: h_mlp[last]; NeuMF: h_neumf[dg + last]
+    float *const W_base = hl + dg + last;
+#define WL_(k) (W_base + woff_of(k))
+#define BL_(k) (b_base + boff_of(k))
 
-    for (int r = tid; r < T; r += NT) {
-        const bool ok = r < nr;
-        su[r] = ok ? u[r0 + r] : 0;
-        si[r] = ok ? i[r0 + r] : 0;
-        yl[r] = ok ? y[r0 + r] : 0.f;
-        zg[r] = 0.f;
+    if (tid < T) {
+        const bool ok = tid < nr;
+        su[tid] = ok ? u[r0 + tid] : 0;
+        si[tid] = ok ? i[r0 + tid] : 0;
+        yl[tid] = ok ? y[r0 + tid] : 0.f;
     }
-    __syncthreads();
-    // ---- gathers ------------------------------------------------------------------------------
-    for (int k = tid; k < T * dg; k += NT) {
-        const int r = k / dg, c = k % dg;
-        G_p[k] = r < nr ? m.Pg[(int64_t)su[r] * dg + c] : 0.f;
-        G_q[k] = r < nr ? m.Qg[(int64_t)si[r] * dg + c] : 0.f;
-    }
-    for (int k = tid; k < T * width[0]; k += NT) {
-        const int r = k / width[0], c = k % width[0];
-        float v = 0.f;
-        if (r < nr)
-            v = c < hm ? m.Pm[(int64_t)su[r] * hm + c] : m.Qm[(int64_t)si[r] * hm + (c - hm)];
-        A[0][k] = v;
-    }
-    __syncthreads();
-    // ---- GMF product: zg[r] = sum_c pg*qg*h_g ----------------------------------------------------
-    const float *h = m.small + m.h_off; // GMF: h_gmf[dg]; MLP: h_mlp[last]; NeuMF: h_neumf[dg + last]
-    if (has_g) {
-        for (int r = tid >> 3; r < T; r += NT >> 3) { // 8 threads per instance
-            float s = 0.f;
-            for (int c = tid & 7; c < dg; c += 8)
-                s = s + (G_p[r * dg + c] * G_q[r * dg + c]) * h[c];
-            s += __shfl_xor(s, 1, 64);
-            s += __shfl_xor(s, 2, 64);
-            s += __shfl_xor(s, 4, 64);
-            if ((tid & 7) == 0)
-                zg[r] = s;
-        }
-    }
-    // ---- tower forward: A[k+1] = relu(A[k] W_k + b_k) --------------------------------------------
-    // W_k is staged in LDS with rows padded by one float (the backward pass reads it column-wise); each
-    // thread produces 4 rows x 1 column, so a weight is read once per 4 FMAs
-    float *Wl = (float *)(si + T);
+    // every parameter on chip for both passes; these loads overlap the index fetch
+    for (int c = tid; c < dg + last; c += NT)
+        hl[c] = m.small[m.h_off + c];
     for (int k = 0; k < L; ++k) {
-        const int kin = width[k], kout = width[k + 1], ws = kout + 1;
-        const float *W = m.small + m.w_off[k], *b = m.small + m.b_off[k];
-        __syncthreads();
-        for (int o = tid; o < kin * kout; o += NT)
-            Wl[(o / kout) * ws + (o % kout)] = W[o];
-        __syncthreads();
-        for (int unit = tid; unit < (T / 4) * kout; unit += NT) {
-            const int rb = unit / kout, c = unit % kout;
-            const float *a = A[k] + (rb * 4) * kin;
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-            for (int kk = 0; kk < kin; ++kk) {
-                const float w = Wl[kk * ws + c];
-                s0 = s0 + a[kk] * w;
-                s1 = s1 + a[kin + kk] * w;
-                s2 = s2 + a[2 * kin + kk] * w;
-                s3 = s3 + a[3 * kin + kk] * w;
-            }
-            float *o4 = A[k + 1] + (rb * 4) * kout + c;
-            const float bb = b[c];
-            s0 += bb, s1 += bb, s2 += bb, s3 += bb;
-            o4[0] = s0 > 0.f ? s0 : 0.f;
-            o4[kout] = s1 > 0.f ? s1 : 0.f;
-            o4[2 * kout] = s2 > 0.f ? s2 : 0.f;
-            o4[3 * kout] = s3 > 0.f ? s3 : 0.f;
-        }
+        for (int c = tid; c < W_(k + 1); c += NT)
+            BL_(k)[c] = m.small[m.b_off[k] + c];
+        stage_weights(WL_(k), m.small + m.w_off[k], W_(k), W_(k + 1));
     }
     __syncthreads();
-    // ---- logit, e, loss --------------------------------------------------------------------------
-    const float *h_m = h + dg;
-    const int last = has_m ? width[L] : 0;
-    for (int r = tid; r < T; r += NT) {
-        float z = zg[r];
-        for (int c = 0; c < last; ++c)
-            z = z + A[L][r * last + c] * h_m[c];
-        const float lab = yl[r];
-        e[r] = r < nr ? sigmoidf_(z) - lab : 0.f;
-        if (r < nr) {
-            // sigmoid_cross_entropy_with_logits (utils/tools.py:68-69) + the l2 terms of the gathered rows
-            float ls = (z > 0.f ? z : 0.f) - z * lab + log1pf(expf(-fabsf(z)));
-            float ng = 0.f, nm = 0.f;
-            for (int c = 0; c < dg; ++c)
-                ng = ng + (G_p[r * dg + c] * G_p[r * dg + c] + G_q[r * dg + c] * G_q[r * dg + c]);
-            for (int c = 0; c < width[0]; ++c)
-                nm = nm + A[0][r * width[0] + c] * A[0][r * width[0] + c];
-            loss_inst[r0 + r] = ls + m.reg_g * (0.5f * ng) + m.reg_m * (0.5f * nm);
+    STAMP(); // 1: parameters staged
+    // ---- gathers: a wave owns RW rows, lanes run along the row; all RW rows' loads in flight together ------------
+    {
+        int64_t ub[RW], ib[RW];
+        bool ok[RW];
+#pragma unroll
+        for (int rr = 0; rr < RW; ++rr) {
+            const int r = wave * RW + rr;
+            ok[rr] = r < nr;
+            ub[rr] = su[r];
+            ib[rr] = si[r];
+        }
+        for (int c = lane; c < dg; c += 64) {
+            float tp[RW], tq[RW];
+#pragma unroll
+            for (int rr = 0; rr < RW; ++rr) {
+                tp[rr] = ok[rr] ? m.Pg[ub[rr] * dg + c] : 0.f;
+                tq[rr] = ok[rr] ? m.Qg[ib[rr] * dg + c] : 0.f;
+            }
+#pragma unroll
+            for (int rr = 0; rr < RW; ++rr) {
+                G_p[(wave * RW + rr) * ldg + c] = tp[rr];
+                G_q[(wave * RW + rr) * ldg + c] = tq[rr];
+            }
+        }
+        if (has_m) {
+            float *A0 = A_(0);
+            const int ld0 = LD_(0);
+            for (int c = lane; c < hm; c += 64) {
+                float tp[RW], tq[RW];
+#pragma unroll
+                for (int rr = 0; rr < RW; ++rr) {
+                    tp[rr] = ok[rr] ? m.Pm[ub[rr] * hm + c] : 0.f;
+                    tq[rr] = ok[rr] ? m.Qm[ib[rr] * hm + c] : 0.f;
+                }
+#pragma unroll
+                for (int rr = 0; rr < RW; ++rr) {
+                    A0[(wave * RW + rr) * ld0 + c] = tp[rr];
+                    A0[(wave * RW + rr) * ld0 + hm + c] = tq[rr];
+                }
+            }
+        }
+    }
+    STAMP(); // 2: rows gathered
+    // ---- tower forward: A[k+1] = relu(A[k] W_k + b_k) --------------------------------------------------------
+    for (int k = 0; k < L; ++k) {
+        const int kin = W_(k), kout = W_(k + 1), ws = kout + 1, lda = LD_(k), ldo = LD_(k + 1);
+        const float *b = BL_(k), *Ak = A_(k), *Wl = WL_(k);
+        float *An = A_(k + 1);
+        __syncthreads(); // A[k] complete
+        tile_gemm(
+            T, kout, kin, [&](int r, int kk) { return Ak[r * lda + kk]; }, [&](int kk, int c) { return Wl[kk * ws + c]; },
+            [&](int r, int c, float s) {
+                s += b[c];
+                An[r * ldo + c] = s > 0.f ? s : 0.f;
+            });
+    }
+    __syncthreads();
+    STAMP(); // 3..: forward
+    // ---- logit, e, loss: 8 lanes per instance, each over a contiguous eighth of the columns, then a fixed
+    // butterfly over the 8 -----------------------------------------------------------------------------------------
+    if (tid < T * 8) {
+        const int r = tid >> 3, sub = tid & 7;
+        const auto eighth = [&](int n, int &c0, int &c1) {
+            const int cw = (n + 7) >> 3;
+            c0 = sub * cw < n ? sub * cw : n;
+            c1 = c0 + cw < n ? c0 + cw : n;
+        };
+        float zg = 0.f, ng = 0.f, zm = 0.f, nm = 0.f;
+        int c0, c1;
+        eighth(dg, c0, c1);
+        for (int c = c0; c < c1; ++c) {
+            const float pg = G_p[r * ldg + c], qg = G_q[r * ldg + c];
+            zg = zg + (pg * qg) * hl[c];
+            ng = ng + (pg * pg + qg * qg);
+        }
+        if (has_m) {
+            const float *AL = A_(L), *A0 = A_(0);
+            const int ldl = LD_(L), ld0 = LD_(0);
+            eighth(last, c0, c1);
+            for (int c = c0; c < c1; ++c)
+                zm = zm + AL[r * ldl + c] * hl[dg + c];
+            eighth(W_(0), c0, c1);
+            for (int c = c0; c < c1; ++c) {
+                const float a = A0[r * ld0 + c];
+                nm = nm + a * a;
+            }
+        }
+#pragma unroll
+        for (int off = 1; off < 8; off <<= 1) {
+            zg += __shfl_xor(zg, off, 64);
+            ng += __shfl_xor(ng, off, 64);
+            zm += __shfl_xor(zm, off, 64);
+            nm += __shfl_xor(nm, off, 64);
+        }
+        if (sub == 0) {
+            const bool ok = r < nr;
+            const float z = zg + zm, lab = yl[r];
+            e[r] = ok ? sigmoidf_(z) - lab : 0.f;
+            if (ok) {
+                // sigmoid_cross_entropy_with_logits (utils/tools.py:68-69) + the l2 terms of the gathered rows
+                const float ls = (z > 0.f ? z : 0.f) - z * lab + log1pf(expf(-fabsf(z)));
+                loss_inst[r0 + r] = ls + m.reg_g * (0.5f * ng) + m.reg_m * (0.5f * nm);
+            }
         }
     }
     __syncthreads();
     float *part = partial + (int64_t)tile * m.n_small;
-    // ---- GMF backward ----------------------------------------------------------------------------
+    STAMP(); // logit
+    // ---- GMF backward ----------------------------------------------------------------------------------------
     if (has_g) {
-        for (int k = tid; k < T * dg; k += NT) {
-            const int r = k / dg, c = k % dg;
-            if (r < nr) {
-                c_pg[(int64_t)(r0 + r) * dg + c] = e[r] * (G_q[k] * h[c]);
-                c_qg[(int64_t)(r0 + r) * dg + c] = e[r] * (G_p[k] * h[c]);
+        for (int c = lane; c < dg; c += 64) {
+            const float hc = hl[c];
+#pragma unroll
+            for (int rr = 0; rr < RW; ++rr) {
+                const int r = wave * RW + rr;
+                if (r < nr) {
+                    const float er = e[r];
+                    c_pg[(int64_t)(r0 + r) * dg + c] = er * (G_q[r * ldg + c] * hc);
+                    c_qg[(int64_t)(r0 + r) * dg + c] = er * (G_p[r * ldg + c] * hc);
+                }
             }
         }
-        for (int c = tid; c < dg; c += NT) { // dL/dh_g
+        for (int c = tid; c < dg; c += NT) { // dL/dh_g (rows past nr carry e = 0)
             float s = 0.f;
-            for (int r = 0; r < nr; ++r)
-                s = s + e[r] * (G_p[r * dg + c] * G_q[r * dg + c]);
+#pragma unroll 16
+            for (int r = 0; r < T; ++r)
+                s = s + e[r] * (G_p[r * ldg + c] * G_q[r * ldg + c]);
             part[m.h_off + c] = s;
         }
     }
     if (has_m) {
+        const float *AL = A_(L);
+        float *DL = D_(L);
+        const int ldl = LD_(L);
         for (int c = tid; c < last; c += NT) { // dL/dh_m
             float s = 0.f;
-            for (int r = 0; r < nr; ++r)
-                s = s + e[r] * A[L][r * last + c];
+#pragma unroll 16
+            for (int r = 0; r < T; ++r)
+                s = s + e[r] * AL[r * ldl + c];
             part[m.h_off + dg + c] = s;
         }
         // D[L] = e * h_m * relu'
-        for (int o = tid; o < T * last; o += NT) {
-            const int r = o / last, c = o % last;
-            D[L][o] = A[L][o] > 0.f ? e[r] * h_m[c] : 0.f;
-        }
-        for (int k = L - 1; k >= 0; --k) {
-            const int kin = width[k], kout = width[k + 1];
-            const float *W = m.small + m.w_off[k];
-            __syncthreads();
-            // dW_k[kk][c] = sum_r A[k][r][kk] * D[k+1][r][c];  db_k[c] = sum_r D[k+1][r][c]
-            for (int o = tid; o < kin * kout; o += NT) {
-                const int kk = o / kout, c = o % kout;
-                float s = 0.f;
-                for (int r = 0; r < nr; ++r)
-                    s = s + A[k][r * kin + kk] * D[k + 1][r * kout + c];
-                part[m.w_off[k] + o] = s;
+        for (int c = lane; c < last; c += 64) {
+            const float hc = hl[dg + c];
+#pragma unroll
+            for (int rr = 0; rr < RW; ++rr) {
+                const int r = wave * RW + rr;
+                DL[r * ldl + c] = AL[r * ldl + c] > 0.f ? e[r] * hc : 0.f;
             }
-            for (int c = tid; c < kout; c += NT) {
+        }
+        STAMP(); // gmf backward, D[L]
+        for (int k = L - 1; k >= 0; --k) {
+            const int kin = W_(k), kout = W_(k + 1), ws = kout + 1, lda = LD_(k), ldd = LD_(k + 1);
+            const float *Ak = A_(k), *Dn = D_(k + 1), *Wl = WL_(k);
+            float *Dk = D_(k);
+            float *pw = part + m.w_off[k];
+            __syncthreads(); // D[k+1] complete
+            // dW_k[kk][c] = sum_r A[k][r][kk] * D[k+1][r][c]   (rows past nr carry D = 0)
+            tile_gemm(
+                    kin, kout, T, [&](int kk, int r) { return Ak[r * lda + kk]; }, [&](int r, int c) { return Dn[r * ldd + c]; },
+                    [&](int kk, int c, float s) { pw[kk * kout + c] = s; });
+            for (int c = tid; c < kout; c += NT) { // db_k[c] = sum_r D[k+1][r][c]
                 float s = 0.f;
-                for (int r = 0; r < nr; ++r)
-                    s = s + D[k + 1][r * kout + c];
+#pragma unroll 16
+                for (int r = 0; r < T; ++r)
+                    s = s + Dn[r * ldd + c];
                 part[m.b_off[k] + c] = s;
             }
-            // delta of the layer below (k > 0: through its ReLU; k == 0: dL/dX, written over A[0]);
-            // W_k back in LDS (padded rows: lanes differ in kk), 4 rows per thread
-            const int ws = kout + 1;
-            for (int o = tid; o < kin * kout; o += NT)
-                Wl[(o / kout) * ws + (o % kout)] = W[o];
-            __syncthreads();
-            for (int unit = tid; unit < (T / 4) * kin; unit += NT) {
-                const int rb = unit / kin, kk = unit % kin;
-                const float *dr = D[k + 1] + (rb * 4) * kout, *wr = Wl + kk * ws;
-                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-                for (int c = 0; c < kout; ++c) {
-                    const float w = wr[c];
-                    s0 = s0 + dr[c] * w;
-                    s1 = s1 + dr[kout + c] * w;
-                    s2 = s2 + dr[2 * kout + c] * w;
-                    s3 = s3 + dr[3 * kout + c] * w;
-                }
-                const float sv[4] = {s0, s1, s2, s3};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int o = (rb * 4 + j) * kin + kk;
-                    if (k > 0)
-                        D[k][o] = A[k][o] > 0.f ? sv[j] : 0.f;
-                    else
-                        A[0][o] = sv[j];
-                }
-            }
-        }
-        __syncthreads();
-        for (int k = tid; k < T * width[0]; k += NT) {
-            const int r = k / width[0], c = k % width[0];
-            if (r < nr) {
-                if (c < hm)
-                    c_pm[(int64_t)(r0 + r) * hm + c] = A[0][k];
-                else
-                    c_qm[(int64_t)(r0 + r) * hm + (c - hm)] = A[0][k];
-            }
+            STAMP(); // dW_k
+            // delta of the layer below: through its ReLU into D[k] (k > 0), or dL/dX = the contribution rows of the
+            // two MLP tables straight to HBM (k == 0)
+            if (k > 0)
+                tile_gemm(
+                    T, kin, kout, [&](int r, int c) { return Dn[r * ldd + c]; }, [&](int c, int kk) { return Wl[kk * ws + c]; },
+                    [&](int r, int kk, float s) {
+                        const int o = r * lda + kk;
+                        Dk[o] = Ak[o] > 0.f ? s : 0.f;
+                    });
+            else
+                tile_gemm(
+                    T, kin, kout, [&](int r, int c) { return Dn[r * ldd + c]; }, [&](int c, int kk) { return Wl[kk * ws + c]; },
+                    [&](int r, int kk, float s) {
+                        if (r < nr) {
+                            if (kk < hm)
+                                c_pm[(int64_t)(r0 + r) * hm + kk] = s;
+                            else
+                                c_qm[(int64_t)(r0 + r) * hm + (kk - hm)] = s;
+                        }
+                    });
+            STAMP(); // dX_k
         }
     }
+    __syncthreads(); // LDS is reused by the next tile
+    }
+}
+
+#undef A_
+#undef D_
+#undef W_
+#undef LD_
+#undef WL_
+#undef BL_
+#undef STAMP
+
+size_t ncf_tile_lds_floats(bool has_g, bool has_m, int dg, int L0, int n_layers)
+{
+    size_t f = 0;
+    int w = has_m ? L0 : 0;
+    f += (size_t)T * (w + 1);
+    for (int k = 0; k < (has_m ? n_layers : 0); ++k) {
+        f += (size_t)w * (w / 2 + 1); // W_k, rows padded by one float
+        w /= 2;
+        f += 2 * (size_t)T * (w + 1) + w; // A_{k+1}, D_{k+1}, b_k
+    }
+    f += 2 * (size_t)T * ((has_g ? dg : 0) + 1) + 4 * T; // gmf rows; e, label, u, i
+    f += (has_g ? dg : 0) + w;                            // h
+    return f;
 }
 
 __global__ __launch_bounds__(256) void ncf_reduce_loss(const float *__restrict__ loss_inst, int64_t n_total, int32_t B,
@@ -305,22 +499,17 @@ extern "C" int crec_ncf_train_epoch(crec_ctx *ctx, const crec_ncf *mdl, crec_ada
     float *loss_inst = (float *)(ws + up(ixu) + up(ixi) + up(cb) + up(pb));
 
     // LDS of the tile kernel
-    size_t lds_f = 0;
-    {
-        int w = has_m ? d.L0 : 0;
-        lds_f += (size_t)T * w;
-        for (int k = 0; k < d.n_layers; ++k) {
-            w /= 2;
-            lds_f += 2 * (size_t)T * w;
-        }
-        lds_f += 2 * (size_t)T * d.dg + 5 * T;
-        if (has_m)
-            lds_f += (size_t)d.L0 * (d.L0 / 2 + 1); // the widest layer's weights, rows padded by one float
-    }
+    const size_t lds_f = ncf_tile_lds_floats(has_g, has_m, d.dg, d.L0, d.n_layers);
     const size_t lds = lds_f * sizeof(float);
     CREC_REQUIRE(ctx, lds <= 160 * 1024, "model too wide for the on-chip tile (%zu bytes of LDS)", lds);
     CREC_HIP(ctx, hipFuncSetAttribute((const void *)ncf_tile, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 
+#ifdef NCF_STAMPS
+    long long *dbg = nullptr;
+    CREC_HIP(ctx, hipMalloc(&dbg, 64 * sizeof(long long)));
+    CREC_HIP(ctx, hipMemset(dbg, 0, 64 * sizeof(long long)));
+    d.dbg = dbg;
+#endif
     for (int64_t b = 0; b < nb; ++b) {
         const int64_t t0 = b * B;
         const int nbt = (int)((N - t0) < B ? (N - t0) : B);
@@ -334,19 +523,40 @@ extern "C" int crec_ncf_train_epoch(crec_ctx *ctx, const crec_ncf *mdl, crec_ada
         hipLaunchKernelGGL(ncf_tile, dim3((unsigned)crec_ceil_div(nbt, T)), dim3(NT), lds, st, d, u + t0, i + t0, y + t0, nbt,
                            c_pg, c_qg, c_pm, c_qm, loss_inst + t0, partial);
         crec_prof_end(ctx, st);
+        // every parameter update of the step in one launch when the tables share a row-width class
+        crec_apply_set set{};
+        const auto job = [&](const crec_param &t, int64_t rows, int cols, const crec_rows_index_view &v, const float *c, float reg) {
+            crec_rows_opt oo = o;
+            oo.reg_occ = reg;
+            set.tables[set.n_tables++] = crec_rows_job{crec_rows_table{t.var, t.m, t.v, rows, cols}, v.rowseg + b * v.rows,
+                                                       v.order + b * v.per_batch, c, nullptr, nullptr, oo};
+        };
+        const auto cls = [](int dd) {
+            int l = 1;
+            while (l * 4 < dd)
+                l <<= 1;
+            return l;
+        };
+        crec_rows_opt od = o;
+        od.kind = ROWS_DENSE;
+        const crec_small_job small{mdl->small.var, mdl->small.m, mdl->small.v, partial, (int)crec_ceil_div(nbt, T), d.n_small,
+                                   d.n_small, od};
         if (has_g) {
-            o.reg_occ = mdl->reg_gmf;
-            crec_rows_apply(ctx, crec_rows_table{mdl->P_gmf.var, mdl->P_gmf.m, mdl->P_gmf.v, U, d.dg}, vu, b, c_pg, nullptr, o, st);
-            crec_rows_apply(ctx, crec_rows_table{mdl->Q_gmf.var, mdl->Q_gmf.m, mdl->Q_gmf.v, I, d.dg}, vi, b, c_qg, nullptr, o, st);
+            job(mdl->P_gmf, U, d.dg, vu, c_pg, mdl->reg_gmf);
+            job(mdl->Q_gmf, I, d.dg, vi, c_qg, mdl->reg_gmf);
+        }
+        if (has_g && has_m && cls(d.dg) != cls(hm)) { // two width classes: two launches
+            if (int rc = crec_apply_all(ctx, set, st))
+                return rc;
+            set = crec_apply_set{};
         }
         if (has_m) {
-            o.reg_occ = mdl->reg_mlp;
-            crec_rows_apply(ctx, crec_rows_table{mdl->P_mlp.var, mdl->P_mlp.m, mdl->P_mlp.v, U, hm}, vu, b, c_pm, nullptr, o, st);
-            crec_rows_apply(ctx, crec_rows_table{mdl->Q_mlp.var, mdl->Q_mlp.m, mdl->Q_mlp.v, I, hm}, vi, b, c_qm, nullptr, o, st);
+            job(mdl->P_mlp, U, hm, vu, c_pm, mdl->reg_mlp);
+            job(mdl->Q_mlp, I, hm, vi, c_qm, mdl->reg_mlp);
         }
-        o.kind = ROWS_DENSE;
-        crec_small_adam_dense(ctx, mdl->small.var, mdl->small.m, mdl->small.v, partial, (int)crec_ceil_div(nbt, T), d.n_small,
-                              d.n_small, o, st);
+        set.small = small;
+        if (int rc = crec_apply_all(ctx, set, st))
+            return rc;
         opt->beta1_power = opt->beta1_power * opt->beta1;
         opt->beta2_power = opt->beta2_power * opt->beta2;
         opt->step += 1;
@@ -354,6 +564,16 @@ extern "C" int crec_ncf_train_epoch(crec_ctx *ctx, const crec_ncf *mdl, crec_ada
     crec_prof_begin(ctx, CREC_K_REDUCE_LOSS, st);
     hipLaunchKernelGGL(ncf_reduce_loss, dim3((unsigned)nb), dim3(256), 0, st, (const float *)loss_inst, N, B, loss_per_batch);
     crec_prof_end(ctx, st);
+#ifdef NCF_STAMPS
+    {
+        long long h[64];
+        CREC_HIP(ctx, hipStreamSynchronize(st));
+        CREC_HIP(ctx, hipMemcpy(h, dbg, sizeof h, hipMemcpyDeviceToHost));
+        for (int k = 1; k < 32 && h[2 * k]; ++k)
+            fprintf(stderr, "ncf_tile stamp %2d: +%6lld clk  +%5.2f us\n", k, h[2 * k] - h[2 * k - 2], 0.01 * (double)(h[2 * k + 1] - h[2 * k - 1]));
+        (void)hipFree(dbg);
+    }
+#endif
     CREC_HIP(ctx, hipGetLastError());
     return crec_prof_flush(ctx, st);
 }

@@ -11,6 +11,7 @@ struct NcfDev {
     int dg, n_layers, L0;
     int w_off[MAX_LAYERS], b_off[MAX_LAYERS], h_off, n_small;
     float reg_g, reg_m;
+    long long *dbg; // -DNCF_STAMPS builds only: per-phase clock stamps of one tile (tools/ncf_variants.sh)
 };
 
 // validates a crec_ncf and lays out the flat small-parameter block [W_0 | b_0 | ... | h]

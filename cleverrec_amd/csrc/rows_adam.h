@@ -25,6 +25,34 @@ struct crec_rows_index_view {
     int64_t rows;
 };
 
+// one table's share of a merged parameter-update launch (crec_apply_all)
+struct crec_rows_job {
+    crec_rows_table t;
+    const int2 *rowseg;      // this batch's {first sorted position, count} per table row
+    const int32_t *order;    // this batch's sorted slot ids
+    const float *contrib;    // [slots][d] contribution rows
+    const float *dense_grad; // optional (see rows_adam.hip)
+    float *row_out;          // optional
+    crec_rows_opt o;
+};
+
+struct crec_small_job { // dense ApplyAdam of a small vector from partial sums
+    float *var, *m, *v;
+    const float *partial;
+    int n_partials;
+    int64_t stride;
+    int n;
+    crec_rows_opt o;
+};
+
+constexpr int CREC_APPLY_MAX_TABLES = 4;
+struct crec_apply_set {
+    crec_rows_job tables[CREC_APPLY_MAX_TABLES];
+    int n_tables;
+    int block_end[CREC_APPLY_MAX_TABLES]; // filled by crec_apply_all
+    crec_small_job small;                 // small.n == 0: none
+};
+
 size_t crec_rows_index_bytes(int64_t n_batches, int32_t per_batch, int64_t rows);
 int crec_rows_index(crec_ctx *ctx, const int32_t *idx, int64_t n_total, int32_t per_batch, int64_t rows, void *ws,
                     crec_rows_index_view *out, hipStream_t st);
@@ -33,3 +61,5 @@ int crec_rows_apply(crec_ctx *ctx, const crec_rows_table &t, const crec_rows_ind
                     float *row_out = nullptr);
 int crec_small_adam_dense(crec_ctx *ctx, float *var, float *m, float *v, const float *partial, int n_partials,
                           int64_t stride, int n, const crec_rows_opt &o, hipStream_t st);
+// all tables (same row-width class) and the small vector of one step in a single launch
+int crec_apply_all(crec_ctx *ctx, crec_apply_set &a, hipStream_t st);

@@ -76,14 +76,13 @@ __device__ inline void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) 
 // one wave per table row; group g of the wave takes slots g, g+G, ... of the row (fixed order),
 // the G partial sums are added in group order
 template <int LPR>
-__global__ __launch_bounds__(256) void rows_apply(crec_rows_table t, const int2 *__restrict__ rowseg,
-                                                  const int32_t *__restrict__ order, const float *__restrict__ contrib,
-                                                  const float *__restrict__ dense_grad, float *__restrict__ row_out,
-                                                  crec_rows_opt o)
+__device__ __forceinline__ void rows_apply_row(const crec_rows_table &t, const int2 *__restrict__ rowseg,
+                                               const int32_t *__restrict__ order, const float *__restrict__ contrib,
+                                               const float *__restrict__ dense_grad, float *__restrict__ row_out,
+                                               const crec_rows_opt &o, int64_t r)
 {
     constexpr int G = 64 / LPR;
     const int lane = threadIdx.x & 63, g = lane / LPR, l = lane % LPR;
-    const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (r >= t.rows)
         return;
     const int d = t.d;
@@ -160,25 +159,82 @@ __global__ __launch_bounds__(256) void rows_apply(crec_rows_table t, const int2 
     st4(t.v + ro, v);
 }
 
-// dense ApplyAdam of a small parameter vector (h, W_k, b_k, w0) from partial sums:
-//   g[e] = sum_p partial[p*stride + e] (p ascending), n elements; one thread per element
-__global__ void small_adam_dense(float *__restrict__ var, float *__restrict__ m, float *__restrict__ v,
-                                 const float *__restrict__ partial, int n_partials, int64_t stride, int n,
-                                 crec_rows_opt o)
+template <int LPR>
+__global__ __launch_bounds__(256) void rows_apply(crec_rows_table t, const int2 *__restrict__ rowseg,
+                                                  const int32_t *__restrict__ order, const float *__restrict__ contrib,
+                                                  const float *__restrict__ dense_grad, float *__restrict__ row_out,
+                                                  crec_rows_opt o)
 {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n)
-        return;
+    rows_apply_row<LPR>(t, rowseg, order, contrib, dense_grad, row_out, o,
+                        (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+}
+
+// dense ApplyAdam of a small parameter vector (h, W_k, b_k, w0) from partial sums:
+//   g[e] = sum_p partial[p*stride + e], n elements.  A workgroup of EL * SAD_SL threads owns EL elements; its
+//   SAD_SL slices each add a contiguous run of the partials in ascending p (8 independent loads in flight at a
+//   time), and the slice sums are combined in slice order -- one fixed summation order whatever the launch shape.
+constexpr int SAD_SL = 16;
+template <int EL> __device__ __forceinline__ void small_adam_block(const crec_small_job &j, int blk, float *red)
+{
+    const int el = threadIdx.x % EL, sl = threadIdx.x / EL;
+    const int e = blk * EL + el;
+    const int per = (j.n_partials + SAD_SL - 1) / SAD_SL;
+    const int p0 = sl * per, p1 = (p0 + per) < j.n_partials ? (p0 + per) : j.n_partials;
     float g = 0.f;
-    for (int p = 0; p < n_partials; ++p)
-        g = g + partial[(int64_t)p * stride + e];
-    const float omb1 = 1.0f - o.beta1, omb2 = 1.0f - o.beta2;
-    float mm = m[e], vv = v[e];
+    if (e < j.n) {
+        int p = p0;
+        for (; p + 8 <= p1; p += 8) {
+            float t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                t[k] = j.partial[(int64_t)(p + k) * j.stride + e];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                g = g + t[k];
+        }
+        for (; p < p1; ++p)
+            g = g + j.partial[(int64_t)p * j.stride + e];
+    }
+    red[sl * EL + el] = g;
+    __syncthreads();
+    if (sl != 0 || e >= j.n)
+        return;
+    g = red[el];
+#pragma unroll
+    for (int s = 1; s < SAD_SL; ++s)
+        g = g + red[s * EL + el];
+    const float omb1 = 1.0f - j.o.beta1, omb2 = 1.0f - j.o.beta2;
+    float mm = j.m[e], vv = j.v[e];
     mm = mm + (g - mm) * omb1;
     vv = vv + (g * g - vv) * omb2;
-    m[e] = mm;
-    v[e] = vv;
-    var[e] = var[e] - (mm * o.lr_t) / (sqrtf(vv) + o.eps);
+    j.m[e] = mm;
+    j.v[e] = vv;
+    j.var[e] = j.var[e] - (mm * j.o.lr_t) / (sqrtf(vv) + j.o.eps);
+}
+
+__global__ __launch_bounds__(64 * SAD_SL) void small_adam_dense(crec_small_job j)
+{
+    __shared__ float red[SAD_SL * 64];
+    small_adam_block<64>(j, blockIdx.x, red);
+}
+
+// every parameter update of a step in ONE launch: up to CREC_APPLY_MAX_TABLES embedding tables (blocks
+// [block_end[k-1], block_end[k]) sweep table k, four rows per block) and, after them, the small dense vector
+// (16 elements per block; same slices, hence the same sums, as small_adam_dense)
+template <int LPR> __global__ __launch_bounds__(256) void apply_all(crec_apply_set a)
+{
+    __shared__ float red[SAD_SL * 16];
+    const int bi = blockIdx.x;
+    int k = 0, first = 0;
+    while (k < a.n_tables && bi >= a.block_end[k])
+        first = a.block_end[k++];
+    if (k < a.n_tables) {
+        const crec_rows_job &j = a.tables[k];
+        rows_apply_row<LPR>(j.t, j.rowseg, j.order, j.contrib, j.dense_grad, j.row_out, j.o,
+                            (int64_t)(bi - first) * 4 + (threadIdx.x >> 6));
+    } else {
+        small_adam_block<16>(a.small, bi - first, red);
+    }
 }
 
 } // namespace
@@ -241,8 +297,46 @@ int crec_small_adam_dense(crec_ctx *ctx, float *var, float *m, float *v, const f
                           int64_t stride, int n, const crec_rows_opt &o, hipStream_t st)
 {
     crec_prof_begin(ctx, CREC_K_SMALL_ADAM, st);
-    hipLaunchKernelGGL(small_adam_dense, dim3((unsigned)crec_ceil_div(n, 256)), dim3(256), 0, st, var, m, v, partial,
-                       n_partials, stride, n, o);
+    hipLaunchKernelGGL(small_adam_dense, dim3((unsigned)crec_ceil_div(n, 64)), dim3(64 * SAD_SL), 0, st,
+                       crec_small_job{var, m, v, partial, n_partials, stride, n, o});
+    crec_prof_end(ctx, st);
+    return CREC_OK;
+}
+
+int crec_apply_all(crec_ctx *ctx, crec_apply_set &a, hipStream_t st)
+{
+    CREC_REQUIRE(ctx, a.n_tables >= 0 && a.n_tables <= CREC_APPLY_MAX_TABLES, "apply set: too many tables");
+    int lpr = 0, blocks = 0;
+    for (int k = 0; k < a.n_tables; ++k) {
+        int l = 1;
+        while (l * 4 < a.tables[k].t.d)
+            l <<= 1;
+        CREC_REQUIRE(ctx, lpr == 0 || l == lpr, "apply set: tables of one launch must share the row width class");
+        lpr = l;
+        blocks += (int)crec_ceil_div(a.tables[k].t.rows, 4);
+        a.block_end[k] = blocks;
+    }
+    if (a.small.n > 0)
+        blocks += (int)crec_ceil_div(a.small.n, 16);
+    if (blocks == 0)
+        return CREC_OK;
+    if (lpr == 0)
+        lpr = 1;
+    crec_prof_begin(ctx, CREC_K_ROWS_APPLY, st);
+#define CREC_AA(L)                                                                  \
+    case L:                                                                         \
+        hipLaunchKernelGGL((apply_all<L>), dim3((unsigned)blocks), dim3(256), 0, st, a); \
+        break;
+    switch (lpr) {
+        CREC_AA(1)
+        CREC_AA(2)
+        CREC_AA(4)
+        CREC_AA(8)
+        CREC_AA(16)
+        CREC_AA(32)
+        CREC_AA(64)
+    }
+#undef CREC_AA
     crec_prof_end(ctx, st);
     return CREC_OK;
 }
