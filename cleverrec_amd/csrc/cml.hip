@@ -11,9 +11,13 @@
 // every row.  Its gradient needs no d x d product: with X centred by the column means mu,
 // dL/dX_ra = (2 reg / n)(s_r - Xc_ra), s_r = sum_b Xc_rb (rows_adam.hip).
 //
-// Per batch: cml_colsum x2 (mu) -> cml_instances (one lane group per instance: distances, arg-min negative,
-// WARP weight, contribution rows for p_u, q_i and the arg-min negative, whose row id is only known now) ->
-// rows_index (item slots of this batch) -> rows_apply P, rows_apply Q -> cml_reduce_loss.
+// Per batch, three launches:
+//   cml_instances   one lane group per instance: distances, arg-min negative, WARP weight, contribution rows for
+//                   p_u, q_i and the arg-min negative (whose row id is only known now).  Riding in the same launch,
+//                   on extra blocks: the column means mu of [Q;P] that this step's update needs (per-block column
+//                   sums; the block that finishes last adds them in block order), and the previous step's loss.
+//   rows_index      the item slots of this batch, in chunks (rows_adam.h)
+//   crec_apply_all  P and Q: contributions + covariance gradient, dense ApplyAdam; leaves the rows' loss terms.
 #include "crec_internal.h"
 #include "rows_adam.h"
 
@@ -36,29 +40,125 @@ __device__ inline float sqdist4(float4 a, float4 b)
     return (x * x + y * y) + (z * z + w * w);
 }
 
-// stage 1: block b sums rows [b*rpb, (b+1)*rpb) of one table, column-wise; thread = column
-__global__ void cml_colsum(const float *__restrict__ X, int64_t rows, int d, int64_t rpb, float *__restrict__ partial)
+constexpr int CS_ROWS = 128; // table rows per column-sum block
+
+struct CmlAux {
+    // column means: blocks [n_inst, n_inst + n_cs) of the launch; the first nbQ of them walk Q, the others P
+    const float *P, *Q;
+    int64_t U, I;
+    int n_inst, n_cs, nbQ;
+    float *partial;    // [n_cs][d]
+    unsigned *counter; // zero between launches
+    float *mu;         // [d]
+    float n_rows;      // U + I
+    // loss of the previous step on one more block (out == nullptr: none): its instance terms and the row terms its
+    // update launch left;  loss = sum_b loss_inst + (reg / n) * (sum_r rowP + sum_r rowQ)
+    const float *prev_inst;
+    int prev_n;
+    const float *rowP, *rowQ;
+    float reg_over_n;
+    float *out;
+};
+
+// thread t adds elements t, t + 256, ... in that order, 8 loads in flight at a time
+__device__ __forceinline__ double strided_sum(const float *__restrict__ x, int64_t n, double acc)
 {
-    const int c = threadIdx.x;
-    if (c >= d)
-        return;
-    const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = (r0 + rpb) < rows ? (r0 + rpb) : rows;
-    float s = 0.f;
-    for (int64_t r = r0; r < r1; ++r)
-        s = s + X[r * d + c];
-    partial[(int64_t)blockIdx.x * d + c] = s;
+    int64_t k = threadIdx.x;
+    for (; k + 7 * 256 < n; k += 8 * 256) {
+        float t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            t[j] = x[k + j * 256];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            acc += (double)t[j];
+    }
+    for (; k < n; k += 256)
+        acc += (double)x[k];
+    return acc;
 }
 
-// stage 2: mu[c] = (sum of all partials of both tables) / n
-__global__ void cml_colmean(const float *__restrict__ partial, int n_partials, int d, float n, float *__restrict__ mu)
+__device__ __forceinline__ void cml_loss_block(const CmlAux &a)
 {
-    const int c = threadIdx.x;
-    if (c >= d)
+    __shared__ double part[256];
+    const double s = strided_sum(a.prev_inst, a.prev_n, 0.0);
+    const double c = strided_sum(a.rowQ, a.I, strided_sum(a.rowP, a.U, 0.0));
+    part[threadIdx.x] = s + (double)a.reg_over_n * c;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off)
+            part[threadIdx.x] += part[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        *a.out = (float)part[0];
+}
+
+// column sums of CS_ROWS rows: LPR lanes (float4 each) along a row, 256 / LPR rows side by side; each lane adds its
+// rows top to bottom, the side-by-side sums are added left to right; the block that finishes last turns the
+// per-block sums into means, in block order
+template <int LPR> __device__ __forceinline__ void cml_colsum_block(const CmlAux &a, int d, int blk)
+{
+    constexpr int RL = 256 / LPR;
+    __shared__ float4 red[256];
+    __shared__ int is_last;
+    const int l = threadIdx.x % LPR, rl = threadIdx.x / LPR;
+    const bool inQ = blk < a.nbQ, act = 4 * l < d;
+    const float *X = inQ ? a.Q : a.P;
+    const int64_t rows = inQ ? a.I : a.U, r0 = (int64_t)(inQ ? blk : blk - a.nbQ) * CS_ROWS;
+    const int64_t r1 = (r0 + CS_ROWS) < rows ? (r0 + CS_ROWS) : rows;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (act) {
+        int64_t r = r0 + rl;
+        for (; r + 7 * RL < r1; r += 8 * RL) {
+            float4 t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                t[j] = ld4(X + (r + j * RL) * d + 4 * l);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                s = make_float4(s.x + t[j].x, s.y + t[j].y, s.z + t[j].z, s.w + t[j].w);
+        }
+        for (; r < r1; r += RL) {
+            const float4 t = ld4(X + r * d + 4 * l);
+            s = make_float4(s.x + t.x, s.y + t.y, s.z + t.z, s.w + t.w);
+        }
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (rl == 0 && act) {
+        for (int k = 1; k < RL; ++k) {
+            const float4 t = red[k * LPR + l];
+            s = make_float4(s.x + t.x, s.y + t.y, s.z + t.z, s.w + t.w);
+        }
+        st4(a.partial + (int64_t)blk * d + 4 * l, s);
+    }
+    __threadfence(); // this block's sums are visible device-wide before its ticket is
+    __syncthreads();
+    if (threadIdx.x == 0)
+        is_last = atomicAdd(a.counter, 1u) == (unsigned)(a.n_cs - 1);
+    __syncthreads();
+    if (!is_last)
         return;
-    float s = 0.f;
-    for (int p = 0; p < n_partials; ++p)
-        s = s + partial[(int64_t)p * d + c];
-    mu[c] = s / n;
+    __threadfence();
+    for (int c = threadIdx.x; c < d; c += 256) {
+        float g = 0.f;
+        int p = 0;
+        for (; p + 8 <= a.n_cs; p += 8) {
+            float t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                t[j] = a.partial[(int64_t)(p + j) * d + c];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                g = g + t[j];
+        }
+        for (; p < a.n_cs; ++p)
+            g = g + a.partial[(int64_t)p * d + c];
+        a.mu[c] = g / a.n_rows;
+    }
+    if (threadIdx.x == 0)
+        *a.counter = 0u;
 }
 
 template <int LPR>
@@ -67,9 +167,16 @@ __global__ __launch_bounds__(256) void cml_instances(const float *__restrict__ P
                                                      const int32_t *__restrict__ neg, int n, int K, float margin,
                                                      float rank_scale /* item_nums / neg_ratio */, float *__restrict__ c_p,
                                                      float *__restrict__ c_q, int32_t *__restrict__ item_slots,
-                                                     float *__restrict__ loss_inst)
+                                                     float *__restrict__ loss_inst, CmlAux aux)
 {
     constexpr int G = 64 / LPR;
+    if ((int)blockIdx.x >= aux.n_inst) { // the riders: column means for this step's update, loss of the previous step
+        if ((int)blockIdx.x < aux.n_inst + aux.n_cs)
+            cml_colsum_block<LPR>(aux, d, (int)blockIdx.x - aux.n_inst);
+        else
+            cml_loss_block(aux);
+        return;
+    }
     const int lane = threadIdx.x & 63, g = lane / LPR, l = lane % LPR;
     const int64_t inst = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * G + g;
     const bool ok = inst < n, act = 4 * l < d;
@@ -112,30 +219,7 @@ __global__ __launch_bounds__(256) void cml_instances(const float *__restrict__ P
     }
 }
 
-// loss_b = sum_b loss_inst + (reg / n) * (sum_r rowP + sum_r rowQ), float64, fixed order
-__global__ __launch_bounds__(256) void cml_reduce_loss(const float *__restrict__ loss_inst, int nb,
-                                                       const float *__restrict__ rowP, int64_t U,
-                                                       const float *__restrict__ rowQ, int64_t I, float reg_over_n,
-                                                       float *__restrict__ out)
-{
-    __shared__ double part[256];
-    double s = 0.0, c = 0.0;
-    for (int k = threadIdx.x; k < nb; k += 256)
-        s += (double)loss_inst[k];
-    for (int64_t k = threadIdx.x; k < U; k += 256)
-        c += (double)rowP[k];
-    for (int64_t k = threadIdx.x; k < I; k += 256)
-        c += (double)rowQ[k];
-    part[threadIdx.x] = s + (double)reg_over_n * c;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off)
-            part[threadIdx.x] += part[threadIdx.x + off];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0)
-        *out = (float)part[0];
-}
+__global__ __launch_bounds__(256) void cml_reduce_loss(CmlAux a) { cml_loss_block(a); }
 
 // rs-evaluation tables (CML.py:76,84; RankingRecommender.py:222-223): |clip_1(p) - q|^2 ascending ==
 // (-2 clip_1(p)) . q + |q|^2 ascending, i.e. a dot product of vectors widened by one slot (padded to 4):
@@ -192,14 +276,15 @@ int crec_cml_train_epoch(crec_ctx *ctx, const crec_cml *m, crec_adam *opt, const
         lpr <<= 1;
     const int G = 64 / lpr;
     auto up = [](size_t x) { return (x + 255) / 256 * 256; };
-    const int64_t rpb = 256; // rows per column-sum block
-    const int nbP = (int)crec_ceil_div(U, rpb), nbQ = (int)crec_ceil_div(I, rpb);
-    const size_t ixu = crec_rows_index_bytes(nb, B, U), ixq = crec_rows_index_bytes(1, 2 * B, I);
+    const int nbP = (int)crec_ceil_div(U, CS_ROWS), nbQ = (int)crec_ceil_div(I, CS_ROWS);
+    const int q_chunks = (int)crec_ceil_div(2 * (int64_t)B, 2048); // item slots: sorted 2048 at a time
+    const size_t ixu = crec_rows_index_bytes(nb, B, U), ixq = crec_rows_index_bytes(1, 2 * B, I, q_chunks);
     const size_t cpb = sizeof(float) * (size_t)B * d, cqb = sizeof(float) * (size_t)2 * B * d;
     const size_t sl = sizeof(int32_t) * (size_t)2 * B, li = sizeof(float) * (size_t)B;
-    const size_t pp = sizeof(float) * (size_t)(nbP + nbQ) * d, mub = sizeof(float) * 256;
+    const size_t pp = sizeof(float) * (size_t)(nbP + nbQ) * d, mub = sizeof(float) * 256 + 256;
     const size_t rP = sizeof(float) * (size_t)U, rQ = sizeof(float) * (size_t)I;
-    if (int rc = crec_reserve(ctx, &ctx->idx_ws, up(ixu) + up(ixq) + up(cpb) + up(cqb) + up(sl) + up(li) + up(pp) + up(mub) + up(rP) + up(rQ)))
+    if (int rc = crec_reserve(ctx, &ctx->idx_ws,
+                              up(ixu) + up(ixq) + up(cpb) + up(cqb) + up(sl) + 2 * up(li) + up(pp) + up(mub) + up(rP) + up(rQ)))
         return rc;
     char *ws = (char *)ctx->idx_ws.ptr;
     crec_rows_index_view vu, vq;
@@ -214,17 +299,24 @@ int crec_cml_train_epoch(crec_ctx *ctx, const crec_cml *m, crec_adam *opt, const
     p += up(cqb);
     int32_t *slots = (int32_t *)p;
     p += up(sl);
-    float *loss_inst = (float *)p;
-    p += up(li);
+    float *loss_inst = (float *)p; // double-buffered: the next step's launch reduces this step's terms
+    p += 2 * up(li);
     float *partial = (float *)p;
     p += up(pp);
     float *mu = (float *)p;
+    unsigned *counter = (unsigned *)(p + sizeof(float) * 256);
     p += up(mub);
     float *rowP = (float *)p;
     p += up(rP);
     float *rowQ = (float *)p;
     const float n_rows = (float)(U + I);
+    CREC_HIP(ctx, hipMemsetAsync(counter, 0, sizeof(unsigned), st));
 
+    CmlAux aux{};
+    aux.P = m->P.var, aux.Q = m->Q.var, aux.U = U, aux.I = I;
+    aux.n_cs = nbP + nbQ, aux.nbQ = nbQ;
+    aux.partial = partial, aux.counter = counter, aux.mu = mu, aux.n_rows = n_rows;
+    aux.rowP = rowP, aux.rowQ = rowQ, aux.reg_over_n = m->reg / n_rows;
     for (int64_t b = 0; b < nb; ++b) {
         const int64_t t0 = b * B;
         const int nbt = (int)((N - t0) < B ? (N - t0) : B);
@@ -235,17 +327,16 @@ int crec_cml_train_epoch(crec_ctx *ctx, const crec_cml *m, crec_adam *opt, const
         o.beta1 = opt->beta1;
         o.beta2 = opt->beta2;
         o.eps = opt->eps;
-        hipLaunchKernelGGL(cml_colsum, dim3(nbQ), dim3(256), 0, st, (const float *)m->Q.var, I, d, rpb, partial);
-        hipLaunchKernelGGL(cml_colsum, dim3(nbP), dim3(256), 0, st, (const float *)m->P.var, U, d, rpb, partial + (size_t)nbQ * d);
-        hipLaunchKernelGGL(cml_colmean, dim3(1), dim3(256), 0, st, (const float *)partial, nbP + nbQ, d, n_rows, mu);
         const int waves = (int)crec_ceil_div(nbt, G);
-        const dim3 grid((unsigned)crec_ceil_div(waves, 4));
+        float *li_b = (float *)((char *)loss_inst + (b & 1) * up(li));
+        aux.n_inst = (int)crec_ceil_div(waves, 4);
+        const dim3 grid((unsigned)(aux.n_inst + aux.n_cs + (aux.out ? 1 : 0)));
         crec_prof_begin(ctx, CREC_K_CML_INSTANCES, st);
 #define CREC_CML(L)                                                                                                          \
     case L:                                                                                                                  \
         hipLaunchKernelGGL((cml_instances<L>), grid, dim3(256), 0, st, (const float *)m->P.var, (const float *)m->Q.var, d,  \
                            u + t0, i + t0, neg + t0 * K, nbt, (int)K, m->margin, (float)I / (float)K, c_p, c_q, slots,        \
-                           loss_inst);                                                                                       \
+                           li_b, aux);                                                                                       \
         break;
         switch (lpr) {
             CREC_CML(1)
@@ -258,16 +349,21 @@ int crec_cml_train_epoch(crec_ctx *ctx, const crec_cml *m, crec_adam *opt, const
         }
 #undef CREC_CML
         crec_prof_end(ctx, st);
-        if (int rc = crec_rows_index(ctx, slots, 2 * (int64_t)nbt, 2 * B, I, ixq_ws, &vq, st))
+        if (int rc = crec_rows_index(ctx, slots, 2 * (int64_t)nbt, 2 * B, I, ixq_ws, &vq, st, q_chunks))
             return rc;
-        crec_rows_apply(ctx, crec_rows_table{m->P.var, m->P.m, m->P.v, U, d}, vu, b, c_p, mu, o, st, rowP);
-        crec_rows_apply(ctx, crec_rows_table{m->Q.var, m->Q.m, m->Q.v, I, d}, vq, 0, c_q, mu, o, st, rowQ);
-        hipLaunchKernelGGL(cml_reduce_loss, dim3(1), dim3(256), 0, st, (const float *)loss_inst, nbt, (const float *)rowP, U,
-                           (const float *)rowQ, I, m->reg / n_rows, loss_per_batch + b);
+        crec_apply_set set{};
+        set.tables[set.n_tables++] = crec_rows_job{crec_rows_table{m->P.var, m->P.m, m->P.v, U, d}, vu.chunks,
+                                                   vu.rowseg + b * vu.chunks * vu.rows, vu.order + b * vu.per_batch, c_p, mu, rowP, o};
+        set.tables[set.n_tables++] = crec_rows_job{crec_rows_table{m->Q.var, m->Q.m, m->Q.v, I, d}, vq.chunks, vq.rowseg, vq.order,
+                                                   c_q, mu, rowQ, o};
+        if (int rc = crec_apply_all(ctx, set, st))
+            return rc;
+        aux.prev_inst = li_b, aux.prev_n = nbt, aux.out = loss_per_batch + b;
         opt->beta1_power = opt->beta1_power * opt->beta1;
         opt->beta2_power = opt->beta2_power * opt->beta2;
         opt->step += 1;
     }
+    hipLaunchKernelGGL(cml_reduce_loss, dim3(1), dim3(256), 0, st, aux); // the last step's loss
     CREC_HIP(ctx, hipGetLastError());
     return crec_prof_flush(ctx, st);
 }

@@ -8,15 +8,67 @@
 //   loss  = sum_b (y - y_pre)^2 + reg * 0.5 * (|wi|^2 + |vif|^2) over the FULL tables (FM.py:52)
 // so wi and vif receive dense gradients and take TF1's dense ApplyAdam on every row each step.
 //
-// Per batch: fm_instances (one lane group per instance: gathers, y_pre, residual, contribution rows for
-// vif and scalars for wi, per-wave partial of dL/dw0) -> rows_apply (vif, ROWS_DENSE + reg*table) ->
-// fm_linear_apply (wi, thread per row) -> small_adam_dense (w0).  Deterministic, no atomics.
+// Per batch, two launches: fm_instances (one lane group per instance: gathers, y_pre, residual, contribution rows
+// for vif and scalars for wi, per-wave partial of dL/dw0; one extra block reduces the previous step's loss) ->
+// crec_apply_all (rows_adam.hip: vif rows ROWS_DENSE + reg*table, wi as a one-column table, w0).
+// Deterministic, no atomics.
 #include "crec_internal.h"
 #include "rows_adam.h"
 
 namespace {
 
 constexpr int FM_MAX_F = 8; // features per row held in registers
+
+// loss_b = sum_b (y - y_pre)^2 + reg * 0.5 * (sum rownorm_w + sum rownorm_v), float64, fixed order
+struct FmLossJob { // the loss of one finished step: its squared errors and the row norms its update launch left
+    const float *sq_err;
+    int nb;
+    const float *nw, *nv;
+    int64_t rows;
+    float reg;
+    float *out; // nullptr: nothing to reduce
+};
+
+__device__ __forceinline__ void fm_reduce_loss_block(const float *__restrict__ sq_err, int nb, const float *__restrict__ nw,
+                                                     const float *__restrict__ nv, int64_t rows, float reg,
+                                                     float *__restrict__ out)
+{
+    __shared__ double part[256];
+    double s = 0.0, l2 = 0.0;
+    // thread t adds elements t, t + 256, ... in that order; 8 loads in flight at a time
+    const auto strided_sum = [](const float *__restrict__ x, int64_t n, double acc) {
+        int64_t k = threadIdx.x;
+        for (; k + 7 * 256 < n; k += 8 * 256) {
+            float t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                t[j] = x[k + j * 256];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                acc += (double)t[j];
+        }
+        for (; k < n; k += 256)
+            acc += (double)x[k];
+        return acc;
+    };
+    s = strided_sum(sq_err, nb, s);
+    l2 = strided_sum(nw, rows, l2);
+    l2 = strided_sum(nv, rows, l2);
+    part[threadIdx.x] = s + (double)reg * 0.5 * l2;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off)
+            part[threadIdx.x] += part[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        *out = (float)part[0];
+}
+
+__global__ __launch_bounds__(256) void fm_reduce_loss(FmLossJob j)
+{
+    fm_reduce_loss_block(j.sq_err, j.nb, j.nw, j.nv, j.rows, j.reg, j.out);
+}
 
 // group = LPR lanes (float4 per lane) per instance; G = 64/LPR instances per wave
 template <int LPR, bool TRAIN>
@@ -25,9 +77,13 @@ __global__ __launch_bounds__(256) void fm_instances(const float *__restrict__ w0
                                                     const float *__restrict__ x_val, const float *__restrict__ y, int n,
                                                     int F, float *__restrict__ y_pre, float *__restrict__ c_v,
                                                     float *__restrict__ c_w, float *__restrict__ sq_err,
-                                                    float *__restrict__ w0_partial)
+                                                    float *__restrict__ w0_partial, FmLossJob prev)
 {
     constexpr int G = 64 / LPR;
+    if (TRAIN && prev.out && blockIdx.x == gridDim.x - 1) { // the extra last block reduces the previous step's loss
+        fm_reduce_loss_block(prev.sq_err, prev.nb, prev.nw, prev.nv, prev.rows, prev.reg, prev.out);
+        return;
+    }
     const int lane = threadIdx.x & 63, g = lane / LPR, l = lane % LPR;
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t inst = wave * G + g;
@@ -100,64 +156,6 @@ __global__ __launch_bounds__(256) void fm_instances(const float *__restrict__ w0
         w0_partial[wave] = s;
 }
 
-// wi: a [rows] vector "table" (one float per row): sum of slot scalars per row + dense ApplyAdam with reg*wi
-__global__ void fm_linear_apply(float *__restrict__ var, float *__restrict__ m, float *__restrict__ v, int64_t rows,
-                                const int2 *__restrict__ rowseg, const int32_t *__restrict__ order,
-                                const float *__restrict__ c_w, float *__restrict__ rownorm, crec_rows_opt o)
-{
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= rows)
-        return;
-    const int2 rs = rowseg[r];
-    float g = 0.f;
-    for (int k = rs.x; k < rs.x + rs.y; ++k)
-        g = g + c_w[order[k]];
-    const float w = var[r];
-    rownorm[r] = w * w;
-    g = g + o.dense_reg * w;
-    const float omb1 = 1.0f - o.beta1, omb2 = 1.0f - o.beta2;
-    float mm = m[r], vv = v[r];
-    mm = mm + (g - mm) * omb1;
-    vv = vv + (g * g - vv) * omb2;
-    m[r] = mm;
-    v[r] = vv;
-    var[r] = w - (mm * o.lr_t) / (sqrtf(vv) + o.eps);
-}
-
-// |row|^2 of every vif row (before the update), one wave per 64 floats chunk ... simple thread-per-row
-__global__ void fm_row_sqnorm(const float *__restrict__ var, int64_t rows, int d, float *__restrict__ out)
-{
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= rows)
-        return;
-    float s = 0.f;
-    for (int c = 0; c < d; ++c)
-        s = s + var[r * d + c] * var[r * d + c];
-    out[r] = s;
-}
-
-// loss_b = sum_b (y - y_pre)^2 + reg * 0.5 * (sum rownorm_w + sum rownorm_v), float64, fixed order
-__global__ __launch_bounds__(256) void fm_reduce_loss(const float *__restrict__ sq_err, int nb, const float *__restrict__ nw,
-                                                      const float *__restrict__ nv, int64_t rows, float reg,
-                                                      float *__restrict__ out)
-{
-    __shared__ double part[256];
-    double s = 0.0, l2 = 0.0;
-    for (int k = threadIdx.x; k < nb; k += 256)
-        s += (double)sq_err[k];
-    for (int64_t k = threadIdx.x; k < rows; k += 256)
-        l2 += (double)nw[k] + (double)nv[k];
-    part[threadIdx.x] = s + (double)reg * 0.5 * l2;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off)
-            part[threadIdx.x] += part[threadIdx.x + off];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0)
-        *out = (float)part[0];
-}
-
 // utils/metrics.py:22-29 in float64: out = {sqrt(mean (y - y_pre)^2), mean |y - y_pre|}
 __global__ __launch_bounds__(1024) void rmse_mae_kernel(const float *__restrict__ y, const float *__restrict__ yp, int64_t n,
                                                         double *__restrict__ out)
@@ -188,12 +186,12 @@ __global__ __launch_bounds__(1024) void rmse_mae_kernel(const float *__restrict_
 template <bool TRAIN>
 void launch_instances(int lpr, dim3 grid, hipStream_t st, const float *w0, const float *wi, const float *vif, int d,
                       const int32_t *x_idx, const float *x_val, const float *y, int n, int F, float *y_pre, float *c_v,
-                      float *c_w, float *sq_err, float *w0_partial)
+                      float *c_w, float *sq_err, float *w0_partial, FmLossJob prev = FmLossJob{})
 {
 #define CREC_FM(L)                                                                                                      \
     case L:                                                                                                             \
         hipLaunchKernelGGL((fm_instances<L, TRAIN>), grid, dim3(256), 0, st, w0, wi, vif, d, x_idx, x_val, y, n, F, y_pre, \
-                           c_v, c_w, sq_err, w0_partial);                                                               \
+                           c_v, c_w, sq_err, w0_partial, prev);                                                         \
         break;
     switch (lpr) {
         CREC_FM(1)
@@ -272,7 +270,7 @@ int crec_fm_train_epoch(crec_ctx *ctx, const crec_fm *m, crec_adam *opt, const i
     const size_t cvb = sizeof(float) * (size_t)B * F * d, cwb = sizeof(float) * (size_t)B * F, seb = sizeof(float) * (size_t)B;
     const int max_waves = (int)crec_ceil_div(B, G);
     const size_t w0b = sizeof(float) * (size_t)max_waves, nrb = sizeof(float) * (size_t)rows;
-    if (int rc = crec_reserve(ctx, &ctx->idx_ws, up(ixb) + up(cvb) + up(cwb) + up(seb) + up(w0b) + 2 * up(nrb)))
+    if (int rc = crec_reserve(ctx, &ctx->idx_ws, up(ixb) + up(cvb) + up(cwb) + 2 * up(seb) + up(w0b) + 2 * up(nrb)))
         return rc;
     char *ws = (char *)ctx->idx_ws.ptr;
     crec_rows_index_view vx;
@@ -281,10 +279,14 @@ int crec_fm_train_epoch(crec_ctx *ctx, const crec_fm *m, crec_adam *opt, const i
     float *c_v = (float *)(ws + up(ixb));
     float *c_w = (float *)((char *)c_v + up(cvb));
     float *sq_err = (float *)((char *)c_w + up(cwb));
-    float *w0_partial = (float *)((char *)sq_err + up(seb));
+    float *w0_partial = (float *)((char *)sq_err + 2 * up(seb)); // sq_err is double-buffered (see below)
     float *nw = (float *)((char *)w0_partial + up(w0b));
     float *nv = (float *)((char *)nw + up(nrb));
 
+    // Two launches per step: fm_instances (+ one extra block that reduces the PREVIOUS step's loss: its squared
+    // errors sit in the other half of the sq_err double buffer, and nw / nv still hold the row norms its update
+    // launch wrote) and crec_apply_all (vif rows, wi as a one-column table, w0).
+    FmLossJob prev{};
     for (int64_t b = 0; b < nb; ++b) {
         const int64_t t0 = b * B;
         const int nbt = (int)((N - t0) < B ? (N - t0) : B);
@@ -297,24 +299,29 @@ int crec_fm_train_epoch(crec_ctx *ctx, const crec_fm *m, crec_adam *opt, const i
         o.beta2 = opt->beta2;
         o.eps = opt->eps;
         const int waves = (int)crec_ceil_div(nbt, G);
+        float *se = (float *)((char *)sq_err + (b & 1) * up(seb));
         crec_prof_begin(ctx, CREC_K_FM_INSTANCES, st);
-        launch_instances<true>(lpr, dim3((unsigned)crec_ceil_div(waves, 4)), st, m->w0.var, m->wi.var, m->vif.var, d,
-                               x_idx + t0 * F, x_val + t0 * F, y + t0, nbt, F, y_pre + t0, c_v, c_w, sq_err, w0_partial);
+        launch_instances<true>(lpr, dim3((unsigned)crec_ceil_div(waves, 4) + (prev.out ? 1u : 0u)), st, m->w0.var, m->wi.var,
+                               m->vif.var, d, x_idx + t0 * F, x_val + t0 * F, y + t0, nbt, F, y_pre + t0, c_v, c_w, se,
+                               w0_partial, prev);
         crec_prof_end(ctx, st);
-        hipLaunchKernelGGL(fm_row_sqnorm, dim3((unsigned)crec_ceil_div(rows, 256)), dim3(256), 0, st, (const float *)m->vif.var,
-                           rows, d, nv);
-        crec_rows_apply(ctx, crec_rows_table{m->vif.var, m->vif.m, m->vif.v, rows, d}, vx, b, c_v, nullptr, o, st);
-        hipLaunchKernelGGL(fm_linear_apply, dim3((unsigned)crec_ceil_div(rows, 256)), dim3(256), 0, st, m->wi.var, m->wi.m,
-                           m->wi.v, rows, (const int2 *)(vx.rowseg + b * vx.rows), (const int32_t *)(vx.order + b * vx.per_batch),
-                           (const float *)c_w, nw, o);
+        crec_apply_set set{};
+        crec_rows_opt ov = o;
+        ov.row_norm = 1;
+        set.tables[set.n_tables++] = crec_rows_job{crec_rows_table{m->vif.var, m->vif.m, m->vif.v, rows, d}, vx.chunks, vx.rowseg + b * vx.rows,
+                                                   vx.order + b * vx.per_batch, c_v, nullptr, nv, ov};
+        set.scalar = crec_scalar_job{m->wi.var, m->wi.m, m->wi.v, rows, vx.rowseg + b * vx.rows, vx.order + b * vx.per_batch,
+                                     c_w, nw, o};
         // waves beyond this batch's count were not written: pass the exact count
-        crec_small_adam_dense(ctx, m->w0.var, m->w0.m, m->w0.v, w0_partial, waves, 1, 1, o, st);
-        hipLaunchKernelGGL(fm_reduce_loss, dim3(1), dim3(256), 0, st, (const float *)sq_err, nbt, (const float *)nw,
-                           (const float *)nv, rows, m->reg, loss_per_batch + b);
+        set.small = crec_small_job{m->w0.var, m->w0.m, m->w0.v, w0_partial, waves, 1, 1, o};
+        if (int rc = crec_apply_all(ctx, set, st))
+            return rc;
+        prev = FmLossJob{se, nbt, nw, nv, rows, m->reg, loss_per_batch + b};
         opt->beta1_power = opt->beta1_power * opt->beta1;
         opt->beta2_power = opt->beta2_power * opt->beta2;
         opt->step += 1;
     }
+    hipLaunchKernelGGL(fm_reduce_loss, dim3(1), dim3(256), 0, st, prev); // the last step's loss
     CREC_HIP(ctx, hipGetLastError());
     return crec_prof_flush(ctx, st);
 }

@@ -528,7 +528,7 @@ extern "C" int crec_ncf_train_epoch(crec_ctx *ctx, const crec_ncf *mdl, crec_ada
         const auto job = [&](const crec_param &t, int64_t rows, int cols, const crec_rows_index_view &v, const float *c, float reg) {
             crec_rows_opt oo = o;
             oo.reg_occ = reg;
-            set.tables[set.n_tables++] = crec_rows_job{crec_rows_table{t.var, t.m, t.v, rows, cols}, v.rowseg + b * v.rows,
+            set.tables[set.n_tables++] = crec_rows_job{crec_rows_table{t.var, t.m, t.v, rows, cols}, v.chunks, v.rowseg + b * v.chunks * v.rows,
                                                        v.order + b * v.per_batch, c, nullptr, nullptr, oo};
         };
         const auto cls = [](int dd) {

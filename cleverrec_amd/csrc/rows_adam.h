@@ -15,20 +15,26 @@ struct crec_rows_opt {
     float reg_occ;    // l2 weight applied once per occurrence of a row (tf.nn.l2_loss on gathered rows)
     float dense_reg;  // ROWS_DENSE: l2 weight on the whole table (FM.py:52)
     float cov_coef;   // ROWS_DENSE, CML: 2*reg/n of the covariance term; dense_grad then holds the column means
+    int row_norm;     // row_out[r] = |row r|^2 of the values before the update (FM's l2 loss term)
     float lr_t, beta1, beta2, eps;
 };
 
+// A batch's slots may be indexed in `chunks` equal runs of slots, each sorted by its own workgroup (a per-step index
+// is then `chunks` short sorts side by side instead of one long one).  A row's slots are visited chunk by chunk, and
+// inside a chunk in slot order -- i.e. still in ascending slot order overall.
 struct crec_rows_index_view {
-    int32_t *order; // [n_batches][per_batch] slot ids sorted by (row, slot)
-    int2 *rowseg;   // [n_batches][rows] {first sorted position, count}
+    int32_t *order; // [n_batches][per_batch] slot ids: per chunk, sorted by (row, slot)
+    int2 *rowseg;   // [n_batches][chunks][rows] {first position in the batch's order array, count}
     int32_t per_batch;
     int64_t rows;
+    int32_t chunks;
 };
 
 // one table's share of a merged parameter-update launch (crec_apply_all)
 struct crec_rows_job {
     crec_rows_table t;
-    const int2 *rowseg;      // this batch's {first sorted position, count} per table row
+    int32_t chunks;          // index chunks of this batch (0 is read as 1)
+    const int2 *rowseg;      // this batch's [chunks][rows] {first sorted position, count}
     const int32_t *order;    // this batch's sorted slot ids
     const float *contrib;    // [slots][d] contribution rows
     const float *dense_grad; // optional (see rows_adam.hip)
@@ -45,17 +51,29 @@ struct crec_small_job { // dense ApplyAdam of a small vector from partial sums
     crec_rows_opt o;
 };
 
+struct crec_scalar_job { // a [rows] vector treated as a one-column table (FM's wi): slot scalars summed per row,
+    float *var, *m, *v;  // dense ApplyAdam with dense_reg * var; sq_out[r] = var[r]^2 before the update
+    int64_t rows;        // rows == 0: none
+    const int2 *rowseg;
+    const int32_t *order;
+    const float *contrib; // [slots]
+    float *sq_out;
+    crec_rows_opt o;
+};
+
 constexpr int CREC_APPLY_MAX_TABLES = 4;
 struct crec_apply_set {
     crec_rows_job tables[CREC_APPLY_MAX_TABLES];
     int n_tables;
     int block_end[CREC_APPLY_MAX_TABLES]; // filled by crec_apply_all
-    crec_small_job small;                 // small.n == 0: none
+    crec_scalar_job scalar;               // after the tables: 256 rows per block
+    int scalar_end;                       // filled by crec_apply_all
+    crec_small_job small;                 // last; small.n == 0: none
 };
 
-size_t crec_rows_index_bytes(int64_t n_batches, int32_t per_batch, int64_t rows);
+size_t crec_rows_index_bytes(int64_t n_batches, int32_t per_batch, int64_t rows, int32_t chunks = 1);
 int crec_rows_index(crec_ctx *ctx, const int32_t *idx, int64_t n_total, int32_t per_batch, int64_t rows, void *ws,
-                    crec_rows_index_view *out, hipStream_t st);
+                    crec_rows_index_view *out, hipStream_t st, int32_t chunks = 1);
 int crec_rows_apply(crec_ctx *ctx, const crec_rows_table &t, const crec_rows_index_view &ix, int64_t batch,
                     const float *contrib, const float *dense_grad, const crec_rows_opt &o, hipStream_t st,
                     float *row_out = nullptr);

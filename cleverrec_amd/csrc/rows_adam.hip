@@ -31,21 +31,24 @@ __device__ inline int lb_key(const unsigned long long *keys, int n, unsigned lon
     return lo;
 }
 
-// one workgroup per batch: sort (row, slot) keys in LDS; order[k] = slot of the k-th sorted key;
-// rowseg[r] = {first k of row r, number of slots on row r} for every table row
+// one workgroup per (batch, chunk): sort the chunk's (row, slot) keys in LDS; order[k] = slot of the k-th sorted key
+// (slot ids and positions are relative to the batch); rowseg[r] = {first position of row r, number of slots on row r}
+// for every table row
 __global__ __launch_bounds__(IDX_THREADS) void rows_index_batches(const int32_t *__restrict__ idx, int64_t n_total,
-                                                                  int32_t per_batch, int64_t rows,
+                                                                  int32_t per_batch, int32_t chunks, int64_t rows,
                                                                   int32_t *__restrict__ order, int2 *__restrict__ rowseg)
 {
     extern __shared__ unsigned long long keys[];
-    const int batch = blockIdx.x, tid = threadIdx.x;
+    const int batch = blockIdx.x / chunks, chunk = blockIdx.x % chunks, tid = threadIdx.x;
     const int64_t t0 = (int64_t)batch * per_batch;
-    const int n = (int)((n_total - t0) < per_batch ? (n_total - t0) : per_batch);
+    const int nbatch = (int)((n_total - t0) < per_batch ? (n_total - t0) : per_batch);
+    const int clen = (per_batch + chunks - 1) / chunks, c0 = chunk * clen < nbatch ? chunk * clen : nbatch;
+    const int n = (nbatch - c0) < clen ? (nbatch - c0) : clen;
     int n_pad = 64;
     while (n_pad < n)
         n_pad <<= 1;
     for (int k = tid; k < n_pad; k += IDX_THREADS)
-        keys[k] = k < n ? (((unsigned long long)(uint32_t)idx[t0 + k] << 32) | (uint32_t)k) : ~0ull;
+        keys[k] = k < n ? (((unsigned long long)(uint32_t)idx[t0 + c0 + k] << 32) | (uint32_t)(c0 + k)) : ~0ull;
     __syncthreads();
     for (int k = 2; k <= n_pad; k <<= 1) {
         for (int jj = k >> 1; jj > 0; jj >>= 1) {
@@ -61,12 +64,12 @@ __global__ __launch_bounds__(IDX_THREADS) void rows_index_batches(const int32_t 
         }
     }
     for (int k = tid; k < n; k += IDX_THREADS)
-        order[t0 + k] = (int32_t)(uint32_t)keys[k];
-    int2 *rs = rowseg + (int64_t)batch * rows;
+        order[t0 + c0 + k] = (int32_t)(uint32_t)keys[k];
+    int2 *rs = rowseg + ((int64_t)batch * chunks + chunk) * rows;
     for (int64_t r = tid; r < rows; r += IDX_THREADS) {
         const int a = lb_key(keys, n, (unsigned long long)r << 32);
         const int b = lb_key(keys, n, (unsigned long long)(r + 1) << 32);
-        rs[r] = make_int2(a, b - a);
+        rs[r] = make_int2(c0 + a, b - a);
     }
 }
 
@@ -79,7 +82,7 @@ template <int LPR>
 __device__ __forceinline__ void rows_apply_row(const crec_rows_table &t, const int2 *__restrict__ rowseg,
                                                const int32_t *__restrict__ order, const float *__restrict__ contrib,
                                                const float *__restrict__ dense_grad, float *__restrict__ row_out,
-                                               const crec_rows_opt &o, int64_t r)
+                                               const crec_rows_opt &o, int64_t r, int chunks = 1)
 {
     constexpr int G = 64 / LPR;
     const int lane = threadIdx.x & 63, g = lane / LPR, l = lane % LPR;
@@ -87,22 +90,29 @@ __device__ __forceinline__ void rows_apply_row(const crec_rows_table &t, const i
         return;
     const int d = t.d;
     const bool act = 4 * l < d;
-    const int2 rs = rowseg[r];
-    if (rs.y == 0 && o.kind == ROWS_SPARSE_LAZY)
-        return;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     const int64_t ro = r * d + 4 * l;
+    const int2 rs0 = rowseg[r];
+    if (chunks == 1 && rs0.y == 0 && o.kind == ROWS_SPARSE_LAZY)
+        return;
     const float4 var = act ? ld4(t.var + ro) : zero;
     float4 acc = zero;
-    for (int k = rs.x + g; k < rs.x + rs.y; k += G) {
-        if (act) {
-            const float4 c = ld4(contrib + (int64_t)order[k] * d + 4 * l);
-            acc.x = acc.x + (c.x + o.reg_occ * var.x);
-            acc.y = acc.y + (c.y + o.reg_occ * var.y);
-            acc.z = acc.z + (c.z + o.reg_occ * var.z);
-            acc.w = acc.w + (c.w + o.reg_occ * var.w);
+    int touched = 0;
+    for (int ch = 0; ch < chunks; ++ch) { // chunk by chunk = ascending slot order
+        const int2 rs = ch == 0 ? rs0 : rowseg[(int64_t)ch * t.rows + r];
+        touched += rs.y;
+        for (int k = rs.x + g; k < rs.x + rs.y; k += G) {
+            if (act) {
+                const float4 c = ld4(contrib + (int64_t)order[k] * d + 4 * l);
+                acc.x = acc.x + (c.x + o.reg_occ * var.x);
+                acc.y = acc.y + (c.y + o.reg_occ * var.y);
+                acc.z = acc.z + (c.z + o.reg_occ * var.z);
+                acc.w = acc.w + (c.w + o.reg_occ * var.w);
+            }
         }
     }
+    if (touched == 0 && o.kind == ROWS_SPARSE_LAZY)
+        return;
 #pragma unroll
     for (int off = LPR; off < 64; off <<= 1) { // groups hold disjoint slots: add them, lower group first
         const float x = __shfl_down(acc.x, off, 64), y = __shfl_down(acc.y, off, 64);
@@ -134,6 +144,14 @@ __device__ __forceinline__ void rows_apply_row(const crec_rows_table &t, const i
     } else if (dense_grad && act && g == 0) {
         dg = ld4(dense_grad + ro);
     }
+    if (o.row_norm) {
+        float sq = (var.x * var.x + var.y * var.y) + (var.z * var.z + var.w * var.w);
+#pragma unroll
+        for (int off = LPR >> 1; off > 0; off >>= 1)
+            sq += __shfl_xor(sq, off, 64);
+        if (row_out && lane == 0)
+            row_out[r] = sq;
+    }
     if (g != 0 || !act)
         return;
     float4 m = ld4(t.m + ro), v = ld4(t.v + ro), nv = var;
@@ -163,10 +181,10 @@ template <int LPR>
 __global__ __launch_bounds__(256) void rows_apply(crec_rows_table t, const int2 *__restrict__ rowseg,
                                                   const int32_t *__restrict__ order, const float *__restrict__ contrib,
                                                   const float *__restrict__ dense_grad, float *__restrict__ row_out,
-                                                  crec_rows_opt o)
+                                                  crec_rows_opt o, int chunks)
 {
     rows_apply_row<LPR>(t, rowseg, order, contrib, dense_grad, row_out, o,
-                        (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+                        (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), chunks);
 }
 
 // dense ApplyAdam of a small parameter vector (h, W_k, b_k, w0) from partial sums:
@@ -218,8 +236,32 @@ __global__ __launch_bounds__(64 * SAD_SL) void small_adam_dense(crec_small_job j
     small_adam_block<64>(j, blockIdx.x, red);
 }
 
+// a one-column table: thread per row
+__device__ __forceinline__ void scalar_rows_block(const crec_scalar_job &j, int blk)
+{
+    const int64_t r = (int64_t)blk * 256 + threadIdx.x;
+    if (r >= j.rows)
+        return;
+    const int2 rs = j.rowseg[r];
+    float g = 0.f;
+    for (int k = rs.x; k < rs.x + rs.y; ++k)
+        g = g + j.contrib[j.order[k]];
+    const float w = j.var[r];
+    if (j.sq_out)
+        j.sq_out[r] = w * w;
+    g = g + j.o.dense_reg * w;
+    const float omb1 = 1.0f - j.o.beta1, omb2 = 1.0f - j.o.beta2;
+    float mm = j.m[r], vv = j.v[r];
+    mm = mm + (g - mm) * omb1;
+    vv = vv + (g * g - vv) * omb2;
+    j.m[r] = mm;
+    j.v[r] = vv;
+    j.var[r] = w - (mm * j.o.lr_t) / (sqrtf(vv) + j.o.eps);
+}
+
 // every parameter update of a step in ONE launch: up to CREC_APPLY_MAX_TABLES embedding tables (blocks
-// [block_end[k-1], block_end[k]) sweep table k, four rows per block) and, after them, the small dense vector
+// [block_end[k-1], block_end[k]) sweep table k, four rows per block), then an optional one-column table (256 rows
+// per block) and, last, the small dense vector
 // (16 elements per block; same slices, hence the same sums, as small_adam_dense)
 template <int LPR> __global__ __launch_bounds__(256) void apply_all(crec_apply_set a)
 {
@@ -231,36 +273,41 @@ template <int LPR> __global__ __launch_bounds__(256) void apply_all(crec_apply_s
     if (k < a.n_tables) {
         const crec_rows_job &j = a.tables[k];
         rows_apply_row<LPR>(j.t, j.rowseg, j.order, j.contrib, j.dense_grad, j.row_out, j.o,
-                            (int64_t)(bi - first) * 4 + (threadIdx.x >> 6));
+                            (int64_t)(bi - first) * 4 + (threadIdx.x >> 6), j.chunks > 1 ? j.chunks : 1);
+    } else if (bi < a.scalar_end) {
+        scalar_rows_block(a.scalar, bi - first);
     } else {
-        small_adam_block<16>(a.small, bi - first, red);
+        small_adam_block<16>(a.small, bi - a.scalar_end, red);
     }
 }
 
 } // namespace
 
-size_t crec_rows_index_bytes(int64_t n_batches, int32_t per_batch, int64_t rows)
+size_t crec_rows_index_bytes(int64_t n_batches, int32_t per_batch, int64_t rows, int32_t chunks)
 {
-    return sizeof(int32_t) * (size_t)n_batches * per_batch + sizeof(int2) * (size_t)n_batches * rows + 512;
+    return sizeof(int32_t) * (size_t)n_batches * per_batch + sizeof(int2) * (size_t)n_batches * chunks * rows + 512;
 }
 
 int crec_rows_index(crec_ctx *ctx, const int32_t *idx, int64_t n_total, int32_t per_batch, int64_t rows, void *ws,
-                    crec_rows_index_view *out, hipStream_t st)
+                    crec_rows_index_view *out, hipStream_t st, int32_t chunks)
 {
-    CREC_REQUIRE(ctx, per_batch >= 1 && per_batch <= 16384, "rows index: at most 16384 slots per batch, got %d", per_batch);
+    CREC_REQUIRE(ctx, chunks >= 1 && chunks <= 64, "rows index: 1..64 chunks");
+    const int clen = (per_batch + chunks - 1) / chunks;
+    CREC_REQUIRE(ctx, per_batch >= 1 && clen <= 16384, "rows index: at most 16384 slots per chunk, got %d", clen);
     const int64_t nb = crec_ceil_div(n_total, per_batch);
     out->order = (int32_t *)ws;
     out->rowseg = (int2 *)((char *)ws + ((sizeof(int32_t) * (size_t)nb * per_batch + 255) / 256) * 256);
     out->per_batch = per_batch;
     out->rows = rows;
+    out->chunks = chunks;
     int n_pad = 64;
-    while (n_pad < per_batch)
+    while (n_pad < clen)
         n_pad <<= 1;
     const size_t lds = sizeof(unsigned long long) * n_pad;
     CREC_HIP(ctx, hipFuncSetAttribute((const void *)rows_index_batches, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     crec_prof_begin(ctx, CREC_K_ROWS_INDEX, st);
-    hipLaunchKernelGGL(rows_index_batches, dim3((unsigned)nb), dim3(IDX_THREADS), lds, st, idx, n_total, per_batch, rows,
-                       out->order, out->rowseg);
+    hipLaunchKernelGGL(rows_index_batches, dim3((unsigned)(nb * chunks)), dim3(IDX_THREADS), lds, st, idx, n_total, per_batch,
+                       chunks, rows, out->order, out->rowseg);
     crec_prof_end(ctx, st);
     return CREC_OK;
 }
@@ -271,13 +318,13 @@ int crec_rows_apply(crec_ctx *ctx, const crec_rows_table &t, const crec_rows_ind
     int lpr = 1;
     while (lpr * 4 < t.d)
         lpr <<= 1;
-    const int2 *rs = ix.rowseg + batch * ix.rows;
+    const int2 *rs = ix.rowseg + batch * ix.chunks * ix.rows;
     const int32_t *ord = ix.order + batch * ix.per_batch;
     const dim3 grid((unsigned)crec_ceil_div(t.rows, 4)), block(256);
     crec_prof_begin(ctx, CREC_K_ROWS_APPLY, st);
 #define CREC_RA(L)                                                                                   \
     case L:                                                                                          \
-        hipLaunchKernelGGL((rows_apply<L>), grid, block, 0, st, t, rs, ord, contrib, dense_grad, row_out, o); \
+        hipLaunchKernelGGL((rows_apply<L>), grid, block, 0, st, t, rs, ord, contrib, dense_grad, row_out, o, (int)ix.chunks); \
         break;
     switch (lpr) {
         CREC_RA(1)
@@ -316,6 +363,9 @@ int crec_apply_all(crec_ctx *ctx, crec_apply_set &a, hipStream_t st)
         blocks += (int)crec_ceil_div(a.tables[k].t.rows, 4);
         a.block_end[k] = blocks;
     }
+    if (a.scalar.rows > 0)
+        blocks += (int)crec_ceil_div(a.scalar.rows, 256);
+    a.scalar_end = blocks;
     if (a.small.n > 0)
         blocks += (int)crec_ceil_div(a.small.n, 16);
     if (blocks == 0)
