@@ -23,6 +23,9 @@
 //              of each triple, plain coalesced stores, then Adam on the user's row) and
 //              bpr_item_side (sums -/+ c_b over the row's occurrences, Adam on the row).
 //              Rows are read only by their own wave inside a launch, so in place is safe.
+//   Either mode: a row with more than CH occurrences in the batch is cut into chunks handled by separate
+//              waves; the chunk wave that draws the row's last ticket sums the partials in chunk order and
+//              applies Adam (chunk_wave), so there is no extra launch.
 // Per chunk: bpr_reduce_loss sums the per-triple loss terms of each batch in a fixed order.
 //
 // A wave owns one table row.  It splits into G = 64/LPR groups of LPR lanes, each lane holding
@@ -70,7 +73,7 @@ struct IndexWs {
     int2 *u_rowseg, *q_rowseg; // tf1 mode: [nbc][U], [nbc][I]  {segment start, length (negative: heavy row)}
     int32_t *hn;               // [nbc][4]   {user heavy rows, user chunks, item heavy rows, item chunks}
     int4 *u_hrows, *q_hrows;   // [nbc][HRu|HRq]  {row, first chunk, chunks<<16 | length, rank among unique rows}
-    int4 *u_hitems, *q_hitems; // [nbc][HIu|HIq]  {row, segment start, length, chunk index}
+    int4 *u_hitems, *q_hitems; // [nbc][HIu|HIq]  {row, segment start, length | heavy row index << 8, chunk index}
     int64_t B, U, I, HRu, HRq, HIu, HIq;
     int32_t CH;                // rows with more than CH occurrences are split into chunks of CH
     size_t bytes;
@@ -248,11 +251,11 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
             rows_out[rank] = (int32_t)(row | (heavy ? 0x80000000u : 0u));
             seg_out[rank] = k;
             if (heavy) {
-                const int parts = (cnt + CH - 1) / CH;
-                hrows_out[hrow++] = make_int4((int)row, hitem, (parts << 16) | cnt, rank);
+                const int parts = (cnt + CH - 1) / CH, my_h = hrow++;
+                hrows_out[my_h] = make_int4((int)row, hitem, (parts << 16) | cnt, rank);
                 for (int p = 0; p < parts; ++p) {
                     const int len = (cnt - p * CH) < CH ? (cnt - p * CH) : CH;
-                    hitems_out[hitem] = make_int4((int)row, k + p * CH, len, hitem);
+                    hitems_out[hitem] = make_int4((int)row, k + p * CH, len | (my_h << 8), hitem);
                     ++hitem;
                 }
             }
@@ -439,8 +442,8 @@ template <int LPR> __device__ inline float triple_s(float4 p, float4 qi, float4 
 //
 // Heavy rows (more than CH occurrences in the batch: popular items) would make their wave the
 // kernel's critical path, so the index kernel cuts them into chunks of CH: chunk waves (R = 1, all
-// G groups on one row) write partial gradients, normal waves skip such a slot, and bpr_finish_heavy
-// adds the partials in chunk order and applies Adam.  Every sum keeps one fixed order.
+// G groups on one row) write partial gradients, normal waves skip such a slot, and the chunk wave that
+// draws the row's last ticket adds the partials in chunk order and applies Adam.  Every sum keeps one fixed order.
 // ------------------------------------------------------------------------------------
 // RW = rows per wave requested | (FULL << 8); FULL: d == 4 * LPR, every lane owns a live float4 (lets the
 // compiler drop the per-lane "inside the row" predicate and its exec-mask branches)
@@ -454,7 +457,7 @@ template <int LPR, int RW> using AccArr = float4[Geo<LPR, RW>::R];
 
 struct Slot { // per lane: the slot of this lane's group (meaningful when g < n_valid)
     int64_t row;
-    int start, cnt; // cnt < 0: heavy row, handled by chunk waves + bpr_finish_heavy
+    int start, cnt; // cnt < 0: heavy row, handled by chunk waves (chunk_wave)
 };
 
 // sum over groups of acc[s], delivered to group s (slot owner); other groups' return value is unused
@@ -709,7 +712,7 @@ __device__ inline void row_wave(const Tables &src, const Tables &dst, int d, con
     const int lane = threadIdx.x & 63, g = lane / LPR, l = lane % LPR;
     const bool heavy = sl.cnt < 0;
     const bool in_slot = g < R && g < n_valid && (FULL || 4 * l < d);
-    const bool owner = in_slot && !heavy; // heavy rows are finished by bpr_finish_heavy
+    const bool owner = in_slot && !heavy; // heavy rows are finished by their last chunk wave
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool user = MODE == 0;
     const int64_t ro = sl.row * d + 4 * l;
@@ -735,23 +738,126 @@ __device__ inline void row_wave(const Tables &src, const Tables &dst, int d, con
     }
 }
 
-// one chunk (<= CH occurrences) of a heavy row: all G groups on the row, partial gradient out
+// what the wave that finishes a heavy row needs beyond its own chunk
+struct FinishArgs {
+    const int4 *hrows; // this side's heavy row descriptors
+    int32_t *tickets;  // this side's per-heavy-row counters, zero between launches
+    Tables dst;        // tf1: the other buffer set; lazy: the tables themselves
+    float *rowterm;    // this side's row terms
+    int dense;         // row terms indexed by row id (tf1) or by rank among the batch's unique rows (lazy)
+};
+
+// one chunk (<= CH occurrences) of a heavy row: all G groups on the row, partial gradient out.  The chunk waves
+// of a row take tickets; the wave that draws the last one adds the partials in chunk order (so the sum does not
+// depend on which wave that is), applies Adam and writes the row term -- no second launch.  The partials cross
+// workgroups, possibly XCDs: release fence before the ticket, acquire fence after it.
 template <int LPR, int MODE, bool STORE_CONTRIB, bool FULL>
 __device__ inline void chunk_wave(const Tables &src, int d, int4 item, const int4 *__restrict__ occ,
                                   float *__restrict__ contrib, float *__restrict__ xb, float *__restrict__ partial,
-                                  const Hyper &h)
+                                  const FinishArgs &f, const Hyper &h)
 {
+    constexpr bool user = MODE == 0;
     const int lane = threadIdx.x & 63, g = lane / LPR, l = lane % LPR;
     const bool act = FULL || 4 * l < d;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int hidx = item.z >> 8;
     Slot sl;
     sl.row = item.x;
     sl.start = item.y;
-    sl.cnt = item.z;
-    const float4 var = act ? ld4((MODE == 0 ? src.P : src.Q) + sl.row * d + 4 * l) : zero; // every group: R == 1
-    const float4 grad = slots_grad<LPR, 1 | (FULL ? 0x100 : 0), MODE, STORE_CONTRIB>(var, sl, 1, src.P, src.Q, d, occ, contrib, xb, h);
-    if (g == 0 && act)
+    sl.cnt = item.z & 0xff;
+    const int64_t ro = sl.row * d + 4 * l;
+    const bool on = g == 0 && act;
+    float4 var = act ? ld4((user ? src.P : src.Q) + ro) : zero; // every group: R == 1
+    // the finishing wave's inputs are fetched by every chunk wave up front: their latency hides behind the
+    // chunk's own gathers instead of extending the row's critical path after the last ticket
+    const int4 rec = f.hrows[hidx];
+    float4 m = on ? ld4((user ? src.mP : src.mQ) + ro) : zero, v = on ? ld4((user ? src.vP : src.vQ) + ro) : zero;
+    float4 grad;
+    if (MODE == 2) {
+        // lazy item side: an occurrence is one contribution row to read and add, nothing to compute first, so the
+        // chunk keeps eight rows in flight per group instead of the generic walk's UNR (a chunk wave is the launch's
+        // critical path).  Same per-group order and the same cross-group sum as the generic walk.
+        constexpr int G = 64 / LPR, DEEP = 8;
+        AccArr<LPR, 1 | (FULL ? 0x100 : 0)> acc;
+        acc[0] = zero;
+        for (int c0 = 0; c0 < sl.cnt; c0 += 64) {
+            const int nc = (sl.cnt - c0) < 64 ? (sl.cnt - c0) : 64;
+            const int mine = lane < nc ? occ[sl.start + c0 + lane].w : 0;
+            const int n_sub = (nc + G - 1) / G;
+            for (int t0 = 0; t0 < n_sub; t0 += DEEP) {
+                float4 a[DEEP];
+                int rw[DEEP];
+                bool has[DEEP];
+#pragma unroll
+                for (int t = 0; t < DEEP; ++t) {
+                    const int kk = (t0 + t) * G + g;
+                    rw[t] = __shfl(mine, kk & 63, 64);
+                    has[t] = (t0 + t) < n_sub && kk < nc;
+                    a[t] = (has[t] && act) ? ld4(contrib + (int64_t)(rw[t] & 0x7fffffff) * d + 4 * l) : zero;
+                }
+#pragma unroll
+                for (int t = 0; t < DEEP; ++t) {
+                    const float sg = rw[t] < 0 ? 1.0f : -1.0f, k = (has[t] && act) ? 1.0f : 0.0f;
+                    add4(acc[0], make_float4(k * (sg * a[t].x + h.reg * var.x), k * (sg * a[t].y + h.reg * var.y),
+                                             k * (sg * a[t].z + h.reg * var.z), k * (sg * a[t].w + h.reg * var.w)));
+                }
+            }
+        }
+        grad = reduce_to_owner<LPR, 1 | (FULL ? 0x100 : 0)>(acc);
+    } else {
+        grad = slots_grad<LPR, 1 | (FULL ? 0x100 : 0), MODE, STORE_CONTRIB>(var, sl, 1, src.P, src.Q, d, occ, contrib, xb, h);
+    }
+    if (on)
         st4(partial + (int64_t)item.w * d + 4 * l, grad);
+    __threadfence();
+    int ticket = 0;
+    if (lane == 0)
+        ticket = atomicAdd(f.tickets + hidx, 1);
+    ticket = __builtin_amdgcn_readfirstlane(ticket);
+    const int first = rec.y, parts = rec.z >> 16, cnt = rec.z & 0xffff;
+    if (ticket != parts - 1)
+        return;
+    __threadfence();
+    grad = zero;
+    if (on) {
+        const float *pp = partial + (int64_t)first * d + 4 * l;
+        int p = 0;
+        for (; p + 16 <= parts; p += 16) { // chunk order, sixteen loads in flight
+            float4 t[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                t[k] = ld4(pp + (int64_t)(p + k) * d);
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                add4(grad, t[k]);
+        }
+        for (; p + 4 <= parts; p += 4) {
+            float4 t[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                t[k] = ld4(pp + (int64_t)(p + k) * d);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                add4(grad, t[k]);
+        }
+        for (; p < parts; ++p)
+            add4(grad, ld4(pp + (int64_t)p * d));
+    }
+    const float nr = group_sum<LPR>(dot4(var, var));
+    if (on) {
+        if (l == 0)
+            f.rowterm[f.dense ? sl.row : (int64_t)rec.w] = (0.5f * nr) * (float)cnt;
+        if (!user && h.dQ) {
+            st4(h.dQ + ro, grad);
+        } else {
+            adam4(var, m, v, grad, true, h);
+            st4((user ? f.dst.P : f.dst.Q) + ro, var);
+            st4((user ? f.dst.mP : f.dst.mQ) + ro, m);
+            st4((user ? f.dst.vP : f.dst.vQ) + ro, v);
+        }
+    }
+    if (lane == 0)
+        f.tickets[hidx] = 0; // ready for the next launch
 }
 
 // ------------------------------------------------------------------------------------
@@ -764,7 +870,9 @@ struct HeavyArgs {
     const int4 *u_hitems, *q_hitems; // chunk descriptors
     const int4 *u_hrows, *q_hrows;   // heavy row descriptors
     float *partial;                  // [HIu + HIq][d]
+    int32_t *tickets;                // [HRu max + HRq max], zero between launches
     int HIu, HIq, HRu, HRq;
+    int HRu_max;                     // item tickets start here
 };
 
 template <int LPR, bool FULL>
@@ -779,13 +887,14 @@ __global__ __launch_bounds__(256) void bpr_step_fused(Tables src, Tables dst, in
     const int lane = threadIdx.x & 63, g = lane / LPR;
     int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (wave_id < hv.HIu) {
-        chunk_wave<LPR, 0, false, FULL>(src, d, hv.u_hitems[wave_id], u_occ, nullptr, xb, hv.partial, h);
+        chunk_wave<LPR, 0, false, FULL>(src, d, hv.u_hitems[wave_id], u_occ, nullptr, xb, hv.partial,
+                                        FinishArgs{hv.u_hrows, hv.tickets, dst, rowterm, 1}, h);
         return;
     }
     wave_id -= hv.HIu;
     if (wave_id < hv.HIq) {
-        chunk_wave<LPR, 1, false, FULL>(src, d, hv.q_hitems[wave_id], q_occ, nullptr, xb,
-                                      hv.partial + (int64_t)hv.HIu * d, h);
+        chunk_wave<LPR, 1, false, FULL>(src, d, hv.q_hitems[wave_id], q_occ, nullptr, xb, hv.partial + (int64_t)hv.HIu * d,
+                                        FinishArgs{hv.q_hrows, hv.tickets + hv.HRu_max, dst, rowterm + U, 1}, h);
         return;
     }
     wave_id -= hv.HIq;
@@ -816,6 +925,7 @@ __global__ __launch_bounds__(256) void bpr_side_lazy(Tables t, int d, const int3
                                                      const int32_t *__restrict__ rows, const int32_t *__restrict__ seg,
                                                      const int4 *__restrict__ occ, const int32_t *__restrict__ n_chunks_p,
                                                      const int4 *__restrict__ hitems, int HI,
+                                                     const int4 *__restrict__ hrows, int32_t *__restrict__ tickets,
                                                      float *__restrict__ partial, float *__restrict__ contrib,
                                                      float *__restrict__ xb, float *__restrict__ rowterm, Hyper h)
 {
@@ -823,7 +933,8 @@ __global__ __launch_bounds__(256) void bpr_side_lazy(Tables t, int d, const int3
     const int lane = threadIdx.x & 63, g = lane / LPR;
     int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (wave_id < HI) {
-        chunk_wave<LPR, MODE, MODE == 0, FULL>(t, d, hitems[wave_id], occ, contrib, xb, partial, h);
+        chunk_wave<LPR, MODE, MODE == 0, FULL>(t, d, hitems[wave_id], occ, contrib, xb, partial,
+                                               FinishArgs{hrows, tickets, t, rowterm, 0}, h);
         return;
     }
     wave_id -= HI;
@@ -840,54 +951,6 @@ __global__ __launch_bounds__(256) void bpr_side_lazy(Tables t, int d, const int3
     const int cnt = seg[idx + 1] - sl.start;
     sl.cnt = g < n_valid ? (rw < 0 ? -cnt : cnt) : 0;
     row_wave<LPR, MODE, MODE == 0, FULL>(t, t, d, sl, n_valid, occ, contrib, xb, rowterm + idx, false, h);
-}
-
-// ------------------------------------------------------------------------------------
-// bpr_finish_heavy: one wave per heavy row: partials summed in chunk order, Adam, row term.
-// Waves [0, HRu) user rows, [HRu, HRu + HRq) item rows.  tf1: src -> dst; lazy: in place.
-// ------------------------------------------------------------------------------------
-template <int LPR>
-__global__ __launch_bounds__(256) void bpr_finish_heavy(Tables src, Tables dst, int d, HeavyArgs hv,
-                                                        float *__restrict__ rowterm, int64_t rt_item_base, int dense,
-                                                        Hyper h)
-{
-    const int lane = threadIdx.x & 63, g = lane / LPR, l = lane % LPR;
-    int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    bool user = true;
-    if (wave_id >= hv.HRu) {
-        user = false;
-        wave_id -= hv.HRu;
-        if (wave_id >= hv.HRq)
-            return;
-    }
-    const int4 rec = user ? hv.u_hrows[wave_id] : hv.q_hrows[wave_id];
-    const int64_t row = rec.x;
-    const int first = rec.y, parts = rec.z >> 16, cnt = rec.z & 0xffff;
-    const bool on = g == 0 && 4 * l < d;
-    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int64_t ro = row * d + 4 * l;
-    float4 var = zero, m = zero, v = zero, grad = zero;
-    if (on) {
-        var = ld4((user ? src.P : src.Q) + ro);
-        m = ld4((user ? src.mP : src.mQ) + ro);
-        v = ld4((user ? src.vP : src.vQ) + ro);
-        const float *part = hv.partial + (int64_t)(user ? 0 : hv.HIu) * d;
-        for (int p = 0; p < parts; ++p)
-            add4(grad, ld4(part + (int64_t)(first + p) * d + 4 * l));
-    }
-    const float nr = group_sum<LPR>(dot4(var, var));
-    if (on) {
-        if (l == 0)
-            rowterm[(user ? 0 : rt_item_base) + (dense ? row : (int64_t)rec.w)] = (0.5f * nr) * (float)cnt;
-        if (!user && h.dQ) {
-            st4(h.dQ + ro, grad);
-        } else {
-            adam4(var, m, v, grad, true, h);
-            st4((user ? dst.P : dst.Q) + ro, var);
-            st4((user ? dst.mP : dst.mQ) + ro, m);
-            st4((user ? dst.vP : dst.vQ) + ro, v);
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -954,6 +1017,7 @@ struct StepArgs {
     int64_t U, I;
     int32_t B;
     float *contrib, *xb, *rowterm, *partial;
+    int32_t *tickets;
     Hyper h;
     hipStream_t st;
 };
@@ -970,6 +1034,8 @@ HeavyArgs heavy_args(const StepArgs &a, const IndexWs &w, int64_t b, const int32
     hv.u_hrows = w.u_hrows + b * w.HRu;
     hv.q_hrows = w.q_hrows + b * w.HRq;
     hv.partial = a.partial;
+    hv.tickets = a.tickets;
+    hv.HRu_max = (int)w.HRu;
     hv.HRu = hn[0];
     hv.HIu = hn[1];
     hv.HRq = hn[2];
@@ -987,12 +1053,6 @@ template <int LPR, bool FULL> void launch_fused(const StepArgs &a, const IndexWs
                        a.d, a.U, a.I, w.u_rowseg + b * w.U, w.u_occ + b * w.B, w.q_rowseg + b * w.I,
                        w.q_occ + b * 2 * w.B, hv, a.xb, a.rowterm, a.h);
     crec_prof_end(a.ctx, a.st);
-    if (hv.HRu + hv.HRq > 0) {
-        crec_prof_begin(a.ctx, CREC_K_FINISH, a.st);
-        hipLaunchKernelGGL((bpr_finish_heavy<LPR>), dim3((unsigned)crec_ceil_div(hv.HRu + hv.HRq, 4)), dim3(256), 0, a.st,
-                           a.cur, a.other, a.d, hv, a.rowterm, a.U, 1, a.h);
-        crec_prof_end(a.ctx, a.st);
-    }
 }
 
 template <int LPR, bool FULL> void launch_lazy(const StepArgs &a, const IndexWs &w, int64_t b, const int32_t *hn)
@@ -1004,19 +1064,14 @@ template <int LPR, bool FULL> void launch_lazy(const StepArgs &a, const IndexWs 
     crec_prof_begin(a.ctx, CREC_K_USER_SIDE, a.st);
     hipLaunchKernelGGL((bpr_side_lazy<LPR, 0, FULL>), dim3((unsigned)crec_ceil_div(u_waves, 4)), dim3(256), 0, a.st, a.cur, a.d,
                        w.n_u + b, w.u_rows + b * w.B, w.u_seg + b * (w.B + 1), w.u_occ + b * w.B, hv.hn + 1, hv.u_hitems,
-                       hv.HIu, a.partial, a.contrib, a.xb, a.rowterm, a.h);
+                       hv.HIu, hv.u_hrows, hv.tickets, a.partial, a.contrib, a.xb, a.rowterm, a.h);
     crec_prof_end(a.ctx, a.st);
     crec_prof_begin(a.ctx, CREC_K_ITEM_SIDE, a.st);
     hipLaunchKernelGGL((bpr_side_lazy<LPR, 2, FULL>), dim3((unsigned)crec_ceil_div(q_waves, 4)), dim3(256), 0, a.st, a.cur, a.d,
                        w.n_q + b, w.q_rows + b * 2 * w.B, w.q_seg + b * (2 * w.B + 1), w.q_occ + b * 2 * w.B, hv.hn + 3,
-                       hv.q_hitems, hv.HIq, a.partial + (int64_t)hv.HIu * a.d, a.contrib, a.xb, a.rowterm + a.B, a.h);
+                       hv.q_hitems, hv.HIq, hv.q_hrows, hv.tickets + hv.HRu_max, a.partial + (int64_t)hv.HIu * a.d, a.contrib,
+                       a.xb, a.rowterm + a.B, a.h);
     crec_prof_end(a.ctx, a.st);
-    if (hv.HRu + hv.HRq > 0) {
-        crec_prof_begin(a.ctx, CREC_K_FINISH, a.st);
-        hipLaunchKernelGGL((bpr_finish_heavy<LPR>), dim3((unsigned)crec_ceil_div(hv.HRu + hv.HRq, 4)), dim3(256), 0, a.st,
-                           a.cur, a.cur, a.d, hv, a.rowterm, (int64_t)a.B, 0, a.h);
-        crec_prof_end(a.ctx, a.st);
-    }
 }
 
 using StepFn = void (*)(const StepArgs &, const IndexWs &, int64_t, const int32_t *);
@@ -1076,11 +1131,12 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
     }
     StepFn step = pick_step(t->d, dense);
     const int64_t nb = crec_ceil_div(N, B);
-    // occurrences per heavy-row chunk.  tf1 mode pays a second launch per step for split rows, so it
-    // only splits rows that would dominate the step; lazy mode (large catalogues, Zipf heads) splits early.
+    // occurrences per heavy-row chunk: short chunks shorten the longest wave, but every chunk wave pays a
+    // device-scope fence and a ticket on its row's counter (measured on S-big: 16 -> 16.3 us, 32 -> 13.7, 64 -> 15.3
+    // for the item side).  tf1 mode at ml-1m shape only splits rows that would dominate the step.
     static const int ch_env = getenv("CREC_CH") ? atoi(getenv("CREC_CH")) : 0;
-    const int CH = ch_env > 0 ? ch_env : (dense ? 64 : 16);
-    CREC_REQUIRE(ctx, CH >= 1, "CREC_CH");
+    const int CH = ch_env > 0 ? ch_env : (dense ? 64 : 32);
+    CREC_REQUIRE(ctx, CH >= 1 && CH <= 255, "CREC_CH: 1..255");
 
     // chunk the epoch so the inverted indices of a chunk stay under ~1 GiB
     const size_t per_batch = layout_index(nullptr, 1, B, t->U, t->I, dense, CH).bytes;
@@ -1093,8 +1149,12 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
     if (int rc = crec_reserve(ctx, &ctx->loss_ws, sizeof(float) * (size_t)chunk * loss_stride))
         return rc;
     const IndexWs w0 = layout_index(nullptr, 1, B, t->U, t->I, dense, CH);
-    if (int rc = crec_reserve(ctx, &ctx->misc, sizeof(float) * (size_t)(w0.HIu + w0.HIq) * t->d))
+    // heavy rows: chunk partials, then one ticket counter per heavy row (zeroed here, re-zeroed by the finishing wave)
+    const size_t part_bytes = align_up(sizeof(float) * (size_t)(w0.HIu + w0.HIq) * t->d, 256);
+    const size_t ticket_bytes = sizeof(int32_t) * (size_t)(w0.HRu + w0.HRq);
+    if (int rc = crec_reserve(ctx, &ctx->misc, part_bytes + ticket_bytes))
         return rc;
+    CREC_HIP(ctx, hipMemsetAsync((char *)ctx->misc.ptr + part_bytes, 0, ticket_bytes, st));
 
     StepArgs a{};
     a.ctx = ctx;
@@ -1105,6 +1165,7 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
     a.B = B;
     a.st = st;
     a.partial = (float *)ctx->misc.ptr;
+    a.tickets = (int32_t *)((char *)ctx->misc.ptr + part_bytes);
     const size_t bytesP = sizeof(float) * (size_t)t->U * t->d, bytesQ = sizeof(float) * (size_t)t->I * t->d;
     if (dense) { // the second buffer set of the ping-pong
         const size_t aP = align_up(bytesP, 256), aQ = align_up(bytesQ, 256);
