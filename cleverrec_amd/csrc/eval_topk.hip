@@ -23,6 +23,8 @@
 // rank_metrics: HR / MRR / NDCG per (K, user) in float64.
 #include "crec_internal.h"
 
+#include <type_traits>
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -49,11 +51,11 @@ __device__ inline float key_score(u64 k) { return from_ordered((uint32_t)(k >> 3
 
 __device__ inline void lds_fence()
 {
-    // LDS operations of one wave execute in issue order; this only stops the compiler from
-    // caching or reordering the cross-lane traffic below.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    // LDS operations of one wave execute and return in issue order, so the cross-lane traffic below needs no
+    // hardware wait of its own; this only stops the compiler from caching or reordering LDS accesses across it.
+    // (A wavefront-scope fence would also drain vmcnt -- i.e. wait for the next tile's global loads in flight.)
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    asm volatile("" ::: "memory");
 }
 
 struct WaveState {
@@ -66,7 +68,7 @@ struct WaveState {
 };
 
 // Keep the K best unseen entries of user row `ul`, sorted best first.  Whole wave.
-__device__ void prune(const WaveState &ws, int ul, int K, const int64_t *__restrict__ seen_ptr,
+__device__ __attribute__((noinline)) void prune(const WaveState &ws, int ul, int K, const int64_t *__restrict__ seen_ptr,
                       const int32_t *__restrict__ seen_items)
 {
     const int lane = threadIdx.x & 63;
@@ -207,67 +209,137 @@ __global__ __launch_bounds__(256) void eval_sweep(const float *__restrict__ P, c
     }
     __syncthreads();
 
-    for (int64_t t = 0; t < n_tiles; ++t) {
+    // Software pipeline over the stream of 32x32 blocks: while the matrix core works through block n (a chain of
+    // DMAX/2 dependent MFMAs), the wave's vector ALU compares block n-1's accumulators with the thresholds -- the
+    // compares sit between the MFMAs in program order, so they issue in the MFMAs' shadow instead of after them.
+    // Two accumulators alternate along the stream (the tile body is instantiated for both parities of its first
+    // block).  Candidates are rare: one ballot per block decides whether the append / prune path runs at all.
+    f32x16 accA, accB;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        accA[r] = accB[r] = 0.f;
+
+    // append block candidates (bits of `hit`) of block `item0 + row`; prunes full buffers
+    auto take_candidates = [&](const f32x16 acc, uint32_t hit, int64_t item) __attribute__((always_inline)) {
+        bool pruned = false;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool is_cand = (hit >> r) & 1u;
+            const u64 bal = __ballot(is_cand);
+            if (bal) {
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const uint32_t m = hh ? (uint32_t)(bal >> 32) : (uint32_t)bal;
+                    if (m) {
+                        const int ul = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                        const int c = __popc(m);
+                        int base = ws.cnt[ul];
+                        if (base + c > CAP) {
+                            prune(ws, ul, K, seen_ptr, seen_items);
+                            pruned = true;
+                            base = ws.cnt[ul];
+                        }
+                        if (h == hh && is_cand)
+                            ws.cand[ul * CAP + base + __popc(m & ((1u << row) - 1u))] = make_key(acc[r], (int)item);
+                        if (lane == 0)
+                            ws.cnt[ul] = base + c;
+                        lds_fence();
+                    }
+                }
+            }
+        }
+        if (pruned)
+            reload_thr();
+    };
+
+    int64_t prev_item = 0; // item of this lane in the block whose accumulators wait for their compares
+    bool have_prev = false;
+    auto tile_body = [&](auto par_c, int64_t t) __attribute__((always_inline)) { // PAR: which accumulator the tile's first block lands in
+        constexpr int PAR = decltype(par_c)::value;
         const int cur = (int)(t & 1);
         const int64_t tile_base = i0 + t * TI;
         if (t + 1 < n_tiles)
             stage_load(tile_base + TI); // in flight while this tile is multiplied
 
         const float *qb = qt + cur * TI * LDQ;
+        // B operands are read a segment (up to 32 MFMAs' worth) ahead into the other half of a register double
+        // buffer, so an LDS round trip is exposed once per tile, not once per pair of reads
+        constexpr int SEGQ = (HS / 4) < 8 ? (HS / 4) : 8; // float4s per segment
+        constexpr int SPB = (HS / 4) / SEGQ;              // segments per block
+        constexpr int NSEG = NBLK * SPB;
+        float4 bb[2][SEGQ];
+        auto load_seg = [&](float4(&dst)[SEGQ], int sgi) __attribute__((always_inline)) {
+            const float *bp = qb + ((sgi / SPB) * 32 + row) * LDQ + h * HS + (sgi % SPB) * SEGQ * 4;
 #pragma unroll
-        for (int blk = 0; blk < NBLK; ++blk) {
-            f32x16 acc;
+            for (int q = 0; q < SEGQ; ++q)
+                dst[q] = *reinterpret_cast<const float4 *>(bp + 4 * q);
+        };
+        load_seg(bb[0], 0);
+        uint32_t hit = 0;
+        bool prev_ok = false;
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                acc[r] = 0.f;
-            const float *bp = qb + (blk * 32 + row) * LDQ + h * HS;
+        for (int sgi = 0; sgi < NSEG; ++sgi) {
+            const int blk = sgi / SPB, part = sgi % SPB;
+            f32x16 &acc = ((PAR + blk) & 1) ? accB : accA;
+            const f32x16 &prv = ((PAR + blk) & 1) ? accA : accB;
+            if (sgi + 1 < NSEG)
+                load_seg(bb[(sgi + 1) & 1], sgi + 1);
+            __builtin_amdgcn_sched_barrier(0); // the reads stay ahead of the MFMA chain
+            if (part == 0) {
+                // accumulator register r of lane (row, h) is score[user (r&3) + 8*(r>>2) + 4*h][item base + row]
+                prev_ok = have_prev && prev_item < i1;
+                hit = 0;
 #pragma unroll
-            for (int q = 0; q < HS / 4; ++q) {
-                const float4 b = *reinterpret_cast<const float4 *>(bp + 4 * q);
+                for (int r = 0; r < 16; ++r)
+                    acc[r] = 0.f;
+            }
+#pragma unroll
+            for (int qq = 0; qq < SEGQ; ++qq) {
+                const int q = part * SEGQ + qq;
+                const float4 b = bb[sgi & 1][qq];
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * q + 0], b.x, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * q + 1], b.y, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * q + 2], b.z, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * q + 3], b.w, acc, 0, 0, 0);
-            }
-            // ---- epilogue: accumulator register r of lane (row, h) is
-            //      score[user (r&3) + 8*(r>>2) + 4*h][item tile_base + blk*32 + row]
-            const int64_t item = tile_base + blk * 32 + row;
-            const bool item_ok = item < i1;
-            bool pruned = false;
+                // this step's share of the previous block's 16 compares
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float sc = acc[r];
-                const bool is_cand = item_ok && sc > thr_r[r];
-                const u64 bal = __ballot(is_cand);
-                if (bal) {
-#pragma unroll
-                    for (int hh = 0; hh < 2; ++hh) {
-                        const uint32_t m = hh ? (uint32_t)(bal >> 32) : (uint32_t)bal;
-                        if (m) {
-                            const int ul = (r & 3) + 8 * (r >> 2) + 4 * hh;
-                            const int c = __popc(m);
-                            int base = ws.cnt[ul];
-                            if (base + c > CAP) {
-                                prune(ws, ul, K, seen_ptr, seen_items);
-                                pruned = true;
-                                base = ws.cnt[ul];
-                            }
-                            if (h == hh && is_cand)
-                                ws.cand[ul * CAP + base + __popc(m & ((1u << row) - 1u))] = make_key(sc, (int)item);
-                            if (lane == 0)
-                                ws.cnt[ul] = base + c;
-                            lds_fence();
-                        }
-                    }
-                }
+                for (int r = (16 * q) / (HS / 4); r < (16 * (q + 1)) / (HS / 4); ++r)
+                    hit |= (prev_ok && prv[r] > thr_r[r]) ? (1u << r) : 0u;
             }
-            if (pruned)
-                reload_thr();
+            if (part == SPB - 1) {
+                if (__ballot(hit != 0))
+                    take_candidates(prv, hit, prev_item);
+                prev_item = tile_base + blk * 32 + row;
+                have_prev = true;
+            }
         }
 
         if (t + 1 < n_tiles)
             stage_store(cur ^ 1);
         __syncthreads();
+    };
+    if (NBLK % 2 == 0) {
+        for (int64_t t = 0; t < n_tiles; ++t)
+            tile_body(std::integral_constant<int, 0>{}, t);
+    } else {
+        for (int64_t t = 0; t < n_tiles; t += 2) {
+            tile_body(std::integral_constant<int, 0>{}, t);
+            if (t + 1 < n_tiles)
+                tile_body(std::integral_constant<int, 1>{}, t + 1);
+        }
+    }
+    if (have_prev) { // the last block of the sweep still waits for its compares
+        const bool inB = ((n_tiles * NBLK - 1) & 1) != 0;
+        uint32_t hit = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            hit |= (prev_item < i1 && (inB ? accB[r] : accA[r]) > thr_r[r]) ? (1u << r) : 0u;
+        if (__ballot(hit != 0)) {
+            if (inB)
+                take_candidates(accB, hit, prev_item);
+            else
+                take_candidates(accA, hit, prev_item);
+        }
     }
 
     // ---- final prune + hand the K best keys of this split to the merge -------------------------
