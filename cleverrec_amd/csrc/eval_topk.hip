@@ -30,9 +30,11 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned long long u64;
 
-constexpr int CAP = 64;        // candidate slots per user
-constexpr int K_MAX = 32;      // CAP - K_MAX >= 32: one half-wave of candidates always fits after a prune
-constexpr int USERS_PER_WG = 128;
+// Candidate slots per user: after a prune at most K stay, and one block can add 32 (one per item lane), so
+// CAP >= K + 32.  Two shapes: 4 waves x CAP 64 (K <= 32), or 8 waves x CAP 56 (K <= 24) -- two waves per SIMD, so that
+// one wave's epilogue, LDS reads and barrier waits fill the other's MFMA gaps -- when its buffers fit the 160 KB of LDS.
+constexpr int K_MAX = 32;
+constexpr int cap_of(int NW) { return NW == 8 ? 56 : 64; }
 constexpr int MAX_SPLITS = 16;
 
 __device__ inline uint32_t ordered_bits(float f)
@@ -59,20 +61,21 @@ __device__ inline void lds_fence()
 }
 
 struct WaveState {
-    u64 *cand;   // [32][CAP]
+    u64 *cand;   // [32][cap]
     int *cnt;    // [32] entries in the buffer
     int *clean;  // [32] leading entries already checked against the seen list
     float *thr;  // [32] score a candidate must beat
     int *uid;    // [32] global user id, -1 for padding rows
+    int cap;     // candidate slots per user
     int keep_listed; // 0: drop items found in the user's list (seen filter); 1: keep only those (candidates)
 };
 
 // Keep the K best unseen entries of user row `ul`, sorted best first.  Whole wave.
-__device__ __attribute__((noinline)) void prune(const WaveState &ws, int ul, int K, const int64_t *__restrict__ seen_ptr,
+__device__ inline void prune(const WaveState &ws, int ul, int K, const int64_t *__restrict__ seen_ptr,
                       const int32_t *__restrict__ seen_items)
 {
     const int lane = threadIdx.x & 63;
-    u64 *buf = ws.cand + ul * CAP;
+    u64 *buf = ws.cand + ul * ws.cap;
     const int n = ws.cnt[ul], clean = ws.clean[ul], uid = ws.uid[ul];
     u64 mine = lane < n ? buf[lane] : 0;
     if (lane >= clean && lane < n) {
@@ -92,7 +95,8 @@ __device__ __attribute__((noinline)) void prune(const WaveState &ws, int ul, int
         if (listed != (ws.keep_listed != 0))
             mine = 0;
     }
-    buf[lane] = mine;
+    if (lane < ws.cap) // a user's buffer may be shorter than the wave
+        buf[lane] = mine;
     lds_fence();
     int rank = 0;
     for (int t = 0; t < n; ++t)
@@ -114,8 +118,8 @@ __device__ __attribute__((noinline)) void prune(const WaveState &ws, int ul, int
     lds_fence();
 }
 
-template <int DMAX, int TI>
-__global__ __launch_bounds__(256) void eval_sweep(const float *__restrict__ P, const float *__restrict__ Q, int64_t I,
+template <int DMAX, int TI, int NW>
+__global__ __launch_bounds__(NW * 64) void eval_sweep(const float *__restrict__ P, const float *__restrict__ Q, int64_t I,
                                                   int d, const int32_t *__restrict__ users, int Bt,
                                                   const int64_t *__restrict__ seen_ptr,
                                                   const int32_t *__restrict__ seen_items, int K, float sign,
@@ -124,22 +128,23 @@ __global__ __launch_bounds__(256) void eval_sweep(const float *__restrict__ P, c
     constexpr int HS = DMAX / 2;          // MFMA steps
     constexpr int LDQ = DMAX + 4;         // padded LDS row (floats)
     constexpr int CPR = DMAX / 4;         // float4 chunks per item row
-    constexpr int NCH = TI * CPR / 256;   // chunks staged per thread
+    constexpr int NT = NW * 64, CAP = cap_of(NW), USERS_PER_WG = NW * 32;
+    constexpr int NCH = TI * CPR / NT;    // chunks staged per thread
     constexpr int NBLK = TI / 32;
     static_assert(NCH >= 1, "tile too small");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *qt = (float *)smem;                                  // [2][TI*LDQ]
-    u64 *cand_all = (u64 *)(qt + 2 * TI * LDQ);                 // [4][32][CAP]
-    int *cnt_all = (int *)(cand_all + 4 * 32 * CAP);            // [4][32]
-    int *clean_all = cnt_all + 4 * 32;
-    float *thr_all = (float *)(clean_all + 4 * 32);
-    int *uid_all = (int *)(thr_all + 4 * 32);
+    u64 *cand_all = (u64 *)(qt + 2 * TI * LDQ);                 // [NW][32][CAP]
+    int *cnt_all = (int *)(cand_all + NW * 32 * CAP);           // [NW][32]
+    int *clean_all = cnt_all + NW * 32;
+    float *thr_all = (float *)(clean_all + NW * 32);
+    int *uid_all = (int *)(thr_all + NW * 32);
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int row = lane & 31, h = lane >> 5;
     // the host packs the filter mode above K: K | keep_listed << 16
-    WaveState ws{cand_all + wv * 32 * CAP, cnt_all + wv * 32, clean_all + wv * 32, thr_all + wv * 32, uid_all + wv * 32, K >> 16};
+    WaveState ws{cand_all + wv * 32 * CAP, cnt_all + wv * 32, clean_all + wv * 32, thr_all + wv * 32, uid_all + wv * 32, CAP, K >> 16};
     K &= 0xffff;
 
     const int S = gridDim.y, sp = blockIdx.y;
@@ -168,7 +173,7 @@ __global__ __launch_bounds__(256) void eval_sweep(const float *__restrict__ P, c
         a[4 * q + 3] = sign * v.w;
     }
     // zero both tile buffers once: the k >= d padding columns are never written again
-    for (int k = tid; k < 2 * TI * LDQ; k += 256)
+    for (int k = tid; k < 2 * TI * LDQ; k += NT)
         qt[k] = 0.f;
     __syncthreads();
 
@@ -177,7 +182,7 @@ __global__ __launch_bounds__(256) void eval_sweep(const float *__restrict__ P, c
     auto stage_load = [&](int64_t tile_base) {
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            const int ch = tid + c * 256, r = ch / CPR, k = (ch % CPR) * 4;
+            const int ch = tid + c * NT, r = ch / CPR, k = (ch % CPR) * 4;
             const int64_t item = tile_base + r;
             stage[c] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (item < i1 && k < d)
@@ -187,7 +192,7 @@ __global__ __launch_bounds__(256) void eval_sweep(const float *__restrict__ P, c
     auto stage_store = [&](int bufi) {
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            const int ch = tid + c * 256, r = ch / CPR, k = (ch % CPR) * 4;
+            const int ch = tid + c * NT, r = ch / CPR, k = (ch % CPR) * 4;
             if (k < d)
                 *reinterpret_cast<float4 *>(qt + bufi * TI * LDQ + r * LDQ + k) = stage[c];
         }
@@ -382,54 +387,82 @@ __global__ __launch_bounds__(64) void eval_merge(const u64 *__restrict__ part, i
     }
 }
 
-// cal_ranking_metrics (utils/metrics.py:9-19): thread per (k index, user), float64
-__global__ void rank_metrics_kernel(const int32_t *__restrict__ topk_ids, const int32_t *__restrict__ users, int Bt,
-                                    int Kmax, const int32_t *__restrict__ ks, int nk,
-                                    const int64_t *__restrict__ test_ptr, const int32_t *__restrict__ test_items,
-                                    double *__restrict__ hr, double *__restrict__ mrr, double *__restrict__ ndcg)
+// cal_ranking_metrics (utils/metrics.py:9-19) in float64: one wave per user.  Lanes stride over the user's test
+// items: each finds its item's position in the recommended list (or not), and adds its share of hit / 1/(rank+1) /
+// 1/log2(rank+2) for every K of the list and of the ideal DCG; the lane sums are combined by a fixed butterfly.
+__device__ inline double wave_sum_f64(double v)
 {
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (int64_t)nk * Bt)
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1)
+        v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void rank_metrics_kernel(const int32_t *__restrict__ topk_ids,
+                                                           const int32_t *__restrict__ users, int Bt, int Kmax,
+                                                           const int32_t *__restrict__ ks, int nk,
+                                                           const int64_t *__restrict__ test_ptr,
+                                                           const int32_t *__restrict__ test_items,
+                                                           double *__restrict__ hr, double *__restrict__ mrr,
+                                                           double *__restrict__ ndcg)
+{
+    __shared__ int32_t rec_all[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * 4 + wv;
+    if (r >= Bt)
         return;
-    const int q = (int)(gid / Bt), r = (int)(gid % Bt);
-    const int K = ks[q];
-    const int32_t *rec = topk_ids + (int64_t)r * Kmax;
+    int32_t *rec = rec_all[wv];
+    rec[lane] = lane < Kmax ? topk_ids[r * Kmax + lane] : -1; // Kmax <= 32 (crec_eval_topk), checked by the host
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
     const int32_t uu = users[r];
     const int64_t t0 = test_ptr[uu], n_real = test_ptr[uu + 1] - t0;
-    double hit = 0, rr = 0, dcg = 0, idcg = 0;
-    for (int64_t id = 0; id < n_real; ++id) {
-        const int32_t item = test_items[t0 + id];
-        for (int idx = 0; idx < K; ++idx) {
-            if (rec[idx] == item) {
+    double idcg = 0.0;
+    for (int64_t id = lane; id < n_real; id += 64)
+        idcg += 1.0 / log2((double)(id + 2));
+    idcg = wave_sum_f64(idcg);
+    for (int q = 0; q < nk; ++q) {
+        const int K = ks[q];
+        double hit = 0.0, rr = 0.0, dcg = 0.0;
+        for (int64_t id = lane; id < n_real; id += 64) {
+            const int32_t item = test_items[t0 + id];
+            int at = -1; // rec.index(item) within the first K
+            for (int idx = K - 1; idx >= 0; --idx)
+                at = rec[idx] == item ? idx : at;
+            if (at >= 0) {
                 hit += 1.0;
-                rr += 1.0 / (double)(idx + 1);
-                dcg += 1.0 / log2((double)(idx + 2));
-                break;
+                rr += 1.0 / (double)(at + 1);
+                dcg += 1.0 / log2((double)(at + 2));
             }
         }
-        idcg += 1.0 / log2((double)(id + 2));
+        hit = wave_sum_f64(hit);
+        rr = wave_sum_f64(rr);
+        dcg = wave_sum_f64(dcg);
+        if (lane == 0) {
+            const double denom = (double)(K < n_real ? (int64_t)K : n_real);
+            hr[(int64_t)q * Bt + r] = hit / denom;
+            mrr[(int64_t)q * Bt + r] = rr;
+            ndcg[(int64_t)q * Bt + r] = dcg / idcg;
+        }
     }
-    const double denom = (double)(K < n_real ? (int64_t)K : n_real);
-    hr[gid] = hit / denom;
-    mrr[gid] = rr;
-    ndcg[gid] = dcg / idcg;
 }
 
-template <int DMAX, int TI> size_t sweep_lds()
+template <int DMAX, int TI, int NW> constexpr size_t sweep_lds()
 {
-    return sizeof(float) * 2 * TI * (DMAX + 4) + sizeof(u64) * 4 * 32 * CAP + sizeof(int) * 4 * 32 * 4;
+    return sizeof(float) * 2 * TI * (DMAX + 4) + sizeof(u64) * NW * 32 * cap_of(NW) + sizeof(int) * NW * 32 * 4;
 }
 
-template <int DMAX, int TI>
+template <int DMAX, int TI, int NW>
 int launch_sweep(crec_ctx *ctx, dim3 grid, hipStream_t st, const float *P, const float *Q, int64_t I, int d,
                  const int32_t *users, int Bt, const int64_t *seen_ptr, const int32_t *seen_items, int K, float sign,
                  int64_t per_split, u64 *part)
 {
-    const size_t lds = sweep_lds<DMAX, TI>();
-    CREC_HIP(ctx, hipFuncSetAttribute((const void *)eval_sweep<DMAX, TI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    constexpr size_t lds = sweep_lds<DMAX, TI, NW>();
+    static_assert(lds <= 160 * 1024, "eval_sweep shape does not fit the LDS");
+    CREC_HIP(ctx, hipFuncSetAttribute((const void *)eval_sweep<DMAX, TI, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds));
     crec_prof_begin(ctx, CREC_K_EVAL_SWEEP, st);
-    hipLaunchKernelGGL((eval_sweep<DMAX, TI>), grid, dim3(256), lds, st, P, Q, I, d, users, Bt, seen_ptr, seen_items, K,
+    hipLaunchKernelGGL((eval_sweep<DMAX, TI, NW>), grid, dim3(NW * 64), lds, st, P, Q, I, d, users, Bt, seen_ptr, seen_items, K,
                        sign, per_split, part);
     crec_prof_end(ctx, st);
     return CREC_OK;
@@ -473,10 +506,16 @@ static int eval_topk_impl(crec_ctx *ctx, const float *P, const float *Q, int64_t
     CREC_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
 
-    const int tile = d > 128 ? 32 : 64;
-    const int user_tiles = (int)crec_ceil_div(Bt, USERS_PER_WG);
+    // shape: 8 waves per workgroup (two per SIMD) when K and the row width leave room for their buffers (measured:
+    // 66 vs 51 % of the MFMA peak at 65536 x 1M x 64, and 0.46 vs 0.67 ms for the ml-1m sweep)
+    const int64_t cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+    const char *shape_env = getenv("CREC_EVAL_SHAPE"); // "8" / "4": force a shape where it is legal (tests, tuning)
+    const bool wide = K <= cap_of(8) - 32 && d <= 128 && (shape_env ? atoi(shape_env) == 8 : Bt > 128);
+    const int tile = wide ? (d > 64 ? 32 : 64) : (d > 128 ? 32 : 64);
+    const int users_per_wg = (wide ? 8 : 4) * 32;
+    const int user_tiles = (int)crec_ceil_div(Bt, users_per_wg);
     const int64_t n_item_tiles = crec_ceil_div(I, tile);
-    int64_t S = crec_ceil_div(2 * (int64_t)(ctx->num_cus > 0 ? ctx->num_cus : 256), user_tiles);
+    int64_t S = crec_ceil_div((wide ? 1 : 2) * cus, user_tiles);
     S = S < 1 ? 1 : (S > MAX_SPLITS ? MAX_SPLITS : S);
     S = S > n_item_tiles ? n_item_tiles : S;
     const int64_t per_split = crec_ceil_div(n_item_tiles, S) * tile;
@@ -487,15 +526,14 @@ static int eval_topk_impl(crec_ctx *ctx, const float *P, const float *Q, int64_t
     u64 *part = (u64 *)ctx->eval_ws.ptr;
     const float sign = ascending ? -1.0f : 1.0f;
     dim3 grid((unsigned)user_tiles, (unsigned)S);
+    const int kk = K | (keep_listed << 16);
     int rc;
-    if (d <= 32)
-        rc = launch_sweep<32, 64>(ctx, grid, st, P, Q, I, d, users, Bt, seen_ptr, seen_items, K | (keep_listed << 16), sign, per_split, part);
-    else if (d <= 64)
-        rc = launch_sweep<64, 64>(ctx, grid, st, P, Q, I, d, users, Bt, seen_ptr, seen_items, K | (keep_listed << 16), sign, per_split, part);
-    else if (d <= 128)
-        rc = launch_sweep<128, 64>(ctx, grid, st, P, Q, I, d, users, Bt, seen_ptr, seen_items, K | (keep_listed << 16), sign, per_split, part);
+#define CREC_SWEEP(DM, TL, W) launch_sweep<DM, TL, W>(ctx, grid, st, P, Q, I, d, users, Bt, seen_ptr, seen_items, kk, sign, per_split, part)
+    if (wide)
+        rc = d <= 32 ? CREC_SWEEP(32, 64, 8) : d <= 64 ? CREC_SWEEP(64, 64, 8) : CREC_SWEEP(128, 32, 8);
     else
-        rc = launch_sweep<256, 32>(ctx, grid, st, P, Q, I, d, users, Bt, seen_ptr, seen_items, K | (keep_listed << 16), sign, per_split, part);
+        rc = d <= 32 ? CREC_SWEEP(32, 64, 4) : d <= 64 ? CREC_SWEEP(64, 64, 4) : d <= 128 ? CREC_SWEEP(128, 64, 4) : CREC_SWEEP(256, 32, 4);
+#undef CREC_SWEEP
     if (rc)
         return rc;
     crec_prof_begin(ctx, CREC_K_EVAL_MERGE, st);
@@ -514,7 +552,7 @@ extern "C" int crec_rank_metrics(crec_ctx *ctx, const int32_t *topk_ids, const i
         return CREC_EINVAL;
     CREC_REQUIRE(ctx, ctx->device >= 0, "host-only ctx: no device bound");
     CREC_REQUIRE(ctx, topk_ids && users && ks && test_ptr && hr && mrr && ndcg, "null argument");
-    CREC_REQUIRE(ctx, nk >= 1 && nk <= 64 && Bt >= 0 && K >= 1, "bad sizes");
+    CREC_REQUIRE(ctx, nk >= 1 && nk <= 64 && Bt >= 0 && K >= 1 && K <= 64, "bad sizes (lists of at most 64 ids)");
     for (int q = 0; q < nk; ++q)
         CREC_REQUIRE(ctx, ks[q] >= 1 && ks[q] <= K, "ks[%d] = %d outside [1, K]", q, ks[q]);
     if (Bt == 0)
@@ -524,9 +562,8 @@ extern "C" int crec_rank_metrics(crec_ctx *ctx, const int32_t *topk_ids, const i
     if (int rc = crec_reserve(ctx, &ctx->ks_dev, sizeof(int32_t) * 64))
         return rc;
     CREC_HIP(ctx, hipMemcpyAsync(ctx->ks_dev.ptr, ks, sizeof(int32_t) * nk, hipMemcpyHostToDevice, st));
-    const int64_t total = (int64_t)nk * Bt;
     crec_prof_begin(ctx, CREC_K_METRICS, st);
-    hipLaunchKernelGGL(rank_metrics_kernel, dim3((unsigned)crec_ceil_div(total, 256)), dim3(256), 0, st, topk_ids, users,
+    hipLaunchKernelGGL(rank_metrics_kernel, dim3((unsigned)crec_ceil_div(Bt, 4)), dim3(256), 0, st, topk_ids, users,
                        Bt, K, (const int32_t *)ctx->ks_dev.ptr, nk, test_ptr, test_items, hr, mrr, ndcg);
     crec_prof_end(ctx, st);
     CREC_HIP(ctx, hipGetLastError());

@@ -152,7 +152,9 @@ def _eval_both(sess, data, P, Q, K, ascending=False, users=None):
 
 @pytest.mark.parametrize("d", [4, 32, 64, 128, 256])
 @pytest.mark.parametrize("ascending", [False, True])
-def test_eval_topk_bit_exact(sess, d, ascending):
+@pytest.mark.parametrize("shape", ["4", "8"])  # waves per workgroup of eval_sweep (8: where K and d allow it)
+def test_eval_topk_bit_exact(sess, d, ascending, shape, monkeypatch):
+    monkeypatch.setenv("CREC_EVAL_SHAPE", shape)
     data = _toy_data(5, 333, 700, 1, 120, test_every=1)
     P, Q = _tables(11, data.user_nums, data.item_nums, d, scale=1.0)
     Q[10] = Q[9]
@@ -169,8 +171,12 @@ def test_eval_topk_edges(sess):
     ui_train = {0: list(range(0, 35)), 1: list(range(I)), 3: [7]}
     data = RankingData(5, I, ui_train, {0: [36], 1: [0], 2: [5], 3: [1], 4: [2]})
     P, Q = _tables(12, 5, I, 16, scale=1.0)
-    for K in (1, 20, 32):
-        ids, sc, oids, oval, _ = _eval_both(sess, data, P, Q, K)
+    for K, shape in ((1, "4"), (1, "8"), (20, "4"), (20, "8"), (24, "8"), (32, "8")):  # K = 32 only has the 4-wave shape
+        os.environ["CREC_EVAL_SHAPE"] = shape
+        try:
+            ids, sc, oids, oval, _ = _eval_both(sess, data, P, Q, K)
+        finally:
+            del os.environ["CREC_EVAL_SHAPE"]
         assert np.array_equal(ids.cpu().numpy(), oids) and np.array_equal(sc.cpu().numpy(), oval)
     ids = ids.cpu().numpy()
     assert (ids[0] >= 0).sum() == 5 and (ids[1] == -1).all() and (ids[2] >= 0).all()
