@@ -149,11 +149,11 @@ def main():
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg[dom],
                            "avg_launch_us": avg_s * 1e6,
-                           "note": "avg_launch_us = HIP-event bracket around each launch minus the mean empty bracket recorded "
-                                   "right behind it on the same stream (an event pair costs ~5.8 us of stream time); rocprofv3 "
-                                   "--kernel-trace reports 13.6 us for the same kernel (profiles/round1_bench_kernel_stats.txt), "
-                                   "which would give frac 0.226.  Tables+slots are 7.5 MB (Infinity-Cache resident): the HBM "
-                                   "fraction is nominal; S-big (synthetic_big) is the HBM-resident form"}
+                           "note": "avg_launch_us = mean over the timed launches of the elapsed time between the two HIP events "
+                                   "attached to each dispatch (hipExtLaunchKernelGGL start/stop events on the launch stream), i.e. "
+                                   "the dispatch's own begin/end timestamps, the quantity rocprofv3 --kernel-trace reports "
+                                   "(profiles/round1_bench_kernel_stats.txt).  Tables+slots are 7.5 MB (Infinity-Cache resident): "
+                                   "the HBM fraction is nominal; S-big (synthetic_big) is the HBM-resident form"}
         step_bytes = alg[dom]
         out["kernels"] = kern
         out["step_algorithmic_GBs"] = step_bytes / (dt / a.steps) / 1e9

@@ -1049,7 +1049,7 @@ template <int LPR, bool FULL> void launch_fused(const StepArgs &a, const IndexWs
     const HeavyArgs hv = heavy_args(a, w, b, hn);
     const int64_t waves = hv.HIu + hv.HIq + crec_ceil_div(a.U, R) + crec_ceil_div(a.I, R);
     crec_prof_begin(a.ctx, CREC_K_STEP_FUSED, a.st);
-    hipLaunchKernelGGL((bpr_step_fused<LPR, FULL>), dim3((unsigned)crec_ceil_div(waves, 4)), dim3(256), 0, a.st, a.cur, a.other,
+    CREC_KLAUNCH(a.ctx, (bpr_step_fused<LPR, FULL>), dim3((unsigned)crec_ceil_div(waves, 4)), dim3(256), 0, a.st, a.cur, a.other,
                        a.d, a.U, a.I, w.u_rowseg + b * w.U, w.u_occ + b * w.B, w.q_rowseg + b * w.I,
                        w.q_occ + b * 2 * w.B, hv, a.xb, a.rowterm, a.h);
     crec_prof_end(a.ctx, a.st);
@@ -1062,12 +1062,12 @@ template <int LPR, bool FULL> void launch_lazy(const StepArgs &a, const IndexWs 
     const int64_t u_waves = hv.HIu + crec_ceil_div(a.U < a.B ? a.U : a.B, R);
     const int64_t q_waves = hv.HIq + crec_ceil_div(a.I < 2 * (int64_t)a.B ? a.I : 2 * (int64_t)a.B, R);
     crec_prof_begin(a.ctx, CREC_K_USER_SIDE, a.st);
-    hipLaunchKernelGGL((bpr_side_lazy<LPR, 0, FULL>), dim3((unsigned)crec_ceil_div(u_waves, 4)), dim3(256), 0, a.st, a.cur, a.d,
+    CREC_KLAUNCH(a.ctx, (bpr_side_lazy<LPR, 0, FULL>), dim3((unsigned)crec_ceil_div(u_waves, 4)), dim3(256), 0, a.st, a.cur, a.d,
                        w.n_u + b, w.u_rows + b * w.B, w.u_seg + b * (w.B + 1), w.u_occ + b * w.B, hv.hn + 1, hv.u_hitems,
                        hv.HIu, hv.u_hrows, hv.tickets, a.partial, a.contrib, a.xb, a.rowterm, a.h);
     crec_prof_end(a.ctx, a.st);
     crec_prof_begin(a.ctx, CREC_K_ITEM_SIDE, a.st);
-    hipLaunchKernelGGL((bpr_side_lazy<LPR, 2, FULL>), dim3((unsigned)crec_ceil_div(q_waves, 4)), dim3(256), 0, a.st, a.cur, a.d,
+    CREC_KLAUNCH(a.ctx, (bpr_side_lazy<LPR, 2, FULL>), dim3((unsigned)crec_ceil_div(q_waves, 4)), dim3(256), 0, a.st, a.cur, a.d,
                        w.n_q + b, w.q_rows + b * 2 * w.B, w.q_seg + b * (2 * w.B + 1), w.q_occ + b * 2 * w.B, hv.hn + 3,
                        hv.q_hitems, hv.HIq, hv.q_hrows, hv.tickets + hv.HRu_max, a.partial + (int64_t)hv.HIu * a.d, a.contrib,
                        a.xb, a.rowterm + a.B, a.h);
@@ -1201,7 +1201,7 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
         const int64_t t0 = b0 * B, n_chunk = (N - t0) < nbc * B ? (N - t0) : nbc * B;
         IndexWs w = layout_index(ctx->idx_ws.ptr, nbc, B, t->U, t->I, dense, CH);
         crec_prof_begin(ctx, CREC_K_INDEX, st);
-        hipLaunchKernelGGL(bpr_index_batches, dim3((unsigned)(2 * nbc)), dim3(PREP_THREADS), lds, st, u + t0, i + t0,
+        CREC_KLAUNCH(ctx, bpr_index_batches, dim3((unsigned)(2 * nbc)), dim3(PREP_THREADS), lds, st, u + t0, i + t0,
                            j + t0, n_chunk, B, w);
         crec_prof_end(ctx, st);
         std::vector<int32_t> hn((size_t)nbc * 4);
@@ -1227,7 +1227,7 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
                 crec_prof_begin(ctx, CREC_K_ADAM_DENSE, st);
                 const int64_t n4 = (int64_t)nq / 4;
                 const unsigned blocks = (unsigned)(crec_ceil_div(n4, 256) < 2048 ? crec_ceil_div(n4, 256) : 2048);
-                hipLaunchKernelGGL(bpr_adam_dense, dim3(blocks), dim3(256), 0, st, t->Q, t->mQ, t->vQ, (const float *)dq, n4,
+                CREC_KLAUNCH(ctx, bpr_adam_dense, dim3(blocks), dim3(256), 0, st, t->Q, t->mQ, t->vQ, (const float *)dq, n4,
                                    a.h);
                 crec_prof_end(ctx, st);
             }
@@ -1242,7 +1242,7 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
             opt->step += 1;
         }
         crec_prof_begin(ctx, CREC_K_REDUCE_LOSS, st);
-        hipLaunchKernelGGL(bpr_reduce_loss, dim3((unsigned)nbc), dim3(256), 0, st, (const float *)ctx->loss_ws.ptr,
+        CREC_KLAUNCH(ctx, bpr_reduce_loss, dim3((unsigned)nbc), dim3(256), 0, st, (const float *)ctx->loss_ws.ptr,
                            loss_stride, n_chunk, B, dense ? t->U + t->I : (int64_t)0, (const int32_t *)w.n_u,
                            (const int32_t *)w.n_q, opt->reg, loss_per_batch + b0);
         crec_prof_end(ctx, st);

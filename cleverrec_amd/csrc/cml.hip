@@ -334,7 +334,7 @@ int crec_cml_train_epoch(crec_ctx *ctx, const crec_cml *m, crec_adam *opt, const
         crec_prof_begin(ctx, CREC_K_CML_INSTANCES, st);
 #define CREC_CML(L)                                                                                                          \
     case L:                                                                                                                  \
-        hipLaunchKernelGGL((cml_instances<L>), grid, dim3(256), 0, st, (const float *)m->P.var, (const float *)m->Q.var, d,  \
+        CREC_KLAUNCH(ctx, (cml_instances<L>), grid, dim3(256), 0, st, (const float *)m->P.var, (const float *)m->Q.var, d,  \
                            u + t0, i + t0, neg + t0 * K, nbt, (int)K, m->margin, (float)I / (float)K, c_p, c_q, slots,        \
                            li_b, aux);                                                                                       \
         break;

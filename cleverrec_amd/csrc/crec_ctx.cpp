@@ -51,45 +51,45 @@ void crec_prof_begin(crec_ctx *ctx, int cls, hipStream_t st)
 {
     if (!ctx->prof.on)
         return;
-    crec_profile::rec r{cls, prof_event(ctx), prof_event(ctx)};
-    (void)hipEventRecord(r.a, st);
+    crec_profile::rec r{cls, prof_event(ctx), prof_event(ctx), false};
     ctx->prof.pending.push_back(r);
+    ctx->prof.open = true;
+    (void)st;
+}
+
+bool crec_prof_events(crec_ctx *ctx, hipEvent_t *a, hipEvent_t *b)
+{
+    if (!ctx || !ctx->prof.on || !ctx->prof.open || ctx->prof.pending.empty() || ctx->prof.pending.back().ext)
+        return false;
+    ctx->prof.pending.back().ext = true;
+    *a = ctx->prof.pending.back().a;
+    *b = ctx->prof.pending.back().b;
+    return true;
 }
 
 void crec_prof_end(crec_ctx *ctx, hipStream_t st)
 {
-    if (!ctx->prof.on || ctx->prof.pending.empty() || ctx->prof.pending.back().cls == CREC_K_COUNT)
+    if (!ctx->prof.on || !ctx->prof.open)
         return;
-    (void)hipEventRecord(ctx->prof.pending.back().b, st);
-    crec_profile::rec cal{CREC_K_COUNT, prof_event(ctx), prof_event(ctx)};
-    (void)hipEventRecord(cal.a, st);
-    (void)hipEventRecord(cal.b, st);
-    ctx->prof.pending.push_back(cal);
+    ctx->prof.open = false;
+    if (ctx->prof.pending.back().ext)
+        return;
+    // no launch claimed the events (a helper launched with plain hipLaunchKernelGGL): drop the record
+    ctx->prof.pool.push_back(ctx->prof.pending.back().a);
+    ctx->prof.pool.push_back(ctx->prof.pending.back().b);
+    ctx->prof.pending.pop_back();
+    (void)st;
 }
 
-// Two events recorded back to back are not zero time apart: the bracket itself costs stream time.
-// Every kernel bracket is therefore followed by an EMPTY bracket on the same (busy) stream; the mean
-// empty-bracket time of a flush is subtracted from its kernel brackets, so the per-kernel figures are
-// comparable with rocprofv3's kernel durations.
+// Per-kernel time = elapsed time between the two events attached to each dispatch (its begin / end timestamps).
 int crec_prof_flush(crec_ctx *ctx, hipStream_t st)
 {
     if (!ctx->prof.on || ctx->prof.pending.empty())
         return CREC_OK;
     CREC_HIP(ctx, hipStreamSynchronize(st));
-    double cal = 0;
-    int ncal = 0;
     for (auto &r : ctx->prof.pending) {
         float ms = 0.f;
-        if (r.cls == CREC_K_COUNT && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
-            cal += ms;
-            ++ncal;
-        }
-    }
-    ctx->prof.overhead_ms = ncal ? (float)(cal / ncal) : 0.f;
-    for (auto &r : ctx->prof.pending) {
-        float ms = 0.f;
-        if (r.cls != CREC_K_COUNT && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
-            ms -= ctx->prof.overhead_ms;
+        if (r.ext && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
             ctx->prof.total_ms[r.cls] += ms > 0.f ? ms : 0.f;
             ctx->prof.launches[r.cls] += 1;
         }
@@ -97,6 +97,7 @@ int crec_prof_flush(crec_ctx *ctx, hipStream_t st)
         ctx->prof.pool.push_back(r.b);
     }
     ctx->prof.pending.clear();
+    ctx->prof.open = false;
     return CREC_OK;
 }
 
@@ -107,7 +108,6 @@ int crec_profile_enable(crec_ctx *ctx, int on)
     if (!ctx)
         return CREC_EINVAL;
     ctx->prof.on = on != 0;
-    ctx->prof.overhead_ms = -1.f;
     for (int k = 0; k < CREC_K_COUNT; ++k) {
         ctx->prof.total_ms[k] = 0;
         ctx->prof.launches[k] = 0;

@@ -1,6 +1,7 @@
 // Internal declarations shared by the translation units of libcrec.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdarg>
 #include <cstdint>
@@ -48,11 +49,12 @@ enum crec_kernel_class {
 
 struct crec_profile {
     bool on = false;
-    float overhead_ms = -1.f; // stream time of an empty event bracket, measured at the first flush
     struct rec {
         int cls;
         hipEvent_t a, b;
+        bool ext; // a / b were handed to hipExtLaunchKernelGGL: they carry the dispatch's own begin / end timestamps
     };
+    bool open = false; // between crec_prof_begin and crec_prof_end
     std::vector<rec> pending;
     std::vector<hipEvent_t> pool;
     double total_ms[CREC_K_COUNT] = {0};
@@ -84,6 +86,19 @@ int crec_fail(crec_ctx *ctx, int code, const char *fmt, ...);
 // profiling brackets: no-ops unless crec_profile_enable(ctx, 1)
 void crec_prof_begin(crec_ctx *ctx, int cls, hipStream_t st);
 void crec_prof_end(crec_ctx *ctx, hipStream_t st);
+// inside a begin/end bracket with profiling on: the bracket's two events, to be attached to the dispatch itself
+bool crec_prof_events(crec_ctx *ctx, hipEvent_t *a, hipEvent_t *b);
+// kernel launch inside a crec_prof_begin / crec_prof_end bracket.  Profiling on: the launch carries the bracket's
+// events (hipExtLaunchKernelGGL), so the measured time is the dispatch's begin-to-end time -- the same timestamps
+// rocprofv3 --kernel-trace reports -- not stream time between two separate event records.
+#define CREC_KLAUNCH(ctx, kernel, grid, block, lds, st, ...)                                        \
+    do {                                                                                            \
+        hipEvent_t ea_, eb_;                                                                        \
+        if (crec_prof_events(ctx, &ea_, &eb_))                                                      \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, st, ea_, eb_, 0, __VA_ARGS__);          \
+        else                                                                                        \
+            hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                          \
+    } while (0)
 int crec_prof_flush(crec_ctx *ctx, hipStream_t st);
 int crec_reserve(crec_ctx *ctx, crec_devbuf *b, size_t bytes);
 

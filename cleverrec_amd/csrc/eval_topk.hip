@@ -462,7 +462,7 @@ int launch_sweep(crec_ctx *ctx, dim3 grid, hipStream_t st, const float *P, const
     CREC_HIP(ctx, hipFuncSetAttribute((const void *)eval_sweep<DMAX, TI, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds));
     crec_prof_begin(ctx, CREC_K_EVAL_SWEEP, st);
-    hipLaunchKernelGGL((eval_sweep<DMAX, TI, NW>), grid, dim3(NW * 64), lds, st, P, Q, I, d, users, Bt, seen_ptr, seen_items, K,
+    CREC_KLAUNCH(ctx, (eval_sweep<DMAX, TI, NW>), grid, dim3(NW * 64), lds, st, P, Q, I, d, users, Bt, seen_ptr, seen_items, K,
                        sign, per_split, part);
     crec_prof_end(ctx, st);
     return CREC_OK;
@@ -537,7 +537,7 @@ static int eval_topk_impl(crec_ctx *ctx, const float *P, const float *Q, int64_t
     if (rc)
         return rc;
     crec_prof_begin(ctx, CREC_K_EVAL_MERGE, st);
-    hipLaunchKernelGGL(eval_merge, dim3((unsigned)Bt), dim3(64), 0, st, (const u64 *)part, (int)S, (int)K, sign,
+    CREC_KLAUNCH(ctx, eval_merge, dim3((unsigned)Bt), dim3(64), 0, st, (const u64 *)part, (int)S, (int)K, sign,
                        topk_ids, topk_scores);
     crec_prof_end(ctx, st);
     CREC_HIP(ctx, hipGetLastError());
@@ -563,7 +563,7 @@ extern "C" int crec_rank_metrics(crec_ctx *ctx, const int32_t *topk_ids, const i
         return rc;
     CREC_HIP(ctx, hipMemcpyAsync(ctx->ks_dev.ptr, ks, sizeof(int32_t) * nk, hipMemcpyHostToDevice, st));
     crec_prof_begin(ctx, CREC_K_METRICS, st);
-    hipLaunchKernelGGL(rank_metrics_kernel, dim3((unsigned)crec_ceil_div(Bt, 4)), dim3(256), 0, st, topk_ids, users,
+    CREC_KLAUNCH(ctx, rank_metrics_kernel, dim3((unsigned)crec_ceil_div(Bt, 4)), dim3(256), 0, st, topk_ids, users,
                        Bt, K, (const int32_t *)ctx->ks_dev.ptr, nk, test_ptr, test_items, hr, mrr, ndcg);
     crec_prof_end(ctx, st);
     CREC_HIP(ctx, hipGetLastError());

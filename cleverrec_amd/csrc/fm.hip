@@ -184,13 +184,13 @@ __global__ __launch_bounds__(1024) void rmse_mae_kernel(const float *__restrict_
 }
 
 template <bool TRAIN>
-void launch_instances(int lpr, dim3 grid, hipStream_t st, const float *w0, const float *wi, const float *vif, int d,
+void launch_instances(crec_ctx *ctx, int lpr, dim3 grid, hipStream_t st, const float *w0, const float *wi, const float *vif, int d,
                       const int32_t *x_idx, const float *x_val, const float *y, int n, int F, float *y_pre, float *c_v,
                       float *c_w, float *sq_err, float *w0_partial, FmLossJob prev = FmLossJob{})
 {
 #define CREC_FM(L)                                                                                                      \
     case L:                                                                                                             \
-        hipLaunchKernelGGL((fm_instances<L, TRAIN>), grid, dim3(256), 0, st, w0, wi, vif, d, x_idx, x_val, y, n, F, y_pre, \
+        CREC_KLAUNCH(ctx, (fm_instances<L, TRAIN>), grid, dim3(256), 0, st, w0, wi, vif, d, x_idx, x_val, y, n, F, y_pre, \
                            c_v, c_w, sq_err, w0_partial, prev);                                                         \
         break;
     switch (lpr) {
@@ -238,7 +238,7 @@ int crec_fm_predict(crec_ctx *ctx, const crec_fm *m, const int32_t *x_idx, const
         lpr <<= 1;
     const int G = 64 / lpr;
     const int64_t waves = crec_ceil_div(N, G);
-    launch_instances<false>(lpr, dim3((unsigned)crec_ceil_div(waves, 4)), st, m->w0.var, m->wi.var, m->vif.var, d, x_idx, x_val,
+    launch_instances<false>(ctx, lpr, dim3((unsigned)crec_ceil_div(waves, 4)), st, m->w0.var, m->wi.var, m->vif.var, d, x_idx, x_val,
                             nullptr, (int)N, F, y_pre, nullptr, nullptr, nullptr, nullptr);
     CREC_HIP(ctx, hipGetLastError());
     return CREC_OK;
@@ -301,7 +301,7 @@ int crec_fm_train_epoch(crec_ctx *ctx, const crec_fm *m, crec_adam *opt, const i
         const int waves = (int)crec_ceil_div(nbt, G);
         float *se = (float *)((char *)sq_err + (b & 1) * up(seb));
         crec_prof_begin(ctx, CREC_K_FM_INSTANCES, st);
-        launch_instances<true>(lpr, dim3((unsigned)crec_ceil_div(waves, 4) + (prev.out ? 1u : 0u)), st, m->w0.var, m->wi.var,
+        launch_instances<true>(ctx, lpr, dim3((unsigned)crec_ceil_div(waves, 4) + (prev.out ? 1u : 0u)), st, m->w0.var, m->wi.var,
                                m->vif.var, d, x_idx + t0 * F, x_val + t0 * F, y + t0, nbt, F, y_pre + t0, c_v, c_w, se,
                                w0_partial, prev);
         crec_prof_end(ctx, st);

@@ -520,7 +520,7 @@ extern "C" int crec_ncf_train_epoch(crec_ctx *ctx, const crec_ncf *mdl, crec_ada
         o.beta2 = opt->beta2;
         o.eps = opt->eps;
         crec_prof_begin(ctx, CREC_K_NCF_TILE, st);
-        hipLaunchKernelGGL(ncf_tile, dim3((unsigned)crec_ceil_div(nbt, T)), dim3(NT), lds, st, d, u + t0, i + t0, y + t0, nbt,
+        CREC_KLAUNCH(ctx, ncf_tile, dim3((unsigned)crec_ceil_div(nbt, T)), dim3(NT), lds, st, d, u + t0, i + t0, y + t0, nbt,
                            c_pg, c_qg, c_pm, c_qm, loss_inst + t0, partial);
         crec_prof_end(ctx, st);
         // every parameter update of the step in one launch when the tables share a row-width class
@@ -562,7 +562,7 @@ extern "C" int crec_ncf_train_epoch(crec_ctx *ctx, const crec_ncf *mdl, crec_ada
         opt->step += 1;
     }
     crec_prof_begin(ctx, CREC_K_REDUCE_LOSS, st);
-    hipLaunchKernelGGL(ncf_reduce_loss, dim3((unsigned)nb), dim3(256), 0, st, (const float *)loss_inst, N, B, loss_per_batch);
+    CREC_KLAUNCH(ctx, ncf_reduce_loss, dim3((unsigned)nb), dim3(256), 0, st, (const float *)loss_inst, N, B, loss_per_batch);
     crec_prof_end(ctx, st);
 #ifdef NCF_STAMPS
     {

@@ -189,7 +189,7 @@ int crec_ncf_scores(crec_ctx *ctx, const crec_ncf *mdl, const int32_t *users, in
     }
     const dim3 grid((unsigned)crec_ceil_div(I, TI), (unsigned)crec_ceil_div(Bt, PT / TI));
     crec_prof_begin(ctx, CREC_K_NCF_SCORES, st);
-    hipLaunchKernelGGL(ncf_pair_logits, grid, dim3(PT), lds, st, d, users, (int)Bt, I, (const float *)Au, (const float *)Bi,
+    CREC_KLAUNCH(ctx, ncf_pair_logits, grid, dim3(PT), lds, st, d, users, (int)Bt, I, (const float *)Au, (const float *)Bi,
                        logits);
     crec_prof_end(ctx, st);
     CREC_HIP(ctx, hipGetLastError());

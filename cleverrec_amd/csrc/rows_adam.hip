@@ -306,7 +306,7 @@ int crec_rows_index(crec_ctx *ctx, const int32_t *idx, int64_t n_total, int32_t 
     const size_t lds = sizeof(unsigned long long) * n_pad;
     CREC_HIP(ctx, hipFuncSetAttribute((const void *)rows_index_batches, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     crec_prof_begin(ctx, CREC_K_ROWS_INDEX, st);
-    hipLaunchKernelGGL(rows_index_batches, dim3((unsigned)(nb * chunks)), dim3(IDX_THREADS), lds, st, idx, n_total, per_batch,
+    CREC_KLAUNCH(ctx, rows_index_batches, dim3((unsigned)(nb * chunks)), dim3(IDX_THREADS), lds, st, idx, n_total, per_batch,
                        chunks, rows, out->order, out->rowseg);
     crec_prof_end(ctx, st);
     return CREC_OK;
@@ -324,7 +324,7 @@ int crec_rows_apply(crec_ctx *ctx, const crec_rows_table &t, const crec_rows_ind
     crec_prof_begin(ctx, CREC_K_ROWS_APPLY, st);
 #define CREC_RA(L)                                                                                   \
     case L:                                                                                          \
-        hipLaunchKernelGGL((rows_apply<L>), grid, block, 0, st, t, rs, ord, contrib, dense_grad, row_out, o, (int)ix.chunks); \
+        CREC_KLAUNCH(ctx, (rows_apply<L>), grid, block, 0, st, t, rs, ord, contrib, dense_grad, row_out, o, (int)ix.chunks); \
         break;
     switch (lpr) {
         CREC_RA(1)
@@ -344,7 +344,7 @@ int crec_small_adam_dense(crec_ctx *ctx, float *var, float *m, float *v, const f
                           int64_t stride, int n, const crec_rows_opt &o, hipStream_t st)
 {
     crec_prof_begin(ctx, CREC_K_SMALL_ADAM, st);
-    hipLaunchKernelGGL(small_adam_dense, dim3((unsigned)crec_ceil_div(n, 64)), dim3(64 * SAD_SL), 0, st,
+    CREC_KLAUNCH(ctx, small_adam_dense, dim3((unsigned)crec_ceil_div(n, 64)), dim3(64 * SAD_SL), 0, st,
                        crec_small_job{var, m, v, partial, n_partials, stride, n, o});
     crec_prof_end(ctx, st);
     return CREC_OK;
@@ -375,7 +375,7 @@ int crec_apply_all(crec_ctx *ctx, crec_apply_set &a, hipStream_t st)
     crec_prof_begin(ctx, CREC_K_ROWS_APPLY, st);
 #define CREC_AA(L)                                                                  \
     case L:                                                                         \
-        hipLaunchKernelGGL((apply_all<L>), dim3((unsigned)blocks), dim3(256), 0, st, a); \
+        CREC_KLAUNCH(ctx, (apply_all<L>), dim3((unsigned)blocks), dim3(256), 0, st, a); \
         break;
     switch (lpr) {
         CREC_AA(1)

@@ -24,6 +24,23 @@ for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_WAVE_CYCL
   n=$(echo $c | cut -d" " -f1)
   rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$n -- python $ROOT/bench.py --steps 100 --warmup 10 --no-extras > /dev/null 2>&1 || echo "pmc $n failed"
 done
+# the HBM-resident form of the path (S-big) and the catalogue-scale eval: kernel-trace stats only
+for leg in "big tools/bench_big.py --steps 200" "eval_big tools/bench_eval_big.py --dim 128"; do
+  set -- $leg; name=$1; shift
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$name -- python $ROOT/$@ > $OUT/${name}_under_trace.json 2>/dev/null
+  f=$(find $OUT/trace_$name -name "*kernel_stats.csv" | head -1)
+  python - "$f" "$*" > $OUT/${name}_kernel_stats.txt <<'PY'
+import csv, re, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+print("rocprofv3 --kernel-trace --stats -- python " + sys.argv[2])
+print("%-60s %8s %14s %12s %8s" % ("kernel", "calls", "total_ns", "avg_ns", "pct"))
+for r in rows[:12]:
+    m = re.search(r"(bpr_\w+|eval_\w+|rank_metrics\w*)(<[^>]*>)?", r["Name"])
+    name = (m.group(0) if m else r["Name"].split("(")[0])[:60]
+    print("%-60s %8s %14s %12.1f %8s" % (name, r["Calls"], r["TotalDurationNs"], float(r["AverageNs"]), r["Percentage"]))
+PY
+  rm -rf $OUT/trace_$name/*/*kernel_trace.csv
+done
 cd $ROOT && python tools/pmc_summary.py $OUT/pmc_* > $OUT/pmc_summary.txt
 rm -rf $OUT/trace/*/*kernel_trace.csv
-cat $OUT/kernel_stats.txt; cat $OUT/pmc_summary.txt
+cat $OUT/kernel_stats.txt $OUT/big_kernel_stats.txt $OUT/eval_big_kernel_stats.txt; cat $OUT/pmc_summary.txt
