@@ -95,6 +95,28 @@ def test_neumf_config3_shape(sess):
     _compare(st, om, names)
 
 
+@pytest.mark.parametrize("d,layers", [(32, [16, 8]), (8, [40, 20, 10]), (12, [24])])
+def test_neumf_mixed_widths(sess, d, layers):
+    """GMF and MLP tables of different row-width classes (two merged-update launches), tower widths that are not
+    multiples of the 16 x 16 x 4 MFMA tile (edge blocks, K tails), a ragged last batch and a ragged last tile."""
+    U, I, B = 70, 50, 200
+    g = np.random.Generator(np.random.PCG64(100 + d))
+    L0 = layers[0]
+    Pg, Qg, Pm, Qm = _rand(g, U, d), _rand(g, I, d), _rand(g, U, L0 // 2), _rand(g, I, L0 // 2)
+    Ws, bs, last = _tower(g, L0, len(layers))
+    h = _rand(g, d + last, scale=0.3)
+    u, i, y = _instances(4, U, I, 2 * B + 77)
+    st = runtime.NcfState(sess, "NeuMF", {"P_gmf": Pg, "Q_gmf": Qg, "P_mlp": Pm, "Q_mlp": Qm}, Ws, bs, h, lr=1e-3,
+                          reg_gmf=1e-2, reg_mlp=1e-3)
+    om = MT.NeuMF(Pg, Qg, Pm, Qm, Ws, bs, h, lr=1e-3, reg1=1e-2, reg2=1e-3)
+    loss = st.train_epoch(sess.to_dev(u), sess.to_dev(i), sess.to_dev(y), B).cpu().numpy()
+    ol = [om.step(u[b * B:(b + 1) * B], i[b * B:(b + 1) * B], y[b * B:(b + 1) * B]) for b in range(len(loss))]
+    np.testing.assert_allclose(loss, ol, rtol=1e-5)
+    names = [(st.t[k], k) for k in ("P_gmf", "Q_gmf", "P_mlp", "Q_mlp")] + [(st.h, "h_neumf")]
+    names += [(st.W[k], "W_%d" % k) for k in range(len(layers))] + [(st.b[k], "b_%d" % k) for k in range(len(layers))]
+    _compare(st, om, names)
+
+
 def test_gmf_class_surface_train_and_eval(sess, tmp_path):
     """GMF(sess, data, configs, logger): pointwise train_model() on the np.random stream, then the
     full-catalogue ranking (sigmoid((pu*h).q), GMF.py:40,57) against the oracle's predict()."""
