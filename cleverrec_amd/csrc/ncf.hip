@@ -28,8 +28,6 @@ constexpr int NT = NCF_NT;   // threads per workgroup
 constexpr int NW = NT / 64;  // waves per workgroup
 constexpr int RW = T / NW;   // tile rows owned by one wave in the row-wise phases
 
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-
 __device__ inline float sigmoidf_(float z) { return 1.0f / (1.0f + expf(-z)); }
 
 __device__ __forceinline__ float wave_sum(float v)
@@ -38,89 +36,6 @@ __device__ __forceinline__ float wave_sum(float v)
     for (int off = 1; off < 64; off <<= 1)
         v += __shfl_xor(v, off, 64);
     return v;
-}
-
-// C[M x N] = A[M x K] * B[K x N] on v_mfma_f32_16x16x4_f32: 16x16 output blocks dealt round-robin to the waves.
-// fa(m, k) / fb(k, n) read the operands (LDS), fs(m, n, v) consumes an output; the edges of M / N / K are handled
-// here (fa / fb only ever see valid indices).
-// Lane l feeds A[l & 15][k_l] and B[k_l][l & 15] and the instruction sums over the four k_l of the quarter-waves
-// q = l >> 4; output register j of lane l is C[4 * q + j][l & 15].  Which four k an instruction covers is free as long
-// as A and B agree, so K is walked in chunks of 4*S columns with k_l = chunk + s + S*q in step s: with S = 16 and row
-// strides that are odd, a half-wave's 32 operand reads fall in 32 different LDS banks whether k runs along the row
-// (A of the forward pass) or down the column (B).  The order of the sum is fixed: chunks ascending, s ascending, q
-// ascending inside the instruction.
-template <int S, class FA, class FB>
-__device__ __forceinline__ f32x4 gemm_chunk(f32x4 acc, int k0, int mc, int nc, int q, FA fa, FB fb)
-{
-    float a[S], b[S];
-#pragma unroll
-    for (int s = 0; s < S; ++s) { // all 2*S operand reads in flight together
-        a[s] = fa(mc, k0 + s + S * q);
-        b[s] = fb(k0 + s + S * q, nc);
-    }
-    __builtin_amdgcn_sched_barrier(0); // keep the reads batched: the scheduler would otherwise pair each with its MFMA
-#pragma unroll
-    for (int s = 0; s < S; ++s)
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc, 0, 0, 0);
-    return acc;
-}
-
-template <class FA, class FB, class FS>
-__device__ __forceinline__ void tile_gemm(int M, int N, int K, FA fa, FB fb, FS fs)
-{
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l16 = lane & 15, q = lane >> 4;
-    const int nbn = (N + 15) >> 4, nblk = ((M + 15) >> 4) * nbn;
-    for (int blk = wave; blk < nblk; blk += NW) {
-        const int m0 = (blk / nbn) << 4, n0 = (blk % nbn) << 4;
-        // rows / columns past the edge read a clamped (valid) address: they only feed outputs that are dropped
-        // below, so no predicate -- a predicated LDS read costs a branch each
-        const int ni = n0 + l16;
-        const int mc = (m0 + l16) < M ? (m0 + l16) : M - 1, nc = ni < N ? ni : N - 1;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        int k = 0;
-        for (; k + 64 <= K; k += 64)
-            acc = gemm_chunk<16>(acc, k, mc, nc, q, fa, fb);
-        if (k + 32 <= K) {
-            acc = gemm_chunk<8>(acc, k, mc, nc, q, fa, fb);
-            k += 32;
-        }
-        if (k + 16 <= K) {
-            acc = gemm_chunk<4>(acc, k, mc, nc, q, fa, fb);
-            k += 16;
-        }
-        for (; k < K; k += 4) { // K tail: columns past the end contribute zeros
-            const bool kok = k + q < K;
-            const int kc = kok ? k + q : K - 1;
-            const float a = fa(mc, kc), b = fb(kc, nc);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kok ? a : 0.f, b, acc, 0, 0, 0);
-        }
-        if (ni < N) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (m0 + q * 4 + j < M)
-                    fs(m0 + q * 4 + j, ni, acc[j]);
-        }
-    }
-}
-
-// stage a row-major [rows x cols] weight matrix in LDS with row stride cols + 1
-__device__ __forceinline__ void stage_weights(float *__restrict__ Wl, const float *__restrict__ W, int rows, int cols)
-{
-    const int n = rows * cols, ws = cols + 1;
-    if ((cols & (cols - 1)) == 0 && cols >= 4 && ((uintptr_t)W & 15) == 0) { // the usual case: no division, 16 B loads
-        const int sh = __builtin_ctz(cols);
-        const float4 *W4 = (const float4 *)W;
-#pragma unroll 8
-        for (int o4 = threadIdx.x; o4 < n / 4; o4 += NT) {
-            const float4 w = W4[o4];
-            float *dst = Wl + ((o4 * 4) >> sh) * ws + ((o4 * 4) & (cols - 1));
-            dst[0] = w.x, dst[1] = w.y, dst[2] = w.z, dst[3] = w.w;
-        }
-    } else {
-#pragma unroll 4
-        for (int o = threadIdx.x; o < n; o += NT)
-            Wl[(o / cols) * ws + (o % cols)] = W[o];
-    }
 }
 
 // dynamic LDS (every 2-D array has its row stride padded by one float, so that the MFMA operand reads -- 16 rows at
@@ -210,7 +125,7 @@ __global__ __launch_bounds__(NT) void ncf_tile(NcfDev m, const int32_t *__restri
     for (int k = 0; k < L; ++k) {
         for (int c = tid; c < W_(k + 1); c += NT)
             BL_(k)[c] = m.small[m.b_off[k] + c];
-        stage_weights(WL_(k), m.small + m.w_off[k], W_(k), W_(k + 1));
+        stage_weights<NT>(WL_(k), m.small + m.w_off[k], W_(k), W_(k + 1));
     }
     __syncthreads();
     STAMP(); // 1: parameters staged
@@ -263,7 +178,7 @@ __global__ __launch_bounds__(NT) void ncf_tile(NcfDev m, const int32_t *__restri
         const float *b = BL_(k), *Ak = A_(k), *Wl = WL_(k);
         float *An = A_(k + 1);
         __syncthreads(); // A[k] complete
-        tile_gemm(
+        tile_gemm<NW>(
             T, kout, kin, [&](int r, int kk) { return Ak[r * lda + kk]; }, [&](int kk, int c) { return Wl[kk * ws + c]; },
             [&](int r, int c, float s) {
                 s += b[c];
@@ -372,7 +287,7 @@ __global__ __launch_bounds__(NT) void ncf_tile(NcfDev m, const int32_t *__restri
             float *pw = part + m.w_off[k];
             __syncthreads(); // D[k+1] complete
             // dW_k[kk][c] = sum_r A[k][r][kk] * D[k+1][r][c]   (rows past nr carry D = 0)
-            tile_gemm(
+            tile_gemm<NW>(
                     kin, kout, T, [&](int kk, int r) { return Ak[r * lda + kk]; }, [&](int r, int c) { return Dn[r * ldd + c]; },
                     [&](int kk, int c, float s) { pw[kk * kout + c] = s; });
             for (int c = tid; c < kout; c += NT) { // db_k[c] = sum_r D[k+1][r][c]
@@ -386,14 +301,14 @@ __global__ __launch_bounds__(NT) void ncf_tile(NcfDev m, const int32_t *__restri
             // delta of the layer below: through its ReLU into D[k] (k > 0), or dL/dX = the contribution rows of the
             // two MLP tables straight to HBM (k == 0)
             if (k > 0)
-                tile_gemm(
+                tile_gemm<NW>(
                     T, kin, kout, [&](int r, int c) { return Dn[r * ldd + c]; }, [&](int c, int kk) { return Wl[kk * ws + c]; },
                     [&](int r, int kk, float s) {
                         const int o = r * lda + kk;
                         Dk[o] = Ak[o] > 0.f ? s : 0.f;
                     });
             else
-                tile_gemm(
+                tile_gemm<NW>(
                     T, kin, kout, [&](int r, int c) { return Dn[r * ldd + c]; }, [&](int c, int kk) { return Wl[kk * ws + c]; },
                     [&](int r, int kk, float s) {
                         if (r < nr) {

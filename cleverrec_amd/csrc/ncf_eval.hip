@@ -6,8 +6,8 @@
 //
 // The first tower layer is linear in concat(pm_u, qm_i): (pm_u W0[:h]) + (qm_i W0[h:] + b0), so it is
 // computed once per user and once per item (ncf_first_layer) and a pair only adds the two and applies ReLU.
-// ncf_pair_logits: one thread per (user, item) pair, activations in LDS ([k][thread]: conflict-free),
-// weights read with wave-uniform addresses.  The logit, not its sigmoid, is written (same ranking).
+// ncf_pair_logits: a workgroup per 4 users walking tiles of 64 items; the remaining layers run on the fp32 matrix cores
+// between LDS activation buffers.  The logit, not its sigmoid, is written (same ranking).
 // topk_rows: one wave per user over a row of the score matrix staged in LDS: seen items are struck out,
 // then K rounds of wave-wide arg-max (ties: lower item id).
 #include "crec_internal.h"
@@ -15,8 +15,10 @@
 
 namespace {
 
-constexpr int PT = 256; // pairs (threads) per workgroup: 4 users x 64 items
-constexpr int TI = 64;
+constexpr int PT = 512; // threads per workgroup (two waves per SIMD)
+constexpr int TI = 64;  // items per tile
+constexpr int TU = 4;   // users per tile (PT == 2 * TU * TI: two threads per pair in the GMF part)
+constexpr int TP = TU * TI; // (user, item) pairs per tile
 
 // out[r][o] = sum_k X[row_id(r)][k] * W[(k0 + k)][o] (+ b[o]);  rows = users (gathered) or all items
 __global__ void ncf_first_layer(const float *__restrict__ X, const int32_t *__restrict__ ids, int64_t rows, int hm,
@@ -35,51 +37,197 @@ __global__ void ncf_first_layer(const float *__restrict__ X, const int32_t *__re
     out[gid] = s;
 }
 
+// A workgroup owns TU users and walks item tiles of TI rows: a tile is TP = TU x TI pairs, pair p = (p / TI, p % TI).
+//   A_1[p] = relu(Au[user] + Bi[item]) (first layer, precomputed per user and per item) is never stored: it is formed
+//   on the fly as the A operand of the next layer's product.  Every further layer is a [TP x w] x [w x w/2] product
+//   on v_mfma_f32_16x16x4_f32 (tile_gemm, ncf_common.h) between LDS activation buffers.  Weights, biases, h and
+//   the users' rows are staged in LDS once per workgroup; a tile's Bi / Q_gmf rows are prefetched into registers
+//   while the previous tile is computed.  The GMF part is a dot product per pair against the tile's Q_gmf rows.
+//   The logit, not its sigmoid, is written (same ranking).
+constexpr int MAXF4 = 4; // float4s of a tile's [TI][width] rows per thread: width <= MAXF4 * 4 * PT / TI = 128
+
 __global__ __launch_bounds__(PT) void ncf_pair_logits(NcfDev m, const int32_t *__restrict__ users, int Bt, int64_t I,
                                                       const float *__restrict__ Au, const float *__restrict__ Bi,
                                                       float *__restrict__ logits)
 {
-    extern __shared__ float lds[]; // two activation buffers [width][PT]
+    extern __shared__ float lds[];
+    constexpr int NWV = PT / 64;
     const int tid = threadIdx.x;
-    const int ul = tid / TI, il = tid % TI;
-    const int64_t ur = (int64_t)blockIdx.y * (PT / TI) + ul, it = (int64_t)blockIdx.x * TI + il;
-    const bool ok = ur < Bt && it < I;
+    const int64_t u0 = (int64_t)blockIdx.y * TU;
     const bool has_g = m.kind != 1, has_m = m.kind != 0;
-    const int dg = has_g ? m.dg : 0;
+    const int dg = has_g ? m.dg : 0, ldg = dg + 1;
+    const int w1 = has_m ? m.L0 / 2 : 0, ldb = w1 + 1, L = has_m ? m.n_layers : 0;
+    const auto width_of = [&](int k) { return m.L0 >> k; }; // input width of layer k
+    const auto woff_of = [&](int k) {                         // floats before W_k among layers 1..
+        int o = 0;
+        for (int j = 1; j < k; ++j)
+            o += width_of(j) * (width_of(j + 1) + 1);
+        return o;
+    };
+    const auto boff_of = [&](int k) {
+        int o = 0;
+        for (int j = 1; j < k; ++j)
+            o += width_of(j + 1);
+        return o;
+    };
+    const int last = has_m ? width_of(L) : 0;
+    // carve (ncf_pair_lds_floats mirrors this)
+    float *Bl = lds;                             // [TI][w1 + 1]   the tile's first-layer item halves
+    float *Ql = Bl + TI * ldb;                   // [TI][dg + 1]   the tile's Q_gmf rows
+    float *Aul = Ql + TI * ldg;                  // [TU][w1]       the users' first-layer halves
+    float *ph = Aul + TU * w1;                   // [TU][dg]       p_gmf * h_gmf
+    float *buf1 = ph + TU * dg;                  // [TP][w1 / 2 + 1]
+    float *buf2 = buf1 + TP * (w1 / 2 + 1);      // [TP][w1 / 4 + 1]
+    float *zg = buf2 + TP * (w1 / 4 + 1);        // [TP]
+    float *b_base = zg + TP;
+    float *hl = b_base + boff_of(L);             // h of the tower part [last]
+    float *W_base = hl + last;
+
+    // ---- once per workgroup: parameters and the users' rows ---------------------------------------------------------
     const float *h = m.small + m.h_off;
-    float z = 0.f;
-    if (has_g && ok) {
-        const float *pg = m.Pg + (int64_t)users[ur] * dg, *qg = m.Qg + it * dg;
-        for (int c = 0; c < dg; ++c)
-            z = z + (pg[c] * qg[c]) * h[c];
+    for (int c = tid; c < last; c += PT)
+        hl[c] = h[dg + c];
+    for (int k = 1; k < L; ++k) {
+        for (int c = tid; c < width_of(k + 1); c += PT)
+            b_base[boff_of(k) + c] = m.small[m.b_off[k] + c];
+        stage_weights<PT>(W_base + woff_of(k), m.small + m.w_off[k], width_of(k), width_of(k + 1));
     }
-    if (has_m) {
-        int w = m.L0 / 2; // width after the first layer
-        float *cur = lds, *nxt = lds + (size_t)w * PT;
-        for (int k = 0; k < w; ++k) {
-            const float v = ok ? Au[ur * w + k] + Bi[it * w + k] : 0.f;
-            cur[k * PT + tid] = v > 0.f ? v : 0.f;
-        }
-        for (int layer = 1; layer < m.n_layers; ++layer) {
-            const int kout = w / 2;
-            const float *W = m.small + m.w_off[layer], *b = m.small + m.b_off[layer];
-            for (int o = 0; o < kout; ++o) {
-                float s = b[o];
-                for (int k = 0; k < w; ++k)
-                    s = s + cur[k * PT + tid] * W[k * kout + o];
-                nxt[o * PT + tid] = s > 0.f ? s : 0.f;
+    for (int k = tid; k < TU * dg; k += PT) {
+        const int ul = k / dg, c = k % dg;
+        ph[k] = u0 + ul < Bt ? m.Pg[(int64_t)users[u0 + ul] * dg + c] * h[c] : 0.f;
+    }
+    for (int k = tid; k < TU * w1; k += PT)
+        Aul[k] = u0 + k / w1 < Bt ? Au[(u0 + k / w1) * w1 + k % w1] : 0.f;
+
+    // ---- tile staging: global -> registers (in flight during the previous tile) -> LDS ------------------------------
+    const int nb4 = TI * w1 / 4, nq4 = TI * dg / 4; // float4s per tile
+    // row / column of a float4 index: widths are powers of two in practice -> shifts instead of divisions
+    const int wb4 = w1 / 4, wq4 = dg / 4;
+    const bool p2b = wb4 > 0 && (wb4 & (wb4 - 1)) == 0, p2q = wq4 > 0 && (wq4 & (wq4 - 1)) == 0;
+    const int shb = p2b ? __builtin_ctz(wb4) : 0, shq = p2q ? __builtin_ctz(wq4) : 0;
+    const auto row_b = [&](int idx) { return p2b ? idx >> shb : idx / (wb4 > 0 ? wb4 : 1); };
+    const auto col_b = [&](int idx) { return p2b ? idx & (wb4 - 1) : idx % (wb4 > 0 ? wb4 : 1); };
+    const auto row_q = [&](int idx) { return p2q ? idx >> shq : idx / (wq4 > 0 ? wq4 : 1); };
+    const auto col_q = [&](int idx) { return p2q ? idx & (wq4 - 1) : idx % (wq4 > 0 ? wq4 : 1); };
+    float4 sb[MAXF4], sq[MAXF4];
+    const auto stage_load = [&](int64_t it0) {
+#pragma unroll
+        for (int c = 0; c < MAXF4; ++c) {
+            const int idx = tid + c * PT;
+            sb[c] = sq[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < nb4) {
+                const int r = row_b(idx), k4 = col_b(idx);
+                if (it0 + r < I)
+                    sb[c] = *reinterpret_cast<const float4 *>(Bi + (it0 + r) * w1 + 4 * k4);
             }
-            float *t = cur;
-            cur = nxt;
-            nxt = t;
-            w = kout;
+            if (idx < nq4) {
+                const int r = row_q(idx), k4 = col_q(idx);
+                if (it0 + r < I)
+                    sq[c] = *reinterpret_cast<const float4 *>(m.Qg + (it0 + r) * dg + 4 * k4);
+            }
         }
-        const float *h_m = h + dg;
-        for (int k = 0; k < w; ++k)
-            z = z + cur[k * PT + tid] * h_m[k];
+    };
+    const auto stage_store = [&]() {
+#pragma unroll
+        for (int c = 0; c < MAXF4; ++c) {
+            const int idx = tid + c * PT;
+            if (idx < nb4) {
+                float *dst = Bl + row_b(idx) * ldb + 4 * col_b(idx);
+                dst[0] = sb[c].x, dst[1] = sb[c].y, dst[2] = sb[c].z, dst[3] = sb[c].w;
+            }
+            if (idx < nq4) {
+                float *dst = Ql + row_q(idx) * ldg + 4 * col_q(idx);
+                dst[0] = sq[c].x, dst[1] = sq[c].y, dst[2] = sq[c].z, dst[3] = sq[c].w;
+            }
+        }
+    };
+
+    const int64_t n_tiles = (I + TI - 1) / TI;
+    int64_t t = blockIdx.x;
+    if (t < n_tiles)
+        stage_load(t * TI);
+    for (; t < n_tiles; t += gridDim.x) {
+        const int64_t it0 = t * TI;
+        __syncthreads(); // the previous tile's readers are done (first pass: the once-per-workgroup stores are visible)
+        stage_store();
+        __syncthreads();
+        if (t + gridDim.x < n_tiles)
+            stage_load((t + gridDim.x) * TI);
+        // ---- GMF part: two threads per pair, each over half of the columns ------------------------------------------
+        if (has_g) {
+            const int p = tid >> 1, half = tid & 1;
+            const int ul = p / TI, il = p % TI;
+            const int c0 = half * ((dg + 1) / 2), c1 = half ? dg : (dg + 1) / 2;
+            float s = 0.f;
+#pragma unroll 8
+            for (int c = c0; c < c1; ++c)
+                s = s + ph[ul * dg + c] * Ql[il * ldg + c];
+            s += __shfl_xor(s, 1, 64);
+            if (half == 0)
+                zg[p] = s;
+        } else if (tid < TP) {
+            zg[tid] = 0.f;
+        }
+        // ---- tower layers 1 .. L-1; layer 1 reads relu(Au + Bi) formed on the fly ---------------------------------------
+        const float *cur = nullptr;
+        for (int k = 1; k < L; ++k) {
+            const int kin = width_of(k), kout = width_of(k + 1), lda = kin + 1, ldo = kout + 1, ws = kout + 1;
+            const float *Wl = W_base + woff_of(k), *b = b_base + boff_of(k);
+            const float *A = cur;
+            float *O = (k & 1) ? buf1 : buf2;
+            const auto fb = [&](int kk, int c) { return Wl[kk * ws + c]; };
+            const auto fs = [&](int p, int c, float s) {
+                s += b[c];
+                O[p * ldo + c] = s > 0.f ? s : 0.f;
+            };
+            if (k == 1)
+                tile_gemm<NWV>(
+                    TP, kout, kin,
+                    [&](int p, int kk) {
+                        const float v = Aul[(p / TI) * w1 + kk] + Bl[(p % TI) * ldb + kk];
+                        return v > 0.f ? v : 0.f;
+                    },
+                    fb, fs);
+            else
+                tile_gemm<NWV>(TP, kout, kin, [&](int p, int kk) { return A[p * lda + kk]; }, fb, fs);
+            __syncthreads();
+            cur = O;
+        }
+        if (L <= 1)
+            __syncthreads(); // zg
+        // ---- logit ---------------------------------------------------------------------------------------------------------
+        if (tid < TP) {
+            const int p = tid, ul = p / TI, il = p % TI;
+            float z = zg[p];
+            if (L == 1) { // a one-layer tower: its output is relu(Au + Bi) itself
+                for (int k = 0; k < last; ++k) {
+                    const float v = Aul[ul * w1 + k] + Bl[il * ldb + k];
+                    z = z + (v > 0.f ? v : 0.f) * hl[k];
+                }
+            } else {
+                const int ldl = last + 1;
+#pragma unroll 8
+                for (int k = 0; k < last; ++k)
+                    z = z + cur[p * ldl + k] * hl[k];
+            }
+            const int64_t ur = u0 + ul, it = it0 + il;
+            if (ur < Bt && it < I)
+                logits[ur * I + it] = z;
+        }
     }
-    if (ok)
-        logits[ur * I + it] = z;
+}
+
+size_t ncf_pair_lds_floats(bool has_g, bool has_m, int dg, int L0, int n_layers)
+{
+    const int w1 = has_m ? L0 / 2 : 0, g = has_g ? dg : 0;
+    size_t f = (size_t)TI * (w1 + 1) + (size_t)TI * (g + 1) + (size_t)TU * w1 + (size_t)TU * g +
+               (size_t)TP * (w1 / 2 + 1) + (size_t)TP * (w1 / 4 + 1) + TP;
+    int w = w1;
+    for (int k = 1; k < (has_m ? n_layers : 0); ++k) { // b_k and W_k of layers 1..
+        f += (size_t)(w / 2) + (size_t)w * (w / 2 + 1);
+        w /= 2;
+    }
+    return f + w; // h of the tower part
 }
 
 typedef unsigned long long u64;
@@ -183,11 +331,17 @@ int crec_ncf_scores(crec_ctx *ctx, const crec_ncf *mdl, const int32_t *users, in
                            (int64_t)Bt, hm, W0, 0, w1, (const float *)nullptr, Au);
         hipLaunchKernelGGL(ncf_first_layer, dim3((unsigned)crec_ceil_div(I * w1, 256)), dim3(256), 0, st, d.Qm,
                            (const int32_t *)nullptr, I, hm, W0, hm, w1, b0, Bi);
-        lds = sizeof(float) * (size_t)(w1 + w1 / 2) * PT;
-        CREC_REQUIRE(ctx, lds <= 160 * 1024, "tower too wide for the pair kernel (layers[0] <= 256)");
-        CREC_HIP(ctx, hipFuncSetAttribute((const void *)ncf_pair_logits, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
-    const dim3 grid((unsigned)crec_ceil_div(I, TI), (unsigned)crec_ceil_div(Bt, PT / TI));
+    lds = sizeof(float) * ncf_pair_lds_floats(d.kind != CREC_NCF_MLP, has_m, d.dg, d.L0, d.n_layers);
+    CREC_REQUIRE(ctx, lds <= 160 * 1024, "model too wide for the scoring tile (%zu bytes of LDS)", lds);
+    CREC_HIP(ctx, hipFuncSetAttribute((const void *)ncf_pair_logits, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CREC_REQUIRE(ctx, d.L0 / 2 <= MAXF4 * 4 * PT / TI && d.dg <= MAXF4 * 4 * PT / TI,
+                 "scoring tile: row widths up to %d", MAXF4 * 4 * PT / TI);
+    // a workgroup keeps its TU users and walks the item tiles; enough splits of the catalogue for two workgroups per CU's worth of work
+    const int64_t user_tiles = crec_ceil_div(Bt, TU), n_tiles = crec_ceil_div(I, TI);
+    int64_t splits = crec_ceil_div(2 * (int64_t)(ctx->num_cus > 0 ? ctx->num_cus : 256), user_tiles);
+    splits = splits < 1 ? 1 : (splits > n_tiles ? n_tiles : splits);
+    const dim3 grid((unsigned)splits, (unsigned)user_tiles);
     crec_prof_begin(ctx, CREC_K_NCF_SCORES, st);
     CREC_KLAUNCH(ctx, ncf_pair_logits, grid, dim3(PT), lds, st, d, users, (int)Bt, I, (const float *)Au, (const float *)Bi,
                        logits);
