@@ -49,10 +49,10 @@ constexpr int MAX_B = 8192;
 #define CREC_UNR 2
 #endif
 #ifndef CREC_RPW
-#define CREC_RPW 2
+#define CREC_RPW 4
 #endif
 #ifndef CREC_PIPE
-#define CREC_PIPE 0
+#define CREC_PIPE 1
 #endif
 constexpr int UNR = CREC_UNR;           // sub-iterations per trip
 constexpr int ROWS_PER_WAVE = CREC_RPW; // table rows a normal wave owns (capped by the groups per wave)
