@@ -18,7 +18,7 @@ COMMON = ["-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 # element-wise semantics; makes the Adam arithmetic bit-reproducible against the oracle).
 SOURCES = {
     "crec_ctx.cpp": [],
-    "crec_sampler.cpp": ["-fno-math-errno"],
+    "crec_sampler.cpp": ["-fno-math-errno", "-pthread"],
     "bpr_train.hip": ["-ffp-contract=off"],
     "eval_topk.hip": [],
     "rows_adam.hip": ["-ffp-contract=off"],

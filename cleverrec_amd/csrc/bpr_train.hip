@@ -299,6 +299,28 @@ struct Tables { // one buffer set
 
 __device__ inline float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ inline void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+#ifndef CREC_NT
+#define CREC_NT 0
+#endif
+typedef float crec_f4v __attribute__((ext_vector_type(4)));
+// streamed table output: rows written once per launch and not re-read by it
+__device__ inline void st4s(float *p, float4 v)
+{
+    if (CREC_NT & 1) {
+        crec_f4v t = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(t, reinterpret_cast<crec_f4v *>(p));
+    } else {
+        st4(p, v);
+    }
+}
+__device__ inline float4 ld4s(const float *p) // streamed slot input (m, v: read once)
+{
+    if (CREC_NT & 2) {
+        const crec_f4v t = __builtin_nontemporal_load(reinterpret_cast<const crec_f4v *>(p));
+        return make_float4(t.x, t.y, t.z, t.w);
+    }
+    return ld4(p);
+}
 __device__ inline float dot4(float4 a, float4 b) { return ((a.x * b.x + a.y * b.y) + a.z * b.z) + a.w * b.w; }
 
 template <int CTRL> __device__ inline float dpp_add(float v)
@@ -719,8 +741,8 @@ __device__ inline void row_wave(const Tables &src, const Tables &dst, int d, con
     float4 var = zero, m = zero, v = zero;
     if (owner) {
         var = ld4((user ? src.P : src.Q) + ro);
-        m = ld4((user ? src.mP : src.mQ) + ro);
-        v = ld4((user ? src.vP : src.vQ) + ro);
+        m = ld4s((user ? src.mP : src.mQ) + ro);
+        v = ld4s((user ? src.vP : src.vQ) + ro);
     }
     const float4 grad = slots_grad<LPR, RW, MODE, STORE_CONTRIB>(var, sl, n_valid, src.P, src.Q, d, occ, contrib, xb, h);
     const float nr = group_sum<LPR>(dot4(var, var));
@@ -731,9 +753,9 @@ __device__ inline void row_wave(const Tables &src, const Tables &dst, int d, con
             st4(h.dQ + ro, grad);
         } else {
             adam4(var, m, v, grad, sl.cnt > 0, h);
-            st4((user ? dst.P : dst.Q) + ro, var);
-            st4((user ? dst.mP : dst.mQ) + ro, m);
-            st4((user ? dst.vP : dst.vQ) + ro, v);
+            st4s((user ? dst.P : dst.Q) + ro, var);
+            st4s((user ? dst.mP : dst.mQ) + ro, m);
+            st4s((user ? dst.vP : dst.vQ) + ro, v);
         }
     }
 }

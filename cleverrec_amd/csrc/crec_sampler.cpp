@@ -15,6 +15,10 @@
 
 #include "crec_internal.h"
 
+#include <atomic>
+#include <thread>
+#include <vector>
+
 namespace {
 
 constexpr int MT_N = 624, MT_M = 397;
@@ -74,7 +78,7 @@ inline uint32_t draw(crec_mt19937 &r, uint32_t max, uint32_t mask)
 // The swap targets depend only on the RNG stream, never on the array, so they are drawn a
 // block ahead and prefetched: the swaps themselves still run strictly in order, but on
 // lines that are already on their way (the array is far larger than the host caches).
-template <typename T> void permutation(crec_mt19937 &r, int64_t n, T *a)
+template <typename T> void permutation(crec_mt19937 &r, int64_t n, T *a, std::atomic<int64_t> *front = nullptr)
 {
     for (int64_t k = 0; k < n; ++k)
         a[k] = (T)k;
@@ -94,7 +98,52 @@ template <typename T> void permutation(crec_mt19937 &r, int64_t n, T *a)
             *y = tmp;
         }
         k -= m;
+        if (front) // positions above k are never touched again: they are final
+            front->store(k + 1, std::memory_order_release);
     }
+    if (front)
+        front->store(0, std::memory_order_release);
+}
+
+// permutation(n) + "for k in [0, n): body(k, perm[k])" with the body spread over worker threads that trail the
+// shuffle: the legacy shuffle walks k downwards and never touches a position above k again, so perm[k..n) is final
+// as soon as step k is done and can be consumed while the (strictly serial) shuffle is still running.  The RNG
+// stream and the result are exactly those of the serial code.
+template <class Body> void shuffled_apply(crec_mt19937 &r, int64_t n, uint32_t *perm, Body body)
+{
+    static const int env_threads = getenv("CREC_SAMPLER_THREADS") ? atoi(getenv("CREC_SAMPLER_THREADS")) : -1;
+    // two workers keep up with the shuffle on the GPU host (43 -> 37 ms per ml-1m epoch); more only add contention
+    int workers = env_threads >= 0 ? env_threads : ((int)std::thread::hardware_concurrency() >= 4 ? 2 : 0);
+    workers = workers > 8 ? 8 : workers;
+    if (workers < 1 || n < (1 << 16)) {
+        permutation(r, n, perm);
+        for (int64_t k = 0; k < n; ++k)
+            body(k, perm[k]);
+        return;
+    }
+    constexpr int64_t CHUNK = 1 << 14;
+    const int64_t n_chunks = (n + CHUNK - 1) / CHUNK;
+    std::atomic<int64_t> front{n}, next{n_chunks - 1};
+    std::vector<std::thread> pool;
+    for (int w = 0; w < workers; ++w)
+        pool.emplace_back([&] {
+            for (;;) {
+                const int64_t c = next.fetch_sub(1, std::memory_order_relaxed); // chunks from the top down
+                if (c < 0)
+                    return;
+                const int64_t lo = c * CHUNK, hi = (lo + CHUNK) < n ? (lo + CHUNK) : n;
+                while (front.load(std::memory_order_acquire) > lo)
+                    std::this_thread::yield();
+                for (int64_t k = lo; k < hi; ++k) {
+                    if (k + 16 < hi)
+                        __builtin_prefetch(&perm[k + 16], 0, 1);
+                    body(k, perm[k]);
+                }
+            }
+        });
+    permutation(r, n, perm, &front);
+    for (auto &t : pool)
+        t.join();
 }
 
 struct Csr {
@@ -246,19 +295,14 @@ int crec_sample_pairwise(crec_ctx *ctx, const int64_t *ptr, const int32_t *items
         return crec_fail(ctx, CREC_ENOMEM, "host allocation failed");
     if (!draw_negatives(ctx->rng, c, neg_ratio, neg.get(), stamp.get()))
         return crec_fail(ctx, CREC_EINVAL, "a user has fewer than neg_ratio unseen items");
-    permutation(ctx->rng, n, perm.get()); // sampler.py:68
-    for (int64_t k = 0; k < n; ++k) {     // np.array(x)[s_idx] for the three columns at once
-        if (k + 32 < n) {
-            uint32_t sp = perm[k + 32], ep = sp / (uint32_t)neg_ratio;
-            __builtin_prefetch(&neg[sp], 0, 1);
-            __builtin_prefetch(&eu[ep], 0, 1);
-            __builtin_prefetch(&items[ep], 0, 1);
-        }
-        uint32_t s = perm[k], e = s / (uint32_t)neg_ratio;
-        u[k] = eu[e];
+    const int32_t *negp = neg.get(), *eup = eu.get();
+    // sampler.py:68 + np.array(x)[s_idx] for the three columns at once
+    shuffled_apply(ctx->rng, n, perm.get(), [=](int64_t k, uint32_t sidx) {
+        const uint32_t e = sidx / (uint32_t)neg_ratio;
+        u[k] = eup[e];
         i[k] = items[e];
-        j[k] = neg[s];
-    }
+        j[k] = negp[sidx];
+    });
     *n_out = n;
     return CREC_OK;
 }
@@ -282,14 +326,14 @@ int crec_sample_pointwise(crec_ctx *ctx, const int64_t *ptr, const int32_t *item
         return crec_fail(ctx, CREC_ENOMEM, "host allocation failed");
     if (!draw_negatives(ctx->rng, c, neg_ratio, neg.get(), stamp.get()))
         return crec_fail(ctx, CREC_EINVAL, "a user has fewer than neg_ratio unseen items");
-    permutation(ctx->rng, n, perm.get()); // sampler.py:37
-    for (int64_t k = 0; k < n; ++k) {
+    const int32_t *negp = neg.get(), *eup = eu.get();
+    shuffled_apply(ctx->rng, n, perm.get(), [=](int64_t k, uint32_t sidx) { // sampler.py:37
         // instance s = e*(1+neg_ratio) + t: t == 0 the positive, t >= 1 its (t-1)-th negative (sampler.py:18-31)
-        uint32_t s = perm[k], e = s / (uint32_t)w, t = s - e * (uint32_t)w;
-        u[k] = eu[e];
-        i[k] = t == 0 ? items[e] : neg[(int64_t)e * neg_ratio + (t - 1)];
+        const uint32_t e = sidx / (uint32_t)w, t = sidx - e * (uint32_t)w;
+        u[k] = eup[e];
+        i[k] = t == 0 ? items[e] : negp[(int64_t)e * neg_ratio + (t - 1)];
         y[k] = t == 0 ? 1.0f : 0.0f;
-    }
+    });
     *n_out = n;
     return CREC_OK;
 }
@@ -312,13 +356,12 @@ int crec_sample_cml(crec_ctx *ctx, const int64_t *ptr, const int32_t *items, int
         return crec_fail(ctx, CREC_ENOMEM, "host allocation failed");
     if (!draw_negatives(ctx->rng, c, neg_ratio, neg.get(), stamp.get()))
         return crec_fail(ctx, CREC_EINVAL, "a user has fewer than neg_ratio unseen items");
-    permutation(ctx->rng, n, perm.get()); // sampler.py:97
-    for (int64_t k = 0; k < n; ++k) {
-        uint32_t e = perm[k];
-        u[k] = eu[e];
+    const int32_t *negp = neg.get(), *eup = eu.get();
+    shuffled_apply(ctx->rng, n, perm.get(), [=](int64_t k, uint32_t e) { // sampler.py:97
+        u[k] = eup[e];
         i[k] = items[e];
-        std::memcpy(neg_out + k * neg_ratio, neg.get() + (int64_t)e * neg_ratio, sizeof(int32_t) * (size_t)neg_ratio);
-    }
+        std::memcpy(neg_out + k * neg_ratio, negp + (int64_t)e * neg_ratio, sizeof(int32_t) * (size_t)neg_ratio);
+    });
     *n_out = n;
     return CREC_OK;
 }

@@ -4,8 +4,8 @@
 cd "$(dirname "$0")/.." || exit 1
 O=cleverrec_amd/lib/obj
 for v in "$@"; do
-  set -- $v; tag="u$1_r$2_p$3_a${4:-0}"; out=/tmp/crec_$tag; mkdir -p $out
-  hipcc --offload-arch=gfx950 -x hip -O3 -fPIC -std=c++17 -ffp-contract=off -Iinclude -DCREC_UNR=$1 -DCREC_RPW=$2 -DCREC_PIPE=$3 -DCREC_ABL=${4:-0} \
+  set -- $v; tag="u$1_r$2_p$3_a${4:-0}_n${5:-0}"; out=/tmp/crec_$tag; mkdir -p $out
+  hipcc --offload-arch=gfx950 -x hip -O3 -fPIC -std=c++17 -ffp-contract=off -Iinclude -DCREC_UNR=$1 -DCREC_RPW=$2 -DCREC_PIPE=$3 -DCREC_ABL=${4:-0} -DCREC_NT=${5:-0} \
         -c cleverrec_amd/csrc/bpr_train.hip -o $out/bpr_train.o -Rpass-analysis=kernel-resource-usage 2> $out/res.txt || { tail -5 $out/res.txt; exit 1; }
   objs=$(ls $O/*.o | grep -v "/bpr_train.o")
   hipcc --offload-arch=gfx950 -shared -o $out/libcrec.so $objs $out/bpr_train.o -L/opt/rocm/lib -lrccl || exit 1
