@@ -112,8 +112,9 @@ template <typename T> void permutation(crec_mt19937 &r, int64_t n, T *a, std::at
 template <class Body> void shuffled_apply(crec_mt19937 &r, int64_t n, uint32_t *perm, Body body)
 {
     static const int env_threads = getenv("CREC_SAMPLER_THREADS") ? atoi(getenv("CREC_SAMPLER_THREADS")) : -1;
-    // two workers keep up with the shuffle on the GPU host (43 -> 37 ms per ml-1m epoch); more only add contention
-    int workers = env_threads >= 0 ? env_threads : ((int)std::thread::hardware_concurrency() >= 4 ? 2 : 0);
+    // one gather worker (+ the swap thread below) keeps up with the RNG thread on the GPU host: 45 -> 34 ms per
+    // ml-1m epoch; more workers only add contention
+    int workers = env_threads >= 0 ? env_threads : ((int)std::thread::hardware_concurrency() >= 4 ? 1 : 0);
     workers = workers > 8 ? 8 : workers;
     if (workers < 1 || n < (1 << 16)) {
         permutation(r, n, perm);
@@ -141,7 +142,39 @@ template <class Body> void shuffled_apply(crec_mt19937 &r, int64_t n, uint32_t *
                 }
             }
         });
-    permutation(r, n, perm, &front);
+    // the shuffle itself in two stages: this thread owns the RNG and only draws the swap targets (they depend on the
+    // stream alone), a second thread applies the swaps behind it -- generation and the cache-missing swaps overlap
+    std::vector<uint32_t> target((size_t)n);
+    std::atomic<int64_t> drawn{n}; // steps k >= drawn have their target
+    std::thread swapper([&] {
+        for (int64_t k = 0; k < n; ++k)
+            perm[k] = (uint32_t)k;
+        constexpr int64_t AHEAD = 64;
+        int64_t avail = n; // local copy of `drawn`
+        for (int64_t k = n - 1; k >= 1; --k) {
+            while (avail > k) {
+                avail = drawn.load(std::memory_order_acquire);
+                if (avail > k)
+                    std::this_thread::yield();
+            }
+            if (k - AHEAD >= avail)
+                __builtin_prefetch(&perm[target[k - AHEAD]], 1, 1);
+            const uint32_t j = target[k], tmp = perm[k];
+            perm[k] = perm[j];
+            perm[j] = tmp;
+            if ((k & 63) == 0) // positions >= k are never touched again: they are final
+                front.store(k, std::memory_order_release);
+        }
+        front.store(0, std::memory_order_release);
+    });
+    for (int64_t k = n - 1; k >= 1; --k) {
+        const uint32_t kk = (uint32_t)k;
+        target[k] = draw(r, kk, mask_of(kk));
+        if ((k & 1023) == 0)
+            drawn.store(k, std::memory_order_release);
+    }
+    drawn.store(1, std::memory_order_release);
+    swapper.join();
     for (auto &t : pool)
         t.join();
 }
