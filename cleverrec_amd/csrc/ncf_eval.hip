@@ -8,8 +8,8 @@
 // computed once per user and once per item (ncf_first_layer) and a pair only adds the two and applies ReLU.
 // ncf_pair_logits: a workgroup per 4 users walking tiles of 64 items; the remaining layers run on the fp32 matrix cores
 // between LDS activation buffers.  The logit, not its sigmoid, is written (same ranking).
-// topk_rows: one wave per user over a row of the score matrix staged in LDS: seen items are struck out,
-// then K rounds of wave-wide arg-max (ties: lower item id).
+// topk_rows: one workgroup per user over a row of the score matrix staged in LDS: seen items are struck out,
+// then K rounds of arg-max over per-thread running bests (ties: lower item id).
 #include "crec_internal.h"
 #include "ncf_common.h"
 
@@ -237,63 +237,86 @@ __device__ inline uint32_t ordered_bits(float f)
     return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
 }
 
-// one wave per user row; the row is staged in LDS ([I] floats), seen items struck out, K arg-max rounds
-__global__ __launch_bounds__(64) void topk_rows(const float *__restrict__ scores, int64_t I, const int32_t *__restrict__ users,
-                                                const int64_t *__restrict__ seen_ptr,
-                                                const int32_t *__restrict__ seen_items, int K, float sign,
-                                                int32_t *__restrict__ ids, float *__restrict__ vals)
+__device__ inline float from_ordered(uint32_t o)
+{
+    const uint32_t u = o ^ ((o >> 31) ? 0x80000000u : 0xffffffffu);
+    return __uint_as_float(u);
+}
+
+// One workgroup (4 waves) per user row: the row is staged in LDS ([I] floats), listed items struck out (or only they
+// kept); every thread keeps the best key (ordered score, ~item: larger is better, ties -> lower item id) among its
+// own items c = tid, tid + 256, ...; each of the K rounds is a workgroup arg-max over those 256 keys, after which
+// only the winner's owner strikes the item and rescans its own items.
+constexpr int TKT = 256;
+__global__ __launch_bounds__(TKT) void topk_rows(const float *__restrict__ scores, int64_t I, const int32_t *__restrict__ users,
+                                                 const int64_t *__restrict__ seen_ptr,
+                                                 const int32_t *__restrict__ seen_items, int K, float sign,
+                                                 int32_t *__restrict__ ids, float *__restrict__ vals)
 {
     extern __shared__ float row[];
-    const int lane = threadIdx.x;
+    __shared__ u64 wbest[2][TKT / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t r = blockIdx.x;
     const float worst = -INFINITY;
     const bool keep_listed = K >> 16; // the host packs the filter mode above K
     K &= 0xffff;
     const int32_t uu = users[r];
     if (!keep_listed) { // listed = seen in training: struck out
-        for (int64_t c = lane; c < I; c += 64)
+        for (int64_t c = tid; c < I; c += TKT)
             row[c] = sign * scores[r * I + c];
         __syncthreads();
-        for (int64_t e = seen_ptr[uu] + lane; e < seen_ptr[uu + 1]; e += 64)
+        for (int64_t e = seen_ptr[uu] + tid; e < seen_ptr[uu + 1]; e += TKT)
             row[seen_items[e]] = worst;
     } else { // listed = the user's candidates: only they compete
-        for (int64_t c = lane; c < I; c += 64)
+        for (int64_t c = tid; c < I; c += TKT)
             row[c] = worst;
         __syncthreads();
-        for (int64_t e = seen_ptr[uu] + lane; e < seen_ptr[uu + 1]; e += 64)
+        for (int64_t e = seen_ptr[uu] + tid; e < seen_ptr[uu + 1]; e += TKT)
             row[seen_items[e]] = sign * scores[r * I + seen_items[e]];
     }
     __syncthreads();
-    for (int k = 0; k < K; ++k) {
-        u64 best = 0; // (ordered score, ~item): larger is better, ties -> lower item id
-        for (int64_t c = lane; c < I; c += 64) {
+    const auto scan = [&]() {
+        u64 b = 0;
+        for (int64_t c = tid; c < I; c += TKT) {
             const float s = row[c];
             if (s != worst) {
                 const u64 key = ((u64)ordered_bits(s) << 32) | (0xffffffffu - (uint32_t)c);
-                best = key > best ? key : best;
+                b = key > b ? key : b;
             }
         }
+        return b;
+    };
+    u64 mine = scan();
+    for (int k = 0; k < K; ++k) {
+        u64 best = mine;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             const u64 o = __shfl_xor(best, off, 64);
             best = o > best ? o : best;
         }
-        if (best == 0) {
-            if (lane == 0) {
-                ids[r * K + k] = -1;
-                vals[r * K + k] = sign * worst;
-            }
-        } else {
-            const int item = (int)(0xffffffffu - (uint32_t)best);
-            if (lane == 0) {
-                ids[r * K + k] = item;
-                vals[r * K + k] = sign * row[item];
-            }
-            __syncthreads();
-            if (lane == 0)
-                row[item] = worst;
+        if (lane == 0)
+            wbest[k & 1][wv] = best;
+        __syncthreads(); // (double-buffered by round parity: one barrier per round)
+#pragma unroll
+        for (int w = 0; w < TKT / 64; ++w)
+            best = wbest[k & 1][w] > best ? wbest[k & 1][w] : best;
+        if (best == 0) { // nothing left: the rest of the list is padding
+            if (tid == 0)
+                for (int kk = k; kk < K; ++kk) {
+                    ids[r * K + kk] = -1;
+                    vals[r * K + kk] = sign * worst;
+                }
+            return;
         }
-        __syncthreads();
+        const int item = (int)(0xffffffffu - (uint32_t)best);
+        if (tid == 0) {
+            ids[r * K + k] = item;
+            vals[r * K + k] = sign * from_ordered((uint32_t)(best >> 32));
+        }
+        if (item % TKT == tid) { // the owner strikes it and finds its next best
+            row[item] = worst;
+            mine = scan();
+        }
     }
 }
 
@@ -382,7 +405,7 @@ static int topk_scores_impl(crec_ctx *ctx, const float *scores, int64_t I, const
     CREC_HIP(ctx, hipSetDevice(ctx->device));
     const size_t lds = sizeof(float) * (size_t)I;
     CREC_HIP(ctx, hipFuncSetAttribute((const void *)topk_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(topk_rows, dim3((unsigned)Bt), dim3(64), lds, (hipStream_t)stream, scores, I, users, seen_ptr, seen_items,
+    hipLaunchKernelGGL(topk_rows, dim3((unsigned)Bt), dim3(TKT), lds, (hipStream_t)stream, scores, I, users, seen_ptr, seen_items,
                        (int)K | (keep_listed << 16), ascending ? -1.0f : 1.0f, topk_ids, topk_scores);
     CREC_HIP(ctx, hipGetLastError());
     return CREC_OK;
