@@ -180,9 +180,22 @@ def main():
 
         # ---- sampler ---------------------------------------------------------------------------------
         epoch_gpu_s = (n_epoch / B) * (dt / a.steps)
-        out["sampler"] = {"mode": "mt19937 bit-exact (host, 1 core)", "triples_per_s": n_epoch / t_sample,
+        out["sampler"] = {"mode": "mt19937 bit-exact (host: one RNG thread + swap and gather threads behind it)", "triples_per_s": n_epoch / t_sample,
                           "epoch_triples": n_epoch, "epoch_inclusive_triples_per_s_serial": n_epoch / (t_sample + epoch_gpu_s),
                           "epoch_inclusive_triples_per_s_overlapped": n_epoch / max(t_sample, epoch_gpu_s)}
+
+        # the optional device sampler (same acceptance rule, counter-based generator: not NumPy-stream compatible)
+        ds = runtime.DeviceSampler(sess, data, seed=1)
+        ds.pairwise(NEG)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            cu, ci, cj = ds.pairwise(NEG)
+        torch.cuda.synchronize()
+        t_dev = (time.perf_counter() - t0) / 5
+        out["sampler"]["device_mode"] = {"triples_per_s": int(cu.numel()) / t_dev, "ms_per_epoch": t_dev * 1e3,
+                                         "epoch_inclusive_triples_per_s": n_epoch / (t_dev + epoch_gpu_s),
+                                         "note": "crec_sample_negatives_device + device randperm + gathers; opt-in (sampler_mode=device)"}
 
         # ---- S-big: the HBM-bound form of the same path (10 M x 1 M, d=128, lazy Adam) ----------------
         if not a.no_big:

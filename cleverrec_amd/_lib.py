@@ -67,6 +67,7 @@ _SIGNATURES = {
     "crec_sample_pairwise": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, C.c_int, _vp, _vp, _vp, C.POINTER(_i64)]),
     "crec_sample_pointwise": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, C.c_int, _vp, _vp, _vp, C.POINTER(_i64)]),
     "crec_sample_cml": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, C.c_int, _vp, _vp, _vp, C.POINTER(_i64)]),
+    "crec_sample_negatives_device": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
     "crec_bpr_train_epoch": (C.c_int, [_vp, C.POINTER(BprTables), C.POINTER(Adam), _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "crec_ncf_train_epoch": (C.c_int, [_vp, C.POINTER(Ncf), C.POINTER(Adam), _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "crec_ncf_scores": (C.c_int, [_vp, C.POINTER(Ncf), _vp, _i32, _vp, _vp]),

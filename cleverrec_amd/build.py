@@ -19,6 +19,7 @@ COMMON = ["-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 SOURCES = {
     "crec_ctx.cpp": [],
     "crec_sampler.cpp": ["-fno-math-errno", "-pthread"],
+    "gpu_sampler.hip": [],
     "bpr_train.hip": ["-ffp-contract=off"],
     "eval_topk.hip": [],
     "rows_adam.hip": ["-ffp-contract=off"],

@@ -24,6 +24,12 @@ class RankingRecommender(Recommender):
         self.test_users = [int(u) for u in (data.test_users if hasattr(data, 'test_users') else data.ui_test.keys())]
         self.test_batches = math.ceil(len(self.test_users) / self.batch_size_t)
         self._eval_cache = None
+        # extension (not in the reference): `sampler_mode=device` draws the epoch on the GPU with the same acceptance
+        # rule but its own generator -- statistically equivalent, not NumPy-stream compatible; the default
+        # (`mt19937`) is the bit-exact host sampler
+        self._dev_sampler = None
+        if str(configs.get('sampler_mode', 'mt19937')).lower() == 'device':
+            self._dev_sampler = runtime.DeviceSampler(sess, data, seed=int(configs.get('seed', 0)))
 
     # -- hooks a model class fills in ---------------------------------------------------------
     def _train_epoch_device(self, u, i, j):
@@ -41,6 +47,11 @@ class RankingRecommender(Recommender):
     # -- one epoch (RankingRecommender.py:33-61) -------------------------------------------------
     def train_model(self):
         s = self.sess
+        if self._dev_sampler is not None:
+            ds = self._dev_sampler
+            cols = ds.pairwise(self.neg_ratio) if self.is_pairwise == 'True' else ds.pointwise(self.neg_ratio)
+            losses = self._train_epoch_device(*cols)
+            return float(losses.double().sum().item()) / int(losses.numel())
         if self.is_pairwise == 'True':
             train_ = pairwise_ranking_sampler(self.data, self.neg_ratio, self.batch_size, fism_like=self.fism_like)
             u, i, j = (s.to_dev(a) for a in train_[1:4])

@@ -41,6 +41,10 @@ class CML(RankingRecommender):
 
     def train_model_cml(self):
         """RankingRecommender.train_model_cml (model/RankingRecommender.py:90-100)."""
+        if self._dev_sampler is not None:
+            u, i, neg = self._dev_sampler.cml(self.neg_ratio)
+            losses = self.state.train_epoch(u, i, neg, self.batch_size)
+            return float(losses.double().sum().item()) / int(losses.numel())
         train_ = ranking_sampler_cml(self.data, self.neg_ratio, self.batch_size)
         s = self.sess
         losses = self.state.train_epoch(s.to_dev(train_[1]), s.to_dev(train_[2]), s.to_dev(train_[3]), self.batch_size)

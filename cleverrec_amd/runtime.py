@@ -242,3 +242,62 @@ def topk_scores(sess, scores, users, seen_ptr, seen_items, K, ascending=False, c
                                              sess.ptr(seen_items), int(K), int(bool(ascending)), sess.ptr(ids), sess.ptr(sc),
                                              sess.stream_ptr()))
     return ids, sc
+
+
+class DeviceSampler:
+    """Epoch samplers on the GPU: the acceptance rule of utils/sampler.py (uniform negatives, not among the user's
+    training items, no repeat inside a positive's group), a counter-based generator instead of NumPy's MT19937
+    stream -- statistically equivalent, NOT stream-compatible (the bit-exact host samplers stay the default).
+    One launch draws every negative of the epoch (crec_sample_negatives_device); the epoch shuffle is a device
+    randperm and the three output formats are gathers.  Opt in with `sampler_mode=device` in the .properties file."""
+
+    def __init__(self, sess, data, seed=0):
+        from .data import RankingData
+        if not hasattr(data, 'train_csr'):
+            data = RankingData(data.user_nums, data.item_nums, data.ui_train, data.ui_test)
+        self.sess, self.item_nums, self.seed, self.epoch = sess, int(data.item_nums), int(seed), 0
+        keys, ptr, items = data.train_csr
+        self.n_pos = int(ptr[-1])
+        self.edge_user = sess.to_dev(np.repeat(np.asarray(keys, np.int32), np.diff(ptr)).astype(np.int32))
+        self.items = sess.to_dev(np.asarray(items, np.int32))
+        sp, si = data.seen_csr
+        self.seen_ptr = sess.to_dev(sp)
+        self.seen_items = sess.to_dev(si if len(si) else np.zeros(1, np.int32))
+        self.max_seen = C.c_int32(int(np.diff(sp).max()) if len(sp) > 1 else 0)
+        self.gen = torch.Generator(device=sess.device)
+        self.gen.manual_seed(self.seed)
+
+    def negatives(self, neg_ratio):
+        """[n_pos, neg_ratio] int32: the negatives of every training positive, in ui_train order."""
+        s = self.sess
+        neg = s.empty((max(self.n_pos, 1), neg_ratio), torch.int32)
+        s.ctx.check(s.lib.crec_sample_negatives_device(s.ctx.h, self.seed, self.epoch, self.n_pos, s.ptr(self.edge_user),
+                                                       s.ptr(self.seen_ptr), s.ptr(self.seen_items), C.byref(self.max_seen),
+                                                       self.item_nums, int(neg_ratio), s.ptr(neg), s.stream_ptr()))
+        self.epoch += 1
+        return neg[:self.n_pos]
+
+    def _perm(self, n):
+        return torch.randperm(n, device=self.sess.device, generator=self.gen)
+
+    def pairwise(self, neg_ratio):
+        """(u, i, j) int32 [n_pos * neg_ratio], shuffled (pairwise_ranking_sampler, sampler.py:46-74)."""
+        neg = self.negatives(neg_ratio)
+        perm = self._perm(self.n_pos * neg_ratio)
+        e = torch.div(perm, neg_ratio, rounding_mode='floor')
+        return self.edge_user[e].contiguous(), self.items[e].contiguous(), neg.reshape(-1)[perm].contiguous()
+
+    def pointwise(self, neg_ratio):
+        """(u, i, y): every positive with label 1 and its negatives with label 0, shuffled (sampler.py:10-43)."""
+        neg = self.negatives(neg_ratio)
+        w = 1 + neg_ratio
+        perm = self._perm(self.n_pos * w)
+        e, t = torch.div(perm, w, rounding_mode='floor'), perm % w
+        both = torch.cat([self.items[:, None], neg], dim=1)  # column 0: the positive, 1..: its negatives
+        return self.edge_user[e].contiguous(), both.reshape(-1)[perm].contiguous(), (t == 0).to(torch.float32)
+
+    def cml(self, neg_ratio):
+        """(u, i, neg[n_pos, neg_ratio]), shuffled (ranking_sampler_cml, sampler.py:77-99)."""
+        neg = self.negatives(neg_ratio)
+        perm = self._perm(self.n_pos)
+        return self.edge_user[perm].contiguous(), self.items[perm].contiguous(), neg[perm].contiguous()

@@ -89,6 +89,17 @@ int crec_sample_pointwise(crec_ctx *ctx, const int64_t *ptr, const int32_t *item
 int crec_sample_cml(crec_ctx *ctx, const int64_t *ptr, const int32_t *items, int64_t n_users, const int32_t *user_ids,
                     int32_t item_nums, int neg_ratio, int32_t *u, int32_t *i, int32_t *neg, int64_t *n_out);
 
+/* ---- device-side negative sampling (optional; NOT stream-compatible with the reference) --------------
+ * Same acceptance rule as utils/sampler.py:18-31,50-66,82-93 -- neg_ratio items per training positive, uniform over
+ * the catalogue, redrawn while seen by the user or already in the positive's group -- but drawn from a counter-based
+ * generator keyed by (seed, epoch, positive, draw), one thread per positive, so an epoch costs one launch instead
+ * of a serial MT19937 walk.  edge_user [dev][n_pos]: the user of every training positive in ui_train order;
+ * seen_ptr/seen_items [dev]: CSR by user id, items sorted; max_seen [host]: the largest row length of that CSR
+ * (termination check); neg [dev][n_pos][neg_ratio] out.  The epoch shuffle is the caller's (device randperm). */
+int crec_sample_negatives_device(crec_ctx *ctx, uint64_t seed, uint64_t epoch, int64_t n_pos, const int32_t *edge_user,
+                                 const int64_t *seen_ptr, const int32_t *seen_items, const int32_t *max_seen,
+                                 int32_t item_nums, int32_t neg_ratio, int32_t *neg, void *stream);
+
 /* ---- BPR training (device) ------------------------------------------------------------
  * replaces, per batch, sess.run([self.train, self.loss], {u_idx, i_idx, j_idx})
  * (model/RankingRecommender.py:46) on the graph of model/ranking/BPR.py:31-44 with
