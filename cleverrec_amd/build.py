@@ -51,16 +51,22 @@ def build(force=False, verbose=False):
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(HERE, "..", "include", "crec.h"))
     cc = hipcc()
-    objs = []
+    objs, jobs = [], []
     for src, extra in SOURCES.items():
         path = os.path.join(CSRC, src)
         obj = os.path.join(objdir, src.rsplit(".", 1)[0] + ".o")
         objs.append(obj)
         if force or _stale(obj, [path] + headers + [os.path.abspath(__file__)]):
-            cmd = [cc, "--offload-arch=" + ARCH, "-x", "hip"] + COMMON + extra + ["-c", path, "-o", obj]
+            jobs.append([cc, "--offload-arch=" + ARCH, "-x", "hip"] + COMMON + extra + ["-c", path, "-o", obj])
+    if jobs:  # translation units are independent: compile up to four at a time
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
+        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as pool:
+            list(pool.map(run, jobs))
     if force or _stale(LIB, objs):
         cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-lrccl"]
         if verbose:
