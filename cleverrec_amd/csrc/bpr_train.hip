@@ -897,17 +897,17 @@ struct HeavyArgs {
     int HRu_max;                     // item tickets start here
 };
 
+// the work of one wave id of a tf1 step: [0, HIu) user chunk waves, [HIu, HIu+HIq) item chunk waves, then WU waves
+// owning user rows, then WI waves owning item rows
 template <int LPR, bool FULL>
-__global__ __launch_bounds__(256) void bpr_step_fused(Tables src, Tables dst, int d, int64_t U, int64_t I,
-                                                      const int2 *__restrict__ u_rowseg,
-                                                      const int4 *__restrict__ u_occ,
-                                                      const int2 *__restrict__ q_rowseg,
-                                                      const int4 *__restrict__ q_occ, HeavyArgs hv,
-                                                      float *__restrict__ xb, float *__restrict__ rowterm, Hyper h)
+__device__ __forceinline__ void fused_wave(int64_t wave_id, const Tables &src, const Tables &dst, int d, int64_t U, int64_t I,
+                                           const int2 *__restrict__ u_rowseg, const int4 *__restrict__ u_occ,
+                                           const int2 *__restrict__ q_rowseg, const int4 *__restrict__ q_occ,
+                                           const HeavyArgs &hv, float *__restrict__ xb, float *__restrict__ rowterm,
+                                           const Hyper &h)
 {
     constexpr int R = Geo<LPR, ROWS_PER_WAVE>::R;
-    const int lane = threadIdx.x & 63, g = lane / LPR;
-    int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int g = (threadIdx.x & 63) / LPR;
     if (wave_id < hv.HIu) {
         chunk_wave<LPR, 0, false, FULL>(src, d, hv.u_hitems[wave_id], u_occ, nullptr, xb, hv.partial,
                                         FinishArgs{hv.u_hrows, hv.tickets, dst, rowterm, 1}, h);
@@ -937,6 +937,121 @@ __global__ __launch_bounds__(256) void bpr_step_fused(Tables src, Tables dst, in
         row_wave<LPR, 0, false, FULL>(src, dst, d, sl, n_valid, u_occ, nullptr, xb, rt, true, h);
     else
         row_wave<LPR, 1, false, FULL>(src, dst, d, sl, n_valid, q_occ, nullptr, xb, rt, true, h);
+}
+
+template <int LPR, bool FULL>
+__global__ __launch_bounds__(256) void bpr_step_fused(Tables src, Tables dst, int d, int64_t U, int64_t I,
+                                                      const int2 *__restrict__ u_rowseg,
+                                                      const int4 *__restrict__ u_occ,
+                                                      const int2 *__restrict__ q_rowseg,
+                                                      const int4 *__restrict__ q_occ, HeavyArgs hv,
+                                                      float *__restrict__ xb, float *__restrict__ rowterm, Hyper h)
+{
+    constexpr int R = Geo<LPR, ROWS_PER_WAVE>::R;
+    const int lane = threadIdx.x & 63, g = lane / LPR;
+    int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (CREC_ABL & 4) // ablation: the launch with no work (dispatch + drain floor of this grid)
+        return;
+    if (CREC_ABL & 8) { // ablation: a pure copy of the six arrays, one wave per R rows (streaming floor of this grid)
+        const int64_t WUc = (U + R - 1) / R, w2 = wave_id - hv.HIu - hv.HIq;
+        const bool usr = w2 < WUc;
+        const int64_t row = (usr ? w2 : w2 - WUc) * R + g;
+        if (w2 >= 0 && g < R && row < (usr ? U : I)) {
+            const int64_t ro = row * d + 4 * (lane % LPR);
+            st4((usr ? dst.P : dst.Q) + ro, ld4((usr ? src.P : src.Q) + ro));
+            st4((usr ? dst.mP : dst.mQ) + ro, ld4((usr ? src.mP : src.mQ) + ro));
+            st4((usr ? dst.vP : dst.vQ) + ro, ld4((usr ? src.vP : src.vQ) + ro));
+        }
+        return;
+    }
+    fused_wave<LPR, FULL>(wave_id, src, dst, d, U, I, u_rowseg, u_occ, q_rowseg, q_occ, hv, xb, rowterm, h);
+}
+
+// ------------------------------------------------------------------------------------
+// tf1 mode, many steps per launch (an experiment kept behind CREC_PERSISTENT=1, off by default).
+// A dispatch costs ~4 us begin-to-end before any wave does work (an empty kernel measures the same with 1 or 4876
+// workgroups, tools/micro/empty_launch.hip) and consecutive dependent dispatches sit another ~3.6 us apart, against
+// ~5 us of work in a step at ml-1m shape.  The idea: run the chunk's steps inside ONE cooperative launch -- a
+// persistent grid walks the wave ids of step s, meets at a device-wide barrier, and goes on to step s+1 with the
+// buffer sets swapped.  The barrier has to re-create a kernel boundary's visibility by hand: every workgroup
+// releases its writes (they may sit in its XCD's L2) before it arrives and acquires after it leaves.
+// RESULT (tools/micro/grid_barrier.hip): the counter part of such a barrier costs 2.4-4 us with a two-level tree
+// (a flat counter serialises: 11 us for 610 workgroups), but the release + acquire fences (buffer_wbl2 / buffer_inv
+// on every workgroup) add 7-17 us even with nothing dirty -- more than the 7.6 us a kernel boundary costs.  With
+// this flat barrier the step takes 65 us instead of 13.  Results are identical (parity tests run both ways).
+// ------------------------------------------------------------------------------------
+struct StepsArgs {
+    Tables t0, t1;   // step s reads (s & 1 ? t1 : t0) and writes the other
+    int d;
+    int64_t U, I;
+    IndexWs w;       // the chunk's index (device pointers)
+    float *partial;
+    int32_t *tickets;
+    float *loss_ws;  // [n_steps][loss_stride]: x_b of every triple, then the row terms
+    int64_t loss_stride;
+    const float *lr_t; // [n_steps]
+    Hyper h;           // lr_t is taken from the table
+    int32_t n_steps;
+    unsigned *bar;     // [0] arrivals (monotonic), [1] set when a wait timed out
+};
+
+__device__ inline bool grid_barrier(unsigned *bar, unsigned target)
+{
+    __shared__ int failed;
+    __syncthreads(); // every wave of the workgroup has issued its stores
+    if (threadIdx.x == 0) {
+        __threadfence(); // release: this XCD's L2 lines reach memory
+        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(); // 100 MHz
+        int bad = 0;
+        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ||
+                __builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { // 2 s: give up instead of hanging the GPU
+                __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bad = 1;
+                break;
+            }
+        }
+        __threadfence(); // acquire: drop stale lines of the other XCDs' writes
+        failed = bad;
+    }
+    __syncthreads();
+    return failed == 0;
+}
+
+template <int LPR, bool FULL> __global__ __launch_bounds__(256) void bpr_steps_persistent(StepsArgs a)
+{
+    constexpr int R = Geo<LPR, ROWS_PER_WAVE>::R;
+    const int64_t grid_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t my_wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t WU = (a.U + R - 1) / R, WI = (a.I + R - 1) / R;
+    const IndexWs &w = a.w;
+    for (int s = 0; s < a.n_steps; ++s) {
+        const Tables &src = (s & 1) ? a.t1 : a.t0, &dst = (s & 1) ? a.t0 : a.t1;
+        HeavyArgs hv;
+        hv.hn = w.hn + (int64_t)s * 4;
+        hv.u_hitems = w.u_hitems + (int64_t)s * w.HIu;
+        hv.q_hitems = w.q_hitems + (int64_t)s * w.HIq;
+        hv.u_hrows = w.u_hrows + (int64_t)s * w.HRu;
+        hv.q_hrows = w.q_hrows + (int64_t)s * w.HRq;
+        hv.partial = a.partial;
+        hv.tickets = a.tickets;
+        hv.HRu_max = (int)w.HRu;
+        hv.HRu = __builtin_amdgcn_readfirstlane(hv.hn[0]);
+        hv.HIu = __builtin_amdgcn_readfirstlane(hv.hn[1]);
+        hv.HRq = __builtin_amdgcn_readfirstlane(hv.hn[2]);
+        hv.HIq = __builtin_amdgcn_readfirstlane(hv.hn[3]);
+        Hyper h = a.h;
+        h.lr_t = a.lr_t[s];
+        float *xb = a.loss_ws + (int64_t)s * a.loss_stride, *rowterm = xb + w.B;
+        const int64_t total = hv.HIu + hv.HIq + WU + WI;
+        for (int64_t wid = my_wave; wid < total; wid += grid_waves)
+            fused_wave<LPR, FULL>(wid, src, dst, a.d, a.U, a.I, w.u_rowseg + (int64_t)s * w.U, w.u_occ + (int64_t)s * w.B,
+                                  w.q_rowseg + (int64_t)s * w.I, w.q_occ + (int64_t)s * 2 * w.B, hv, xb, rowterm, h);
+        if (s + 1 < a.n_steps && !grid_barrier(a.bar, (unsigned)(s + 1) * gridDim.x))
+            return;
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -1098,6 +1213,62 @@ template <int LPR, bool FULL> void launch_lazy(const StepArgs &a, const IndexWs 
 
 using StepFn = void (*)(const StepArgs &, const IndexWs &, int64_t, const int32_t *);
 
+// all steps of a chunk in one cooperative launch (bpr_steps_persistent); returns a hipError_t
+template <int LPR, bool FULL> int launch_persistent(crec_ctx *ctx, StepsArgs &sa, hipStream_t st)
+{
+    constexpr int R = Geo<LPR, ROWS_PER_WAVE>::R;
+    static int per_cu = 0; // resident workgroups per CU of this instantiation
+    if (per_cu == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)bpr_steps_persistent<LPR, FULL>, 256, 0) !=
+                hipSuccess ||
+            nb < 1)
+            return (int)hipErrorLaunchFailure;
+        per_cu = nb;
+    }
+    const int64_t cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+    const int64_t want = crec_ceil_div(sa.w.HIu + sa.w.HIq + crec_ceil_div(sa.U, R) + crec_ceil_div(sa.I, R), 4);
+    int64_t grid = (int64_t)per_cu * cus;
+    grid = grid > want ? want : grid;
+    void *params[] = {(void *)&sa};
+    if (ctx->prof.on) { // a launch of many steps: a plain event bracket is accurate enough (cooperative launches
+        crec_prof_begin(ctx, CREC_K_FINISH, st); // cannot carry their own events); class 8 = bpr_steps_persistent
+        hipEvent_t ea, eb;
+        (void)crec_prof_events(ctx, &ea, &eb);
+        (void)hipEventRecord(ea, st);
+        const hipError_t e = hipLaunchCooperativeKernel((const void *)bpr_steps_persistent<LPR, FULL>, dim3((unsigned)grid),
+                                                        dim3(256), params, 0, st);
+        (void)hipEventRecord(eb, st);
+        crec_prof_end(ctx, st);
+        return (int)e;
+    }
+    return (int)hipLaunchCooperativeKernel((const void *)bpr_steps_persistent<LPR, FULL>, dim3((unsigned)grid), dim3(256), params,
+                                           0, st);
+}
+
+using PersistFn = int (*)(crec_ctx *, StepsArgs &, hipStream_t);
+PersistFn pick_persistent(int d)
+{
+    int lpr = 1;
+    while (lpr * 4 < d)
+        lpr <<= 1;
+    const bool full = d == 4 * lpr;
+#define CREC_PICK(L) \
+    case L:          \
+        return full ? launch_persistent<L, true> : launch_persistent<L, false>;
+    switch (lpr) {
+        CREC_PICK(1)
+        CREC_PICK(2)
+        CREC_PICK(4)
+        CREC_PICK(8)
+        CREC_PICK(16)
+        CREC_PICK(32)
+        CREC_PICK(64)
+    }
+#undef CREC_PICK
+    return nullptr;
+}
+
 StepFn pick_step(int d, bool dense)
 {
     int lpr = 1;
@@ -1217,6 +1388,11 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
     CREC_HIP(ctx, hipFuncSetAttribute((const void *)bpr_index_batches, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds));
 
+    // tf1 single-GPU, opt-in (CREC_PERSISTENT=1): a chunk's steps inside one cooperative launch.  Measured slower than
+    // a launch per step on MI355X (65 vs 13 us per step): see the note at bpr_steps_persistent.
+    const char *persist_env = getenv("CREC_PERSISTENT");
+    const bool persistent = dense && !dp && persist_env && atoi(persist_env) != 0;
+    const PersistFn persist = pick_persistent(t->d);
     bool in_shadow = false; // tf1: which buffer set holds the current tables
     for (int64_t b0 = 0; b0 < nb; b0 += chunk) {
         const int64_t nbc = (nb - b0) < chunk ? (nb - b0) : chunk;
@@ -1226,10 +1402,60 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
         CREC_KLAUNCH(ctx, bpr_index_batches, dim3((unsigned)(2 * nbc)), dim3(PREP_THREADS), lds, st, u + t0, i + t0,
                            j + t0, n_chunk, B, w);
         crec_prof_end(ctx, st);
-        std::vector<int32_t> hn((size_t)nbc * 4);
-        CREC_HIP(ctx, hipMemcpyAsync(hn.data(), w.hn, sizeof(int32_t) * hn.size(), hipMemcpyDeviceToHost, st));
-        CREC_HIP(ctx, hipStreamSynchronize(st));
-        for (int64_t b = 0; b < nbc; ++b) {
+        if (persistent) {
+            // the chunk's steps in one cooperative launch: per-step lr_t from a table, the buffer sets alternate inside
+            std::vector<float> lr((size_t)nbc);
+            for (int64_t b = 0; b < nbc; ++b) { // lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t), fp32 running powers (TF1)
+                lr[(size_t)b] = (opt->lr * sqrtf(1.0f - opt->beta2_power)) / (1.0f - opt->beta1_power);
+                opt->beta1_power = opt->beta1_power * opt->beta1;
+                opt->beta2_power = opt->beta2_power * opt->beta2;
+                opt->step += 1;
+            }
+            if (int rc = crec_reserve(ctx, &ctx->lr_table, sizeof(float) * (size_t)nbc + 64))
+                return rc;
+            unsigned *bar = (unsigned *)((char *)ctx->lr_table.ptr + sizeof(float) * (size_t)nbc / 16 * 16 + 16);
+            CREC_HIP(ctx, hipMemcpyAsync(ctx->lr_table.ptr, lr.data(), sizeof(float) * (size_t)nbc, hipMemcpyHostToDevice, st));
+            CREC_HIP(ctx, hipMemsetAsync(bar, 0, 2 * sizeof(unsigned), st));
+            StepsArgs sa{};
+            sa.t0 = a.cur;
+            sa.t1 = a.other;
+            sa.d = a.d;
+            sa.U = a.U;
+            sa.I = a.I;
+            sa.w = w;
+            sa.partial = a.partial;
+            sa.tickets = a.tickets;
+            sa.loss_ws = (float *)ctx->loss_ws.ptr;
+            sa.loss_stride = loss_stride;
+            sa.lr_t = (const float *)ctx->lr_table.ptr;
+            sa.h.beta1 = opt->beta1;
+            sa.h.beta2 = opt->beta2;
+            sa.h.eps = opt->eps;
+            sa.h.reg = opt->reg;
+            sa.h.dQ = nullptr;
+            sa.n_steps = (int32_t)nbc;
+            sa.bar = bar;
+            const int e = persist(ctx, sa, st);
+            if (e != (int)hipSuccess)
+                return crec_fail(ctx, CREC_EHIP, "cooperative launch of bpr_steps_persistent failed: %s",
+                                 hipGetErrorString((hipError_t)e));
+            if (nbc & 1) {
+                Tables tmp = a.cur;
+                a.cur = a.other;
+                a.other = tmp;
+                in_shadow = !in_shadow;
+            }
+            unsigned flags[2] = {0, 0};
+            CREC_HIP(ctx, hipMemcpyAsync(flags, bar, sizeof flags, hipMemcpyDeviceToHost, st));
+            CREC_HIP(ctx, hipStreamSynchronize(st));
+            CREC_REQUIRE(ctx, flags[1] == 0, "bpr_steps_persistent: a grid barrier timed out (the tables are unusable)");
+        }
+        std::vector<int32_t> hn((size_t)(persistent ? 0 : nbc) * 4);
+        if (!persistent) {
+            CREC_HIP(ctx, hipMemcpyAsync(hn.data(), w.hn, sizeof(int32_t) * hn.size(), hipMemcpyDeviceToHost, st));
+            CREC_HIP(ctx, hipStreamSynchronize(st));
+        }
+        for (int64_t b = 0; b < (persistent ? 0 : nbc); ++b) {
             // lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t) with fp32 running powers (TF1 _prepare/_finish)
             a.h.lr_t = (opt->lr * sqrtf(1.0f - opt->beta2_power)) / (1.0f - opt->beta1_power);
             a.h.beta1 = opt->beta1;

@@ -86,6 +86,24 @@ def test_bpr_heavy_duplicates_and_large_scores(sess):
     _assert_state_close(st, om, atol=5e-5)
 
 
+def test_bpr_persistent_launch_matches_per_step_launches(sess, monkeypatch):
+    """CREC_PERSISTENT=1 (all steps of a chunk in one cooperative launch, device-wide barriers between steps): the
+    same tables bit for bit as a launch per step, heavy rows and a ragged last batch included."""
+    data = synthetic("S-ml100k")
+    P0, Q0 = _tables(5, data.user_nums, data.item_nums, 32)
+    sess.ctx.seed(2)
+    u, i, j = (sess.to_dev(a) for a in sess.ctx.sample_pairwise(data.train_csr, data.item_nums, 4))
+    n = 9 * 6144 + 1000
+    out = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("CREC_PERSISTENT", flag)
+        st = runtime.BprState(sess, P0, Q0, lr=1e-3, reg=0.01, adam_mode="tf1")
+        loss = st.train_epoch(u[:n], i[:n], j[:n], 6144)
+        out.append([t.cpu().numpy() for t in (loss, st.P, st.Q, st.mP, st.vQ)])
+    for a, b in zip(*out):
+        assert np.array_equal(a, b)
+
+
 def test_bpr_ml100k_shape_full_epoch(sess):
     """BASELINE config C1 shape (943 x 1349, d=32, B=6144, neg_ratio 4) on synthetic data."""
     data = synthetic("S-ml100k")
