@@ -67,6 +67,9 @@ struct WaveState {
     float *thr;  // [32] score a candidate must beat
     int *uid;    // [32] global user id, -1 for padding rows
     int cap;     // candidate slots per user
+    const uint32_t *bits; // optional [rows][words] membership bitmap of the users' lists (small catalogues), else nullptr
+    int64_t row0;         // bitmap row of this wave's first user
+    int words;
     int keep_listed; // 0: drop items found in the user's list (seen filter); 1: keep only those (candidates)
 };
 
@@ -80,18 +83,23 @@ __device__ inline void prune(const WaveState &ws, int ul, int K, const int64_t *
     u64 mine = lane < n ? buf[lane] : 0;
     if (lane >= clean && lane < n) {
         const int item = key_item(mine);
-        int64_t lo = seen_ptr[uid], hi = seen_ptr[uid + 1];
-        const int64_t end = hi;
-        while (lo < hi) {
-            int64_t mid = (lo + hi) >> 1;
-            if (seen_items[mid] < item)
-                lo = mid + 1;
-            else
-                hi = mid;
+        bool listed;
+        if (ws.bits) { // one load instead of a dependent chain of ~log2(list) loads
+            listed = (ws.bits[(ws.row0 + ul) * ws.words + (item >> 5)] >> (item & 31)) & 1u;
+        } else {
+            int64_t lo = seen_ptr[uid], hi = seen_ptr[uid + 1];
+            const int64_t end = hi;
+            while (lo < hi) {
+                int64_t mid = (lo + hi) >> 1;
+                if (seen_items[mid] < item)
+                    lo = mid + 1;
+                else
+                    hi = mid;
+            }
+            listed = lo < end && seen_items[lo] == item;
         }
         // exclude mode: listed = seen in training, never recommended (RankingRecommender.py:236);
         // keep mode: listed = the user's candidate items (leave-one-out / sampled-negative evaluation, :250-299)
-        const bool listed = lo < end && seen_items[lo] == item;
         if (listed != (ws.keep_listed != 0))
             mine = 0;
     }
@@ -123,7 +131,8 @@ __global__ __launch_bounds__(NW * 64) void eval_sweep(const float *__restrict__ 
                                                   int d, const int32_t *__restrict__ users, int Bt,
                                                   const int64_t *__restrict__ seen_ptr,
                                                   const int32_t *__restrict__ seen_items, int K, float sign,
-                                                  int64_t items_per_split, u64 *__restrict__ part /*[Bt][S][K]*/)
+                                                  int64_t items_per_split, u64 *__restrict__ part /*[Bt][S][K]*/,
+                                                  const uint32_t *__restrict__ bits, int words)
 {
     constexpr int HS = DMAX / 2;          // MFMA steps
     constexpr int LDQ = DMAX + 4;         // padded LDS row (floats)
@@ -144,7 +153,8 @@ __global__ __launch_bounds__(NW * 64) void eval_sweep(const float *__restrict__ 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int row = lane & 31, h = lane >> 5;
     // the host packs the filter mode above K: K | keep_listed << 16
-    WaveState ws{cand_all + wv * 32 * CAP, cnt_all + wv * 32, clean_all + wv * 32, thr_all + wv * 32, uid_all + wv * 32, CAP, K >> 16};
+    WaveState ws{cand_all + wv * 32 * CAP, cnt_all + wv * 32, clean_all + wv * 32, thr_all + wv * 32, uid_all + wv * 32, CAP, bits,
+                 (int64_t)blockIdx.x * USERS_PER_WG + wv * 32, words, K >> 16};
     K &= 0xffff;
 
     const int S = gridDim.y, sp = blockIdx.y;
@@ -447,6 +457,21 @@ __global__ __launch_bounds__(256) void rank_metrics_kernel(const int32_t *__rest
     }
 }
 
+// membership bitmap of the users' lists: bits[r][item / 32] |= 1 << (item % 32) for every listed item of user row r
+// (one wave per user row; integer OR is order-independent)
+__global__ __launch_bounds__(256) void list_bitmap(const int32_t *__restrict__ users, int Bt, const int64_t *__restrict__ ptr,
+                                                   const int32_t *__restrict__ items, int words, uint32_t *__restrict__ bits)
+{
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= Bt)
+        return;
+    const int32_t uu = users[r];
+    for (int64_t e = ptr[uu] + (threadIdx.x & 63); e < ptr[uu + 1]; e += 64) {
+        const int32_t it = items[e];
+        atomicOr(bits + r * words + (it >> 5), 1u << (it & 31));
+    }
+}
+
 template <int DMAX, int TI, int NW> constexpr size_t sweep_lds()
 {
     return sizeof(float) * 2 * TI * (DMAX + 4) + sizeof(u64) * NW * 32 * cap_of(NW) + sizeof(int) * NW * 32 * 4;
@@ -455,7 +480,7 @@ template <int DMAX, int TI, int NW> constexpr size_t sweep_lds()
 template <int DMAX, int TI, int NW>
 int launch_sweep(crec_ctx *ctx, dim3 grid, hipStream_t st, const float *P, const float *Q, int64_t I, int d,
                  const int32_t *users, int Bt, const int64_t *seen_ptr, const int32_t *seen_items, int K, float sign,
-                 int64_t per_split, u64 *part)
+                 int64_t per_split, u64 *part, const uint32_t *bits, int words)
 {
     constexpr size_t lds = sweep_lds<DMAX, TI, NW>();
     static_assert(lds <= 160 * 1024, "eval_sweep shape does not fit the LDS");
@@ -463,7 +488,7 @@ int launch_sweep(crec_ctx *ctx, dim3 grid, hipStream_t st, const float *P, const
                                       (int)lds));
     crec_prof_begin(ctx, CREC_K_EVAL_SWEEP, st);
     CREC_KLAUNCH(ctx, (eval_sweep<DMAX, TI, NW>), grid, dim3(NW * 64), lds, st, P, Q, I, d, users, Bt, seen_ptr, seen_items, K,
-                       sign, per_split, part);
+                       sign, per_split, part, bits, words);
     crec_prof_end(ctx, st);
     return CREC_OK;
 }
@@ -521,14 +546,26 @@ static int eval_topk_impl(crec_ctx *ctx, const float *P, const float *Q, int64_t
     const int64_t per_split = crec_ceil_div(n_item_tiles, S) * tile;
     S = crec_ceil_div(I, per_split);
 
-    if (int rc = crec_reserve(ctx, &ctx->eval_ws, sizeof(u64) * (size_t)Bt * S * K))
+    // small catalogues: the users' lists as bitmaps, so that a prune tests membership with one load instead of a
+    // binary search in global memory (the startup of every (user, split) sweep is prune-bound)
+    const int words = (int)crec_ceil_div(I, 32);
+    const size_t part_bytes = (sizeof(u64) * (size_t)Bt * S * K + 255) / 256 * 256;
+    const size_t bits_bytes = sizeof(uint32_t) * (size_t)Bt * words;
+    const bool use_bits = bits_bytes <= ((size_t)64 << 20) && !getenv("CREC_EVAL_NO_BITMAP");
+    if (int rc = crec_reserve(ctx, &ctx->eval_ws, part_bytes + (use_bits ? bits_bytes : 0)))
         return rc;
     u64 *part = (u64 *)ctx->eval_ws.ptr;
+    uint32_t *bits = use_bits ? (uint32_t *)((char *)ctx->eval_ws.ptr + part_bytes) : nullptr;
+    if (use_bits) {
+        CREC_HIP(ctx, hipMemsetAsync(bits, 0, bits_bytes, st));
+        hipLaunchKernelGGL(list_bitmap, dim3((unsigned)crec_ceil_div(Bt, 4)), dim3(256), 0, st, users, (int)Bt, seen_ptr, seen_items,
+                           words, bits);
+    }
     const float sign = ascending ? -1.0f : 1.0f;
     dim3 grid((unsigned)user_tiles, (unsigned)S);
     const int kk = K | (keep_listed << 16);
     int rc;
-#define CREC_SWEEP(DM, TL, W) launch_sweep<DM, TL, W>(ctx, grid, st, P, Q, I, d, users, Bt, seen_ptr, seen_items, kk, sign, per_split, part)
+#define CREC_SWEEP(DM, TL, W) launch_sweep<DM, TL, W>(ctx, grid, st, P, Q, I, d, users, Bt, seen_ptr, seen_items, kk, sign, per_split, part, bits, words)
     if (wide)
         rc = d <= 32 ? CREC_SWEEP(32, 64, 8) : d <= 64 ? CREC_SWEEP(64, 64, 8) : CREC_SWEEP(128, 32, 8);
     else
