@@ -302,6 +302,25 @@ __device__ inline void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) 
 #ifndef CREC_NT
 #define CREC_NT 0
 #endif
+#ifndef CREC_TICKET_FENCES
+#define CREC_TICKET_FENCES 0 // 1: publish heavy-row partials with plain stores + release/acquire fences
+#endif
+// device-coherent float4 traffic for the heavy-row partials: agent-scope (sc1) accesses are served at the level the
+// XCDs share, so publishing a partial needs no L2 write-back and reading it no L2 invalidate
+__device__ inline void st4_agent(float *p, float4 v)
+{
+    __hip_atomic_store(p + 0, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p + 2, v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p + 3, v.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline float4 ld4_agent(const float *p)
+{
+    return make_float4(__hip_atomic_load(p + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                       __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                       __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                       __hip_atomic_load(p + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
 typedef float crec_f4v __attribute__((ext_vector_type(4)));
 // streamed table output: rows written once per launch and not re-read by it
 __device__ inline void st4s(float *p, float4 v)
@@ -829,41 +848,45 @@ __device__ inline void chunk_wave(const Tables &src, int d, int4 item, const int
     } else {
         grad = slots_grad<LPR, 1 | (FULL ? 0x100 : 0), MODE, STORE_CONTRIB>(var, sl, 1, src.P, src.Q, d, occ, contrib, xb, h);
     }
-    if (on)
-        st4(partial + (int64_t)item.w * d + 4 * l, grad);
-    __threadfence();
+    // publish the partial, then take a ticket.  The partial travels with agent-scope stores (served where the XCDs
+    // meet) and the wave waits for their completion before its ticket: the same guarantee as a release fence for
+    // this one buffer, without writing back the whole L2 (a fence pair per chunk wave cost ~4 us of the launch).
+    if (CREC_TICKET_FENCES) {
+        if (on)
+            st4(partial + (int64_t)item.w * d + 4 * l, grad);
+        __threadfence();
+    } else {
+        if (on)
+            st4_agent(partial + (int64_t)item.w * d + 4 * l, grad);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     int ticket = 0;
     if (lane == 0)
-        ticket = atomicAdd(f.tickets + hidx, 1);
+        ticket = __hip_atomic_fetch_add(f.tickets + hidx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     ticket = __builtin_amdgcn_readfirstlane(ticket);
     const int first = rec.y, parts = rec.z >> 16, cnt = rec.z & 0xffff;
     if (ticket != parts - 1)
         return;
-    __threadfence();
+    if (CREC_TICKET_FENCES)
+        __threadfence();
+    else
+        asm volatile("" ::: "memory");
     grad = zero;
     if (on) {
         const float *pp = partial + (int64_t)first * d + 4 * l;
+        const auto ldp = [](const float *q) { return CREC_TICKET_FENCES ? ld4(q) : ld4_agent(q); };
         int p = 0;
-        for (; p + 16 <= parts; p += 16) { // chunk order, sixteen loads in flight
-            float4 t[16];
+        for (; p + 8 <= parts; p += 8) { // chunk order, eight rows in flight
+            float4 t[8];
 #pragma unroll
-            for (int k = 0; k < 16; ++k)
-                t[k] = ld4(pp + (int64_t)(p + k) * d);
+            for (int k = 0; k < 8; ++k)
+                t[k] = ldp(pp + (int64_t)(p + k) * d);
 #pragma unroll
-            for (int k = 0; k < 16; ++k)
-                add4(grad, t[k]);
-        }
-        for (; p + 4 <= parts; p += 4) {
-            float4 t[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                t[k] = ld4(pp + (int64_t)(p + k) * d);
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < 8; ++k)
                 add4(grad, t[k]);
         }
         for (; p < parts; ++p)
-            add4(grad, ld4(pp + (int64_t)p * d));
+            add4(grad, ldp(pp + (int64_t)p * d));
     }
     const float nr = group_sum<LPR>(dot4(var, var));
     if (on) {
@@ -879,7 +902,7 @@ __device__ inline void chunk_wave(const Tables &src, int d, int4 item, const int
         }
     }
     if (lane == 0)
-        f.tickets[hidx] = 0; // ready for the next launch
+        __hip_atomic_store(f.tickets + hidx, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next launch
 }
 
 // ------------------------------------------------------------------------------------
@@ -1324,11 +1347,11 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
     }
     StepFn step = pick_step(t->d, dense);
     const int64_t nb = crec_ceil_div(N, B);
-    // occurrences per heavy-row chunk: short chunks shorten the longest wave, but every chunk wave pays a
-    // device-scope fence and a ticket on its row's counter (measured on S-big: 16 -> 16.3 us, 32 -> 13.7, 64 -> 15.3
-    // for the item side).  tf1 mode at ml-1m shape only splits rows that would dominate the step.
+    // occurrences per heavy-row chunk: short chunks shorten the longest wave, every chunk wave pays a ticket on its
+    // row's counter.  Item side of S-big: CH 8 -> 12.4 us, 16 -> 11.4, 32 -> 12.0 (with fence-published partials the
+    // sweep read 16 -> 16.3, 32 -> 13.7, 64 -> 15.3).  tf1 mode at ml-1m shape: 32 -> 14.4 us/step, 64 -> 13.2.
     static const int ch_env = getenv("CREC_CH") ? atoi(getenv("CREC_CH")) : 0;
-    const int CH = ch_env > 0 ? ch_env : (dense ? 64 : 32);
+    const int CH = ch_env > 0 ? ch_env : (dense ? 64 : 16);
     CREC_REQUIRE(ctx, CH >= 1 && CH <= 255, "CREC_CH: 1..255");
 
     // chunk the epoch so the inverted indices of a chunk stay under ~1 GiB
