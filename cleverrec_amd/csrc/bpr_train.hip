@@ -332,6 +332,15 @@ __device__ inline void st4s(float *p, float4 v)
         st4(p, v);
     }
 }
+// write-through (agent-scope, sc1) 16-byte store: the line does not stay dirty in this XCD's L2, so a later device-wide
+// barrier needs no L2 write-back to publish it.  base: wave-uniform table pointer; off: float index (< 2^29)
+typedef unsigned crec_u4v __attribute__((ext_vector_type(4)));
+__device__ inline void st4_wt(float *base, int64_t off, float4 v)
+{
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000);
+    const crec_u4v x = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(x, r, (int)(off * 4), 0, 16 /* sc1 */);
+}
 __device__ inline float4 ld4s(const float *p) // streamed slot input (m, v: read once)
 {
     if (CREC_NT & 2) {
@@ -744,7 +753,7 @@ __device__ inline float4 slots_grad(float4 var, const Slot &sl, int n_valid, con
 // triple, every owner group stores its row term; bpr_reduce_loss does the softplus and the sums.
 // Per batch the workspace holds xb[B] then rowterm[RT] (RT = U + I in tf1 mode, 3B in lazy mode).
 // ------------------------------------------------------------------------------------
-template <int LPR, int MODE, bool STORE_CONTRIB, bool FULL>
+template <int LPR, int MODE, bool STORE_CONTRIB, bool FULL, bool WT = false>
 __device__ inline void row_wave(const Tables &src, const Tables &dst, int d, const Slot &sl, int n_valid,
                                 const int4 *__restrict__ occ, float *__restrict__ contrib, float *__restrict__ xb,
                                 float *__restrict__ rowterm_slot, bool dense, const Hyper &h)
@@ -772,9 +781,15 @@ __device__ inline void row_wave(const Tables &src, const Tables &dst, int d, con
             st4(h.dQ + ro, grad);
         } else {
             adam4(var, m, v, grad, sl.cnt > 0, h);
-            st4s((user ? dst.P : dst.Q) + ro, var);
-            st4s((user ? dst.mP : dst.mQ) + ro, m);
-            st4s((user ? dst.vP : dst.vQ) + ro, v);
+            if (WT) {
+                st4_wt(user ? dst.P : dst.Q, ro, var);
+                st4_wt(user ? dst.mP : dst.mQ, ro, m);
+                st4_wt(user ? dst.vP : dst.vQ, ro, v);
+            } else {
+                st4s((user ? dst.P : dst.Q) + ro, var);
+                st4s((user ? dst.mP : dst.mQ) + ro, m);
+                st4s((user ? dst.vP : dst.vQ) + ro, v);
+            }
         }
     }
 }
@@ -792,7 +807,7 @@ struct FinishArgs {
 // of a row take tickets; the wave that draws the last one adds the partials in chunk order (so the sum does not
 // depend on which wave that is), applies Adam and writes the row term -- no second launch.  The partials cross
 // workgroups, possibly XCDs: release fence before the ticket, acquire fence after it.
-template <int LPR, int MODE, bool STORE_CONTRIB, bool FULL>
+template <int LPR, int MODE, bool STORE_CONTRIB, bool FULL, bool WT = false>
 __device__ inline void chunk_wave(const Tables &src, int d, int4 item, const int4 *__restrict__ occ,
                                   float *__restrict__ contrib, float *__restrict__ xb, float *__restrict__ partial,
                                   const FinishArgs &f, const Hyper &h)
@@ -896,9 +911,15 @@ __device__ inline void chunk_wave(const Tables &src, int d, int4 item, const int
             st4(h.dQ + ro, grad);
         } else {
             adam4(var, m, v, grad, true, h);
-            st4((user ? f.dst.P : f.dst.Q) + ro, var);
-            st4((user ? f.dst.mP : f.dst.mQ) + ro, m);
-            st4((user ? f.dst.vP : f.dst.vQ) + ro, v);
+            if (WT) {
+                st4_wt(user ? f.dst.P : f.dst.Q, ro, var);
+                st4_wt(user ? f.dst.mP : f.dst.mQ, ro, m);
+                st4_wt(user ? f.dst.vP : f.dst.vQ, ro, v);
+            } else {
+                st4((user ? f.dst.P : f.dst.Q) + ro, var);
+                st4((user ? f.dst.mP : f.dst.mQ) + ro, m);
+                st4((user ? f.dst.vP : f.dst.vQ) + ro, v);
+            }
         }
     }
     if (lane == 0)
@@ -922,7 +943,7 @@ struct HeavyArgs {
 
 // the work of one wave id of a tf1 step: [0, HIu) user chunk waves, [HIu, HIu+HIq) item chunk waves, then WU waves
 // owning user rows, then WI waves owning item rows
-template <int LPR, bool FULL>
+template <int LPR, bool FULL, bool WT = false>
 __device__ __forceinline__ void fused_wave(int64_t wave_id, const Tables &src, const Tables &dst, int d, int64_t U, int64_t I,
                                            const int2 *__restrict__ u_rowseg, const int4 *__restrict__ u_occ,
                                            const int2 *__restrict__ q_rowseg, const int4 *__restrict__ q_occ,
@@ -932,13 +953,13 @@ __device__ __forceinline__ void fused_wave(int64_t wave_id, const Tables &src, c
     constexpr int R = Geo<LPR, ROWS_PER_WAVE>::R;
     const int g = (threadIdx.x & 63) / LPR;
     if (wave_id < hv.HIu) {
-        chunk_wave<LPR, 0, false, FULL>(src, d, hv.u_hitems[wave_id], u_occ, nullptr, xb, hv.partial,
+        chunk_wave<LPR, 0, false, FULL, WT>(src, d, hv.u_hitems[wave_id], u_occ, nullptr, xb, hv.partial,
                                         FinishArgs{hv.u_hrows, hv.tickets, dst, rowterm, 1}, h);
         return;
     }
     wave_id -= hv.HIu;
     if (wave_id < hv.HIq) {
-        chunk_wave<LPR, 1, false, FULL>(src, d, hv.q_hitems[wave_id], q_occ, nullptr, xb, hv.partial + (int64_t)hv.HIu * d,
+        chunk_wave<LPR, 1, false, FULL, WT>(src, d, hv.q_hitems[wave_id], q_occ, nullptr, xb, hv.partial + (int64_t)hv.HIu * d,
                                         FinishArgs{hv.q_hrows, hv.tickets + hv.HRu_max, dst, rowterm + U, 1}, h);
         return;
     }
@@ -957,9 +978,9 @@ __device__ __forceinline__ void fused_wave(int64_t wave_id, const Tables &src, c
     sl.cnt = g < n_valid ? rs.y : 0;
     float *rt = rowterm + (is_user ? 0 : U) + sl.row;
     if (is_user)
-        row_wave<LPR, 0, false, FULL>(src, dst, d, sl, n_valid, u_occ, nullptr, xb, rt, true, h);
+        row_wave<LPR, 0, false, FULL, WT>(src, dst, d, sl, n_valid, u_occ, nullptr, xb, rt, true, h);
     else
-        row_wave<LPR, 1, false, FULL>(src, dst, d, sl, n_valid, q_occ, nullptr, xb, rt, true, h);
+        row_wave<LPR, 1, false, FULL, WT>(src, dst, d, sl, n_valid, q_occ, nullptr, xb, rt, true, h);
 }
 
 template <int LPR, bool FULL>
@@ -998,10 +1019,12 @@ __global__ __launch_bounds__(256) void bpr_step_fused(Tables src, Tables dst, in
 // persistent grid walks the wave ids of step s, meets at a device-wide barrier, and goes on to step s+1 with the
 // buffer sets swapped.  The barrier has to re-create a kernel boundary's visibility by hand: every workgroup
 // releases its writes (they may sit in its XCD's L2) before it arrives and acquires after it leaves.
-// RESULT (tools/micro/grid_barrier.hip): the counter part of such a barrier costs 2.4-4 us with a two-level tree
-// (a flat counter serialises: 11 us for 610 workgroups), but the release + acquire fences (buffer_wbl2 / buffer_inv
-// on every workgroup) add 7-17 us even with nothing dirty -- more than the 7.6 us a kernel boundary costs.  With
-// this flat barrier the step takes 65 us instead of 13.  Results are identical (parity tests run both ways).
+// RESULT (tools/micro/grid_barrier.hip): the counter part of such a barrier costs 2.4 us (256 workgroups) to 5.6 us
+// (610) with a two-level tree -- a flat counter serialises: 11 us for 610 -- a release + acquire fence pair on every
+// workgroup (buffer_wbl2 / buffer_inv) adds 7-17 us even with nothing dirty, an acquire alone 1.7-2 us.  With
+// write-through table stores, the tree and an acquire-only exit the step takes 19-20 us against 16 us for a launch
+// per step on the same box: a kernel boundary (7.6 us) is no dearer than this barrier.  Results are identical
+// (the parity tests run both ways).
 // ------------------------------------------------------------------------------------
 struct StepsArgs {
     Tables t0, t1;   // step s reads (s & 1 ? t1 : t0) and writes the other
@@ -1018,16 +1041,31 @@ struct StepsArgs {
     unsigned *bar;     // [0] arrivals (monotonic), [1] set when a wait timed out
 };
 
-__device__ inline bool grid_barrier(unsigned *bar, unsigned target)
+// Device-wide barrier of a cooperative launch, epoch `it` (1, 2, ...).  Two-level arrival tree (a single counter
+// serialises: 11 us for 610 workgroups against 4-5 us), one release word everybody polls.  bar: [0] root counter,
+// [1] time-out flag, [16] release word, [32 + 16 g] counter of group g (FAN consecutive workgroups) -- 64 B apart.
+// Visibility: the tables are written with write-through (sc1) stores and every other cross-step buffer with
+// agent-scope accesses, so arriving only needs the wave's stores to have completed; leaving invalidates this CU's
+// L1 and the XCD's L2 copies of lines other XCDs rewrote (acquire fence).  A full release + acquire fence pair on
+// every workgroup would cost 7-17 us (tools/micro/grid_barrier.hip).
+constexpr unsigned BAR_FAN = 32;
+__device__ inline bool grid_barrier(unsigned *bar, unsigned it)
 {
     __shared__ int failed;
-    __syncthreads(); // every wave of the workgroup has issued its stores
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's write-through stores have landed
+    __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence(); // release: this XCD's L2 lines reach memory
-        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned nb = gridDim.x, b = blockIdx.x, g = b / BAR_FAN, ng = (nb + BAR_FAN - 1) / BAR_FAN;
+        const unsigned gsz = (g + 1) * BAR_FAN <= nb ? BAR_FAN : nb - g * BAR_FAN;
+        const unsigned t = __hip_atomic_fetch_add(bar + 32 + 16 * g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == it * gsz - 1) { // last of its group
+            const unsigned r = __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (r == it * ng - 1)
+                __hip_atomic_store(bar + 16, it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(); // 100 MHz
         int bad = 0;
-        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        while (__hip_atomic_load(bar + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < it) {
             __builtin_amdgcn_s_sleep(1);
             if (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ||
                 __builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { // 2 s: give up instead of hanging the GPU
@@ -1036,7 +1074,7 @@ __device__ inline bool grid_barrier(unsigned *bar, unsigned target)
                 break;
             }
         }
-        __threadfence(); // acquire: drop stale lines of the other XCDs' writes
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         failed = bad;
     }
     __syncthreads();
@@ -1070,9 +1108,9 @@ template <int LPR, bool FULL> __global__ __launch_bounds__(256) void bpr_steps_p
         float *xb = a.loss_ws + (int64_t)s * a.loss_stride, *rowterm = xb + w.B;
         const int64_t total = hv.HIu + hv.HIq + WU + WI;
         for (int64_t wid = my_wave; wid < total; wid += grid_waves)
-            fused_wave<LPR, FULL>(wid, src, dst, a.d, a.U, a.I, w.u_rowseg + (int64_t)s * w.U, w.u_occ + (int64_t)s * w.B,
+            fused_wave<LPR, FULL, true>(wid, src, dst, a.d, a.U, a.I, w.u_rowseg + (int64_t)s * w.U, w.u_occ + (int64_t)s * w.B,
                                   w.q_rowseg + (int64_t)s * w.I, w.q_occ + (int64_t)s * 2 * w.B, hv, xb, rowterm, h);
-        if (s + 1 < a.n_steps && !grid_barrier(a.bar, (unsigned)(s + 1) * gridDim.x))
+        if (s + 1 < a.n_steps && !grid_barrier(a.bar, (unsigned)(s + 1)))
             return;
     }
 }
@@ -1253,6 +1291,8 @@ template <int LPR, bool FULL> int launch_persistent(crec_ctx *ctx, StepsArgs &sa
     const int64_t want = crec_ceil_div(sa.w.HIu + sa.w.HIq + crec_ceil_div(sa.U, R) + crec_ceil_div(sa.I, R), 4);
     int64_t grid = (int64_t)per_cu * cus;
     grid = grid > want ? want : grid;
+    if (const char *g = getenv("CREC_PERSIST_GRID")) // tuning knob: fewer workgroups = cheaper barrier, less parallel slack
+        grid = atoi(g) > 0 && atoi(g) < grid ? atoi(g) : grid;
     void *params[] = {(void *)&sa};
     if (ctx->prof.on) { // a launch of many steps: a plain event bracket is accurate enough (cooperative launches
         crec_prof_begin(ctx, CREC_K_FINISH, st); // cannot carry their own events); class 8 = bpr_steps_persistent
@@ -1434,11 +1474,12 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
                 opt->beta2_power = opt->beta2_power * opt->beta2;
                 opt->step += 1;
             }
-            if (int rc = crec_reserve(ctx, &ctx->lr_table, sizeof(float) * (size_t)nbc + 64))
+            CREC_REQUIRE(ctx, bytesP < ((size_t)1 << 31) && bytesQ < ((size_t)1 << 31), "persistent launch: tables under 2 GiB each");
+            if (int rc = crec_reserve(ctx, &ctx->lr_table, sizeof(float) * (size_t)nbc + 64 + 8192))
                 return rc;
             unsigned *bar = (unsigned *)((char *)ctx->lr_table.ptr + sizeof(float) * (size_t)nbc / 16 * 16 + 16);
             CREC_HIP(ctx, hipMemcpyAsync(ctx->lr_table.ptr, lr.data(), sizeof(float) * (size_t)nbc, hipMemcpyHostToDevice, st));
-            CREC_HIP(ctx, hipMemsetAsync(bar, 0, 2 * sizeof(unsigned), st));
+            CREC_HIP(ctx, hipMemsetAsync(bar, 0, 8192, st));
             StepsArgs sa{};
             sa.t0 = a.cur;
             sa.t1 = a.other;

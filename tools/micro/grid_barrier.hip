@@ -15,6 +15,7 @@ __global__ __launch_bounds__(256) void k(unsigned *bar, int iters, int mode, int
         __syncthreads();
         if (threadIdx.x == 0) {
             if (mode & 4) __threadfence();
+            if (mode & 16) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             if ((mode & 3) == 0) { // flat
                 __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 wait_ge(bar, (unsigned)it * nb);
@@ -30,6 +31,7 @@ __global__ __launch_bounds__(256) void k(unsigned *bar, int iters, int mode, int
                 wait_ge(bar + 16, (unsigned)it);
             }
             if (mode & 4) __threadfence();
+            if (mode & 8) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
     }
@@ -40,14 +42,14 @@ int main()
     unsigned *bar; long long *out;
     (void)hipMalloc(&bar, 1 << 20); (void)hipMalloc(&out, 64);
     const int iters = 200;
-    for (int grid : {256, 610}) for (int mode : {0, 1, 4, 5}) for (int fan : {8, 16, 32}) {
+    for (int grid : {256, 610}) for (int mode : {0, 1, 5, 9, 17}) for (int fan : {32}) {
         if ((mode & 3) == 0 && fan != 8) continue;
         (void)hipMemset(bar, 0, 1 << 20);
         void *args[] = {&bar, (void *)&iters, &mode, &fan, &out};
         hipError_t e = hipLaunchCooperativeKernel((const void *)k, dim3(grid), dim3(256), args, 0, 0);
         (void)hipDeviceSynchronize();
         long long h; (void)hipMemcpy(&h, out, 8, hipMemcpyDeviceToHost);
-        printf("grid %d %s%s fan %2d: %.2f us per barrier (%s)\n", grid, (mode & 3) ? "tree" : "flat", (mode & 4) ? "+fences" : "", fan,
+        printf("grid %d %s%s fan %2d: %.2f us per barrier (%s)\n", grid, (mode & 3) ? "tree" : "flat", (mode & 4) ? "+fences" : (mode & 8) ? "+acquire only" : (mode & 16) ? "+release only" : "", fan,
                h * 0.01 / iters, hipGetErrorString(e));
     }
     return 0;
