@@ -1451,8 +1451,8 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
     CREC_HIP(ctx, hipFuncSetAttribute((const void *)bpr_index_batches, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds));
 
-    // tf1 single-GPU, opt-in (CREC_PERSISTENT=1): a chunk's steps inside one cooperative launch.  Measured slower than
-    // a launch per step on MI355X (65 vs 13 us per step): see the note at bpr_steps_persistent.
+    // tf1 single-GPU, opt-in (CREC_PERSISTENT=1): a chunk's steps inside one cooperative launch.  Measured no faster
+    // than a launch per step on MI355X (19-20 vs 16 us per step): see the note at bpr_steps_persistent.
     const char *persist_env = getenv("CREC_PERSISTENT");
     const bool persistent = dense && !dp && persist_env && atoi(persist_env) != 0;
     const PersistFn persist = pick_persistent(t->d);
