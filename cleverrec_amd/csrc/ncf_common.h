@@ -128,6 +128,67 @@ __device__ __forceinline__ void tile_gemm(int M, int N, int K, FA fa, FB fb, FS 
     }
 }
 
+// The same product with each wave taking a row block and TWO neighbouring column blocks at a time (N is walked in
+// steps of 32): the A operand -- which may be computed on the fly by fa -- is read once for both, and the two
+// accumulator chains interleave, so a dependent MFMA never waits on its predecessor.  For tall products (many row
+// blocks per wave); with few row blocks tile_gemm keeps more waves busy.
+template <int S, class FA, class FB>
+__device__ __forceinline__ void gemm_chunk2(f32x4 &acc0, f32x4 &acc1, int k0, int mc, int nc0, int nc1, int q, FA fa, FB fb)
+{
+    float a[S], b0[S], b1[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        a[s] = fa(mc, k0 + s + S * q);
+        b0[s] = fb(k0 + s + S * q, nc0);
+        b1[s] = fb(k0 + s + S * q, nc1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b0[s], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b1[s], acc1, 0, 0, 0);
+    }
+}
+
+template <int NWV, class FA, class FB, class FS>
+__device__ __forceinline__ void tile_gemm_wide(int M, int N, int K, FA fa, FB fb, FS fs)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l16 = lane & 15, q = lane >> 4;
+    const int nbn = (N + 31) >> 5, nblk = ((M + 15) >> 4) * nbn;
+    for (int blk = wave; blk < nblk; blk += NWV) {
+        const int m0 = (blk / nbn) << 4, n0 = (blk % nbn) << 5;
+        const int ni0 = n0 + l16, ni1 = n0 + 16 + l16;
+        const int mc = (m0 + l16) < M ? (m0 + l16) : M - 1, nc0 = ni0 < N ? ni0 : N - 1, nc1 = ni1 < N ? ni1 : N - 1;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        int k = 0;
+        for (; k + 64 <= K; k += 64)
+            gemm_chunk2<16>(acc0, acc1, k, mc, nc0, nc1, q, fa, fb);
+        if (k + 32 <= K) {
+            gemm_chunk2<8>(acc0, acc1, k, mc, nc0, nc1, q, fa, fb);
+            k += 32;
+        }
+        if (k + 16 <= K) {
+            gemm_chunk2<4>(acc0, acc1, k, mc, nc0, nc1, q, fa, fb);
+            k += 16;
+        }
+        for (; k < K; k += 4) { // K tail: columns past the end contribute zeros
+            const bool kok = k + q < K;
+            const int kc = kok ? k + q : K - 1;
+            const float a = kok ? fa(mc, kc) : 0.f;
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, fb(kc, nc0), acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, fb(kc, nc1), acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (m0 + q * 4 + j < M) {
+                if (ni0 < N)
+                    fs(m0 + q * 4 + j, ni0, acc0[j]);
+                if (ni1 < N)
+                    fs(m0 + q * 4 + j, ni1, acc1[j]);
+            }
+    }
+}
+
 // stage a row-major [rows x cols] weight matrix in LDS with row stride cols + 1
 template <int NTH>
 __device__ __forceinline__ void stage_weights(float *__restrict__ Wl, const float *__restrict__ W, int rows, int cols)

@@ -180,8 +180,8 @@ __global__ __launch_bounds__(PT) void ncf_pair_logits(NcfDev m, const int32_t *_
                 s += b[c];
                 O[p * ldo + c] = s > 0.f ? s : 0.f;
             };
-            if (k == 1)
-                tile_gemm<NWV>(
+            if (k == 1) // the tall product with the computed A operand: two column blocks per pass
+                tile_gemm_wide<NWV>(
                     TP, kout, kin,
                     [&](int p, int kk) {
                         const float v = Aul[(p / TI) * w1 + kk] + Bl[(p % TI) * ldb + kk];
