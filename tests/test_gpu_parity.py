@@ -170,8 +170,11 @@ def _eval_both(sess, data, P, Q, K, ascending=False, users=None):
 
 @pytest.mark.parametrize("d", [4, 32, 64, 128, 256])
 @pytest.mark.parametrize("ascending", [False, True])
-@pytest.mark.parametrize("shape", ["4", "8"])  # waves per workgroup of eval_sweep (8: where K and d allow it)
-def test_eval_topk_bit_exact(sess, d, ascending, shape, monkeypatch):
+@pytest.mark.parametrize("shape", ["4", "8", "8-search"])  # waves per workgroup of eval_sweep (8: where K and d allow it);
+def test_eval_topk_bit_exact(sess, d, ascending, shape, monkeypatch):  # "-search": binary-search seen filter, no bitmaps
+    if shape.endswith("-search"):
+        monkeypatch.setenv("CREC_EVAL_NO_BITMAP", "1")
+        shape = shape.split("-")[0]
     monkeypatch.setenv("CREC_EVAL_SHAPE", shape)
     data = _toy_data(5, 333, 700, 1, 120, test_every=1)
     P, Q = _tables(11, data.user_nums, data.item_nums, d, scale=1.0)
