@@ -120,7 +120,7 @@ IndexWs layout_index(void *base, int64_t nbc, int64_t B, int64_t U, int64_t I, b
 // ------------------------------------------------------------------------------------
 // block-wide exclusive scan of one int per thread (PREP_THREADS threads)
 // ------------------------------------------------------------------------------------
-__device__ inline int wave_incl_scan(int v)
+__device__ __forceinline__ int wave_incl_scan(int v)
 {
     const int lane = threadIdx.x & 63;
 #pragma unroll
@@ -132,7 +132,7 @@ __device__ inline int wave_incl_scan(int v)
     return v;
 }
 
-__device__ inline int block_excl_scan(int v, int *wave_sums /* [PREP_THREADS/64 + 1] LDS */, int *total)
+__device__ __forceinline__ int block_excl_scan(int v, int *wave_sums /* [PREP_THREADS/64 + 1] LDS */, int *total)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int incl = wave_incl_scan(v);
@@ -152,7 +152,7 @@ __device__ inline int block_excl_scan(int v, int *wave_sums /* [PREP_THREADS/64 
     return wave_sums[wave] + incl - v;
 }
 
-__device__ inline int lower_bound_key(const unsigned long long *keys, int n, unsigned long long key)
+__device__ __forceinline__ int lower_bound_key(const unsigned long long *keys, int n, unsigned long long key)
 {
     int lo = 0, hi = n;
     while (lo < hi) {
@@ -297,8 +297,8 @@ struct Tables { // one buffer set
     float *P, *mP, *vP, *Q, *mQ, *vQ;
 };
 
-__device__ inline float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
-__device__ inline void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
 #ifndef CREC_NT
 #define CREC_NT 0
 #endif
@@ -307,14 +307,14 @@ __device__ inline void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) 
 #endif
 // device-coherent float4 traffic for the heavy-row partials: agent-scope (sc1) accesses are served at the level the
 // XCDs share, so publishing a partial needs no L2 write-back and reading it no L2 invalidate
-__device__ inline void st4_agent(float *p, float4 v)
+__device__ __forceinline__ void st4_agent(float *p, float4 v)
 {
     __hip_atomic_store(p + 0, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(p + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(p + 2, v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(p + 3, v.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ inline float4 ld4_agent(const float *p)
+__device__ __forceinline__ float4 ld4_agent(const float *p)
 {
     return make_float4(__hip_atomic_load(p + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
                        __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
@@ -323,7 +323,7 @@ __device__ inline float4 ld4_agent(const float *p)
 }
 typedef float crec_f4v __attribute__((ext_vector_type(4)));
 // streamed table output: rows written once per launch and not re-read by it
-__device__ inline void st4s(float *p, float4 v)
+__device__ __forceinline__ void st4s(float *p, float4 v)
 {
     if (CREC_NT & 1) {
         crec_f4v t = {v.x, v.y, v.z, v.w};
@@ -335,13 +335,13 @@ __device__ inline void st4s(float *p, float4 v)
 // write-through (agent-scope, sc1) 16-byte store: the line does not stay dirty in this XCD's L2, so a later device-wide
 // barrier needs no L2 write-back to publish it.  base: wave-uniform table pointer; off: float index (< 2^29)
 typedef unsigned crec_u4v __attribute__((ext_vector_type(4)));
-__device__ inline void st4_wt(float *base, int64_t off, float4 v)
+__device__ __forceinline__ void st4_wt(float *base, int64_t off, float4 v)
 {
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000);
     const crec_u4v x = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
     __builtin_amdgcn_raw_buffer_store_b128(x, r, (int)(off * 4), 0, 16 /* sc1 */);
 }
-__device__ inline float4 ld4s(const float *p) // streamed slot input (m, v: read once)
+__device__ __forceinline__ float4 ld4s(const float *p) // streamed slot input (m, v: read once)
 {
     if (CREC_NT & 2) {
         const crec_f4v t = __builtin_nontemporal_load(reinterpret_cast<const crec_f4v *>(p));
@@ -349,9 +349,9 @@ __device__ inline float4 ld4s(const float *p) // streamed slot input (m, v: read
     }
     return ld4(p);
 }
-__device__ inline float dot4(float4 a, float4 b) { return ((a.x * b.x + a.y * b.y) + a.z * b.z) + a.w * b.w; }
+__device__ __forceinline__ float dot4(float4 a, float4 b) { return ((a.x * b.x + a.y * b.y) + a.z * b.z) + a.w * b.w; }
 
-template <int CTRL> __device__ inline float dpp_add(float v)
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v)
 {
     // v + (v read through the DPP lane pattern CTRL); all lanes active
     return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
@@ -360,7 +360,7 @@ template <int CTRL> __device__ inline float dpp_add(float v)
 // all-reduce over the LPR lanes of a group; every lane ends with the bit-identical sum.
 // xor-1 / xor-2 inside quads, then mirror patterns (a quad, then an 8-lane half, already holds one
 // value, so a mirror is as good as an xor), then real cross-row shuffles above 16 lanes.
-template <int LPR> __device__ inline float group_sum(float v)
+template <int LPR> __device__ __forceinline__ float group_sum(float v)
 {
     if (LPR >= 2)
         v = dpp_add<0xB1>(v); // quad_perm [1,0,3,2]
@@ -378,7 +378,7 @@ template <int LPR> __device__ inline float group_sum(float v)
 }
 
 // sum over the G groups of a wave (same lane position in each group)
-template <int LPR> __device__ inline float4 cross_group_sum(float4 g)
+template <int LPR> __device__ __forceinline__ float4 cross_group_sum(float4 g)
 {
 #pragma unroll
     for (int off = LPR; off < 64; off <<= 1) {
@@ -397,7 +397,7 @@ template <int LPR> __device__ inline float4 cross_group_sum(float4 g)
 }
 
 // Eigen softplus as TF1 evaluates -log_sigmoid (utils/tools.py:70-71)
-__device__ inline float tf_softplus(float z)
+__device__ __forceinline__ float tf_softplus(float z)
 {
     const float thr = -13.942385f; // log(FLT_EPSILON) + 2
     if (z > -thr)
@@ -413,19 +413,19 @@ __device__ inline float tf_softplus(float z)
 // rounded one by <= ~3e-7 of ITSELF (an update is ~lr = 1e-3), five orders below the 1e-5 parity bar.
 // -DCREC_EXACT_MATH restores the exactly rounded forms (bit-reproducible against the CPU oracle's Adam).
 #ifdef CREC_EXACT_MATH
-__device__ inline float adam_quot(float num, float v, float eps) { return num / (sqrtf(v) + eps); }
-__device__ inline float sigmoid_neg(float x) { return 1.0f / (1.0f + expf(x)); }
+__device__ __forceinline__ float adam_quot(float num, float v, float eps) { return num / (sqrtf(v) + eps); }
+__device__ __forceinline__ float sigmoid_neg(float x) { return 1.0f / (1.0f + expf(x)); }
 #else
-__device__ inline float adam_quot(float num, float v, float eps)
+__device__ __forceinline__ float adam_quot(float num, float v, float eps)
 {
     return num * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) + eps);
 }
-__device__ inline float sigmoid_neg(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(x)); }
+__device__ __forceinline__ float sigmoid_neg(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(x)); }
 #endif
 
 // TF1 Adam on one float4 of a row.  touched == false: the g = 0 sweep of a row the batch does not
 // index (m, v still decay and var still moves: _apply_sparse_shared).
-__device__ inline void adam4(float4 &var, float4 &m, float4 &v, float4 g, bool touched, const Hyper &h)
+__device__ __forceinline__ void adam4(float4 &var, float4 &m, float4 &v, float4 g, bool touched, const Hyper &h)
 {
     const float omb1 = 1.0f - h.beta1, omb2 = 1.0f - h.beta2;
     float *pv = &var.x, *pm = &m.x, *pw = &v.x;
@@ -444,20 +444,20 @@ __device__ inline void adam4(float4 &var, float4 &m, float4 &v, float4 g, bool t
     }
 }
 
-__device__ inline int4 shfl4(int4 v, int src)
+__device__ __forceinline__ int4 shfl4(int4 v, int src)
 {
     return make_int4(__shfl(v.x, src, 64), __shfl(v.y, src, 64), __shfl(v.z, src, 64), __shfl(v.w, src, 64));
 }
-__device__ inline float4 shfl4f(float4 v, int src)
+__device__ __forceinline__ float4 shfl4f(float4 v, int src)
 {
     return make_float4(__shfl(v.x, src, 64), __shfl(v.y, src, 64), __shfl(v.z, src, 64), __shfl(v.w, src, 64));
 }
-__device__ inline float4 shfl4f_xor(float4 v, int mask)
+__device__ __forceinline__ float4 shfl4f_xor(float4 v, int mask)
 {
     return make_float4(__shfl_xor(v.x, mask, 64), __shfl_xor(v.y, mask, 64), __shfl_xor(v.z, mask, 64),
                        __shfl_xor(v.w, mask, 64));
 }
-__device__ inline void add4(float4 &a, float4 b)
+__device__ __forceinline__ void add4(float4 &a, float4 b)
 {
     a.x = a.x + b.x;
     a.y = a.y + b.y;
@@ -467,7 +467,7 @@ __device__ inline void add4(float4 &a, float4 b)
 
 // x_b and s_b of one triple from the group's float4 slices: the ONE place this arithmetic lives,
 // so user-row and item-row waves agree bit for bit.
-template <int LPR> __device__ inline float triple_s(float4 p, float4 qi, float4 qj, float *x_out)
+template <int LPR> __device__ __forceinline__ float triple_s(float4 p, float4 qi, float4 qj, float *x_out)
 {
     if (CREC_ABL & 2) {
         *x_out = p.x + qi.x + qj.x;
@@ -511,7 +511,7 @@ struct Slot { // per lane: the slot of this lane's group (meaningful when g < n_
 };
 
 // sum over groups of acc[s], delivered to group s (slot owner); other groups' return value is unused
-template <int LPR, int RW> __device__ inline float4 reduce_to_owner(AccArr<LPR, RW> &acc)
+template <int LPR, int RW> __device__ __forceinline__ float4 reduce_to_owner(AccArr<LPR, RW> &acc)
 {
     constexpr int G = Geo<LPR, RW>::G, R = Geo<LPR, RW>::R;
     const int g = (threadIdx.x & 63) / LPR;
@@ -694,7 +694,7 @@ __device__ __forceinline__ void walk_range(const WaveCtx<Geo<LPR, RW>::R> &w, fl
 }
 
 template <int LPR, int RW, int MODE, bool STORE_CONTRIB>
-__device__ inline float4 slots_grad(float4 var, const Slot &sl, int n_valid, const float *__restrict__ P,
+__device__ __forceinline__ float4 slots_grad(float4 var, const Slot &sl, int n_valid, const float *__restrict__ P,
                                     const float *__restrict__ Q, int d, const int4 *__restrict__ occ,
                                     float *__restrict__ contrib, float *__restrict__ xb, const Hyper &h)
 {
@@ -754,7 +754,7 @@ __device__ inline float4 slots_grad(float4 var, const Slot &sl, int n_valid, con
 // Per batch the workspace holds xb[B] then rowterm[RT] (RT = U + I in tf1 mode, 3B in lazy mode).
 // ------------------------------------------------------------------------------------
 template <int LPR, int MODE, bool STORE_CONTRIB, bool FULL, bool WT = false>
-__device__ inline void row_wave(const Tables &src, const Tables &dst, int d, const Slot &sl, int n_valid,
+__device__ __forceinline__ void row_wave(const Tables &src, const Tables &dst, int d, const Slot &sl, int n_valid,
                                 const int4 *__restrict__ occ, float *__restrict__ contrib, float *__restrict__ xb,
                                 float *__restrict__ rowterm_slot, bool dense, const Hyper &h)
 {
@@ -808,7 +808,7 @@ struct FinishArgs {
 // depend on which wave that is), applies Adam and writes the row term -- no second launch.  The partials cross
 // workgroups, possibly XCDs: release fence before the ticket, acquire fence after it.
 template <int LPR, int MODE, bool STORE_CONTRIB, bool FULL, bool WT = false>
-__device__ inline void chunk_wave(const Tables &src, int d, int4 item, const int4 *__restrict__ occ,
+__device__ __forceinline__ void chunk_wave(const Tables &src, int d, int4 item, const int4 *__restrict__ occ,
                                   float *__restrict__ contrib, float *__restrict__ xb, float *__restrict__ partial,
                                   const FinishArgs &f, const Hyper &h)
 {
@@ -1022,8 +1022,8 @@ __global__ __launch_bounds__(256) void bpr_step_fused(Tables src, Tables dst, in
 // RESULT (tools/micro/grid_barrier.hip): the counter part of such a barrier costs 2.4 us (256 workgroups) to 5.6 us
 // (610) with a two-level tree -- a flat counter serialises: 11 us for 610 -- a release + acquire fence pair on every
 // workgroup (buffer_wbl2 / buffer_inv) adds 7-17 us even with nothing dirty, an acquire alone 1.7-2 us.  With
-// write-through table stores, the tree and an acquire-only exit the step takes 19-20 us against 16 us for a launch
-// per step on the same box: a kernel boundary (7.6 us) is no dearer than this barrier.  Results are identical
+// write-through table stores, the tree and an acquire-only exit the step takes 19-20 us against 13 us for a launch
+// per step: a kernel boundary (7.6 us) is cheaper than this barrier plus the slower write-through stores.  Results are identical
 // (the parity tests run both ways).
 // ------------------------------------------------------------------------------------
 struct StepsArgs {
@@ -1049,7 +1049,7 @@ struct StepsArgs {
 // L1 and the XCD's L2 copies of lines other XCDs rewrote (acquire fence).  A full release + acquire fence pair on
 // every workgroup would cost 7-17 us (tools/micro/grid_barrier.hip).
 constexpr unsigned BAR_FAN = 32;
-__device__ inline bool grid_barrier(unsigned *bar, unsigned it)
+__device__ __forceinline__ bool grid_barrier(unsigned *bar, unsigned it)
 {
     __shared__ int failed;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's write-through stores have landed
@@ -1452,7 +1452,7 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
                                       (int)lds));
 
     // tf1 single-GPU, opt-in (CREC_PERSISTENT=1): a chunk's steps inside one cooperative launch.  Measured no faster
-    // than a launch per step on MI355X (19-20 vs 16 us per step): see the note at bpr_steps_persistent.
+    // than a launch per step on MI355X (19-20 vs 13 us per step): see the note at bpr_steps_persistent.
     const char *persist_env = getenv("CREC_PERSISTENT");
     const bool persistent = dense && !dp && persist_env && atoi(persist_env) != 0;
     const PersistFn persist = pick_persistent(t->d);
