@@ -1,0 +1,43 @@
+"""Guards the hot kernels' register budget at build time (no GPU needed: hipcc cross-compiles).  A template change once
+turned the occurrence walk into a real function call: the fused BPR step went from 141 to 228 VGPRs (occupancy 3 -> 2)
+and from 13 to 16 us per step without any test noticing."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _resources(src, extra=()):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    cmd = [hipcc, "--offload-arch=gfx950", "-x", "hip", "-O3", "-std=c++17", "--cuda-device-only", "-c", *extra,
+           "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "cleverrec_amd", "csrc", src), "-o", os.devnull,
+           "-Rpass-analysis=kernel-resource-usage"]
+    err = subprocess.run(cmd, capture_output=True, text=True, check=True).stderr
+    out, name = {}, None
+    for line in err.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            out[name] = {}
+        for key in ("VGPRs", "ScratchSize [bytes/lane]", "Occupancy [waves/SIMD]"):
+            m = re.search(re.escape(key) + r": (\d+)", line)
+            if m and name and "remark" in line:
+                out[name][key.split(" ")[0]] = int(m.group(1))
+    return out
+
+
+def test_bpr_kernels_register_budget():
+    res = _resources("bpr_train.hip", ["-ffp-contract=off"])
+    fused = [v for k, v in res.items() if "bpr_step_fusedILi16ELb1" in k]
+    lazy = [v for k, v in res.items() if "bpr_side_lazyILi32E" in k and "ELb1" in k]
+    assert fused and lazy
+    for v in fused:  # d = 64: three waves per SIMD
+        assert v["VGPRs"] <= 168 and v["ScratchSize"] == 0 and v["Occupancy"] >= 3, v
+    for v in lazy:  # d = 128 lazy sides: four waves per SIMD
+        assert v["VGPRs"] <= 128 and v["ScratchSize"] == 0 and v["Occupancy"] >= 4, v
