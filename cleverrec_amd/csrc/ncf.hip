@@ -20,7 +20,10 @@
 
 namespace {
 
-constexpr int T = 32;        // instances per tile
+#ifndef NCF_T
+#define NCF_T 32
+#endif
+constexpr int T = NCF_T;     // instances per tile
 #ifndef NCF_NT
 #define NCF_NT 512
 #endif
