@@ -7,10 +7,10 @@ for d in sys.argv[1:]:
         with open(f) as fh:
             for row in csv.DictReader(fh):
                 name = row["Kernel_Name"]
-                m = re.search(r"(bpr_\w+|eval_\w+|rank_metrics\w*)", name)
+                m = re.search(r"(bpr_\w+|eval_\w+|rank_metrics\w*)(<[^>(]*>)?", name)
                 if not m:
                     continue
-                key = (m.group(1), row["Counter_Name"])
+                key = (m.group(1) + (m.group(2) or "").replace(" ", ""), row["Counter_Name"])
                 acc[key][0] += float(row["Counter_Value"]); acc[key][1] += 1
         for (k, c), (s, n) in sorted(acc.items()):
-            print("%-22s %-24s mean %14.1f  n=%d" % (k, c, s / n, n))
+            print("%-30s %-26s mean %16.1f  n=%d" % (k, c, s / n, n))

@@ -41,6 +41,13 @@ for r in rows[:12]:
 PY
   rm -rf $OUT/trace_$name/*/*kernel_trace.csv
 done
+# counters for the two secondary legs: HBM-side traffic of the S-big kernels, matrix-core busy cycles of the big eval
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --output-format csv -d $OUT/pmcbig_$c -- python $ROOT/tools/bench_big.py --steps 60 > /dev/null 2>&1 || echo "pmc big $c failed"
+done
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmceval_MFMA -- python $ROOT/tools/bench_eval_big.py --dim 128 > /dev/null 2>&1 || echo "pmc eval failed"
 cd $ROOT && python tools/pmc_summary.py $OUT/pmc_* > $OUT/pmc_summary.txt
+python tools/pmc_summary.py $OUT/pmcbig_* > $OUT/big_pmc_summary.txt
+python tools/pmc_summary.py $OUT/pmceval_* > $OUT/eval_big_pmc_summary.txt
 rm -rf $OUT/trace/*/*kernel_trace.csv
-cat $OUT/kernel_stats.txt $OUT/big_kernel_stats.txt $OUT/eval_big_kernel_stats.txt; cat $OUT/pmc_summary.txt
+cat $OUT/kernel_stats.txt $OUT/big_kernel_stats.txt $OUT/eval_big_kernel_stats.txt; cat $OUT/pmc_summary.txt $OUT/big_pmc_summary.txt $OUT/eval_big_pmc_summary.txt
