@@ -119,13 +119,16 @@ def main():
                    "neg_ratio": NEG, "adam_mode": "tf1", "sharding": "users sharded (one S-ml1m user shard per GPU), Q replicated, 1 RCCL all-reduce of dQ per step" if world > 1 else "none"},
     }
 
-    if rank == 0 and not a.no_extras:
-        # ---- roofline: per-kernel durations from HIP events on the launch stream ----------------
+    prof = None
+    if not a.no_extras:
+        # ---- roofline: per-kernel durations from the HIP events attached to each dispatch.  The data-parallel
+        # epoch is collective, so at N > 1 EVERY rank runs these steps; rank 0 reports its own kernels.
         sess.ctx.profile(True)
         run_steps(min(a.steps, n_epoch // B))
-        torch.cuda.synchronize()
+        fence()
         prof = sess.ctx.profile_read()
         sess.ctx.profile(False)
+    if rank == 0 and prof is not None:
         U, I = data.user_nums, data.item_nums
         # algorithmic bytes per launch (DESIGN.md "Algorithmic bytes"): SURVEY 8(d)'s 24d+12 per triple
         # split by which kernel owns the access, plus the tf1 Adam sweep 24*d*rows
@@ -158,6 +161,8 @@ def main():
         out["kernels"] = kern
         out["step_algorithmic_GBs"] = step_bytes / (dt / a.steps) / 1e9
 
+    if rank == 0 and prof is not None and world == 1 and not force_dp:  # single-process legs only at N = 1
+        U, I = data.user_nums, data.item_nums
         # ---- eval: all test users, full catalogue, K = 20 ---------------------------------------
         users = sess.to_dev(data.test_users)
         sp, si = sess.to_dev(data.seen_csr[0]), sess.to_dev(data.seen_csr[1])
