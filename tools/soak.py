@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""Randomised parity soak (GPU): many random shapes of the BPR step (both Adam modes, heavy rows included), the fused
+eval and the device sampler against the CPU oracle / the rule's properties.  Not part of the test suite (minutes of
+run time); `python tools/soak.py --minutes 3` prints one line per failure and a summary."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--minutes", type=float, default=3.0)
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    import torch
+    import oracle
+    from cleverrec_amd import runtime
+    from cleverrec_amd.data import RankingData
+    sess = runtime.Session(0)
+    g = np.random.Generator(np.random.PCG64(a.seed))
+    t_end = time.time() + 60 * a.minutes
+    n_bpr = n_eval = n_samp = fails = 0
+    while time.time() < t_end:
+        # ---- a BPR configuration: small catalogues make heavy rows; ragged batch sizes -------------------------------
+        U, I = int(g.integers(3, 400)), int(g.integers(6, 300))
+        d = int(g.choice([4, 8, 12, 16, 32, 64, 128, 256]))
+        B = int(g.choice([1, 7, 64, 333, 1000, 2048, 6144, 8192]))
+        nr = int(g.integers(1, 5))
+        mode = str(g.choice(["tf1", "lazy"]))
+        deg_hi = max(2, min(I - nr - 1, int(g.integers(2, 40))))
+        ui_train = {u: [int(x) for x in g.choice(I, size=int(g.integers(1, deg_hi + 1)), replace=False)] for u in range(U) if g.random() < 0.9}
+        if not ui_train:
+            continue
+        data = RankingData(U, I, ui_train, {u: [0] for u in list(ui_train)[:3]})
+        scale = float(g.choice([0.01, 0.3, 1.0]))
+        P0 = (g.standard_normal((U, d)) * scale).astype(np.float32)
+        Q0 = (g.standard_normal((I, d)) * scale).astype(np.float32)
+        st = runtime.BprState(sess, P0, Q0, lr=1e-3, reg=0.01, adam_mode=mode)
+        om = oracle.BprModel(P0, Q0, lr=1e-3, reg=0.01, adam_mode={"tf1": 0, "lazy": 1}[mode])
+        seed = int(g.integers(0, 2 ** 31))
+        sess.ctx.seed(seed)
+        rng = oracle.Rng(seed)
+        try:
+            for _ in range(2):
+                u, i, j = sess.ctx.sample_pairwise(data.train_csr, I, nr)
+                nb, ou, oi, oj = oracle.sample_pairwise(rng, data.ui_train, I, nr, B)
+                assert np.array_equal(u, ou) and np.array_equal(i, oi) and np.array_equal(j, oj), "index stream"
+                # at most 48 steps per epoch: the comparison is of the step, not of how fp32 rounding noise grows over
+                # thousands of Adam steps (tools/drift.py: ~1e-9 per step at |P| ~ 1e-2)
+                n = min(len(u), 48 * B)
+                nb = -(-n // B)
+                u, i, j, ou, oi, oj = u[:n], i[:n], j[:n], ou[:n], oi[:n], oj[:n]
+                loss = st.train_epoch(sess.to_dev(u), sess.to_dev(i), sess.to_dev(j), B).cpu().numpy()
+                ol = oracle.train_model_py(om, nb, ou, oi, oj, B)[1]
+                np.testing.assert_allclose(loss, ol, rtol=2e-5, atol=1e-6)
+            for name in ("P", "Q"):
+                # Adam's first steps move a weight by ~lr * g/|g|: where a gradient sum cancels to ~0, fp32 summation order
+                # decides its sign, and the two sides legitimately differ by up to a step or two on that element.  So:
+                # nearly every element tight, a vanishing fraction within a couple of Adam steps, nothing beyond.
+                diff = np.abs(getattr(st, name).cpu().numpy() - getattr(om, name))
+                loose = diff > 2e-4 * max(scale, 0.05)
+                assert loose.mean() <= 2e-3 and diff.max() <= 6e-3, "%s: %.3g of elements off, max %.3g" % (name, loose.mean(), diff.max())
+        except AssertionError as e:
+            fails += 1
+            print("BPR FAIL U=%d I=%d d=%d B=%d nr=%d mode=%s scale=%g seed=%d: %s" % (U, I, d, B, nr, mode, scale, seed, str(e).split("\n")[0:3]))
+        n_bpr += 1
+        # ---- eval: bit-exact ids and scores -------------------------------------------------------------------------
+        K = int(g.choice([1, 5, 10, 20, 24, 32]))
+        users = np.asarray(sorted(g.choice(U, size=int(g.integers(1, U + 1)), replace=False)), np.int32)
+        asc = bool(g.integers(0, 2))
+        os.environ["CREC_EVAL_SHAPE"] = str(g.choice(["4", "8"]))
+        if g.random() < 0.5:
+            os.environ["CREC_EVAL_NO_BITMAP"] = "1"
+        else:
+            os.environ.pop("CREC_EVAL_NO_BITMAP", None)
+        try:
+            seen_items = data.seen_csr[1] if len(data.seen_csr[1]) else np.zeros(1, np.int32)
+            ids, sc = runtime.eval_topk(sess, st.P, st.Q, sess.to_dev(users), sess.to_dev(data.seen_csr[0]), sess.to_dev(seen_items), K, asc)
+            Pn, Qn = st.P.cpu().numpy(), st.Q.cpu().numpy()
+            oids, oval = oracle.topk(oracle.scores(Pn, Qn, users, order=1), users, data.seen_csr[0], data.seen_csr[1], K, asc)
+            assert np.array_equal(ids.cpu().numpy(), oids), "top-K ids"
+            assert np.array_equal(sc.cpu().numpy(), oval), "top-K scores"
+        except AssertionError as e:
+            fails += 1
+            print("EVAL FAIL U=%d I=%d d=%d K=%d asc=%s shape=%s: %s" % (U, I, d, K, asc, os.environ.get("CREC_EVAL_SHAPE"), e))
+        n_eval += 1
+        # ---- device sampler: the rule -----------------------------------------------------------------------------------
+        try:
+            ds = runtime.DeviceSampler(sess, data, seed=seed)
+            neg = ds.negatives(nr).cpu().numpy()
+            eu = ds.edge_user.cpu().numpy()
+            seen = {k: set(v) for k, v in data.ui_train.items()}
+            for uu, row in zip(eu[::7], neg[::7]):
+                assert not (set(row.tolist()) & seen[int(uu)]) and len(set(row.tolist())) == len(row), "negatives rule"
+            assert neg.min() >= 0 and neg.max() < I
+        except AssertionError as e:
+            fails += 1
+            print("SAMPLER FAIL U=%d I=%d nr=%d: %s" % (U, I, nr, e))
+        n_samp += 1
+    print("soak: %d BPR configs, %d evals, %d sampler draws, %d failures" % (n_bpr, n_eval, n_samp, fails))
+    sys.exit(1 if fails else 0)
+
+
+if __name__ == "__main__":
+    main()
