@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""Randomised parity soak of the other graphs (GMF / MLP / NeuMF, FM, CML) against oracle/models_torch.py (GPU).
+`python tools/soak_models.py --minutes 2`.  Losses rtol 2e-5; parameters: nearly every element within 1e-5, a vanishing
+fraction within a couple of Adam steps (see tools/soak.py for why).
+Known benign source of a rare CML loss mismatch at B = 1: the WARP rank counts negatives with d_ui + margin - d_un > 0, an
+indicator; when that difference is within fp32 summation noise of 0 the count -- and log(rank + 1) -- legitimately differs
+(about one instance-negative pair in 10^6 with random data; diluted below tolerance in larger batches)."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def close(dev, ref, name):
+    diff = np.abs(dev.cpu().numpy().reshape(-1) - ref.reshape(-1))
+    loose = diff > 1e-5
+    assert loose.mean() <= 2e-3 and diff.max() <= 6e-3, "%s: %.3g of elements off, max %.3g" % (name, loose.mean(), diff.max())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--minutes", type=float, default=2.0)
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    import torch
+    from oracle import models_torch as MT
+    from cleverrec_amd import runtime
+    sess = runtime.Session(0)
+    g = np.random.Generator(np.random.PCG64(a.seed))
+    rnd = lambda *s, scale=0.1: (g.standard_normal(s) * scale).astype(np.float32)
+    t_end, n, fails = time.time() + 60 * a.minutes, {"ncf": 0, "fm": 0, "cml": 0}, 0
+    while time.time() < t_end:
+        U, I = int(g.integers(5, 120)), int(g.integers(5, 90))
+        B = int(g.choice([1, 31, 32, 33, 200, 1000]))
+        N = int(min(3 * B + g.integers(0, B + 1), 2500))
+        u, i = g.integers(0, U, N).astype(np.int32), g.integers(0, I, N).astype(np.int32)
+        # ---- NCF family -------------------------------------------------------------------------------------------------
+        kind = str(g.choice(["GMF", "MLP", "NeuMF"]))
+        dg = int(g.choice([4, 8, 12, 32, 64]))
+        n_layers = int(g.integers(1, 5))
+        L0 = int(g.choice([8, 16, 24, 40, 64, 128])) if n_layers < 4 else int(g.choice([16, 64, 128]))
+        ok = all((L0 >> k) % 2 == 0 and (L0 >> k) >= 2 for k in range(n_layers)) and (L0 // 2) % 4 == 0
+        if not ok:
+            n_layers, L0 = 2, 16
+        y = (g.random(N) < 0.2).astype(np.float32)
+        Ws, bs, w = [], [], L0
+        for _ in range(n_layers):
+            Ws.append(rnd(w, w // 2, scale=0.2)); bs.append(rnd(w // 2, scale=0.05)); w //= 2
+        try:
+            if kind == "GMF":
+                P, Q, h = rnd(U, dg), rnd(I, dg), rnd(dg, scale=0.5)
+                st = runtime.NcfState(sess, "GMF", {"P_gmf": P, "Q_gmf": Q}, [], [], h, lr=1e-3, reg_gmf=0.01)
+                om = MT.GMF(P, Q, h, lr=1e-3, reg=0.01)
+                names = [(st.t["P_gmf"], "P"), (st.t["Q_gmf"], "Q"), (st.h, "h_gmf")]
+            elif kind == "MLP":
+                P, Q, h = rnd(U, L0 // 2), rnd(I, L0 // 2), rnd(w, scale=0.5)
+                st = runtime.NcfState(sess, "MLP", {"P_mlp": P, "Q_mlp": Q}, Ws, bs, h, lr=1e-3, reg_mlp=0.01)
+                om = MT.MLP(P, Q, Ws, bs, h, lr=1e-3, reg=0.01)
+                names = [(st.t["P_mlp"], "P"), (st.t["Q_mlp"], "Q"), (st.h, "h_mlp")] + [(st.W[k], "W_%d" % k) for k in range(n_layers)]
+            else:
+                Pg, Qg, Pm, Qm, h = rnd(U, dg), rnd(I, dg), rnd(U, L0 // 2), rnd(I, L0 // 2), rnd(dg + w, scale=0.3)
+                st = runtime.NcfState(sess, "NeuMF", {"P_gmf": Pg, "Q_gmf": Qg, "P_mlp": Pm, "Q_mlp": Qm}, Ws, bs, h, lr=1e-3, reg_gmf=1e-2, reg_mlp=1e-3)
+                om = MT.NeuMF(Pg, Qg, Pm, Qm, Ws, bs, h, lr=1e-3, reg1=1e-2, reg2=1e-3)
+                names = [(st.t[k], k) for k in ("P_gmf", "Q_gmf", "P_mlp", "Q_mlp")] + [(st.h, "h_neumf")] + [(st.W[k], "W_%d" % k) for k in range(n_layers)]
+            loss = st.train_epoch(sess.to_dev(u), sess.to_dev(i), sess.to_dev(y), B).cpu().numpy()
+            ol = [om.step(u[b * B:(b + 1) * B], i[b * B:(b + 1) * B], y[b * B:(b + 1) * B]) for b in range(len(loss))]
+            np.testing.assert_allclose(loss, ol, rtol=2e-5, atol=1e-6)
+            for dev, name in names:
+                close(dev, om.numpy(name), name)
+        except AssertionError as e:
+            fails += 1
+            print("NCF FAIL %s U=%d I=%d B=%d N=%d dg=%d L0=%d layers=%d: %s" % (kind, U, I, B, N, dg, L0, n_layers, str(e).strip().split("\n")[0]))
+        n["ncf"] += 1
+        # ---- FM ---------------------------------------------------------------------------------------------------------
+        d, F, nf = int(g.choice([4, 8, 20, 32, 64])), int(g.integers(1, 9)), int(g.integers(10, 200))
+        Bf = int(g.choice([1, 64, 256]))
+        Nf = int(min(3 * Bf + g.integers(0, Bf + 1), 800))
+        w0, wi, vif = np.array([0.1], np.float32), rnd(nf), rnd(nf, d)
+        x_idx = g.integers(0, nf, (Nf, F)).astype(np.int32)
+        x_val = np.where(g.random((Nf, F)) < 0.7, 1.0, g.random((Nf, F)) * 2).astype(np.float32)
+        yy = g.integers(1, 6, Nf).astype(np.float32)
+        try:
+            st = runtime.FmState(sess, w0, wi, vif, lr=1e-3, reg=1e-3)
+            om = MT.FM(w0.reshape(()), wi, vif, lr=1e-3, reg=1e-3)
+            y_pre, loss = st.train_epoch(sess.to_dev(x_idx), sess.to_dev(x_val), sess.to_dev(yy), Bf)
+            ol = [om.step(x_idx[b * Bf:(b + 1) * Bf], x_val[b * Bf:(b + 1) * Bf], yy[b * Bf:(b + 1) * Bf]) for b in range(len(loss))]
+            np.testing.assert_allclose(loss.cpu().numpy(), ol, rtol=2e-5)
+            for dev, name in ((st.w0, "w0"), (st.wi, "wi"), (st.vif, "vif")):
+                close(dev, om.numpy(name), name)
+        except AssertionError as e:
+            fails += 1
+            print("FM FAIL d=%d F=%d nf=%d B=%d N=%d: %s" % (d, F, nf, Bf, Nf, str(e).strip().split("\n")[0]))
+        n["fm"] += 1
+        # ---- CML --------------------------------------------------------------------------------------------------------
+        dc, K = int(g.choice([4, 16, 32, 128])), int(g.integers(1, 25))
+        Bc = int(g.choice([1, 100, 700]))
+        Nc = int(min(2 * Bc + g.integers(0, Bc + 1), 1500))
+        uc, ic = g.integers(0, U, Nc).astype(np.int32), g.integers(0, I, Nc).astype(np.int32)
+        neg = g.integers(0, I, (Nc, K)).astype(np.int32)
+        P, Q = rnd(U, dc, scale=0.3), rnd(I, dc, scale=0.3)
+        try:
+            st = runtime.CmlState(sess, P, Q, lr=1e-3, reg=10.0, margin=1.0)
+            om = MT.CML(P, Q, lr=1e-3, reg=10.0, margin=1.0, item_nums=I)
+            loss = st.train_epoch(sess.to_dev(uc), sess.to_dev(ic), sess.to_dev(neg), Bc).cpu().numpy()
+            ol = [om.step(uc[b * Bc:(b + 1) * Bc], ic[b * Bc:(b + 1) * Bc], neg[b * Bc:(b + 1) * Bc]) for b in range(len(loss))]
+            np.testing.assert_allclose(loss, ol, rtol=5e-5, atol=1e-5)
+            close(st.P, om.numpy("P"), "P")
+            close(st.Q, om.numpy("Q"), "Q")
+        except AssertionError as e:
+            fails += 1
+            print("CML FAIL U=%d I=%d d=%d K=%d B=%d N=%d: %s" % (U, I, dc, K, Bc, Nc, str(e).strip().split("\n")[0]))
+        n["cml"] += 1
+    print("soak_models: %s, %d failures" % (n, fails))
+    sys.exit(1 if fails else 0)
+
+
+if __name__ == "__main__":
+    main()
