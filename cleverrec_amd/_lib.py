@@ -140,7 +140,7 @@ class Context:
 
     # ---- measurement ---------------------------------------------------------------------------
     KERNELS = ("bpr_index_batches", "bpr_step_fused", "bpr_user_side", "bpr_item_side", "bpr_reduce_loss", "eval_sweep",
-               "eval_merge", "rank_metrics", "bpr_finish_heavy", "bpr_adam_dense", "rows_index_batches", "rows_apply", "small_adam_dense", "ncf_tile", "fm_instances", "cml_instances", "ncf_pair_logits")
+               "eval_merge", "rank_metrics", "bpr_steps_persistent", "bpr_adam_dense", "rows_index_batches", "rows_apply", "small_adam_dense", "ncf_tile", "fm_instances", "cml_instances", "ncf_pair_logits")
 
     def profile(self, on):
         self.check(self.lib.crec_profile_enable(self.h, int(bool(on))))

@@ -54,7 +54,7 @@ const char *crec_last_error(const crec_ctx *ctx);
  * While enabled, every kernel launch of this ctx is bracketed by two events and each API call
  * ends with a stream synchronise (so do not time whole-job throughput with it on).
  * kernel_class: 0 bpr_index_batches, 1 bpr_step_fused, 2 bpr_user_side, 3 bpr_item_side,
- *               4 bpr_reduce_loss, 5 eval_sweep, 6 eval_merge, 7 rank_metrics, 8 (unused since heavy rows are finished by their last chunk wave), 9 bpr_adam_dense,
+ *               4 bpr_reduce_loss, 5 eval_sweep, 6 eval_merge, 7 rank_metrics, 8 bpr_steps_persistent (opt-in multi-step launch; heavy rows are finished by their last chunk wave), 9 bpr_adam_dense,
  *               10 rows_index_batches, 11 rows_apply, 12 small_adam_dense, 13 ncf_tile, 14 fm_instances, 15 cml_instances,
  *               16 ncf_pair_logits.
  * enable(.., 1) also clears the accumulated totals. */
