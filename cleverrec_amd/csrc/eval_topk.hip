@@ -73,20 +73,17 @@ struct WaveState {
     int keep_listed; // 0: drop items found in the user's list (seen filter); 1: keep only those (candidates)
 };
 
-// Keep the K best unseen entries of user row `ul`, sorted best first.  Whole wave.
-__device__ inline void prune(const WaveState &ws, int ul, int K, const int64_t *__restrict__ seen_ptr,
-                      const int32_t *__restrict__ seen_items)
+// Keep the K best unseen entries of user row `ul` (n buffered), sorted best first; returns how many stay.  Whole wave.
+__device__ inline int prune(const WaveState &ws, int ul, int K, int n, const int64_t *__restrict__ seen_ptr,
+                            const int32_t *__restrict__ seen_items)
 {
     const int lane = threadIdx.x & 63;
     u64 *buf = ws.cand + ul * ws.cap;
-    const int n = ws.cnt[ul], clean = ws.clean[ul], uid = ws.uid[ul];
     u64 mine = lane < n ? buf[lane] : 0;
-    if (lane >= clean && lane < n) {
-        const int item = key_item(mine);
-        bool listed;
-        if (ws.bits) { // one load instead of a dependent chain of ~log2(list) loads
-            listed = (ws.bits[(ws.row0 + ul) * ws.words + (item >> 5)] >> (item & 31)) & 1u;
-        } else {
+    if (!ws.bits) { // with bitmaps the candidates were filtered before they got here
+        const int clean = ws.clean[ul], uid = ws.uid[ul];
+        if (lane >= clean && lane < n) {
+            const int item = key_item(mine);
             int64_t lo = seen_ptr[uid], hi = seen_ptr[uid + 1];
             const int64_t end = hi;
             while (lo < hi) {
@@ -96,18 +93,30 @@ __device__ inline void prune(const WaveState &ws, int ul, int K, const int64_t *
                 else
                     hi = mid;
             }
-            listed = lo < end && seen_items[lo] == item;
+            // exclude mode: listed = seen in training, never recommended (RankingRecommender.py:236);
+            // keep mode: listed = the user's candidate items (leave-one-out / sampled-negative evaluation, :250-299)
+            const bool listed = lo < end && seen_items[lo] == item;
+            if (listed != (ws.keep_listed != 0))
+                mine = 0;
         }
-        // exclude mode: listed = seen in training, never recommended (RankingRecommender.py:236);
-        // keep mode: listed = the user's candidate items (leave-one-out / sampled-negative evaluation, :250-299)
-        if (listed != (ws.keep_listed != 0))
-            mine = 0;
+        if (lane < ws.cap) // a user's buffer may be shorter than the wave
+            buf[lane] = mine;
     }
-    if (lane < ws.cap) // a user's buffer may be shorter than the wave
-        buf[lane] = mine;
     lds_fence();
     int rank = 0;
-    for (int t = 0; t < n; ++t)
+    // all-pairs rank against the (<= 64) buffered keys: broadcast LDS reads, kept in flight eight at a time -- one at
+    // a time this loop was most of a prune (56 x an LDS round trip)
+    int t = 0;
+    for (; t + 8 <= n; t += 8) {
+        u64 k[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            k[q] = buf[t + q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            rank += k[q] > mine;
+    }
+    for (; t < n; ++t)
         rank += buf[t] > mine;
     lds_fence();
     const bool valid = mine != 0;
@@ -119,11 +128,10 @@ __device__ inline void prune(const WaveState &ws, int ul, int K, const int64_t *
         if (valid && rank == K - 1)
             ws.thr[ul] = key_score(mine);
     }
-    if (lane == 0) {
-        ws.cnt[ul] = kept;
+    if (lane == 0 && !ws.bits)
         ws.clean[ul] = kept;
-    }
     lds_fence();
+    return kept;
 }
 
 template <int DMAX, int TI, int NW>
@@ -235,8 +243,23 @@ __global__ __launch_bounds__(NW * 64) void eval_sweep(const float *__restrict__ 
         accA[r] = accB[r] = 0.f;
 
     // append block candidates (bits of `hit`) of block `item0 + row`; prunes full buffers
+    int cnt_reg = 0; // lane ul < 32: entries in user ul's candidate buffer (kept in a register: no LDS round trip per append)
     auto take_candidates = [&](const f32x16 acc, uint32_t hit, int64_t item) __attribute__((always_inline)) {
         bool pruned = false;
+        if (ws.bits) {
+            // small catalogues: drop listed (or keep only listed) items HERE, with one coalesced load of the 32 users'
+            // bitmap words for this 32-item block, so that a prune is pure LDS work.  Lane L < 32 holds user L's word.
+            const int64_t wi = (item - row) >> 5; // blocks are 32-aligned: one word per (user, block)
+            const uint32_t wmine = (lane < 32 && ws.uid[lane] >= 0) ? ws.bits[(ws.row0 + lane) * ws.words + wi] : 0u;
+            const uint32_t keep = ws.keep_listed ? 1u : 0u;
+            uint32_t ok = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t wr = (uint32_t)__shfl((int)wmine, (r & 3) + 8 * (r >> 2) + 4 * h, 64);
+                ok |= (((wr >> row) & 1u) == keep ? 1u : 0u) << r;
+            }
+            hit &= ok;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const bool is_cand = (hit >> r) & 1u;
@@ -248,16 +271,14 @@ __global__ __launch_bounds__(NW * 64) void eval_sweep(const float *__restrict__ 
                     if (m) {
                         const int ul = (r & 3) + 8 * (r >> 2) + 4 * hh;
                         const int c = __popc(m);
-                        int base = ws.cnt[ul];
+                        int base = __builtin_amdgcn_readlane(cnt_reg, ul); // the count lives in lane ul's register
                         if (base + c > CAP) {
-                            prune(ws, ul, K, seen_ptr, seen_items);
+                            base = prune(ws, ul, K, base, seen_ptr, seen_items);
                             pruned = true;
-                            base = ws.cnt[ul];
                         }
                         if (h == hh && is_cand)
                             ws.cand[ul * CAP + base + __popc(m & ((1u << row) - 1u))] = make_key(acc[r], (int)item);
-                        if (lane == 0)
-                            ws.cnt[ul] = base + c;
+                        cnt_reg = lane == ul ? base + c : cnt_reg;
                         lds_fence();
                     }
                 }
@@ -362,8 +383,7 @@ __global__ __launch_bounds__(NW * 64) void eval_sweep(const float *__restrict__ 
         const int gu = blockIdx.x * USERS_PER_WG + wv * 32 + ul;
         if (gu >= Bt)
             break;
-        prune(ws, ul, K, seen_ptr, seen_items);
-        const int n = ws.cnt[ul];
+        const int n = prune(ws, ul, K, __shfl(cnt_reg, ul, 64), seen_ptr, seen_items);
         if (lane < K)
             part[((int64_t)gu * S + sp) * K + lane] = lane < n ? ws.cand[ul * CAP + lane] : 0;
     }
