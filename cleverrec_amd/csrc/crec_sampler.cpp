@@ -125,48 +125,61 @@ template <class Body> void shuffled_apply(crec_mt19937 &r, int64_t n, uint32_t *
     constexpr int64_t CHUNK = 1 << 14;
     const int64_t n_chunks = (n + CHUNK - 1) / CHUNK;
     std::atomic<int64_t> front{n}, next{n_chunks - 1};
-    std::vector<std::thread> pool;
-    for (int w = 0; w < workers; ++w)
-        pool.emplace_back([&] {
-            for (;;) {
-                const int64_t c = next.fetch_sub(1, std::memory_order_relaxed); // chunks from the top down
-                if (c < 0)
-                    return;
-                const int64_t lo = c * CHUNK, hi = (lo + CHUNK) < n ? (lo + CHUNK) : n;
-                while (front.load(std::memory_order_acquire) > lo)
-                    std::this_thread::yield();
-                for (int64_t k = lo; k < hi; ++k) {
-                    if (k + 16 < hi)
-                        __builtin_prefetch(&perm[k + 16], 0, 1);
-                    body(k, perm[k]);
-                }
-            }
-        });
     // the shuffle itself in two stages: this thread owns the RNG and only draws the swap targets (they depend on the
     // stream alone), a second thread applies the swaps behind it -- generation and the cache-missing swaps overlap
-    std::vector<uint32_t> target((size_t)n);
+    std::vector<uint32_t> target;
     std::atomic<int64_t> drawn{n}; // steps k >= drawn have their target
-    std::thread swapper([&] {
-        for (int64_t k = 0; k < n; ++k)
-            perm[k] = (uint32_t)k;
-        constexpr int64_t AHEAD = 64;
-        int64_t avail = n; // local copy of `drawn`
-        for (int64_t k = n - 1; k >= 1; --k) {
-            while (avail > k) {
-                avail = drawn.load(std::memory_order_acquire);
-                if (avail > k)
-                    std::this_thread::yield();
+    std::thread swapper;
+    try { // nothing may escape through the C ABI: without memory or threads, do it serially
+        target.resize((size_t)n);
+        swapper = std::thread([&] {
+            for (int64_t k = 0; k < n; ++k)
+                perm[k] = (uint32_t)k;
+            constexpr int64_t AHEAD = 64;
+            int64_t avail = n; // local copy of `drawn`
+            for (int64_t k = n - 1; k >= 1; --k) {
+                while (avail > k) {
+                    avail = drawn.load(std::memory_order_acquire);
+                    if (avail > k)
+                        std::this_thread::yield();
+                }
+                if (k - AHEAD >= avail)
+                    __builtin_prefetch(&perm[target[k - AHEAD]], 1, 1);
+                const uint32_t j = target[k], tmp = perm[k];
+                perm[k] = perm[j];
+                perm[j] = tmp;
+                if ((k & 63) == 0) // positions >= k are never touched again: they are final
+                    front.store(k, std::memory_order_release);
             }
-            if (k - AHEAD >= avail)
-                __builtin_prefetch(&perm[target[k - AHEAD]], 1, 1);
-            const uint32_t j = target[k], tmp = perm[k];
-            perm[k] = perm[j];
-            perm[j] = tmp;
-            if ((k & 63) == 0) // positions >= k are never touched again: they are final
-                front.store(k, std::memory_order_release);
+            front.store(0, std::memory_order_release);
+        });
+    } catch (...) {
+        permutation(r, n, perm);
+        for (int64_t k = 0; k < n; ++k)
+            body(k, perm[k]);
+        return;
+    }
+    const auto gather = [&] { // chunks from the top down, each as soon as the shuffle has passed it
+        for (;;) {
+            const int64_t c = next.fetch_sub(1, std::memory_order_relaxed);
+            if (c < 0)
+                return;
+            const int64_t lo = c * CHUNK, hi = (lo + CHUNK) < n ? (lo + CHUNK) : n;
+            while (front.load(std::memory_order_acquire) > lo)
+                std::this_thread::yield();
+            for (int64_t k = lo; k < hi; ++k) {
+                if (k + 16 < hi)
+                    __builtin_prefetch(&perm[k + 16], 0, 1);
+                body(k, perm[k]);
+            }
         }
-        front.store(0, std::memory_order_release);
-    });
+    };
+    std::vector<std::thread> pool;
+    try {
+        for (int w = 0; w < workers; ++w)
+            pool.emplace_back(gather);
+    } catch (...) { // fewer workers than asked for: this thread picks up what is left at the end
+    }
     for (int64_t k = n - 1; k >= 1; --k) {
         const uint32_t kk = (uint32_t)k;
         target[k] = draw(r, kk, mask_of(kk));
@@ -175,6 +188,7 @@ template <class Body> void shuffled_apply(crec_mt19937 &r, int64_t n, uint32_t *
     }
     drawn.store(1, std::memory_order_release);
     swapper.join();
+    gather(); // whatever the workers have not claimed (everything, if there are none)
     for (auto &t : pool)
         t.join();
 }
