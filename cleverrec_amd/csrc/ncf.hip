@@ -4,15 +4,16 @@
 // Replaces sess.run([train, loss], {u_idx, i_idx, y}) (model/RankingRecommender.py:52-58) on the graphs
 // of model/ranking/GMF.py:29-57, MLP.py:31-77, NeuMF.py:33-105; see include/crec.h (crec_ncf).
 //
-// Per batch:
-//   ncf_tile        one workgroup per tile of T = 32 instances: gathers the embedding rows into LDS,
-//                   GMF product, the ReLU tower forward, logit, e = sigmoid(logit) - y, loss term,
-//                   tower backward -- all on chip; writes per-instance contribution rows for the
-//                   embedding tables (dL/drow without the l2 term) and per-tile partial gradients of
-//                   the small dense parameters (W_k, b_k, h).
-//   rows_apply      (rows_adam.hip) per embedding table: sum contribution rows per table row in batch
-//                   order (+ reg * row per occurrence), TF1 sparse Adam over every row.
-//   small_adam_dense the small parameters: tile partials added in tile order, TF1 dense ApplyAdam.
+// Per batch, two launches:
+//   ncf_tile        one workgroup (8 waves) per tile of T = 32 instances, everything on chip: every tower weight,
+//                   bias and h staged in LDS once; gathers of the embedding rows; ReLU tower forward and backward
+//                   as 16x16x4 fp32 MFMA products between LDS buffers (tile_gemm, ncf_common.h); GMF product, logit,
+//                   e = sigmoid(logit) - y, loss term.  Writes per-instance contribution rows for the embedding
+//                   tables (dL/drow without the l2 term; layer 0's dL/dX goes straight out) and per-tile partial
+//                   gradients of the small dense parameters (W_k, b_k, h).
+//   crec_apply_all  (rows_adam.hip) every parameter update in one launch: per embedding table, contribution rows
+//                   summed per table row in batch order (+ reg * row per occurrence), TF1 sparse Adam over every
+//                   row; the small parameters: tile partials added in 16 fixed slices, TF1 dense ApplyAdam.
 // Everything is deterministic (fixed summation orders, no atomics).
 #include "crec_internal.h"
 #include "rows_adam.h"

@@ -11,6 +11,8 @@
 //                    every row; g = contributions + dense_reg*var (+ an optional dense gradient).
 //
 // In place is safe: the instance kernel has already consumed the old rows.
+// A step's updates go out as ONE launch (apply_all: up to four tables of one row-width class, an optional
+// one-column table, the small dense vector): these steps are bound by launches, not bytes.
 #include "crec_internal.h"
 #include "rows_adam.h"
 
