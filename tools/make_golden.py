@@ -200,6 +200,38 @@ def rating_case(ref):
     return out
 
 
+def libfm_case(ref):
+    """utils/fm_to_libfm.py run as the script it is, inside a scratch tree: cwd = <tmp>/utils so that its
+    '../dataset/ml-1m/ratings.dat' is a synthetic file and its outputs land in <tmp>.  The golden holds the input
+    text, the seed and the two output texts."""
+    import runpy
+    g = np.random.Generator(np.random.PCG64(33))
+    tmp = tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp, "utils"))
+    os.makedirs(os.path.join(tmp, "dataset", "ml-1m"))
+    users = g.choice(np.arange(1, 400), size=90, replace=False)
+    items = g.choice(np.arange(1, 4000), size=250, replace=False)
+    lines = ["%d::%d::%d::%d" % (g.choice(users), g.choice(items), g.integers(1, 6), 956703932 + g.integers(0, 10 ** 7))
+             for _ in range(1500)]
+    text = "\n".join(lines) + "\n"
+    with open(os.path.join(tmp, "dataset", "ml-1m", "ratings.dat"), "w") as f:
+        f.write(text)
+    cwd = os.getcwd()
+    sys.path.insert(0, os.path.join(ref, "utils"))
+    os.chdir(os.path.join(tmp, "utils"))
+    try:
+        np.random.seed(7)
+        runpy.run_path(os.path.join(ref, "utils", "fm_to_libfm.py"), run_name="__main__")
+    finally:
+        os.chdir(cwd)
+        sys.path.pop(0)
+    out = {"seed": 7, "ratings": text}
+    for part in ("train", "test"):
+        with open(os.path.join(tmp, "dataset", "ml-1m", "ml-1m.%s.libfm" % part)) as f:
+            out[part] = f.read()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -223,6 +255,8 @@ def main():
         json.dump(metrics_cases(metrics), f)
     np.savez_compressed(os.path.join(a.out, "preprocess_syn.npz"), **preprocess_case(a.ref))
     np.savez_compressed(os.path.join(a.out, "rating_syn.npz"), **rating_case(a.ref))
+    with open(os.path.join(a.out, "libfm_syn.json"), "w") as f:
+        json.dump(libfm_case(a.ref), f)
     anchor = ml100k_anchor(a.ref, sampler)
     if anchor is not None:
         with open(os.path.join(a.out, "ml100k_anchor.json"), "w") as f:
