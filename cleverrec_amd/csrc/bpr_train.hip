@@ -5,8 +5,8 @@
 // with tf.train.AdamOptimizer semantics (utils/tools.py:83-84); see include/crec.h.
 //
 // Per chunk of batches, one launch:
-//   bpr_index_batches  one workgroup per (batch, side): bitonic sort in LDS of (row, position)
-//                      keys -> unique rows, segment starts, occurrence records {u, i, j, pos}.
+//   bpr_index_batches  one workgroup per (batch, side): stable radix sort in LDS of (row, position)
+//                      pairs (block_sort.h) -> unique rows, segment starts, occurrence records {u, i, j, pos}.
 //                      This is the "unique + unsorted_segment_sum" bookkeeping of TF1's sparse
 //                      Adam, done once for the whole chunk, in batch position order, i-slices
 //                      before j-slices, so every row sum has one fixed order (deterministic).
@@ -38,6 +38,7 @@
 // element-wise Eigen kernels TF1 runs (and like the CPU oracle), so the Adam arithmetic is
 // bit-reproducible.
 #include "crec_internal.h"
+#include "block_sort.h"
 
 #include <rccl/rccl.h>
 
@@ -60,6 +61,9 @@ constexpr bool PIPELINED = CREC_PIPE;   // two trips in flight
 #ifndef CREC_ABL
 #define CREC_ABL 0
 #endif
+#ifndef CREC_FUSED_WT
+#define CREC_FUSED_WT 0 // 1: the launch-per-step tf1 kernel writes its tables with write-through (sc1) stores
+#endif
 
 // ------------------------------------------------------------------------------------
 // index workspace layout for one chunk of nbc batches
@@ -76,10 +80,19 @@ struct IndexWs {
     int4 *u_hitems, *q_hitems; // [nbc][HIu|HIq]  {row, segment start, length | heavy row index << 8, chunk index}
     int64_t B, U, I, HRu, HRq, HIu, HIq;
     int32_t CH;                // rows with more than CH occurrences are split into chunks of CH
+    int32_t bits_u, bits_q;    // significant bits of a user / item row id (radix passes of the index sort)
     size_t bytes;
 };
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+inline int row_bits(int64_t n_rows)
+{
+    int b = 1;
+    while (b < 32 && ((int64_t)1 << b) < n_rows)
+        ++b;
+    return b;
+}
 
 IndexWs layout_index(void *base, int64_t nbc, int64_t B, int64_t U, int64_t I, bool dense, int CH)
 {
@@ -88,6 +101,8 @@ IndexWs layout_index(void *base, int64_t nbc, int64_t B, int64_t U, int64_t I, b
     w.U = dense ? U : 0;
     w.I = dense ? I : 0;
     w.CH = CH;
+    w.bits_u = row_bits(U);
+    w.bits_q = row_bits(I);
     w.HRu = B / (CH + 1) + 1;
     w.HRq = 2 * B / (CH + 1) + 1;
     w.HIu = B / CH + w.HRu + 1;
@@ -118,170 +133,111 @@ IndexWs layout_index(void *base, int64_t nbc, int64_t B, int64_t U, int64_t I, b
 }
 
 // ------------------------------------------------------------------------------------
-// block-wide exclusive scan of one int per thread (PREP_THREADS threads)
+// bpr_index_batches: grid = 2*nbc workgroups; block b>>1 = batch, b&1 = side (0 user, 1 item).
+// Stable radix sort in LDS of the side's (row, slot) pairs (block_sort.h): slots are the triples' positions on the
+// user side, i-slices then j-slices on the item side, so that a row's occurrences come out in batch order, i before j.
+// LDS: rows u32[cap], tag u16[cap], seg u16[cap+64], digit counters, scan scratch (cap = 2B rounded up to 64).
 // ------------------------------------------------------------------------------------
-__device__ __forceinline__ int wave_incl_scan(int v)
+inline size_t index_lds_bytes(int cap)
 {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        int t = __shfl_up(v, off, 64);
-        if (lane >= off)
-            v += t;
-    }
-    return v;
+    return sizeof(uint32_t) * cap + sizeof(uint16_t) * (2 * (size_t)cap + 64) +
+           sizeof(int) * (crec_sort::hist_ints<PREP_THREADS>() + crec_sort::scan_ints<PREP_THREADS>());
 }
 
-__device__ __forceinline__ int block_excl_scan(int v, int *wave_sums /* [PREP_THREADS/64 + 1] LDS */, int *total)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int incl = wave_incl_scan(v);
-    if (lane == 63)
-        wave_sums[wave] = incl;
-    __syncthreads();
-    if (wave == 0) {
-        int s = lane < PREP_THREADS / 64 ? wave_sums[lane] : 0;
-        int si = wave_incl_scan(s);
-        if (lane < PREP_THREADS / 64)
-            wave_sums[lane] = si - s;
-        if (lane == PREP_THREADS / 64 - 1)
-            wave_sums[PREP_THREADS / 64] = si;
-    }
-    __syncthreads();
-    *total = wave_sums[PREP_THREADS / 64];
-    return wave_sums[wave] + incl - v;
-}
-
-__device__ __forceinline__ int lower_bound_key(const unsigned long long *keys, int n, unsigned long long key)
-{
-    int lo = 0, hi = n;
-    while (lo < hi) {
-        int mid = (lo + hi) >> 1;
-        if (keys[mid] < key)
-            lo = mid + 1;
-        else
-            hi = mid;
-    }
-    return lo;
-}
-
-// ------------------------------------------------------------------------------------
-// bpr_index_batches: grid = 2*nbc workgroups; block b>>1 = batch, b&1 = side (0 user, 1 item)
-// ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t *__restrict__ u,
                                                                   const int32_t *__restrict__ i,
                                                                   const int32_t *__restrict__ j, int64_t n_total,
-                                                                  int32_t B, IndexWs w)
+                                                                  int32_t B, int32_t cap, IndexWs w)
 {
-    extern __shared__ unsigned long long keys[]; // [n_pad], then int scan scratch
+    extern __shared__ uint32_t rows[]; // [cap]
+    uint16_t *tag = (uint16_t *)(rows + cap);
+    uint16_t *seg = tag + cap; // [cap + 64] run starts by rank, closed by n
+    int *hist = (int *)(seg + cap + 64);
+    int *scan = hist + crec_sort::hist_ints<PREP_THREADS>();
     const int batch = blockIdx.x >> 1, side = blockIdx.x & 1;
     const int tid = threadIdx.x;
     const int64_t t0 = (int64_t)batch * B;
     const int nb = (int)((n_total - t0) < B ? (n_total - t0) : B); // triples in this batch
     const int n = side ? 2 * nb : nb;
     const int CH = w.CH;
-    int n_pad = 64;
-    while (n_pad < n)
-        n_pad <<= 1;
-    int *scratch = (int *)(keys + n_pad);
 
-    for (int k = tid; k < n_pad; k += PREP_THREADS) {
-        unsigned long long key = ~0ull;
-        if (k < n) {
-            if (side == 0) {
-                key = ((unsigned long long)(uint32_t)u[t0 + k] << 32) | (uint32_t)k;
-            } else { // i-slices first, then j-slices: the side flag is the high payload bit
-                int pos = k < nb ? k : k - nb;
-                uint32_t sd = k < nb ? 0u : 1u;
-                int32_t row = sd ? j[t0 + pos] : i[t0 + pos];
-                key = ((unsigned long long)(uint32_t)row << 32) | (sd << 31) | (uint32_t)pos;
-            }
-        }
-        keys[k] = key;
+    for (int k = tid; k < n; k += PREP_THREADS) {
+        rows[k] = (uint32_t)(side == 0 ? u[t0 + k] : (k < nb ? i[t0 + k] : j[t0 + k - nb]));
+        tag[k] = (uint16_t)k;
     }
-    __syncthreads();
+    crec_sort::block_sort_rows<PREP_THREADS>(rows, tag, n, side ? w.bits_q : w.bits_u, hist, scan);
 
-    // bitonic sort, ascending
-    for (int k = 2; k <= n_pad; k <<= 1) {
-        for (int jj = k >> 1; jj > 0; jj >>= 1) {
-            for (int t = tid; t < (n_pad >> 1); t += PREP_THREADS) {
-                int lo = ((t & ~(jj - 1)) << 1) | (t & (jj - 1));
-                int hi = lo + jj;
-                unsigned long long a = keys[lo], b = keys[hi];
-                bool up = (lo & k) == 0;
-                if ((a > b) == up) {
-                    keys[lo] = b;
-                    keys[hi] = a;
-                }
-            }
-            __syncthreads();
-        }
-    }
-
-    // pass 1: heads of equal-row runs; heavy rows (more than CH occurrences) and their chunk counts
-    const int per = n_pad / PREP_THREADS > 0 ? n_pad / PREP_THREADS : 1;
-    const int k0 = tid * per;
-    int heads = 0, hv = 0; // hv = heavy rows << 16 | chunks
-    for (int k = k0; k < k0 + per && k < n; ++k) {
-        const uint32_t row = (uint32_t)(keys[k] >> 32);
-        if (k == 0 || row != (uint32_t)(keys[k - 1] >> 32)) {
-            ++heads;
-            const int cnt = lower_bound_key(keys, n, (unsigned long long)(row + 1) << 32) - k;
-            if (cnt > CH)
-                hv += (1 << 16) + (cnt + CH - 1) / CH;
-        }
-    }
+    // run starts (blocked over positions, so that the scan runs in sorted order) -> seg[rank]
+    const int per = (n + PREP_THREADS - 1) / PREP_THREADS;
+    const int k0 = tid * per, k1 = (k0 + per) < n ? (k0 + per) : n;
+    int heads = 0;
+    for (int k = k0; k < k1; ++k)
+        heads += (k == 0 || rows[k] != rows[k - 1]) ? 1 : 0;
     int total = 0, hv_total = 0;
-    int rank = block_excl_scan(heads, scratch, &total);
+    int rank = crec_sort::block_excl_scan<PREP_THREADS>(heads, scan, &total);
+    for (int k = k0; k < k1; ++k)
+        if (k == 0 || rows[k] != rows[k - 1])
+            seg[rank++] = (uint16_t)k;
+    if (tid == 0)
+        seg[total] = (uint16_t)n;
     __syncthreads();
-    const int hv_before = block_excl_scan(hv, scratch, &hv_total);
-    int hrow = hv_before >> 16, hitem = hv_before & 0xffff;
 
-    int32_t *rows_out = side ? w.q_rows + (int64_t)batch * 2 * B : w.u_rows + (int64_t)batch * B;
-    int32_t *seg_out = side ? w.q_seg + (int64_t)batch * (2 * B + 1) : w.u_seg + (int64_t)batch * (B + 1);
-    int4 *occ_out = side ? w.q_occ + (int64_t)batch * 2 * B : w.u_occ + (int64_t)batch * B;
+    // heavy rows (more than CH occurrences) and their chunks, in rank order (blocked over ranks)
     int4 *hrows_out = side ? w.q_hrows + (int64_t)batch * w.HRq : w.u_hrows + (int64_t)batch * w.HRu;
     int4 *hitems_out = side ? w.q_hitems + (int64_t)batch * w.HIq : w.u_hitems + (int64_t)batch * w.HIu;
-    for (int k = k0; k < k0 + per && k < n; ++k) {
-        unsigned long long key = keys[k];
-        uint32_t row = (uint32_t)(key >> 32);
-        if (k == 0 || row != (uint32_t)(keys[k - 1] >> 32)) {
-            const int cnt = lower_bound_key(keys, n, (unsigned long long)(row + 1) << 32) - k;
-            const bool heavy = cnt > CH;
-            rows_out[rank] = (int32_t)(row | (heavy ? 0x80000000u : 0u));
-            seg_out[rank] = k;
-            if (heavy) {
-                const int parts = (cnt + CH - 1) / CH, my_h = hrow++;
-                hrows_out[my_h] = make_int4((int)row, hitem, (parts << 16) | cnt, rank);
+    const int rper = (total + PREP_THREADS - 1) / PREP_THREADS;
+    const int q0 = tid * rper, q1 = (q0 + rper) < total ? (q0 + rper) : total;
+    int hv = 0; // heavy rows << 16 | chunks
+    for (int q = q0; q < q1; ++q) {
+        const int cnt = (int)seg[q + 1] - (int)seg[q];
+        if (cnt > CH)
+            hv += (1 << 16) + (cnt + CH - 1) / CH;
+    }
+    const int hv_before = crec_sort::block_excl_scan<PREP_THREADS>(hv, scan, &hv_total);
+    if (hv) {
+        int hrow = hv_before >> 16, hitem = hv_before & 0xffff;
+        for (int q = q0; q < q1; ++q) {
+            const int k = seg[q], cnt = (int)seg[q + 1] - k;
+            if (cnt > CH) {
+                const int row = (int)rows[k], parts = (cnt + CH - 1) / CH, my_h = hrow++;
+                hrows_out[my_h] = make_int4(row, hitem, (parts << 16) | cnt, q);
                 for (int p = 0; p < parts; ++p) {
                     const int len = (cnt - p * CH) < CH ? (cnt - p * CH) : CH;
-                    hitems_out[hitem] = make_int4((int)row, k + p * CH, len | (my_h << 8), hitem);
+                    hitems_out[hitem] = make_int4(row, k + p * CH, len | (my_h << 8), hitem);
                     ++hitem;
                 }
             }
-            ++rank;
         }
-        const uint32_t payload = (uint32_t)key;
-        const int pos = (int)(payload & 0x7fffffffu);
+    }
+
+    // per-rank outputs and (tf1 mode) every table row's {segment start, length; negative: heavy}, striped over ranks
+    int32_t *rows_out = side ? w.q_rows + (int64_t)batch * 2 * B : w.u_rows + (int64_t)batch * B;
+    int32_t *seg_out = side ? w.q_seg + (int64_t)batch * (2 * B + 1) : w.u_seg + (int64_t)batch * (B + 1);
+    const int64_t n_rows = side ? w.I : w.U;
+    int2 *rs = side ? w.q_rowseg + (int64_t)batch * w.I : w.u_rowseg + (int64_t)batch * w.U;
+    for (int q = tid; q <= total; q += PREP_THREADS) {
+        if (q < total) {
+            const int k = seg[q], cnt = (int)seg[q + 1] - k;
+            rows_out[q] = (int32_t)(rows[k] | (cnt > CH ? 0x80000000u : 0u));
+            seg_out[q] = k;
+        } else {
+            seg_out[q] = n;
+        }
+        if (n_rows > 0)
+            crec_sort::rowseg_fill(rs, n_rows, q, total, n, rows, seg, 0, [CH](int c) { return c > CH ? -c : c; });
+    }
+
+    // occurrence records in sorted order
+    int4 *occ_out = side ? w.q_occ + (int64_t)batch * 2 * B : w.u_occ + (int64_t)batch * B;
+    for (int k = tid; k < n; k += PREP_THREADS) {
+        const int t = tag[k], pos = t < nb ? t : t - nb;
+        const uint32_t payload = (t < nb ? 0u : 0x80000000u) | (uint32_t)pos; // side flag: the row is the triple's j
         occ_out[k] = make_int4(u[t0 + pos], i[t0 + pos], j[t0 + pos], (int)payload);
     }
     if (tid == 0) {
-        seg_out[total] = n;
         (side ? w.n_q : w.n_u)[batch] = total;
         w.hn[batch * 4 + side * 2 + 0] = hv_total >> 16;
         w.hn[batch * 4 + side * 2 + 1] = hv_total & 0xffff;
-    }
-
-    // tf1 mode: every table row's {segment start, length} by two binary searches in the sorted keys
-    const int64_t n_rows = side ? w.I : w.U;
-    if (n_rows > 0) {
-        int2 *rs = side ? w.q_rowseg + (int64_t)batch * w.I : w.u_rowseg + (int64_t)batch * w.U;
-        for (int64_t r = tid; r < n_rows; r += PREP_THREADS) {
-            const int a = lower_bound_key(keys, n, (unsigned long long)r << 32);
-            const int b = lower_bound_key(keys, n, (unsigned long long)(r + 1) << 32);
-            const int cnt = b - a;
-            rs[r] = make_int2(a, cnt > CH ? -cnt : cnt);
-        }
     }
 }
 
@@ -666,6 +622,8 @@ __device__ __forceinline__ void walk_range(const WaveCtx<Geo<LPR, RW>::R> &w, fl
 {
     constexpr int G = Geo<LPR, RW>::G;
     const int lane = threadIdx.x & 63;
+    if ((CREC_ABL & 16) && k_end > k_begin + 16) // ablation (timing only): no wave walks more than 16 records
+        k_end = k_begin + 16;
     for (int c0 = k_begin; c0 < k_end; c0 += 64) {
         const int nc = (k_end - c0) < 64 ? (k_end - c0) : 64;
         const int4 mine = lane < nc ? occ[c0 + lane] : make_int4(0, 0, 0, 0);
@@ -1008,7 +966,7 @@ __global__ __launch_bounds__(256) void bpr_step_fused(Tables src, Tables dst, in
         }
         return;
     }
-    fused_wave<LPR, FULL>(wave_id, src, dst, d, U, I, u_rowseg, u_occ, q_rowseg, q_occ, hv, xb, rowterm, h);
+    fused_wave<LPR, FULL, CREC_FUSED_WT != 0>(wave_id, src, dst, d, U, I, u_rowseg, u_occ, q_rowseg, q_occ, hv, xb, rowterm, h);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1443,11 +1401,9 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
         a.contrib = (float *)ctx->contrib.ptr;
     }
 
-    // dynamic LDS of the index kernel: padded key array + scan scratch
-    int n_pad = 64;
-    while (n_pad < 2 * B)
-        n_pad <<= 1;
-    const size_t lds = sizeof(unsigned long long) * n_pad + sizeof(int) * (PREP_THREADS / 64 + 2);
+    // dynamic LDS of the index kernel
+    const int cap = (2 * B + 63) / 64 * 64;
+    const size_t lds = index_lds_bytes(cap);
     CREC_HIP(ctx, hipFuncSetAttribute((const void *)bpr_index_batches, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds));
 
@@ -1463,7 +1419,7 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
         IndexWs w = layout_index(ctx->idx_ws.ptr, nbc, B, t->U, t->I, dense, CH);
         crec_prof_begin(ctx, CREC_K_INDEX, st);
         CREC_KLAUNCH(ctx, bpr_index_batches, dim3((unsigned)(2 * nbc)), dim3(PREP_THREADS), lds, st, u + t0, i + t0,
-                           j + t0, n_chunk, B, w);
+                           j + t0, n_chunk, B, cap, w);
         crec_prof_end(ctx, st);
         if (persistent) {
             // the chunk's steps in one cooperative launch: per-step lr_t from a table, the buffer sets alternate inside

@@ -15,64 +15,61 @@
 // one-column table, the small dense vector): these steps are bound by launches, not bytes.
 #include "crec_internal.h"
 #include "rows_adam.h"
+#include "block_sort.h"
 
 namespace {
 
 constexpr int IDX_THREADS = 1024;
 
-__device__ inline int lb_key(const unsigned long long *keys, int n, unsigned long long key)
+inline size_t rows_index_lds_bytes(int cap)
 {
-    int lo = 0, hi = n;
-    while (lo < hi) {
-        int mid = (lo + hi) >> 1;
-        if (keys[mid] < key)
-            lo = mid + 1;
-        else
-            hi = mid;
-    }
-    return lo;
+    return sizeof(uint32_t) * cap + sizeof(uint16_t) * (2 * (size_t)cap + 64) +
+           sizeof(int) * (crec_sort::hist_ints<IDX_THREADS>() + crec_sort::scan_ints<IDX_THREADS>());
 }
 
-// one workgroup per (batch, chunk): sort the chunk's (row, slot) keys in LDS; order[k] = slot of the k-th sorted key
-// (slot ids and positions are relative to the batch); rowseg[r] = {first position of row r, number of slots on row r}
-// for every table row
+// one workgroup per (batch, chunk): stable sort of the chunk's (row, slot) pairs in LDS (block_sort.h);
+// order[k] = slot of the k-th sorted pair (slot ids and positions are relative to the batch); rowseg[r] = {first
+// position of row r, number of slots on row r} for every table row
 __global__ __launch_bounds__(IDX_THREADS) void rows_index_batches(const int32_t *__restrict__ idx, int64_t n_total,
-                                                                  int32_t per_batch, int32_t chunks, int64_t rows,
+                                                                  int32_t per_batch, int32_t chunks, int64_t n_rows,
+                                                                  int32_t key_bits, int32_t cap,
                                                                   int32_t *__restrict__ order, int2 *__restrict__ rowseg)
 {
-    extern __shared__ unsigned long long keys[];
+    extern __shared__ uint32_t rows[]; // [cap]
+    uint16_t *tag = (uint16_t *)(rows + cap);
+    uint16_t *seg = tag + cap; // [cap + 64]
+    int *hist = (int *)(seg + cap + 64);
+    int *scan = hist + crec_sort::hist_ints<IDX_THREADS>();
     const int batch = blockIdx.x / chunks, chunk = blockIdx.x % chunks, tid = threadIdx.x;
     const int64_t t0 = (int64_t)batch * per_batch;
     const int nbatch = (int)((n_total - t0) < per_batch ? (n_total - t0) : per_batch);
     const int clen = (per_batch + chunks - 1) / chunks, c0 = chunk * clen < nbatch ? chunk * clen : nbatch;
     const int n = (nbatch - c0) < clen ? (nbatch - c0) : clen;
-    int n_pad = 64;
-    while (n_pad < n)
-        n_pad <<= 1;
-    for (int k = tid; k < n_pad; k += IDX_THREADS)
-        keys[k] = k < n ? (((unsigned long long)(uint32_t)idx[t0 + c0 + k] << 32) | (uint32_t)(c0 + k)) : ~0ull;
-    __syncthreads();
-    for (int k = 2; k <= n_pad; k <<= 1) {
-        for (int jj = k >> 1; jj > 0; jj >>= 1) {
-            for (int t = tid; t < (n_pad >> 1); t += IDX_THREADS) {
-                int lo = ((t & ~(jj - 1)) << 1) | (t & (jj - 1)), hi = lo + jj;
-                unsigned long long a = keys[lo], b = keys[hi];
-                if ((a > b) == ((lo & k) == 0)) {
-                    keys[lo] = b;
-                    keys[hi] = a;
-                }
-            }
-            __syncthreads();
-        }
+    for (int k = tid; k < n; k += IDX_THREADS) {
+        rows[k] = (uint32_t)idx[t0 + c0 + k];
+        tag[k] = (uint16_t)k;
     }
+    crec_sort::block_sort_rows<IDX_THREADS>(rows, tag, n, key_bits, hist, scan);
     for (int k = tid; k < n; k += IDX_THREADS)
-        order[t0 + c0 + k] = (int32_t)(uint32_t)keys[k];
-    int2 *rs = rowseg + ((int64_t)batch * chunks + chunk) * rows;
-    for (int64_t r = tid; r < rows; r += IDX_THREADS) {
-        const int a = lb_key(keys, n, (unsigned long long)r << 32);
-        const int b = lb_key(keys, n, (unsigned long long)(r + 1) << 32);
-        rs[r] = make_int2(c0 + a, b - a);
-    }
+        order[t0 + c0 + k] = c0 + (int32_t)tag[k];
+
+    // run starts by rank (blocked over positions: the scan runs in sorted order), then the table rows' segments
+    const int per = (n + IDX_THREADS - 1) / IDX_THREADS;
+    const int k0 = tid * per, k1 = (k0 + per) < n ? (k0 + per) : n;
+    int heads = 0;
+    for (int k = k0; k < k1; ++k)
+        heads += (k == 0 || rows[k] != rows[k - 1]) ? 1 : 0;
+    int total = 0;
+    int rank = crec_sort::block_excl_scan<IDX_THREADS>(heads, scan, &total);
+    for (int k = k0; k < k1; ++k)
+        if (k == 0 || rows[k] != rows[k - 1])
+            seg[rank++] = (uint16_t)k;
+    if (tid == 0)
+        seg[total] = (uint16_t)n;
+    __syncthreads();
+    int2 *rs = rowseg + ((int64_t)batch * chunks + chunk) * n_rows;
+    for (int q = tid; q <= total; q += IDX_THREADS)
+        crec_sort::rowseg_fill(rs, n_rows, q, total, n, rows, seg, c0, [](int c) { return c; });
 }
 
 __device__ inline float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
@@ -302,14 +299,15 @@ int crec_rows_index(crec_ctx *ctx, const int32_t *idx, int64_t n_total, int32_t 
     out->per_batch = per_batch;
     out->rows = rows;
     out->chunks = chunks;
-    int n_pad = 64;
-    while (n_pad < clen)
-        n_pad <<= 1;
-    const size_t lds = sizeof(unsigned long long) * n_pad;
+    const int cap = (clen + 63) / 64 * 64;
+    const size_t lds = rows_index_lds_bytes(cap);
+    int key_bits = 1;
+    while (key_bits < 32 && ((int64_t)1 << key_bits) < rows)
+        ++key_bits;
     CREC_HIP(ctx, hipFuncSetAttribute((const void *)rows_index_batches, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     crec_prof_begin(ctx, CREC_K_ROWS_INDEX, st);
     CREC_KLAUNCH(ctx, rows_index_batches, dim3((unsigned)(nb * chunks)), dim3(IDX_THREADS), lds, st, idx, n_total, per_batch,
-                       chunks, rows, out->order, out->rowseg);
+                       chunks, rows, key_bits, cap, out->order, out->rowseg);
     crec_prof_end(ctx, st);
     return CREC_OK;
 }
