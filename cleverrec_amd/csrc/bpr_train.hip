@@ -423,15 +423,16 @@ __device__ __forceinline__ void add4(float4 &a, float4 b)
 
 // x_b and s_b of one triple from the group's float4 slices: the ONE place this arithmetic lives,
 // so user-row and item-row waves agree bit for bit.
-template <int LPR> __device__ __forceinline__ float triple_s(float4 p, float4 qi, float4 qj, float *x_out)
+// `part` is the lane's share of p.q_i - p.q_j (its float4 slice of both products, subtracted before the cross-lane
+// sum: one reduction instead of two).  Item-row waves hold the row they own as q_i or as q_j and form the same share
+// from dot4(p, own) and dot4(p, other) with an exact sign flip, so the bits agree with the user-row waves'.
+template <int LPR> __device__ __forceinline__ float triple_s(float part, float *x_out)
 {
     if (CREC_ABL & 2) {
-        *x_out = p.x + qi.x + qj.x;
-        return *x_out;
+        *x_out = part;
+        return part;
     }
-    const float di = group_sum<LPR>(dot4(p, qi));
-    const float dj = group_sum<LPR>(dot4(p, qj));
-    const float x = di - dj; // ui_scores - uj_scores (BPR.py:39-42)
+    const float x = group_sum<LPR>(part); // ui_scores - uj_scores (BPR.py:39-42)
     *x_out = x;
     return sigmoid_neg(x); // sigmoid(-x) = -d softplus(-x)/dx
 }
@@ -578,7 +579,7 @@ __device__ __forceinline__ void trip_consume(const Trip &tr, const WaveCtx<Geo<L
         float4 c;
         if (MODE == 0) {
             float x;
-            const float s = triple_s<LPR>(own, tr.a[t], tr.b[t], &x);
+            const float s = triple_s<LPR>(dot4(own, tr.a[t]) - dot4(own, tr.b[t]), &x);
             const int pos = tr.rec[t].w & 0x7fffffff;
             if (tr.has[t] && w.l == 0)
                 w.xb[pos] = x; // softplus(-x) is taken in bpr_reduce_loss
@@ -591,26 +592,29 @@ __device__ __forceinline__ void trip_consume(const Trip &tr, const WaveCtx<Geo<L
             c.w = ns * (tr.a[t].w - tr.b[t].w) + w.reg * own.w;
         } else {
             const bool is_j = tr.rec[t].w < 0;
-            float4 sp = tr.a[t];
-            if (MODE == 1) {
-                // operands selected, not branched: the cross-lane sums run with every lane active
-                const float4 qi = is_j ? tr.b[t] : own, qj = is_j ? own : tr.b[t];
-                float x;
-                const float s = triple_s<LPR>(tr.a[t], qi, qj, &x);
-                sp = make_float4(s * tr.a[t].x, s * tr.a[t].y, s * tr.a[t].z, s * tr.a[t].w);
-            }
             const float sg = is_j ? 1.0f : -1.0f; // j-slices get +s*p, i-slices -s*p
-            c.x = sg * sp.x + w.reg * own.x;
-            c.y = sg * sp.y + w.reg * own.y;
-            c.z = sg * sp.z + w.reg * own.z;
-            c.w = sg * sp.w + w.reg * own.w;
+            float4 sp;
+            if (MODE == 1) {
+                // p.q_i - p.q_j with the owned row on either side: (p.other - p.own) * sg, the sign flip is exact
+                float x;
+                const float s = triple_s<LPR>((dot4(tr.a[t], tr.b[t]) - dot4(tr.a[t], own)) * sg, &x);
+                const float ss = sg * s;
+                sp = make_float4(ss * tr.a[t].x, ss * tr.a[t].y, ss * tr.a[t].z, ss * tr.a[t].w);
+            } else {
+                sp = make_float4(sg * tr.a[t].x, sg * tr.a[t].y, sg * tr.a[t].z, sg * tr.a[t].w);
+            }
+            c.x = sp.x + w.reg * own.x;
+            c.y = sp.y + w.reg * own.y;
+            c.z = sp.z + w.reg * own.z;
+            c.w = sp.w + w.reg * own.w;
         }
         // branch-free: a contribution that is not taken is added as +0 (exact)
         const bool take = tr.has[t] && w.act;
 #pragma unroll
         for (int s = 0; s < R; ++s) {
-            const float k = (take && tr.slot[t] == s) ? 1.0f : 0.0f;
-            add4(acc[s], make_float4(k * c.x, k * c.y, k * c.z, k * c.w));
+            const float k = (take && tr.slot[t] == s) ? 1.0f : 0.0f; // k * c is exact, so the fused form rounds once, the same
+            acc[s] = make_float4(__builtin_fmaf(k, c.x, acc[s].x), __builtin_fmaf(k, c.y, acc[s].y),
+                                 __builtin_fmaf(k, c.z, acc[s].z), __builtin_fmaf(k, c.w, acc[s].w));
         }
     }
 }
@@ -672,8 +676,8 @@ __device__ __forceinline__ float4 slots_grad(float4 var, const Slot &sl, int n_v
     int st[R], cn[R]; // wave-uniform copies of the slots' segments
 #pragma unroll
     for (int s = 0; s < R; ++s) {
-        st[s] = __shfl(sl.start, s * LPR, 64);
-        cn[s] = s < n_valid ? __shfl(sl.cnt, s * LPR, 64) : 0;
+        st[s] = __builtin_amdgcn_readlane(sl.start, s * LPR); // a fixed lane: a scalar, not a cross-lane permute
+        cn[s] = s < n_valid ? __builtin_amdgcn_readlane(sl.cnt, s * LPR) : 0;
         const int len = cn[s] < 0 ? -cn[s] : cn[s];
         w.e[s] = s < n_valid ? st[s] + len : 0x7fffffff; // INT_MAX for slots beyond the table
     }
@@ -695,8 +699,14 @@ __device__ __forceinline__ float4 slots_grad(float4 var, const Slot &sl, int n_v
         if (last > first)
             walk_range<LPR, RW, MODE, STORE_CONTRIB>(w, var, acc, occ, first, last);
     } else { // a heavy slot sits in the middle: walk the other slots one by one
+#pragma unroll 1
         for (int s = 0; s < n_valid; ++s) {
-            const int b = __shfl(sl.start, s * LPR, 64), c = __shfl(sl.cnt, s * LPR, 64);
+            int b = st[0], c = cn[0];
+#pragma unroll
+            for (int q = 1; q < R; ++q) {
+                b = s == q ? st[q] : b;
+                c = s == q ? cn[q] : c;
+            }
             if (c > 0)
                 walk_range<LPR, RW, MODE, STORE_CONTRIB>(w, var, acc, occ, b, b + c);
         }
@@ -951,7 +961,9 @@ __global__ __launch_bounds__(256) void bpr_step_fused(Tables src, Tables dst, in
 {
     constexpr int R = Geo<LPR, ROWS_PER_WAVE>::R;
     const int lane = threadIdx.x & 63, g = lane / LPR;
-    int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    // the wave index is the same in every lane: say so (readfirstlane), and everything derived from it -- which rows,
+    // how many, which side, loop bounds -- stays in scalar registers and scalar branches
+    int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (CREC_ABL & 4) // ablation: the launch with no work (dispatch + drain floor of this grid)
         return;
     if (CREC_ABL & 8) { // ablation: a pure copy of the six arrays, one wave per R rows (streaming floor of this grid)
@@ -1043,7 +1055,7 @@ template <int LPR, bool FULL> __global__ __launch_bounds__(256) void bpr_steps_p
 {
     constexpr int R = Geo<LPR, ROWS_PER_WAVE>::R;
     const int64_t grid_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
-    const int64_t my_wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t my_wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t WU = (a.U + R - 1) / R, WI = (a.I + R - 1) / R;
     const IndexWs &w = a.w;
     for (int s = 0; s < a.n_steps; ++s) {
@@ -1087,7 +1099,9 @@ __global__ __launch_bounds__(256) void bpr_side_lazy(Tables t, int d, const int3
 {
     constexpr int R = Geo<LPR, ROWS_PER_WAVE>::R;
     const int lane = threadIdx.x & 63, g = lane / LPR;
-    int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    // the wave index is the same in every lane: say so (readfirstlane), and everything derived from it -- which rows,
+    // how many, which side, loop bounds -- stays in scalar registers and scalar branches
+    int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (wave_id < HI) {
         chunk_wave<LPR, MODE, MODE == 0, FULL>(t, d, hitems[wave_id], occ, contrib, xb, partial,
                                                FinishArgs{hrows, tickets, t, rowterm, 0}, h);
