@@ -61,6 +61,33 @@ constexpr bool PIPELINED = CREC_PIPE;   // two trips in flight
 #ifndef CREC_ABL
 #define CREC_ABL 0
 #endif
+#ifdef CREC_STAMPS // debug build: every wave of bpr_step_fused records when it started and ended and when its loads
+                   // arrived (tools/wave_stamps.sh); [wave][8] = {begin, end, shader clocks, xcd, marks 0..3}, 100 MHz clock
+__device__ unsigned long long crec_stamps[8 * 16384];
+extern "C" int crec_debug_stamps(unsigned long long *out, size_t n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(crec_stamps), n * sizeof(unsigned long long));
+}
+__device__ __forceinline__ void crec_mark(int slot, int dep) // the time at which `dep` is available to the wave
+{
+#ifndef CREC_STAMP_MARKS // marks make the wave wait for `dep` where it stands: they perturb what they measure
+    return;
+#endif
+    asm volatile("" ::"v"(dep));
+    const unsigned long long t = wall_clock64();
+    const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if ((threadIdx.x & 63) == 0 && w < 16384)
+        crec_stamps[8 * w + 4 + slot] = t;
+}
+#else
+#define crec_mark(slot, dep)
+#endif
+#ifndef CREC_FUSED_BLOCK
+#define CREC_FUSED_BLOCK 256 // threads per workgroup of bpr_step_fused
+#endif
+#ifndef CREC_ITEMS_FIRST
+#define CREC_ITEMS_FIRST 0 // 1: item-row waves take the low wave ids (they are the longer ones)
+#endif
 #ifndef CREC_FUSED_WT
 #define CREC_FUSED_WT 0 // 1: the launch-per-step tf1 kernel writes its tables with write-through (sc1) stores
 #endif
@@ -81,6 +108,12 @@ struct IndexWs {
     int64_t B, U, I, HRu, HRq, HIu, HIq;
     int32_t CH;                // rows with more than CH occurrences are split into chunks of CH
     int32_t bits_u, bits_q;    // significant bits of a user / item row id (radix passes of the index sort)
+    // tf1 mode, wide groups: the R consecutive table rows of one row wave that hold more than wide_total occurrences
+    // together are handed to a whole workgroup (wide_group): its rows are flagged like heavy rows for the row wave
+    int32_t wide_rows, wide_total; // R (0: off), threshold
+    int32_t *u_wide, *q_wide;  // [nbc][WMu|WMq] group index = first row / R
+    int32_t *nwide;            // [nbc][2] wide groups per batch {user, item}
+    int64_t WMu, WMq;
     size_t bytes;
 };
 
@@ -94,7 +127,8 @@ inline int row_bits(int64_t n_rows)
     return b;
 }
 
-IndexWs layout_index(void *base, int64_t nbc, int64_t B, int64_t U, int64_t I, bool dense, int CH)
+IndexWs layout_index(void *base, int64_t nbc, int64_t B, int64_t U, int64_t I, bool dense, int CH, int wide_rows = 0,
+                     int wide_total = 0)
 {
     IndexWs w{};
     w.B = B;
@@ -128,6 +162,13 @@ IndexWs layout_index(void *base, int64_t nbc, int64_t B, int64_t U, int64_t I, b
     w.q_hrows = (int4 *)take(sizeof(int4) * nbc * w.HRq);
     w.u_hitems = (int4 *)take(sizeof(int4) * nbc * w.HIu);
     w.q_hitems = (int4 *)take(sizeof(int4) * nbc * w.HIq);
+    w.wide_rows = dense && wide_total > 0 ? wide_rows : 0;
+    w.wide_total = wide_total;
+    w.WMu = w.wide_rows ? B / (wide_total + 1) + 1 : 0;
+    w.WMq = w.wide_rows ? 2 * B / (wide_total + 1) + 1 : 0;
+    w.u_wide = (int32_t *)take(sizeof(int32_t) * nbc * w.WMu);
+    w.q_wide = (int32_t *)take(sizeof(int32_t) * nbc * w.WMq);
+    w.nwide = (int32_t *)take(sizeof(int32_t) * nbc * 2);
     w.bytes = off;
     return w;
 }
@@ -210,10 +251,46 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
         }
     }
 
+    // wide groups (tf1 mode): ranks whose rows share one row wave (row / R) and hold more than wide_total occurrences
+    // together, none of them heavy.  The group's first present rank speaks for it.
+    const int64_t n_rows = side ? w.I : w.U;
+    const int WR = n_rows > 0 ? w.wide_rows : 0, WT_ = w.wide_total;
+    const auto group_of = [&](int q) { return rows[seg[q]] / (uint32_t)WR; };
+    const auto group_total = [&](int q) -> int { // q: first rank of its group; -1 if the group holds a heavy row
+        const uint32_t gq = group_of(q);
+        int tot = 0;
+        for (int p = q; p < total && p < q + WR && group_of(p) == gq; ++p) {
+            const int c = (int)seg[p + 1] - (int)seg[p];
+            if (c > CH)
+                return -1;
+            tot += c;
+        }
+        return tot;
+    };
+    const auto in_wide = [&](int q) -> bool { // rank q belongs to a wide group
+        if (WR <= 0)
+            return false;
+        int lead = q;
+        while (lead > 0 && lead > q - WR && group_of(lead - 1) == group_of(q))
+            --lead;
+        return group_total(lead) > WT_;
+    };
+    int wide_total_n = 0;
+    if (WR > 0) {
+        int nw = 0;
+        for (int q = q0; q < q1; ++q)
+            if ((q == 0 || group_of(q - 1) != group_of(q)) && group_total(q) > WT_)
+                ++nw;
+        int at = crec_sort::block_excl_scan<PREP_THREADS>(nw, scan, &wide_total_n);
+        int32_t *wide_out = side ? w.q_wide + (int64_t)batch * w.WMq : w.u_wide + (int64_t)batch * w.WMu;
+        for (int q = q0; q < q1; ++q)
+            if ((q == 0 || group_of(q - 1) != group_of(q)) && group_total(q) > WT_)
+                wide_out[at++] = (int32_t)group_of(q);
+    }
+
     // per-rank outputs and (tf1 mode) every table row's {segment start, length; negative: heavy}, striped over ranks
     int32_t *rows_out = side ? w.q_rows + (int64_t)batch * 2 * B : w.u_rows + (int64_t)batch * B;
     int32_t *seg_out = side ? w.q_seg + (int64_t)batch * (2 * B + 1) : w.u_seg + (int64_t)batch * (B + 1);
-    const int64_t n_rows = side ? w.I : w.U;
     int2 *rs = side ? w.q_rowseg + (int64_t)batch * w.I : w.u_rowseg + (int64_t)batch * w.U;
     for (int q = tid; q <= total; q += PREP_THREADS) {
         if (q < total) {
@@ -224,7 +301,8 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
             seg_out[q] = n;
         }
         if (n_rows > 0)
-            crec_sort::rowseg_fill(rs, n_rows, q, total, n, rows, seg, 0, [CH](int c) { return c > CH ? -c : c; });
+            crec_sort::rowseg_fill(rs, n_rows, q, total, n, rows, seg, 0,
+                                   [&](int c) { return (c > CH || in_wide(q)) ? -c : c; });
     }
 
     // occurrence records in sorted order
@@ -238,6 +316,7 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
         (side ? w.n_q : w.n_u)[batch] = total;
         w.hn[batch * 4 + side * 2 + 0] = hv_total >> 16;
         w.hn[batch * 4 + side * 2 + 1] = hv_total & 0xffff;
+        w.nwide[batch * 2 + side] = wide_total_n;
     }
 }
 
@@ -631,6 +710,10 @@ __device__ __forceinline__ void walk_range(const WaveCtx<Geo<LPR, RW>::R> &w, fl
     for (int c0 = k_begin; c0 < k_end; c0 += 64) {
         const int nc = (k_end - c0) < 64 ? (k_end - c0) : 64;
         const int4 mine = lane < nc ? occ[c0 + lane] : make_int4(0, 0, 0, 0);
+#ifndef CREC_STAMP_VAR
+        if (c0 == k_begin)
+            crec_mark(1, mine.x); // the first chunk of records has arrived
+#endif
         const int n_sub = (nc + G - 1) / G;
         if (PIPELINED) {
             Trip ta, tb;
@@ -658,7 +741,8 @@ __device__ __forceinline__ void walk_range(const WaveCtx<Geo<LPR, RW>::R> &w, fl
 template <int LPR, int RW, int MODE, bool STORE_CONTRIB>
 __device__ __forceinline__ float4 slots_grad(float4 var, const Slot &sl, int n_valid, const float *__restrict__ P,
                                     const float *__restrict__ Q, int d, const int4 *__restrict__ occ,
-                                    float *__restrict__ contrib, float *__restrict__ xb, const Hyper &h)
+                                    float *__restrict__ contrib, float *__restrict__ xb, const Hyper &h, int part = 0,
+                                    int nparts = 1)
 {
     constexpr int R = Geo<LPR, RW>::R;
     const int lane = threadIdx.x & 63;
@@ -695,6 +779,19 @@ __device__ __forceinline__ float4 slots_grad(float4 var, const Slot &sl, int n_v
             last = w.e[s];
         }
     }
+#ifdef CREC_STAMPS
+    {
+        const int wv = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        if (lane == 0 && wv < 16384 && R > 1)
+            crec_stamps[8 * wv + 7] = ((unsigned long long)(unsigned)(last - first) << 32) | (unsigned)(any_heavy ? 1 : 0) | 2u;
+    }
+#endif
+    if (nparts > 1) { // a wide group: this wave walks its share of the range (whole sub-iterations of G records)
+        constexpr int G = Geo<LPR, RW>::G;
+        const int per = ((last - first + nparts - 1) / nparts + G - 1) / G * G;
+        first += part * per;
+        last = (first + per) < last ? (first + per) : last;
+    }
     if (!any_heavy) { // the usual case: the slots' segments are one contiguous range
         if (last > first)
             walk_range<LPR, RW, MODE, STORE_CONTRIB>(w, var, acc, occ, first, last);
@@ -721,6 +818,11 @@ __device__ __forceinline__ float4 slots_grad(float4 var, const Slot &sl, int n_v
 // triple, every owner group stores its row term; bpr_reduce_loss does the softplus and the sums.
 // Per batch the workspace holds xb[B] then rowterm[RT] (RT = U + I in tf1 mode, 3B in lazy mode).
 // ------------------------------------------------------------------------------------
+template <int LPR, int MODE, bool WT>
+__device__ __forceinline__ void row_finish(const Tables &dst, const Slot &sl, int64_t ro, bool owner, float4 var, float4 m,
+                                           float4 v, float4 grad, float *__restrict__ rowterm_slot, bool dense,
+                                           const Hyper &h);
+
 template <int LPR, int MODE, bool STORE_CONTRIB, bool FULL, bool WT = false>
 __device__ __forceinline__ void row_wave(const Tables &src, const Tables &dst, int d, const Slot &sl, int n_valid,
                                 const int4 *__restrict__ occ, float *__restrict__ contrib, float *__restrict__ xb,
@@ -740,7 +842,23 @@ __device__ __forceinline__ void row_wave(const Tables &src, const Tables &dst, i
         m = ld4s((user ? src.mP : src.mQ) + ro);
         v = ld4s((user ? src.vP : src.vQ) + ro);
     }
+    crec_mark(0, sl.cnt); // the row's segment {start, count} has arrived
+#ifdef CREC_STAMP_VAR
+    crec_mark(1, __float_as_int(var.x)); // diagnosis: when the wave's own row arrives (overrides the records mark)
+#endif
     const float4 grad = slots_grad<LPR, RW, MODE, STORE_CONTRIB>(var, sl, n_valid, src.P, src.Q, d, occ, contrib, xb, h);
+    crec_mark(2, __float_as_int(grad.x)); // every record walked, the gradient reduced to its owner
+    row_finish<LPR, MODE, WT>(dst, sl, ro, owner, var, m, v, grad, rowterm_slot, dense, h);
+}
+
+// the owner group's end of a row: row term, Adam (or the gradient row for the data-parallel all-reduce), stores
+template <int LPR, int MODE, bool WT>
+__device__ __forceinline__ void row_finish(const Tables &dst, const Slot &sl, int64_t ro, bool owner, float4 var, float4 m,
+                                           float4 v, float4 grad, float *__restrict__ rowterm_slot, bool dense,
+                                           const Hyper &h)
+{
+    constexpr bool user = MODE == 0;
+    const int l = (threadIdx.x & 63) % LPR;
     const float nr = group_sum<LPR>(dot4(var, var));
     if (owner) {
         if (l == 0 && (dense || sl.cnt > 0))
@@ -760,6 +878,50 @@ __device__ __forceinline__ void row_wave(const Tables &src, const Tables &dst, i
             }
         }
     }
+}
+
+// A wide group (tf1 mode): the R rows of one row wave hold more occurrences than a single wave should walk (a launch
+// lasts as long as its longest wave: 50 records take a row wave twice as long as the median one).  A whole workgroup
+// takes the group: its NW waves walk equal shares of the group's record range with the usual slot bookkeeping, the
+// per-slot partial gradients meet in LDS, and wave 0 adds them in wave order and finishes the rows.  A barrier and
+// 4 KB of LDS instead of the chunk waves' partials in memory + ticket, which cost as much as the walk they save.
+template <int LPR, int MODE, bool FULL, bool WT>
+__device__ __forceinline__ void wide_group(const Tables &src, const Tables &dst, int d, int64_t n_rows, int64_t group,
+                                           const int2 *__restrict__ rowseg, const int4 *__restrict__ occ,
+                                           float *__restrict__ xb, float *__restrict__ rowterm, const Hyper &h,
+                                           float4 *__restrict__ lds /* [NW][64] */)
+{
+    constexpr int RW = ROWS_PER_WAVE | (FULL ? 0x100 : 0), R = Geo<LPR, RW>::R;
+    constexpr bool user = MODE == 0;
+    const int lane = threadIdx.x & 63, g = lane / LPR, l = lane % LPR;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = (int)(blockDim.x >> 6);
+    const int64_t base = group * R;
+    const int n_valid = (int)((n_rows - base) < R ? (n_rows - base) : R);
+    Slot sl;
+    sl.row = base + (g < n_valid ? g : 0);
+    const int2 rs = rowseg[sl.row];
+    sl.start = rs.x;
+    sl.cnt = g < n_valid ? (rs.y < 0 ? -rs.y : rs.y) : 0; // the index flags the group's rows like heavy rows: undo
+    const bool owner = g < R && g < n_valid && (FULL || 4 * l < d);
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t ro = sl.row * d + 4 * l;
+    float4 var = zero, m = zero, v = zero;
+    if (owner) {
+        var = ld4((user ? src.P : src.Q) + ro); // every wave: the records' arithmetic needs the rows
+        if (wv == 0) {
+            m = ld4s((user ? src.mP : src.mQ) + ro);
+            v = ld4s((user ? src.vP : src.vQ) + ro);
+        }
+    }
+    float4 grad = slots_grad<LPR, RW, MODE, false>(var, sl, n_valid, src.P, src.Q, d, occ, nullptr, xb, h, wv, nw);
+    lds[wv * 64 + lane] = grad;
+    __syncthreads();
+    if (wv != 0)
+        return;
+    grad = lds[lane];
+    for (int k = 1; k < nw; ++k) // wave order: the sum does not depend on timing
+        add4(grad, lds[k * 64 + lane]);
+    row_finish<LPR, MODE, WT>(dst, sl, ro, owner, var, m, v, grad, rowterm + sl.row, true, h);
 }
 
 // what the wave that finishes a heavy row needs beyond its own chunk
@@ -907,6 +1069,8 @@ struct HeavyArgs {
     int32_t *tickets;                // [HRu max + HRq max], zero between launches
     int HIu, HIq, HRu, HRq;
     int HRu_max;                     // item tickets start here
+    const int32_t *u_wide, *q_wide;  // wide groups of this batch (tf1 mode)
+    int NWu, NWq, NWpad;
 };
 
 // the work of one wave id of a tf1 step: [0, HIu) user chunk waves, [HIu, HIu+HIq) item chunk waves, then WU waves
@@ -935,9 +1099,9 @@ __device__ __forceinline__ void fused_wave(int64_t wave_id, const Tables &src, c
     const int64_t WU = (U + R - 1) / R, WI = (I + R - 1) / R;
     if (wave_id >= WU + WI)
         return;
-    const bool is_user = wave_id < WU;
+    const bool is_user = CREC_ITEMS_FIRST ? wave_id >= WI : wave_id < WU;
     const int64_t n_rows = is_user ? U : I;
-    const int64_t base = (is_user ? wave_id : wave_id - WU) * R;
+    const int64_t base = (CREC_ITEMS_FIRST ? (is_user ? wave_id - WI : wave_id) : (is_user ? wave_id : wave_id - WU)) * R;
     const int n_valid = (int)((n_rows - base) < R ? (n_rows - base) : R);
     Slot sl;
     sl.row = base + (g < n_valid ? g : 0);
@@ -952,7 +1116,7 @@ __device__ __forceinline__ void fused_wave(int64_t wave_id, const Tables &src, c
 }
 
 template <int LPR, bool FULL>
-__global__ __launch_bounds__(256) void bpr_step_fused(Tables src, Tables dst, int d, int64_t U, int64_t I,
+__global__ __launch_bounds__(CREC_FUSED_BLOCK) void bpr_step_fused(Tables src, Tables dst, int d, int64_t U, int64_t I,
                                                       const int2 *__restrict__ u_rowseg,
                                                       const int4 *__restrict__ u_occ,
                                                       const int2 *__restrict__ q_rowseg,
@@ -963,9 +1127,40 @@ __global__ __launch_bounds__(256) void bpr_step_fused(Tables src, Tables dst, in
     const int lane = threadIdx.x & 63, g = lane / LPR;
     // the wave index is the same in every lane: say so (readfirstlane), and everything derived from it -- which rows,
     // how many, which side, loop bounds -- stays in scalar registers and scalar branches
-    int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (CREC_ABL & 4) // ablation: the launch with no work (dispatch + drain floor of this grid)
         return;
+    // the first workgroups are the wide groups' (users, then items); the wave ids of the rest start after them
+    __shared__ float4 wide_lds[(CREC_FUSED_BLOCK / 64) * 64];
+    const int n_wide = hv.NWpad; // the wide groups' workgroups, padded by the host so that the grid size changes rarely
+#ifdef CREC_STAMPS
+    const unsigned long long t_begin = wall_clock64(), c_begin = clock64();
+    const int raw_wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const auto stamp_end = [&](unsigned flag) {
+        if (lane == 0 && raw_wave < 16384) {
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            crec_stamps[8 * raw_wave + 0] = t_begin;
+            crec_stamps[8 * raw_wave + 1] = wall_clock64();
+            crec_stamps[8 * raw_wave + 2] = clock64() - c_begin;
+            crec_stamps[8 * raw_wave + 3] = xcc & 15;
+            crec_stamps[8 * raw_wave + 7] |= flag;
+        }
+    };
+#endif
+    if ((int)blockIdx.x < n_wide) {
+        if ((int)blockIdx.x < hv.NWu)
+            wide_group<LPR, 0, FULL, CREC_FUSED_WT != 0>(src, dst, d, U, hv.u_wide[blockIdx.x], u_rowseg, u_occ, xb, rowterm, h,
+                                                         wide_lds);
+        else if ((int)blockIdx.x < hv.NWu + hv.NWq)
+            wide_group<LPR, 1, FULL, CREC_FUSED_WT != 0>(src, dst, d, I, hv.q_wide[blockIdx.x - hv.NWu], q_rowseg, q_occ, xb,
+                                                         rowterm + U, h, wide_lds);
+#ifdef CREC_STAMPS
+        stamp_end(4);
+#endif
+        return;
+    }
+    int64_t wave_id = (int64_t)(blockIdx.x - n_wide) * (blockDim.x >> 6) +
+                      __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (CREC_ABL & 8) { // ablation: a pure copy of the six arrays, one wave per R rows (streaming floor of this grid)
         const int64_t WUc = (U + R - 1) / R, w2 = wave_id - hv.HIu - hv.HIq;
         const bool usr = w2 < WUc;
@@ -976,9 +1171,12 @@ __global__ __launch_bounds__(256) void bpr_step_fused(Tables src, Tables dst, in
             st4((usr ? dst.mP : dst.mQ) + ro, ld4((usr ? src.mP : src.mQ) + ro));
             st4((usr ? dst.vP : dst.vQ) + ro, ld4((usr ? src.vP : src.vQ) + ro));
         }
-        return;
+    } else {
+        fused_wave<LPR, FULL, CREC_FUSED_WT != 0>(wave_id, src, dst, d, U, I, u_rowseg, u_occ, q_rowseg, q_occ, hv, xb, rowterm, h);
     }
-    fused_wave<LPR, FULL, CREC_FUSED_WT != 0>(wave_id, src, dst, d, U, I, u_rowseg, u_occ, q_rowseg, q_occ, hv, xb, rowterm, h);
+#ifdef CREC_STAMPS
+    stamp_end(0);
+#endif
 }
 
 // ------------------------------------------------------------------------------------
@@ -1190,6 +1388,11 @@ struct StepArgs {
     int32_t *tickets;
     Hyper h;
     hipStream_t st;
+    const int32_t *nwide; // host copy of the chunk's wide-group counts [nbc][2] (tf1 mode)
+    // A launch whose grid differs from the previous launch's costs ~2.4 us more than one that repeats it (measured:
+    // the same kernel, 9.8 us with the wide groups' workgroup count changing per step, 7.2 us with it padded to a
+    // constant).  So every step of a chunk is launched with the chunk's largest counts; surplus waves exit at once.
+    int pad_wide, pad_chunks_u, pad_chunks_q; // max over the chunk of NWu+NWq, HIu, HIq
 };
 
 // hn: this batch's {user heavy rows, user chunks, item heavy rows, item chunks}, read back by the host
@@ -1206,6 +1409,9 @@ HeavyArgs heavy_args(const StepArgs &a, const IndexWs &w, int64_t b, const int32
     hv.partial = a.partial;
     hv.tickets = a.tickets;
     hv.HRu_max = (int)w.HRu;
+    hv.u_wide = w.u_wide + b * w.WMu;
+    hv.q_wide = w.q_wide + b * w.WMq;
+    hv.NWu = hv.NWq = hv.NWpad = 0; // launch_fused fills them in
     hv.HRu = hn[0];
     hv.HIu = hn[1];
     hv.HRq = hn[2];
@@ -1216,10 +1422,16 @@ HeavyArgs heavy_args(const StepArgs &a, const IndexWs &w, int64_t b, const int32
 template <int LPR, bool FULL> void launch_fused(const StepArgs &a, const IndexWs &w, int64_t b, const int32_t *hn)
 {
     constexpr int R = Geo<LPR, ROWS_PER_WAVE>::R;
-    const HeavyArgs hv = heavy_args(a, w, b, hn);
-    const int64_t waves = hv.HIu + hv.HIq + crec_ceil_div(a.U, R) + crec_ceil_div(a.I, R);
+    HeavyArgs hv = heavy_args(a, w, b, hn);
+    if (w.wide_rows && a.nwide) {
+        hv.NWu = a.nwide[b * 2 + 0];
+        hv.NWq = a.nwide[b * 2 + 1];
+        hv.NWpad = a.pad_wide;
+    }
+    const int64_t waves = a.pad_chunks_u + a.pad_chunks_q + crec_ceil_div(a.U, R) + crec_ceil_div(a.I, R);
     crec_prof_begin(a.ctx, CREC_K_STEP_FUSED, a.st);
-    CREC_KLAUNCH(a.ctx, (bpr_step_fused<LPR, FULL>), dim3((unsigned)crec_ceil_div(waves, 4)), dim3(256), 0, a.st, a.cur, a.other,
+    CREC_KLAUNCH(a.ctx, (bpr_step_fused<LPR, FULL>), dim3((unsigned)(hv.NWpad + crec_ceil_div(waves, CREC_FUSED_BLOCK / 64))),
+                 dim3(CREC_FUSED_BLOCK), 0, a.st, a.cur, a.other,
                        a.d, a.U, a.I, w.u_rowseg + b * w.U, w.u_occ + b * w.B, w.q_rowseg + b * w.I,
                        w.q_occ + b * 2 * w.B, hv, a.xb, a.rowterm, a.h);
     crec_prof_end(a.ctx, a.st);
@@ -1229,8 +1441,8 @@ template <int LPR, bool FULL> void launch_lazy(const StepArgs &a, const IndexWs 
 {
     constexpr int R = Geo<LPR, ROWS_PER_WAVE>::R;
     const HeavyArgs hv = heavy_args(a, w, b, hn);
-    const int64_t u_waves = hv.HIu + crec_ceil_div(a.U < a.B ? a.U : a.B, R);
-    const int64_t q_waves = hv.HIq + crec_ceil_div(a.I < 2 * (int64_t)a.B ? a.I : 2 * (int64_t)a.B, R);
+    const int64_t u_waves = a.pad_chunks_u + crec_ceil_div(a.U < a.B ? a.U : a.B, R);
+    const int64_t q_waves = a.pad_chunks_q + crec_ceil_div(a.I < 2 * (int64_t)a.B ? a.I : 2 * (int64_t)a.B, R);
     crec_prof_begin(a.ctx, CREC_K_USER_SIDE, a.st);
     CREC_KLAUNCH(a.ctx, (bpr_side_lazy<LPR, 0, FULL>), dim3((unsigned)crec_ceil_div(u_waves, 4)), dim3(256), 0, a.st, a.cur, a.d,
                        w.n_u + b, w.u_rows + b * w.B, w.u_seg + b * (w.B + 1), w.u_occ + b * w.B, hv.hn + 1, hv.u_hitems,
@@ -1366,17 +1578,31 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
     const int CH = ch_env > 0 ? ch_env : (dense ? 64 : 16);
     CREC_REQUIRE(ctx, CH >= 1 && CH <= 255, "CREC_CH: 1..255");
 
+    // wide groups (tf1 mode, launch per step): the rows of a row wave that hold more than `wide_total` occurrences
+    // together go to a whole workgroup.  CREC_WIDE=0 turns it off, any other value is the threshold.
+    const char *persist_env = getenv("CREC_PERSISTENT");
+    const bool persistent = dense && !dp && persist_env && atoi(persist_env) != 0;
+    const int wide_env = getenv("CREC_WIDE") ? atoi(getenv("CREC_WIDE")) : -1; // read per call: tests switch it
+    int wide_rows = 1;
+    {
+        int lpr = 1;
+        while (lpr * 4 < t->d)
+            lpr <<= 1;
+        wide_rows = 64 / lpr < ROWS_PER_WAVE ? 64 / lpr : ROWS_PER_WAVE;
+    }
+    const int wide_total = (!dense || persistent || wide_rows < 2) ? 0 : (wide_env >= 0 ? wide_env : 16);
+
     // chunk the epoch so the inverted indices of a chunk stay under ~1 GiB
-    const size_t per_batch = layout_index(nullptr, 1, B, t->U, t->I, dense, CH).bytes;
+    const size_t per_batch = layout_index(nullptr, 1, B, t->U, t->I, dense, CH, wide_rows, wide_total).bytes;
     int64_t chunk = (int64_t)((size_t)1 << 30) / (int64_t)per_batch;
     chunk = chunk < 1 ? 1 : (chunk > nb ? nb : chunk);
-    if (int rc = crec_reserve(ctx, &ctx->idx_ws, layout_index(nullptr, chunk, B, t->U, t->I, dense, CH).bytes))
+    if (int rc = crec_reserve(ctx, &ctx->idx_ws, layout_index(nullptr, chunk, B, t->U, t->I, dense, CH, wide_rows, wide_total).bytes))
         return rc;
     // per batch: x_b of every triple, then one l2 term per row wave
     const int64_t loss_stride = B + (dense ? t->U + t->I : 3 * (int64_t)B);
     if (int rc = crec_reserve(ctx, &ctx->loss_ws, sizeof(float) * (size_t)chunk * loss_stride))
         return rc;
-    const IndexWs w0 = layout_index(nullptr, 1, B, t->U, t->I, dense, CH);
+    const IndexWs w0 = layout_index(nullptr, 1, B, t->U, t->I, dense, CH, wide_rows, wide_total);
     // heavy rows: chunk partials, then one ticket counter per heavy row (zeroed here, re-zeroed by the finishing wave)
     const size_t part_bytes = align_up(sizeof(float) * (size_t)(w0.HIu + w0.HIq) * t->d, 256);
     const size_t ticket_bytes = sizeof(int32_t) * (size_t)(w0.HRu + w0.HRq);
@@ -1423,14 +1649,12 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
 
     // tf1 single-GPU, opt-in (CREC_PERSISTENT=1): a chunk's steps inside one cooperative launch.  Measured no faster
     // than a launch per step on MI355X (19-20 vs 13 us per step): see the note at bpr_steps_persistent.
-    const char *persist_env = getenv("CREC_PERSISTENT");
-    const bool persistent = dense && !dp && persist_env && atoi(persist_env) != 0;
     const PersistFn persist = pick_persistent(t->d);
     bool in_shadow = false; // tf1: which buffer set holds the current tables
     for (int64_t b0 = 0; b0 < nb; b0 += chunk) {
         const int64_t nbc = (nb - b0) < chunk ? (nb - b0) : chunk;
         const int64_t t0 = b0 * B, n_chunk = (N - t0) < nbc * B ? (N - t0) : nbc * B;
-        IndexWs w = layout_index(ctx->idx_ws.ptr, nbc, B, t->U, t->I, dense, CH);
+        IndexWs w = layout_index(ctx->idx_ws.ptr, nbc, B, t->U, t->I, dense, CH, wide_rows, wide_total);
         crec_prof_begin(ctx, CREC_K_INDEX, st);
         CREC_KLAUNCH(ctx, bpr_index_batches, dim3((unsigned)(2 * nbc)), dim3(PREP_THREADS), lds, st, u + t0, i + t0,
                            j + t0, n_chunk, B, cap, w);
@@ -1484,10 +1708,19 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
             CREC_HIP(ctx, hipStreamSynchronize(st));
             CREC_REQUIRE(ctx, flags[1] == 0, "bpr_steps_persistent: a grid barrier timed out (the tables are unusable)");
         }
-        std::vector<int32_t> hn((size_t)(persistent ? 0 : nbc) * 4);
+        std::vector<int32_t> hn((size_t)(persistent ? 0 : nbc) * 4), nwide((size_t)(persistent ? 0 : nbc) * 2);
+        a.nwide = nwide.data();
         if (!persistent) {
             CREC_HIP(ctx, hipMemcpyAsync(hn.data(), w.hn, sizeof(int32_t) * hn.size(), hipMemcpyDeviceToHost, st));
+            CREC_HIP(ctx, hipMemcpyAsync(nwide.data(), w.nwide, sizeof(int32_t) * nwide.size(), hipMemcpyDeviceToHost, st));
             CREC_HIP(ctx, hipStreamSynchronize(st));
+        }
+        a.pad_wide = a.pad_chunks_u = a.pad_chunks_q = 0;
+        for (int64_t b = 0; b < (persistent ? 0 : nbc); ++b) {
+            const int nw = nwide[(size_t)b * 2] + nwide[(size_t)b * 2 + 1];
+            a.pad_wide = nw > a.pad_wide ? nw : a.pad_wide;
+            a.pad_chunks_u = hn[(size_t)b * 4 + 1] > a.pad_chunks_u ? hn[(size_t)b * 4 + 1] : a.pad_chunks_u;
+            a.pad_chunks_q = hn[(size_t)b * 4 + 3] > a.pad_chunks_q ? hn[(size_t)b * 4 + 3] : a.pad_chunks_q;
         }
         for (int64_t b = 0; b < (persistent ? 0 : nbc); ++b) {
             // lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t) with fp32 running powers (TF1 _prepare/_finish)

@@ -88,13 +88,16 @@ def test_bpr_heavy_duplicates_and_large_scores(sess):
 
 def test_bpr_persistent_launch_matches_per_step_launches(sess, monkeypatch):
     """CREC_PERSISTENT=1 (all steps of a chunk in one cooperative launch, device-wide barriers between steps): the
-    same tables bit for bit as a launch per step, heavy rows and a ragged last batch included."""
+    same tables bit for bit as a launch per step, heavy rows and a ragged last batch included.  Wide groups (a
+    workgroup per overloaded row wave, CREC_WIDE) exist only in the launch-per-step form and add their partial sums in
+    another order, so the comparison runs with them off; the next test pins them against the plain form."""
     data = synthetic("S-ml100k")
     P0, Q0 = _tables(5, data.user_nums, data.item_nums, 32)
     sess.ctx.seed(2)
     u, i, j = (sess.to_dev(a) for a in sess.ctx.sample_pairwise(data.train_csr, data.item_nums, 4))
     n = 9 * 6144 + 1000
     out = []
+    monkeypatch.setenv("CREC_WIDE", "0")
     for flag in ("0", "1"):
         monkeypatch.setenv("CREC_PERSISTENT", flag)
         st = runtime.BprState(sess, P0, Q0, lr=1e-3, reg=0.01, adam_mode="tf1")
@@ -102,6 +105,31 @@ def test_bpr_persistent_launch_matches_per_step_launches(sess, monkeypatch):
         out.append([t.cpu().numpy() for t in (loss, st.P, st.Q, st.mP, st.vQ)])
     for a, b in zip(*out):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("threshold", ["1", "8", "24"])
+def test_bpr_wide_groups_match_plain_row_waves(sess, monkeypatch, threshold):
+    """tf1 step with overloaded row waves handed to whole workgroups (CREC_WIDE = occurrences per row wave above which
+    that happens; 1: nearly every group that has records) against the same epoch with the mechanism off: same tables up
+    to the order of the fp32 partial sums, every row written exactly once (slots of untouched rows decay identically)."""
+    data = synthetic("S-ml100k")
+    P0, Q0 = _tables(6, data.user_nums, data.item_nums, 64)
+    sess.ctx.seed(3)
+    u, i, j = (sess.to_dev(a) for a in sess.ctx.sample_pairwise(data.train_csr, data.item_nums, 4))
+    n = 5 * 6144 + 777
+    out = []
+    for wide in ("0", threshold):
+        monkeypatch.setenv("CREC_WIDE", wide)
+        st = runtime.BprState(sess, P0, Q0, lr=1e-3, reg=0.01, adam_mode="tf1")
+        loss = st.train_epoch(u[:n], i[:n], j[:n], 6144)
+        out.append([t.cpu().numpy() for t in (loss, st.P, st.Q, st.mP, st.vP, st.mQ, st.vQ)])
+    np.testing.assert_allclose(out[1][0], out[0][0], rtol=1e-6)
+    for a, b in zip(out[0][1:], out[1][1:]):
+        np.testing.assert_allclose(b, a, rtol=0, atol=2e-6)
+    # a second run with the mechanism on is bitwise the first: the partial sums have a fixed order
+    st = runtime.BprState(sess, P0, Q0, lr=1e-3, reg=0.01, adam_mode="tf1")
+    st.train_epoch(u[:n], i[:n], j[:n], 6144)
+    assert np.array_equal(st.Q.cpu().numpy(), out[1][2]) and np.array_equal(st.vP.cpu().numpy(), out[1][4])
 
 
 def test_bpr_ml100k_shape_full_epoch(sess):
