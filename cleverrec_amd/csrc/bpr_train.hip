@@ -830,18 +830,21 @@ __device__ __forceinline__ void row_wave(const Tables &src, const Tables &dst, i
 {
     constexpr int RW = ROWS_PER_WAVE | (FULL ? 0x100 : 0), R = Geo<LPR, RW>::R;
     const int lane = threadIdx.x & 63, g = lane / LPR, l = lane % LPR;
-    const bool heavy = sl.cnt < 0;
     const bool in_slot = g < R && g < n_valid && (FULL || 4 * l < d);
-    const bool owner = in_slot && !heavy; // heavy rows are finished by their last chunk wave
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool user = MODE == 0;
     const int64_t ro = sl.row * d + 4 * l;
+    // the rows are fetched without waiting for their segment {start, count} (sl, still in flight when this is called
+    // with a dense table: the row ids follow from the wave id): one round trip less on every wave's critical path.
+    // The few rows that turn out to be heavy or in a wide group are fetched for nothing.
     float4 var = zero, m = zero, v = zero;
-    if (owner) {
+    if (in_slot) {
         var = ld4((user ? src.P : src.Q) + ro);
         m = ld4s((user ? src.mP : src.mQ) + ro);
         v = ld4s((user ? src.vP : src.vQ) + ro);
     }
+    const bool heavy = sl.cnt < 0;
+    const bool owner = in_slot && !heavy; // heavy rows are finished by their last chunk wave
     crec_mark(0, sl.cnt); // the row's segment {start, count} has arrived
 #ifdef CREC_STAMP_VAR
     crec_mark(1, __float_as_int(var.x)); // diagnosis: when the wave's own row arrives (overrides the records mark)
