@@ -154,9 +154,13 @@ def main():
                            "avg_launch_us": avg_s * 1e6,
                            "note": "avg_launch_us = mean over the timed launches of the elapsed time between the two HIP events "
                                    "attached to each dispatch (hipExtLaunchKernelGGL start/stop events on the launch stream), i.e. "
-                                   "the dispatch's own begin/end timestamps, the quantity rocprofv3 --kernel-trace reports "
-                                   "(profiles/round1_bench_kernel_stats.txt).  Tables+slots are 7.5 MB (Infinity-Cache resident): "
-                                   "the HBM fraction is nominal; S-big (synthetic_big) is the HBM-resident form"}
+                                   "the dispatch's own begin/end timestamps.  rocprofv3 --kernel-trace of the same workload "
+                                   "(profiles/round1_bench_kernel_stats.txt) reads 7.84 us median / 7.99 us mean: under tracing "
+                                   "consecutive dependent dispatches tile the timeline, so its figure is the launch-to-launch "
+                                   "period (launch_period_us here, untraced).  Tables+slots are 7.5 MB (Infinity-Cache resident): "
+                                   "the HBM fraction is nominal; S-big (synthetic_big) is the HBM-resident form",
+                           "launch_period_us": dt / a.steps * 1e6 - sum(v["avg_us"] * v["launches"] for k, v in kern.items()
+                                                                          if k != dom) / max(kern[dom]["launches"], 1)}
         step_bytes = alg[dom]
         out["kernels"] = kern
         out["step_algorithmic_GBs"] = step_bytes / (dt / a.steps) / 1e9

@@ -7,19 +7,20 @@ OUT=$ROOT/gpurun_out/profiles
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--steps 456 --warmup 50 --no-extras"
+ARGS="--steps 1824 --warmup 456 --no-extras"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $ROOT/bench.py $ARGS > $OUT/bench_under_trace.json 2>/dev/null
 f=$(find $OUT/trace -name "*kernel_stats.csv" | head -1)
 python - "$f" > $OUT/kernel_stats.txt <<'PY'
 import csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-print("rocprofv3 --kernel-trace --stats -- python bench.py --steps 456 --warmup 50 --no-extras")
+print("rocprofv3 --kernel-trace --stats -- python bench.py --steps 1824 --warmup 456 --no-extras")
 print("%-60s %8s %14s %12s %8s" % ("kernel", "calls", "total_ns", "avg_ns", "pct"))
 for r in rows:
     m = re.search(r"(bpr_\w+|eval_\w+|rank_metrics\w*)(<[^>]*>)?", r["Name"])
     name = (m.group(0) if m else r["Name"].split("(")[0])[:60]
     print("%-60s %8s %14s %12.1f %8s" % (name, r["Calls"], r["TotalDurationNs"], float(r["AverageNs"]), r["Percentage"]))
 PY
+python $ROOT/tools/trace_steady.py $OUT/trace bpr_step_fused 456 >> $OUT/kernel_stats.txt
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_SALU"; do
   n=$(echo $c | cut -d" " -f1)
   rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$n -- python $ROOT/bench.py --steps 100 --warmup 10 --no-extras > /dev/null 2>&1 || echo "pmc $n failed"
