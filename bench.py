@@ -33,6 +33,10 @@ D, B, NEG, LR, REG = 64, 6144, 4, 1e-3, 0.01
 
 
 def main():
+    # stdout carries exactly one line, the JSON: everything else that lands on fd 1 (RCCL prints a version banner
+    # there when it initialises) is sent to stderr
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=9120)
@@ -232,7 +236,7 @@ def main():
                                              "times), oracle/crec_oracle.c orc_bpr_step (scalar C, tf1 Adam), %.1f s; host has "
                                              "%d cores" % (k, nbe, k / nbe, tc, os.cpu_count())}
     if rank == 0:
-        print(json.dumps(out))
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dp:
         dist.destroy_process_group()
 

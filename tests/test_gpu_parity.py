@@ -77,6 +77,21 @@ def test_bpr_batch_sizes_and_ragged_tail(sess, B):
     _assert_state_close(st, om, atol=2e-6)
 
 
+@pytest.mark.parametrize("mode,U,I", [("lazy", 300_001, 70_003), ("tf1", 65_537, 66_000), ("lazy", 17_000_000, 257)])
+def test_bpr_sparse_ids_in_large_tables(sess, mode, U, I):
+    """Row ids that need three or four 8-bit passes of the index kernel's radix sort (17 to 25 significant bits, with a
+    one-bit last pass at 65 537 rows), active rows scattered over the whole id range, against the oracle.  The tables
+    are as tall as the ids but narrow (d = 4), so the CPU side stays small."""
+    g = np.random.Generator(np.random.PCG64(33))
+    users = np.unique(np.concatenate([g.integers(0, U, 600), [0, U - 1, U // 2, 65_535 % U, 65_536 % U]]))
+    items = np.unique(np.concatenate([g.integers(0, I, 200), [0, I - 1]]))
+    ui_train = {int(u): [int(x) for x in g.choice(items, size=int(g.integers(1, 12)), replace=False)] for u in users}
+    data = RankingData(U, I, ui_train, {int(users[0]): [int(items[0])]})
+    st, om, loss, oloss = _run_both(sess, data, 4, B=512, epochs=2, mode=mode)
+    np.testing.assert_allclose(loss, oloss, rtol=1e-5)
+    _assert_state_close(st, om, atol=2e-6)
+
+
 def test_bpr_heavy_duplicates_and_large_scores(sess):
     # 3 users x 6 items: every row is hit hundreds of times per batch; scale 1.0 drives x far from 0
     # (softplus branches, saturated sigmoid)
