@@ -88,6 +88,12 @@ __device__ __forceinline__ void crec_mark(int slot, int dep) // the time at whic
 #ifndef CREC_ITEMS_FIRST
 #define CREC_ITEMS_FIRST 0 // 1: item-row waves take the low wave ids (they are the longer ones)
 #endif
+// waves per SIMD the lazy launches are compiled for.  The item side of S-big is ~4 960 waves (two ranks per wave at
+// d = 128): at four waves per SIMD (4 096 slots) the last fifth starts when the first waves retire, a second round.
+#ifndef CREC_LAZY_ITEM_WAVES
+#define CREC_LAZY_ITEM_WAVES 4 // 5 (96 VGPRs, 12 bytes of scratch) measured the same: 10.8 us
+#endif
+#define CREC_LAZY_WAVES(MODE) ((MODE) == 2 ? CREC_LAZY_ITEM_WAVES : 4)
 #ifndef CREC_FUSED_WT
 #define CREC_FUSED_WT 0 // 1: the launch-per-step tf1 kernel writes its tables with write-through (sc1) stores
 #endif
@@ -1290,7 +1296,7 @@ template <int LPR, bool FULL> __global__ __launch_bounds__(256) void bpr_steps_p
 // lazy mode: touched rows only, in place, two launches (MODE 0 users, MODE 2 items)
 // ------------------------------------------------------------------------------------
 template <int LPR, int MODE, bool FULL>
-__global__ __launch_bounds__(256) void bpr_side_lazy(Tables t, int d, const int32_t *__restrict__ n_rows_p,
+__global__ __launch_bounds__(256, CREC_LAZY_WAVES(MODE)) void bpr_side_lazy(Tables t, int d, const int32_t *__restrict__ n_rows_p,
                                                      const int32_t *__restrict__ rows, const int32_t *__restrict__ seg,
                                                      const int4 *__restrict__ occ, const int32_t *__restrict__ n_chunks_p,
                                                      const int4 *__restrict__ hitems, int HI,
@@ -1303,9 +1309,23 @@ __global__ __launch_bounds__(256) void bpr_side_lazy(Tables t, int d, const int3
     // the wave index is the same in every lane: say so (readfirstlane), and everything derived from it -- which rows,
     // how many, which side, loop bounds -- stays in scalar registers and scalar branches
     int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#ifdef CREC_STAMPS // user side: stamps [0, 8192), item side: [8192, 16384); [6] = 1 chunk wave, 2 row wave
+    const unsigned long long t_begin = wall_clock64();
+    const int raw_wave = (int)wave_id + (MODE == 0 ? 0 : 8192);
+    const auto stamp_end = [&](unsigned flag) {
+        if (lane == 0 && wave_id < 8192) {
+            crec_stamps[8 * raw_wave + 0] = t_begin;
+            crec_stamps[8 * raw_wave + 1] = wall_clock64();
+            crec_stamps[8 * raw_wave + 6] = flag; // [7] belongs to slots_grad's record count
+        }
+    };
+#endif
     if (wave_id < HI) {
         chunk_wave<LPR, MODE, MODE == 0, FULL>(t, d, hitems[wave_id], occ, contrib, xb, partial,
                                                FinishArgs{hrows, tickets, t, rowterm, 0}, h);
+#ifdef CREC_STAMPS
+        stamp_end(1);
+#endif
         return;
     }
     wave_id -= HI;
@@ -1322,6 +1342,9 @@ __global__ __launch_bounds__(256) void bpr_side_lazy(Tables t, int d, const int3
     const int cnt = seg[idx + 1] - sl.start;
     sl.cnt = g < n_valid ? (rw < 0 ? -cnt : cnt) : 0;
     row_wave<LPR, MODE, MODE == 0, FULL>(t, t, d, sl, n_valid, occ, contrib, xb, rowterm + idx, false, h);
+#ifdef CREC_STAMPS
+    stamp_end(2);
+#endif
 }
 
 // ------------------------------------------------------------------------------------
