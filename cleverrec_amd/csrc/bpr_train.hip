@@ -1415,9 +1415,12 @@ struct StepArgs {
     Hyper h;
     hipStream_t st;
     const int32_t *nwide; // host copy of the chunk's wide-group counts [nbc][2] (tf1 mode)
-    // A launch whose grid differs from the previous launch's costs ~2.4 us more than one that repeats it (measured:
-    // the same kernel, 9.8 us with the wide groups' workgroup count changing per step, 7.2 us with it padded to a
-    // constant).  So every step of a chunk is launched with the chunk's largest counts; surplus waves exit at once.
+    // Workgroups are dealt round-robin to the 8 XCDs, and a table row is cheap to read on the XCD that wrote it in
+    // the previous step.  The workgroups in front of the row waves (wide groups, heavy-row chunk waves) change in
+    // number from batch to batch; if that shifted the row waves by anything but a multiple of 8 workgroups, every
+    // row would move to another XCD every step: the same kernel and work measured 9.5 us per launch so against 7.1
+    // (CREC_WIDE_ROUND=7 vs 8).  Every step of a chunk is launched with the chunk's largest counts; surplus waves
+    // exit at once.
     int pad_wide, pad_chunks_u, pad_chunks_q; // max over the chunk of NWu+NWq, HIu, HIq
 };
 
@@ -1453,6 +1456,10 @@ template <int LPR, bool FULL> void launch_fused(const StepArgs &a, const IndexWs
         hv.NWu = a.nwide[b * 2 + 0];
         hv.NWq = a.nwide[b * 2 + 1];
         hv.NWpad = a.pad_wide;
+        if (const char *e = getenv("CREC_WIDE_ROUND")) { // experiment: this batch's own count rounded up to a multiple of e
+            const int r = atoi(e) > 0 ? atoi(e) : 1;
+            hv.NWpad = (hv.NWu + hv.NWq + r - 1) / r * r;
+        }
     }
     const int64_t waves = a.pad_chunks_u + a.pad_chunks_q + crec_ceil_div(a.U, R) + crec_ceil_div(a.I, R);
     crec_prof_begin(a.ctx, CREC_K_STEP_FUSED, a.st);
