@@ -36,3 +36,21 @@ def parse_list(s, typ=float):
 def is_true(s):
     """The reference compares strings to 'True' (RankingRecommender.py:35)."""
     return str(s).strip() == "True"
+
+
+GRID_KEYS = (("embed_size", int), ("reg", float), ("neg_ratio", int))
+
+
+def grid(configs):
+    """The reference's grid search (main_tuning.py:38-47): embed_size, reg and neg_ratio are bracketed lists in the
+    model's .properties file and every combination is run, embed_size outermost, neg_ratio innermost.  Yields the
+    {'embed_size': .., 'reg': .., 'neg_ratio': ..} update of each run (values typed as the reference types them).
+    A scalar value ('64') counts as a one-element list, so the shipped single-run files work unchanged."""
+    axes = []
+    for key, typ in GRID_KEYS:
+        s = str(configs[key]).strip()
+        axes.append(parse_list(s, typ) if s.startswith("[") else [typ(s)])
+    for e in axes[0]:
+        for r in axes[1]:
+            for n in axes[2]:
+                yield {"embed_size": e, "reg": r, "neg_ratio": n}

@@ -327,6 +327,29 @@ def test_model_class_end_to_end(sess, tmp_path):
     assert os.path.exists(m.save())
 
 
+def test_grid_search_driver(sess, tmp_path):
+    """main_tuning.run_grid: one model per grid point, each the same as building that model alone (same np.random
+    state -> same sampler stream and the same initial tables -> the same best epoch and metrics)."""
+    import logging
+    import main_tuning
+    from cleverrec_amd.model.ranking.BPR import BPR
+    data = _toy_data(31, 120, 80, 3, 20)
+    configs = {"recommender": "BPR", "model_type": "ranking", "epoches": "2", "batch_size": "256", "test.batch_size": "64",
+               "lr": "0.001", "test.neg_samples": "0", "is_pairwise": "True", "init_method": "normal", "stddev": "0.01",
+               "loss_func": "bpr", "optimizer": "Adam", "saved_dir": str(tmp_path), "test.interval": "1", "topk": "[10,20]",
+               "neg_ratio": "[2,4]", "embed_size": "[8,32]", "reg": "0.01", "data.split_way": "rs"}
+    import torch
+    np.random.seed(5)
+    torch.manual_seed(5)
+    results = main_tuning.run_grid(sess, data, configs, logging.getLogger("t"))
+    assert [r[0] for r in results] == [{"embed_size": 8, "reg": 0.01, "neg_ratio": 2}, {"embed_size": 8, "reg": 0.01, "neg_ratio": 4},
+                                       {"embed_size": 32, "reg": 0.01, "neg_ratio": 2}, {"embed_size": 32, "reg": 0.01, "neg_ratio": 4}]
+    np.random.seed(5)
+    torch.manual_seed(5)
+    alone = BPR(sess, data, dict(configs, embed_size=8, reg=0.01, neg_ratio=2), logging.getLogger("t")).run_model()
+    assert alone[0] == results[0][1][0] and alone[1] == results[0][1][1]
+
+
 def test_data_parallel_epoch_world1_matches_oracle(sess):
     """crec_bpr_train_epoch_dp with a 1-rank RCCL communicator: the same kernels, collectives and dense
     Adam the multi-GPU bench runs, against the oracle's data-parallel restatement and the fused step."""

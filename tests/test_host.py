@@ -166,3 +166,15 @@ print(h.hexdigest())
     u, i, j = c.sample_pairwise(data.train_csr, data.item_nums, 4)
     nb, ou, oi, oj = oracle.sample_pairwise(oracle.Rng(11), data.ui_train, data.item_nums, 4, 6144)
     assert len(u) >= 65536 and np.array_equal(u, ou) and np.array_equal(i, oi) and np.array_equal(j, oj)
+
+
+def test_grid_search_order_and_types():
+    """cleverrec_amd.config.grid: the reference's loop nest (main_tuning.py:38-47): embed_size outermost, neg_ratio
+    innermost, ints / floats as it types them; scalars count as one-element lists."""
+    from cleverrec_amd.config import grid
+    pts = list(grid({"embed_size": "[8,16]", "reg": "[0.1,0.01]", "neg_ratio": "[2,4]"}))
+    assert len(pts) == 8
+    assert pts[0] == {"embed_size": 8, "reg": 0.1, "neg_ratio": 2} and pts[1] == {"embed_size": 8, "reg": 0.1, "neg_ratio": 4}
+    assert pts[2]["reg"] == 0.01 and pts[4]["embed_size"] == 16
+    assert all(isinstance(p["embed_size"], int) and isinstance(p["reg"], float) and isinstance(p["neg_ratio"], int) for p in pts)
+    assert list(grid({"embed_size": "64", "reg": "1e-2", "neg_ratio": " [4] "})) == [{"embed_size": 64, "reg": 0.01, "neg_ratio": 4}]
