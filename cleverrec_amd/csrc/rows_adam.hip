@@ -74,6 +74,20 @@ __global__ __launch_bounds__(IDX_THREADS) void rows_index_batches(const int32_t 
 
 __device__ inline float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ inline void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+// rows written once per launch and not read again by it (bpr_train.hip, CREC_NT): non-temporal when CREC_ROWS_NT
+#ifndef CREC_ROWS_NT
+#define CREC_ROWS_NT 1
+#endif
+typedef float crec_rows_f4v __attribute__((ext_vector_type(4)));
+__device__ inline void st4_stream(float *p, float4 v)
+{
+    if (CREC_ROWS_NT) {
+        crec_rows_f4v t = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(t, reinterpret_cast<crec_rows_f4v *>(p));
+    } else {
+        st4(p, v);
+    }
+}
 
 // one wave per table row; group g of the wave takes slots g, g+G, ... of the row (fixed order),
 // the G partial sums are added in group order
@@ -171,9 +185,9 @@ __device__ __forceinline__ void rows_apply_row(const crec_rows_table &t, const i
             pn[c] = pvar[c] - (o.lr_t * pm[c]) / (sqrtf(pv[c]) + o.eps);
         }
     }
-    st4(t.var + ro, nv);
-    st4(t.m + ro, m);
-    st4(t.v + ro, v);
+    st4_stream(t.var + ro, nv);
+    st4_stream(t.m + ro, m);
+    st4_stream(t.v + ro, v);
 }
 
 template <int LPR>
