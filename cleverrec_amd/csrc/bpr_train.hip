@@ -672,7 +672,7 @@ __device__ __forceinline__ void trip_consume(const Trip &tr, const WaveCtx<Geo<L
             if (tr.has[t] && w.l == 0)
                 w.xb[pos] = x; // softplus(-x) is taken in bpr_reduce_loss
             if (STORE_CONTRIB && tr.has[t] && w.act)
-                st4(w.contrib + (int64_t)pos * w.d + 4 * w.l, make_float4(s * own.x, s * own.y, s * own.z, s * own.w));
+                st4s(w.contrib + (int64_t)pos * w.d + 4 * w.l, make_float4(s * own.x, s * own.y, s * own.z, s * own.w));
             const float ns = -s;
             c.x = ns * (tr.a[t].x - tr.b[t].x) + w.reg * own.x;
             c.y = ns * (tr.a[t].y - tr.b[t].y) + w.reg * own.y;
