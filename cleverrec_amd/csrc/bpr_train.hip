@@ -212,7 +212,19 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
         rows[k] = (uint32_t)(side == 0 ? u[t0 + k] : (k < nb ? i[t0 + k] : j[t0 + k - nb]));
         tag[k] = (uint16_t)k;
     }
+#ifdef CREC_STAMPS // phase times of workgroups 0 (user side) and 1 (item side) of the launch: crec_stamps[16000*8 + ...]
+#define CREC_IDX_MARK(k)                                                           \
+    do {                                                                           \
+        __syncthreads();                                                           \
+        if (tid == 0 && blockIdx.x < 2)                                            \
+            crec_stamps[8 * (16000 + 2 * (k) + blockIdx.x)] = wall_clock64();      \
+    } while (0)
+#else
+#define CREC_IDX_MARK(k)
+#endif
+    CREC_IDX_MARK(0);
     crec_sort::block_sort_rows<PREP_THREADS>(rows, tag, n, side ? w.bits_q : w.bits_u, hist, scan);
+    CREC_IDX_MARK(1);
 
     // run starts (blocked over positions, so that the scan runs in sorted order) -> seg[rank]
     const int per = (n + PREP_THREADS - 1) / PREP_THREADS;
@@ -229,6 +241,7 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
         seg[total] = (uint16_t)n;
     __syncthreads();
 
+    CREC_IDX_MARK(2);
     // heavy rows (more than CH occurrences) and their chunks, in rank order (blocked over ranks)
     int4 *hrows_out = side ? w.q_hrows + (int64_t)batch * w.HRq : w.u_hrows + (int64_t)batch * w.HRu;
     int4 *hitems_out = side ? w.q_hitems + (int64_t)batch * w.HIq : w.u_hitems + (int64_t)batch * w.HIu;
@@ -257,11 +270,14 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
         }
     }
 
+    CREC_IDX_MARK(3);
     // wide groups (tf1 mode): ranks whose rows share one row wave (row / R) and hold more than wide_total occurrences
     // together, none of them heavy.  The group's first present rank speaks for it.
     const int64_t n_rows = side ? w.I : w.U;
     const int WR = n_rows > 0 ? w.wide_rows : 0, WT_ = w.wide_total;
-    const auto group_of = [&](int q) { return rows[seg[q]] / (uint32_t)WR; };
+    // R is a power of two (lane groups per wave, capped at 4): a row's group is a shift away
+    const int wshift = WR > 0 ? 31 - __builtin_clz((unsigned)WR) : 0;
+    const auto group_of = [&](int q) { return rows[seg[q]] >> wshift; };
     const auto group_total = [&](int q) -> int { // q: first rank of its group; -1 if the group holds a heavy row
         const uint32_t gq = group_of(q);
         int tot = 0;
@@ -273,27 +289,33 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
         }
         return tot;
     };
-    const auto in_wide = [&](int q) -> bool { // rank q belongs to a wide group
-        if (WR <= 0)
-            return false;
-        int lead = q;
-        while (lead > 0 && lead > q - WR && group_of(lead - 1) == group_of(q))
-            --lead;
-        return group_total(lead) > WT_;
-    };
+    // one flag per rank (in the sort's counter space, free by now): the rank belongs to a wide group.  A group's first
+    // present rank decides for the group
+    uint8_t *wflag = (uint8_t *)hist;
     int wide_total_n = 0;
     if (WR > 0) {
+        __syncthreads();
+        for (int q = tid; q < total; q += PREP_THREADS) {
+            if (q > 0 && group_of(q - 1) == group_of(q))
+                continue;
+            const bool wide = group_total(q) > WT_;
+            const uint32_t gq = group_of(q);
+            for (int p = q; p < total && p < q + WR && group_of(p) == gq; ++p)
+                wflag[p] = wide ? 1 : 0;
+        }
+        __syncthreads();
         int nw = 0;
         for (int q = q0; q < q1; ++q)
-            if ((q == 0 || group_of(q - 1) != group_of(q)) && group_total(q) > WT_)
-                ++nw;
+            nw += (wflag[q] && (q == 0 || group_of(q - 1) != group_of(q))) ? 1 : 0;
         int at = crec_sort::block_excl_scan<PREP_THREADS>(nw, scan, &wide_total_n);
         int32_t *wide_out = side ? w.q_wide + (int64_t)batch * w.WMq : w.u_wide + (int64_t)batch * w.WMu;
         for (int q = q0; q < q1; ++q)
-            if ((q == 0 || group_of(q - 1) != group_of(q)) && group_total(q) > WT_)
+            if (wflag[q] && (q == 0 || group_of(q - 1) != group_of(q)))
                 wide_out[at++] = (int32_t)group_of(q);
     }
+    const auto in_wide = [&](int q) -> bool { return WR > 0 && wflag[q] != 0; };
 
+    CREC_IDX_MARK(4);
     // per-rank outputs and (tf1 mode) every table row's {segment start, length; negative: heavy}, striped over ranks
     int32_t *rows_out = side ? w.q_rows + (int64_t)batch * 2 * B : w.u_rows + (int64_t)batch * B;
     int32_t *seg_out = side ? w.q_seg + (int64_t)batch * (2 * B + 1) : w.u_seg + (int64_t)batch * (B + 1);
@@ -311,12 +333,35 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
                                    [&](int c) { return (c > CH || in_wide(q)) ? -c : c; });
     }
 
+    CREC_IDX_MARK(5);
     // occurrence records in sorted order
     int4 *occ_out = side ? w.q_occ + (int64_t)batch * 2 * B : w.u_occ + (int64_t)batch * B;
-    for (int k = tid; k < n; k += PREP_THREADS) {
-        const int t = tag[k], pos = t < nb ? t : t - nb;
-        const uint32_t payload = (t < nb ? 0u : 0x80000000u) | (uint32_t)pos; // side flag: the row is the triple's j
-        occ_out[k] = make_int4(u[t0 + pos], i[t0 + pos], j[t0 + pos], (int)payload);
+    for (int k0r = tid; k0r < n; k0r += 4 * PREP_THREADS) { // four records per thread in flight: the gathers are the cost
+        int pos[4];
+        uint32_t payload[4];
+        int4 rec[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = k0r + e * PREP_THREADS;
+            const int t = k < n ? tag[k] : 0;
+            pos[e] = t < nb ? t : t - nb;
+            payload[e] = (t < nb ? 0u : 0x80000000u) | (uint32_t)pos[e]; // side flag: the row is the triple's j
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { // the sorted row is one of the three ids: two scattered loads per record, not three
+            const int k = k0r + e * PREP_THREADS;
+            const int row = k < n ? (int)rows[k] : 0;
+            if (side == 0)
+                rec[e] = make_int4(row, i[t0 + pos[e]], j[t0 + pos[e]], (int)payload[e]);
+            else if ((int)payload[e] < 0)
+                rec[e] = make_int4(u[t0 + pos[e]], i[t0 + pos[e]], row, (int)payload[e]);
+            else
+                rec[e] = make_int4(u[t0 + pos[e]], row, j[t0 + pos[e]], (int)payload[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (k0r + e * PREP_THREADS < n)
+                occ_out[k0r + e * PREP_THREADS] = rec[e];
     }
     if (tid == 0) {
         (side ? w.n_q : w.n_u)[batch] = total;
@@ -324,6 +369,7 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
         w.hn[batch * 4 + side * 2 + 1] = hv_total & 0xffff;
         w.nwide[batch * 2 + side] = wide_total_n;
     }
+    CREC_IDX_MARK(6);
 }
 
 // ------------------------------------------------------------------------------------

@@ -35,6 +35,13 @@ def main():
     rc = lib.crec_debug_stamps(buf, ctypes.c_size_t(n))
     assert rc == 0, rc
     a = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 8).astype(np.int64)
+    marks_idx = a[16000:16014, 0].reshape(7, 2)  # bpr_index_batches, workgroups 0 (user side) and 1 (item side)
+    if marks_idx.min() > 0:
+        names = ("fill + sort", "run starts", "heavy rows", "wide groups", "per-rank outputs, row segments", "occurrence records")
+        for side, sname in enumerate(("user", "item")):
+            d = np.diff(marks_idx[:, side]) * 10.0 / 1e3
+            print("index kernel, %s-side workgroup: %s = %.1f us" % (sname, ", ".join("%s %.1f" % (nm, x) for nm, x in zip(names, d)), d.sum()))
+    a[16000:] = 0
     n_wide = int(((a[:, 7] & 4) != 0).sum())  # waves of the wide groups' workgroups come first
     rowflag = ((a[:, 7] & 2) != 0) & ((a[:, 7] & 4) == 0)
     first_row = n_wide + int(np.argmax(rowflag[n_wide:]))
