@@ -159,7 +159,7 @@ def main():
                            "note": "avg_launch_us = mean over the timed launches of the elapsed time between the two HIP events "
                                    "attached to each dispatch (hipExtLaunchKernelGGL start/stop events on the launch stream), i.e. "
                                    "the dispatch's own begin/end timestamps.  rocprofv3 --kernel-trace of the same workload "
-                                   "(profiles/round1_bench_kernel_stats.txt) reads 6.92 us median / 7.08 us mean: under tracing "
+                                   "(profiles/round1_bench_kernel_stats.txt) reads 7.04 us median / 7.21 us mean: under tracing "
                                    "consecutive dependent dispatches tile the timeline, so its figure is the launch-to-launch "
                                    "period (launch_period_us here, untraced).  Tables+slots are 7.5 MB (Infinity-Cache resident): "
                                    "the HBM fraction is nominal; S-big (synthetic_big) is the HBM-resident form",
