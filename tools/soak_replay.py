@@ -71,6 +71,15 @@ def main():
                       "oracle": (om.P.astype(np.float64), om.Q.astype(np.float64))}
             loss = st.train_epoch(sess.to_dev(u[sl]), sess.to_dev(i[sl]), sess.to_dev(j[sl]), B).cpu().numpy()
             ol = oracle.train_model_py(om, 1, u[sl], i[sl], j[sl], B)[1]
+            if abs(loss[0] - ol[0]) > 2e-5 * abs(ol[0]) + 1e-6:
+                P64, Q64 = before["oracle"]
+                x = [float(P64[a_] @ Q64[b_] - P64[a_] @ Q64[c_]) for a_, b_, c_ in zip(u[sl], i[sl], j[sl])]
+                print("epoch %d batch %d: loss %.9g (gpu) vs %.9g (oracle), relative %.3g; x of the batch's triples (float64, oracle tables): %s" % (
+                    ep, b, loss[0], ol[0], abs(loss[0] - ol[0]) / abs(ol[0]), np.round(x[:8], 4)))
+                Pg, Qg = before["gpu"]
+                xg = [float(Pg[a_] @ Qg[b_] - Pg[a_] @ Qg[c_]) for a_, b_, c_ in zip(u[sl], i[sl], j[sl])]
+                print("   x from the gpu's tables:", np.round(xg[:8], 4), " max |table difference| P %.3g Q %.3g" % (np.abs(Pg - P64).max(), np.abs(Qg - Q64).max()))
+                return
             for name, idx in (("P", u[sl]), ("Q", np.concatenate([i[sl], j[sl]]))):
                 diff = np.abs(getattr(st, name).cpu().numpy() - getattr(om, name))
                 bad = np.nonzero((diff > 1e-5 * max(c["scale"], 0.05) * 20).any(1))[0]
