@@ -895,8 +895,10 @@ __device__ __forceinline__ void row_wave(const Tables &src, const Tables &dst, i
     float4 var = zero, m = zero, v = zero;
     if (in_slot) {
         var = ld4((user ? src.P : src.Q) + ro);
-        m = ld4s((user ? src.mP : src.mQ) + ro);
-        v = ld4s((user ? src.vP : src.vQ) + ro);
+        if (user || !h.dQ) { // the data-parallel step hands item rows' Adam to bpr_adam_dense: no need for their slots here
+            m = ld4s((user ? src.mP : src.mQ) + ro);
+            v = ld4s((user ? src.vP : src.vQ) + ro);
+        }
     }
     const bool heavy = sl.cnt < 0;
     const bool owner = in_slot && !heavy; // heavy rows are finished by their last chunk wave
@@ -966,7 +968,7 @@ __device__ __forceinline__ void wide_group(const Tables &src, const Tables &dst,
     float4 var = zero, m = zero, v = zero;
     if (owner) {
         var = ld4((user ? src.P : src.Q) + ro); // every wave: the records' arithmetic needs the rows
-        if (wv == 0) {
+        if (wv == 0 && (user || !h.dQ)) {
             m = ld4s((user ? src.mP : src.mQ) + ro);
             v = ld4s((user ? src.vP : src.vQ) + ro);
         }
@@ -1407,9 +1409,9 @@ __global__ __launch_bounds__(256) void bpr_adam_dense(float *__restrict__ var, f
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n4; k += (int64_t)gridDim.x * blockDim.x) {
         float4 a = ld4(var + 4 * k), b = ld4(m + 4 * k), c = ld4(v + 4 * k);
         adam4(a, b, c, ld4(g + 4 * k), true, h);
-        st4(var + 4 * k, a);
-        st4(m + 4 * k, b);
-        st4(v + 4 * k, c);
+        st4s(var + 4 * k, a);
+        st4s(m + 4 * k, b);
+        st4s(v + 4 * k, c);
     }
 }
 
