@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity soak (GPU): many random shapes of the BPR step (both Adam modes, heavy rows included), the fused
 eval and the device sampler against the CPU oracle / the rule's properties.  Not part of the test suite (minutes of
-run time); `python tools/soak.py --minutes 3` prints one line per failure and a summary."""
+run time); `python tests/soak/soak.py --minutes 3` prints one line per failure and a summary."""
 import argparse
 import os
 import sys
@@ -9,7 +9,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 

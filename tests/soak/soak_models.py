@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity soak of the other graphs (GMF / MLP / NeuMF, FM, CML) against oracle/models_torch.py (GPU).
-`python tools/soak_models.py --minutes 2`.  Losses rtol 2e-5; parameters: nearly every element within 1e-5, a vanishing
-fraction within a couple of Adam steps (see tools/soak.py for why).
+`python tests/soak/soak_models.py --minutes 2`.  Losses rtol 2e-5; parameters: nearly every element within 1e-5, a vanishing
+fraction within a couple of Adam steps (see tests/soak/soak.py for why).
 Known benign source of a rare CML loss mismatch at B = 1: the WARP rank counts negatives with d_ui + margin - d_un > 0, an
 indicator; when that difference is within fp32 summation noise of 0 the count -- and log(rank + 1) -- legitimately differs
 (about one instance-negative pair in 10^6 with random data; diluted below tolerance in larger batches)."""
@@ -12,7 +12,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 

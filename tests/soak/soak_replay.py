@@ -1,15 +1,15 @@
 #!/usr/bin/env python3
-"""Rebuild one BPR configuration of tools/soak.py from the soak's seed and the failing line's sampler seed (the soak
+"""Rebuild one BPR configuration of tests/soak/soak.py from the soak's seed and the failing line's sampler seed (the soak
 draws everything from one generator, so the draws of all earlier configurations are replayed, without the GPU work),
 run it again on the GPU and report where the tables differ from the oracle's: which rows, how many occurrences they
-had in each batch, how large the differences are.   python tools/soak_replay.py --seed 11 --target 600540297"""
+had in each batch, how large the differences are.   python tests/soak/soak_replay.py --seed 11 --target 600540297"""
 import argparse
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
