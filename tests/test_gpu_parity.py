@@ -77,6 +77,28 @@ def test_bpr_batch_sizes_and_ragged_tail(sess, B):
     _assert_state_close(st, om, atol=2e-6)
 
 
+def test_bpr_launch_padding_does_not_change_results(sess, monkeypatch):
+    """The workgroups in front of the row waves are padded (to the chunk's largest count, or with CREC_WIDE_ROUND to a
+    multiple of this batch's own) only to keep every row on one XCD from step to step: bitwise the same tables."""
+    data = synthetic("S-ml100k")
+    P0, Q0 = _tables(12, data.user_nums, data.item_nums, 64)
+    sess.ctx.seed(5)
+    u, i, j = (sess.to_dev(a) for a in sess.ctx.sample_pairwise(data.train_csr, data.item_nums, 4))
+    n = 6 * 6144 + 55
+    out = []
+    for rnd in (None, "1", "7", "8"):
+        if rnd is None:
+            monkeypatch.delenv("CREC_WIDE_ROUND", raising=False)
+        else:
+            monkeypatch.setenv("CREC_WIDE_ROUND", rnd)
+        st = runtime.BprState(sess, P0, Q0, lr=1e-3, reg=0.01, adam_mode="tf1")
+        loss = st.train_epoch(u[:n], i[:n], j[:n], 6144)
+        out.append([t.cpu().numpy() for t in (loss, st.P, st.Q, st.vP, st.mQ)])
+    for other in out[1:]:
+        for a, b in zip(out[0], other):
+            assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("mode,U,I", [("lazy", 300_001, 70_003), ("tf1", 65_537, 66_000), ("lazy", 17_000_000, 257)])
 def test_bpr_sparse_ids_in_large_tables(sess, mode, U, I):
     """Row ids that need three or four 8-bit passes of the index kernel's radix sort (17 to 25 significant bits, with a
