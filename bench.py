@@ -33,6 +33,8 @@ D, B, NEG, LR, REG = 64, 6144, 4, 1e-3, 0.01
 
 
 def main():
+    # the host driver only supports dmabuf IPC: RCCL between processes needs this before HIP is initialised
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # stdout carries exactly one line, the JSON: everything else that lands on fd 1 (RCCL prints a version banner
     # there when it initialises) is sent to stderr
     real_stdout = os.dup(1)
