@@ -1,11 +1,11 @@
 #!/bin/bash
 # Build libcrec.so variants of bpr_train.hip with different tuning / ablation macros and bench each (GPU box).
-# usage: tools/variants.sh "UNR RPW PIPE [ABL [NT [WT [BLOCK]]]]" ...   e.g. tools/variants.sh "2 2 0" "2 2 0 1" ; BIG=1 adds the S-big leg
+# usage: tools/variants.sh "UNR RPW PIPE [ABL [NT [WT [BLOCK [ITEMS_FIRST]]]]]" ...   e.g. tools/variants.sh "2 2 0" "2 2 0 1" ; BIG=1 adds the S-big leg
 cd "$(dirname "$0")/.." || exit 1
 O=cleverrec_amd/lib/obj
 for v in "$@"; do
-  set -- $v; tag="u$1_r$2_p$3_a${4:-0}_n${5:-0}_w${6:-0}_b${7:-256}"; out=/tmp/crec_$tag; mkdir -p $out
-  hipcc --offload-arch=gfx950 -x hip -O3 -fPIC -std=c++17 -ffp-contract=off -Iinclude -DCREC_UNR=$1 -DCREC_RPW=$2 -DCREC_PIPE=$3 -DCREC_ABL=${4:-0} -DCREC_NT=${5:-0} -DCREC_FUSED_WT=${6:-0} -DCREC_FUSED_BLOCK=${7:-256} \
+  set -- $v; tag="u$1_r$2_p$3_a${4:-0}_n${5:-0}_w${6:-0}_b${7:-256}_i${8:-0}"; out=/tmp/crec_$tag; mkdir -p $out
+  hipcc --offload-arch=gfx950 -x hip -O3 -fPIC -std=c++17 -ffp-contract=off -Iinclude -DCREC_UNR=$1 -DCREC_RPW=$2 -DCREC_PIPE=$3 -DCREC_ABL=${4:-0} -DCREC_NT=${5:-0} -DCREC_FUSED_WT=${6:-0} -DCREC_FUSED_BLOCK=${7:-256} -DCREC_ITEMS_FIRST=${8:-0} \
         -c cleverrec_amd/csrc/bpr_train.hip -o $out/bpr_train.o -Rpass-analysis=kernel-resource-usage 2> $out/res.txt || { tail -5 $out/res.txt; exit 1; }
   objs=$(ls $O/*.o | grep -v "/bpr_train.o")
   hipcc --offload-arch=gfx950 -shared -o $out/libcrec.so $objs $out/bpr_train.o -L/opt/rocm/lib -lrccl || exit 1
