@@ -41,8 +41,8 @@ def main():
     os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=9120)
-    ap.add_argument("--warmup", type=int, default=9120)
+    ap.add_argument("--steps", type=int, default=45600)
+    ap.add_argument("--warmup", type=int, default=65536)
     ap.add_argument("--cpu-steps", type=int, default=5000, help="steps of the CPU baseline sample (0 = skip); 5000 ~ 12 s")
     ap.add_argument("--no-extras", action="store_true", help="skip the roofline/eval/sampler/cpu legs")
     ap.add_argument("--no-big", action="store_true", help="skip the S-big (10M x 1M, d=128) leg")
