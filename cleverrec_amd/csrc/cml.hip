@@ -187,15 +187,28 @@ __global__ __launch_bounds__(256) void cml_instances(const float *__restrict__ P
     const float d_ui = gsum<LPR>(sqdist4(p, qi));
     float dmin = INFINITY;
     int kmin = 0, imp = 0;
-    for (int k = 0; k < K; ++k) { // wave-uniform trip count
-        const int nk = ok ? neg[inst * K + k] : 0;
-        const float4 qn = (ok && act) ? ld4(Q + (int64_t)nk * d + 4 * l) : zero;
-        const float dn = gsum<LPR>(sqdist4(p, qn));
-        if (dn < dmin) { // first minimum wins
-            dmin = dn;
-            kmin = nk;
+    // four negatives' rows in flight per group: the loop is a chain of row fetches otherwise (K is 20 in the shipped conf)
+    constexpr int NB = 4;
+    for (int k0 = 0; k0 < K; k0 += NB) { // wave-uniform trip count
+        int nk[NB];
+        float4 qn[NB];
+#pragma unroll
+        for (int e = 0; e < NB; ++e)
+            nk[e] = (ok && k0 + e < K) ? neg[inst * K + k0 + e] : 0;
+#pragma unroll
+        for (int e = 0; e < NB; ++e)
+            qn[e] = (ok && act) ? ld4(Q + (int64_t)nk[e] * d + 4 * l) : zero;
+#pragma unroll
+        for (int e = 0; e < NB; ++e) {
+            if (k0 + e < K) { // wave-uniform
+                const float dn = gsum<LPR>(sqdist4(p, qn[e]));
+                if (dn < dmin) { // first minimum wins
+                    dmin = dn;
+                    kmin = nk[e];
+                }
+                imp += (d_ui + margin - dn) > 0.f;
+            }
         }
-        imp += (d_ui + margin - dn) > 0.f;
     }
     const float base = fmaxf(d_ui + margin - dmin, 0.f);
     const float rank = ((float)imp / (float)K) * rank_scale;
