@@ -109,6 +109,13 @@ __device__ __forceinline__ void rows_apply_row(const crec_rows_table &t, const i
     if (chunks == 1 && rs0.y == 0 && o.kind == ROWS_SPARSE_LAZY)
         return;
     const float4 var = act ? ld4(t.var + ro) : zero;
+    // the slots are only needed for the update at the end, but asked for here: behind the slot walk their round trip
+    // would be the last link of every wave's chain
+    float4 m = zero, v = zero;
+    if (g == 0 && act) {
+        m = ld4(t.m + ro);
+        v = ld4(t.v + ro);
+    }
     float4 acc = zero;
     int touched = 0;
     for (int ch = 0; ch < chunks; ++ch) { // chunk by chunk = ascending slot order
@@ -167,7 +174,7 @@ __device__ __forceinline__ void rows_apply_row(const crec_rows_table &t, const i
     }
     if (g != 0 || !act)
         return;
-    float4 m = ld4(t.m + ro), v = ld4(t.v + ro), nv = var;
+    float4 nv = var;
     float *pg = &acc.x, *pm = &m.x, *pv = &v.x, *pn = &nv.x;
     const float *pvar = &var.x;
     const float *pdg = &dg.x;
