@@ -119,7 +119,9 @@ __device__ __forceinline__ void rows_apply_row(const crec_rows_table &t, const i
     float4 acc = zero;
     int touched = 0;
     for (int ch = 0; ch < chunks; ++ch) { // chunk by chunk = ascending slot order
-        const int2 rs = ch == 0 ? rs0 : rowseg[(int64_t)ch * t.rows + r];
+        int2 rs = rs0; // (a ?: of the two int2 objects selects between addresses and sends rs0 to scratch)
+        if (ch != 0)
+            rs = rowseg[(int64_t)ch * t.rows + r];
         touched += rs.y;
         for (int k = rs.x + g; k < rs.x + rs.y; k += G) {
             if (act) {
@@ -175,23 +177,24 @@ __device__ __forceinline__ void rows_apply_row(const crec_rows_table &t, const i
     if (g != 0 || !act)
         return;
     float4 nv = var;
-    float *pg = &acc.x, *pm = &m.x, *pv = &v.x, *pn = &nv.x;
-    const float *pvar = &var.x;
-    const float *pdg = &dg.x;
     const float omb1 = 1.0f - o.beta1, omb2 = 1.0f - o.beta2;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    // component by component in registers (indexing the float4s through pointers put them in scratch)
+    const auto upd = [&](float g_, float d_, float var_, float &m_, float &v_, float &n_) {
         if (o.kind == ROWS_DENSE) {
-            const float gg = (pg[c] + pdg[c]) + o.dense_reg * pvar[c];
-            pm[c] = pm[c] + (gg - pm[c]) * omb1;
-            pv[c] = pv[c] + (gg * gg - pv[c]) * omb2;
-            pn[c] = pvar[c] - (pm[c] * o.lr_t) / (sqrtf(pv[c]) + o.eps);
+            const float gg = (g_ + d_) + o.dense_reg * var_;
+            m_ = m_ + (gg - m_) * omb1;
+            v_ = v_ + (gg * gg - v_) * omb2;
+            n_ = var_ - (m_ * o.lr_t) / (sqrtf(v_) + o.eps);
         } else {
-            pm[c] = pm[c] * o.beta1 + pg[c] * omb1;
-            pv[c] = pv[c] * o.beta2 + (pg[c] * pg[c]) * omb2;
-            pn[c] = pvar[c] - (o.lr_t * pm[c]) / (sqrtf(pv[c]) + o.eps);
+            m_ = m_ * o.beta1 + g_ * omb1;
+            v_ = v_ * o.beta2 + (g_ * g_) * omb2;
+            n_ = var_ - (o.lr_t * m_) / (sqrtf(v_) + o.eps);
         }
-    }
+    };
+    upd(acc.x, dg.x, var.x, m.x, v.x, nv.x);
+    upd(acc.y, dg.y, var.y, m.y, v.y, nv.y);
+    upd(acc.z, dg.z, var.z, m.z, v.z, nv.z);
+    upd(acc.w, dg.w, var.w, m.w, v.w, nv.w);
     st4_stream(t.var + ro, nv);
     st4_stream(t.m + ro, m);
     st4_stream(t.v + ro, v);
@@ -288,8 +291,12 @@ template <int LPR> __global__ __launch_bounds__(256) void apply_all(crec_apply_s
     __shared__ float red[SAD_SL * 16];
     const int bi = blockIdx.x;
     int k = 0, first = 0;
-    while (k < a.n_tables && bi >= a.block_end[k])
-        first = a.block_end[k++];
+#pragma unroll
+    for (int q = 0; q < CREC_APPLY_MAX_TABLES; ++q) // unrolled: a loop indexing block_end[] sent the array to scratch
+        if (q < a.n_tables && bi >= a.block_end[q]) {
+            first = a.block_end[q];
+            k = q + 1;
+        }
     if (k < a.n_tables) {
         const crec_rows_job &j = a.tables[k];
         rows_apply_row<LPR>(j.t, j.rowseg, j.order, j.contrib, j.dense_grad, j.row_out, j.o,

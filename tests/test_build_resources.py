@@ -53,3 +53,13 @@ def test_index_kernels_keep_their_elements_in_registers():
         assert idx
         for v in idx:  # 1024-thread workgroups: at most 128 VGPRs, and no spills
             assert v["VGPRs"] <= 128 and v["ScratchSize"] == 0, v
+
+
+def test_row_apply_kernels_do_not_spill():
+    """rows_apply / apply_all once kept an int2 and block_end[] in scratch (a ?: between two objects selects between
+    addresses): 16 bytes per lane of private memory on every wave of the models' update launches."""
+    res = _resources("rows_adam.hip", ("-ffp-contract=off",))
+    ks = [v for k, v in res.items() if "apply_all" in k or "rows_applyI" in k]
+    assert ks
+    for v in ks:
+        assert v["ScratchSize"] == 0 and v["Occupancy"] >= 8, v
