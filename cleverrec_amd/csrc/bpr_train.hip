@@ -1473,6 +1473,7 @@ struct StepArgs {
     // (CREC_WIDE_ROUND=7 vs 8).  Every step of a chunk is launched with the chunk's largest counts; surplus waves
     // exit at once.
     int pad_wide, pad_chunks_u, pad_chunks_q; // max over the chunk of NWu+NWq, HIu, HIq
+    int wide_round;                           // CREC_WIDE_ROUND, read once per epoch (0: unset)
 };
 
 // hn: this batch's {user heavy rows, user chunks, item heavy rows, item chunks}, read back by the host
@@ -1507,10 +1508,8 @@ template <int LPR, bool FULL> void launch_fused(const StepArgs &a, const IndexWs
         hv.NWu = a.nwide[b * 2 + 0];
         hv.NWq = a.nwide[b * 2 + 1];
         hv.NWpad = a.pad_wide;
-        if (const char *e = getenv("CREC_WIDE_ROUND")) { // experiment: this batch's own count rounded up to a multiple of e
-            const int r = atoi(e) > 0 ? atoi(e) : 1;
-            hv.NWpad = (hv.NWu + hv.NWq + r - 1) / r * r;
-        }
+        if (a.wide_round > 0) // experiment: this batch's own count rounded up to a multiple
+            hv.NWpad = (hv.NWu + hv.NWq + a.wide_round - 1) / a.wide_round * a.wide_round;
     }
     const int64_t waves = a.pad_chunks_u + a.pad_chunks_q + crec_ceil_div(a.U, R) + crec_ceil_div(a.I, R);
     crec_prof_begin(a.ctx, CREC_K_STEP_FUSED, a.st);
@@ -1696,6 +1695,7 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
 
     StepArgs a{};
     a.ctx = ctx;
+    a.wide_round = getenv("CREC_WIDE_ROUND") ? atoi(getenv("CREC_WIDE_ROUND")) : 0;
     a.cur = Tables{t->P, t->mP, t->vP, t->Q, t->mQ, t->vQ};
     a.d = t->d;
     a.U = t->U;
