@@ -184,6 +184,8 @@ void crec_ctx_destroy(crec_ctx *ctx)
         }
         for (hipEvent_t e : ctx->prof.pool)
             (void)hipEventDestroy(e);
+        if (ctx->pinned)
+            (void)hipHostFree(ctx->pinned);
     }
     delete ctx;
 }

@@ -76,6 +76,8 @@ struct crec_ctx {
     crec_devbuf loss_ws;  // per-triple loss terms of one chunk
     crec_devbuf lr_table; // per-step lr_t of one chunk
     crec_devbuf misc;     // small counters
+    int32_t *pinned = nullptr; // page-locked host buffer for the per-chunk counts read back from the index kernel
+    size_t pinned_ints = 0;
     // eval workspace (eval_topk.hip)
     crec_devbuf eval_ws;
     crec_devbuf ks_dev;
