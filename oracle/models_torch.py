@@ -11,11 +11,53 @@ backward is autograd; the optimizer is a restatement of TF1's AdamOptimizer with
 
 lr_t = lr*sqrt(1-b2^t)/(1-b1^t) with fp32 running powers.  Parity is unpinned at the TF boundary
 (TensorFlow is absent, reference README.md:57); see DESIGN.md 2.
+
+Determinism.  Every embedding_lookup goes through `gather` below, whose backward sums the per-slot gradient
+rows serially in slot order -- what TF1's CPU UnsortedSegmentSum does.  (torch's own index backward is
+index_put_(accumulate=True), which runs as parallel float atomic adds above 32768 elements: a run-to-run
+summation order.)  Model.step also pins torch to one thread so that matmul blocking does not depend on the host.
+
+Rounding-error envelope.  fp32 sums of contribution rows agree between two correct implementations only up to
+the order of additions: |delta g| <= NOISE * sum|c_k|.  Adam turns that into lr_t*delta_g/(sqrt(v)+eps) on the
+variable -- of the order of lr itself where a gradient sum cancels to ~0 -- so a flat atol on post-Adam weights
+is a cliff edge.  Model.step therefore propagates the envelope: tol_m, tol_v, tol_var per element, which
+tests/ use as the comparison bound (tight where the gradient is well conditioned, wide only where it cancels).
 """
 import numpy as np
 import torch
 
 f32 = torch.float32
+NOISE = 1e-5  # relative to sum|c_k|: contributions come out of length-d dot products (and a tower) rounded in another
+              # order; a pure permutation of the batch already uses 0.6 of a 4e-6 envelope (tests/test_oracle_models.py)
+
+
+class _Gather(torch.autograd.Function):
+    """table[idx] (tf.nn.embedding_lookup / tf.gather) with a serial, slot-ordered backward; also leaves
+    sum_k |c_k| per table element in sink[key] (the rounding envelope's scale)."""
+
+    @staticmethod
+    def forward(ctx, table, idx, sink, key):
+        ctx.save_for_backward(idx)
+        ctx.shape, ctx.sink, ctx.key = tuple(table.shape), sink, key
+        return table.detach()[idx]
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        flat = idx.numpy().reshape(-1)
+        rows = np.ascontiguousarray(g.numpy(), dtype=np.float32).reshape((flat.shape[0],) + ctx.shape[1:])
+        out = np.zeros(ctx.shape, np.float32)
+        np.add.at(out, flat, rows)  # unbuffered, in slot order: one fixed fp32 summation order
+        if ctx.sink is not None:
+            a = np.zeros(ctx.shape, np.float32)
+            np.add.at(a, flat, np.abs(rows))
+            ctx.sink[ctx.key] = ctx.sink.get(ctx.key, 0) + a
+        return torch.from_numpy(out), None, None, None
+
+
+def gather(w, key, idx):
+    """w: the step's leaf dict (may carry '_abs', the |c| sink); key: variable name; idx: long tensor."""
+    return _Gather.apply(w[key], idx, w.get("_abs"), key)
 
 
 class TF1Adam:
@@ -26,8 +68,25 @@ class TF1Adam:
         self.b1p, self.b2p = np.float32(beta1), np.float32(beta2)
         self.m = {k: torch.zeros_like(v) for k, v in params.items()}
         self.v = {k: torch.zeros_like(v) for k, v in params.items()}
+        # rounding-error envelopes (see the module docstring), float64
+        self.tol_m = {k: np.zeros(tuple(v.shape)) for k, v in params.items()}
+        self.tol_v = {k: np.zeros(tuple(v.shape)) for k, v in params.items()}
+        self.tol_var = {k: np.zeros(tuple(v.shape)) for k, v in params.items()}
 
-    def step(self, grads):
+    def _envelope(self, k, g, gabs, lr_t):
+        """after the update of variable k with gradient g: |delta g| <= NOISE * (sum|c| of the gathers + |g|)
+        (dense gradients: NOISE * max|g| as the scale of the cancelled terms)."""
+        ga = np.abs(g.numpy().astype(np.float64))
+        dg = NOISE * (np.asarray(gabs, dtype=np.float64) + ga) if gabs is not None else NOISE * np.maximum(ga, ga.max(initial=0.0))
+        b1, b2 = float(self.b1), float(self.b2)
+        self.tol_m[k] = b1 * self.tol_m[k] + (1 - b1) * dg
+        self.tol_v[k] = b2 * self.tol_v[k] + (1 - b2) * (2 * ga * dg + dg * dg)
+        # a change of this step's g moves var by lr_t*dg/(sqrt(v)+eps) over the following steps (the (1-b1)*b1^k
+        # weights of m sum to one); never by more than a few whole steps
+        sens = float(lr_t) * dg / (np.sqrt(self.v[k].numpy().astype(np.float64)) + float(self.eps))
+        self.tol_var[k] = self.tol_var[k] + np.minimum(sens, 4.0 * float(self.lr))
+
+    def step(self, grads, gabs=None):
         lr_t = np.float32(np.float32(self.lr * np.sqrt(np.float32(1) - self.b2p)) / (np.float32(1) - self.b1p))
         omb1, omb2 = np.float32(1) - self.b1, np.float32(1) - self.b2
         for k, g in grads.items():
@@ -42,6 +101,7 @@ class TF1Adam:
                 m.add_((g - m) * float(omb1))
                 v.add_((g * g - v) * float(omb2))
                 var.sub_((m * float(lr_t)) / (v.sqrt() + float(self.eps)))
+            self._envelope(k, g, (gabs or {}).get(k), lr_t)
         self.b1p = np.float32(self.b1p * self.b1)
         self.b2p = np.float32(self.b2p * self.b2)
         return float(lr_t)
@@ -63,11 +123,35 @@ class Model:
         self.opt = TF1Adam(self.params, kinds, lr)
 
     def step(self, *batch):
-        leaves = {k: v.clone().requires_grad_(True) for k, v in self.params.items()}
-        loss = self.loss(leaves, *batch)
-        grads = torch.autograd.grad(loss, list(leaves.values()), allow_unused=True)
-        self.opt.step(dict(zip(leaves.keys(), grads)))
+        nt = torch.get_num_threads()
+        torch.set_num_threads(1)  # matmul / reduction blocking independent of the host's core count
+        try:
+            leaves = {k: v.clone().requires_grad_(True) for k, v in self.params.items()}
+            w = dict(leaves)
+            w["_abs"] = {}
+            loss = self.loss(w, *batch)
+            grads = torch.autograd.grad(loss, list(leaves.values()), allow_unused=True)
+            self.opt.step(dict(zip(leaves.keys(), grads)), w["_abs"])
+        finally:
+            torch.set_num_threads(nt)
         return float(loss.detach())
+
+    def loss64(self, *batch):
+        """the same graph evaluated in float64 on the current parameters (no update): the exact value any fp32
+        implementation of the loss is an approximation of."""
+        w = {k: v.double() for k, v in self.params.items()}
+        self._f64 = True
+        try:
+            return float(self.loss(w, *batch))
+        finally:
+            self._f64 = False
+
+    def _float(self, a):  # labels / values in the dtype of the current evaluation
+        return torch.as_tensor(np.asarray(a, dtype=np.float64 if getattr(self, "_f64", False) else np.float32))
+
+    def bounds(self, k):
+        """(tol_var, tol_m, tol_v) of variable k, float64 arrays: the propagated rounding envelope."""
+        return self.opt.tol_var[k], self.opt.tol_m[k], self.opt.tol_v[k]
 
     def numpy(self, k):
         return self.params[k].numpy()
@@ -82,8 +166,8 @@ class GMF(Model):
 
     def loss(self, w, u, i, y):
         u, i = torch.as_tensor(u, dtype=torch.long), torch.as_tensor(i, dtype=torch.long)
-        y = torch.as_tensor(np.asarray(y, dtype=np.float32))
-        pu, qi = w["P"][u], w["Q"][i]
+        y = self._float(y)
+        pu, qi = gather(w, "P", u), gather(w, "Q", i)
         logits = ((pu * qi) * w["h_gmf"]).sum(1)
         return _ce_sum(y, logits) + self.reg * (_l2(pu) + _l2(qi))
 
@@ -112,8 +196,8 @@ class MLP(Model):
 
     def loss(self, w, u, i, y):
         u, i = torch.as_tensor(u, dtype=torch.long), torch.as_tensor(i, dtype=torch.long)
-        y = torch.as_tensor(np.asarray(y, dtype=np.float32))
-        pu, qi = w["P"][u], w["Q"][i]
+        y = self._float(y)
+        pu, qi = gather(w, "P", u), gather(w, "Q", i)
         logits = _tower(torch.cat([pu, qi], 1), w, self.n_layers) @ w["h_mlp"]
         return _ce_sum(y, logits) + self.reg * (_l2(pu) + _l2(qi))
 
@@ -134,8 +218,8 @@ class NeuMF(Model):
 
     def loss(self, w, u, i, y):
         u, i = torch.as_tensor(u, dtype=torch.long), torch.as_tensor(i, dtype=torch.long)
-        y = torch.as_tensor(np.asarray(y, dtype=np.float32))
-        pg, qg, pm, qm = w["P_gmf"][u], w["Q_gmf"][i], w["P_mlp"][u], w["Q_mlp"][i]
+        y = self._float(y)
+        pg, qg, pm, qm = gather(w, "P_gmf", u), gather(w, "Q_gmf", i), gather(w, "P_mlp", u), gather(w, "Q_mlp", i)
         y_mlp = _tower(torch.cat([pm, qm], 1), w, self.n_layers)
         logits = torch.cat([pg * qg, y_mlp], 1) @ w["h_neumf"]
         return _ce_sum(y, logits) + self.reg1 * (_l2(pg) + _l2(qg)) + self.reg2 * (_l2(pm) + _l2(qm))
@@ -164,11 +248,11 @@ class CML(Model):
     def loss(self, w, u, i, neg):
         u, i = torch.as_tensor(u, dtype=torch.long), torch.as_tensor(i, dtype=torch.long)
         neg = torch.as_tensor(np.asarray(neg), dtype=torch.long)
-        pu, qi, qn = w["P"][u], w["Q"][i], w["Q"][neg]  # qn [B, K, d]
+        pu, qi, qn = gather(w, "P", u), gather(w, "Q", i), gather(w, "Q", neg)  # qn [B, K, d]
         d_ui = ((pu - qi) ** 2).sum(1)
         d_un = ((pu[:, None, :] - qn) ** 2).sum(2)
         base = torch.clamp(d_ui + self.margin - d_un.min(1).values, min=0)
-        imp = ((d_ui[:, None] + self.margin - d_un) > 0).to(f32)
+        imp = ((d_ui[:, None] + self.margin - d_un) > 0).to(d_ui.dtype)
         rank = imp.mean(1) * self.item_nums / neg.shape[1]
         per_pair = base * torch.log(rank + 1).detach()
         X = torch.cat([w["Q"], w["P"]], 0)
@@ -197,14 +281,14 @@ class FM(Model):
 
     def y_pre(self, w, x_idx, x_val):
         x_idx = torch.as_tensor(np.asarray(x_idx), dtype=torch.long)
-        x_val = torch.as_tensor(np.asarray(x_val, dtype=np.float32))
-        wi_e, v_e = w["wi"][x_idx], w["vif"][x_idx]  # [B,F], [B,F,d]
+        x_val = self._float(x_val)
+        wi_e, v_e = gather(w, "wi", x_idx), gather(w, "vif", x_idx)  # [B,F], [B,F,d]
         sq_sum = ((x_val[:, :, None] * v_e).sum(1)) ** 2
         sum_sq = ((x_val ** 2)[:, :, None] * (v_e ** 2)).sum(1)
         return w["w0"] + wi_e.sum(1) + 0.5 * (sq_sum - sum_sq).sum(1)
 
     def loss(self, w, x_idx, x_val, y):
-        y = torch.as_tensor(np.asarray(y, dtype=np.float32))
+        y = self._float(y)
         yp = self.y_pre(w, x_idx, x_val)
         self.last_y_pre = yp.detach().numpy()
         return ((y - yp) ** 2).sum() + self.reg * (_l2(w["wi"]) + _l2(w["vif"]))

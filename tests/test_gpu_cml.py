@@ -9,6 +9,7 @@ import oracle
 from oracle import models_torch as MT
 from cleverrec_amd import runtime
 from cleverrec_amd.data import RankingData
+from _adam_close import assert_adam_close
 
 pytestmark = pytest.mark.gpu
 
@@ -33,8 +34,8 @@ def test_cml_steps_match_oracle(sess, d, K):
     loss = st.train_epoch(sess.to_dev(u), sess.to_dev(i), sess.to_dev(neg), B).cpu().numpy()
     ol = [om.step(u[b * B:(b + 1) * B], i[b * B:(b + 1) * B], neg[b * B:(b + 1) * B]) for b in range(len(loss))]
     np.testing.assert_allclose(loss, ol, rtol=2e-5)
-    np.testing.assert_allclose(st.P.cpu().numpy(), om.numpy("P"), rtol=0, atol=1e-5)
-    np.testing.assert_allclose(st.Q.cpu().numpy(), om.numpy("Q"), rtol=0, atol=1e-5)
+    assert_adam_close(om, "P", st.P, st.mP, st.vP)
+    assert_adam_close(om, "Q", st.Q, st.mQ, st.vQ)
 
 
 def test_cml_class_surface_and_distance_ranking(sess, tmp_path):

@@ -6,6 +6,7 @@ import pytest
 from oracle import models_torch as MT
 from cleverrec_amd import runtime
 from cleverrec_amd.utils.metrics import cal_rmse_mae
+from _adam_close import assert_adam_close
 
 pytestmark = pytest.mark.gpu
 
@@ -37,7 +38,7 @@ def test_fm_steps_match_oracle(sess, d, F):
     np.testing.assert_allclose(loss.cpu().numpy(), ol, rtol=1e-5)
     np.testing.assert_allclose(y_pre.cpu().numpy(), np.concatenate(oy), rtol=1e-5, atol=1e-6)
     for dev, name in ((st.w0, "w0"), (st.wi, "wi"), (st.vif, "vif")):
-        np.testing.assert_allclose(dev.cpu().numpy().reshape(-1), om.numpy(name).reshape(-1), rtol=0, atol=1e-5, err_msg=name)
+        assert_adam_close(om, name, dev, *st.slots[name])
     # prediction + RMSE/MAE against the reference-shaped Python loop
     yp = st.predict(sess.to_dev(x_idx), sess.to_dev(x_val))
     rm, ma = runtime.rmse_mae(sess, sess.to_dev(y), yp)

@@ -1,6 +1,8 @@
 """GMF / MLP / NeuMF training steps (HIP, through the C ABI) against the torch-autograd restatement of the
 reference graphs with TF1 Adam semantics (oracle/models_torch.py).  Needs an MI355X.
-fp32; losses rtol 1e-5, parameters |delta| <= 1e-5 = 1% of one Adam step of 1e-3 (different fp32 summation order; Adam divides by sqrt(v))."""
+fp32; losses rtol 1e-5; variables and Adam slots within the propagated fp32 rounding envelope of tests/_adam_close.py
+(tight wherever a gradient is well conditioned; a flat atol on post-Adam weights is a cliff edge where a row's
+gradient sum cancels)."""
 import numpy as np
 import pytest
 import torch
@@ -8,6 +10,7 @@ import torch
 import oracle
 from oracle import models_torch as MT
 from cleverrec_amd import runtime
+from _adam_close import assert_adam_close
 
 pytestmark = pytest.mark.gpu
 
@@ -38,9 +41,19 @@ def _tower(g, L0, n_layers):
     return Ws, bs, w
 
 
-def _compare(st, om, names, atol=1e-5):  # 1% of one Adam step: where a gradient sum cancels to ~0, g/sqrt(v) amplifies fp32 order noise
+def _slots(st, dev):
+    """Adam slots (m, v) of a device variable of an NcfState: a table, or a named view into the flat small block."""
+    for k, t in st.t.items():
+        if t is dev:
+            return st.slots[k]
+    off = (dev.data_ptr() - st.small.data_ptr()) // 4
+    return st.small_m[off:off + dev.numel()], st.small_v[off:off + dev.numel()]
+
+
+def _compare(st, om, names):
     for dev, ref in names:
-        np.testing.assert_allclose(dev.cpu().numpy().reshape(-1), om.numpy(ref).reshape(-1), rtol=0, atol=atol, err_msg=ref)
+        m, v = _slots(st, dev)
+        assert_adam_close(om, ref, dev, m, v)
 
 
 @pytest.mark.parametrize("d", [8, 32, 64])

@@ -45,3 +45,31 @@ def test_dense_formula_is_apply_adam():
         v = v + (g * g - v) * 0.001
         w = w - (m * 1e-2 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)) / (np.sqrt(v) + 1e-8)
     np.testing.assert_allclose(opt.p["w"].numpy(), w, rtol=2e-6)
+
+
+def test_envelope_covers_a_reordered_batch():
+    """Model.bounds (the propagated fp32 rounding envelope the GPU tests compare under) must cover what a mere
+    change of summation order does: the NeuMF C3-shaped step on a batch and on a permutation of the same batch.
+    Also pins that the oracle is deterministic (same batch twice -> bit-identical state)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _adam_close import assert_adam_close
+    g = np.random.Generator(np.random.PCG64(9))
+    r = lambda *shape, scale=0.1: (g.standard_normal(shape) * scale).astype(np.float32)
+    U, I, B, d = 400, 300, 6144, 64
+    Pg, Qg, Pm, Qm = r(U, d), r(I, d), r(U, 64), r(I, 64)
+    Ws, bs = [r(128, 64, scale=0.2), r(64, 32, scale=0.2), r(32, 16, scale=0.2)], [r(64, scale=0.05), r(32, scale=0.05), r(16, scale=0.05)]
+    h = r(d + 16, scale=0.3)
+    mk = lambda: MT.NeuMF(Pg, Qg, Pm, Qm, Ws, bs, h, lr=1e-3, reg1=1e-2, reg2=1e-3)
+    a, b, c = mk(), mk(), mk()
+    for k in range(3):
+        u, i, y = g.integers(0, U, B), g.integers(0, I, B), (g.random(B) < 0.2).astype(np.float32)
+        perm = g.permutation(B)
+        la, lb, lc = a.step(u, i, y), b.step(u[perm], i[perm], y[perm]), c.step(u, i, y)
+        assert la == lc and abs(la - lb) <= 1e-6 * abs(la)
+    rep = []
+    for name in a.params:
+        assert np.array_equal(a.numpy(name), c.numpy(name)), name  # deterministic above torch's 32768-element atomics threshold
+        assert_adam_close(a, name, b.params[name], b.opt.m[name], b.opt.v[name], report=rep)
+    assert max(x[2] for x in rep) < 0.5  # a reordering alone uses less than half of the envelope
