@@ -31,6 +31,12 @@ class Adam(C.Structure):
                 ("adam_mode", C.c_int32), ("beta1_power", C.c_float), ("beta2_power", C.c_float), ("step", C.c_int64)]
 
 
+class ShardStats(C.Structure):
+    _fields_ = [("bytes_ids_sent", C.c_int64), ("bytes_rows_sent", C.c_int64), ("bytes_grads_sent", C.c_int64),
+                ("rows_requested", C.c_int64), ("rows_served", C.c_int64), ("max_rows_served_per_batch", C.c_int64),
+                ("steps", C.c_int64)]
+
+
 class Param(C.Structure):
     _fields_ = [("var", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("rows", C.c_int64), ("cols", C.c_int32)]
 
@@ -57,6 +63,7 @@ _SIGNATURES = {
     "crec_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "crec_ctx_destroy": (None, [_vp]),
     "crec_last_error": (C.c_char_p, [_vp]),
+    "crec_ctx_set_option": (C.c_int, [_vp, C.c_char_p, _i64]),
     "crec_profile_enable": (C.c_int, [_vp, C.c_int]),
     "crec_profile_read": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(_i64)]),
     "crec_rng_seed": (C.c_int, [_vp, C.c_uint32]),
@@ -83,6 +90,9 @@ _SIGNATURES = {
     "crec_comm_unique_id": (C.c_int, [_vp, _vp]),
     "crec_comm_init": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
     "crec_comm_destroy": (C.c_int, [_vp]),
+    "crec_comm_init_local": (C.c_int, [C.POINTER(_vp), C.c_int]),
+    "crec_bpr_train_epoch_sharded": (C.c_int, [_vp, C.POINTER(BprTables), _i64, C.POINTER(Adam), _vp, _vp, _vp, _i64, _i32, _vp,
+                                               C.POINTER(ShardStats), _vp]),
     "crec_eval_topk": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "crec_rank_metrics": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
@@ -138,9 +148,14 @@ class Context:
         if rc != OK:
             raise CrecError(rc, self.lib.crec_last_error(self.h).decode())
 
+    def set_option(self, name, value):
+        """crec_ctx_set_option: tuning / test knobs ("ch", "wide", "wide_round", "eval_shape", "eval_no_bitmap")."""
+        self.check(self.lib.crec_ctx_set_option(self.h, name.encode(), int(value)))
+
     # ---- measurement ---------------------------------------------------------------------------
     KERNELS = ("bpr_index_batches", "bpr_step_fused", "bpr_user_side", "bpr_item_side", "bpr_reduce_loss", "eval_sweep",
-               "eval_merge", "rank_metrics", "bpr_steps_persistent", "bpr_adam_dense", "rows_index_batches", "rows_apply", "small_adam_dense", "ncf_tile", "fm_instances", "cml_instances", "ncf_pair_logits")
+               "eval_merge", "rank_metrics", "unused8", "bpr_adam_dense", "rows_index_batches", "rows_apply", "small_adam_dense", "ncf_tile", "fm_instances", "cml_instances", "ncf_pair_logits",
+               "shard_plan_batches", "shard_serve_rows", "shard_owner_apply")
 
     def profile(self, on):
         self.check(self.lib.crec_profile_enable(self.h, int(bool(on))))

@@ -18,6 +18,7 @@ COMMON = ["-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 # element-wise semantics; makes the Adam arithmetic bit-reproducible against the oracle).
 SOURCES = {
     "crec_ctx.cpp": [],
+    "crec_comm.cpp": ["-pthread"],
     "crec_sampler.cpp": ["-fno-math-errno", "-pthread"],
     "gpu_sampler.hip": [],
     "bpr_train.hip": ["-ffp-contract=off"],

@@ -39,6 +39,7 @@
 // bit-reproducible.
 #include "crec_internal.h"
 #include "block_sort.h"
+#include "crec_comm.h"
 
 #include <rccl/rccl.h>
 
@@ -1017,7 +1018,8 @@ __device__ __forceinline__ void chunk_wave(const Tables &src, int d, int4 item, 
     // the finishing wave's inputs are fetched by every chunk wave up front: their latency hides behind the
     // chunk's own gathers instead of extending the row's critical path after the last ticket
     const int4 rec = f.hrows[hidx];
-    float4 m = on ? ld4((user ? src.mP : src.mQ) + ro) : zero, v = on ? ld4((user ? src.vP : src.vQ) + ro) : zero;
+    const bool slots = on && (user || !h.dQ); // item rows that only emit their gradient row (h.dQ) have no slots here
+    float4 m = slots ? ld4((user ? src.mP : src.mQ) + ro) : zero, v = slots ? ld4((user ? src.vP : src.vQ) + ro) : zero;
     float4 grad;
     if (MODE == 2) {
         // lazy item side: an occurrence is one contribution row to read and add, nothing to compute first, so the
@@ -1240,110 +1242,6 @@ __global__ __launch_bounds__(CREC_FUSED_BLOCK) void bpr_step_fused(Tables src, T
 }
 
 // ------------------------------------------------------------------------------------
-// tf1 mode, many steps per launch (an experiment kept behind CREC_PERSISTENT=1, off by default).
-// A dispatch costs ~4 us begin-to-end before any wave does work (an empty kernel measures the same with 1 or 4876
-// workgroups, tools/micro/empty_launch.hip) and consecutive dependent dispatches sit another ~3.6 us apart, against
-// ~5 us of work in a step at ml-1m shape.  The idea: run the chunk's steps inside ONE cooperative launch -- a
-// persistent grid walks the wave ids of step s, meets at a device-wide barrier, and goes on to step s+1 with the
-// buffer sets swapped.  The barrier has to re-create a kernel boundary's visibility by hand: every workgroup
-// releases its writes (they may sit in its XCD's L2) before it arrives and acquires after it leaves.
-// RESULT (tools/micro/grid_barrier.hip): the counter part of such a barrier costs 2.4 us (256 workgroups) to 5.6 us
-// (610) with a two-level tree -- a flat counter serialises: 11 us for 610 -- a release + acquire fence pair on every
-// workgroup (buffer_wbl2 / buffer_inv) adds 7-17 us even with nothing dirty, an acquire alone 1.7-2 us.  With
-// write-through table stores, the tree and an acquire-only exit the step takes 19-20 us against 13 us for a launch
-// per step: a kernel boundary (7.6 us) is cheaper than this barrier plus the slower write-through stores.  Results are identical
-// (the parity tests run both ways).
-// ------------------------------------------------------------------------------------
-struct StepsArgs {
-    Tables t0, t1;   // step s reads (s & 1 ? t1 : t0) and writes the other
-    int d;
-    int64_t U, I;
-    IndexWs w;       // the chunk's index (device pointers)
-    float *partial;
-    int32_t *tickets;
-    float *loss_ws;  // [n_steps][loss_stride]: x_b of every triple, then the row terms
-    int64_t loss_stride;
-    const float *lr_t; // [n_steps]
-    Hyper h;           // lr_t is taken from the table
-    int32_t n_steps;
-    unsigned *bar;     // [0] arrivals (monotonic), [1] set when a wait timed out
-};
-
-// Device-wide barrier of a cooperative launch, epoch `it` (1, 2, ...).  Two-level arrival tree (a single counter
-// serialises: 11 us for 610 workgroups against 4-5 us), one release word everybody polls.  bar: [0] root counter,
-// [1] time-out flag, [16] release word, [32 + 16 g] counter of group g (FAN consecutive workgroups) -- 64 B apart.
-// Visibility: the tables are written with write-through (sc1) stores and every other cross-step buffer with
-// agent-scope accesses, so arriving only needs the wave's stores to have completed; leaving invalidates this CU's
-// L1 and the XCD's L2 copies of lines other XCDs rewrote (acquire fence).  A full release + acquire fence pair on
-// every workgroup would cost 7-17 us (tools/micro/grid_barrier.hip).
-constexpr unsigned BAR_FAN = 32;
-__device__ __forceinline__ bool grid_barrier(unsigned *bar, unsigned it)
-{
-    __shared__ int failed;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's write-through stores have landed
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned nb = gridDim.x, b = blockIdx.x, g = b / BAR_FAN, ng = (nb + BAR_FAN - 1) / BAR_FAN;
-        const unsigned gsz = (g + 1) * BAR_FAN <= nb ? BAR_FAN : nb - g * BAR_FAN;
-        const unsigned t = __hip_atomic_fetch_add(bar + 32 + 16 * g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t == it * gsz - 1) { // last of its group
-            const unsigned r = __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (r == it * ng - 1)
-                __hip_atomic_store(bar + 16, it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(); // 100 MHz
-        int bad = 0;
-        while (__hip_atomic_load(bar + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < it) {
-            __builtin_amdgcn_s_sleep(1);
-            if (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ||
-                __builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { // 2 s: give up instead of hanging the GPU
-                __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                bad = 1;
-                break;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        failed = bad;
-    }
-    __syncthreads();
-    return failed == 0;
-}
-
-template <int LPR, bool FULL> __global__ __launch_bounds__(256) void bpr_steps_persistent(StepsArgs a)
-{
-    constexpr int R = Geo<LPR, ROWS_PER_WAVE>::R;
-    const int64_t grid_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
-    const int64_t my_wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t WU = (a.U + R - 1) / R, WI = (a.I + R - 1) / R;
-    const IndexWs &w = a.w;
-    for (int s = 0; s < a.n_steps; ++s) {
-        const Tables &src = (s & 1) ? a.t1 : a.t0, &dst = (s & 1) ? a.t0 : a.t1;
-        HeavyArgs hv;
-        hv.hn = w.hn + (int64_t)s * 4;
-        hv.u_hitems = w.u_hitems + (int64_t)s * w.HIu;
-        hv.q_hitems = w.q_hitems + (int64_t)s * w.HIq;
-        hv.u_hrows = w.u_hrows + (int64_t)s * w.HRu;
-        hv.q_hrows = w.q_hrows + (int64_t)s * w.HRq;
-        hv.partial = a.partial;
-        hv.tickets = a.tickets;
-        hv.HRu_max = (int)w.HRu;
-        hv.HRu = __builtin_amdgcn_readfirstlane(hv.hn[0]);
-        hv.HIu = __builtin_amdgcn_readfirstlane(hv.hn[1]);
-        hv.HRq = __builtin_amdgcn_readfirstlane(hv.hn[2]);
-        hv.HIq = __builtin_amdgcn_readfirstlane(hv.hn[3]);
-        Hyper h = a.h;
-        h.lr_t = a.lr_t[s];
-        float *xb = a.loss_ws + (int64_t)s * a.loss_stride, *rowterm = xb + w.B;
-        const int64_t total = hv.HIu + hv.HIq + WU + WI;
-        for (int64_t wid = my_wave; wid < total; wid += grid_waves)
-            fused_wave<LPR, FULL, true>(wid, src, dst, a.d, a.U, a.I, w.u_rowseg + (int64_t)s * w.U, w.u_occ + (int64_t)s * w.B,
-                                  w.q_rowseg + (int64_t)s * w.I, w.q_occ + (int64_t)s * 2 * w.B, hv, xb, rowterm, h);
-        if (s + 1 < a.n_steps && !grid_barrier(a.bar, (unsigned)(s + 1)))
-            return;
-    }
-}
-
-// ------------------------------------------------------------------------------------
 // lazy mode: touched rows only, in place, two launches (MODE 0 users, MODE 2 items)
 // ------------------------------------------------------------------------------------
 template <int LPR, int MODE, bool FULL>
@@ -1429,17 +1327,30 @@ __global__ __launch_bounds__(256) void bpr_reduce_loss(const float *__restrict__
     const int nb = (int)((n_total - t0) < B ? (n_total - t0) : B);
     const float *xb = ws + blockIdx.x * stride, *rowterm = xb + B;
     double s = 0.0, l2 = 0.0;
-    for (int k = threadIdx.x; k < nb; k += 256)
-        s += (double)tf_softplus(-xb[k]);
+    // a thread's terms are added in ascending k; the loads of eight of them are issued together (a load per add was a
+    // chain of ~60 dependent round trips: 24 us for a chunk of 20 batches)
+    const auto sum_f = [](const float *p, int64_t n, auto f, double acc) {
+        int64_t k = threadIdx.x;
+        for (; k + 7 * 256 < n; k += 8 * 256) {
+            float t[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                t[e] = p[k + e * 256];
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                acc += (double)f(t[e]);
+        }
+        for (; k < n; k += 256)
+            acc += (double)f(p[k]);
+        return acc;
+    };
+    const auto ident = [](float x) { return x; };
+    s = sum_f(xb, nb, [](float x) { return tf_softplus(-x); }, 0.0);
     if (n_dense > 0) {
-        for (int64_t k = threadIdx.x; k < n_dense; k += 256)
-            l2 += (double)rowterm[k];
+        l2 = sum_f(rowterm, n_dense, ident, 0.0);
     } else {
-        const int nu = n_u[blockIdx.x], nq = n_q[blockIdx.x];
-        for (int k = threadIdx.x; k < nu; k += 256)
-            l2 += (double)rowterm[k];
-        for (int k = threadIdx.x; k < nq; k += 256)
-            l2 += (double)rowterm[B + k];
+        l2 = sum_f(rowterm, n_u[blockIdx.x], ident, 0.0);
+        l2 = sum_f(rowterm + B, n_q[blockIdx.x], ident, l2);
     }
     part[threadIdx.x] = s + (double)reg * l2;
     __syncthreads();
@@ -1451,6 +1362,8 @@ __global__ __launch_bounds__(256) void bpr_reduce_loss(const float *__restrict__
     if (threadIdx.x == 0)
         loss_per_batch[blockIdx.x] = (float)part[0];
 }
+
+#include "shard_kernels.h"
 
 // ------------------------------------------------------------------------------------
 // host side
@@ -1541,64 +1454,6 @@ template <int LPR, bool FULL> void launch_lazy(const StepArgs &a, const IndexWs 
 
 using StepFn = void (*)(const StepArgs &, const IndexWs &, int64_t, const int32_t *);
 
-// all steps of a chunk in one cooperative launch (bpr_steps_persistent); returns a hipError_t
-template <int LPR, bool FULL> int launch_persistent(crec_ctx *ctx, StepsArgs &sa, hipStream_t st)
-{
-    constexpr int R = Geo<LPR, ROWS_PER_WAVE>::R;
-    static int per_cu = 0; // resident workgroups per CU of this instantiation
-    if (per_cu == 0) {
-        int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)bpr_steps_persistent<LPR, FULL>, 256, 0) !=
-                hipSuccess ||
-            nb < 1)
-            return (int)hipErrorLaunchFailure;
-        per_cu = nb;
-    }
-    const int64_t cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
-    const int64_t want = crec_ceil_div(sa.w.HIu + sa.w.HIq + crec_ceil_div(sa.U, R) + crec_ceil_div(sa.I, R), 4);
-    int64_t grid = (int64_t)per_cu * cus;
-    grid = grid > want ? want : grid;
-    if (const char *g = getenv("CREC_PERSIST_GRID")) // tuning knob: fewer workgroups = cheaper barrier, less parallel slack
-        grid = atoi(g) > 0 && atoi(g) < grid ? atoi(g) : grid;
-    void *params[] = {(void *)&sa};
-    if (ctx->prof.on) { // a launch of many steps: a plain event bracket is accurate enough (cooperative launches
-        crec_prof_begin(ctx, CREC_K_FINISH, st); // cannot carry their own events); class 8 = bpr_steps_persistent
-        hipEvent_t ea, eb;
-        (void)crec_prof_events(ctx, &ea, &eb);
-        (void)hipEventRecord(ea, st);
-        const hipError_t e = hipLaunchCooperativeKernel((const void *)bpr_steps_persistent<LPR, FULL>, dim3((unsigned)grid),
-                                                        dim3(256), params, 0, st);
-        (void)hipEventRecord(eb, st);
-        crec_prof_end(ctx, st);
-        return (int)e;
-    }
-    return (int)hipLaunchCooperativeKernel((const void *)bpr_steps_persistent<LPR, FULL>, dim3((unsigned)grid), dim3(256), params,
-                                           0, st);
-}
-
-using PersistFn = int (*)(crec_ctx *, StepsArgs &, hipStream_t);
-PersistFn pick_persistent(int d)
-{
-    int lpr = 1;
-    while (lpr * 4 < d)
-        lpr <<= 1;
-    const bool full = d == 4 * lpr;
-#define CREC_PICK(L) \
-    case L:          \
-        return full ? launch_persistent<L, true> : launch_persistent<L, false>;
-    switch (lpr) {
-        CREC_PICK(1)
-        CREC_PICK(2)
-        CREC_PICK(4)
-        CREC_PICK(8)
-        CREC_PICK(16)
-        CREC_PICK(32)
-        CREC_PICK(64)
-    }
-#undef CREC_PICK
-    return nullptr;
-}
-
 StepFn pick_step(int d, bool dense)
 {
     int lpr = 1;
@@ -1657,15 +1512,11 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
     // occurrences per heavy-row chunk: short chunks shorten the longest wave, every chunk wave pays a ticket on its
     // row's counter.  Item side of S-big: CH 8 -> 12.4 us, 16 -> 11.4, 32 -> 12.0 (with fence-published partials the
     // sweep read 16 -> 16.3, 32 -> 13.7, 64 -> 15.3).  tf1 mode at ml-1m shape: 32 -> 14.4 us/step, 64 -> 13.2.
-    static const int ch_env = getenv("CREC_CH") ? atoi(getenv("CREC_CH")) : 0;
-    const int CH = ch_env > 0 ? ch_env : (dense ? 64 : 16);
-    CREC_REQUIRE(ctx, CH >= 1 && CH <= 255, "CREC_CH: 1..255");
+    const int CH = ctx->knob_ch > 0 ? ctx->knob_ch : (dense ? 64 : 16);
+    CREC_REQUIRE(ctx, CH >= 1 && CH <= 255, "option ch: 1..255");
 
-    // wide groups (tf1 mode, launch per step): the rows of a row wave that hold more than `wide_total` occurrences
-    // together go to a whole workgroup.  CREC_WIDE=0 turns it off, any other value is the threshold.
-    const char *persist_env = getenv("CREC_PERSISTENT");
-    const bool persistent = dense && !dp && persist_env && atoi(persist_env) != 0;
-    const int wide_env = getenv("CREC_WIDE") ? atoi(getenv("CREC_WIDE")) : -1; // read per call: tests switch it
+    // wide groups (tf1 mode): the rows of a row wave that hold more than `wide_total` occurrences together go to a
+    // whole workgroup.  ctx->knob_wide: 0 turns it off, any other value >= 0 is the threshold (crec_ctx_set_option).
     int wide_rows = 1;
     {
         int lpr = 1;
@@ -1673,7 +1524,7 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
             lpr <<= 1;
         wide_rows = 64 / lpr < ROWS_PER_WAVE ? 64 / lpr : ROWS_PER_WAVE;
     }
-    const int wide_total = (!dense || persistent || wide_rows < 2) ? 0 : (wide_env >= 0 ? wide_env : 16);
+    const int wide_total = (!dense || wide_rows < 2) ? 0 : (ctx->knob_wide >= 0 ? ctx->knob_wide : 16);
 
     // chunk the epoch so the inverted indices of a chunk stay under ~1 GiB
     const size_t per_batch = layout_index(nullptr, 1, B, t->U, t->I, dense, CH, wide_rows, wide_total).bytes;
@@ -1695,7 +1546,7 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
 
     StepArgs a{};
     a.ctx = ctx;
-    a.wide_round = getenv("CREC_WIDE_ROUND") ? atoi(getenv("CREC_WIDE_ROUND")) : 0;
+    a.wide_round = ctx->knob_wide_round;
     a.cur = Tables{t->P, t->mP, t->vP, t->Q, t->mQ, t->vQ};
     a.d = t->d;
     a.U = t->U;
@@ -1731,9 +1582,6 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
     CREC_HIP(ctx, hipFuncSetAttribute((const void *)bpr_index_batches, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds));
 
-    // tf1 single-GPU, opt-in (CREC_PERSISTENT=1): a chunk's steps inside one cooperative launch.  Measured no faster
-    // than a launch per step on MI355X (19-20 vs 13 us per step): see the note at bpr_steps_persistent.
-    const PersistFn persist = pick_persistent(t->d);
     bool in_shadow = false; // tf1: which buffer set holds the current tables
     for (int64_t b0 = 0; b0 < nb; b0 += chunk) {
         const int64_t nbc = (nb - b0) < chunk ? (nb - b0) : chunk;
@@ -1743,58 +1591,9 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
         CREC_KLAUNCH(ctx, bpr_index_batches, dim3((unsigned)(2 * nbc)), dim3(PREP_THREADS), lds, st, u + t0, i + t0,
                            j + t0, n_chunk, B, cap, w);
         crec_prof_end(ctx, st);
-        if (persistent) {
-            // the chunk's steps in one cooperative launch: per-step lr_t from a table, the buffer sets alternate inside
-            std::vector<float> lr((size_t)nbc);
-            for (int64_t b = 0; b < nbc; ++b) { // lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t), fp32 running powers (TF1)
-                lr[(size_t)b] = (opt->lr * sqrtf(1.0f - opt->beta2_power)) / (1.0f - opt->beta1_power);
-                opt->beta1_power = opt->beta1_power * opt->beta1;
-                opt->beta2_power = opt->beta2_power * opt->beta2;
-                opt->step += 1;
-            }
-            CREC_REQUIRE(ctx, bytesP < ((size_t)1 << 31) && bytesQ < ((size_t)1 << 31), "persistent launch: tables under 2 GiB each");
-            if (int rc = crec_reserve(ctx, &ctx->lr_table, sizeof(float) * (size_t)nbc + 64 + 8192))
-                return rc;
-            unsigned *bar = (unsigned *)((char *)ctx->lr_table.ptr + sizeof(float) * (size_t)nbc / 16 * 16 + 16);
-            CREC_HIP(ctx, hipMemcpyAsync(ctx->lr_table.ptr, lr.data(), sizeof(float) * (size_t)nbc, hipMemcpyHostToDevice, st));
-            CREC_HIP(ctx, hipMemsetAsync(bar, 0, 8192, st));
-            StepsArgs sa{};
-            sa.t0 = a.cur;
-            sa.t1 = a.other;
-            sa.d = a.d;
-            sa.U = a.U;
-            sa.I = a.I;
-            sa.w = w;
-            sa.partial = a.partial;
-            sa.tickets = a.tickets;
-            sa.loss_ws = (float *)ctx->loss_ws.ptr;
-            sa.loss_stride = loss_stride;
-            sa.lr_t = (const float *)ctx->lr_table.ptr;
-            sa.h.beta1 = opt->beta1;
-            sa.h.beta2 = opt->beta2;
-            sa.h.eps = opt->eps;
-            sa.h.reg = opt->reg;
-            sa.h.dQ = nullptr;
-            sa.n_steps = (int32_t)nbc;
-            sa.bar = bar;
-            const int e = persist(ctx, sa, st);
-            if (e != (int)hipSuccess)
-                return crec_fail(ctx, CREC_EHIP, "cooperative launch of bpr_steps_persistent failed: %s",
-                                 hipGetErrorString((hipError_t)e));
-            if (nbc & 1) {
-                Tables tmp = a.cur;
-                a.cur = a.other;
-                a.other = tmp;
-                in_shadow = !in_shadow;
-            }
-            unsigned flags[2] = {0, 0};
-            CREC_HIP(ctx, hipMemcpyAsync(flags, bar, sizeof flags, hipMemcpyDeviceToHost, st));
-            CREC_HIP(ctx, hipStreamSynchronize(st));
-            CREC_REQUIRE(ctx, flags[1] == 0, "bpr_steps_persistent: a grid barrier timed out (the tables are unusable)");
-        }
         // the chunk's counts come back into page-locked memory: a pageable destination is staged and costs tens of
         // microseconds per copy, once per epoch -- a tenth of an ml-100k epoch of 45 steps
-        const size_t n_hn = (size_t)(persistent ? 0 : nbc) * 4, n_nw = (size_t)(persistent ? 0 : nbc) * 2;
+        const size_t n_hn = (size_t)nbc * 4, n_nw = (size_t)nbc * 2;
         if (n_hn + n_nw > ctx->pinned_ints) {
             if (ctx->pinned)
                 CREC_HIP(ctx, hipHostFree(ctx->pinned));
@@ -1805,19 +1604,17 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
         }
         const int32_t *hn = ctx->pinned, *nwide = ctx->pinned + n_hn;
         a.nwide = nwide;
-        if (!persistent) {
-            CREC_HIP(ctx, hipMemcpyAsync(ctx->pinned, w.hn, sizeof(int32_t) * n_hn, hipMemcpyDeviceToHost, st));
-            CREC_HIP(ctx, hipMemcpyAsync(ctx->pinned + n_hn, w.nwide, sizeof(int32_t) * n_nw, hipMemcpyDeviceToHost, st));
-            CREC_HIP(ctx, hipStreamSynchronize(st));
-        }
+        CREC_HIP(ctx, hipMemcpyAsync(ctx->pinned, w.hn, sizeof(int32_t) * n_hn, hipMemcpyDeviceToHost, st));
+        CREC_HIP(ctx, hipMemcpyAsync(ctx->pinned + n_hn, w.nwide, sizeof(int32_t) * n_nw, hipMemcpyDeviceToHost, st));
+        CREC_HIP(ctx, hipStreamSynchronize(st));
         a.pad_wide = a.pad_chunks_u = a.pad_chunks_q = 0;
-        for (int64_t b = 0; b < (persistent ? 0 : nbc); ++b) {
+        for (int64_t b = 0; b < nbc; ++b) {
             const int nw = nwide[(size_t)b * 2] + nwide[(size_t)b * 2 + 1];
             a.pad_wide = nw > a.pad_wide ? nw : a.pad_wide;
             a.pad_chunks_u = hn[(size_t)b * 4 + 1] > a.pad_chunks_u ? hn[(size_t)b * 4 + 1] : a.pad_chunks_u;
             a.pad_chunks_q = hn[(size_t)b * 4 + 3] > a.pad_chunks_q ? hn[(size_t)b * 4 + 3] : a.pad_chunks_q;
         }
-        for (int64_t b = 0; b < (persistent ? 0 : nbc); ++b) {
+        for (int64_t b = 0; b < nbc; ++b) {
             // lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t) with fp32 running powers (TF1 _prepare/_finish)
             a.h.lr_t = (opt->lr * sqrtf(1.0f - opt->beta2_power)) / (1.0f - opt->beta1_power);
             a.h.beta1 = opt->beta1;
@@ -1876,6 +1673,337 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
     }
     return CREC_OK;
 }
+
+// ------------------------------------------------------------------------------------
+// Row-sharded epoch (include/crec.h "row-sharded training"): users range-sharded, items dealt round-robin, lazy Adam.
+// Per chunk of batches: plan (compact ids + request lists) -> counts to the host -> all-to-all-v of the request
+// lists (ONE per chunk) -> owner-side index -> the usual occurrence index over the compact ids.
+// Per batch: serve rows -> all-to-all-v (rows forward) -> bpr_side_lazy<user> (Adam on the local user rows),
+// bpr_side_lazy<item> emitting gradient rows instead of Adam -> all-to-all-v (gradient rows back) -> owner apply.
+// ------------------------------------------------------------------------------------
+struct ShardTake {
+    size_t off = 0;
+    char *base = nullptr;
+    template <typename T> T *take(size_t n)
+    {
+        T *p = base ? (T *)(base + off) : nullptr;
+        off = align_up(off + sizeof(T) * n, 256);
+        return p;
+    }
+};
+
+int sharded_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, int64_t I_global, crec_adam *opt, const int32_t *u,
+                       const int32_t *i, const int32_t *j, int64_t N, int32_t B, float *loss_per_batch,
+                       crec_shard_stats *stats, void *stream)
+{
+    if (!ctx)
+        return CREC_EINVAL;
+    CREC_REQUIRE(ctx, ctx->device >= 0, "host-only ctx: no device bound");
+    CREC_REQUIRE(ctx, t && opt, "null argument");
+    CREC_REQUIRE(ctx, N >= 1 && u && i && j && loss_per_batch, "the sharded epoch is collective: every rank passes N >= 1 triples");
+    CREC_REQUIRE(ctx, t->P && t->Q && t->mP && t->vP && t->mQ && t->vQ, "null table pointer");
+    CREC_REQUIRE(ctx, t->d >= 4 && t->d <= 256 && t->d % 4 == 0, "embed_size %d: need a multiple of 4 in [4, 256]", t->d);
+    CREC_REQUIRE(ctx, B >= 1 && B <= MAX_B, "batch_size %d: this build indexes batches of at most %d in LDS", B, MAX_B);
+    CREC_REQUIRE(ctx, opt->adam_mode == CREC_ADAM_LAZY, "the row-sharded step is built for adam_mode lazy");
+    crec_xch *x = crec_xch_of(ctx);
+    const int G = x->world, me = x->rank;
+    CREC_REQUIRE(ctx, G >= 1 && G <= 64, "world size 1..64");
+    const int64_t S = crec_ceil_div(I_global, G); // rows per shard; item g = local row g / G of rank g % G
+    CREC_REQUIRE(ctx, I_global >= 1 && (int64_t)G * S < ((int64_t)1 << 31), "item count");
+    CREC_REQUIRE(ctx, t->I >= S, "Q shard holds %lld rows, needs ceil(%lld / %d) = %lld", (long long)t->I, (long long)I_global, G, (long long)S);
+    CREC_REQUIRE(ctx, t->U >= 1 && t->U < ((int64_t)1 << 31), "table rows");
+    const float *tabs[] = {t->P, t->Q, t->mP, t->vP, t->mQ, t->vQ};
+    for (const float *p : tabs)
+        CREC_REQUIRE(ctx, ((uintptr_t)p & 15) == 0, "table base not 16-byte aligned");
+    CREC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int d = t->d;
+    int lpr = 1;
+    while (lpr * 4 < d)
+        lpr <<= 1;
+    const int64_t nb = crec_ceil_div(N, B);
+    const int64_t IC = 2 * (int64_t)B; // compact item id space of a batch
+    StepFn step = pick_step(d, false);
+    const int CH = ctx->knob_ch > 0 ? ctx->knob_ch : 16;
+    CREC_REQUIRE(ctx, CH >= 1 && CH <= 255, "option ch: 1..255");
+
+    const size_t per_batch = layout_index(nullptr, 1, B, t->U, IC, false, CH).bytes;
+    int64_t chunk = (int64_t)((size_t)1 << 30) / (int64_t)per_batch;
+    chunk = chunk < 1 ? 1 : (chunk > 1024 ? 1024 : chunk);
+    chunk = chunk > nb ? nb : chunk;
+    if (int rc = crec_reserve(ctx, &ctx->idx_ws, layout_index(nullptr, chunk, B, t->U, IC, false, CH).bytes))
+        return rc;
+    const int64_t loss_stride = B + 3 * (int64_t)B;
+    if (int rc = crec_reserve(ctx, &ctx->loss_ws, sizeof(float) * (size_t)chunk * loss_stride))
+        return rc;
+    const IndexWs w0 = layout_index(nullptr, 1, B, t->U, IC, false, CH);
+    const size_t part_bytes = align_up(sizeof(float) * (size_t)(w0.HIu + w0.HIq) * d, 256);
+    const size_t ticket_bytes = sizeof(int32_t) * (size_t)(w0.HRu + w0.HRq);
+    if (int rc = crec_reserve(ctx, &ctx->misc, part_bytes + ticket_bytes))
+        return rc;
+    CREC_HIP(ctx, hipMemsetAsync((char *)ctx->misc.ptr + part_bytes, 0, ticket_bytes, st));
+    if (int rc = crec_reserve(ctx, &ctx->contrib, sizeof(float) * (size_t)B * d))
+        return rc;
+
+    // plan-side workspace (sizes known up front) ...
+    struct PlanWs {
+        int32_t *req_keys, *n_req, *req_off, *ci, *cj, *cnt_send, *cnt_recv, *srv_cnt, *ids_send;
+        int64_t *pack_off, *srv_base;
+        float *Qc, *dQc;
+        size_t bytes;
+    };
+    const auto plan_layout = [&](void *base, int64_t nbc) {
+        ShardTake k;
+        k.base = (char *)base;
+        PlanWs p{};
+        p.req_keys = k.take<int32_t>((size_t)nbc * IC);
+        p.n_req = k.take<int32_t>((size_t)nbc);
+        p.req_off = k.take<int32_t>((size_t)nbc * (G + 1));
+        p.ci = k.take<int32_t>((size_t)nbc * B);
+        p.cj = k.take<int32_t>((size_t)nbc * B);
+        p.cnt_send = k.take<int32_t>((size_t)nbc * G);
+        p.cnt_recv = k.take<int32_t>((size_t)nbc * G);
+        p.srv_cnt = k.take<int32_t>((size_t)nbc * G);
+        p.ids_send = k.take<int32_t>((size_t)nbc * IC);
+        p.pack_off = k.take<int64_t>((size_t)nbc * G);
+        p.srv_base = k.take<int64_t>((size_t)nbc * G);
+        p.Qc = k.take<float>((size_t)IC * d);
+        p.dQc = k.take<float>((size_t)IC * d);
+        p.bytes = k.off;
+        return p;
+    };
+    if (int rc = crec_reserve(ctx, &ctx->shard_ws, plan_layout(nullptr, chunk).bytes))
+        return rc;
+    // ... and the serve side, sized once the peers' request counts are known
+    struct ServeWs {
+        int32_t *ids_recv, *srv_rows, *order, *urows, *useg, *n_urows;
+        float *sendrows, *recvgrads;
+        size_t bytes;
+    };
+    const auto serve_layout = [&](void *base, int64_t nbc, int64_t total_ids, int64_t stride) {
+        ShardTake k;
+        k.base = (char *)base;
+        ServeWs v{};
+        v.ids_recv = k.take<int32_t>((size_t)total_ids + 1);
+        v.srv_rows = k.take<int32_t>((size_t)nbc * stride);
+        v.order = k.take<int32_t>((size_t)nbc * stride);
+        v.urows = k.take<int32_t>((size_t)nbc * stride);
+        v.useg = k.take<int32_t>((size_t)nbc * (stride + 1));
+        v.n_urows = k.take<int32_t>((size_t)nbc);
+        v.sendrows = k.take<float>((size_t)stride * d);
+        v.recvgrads = k.take<float>((size_t)stride * d);
+        v.bytes = k.off;
+        return v;
+    };
+    // host staging (page-locked: the per-chunk counts cross PCIe a few times)
+    const size_t host_ints = (size_t)chunk * (G + 1) + 4 * (size_t)chunk * G + 8 * (size_t)chunk + 64;
+    if (host_ints > ctx->pinned64_n) {
+        if (ctx->pinned64)
+            CREC_HIP(ctx, hipHostFree(ctx->pinned64));
+        ctx->pinned64 = nullptr;
+        ctx->pinned64_n = 0;
+        CREC_HIP(ctx, hipHostMalloc((void **)&ctx->pinned64, sizeof(int64_t) * host_ints * 2, hipHostMallocDefault));
+        ctx->pinned64_n = host_ints * 2;
+    }
+
+    const int cap_plan = (int)((IC + 63) / 64 * 64);
+    CREC_HIP(ctx, hipFuncSetAttribute((const void *)shard_plan_batches, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)shard_lds_bytes(cap_plan)));
+    const int cap_idx = (2 * B + 63) / 64 * 64;
+    const size_t lds_idx = index_lds_bytes(cap_idx);
+    CREC_HIP(ctx, hipFuncSetAttribute((const void *)bpr_index_batches, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_idx));
+
+    StepArgs a{};
+    a.ctx = ctx;
+    a.d = d;
+    a.U = t->U;
+    a.I = IC;
+    a.B = B;
+    a.st = st;
+    a.partial = (float *)ctx->misc.ptr;
+    a.tickets = (int32_t *)((char *)ctx->misc.ptr + part_bytes);
+    a.contrib = (float *)ctx->contrib.ptr;
+    int64_t sent_ids = 0, sent_rows = 0, sent_grads = 0, n_requested = 0, n_served = 0, max_served = 0;
+
+    std::vector<int64_t> scnt(G), sdsp(G), rcnt(G), rdsp(G);
+    for (int64_t b0 = 0; b0 < nb; b0 += chunk) {
+        const int64_t nbc = (nb - b0) < chunk ? (nb - b0) : chunk;
+        const int64_t t0 = b0 * B, n_chunk = (N - t0) < nbc * B ? (N - t0) : nbc * B;
+        const PlanWs p = plan_layout(ctx->shard_ws.ptr, nbc);
+        // 1. plan: compact ids and request lists of every batch of the chunk
+        crec_prof_begin(ctx, CREC_K_SHARD_PLAN, st);
+        CREC_KLAUNCH(ctx, shard_plan_batches, dim3((unsigned)nbc), dim3(SHARD_THREADS), shard_lds_bytes(cap_plan), st, i + t0,
+                     j + t0, n_chunk, B, cap_plan, G, S, row_bits((int64_t)G * S), p.req_keys, p.n_req, p.req_off, p.ci, p.cj);
+        crec_prof_end(ctx, st);
+        // 2. the per-owner counts -> host; every rank tells every owner how many rows each batch will ask for
+        char *hp = (char *)ctx->pinned64;
+        const auto htake = [&hp](size_t bytes) {
+            char *q = hp;
+            hp += (bytes + 7) / 8 * 8;
+            return q;
+        };
+        int32_t *h_off = (int32_t *)htake(sizeof(int32_t) * (size_t)nbc * (G + 1)); // [nbc][G+1]
+        int32_t *h_cnt_send = (int32_t *)htake(sizeof(int32_t) * (size_t)nbc * G);  // [G][nbc]
+        int32_t *h_cnt_recv = (int32_t *)htake(sizeof(int32_t) * (size_t)nbc * G);  // [G][nbc]  rows peer p asks of me in batch b
+        int32_t *h_srv_cnt = (int32_t *)htake(sizeof(int32_t) * (size_t)nbc * G);   // [nbc][G]
+        int64_t *h_pack = (int64_t *)htake(sizeof(int64_t) * (size_t)nbc * G);      // [nbc][G]
+        int64_t *h_base = (int64_t *)htake(sizeof(int64_t) * (size_t)nbc * G);      // [nbc][G]
+        CREC_HIP(ctx, hipMemcpyAsync(h_off, p.req_off, sizeof(int32_t) * (size_t)nbc * (G + 1), hipMemcpyDeviceToHost, st));
+        CREC_HIP(ctx, hipStreamSynchronize(st));
+        for (int o = 0; o < G; ++o)
+            for (int64_t b = 0; b < nbc; ++b)
+                h_cnt_send[(size_t)o * nbc + b] = h_off[b * (G + 1) + o + 1] - h_off[b * (G + 1) + o];
+        CREC_HIP(ctx, hipMemcpyAsync(p.cnt_send, h_cnt_send, sizeof(int32_t) * (size_t)nbc * G, hipMemcpyHostToDevice, st));
+        for (int q = 0; q < G; ++q) {
+            scnt[q] = rcnt[q] = nbc;
+            sdsp[q] = rdsp[q] = (int64_t)q * nbc;
+        }
+        if (int rc = x->alltoallv(ctx, p.cnt_send, scnt.data(), sdsp.data(), p.cnt_recv, rcnt.data(), rdsp.data(), 4, st))
+            return rc;
+        CREC_HIP(ctx, hipMemcpyAsync(h_cnt_recv, p.cnt_recv, sizeof(int32_t) * (size_t)nbc * G, hipMemcpyDeviceToHost, st));
+        CREC_HIP(ctx, hipStreamSynchronize(st));
+        // 3. where everything goes: owner-major packing of my requests, peer-major layout of what I serve
+        int64_t at = 0, total_srv = 0, stride = 64;
+        for (int o = 0; o < G; ++o) {
+            sdsp[o] = at;
+            for (int64_t b = 0; b < nbc; ++b) {
+                h_pack[b * G + o] = at;
+                at += h_cnt_send[(size_t)o * nbc + b];
+            }
+            scnt[o] = at - sdsp[o];
+        }
+        n_requested += at;
+        for (int q = 0; q < G; ++q) {
+            rdsp[q] = total_srv;
+            for (int64_t b = 0; b < nbc; ++b) {
+                h_base[b * G + q] = total_srv;
+                h_srv_cnt[b * G + q] = h_cnt_recv[(size_t)q * nbc + b];
+                total_srv += h_cnt_recv[(size_t)q * nbc + b];
+            }
+            rcnt[q] = total_srv - rdsp[q];
+        }
+        n_served += total_srv;
+        for (int64_t b = 0; b < nbc; ++b) {
+            int64_t n_b = 0;
+            for (int q = 0; q < G; ++q)
+                n_b += h_srv_cnt[b * G + q];
+            stride = n_b > stride ? n_b : stride;
+        }
+        max_served = stride > max_served ? stride : max_served;
+        stride = (stride + 63) / 64 * 64;
+        CREC_REQUIRE(ctx, stride <= 16 * SHARD_THREADS,
+                     "a batch asks this rank for %lld rows; the owner-side index sorts at most %d per batch in LDS", (long long)stride,
+                     16 * SHARD_THREADS);
+        if (int rc = crec_reserve(ctx, &ctx->shard_ws2, serve_layout(nullptr, nbc, total_srv, stride).bytes))
+            return rc;
+        const ServeWs v = serve_layout(ctx->shard_ws2.ptr, nbc, total_srv, stride);
+        CREC_HIP(ctx, hipMemcpyAsync(p.pack_off, h_pack, sizeof(int64_t) * (size_t)nbc * G, hipMemcpyHostToDevice, st));
+        CREC_HIP(ctx, hipMemcpyAsync(p.srv_base, h_base, sizeof(int64_t) * (size_t)nbc * G, hipMemcpyHostToDevice, st));
+        CREC_HIP(ctx, hipMemcpyAsync(p.srv_cnt, h_srv_cnt, sizeof(int32_t) * (size_t)nbc * G, hipMemcpyHostToDevice, st));
+        // 4. the index exchange, once per chunk
+        hipLaunchKernelGGL(shard_pack_ids, dim3((unsigned)nbc), dim3(256), 0, st, (const int32_t *)p.req_keys,
+                           (const int32_t *)p.req_off, (const int64_t *)p.pack_off, B, G, S, p.ids_send);
+        if (int rc = x->alltoallv(ctx, p.ids_send, scnt.data(), sdsp.data(), v.ids_recv, rcnt.data(), rdsp.data(), 4, st))
+            return rc;
+        for (int q = 0; q < G; ++q)
+            sent_ids += q == me ? 0 : 4 * (scnt[q] + nbc);
+        // 5. owner-side index of every batch, then the occurrence index over the compact ids
+        const int cap_srv = (int)stride;
+        CREC_HIP(ctx, hipFuncSetAttribute((const void *)shard_owner_index, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)shard_lds_bytes(cap_srv)));
+        hipLaunchKernelGGL(shard_owner_index, dim3((unsigned)nbc), dim3(SHARD_THREADS), shard_lds_bytes(cap_srv), st,
+                           (const int32_t *)v.ids_recv, (const int64_t *)p.srv_base, (const int32_t *)p.srv_cnt, G, cap_srv,
+                           cap_srv, row_bits(S), v.srv_rows, v.order, v.urows, v.useg, v.n_urows);
+        IndexWs w = layout_index(ctx->idx_ws.ptr, nbc, B, t->U, IC, false, CH);
+        crec_prof_begin(ctx, CREC_K_INDEX, st);
+        CREC_KLAUNCH(ctx, bpr_index_batches, dim3((unsigned)(2 * nbc)), dim3(PREP_THREADS), lds_idx, st, u + t0,
+                     (const int32_t *)p.ci, (const int32_t *)p.cj, n_chunk, B, cap_idx, w);
+        crec_prof_end(ctx, st);
+        const size_t n_hn = (size_t)nbc * 4;
+        if (n_hn > ctx->pinned_ints) {
+            if (ctx->pinned)
+                CREC_HIP(ctx, hipHostFree(ctx->pinned));
+            ctx->pinned = nullptr;
+            ctx->pinned_ints = 0;
+            CREC_HIP(ctx, hipHostMalloc((void **)&ctx->pinned, sizeof(int32_t) * n_hn * 2, hipHostMallocDefault));
+            ctx->pinned_ints = n_hn * 2;
+        }
+        const int32_t *hn = ctx->pinned;
+        CREC_HIP(ctx, hipMemcpyAsync(ctx->pinned, w.hn, sizeof(int32_t) * n_hn, hipMemcpyDeviceToHost, st));
+        CREC_HIP(ctx, hipStreamSynchronize(st));
+        a.pad_wide = a.pad_chunks_u = a.pad_chunks_q = 0;
+        for (int64_t b = 0; b < nbc; ++b) {
+            a.pad_chunks_u = hn[(size_t)b * 4 + 1] > a.pad_chunks_u ? hn[(size_t)b * 4 + 1] : a.pad_chunks_u;
+            a.pad_chunks_q = hn[(size_t)b * 4 + 3] > a.pad_chunks_q ? hn[(size_t)b * 4 + 3] : a.pad_chunks_q;
+        }
+        a.cur = Tables{t->P, t->mP, t->vP, p.Qc, nullptr, nullptr};
+        // 6. the steps
+        for (int64_t b = 0; b < nbc; ++b) {
+            int64_t n_srv = 0;
+            for (int q = 0; q < G; ++q) { // forward: I send peer q the rows it asked for, owner o sends me mine
+                scnt[q] = (int64_t)h_srv_cnt[b * G + q] * d;
+                sdsp[q] = n_srv * d;
+                n_srv += h_srv_cnt[b * G + q];
+                rcnt[q] = (int64_t)(h_off[b * (G + 1) + q + 1] - h_off[b * (G + 1) + q]) * d;
+                rdsp[q] = (int64_t)h_off[b * (G + 1) + q] * d;
+                if (q != me) {
+                    sent_rows += 4 * scnt[q];
+                    sent_grads += 4 * rcnt[q];
+                }
+            }
+            if (n_srv > 0) {
+                crec_prof_begin(ctx, CREC_K_SHARD_SERVE, st);
+                CREC_KLAUNCH(ctx, shard_serve_rows, dim3((unsigned)crec_ceil_div(n_srv * lpr, 256)), dim3(256), 0, st,
+                             (const float *)t->Q, (const int32_t *)(v.srv_rows + b * stride), (int)n_srv, d, lpr, v.sendrows);
+                crec_prof_end(ctx, st);
+            }
+            if (int rc = x->alltoallv(ctx, v.sendrows, scnt.data(), sdsp.data(), p.Qc, rcnt.data(), rdsp.data(), 4, st))
+                return rc;
+            a.h.lr_t = (opt->lr * sqrtf(1.0f - opt->beta2_power)) / (1.0f - opt->beta1_power);
+            a.h.beta1 = opt->beta1;
+            a.h.beta2 = opt->beta2;
+            a.h.eps = opt->eps;
+            a.h.reg = opt->reg;
+            a.h.dQ = p.dQc; // the item side emits each compact row's gradient sum (incl. its l2 term) instead of Adam
+            a.xb = (float *)ctx->loss_ws.ptr + b * loss_stride;
+            a.rowterm = a.xb + B;
+            step(a, w, b, hn + b * 4);
+            // back: the gradient row of every item I referenced goes to its owner (the forward sizes, reversed)
+            if (int rc = x->alltoallv(ctx, p.dQc, rcnt.data(), rdsp.data(), v.recvgrads, scnt.data(), sdsp.data(), 4, st))
+                return rc;
+            if (n_srv > 0) {
+                crec_prof_begin(ctx, CREC_K_SHARD_APPLY, st);
+                CREC_KLAUNCH(ctx, shard_owner_apply, dim3((unsigned)crec_ceil_div(n_srv * lpr, 256)), dim3(256), 0, st, t->Q, t->mQ,
+                             t->vQ, (const int32_t *)(v.urows + b * stride), (const int32_t *)(v.useg + b * (stride + 1)),
+                             (const int32_t *)(v.order + b * stride), (const int32_t *)(v.n_urows + b),
+                             (const float *)v.recvgrads, d, lpr, a.h);
+                crec_prof_end(ctx, st);
+            }
+            opt->beta1_power = opt->beta1_power * opt->beta1;
+            opt->beta2_power = opt->beta2_power * opt->beta2;
+            opt->step += 1;
+        }
+        crec_prof_begin(ctx, CREC_K_REDUCE_LOSS, st);
+        CREC_KLAUNCH(ctx, bpr_reduce_loss, dim3((unsigned)nbc), dim3(256), 0, st, (const float *)ctx->loss_ws.ptr, loss_stride,
+                     n_chunk, B, (int64_t)0, (const int32_t *)w.n_u, (const int32_t *)w.n_q, opt->reg, loss_per_batch + b0);
+        crec_prof_end(ctx, st);
+        if (int rc = x->allreduce_sum_f32(ctx, loss_per_batch + b0, (size_t)nbc, st))
+            return rc;
+        CREC_HIP(ctx, hipGetLastError());
+        if (int rc = crec_prof_flush(ctx, st))
+            return rc;
+    }
+    if (stats) {
+        stats->bytes_ids_sent += sent_ids;
+        stats->bytes_rows_sent += sent_rows;
+        stats->bytes_grads_sent += sent_grads;
+        stats->rows_requested += n_requested;
+        stats->rows_served += n_served;
+        stats->max_rows_served_per_batch = max_served > stats->max_rows_served_per_batch ? max_served : stats->max_rows_served_per_batch;
+        stats->steps += nb;
+    }
+    return CREC_OK;
+}
 } // namespace
 
 extern "C" {
@@ -1893,45 +2021,11 @@ int crec_bpr_train_epoch_dp(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *
     return train_epoch_impl(ctx, t, opt, u, i, j, N, B, loss_per_batch, stream, true);
 }
 
-int crec_comm_unique_id(crec_ctx *ctx, void *id_out)
+int crec_bpr_train_epoch_sharded(crec_ctx *ctx, const crec_bpr_tables *t, int64_t I_global, crec_adam *opt, const int32_t *u,
+                                 const int32_t *i, const int32_t *j, int64_t N, int32_t B, float *loss_per_batch,
+                                 crec_shard_stats *stats, void *stream)
 {
-    if (!ctx || !id_out)
-        return CREC_EINVAL;
-    static_assert(sizeof(ncclUniqueId) == CREC_UNIQUE_ID_BYTES, "unique id size");
-    if (ncclGetUniqueId((ncclUniqueId *)id_out) != ncclSuccess)
-        return crec_fail(ctx, CREC_EHIP, "ncclGetUniqueId failed");
-    return CREC_OK;
-}
-
-int crec_comm_init(crec_ctx *ctx, int rank, int world, const void *id)
-{
-    if (!ctx)
-        return CREC_EINVAL;
-    CREC_REQUIRE(ctx, ctx->device >= 0, "host-only ctx: no device bound");
-    CREC_REQUIRE(ctx, id && world >= 1 && rank >= 0 && rank < world, "bad rank/world");
-    CREC_REQUIRE(ctx, ctx->comm == nullptr, "communicator already initialised");
-    CREC_HIP(ctx, hipSetDevice(ctx->device));
-    ncclUniqueId uid;
-    std::memcpy(&uid, id, sizeof(uid));
-    ncclComm_t comm = nullptr;
-    ncclResult_t r = ncclCommInitRank(&comm, world, uid, rank);
-    if (r != ncclSuccess)
-        return crec_fail(ctx, CREC_EHIP, "ncclCommInitRank failed: %s", ncclGetErrorString(r));
-    ctx->comm = comm;
-    ctx->rank = rank;
-    ctx->world = world;
-    return CREC_OK;
-}
-
-int crec_comm_destroy(crec_ctx *ctx)
-{
-    if (!ctx)
-        return CREC_EINVAL;
-    if (ctx->comm) {
-        ncclCommDestroy((ncclComm_t)ctx->comm);
-        ctx->comm = nullptr;
-    }
-    return CREC_OK;
+    return sharded_epoch_impl(ctx, t, I_global, opt, u, i, j, N, B, loss_per_batch, stats, stream);
 }
 
 } // extern "C"

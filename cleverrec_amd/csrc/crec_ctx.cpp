@@ -1,6 +1,8 @@
 // Context, error reporting and workspace management of libcrec.so.
 #include "crec_internal.h"
 
+#include <cstdlib>
+
 int crec_fail(crec_ctx *ctx, int code, const char *fmt, ...)
 {
     if (ctx) {
@@ -136,6 +138,15 @@ int crec_ctx_create(int device, crec_ctx **out)
         return CREC_ENOMEM;
     ctx->device = device;
     crec_rng_seed(ctx, 5489u);
+    const auto env_int = [](const char *name, int dflt) {
+        const char *v = getenv(name);
+        return v && *v ? atoi(v) : dflt;
+    };
+    ctx->knob_ch = env_int("CREC_CH", 0);
+    ctx->knob_wide = env_int("CREC_WIDE", -1);
+    ctx->knob_wide_round = env_int("CREC_WIDE_ROUND", 0);
+    ctx->knob_eval_shape = env_int("CREC_EVAL_SHAPE", 0);
+    ctx->knob_eval_no_bitmap = env_int("CREC_EVAL_NO_BITMAP", 0);
     if (device >= 0) {
         int n = 0;
         hipError_t e = hipGetDeviceCount(&n);
@@ -173,8 +184,8 @@ void crec_ctx_destroy(crec_ctx *ctx)
         (void)hipSetDevice(ctx->device);
         (void)hipDeviceSynchronize();
         (void)crec_comm_destroy(ctx);
-        crec_devbuf *bufs[] = {&ctx->idx_ws, &ctx->contrib, &ctx->loss_ws, &ctx->lr_table,
-                               &ctx->misc,   &ctx->eval_ws, &ctx->ks_dev, &ctx->shadow, &ctx->dq};
+        crec_devbuf *bufs[] = {&ctx->idx_ws, &ctx->contrib, &ctx->loss_ws,
+                               &ctx->misc,   &ctx->eval_ws, &ctx->ks_dev, &ctx->shadow, &ctx->dq, &ctx->shard_ws, &ctx->shard_ws2};
         for (crec_devbuf *b : bufs)
             if (b->ptr)
                 (void)hipFree(b->ptr);
@@ -186,8 +197,30 @@ void crec_ctx_destroy(crec_ctx *ctx)
             (void)hipEventDestroy(e);
         if (ctx->pinned)
             (void)hipHostFree(ctx->pinned);
+        if (ctx->pinned64)
+            (void)hipHostFree(ctx->pinned64);
     }
     delete ctx;
+}
+
+int crec_ctx_set_option(crec_ctx *ctx, const char *name, int64_t value)
+{
+    if (!ctx || !name)
+        return CREC_EINVAL;
+    const std::string n(name);
+    if (n == "ch")
+        ctx->knob_ch = (int)value;
+    else if (n == "wide")
+        ctx->knob_wide = (int)value;
+    else if (n == "wide_round")
+        ctx->knob_wide_round = (int)value;
+    else if (n == "eval_shape")
+        ctx->knob_eval_shape = (int)value;
+    else if (n == "eval_no_bitmap")
+        ctx->knob_eval_no_bitmap = (int)value;
+    else
+        return crec_fail(ctx, CREC_EINVAL, "unknown option '%s'", name);
+    return CREC_OK;
 }
 
 // ctx == NULL: why the last crec_ctx_create failed

@@ -44,6 +44,9 @@ enum crec_kernel_class {
     CREC_K_FM_INSTANCES,
     CREC_K_CML_INSTANCES,
     CREC_K_NCF_SCORES,
+    CREC_K_SHARD_PLAN,
+    CREC_K_SHARD_SERVE,
+    CREC_K_SHARD_APPLY,
     CREC_K_COUNT
 };
 
@@ -72,9 +75,12 @@ struct crec_ctx {
     crec_devbuf dq;       // data-parallel step: dense per-item gradient sums [I, d]
     void *comm = nullptr; // ncclComm_t (RCCL), set by crec_comm_init
     int rank = 0, world = 1;
+    struct crec_xch *xch = nullptr; // exchange object of the row-sharded path (crec_comm.h): local group, RCCL or world of one
+    crec_devbuf shard_ws, shard_ws2; // row-sharded step: plan side (request lists, compact ids, Qc / dQc), serve side
+    int64_t *pinned64 = nullptr;    // page-locked host staging of the sharded path's counts
+    size_t pinned64_n = 0;
     crec_devbuf shadow;   // second buffer set of the tf1-mode ping-pong: P, mP, vP, Q, mQ, vQ
     crec_devbuf loss_ws;  // per-triple loss terms of one chunk
-    crec_devbuf lr_table; // per-step lr_t of one chunk
     crec_devbuf misc;     // small counters
     int32_t *pinned = nullptr; // page-locked host buffer for the per-chunk counts read back from the index kernel
     size_t pinned_ints = 0;
@@ -82,6 +88,13 @@ struct crec_ctx {
     crec_devbuf eval_ws;
     crec_devbuf ks_dev;
     int num_cus = 0;
+    // tuning / test options: read ONCE from the environment at crec_ctx_create (CREC_CH, CREC_WIDE, CREC_WIDE_ROUND,
+    // CREC_EVAL_SHAPE, CREC_EVAL_NO_BITMAP), changed afterwards only through crec_ctx_set_option -- never getenv on a hot path
+    int knob_ch = 0;             // occurrences per heavy-row chunk (0: the mode's default)
+    int knob_wide = -1;          // wide-group threshold of the tf1 step (-1: default 16, 0: off)
+    int knob_wide_round = 0;     // experiment: pad the wide groups' workgroups to a multiple of this (0: chunk maximum)
+    int knob_eval_shape = 0;     // 4 / 8: force an eval_sweep workgroup shape where legal (0: choose)
+    int knob_eval_no_bitmap = 0; // 1: seen filter by binary search even where the bitmaps would fit
 };
 
 int crec_fail(crec_ctx *ctx, int code, const char *fmt, ...);

@@ -554,8 +554,8 @@ static int eval_topk_impl(crec_ctx *ctx, const float *P, const float *Q, int64_t
     // shape: 8 waves per workgroup (two per SIMD) when K and the row width leave room for their buffers (measured:
     // 66 vs 51 % of the MFMA peak at 65536 x 1M x 64, and 0.46 vs 0.67 ms for the ml-1m sweep)
     const int64_t cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
-    const char *shape_env = getenv("CREC_EVAL_SHAPE"); // "8" / "4": force a shape where it is legal (tests, tuning)
-    const bool wide = K <= cap_of(8) - 32 && d <= 128 && (shape_env ? atoi(shape_env) == 8 : Bt > 128);
+    // option eval_shape = 8 / 4: force a shape where it is legal (tests, tuning; crec_ctx_set_option)
+    const bool wide = K <= cap_of(8) - 32 && d <= 128 && (ctx->knob_eval_shape ? ctx->knob_eval_shape == 8 : Bt > 128);
     const int tile = wide ? (d > 64 ? 32 : 64) : (d > 128 ? 32 : 64);
     const int users_per_wg = (wide ? 8 : 4) * 32;
     const int user_tiles = (int)crec_ceil_div(Bt, users_per_wg);
@@ -571,7 +571,7 @@ static int eval_topk_impl(crec_ctx *ctx, const float *P, const float *Q, int64_t
     const int words = (int)crec_ceil_div(I, 32);
     const size_t part_bytes = (sizeof(u64) * (size_t)Bt * S * K + 255) / 256 * 256;
     const size_t bits_bytes = sizeof(uint32_t) * (size_t)Bt * words;
-    const bool use_bits = bits_bytes <= ((size_t)64 << 20) && !getenv("CREC_EVAL_NO_BITMAP");
+    const bool use_bits = bits_bytes <= ((size_t)64 << 20) && !ctx->knob_eval_no_bitmap;
     if (int rc = crec_reserve(ctx, &ctx->eval_ws, part_bytes + (use_bits ? bits_bytes : 0)))
         return rc;
     u64 *part = (u64 *)ctx->eval_ws.ptr;

@@ -1,0 +1,196 @@
+// Kernels of the row-sharded BPR step (included by bpr_train.hip inside its anonymous namespace, after the shared
+// device pieces: ld4 / st4 / adam4 / Hyper).  Items are dealt to ranks round-robin: item g lives on rank g % G as
+// local row g / G of that rank's Q shard (S = ceil(I / G) rows per shard).  A rank runs the lazy BPR step of
+// bpr_train.hip on its own triples against a COMPACT item table Qc holding just the rows its batch references:
+//
+//   shard_plan_batches   (per chunk of batches) the batch's 2B item ids -> owner-major keys (g % G) * S + g / G,
+//                        stable radix sort in LDS (block_sort.h) -> the unique keys in ascending order = the batch's
+//                        request list, grouped by owner; every triple's i and j are replaced by their rank in that
+//                        list (the compact id).  The per-owner counts go to the host once per chunk.
+//   shard_pack_ids       request lists of all batches of the chunk -> one owner-major buffer (local row ids), which one
+//                        all-to-all-v per CHUNK delivers to the owners: the index exchange is off the per-step path.
+//   shard_owner_index    owner side, per chunk: for every batch the rows the peers ask for, peer after peer, sorted
+//                        by row -> unique rows, their slot lists in peer order (one fixed summation order).
+//   shard_serve_rows     per step: the requested rows of the shard, staged peer by peer for the forward all-to-all-v.
+//   shard_owner_apply    per step: a row's gradient rows, as they came back from the peers, are added in peer order
+//                        and the row takes its lazy Adam update in place.
+#pragma once
+
+constexpr int SHARD_THREADS = 1024;
+
+inline size_t shard_lds_bytes(int cap)
+{
+    return sizeof(uint32_t) * cap + sizeof(uint16_t) * (2 * (size_t)cap + 64) +
+           sizeof(int) * (crec_sort::hist_ints<SHARD_THREADS>() + crec_sort::scan_ints<SHARD_THREADS>() + 80);
+}
+
+// grid = batches of the chunk.  req_keys [nbc][2B], n_req [nbc], req_off [nbc][G+1], ci / cj [n_total]
+__global__ __launch_bounds__(SHARD_THREADS) void shard_plan_batches(const int32_t *__restrict__ i,
+                                                                    const int32_t *__restrict__ j, int64_t n_total,
+                                                                    int32_t B, int32_t cap, int32_t G, int64_t S,
+                                                                    int32_t key_bits, int32_t *__restrict__ req_keys,
+                                                                    int32_t *__restrict__ n_req,
+                                                                    int32_t *__restrict__ req_off,
+                                                                    int32_t *__restrict__ ci, int32_t *__restrict__ cj)
+{
+    extern __shared__ uint32_t rows[]; // [cap]
+    uint16_t *tag = (uint16_t *)(rows + cap);
+    uint16_t *seg = tag + cap; // unused here (same layout as the index kernels)
+    int *hist = (int *)(seg + cap + 64);
+    int *scan = hist + crec_sort::hist_ints<SHARD_THREADS>();
+    int *per_owner = scan + crec_sort::scan_ints<SHARD_THREADS>(); // [<= 64] + 16
+    const int batch = blockIdx.x, tid = threadIdx.x;
+    const int64_t t0 = (int64_t)batch * B;
+    const int nb = (int)((n_total - t0) < B ? (n_total - t0) : B);
+    const int n = 2 * nb;
+    for (int k = tid; k < n; k += SHARD_THREADS) {
+        const int64_t g = k < nb ? i[t0 + k] : j[t0 + k - nb];
+        rows[k] = (uint32_t)((g % G) * S + g / G);
+        tag[k] = (uint16_t)k;
+    }
+    if (tid < 80)
+        per_owner[tid] = 0;
+    crec_sort::block_sort_rows<SHARD_THREADS>(rows, tag, n, key_bits, hist, scan);
+
+    const int per = (n + SHARD_THREADS - 1) / SHARD_THREADS;
+    const int k0 = tid * per, k1 = (k0 + per) < n ? (k0 + per) : n;
+    int heads = 0;
+    for (int k = k0; k < k1; ++k)
+        heads += (k == 0 || rows[k] != rows[k - 1]) ? 1 : 0;
+    int total = 0;
+    int r = crec_sort::block_excl_scan<SHARD_THREADS>(heads, scan, &total);
+    int32_t *keys_out = req_keys + (int64_t)batch * 2 * B;
+    for (int k = k0; k < k1; ++k) {
+        if (k == 0 || rows[k] != rows[k - 1]) {
+            keys_out[r] = (int32_t)rows[k];
+            atomicAdd(&per_owner[(int)((int64_t)rows[k] / S)], 1); // counts only: the order of the adds does not matter
+            ++r;
+        }
+        const int slot = tag[k]; // every slot learns the rank of its item among the batch's unique items
+        if (slot < nb)
+            ci[t0 + slot] = r - 1;
+        else
+            cj[t0 + slot - nb] = r - 1;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int at = 0;
+        int32_t *off = req_off + (int64_t)batch * (G + 1);
+        for (int o = 0; o < G; ++o) {
+            off[o] = at;
+            at += per_owner[o];
+        }
+        off[G] = at;
+        n_req[batch] = total;
+    }
+}
+
+// grid = batches.  ids_send[pack_off[b][o] + k] = local row of the k-th item this batch requests from owner o
+__global__ __launch_bounds__(256) void shard_pack_ids(const int32_t *__restrict__ req_keys, const int32_t *__restrict__ req_off,
+                                                      const int64_t *__restrict__ pack_off, int32_t B, int32_t G, int64_t S,
+                                                      int32_t *__restrict__ ids_send)
+{
+    const int b = blockIdx.x;
+    const int32_t *keys = req_keys + (int64_t)b * 2 * B, *off = req_off + (int64_t)b * (G + 1);
+    const int n = off[G];
+    for (int q = threadIdx.x; q < n; q += 256) {
+        const int64_t key = keys[q];
+        const int o = (int)(key / S);
+        ids_send[pack_off[(int64_t)b * G + o] + (q - off[o])] = (int32_t)(key - o * S);
+    }
+}
+
+// grid = batches.  The peers' request lists for batch b (peer p: ids_recv[srv_base[b][p] ..) of srv_cnt[b][p] rows)
+// -> srv_rows[b][slot] (peer-major, the order rows are served and gradient rows come back in), order[b][k] = slot of
+// the k-th (row, slot) pair sorted by row, urows[b][q] / useg[b][q] = unique rows and where their slots start.
+__global__ __launch_bounds__(SHARD_THREADS) void shard_owner_index(const int32_t *__restrict__ ids_recv,
+                                                                   const int64_t *__restrict__ srv_base,
+                                                                   const int32_t *__restrict__ srv_cnt, int32_t G,
+                                                                   int32_t cap, int32_t stride, int32_t key_bits,
+                                                                   int32_t *__restrict__ srv_rows,
+                                                                   int32_t *__restrict__ order, int32_t *__restrict__ urows,
+                                                                   int32_t *__restrict__ useg, int32_t *__restrict__ n_urows)
+{
+    extern __shared__ uint32_t rows[]; // [cap]
+    uint16_t *tag = (uint16_t *)(rows + cap);
+    uint16_t *seg = tag + cap;
+    int *hist = (int *)(seg + cap + 64);
+    int *scan = hist + crec_sort::hist_ints<SHARD_THREADS>();
+    const int b = blockIdx.x, tid = threadIdx.x;
+    int n = 0;
+    for (int p = 0; p < G; ++p) {
+        const int c = srv_cnt[(int64_t)b * G + p];
+        const int32_t *src = ids_recv + srv_base[(int64_t)b * G + p];
+        for (int k = tid; k < c; k += SHARD_THREADS) {
+            const int32_t row = src[k];
+            rows[n + k] = (uint32_t)row;
+            tag[n + k] = (uint16_t)(n + k);
+            srv_rows[(int64_t)b * stride + n + k] = row;
+        }
+        n += c;
+    }
+    crec_sort::block_sort_rows<SHARD_THREADS>(rows, tag, n, key_bits, hist, scan);
+    const int per = (n + SHARD_THREADS - 1) / SHARD_THREADS;
+    const int k0 = tid * per, k1 = (k0 + per) < n ? (k0 + per) : n;
+    int heads = 0;
+    for (int k = k0; k < k1; ++k)
+        heads += (k == 0 || rows[k] != rows[k - 1]) ? 1 : 0;
+    int total = 0;
+    int r = crec_sort::block_excl_scan<SHARD_THREADS>(heads, scan, &total);
+    for (int k = k0; k < k1; ++k) {
+        if (k == 0 || rows[k] != rows[k - 1]) {
+            urows[(int64_t)b * stride + r] = (int32_t)rows[k];
+            useg[(int64_t)b * (stride + 1) + r] = k;
+            ++r;
+        }
+        order[(int64_t)b * stride + k] = tag[k];
+    }
+    if (tid == 0) {
+        useg[(int64_t)b * (stride + 1) + total] = n;
+        n_urows[b] = total;
+    }
+}
+
+// one group of lpr lanes per served slot: out[slot] = Q[srv_rows[slot]]
+__global__ __launch_bounds__(256) void shard_serve_rows(const float *__restrict__ Q, const int32_t *__restrict__ srv_rows, int n,
+                                                        int d, int lpr, float *__restrict__ out)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t slot = t / lpr;
+    const int l = (int)(t % lpr);
+    if (slot >= n || 4 * l >= d)
+        return;
+    st4s(out + slot * d + 4 * l, ld4(Q + (int64_t)srv_rows[slot] * d + 4 * l));
+}
+
+// one group of lpr lanes per unique row of the batch: the row's gradient rows (one per requesting peer, each already
+// the peer's sum over its own occurrences incl. the l2 term) are added in peer order, then lazy Adam in place
+__global__ __launch_bounds__(256) void shard_owner_apply(float *__restrict__ Q, float *__restrict__ mQ, float *__restrict__ vQ,
+                                                         const int32_t *__restrict__ urows, const int32_t *__restrict__ useg,
+                                                         const int32_t *__restrict__ order, const int32_t *__restrict__ n_urows_p,
+                                                         const float *__restrict__ grads, int d, int lpr, Hyper h)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t q = t / lpr;
+    const int l = (int)(t % lpr);
+    if (q >= *n_urows_p || 4 * l >= d)
+        return;
+    const int64_t ro = (int64_t)urows[q] * d + 4 * l;
+    const int k0 = useg[q], k1 = useg[q + 1];
+    float4 var = ld4(Q + ro), m = ld4(mQ + ro), v = ld4(vQ + ro);
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = k0; k < k1; k += 8) { // up to eight peers' rows in flight, added in slot (= peer) order
+        float4 c[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            c[e] = k + e < k1 ? ld4(grads + (int64_t)order[k + e] * d + 4 * l) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (k + e < k1)
+                add4(g, c[e]);
+    }
+    adam4(var, m, v, g, true, h);
+    st4(Q + ro, var);
+    st4(mQ + ro, m);
+    st4(vQ + ro, v);
+}

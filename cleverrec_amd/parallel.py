@@ -1,11 +1,17 @@
-"""Multi-GPU form of the BPR path: one process per GPU of one node, RCCL over xGMI.
+"""Multi-GPU forms of the BPR path: one process per GPU of one node, RCCL over xGMI.
 
-The path shards with one real exchange: users -- rows of P, their Adam slots, their
-ui_train CSR, hence their sampler work and their triples -- are range-sharded over ranks, so all P
-traffic is local; Q and its slots are replicated; every step each rank emits its dense partial dQ,
-ONE all-reduce sums it, and every replica applies the identical tf1 Adam update
-(crec_bpr_train_epoch_dp; replicas stay bit-identical).  torch.distributed is used only to ship
-the RCCL unique id and to agree on the batch count."""
+Users -- rows of P, their Adam slots, their ui_train CSR, hence their sampler work and their triples -- are
+range-sharded over ranks in both forms, so all P traffic is local.
+
+  ShardedBprState  tables that outgrow a GPU (BASELINE configs[4]): items dealt round-robin (item g = local row g // G
+                   of rank g % G); per step the referenced rows travel to the ranks that reference them and the
+                   per-row gradient sums travel back to their owners, both as all-to-all-v over the xGMI mesh; the
+                   owner applies lazy Adam (crec_bpr_train_epoch_sharded).  No dense all-reduce of a table.
+  DpBprState       small catalogues with TF1-exact Adam (ml-1m shape): Q and its slots replicated, one all-reduce of the
+                   dense dQ per step, identical tf1 update on every replica (crec_bpr_train_epoch_dp).
+
+torch.distributed is used only to ship the RCCL unique id, to agree on the batch count and (evaluation) to gather
+the item shards."""
 import ctypes as C
 
 import numpy as np
@@ -60,13 +66,7 @@ class DpBprState(BprState):
 
     def __init__(self, sess, P0, Q0, lr, reg, rank=None, world=None):
         super().__init__(sess, P0, Q0, lr, reg, "tf1")
-        self.rank = dist.get_rank() if rank is None else rank
-        self.world = dist.get_world_size() if world is None else world
-        uid = (C.c_char * 128)()
-        if self.rank == 0:
-            sess.ctx.check(sess.lib.crec_comm_unique_id(sess.ctx.h, uid))
-        raw = bytes(uid) if self.world == 1 else broadcast_bytes(bytes(uid), 0)
-        sess.ctx.check(sess.lib.crec_comm_init(sess.ctx.h, self.rank, self.world, C.c_char_p(raw)))
+        self.rank, self.world = init_rccl(sess, rank, world)
 
     def train_epoch(self, u, i, j, batch_size):
         """Collective.  u: row ids inside this rank's shard.  Returns per-batch losses summed over ranks."""
@@ -77,3 +77,71 @@ class DpBprState(BprState):
         s.ctx.check(s.lib.crec_bpr_train_epoch_dp(s.ctx.h, C.byref(self.tables), C.byref(self.adam), s.ptr(u), s.ptr(i),
                                                   s.ptr(j), n, int(batch_size), s.ptr(loss), s.stream_ptr()))
         return loss
+
+
+def init_rccl(sess, rank=None, world=None):
+    """crec_comm_init on this rank's ctx: rank 0 creates the RCCL unique id, torch.distributed ships it."""
+    rank = dist.get_rank() if rank is None else rank
+    world = dist.get_world_size() if world is None else world
+    uid = (C.c_char * 128)()
+    if rank == 0:
+        sess.ctx.check(sess.lib.crec_comm_unique_id(sess.ctx.h, uid))
+    raw = bytes(uid) if world == 1 else broadcast_bytes(bytes(uid), 0)
+    sess.ctx.check(sess.lib.crec_comm_init(sess.ctx.h, rank, world, C.c_char_p(raw)))
+    return rank, world
+
+
+def init_local_group(sessions):
+    """crec_comm_init_local: the ranks are the given Sessions of THIS process (rank = position), each to be driven by
+    its own host thread."""
+    arr = (C.c_void_p * len(sessions))(*[s.ctx.h for s in sessions])
+    sessions[0].ctx.check(sessions[0].lib.crec_comm_init_local(arr, len(sessions)))
+
+
+def shard_rows(item_nums, world):
+    """rows per item shard: ceil(I / G)"""
+    return -(-int(item_nums) // int(world))
+
+
+def shard_items(Q, rank, world):
+    """this rank's item shard of a full [I, d] table: rows rank, rank + G, ... padded with zeros to ceil(I / G) rows"""
+    Q = np.asarray(Q)
+    out = np.zeros((shard_rows(len(Q), world), Q.shape[1]), Q.dtype)
+    part = Q[rank::world]
+    out[:len(part)] = part
+    return out
+
+
+def unshard_items(shards, item_nums):
+    """inverse of shard_items over all ranks' shards (numpy)"""
+    world = len(shards)
+    out = np.empty((int(item_nums), shards[0].shape[1]), shards[0].dtype)
+    for r, sh in enumerate(shards):
+        n = len(out[r::world])
+        out[r::world] = np.asarray(sh)[:n]
+    return out
+
+
+class ShardedBprState(BprState):
+    """P0: this rank's user rows; Q_shard: this rank's item shard (shard_items); item_nums: the global catalogue size.
+    The communicator (init_rccl / init_local_group; none = a world of one) must exist before the first epoch."""
+
+    def __init__(self, sess, P0, Q_shard, item_nums, lr, reg, rank=0, world=1):
+        super().__init__(sess, P0, Q_shard, lr, reg, "lazy")
+        self.item_nums, self.rank, self.world = int(item_nums), int(rank), int(world)
+        assert self.Q.shape[0] >= shard_rows(item_nums, world)
+        self.stats = _lib.ShardStats()
+
+    def train_epoch(self, u, i, j, batch_size):
+        """Collective.  u: row ids inside this rank's user shard; i, j: GLOBAL item ids (int32 device tensors).
+        Returns the per-batch losses summed over ranks."""
+        s = self.sess
+        n = int(u.numel())
+        loss = s.empty((-(-n // batch_size),), torch.float32)
+        s.ctx.check(s.lib.crec_bpr_train_epoch_sharded(s.ctx.h, C.byref(self.tables), self.item_nums, C.byref(self.adam),
+                                                       s.ptr(u), s.ptr(i), s.ptr(j), n, int(batch_size), s.ptr(loss),
+                                                       C.byref(self.stats), s.stream_ptr()))
+        return loss
+
+    def stats_dict(self):
+        return {k: int(getattr(self.stats, k)) for k, _ in _lib.ShardStats._fields_}

@@ -49,14 +49,23 @@ int crec_ctx_create(int device, crec_ctx **out);
 void crec_ctx_destroy(crec_ctx *ctx);
 /* ctx == NULL: the reason the last crec_ctx_create on this process failed */
 const char *crec_last_error(const crec_ctx *ctx);
+/* Tuning / test options of a ctx (no reference counterpart: TF1 has no such knobs).  Defaults come from the
+ * environment ONCE at crec_ctx_create (CREC_CH, CREC_WIDE, CREC_WIDE_ROUND, CREC_EVAL_SHAPE, CREC_EVAL_NO_BITMAP);
+ * results never depend on them beyond fp32 summation order ("ch") -- they move work between waves.
+ *   "ch"            occurrences per heavy-row chunk of the BPR step (0 = default: 64 tf1, 16 lazy; 1..255)
+ *   "wide"          tf1 step: occurrences per row wave above which a whole workgroup takes it (-1 default 16, 0 off)
+ *   "wide_round"    experiment: pad the wide groups' workgroups to a multiple of this (0 = the chunk's maximum)
+ *   "eval_shape"    4 / 8: force an eval_sweep workgroup shape where legal (0 = choose)
+ *   "eval_no_bitmap" 1: seen filter by binary search even where per-user bitmaps would fit */
+int crec_ctx_set_option(crec_ctx *ctx, const char *name, int64_t value);
 
 /* ---- measurement: per-kernel time from HIP events recorded on the launch stream ------------
  * While enabled, every kernel launch of this ctx is bracketed by two events and each API call
  * ends with a stream synchronise (so do not time whole-job throughput with it on).
  * kernel_class: 0 bpr_index_batches, 1 bpr_step_fused, 2 bpr_user_side, 3 bpr_item_side,
- *               4 bpr_reduce_loss, 5 eval_sweep, 6 eval_merge, 7 rank_metrics, 8 bpr_steps_persistent (opt-in multi-step launch; heavy rows are finished by their last chunk wave), 9 bpr_adam_dense,
+ *               4 bpr_reduce_loss, 5 eval_sweep, 6 eval_merge, 7 rank_metrics, 8 (unused), 9 bpr_adam_dense,
  *               10 rows_index_batches, 11 rows_apply, 12 small_adam_dense, 13 ncf_tile, 14 fm_instances, 15 cml_instances,
- *               16 ncf_pair_logits.
+ *               16 ncf_pair_logits, 17 shard_plan_batches, 18 shard_serve_rows, 19 shard_owner_apply.
  * enable(.., 1) also clears the accumulated totals. */
 int crec_profile_enable(crec_ctx *ctx, int on);
 int crec_profile_read(const crec_ctx *ctx, int kernel_class, double *total_ms, int64_t *launches);
@@ -234,6 +243,36 @@ int crec_comm_init(crec_ctx *ctx, int rank, int world, const void *id);
 int crec_comm_destroy(crec_ctx *ctx);
 int crec_bpr_train_epoch_dp(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, const int32_t *u, const int32_t *i,
                             const int32_t *j, int64_t N, int32_t B, float *loss_per_batch, void *stream);
+
+/* ---- row-sharded training over the GPUs of one node (device) ------------------------------------------
+ * No reference counterpart: the reference is one process on one device (main.py:40-47).  This is the form of the
+ * BPR step for tables that outgrow a GPU (BASELINE.json configs[4]: 10 M users x 1 M items, d = 128):
+ *   users -- rows of P, their slots, their triples -- are range-sharded: all P traffic is local;
+ *   items are dealt round-robin: item g is local row g / G of rank g % G, whose Q shard holds ceil(I / G) rows;
+ *   per batch: the referenced rows travel to the ranks that reference them (all-to-all-v), every rank runs the lazy
+ *   BPR step on its own triples against those rows, the per-row gradient sums travel back to their owners
+ *   (all-to-all-v), and the owner adds them in rank order and applies lazy Adam.  The row-id lists are exchanged
+ *   once per chunk of batches, not per step.  No dense all-reduce of a table.
+ * A global batch of G * B triples processed this way equals the single-GPU lazy step on the concatenated batch up
+ * to the order of the fp32 additions (a row's sum is formed per rank first, then over ranks in rank order).
+ *
+ * Communicator: crec_comm_init (RCCL, one process per GPU) or crec_comm_init_local (the ranks are `world` ctxs of
+ * THIS process, each driven by its own host thread -- one per GPU of a node, or several ranks on one GPU in tests);
+ * a ctx with neither is a world of one.
+ *   t->P, slots   [U_local, d]   this rank's user rows; u = row ids inside the shard
+ *   t->Q, slots   [>= ceil(I_global / G), d]   this rank's item shard; i, j = GLOBAL item ids
+ *   collective: every rank passes the same number of batches ceil(N / B), N >= 1; adam_mode lazy.
+ *   loss_per_batch [dev] receives the sum over ranks.  stats (optional) accumulates what this rank sent to OTHER ranks. */
+typedef struct {
+    int64_t bytes_ids_sent, bytes_rows_sent, bytes_grads_sent; /* to other ranks */
+    int64_t rows_requested, rows_served;                       /* unique (batch, item) pairs asked for / served, incl. own */
+    int64_t max_rows_served_per_batch;
+    int64_t steps;
+} crec_shard_stats;
+int crec_comm_init_local(crec_ctx **ctxs, int world);
+int crec_bpr_train_epoch_sharded(crec_ctx *ctx, const crec_bpr_tables *t, int64_t I_global, crec_adam *opt, const int32_t *u,
+                                 const int32_t *i, const int32_t *j, int64_t N, int32_t B, float *loss_per_batch,
+                                 crec_shard_stats *stats, void *stream);
 
 /* ---- full-catalogue evaluation (device) -------------------------------------------------
  * replaces sess.run(self.pre_scores) (BPR._predict rs branch, BPR.py:51) + np.argsort +

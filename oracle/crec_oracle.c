@@ -572,3 +572,66 @@ void orc_adam_dense(float *var, float *m, float *v, const float *g, int64_t rows
     for (int64_t r = 0; r < rows; r++)
         adam_row(var + r * d, m + r * d, v + r * d, g + r * d, d, lr_t, beta1, beta2, eps);
 }
+
+/* ------------------------------------------------------------------------
+ * Row-sharded form of the lazy step (include/crec.h "row-sharded training"): users sharded over
+ * ranks, items owned round-robin.  The arithmetic of one rank, on a full-size Q for simplicity (the oracle does
+ * not model where rows live, only in which order sums are formed):
+ * orc_bpr_shard_local: this rank's triples -> lazy Adam on the P rows they touch; for every item row they
+ *                   reference, the rank's gradient sum dQ (i-slices then j-slices, position order, l2 term
+ *                   per occurrence) and the occurrence count cntQ; local loss.
+ * orc_adam_rows_lazy : lazy Adam of the rows with touched[r] != 0 from a gradient the caller has summed over
+ *                   ranks in rank order.
+ * Summing dQ over ranks and applying orc_adam_rows_lazy equals orc_bpr_step(adam_mode 1) on the concatenated
+ * batch up to fp32 add order.
+ * --------------------------------------------------------------------- */
+void orc_bpr_shard_local(float *P, const float *Q, float *mP, float *vP, int64_t U, int64_t I, int d, const int32_t *u,
+                         const int32_t *i, const int32_t *j, int64_t B, float reg, float lr_t, float beta1, float beta2,
+                         float eps, float *gP, int32_t *cntP, float *dQ, int32_t *cntQ, double *loss_out)
+{
+    memset(gP, 0, sizeof(float) * (size_t)U * d);
+    memset(cntP, 0, sizeof(int32_t) * (size_t)U);
+    memset(dQ, 0, sizeof(float) * (size_t)I * d);
+    memset(cntQ, 0, sizeof(int32_t) * (size_t)I);
+    double loss = 0.0;
+    float *sb = (float *)malloc(sizeof(float) * (size_t)(B > 0 ? B : 1));
+    for (int64_t b = 0; b < B; b++) {
+        const float *pu = P + (int64_t)u[b] * d, *qi = Q + (int64_t)i[b] * d, *qj = Q + (int64_t)j[b] * d;
+        float x = dotf(pu, qi, d) - dotf(pu, qj, d);
+        float s = 1.0f / (1.0f + expf(x));
+        sb[b] = s;
+        float l2 = 0.5f * dotf(pu, pu, d) + 0.5f * dotf(qi, qi, d) + 0.5f * dotf(qj, qj, d);
+        loss += (double)tf_softplus(-x) + (double)(reg * l2);
+        float *g = gP + (int64_t)u[b] * d;
+        for (int k = 0; k < d; k++)
+            g[k] = g[k] + ((-s) * (qi[k] - qj[k]) + reg * pu[k]);
+        cntP[u[b]]++;
+    }
+    for (int64_t b = 0; b < B; b++) {
+        const float *pu = P + (int64_t)u[b] * d, *qi = Q + (int64_t)i[b] * d;
+        float *g = dQ + (int64_t)i[b] * d;
+        for (int k = 0; k < d; k++)
+            g[k] = g[k] + ((-sb[b]) * pu[k] + reg * qi[k]);
+        cntQ[i[b]]++;
+    }
+    for (int64_t b = 0; b < B; b++) {
+        const float *pu = P + (int64_t)u[b] * d, *qj = Q + (int64_t)j[b] * d;
+        float *g = dQ + (int64_t)j[b] * d;
+        for (int k = 0; k < d; k++)
+            g[k] = g[k] + (sb[b] * pu[k] + reg * qj[k]);
+        cntQ[j[b]]++;
+    }
+    for (int64_t r = 0; r < U; r++)
+        if (cntP[r])
+            adam_row(P + r * d, mP + r * d, vP + r * d, gP + r * d, d, lr_t, beta1, beta2, eps);
+    free(sb);
+    *loss_out = loss;
+}
+
+void orc_adam_rows_lazy(float *var, float *m, float *v, const float *g, const int32_t *touched, int64_t rows, int d,
+                        float lr_t, float beta1, float beta2, float eps)
+{
+    for (int64_t r = 0; r < rows; r++)
+        if (touched[r])
+            adam_row(var + r * d, m + r * d, v + r * d, g + r * d, d, lr_t, beta1, beta2, eps);
+}

@@ -291,4 +291,19 @@ class FM(Model):
         y = self._float(y)
         yp = self.y_pre(w, x_idx, x_val)
         self.last_y_pre = yp.detach().numpy()
+        if w.get("_abs") is not None:
+            # rounding scale of d loss / d vif beyond sum|c_k|: the slot gradient -2(y-y')*x_f*(S - x_f*v_f), S = sum_f x_f*v_f,
+            # is a DIFFERENCE of two terms each rounded at its own magnitude (the sum / sum-of-squares trick, FM.py:43-49;
+            # autograd: x_f*S and -x_f^2*v_f), so its rounding error scales with |x_f|*(|S| + |x_f*v_f|), not with the result
+            xi = np.asarray(x_idx).reshape(-1)
+            xv = np.asarray(x_val, dtype=np.float64)
+            ve = w["vif"].detach().numpy().astype(np.float64)[np.asarray(x_idx)]  # [B,F,d]
+            xve = xv[:, :, None] * ve
+            S = xve.sum(1)
+            r = 2.0 * np.abs(np.asarray(y, dtype=np.float64) - yp.detach().numpy().astype(np.float64))
+            # (plain fp32 rounding of the two terms, ~8 ulp: 5e-7, i.e. 0.05 * NOISE of their magnitude)
+            term = 0.05 * r[:, None, None] * np.abs(xv)[:, :, None] * (np.abs(S)[:, None, :] + np.abs(xve))
+            a = np.zeros(tuple(w["vif"].shape), np.float64)
+            np.add.at(a, xi, term.reshape(len(xi), -1))
+            w["_abs"]["vif"] = w["_abs"].get("vif", 0) + a
         return ((y - yp) ** 2).sum() + self.reg * (_l2(w["wi"]) + _l2(w["vif"]))

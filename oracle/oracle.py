@@ -16,7 +16,7 @@ _SO = os.path.join(_HERE, "liboracle.so")
 __all__ = [
     "build", "Rng", "to_csr", "dict_from_csr", "sample_pairwise", "sample_pointwise", "sample_cml",
     "AdamSchedule", "BprModel", "bpr_step", "scores", "topk", "rank_metrics",
-    "cal_ranking_metrics_py", "test_model_rs_py", "train_model_py", "tf_softplus_np", "bpr_dp_local", "adam_dense", "test_model_loo_py",
+    "cal_ranking_metrics_py", "test_model_rs_py", "train_model_py", "tf_softplus_np", "bpr_dp_local", "adam_dense", "test_model_loo_py", "bpr_shard_local", "adam_rows_lazy", "sharded_steps",
 ]
 
 
@@ -309,6 +309,54 @@ def adam_dense(m, g, lr_t):
     g = np.ascontiguousarray(g, dtype=np.float32)
     lib().orc_adam_dense(_p(m.Q), _p(m.mQ), _p(m.vQ), _p(g), C.c_int64(len(m.Q)), C.c_int(m.Q.shape[1]), C.c_float(lr_t),
                          C.c_float(m.sched.beta1), C.c_float(m.sched.beta2), C.c_float(m.sched.eps))
+
+
+def bpr_shard_local(m, u, i, j, lr_t):
+    """Row-sharded lazy step, one rank's half (orc_bpr_shard_local): lazy Adam on the rank's touched rows of m.P in
+    place; returns (dQ [I,d] the rank's per-item gradient sums, cntQ [I] occurrences, loss)."""
+    u, i, j = (np.ascontiguousarray(x, dtype=np.int32) for x in (u, i, j))
+    dQ, cntQ = np.empty_like(m.Q), np.empty(len(m.Q), np.int32)
+    loss = C.c_double()
+    U, d = m.P.shape
+    lib().orc_bpr_shard_local(_p(m.P), _p(m.Q), _p(m.mP), _p(m.vP), C.c_int64(U), C.c_int64(len(m.Q)), C.c_int(d), _p(u),
+                              _p(i), _p(j), C.c_int64(len(u)), C.c_float(m.reg), C.c_float(lr_t), C.c_float(m.sched.beta1),
+                              C.c_float(m.sched.beta2), C.c_float(m.sched.eps), _p(m._gP), _p(m._cP), _p(dQ), _p(cntQ),
+                              C.byref(loss))
+    return dQ, cntQ, loss.value
+
+
+def adam_rows_lazy(m, g, touched, lr_t):
+    """lazy Adam of the Q rows with touched != 0 from the rank-summed gradient (orc_adam_rows_lazy)."""
+    g = np.ascontiguousarray(g, dtype=np.float32)
+    touched = np.ascontiguousarray(touched, dtype=np.int32)
+    lib().orc_adam_rows_lazy(_p(m.Q), _p(m.mQ), _p(m.vQ), _p(g), _p(touched), C.c_int64(len(m.Q)), C.c_int(m.Q.shape[1]),
+                             C.c_float(lr_t), C.c_float(m.sched.beta1), C.c_float(m.sched.beta2), C.c_float(m.sched.eps))
+
+
+def sharded_steps(P0, Q0, user_ranges, streams, B, lr=1e-3, reg=0.01):
+    """The row-sharded epoch as one process would compute it (arithmetic order of include/crec.h "row-sharded
+    training"): rank r owns users [lo, hi) = user_ranges[r] and runs its own triples streams[r] = (u local ids, i, j
+    global item ids); per step every rank forms its per-item gradient sums against the step's Q, the sums are added
+    over ranks in rank order, lazy Adam on the touched rows.  Returns (P full, Q, losses per step summed over ranks)."""
+    G = len(user_ranges)
+    ms = [BprModel(P0[lo:hi], Q0, lr=lr, reg=reg, adam_mode=1) for lo, hi in user_ranges]
+    owner = BprModel(P0[:1], Q0, lr=lr, reg=reg, adam_mode=1)  # holds Q and its slots
+    nb = max(-(-len(s[0]) // B) for s in streams)
+    losses = []
+    for b in range(nb):
+        lr_t = float(owner.sched.next(1)[0])
+        g, touched, tot = np.zeros_like(owner.Q), np.zeros(len(owner.Q), np.int32), 0.0
+        for r in range(G):
+            u, i, j = (x[b * B:(b + 1) * B] for x in streams[r])
+            ms[r].Q = owner.Q  # every rank sees the step's Q
+            dQ, cnt, loss = bpr_shard_local(ms[r], u, i, j, lr_t)
+            g = g + dQ if r else dQ  # rank order; a rank that does not touch a row adds an exact 0
+            touched += cnt
+            tot += loss
+        adam_rows_lazy(owner, g, touched, lr_t)
+        losses.append(tot)
+    P = np.concatenate([m.P for m in ms])
+    return P, owner.Q, np.array(losses), owner
 
 
 def test_model_loo_py(pair_score_fn, test_users, ui_test, neg_samples, topk_list, batch_size_t, ascending=False):

@@ -12,6 +12,7 @@ import numpy as np
 
 ATOL_VAR = 5e-7
 LOOSE_FRAC = 0.005
+MARGINS = []  # (tensor, what, worst |delta| / bound, max |delta|) of every comparison of the session (conftest writes them out)
 
 
 def _np(t):
@@ -26,8 +27,10 @@ def assert_adam_close(om, name, var, m=None, v=None, lr=1e-3, report=None):
     def check(what, dev, refv, bound):
         dv = np.abs(_np(dev).reshape(shape) - refv)
         worst = float((dv / bound).max()) if dv.size else 0.0
+        rec = (name, what, worst, float(dv.max()) if dv.size else 0.0)
+        MARGINS.append(rec)
         if report is not None:
-            report.append((name, what, worst, float(dv.max()) if dv.size else 0.0))
+            report.append(rec)
         if worst > 1.0:
             k = np.unravel_index(np.argmax(dv / bound), shape)
             raise AssertionError("%s.%s: |delta| %.3e > bound %.3e at %s (ref %.6e); %d of %d elements beyond their bound"

@@ -21,7 +21,7 @@ def golden_dir():
 
 # The GPU suite runs with -x: the headline path (BPR step, eval, metrics, class surface, data-parallel, LOO) goes
 # first so that a failure in a side model cannot hide it.
-_ORDER = ["test_gpu_parity.py", "test_gpu_sampler.py", "test_gpu_big.py", "test_gpu_ncf.py", "test_gpu_fm.py", "test_gpu_cml.py"]
+_ORDER = ["test_gpu_parity.py", "test_gpu_sharded.py", "test_gpu_sampler.py", "test_gpu_big.py", "test_gpu_ncf.py", "test_gpu_fm.py", "test_gpu_cml.py"]
 
 
 def pytest_collection_modifyitems(config, items):
@@ -29,3 +29,19 @@ def pytest_collection_modifyitems(config, items):
         name = os.path.basename(str(item.fspath))
         return _ORDER.index(name) if name in _ORDER else len(_ORDER)
     items.sort(key=key)  # stable: file order inside a module is kept
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """How much of the rounding envelope the GPU comparisons used (tests/_adam_close.py): kept as evidence under gpurun_out/."""
+    mod = sys.modules.get("_adam_close")
+    out = os.path.join(ROOT, "gpurun_out")
+    if mod is None or not mod.MARGINS or not os.path.isdir(out):
+        return
+    import json
+    worst = {}
+    for name, what, ratio, dmax in mod.MARGINS:
+        k = what
+        if ratio > worst.get(k, (0, 0, ""))[0]:
+            worst[k] = (ratio, dmax, name)
+    with open(os.path.join(out, "adam_margins.json"), "w") as f:
+        json.dump({"comparisons": len(mod.MARGINS), "worst_ratio_of_bound": worst}, f)

@@ -75,11 +75,9 @@ def main():
         K = int(g.choice([1, 5, 10, 20, 24, 32]))
         users = np.asarray(sorted(g.choice(U, size=int(g.integers(1, U + 1)), replace=False)), np.int32)
         asc = bool(g.integers(0, 2))
-        os.environ["CREC_EVAL_SHAPE"] = str(g.choice(["4", "8"]))
-        if g.random() < 0.5:
-            os.environ["CREC_EVAL_NO_BITMAP"] = "1"
-        else:
-            os.environ.pop("CREC_EVAL_NO_BITMAP", None)
+        shape = int(g.choice([4, 8]))
+        sess.ctx.set_option("eval_shape", shape)
+        sess.ctx.set_option("eval_no_bitmap", int(g.random() < 0.5))
         try:
             seen_items = data.seen_csr[1] if len(data.seen_csr[1]) else np.zeros(1, np.int32)
             ids, sc = runtime.eval_topk(sess, st.P, st.Q, sess.to_dev(users), sess.to_dev(data.seen_csr[0]), sess.to_dev(seen_items), K, asc)
@@ -89,7 +87,7 @@ def main():
             assert np.array_equal(sc.cpu().numpy(), oval), "top-K scores"
         except AssertionError as e:
             fails += 1
-            print("EVAL FAIL U=%d I=%d d=%d K=%d asc=%s shape=%s: %s" % (U, I, d, K, asc, os.environ.get("CREC_EVAL_SHAPE"), e))
+            print("EVAL FAIL U=%d I=%d d=%d K=%d asc=%s shape=%s: %s" % (U, I, d, K, asc, shape, e))
         n_eval += 1
         # ---- device sampler: the rule -----------------------------------------------------------------------------------
         try:

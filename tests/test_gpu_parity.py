@@ -77,8 +77,8 @@ def test_bpr_batch_sizes_and_ragged_tail(sess, B):
     _assert_state_close(st, om, atol=2e-6)
 
 
-def test_bpr_launch_padding_does_not_change_results(sess, monkeypatch):
-    """The workgroups in front of the row waves are padded (to the chunk's largest count, or with CREC_WIDE_ROUND to a
+def test_bpr_launch_padding_does_not_change_results(sess):
+    """The workgroups in front of the row waves are padded (to the chunk's largest count, or with option wide_round to a
     multiple of this batch's own) only to keep every row on one XCD from step to step: bitwise the same tables."""
     data = synthetic("S-ml100k")
     P0, Q0 = _tables(12, data.user_nums, data.item_nums, 64)
@@ -86,14 +86,14 @@ def test_bpr_launch_padding_does_not_change_results(sess, monkeypatch):
     u, i, j = (sess.to_dev(a) for a in sess.ctx.sample_pairwise(data.train_csr, data.item_nums, 4))
     n = 6 * 6144 + 55
     out = []
-    for rnd in (None, "1", "7", "8"):
-        if rnd is None:
-            monkeypatch.delenv("CREC_WIDE_ROUND", raising=False)
-        else:
-            monkeypatch.setenv("CREC_WIDE_ROUND", rnd)
-        st = runtime.BprState(sess, P0, Q0, lr=1e-3, reg=0.01, adam_mode="tf1")
-        loss = st.train_epoch(u[:n], i[:n], j[:n], 6144)
-        out.append([t.cpu().numpy() for t in (loss, st.P, st.Q, st.vP, st.mQ)])
+    try:
+        for rnd in (0, 1, 7, 8):
+            sess.ctx.set_option("wide_round", rnd)
+            st = runtime.BprState(sess, P0, Q0, lr=1e-3, reg=0.01, adam_mode="tf1")
+            loss = st.train_epoch(u[:n], i[:n], j[:n], 6144)
+            out.append([t.cpu().numpy() for t in (loss, st.P, st.Q, st.vP, st.mQ)])
+    finally:
+        sess.ctx.set_option("wide_round", 0)
     for other in out[1:]:
         for a, b in zip(out[0], other):
             assert np.array_equal(a, b)
@@ -123,30 +123,9 @@ def test_bpr_heavy_duplicates_and_large_scores(sess):
     _assert_state_close(st, om, atol=5e-5)
 
 
-def test_bpr_persistent_launch_matches_per_step_launches(sess, monkeypatch):
-    """CREC_PERSISTENT=1 (all steps of a chunk in one cooperative launch, device-wide barriers between steps): the
-    same tables bit for bit as a launch per step, heavy rows and a ragged last batch included.  Wide groups (a
-    workgroup per overloaded row wave, CREC_WIDE) exist only in the launch-per-step form and add their partial sums in
-    another order, so the comparison runs with them off; the next test pins them against the plain form."""
-    data = synthetic("S-ml100k")
-    P0, Q0 = _tables(5, data.user_nums, data.item_nums, 32)
-    sess.ctx.seed(2)
-    u, i, j = (sess.to_dev(a) for a in sess.ctx.sample_pairwise(data.train_csr, data.item_nums, 4))
-    n = 9 * 6144 + 1000
-    out = []
-    monkeypatch.setenv("CREC_WIDE", "0")
-    for flag in ("0", "1"):
-        monkeypatch.setenv("CREC_PERSISTENT", flag)
-        st = runtime.BprState(sess, P0, Q0, lr=1e-3, reg=0.01, adam_mode="tf1")
-        loss = st.train_epoch(u[:n], i[:n], j[:n], 6144)
-        out.append([t.cpu().numpy() for t in (loss, st.P, st.Q, st.mP, st.vQ)])
-    for a, b in zip(*out):
-        assert np.array_equal(a, b)
-
-
-@pytest.mark.parametrize("threshold", ["1", "8", "24"])
-def test_bpr_wide_groups_match_plain_row_waves(sess, monkeypatch, threshold):
-    """tf1 step with overloaded row waves handed to whole workgroups (CREC_WIDE = occurrences per row wave above which
+@pytest.mark.parametrize("threshold", [1, 8, 24])
+def test_bpr_wide_groups_match_plain_row_waves(sess, threshold):
+    """tf1 step with overloaded row waves handed to whole workgroups (option wide = occurrences per row wave above which
     that happens; 1: nearly every group that has records) against the same epoch with the mechanism off: same tables up
     to the order of the fp32 partial sums, every row written exactly once (slots of untouched rows decay identically)."""
     data = synthetic("S-ml100k")
@@ -155,18 +134,21 @@ def test_bpr_wide_groups_match_plain_row_waves(sess, monkeypatch, threshold):
     u, i, j = (sess.to_dev(a) for a in sess.ctx.sample_pairwise(data.train_csr, data.item_nums, 4))
     n = 5 * 6144 + 777
     out = []
-    for wide in ("0", threshold):
-        monkeypatch.setenv("CREC_WIDE", wide)
+    try:
+        for wide in (0, threshold):
+            sess.ctx.set_option("wide", wide)
+            st = runtime.BprState(sess, P0, Q0, lr=1e-3, reg=0.01, adam_mode="tf1")
+            loss = st.train_epoch(u[:n], i[:n], j[:n], 6144)
+            out.append([t.cpu().numpy() for t in (loss, st.P, st.Q, st.mP, st.vP, st.mQ, st.vQ)])
+        np.testing.assert_allclose(out[1][0], out[0][0], rtol=1e-6)
+        for a, b in zip(out[0][1:], out[1][1:]):
+            np.testing.assert_allclose(b, a, rtol=0, atol=2e-6)
+        # a second run with the mechanism on is bitwise the first: the partial sums have a fixed order
         st = runtime.BprState(sess, P0, Q0, lr=1e-3, reg=0.01, adam_mode="tf1")
-        loss = st.train_epoch(u[:n], i[:n], j[:n], 6144)
-        out.append([t.cpu().numpy() for t in (loss, st.P, st.Q, st.mP, st.vP, st.mQ, st.vQ)])
-    np.testing.assert_allclose(out[1][0], out[0][0], rtol=1e-6)
-    for a, b in zip(out[0][1:], out[1][1:]):
-        np.testing.assert_allclose(b, a, rtol=0, atol=2e-6)
-    # a second run with the mechanism on is bitwise the first: the partial sums have a fixed order
-    st = runtime.BprState(sess, P0, Q0, lr=1e-3, reg=0.01, adam_mode="tf1")
-    st.train_epoch(u[:n], i[:n], j[:n], 6144)
-    assert np.array_equal(st.Q.cpu().numpy(), out[1][2]) and np.array_equal(st.vP.cpu().numpy(), out[1][4])
+        st.train_epoch(u[:n], i[:n], j[:n], 6144)
+        assert np.array_equal(st.Q.cpu().numpy(), out[1][2]) and np.array_equal(st.vP.cpu().numpy(), out[1][4])
+    finally:
+        sess.ctx.set_option("wide", -1)
 
 
 def test_bpr_ml100k_shape_full_epoch(sess):
@@ -236,16 +218,18 @@ def _eval_both(sess, data, P, Q, K, ascending=False, users=None):
 @pytest.mark.parametrize("d", [4, 32, 64, 128, 256])
 @pytest.mark.parametrize("ascending", [False, True])
 @pytest.mark.parametrize("shape", ["4", "8", "8-search"])  # waves per workgroup of eval_sweep (8: where K and d allow it);
-def test_eval_topk_bit_exact(sess, d, ascending, shape, monkeypatch):  # "-search": binary-search seen filter, no bitmaps
-    if shape.endswith("-search"):
-        monkeypatch.setenv("CREC_EVAL_NO_BITMAP", "1")
-        shape = shape.split("-")[0]
-    monkeypatch.setenv("CREC_EVAL_SHAPE", shape)
+def test_eval_topk_bit_exact(sess, d, ascending, shape):  # "-search": binary-search seen filter, no bitmaps
     data = _toy_data(5, 333, 700, 1, 120, test_every=1)
     P, Q = _tables(11, data.user_nums, data.item_nums, d, scale=1.0)
     Q[10] = Q[9]
     Q[500] = Q[9]  # exact score ties across tiles -> lower id first
-    ids, sc, oids, oval, _ = _eval_both(sess, data, P, Q, 20, ascending)
+    try:
+        sess.ctx.set_option("eval_no_bitmap", int(shape.endswith("-search")))
+        sess.ctx.set_option("eval_shape", int(shape.split("-")[0]))
+        ids, sc, oids, oval, _ = _eval_both(sess, data, P, Q, 20, ascending)
+    finally:
+        sess.ctx.set_option("eval_no_bitmap", 0)
+        sess.ctx.set_option("eval_shape", 0)
     assert np.array_equal(ids.cpu().numpy(), oids)
     assert np.array_equal(sc.cpu().numpy(), oval)
 
@@ -258,11 +242,11 @@ def test_eval_topk_edges(sess):
     data = RankingData(5, I, ui_train, {0: [36], 1: [0], 2: [5], 3: [1], 4: [2]})
     P, Q = _tables(12, 5, I, 16, scale=1.0)
     for K, shape in ((1, "4"), (1, "8"), (20, "4"), (20, "8"), (24, "8"), (32, "8")):  # K = 32 only has the 4-wave shape
-        os.environ["CREC_EVAL_SHAPE"] = shape
+        sess.ctx.set_option("eval_shape", int(shape))
         try:
             ids, sc, oids, oval, _ = _eval_both(sess, data, P, Q, K)
         finally:
-            del os.environ["CREC_EVAL_SHAPE"]
+            sess.ctx.set_option("eval_shape", 0)
         assert np.array_equal(ids.cpu().numpy(), oids) and np.array_equal(sc.cpu().numpy(), oval)
     ids = ids.cpu().numpy()
     assert (ids[0] >= 0).sum() == 5 and (ids[1] == -1).all() and (ids[2] >= 0).all()

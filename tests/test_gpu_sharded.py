@@ -1,0 +1,165 @@
+"""Row-sharded BPR step (crec_bpr_train_epoch_sharded, BASELINE configs[4] path) on ONE MI355X.
+
+World sizes 2 and 4 run as ranks of an in-process local group (crec_comm_init_local): one ctx, one host thread and
+one stream per rank, all on cuda:0 -- the REAL kernels and the REAL exchange sequence (request lists per chunk,
+rows forward / gradient rows back per step as all-to-all-v), with device copies standing in for xGMI.  Checked
+  * against the oracle's restatement of the sharded arithmetic (per-rank sums, then rank order): tight bounds;
+  * 1 rank == 2 ranks == 4 ranks on the same global batches, up to the order of the fp32 additions;
+  * world of one against the plain lazy step (crec_bpr_train_epoch) on the same triples.
+Index work (compact ids, request lists) is checked bit-exact through its consequences: any wrong row id shows up as
+an O(1e-3) error in a table row."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from cleverrec_amd import parallel, runtime
+
+pytestmark = pytest.mark.gpu
+
+
+def _tables(seed, U, I, d, scale=0.01):
+    g = np.random.Generator(np.random.PCG64(seed))
+    return (g.standard_normal((U, d)) * scale).astype(np.float32), (g.standard_normal((I, d)) * scale).astype(np.float32)
+
+
+def _streams(seed, U, I, G, n_per_rank, zipf=True):
+    """per-rank triples: users from the rank's own range (local ids), positives popular-heavy, negatives uniform"""
+    g = np.random.Generator(np.random.PCG64(seed))
+    out, ranges = [], []
+    for r in range(G):
+        lo, hi = parallel.user_range(U, r, G)
+        n = n_per_rank[r]
+        u = g.integers(0, hi - lo, n).astype(np.int32)
+        i = (np.minimum(g.zipf(1.3, n) - 1, I - 1) if zipf else g.integers(0, I, n)).astype(np.int32)
+        j = g.integers(0, I, n).astype(np.int32)
+        out.append((u, i, j))
+        ranges.append((lo, hi))
+    return out, ranges
+
+
+def _run_sharded(G, P0, Q0, ranges, streams, B, d, lr=1e-3, reg=0.01, epochs=1):
+    """G ranks of a local group on cuda:0 -> (P full, Q full, losses [nb], stats of every rank)"""
+    I = len(Q0)
+    sessions = [runtime.Session(0) for _ in range(G)]
+    if G > 1:
+        parallel.init_local_group(sessions)
+    states, result, errors = [None] * G, [None] * G, []
+
+    def work(r):
+        try:
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                s = sessions[r]
+                lo, hi = ranges[r]
+                st = parallel.ShardedBprState(s, P0[lo:hi], parallel.shard_items(Q0, r, G), I, lr, reg, r, G)
+                u, i, j = (s.to_dev(x) for x in streams[r])
+                losses = [st.train_epoch(u, i, j, B).cpu().numpy() for _ in range(epochs)]
+                torch.cuda.current_stream().synchronize()
+                states[r] = st
+                result[r] = (st.P.cpu().numpy(), st.Q.cpu().numpy(), np.concatenate(losses), st.stats_dict())
+        except Exception as e:  # noqa: BLE001
+            errors.append((r, e))
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(G)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+    assert not any(t.is_alive() for t in threads), "a rank hung"
+    if errors:
+        raise errors[0][1]
+    P = np.concatenate([x[0] for x in result])
+    Q = parallel.unshard_items([x[1] for x in result], I)
+    for r in range(1, G):
+        assert np.array_equal(result[r][2], result[0][2])  # every rank holds the same all-reduced losses
+    stats = [x[3] for x in result]
+    for s in sessions:
+        s.close()
+    return P, Q, result[0][2], stats
+
+
+@pytest.mark.parametrize("G", [1, 2, 4])
+@pytest.mark.parametrize("d", [16, 128])
+def test_sharded_matches_oracle(G, d):
+    U, I, B = 400, 301, 256  # 301: not a multiple of any G, so the last shard rows are padding
+    P0, Q0 = _tables(3, U, I, d)
+    n = [3 * B + 40, 3 * B + 7, 2 * B + 1, 3 * B][:G]  # ragged last batches, every rank 3 batches
+    streams, ranges = _streams(5, U, I, G, n)
+    P, Q, loss, stats = _run_sharded(G, P0, Q0, ranges, streams, B, d)
+    oP, oQ, oloss, _ = oracle.sharded_steps(P0, Q0, ranges, streams, B)
+    np.testing.assert_allclose(loss, oloss, rtol=1e-5)
+    np.testing.assert_allclose(P, oP, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(Q, oQ, rtol=0, atol=2e-6)
+    # what was exchanged: every (batch, unique item) pair once, and served exactly as often as requested
+    want = sum(len(np.unique(np.concatenate([i[b * B:(b + 1) * B], j[b * B:(b + 1) * B]]))) for _, i, j in streams for b in range(3))
+    assert sum(s["rows_requested"] for s in stats) == want == sum(s["rows_served"] for s in stats)
+    if G == 1:
+        assert stats[0]["bytes_rows_sent"] == 0 and stats[0]["bytes_grads_sent"] == 0
+    else:
+        assert sum(s["bytes_rows_sent"] for s in stats) == sum(s["bytes_grads_sent"] for s in stats) > 0
+
+
+def test_one_two_four_ranks_agree_on_the_same_global_batches():
+    """The same global batches (rank-major concatenation of the ranks' batches) on 1, 2 and 4 ranks: same losses,
+    same tables up to fp32 add order (a row's gradient is summed per rank first, then over ranks)."""
+    U, I, B4, d = 512, 257, 128, 64
+    P0, Q0 = _tables(9, U, I, d)
+    streams4, ranges4 = _streams(11, U, I, 4, [4 * B4] * 4)
+    glob = [(u + lo, i, j) for (u, i, j), (lo, hi) in zip(streams4, ranges4)]
+
+    def merged(G):  # the 4 ranks' batches regrouped for G ranks: rank r of G takes the users of 4/G consecutive quarter-ranks
+        per = 4 // G
+        out, rng = [], []
+        for r in range(G):
+            lo, hi = ranges4[r * per][0], ranges4[r * per + per - 1][1]
+            parts = glob[r * per:(r + 1) * per]
+            u = np.concatenate([np.concatenate([p[0][b * B4:(b + 1) * B4] for p in parts]) for b in range(4)]) - lo
+            i = np.concatenate([np.concatenate([p[1][b * B4:(b + 1) * B4] for p in parts]) for b in range(4)])
+            j = np.concatenate([np.concatenate([p[2][b * B4:(b + 1) * B4] for p in parts]) for b in range(4)])
+            out.append((u.astype(np.int32), i, j))
+            rng.append((lo, hi))
+        return out, rng
+
+    res = {}
+    for G in (1, 2, 4):
+        st, rg = merged(G)
+        assert rg == [parallel.user_range(U, r, G) for r in range(G)]
+        res[G] = _run_sharded(G, P0, Q0, rg, st, B4 * (4 // G), d)
+    for G in (2, 4):
+        np.testing.assert_allclose(res[G][2], res[1][2], rtol=1e-6)
+        for a, b in ((res[G][0], res[1][0]), (res[G][1], res[1][1])):
+            diff = np.abs(a - b)
+            assert diff.max() <= 2e-5 and (diff > 2e-6).mean() < 1e-3  # a different add order: nearly every element tight
+
+
+def test_world_of_one_matches_plain_lazy_step():
+    """No communicator at all: the sharded epoch (plan, compact table, owner apply) against crec_bpr_train_epoch (lazy)
+    on the same triples -- heavy rows included (a 40-item catalogue: every popular item has > 16 occurrences)."""
+    U, I, B, d = 300, 40, 1024, 32
+    P0, Q0 = _tables(4, U, I, d)
+    streams, ranges = _streams(6, U, I, 1, [2 * B + 100])
+    P, Q, loss, _ = _run_sharded(1, P0, Q0, ranges, streams, B, d, epochs=2)
+    sess = runtime.Session(0)
+    st = runtime.BprState(sess, P0, Q0, lr=1e-3, reg=0.01, adam_mode="lazy")
+    u, i, j = (sess.to_dev(x) for x in streams[0])
+    ref = np.concatenate([st.train_epoch(u, i, j, B).cpu().numpy() for _ in range(2)])
+    np.testing.assert_allclose(loss, ref, rtol=1e-6)
+    np.testing.assert_allclose(P, st.P.cpu().numpy(), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(Q, st.Q.cpu().numpy(), rtol=0, atol=2e-6)
+    sess.close()
+
+
+def test_sharded_c5_row_width_and_batch():
+    """BASELINE configs[4] row width and batch (d = 128, B = 6144 per rank) on a scaled-down catalogue, 2 ranks."""
+    U, I, B, d = 20000, 5003, 6144, 128
+    P0, Q0 = _tables(8, U, I, d)
+    streams, ranges = _streams(10, U, I, 2, [2 * B, 2 * B])
+    P, Q, loss, stats = _run_sharded(2, P0, Q0, ranges, streams, B, d)
+    oP, oQ, oloss, _ = oracle.sharded_steps(P0, Q0, ranges, streams, B)
+    np.testing.assert_allclose(loss, oloss, rtol=1e-5)
+    np.testing.assert_allclose(P, oP, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(Q, oQ, rtol=0, atol=2e-6)
+    assert all(s["max_rows_served_per_batch"] <= 16384 for s in stats)

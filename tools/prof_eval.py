@@ -11,7 +11,7 @@ def once():
     ids, _ = runtime.eval_topk(sess, P, Q, users, sp, si, 20)
     return runtime.rank_metrics(sess, ids, users, [10, 20], tp, ti)
 for shape in ("4", "8", "4", "8"):
-    os.environ["CREC_EVAL_SHAPE"] = shape
+    sess.ctx.set_option("eval_shape", int(shape))
     once(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(50): once()
