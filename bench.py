@@ -188,6 +188,23 @@ def main():
         out["kernels"] = kern
         out["step_algorithmic_GBs"] = step_bytes / (dt / a.steps) / 1e9
 
+    big_sharded = None
+    if not a.no_extras and not a.no_big and dp:
+        # ---- S-big row-sharded over the N ranks (BASELINE configs[4]; collective: every rank runs it) ----------
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_big
+
+            def big_max(x):
+                tt = torch.tensor([x], dtype=torch.float64, device=sess.device)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                return float(tt.item())
+            big_sharded = bench_big.run_sharded(steps=200, sess=sess, rank=rank, world=world, barrier=fence, max_reduce=big_max)
+        except Exception as e:  # every rank fails or none: the sizes are the same everywhere
+            big_sharded = {"error": repr(e)}
+    if rank == 0 and big_sharded is not None:
+        out["synthetic_big"] = big_sharded
+
     if rank == 0 and prof is not None and world == 1 and not force_dp:  # single-process legs only at N = 1
         U, I = data.user_nums, data.item_nums
         # ---- eval: all test users, full catalogue, K = 20 ---------------------------------------
@@ -216,6 +233,27 @@ def main():
                           "epoch_triples": n_epoch, "epoch_inclusive_triples_per_s_serial": n_epoch / (t_sample + epoch_gpu_s),
                           "epoch_inclusive_triples_per_s_overlapped": n_epoch / max(t_sample, epoch_gpu_s)}
 
+        # measured, not derived: epochs through the drop-in sampler wrapper with the next epoch's sample drawn ahead on
+        # a host thread (utils/sampler.py; bit-identical stream) into page-locked memory, uploaded asynchronously
+        from cleverrec_amd.utils import sampler as S
+        S.drop_prefetch()
+        np.random.seed(1)
+        keep, t_ep = [], []
+        for e in range(6):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            nb_, uu, ii, jj = S.pairwise_ranking_sampler(data, NEG, B, prefetch_next=True)
+            keep = [uu, ii, jj]
+            st.train_epoch(sess.to_dev(uu), sess.to_dev(ii), sess.to_dev(jj), B)
+            torch.cuda.synchronize()
+            t_ep.append(time.perf_counter() - t0)
+        S.drop_prefetch()
+        steady = sorted(t_ep[1:])[len(t_ep[1:]) // 2]
+        out["sampler"]["epoch_inclusive_triples_per_s"] = len(uu) / steady
+        out["sampler"]["epoch_inclusive_note"] = ("measured: median of 5 epochs (sample -> upload -> %d steps), next epoch's sample prefetched on a host "
+                                                  "thread; first epoch (no prefetch) %.1f ms, steady %.1f ms; bound = min(sampler %.0f M/s, GPU %.0f M/s)"
+                                                  % (len(uu) // B, t_ep[0] * 1e3, steady * 1e3, n_epoch / t_sample / 1e6, value / 1e6))
+
         # the optional device sampler (same acceptance rule, counter-based generator: not NumPy-stream compatible)
         ds = runtime.DeviceSampler(sess, data, seed=1)
         ds.pairwise(NEG)
@@ -235,6 +273,7 @@ def main():
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import bench_big
                 out["synthetic_big"] = bench_big.run(steps=200, sess=sess)
+                out["synthetic_big"]["sharded_world1"] = bench_big.run_sharded(steps=200, sess=sess)  # protocol cost
                 import bench_eval_big
                 out["eval_big"] = bench_eval_big.run(sess=sess, reps=2)  # 65536 users x 1 M items: MFMA utilisation
             except Exception as e:  # e.g. not enough free HBM on a shared box

@@ -194,9 +194,11 @@ class Context:
         return out
 
     # ---- samplers (host) ------------------------------------------------------------------------
+    alloc = staticmethod(np.empty)  # (n, dtype) -> ndarray the samplers write into; utils/sampler.py swaps in page-locked memory
+
     def _sample(self, fn, csr, item_nums, neg_ratio, cap, third):
         keys, ptr, items = csr
-        u, i = np.empty(max(cap, 1), np.int32), np.empty(max(cap, 1), np.int32)
+        u, i = self.alloc(max(cap, 1), np.int32), self.alloc(max(cap, 1), np.int32)
         n = C.c_int64()
         self.check(fn(self.h, _np(ptr), _np(items), len(keys), _np(keys), int(item_nums), int(neg_ratio), _np(u), _np(i),
                       _np(third), C.byref(n)))
@@ -204,18 +206,18 @@ class Context:
 
     def sample_pairwise(self, csr, item_nums, neg_ratio):
         cap = int(csr[1][-1]) * neg_ratio
-        j = np.empty(max(cap, 1), np.int32)
+        j = self.alloc(max(cap, 1), np.int32)
         n, u, i = self._sample(self.lib.crec_sample_pairwise, csr, item_nums, neg_ratio, cap, j)
         return u[:n], i[:n], j[:n]
 
     def sample_pointwise(self, csr, item_nums, neg_ratio):
         cap = int(csr[1][-1]) * (1 + neg_ratio)
-        y = np.empty(max(cap, 1), np.float32)
+        y = self.alloc(max(cap, 1), np.float32)
         n, u, i = self._sample(self.lib.crec_sample_pointwise, csr, item_nums, neg_ratio, cap, y)
         return u[:n], i[:n], y[:n]
 
     def sample_cml(self, csr, item_nums, neg_ratio):
         cap = int(csr[1][-1])
-        neg = np.empty(max(cap * neg_ratio, 1), np.int32)
+        neg = self.alloc(max(cap * neg_ratio, 1), np.int32)
         n, u, i = self._sample(self.lib.crec_sample_cml, csr, item_nums, neg_ratio, cap, neg)
         return u[:n], i[:n], neg[:n * neg_ratio].reshape(n, neg_ratio)

@@ -165,6 +165,7 @@ IndexWs layout_index(void *base, int64_t nbc, int64_t B, int64_t U, int64_t I, b
     w.u_rowseg = (int2 *)take(sizeof(int2) * nbc * w.U);
     w.q_rowseg = (int2 *)take(sizeof(int2) * nbc * w.I);
     w.hn = (int32_t *)take(sizeof(int32_t) * nbc * 4);
+    w.nwide = (int32_t *)take(sizeof(int32_t) * nbc * 2); // right behind hn: the host reads both back with one copy
     w.u_hrows = (int4 *)take(sizeof(int4) * nbc * w.HRu);
     w.q_hrows = (int4 *)take(sizeof(int4) * nbc * w.HRq);
     w.u_hitems = (int4 *)take(sizeof(int4) * nbc * w.HIu);
@@ -175,7 +176,6 @@ IndexWs layout_index(void *base, int64_t nbc, int64_t B, int64_t U, int64_t I, b
     w.WMq = w.wide_rows ? 2 * B / (wide_total + 1) + 1 : 0;
     w.u_wide = (int32_t *)take(sizeof(int32_t) * nbc * w.WMu);
     w.q_wide = (int32_t *)take(sizeof(int32_t) * nbc * w.WMq);
-    w.nwide = (int32_t *)take(sizeof(int32_t) * nbc * 2);
     w.bytes = off;
     return w;
 }
@@ -1542,7 +1542,12 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
     const size_t ticket_bytes = sizeof(int32_t) * (size_t)(w0.HRu + w0.HRq);
     if (int rc = crec_reserve(ctx, &ctx->misc, part_bytes + ticket_bytes))
         return rc;
-    CREC_HIP(ctx, hipMemsetAsync((char *)ctx->misc.ptr + part_bytes, 0, ticket_bytes, st));
+    // the finishing wave of a heavy row re-zeroes its counter, so the counters only need clearing when they move
+    if (ctx->tickets_at != (char *)ctx->misc.ptr + part_bytes || ctx->tickets_bytes != ticket_bytes) {
+        CREC_HIP(ctx, hipMemsetAsync((char *)ctx->misc.ptr + part_bytes, 0, ticket_bytes, st));
+        ctx->tickets_at = (char *)ctx->misc.ptr + part_bytes;
+        ctx->tickets_bytes = ticket_bytes;
+    }
 
     StepArgs a{};
     a.ctx = ctx;
@@ -1579,8 +1584,11 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
     // dynamic LDS of the index kernel
     const int cap = (2 * B + 63) / 64 * 64;
     const size_t lds = index_lds_bytes(cap);
-    CREC_HIP(ctx, hipFuncSetAttribute((const void *)bpr_index_batches, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)lds));
+    if (lds > ctx->index_lds_set) { // a driver call per epoch otherwise
+        CREC_HIP(ctx, hipFuncSetAttribute((const void *)bpr_index_batches, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)lds));
+        ctx->index_lds_set = lds;
+    }
 
     bool in_shadow = false; // tf1: which buffer set holds the current tables
     for (int64_t b0 = 0; b0 < nb; b0 += chunk) {
@@ -1593,19 +1601,19 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
         crec_prof_end(ctx, st);
         // the chunk's counts come back into page-locked memory: a pageable destination is staged and costs tens of
         // microseconds per copy, once per epoch -- a tenth of an ml-100k epoch of 45 steps
-        const size_t n_hn = (size_t)nbc * 4, n_nw = (size_t)nbc * 2;
-        if (n_hn + n_nw > ctx->pinned_ints) {
+        // one copy for both arrays: a device-to-host copy costs ~10 us of latency whatever its size
+        const size_t nw_off = (size_t)(w.nwide - w.hn), n_back = nw_off + (size_t)nbc * 2;
+        if (n_back > ctx->pinned_ints) {
             if (ctx->pinned)
                 CREC_HIP(ctx, hipHostFree(ctx->pinned));
             ctx->pinned = nullptr;
             ctx->pinned_ints = 0;
-            CREC_HIP(ctx, hipHostMalloc((void **)&ctx->pinned, sizeof(int32_t) * (n_hn + n_nw) * 2, hipHostMallocDefault));
-            ctx->pinned_ints = (n_hn + n_nw) * 2;
+            CREC_HIP(ctx, hipHostMalloc((void **)&ctx->pinned, sizeof(int32_t) * n_back * 2, hipHostMallocDefault));
+            ctx->pinned_ints = n_back * 2;
         }
-        const int32_t *hn = ctx->pinned, *nwide = ctx->pinned + n_hn;
+        const int32_t *hn = ctx->pinned, *nwide = ctx->pinned + nw_off;
         a.nwide = nwide;
-        CREC_HIP(ctx, hipMemcpyAsync(ctx->pinned, w.hn, sizeof(int32_t) * n_hn, hipMemcpyDeviceToHost, st));
-        CREC_HIP(ctx, hipMemcpyAsync(ctx->pinned + n_hn, w.nwide, sizeof(int32_t) * n_nw, hipMemcpyDeviceToHost, st));
+        CREC_HIP(ctx, hipMemcpyAsync(ctx->pinned, w.hn, sizeof(int32_t) * n_back, hipMemcpyDeviceToHost, st));
         CREC_HIP(ctx, hipStreamSynchronize(st));
         a.pad_wide = a.pad_chunks_u = a.pad_chunks_q = 0;
         for (int64_t b = 0; b < nbc; ++b) {
@@ -1741,7 +1749,12 @@ int sharded_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, int64_t I_global
     const size_t ticket_bytes = sizeof(int32_t) * (size_t)(w0.HRu + w0.HRq);
     if (int rc = crec_reserve(ctx, &ctx->misc, part_bytes + ticket_bytes))
         return rc;
-    CREC_HIP(ctx, hipMemsetAsync((char *)ctx->misc.ptr + part_bytes, 0, ticket_bytes, st));
+    // the finishing wave of a heavy row re-zeroes its counter, so the counters only need clearing when they move
+    if (ctx->tickets_at != (char *)ctx->misc.ptr + part_bytes || ctx->tickets_bytes != ticket_bytes) {
+        CREC_HIP(ctx, hipMemsetAsync((char *)ctx->misc.ptr + part_bytes, 0, ticket_bytes, st));
+        ctx->tickets_at = (char *)ctx->misc.ptr + part_bytes;
+        ctx->tickets_bytes = ticket_bytes;
+    }
     if (int rc = crec_reserve(ctx, &ctx->contrib, sizeof(float) * (size_t)B * d))
         return rc;
 
@@ -1811,7 +1824,10 @@ int sharded_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, int64_t I_global
                                       (int)shard_lds_bytes(cap_plan)));
     const int cap_idx = (2 * B + 63) / 64 * 64;
     const size_t lds_idx = index_lds_bytes(cap_idx);
-    CREC_HIP(ctx, hipFuncSetAttribute((const void *)bpr_index_batches, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_idx));
+    if (lds_idx > ctx->index_lds_set) {
+        CREC_HIP(ctx, hipFuncSetAttribute((const void *)bpr_index_batches, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_idx));
+        ctx->index_lds_set = lds_idx;
+    }
 
     StepArgs a{};
     a.ctx = ctx;

@@ -81,7 +81,10 @@ struct crec_ctx {
     size_t pinned64_n = 0;
     crec_devbuf shadow;   // second buffer set of the tf1-mode ping-pong: P, mP, vP, Q, mQ, vQ
     crec_devbuf loss_ws;  // per-triple loss terms of one chunk
-    crec_devbuf misc;     // small counters
+    crec_devbuf misc;     // heavy-row partials + ticket counters
+    char *tickets_at = nullptr; // where the counters were last cleared (they are re-zeroed by the kernels after use)
+    size_t tickets_bytes = 0;
+    size_t index_lds_set = 0;   // dynamic LDS limit already granted to bpr_index_batches
     int32_t *pinned = nullptr; // page-locked host buffer for the per-chunk counts read back from the index kernel
     size_t pinned_ints = 0;
     // eval workspace (eval_topk.hip)

@@ -27,6 +27,9 @@ class RankingRecommender(Recommender):
         # extension (not in the reference): `sampler_mode=device` draws the epoch on the GPU with the same acceptance
         # rule but its own generator -- statistically equivalent, not NumPy-stream compatible; the default
         # (`mt19937`) is the bit-exact host sampler
+        # extension: draw the next epoch's (bit-exact) sample on a host thread while the GPU runs this one; the index
+        # stream and np.random's state afterwards are unchanged (utils/sampler.py).  `sampler_prefetch=False` turns it off
+        self.sampler_prefetch = str(configs.get('sampler_prefetch', 'True')).lower() not in ('false', '0', 'no')
         self._dev_sampler = None
         if str(configs.get('sampler_mode', 'mt19937')).lower() == 'device':
             self._dev_sampler = runtime.DeviceSampler(sess, data, seed=int(configs.get('seed', 0)))
@@ -53,11 +56,13 @@ class RankingRecommender(Recommender):
             losses = self._train_epoch_device(*cols)
             return float(losses.double().sum().item()) / int(losses.numel())
         if self.is_pairwise == 'True':
-            train_ = pairwise_ranking_sampler(self.data, self.neg_ratio, self.batch_size, fism_like=self.fism_like)
+            train_ = pairwise_ranking_sampler(self.data, self.neg_ratio, self.batch_size, fism_like=self.fism_like,
+                                              prefetch_next=self.sampler_prefetch)
             u, i, j = (s.to_dev(a) for a in train_[1:4])
             losses = self._train_epoch_device(u, i, j)
         else:  # pointwise: (u, i, label) instances (RankingRecommender.py:48-58)
-            train_ = pointwise_ranking_sampler(self.data, self.neg_ratio, self.batch_size, fism_like=self.fism_like)
+            train_ = pointwise_ranking_sampler(self.data, self.neg_ratio, self.batch_size, fism_like=self.fism_like,
+                                               prefetch_next=self.sampler_prefetch)
             u, i = s.to_dev(train_[1]), s.to_dev(train_[2])
             y = s.to_dev(np.asarray(train_[3], dtype=np.float32))
             losses = self._train_epoch_device(u, i, y)

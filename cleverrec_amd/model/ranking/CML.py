@@ -45,7 +45,7 @@ class CML(RankingRecommender):
             u, i, neg = self._dev_sampler.cml(self.neg_ratio)
             losses = self.state.train_epoch(u, i, neg, self.batch_size)
             return float(losses.double().sum().item()) / int(losses.numel())
-        train_ = ranking_sampler_cml(self.data, self.neg_ratio, self.batch_size)
+        train_ = ranking_sampler_cml(self.data, self.neg_ratio, self.batch_size, prefetch_next=self.sampler_prefetch)
         s = self.sess
         losses = self.state.train_epoch(s.to_dev(train_[1]), s.to_dev(train_[2]), s.to_dev(train_[3]), self.batch_size)
         return float(losses.double().sum().item()) / train_[0]

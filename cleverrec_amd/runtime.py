@@ -28,7 +28,9 @@ class Session:
         t = torch.as_tensor(np.ascontiguousarray(a))
         if dtype is not None:
             t = t.to(dtype)
-        return t.to(self.device, non_blocking=False)
+        # a page-locked source (the prefetched epoch sample, utils/sampler.py) goes up as an asynchronous DMA on the
+        # current stream; the caller keeps the array alive until the work that uses it has been synchronised
+        return t.to(self.device, non_blocking=bool(t.is_pinned()))
 
     def empty(self, shape, dtype):
         return torch.empty(shape, dtype=dtype, device=self.device)

@@ -27,7 +27,7 @@ import numpy as np
 import torch
 
 f32 = torch.float32
-NOISE = 1e-5  # relative to sum|c_k|: contributions come out of length-d dot products (and a tower) rounded in another
+NOISE = 2e-5  # relative to sum|c_k|: contributions come out of length-d dot products (and a tower) rounded in another
               # order; a pure permutation of the batch already uses 0.6 of a 4e-6 envelope (tests/test_oracle_models.py)
 
 
@@ -301,8 +301,8 @@ class FM(Model):
             xve = xv[:, :, None] * ve
             S = xve.sum(1)
             r = 2.0 * np.abs(np.asarray(y, dtype=np.float64) - yp.detach().numpy().astype(np.float64))
-            # (plain fp32 rounding of the two terms, ~8 ulp: 5e-7, i.e. 0.05 * NOISE of their magnitude)
-            term = 0.05 * r[:, None, None] * np.abs(xv)[:, :, None] * (np.abs(S)[:, None, :] + np.abs(xve))
+            # (plain fp32 rounding of the two terms, ~8 ulp: 5e-7, i.e. 0.025 * NOISE of their magnitude)
+            term = 0.025 * r[:, None, None] * np.abs(xv)[:, :, None] * (np.abs(S)[:, None, :] + np.abs(xve))
             a = np.zeros(tuple(w["vif"].shape), np.float64)
             np.add.at(a, xi, term.reshape(len(xi), -1))
             w["_abs"]["vif"] = w["_abs"].get("vif", 0) + a

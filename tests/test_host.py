@@ -178,3 +178,40 @@ def test_grid_search_order_and_types():
     assert pts[2]["reg"] == 0.01 and pts[4]["embed_size"] == 16
     assert all(isinstance(p["embed_size"], int) and isinstance(p["reg"], float) and isinstance(p["neg_ratio"], int) for p in pts)
     assert list(grid({"embed_size": "64", "reg": "1e-2", "neg_ratio": " [4] "})) == [{"embed_size": 64, "reg": 0.01, "neg_ratio": 4}]
+
+
+def test_sampler_prefetch_is_stream_exact(golden_dir):
+    """utils/sampler.py prefetch: epochs drawn ahead on a host thread give the same arrays and leave np.random in the
+    same state as the serial order -- against the reference-generated golden stream for the first call, against the
+    serial path for the following epochs; a foreign np.random draw between epochs drops the prefetch (miss) and the
+    results still equal the serial order."""
+    g = np.load(os.path.join(golden_dir, "sampler_syn200.npz"))
+
+    class D:
+        pass
+    data = D()
+    data.ui_train = {int(k): g["items"][g["ptr"][n]:g["ptr"][n + 1]].tolist() for n, k in enumerate(g["keys"])}
+    data.item_nums = int(g["item_nums"])
+    seed, nr, B = int(g["seed"]), int(g["neg_ratio"]), int(g["batch"])
+
+    def run(prefetch, disturb):
+        S.drop_prefetch()
+        np.random.seed(seed)
+        outs = []
+        for e in range(4):
+            outs.append(S.pairwise_ranking_sampler(data, nr, B, prefetch_next=prefetch))
+            if disturb and e == 1:
+                outs.append(np.random.randint(1000))  # somebody else draws between two epochs
+        outs.append(np.random.randint(2 ** 30))  # where the stream stands afterwards
+        return outs
+
+    def same(a, b):
+        return all((x == y) if np.isscalar(x) else all(np.array_equal(p, q) for p, q in zip(x, y)) for x, y in zip(a, b))
+    base = run(False, False)
+    assert np.array_equal(base[0][1], g["pw_u"]) and np.array_equal(base[0][3], g["pw_j"])  # the reference's own stream
+    h0 = dict(S.stats)
+    assert same(run(True, False), base)
+    assert S.stats["prefetch_hits"] - h0["prefetch_hits"] == 3 and S.stats["prefetch_misses"] == h0["prefetch_misses"]
+    dbase = run(False, True)
+    assert same(run(True, True), dbase) and S.stats["prefetch_misses"] - h0["prefetch_misses"] == 1
+    S.drop_prefetch()

@@ -1,4 +1,4 @@
-"""The multi-GPU path's host logic on CPU: world_size-2 gloo processes.
+"""The multi-GPU paths' host logic and exchange protocol on CPU: gloo processes, world sizes 2 and 4.
 
 What can be checked without GPUs: the user-range sharding of the `data` protocol, the byte/int
 agreement helpers the RCCL bootstrap uses, and -- with the CPU oracle standing in for the kernels --
@@ -114,5 +114,62 @@ def test_exchange_scheme_two_ranks_gloo():
         p.start()
     for p in procs:
         p.join(120)
+        assert p.exitcode == 0
+    assert out.get(timeout=5) == "ok"
+
+
+def _shard_worker(rank, world, port, out):
+    """The row-sharded exchange (include/crec.h "row-sharded training") as real multi-process all-to-all-v over gloo:
+    every rank holds ONLY its user rows and its item shard (oracle/shard_protocol.py); the result must equal, bit for
+    bit, the single-process restatement of the sharded arithmetic (oracle.sharded_steps: per-rank sums, then rank
+    order), i.e. owner mapping, compact ids, request lists and segment offsets all line up."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import shard_protocol as SP
+        U, I, d, B, steps = 97, 53, 8, 64, 3  # 53 items: no world size divides it, the last shard rows are padding
+        g = np.random.Generator(np.random.PCG64(7))
+        P0 = (g.standard_normal((U, d)) * 0.1).astype(np.float32)
+        Q0 = (g.standard_normal((I, d)) * 0.1).astype(np.float32)
+        ranges = [parallel.user_range(U, r, world) for r in range(world)]
+        streams = []
+        for lo, hi in ranges:  # every rank can rebuild every stream (same generator): rank 0 needs them all
+            n = steps * B - int(g.integers(0, B // 2))
+            streams.append((g.integers(0, hi - lo, n).astype(np.int32), np.minimum(g.zipf(1.5, n) - 1, I - 1).astype(np.int32),
+                            g.integers(0, I, n).astype(np.int32)))
+        lo, hi = ranges[rank]
+        me = SP.ShardedRank(P0[lo:hi], parallel.shard_items(Q0, rank, world), I, lr=1e-2, reg=0.01)
+        u, i, j = streams[rank]
+        losses = [me.step(u[b * B:(b + 1) * B], i[b * B:(b + 1) * B], j[b * B:(b + 1) * B]) for b in range(steps)]
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (me.user.P, me.item.Q))
+        if rank == 0:
+            P = np.concatenate([x[0] for x in gathered])
+            Q = parallel.unshard_items([x[1] for x in gathered], I)
+            oP, oQ, oloss, _ = oracle.sharded_steps(P0, Q0, ranges, streams, B, lr=1e-2, reg=0.01)
+            assert np.array_equal(P, oP) and np.array_equal(Q, oQ)
+            np.testing.assert_allclose(losses, oloss, rtol=1e-12)
+            # and the same global batches on ONE rank (the plain lazy step on the rank-major concatenation): fp32 add order only
+            ref = oracle.BprModel(P0, Q0, lr=1e-2, reg=0.01, adam_mode=1)
+            for b in range(steps):
+                parts = [(s[0][b * B:(b + 1) * B] + r[0], s[1][b * B:(b + 1) * B], s[2][b * B:(b + 1) * B]) for s, r in zip(streams, ranges)]
+                ref.step(*(np.concatenate([p[k] for p in parts]) for k in range(3)))
+            np.testing.assert_allclose(P, ref.P, rtol=0, atol=5e-6)
+            np.testing.assert_allclose(Q, ref.Q, rtol=0, atol=5e-6)
+            out.put("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_exchange_protocol_gloo(world):
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
         assert p.exitcode == 0
     assert out.get(timeout=5) == "ok"

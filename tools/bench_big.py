@@ -87,6 +87,69 @@ def run(users=10_000_000, items=1_000_000, dim=128, steps=300, warmup=30, batch=
     return out
 
 
+def run_sharded(users=10_000_000, items=1_000_000, dim=128, steps=200, warmup=30, batch=6144, sess=None, seed=0, rank=0,
+                world=1, barrier=None, max_reduce=None):
+    """The same workload row-sharded over `world` ranks (crec_bpr_train_epoch_sharded): users range-sharded
+    (users / world rows of P per rank), items dealt round-robin (ceil(items / world) rows of Q per rank), `batch`
+    triples per rank per step (weak scaling in triples, the tables' total size fixed).  Collective: every rank calls it.
+    barrier(): device sync + process barrier; max_reduce(x): max over ranks of a host float.  world == 1 measures
+    what the exchange protocol itself costs against the direct lazy step (plan, compact table, serve / apply)."""
+    import torch
+    from cleverrec_amd import parallel, runtime
+    sess = sess or runtime.Session(0)
+    dev = sess.device
+    barrier = barrier or torch.cuda.synchronize
+    max_reduce = max_reduce or (lambda x: x)
+    g = torch.Generator(device=dev).manual_seed(seed + 1000 * rank)
+    lo, hi = parallel.user_range(users, rank, world)
+    S = parallel.shard_rows(items, world)
+    f32 = torch.float32
+    st = parallel.ShardedBprState.__new__(parallel.ShardedBprState)
+    st.sess = sess
+    st.P = torch.empty((hi - lo, dim), dtype=f32, device=dev).normal_(0, 0.01, generator=g)
+    st.Q = torch.empty((S, dim), dtype=f32, device=dev).normal_(0, 0.01, generator=g)
+    st.mP, st.vP = torch.zeros_like(st.P), torch.zeros_like(st.P)
+    st.mQ, st.vQ = torch.zeros_like(st.Q), torch.zeros_like(st.Q)
+    from cleverrec_amd import _lib
+    st.tables = _lib.BprTables(*(t.data_ptr() for t in (st.P, st.Q, st.mP, st.vP, st.mQ, st.vQ)), hi - lo, S, dim)
+    st.adam = _lib.Adam(1e-3, 0.9, 0.999, 1e-8, 0.01, _lib.ADAM_LAZY, 0.9, 0.999, 0)
+    st.item_nums, st.rank, st.world, st.stats = items, rank, world, _lib.ShardStats()
+
+    n = steps * batch
+    u = torch.randint(0, hi - lo, (n,), generator=g, device=dev, dtype=torch.int64).to(torch.int32)
+    w = 1.0 / torch.arange(1, items + 1, dtype=torch.float64, device=dev)
+    cdf = torch.cumsum(w / w.sum(), 0)
+    i = torch.searchsorted(cdf, torch.rand(n, generator=g, device=dev, dtype=torch.float64)).clamp_(max=items - 1).to(torch.int32)
+    j = torch.randint(0, items, (n,), generator=g, device=dev, dtype=torch.int64).to(torch.int32)
+    del cdf, w
+    st.train_epoch(u, i, j, batch)  # same call shape as the timed one: every workspace reaches its final size
+    barrier()
+    st.stats = _lib.ShardStats()
+    t0 = time.perf_counter()
+    loss = st.train_epoch(u, i, j, batch)
+    barrier()
+    dt = max_reduce(time.perf_counter() - t0)
+    stats = st.stats_dict()
+    sess.ctx.profile(True)
+    st.train_epoch(u, i, j, batch)
+    barrier()
+    prof = sess.ctx.profile_read()
+    sess.ctx.profile(False)
+    kern = {k: round(ms / cnt * 1e3, 2) for k, (ms, cnt) in prof.items() if cnt}
+    per_step = {k: stats[k] / steps for k in ("bytes_ids_sent", "bytes_rows_sent", "bytes_grads_sent", "rows_requested", "rows_served")}
+    out = {
+        "workload": "S-big row-sharded: %d users x %d items over %d rank(s), d=%d fp32, batch %d per rank per step, lazy Adam, "
+                    "Zipf(1.0) positives" % (users, items, world, dim, batch),
+        "world": world, "triples_per_s": steps * batch * world / dt, "us_per_step": dt / steps * 1e6, "steps": steps,
+        "exchange_per_rank_per_step": per_step, "max_rows_served_per_batch": stats["max_rows_served_per_batch"],
+        "kernel_avg_us": kern, "loss_first_last": [float(loss[0]), float(loss[-1])],
+        "exchange": "per chunk: request lists (all-to-all-v); per step: rows forward, gradient rows back (2 all-to-all-v)",
+    }
+    del st
+    torch.cuda.empty_cache()
+    return out
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--users", type=int, default=10_000_000)
@@ -94,5 +157,9 @@ if __name__ == "__main__":
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--batch", type=int, default=6144)
+    ap.add_argument("--sharded", action="store_true", help="the row-sharded epoch on a world of one (protocol cost)")
     a = ap.parse_args()
-    print(json.dumps(run(a.users, a.items, a.dim, a.steps, batch=a.batch)))
+    if a.sharded:
+        print(json.dumps(run_sharded(a.users, a.items, a.dim, a.steps, batch=a.batch)))
+    else:
+        print(json.dumps(run(a.users, a.items, a.dim, a.steps, batch=a.batch)))
