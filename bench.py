@@ -234,7 +234,7 @@ def main():
                           "epoch_inclusive_triples_per_s_overlapped": n_epoch / max(t_sample, epoch_gpu_s)}
 
         # measured, not derived: epochs through the drop-in sampler wrapper with the next epoch's sample drawn ahead on
-        # a host thread (utils/sampler.py; bit-identical stream) into page-locked memory, uploaded asynchronously
+        # a host thread (utils/sampler.py; bit-identical stream)
         from cleverrec_amd.utils import sampler as S
         S.drop_prefetch()
         np.random.seed(1)

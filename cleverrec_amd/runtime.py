@@ -28,9 +28,9 @@ class Session:
         t = torch.as_tensor(np.ascontiguousarray(a))
         if dtype is not None:
             t = t.to(dtype)
-        # a page-locked source (the prefetched epoch sample, utils/sampler.py) goes up as an asynchronous DMA on the
-        # current stream; the caller keeps the array alive until the work that uses it has been synchronised
-        return t.to(self.device, non_blocking=bool(t.is_pinned()))
+        # pageable memory goes up at ~50 GB/s on this platform (33.6 MB of epoch sample: 0.64 ms); page-locking the sample
+        # buffers was measured and dropped (tools/prof_prefetch.py: allocation jitter, a 137 ms first-touch registration)
+        return t.to(self.device, non_blocking=False)
 
     def empty(self, shape, dtype):
         return torch.empty(shape, dtype=dtype, device=self.device)

@@ -49,15 +49,6 @@ def _with_numpy_stream(fn):
     return out
 
 
-def _pinned(n, dtype):
-    """page-locked output arrays for a sample drawn ahead: its upload is then an asynchronous DMA that overlaps the
-    previous epoch's kernels (torch's caching host allocator recycles the blocks from epoch to epoch)"""
-    import torch
-    if not torch.cuda.is_available():
-        return np.empty(n, dtype)
-    return torch.empty(int(n), dtype={np.int32: torch.int32, np.float32: torch.float32}[dtype], pin_memory=True).numpy()
-
-
 _KINDS = {"pairwise": "sample_pairwise", "pointwise": "sample_pointwise", "cml": "sample_cml"}
 
 
@@ -74,7 +65,6 @@ class _Prefetch:
             try:
                 ctx = _lib.Context(None)  # its own host ctx: the RNG state is per ctx
                 ctx.set_state(self.key, self.pos)
-                ctx.alloc = _pinned
                 self.out = getattr(ctx, _KINDS[kind])(csr, item_nums, neg_ratio)  # ctypes drops the GIL for the call
                 self.end = ctx.get_state()
                 ctx.close()
