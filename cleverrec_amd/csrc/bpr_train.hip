@@ -19,10 +19,15 @@
 //              side.  An item wave recomputes s_b = sigmoid(-x_b) of its occurrences from
 //              p_u, q_i, q_j with the very instruction sequence the user wave uses, so both
 //              sides use bit-identical s_b.
-//   lazy mode  two launches in place: bpr_user_side (stores the contribution row c_b = s_b*p_u
-//              of each triple, plain coalesced stores, then Adam on the user's row) and
-//              bpr_item_side (sums -/+ c_b over the row's occurrences, Adam on the row).
-//              Rows are read only by their own wave inside a launch, so in place is safe.
+//   lazy mode  two launches in place.  bpr_triples_lazy walks the batch triple by triple: a lane group loads
+//              p_u, q_i, q_j (and the Adam slots of those of the three rows that occur ONCE in the batch --
+//              the index kernel flags them) in one round of loads, computes x_b, s_b and the three gradient
+//              rows, applies Adam to the single-occurrence rows right there and stores contribution rows
+//              (s_b*p_u, s_b*(q_i-q_j)) only for rows that occur more than once.  bpr_rows_lazy then sums the
+//              stored contribution rows of every multi-occurrence row (+ reg*row per occurrence) and applies
+//              Adam.  A row that occurs once is touched by exactly one lane group, rows that occur more
+//              often are only READ by the first launch, so in place is safe.  Two dependent round trips per
+//              wave instead of the four of a row-major walk (row list -> records -> gathers -> slots).
 //   Either mode: a row with more than CH occurrences in the batch is cut into chunks handled by separate
 //              waves; the chunk wave that draws the row's last ticket sums the partials in chunk order and
 //              applies Adam (chunk_wave), so there is no extra launch.
@@ -109,7 +114,12 @@ struct IndexWs {
     int32_t *q_rows, *q_seg;   // [nbc][2B], [nbc][2B+1]
     int4 *q_occ;               // [nbc][2B]  {u, i, j, position | side<<31}  (side 1: row is the triple's j)
     int2 *u_rowseg, *q_rowseg; // tf1 mode: [nbc][U], [nbc][I]  {segment start, length (negative: heavy row)}
-    int32_t *hn;               // [nbc][4]   {user heavy rows, user chunks, item heavy rows, item chunks}
+    int32_t *hn;               // [nbc][HN]  {user heavy rows, user chunks, item heavy rows, item chunks, user multi rows,
+                               //             item multi rows, -, -}
+    // lazy mode: per batch position, the triple's ids with bit 31 = "this row occurs once in the batch"
+    int32_t *u_flag, *i_flag, *j_flag; // [nbc][B]
+    int4 *u_multi, *q_multi;   // [nbc][MMu|MMq]  rows with 2..CH occurrences: {row, segment start, length, rank}
+    int64_t MMu, MMq;
     int4 *u_hrows, *q_hrows;   // [nbc][HRu|HRq]  {row, first chunk, chunks<<16 | length, rank among unique rows}
     int4 *u_hitems, *q_hitems; // [nbc][HIu|HIq]  {row, segment start, length | heavy row index << 8, chunk index}
     int64_t B, U, I, HRu, HRq, HIu, HIq;
@@ -123,6 +133,8 @@ struct IndexWs {
     int64_t WMu, WMq;
     size_t bytes;
 };
+
+constexpr int HN = 8; // per-batch counters the host reads back
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -164,12 +176,19 @@ IndexWs layout_index(void *base, int64_t nbc, int64_t B, int64_t U, int64_t I, b
     w.q_occ = (int4 *)take(sizeof(int4) * nbc * 2 * B);
     w.u_rowseg = (int2 *)take(sizeof(int2) * nbc * w.U);
     w.q_rowseg = (int2 *)take(sizeof(int2) * nbc * w.I);
-    w.hn = (int32_t *)take(sizeof(int32_t) * nbc * 4);
+    w.hn = (int32_t *)take(sizeof(int32_t) * nbc * HN);
     w.nwide = (int32_t *)take(sizeof(int32_t) * nbc * 2); // right behind hn: the host reads both back with one copy
     w.u_hrows = (int4 *)take(sizeof(int4) * nbc * w.HRu);
     w.q_hrows = (int4 *)take(sizeof(int4) * nbc * w.HRq);
     w.u_hitems = (int4 *)take(sizeof(int4) * nbc * w.HIu);
     w.q_hitems = (int4 *)take(sizeof(int4) * nbc * w.HIq);
+    w.MMu = dense ? 0 : B / 2 + 1;
+    w.MMq = dense ? 0 : B + 1;
+    w.u_flag = (int32_t *)take(sizeof(int32_t) * nbc * (dense ? 0 : B));
+    w.i_flag = (int32_t *)take(sizeof(int32_t) * nbc * (dense ? 0 : B));
+    w.j_flag = (int32_t *)take(sizeof(int32_t) * nbc * (dense ? 0 : B));
+    w.u_multi = (int4 *)take(sizeof(int4) * nbc * w.MMu);
+    w.q_multi = (int4 *)take(sizeof(int4) * nbc * w.MMq);
     w.wide_rows = dense && wide_total > 0 ? wide_rows : 0;
     w.wide_total = wide_total;
     w.WMu = w.wide_rows ? B / (wide_total + 1) + 1 : 0;
@@ -235,12 +254,26 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
         heads += (k == 0 || rows[k] != rows[k - 1]) ? 1 : 0;
     int total = 0, hv_total = 0;
     int rank = crec_sort::block_excl_scan<PREP_THREADS>(heads, scan, &total);
+    const int rank_first = rank; // runs that start before this thread's positions
     for (int k = k0; k < k1; ++k)
         if (k == 0 || rows[k] != rows[k - 1])
             seg[rank++] = (uint16_t)k;
     if (tid == 0)
         seg[total] = (uint16_t)n;
     __syncthreads();
+
+    const bool lazy = (side ? w.I : w.U) == 0; // lazy mode keeps no per-table-row segments
+    if (lazy) { // every batch position learns whether its row occurs once in the batch (bit 31 of its id)
+        int r = rank_first;
+        for (int k = k0; k < k1; ++k) {
+            if (k == 0 || rows[k] != rows[k - 1])
+                ++r;
+            const uint32_t single = ((int)seg[r] - (int)seg[r - 1]) == 1 ? 0x80000000u : 0u;
+            const int slot = tag[k];
+            int32_t *dst = side == 0 ? w.u_flag : (slot < nb ? w.i_flag : w.j_flag);
+            dst[(int64_t)batch * B + (slot < nb ? slot : slot - nb)] = (int32_t)(rows[k] | single);
+        }
+    }
 
     CREC_IDX_MARK(2);
     // heavy rows (more than CH occurrences) and their chunks, in rank order (blocked over ranks)
@@ -268,6 +301,24 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
                     ++hitem;
                 }
             }
+        }
+    }
+
+    // lazy mode: the rows with 2..CH occurrences, in rank order (their sums are formed by bpr_rows_lazy; rows with one
+    // occurrence are finished by bpr_triples_lazy, rows with more than CH by the chunk waves)
+    int multi_total = 0;
+    if (lazy) {
+        int nm = 0;
+        for (int q = q0; q < q1; ++q) {
+            const int cnt = (int)seg[q + 1] - (int)seg[q];
+            nm += (cnt >= 2 && cnt <= CH) ? 1 : 0;
+        }
+        int at = crec_sort::block_excl_scan<PREP_THREADS>(nm, scan, &multi_total);
+        int4 *multi_out = side ? w.q_multi + (int64_t)batch * w.MMq : w.u_multi + (int64_t)batch * w.MMu;
+        for (int q = q0; q < q1; ++q) {
+            const int k = seg[q], cnt = (int)seg[q + 1] - k;
+            if (cnt >= 2 && cnt <= CH)
+                multi_out[at++] = make_int4((int)rows[k], k, cnt, q);
         }
     }
 
@@ -366,8 +417,9 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
     }
     if (tid == 0) {
         (side ? w.n_q : w.n_u)[batch] = total;
-        w.hn[batch * 4 + side * 2 + 0] = hv_total >> 16;
-        w.hn[batch * 4 + side * 2 + 1] = hv_total & 0xffff;
+        w.hn[batch * HN + side * 2 + 0] = hv_total >> 16;
+        w.hn[batch * HN + side * 2 + 1] = hv_total & 0xffff;
+        w.hn[batch * HN + 4 + side] = multi_total;
         w.nwide[batch * 2 + side] = wide_total_n;
     }
     CREC_IDX_MARK(6);
@@ -646,6 +698,7 @@ template <int LPR, int RW> __device__ __forceinline__ float4 reduce_to_owner(Acc
 // MODE 0: user rows (gathers q_i, q_j; stores x_b; lazy mode also stores c_b = s_b * p_u)
 // MODE 1: item rows, fused step (gathers p_u and the triple's other item row; recomputes s_b)
 // MODE 2: item rows, lazy mode (reads c_b back)
+// MODE 3: user rows, lazy mode (reads the stored s_b*(q_i-q_j) back) -- chunk waves of heavy rows only
 //
 // One "trip" = UNR sub-iterations of G occurrences.  Trips are software-pipelined two deep: the
 // gathers of trip n+1 are issued before trip n is consumed.
@@ -1003,7 +1056,7 @@ __device__ __forceinline__ void chunk_wave(const Tables &src, int d, int4 item, 
                                   float *__restrict__ contrib, float *__restrict__ xb, float *__restrict__ partial,
                                   const FinishArgs &f, const Hyper &h)
 {
-    constexpr bool user = MODE == 0;
+    constexpr bool user = MODE == 0 || MODE == 3;
     const int lane = threadIdx.x & 63, g = lane / LPR, l = lane % LPR;
     const bool act = FULL || 4 * l < d;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1021,8 +1074,8 @@ __device__ __forceinline__ void chunk_wave(const Tables &src, int d, int4 item, 
     const bool slots = on && (user || !h.dQ); // item rows that only emit their gradient row (h.dQ) have no slots here
     float4 m = slots ? ld4((user ? src.mP : src.mQ) + ro) : zero, v = slots ? ld4((user ? src.vP : src.vQ) + ro) : zero;
     float4 grad;
-    if (MODE == 2) {
-        // lazy item side: an occurrence is one contribution row to read and add, nothing to compute first, so the
+    if (MODE >= 2) {
+        // lazy mode (item rows, and user rows whose contributions were stored by bpr_triples_lazy): an occurrence is one contribution row to read and add, nothing to compute first, so the
         // chunk keeps eight rows in flight per group instead of the generic walk's UNR (a chunk wave is the launch's
         // critical path).  Same per-group order and the same cross-group sum as the generic walk.
         constexpr int G = 64 / LPR, DEEP = 8;
@@ -1097,7 +1150,7 @@ __device__ __forceinline__ void chunk_wave(const Tables &src, int d, int4 item, 
     }
     const float nr = group_sum<LPR>(dot4(var, var));
     if (on) {
-        if (l == 0)
+        if (l == 0 && f.rowterm) // lazy mode keeps its l2 terms per triple
             f.rowterm[f.dense ? sl.row : (int64_t)rec.w] = (0.5f * nr) * (float)cnt;
         if (!user && h.dQ) {
             st4(h.dQ + ro, grad);
@@ -1242,58 +1295,188 @@ __global__ __launch_bounds__(CREC_FUSED_BLOCK) void bpr_step_fused(Tables src, T
 }
 
 // ------------------------------------------------------------------------------------
-// lazy mode: touched rows only, in place, two launches (MODE 0 users, MODE 2 items)
+// lazy mode: touched rows only, in place, two launches
 // ------------------------------------------------------------------------------------
-template <int LPR, int MODE, bool FULL>
-__global__ __launch_bounds__(256, CREC_LAZY_WAVES(MODE)) void bpr_side_lazy(Tables t, int d, const int32_t *__restrict__ n_rows_p,
-                                                     const int32_t *__restrict__ rows, const int32_t *__restrict__ seg,
-                                                     const int4 *__restrict__ occ, const int32_t *__restrict__ n_chunks_p,
-                                                     const int4 *__restrict__ hitems, int HI,
-                                                     const int4 *__restrict__ hrows, int32_t *__restrict__ tickets,
-                                                     float *__restrict__ partial, float *__restrict__ contrib,
-                                                     float *__restrict__ xb, float *__restrict__ rowterm, Hyper h)
+// bpr_triples_lazy: a lane group per triple.  uf / jf / if_: the triple's ids by batch position, bit 31 = the row
+// occurs once in the batch (bpr_index_batches).  One round of loads brings p_u, q_i, q_j and the slots of the
+// single-occurrence rows; those rows are finished here, rows that occur more often only leave a contribution row.
+template <int LPR, bool FULL>
+__global__ __launch_bounds__(256) void bpr_triples_lazy(Tables t, int d, const int32_t *__restrict__ uf,
+                                                        const int32_t *__restrict__ if_, const int32_t *__restrict__ jf,
+                                                        int nb, float *__restrict__ contrib, float *__restrict__ ucontrib,
+                                                        float *__restrict__ xb, float *__restrict__ l2b, Hyper h)
 {
-    constexpr int R = Geo<LPR, ROWS_PER_WAVE>::R;
-    const int lane = threadIdx.x & 63, g = lane / LPR;
-    // the wave index is the same in every lane: say so (readfirstlane), and everything derived from it -- which rows,
-    // how many, which side, loop bounds -- stays in scalar registers and scalar branches
-    int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-#ifdef CREC_STAMPS // user side: stamps [0, 8192), item side: [8192, 16384); [6] = 1 chunk wave, 2 row wave
-    const unsigned long long t_begin = wall_clock64();
-    const int raw_wave = (int)wave_id + (MODE == 0 ? 0 : 8192);
-    const auto stamp_end = [&](unsigned flag) {
-        if (lane == 0 && wave_id < 8192) {
-            crec_stamps[8 * raw_wave + 0] = t_begin;
-            crec_stamps[8 * raw_wave + 1] = wall_clock64();
-            crec_stamps[8 * raw_wave + 6] = flag; // [7] belongs to slots_grad's record count
+    constexpr int G = 64 / LPR;
+    const int lane = threadIdx.x & 63, g = lane / LPR, l = lane % LPR;
+    const int pos = (int)((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * G + g);
+    const bool valid = pos < nb, act = FULL || 4 * l < d, on = valid && act;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int32_t ru = valid ? uf[pos] : 0, ri = valid ? if_[pos] : 0, rj = valid ? jf[pos] : 0;
+    const bool us = ru < 0, is = ri < 0, js = rj < 0;
+    const int64_t ou = (int64_t)(ru & 0x7fffffff) * d + 4 * l, oi = (int64_t)(ri & 0x7fffffff) * d + 4 * l,
+                  oj = (int64_t)(rj & 0x7fffffff) * d + 4 * l;
+    const bool item_adam = h.dQ == nullptr; // the row-sharded step only emits the item rows' gradient sums
+    float4 p = zero, qi = zero, qj = zero, mp = zero, vp = zero, mi = zero, vi = zero, mj = zero, vj = zero;
+    if (on) { // every address is known: one round of loads
+        p = ld4(t.P + ou);
+        qi = ld4(t.Q + oi);
+        qj = ld4(t.Q + oj);
+        if (us) {
+            mp = ld4s(t.mP + ou);
+            vp = ld4s(t.vP + ou);
         }
-    };
-#endif
-    if (wave_id < HI) {
-        chunk_wave<LPR, MODE, MODE == 0, FULL>(t, d, hitems[wave_id], occ, contrib, xb, partial,
-                                               FinishArgs{hrows, tickets, t, rowterm, 0}, h);
-#ifdef CREC_STAMPS
-        stamp_end(1);
-#endif
+        if (is && item_adam) {
+            mi = ld4s(t.mQ + oi);
+            vi = ld4s(t.vQ + oi);
+        }
+        if (js && item_adam) {
+            mj = ld4s(t.mQ + oj);
+            vj = ld4s(t.vQ + oj);
+        }
+    }
+    float x;
+    const float s = triple_s<LPR>(dot4(p, qi) - dot4(p, qj), &x);
+    const float l2 = (0.5f * group_sum<LPR>(dot4(p, p)) + 0.5f * group_sum<LPR>(dot4(qi, qi))) + 0.5f * group_sum<LPR>(dot4(qj, qj));
+    if (valid && l == 0) {
+        xb[pos] = x; // softplus(-x) is taken in bpr_reduce_loss
+        l2b[pos] = l2;
+    }
+    if (!on)
+        return;
+    // user row: -s*(q_i - q_j) + reg*p
+    const float4 dq = make_float4(qi.x - qj.x, qi.y - qj.y, qi.z - qj.z, qi.w - qj.w);
+    if (us) {
+        const float ns = -s;
+        const float4 gp = make_float4(ns * dq.x + h.reg * p.x, ns * dq.y + h.reg * p.y, ns * dq.z + h.reg * p.z, ns * dq.w + h.reg * p.w);
+        float4 np = p;
+        adam4(np, mp, vp, gp, true, h);
+        st4s(t.P + ou, np);
+        st4s(t.mP + ou, mp);
+        st4s(t.vP + ou, vp);
+    } else {
+        st4s(ucontrib + (int64_t)pos * d + 4 * l, make_float4(s * dq.x, s * dq.y, s * dq.z, s * dq.w));
+    }
+    // item rows: -/+ s*p + reg*q
+    const float4 sp = make_float4(s * p.x, s * p.y, s * p.z, s * p.w);
+    if (is) {
+        const float4 gi = make_float4(-sp.x + h.reg * qi.x, -sp.y + h.reg * qi.y, -sp.z + h.reg * qi.z, -sp.w + h.reg * qi.w);
+        if (item_adam) {
+            float4 nq = qi;
+            adam4(nq, mi, vi, gi, true, h);
+            st4s(t.Q + oi, nq);
+            st4s(t.mQ + oi, mi);
+            st4s(t.vQ + oi, vi);
+        } else {
+            st4s(h.dQ + oi, gi);
+        }
+    }
+    if (js) {
+        const float4 gj = make_float4(sp.x + h.reg * qj.x, sp.y + h.reg * qj.y, sp.z + h.reg * qj.z, sp.w + h.reg * qj.w);
+        if (item_adam) {
+            float4 nq = qj;
+            adam4(nq, mj, vj, gj, true, h);
+            st4s(t.Q + oj, nq);
+            st4s(t.mQ + oj, mj);
+            st4s(t.vQ + oj, vj);
+        } else {
+            st4s(h.dQ + oj, gj);
+        }
+    }
+    if (!is || !js)
+        st4s(contrib + (int64_t)pos * d + 4 * l, sp);
+}
+
+// a row with 2..CH occurrences: all groups of the wave walk its occurrences (eight contribution rows in flight per
+// group), the partial sums meet in group 0, Adam in place (items of the row-sharded step: the gradient row instead)
+template <int LPR, bool USER, bool FULL>
+__device__ __forceinline__ void multi_row_wave(const Tables &t, int d, int4 item, const int4 *__restrict__ occ,
+                                               const float *__restrict__ contrib, const Hyper &h)
+{
+    constexpr int G = 64 / LPR, DEEP = 8;
+    const int lane = threadIdx.x & 63, g = lane / LPR, l = lane % LPR;
+    const bool act = FULL || 4 * l < d, on = g == 0 && act;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t ro = (int64_t)item.x * d + 4 * l;
+    const int start = item.y, cnt = item.z;
+    const bool slots = on && (USER || !h.dQ);
+    const float4 var = act ? ld4((USER ? t.P : t.Q) + ro) : zero;
+    float4 m = slots ? ld4s((USER ? t.mP : t.mQ) + ro) : zero, v = slots ? ld4s((USER ? t.vP : t.vQ) + ro) : zero;
+    AccArr<LPR, 1 | (FULL ? 0x100 : 0)> acc;
+    acc[0] = zero;
+    const int mine = lane < cnt ? occ[start + lane].w : 0; // cnt <= CH <= 255; the records of one row: one load for <= 64
+    for (int c0 = 0; c0 < cnt; c0 += 64) {
+        const int nc = (cnt - c0) < 64 ? (cnt - c0) : 64;
+        const int rec = c0 == 0 ? mine : (lane < nc ? occ[start + c0 + lane].w : 0);
+        const int n_sub = (nc + G - 1) / G;
+        for (int t0 = 0; t0 < n_sub; t0 += DEEP) {
+            float4 a[DEEP];
+            int rw[DEEP];
+            bool has[DEEP];
+#pragma unroll
+            for (int e = 0; e < DEEP; ++e) {
+                const int kk = (t0 + e) * G + g;
+                rw[e] = __shfl(rec, kk & 63, 64);
+                has[e] = (t0 + e) < n_sub && kk < nc;
+                a[e] = (has[e] && act) ? ld4(contrib + (int64_t)(rw[e] & 0x7fffffff) * d + 4 * l) : zero;
+            }
+#pragma unroll
+            for (int e = 0; e < DEEP; ++e) {
+                const float sg = rw[e] < 0 ? 1.0f : -1.0f, k = (has[e] && act) ? 1.0f : 0.0f;
+                add4(acc[0], make_float4(k * (sg * a[e].x + h.reg * var.x), k * (sg * a[e].y + h.reg * var.y),
+                                         k * (sg * a[e].z + h.reg * var.z), k * (sg * a[e].w + h.reg * var.w)));
+            }
+        }
+    }
+    const float4 grad = reduce_to_owner<LPR, 1 | (FULL ? 0x100 : 0)>(acc);
+    if (!on)
+        return;
+    if (!USER && h.dQ) {
+        st4(h.dQ + ro, grad);
         return;
     }
-    wave_id -= HI;
-    const int n_rows = *n_rows_p;
-    const int64_t base = wave_id * R;
-    if (base >= n_rows)
+    float4 nv = var;
+    adam4(nv, m, v, grad, true, h);
+    st4s((USER ? t.P : t.Q) + ro, nv);
+    st4s((USER ? t.mP : t.mQ) + ro, m);
+    st4s((USER ? t.vP : t.vQ) + ro, v);
+}
+
+// bpr_rows_lazy: wave ids [0, pcu) user heavy-row chunks, [pcu, pcu+pcq) item heavy-row chunks, then pmu waves for the
+// user rows with 2..CH occurrences, then pmq for the item rows (p*: the chunk's largest counts; surplus waves exit)
+struct RowsLazyArgs {
+    const int32_t *hn; // this batch's counters {.., user chunks, .., item chunks, user multi rows, item multi rows}
+    const int4 *u_hitems, *q_hitems, *u_hrows, *q_hrows, *u_multi, *q_multi, *u_occ, *q_occ;
+    int32_t *tickets_u, *tickets_q;
+    float *partial_u, *partial_q, *contrib, *ucontrib;
+    int pcu, pcq, pmu, pmq;
+};
+
+template <int LPR, bool FULL>
+__global__ __launch_bounds__(256, CREC_LAZY_ITEM_WAVES) void bpr_rows_lazy(Tables t, int d, RowsLazyArgs r, Hyper h)
+{
+    int wave_id = (int)(blockIdx.x * (blockDim.x >> 6)) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (wave_id < r.pcu) {
+        if (wave_id < r.hn[1])
+            chunk_wave<LPR, 3, false, FULL>(t, d, r.u_hitems[wave_id], r.u_occ, r.ucontrib, nullptr, r.partial_u,
+                                            FinishArgs{r.u_hrows, r.tickets_u, t, nullptr, 0}, h);
         return;
-    const int n_valid = (int)((n_rows - base) < R ? (n_rows - base) : R);
-    const int64_t idx = base + (g < n_valid ? g : 0);
-    const int32_t rw = rows[idx];
-    Slot sl;
-    sl.row = rw & 0x7fffffff;
-    sl.start = seg[idx];
-    const int cnt = seg[idx + 1] - sl.start;
-    sl.cnt = g < n_valid ? (rw < 0 ? -cnt : cnt) : 0;
-    row_wave<LPR, MODE, MODE == 0, FULL>(t, t, d, sl, n_valid, occ, contrib, xb, rowterm + idx, false, h);
-#ifdef CREC_STAMPS
-    stamp_end(2);
-#endif
+    }
+    wave_id -= r.pcu;
+    if (wave_id < r.pcq) {
+        if (wave_id < r.hn[3])
+            chunk_wave<LPR, 2, false, FULL>(t, d, r.q_hitems[wave_id], r.q_occ, r.contrib, nullptr, r.partial_q,
+                                            FinishArgs{r.q_hrows, r.tickets_q, t, nullptr, 0}, h);
+        return;
+    }
+    wave_id -= r.pcq;
+    if (wave_id < r.pmu) {
+        if (wave_id < r.hn[4])
+            multi_row_wave<LPR, true, FULL>(t, d, r.u_multi[wave_id], r.u_occ, r.ucontrib, h);
+        return;
+    }
+    wave_id -= r.pmu;
+    if (wave_id < r.pmq && wave_id < r.hn[5])
+        multi_row_wave<LPR, false, FULL>(t, d, r.q_multi[wave_id], r.q_occ, r.contrib, h);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1315,7 +1498,7 @@ __global__ __launch_bounds__(256) void bpr_adam_dense(float *__restrict__ var, f
 
 // ------------------------------------------------------------------------------------
 // bpr_reduce_loss: one workgroup per batch, fixed summation order, float64 accumulation.
-//   dense: rowterm[0 .. n_dense).  lazy (n_dense == 0): rowterm[0 .. n_u) and rowterm[B .. B + n_q).
+//   dense: rowterm[0 .. n_dense).  lazy (n_dense == 0): one l2 term per triple, rowterm[0 .. nb).
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bpr_reduce_loss(const float *__restrict__ ws, int64_t stride, int64_t n_total,
                                                        int32_t B, int64_t n_dense, const int32_t *__restrict__ n_u,
@@ -1348,9 +1531,8 @@ __global__ __launch_bounds__(256) void bpr_reduce_loss(const float *__restrict__
     s = sum_f(xb, nb, [](float x) { return tf_softplus(-x); }, 0.0);
     if (n_dense > 0) {
         l2 = sum_f(rowterm, n_dense, ident, 0.0);
-    } else {
-        l2 = sum_f(rowterm, n_u[blockIdx.x], ident, 0.0);
-        l2 = sum_f(rowterm + B, n_q[blockIdx.x], ident, l2);
+    } else { // lazy mode: one l2 term per triple (bpr_triples_lazy), 0.5*(|p_u|^2 + |q_i|^2 + |q_j|^2) as in BPR.py:42-43
+        l2 = sum_f(rowterm, nb, ident, 0.0);
     }
     part[threadIdx.x] = s + (double)reg * l2;
     __syncthreads();
@@ -1386,6 +1568,9 @@ struct StepArgs {
     // (CREC_WIDE_ROUND=7 vs 8).  Every step of a chunk is launched with the chunk's largest counts; surplus waves
     // exit at once.
     int pad_wide, pad_chunks_u, pad_chunks_q; // max over the chunk of NWu+NWq, HIu, HIq
+    int pad_multi_u, pad_multi_q;             // lazy mode: max over the chunk of the rows with 2..CH occurrences
+    float *ucontrib;                          // lazy mode: [B][d] s_b*(q_i-q_j) of the triples whose user occurs more than once
+    int32_t nb_cur;                           // triples in the batch being launched
     int wide_round;                           // CREC_WIDE_ROUND, read once per epoch (0: unset)
 };
 
@@ -1395,7 +1580,7 @@ struct StepArgs {
 HeavyArgs heavy_args(const StepArgs &a, const IndexWs &w, int64_t b, const int32_t *hn)
 {
     HeavyArgs hv;
-    hv.hn = w.hn + b * 4;
+    hv.hn = w.hn + b * HN;
     hv.u_hitems = w.u_hitems + b * w.HIu;
     hv.q_hitems = w.q_hitems + b * w.HIq;
     hv.u_hrows = w.u_hrows + b * w.HRu;
@@ -1435,20 +1620,38 @@ template <int LPR, bool FULL> void launch_fused(const StepArgs &a, const IndexWs
 
 template <int LPR, bool FULL> void launch_lazy(const StepArgs &a, const IndexWs &w, int64_t b, const int32_t *hn)
 {
-    constexpr int R = Geo<LPR, ROWS_PER_WAVE>::R;
-    const HeavyArgs hv = heavy_args(a, w, b, hn);
-    const int64_t u_waves = a.pad_chunks_u + crec_ceil_div(a.U < a.B ? a.U : a.B, R);
-    const int64_t q_waves = a.pad_chunks_q + crec_ceil_div(a.I < 2 * (int64_t)a.B ? a.I : 2 * (int64_t)a.B, R);
+    constexpr int G = 64 / LPR;
+    (void)hn;
     crec_prof_begin(a.ctx, CREC_K_USER_SIDE, a.st);
-    CREC_KLAUNCH(a.ctx, (bpr_side_lazy<LPR, 0, FULL>), dim3((unsigned)crec_ceil_div(u_waves, 4)), dim3(256), 0, a.st, a.cur, a.d,
-                       w.n_u + b, w.u_rows + b * w.B, w.u_seg + b * (w.B + 1), w.u_occ + b * w.B, hv.hn + 1, hv.u_hitems,
-                       hv.HIu, hv.u_hrows, hv.tickets, a.partial, a.contrib, a.xb, a.rowterm, a.h);
+    CREC_KLAUNCH(a.ctx, (bpr_triples_lazy<LPR, FULL>), dim3((unsigned)crec_ceil_div(a.nb_cur, 4 * G)), dim3(256), 0, a.st, a.cur, a.d,
+                 (const int32_t *)(w.u_flag + b * w.B), (const int32_t *)(w.i_flag + b * w.B), (const int32_t *)(w.j_flag + b * w.B),
+                 (int)a.nb_cur, a.contrib, a.ucontrib, a.xb, a.rowterm, a.h);
     crec_prof_end(a.ctx, a.st);
+    RowsLazyArgs r;
+    r.hn = w.hn + b * HN;
+    r.u_hitems = w.u_hitems + b * w.HIu;
+    r.q_hitems = w.q_hitems + b * w.HIq;
+    r.u_hrows = w.u_hrows + b * w.HRu;
+    r.q_hrows = w.q_hrows + b * w.HRq;
+    r.u_multi = w.u_multi + b * w.MMu;
+    r.q_multi = w.q_multi + b * w.MMq;
+    r.u_occ = w.u_occ + b * w.B;
+    r.q_occ = w.q_occ + b * 2 * w.B;
+    r.tickets_u = a.tickets;
+    r.tickets_q = a.tickets + w.HRu;
+    r.partial_u = a.partial;
+    r.partial_q = a.partial + (int64_t)w.HIu * a.d; // fixed split: the user chunks' partials never reach beyond HIu rows
+    r.contrib = a.contrib;
+    r.ucontrib = a.ucontrib;
+    r.pcu = a.pad_chunks_u;
+    r.pcq = a.pad_chunks_q;
+    r.pmu = a.pad_multi_u;
+    r.pmq = a.pad_multi_q;
+    const int64_t waves = (int64_t)r.pcu + r.pcq + r.pmu + r.pmq;
+    if (waves == 0)
+        return;
     crec_prof_begin(a.ctx, CREC_K_ITEM_SIDE, a.st);
-    CREC_KLAUNCH(a.ctx, (bpr_side_lazy<LPR, 2, FULL>), dim3((unsigned)crec_ceil_div(q_waves, 4)), dim3(256), 0, a.st, a.cur, a.d,
-                       w.n_q + b, w.q_rows + b * 2 * w.B, w.q_seg + b * (2 * w.B + 1), w.q_occ + b * 2 * w.B, hv.hn + 3,
-                       hv.q_hitems, hv.HIq, hv.q_hrows, hv.tickets + hv.HRu_max, a.partial + (int64_t)hv.HIu * a.d, a.contrib,
-                       a.xb, a.rowterm + a.B, a.h);
+    CREC_KLAUNCH(a.ctx, (bpr_rows_lazy<LPR, FULL>), dim3((unsigned)crec_ceil_div(waves, 4)), dim3(256), 0, a.st, a.cur, a.d, r, a.h);
     crec_prof_end(a.ctx, a.st);
 }
 
@@ -1533,7 +1736,7 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
     if (int rc = crec_reserve(ctx, &ctx->idx_ws, layout_index(nullptr, chunk, B, t->U, t->I, dense, CH, wide_rows, wide_total).bytes))
         return rc;
     // per batch: x_b of every triple, then one l2 term per row wave
-    const int64_t loss_stride = B + (dense ? t->U + t->I : 3 * (int64_t)B);
+    const int64_t loss_stride = B + (dense ? t->U + t->I : (int64_t)B); // lazy: x_b, then the l2 term of every triple
     if (int rc = crec_reserve(ctx, &ctx->loss_ws, sizeof(float) * (size_t)chunk * loss_stride))
         return rc;
     const IndexWs w0 = layout_index(nullptr, 1, B, t->U, t->I, dense, CH, wide_rows, wide_total);
@@ -1576,9 +1779,10 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
                 return rc;
         }
     } else {
-        if (int rc = crec_reserve(ctx, &ctx->contrib, sizeof(float) * (size_t)B * t->d))
+        if (int rc = crec_reserve(ctx, &ctx->contrib, 2 * sizeof(float) * (size_t)B * t->d))
             return rc;
         a.contrib = (float *)ctx->contrib.ptr;
+        a.ucontrib = a.contrib + (size_t)B * t->d;
     }
 
     // dynamic LDS of the index kernel
@@ -1615,12 +1819,14 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
         a.nwide = nwide;
         CREC_HIP(ctx, hipMemcpyAsync(ctx->pinned, w.hn, sizeof(int32_t) * n_back, hipMemcpyDeviceToHost, st));
         CREC_HIP(ctx, hipStreamSynchronize(st));
-        a.pad_wide = a.pad_chunks_u = a.pad_chunks_q = 0;
+        a.pad_wide = a.pad_chunks_u = a.pad_chunks_q = a.pad_multi_u = a.pad_multi_q = 0;
         for (int64_t b = 0; b < nbc; ++b) {
             const int nw = nwide[(size_t)b * 2] + nwide[(size_t)b * 2 + 1];
             a.pad_wide = nw > a.pad_wide ? nw : a.pad_wide;
-            a.pad_chunks_u = hn[(size_t)b * 4 + 1] > a.pad_chunks_u ? hn[(size_t)b * 4 + 1] : a.pad_chunks_u;
-            a.pad_chunks_q = hn[(size_t)b * 4 + 3] > a.pad_chunks_q ? hn[(size_t)b * 4 + 3] : a.pad_chunks_q;
+            a.pad_chunks_u = hn[(size_t)b * HN + 1] > a.pad_chunks_u ? hn[(size_t)b * HN + 1] : a.pad_chunks_u;
+            a.pad_chunks_q = hn[(size_t)b * HN + 3] > a.pad_chunks_q ? hn[(size_t)b * HN + 3] : a.pad_chunks_q;
+            a.pad_multi_u = hn[(size_t)b * HN + 4] > a.pad_multi_u ? hn[(size_t)b * HN + 4] : a.pad_multi_u;
+            a.pad_multi_q = hn[(size_t)b * HN + 5] > a.pad_multi_q ? hn[(size_t)b * HN + 5] : a.pad_multi_q;
         }
         for (int64_t b = 0; b < nbc; ++b) {
             // lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t) with fp32 running powers (TF1 _prepare/_finish)
@@ -1631,8 +1837,9 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
             a.h.reg = opt->reg;
             a.h.dQ = dp ? (float *)ctx->dq.ptr : nullptr;
             a.xb = (float *)ctx->loss_ws.ptr + b * loss_stride;
+            a.nb_cur = (int32_t)((n_chunk - b * B) < B ? (n_chunk - b * B) : B);
             a.rowterm = a.xb + B;
-            step(a, w, b, hn + b * 4);
+            step(a, w, b, hn + b * HN);
             if (dp) {
                 // the one exchange of the path: per-item gradient sums over all ranks' triples
                 float *dq = (float *)ctx->dq.ptr;
@@ -1741,7 +1948,7 @@ int sharded_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, int64_t I_global
     chunk = chunk > nb ? nb : chunk;
     if (int rc = crec_reserve(ctx, &ctx->idx_ws, layout_index(nullptr, chunk, B, t->U, IC, false, CH).bytes))
         return rc;
-    const int64_t loss_stride = B + 3 * (int64_t)B;
+    const int64_t loss_stride = 2 * (int64_t)B; // x_b, then the l2 term of every triple
     if (int rc = crec_reserve(ctx, &ctx->loss_ws, sizeof(float) * (size_t)chunk * loss_stride))
         return rc;
     const IndexWs w0 = layout_index(nullptr, 1, B, t->U, IC, false, CH);
@@ -1755,7 +1962,7 @@ int sharded_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, int64_t I_global
         ctx->tickets_at = (char *)ctx->misc.ptr + part_bytes;
         ctx->tickets_bytes = ticket_bytes;
     }
-    if (int rc = crec_reserve(ctx, &ctx->contrib, sizeof(float) * (size_t)B * d))
+    if (int rc = crec_reserve(ctx, &ctx->contrib, 2 * sizeof(float) * (size_t)B * d))
         return rc;
 
     // plan-side workspace (sizes known up front) ...
@@ -1839,6 +2046,7 @@ int sharded_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, int64_t I_global
     a.partial = (float *)ctx->misc.ptr;
     a.tickets = (int32_t *)((char *)ctx->misc.ptr + part_bytes);
     a.contrib = (float *)ctx->contrib.ptr;
+    a.ucontrib = a.contrib + (size_t)B * d;
     int64_t sent_ids = 0, sent_rows = 0, sent_grads = 0, n_requested = 0, n_served = 0, max_served = 0;
 
     std::vector<int64_t> scnt(G), sdsp(G), rcnt(G), rdsp(G);
@@ -1935,7 +2143,7 @@ int sharded_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, int64_t I_global
         CREC_KLAUNCH(ctx, bpr_index_batches, dim3((unsigned)(2 * nbc)), dim3(PREP_THREADS), lds_idx, st, u + t0,
                      (const int32_t *)p.ci, (const int32_t *)p.cj, n_chunk, B, cap_idx, w);
         crec_prof_end(ctx, st);
-        const size_t n_hn = (size_t)nbc * 4;
+        const size_t n_hn = (size_t)nbc * HN;
         if (n_hn > ctx->pinned_ints) {
             if (ctx->pinned)
                 CREC_HIP(ctx, hipHostFree(ctx->pinned));
@@ -1947,10 +2155,12 @@ int sharded_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, int64_t I_global
         const int32_t *hn = ctx->pinned;
         CREC_HIP(ctx, hipMemcpyAsync(ctx->pinned, w.hn, sizeof(int32_t) * n_hn, hipMemcpyDeviceToHost, st));
         CREC_HIP(ctx, hipStreamSynchronize(st));
-        a.pad_wide = a.pad_chunks_u = a.pad_chunks_q = 0;
+        a.pad_wide = a.pad_chunks_u = a.pad_chunks_q = a.pad_multi_u = a.pad_multi_q = 0;
         for (int64_t b = 0; b < nbc; ++b) {
-            a.pad_chunks_u = hn[(size_t)b * 4 + 1] > a.pad_chunks_u ? hn[(size_t)b * 4 + 1] : a.pad_chunks_u;
-            a.pad_chunks_q = hn[(size_t)b * 4 + 3] > a.pad_chunks_q ? hn[(size_t)b * 4 + 3] : a.pad_chunks_q;
+            a.pad_chunks_u = hn[(size_t)b * HN + 1] > a.pad_chunks_u ? hn[(size_t)b * HN + 1] : a.pad_chunks_u;
+            a.pad_chunks_q = hn[(size_t)b * HN + 3] > a.pad_chunks_q ? hn[(size_t)b * HN + 3] : a.pad_chunks_q;
+            a.pad_multi_u = hn[(size_t)b * HN + 4] > a.pad_multi_u ? hn[(size_t)b * HN + 4] : a.pad_multi_u;
+            a.pad_multi_q = hn[(size_t)b * HN + 5] > a.pad_multi_q ? hn[(size_t)b * HN + 5] : a.pad_multi_q;
         }
         a.cur = Tables{t->P, t->mP, t->vP, p.Qc, nullptr, nullptr};
         // 6. the steps
@@ -1982,8 +2192,9 @@ int sharded_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, int64_t I_global
             a.h.reg = opt->reg;
             a.h.dQ = p.dQc; // the item side emits each compact row's gradient sum (incl. its l2 term) instead of Adam
             a.xb = (float *)ctx->loss_ws.ptr + b * loss_stride;
+            a.nb_cur = (int32_t)((n_chunk - b * B) < B ? (n_chunk - b * B) : B);
             a.rowterm = a.xb + B;
-            step(a, w, b, hn + b * 4);
+            step(a, w, b, hn + b * HN);
             // back: the gradient row of every item I referenced goes to its owner (the forward sizes, reversed)
             if (int rc = x->alltoallv(ctx, p.dQc, rcnt.data(), rdsp.data(), v.recvgrads, scnt.data(), sdsp.data(), 4, st))
                 return rc;

@@ -28,7 +28,7 @@ class BPR(RankingRecommender):
         self.P, self.Q = self.state.P, self.state.Q
 
     def _create_embeddings(self):
-        pass  # the three embedding_lookups (BPR.py:31-34) happen inside bpr_user_side
+        pass  # the three embedding_lookups (BPR.py:31-34) happen inside bpr_step_fused / bpr_triples_lazy
 
     def _create_inference(self):
         pass  # scores, loss and optimizer.minimize (BPR.py:36-44) are the fused step

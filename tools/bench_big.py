@@ -4,7 +4,7 @@
 Synthetic U = 10 M users x I = 1 M items, d = 128 fp32 (tables + Adam slots = 16.9 GB, far
 beyond the 256 MiB Infinity Cache), batch 6144, lazy Adam (only touched rows move; a TF1-exact
 dense sweep would stream all 16.9 GB per step).  Users uniform, positives Zipf(1.0), negatives
-uniform.  Measures the two kernels of the lazy step with HIP events and prices them against
+uniform.  Measures the two kernels of the lazy step (triple pass, multi-occurrence rows) with HIP events and prices them against
 SURVEY.md 8(d)'s algorithmic bytes: (24d+12) per triple + 28d per unique touched row.
 
     python tools/bench_big.py [--users 10000000] [--items 1000000] [--dim 128] [--steps 300]
@@ -57,28 +57,40 @@ def run(users=10_000_000, items=1_000_000, dim=128, steps=300, warmup=30, batch=
     prof = sess.ctx.profile_read()
     sess.ctx.profile(False)
 
-    # unique touched rows per batch (sampled) for the 28d Adam term
-    uq_u = uq_q = 0
+    # row multiplicities per batch (sampled): unique touched rows for the 28d Adam term, and which kernel owns a row --
+    # rows that occur once are finished by bpr_triples_lazy, the others by bpr_rows_lazy
+    uq_u = uq_q = single_u = single_q = multi_slots_q = multi_slots_u = 0
     sample = range(0, steps, max(1, steps // 16))
     for b in sample:
         sl = slice(nw + b * batch, nw + (b + 1) * batch)
-        uq_u += int(torch.unique(u[sl]).numel())
-        uq_q += int(torch.unique(torch.cat([i[sl], j[sl]])).numel())
-    uq_u /= len(sample)
-    uq_q /= len(sample)
+        cu = torch.unique(u[sl], return_counts=True)[1]
+        cq = torch.unique(torch.cat([i[sl], j[sl]]), return_counts=True)[1]
+        uq_u += int(cu.numel())
+        uq_q += int(cq.numel())
+        single_u += int((cu == 1).sum())
+        single_q += int((cq == 1).sum())
+        multi_slots_u += int(cu[cu > 1].sum())
+        multi_slots_q += int(cq[cq > 1].sum())
+    uq_u, uq_q, single_u, single_q = (x / len(sample) for x in (uq_u, uq_q, single_u, single_q))
+    multi_slots_u, multi_slots_q = multi_slots_u / len(sample), multi_slots_q / len(sample)
     d = dim
-    alg_user = batch * (16 * d + 12) + uq_u * 28 * d   # indices + 3 row reads + dL/dp, + Adam on the user rows
-    alg_item = batch * 8 * d + uq_q * 28 * d           # dL/dq_i, dL/dq_j, + Adam on the item rows
-    us = prof["bpr_user_side"][0] / prof["bpr_user_side"][1] * 1e3
-    it = prof["bpr_item_side"][0] / prof["bpr_item_side"][1] * 1e3
+    # (24d + 12) B per triple (3 ids, 3 row reads, 3 gradient rows) + 28d B per unique touched row (Adam).
+    # The triple pass owns the ids, the row reads, the gradient rows and the Adam traffic of the single-occurrence
+    # rows; the rows kernel owns the gradient rows (= the stored contribution rows it sums) and the Adam of the rest
+    alg_triples = batch * (12 * d + 12) + (single_u + single_q) * (4 * d + 28 * d)
+    alg_rows = (multi_slots_u + multi_slots_q) * 4 * d + (uq_u - single_u + uq_q - single_q) * 28 * d
+    us = prof["bpr_triples_lazy"][0] / prof["bpr_triples_lazy"][1] * 1e3
+    it = prof["bpr_rows_lazy"][0] / max(prof["bpr_rows_lazy"][1], 1) * 1e3
     out = {
         "workload": "S-big: %d users x %d items, d=%d fp32, batch %d, lazy Adam, Zipf(1.0) positives" % (users, items, dim, batch),
         "state_GB": (users + items) * dim * 4 * 3 / 1e9,
         "triples_per_s": steps * batch / dt, "us_per_step": dt / steps * 1e6,
         "unique_user_rows_per_batch": uq_u, "unique_item_rows_per_batch": uq_q,
-        "bpr_user_side": {"avg_us": us, "algorithmic_bytes": alg_user, "GBs": alg_user / us / 1e3, "frac_of_8TBs": alg_user / us / 1e3 / 8000},
-        "bpr_item_side": {"avg_us": it, "algorithmic_bytes": alg_item, "GBs": alg_item / it / 1e3, "frac_of_8TBs": alg_item / it / 1e3 / 8000},
-        "step_algorithmic_GBs": (alg_user + alg_item) / (dt / steps) / 1e9,
+        "single_occurrence_rows_per_batch": {"users": single_u, "items": single_q},
+        "bpr_triples_lazy": {"avg_us": us, "algorithmic_bytes": alg_triples, "GBs": alg_triples / us / 1e3, "frac_of_8TBs": alg_triples / us / 1e3 / 8000},
+        "bpr_rows_lazy": {"avg_us": it, "algorithmic_bytes": alg_rows, "GBs": alg_rows / max(it, 1e-9) / 1e3, "frac_of_8TBs": alg_rows / max(it, 1e-9) / 1e3 / 8000},
+        "step_algorithmic_bytes": batch * (24 * d + 12) + (uq_u + uq_q) * 28 * d,
+        "step_algorithmic_GBs": (batch * (24 * d + 12) + (uq_u + uq_q) * 28 * d) / (dt / steps) / 1e9,
         "bpr_index_batches_us_per_step": prof["bpr_index_batches"][0] * 1e3 / steps,
         "loss_first_last": [float(loss[0]), float(loss[-1])],
     }
