@@ -19,16 +19,18 @@
 //              side.  An item wave recomputes s_b = sigmoid(-x_b) of its occurrences from
 //              p_u, q_i, q_j with the very instruction sequence the user wave uses, so both
 //              sides use bit-identical s_b.
-//   lazy mode  two launches in place.  bpr_triples_lazy walks the batch triple by triple: a lane group loads
-//              p_u, q_i, q_j (and the Adam slots of those of the three rows that occur ONCE in the batch --
-//              the index kernel flags them) in one round of loads, computes x_b, s_b and the three gradient
-//              rows, applies Adam to the single-occurrence rows right there and stores contribution rows
-//              (s_b*p_u, s_b*(q_i-q_j)) only for rows that occur more than once.  bpr_rows_lazy then sums the
-//              stored contribution rows of every multi-occurrence row (+ reg*row per occurrence) and applies
-//              Adam.  A row that occurs once is touched by exactly one lane group, rows that occur more
-//              often are only READ by the first launch, so in place is safe.  Two dependent round trips per
-//              wave instead of the four of a row-major walk (row list -> records -> gathers -> slots).
-//   Either mode: a row with more than CH occurrences in the batch is cut into chunks handled by separate
+//   lazy mode  ONE launch in place, bpr_triples_lazy, a lane group per triple.  The index kernel tells every
+//              triple, for each of its three rows, whether the row occurs once in the batch.  One round of
+//              loads brings p_u, q_i, q_j and the Adam slots of the single-occurrence rows; those rows (nearly
+//              all of them when the tables are large) are finished right there -- no contribution rows, no
+//              second pass.  For a row that occurs several times every contributing group publishes its
+//              contribution row at the slot's position in the side's sorted order and draws a ticket on the
+//              row's counter; the group that draws the last one adds the row's contributions in sorted
+//              (= batch) order and applies Adam.  Rows with more than CH occurrences do this per chunk of CH
+//              slots first and then over the chunks' partial sums.  Nobody waits for anybody, every sum has
+//              one fixed order, and a multi-occurrence row is only ever written by its last contributor,
+//              after every reader of it has taken its ticket.
+//   tf1 mode:   a row with more than CH occurrences in the batch is cut into chunks handled by separate
 //              waves; the chunk wave that draws the row's last ticket sums the partials in chunk order and
 //              applies Adam (chunk_wave), so there is no extra launch.
 // Per chunk: bpr_reduce_loss sums the per-triple loss terms of each batch in a fixed order.
@@ -116,10 +118,10 @@ struct IndexWs {
     int2 *u_rowseg, *q_rowseg; // tf1 mode: [nbc][U], [nbc][I]  {segment start, length (negative: heavy row)}
     int32_t *hn;               // [nbc][HN]  {user heavy rows, user chunks, item heavy rows, item chunks, user multi rows,
                                //             item multi rows, -, -}
-    // lazy mode: per batch position, the triple's ids with bit 31 = "this row occurs once in the batch"
-    int32_t *u_flag, *i_flag, *j_flag; // [nbc][B]
-    int4 *u_multi, *q_multi;   // [nbc][MMu|MMq]  rows with 2..CH occurrences: {row, segment start, length, rank}
-    int64_t MMu, MMq;
+    // lazy mode: per batch position and role (user, positive, negative) {row | single << 31, k, start, cnt}: the row
+    // id (bit 31: it occurs once in the batch), the slot's position k in the side's sorted order, the row's segment
+    // [start, start + cnt) there.  These are the lazy step's whole index: nothing else is written in lazy mode.
+    int4 *u_desc, *i_desc, *j_desc; // [nbc][B]
     int4 *u_hrows, *q_hrows;   // [nbc][HRu|HRq]  {row, first chunk, chunks<<16 | length, rank among unique rows}
     int4 *u_hitems, *q_hitems; // [nbc][HIu|HIq]  {row, segment start, length | heavy row index << 8, chunk index}
     int64_t B, U, I, HRu, HRq, HIu, HIq;
@@ -156,39 +158,35 @@ IndexWs layout_index(void *base, int64_t nbc, int64_t B, int64_t U, int64_t I, b
     w.CH = CH;
     w.bits_u = row_bits(U);
     w.bits_q = row_bits(I);
-    w.HRu = B / (CH + 1) + 1;
-    w.HRq = 2 * B / (CH + 1) + 1;
-    w.HIu = B / CH + w.HRu + 1;
-    w.HIq = 2 * B / CH + w.HRq + 1;
+    w.HRu = dense ? B / (CH + 1) + 1 : 0;
+    w.HRq = dense ? 2 * B / (CH + 1) + 1 : 0;
+    w.HIu = dense ? B / CH + w.HRu + 1 : 0;
+    w.HIq = dense ? 2 * B / CH + w.HRq + 1 : 0;
     size_t off = 0;
     auto take = [&](size_t bytes) {
         char *p = base ? (char *)base + off : nullptr;
         off = align_up(off + bytes, 256);
         return (void *)p;
     };
-    w.n_u = (int32_t *)take(sizeof(int32_t) * nbc);
-    w.n_q = (int32_t *)take(sizeof(int32_t) * nbc);
-    w.u_rows = (int32_t *)take(sizeof(int32_t) * nbc * B);
-    w.u_seg = (int32_t *)take(sizeof(int32_t) * nbc * (B + 1));
-    w.u_occ = (int4 *)take(sizeof(int4) * nbc * B);
-    w.q_rows = (int32_t *)take(sizeof(int32_t) * nbc * 2 * B);
-    w.q_seg = (int32_t *)take(sizeof(int32_t) * nbc * (2 * B + 1));
-    w.q_occ = (int4 *)take(sizeof(int4) * nbc * 2 * B);
+    w.n_u = (int32_t *)take(sizeof(int32_t) * nbc * (dense ? 1 : 0));
+    w.n_q = (int32_t *)take(sizeof(int32_t) * nbc * (dense ? 1 : 0));
+    w.u_rows = (int32_t *)take(sizeof(int32_t) * nbc * (dense ? B : 0));
+    w.u_seg = (int32_t *)take(sizeof(int32_t) * nbc * (dense ? B + 1 : 0));
+    w.u_occ = (int4 *)take(sizeof(int4) * nbc * (dense ? B : 0));
+    w.q_rows = (int32_t *)take(sizeof(int32_t) * nbc * (dense ? 2 * B : 0));
+    w.q_seg = (int32_t *)take(sizeof(int32_t) * nbc * (dense ? 2 * B + 1 : 0));
+    w.q_occ = (int4 *)take(sizeof(int4) * nbc * (dense ? 2 * B : 0));
     w.u_rowseg = (int2 *)take(sizeof(int2) * nbc * w.U);
     w.q_rowseg = (int2 *)take(sizeof(int2) * nbc * w.I);
-    w.hn = (int32_t *)take(sizeof(int32_t) * nbc * HN);
+    w.hn = (int32_t *)take(sizeof(int32_t) * nbc * (dense ? HN : 0));
     w.nwide = (int32_t *)take(sizeof(int32_t) * nbc * 2); // right behind hn: the host reads both back with one copy
     w.u_hrows = (int4 *)take(sizeof(int4) * nbc * w.HRu);
     w.q_hrows = (int4 *)take(sizeof(int4) * nbc * w.HRq);
     w.u_hitems = (int4 *)take(sizeof(int4) * nbc * w.HIu);
     w.q_hitems = (int4 *)take(sizeof(int4) * nbc * w.HIq);
-    w.MMu = dense ? 0 : B / 2 + 1;
-    w.MMq = dense ? 0 : B + 1;
-    w.u_flag = (int32_t *)take(sizeof(int32_t) * nbc * (dense ? 0 : B));
-    w.i_flag = (int32_t *)take(sizeof(int32_t) * nbc * (dense ? 0 : B));
-    w.j_flag = (int32_t *)take(sizeof(int32_t) * nbc * (dense ? 0 : B));
-    w.u_multi = (int4 *)take(sizeof(int4) * nbc * w.MMu);
-    w.q_multi = (int4 *)take(sizeof(int4) * nbc * w.MMq);
+    w.u_desc = (int4 *)take(sizeof(int4) * nbc * (dense ? 0 : B));
+    w.i_desc = (int4 *)take(sizeof(int4) * nbc * (dense ? 0 : B));
+    w.j_desc = (int4 *)take(sizeof(int4) * nbc * (dense ? 0 : B));
     w.wide_rows = dense && wide_total > 0 ? wide_rows : 0;
     w.wide_total = wide_total;
     w.WMu = w.wide_rows ? B / (wide_total + 1) + 1 : 0;
@@ -262,17 +260,18 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
         seg[total] = (uint16_t)n;
     __syncthreads();
 
-    const bool lazy = (side ? w.I : w.U) == 0; // lazy mode keeps no per-table-row segments
-    if (lazy) { // every batch position learns whether its row occurs once in the batch (bit 31 of its id)
-        int r = rank_first;
+    if ((side ? w.I : w.U) == 0) { // lazy mode: the triple pass needs, per batch position and role, where the slot and its
+        int r = rank_first;        // row sit in the sorted order -- and nothing else
         for (int k = k0; k < k1; ++k) {
             if (k == 0 || rows[k] != rows[k - 1])
                 ++r;
-            const uint32_t single = ((int)seg[r] - (int)seg[r - 1]) == 1 ? 0x80000000u : 0u;
+            const int start = seg[r - 1], cnt = (int)seg[r] - start;
             const int slot = tag[k];
-            int32_t *dst = side == 0 ? w.u_flag : (slot < nb ? w.i_flag : w.j_flag);
-            dst[(int64_t)batch * B + (slot < nb ? slot : slot - nb)] = (int32_t)(rows[k] | single);
+            int4 *dst = side == 0 ? w.u_desc : (slot < nb ? w.i_desc : w.j_desc);
+            dst[(int64_t)batch * B + (slot < nb ? slot : slot - nb)] =
+                make_int4((int)(rows[k] | (cnt == 1 ? 0x80000000u : 0u)), k, start, cnt);
         }
+        return;
     }
 
     CREC_IDX_MARK(2);
@@ -301,24 +300,6 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
                     ++hitem;
                 }
             }
-        }
-    }
-
-    // lazy mode: the rows with 2..CH occurrences, in rank order (their sums are formed by bpr_rows_lazy; rows with one
-    // occurrence are finished by bpr_triples_lazy, rows with more than CH by the chunk waves)
-    int multi_total = 0;
-    if (lazy) {
-        int nm = 0;
-        for (int q = q0; q < q1; ++q) {
-            const int cnt = (int)seg[q + 1] - (int)seg[q];
-            nm += (cnt >= 2 && cnt <= CH) ? 1 : 0;
-        }
-        int at = crec_sort::block_excl_scan<PREP_THREADS>(nm, scan, &multi_total);
-        int4 *multi_out = side ? w.q_multi + (int64_t)batch * w.MMq : w.u_multi + (int64_t)batch * w.MMu;
-        for (int q = q0; q < q1; ++q) {
-            const int k = seg[q], cnt = (int)seg[q + 1] - k;
-            if (cnt >= 2 && cnt <= CH)
-                multi_out[at++] = make_int4((int)rows[k], k, cnt, q);
         }
     }
 
@@ -419,7 +400,6 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
         (side ? w.n_q : w.n_u)[batch] = total;
         w.hn[batch * HN + side * 2 + 0] = hv_total >> 16;
         w.hn[batch * HN + side * 2 + 1] = hv_total & 0xffff;
-        w.hn[batch * HN + 4 + side] = multi_total;
         w.nwide[batch * 2 + side] = wide_total_n;
     }
     CREC_IDX_MARK(6);
@@ -1131,22 +1111,27 @@ __device__ __forceinline__ void chunk_wave(const Tables &src, int d, int4 item, 
         __threadfence();
     else
         asm volatile("" ::: "memory");
-    grad = zero;
-    if (on) {
-        const float *pp = partial + (int64_t)first * d + 4 * l;
-        const auto ldp = [](const float *q) { return CREC_TICKET_FENCES ? ld4(q) : ld4_agent(q); };
-        int p = 0;
-        for (; p + 8 <= parts; p += 8) { // chunk order, eight rows in flight
-            float4 t[8];
+    // the partials, chunk c by group c % G, eight in flight per group; then the groups' sums in the fixed order of the
+    // cross-group reduction -- one order whichever wave ends up here (a single group reading all partials in sequence
+    // was the longest link of a heavy row's chain: 54 partials = 7 dependent rounds)
+    {
+        constexpr int G = 64 / LPR;
+        AccArr<LPR, 1 | (FULL ? 0x100 : 0)> accp;
+        accp[0] = zero;
+        if (act) {
+            const float *pp = partial + (int64_t)first * d + 4 * l;
+            const auto ldp = [](const float *q) { return CREC_TICKET_FENCES ? ld4(q) : ld4_agent(q); };
+            for (int p0 = g; p0 < parts; p0 += 8 * G) {
+                float4 t[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
-                t[k] = ldp(pp + (int64_t)(p + k) * d);
+                for (int k = 0; k < 8; ++k)
+                    t[k] = (p0 + k * G) < parts ? ldp(pp + (int64_t)(p0 + k * G) * d) : zero;
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
-                add4(grad, t[k]);
+                for (int k = 0; k < 8; ++k)
+                    add4(accp[0], t[k]);
+            }
         }
-        for (; p < parts; ++p)
-            add4(grad, ldp(pp + (int64_t)p * d));
+        grad = reduce_to_owner<LPR, 1 | (FULL ? 0x100 : 0)>(accp);
     }
     const float nr = group_sum<LPR>(dot4(var, var));
     if (on) {
@@ -1295,26 +1280,112 @@ __global__ __launch_bounds__(CREC_FUSED_BLOCK) void bpr_step_fused(Tables src, T
 }
 
 // ------------------------------------------------------------------------------------
-// lazy mode: touched rows only, in place, two launches
+// lazy mode: touched rows only, in place, one launch
 // ------------------------------------------------------------------------------------
-// bpr_triples_lazy: a lane group per triple.  uf / jf / if_: the triple's ids by batch position, bit 31 = the row
-// occurs once in the batch (bpr_index_batches).  One round of loads brings p_u, q_i, q_j and the slots of the
-// single-occurrence rows; those rows are finished here, rows that occur more often only leave a contribution row.
+struct LazyBufs {
+    float *ucontrib, *qcontrib; // [B][d], [2B][d] contribution rows by sorted slot position (sign and s_b applied)
+    float *upart, *qpart;       // [B][d], [2B][d] partial sums of heavy rows' chunks, at the chunk's first slot position
+    int32_t *urow_t, *uchk_t;   // [B] ticket counters by segment start / chunk start, zero between launches
+    int32_t *qrow_t, *qchk_t;   // [2B]
+    int32_t CH;                 // slots per chunk of a heavy row
+};
+
+// sum of n rows base[0], base[stride], ... in that order, each plus `add` (reg * row, or zero); agent-scope loads
+// (the rows were published by other waves, possibly on another XCD), eight in flight
+__device__ __forceinline__ float4 lazy_sum_rows(const float *base, int n, int64_t stride, float4 add)
+{
+    constexpr int DEEP = 8; // sixteen in flight cost 32 more VGPRs on every wave of the launch (occupancy 4 -> 3)
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k0 = 0; k0 < n; k0 += DEEP) {
+        float4 c[DEEP];
+#pragma unroll
+        for (int e = 0; e < DEEP; ++e)
+            c[e] = k0 + e < n ? ld4_agent(base + (int64_t)(k0 + e) * stride) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int e = 0; e < DEEP; ++e)
+            if (k0 + e < n)
+                add4(g, make_float4(c[e].x + add.x, c[e].y + add.y, c[e].z + add.z, c[e].w + add.w));
+    }
+    return g;
+}
+
+// One multi-occurrence row of this group's triple, after the group's contribution row has been published (and the
+// wave has waited for the store): draw a ticket; the last contributor of the row -- of the chunk first, for a heavy
+// row -- forms the sum in sorted order and finishes the row.  Every lane of the group takes the same path.
+template <int LPR, bool USER>
+__device__ __forceinline__ void lazy_role_tail(const Tables &t, int d, bool act, int4 desc, float4 own, float *cbuf, float *pbuf,
+                                               int32_t *row_t, int32_t *chk_t, int CH, const Hyper &h)
+{
+    const int lane = threadIdx.x & 63, l = lane % LPR, lead = lane - l;
+    const int k = desc.y, start = desc.z, cnt = desc.w;
+    const bool light = cnt <= CH;
+    const int idx = light ? start : start + (k - start) / CH * CH; // the counter / first slot of the row or of the chunk
+    const int need = light ? cnt : ((cnt - (idx - start)) < CH ? (cnt - (idx - start)) : CH);
+    int32_t *ctr = (light ? row_t : chk_t) + idx;
+    int tk = -1;
+    if (l == 0)
+        tk = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    tk = __shfl(tk, lead, 64);
+    if (tk != need - 1)
+        return;
+    asm volatile("" ::: "memory");
+    const int64_t ro = (int64_t)(desc.x & 0x7fffffff) * d + 4 * l;
+    const bool slots = act && (USER || !h.dQ);
+    // the slots are only needed at the very end: asked for now, their round trip hides behind the contributions'
+    float4 m = slots ? ld4((USER ? t.mP : t.mQ) + ro) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 v = slots ? ld4((USER ? t.vP : t.vQ) + ro) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 regrow = make_float4(h.reg * own.x, h.reg * own.y, h.reg * own.z, h.reg * own.w);
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (act)
+        g = lazy_sum_rows(cbuf + (int64_t)idx * d + 4 * l, need, d, regrow);
+    if (l == 0)
+        __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next launch
+    if (!light) { // a chunk of a heavy row: publish the partial, then the same game over the row's chunks
+        if (act)
+            st4_agent(pbuf + (int64_t)idx * d + 4 * l, g);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int parts = (cnt + CH - 1) / CH;
+        int t2 = -1;
+        if (l == 0)
+            t2 = __hip_atomic_fetch_add(row_t + start, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t2 = __shfl(t2, lead, 64);
+        if (t2 != parts - 1)
+            return;
+        asm volatile("" ::: "memory");
+        if (act)
+            g = lazy_sum_rows(pbuf + (int64_t)start * d + 4 * l, parts, (int64_t)CH * d, make_float4(0.f, 0.f, 0.f, 0.f));
+        if (l == 0)
+            __hip_atomic_store(row_t + start, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!act)
+        return;
+    if (!USER && h.dQ) { // row-sharded step: the item row's gradient sum goes back to its owner
+        st4(h.dQ + ro, g);
+        return;
+    }
+    float4 nv = own;
+    adam4(nv, m, v, g, true, h);
+    st4((USER ? t.P : t.Q) + ro, nv);
+    st4((USER ? t.mP : t.mQ) + ro, m);
+    st4((USER ? t.vP : t.vQ) + ro, v);
+}
+
+// bpr_triples_lazy: a lane group per triple; ud / id / jd: the triple's three roles by batch position (IndexWs).
 template <int LPR, bool FULL>
-__global__ __launch_bounds__(256) void bpr_triples_lazy(Tables t, int d, const int32_t *__restrict__ uf,
-                                                        const int32_t *__restrict__ if_, const int32_t *__restrict__ jf,
-                                                        int nb, float *__restrict__ contrib, float *__restrict__ ucontrib,
-                                                        float *__restrict__ xb, float *__restrict__ l2b, Hyper h)
+__global__ __launch_bounds__(256) void bpr_triples_lazy(Tables t, int d, const int4 *__restrict__ ud,
+                                                        const int4 *__restrict__ id, const int4 *__restrict__ jd, int nb,
+                                                        LazyBufs z, float *__restrict__ xb, float *__restrict__ l2b, Hyper h)
 {
     constexpr int G = 64 / LPR;
     const int lane = threadIdx.x & 63, g = lane / LPR, l = lane % LPR;
     const int pos = (int)((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * G + g);
     const bool valid = pos < nb, act = FULL || 4 * l < d, on = valid && act;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int32_t ru = valid ? uf[pos] : 0, ri = valid ? if_[pos] : 0, rj = valid ? jf[pos] : 0;
-    const bool us = ru < 0, is = ri < 0, js = rj < 0;
-    const int64_t ou = (int64_t)(ru & 0x7fffffff) * d + 4 * l, oi = (int64_t)(ri & 0x7fffffff) * d + 4 * l,
-                  oj = (int64_t)(rj & 0x7fffffff) * d + 4 * l;
+    const int4 none = make_int4((int)0x80000000u, 0, 0, 1); // a dead group: "single" rows, no tails
+    const int4 du = valid ? ud[pos] : none, di = valid ? id[pos] : none, dj = valid ? jd[pos] : none;
+    const bool us = du.x < 0, is = di.x < 0, js = dj.x < 0;
+    const int64_t ou = (int64_t)(du.x & 0x7fffffff) * d + 4 * l, oi = (int64_t)(di.x & 0x7fffffff) * d + 4 * l,
+                  oj = (int64_t)(dj.x & 0x7fffffff) * d + 4 * l;
     const bool item_adam = h.dQ == nullptr; // the row-sharded step only emits the item rows' gradient sums
     float4 p = zero, qi = zero, qj = zero, mp = zero, vp = zero, mi = zero, vi = zero, mj = zero, vj = zero;
     if (on) { // every address is known: one round of loads
@@ -1341,142 +1412,62 @@ __global__ __launch_bounds__(256) void bpr_triples_lazy(Tables t, int d, const i
         xb[pos] = x; // softplus(-x) is taken in bpr_reduce_loss
         l2b[pos] = l2;
     }
-    if (!on)
-        return;
-    // user row: -s*(q_i - q_j) + reg*p
-    const float4 dq = make_float4(qi.x - qj.x, qi.y - qj.y, qi.z - qj.z, qi.w - qj.w);
-    if (us) {
-        const float ns = -s;
-        const float4 gp = make_float4(ns * dq.x + h.reg * p.x, ns * dq.y + h.reg * p.y, ns * dq.z + h.reg * p.z, ns * dq.w + h.reg * p.w);
-        float4 np = p;
-        adam4(np, mp, vp, gp, true, h);
-        st4s(t.P + ou, np);
-        st4s(t.mP + ou, mp);
-        st4s(t.vP + ou, vp);
-    } else {
-        st4s(ucontrib + (int64_t)pos * d + 4 * l, make_float4(s * dq.x, s * dq.y, s * dq.z, s * dq.w));
-    }
-    // item rows: -/+ s*p + reg*q
-    const float4 sp = make_float4(s * p.x, s * p.y, s * p.z, s * p.w);
-    if (is) {
-        const float4 gi = make_float4(-sp.x + h.reg * qi.x, -sp.y + h.reg * qi.y, -sp.z + h.reg * qi.z, -sp.w + h.reg * qi.w);
-        if (item_adam) {
-            float4 nq = qi;
-            adam4(nq, mi, vi, gi, true, h);
-            st4s(t.Q + oi, nq);
-            st4s(t.mQ + oi, mi);
-            st4s(t.vQ + oi, vi);
+    // user row: -s*(q_i - q_j) + reg*p; item rows: -/+ s*p + reg*q.  A row that occurs once is finished here; of a row
+    // that occurs more often only the contribution (without the reg term) is published, at its slot's sorted position
+    const float ns = -s;
+    const float4 cu = make_float4(ns * (qi.x - qj.x), ns * (qi.y - qj.y), ns * (qi.z - qj.z), ns * (qi.w - qj.w));
+    const float4 sp = make_float4(s * p.x, s * p.y, s * p.z, s * p.w), nsp = make_float4(-sp.x, -sp.y, -sp.z, -sp.w);
+    if (on) {
+        if (us) {
+            const float4 gp = make_float4(cu.x + h.reg * p.x, cu.y + h.reg * p.y, cu.z + h.reg * p.z, cu.w + h.reg * p.w);
+            float4 np = p;
+            adam4(np, mp, vp, gp, true, h);
+            st4s(t.P + ou, np);
+            st4s(t.mP + ou, mp);
+            st4s(t.vP + ou, vp);
         } else {
-            st4s(h.dQ + oi, gi);
+            st4_agent(z.ucontrib + (int64_t)du.y * d + 4 * l, cu);
         }
-    }
-    if (js) {
-        const float4 gj = make_float4(sp.x + h.reg * qj.x, sp.y + h.reg * qj.y, sp.z + h.reg * qj.z, sp.w + h.reg * qj.w);
-        if (item_adam) {
-            float4 nq = qj;
-            adam4(nq, mj, vj, gj, true, h);
-            st4s(t.Q + oj, nq);
-            st4s(t.mQ + oj, mj);
-            st4s(t.vQ + oj, vj);
+        if (is) {
+            const float4 gi = make_float4(nsp.x + h.reg * qi.x, nsp.y + h.reg * qi.y, nsp.z + h.reg * qi.z, nsp.w + h.reg * qi.w);
+            if (item_adam) {
+                float4 nq = qi;
+                adam4(nq, mi, vi, gi, true, h);
+                st4s(t.Q + oi, nq);
+                st4s(t.mQ + oi, mi);
+                st4s(t.vQ + oi, vi);
+            } else {
+                st4s(h.dQ + oi, gi);
+            }
         } else {
-            st4s(h.dQ + oj, gj);
+            st4_agent(z.qcontrib + (int64_t)di.y * d + 4 * l, nsp);
+        }
+        if (js) {
+            const float4 gj = make_float4(sp.x + h.reg * qj.x, sp.y + h.reg * qj.y, sp.z + h.reg * qj.z, sp.w + h.reg * qj.w);
+            if (item_adam) {
+                float4 nq = qj;
+                adam4(nq, mj, vj, gj, true, h);
+                st4s(t.Q + oj, nq);
+                st4s(t.mQ + oj, mj);
+                st4s(t.vQ + oj, vj);
+            } else {
+                st4s(h.dQ + oj, gj);
+            }
+        } else {
+            st4_agent(z.qcontrib + (int64_t)dj.y * d + 4 * l, sp);
         }
     }
-    if (!is || !js)
-        st4s(contrib + (int64_t)pos * d + 4 * l, sp);
-}
-
-// a row with 2..CH occurrences: all groups of the wave walk its occurrences (eight contribution rows in flight per
-// group), the partial sums meet in group 0, Adam in place (items of the row-sharded step: the gradient row instead)
-template <int LPR, bool USER, bool FULL>
-__device__ __forceinline__ void multi_row_wave(const Tables &t, int d, int4 item, const int4 *__restrict__ occ,
-                                               const float *__restrict__ contrib, const Hyper &h)
-{
-    constexpr int G = 64 / LPR, DEEP = 8;
-    const int lane = threadIdx.x & 63, g = lane / LPR, l = lane % LPR;
-    const bool act = FULL || 4 * l < d, on = g == 0 && act;
-    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int64_t ro = (int64_t)item.x * d + 4 * l;
-    const int start = item.y, cnt = item.z;
-    const bool slots = on && (USER || !h.dQ);
-    const float4 var = act ? ld4((USER ? t.P : t.Q) + ro) : zero;
-    float4 m = slots ? ld4s((USER ? t.mP : t.mQ) + ro) : zero, v = slots ? ld4s((USER ? t.vP : t.vQ) + ro) : zero;
-    AccArr<LPR, 1 | (FULL ? 0x100 : 0)> acc;
-    acc[0] = zero;
-    const int mine = lane < cnt ? occ[start + lane].w : 0; // cnt <= CH <= 255; the records of one row: one load for <= 64
-    for (int c0 = 0; c0 < cnt; c0 += 64) {
-        const int nc = (cnt - c0) < 64 ? (cnt - c0) : 64;
-        const int rec = c0 == 0 ? mine : (lane < nc ? occ[start + c0 + lane].w : 0);
-        const int n_sub = (nc + G - 1) / G;
-        for (int t0 = 0; t0 < n_sub; t0 += DEEP) {
-            float4 a[DEEP];
-            int rw[DEEP];
-            bool has[DEEP];
-#pragma unroll
-            for (int e = 0; e < DEEP; ++e) {
-                const int kk = (t0 + e) * G + g;
-                rw[e] = __shfl(rec, kk & 63, 64);
-                has[e] = (t0 + e) < n_sub && kk < nc;
-                a[e] = (has[e] && act) ? ld4(contrib + (int64_t)(rw[e] & 0x7fffffff) * d + 4 * l) : zero;
-            }
-#pragma unroll
-            for (int e = 0; e < DEEP; ++e) {
-                const float sg = rw[e] < 0 ? 1.0f : -1.0f, k = (has[e] && act) ? 1.0f : 0.0f;
-                add4(acc[0], make_float4(k * (sg * a[e].x + h.reg * var.x), k * (sg * a[e].y + h.reg * var.y),
-                                         k * (sg * a[e].z + h.reg * var.z), k * (sg * a[e].w + h.reg * var.w)));
-            }
-        }
-    }
-    const float4 grad = reduce_to_owner<LPR, 1 | (FULL ? 0x100 : 0)>(acc);
-    if (!on)
-        return;
-    if (!USER && h.dQ) {
-        st4(h.dQ + ro, grad);
-        return;
-    }
-    float4 nv = var;
-    adam4(nv, m, v, grad, true, h);
-    st4s((USER ? t.P : t.Q) + ro, nv);
-    st4s((USER ? t.mP : t.mQ) + ro, m);
-    st4s((USER ? t.vP : t.vQ) + ro, v);
-}
-
-// bpr_rows_lazy: wave ids [0, pcu) user heavy-row chunks, [pcu, pcu+pcq) item heavy-row chunks, then pmu waves for the
-// user rows with 2..CH occurrences, then pmq for the item rows (p*: the chunk's largest counts; surplus waves exit)
-struct RowsLazyArgs {
-    const int32_t *hn; // this batch's counters {.., user chunks, .., item chunks, user multi rows, item multi rows}
-    const int4 *u_hitems, *q_hitems, *u_hrows, *q_hrows, *u_multi, *q_multi, *u_occ, *q_occ;
-    int32_t *tickets_u, *tickets_q;
-    float *partial_u, *partial_q, *contrib, *ucontrib;
-    int pcu, pcq, pmu, pmq;
-};
-
-template <int LPR, bool FULL>
-__global__ __launch_bounds__(256, CREC_LAZY_ITEM_WAVES) void bpr_rows_lazy(Tables t, int d, RowsLazyArgs r, Hyper h)
-{
-    int wave_id = (int)(blockIdx.x * (blockDim.x >> 6)) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (wave_id < r.pcu) {
-        if (wave_id < r.hn[1])
-            chunk_wave<LPR, 3, false, FULL>(t, d, r.u_hitems[wave_id], r.u_occ, r.ucontrib, nullptr, r.partial_u,
-                                            FinishArgs{r.u_hrows, r.tickets_u, t, nullptr, 0}, h);
-        return;
-    }
-    wave_id -= r.pcu;
-    if (wave_id < r.pcq) {
-        if (wave_id < r.hn[3])
-            chunk_wave<LPR, 2, false, FULL>(t, d, r.q_hitems[wave_id], r.q_occ, r.contrib, nullptr, r.partial_q,
-                                            FinishArgs{r.q_hrows, r.tickets_q, t, nullptr, 0}, h);
-        return;
-    }
-    wave_id -= r.pcq;
-    if (wave_id < r.pmu) {
-        if (wave_id < r.hn[4])
-            multi_row_wave<LPR, true, FULL>(t, d, r.u_multi[wave_id], r.u_occ, r.ucontrib, h);
-        return;
-    }
-    wave_id -= r.pmu;
-    if (wave_id < r.pmq && wave_id < r.hn[5])
-        multi_row_wave<LPR, false, FULL>(t, d, r.q_multi[wave_id], r.q_occ, r.contrib, h);
+    if (__builtin_amdgcn_ballot_w64(!(us && is && js)) == 0)
+        return; // the usual wave on large tables: nothing but single-occurrence rows
+    // the contribution rows travel with agent-scope stores; wait for their completion before any ticket (the same
+    // guarantee as a release fence for these buffers, without writing back the whole L2)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!us)
+        lazy_role_tail<LPR, true>(t, d, act, du, p, z.ucontrib, z.upart, z.urow_t, z.uchk_t, z.CH, h);
+    if (!is)
+        lazy_role_tail<LPR, false>(t, d, act, di, qi, z.qcontrib, z.qpart, z.qrow_t, z.qchk_t, z.CH, h);
+    if (!js)
+        lazy_role_tail<LPR, false>(t, d, act, dj, qj, z.qcontrib, z.qpart, z.qrow_t, z.qchk_t, z.CH, h);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1568,8 +1559,7 @@ struct StepArgs {
     // (CREC_WIDE_ROUND=7 vs 8).  Every step of a chunk is launched with the chunk's largest counts; surplus waves
     // exit at once.
     int pad_wide, pad_chunks_u, pad_chunks_q; // max over the chunk of NWu+NWq, HIu, HIq
-    int pad_multi_u, pad_multi_q;             // lazy mode: max over the chunk of the rows with 2..CH occurrences
-    float *ucontrib;                          // lazy mode: [B][d] s_b*(q_i-q_j) of the triples whose user occurs more than once
+    LazyBufs lazy;                            // lazy mode: contribution rows, partials, ticket counters
     int32_t nb_cur;                           // triples in the batch being launched
     int wide_round;                           // CREC_WIDE_ROUND, read once per epoch (0: unset)
 };
@@ -1624,35 +1614,35 @@ template <int LPR, bool FULL> void launch_lazy(const StepArgs &a, const IndexWs 
     (void)hn;
     crec_prof_begin(a.ctx, CREC_K_USER_SIDE, a.st);
     CREC_KLAUNCH(a.ctx, (bpr_triples_lazy<LPR, FULL>), dim3((unsigned)crec_ceil_div(a.nb_cur, 4 * G)), dim3(256), 0, a.st, a.cur, a.d,
-                 (const int32_t *)(w.u_flag + b * w.B), (const int32_t *)(w.i_flag + b * w.B), (const int32_t *)(w.j_flag + b * w.B),
-                 (int)a.nb_cur, a.contrib, a.ucontrib, a.xb, a.rowterm, a.h);
+                 (const int4 *)(w.u_desc + b * w.B), (const int4 *)(w.i_desc + b * w.B), (const int4 *)(w.j_desc + b * w.B),
+                 (int)a.nb_cur, a.lazy, a.xb, a.rowterm, a.h);
     crec_prof_end(a.ctx, a.st);
-    RowsLazyArgs r;
-    r.hn = w.hn + b * HN;
-    r.u_hitems = w.u_hitems + b * w.HIu;
-    r.q_hitems = w.q_hitems + b * w.HIq;
-    r.u_hrows = w.u_hrows + b * w.HRu;
-    r.q_hrows = w.q_hrows + b * w.HRq;
-    r.u_multi = w.u_multi + b * w.MMu;
-    r.q_multi = w.q_multi + b * w.MMq;
-    r.u_occ = w.u_occ + b * w.B;
-    r.q_occ = w.q_occ + b * 2 * w.B;
-    r.tickets_u = a.tickets;
-    r.tickets_q = a.tickets + w.HRu;
-    r.partial_u = a.partial;
-    r.partial_q = a.partial + (int64_t)w.HIu * a.d; // fixed split: the user chunks' partials never reach beyond HIu rows
-    r.contrib = a.contrib;
-    r.ucontrib = a.ucontrib;
-    r.pcu = a.pad_chunks_u;
-    r.pcq = a.pad_chunks_q;
-    r.pmu = a.pad_multi_u;
-    r.pmq = a.pad_multi_q;
-    const int64_t waves = (int64_t)r.pcu + r.pcq + r.pmu + r.pmq;
-    if (waves == 0)
-        return;
-    crec_prof_begin(a.ctx, CREC_K_ITEM_SIDE, a.st);
-    CREC_KLAUNCH(a.ctx, (bpr_rows_lazy<LPR, FULL>), dim3((unsigned)crec_ceil_div(waves, 4)), dim3(256), 0, a.st, a.cur, a.d, r, a.h);
-    crec_prof_end(a.ctx, a.st);
+}
+
+// lazy mode: contribution rows and partials by sorted slot position (user side B slots, item side 2B), then the
+// ticket counters, cleared here once -- the kernels leave them at zero
+int setup_lazy_bufs(crec_ctx *ctx, int64_t B, int d, int CH, hipStream_t st, LazyBufs *z)
+{
+    const size_t rows = 6 * (size_t)B, row_bytes = align_up(sizeof(float) * rows * d, 256), ctr_bytes = sizeof(int32_t) * rows;
+    if (int rc = crec_reserve(ctx, &ctx->contrib, row_bytes + ctr_bytes))
+        return rc;
+    float *f = (float *)ctx->contrib.ptr;
+    z->ucontrib = f;
+    z->qcontrib = f + (size_t)B * d;
+    z->upart = f + 3 * (size_t)B * d;
+    z->qpart = f + 4 * (size_t)B * d;
+    int32_t *c = (int32_t *)((char *)ctx->contrib.ptr + row_bytes);
+    z->urow_t = c;
+    z->uchk_t = c + B;
+    z->qrow_t = c + 2 * B;
+    z->qchk_t = c + 4 * B;
+    z->CH = CH;
+    if (ctx->lazy_tickets_at != (char *)c || ctx->lazy_tickets_bytes != ctr_bytes) {
+        CREC_HIP(ctx, hipMemsetAsync(c, 0, ctr_bytes, st));
+        ctx->lazy_tickets_at = (char *)c;
+        ctx->lazy_tickets_bytes = ctr_bytes;
+    }
+    return CREC_OK;
 }
 
 using StepFn = void (*)(const StepArgs &, const IndexWs &, int64_t, const int32_t *);
@@ -1715,7 +1705,7 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
     // occurrences per heavy-row chunk: short chunks shorten the longest wave, every chunk wave pays a ticket on its
     // row's counter.  Item side of S-big: CH 8 -> 12.4 us, 16 -> 11.4, 32 -> 12.0 (with fence-published partials the
     // sweep read 16 -> 16.3, 32 -> 13.7, 64 -> 15.3).  tf1 mode at ml-1m shape: 32 -> 14.4 us/step, 64 -> 13.2.
-    const int CH = ctx->knob_ch > 0 ? ctx->knob_ch : (dense ? 64 : 16);
+    const int CH = ctx->knob_ch > 0 ? ctx->knob_ch : (dense ? 64 : 32);
     CREC_REQUIRE(ctx, CH >= 1 && CH <= 255, "option ch: 1..255");
 
     // wide groups (tf1 mode): the rows of a row wave that hold more than `wide_total` occurrences together go to a
@@ -1746,7 +1736,7 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
     if (int rc = crec_reserve(ctx, &ctx->misc, part_bytes + ticket_bytes))
         return rc;
     // the finishing wave of a heavy row re-zeroes its counter, so the counters only need clearing when they move
-    if (ctx->tickets_at != (char *)ctx->misc.ptr + part_bytes || ctx->tickets_bytes != ticket_bytes) {
+    if (ticket_bytes && (ctx->tickets_at != (char *)ctx->misc.ptr + part_bytes || ctx->tickets_bytes != ticket_bytes)) {
         CREC_HIP(ctx, hipMemsetAsync((char *)ctx->misc.ptr + part_bytes, 0, ticket_bytes, st));
         ctx->tickets_at = (char *)ctx->misc.ptr + part_bytes;
         ctx->tickets_bytes = ticket_bytes;
@@ -1779,10 +1769,8 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
                 return rc;
         }
     } else {
-        if (int rc = crec_reserve(ctx, &ctx->contrib, 2 * sizeof(float) * (size_t)B * t->d))
+        if (int rc = setup_lazy_bufs(ctx, B, t->d, CH, st, &a.lazy))
             return rc;
-        a.contrib = (float *)ctx->contrib.ptr;
-        a.ucontrib = a.contrib + (size_t)B * t->d;
     }
 
     // dynamic LDS of the index kernel
@@ -1805,8 +1793,10 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
         crec_prof_end(ctx, st);
         // the chunk's counts come back into page-locked memory: a pageable destination is staged and costs tens of
         // microseconds per copy, once per epoch -- a tenth of an ml-100k epoch of 45 steps
-        // one copy for both arrays: a device-to-host copy costs ~10 us of latency whatever its size
-        const size_t nw_off = (size_t)(w.nwide - w.hn), n_back = nw_off + (size_t)nbc * 2;
+        // tf1 mode: the chunk's counts of heavy-row chunks and wide groups size the launches.  One copy for both arrays:
+        // a device-to-host copy costs ~10 us of latency whatever its size.  (Lazy mode has nothing to read back: its
+        // launches are sized by the batch alone, so the whole epoch is enqueued without a host synchronisation.)
+        const size_t nw_off = (size_t)(w.nwide - w.hn), n_back = dense ? nw_off + (size_t)nbc * 2 : 0;
         if (n_back > ctx->pinned_ints) {
             if (ctx->pinned)
                 CREC_HIP(ctx, hipHostFree(ctx->pinned));
@@ -1817,16 +1807,16 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
         }
         const int32_t *hn = ctx->pinned, *nwide = ctx->pinned + nw_off;
         a.nwide = nwide;
-        CREC_HIP(ctx, hipMemcpyAsync(ctx->pinned, w.hn, sizeof(int32_t) * n_back, hipMemcpyDeviceToHost, st));
-        CREC_HIP(ctx, hipStreamSynchronize(st));
-        a.pad_wide = a.pad_chunks_u = a.pad_chunks_q = a.pad_multi_u = a.pad_multi_q = 0;
-        for (int64_t b = 0; b < nbc; ++b) {
+        if (dense) {
+            CREC_HIP(ctx, hipMemcpyAsync(ctx->pinned, w.hn, sizeof(int32_t) * n_back, hipMemcpyDeviceToHost, st));
+            CREC_HIP(ctx, hipStreamSynchronize(st));
+        }
+        a.pad_wide = a.pad_chunks_u = a.pad_chunks_q = 0;
+        for (int64_t b = 0; b < (dense ? nbc : 0); ++b) {
             const int nw = nwide[(size_t)b * 2] + nwide[(size_t)b * 2 + 1];
             a.pad_wide = nw > a.pad_wide ? nw : a.pad_wide;
             a.pad_chunks_u = hn[(size_t)b * HN + 1] > a.pad_chunks_u ? hn[(size_t)b * HN + 1] : a.pad_chunks_u;
             a.pad_chunks_q = hn[(size_t)b * HN + 3] > a.pad_chunks_q ? hn[(size_t)b * HN + 3] : a.pad_chunks_q;
-            a.pad_multi_u = hn[(size_t)b * HN + 4] > a.pad_multi_u ? hn[(size_t)b * HN + 4] : a.pad_multi_u;
-            a.pad_multi_q = hn[(size_t)b * HN + 5] > a.pad_multi_q ? hn[(size_t)b * HN + 5] : a.pad_multi_q;
         }
         for (int64_t b = 0; b < nbc; ++b) {
             // lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t) with fp32 running powers (TF1 _prepare/_finish)
@@ -1939,7 +1929,7 @@ int sharded_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, int64_t I_global
     const int64_t nb = crec_ceil_div(N, B);
     const int64_t IC = 2 * (int64_t)B; // compact item id space of a batch
     StepFn step = pick_step(d, false);
-    const int CH = ctx->knob_ch > 0 ? ctx->knob_ch : 16;
+    const int CH = ctx->knob_ch > 0 ? ctx->knob_ch : 32;
     CREC_REQUIRE(ctx, CH >= 1 && CH <= 255, "option ch: 1..255");
 
     const size_t per_batch = layout_index(nullptr, 1, B, t->U, IC, false, CH).bytes;
@@ -1957,13 +1947,12 @@ int sharded_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, int64_t I_global
     if (int rc = crec_reserve(ctx, &ctx->misc, part_bytes + ticket_bytes))
         return rc;
     // the finishing wave of a heavy row re-zeroes its counter, so the counters only need clearing when they move
-    if (ctx->tickets_at != (char *)ctx->misc.ptr + part_bytes || ctx->tickets_bytes != ticket_bytes) {
+    if (ticket_bytes && (ctx->tickets_at != (char *)ctx->misc.ptr + part_bytes || ctx->tickets_bytes != ticket_bytes)) {
         CREC_HIP(ctx, hipMemsetAsync((char *)ctx->misc.ptr + part_bytes, 0, ticket_bytes, st));
         ctx->tickets_at = (char *)ctx->misc.ptr + part_bytes;
         ctx->tickets_bytes = ticket_bytes;
     }
-    if (int rc = crec_reserve(ctx, &ctx->contrib, 2 * sizeof(float) * (size_t)B * d))
-        return rc;
+
 
     // plan-side workspace (sizes known up front) ...
     struct PlanWs {
@@ -2045,8 +2034,8 @@ int sharded_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, int64_t I_global
     a.st = st;
     a.partial = (float *)ctx->misc.ptr;
     a.tickets = (int32_t *)((char *)ctx->misc.ptr + part_bytes);
-    a.contrib = (float *)ctx->contrib.ptr;
-    a.ucontrib = a.contrib + (size_t)B * d;
+    if (int rc = setup_lazy_bufs(ctx, B, d, CH, st, &a.lazy))
+        return rc;
     int64_t sent_ids = 0, sent_rows = 0, sent_grads = 0, n_requested = 0, n_served = 0, max_served = 0;
 
     std::vector<int64_t> scnt(G), sdsp(G), rcnt(G), rdsp(G);
@@ -2143,25 +2132,7 @@ int sharded_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, int64_t I_global
         CREC_KLAUNCH(ctx, bpr_index_batches, dim3((unsigned)(2 * nbc)), dim3(PREP_THREADS), lds_idx, st, u + t0,
                      (const int32_t *)p.ci, (const int32_t *)p.cj, n_chunk, B, cap_idx, w);
         crec_prof_end(ctx, st);
-        const size_t n_hn = (size_t)nbc * HN;
-        if (n_hn > ctx->pinned_ints) {
-            if (ctx->pinned)
-                CREC_HIP(ctx, hipHostFree(ctx->pinned));
-            ctx->pinned = nullptr;
-            ctx->pinned_ints = 0;
-            CREC_HIP(ctx, hipHostMalloc((void **)&ctx->pinned, sizeof(int32_t) * n_hn * 2, hipHostMallocDefault));
-            ctx->pinned_ints = n_hn * 2;
-        }
-        const int32_t *hn = ctx->pinned;
-        CREC_HIP(ctx, hipMemcpyAsync(ctx->pinned, w.hn, sizeof(int32_t) * n_hn, hipMemcpyDeviceToHost, st));
-        CREC_HIP(ctx, hipStreamSynchronize(st));
-        a.pad_wide = a.pad_chunks_u = a.pad_chunks_q = a.pad_multi_u = a.pad_multi_q = 0;
-        for (int64_t b = 0; b < nbc; ++b) {
-            a.pad_chunks_u = hn[(size_t)b * HN + 1] > a.pad_chunks_u ? hn[(size_t)b * HN + 1] : a.pad_chunks_u;
-            a.pad_chunks_q = hn[(size_t)b * HN + 3] > a.pad_chunks_q ? hn[(size_t)b * HN + 3] : a.pad_chunks_q;
-            a.pad_multi_u = hn[(size_t)b * HN + 4] > a.pad_multi_u ? hn[(size_t)b * HN + 4] : a.pad_multi_u;
-            a.pad_multi_q = hn[(size_t)b * HN + 5] > a.pad_multi_q ? hn[(size_t)b * HN + 5] : a.pad_multi_q;
-        }
+        const int32_t *hn = nullptr; // the lazy step's launches are sized by the batch alone
         a.cur = Tables{t->P, t->mP, t->vP, p.Qc, nullptr, nullptr};
         // 6. the steps
         for (int64_t b = 0; b < nbc; ++b) {

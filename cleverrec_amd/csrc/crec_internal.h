@@ -71,7 +71,7 @@ struct crec_ctx {
     crec_mt19937 rng;
     // BPR training workspace (bpr_train.hip)
     crec_devbuf idx_ws;   // per-batch inverted indices of one chunk of batches
-    crec_devbuf contrib;  // [B, d] per-triple contribution rows s_b * p_u (lazy mode)
+    crec_devbuf contrib;  // lazy mode: contribution rows, heavy-row partials and ticket counters (setup_lazy_bufs)
     crec_devbuf dq;       // data-parallel step: dense per-item gradient sums [I, d]
     void *comm = nullptr; // ncclComm_t (RCCL), set by crec_comm_init
     int rank = 0, world = 1;
@@ -84,6 +84,8 @@ struct crec_ctx {
     crec_devbuf misc;     // heavy-row partials + ticket counters
     char *tickets_at = nullptr; // where the counters were last cleared (they are re-zeroed by the kernels after use)
     size_t tickets_bytes = 0;
+    char *lazy_tickets_at = nullptr; // the lazy step's counters (inside `contrib`), likewise
+    size_t lazy_tickets_bytes = 0;
     size_t index_lds_set = 0;   // dynamic LDS limit already granted to bpr_index_batches
     int32_t *pinned = nullptr; // page-locked host buffer for the per-chunk counts read back from the index kernel
     size_t pinned_ints = 0;

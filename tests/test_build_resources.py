@@ -38,11 +38,11 @@ def _resources(src, extra=()):
 def test_bpr_kernels_register_budget():
     res = _resources("bpr_train.hip", ("-ffp-contract=off",))
     fused = [v for k, v in res.items() if "bpr_step_fusedILi16ELb1" in k]
-    lazy = [v for k, v in res.items() if ("bpr_triples_lazyILi32ELb1" in k or "bpr_rows_lazyILi32ELb1" in k)]
-    assert fused and len(lazy) == 2
+    lazy = [v for k, v in res.items() if "bpr_triples_lazyILi32ELb1" in k]
+    assert fused and len(lazy) == 1
     for v in fused:  # d = 64: four waves per SIMD (3 313 waves of a step at ml-1m shape fit the 4 096 slots at once)
         assert v["VGPRs"] <= 128 and v["ScratchSize"] == 0 and v["Occupancy"] >= 4, v
-    for v in lazy:  # d = 128 lazy launches (triple pass, multi rows): four waves per SIMD
+    for v in lazy:  # d = 128 lazy step (one launch): four waves per SIMD
         assert v["VGPRs"] <= 128 and v["ScratchSize"] == 0 and v["Occupancy"] >= 4, v
 
 
