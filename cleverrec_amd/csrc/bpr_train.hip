@@ -122,6 +122,10 @@ struct IndexWs {
     // id (bit 31: it occurs once in the batch), the slot's position k in the side's sorted order, the row's segment
     // [start, start + cnt) there.  These are the lazy step's whole index: nothing else is written in lazy mode.
     int4 *u_desc, *i_desc, *j_desc; // [nbc][B]
+    // lazy mode: the order in which the triple pass takes the batch positions -- triples of heavy item rows first, then
+    // those of other multi-occurrence item rows, then the rest: a multi-occurrence row is finished by its LAST
+    // contributor, and a heavy row's finish is a chain of dependent round trips that should not start at the very end
+    int32_t *order;                 // [nbc][B]
     int4 *u_hrows, *q_hrows;   // [nbc][HRu|HRq]  {row, first chunk, chunks<<16 | length, rank among unique rows}
     int4 *u_hitems, *q_hitems; // [nbc][HIu|HIq]  {row, segment start, length | heavy row index << 8, chunk index}
     int64_t B, U, I, HRu, HRq, HIu, HIq;
@@ -187,6 +191,7 @@ IndexWs layout_index(void *base, int64_t nbc, int64_t B, int64_t U, int64_t I, b
     w.u_desc = (int4 *)take(sizeof(int4) * nbc * (dense ? 0 : B));
     w.i_desc = (int4 *)take(sizeof(int4) * nbc * (dense ? 0 : B));
     w.j_desc = (int4 *)take(sizeof(int4) * nbc * (dense ? 0 : B));
+    w.order = (int32_t *)take(sizeof(int32_t) * nbc * (dense ? 0 : B));
     w.wide_rows = dense && wide_total > 0 ? wide_rows : 0;
     w.wide_total = wide_total;
     w.WMu = w.wide_rows ? B / (wide_total + 1) + 1 : 0;
@@ -261,7 +266,8 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
     __syncthreads();
 
     if ((side ? w.I : w.U) == 0) { // lazy mode: the triple pass needs, per batch position and role, where the slot and its
-        int r = rank_first;        // row sit in the sorted order -- and nothing else
+        int r = rank_first;        // row sit in the sorted order -- and the order to take the positions in
+        uint16_t *wt = (uint16_t *)hist; // [B] occurrences of the triple's busier item row (the sort's counters are free by now)
         for (int k = k0; k < k1; ++k) {
             if (k == 0 || rows[k] != rows[k - 1])
                 ++r;
@@ -270,6 +276,41 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
             int4 *dst = side == 0 ? w.u_desc : (slot < nb ? w.i_desc : w.j_desc);
             dst[(int64_t)batch * B + (slot < nb ? slot : slot - nb)] =
                 make_int4((int)(rows[k] | (cnt == 1 ? 0x80000000u : 0u)), k, start, cnt);
+            if (side == 1 && slot < nb)
+                wt[slot] = (uint16_t)(cnt > 0xffff ? 0xffff : cnt);
+        }
+        if (side == 0)
+            return;
+        __syncthreads();
+        r = rank_first;
+        for (int k = k0; k < k1; ++k) { // every position has one i-slot (above) and one j-slot (here): no two writers
+            if (k == 0 || rows[k] != rows[k - 1])
+                ++r;
+            const int cnt = (int)seg[r] - (int)seg[r - 1], slot = tag[k];
+            if (slot >= nb && cnt > (int)wt[slot - nb])
+                wt[slot - nb] = (uint16_t)(cnt > 0xffff ? 0xffff : cnt);
+        }
+        __syncthreads();
+        // stable three-way partition of the positions: heavy (> CH), multi (2..CH), single
+        const int pper = (nb + PREP_THREADS - 1) / PREP_THREADS;
+        const int p0 = tid * pper, p1 = (p0 + pper) < nb ? (p0 + pper) : nb;
+        int n_heavy = 0, n_multi = 0;
+        for (int q = p0; q < p1; ++q) {
+            n_heavy += wt[q] > CH ? 1 : 0;
+            n_multi += (wt[q] >= 2 && wt[q] <= CH) ? 1 : 0;
+        }
+        int tot_pack = 0;
+        const int before = crec_sort::block_excl_scan<PREP_THREADS>((n_heavy << 16) | n_multi, scan, &tot_pack);
+        const int tot_heavy = tot_pack >> 16, tot_multi = tot_pack & 0xffff;
+        int at_h = before >> 16, at_m = tot_heavy + (before & 0xffff), at_s = tot_heavy + tot_multi + (p0 - (before >> 16) - (before & 0xffff));
+        int32_t *ord = w.order + (int64_t)batch * B;
+        for (int q = p0; q < p1; ++q) {
+            if (wt[q] > CH)
+                ord[at_h++] = q;
+            else if (wt[q] >= 2)
+                ord[at_m++] = q;
+            else
+                ord[at_s++] = q;
         }
         return;
     }
@@ -1372,14 +1413,16 @@ __device__ __forceinline__ void lazy_role_tail(const Tables &t, int d, bool act,
 
 // bpr_triples_lazy: a lane group per triple; ud / id / jd: the triple's three roles by batch position (IndexWs).
 template <int LPR, bool FULL>
-__global__ __launch_bounds__(256) void bpr_triples_lazy(Tables t, int d, const int4 *__restrict__ ud,
-                                                        const int4 *__restrict__ id, const int4 *__restrict__ jd, int nb,
-                                                        LazyBufs z, float *__restrict__ xb, float *__restrict__ l2b, Hyper h)
+__global__ __launch_bounds__(256) void bpr_triples_lazy(Tables t, int d, const int32_t *__restrict__ order,
+                                                        const int4 *__restrict__ ud, const int4 *__restrict__ id,
+                                                        const int4 *__restrict__ jd, int nb, LazyBufs z,
+                                                        float *__restrict__ xb, float *__restrict__ l2b, Hyper h)
 {
     constexpr int G = 64 / LPR;
     const int lane = threadIdx.x & 63, g = lane / LPR, l = lane % LPR;
-    const int pos = (int)((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * G + g);
-    const bool valid = pos < nb, act = FULL || 4 * l < d, on = valid && act;
+    const int slot = (int)((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * G + g);
+    const bool valid = slot < nb, act = FULL || 4 * l < d, on = valid && act;
+    const int pos = valid ? order[slot] : 0; // heavy rows' triples first (IndexWs::order)
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     const int4 none = make_int4((int)0x80000000u, 0, 0, 1); // a dead group: "single" rows, no tails
     const int4 du = valid ? ud[pos] : none, di = valid ? id[pos] : none, dj = valid ? jd[pos] : none;
@@ -1614,8 +1657,8 @@ template <int LPR, bool FULL> void launch_lazy(const StepArgs &a, const IndexWs 
     (void)hn;
     crec_prof_begin(a.ctx, CREC_K_USER_SIDE, a.st);
     CREC_KLAUNCH(a.ctx, (bpr_triples_lazy<LPR, FULL>), dim3((unsigned)crec_ceil_div(a.nb_cur, 4 * G)), dim3(256), 0, a.st, a.cur, a.d,
-                 (const int4 *)(w.u_desc + b * w.B), (const int4 *)(w.i_desc + b * w.B), (const int4 *)(w.j_desc + b * w.B),
-                 (int)a.nb_cur, a.lazy, a.xb, a.rowterm, a.h);
+                 (const int32_t *)(w.order + b * w.B), (const int4 *)(w.u_desc + b * w.B), (const int4 *)(w.i_desc + b * w.B),
+                 (const int4 *)(w.j_desc + b * w.B), (int)a.nb_cur, a.lazy, a.xb, a.rowterm, a.h);
     crec_prof_end(a.ctx, a.st);
 }
 
