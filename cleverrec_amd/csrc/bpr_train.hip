@@ -102,6 +102,10 @@ __device__ __forceinline__ void crec_mark(int slot, int dep) // the time at whic
 #define CREC_LAZY_ITEM_WAVES 4 // 5 (96 VGPRs, 12 bytes of scratch) measured the same: 10.8 us
 #endif
 #define CREC_LAZY_WAVES(MODE) ((MODE) == 2 ? CREC_LAZY_ITEM_WAVES : 4)
+#ifndef CREC_LAZY_DEEP
+#define CREC_LAZY_DEEP 11 // contribution / partial rows in flight in a finisher's sum: 126 VGPRs, four waves per SIMD (12: 132 VGPRs,
+                          // three; measured 8 / 11 / 12 / 16 x CH 16 / 24 / 32 on S-big: all within 2 %, tools/lazy_variants.sh)
+#endif
 #ifndef CREC_FUSED_WT
 #define CREC_FUSED_WT 0 // 1: the launch-per-step tf1 kernel writes its tables with write-through (sc1) stores
 #endif
@@ -1335,7 +1339,7 @@ struct LazyBufs {
 // (the rows were published by other waves, possibly on another XCD), eight in flight
 __device__ __forceinline__ float4 lazy_sum_rows(const float *base, int n, int64_t stride, float4 add)
 {
-    constexpr int DEEP = 8; // sixteen in flight cost 32 more VGPRs on every wave of the launch (occupancy 4 -> 3)
+    constexpr int DEEP = CREC_LAZY_DEEP;
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int k0 = 0; k0 < n; k0 += DEEP) {
         float4 c[DEEP];
@@ -1350,25 +1354,37 @@ __device__ __forceinline__ float4 lazy_sum_rows(const float *base, int n, int64_
     return g;
 }
 
-// One multi-occurrence row of this group's triple, after the group's contribution row has been published (and the
-// wave has waited for the store): draw a ticket; the last contributor of the row -- of the chunk first, for a heavy
-// row -- forms the sum in sorted order and finishes the row.  Every lane of the group takes the same path.
+// Where a slot's ticket counter lives and how many tickets complete it: the row's own counter for a light row (<= CH
+// slots), the counter of the slot's chunk for a heavy row.
+struct LazyTicket {
+    int idx, need;
+    bool light;
+};
+__device__ __forceinline__ LazyTicket lazy_ticket_of(int4 desc, int CH)
+{
+    const int k = desc.y, start = desc.z, cnt = desc.w;
+    LazyTicket q;
+    q.light = cnt <= CH;
+    q.idx = q.light ? start : start + (k - start) / CH * CH;
+    q.need = q.light ? cnt : ((cnt - (q.idx - start)) < CH ? (cnt - (q.idx - start)) : CH);
+    return q;
+}
+
+// One multi-occurrence row of this group's triple.  The group has published its contribution row, waited for the
+// store, and drawn ticket `tk` on the row's (chunk's) counter.  The last contributor of the row -- of the chunk first,
+// for a heavy row -- forms the sum in sorted order and finishes the row.  Every lane of the group takes the same path.
 template <int LPR, bool USER>
-__device__ __forceinline__ void lazy_role_tail(const Tables &t, int d, bool act, int4 desc, float4 own, float *cbuf, float *pbuf,
-                                               int32_t *row_t, int32_t *chk_t, int CH, const Hyper &h)
+__device__ __forceinline__ void lazy_role_tail(const Tables &t, int d, bool act, int4 desc, int tk, float4 own, float *cbuf,
+                                               float *pbuf, int32_t *row_t, int32_t *chk_t, int CH, const Hyper &h)
 {
     const int lane = threadIdx.x & 63, l = lane % LPR, lead = lane - l;
-    const int k = desc.y, start = desc.z, cnt = desc.w;
-    const bool light = cnt <= CH;
-    const int idx = light ? start : start + (k - start) / CH * CH; // the counter / first slot of the row or of the chunk
-    const int need = light ? cnt : ((cnt - (idx - start)) < CH ? (cnt - (idx - start)) : CH);
-    int32_t *ctr = (light ? row_t : chk_t) + idx;
-    int tk = -1;
-    if (l == 0)
-        tk = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    tk = __shfl(tk, lead, 64);
-    if (tk != need - 1)
+    const int start = desc.z, cnt = desc.w;
+    const LazyTicket q = lazy_ticket_of(desc, CH);
+    if (tk != q.need - 1)
         return;
+    const int idx = q.idx, need = q.need;
+    const bool light = q.light;
+    int32_t *ctr = (light ? row_t : chk_t) + idx;
     asm volatile("" ::: "memory");
     const int64_t ro = (int64_t)(desc.x & 0x7fffffff) * d + 4 * l;
     const bool slots = act && (USER || !h.dQ);
@@ -1460,6 +1476,34 @@ __global__ __launch_bounds__(256) void bpr_triples_lazy(Tables t, int d, const i
     const float ns = -s;
     const float4 cu = make_float4(ns * (qi.x - qj.x), ns * (qi.y - qj.y), ns * (qi.z - qj.z), ns * (qi.w - qj.w));
     const float4 sp = make_float4(s * p.x, s * p.y, s * p.z, s * p.w), nsp = make_float4(-sp.x, -sp.y, -sp.z, -sp.w);
+    // 1. the contribution rows of the multi-occurrence roles, first: their completion is what the tickets wait for
+    if (on) {
+        if (!us)
+            st4_agent(z.ucontrib + (int64_t)du.y * d + 4 * l, cu);
+        if (!is)
+            st4_agent(z.qcontrib + (int64_t)di.y * d + 4 * l, nsp);
+        if (!js)
+            st4_agent(z.qcontrib + (int64_t)dj.y * d + 4 * l, sp);
+    }
+    // 2. the tickets of all three roles at once (one round trip, not three).  The contribution rows travel with
+    // agent-scope stores; the wave waits for their completion first -- the same guarantee as a release fence for these
+    // buffers, without writing back the whole L2 (the row loads above have long been consumed: only these stores are
+    // outstanding)
+    const bool any_multi = __builtin_amdgcn_ballot_w64(!(us && is && js)) != 0; // false for the usual wave on large tables
+    int tku = -1, tki = -1, tkj = -1;
+    if (any_multi) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (valid && l == 0) {
+            const LazyTicket qu = lazy_ticket_of(du, z.CH), qi_ = lazy_ticket_of(di, z.CH), qj_ = lazy_ticket_of(dj, z.CH);
+            if (!us)
+                tku = __hip_atomic_fetch_add((qu.light ? z.urow_t : z.uchk_t) + qu.idx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!is)
+                tki = __hip_atomic_fetch_add((qi_.light ? z.qrow_t : z.qchk_t) + qi_.idx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!js)
+                tkj = __hip_atomic_fetch_add((qj_.light ? z.qrow_t : z.qchk_t) + qj_.idx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // 3. the rows that occur once are finished here, while the tickets travel
     if (on) {
         if (us) {
             const float4 gp = make_float4(cu.x + h.reg * p.x, cu.y + h.reg * p.y, cu.z + h.reg * p.z, cu.w + h.reg * p.w);
@@ -1468,8 +1512,6 @@ __global__ __launch_bounds__(256) void bpr_triples_lazy(Tables t, int d, const i
             st4s(t.P + ou, np);
             st4s(t.mP + ou, mp);
             st4s(t.vP + ou, vp);
-        } else {
-            st4_agent(z.ucontrib + (int64_t)du.y * d + 4 * l, cu);
         }
         if (is) {
             const float4 gi = make_float4(nsp.x + h.reg * qi.x, nsp.y + h.reg * qi.y, nsp.z + h.reg * qi.z, nsp.w + h.reg * qi.w);
@@ -1482,8 +1524,6 @@ __global__ __launch_bounds__(256) void bpr_triples_lazy(Tables t, int d, const i
             } else {
                 st4s(h.dQ + oi, gi);
             }
-        } else {
-            st4_agent(z.qcontrib + (int64_t)di.y * d + 4 * l, nsp);
         }
         if (js) {
             const float4 gj = make_float4(sp.x + h.reg * qj.x, sp.y + h.reg * qj.y, sp.z + h.reg * qj.z, sp.w + h.reg * qj.w);
@@ -1496,21 +1536,21 @@ __global__ __launch_bounds__(256) void bpr_triples_lazy(Tables t, int d, const i
             } else {
                 st4s(h.dQ + oj, gj);
             }
-        } else {
-            st4_agent(z.qcontrib + (int64_t)dj.y * d + 4 * l, sp);
         }
     }
-    if (__builtin_amdgcn_ballot_w64(!(us && is && js)) == 0)
-        return; // the usual wave on large tables: nothing but single-occurrence rows
-    // the contribution rows travel with agent-scope stores; wait for their completion before any ticket (the same
-    // guarantee as a release fence for these buffers, without writing back the whole L2)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (!us)
-        lazy_role_tail<LPR, true>(t, d, act, du, p, z.ucontrib, z.upart, z.urow_t, z.uchk_t, z.CH, h);
-    if (!is)
-        lazy_role_tail<LPR, false>(t, d, act, di, qi, z.qcontrib, z.qpart, z.qrow_t, z.qchk_t, z.CH, h);
-    if (!js)
-        lazy_role_tail<LPR, false>(t, d, act, dj, qj, z.qcontrib, z.qpart, z.qrow_t, z.qchk_t, z.CH, h);
+    if (!any_multi)
+        return;
+    // 4. whoever drew the last ticket of a row (chunk) finishes it
+    const int lead = lane - l;
+    tku = __shfl(tku, lead, 64);
+    tki = __shfl(tki, lead, 64);
+    tkj = __shfl(tkj, lead, 64);
+    if (valid && !us)
+        lazy_role_tail<LPR, true>(t, d, act, du, tku, p, z.ucontrib, z.upart, z.urow_t, z.uchk_t, z.CH, h);
+    if (valid && !is)
+        lazy_role_tail<LPR, false>(t, d, act, di, tki, qi, z.qcontrib, z.qpart, z.qrow_t, z.qchk_t, z.CH, h);
+    if (valid && !js)
+        lazy_role_tail<LPR, false>(t, d, act, dj, tkj, qj, z.qcontrib, z.qpart, z.qrow_t, z.qchk_t, z.CH, h);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1748,7 +1788,7 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
     // occurrences per heavy-row chunk: short chunks shorten the longest wave, every chunk wave pays a ticket on its
     // row's counter.  Item side of S-big: CH 8 -> 12.4 us, 16 -> 11.4, 32 -> 12.0 (with fence-published partials the
     // sweep read 16 -> 16.3, 32 -> 13.7, 64 -> 15.3).  tf1 mode at ml-1m shape: 32 -> 14.4 us/step, 64 -> 13.2.
-    const int CH = ctx->knob_ch > 0 ? ctx->knob_ch : (dense ? 64 : 32);
+    const int CH = ctx->knob_ch > 0 ? ctx->knob_ch : (dense ? 64 : 16);
     CREC_REQUIRE(ctx, CH >= 1 && CH <= 255, "option ch: 1..255");
 
     // wide groups (tf1 mode): the rows of a row wave that hold more than `wide_total` occurrences together go to a
@@ -1972,7 +2012,7 @@ int sharded_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, int64_t I_global
     const int64_t nb = crec_ceil_div(N, B);
     const int64_t IC = 2 * (int64_t)B; // compact item id space of a batch
     StepFn step = pick_step(d, false);
-    const int CH = ctx->knob_ch > 0 ? ctx->knob_ch : 32;
+    const int CH = ctx->knob_ch > 0 ? ctx->knob_ch : 16;
     CREC_REQUIRE(ctx, CH >= 1 && CH <= 255, "option ch: 1..255");
 
     const size_t per_batch = layout_index(nullptr, 1, B, t->U, IC, false, CH).bytes;
