@@ -165,7 +165,9 @@ def main():
         # command, tools/profile.sh; gfx950 FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes).  PMC
         # counters cannot be read from inside the process, so the committed measurement is quoted.
         traffic = None
-        tf = os.path.join(ROOT, "profiles", "round1_traffic.json")
+        tf = os.path.join(ROOT, "profiles", "round2_traffic.json")
+        if not os.path.exists(tf):
+            tf = os.path.join(ROOT, "profiles", "round1_traffic.json")
         if os.path.exists(tf) and not dp:
             traffic = json.load(open(tf)).get("traffic_bytes_per_launch")
         if dp:

@@ -7,7 +7,7 @@ for d in sys.argv[1:]:
         with open(f) as fh:
             for row in csv.DictReader(fh):
                 name = row["Kernel_Name"]
-                m = re.search(r"(bpr_\w+|eval_\w+|rank_metrics\w*)(<[^>(]*>)?", name)
+                m = re.search(r"(bpr_\w+|eval_\w+|rank_metrics\w*|shard_\w+|ncf_\w+|fm_\w+|cml_\w+|rows_\w+|apply_all|small_adam\w*|topk_\w+)(<[^>(]*>)?", name)
                 if not m:
                     continue
                 key = (m.group(1) + (m.group(2) or "").replace(" ", ""), row["Counter_Name"])
