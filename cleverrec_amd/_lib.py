@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CREC_LIB") or os.path.join(_HERE, "lib", "libcrec.so")  # CREC_LIB: an alternative build
 
 OK, EINVAL, EHIP, ENOMEM, EUNSUPPORTED, ENODEVICE = 0, -1, -2, -3, -4, -5
-ADAM_TF1, ADAM_LAZY = 0, 1
+ADAM_TF1, ADAM_LAZY, OPT_SGD, OPT_ADAGRAD = 0, 1, 2, 3
 _CODES = {EINVAL: "CREC_EINVAL", EHIP: "CREC_EHIP", ENOMEM: "CREC_ENOMEM", EUNSUPPORTED: "CREC_EUNSUPPORTED",
           ENODEVICE: "CREC_ENODEVICE"}
 
@@ -85,7 +85,7 @@ _SIGNATURES = {
     "crec_fm_predict": (C.c_int, [_vp, C.POINTER(Fm), _vp, _vp, _i64, _i32, _vp, _vp]),
     "crec_rmse_mae": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "crec_cml_train_epoch": (C.c_int, [_vp, C.POINTER(Cml), C.POINTER(Adam), _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
-    "crec_cml_eval_tables": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp]),
+    "crec_cml_eval_tables": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp]),
     "crec_bpr_train_epoch_dp": (C.c_int, [_vp, C.POINTER(BprTables), C.POINTER(Adam), _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "crec_comm_unique_id": (C.c_int, [_vp, _vp]),
     "crec_comm_init": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),

@@ -455,6 +455,7 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
 // ------------------------------------------------------------------------------------
 struct Hyper {
     float lr_t, beta1, beta2, eps, reg;
+    int opt; // 0 Adam; CREC_OPT_SGD, CREC_OPT_ADAGRAD: the touched-rows-only optimizers of utils/tools.py:79-87
     float *dQ; // data-parallel step: item rows' gradient sums go here ([I,d], every row written) instead of Adam
 };
 
@@ -609,6 +610,36 @@ __device__ __forceinline__ void adam4(float4 &var, float4 &m, float4 &v, float4 
         pm[c] = mk;
         pw[c] = vk;
         pv[c] = pv[c] - adam_quot(h.lr_t * mk, vk, h.eps);
+    }
+}
+
+// The update of a touched row under the configured optimizer (utils/tools.py:79-87), gradient already summed over the
+// row's occurrences (TF1 deduplicates IndexedSlices before _apply_sparse).
+//   Adam     see adam4 (lazy form: touched rows only)
+//   SGD      GradientDescentOptimizer: var -= lr * g
+//   Adagrad  AdagradOptimizer(lr), initial_accumulator_value 0.1 (the caller initialises the slot `m` to it):
+//            accum += g*g; var -= lr * g / sqrt(accum)
+__device__ __forceinline__ void opt4(float4 &var, float4 &m, float4 &v, float4 g, const Hyper &h)
+{
+    if (h.opt == 0) {
+        adam4(var, m, v, g, true, h);
+        return;
+    }
+    float *pv = &var.x, *pm = &m.x;
+    const float *pg = &g.x;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (h.opt == CREC_OPT_SGD) {
+            pv[c] = pv[c] - h.lr_t * pg[c];
+        } else {
+            const float a = pm[c] + pg[c] * pg[c];
+            pm[c] = a;
+#ifdef CREC_EXACT_MATH
+            pv[c] = pv[c] - (h.lr_t * pg[c]) / sqrtf(a);
+#else
+            pv[c] = pv[c] - (h.lr_t * pg[c]) * __builtin_amdgcn_rsqf(a);
+#endif
+        }
     }
 }
 
@@ -1389,8 +1420,8 @@ __device__ __forceinline__ void lazy_role_tail(const Tables &t, int d, bool act,
     const int64_t ro = (int64_t)(desc.x & 0x7fffffff) * d + 4 * l;
     const bool slots = act && (USER || !h.dQ);
     // the slots are only needed at the very end: asked for now, their round trip hides behind the contributions'
-    float4 m = slots ? ld4((USER ? t.mP : t.mQ) + ro) : make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 v = slots ? ld4((USER ? t.vP : t.vQ) + ro) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 m = slots && h.opt != CREC_OPT_SGD ? ld4((USER ? t.mP : t.mQ) + ro) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 v = slots && h.opt == 0 ? ld4((USER ? t.vP : t.vQ) + ro) : make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 regrow = make_float4(h.reg * own.x, h.reg * own.y, h.reg * own.z, h.reg * own.w);
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
     if (act)
@@ -1421,10 +1452,12 @@ __device__ __forceinline__ void lazy_role_tail(const Tables &t, int d, bool act,
         return;
     }
     float4 nv = own;
-    adam4(nv, m, v, g, true, h);
+    opt4(nv, m, v, g, h);
     st4((USER ? t.P : t.Q) + ro, nv);
-    st4((USER ? t.mP : t.mQ) + ro, m);
-    st4((USER ? t.vP : t.vQ) + ro, v);
+    if (h.opt != CREC_OPT_SGD)
+        st4((USER ? t.mP : t.mQ) + ro, m);
+    if (h.opt == 0)
+        st4((USER ? t.vP : t.vQ) + ro, v);
 }
 
 // bpr_triples_lazy: a lane group per triple; ud / id / jd: the triple's three roles by batch position (IndexWs).
@@ -1451,18 +1484,19 @@ __global__ __launch_bounds__(256) void bpr_triples_lazy(Tables t, int d, const i
         p = ld4(t.P + ou);
         qi = ld4(t.Q + oi);
         qj = ld4(t.Q + oj);
-        if (us) {
+        const bool has_m = h.opt != CREC_OPT_SGD, has_v = h.opt == 0; // the slots this optimizer keeps
+        if (us && has_m)
             mp = ld4s(t.mP + ou);
+        if (us && has_v)
             vp = ld4s(t.vP + ou);
-        }
-        if (is && item_adam) {
+        if (is && item_adam && has_m)
             mi = ld4s(t.mQ + oi);
+        if (is && item_adam && has_v)
             vi = ld4s(t.vQ + oi);
-        }
-        if (js && item_adam) {
+        if (js && item_adam && has_m)
             mj = ld4s(t.mQ + oj);
+        if (js && item_adam && has_v)
             vj = ld4s(t.vQ + oj);
-        }
     }
     float x;
     const float s = triple_s<LPR>(dot4(p, qi) - dot4(p, qj), &x);
@@ -1508,19 +1542,23 @@ __global__ __launch_bounds__(256) void bpr_triples_lazy(Tables t, int d, const i
         if (us) {
             const float4 gp = make_float4(cu.x + h.reg * p.x, cu.y + h.reg * p.y, cu.z + h.reg * p.z, cu.w + h.reg * p.w);
             float4 np = p;
-            adam4(np, mp, vp, gp, true, h);
+            opt4(np, mp, vp, gp, h);
             st4s(t.P + ou, np);
-            st4s(t.mP + ou, mp);
-            st4s(t.vP + ou, vp);
+            if (h.opt != CREC_OPT_SGD)
+                st4s(t.mP + ou, mp);
+            if (h.opt == 0)
+                st4s(t.vP + ou, vp);
         }
         if (is) {
             const float4 gi = make_float4(nsp.x + h.reg * qi.x, nsp.y + h.reg * qi.y, nsp.z + h.reg * qi.z, nsp.w + h.reg * qi.w);
             if (item_adam) {
                 float4 nq = qi;
-                adam4(nq, mi, vi, gi, true, h);
+                opt4(nq, mi, vi, gi, h);
                 st4s(t.Q + oi, nq);
-                st4s(t.mQ + oi, mi);
-                st4s(t.vQ + oi, vi);
+                if (h.opt != CREC_OPT_SGD)
+                    st4s(t.mQ + oi, mi);
+                if (h.opt == 0)
+                    st4s(t.vQ + oi, vi);
             } else {
                 st4s(h.dQ + oi, gi);
             }
@@ -1529,10 +1567,12 @@ __global__ __launch_bounds__(256) void bpr_triples_lazy(Tables t, int d, const i
             const float4 gj = make_float4(sp.x + h.reg * qj.x, sp.y + h.reg * qj.y, sp.z + h.reg * qj.z, sp.w + h.reg * qj.w);
             if (item_adam) {
                 float4 nq = qj;
-                adam4(nq, mj, vj, gj, true, h);
+                opt4(nq, mj, vj, gj, h);
                 st4s(t.Q + oj, nq);
-                st4s(t.mQ + oj, mj);
-                st4s(t.vQ + oj, vj);
+                if (h.opt != CREC_OPT_SGD)
+                    st4s(t.mQ + oj, mj);
+                if (h.opt == 0)
+                    st4s(t.vQ + oj, vj);
             } else {
                 st4s(h.dQ + oj, gj);
             }
@@ -1769,7 +1809,8 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
     CREC_REQUIRE(ctx, t->d >= 4 && t->d <= 256 && t->d % 4 == 0, "embed_size %d: need a multiple of 4 in [4, 256]", t->d);
     CREC_REQUIRE(ctx, t->U >= 1 && t->I >= 1 && t->U < ((int64_t)1 << 31) && t->I < ((int64_t)1 << 31), "table rows");
     CREC_REQUIRE(ctx, B >= 1 && B <= MAX_B, "batch_size %d: this build indexes batches of at most %d in LDS", B, MAX_B);
-    CREC_REQUIRE(ctx, opt->adam_mode == CREC_ADAM_TF1 || opt->adam_mode == CREC_ADAM_LAZY, "adam_mode");
+    CREC_REQUIRE(ctx, opt->adam_mode == CREC_ADAM_TF1 || opt->adam_mode == CREC_ADAM_LAZY || opt->adam_mode == CREC_OPT_SGD ||
+                          opt->adam_mode == CREC_OPT_ADAGRAD, "adam_mode");
     const float *tabs[] = {t->P, t->Q, t->mP, t->vP, t->mQ, t->vQ};
     for (const float *p : tabs)
         CREC_REQUIRE(ctx, ((uintptr_t)p & 15) == 0, "table base not 16-byte aligned");
@@ -1902,8 +1943,9 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
             a.pad_chunks_q = hn[(size_t)b * HN + 3] > a.pad_chunks_q ? hn[(size_t)b * HN + 3] : a.pad_chunks_q;
         }
         for (int64_t b = 0; b < nbc; ++b) {
-            // lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t) with fp32 running powers (TF1 _prepare/_finish)
-            a.h.lr_t = (opt->lr * sqrtf(1.0f - opt->beta2_power)) / (1.0f - opt->beta1_power);
+            // lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t) with fp32 running powers (TF1 _prepare/_finish); SGD / Adagrad: lr
+            a.h.opt = opt->adam_mode >= CREC_OPT_SGD ? opt->adam_mode : 0;
+            a.h.lr_t = a.h.opt ? opt->lr : (opt->lr * sqrtf(1.0f - opt->beta2_power)) / (1.0f - opt->beta1_power);
             a.h.beta1 = opt->beta1;
             a.h.beta2 = opt->beta2;
             a.h.eps = opt->eps;
@@ -2239,6 +2281,7 @@ int sharded_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, int64_t I_global
             }
             if (int rc = x->alltoallv(ctx, v.sendrows, scnt.data(), sdsp.data(), p.Qc, rcnt.data(), rdsp.data(), 4, st))
                 return rc;
+            a.h.opt = 0;
             a.h.lr_t = (opt->lr * sqrtf(1.0f - opt->beta2_power)) / (1.0f - opt->beta1_power);
             a.h.beta1 = opt->beta1;
             a.h.beta2 = opt->beta2;

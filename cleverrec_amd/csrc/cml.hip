@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void cml_reduce_loss(CmlAux a) { cml_loss_bloc
 // (-2 clip_1(p)) . q + |q|^2 ascending, i.e. a dot product of vectors widened by one slot (padded to 4):
 //   P_aug = [-2 clip_1(p), 1, 0, 0, 0],  Q_aug = [q, |q|^2, 0, 0, 0]
 __global__ void cml_aug_tables(const float *__restrict__ P, const float *__restrict__ Q, int64_t U, int64_t I, int d,
-                               float *__restrict__ Pa, float *__restrict__ Qa)
+                               int clip_users, float *__restrict__ Pa, float *__restrict__ Qa)
 {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int da = d + 4;
@@ -246,7 +246,8 @@ __global__ void cml_aug_tables(const float *__restrict__ P, const float *__restr
         float nn = 0.f;
         for (int c = 0; c < d; ++c)
             nn = nn + P[r * d + c] * P[r * d + c];
-        const float nrm = sqrtf(nn), sc = nrm > 1.0f ? 1.0f / nrm : 1.0f; // tf.clip_by_norm(., 1.0, axes=[1])
+        // tf.clip_by_norm(., 1.0, axes=[1]) on the rs branch only (CML.py:76,84); the loo branch scores with the unclipped row
+        const float nrm = sqrtf(nn), sc = (clip_users && nrm > 1.0f) ? 1.0f / nrm : 1.0f;
         for (int c = 0; c < d; ++c)
             Pa[r * da + c] = -2.0f * (P[r * d + c] * sc);
         Pa[r * da + d] = 1.0f;
@@ -381,16 +382,17 @@ int crec_cml_train_epoch(crec_ctx *ctx, const crec_cml *m, crec_adam *opt, const
     return crec_prof_flush(ctx, st);
 }
 
-int crec_cml_eval_tables(crec_ctx *ctx, const float *P, const float *Q, int64_t U, int64_t I, int32_t d, float *P_aug,
-                         float *Q_aug, void *stream)
+int crec_cml_eval_tables(crec_ctx *ctx, const float *P, const float *Q, int64_t U, int64_t I, int32_t d, int32_t clip_users,
+                         float *P_aug, float *Q_aug, void *stream)
 {
     if (!ctx)
         return CREC_EINVAL;
     CREC_REQUIRE(ctx, ctx->device >= 0, "host-only ctx: no device bound");
     CREC_REQUIRE(ctx, P && Q && P_aug && Q_aug && U >= 1 && I >= 1 && d >= 1, "bad argument");
+    CREC_REQUIRE(ctx, d + 4 <= 256, "embed_size %d: the widened rows [d + 4] must fit crec_eval_topk's 256 columns", d);
     CREC_HIP(ctx, hipSetDevice(ctx->device));
     hipLaunchKernelGGL(cml_aug_tables, dim3((unsigned)crec_ceil_div(U + I, 256)), dim3(256), 0, (hipStream_t)stream, P, Q, U, I,
-                       d, P_aug, Q_aug);
+                       d, (int)clip_users, P_aug, Q_aug);
     CREC_HIP(ctx, hipGetLastError());
     return CREC_OK;
 }

@@ -24,10 +24,13 @@ class Recommender(object):
         # the reference attaches l2_regularizer(0.001) to every variable but never adds
         # REGULARIZATION_LOSSES to the loss, so it has no effect: nothing to carry.
         self.loss_func = c['loss_func']
+        # get_optimizer (utils/tools.py:79-87): 'SGD' | 'Adam' | 'Adagrad'; any other name leaves the reference with
+        # optim = None and an AttributeError at .minimize -- here a ValueError up front
         self.optimizer = c['optimizer']
-        if self.optimizer != 'Adam':
-            raise NotImplementedError("optimizer=%s: this core implements Adam (the shipped confs' choice)" % self.optimizer)
-        self.adam_mode = c.get('adam_mode', 'tf1')
+        if self.optimizer not in ('SGD', 'Adam', 'Adagrad'):
+            raise ValueError("optimizer=%s: utils/tools.py get_optimizer knows SGD, Adam, Adagrad" % self.optimizer)
+        # 'tf1' (default) | 'lazy' for Adam; SGD / Adagrad update touched rows only, which is their TF1 semantics
+        self.adam_mode = {'Adam': c.get('adam_mode', 'tf1'), 'SGD': 'sgd', 'Adagrad': 'adagrad'}[self.optimizer]
         self.saved_model_dir = c['saved_dir']
         self.T = int(c['test.interval'])
         self.topk = parse_list(c['topk'], int)

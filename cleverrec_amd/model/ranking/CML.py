@@ -8,7 +8,11 @@ from ..RankingRecommender import RankingRecommender
 class CML(RankingRecommender):
     def __init__(self, sess, data, configs, logger):
         super(CML, self).__init__(sess, data, configs, logger)
+        if self.optimizer != 'Adam':  # SGD / Adagrad are built for the BPR step only (csrc/bpr_train.hip)
+            raise NotImplementedError("optimizer=%s: this model's step implements Adam (its shipped conf's choice)" % self.optimizer)
         self.embed_size, self.reg, self.margin = int(configs['embed_size']), float(configs['reg']), float(configs['margin'])
+        if self.embed_size > 252:
+            raise ValueError("CML embed_size=%d: the evaluation widens rows by 4 columns and crec_eval_topk takes at most 256" % self.embed_size)
         logger.info(' model_params: embed_size=%d, reg=%s, margin=%s' % (self.embed_size, self.reg, self.margin) + ', ' + self.model_params)
         self.train_model = self.train_model_cml  # CML.py:16
 
@@ -51,4 +55,8 @@ class CML(RankingRecommender):
         return float(losses.double().sum().item()) / train_[0]
 
     def _eval_tables(self):
-        return self.state.eval_tables()  # with cml_like in the conf the trainer sorts ascending (:222-223)
+        # with cml_like in the conf the trainer sorts ascending (:222-223).  CML._predict: the loo / sampled-negatives
+        # branch scores with u_i_dist, built from the UNCLIPPED p_u before _unit_clipping rebinds u_embed (CML.py:42,81-82);
+        # only the rs branch sees clip_1(p_u) (CML.py:76,84)
+        loo = self.configs['data.split_way'] == 'loo' or self.neg_samples > 0
+        return self.state.eval_tables(clip_users=not loo)

@@ -11,6 +11,8 @@ from ..RankingRecommender import RankingRecommender
 class GMF(RankingRecommender):
     def __init__(self, sess, data, configs, logger):
         super(GMF, self).__init__(sess, data, configs, logger)
+        if self.optimizer != 'Adam':  # SGD / Adagrad are built for the BPR step only (csrc/bpr_train.hip)
+            raise NotImplementedError("optimizer=%s: this model's step implements Adam (its shipped conf's choice)" % self.optimizer)
         self.embed_size = int(configs['embed_size'])
         # the class reads configs['reg'] but the shipped conf defines reg_gmf: accept both
         self.reg = float(configs['reg'] if 'reg' in configs else configs['reg_gmf'])

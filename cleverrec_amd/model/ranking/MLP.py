@@ -12,6 +12,8 @@ from ..RankingRecommender import RankingRecommender
 class MLP(RankingRecommender):
     def __init__(self, sess, data, configs, logger):
         super(MLP, self).__init__(sess, data, configs, logger)
+        if self.optimizer != 'Adam':  # SGD / Adagrad are built for the BPR step only (csrc/bpr_train.hip)
+            raise NotImplementedError("optimizer=%s: this model's step implements Adam (its shipped conf's choice)" % self.optimizer)
         self.layers = parse_list(configs['layers'], int)
         self.reg = float(configs['reg'] if 'reg' in configs else configs['reg_mlp'])
         logger.info(' model_params: layers=%s, reg=%s' % (self.layers, self.reg) + ', ' + self.model_params)

@@ -12,6 +12,8 @@ from ..RankingRecommender import RankingRecommender
 class NeuMF(RankingRecommender):
     def __init__(self, sess, data, configs, logger):
         super(NeuMF, self).__init__(sess, data, configs, logger)
+        if self.optimizer != 'Adam':  # SGD / Adagrad are built for the BPR step only (csrc/bpr_train.hip)
+            raise NotImplementedError("optimizer=%s: this model's step implements Adam (its shipped conf's choice)" % self.optimizer)
         self.embed_size = int(configs['embed_size'])
         self.layers = parse_list(configs['layers'], int)
         # the class reads reg1/reg2, the shipped conf defines reg_gmf/reg_mlp: accept both

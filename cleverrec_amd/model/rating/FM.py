@@ -9,6 +9,8 @@ from ..RatingRecommender import RatingRecommender
 class FM(RatingRecommender):
     def __init__(self, sess, data, configs, logger):
         super(FM, self).__init__(sess, data, configs, logger)
+        if self.optimizer != 'Adam':  # SGD / Adagrad are built for the BPR step only (csrc/bpr_train.hip)
+            raise NotImplementedError("optimizer=%s: this model's step implements Adam (its shipped conf's choice)" % self.optimizer)
         self.embed_size, self.reg = int(configs['embed_size']), float(configs['reg'])
         if self.loss_func != 'square':
             raise NotImplementedError("FM is built with loss_func=square (conf/FM.properties)")

@@ -47,7 +47,8 @@ class Session:
 
 
 class BprState:
-    """P, Q and their Adam slots in HBM + the optimizer scalars (crec_bpr_tables / crec_adam)."""
+    """P, Q and their optimizer slots in HBM + the optimizer scalars (crec_bpr_tables / crec_adam).
+    adam_mode: 'tf1' | 'lazy' (Adam), 'sgd', 'adagrad' (utils/tools.py:79-87)."""
 
     def __init__(self, sess, P0, Q0, lr, reg, adam_mode="tf1", beta1=0.9, beta2=0.999, eps=1e-8):
         self.sess = sess
@@ -56,9 +57,12 @@ class BprState:
         self.Q = sess.to_dev(Q0, f32).contiguous()
         self.mP, self.vP = torch.zeros_like(self.P), torch.zeros_like(self.P)
         self.mQ, self.vQ = torch.zeros_like(self.Q), torch.zeros_like(self.Q)
+        if adam_mode == "adagrad":  # tf.train.AdagradOptimizer: initial_accumulator_value = 0.1, kept in the `m` slots
+            self.mP.fill_(0.1)
+            self.mQ.fill_(0.1)
         self.tables = _lib.BprTables(*(t.data_ptr() for t in (self.P, self.Q, self.mP, self.vP, self.mQ, self.vQ)),
                                      self.P.shape[0], self.Q.shape[0], self.P.shape[1])
-        mode = {"tf1": _lib.ADAM_TF1, "lazy": _lib.ADAM_LAZY}[adam_mode]
+        mode = {"tf1": _lib.ADAM_TF1, "lazy": _lib.ADAM_LAZY, "sgd": _lib.OPT_SGD, "adagrad": _lib.OPT_ADAGRAD}[adam_mode]
         self.adam = _lib.Adam(lr, beta1, beta2, eps, reg, mode, beta1, beta2, 0)
 
     def train_epoch(self, u, i, j, batch_size):
@@ -216,13 +220,15 @@ class CmlState:
                                                n, K, int(batch_size), s.ptr(loss), s.stream_ptr()))
         return loss
 
-    def eval_tables(self):
-        """(P_aug, Q_aug) for crec_eval_topk(ascending=1): CML._predict's distances as a dot product."""
+    def eval_tables(self, clip_users=True):
+        """(P_aug, Q_aug) for crec_eval_topk(ascending=1): CML._predict's distances as a dot product.  clip_users: the rs
+        branch scores with clip_1(p_u) (CML.py:76,84), the loo / sampled-negatives branch with p_u itself (CML.py:42,81-82)."""
         s = self.sess
         U, d = self.P.shape
         I = self.Q.shape[0]
         Pa, Qa = s.empty((U, d + 4), torch.float32), s.empty((I, d + 4), torch.float32)
-        s.ctx.check(s.lib.crec_cml_eval_tables(s.ctx.h, s.ptr(self.P), s.ptr(self.Q), U, I, d, s.ptr(Pa), s.ptr(Qa), s.stream_ptr()))
+        s.ctx.check(s.lib.crec_cml_eval_tables(s.ctx.h, s.ptr(self.P), s.ptr(self.Q), U, I, d, int(bool(clip_users)), s.ptr(Pa),
+                                               s.ptr(Qa), s.stream_ptr()))
         return Pa, Qa
 
 

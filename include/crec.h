@@ -38,6 +38,13 @@ extern "C" {
 
 #define CREC_ADAM_TF1 0  /* TF1 AdamOptimizer on IndexedSlices: every row decays and moves each step */
 #define CREC_ADAM_LAZY 1 /* only rows touched by the batch are updated */
+/* the other two optimizers of utils/tools.py:79-87, in the same field (crec_adam.adam_mode); both update the rows a batch
+ * touches only, which IS their TF1 semantics on IndexedSlices (gradients of duplicate indices summed first):
+ *   SGD      tf.train.GradientDescentOptimizer(lr): var -= lr * g
+ *   Adagrad  tf.train.AdagradOptimizer(lr): accum += g*g; var -= lr * g / sqrt(accum); the accumulator is the table's `m`
+ *            slot, which the caller initialises to 0.1 (initial_accumulator_value); `v` is unused */
+#define CREC_OPT_SGD 2
+#define CREC_OPT_ADAGRAD 3
 
 typedef struct crec_ctx crec_ctx;
 
@@ -221,11 +228,14 @@ typedef struct {
 } crec_cml;
 int crec_cml_train_epoch(crec_ctx *ctx, const crec_cml *model, crec_adam *opt, const int32_t *u, const int32_t *i,
                          const int32_t *neg, int64_t N, int32_t K, int32_t B, float *loss_per_batch, void *stream);
-/* rs-evaluation form of CML._predict (CML.py:76,84): |clip_1(p_u) - q_i|^2 ascending equals the ascending
- * dot product of P_aug [U, d+4] = [-2 clip_1(p), 1, 0,0,0] and Q_aug [I, d+4] = [q, |q|^2, 0,0,0]; feed them to
- * crec_eval_topk with ascending = 1 (cml_like, model/RankingRecommender.py:222-223). */
-int crec_cml_eval_tables(crec_ctx *ctx, const float *P, const float *Q, int64_t U, int64_t I, int32_t d, float *P_aug,
-                         float *Q_aug, void *stream);
+/* Evaluation form of CML._predict: the squared distance ranks like the ascending dot product of
+ * P_aug [U, d+4] = [-2 p', 1, 0,0,0] and Q_aug [I, d+4] = [q, |q|^2, 0,0,0] (|p'|^2 is constant per user); feed them to
+ * crec_eval_topk[_candidates] with ascending = 1 (cml_like, model/RankingRecommender.py:222-223).
+ *   clip_users = 1: p' = clip_1(p_u), the rs branch (pre_scores from the re-bound u_embed, CML.py:76,84);
+ *   clip_users = 0: p' = p_u, the loo / sampled-negatives branch (pre_scores = u_i_dist, built before _unit_clipping,
+ *                   CML.py:42,81-82).  d <= 252. */
+int crec_cml_eval_tables(crec_ctx *ctx, const float *P, const float *Q, int64_t U, int64_t I, int32_t d, int32_t clip_users,
+                         float *P_aug, float *Q_aug, void *stream);
 
 /* ---- data-parallel training over RCCL (one process per GPU of one node) -----------------------
  * The path shards with one real exchange: gradients of the same Q row must be summed over all ranks'

@@ -329,7 +329,23 @@ static void adam_row(float *var, float *m, float *v, const float *g, int d, floa
     }
 }
 
+/* touched-rows-only optimizers of utils/tools.py:79-87 (TF1 semantics on IndexedSlices, duplicates summed first):
+ * mode 2 GradientDescentOptimizer: var -= lr*g; mode 3 AdagradOptimizer: accum += g*g (accum kept in m, initialised
+ * to 0.1 by the caller), var -= lr*g/sqrt(accum). */
+static void sgd_or_adagrad_row(int mode, float *var, float *acc, const float *g, int d, float lr)
+{
+    for (int k = 0; k < d; k++) {
+        if (mode == 2) {
+            var[k] = var[k] - lr * g[k];
+        } else {
+            acc[k] = acc[k] + g[k] * g[k];
+            var[k] = var[k] - (lr * g[k]) / sqrtf(acc[k]);
+        }
+    }
+}
+
 /*
+ * adam_mode 2 / 3: SGD / Adagrad on the touched rows (lr_t = lr), see sgd_or_adagrad_row.
  * adam_mode 0 ("tf1"): TF1 _apply_sparse_shared: m,v decayed and var updated
  *                       on EVERY row, gradients summed per unique row first.
  * adam_mode 1 ("lazy"): only rows touched by the batch are updated.
@@ -379,13 +395,17 @@ void orc_bpr_step(float *P, float *Q, float *mP, float *vP, float *mQ, float *vQ
         cntQ[j[b]]++;
     }
     for (int64_t r = 0; r < U; r++) {
-        if (cntP[r])
+        if (cntP[r] && adam_mode >= 2)
+            sgd_or_adagrad_row(adam_mode, P + r * d, mP + r * d, gP + r * d, d, lr_t);
+        else if (cntP[r])
             adam_row(P + r * d, mP + r * d, vP + r * d, gP + r * d, d, lr_t, beta1, beta2, eps);
         else if (adam_mode == 0)
             adam_row(P + r * d, mP + r * d, vP + r * d, NULL, d, lr_t, beta1, beta2, eps);
     }
     for (int64_t r = 0; r < I; r++) {
-        if (cntQ[r])
+        if (cntQ[r] && adam_mode >= 2)
+            sgd_or_adagrad_row(adam_mode, Q + r * d, mQ + r * d, gQ + r * d, d, lr_t);
+        else if (cntQ[r])
             adam_row(Q + r * d, mQ + r * d, vQ + r * d, gQ + r * d, d, lr_t, beta1, beta2, eps);
         else if (adam_mode == 0)
             adam_row(Q + r * d, mQ + r * d, vQ + r * d, NULL, d, lr_t, beta1, beta2, eps);

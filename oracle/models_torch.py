@@ -269,6 +269,10 @@ class CML(Model):
         pu = torch.where(nrm > 1.0, pu / nrm, pu)  # tf.clip_by_norm(.., 1.0, axes=[1])
         return ((pu[:, None, :] - Q[None]) ** 2).sum(2).numpy()
 
+    def pair_scores(self, u, items):  # CML.py:42,81-82 (loo / sampled negatives): u_i_dist = |pu - qi|^2 with the UNCLIPPED pu
+        P, Q = self.params["P"], self.params["Q"]
+        return ((P[int(u)][None, :] - Q[torch.as_tensor(np.asarray(items), dtype=torch.long)]) ** 2).sum(1).numpy()
+
 
 class FM(Model):
     """model/rating/FM.py:20-53: y = w0 + sum_f wi[x_f] + 0.5*sum_k[(sum_f x v)^2 - sum_f x^2 v^2] (the linear

@@ -165,10 +165,15 @@ class BprModel:
     """Parameters + Adam slots of model/ranking/BPR.py:23-29 (P, Q fp32) on the CPU."""
 
     def __init__(self, P, Q, lr=1e-3, reg=0.01, adam_mode=0):
+        """adam_mode: 0 Adam (TF1: every row every step), 1 Adam on touched rows only, 2 SGD, 3 Adagrad (the accumulator
+        lives in mP / mQ, initial_accumulator_value 0.1) -- utils/tools.py:79-87."""
         self.P = np.array(P, dtype=np.float32, order="C")
         self.Q = np.array(Q, dtype=np.float32, order="C")
         self.mP, self.vP = np.zeros_like(self.P), np.zeros_like(self.P)
         self.mQ, self.vQ = np.zeros_like(self.Q), np.zeros_like(self.Q)
+        if adam_mode == 3:
+            self.mP += np.float32(0.1)
+            self.mQ += np.float32(0.1)
         self.sched = AdamSchedule(lr)
         self.reg, self.adam_mode = float(reg), int(adam_mode)
         self._gP, self._gQ = np.empty_like(self.P), np.empty_like(self.Q)
@@ -177,6 +182,8 @@ class BprModel:
     def step(self, u, i, j, want_s=False):
         """One sess.run([train, loss]) (RankingRecommender.py:46): returns the summed batch loss."""
         lr_t = float(self.sched.next(1)[0])
+        if self.adam_mode >= 2:
+            lr_t = float(self.sched.lr)  # SGD / Adagrad: the plain learning rate
         return bpr_step(self, u, i, j, lr_t, want_s)
 
 

@@ -416,3 +416,50 @@ def test_model_loo_matches_reference_semantics(sess, tmp_path, neg_samples):
         np.testing.assert_allclose(HR[kid], H[kid], rtol=0)
         np.testing.assert_allclose(MRR[kid], M[kid], rtol=1e-12)
         np.testing.assert_allclose(NDCG[kid], N[kid], rtol=1e-12)
+
+
+@pytest.mark.parametrize("opt,mode", [("sgd", 2), ("adagrad", 3)])
+@pytest.mark.parametrize("d", [16, 64, 128])
+def test_bpr_sgd_and_adagrad_match_oracle(sess, opt, mode, d):
+    """optimizer = SGD / Adagrad (utils/tools.py:79-87): touched rows only, duplicates summed first; Adagrad's
+    accumulator starts at 0.1.  Heavy rows (a 60-item catalogue at B = 512) and a ragged tail included."""
+    data = _toy_data(3, 120, 60, 2, 20)
+    P0, Q0 = _tables(7, data.user_nums, data.item_nums, d, 0.05)
+    lr = 0.05
+    st = runtime.BprState(sess, P0, Q0, lr=lr, reg=0.01, adam_mode=opt)
+    om = oracle.BprModel(P0, Q0, lr=lr, reg=0.01, adam_mode=mode)
+    sess.ctx.seed(4)
+    rng = oracle.Rng(4)
+    for _ in range(2):
+        u, i, j = sess.ctx.sample_pairwise(data.train_csr, data.item_nums, 4)
+        nb, ou, oi, oj = oracle.sample_pairwise(rng, data.ui_train, data.item_nums, 4, 512)
+        loss = st.train_epoch(sess.to_dev(u), sess.to_dev(i), sess.to_dev(j), 512).cpu().numpy()
+        oloss = oracle.train_model_py(om, nb, ou, oi, oj, 512)[1]
+        np.testing.assert_allclose(loss, oloss, rtol=1e-5)
+    for name in ("P", "Q") + (("mP", "mQ") if opt == "adagrad" else ()):
+        np.testing.assert_allclose(getattr(st, name).cpu().numpy(), getattr(om, name), rtol=2e-6, atol=2e-6, err_msg=name)
+    if opt == "sgd":  # SGD keeps no slots: they must still be zero
+        assert float(st.mP.abs().max()) == 0.0 and float(st.vQ.abs().max()) == 0.0
+
+
+def test_model_class_with_sgd_and_adagrad(sess, tmp_path):
+    """optimizer=SGD / Adagrad in the .properties dict reaches the kernels through the class surface."""
+    import logging
+    from cleverrec_amd.model.ranking.BPR import BPR
+    data = _toy_data(5, 90, 70, 3, 15)
+    for name, mode in (("SGD", 2), ("Adagrad", 3)):
+        configs = {"recommender": "BPR", "epoches": "1", "batch_size": "256", "test.batch_size": "64", "lr": "0.05",
+                   "test.neg_samples": "0", "is_pairwise": "True", "init_method": "normal", "stddev": "0.01", "loss_func": "bpr",
+                   "optimizer": name, "saved_dir": str(tmp_path), "test.interval": "1", "topk": "[10,20]", "neg_ratio": "4",
+                   "embed_size": "32", "reg": "0.01", "data.split_way": "rs", "sampler_prefetch": "False"}
+        m = BPR(sess, data, configs, logging.getLogger("t"))
+        P0, Q0 = _tables(2, data.user_nums, data.item_nums, 32)
+        m.build_model(P0, Q0)
+        om = oracle.BprModel(P0, Q0, lr=0.05, reg=0.01, adam_mode=mode)
+        np.random.seed(9)
+        rng = oracle.Rng(9)
+        avg = m.train_model()
+        nb, ou, oi, oj = oracle.sample_pairwise(rng, data.ui_train, data.item_nums, 4, 256)
+        oavg, _ = oracle.train_model_py(om, nb, ou, oi, oj, 256)
+        assert avg == pytest.approx(oavg, rel=1e-5)
+        np.testing.assert_allclose(m.Q.cpu().numpy(), om.Q, rtol=2e-6, atol=2e-6)
