@@ -43,7 +43,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=45600)
     ap.add_argument("--warmup", type=int, default=65536)
-    ap.add_argument("--cpu-steps", type=int, default=5000, help="steps of the CPU baseline sample (0 = skip); 5000 ~ 12 s")
+    ap.add_argument("--cpu-steps", type=int, default=3000, help="steps of the scalar-C CPU baseline sample (0 = skip all CPU legs); 3000 ~ 7 s")
     ap.add_argument("--no-extras", action="store_true", help="skip the roofline/eval/sampler/cpu legs")
     ap.add_argument("--no-big", action="store_true", help="skip the S-big (10M x 1M, d=128) leg")
     a = ap.parse_args()
@@ -67,7 +67,9 @@ def main():
     # N > 1 (weak scaling): users are sharded, every rank holds one ml-1m-shaped shard of users (its own
     # P rows, its own sampled stream of 6144 triples per step); Q is replicated and kept identical by one
     # RCCL all-reduce of the per-item gradient sums per step (cleverrec_amd/parallel.py).
-    data = synthetic("S-ml1m", seed=20240601 + rank)
+    # every rank draws the SAME synthetic population (one catalogue by construction: the replicas of Q line up); what differs
+    # per rank is the sampled index stream (sampler seed 1 + rank) and its own P rows
+    data = synthetic("S-ml1m", seed=20240601)
     P0 = torch.empty(data.user_nums, D).normal_(0, 0.01, generator=torch.Generator().manual_seed(1000 + rank)).numpy()
     Q0 = torch.empty(3706, D).normal_(0, 0.01, generator=torch.Generator().manual_seed(0)).numpy()[:data.item_nums]
     dp = world > 1 or force_dp
@@ -295,6 +297,13 @@ def main():
                                    "sample": "%d steps of 6144 triples over the same sampled epoch (%d batches, walked %.1f "
                                              "times), oracle/crec_oracle.c orc_bpr_step (scalar C, tf1 Adam), %.1f s; host has "
                                              "%d cores" % (k, nbe, k / nbe, tc, os.cpu_count())}
+            # the reference-STYLE path of SURVEY 8(d): pure-Python sampler loop + vectorised torch-CPU fp32 step (tf1 Adam
+            # sweep) at 1 thread and at all cores, and the argsort / Python-filter evaluation loop -- each on a bounded sample
+            from oracle import reference_style
+            n_all = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            out["cpu_baseline"]["reference_style"] = reference_style.measure(data, P0, Q0, u, i, j, B, NEG, sorted({1, n_all}), budget_s=4.0)
+            out["cpu_baseline"]["reference_style"]["note"] = ("TensorFlow 1.x is not installable here: the TF1-CPU path is represented by the same "
+                                                              "structure on PyTorch-CPU (oracle/reference_style.py); cores = torch.set_num_threads(n)")
     if rank == 0:
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dp:

@@ -1907,6 +1907,36 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
     }
 
     bool in_shadow = false; // tf1: which buffer set holds the current tables
+    // Whatever way this function is left -- also through one of the error returns below -- the caller's buffers must hold
+    // the newest tables: after an odd number of completed steps they live in the ctx's second buffer set
+    struct BringHome {
+        const crec_bpr_tables *t;
+        const StepArgs *a;
+        const bool *in_shadow;
+        size_t bytesP, bytesQ;
+        hipStream_t st;
+        int run() const
+        {
+            if (!*in_shadow)
+                return (int)hipSuccess;
+            const Tables &s = a->cur;
+            int e = (int)hipMemcpyAsync(t->P, s.P, bytesP, hipMemcpyDeviceToDevice, st);
+            e |= (int)hipMemcpyAsync(t->mP, s.mP, bytesP, hipMemcpyDeviceToDevice, st);
+            e |= (int)hipMemcpyAsync(t->vP, s.vP, bytesP, hipMemcpyDeviceToDevice, st);
+            if (s.Q != t->Q) {
+                e |= (int)hipMemcpyAsync(t->Q, s.Q, bytesQ, hipMemcpyDeviceToDevice, st);
+                e |= (int)hipMemcpyAsync(t->mQ, s.mQ, bytesQ, hipMemcpyDeviceToDevice, st);
+                e |= (int)hipMemcpyAsync(t->vQ, s.vQ, bytesQ, hipMemcpyDeviceToDevice, st);
+            }
+            return e;
+        }
+        bool done = false;
+        ~BringHome()
+        {
+            if (!done)
+                (void)run(); // an error return: best effort, the error code of the failing call is what the caller sees
+        }
+    } home{t, &a, &in_shadow, bytesP, bytesQ, st};
     for (int64_t b0 = 0; b0 < nb; b0 += chunk) {
         const int64_t nbc = (nb - b0) < chunk ? (nb - b0) : chunk;
         const int64_t t0 = b0 * B, n_chunk = (N - t0) < nbc * B ? (N - t0) : nbc * B;
@@ -1990,17 +2020,9 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
         if (int rc = crec_prof_flush(ctx, st))
             return rc;
     }
-    if (in_shadow) { // an odd number of steps: bring the result home to the caller's buffers
-        const Tables &s = a.cur;
-        CREC_HIP(ctx, hipMemcpyAsync(t->P, s.P, bytesP, hipMemcpyDeviceToDevice, st));
-        CREC_HIP(ctx, hipMemcpyAsync(t->mP, s.mP, bytesP, hipMemcpyDeviceToDevice, st));
-        CREC_HIP(ctx, hipMemcpyAsync(t->vP, s.vP, bytesP, hipMemcpyDeviceToDevice, st));
-        if (s.Q != t->Q) {
-            CREC_HIP(ctx, hipMemcpyAsync(t->Q, s.Q, bytesQ, hipMemcpyDeviceToDevice, st));
-            CREC_HIP(ctx, hipMemcpyAsync(t->mQ, s.mQ, bytesQ, hipMemcpyDeviceToDevice, st));
-            CREC_HIP(ctx, hipMemcpyAsync(t->vQ, s.vQ, bytesQ, hipMemcpyDeviceToDevice, st));
-        }
-    }
+    home.done = true; // an odd number of steps: bring the result home to the caller's buffers
+    if (home.run() != (int)hipSuccess)
+        return crec_fail(ctx, CREC_EHIP, "copying the tables back from the second buffer set failed");
     return CREC_OK;
 }
 

@@ -145,3 +145,45 @@ class ShardedBprState(BprState):
 
     def stats_dict(self):
         return {k: int(getattr(self.stats, k)) for k, _ in _lib.ShardStats._fields_}
+
+
+# ---- evaluation sharded over ranks: every rank ranks ITS test users against the full catalogue --------
+def gather_item_shards(Q_shard, item_nums):
+    """All-gather of the ranks' item shards into the full [I, d] table on this rank's device (one collective per
+    evaluation, 0.5 GB at C5): rows come back in shard order and are dealt to their global positions r, r + G, ..."""
+    world = dist.get_world_size()
+    parts = [torch.empty_like(Q_shard) for _ in range(world)]
+    dist.all_gather(parts, Q_shard.contiguous())
+    out = torch.empty((int(item_nums), Q_shard.shape[1]), dtype=Q_shard.dtype, device=Q_shard.device)
+    for r, sh in enumerate(parts):
+        n = out[r::world].shape[0]
+        out[r::world] = sh[:n]
+    return out
+
+
+def reduce_metric_sums(sums, count):
+    """sums: float64 tensor [3, nk] of this rank's per-user HR / MRR / NDCG sums; count: its number of test users.
+    -> (means [3, nk] over ALL ranks' users, total users).  One all-reduce of 3 * nk + 1 doubles."""
+    buf = torch.cat([sums.reshape(-1).to(torch.float64), torch.tensor([float(count)], dtype=torch.float64, device=sums.device)])
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(buf)
+    total = float(buf[-1].item())
+    return (buf[:-1] / max(total, 1.0)).reshape(sums.shape), int(total)
+
+
+def eval_rs_sharded(sess, P_local, Q_full, shard, topk, batch_size_t=1024, ascending=False):
+    """RankingRecommender.test_model_rs (:198-247) with the test users sharded over ranks: this rank's users (rows of
+    its P shard, its slice of the `data` protocol -- shard_users) against the full catalogue through crec_eval_topk /
+    crec_rank_metrics, then one all-reduce of the metric sums.  -> (HR, MRR, NDCG) means per K over all ranks, users."""
+    from . import runtime
+    users = sess.to_dev(np.asarray(shard.test_users, dtype=np.int32))
+    sp, si = sess.to_dev(shard.seen_csr[0]), sess.to_dev(shard.seen_csr[1] if len(shard.seen_csr[1]) else np.zeros(1, np.int32))
+    tp, ti = sess.to_dev(shard.test_csr[0]), sess.to_dev(shard.test_csr[1] if len(shard.test_csr[1]) else np.zeros(1, np.int32))
+    sums = torch.zeros((3, len(topk)), dtype=torch.float64, device=sess.device)
+    for t0 in range(0, int(users.numel()), batch_size_t):
+        cur = users[t0:t0 + batch_size_t]
+        ids, _ = runtime.eval_topk(sess, P_local, Q_full, cur, sp, si, topk[-1], ascending)
+        hr, mrr, ndcg = runtime.rank_metrics(sess, ids, cur, topk, tp, ti)
+        sums += torch.stack([hr.sum(1), mrr.sum(1), ndcg.sum(1)])
+    means, total = reduce_metric_sums(sums, int(users.numel()))
+    return means[0].cpu().numpy(), means[1].cpu().numpy(), means[2].cpu().numpy(), total

@@ -66,3 +66,36 @@ def test_cml_class_surface_and_distance_ranking(sess, tmp_path):
                                       ascending=True)
     np.testing.assert_allclose(np.mean(NDCG[0]), np.mean(N[0]), rtol=1e-6)
     np.testing.assert_allclose(np.mean(HR[1]), np.mean(H[1]), rtol=1e-6)
+
+
+def test_cml_loo_uses_unclipped_user_rows(sess, tmp_path):
+    """CML._predict on the loo / sampled-negatives branch scores with u_i_dist, built from the UNCLIPPED p_u before
+    _unit_clipping rebinds u_embed (CML.py:42,81-82); only the rs branch sees clip_1(p_u).  User rows with |p| > 1 (variables
+    are never clipped during training) make the two rankings differ: the candidate ranking must follow the unclipped one."""
+    from cleverrec_amd.model.ranking.CML import CML
+    g = np.random.Generator(np.random.PCG64(12))
+    U, I, d, neg_samples = 80, 300, 32, 40
+    ui_train = {uu: [int(x) for x in g.choice(I, size=int(g.integers(3, 15)), replace=False)] for uu in range(U)}
+    ui_test = {}
+    for uu in range(0, U, 2):  # negatives first, then the held-out items (RankingPreprocess._split_data)
+        rest = np.setdiff1d(np.arange(I), ui_train[uu])
+        ui_test[uu] = [int(x) for x in g.choice(rest, size=neg_samples + 2, replace=False)]
+    data = RankingData(U, I, ui_train, ui_test)
+    configs = {"recommender": "CML", "epoches": "1", "batch_size": "256", "test.batch_size": "16", "lr": "0.001",
+               "test.neg_samples": str(neg_samples), "is_pairwise": "False", "init_method": "xavier", "stddev": "0.01",
+               "loss_func": "hinge", "optimizer": "Adam", "saved_dir": str(tmp_path), "test.interval": "1", "topk": "[5,10]",
+               "neg_ratio": "5", "embed_size": str(d), "reg": "10.0", "margin": "1.0", "cml_like": "True", "data.split_way": "loo"}
+    m = CML(sess, data, configs, logging.getLogger("t"))
+    init = {"P": (g.standard_normal((U, d)) * 0.6).astype(np.float32), "Q": (g.standard_normal((I, d)) * 0.6).astype(np.float32)}
+    assert (np.linalg.norm(init["P"], axis=1) > 1.0).all()  # every user row would be clipped on the rs branch
+    m.build_model(init)
+    HR, MRR, NDCG = m.test_model_loo()
+    om = MT.CML(init["P"], init["Q"], lr=1e-3, reg=10.0, margin=1.0, item_nums=I)
+    H, M, N = oracle.test_model_loo_py(om.pair_scores, m.test_users, data.ui_test, neg_samples, [5, 10], 16, ascending=True)
+    for kid in range(2):
+        np.testing.assert_allclose(HR[kid], H[kid], rtol=0)
+        np.testing.assert_allclose(NDCG[kid], N[kid], rtol=1e-12)
+    # the clipped ranking is a different one on this data (the test would not notice the flag otherwise)
+    clipped = lambda u, items: om.predict([u])[0][np.asarray(items)]
+    Hc, _, Nc = oracle.test_model_loo_py(clipped, m.test_users, data.ui_test, neg_samples, [5, 10], 16, ascending=True)
+    assert not np.allclose(N[1], Nc[1])

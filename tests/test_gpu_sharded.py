@@ -166,3 +166,31 @@ def test_sharded_c5_row_width_and_batch():
         diff = np.abs(a - b)
         assert diff.max() <= 2e-5 and (diff > 2e-6).mean() <= 1e-5
     assert all(s["max_rows_served_per_batch"] <= 16384 for s in stats)
+
+
+def test_sharded_eval_matches_reference_loop():
+    """parallel.eval_rs_sharded (test users sharded over ranks, one all-reduce of the metric sums) on two user shards run
+    one after the other on cuda:0: the combined means equal the reference loop over all users (oracle.test_model_rs_py)."""
+    from cleverrec_amd.data import RankingData
+    g = np.random.Generator(np.random.PCG64(21))
+    U, I, d = 150, 400, 32
+    ui_train = {u: [int(x) for x in g.choice(I, size=int(g.integers(2, 25)), replace=False)] for u in range(U) if u % 11 != 10}
+    ui_test = {u: [int(x) for x in g.choice(I, size=int(g.integers(1, 4)), replace=False)] for u in range(0, U, 2)}
+    data = RankingData(U, I, ui_train, ui_test)
+    P, Q = _tables(5, U, I, d, scale=1.0)
+    sess = runtime.Session(0)
+    tot = np.zeros((3, 2))
+    n = 0
+    for r in range(2):
+        lo, hi = parallel.user_range(U, r, 2)
+        shard = parallel.shard_users(data, r, 2)
+        hr, mrr, ndcg, cnt = parallel.eval_rs_sharded(sess, sess.to_dev(P[lo:hi]), sess.to_dev(Q), shard, [10, 20], batch_size_t=32)
+        tot += np.stack([hr, mrr, ndcg]) * cnt
+        n += cnt
+    H, M, N = oracle.test_model_rs_py(lambda cur: oracle.scores(P, Q, cur, 1), data.test_users, data.ui_train, data.ui_test, [10, 20], 64)
+    assert n == len(data.test_users)
+    for kid in range(2):
+        np.testing.assert_allclose(tot[0, kid] / n, np.mean(H[kid]), rtol=1e-12)
+        np.testing.assert_allclose(tot[1, kid] / n, np.mean(M[kid]), rtol=1e-12)
+        np.testing.assert_allclose(tot[2, kid] / n, np.mean(N[kid]), rtol=1e-12)
+    sess.close()

@@ -57,6 +57,13 @@ def _worker(rank, world, port, out):
         # bootstrap helpers
         assert parallel.broadcast_bytes(b"\x01\x02id-from-rank0" if rank == 0 else b"", 0) == b"\x01\x02id-from-rank0"
         assert parallel.agree_min(10 + rank) == 10
+        # sharded evaluation: metric sums of the ranks' own users -> means over all users; item shards -> the full table
+        sums = torch.tensor([[1.0 + rank, 2.0], [0.5, 0.25 * rank], [3.0, 1.0]], dtype=torch.float64)
+        means, total = parallel.reduce_metric_sums(sums, 3 + rank)
+        assert total == 7 and torch.allclose(means, torch.tensor([[3.0, 4.0], [1.0, 0.25], [6.0, 2.0]], dtype=torch.float64) / 7)
+        Qfull = torch.arange(5 * 3, dtype=torch.float32).reshape(5, 3)
+        got = parallel.gather_item_shards(torch.from_numpy(parallel.shard_items(Qfull.numpy(), rank, world)), 5)
+        assert torch.equal(got, Qfull)
 
         # the exchange scheme, oracle as the per-rank compute
         data = _toy()
