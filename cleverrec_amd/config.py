@@ -54,3 +54,30 @@ def grid(configs):
         for r in axes[1]:
             for n in axes[2]:
                 yield {"embed_size": e, "reg": r, "neg_ratio": n}
+
+
+# Shapes this build's kernels are written for (include/crec.h).  The reference (TensorFlow) has no such limits; a
+# .properties file beyond them is refused HERE, when the model object is built, with the key, the value and the limit
+# -- not as a CREC_EINVAL from the middle of an epoch.
+LIMITS = {
+    "batch_size": 8192,   # a batch's (row, slot) pairs are sorted in LDS: 2 * batch_size <= 16384 pairs
+    "topk": 32,           # the fused evaluation keeps at most 32 candidates per user
+    "embed_size": 256,    # table rows are walked as float4 slices by at most 64 lanes
+}
+
+
+def validate(configs, extra_width=0):
+    """Raise ValueError for a configuration outside the built shapes.  extra_width: columns a model adds to its rows
+    before evaluation (CML: 4)."""
+    def bad(key, value, why):
+        raise ValueError("%s = %s: %s (this build's limit; see cleverrec_amd/config.py LIMITS and include/crec.h)" % (key, value, why))
+    b = int(configs["batch_size"])
+    if not 1 <= b <= LIMITS["batch_size"]:
+        bad("batch_size", b, "batches of 1..%d instances" % LIMITS["batch_size"])
+    ks = parse_list(configs["topk"], int)
+    if not ks or ks != sorted(ks) or ks[0] < 1 or ks[-1] > LIMITS["topk"]:
+        bad("topk", configs["topk"], "an ascending list of cut-offs in 1..%d" % LIMITS["topk"])
+    if "embed_size" in configs and not str(configs["embed_size"]).strip().startswith("["):
+        d = int(configs["embed_size"])
+        if d < 4 or d % 4 or d + extra_width > LIMITS["embed_size"]:
+            bad("embed_size", d, "a multiple of 4 in 4..%d" % (LIMITS["embed_size"] - extra_width))

@@ -1,6 +1,6 @@
 """Base Recommender (reference model/Recommender.py:9-40): same constructor, same parsed
 attributes; `sess` is a cleverrec_amd.runtime.Session (or None: one is opened on gpu.id)."""
-from ..config import parse_list
+from ..config import parse_list, validate
 from ..runtime import Session
 from ..utils.tools import get_initializer
 
@@ -15,6 +15,7 @@ class Recommender(object):
 
     def _get_common_params(self):
         c = self.configs
+        validate(c, extra_width=4 if c.get('recommender') == 'CML' else 0)  # shapes outside the built kernels: refused here
         self.epoches, self.batch_size, self.batch_size_t = int(c['epoches']), int(c['batch_size']), int(c['test.batch_size'])
         self.lr, self.neg_samples = float(c['lr']), int(c['test.neg_samples'])
         # presence flags, as in the reference (Recommender.py:19)

@@ -11,8 +11,6 @@ class CML(RankingRecommender):
         if self.optimizer != 'Adam':  # SGD / Adagrad are built for the BPR step only (csrc/bpr_train.hip)
             raise NotImplementedError("optimizer=%s: this model's step implements Adam (its shipped conf's choice)" % self.optimizer)
         self.embed_size, self.reg, self.margin = int(configs['embed_size']), float(configs['reg']), float(configs['margin'])
-        if self.embed_size > 252:
-            raise ValueError("CML embed_size=%d: the evaluation widens rows by 4 columns and crec_eval_topk takes at most 256" % self.embed_size)
         logger.info(' model_params: embed_size=%d, reg=%s, margin=%s' % (self.embed_size, self.reg, self.margin) + ', ' + self.model_params)
         self.train_model = self.train_model_cml  # CML.py:16
 

@@ -215,3 +215,21 @@ def test_sampler_prefetch_is_stream_exact(golden_dir):
     dbase = run(False, True)
     assert same(run(True, True), dbase) and S.stats["prefetch_misses"] - h0["prefetch_misses"] == 1
     S.drop_prefetch()
+
+
+def test_properties_outside_the_built_shapes_are_refused_up_front():
+    """batch_size, topk and embed_size beyond include/crec.h's shapes raise a ValueError naming key, value and limit when
+    the model object is built -- not a CREC_EINVAL in the middle of an epoch (the reference has no such limits)."""
+    from cleverrec_amd import config
+    base = {"recommender": "BPR", "batch_size": "6144", "topk": "[10,20]", "embed_size": "64"}
+    config.validate(base)
+    for key, val, frag in (("batch_size", "10000", "batch_size = 10000"), ("topk", "[10,20,50]", "topk = [10,20,50]"),
+                           ("embed_size", "300", "embed_size = 300"), ("embed_size", "30", "embed_size = 30"),
+                           ("topk", "[20,10]", "ascending")):
+        with pytest.raises(ValueError) as e:
+            config.validate(dict(base, **{key: val}))
+        assert frag in str(e.value)
+    config.validate(dict(base, embed_size="252"), extra_width=4)
+    with pytest.raises(ValueError):
+        config.validate(dict(base, embed_size="256"), extra_width=4)  # CML widens its rows by 4 columns for evaluation
+    config.validate(dict(base, embed_size="[32,64]"))  # a grid list (main_tuning.py) is validated per run
