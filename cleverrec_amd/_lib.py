@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CREC_LIB") or os.path.join(_HERE, "lib", "libcrec.so")  # CREC_LIB: an alternative build
 
 OK, EINVAL, EHIP, ENOMEM, EUNSUPPORTED, ENODEVICE = 0, -1, -2, -3, -4, -5
-ADAM_TF1, ADAM_LAZY, OPT_SGD, OPT_ADAGRAD = 0, 1, 2, 3
+ADAM_TF1, ADAM_LAZY, OPT_SGD, OPT_ADAGRAD, ADAM_DEFERRED = 0, 1, 2, 3, 4
 _CODES = {EINVAL: "CREC_EINVAL", EHIP: "CREC_EHIP", ENOMEM: "CREC_ENOMEM", EUNSUPPORTED: "CREC_EUNSUPPORTED",
           ENODEVICE: "CREC_ENODEVICE"}
 
@@ -35,6 +35,10 @@ class ShardStats(C.Structure):
     _fields_ = [("bytes_ids_sent", C.c_int64), ("bytes_rows_sent", C.c_int64), ("bytes_grads_sent", C.c_int64),
                 ("rows_requested", C.c_int64), ("rows_served", C.c_int64), ("max_rows_served_per_batch", C.c_int64),
                 ("steps", C.c_int64)]
+
+
+class BprDeferred(C.Structure):
+    _fields_ = [("lastP", C.c_void_p), ("lastQ", C.c_void_p)]
 
 
 class Param(C.Structure):
@@ -76,6 +80,8 @@ _SIGNATURES = {
     "crec_sample_cml": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, C.c_int, _vp, _vp, _vp, C.POINTER(_i64)]),
     "crec_sample_negatives_device": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
     "crec_bpr_train_epoch": (C.c_int, [_vp, C.POINTER(BprTables), C.POINTER(Adam), _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
+    "crec_bpr_train_epoch_deferred": (C.c_int, [_vp, C.POINTER(BprTables), C.POINTER(BprDeferred), C.POINTER(Adam), _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
+    "crec_bpr_adam_flush": (C.c_int, [_vp, C.POINTER(BprTables), C.POINTER(BprDeferred), C.POINTER(Adam), _vp]),
     "crec_ncf_train_epoch": (C.c_int, [_vp, C.POINTER(Ncf), C.POINTER(Adam), _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "crec_ncf_scores": (C.c_int, [_vp, C.POINTER(Ncf), _vp, _i32, _vp, _vp]),
     "crec_topk_scores": (C.c_int, [_vp, _vp, _i64, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),

@@ -6,7 +6,7 @@ import configparser as cp
 import os
 
 DEFAULTS = {
-    "adam_mode": "tf1",        # tf1 | lazy  (include/crec.h CREC_ADAM_*)
+    "adam_mode": "tf1",        # tf1 | lazy | deferred  (include/crec.h CREC_ADAM_*)
     "sampler_mode": "mt19937",  # mt19937: bit-exact host sampler | device: GPU sampler, same rule, own generator
 }
 

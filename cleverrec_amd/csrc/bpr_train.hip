@@ -457,6 +457,13 @@ struct Hyper {
     float lr_t, beta1, beta2, eps, reg;
     int opt; // 0 Adam; CREC_OPT_SGD, CREC_OPT_ADAGRAD: the touched-rows-only optimizers of utils/tools.py:79-87
     float *dQ; // data-parallel step: item rows' gradient sums go here ([I,d], every row written) instead of Adam
+    // deferred mode (exact TF1 Adam with the traffic of the lazy step): TF1 decays m, v and moves var on EVERY row at
+    // every step; here a row carries the step at which its (var, m, v) were last brought up to date and replays the
+    // steps it skipped -- m *= b1, v *= b2, var -= lr_s*m/(sqrt(v)+eps) for s = last+1 .. -- whenever it is touched
+    // (before its values are used) and before evaluation (crec_bpr_adam_flush)
+    const float *lr_tab;     // lr_s by step s (1-based), device
+    int32_t *lastP, *lastQ;  // per row: the step its state is current at
+    int32_t step;            // the step being applied
 };
 
 struct Tables { // one buffer set
@@ -640,6 +647,29 @@ __device__ __forceinline__ void opt4(float4 &var, float4 &m, float4 &v, float4 g
             pv[c] = pv[c] - (h.lr_t * pg[c]) * __builtin_amdgcn_rsqf(a);
 #endif
         }
+    }
+}
+
+// deferred mode: bring a row's float4 slice from the state after step `last` to the state after step `upto` with the
+// untouched-row update of TF1's sparse Adam.  m falls below the smallest fp32 denormal after < 1024 steps (0.9^1024 =
+// 1e-47 of itself), from where on var no longer moves: the rest of the gap is v *= b2^n.
+constexpr int CREC_REPLAY_MAX = 1024;
+__device__ __forceinline__ void adam_replay(float4 &var, float4 &m, float4 &v, int last, int upto, const Hyper &h)
+{
+    const int n = upto - last;
+    if (n <= 0 || last == 0) // a row that was never updated has m = v = 0: the replayed update is var -= 0
+        return;
+    const int nr = n < CREC_REPLAY_MAX ? n : CREC_REPLAY_MAX;
+    Hyper hs = h;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < nr; ++k) {
+        hs.lr_t = h.lr_tab[last + 1 + k];
+        adam4(var, m, v, zero, false, hs);
+    }
+    if (n > nr) {
+        const float f = powf(h.beta2, (float)(n - nr));
+        v = make_float4(v.x * f, v.y * f, v.z * f, v.w * f);
+        m = zero;
     }
 }
 
@@ -1404,7 +1434,7 @@ __device__ __forceinline__ LazyTicket lazy_ticket_of(int4 desc, int CH)
 // One multi-occurrence row of this group's triple.  The group has published its contribution row, waited for the
 // store, and drawn ticket `tk` on the row's (chunk's) counter.  The last contributor of the row -- of the chunk first,
 // for a heavy row -- forms the sum in sorted order and finishes the row.  Every lane of the group takes the same path.
-template <int LPR, bool USER>
+template <int LPR, bool USER, bool DEFER>
 __device__ __forceinline__ void lazy_role_tail(const Tables &t, int d, bool act, int4 desc, int tk, float4 own, float *cbuf,
                                                float *pbuf, int32_t *row_t, int32_t *chk_t, int CH, const Hyper &h)
 {
@@ -1451,7 +1481,14 @@ __device__ __forceinline__ void lazy_role_tail(const Tables &t, int d, bool act,
         st4(h.dQ + ro, g);
         return;
     }
-    float4 nv = own;
+    float4 nv = own; // deferred mode: `own` is the contributor's caught-up copy of the row; m, v as stored are replayed here
+    if (DEFER) {
+        float4 scratch = ld4((USER ? t.P : t.Q) + ro);
+        int32_t *last = (USER ? h.lastP : h.lastQ) + (desc.x & 0x7fffffff);
+        adam_replay(scratch, m, v, *last, h.step - 1, h);
+        if (l == 0)
+            *last = h.step;
+    }
     opt4(nv, m, v, g, h);
     st4((USER ? t.P : t.Q) + ro, nv);
     if (h.opt != CREC_OPT_SGD)
@@ -1461,7 +1498,7 @@ __device__ __forceinline__ void lazy_role_tail(const Tables &t, int d, bool act,
 }
 
 // bpr_triples_lazy: a lane group per triple; ud / id / jd: the triple's three roles by batch position (IndexWs).
-template <int LPR, bool FULL>
+template <int LPR, bool FULL, bool DEFER>
 __global__ __launch_bounds__(256) void bpr_triples_lazy(Tables t, int d, const int32_t *__restrict__ order,
                                                         const int4 *__restrict__ ud, const int4 *__restrict__ id,
                                                         const int4 *__restrict__ jd, int nb, LazyBufs z,
@@ -1485,18 +1522,33 @@ __global__ __launch_bounds__(256) void bpr_triples_lazy(Tables t, int d, const i
         qi = ld4(t.Q + oi);
         qj = ld4(t.Q + oj);
         const bool has_m = h.opt != CREC_OPT_SGD, has_v = h.opt == 0; // the slots this optimizer keeps
-        if (us && has_m)
+        if ((us || DEFER) && has_m) // deferred mode: every row is brought up to date before its values are used
             mp = ld4s(t.mP + ou);
-        if (us && has_v)
+        if ((us || DEFER) && has_v)
             vp = ld4s(t.vP + ou);
-        if (is && item_adam && has_m)
+        if ((is || DEFER) && item_adam && has_m)
             mi = ld4s(t.mQ + oi);
-        if (is && item_adam && has_v)
+        if ((is || DEFER) && item_adam && has_v)
             vi = ld4s(t.vQ + oi);
-        if (js && item_adam && has_m)
+        if ((js || DEFER) && item_adam && has_m)
             mj = ld4s(t.mQ + oj);
-        if (js && item_adam && has_v)
+        if ((js || DEFER) && item_adam && has_v)
             vj = ld4s(t.vQ + oj);
+    }
+    if (DEFER) { // the steps these rows sat out, replayed: from here on p, q_i, q_j are what TF1's tables hold after step - 1
+        const int lu = valid ? h.lastP[du.x & 0x7fffffff] : h.step, li = valid ? h.lastQ[di.x & 0x7fffffff] : h.step,
+                  lj = valid ? h.lastQ[dj.x & 0x7fffffff] : h.step;
+        adam_replay(p, mp, vp, lu, h.step - 1, h);
+        adam_replay(qi, mi, vi, li, h.step - 1, h);
+        adam_replay(qj, mj, vj, lj, h.step - 1, h);
+        if (on && l == 0) { // the single-occurrence rows are finished below
+            if (us)
+                h.lastP[du.x & 0x7fffffff] = h.step;
+            if (is)
+                h.lastQ[di.x & 0x7fffffff] = h.step;
+            if (js)
+                h.lastQ[dj.x & 0x7fffffff] = h.step;
+        }
     }
     float x;
     const float s = triple_s<LPR>(dot4(p, qi) - dot4(p, qj), &x);
@@ -1586,11 +1638,35 @@ __global__ __launch_bounds__(256) void bpr_triples_lazy(Tables t, int d, const i
     tki = __shfl(tki, lead, 64);
     tkj = __shfl(tkj, lead, 64);
     if (valid && !us)
-        lazy_role_tail<LPR, true>(t, d, act, du, tku, p, z.ucontrib, z.upart, z.urow_t, z.uchk_t, z.CH, h);
+        lazy_role_tail<LPR, true, DEFER>(t, d, act, du, tku, p, z.ucontrib, z.upart, z.urow_t, z.uchk_t, z.CH, h);
     if (valid && !is)
-        lazy_role_tail<LPR, false>(t, d, act, di, tki, qi, z.qcontrib, z.qpart, z.qrow_t, z.qchk_t, z.CH, h);
+        lazy_role_tail<LPR, false, DEFER>(t, d, act, di, tki, qi, z.qcontrib, z.qpart, z.qrow_t, z.qchk_t, z.CH, h);
     if (valid && !js)
-        lazy_role_tail<LPR, false>(t, d, act, dj, tkj, qj, z.qcontrib, z.qpart, z.qrow_t, z.qchk_t, z.CH, h);
+        lazy_role_tail<LPR, false, DEFER>(t, d, act, dj, tkj, qj, z.qcontrib, z.qpart, z.qrow_t, z.qchk_t, z.CH, h);
+}
+
+// deferred mode: every row of a table brought up to the state after step h.step (before evaluation / a checkpoint);
+// a lane group per row
+__global__ __launch_bounds__(256) void bpr_adam_flush(float *__restrict__ var, float *__restrict__ m, float *__restrict__ v,
+                                                      int32_t *__restrict__ last, int64_t rows, int d, int lpr, Hyper h)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t r = t / lpr;
+    const int l = (int)(t % lpr);
+    if (r >= rows || 4 * l >= d)
+        return;
+    const int L = last[r];
+    if (L >= h.step)
+        return;
+    const int64_t ro = r * d + 4 * l;
+    float4 a = ld4(var + ro), b = ld4(m + ro), c = ld4(v + ro);
+    adam_replay(a, b, c, L, h.step, h);
+    st4(var + ro, a);
+    st4(m + ro, b);
+    st4(v + ro, c);
+    // the row's lanes read `last` before any of them may write it: the writer is the lane that finishes the row's last slice
+    if (4 * (l + 1) >= d)
+        last[r] = h.step;
 }
 
 // ------------------------------------------------------------------------------------
@@ -1736,9 +1812,14 @@ template <int LPR, bool FULL> void launch_lazy(const StepArgs &a, const IndexWs 
     constexpr int G = 64 / LPR;
     (void)hn;
     crec_prof_begin(a.ctx, CREC_K_USER_SIDE, a.st);
-    CREC_KLAUNCH(a.ctx, (bpr_triples_lazy<LPR, FULL>), dim3((unsigned)crec_ceil_div(a.nb_cur, 4 * G)), dim3(256), 0, a.st, a.cur, a.d,
-                 (const int32_t *)(w.order + b * w.B), (const int4 *)(w.u_desc + b * w.B), (const int4 *)(w.i_desc + b * w.B),
-                 (const int4 *)(w.j_desc + b * w.B), (int)a.nb_cur, a.lazy, a.xb, a.rowterm, a.h);
+    if (a.h.lr_tab)
+        CREC_KLAUNCH(a.ctx, (bpr_triples_lazy<LPR, FULL, true>), dim3((unsigned)crec_ceil_div(a.nb_cur, 4 * G)), dim3(256), 0, a.st, a.cur,
+                     a.d, (const int32_t *)(w.order + b * w.B), (const int4 *)(w.u_desc + b * w.B), (const int4 *)(w.i_desc + b * w.B),
+                     (const int4 *)(w.j_desc + b * w.B), (int)a.nb_cur, a.lazy, a.xb, a.rowterm, a.h);
+    else
+        CREC_KLAUNCH(a.ctx, (bpr_triples_lazy<LPR, FULL, false>), dim3((unsigned)crec_ceil_div(a.nb_cur, 4 * G)), dim3(256), 0, a.st, a.cur,
+                     a.d, (const int32_t *)(w.order + b * w.B), (const int4 *)(w.u_desc + b * w.B), (const int4 *)(w.i_desc + b * w.B),
+                     (const int4 *)(w.j_desc + b * w.B), (int)a.nb_cur, a.lazy, a.xb, a.rowterm, a.h);
     crec_prof_end(a.ctx, a.st);
 }
 
@@ -1796,8 +1877,42 @@ StepFn pick_step(int d, bool dense)
 } // namespace
 
 namespace {
+// deferred mode: lr_s of every step so far, kept on the device (TF1's fp32 running beta powers from step 1 on)
+int lr_history(crec_ctx *ctx, const crec_adam *opt, int64_t upto, hipStream_t st, const float **dev)
+{
+    if (ctx->lr_hist.empty() || ctx->lr_hist_key[0] != opt->lr || ctx->lr_hist_key[1] != opt->beta1 || ctx->lr_hist_key[2] != opt->beta2) {
+        ctx->lr_hist.assign(1, 0.f); // [0] unused: steps are 1-based
+        ctx->lr_hist_key[0] = opt->lr;
+        ctx->lr_hist_key[1] = opt->beta1;
+        ctx->lr_hist_key[2] = opt->beta2;
+        ctx->lr_hist_b1p = opt->beta1;
+        ctx->lr_hist_b2p = opt->beta2;
+        ctx->lr_hist_uploaded = 0;
+    }
+    while ((int64_t)ctx->lr_hist.size() <= upto) {
+        ctx->lr_hist.push_back((opt->lr * sqrtf(1.0f - ctx->lr_hist_b2p)) / (1.0f - ctx->lr_hist_b1p));
+        ctx->lr_hist_b1p = ctx->lr_hist_b1p * opt->beta1;
+        ctx->lr_hist_b2p = ctx->lr_hist_b2p * opt->beta2;
+    }
+    const void *before = ctx->lr_hist_dev.ptr;
+    if (int rc = crec_reserve(ctx, &ctx->lr_hist_dev, sizeof(float) * (ctx->lr_hist.size() + 4096)))
+        return rc;
+    if (ctx->lr_hist_dev.ptr != before)
+        ctx->lr_hist_uploaded = 0;
+    if (ctx->lr_hist_uploaded < ctx->lr_hist.size()) {
+        // a blocking copy from pageable memory: the vector may grow (and move) on the next call
+        CREC_HIP(ctx, hipMemcpyAsync((float *)ctx->lr_hist_dev.ptr + ctx->lr_hist_uploaded, ctx->lr_hist.data() + ctx->lr_hist_uploaded,
+                                     sizeof(float) * (ctx->lr_hist.size() - ctx->lr_hist_uploaded), hipMemcpyHostToDevice, st));
+        CREC_HIP(ctx, hipStreamSynchronize(st));
+        ctx->lr_hist_uploaded = ctx->lr_hist.size();
+    }
+    *dev = (const float *)ctx->lr_hist_dev.ptr;
+    return CREC_OK;
+}
+
 int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, const int32_t *u, const int32_t *i,
-                     const int32_t *j, int64_t N, int32_t B, float *loss_per_batch, void *stream, bool dp)
+                     const int32_t *j, int64_t N, int32_t B, float *loss_per_batch, void *stream, bool dp,
+                     const crec_bpr_deferred *df = nullptr)
 {
     if (!ctx)
         return CREC_EINVAL;
@@ -1810,7 +1925,10 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
     CREC_REQUIRE(ctx, t->U >= 1 && t->I >= 1 && t->U < ((int64_t)1 << 31) && t->I < ((int64_t)1 << 31), "table rows");
     CREC_REQUIRE(ctx, B >= 1 && B <= MAX_B, "batch_size %d: this build indexes batches of at most %d in LDS", B, MAX_B);
     CREC_REQUIRE(ctx, opt->adam_mode == CREC_ADAM_TF1 || opt->adam_mode == CREC_ADAM_LAZY || opt->adam_mode == CREC_OPT_SGD ||
-                          opt->adam_mode == CREC_OPT_ADAGRAD, "adam_mode");
+                          opt->adam_mode == CREC_OPT_ADAGRAD || opt->adam_mode == CREC_ADAM_DEFERRED, "adam_mode");
+    CREC_REQUIRE(ctx, (opt->adam_mode == CREC_ADAM_DEFERRED) == (df != nullptr),
+                 "adam_mode deferred goes through crec_bpr_train_epoch_deferred (and only it)");
+    CREC_REQUIRE(ctx, !df || (df->lastP && df->lastQ), "null last-step arrays");
     const float *tabs[] = {t->P, t->Q, t->mP, t->vP, t->mQ, t->vQ};
     for (const float *p : tabs)
         CREC_REQUIRE(ctx, ((uintptr_t)p & 15) == 0, "table base not 16-byte aligned");
@@ -1826,6 +1944,12 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
     }
     StepFn step = pick_step(t->d, dense);
     const int64_t nb = crec_ceil_div(N, B);
+    const float *lr_tab = nullptr;
+    if (df) {
+        CREC_REQUIRE(ctx, opt->step + nb < ((int64_t)1 << 31), "step counter");
+        if (int rc = lr_history(ctx, opt, opt->step + nb, st, &lr_tab))
+            return rc;
+    }
     // occurrences per heavy-row chunk: short chunks shorten the longest wave, every chunk wave pays a ticket on its
     // row's counter.  Item side of S-big: CH 8 -> 12.4 us, 16 -> 11.4, 32 -> 12.0 (with fence-published partials the
     // sweep read 16 -> 16.3, 32 -> 13.7, 64 -> 15.3).  tf1 mode at ml-1m shape: 32 -> 14.4 us/step, 64 -> 13.2.
@@ -1974,7 +2098,11 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
         }
         for (int64_t b = 0; b < nbc; ++b) {
             // lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t) with fp32 running powers (TF1 _prepare/_finish); SGD / Adagrad: lr
-            a.h.opt = opt->adam_mode >= CREC_OPT_SGD ? opt->adam_mode : 0;
+            a.h.opt = (opt->adam_mode == CREC_OPT_SGD || opt->adam_mode == CREC_OPT_ADAGRAD) ? opt->adam_mode : 0;
+            a.h.lr_tab = lr_tab; // deferred mode (else null)
+            a.h.lastP = df ? df->lastP : nullptr;
+            a.h.lastQ = df ? df->lastQ : nullptr;
+            a.h.step = (int32_t)(opt->step + 1);
             a.h.lr_t = a.h.opt ? opt->lr : (opt->lr * sqrtf(1.0f - opt->beta2_power)) / (1.0f - opt->beta1_power);
             a.h.beta1 = opt->beta1;
             a.h.beta2 = opt->beta2;
@@ -2304,6 +2432,7 @@ int sharded_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, int64_t I_global
             if (int rc = x->alltoallv(ctx, v.sendrows, scnt.data(), sdsp.data(), p.Qc, rcnt.data(), rdsp.data(), 4, st))
                 return rc;
             a.h.opt = 0;
+            a.h.lr_tab = nullptr;
             a.h.lr_t = (opt->lr * sqrtf(1.0f - opt->beta2_power)) / (1.0f - opt->beta1_power);
             a.h.beta1 = opt->beta1;
             a.h.beta2 = opt->beta2;
@@ -2365,6 +2494,46 @@ int crec_bpr_train_epoch_dp(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *
                             void *stream)
 {
     return train_epoch_impl(ctx, t, opt, u, i, j, N, B, loss_per_batch, stream, true);
+}
+
+int crec_bpr_train_epoch_deferred(crec_ctx *ctx, const crec_bpr_tables *t, const crec_bpr_deferred *df, crec_adam *opt,
+                                  const int32_t *u, const int32_t *i, const int32_t *j, int64_t N, int32_t B,
+                                  float *loss_per_batch, void *stream)
+{
+    if (!ctx)
+        return CREC_EINVAL;
+    CREC_REQUIRE(ctx, df != nullptr, "null argument");
+    return train_epoch_impl(ctx, t, opt, u, i, j, N, B, loss_per_batch, stream, false, df);
+}
+
+int crec_bpr_adam_flush(crec_ctx *ctx, const crec_bpr_tables *t, const crec_bpr_deferred *df, const crec_adam *opt, void *stream)
+{
+    if (!ctx)
+        return CREC_EINVAL;
+    CREC_REQUIRE(ctx, ctx->device >= 0, "host-only ctx: no device bound");
+    CREC_REQUIRE(ctx, t && df && opt && df->lastP && df->lastQ, "null argument");
+    CREC_REQUIRE(ctx, opt->adam_mode == CREC_ADAM_DEFERRED, "crec_bpr_adam_flush belongs to adam_mode deferred");
+    CREC_REQUIRE(ctx, t->d >= 4 && t->d <= 256 && t->d % 4 == 0, "embed_size");
+    if (opt->step == 0)
+        return CREC_OK;
+    CREC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    Hyper h{};
+    if (int rc = lr_history(ctx, opt, opt->step, st, &h.lr_tab))
+        return rc;
+    h.beta1 = opt->beta1;
+    h.beta2 = opt->beta2;
+    h.eps = opt->eps;
+    h.step = (int32_t)opt->step;
+    int lpr = 1;
+    while (lpr * 4 < t->d)
+        lpr <<= 1;
+    hipLaunchKernelGGL(bpr_adam_flush, dim3((unsigned)crec_ceil_div(t->U * lpr, 256)), dim3(256), 0, st, t->P, t->mP, t->vP, df->lastP,
+                       t->U, (int)t->d, lpr, h);
+    hipLaunchKernelGGL(bpr_adam_flush, dim3((unsigned)crec_ceil_div(t->I * lpr, 256)), dim3(256), 0, st, t->Q, t->mQ, t->vQ, df->lastQ,
+                       t->I, (int)t->d, lpr, h);
+    CREC_HIP(ctx, hipGetLastError());
+    return CREC_OK;
 }
 
 int crec_bpr_train_epoch_sharded(crec_ctx *ctx, const crec_bpr_tables *t, int64_t I_global, crec_adam *opt, const int32_t *u,

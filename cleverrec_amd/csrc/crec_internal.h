@@ -84,6 +84,11 @@ struct crec_ctx {
     crec_devbuf misc;     // heavy-row partials + ticket counters
     char *tickets_at = nullptr; // where the counters were last cleared (they are re-zeroed by the kernels after use)
     size_t tickets_bytes = 0;
+    // deferred Adam: lr_s of every step so far (host copy, device copy, the running beta powers behind it)
+    std::vector<float> lr_hist;
+    crec_devbuf lr_hist_dev;
+    size_t lr_hist_uploaded = 0;
+    float lr_hist_key[3] = {0, 0, 0}, lr_hist_b1p = 0, lr_hist_b2p = 0;
     char *lazy_tickets_at = nullptr; // the lazy step's counters (inside `contrib`), likewise
     size_t lazy_tickets_bytes = 0;
     size_t index_lds_set = 0;   // dynamic LDS limit already granted to bpr_index_batches

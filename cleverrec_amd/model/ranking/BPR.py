@@ -43,6 +43,7 @@ class BPR(RankingRecommender):
     def save(self, path=None):
         """Variables under the reference's checkpoint names (BPR.py:53-58)."""
         path = path or os.path.join(self.saved_model_dir, self.model, self.model + '.pt')
+        self.state.flush()
         torch.save({'BPR_params/P': self.P.cpu(), 'BPR_params/Q': self.Q.cpu()}, path)
         return path
 
@@ -58,4 +59,5 @@ class BPR(RankingRecommender):
         return self.state.train_epoch(u, i, j, self.batch_size)
 
     def _eval_tables(self):
+        self.state.flush()  # adam_mode deferred: every row replays the steps it sat out; a no-op otherwise
         return self.state.P, self.state.Q

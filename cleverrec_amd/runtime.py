@@ -48,7 +48,8 @@ class Session:
 
 class BprState:
     """P, Q and their optimizer slots in HBM + the optimizer scalars (crec_bpr_tables / crec_adam).
-    adam_mode: 'tf1' | 'lazy' (Adam), 'sgd', 'adagrad' (utils/tools.py:79-87)."""
+    adam_mode: 'tf1' | 'lazy' | 'deferred' (Adam; deferred = TF1 results with the lazy step's traffic, flush() before the
+    tables are read), 'sgd', 'adagrad' (utils/tools.py:79-87)."""
 
     def __init__(self, sess, P0, Q0, lr, reg, adam_mode="tf1", beta1=0.9, beta2=0.999, eps=1e-8):
         self.sess = sess
@@ -62,8 +63,14 @@ class BprState:
             self.mQ.fill_(0.1)
         self.tables = _lib.BprTables(*(t.data_ptr() for t in (self.P, self.Q, self.mP, self.vP, self.mQ, self.vQ)),
                                      self.P.shape[0], self.Q.shape[0], self.P.shape[1])
-        mode = {"tf1": _lib.ADAM_TF1, "lazy": _lib.ADAM_LAZY, "sgd": _lib.OPT_SGD, "adagrad": _lib.OPT_ADAGRAD}[adam_mode]
+        mode = {"tf1": _lib.ADAM_TF1, "lazy": _lib.ADAM_LAZY, "sgd": _lib.OPT_SGD, "adagrad": _lib.OPT_ADAGRAD,
+                "deferred": _lib.ADAM_DEFERRED}[adam_mode]
         self.adam = _lib.Adam(lr, beta1, beta2, eps, reg, mode, beta1, beta2, 0)
+        self.deferred = None
+        if adam_mode == "deferred":  # per row: the step its state is current at (crec_bpr_deferred)
+            self.lastP = torch.zeros(self.P.shape[0], dtype=torch.int32, device=sess.device)
+            self.lastQ = torch.zeros(self.Q.shape[0], dtype=torch.int32, device=sess.device)
+            self.deferred = _lib.BprDeferred(self.lastP.data_ptr(), self.lastQ.data_ptr())
 
     def train_epoch(self, u, i, j, batch_size):
         """u, i, j: int32 device tensors [N].  Returns the per-batch summed losses (device fp32)."""
@@ -71,9 +78,20 @@ class BprState:
         n = int(u.numel())
         nb = -(-n // batch_size)
         loss = s.empty((nb,), torch.float32)
+        if self.deferred is not None:
+            s.ctx.check(s.lib.crec_bpr_train_epoch_deferred(s.ctx.h, C.byref(self.tables), C.byref(self.deferred), C.byref(self.adam),
+                                                            s.ptr(u), s.ptr(i), s.ptr(j), n, int(batch_size), s.ptr(loss), s.stream_ptr()))
+            return loss
         s.ctx.check(s.lib.crec_bpr_train_epoch(s.ctx.h, C.byref(self.tables), C.byref(self.adam), s.ptr(u), s.ptr(i),
                                                s.ptr(j), n, int(batch_size), s.ptr(loss), s.stream_ptr()))
         return loss
+
+    def flush(self):
+        """adam_mode 'deferred': replay the steps every row sat out (crec_bpr_adam_flush) -- before evaluating, saving or
+        reading the tables.  A no-op in the other modes."""
+        if self.deferred is not None:
+            s = self.sess
+            s.ctx.check(s.lib.crec_bpr_adam_flush(s.ctx.h, C.byref(self.tables), C.byref(self.deferred), C.byref(self.adam), s.stream_ptr()))
 
 
 def eval_topk(sess, P, Q, users, seen_ptr, seen_items, K, ascending=False, candidates=False):

@@ -45,6 +45,12 @@ extern "C" {
  *            slot, which the caller initialises to 0.1 (initial_accumulator_value); `v` is unused */
 #define CREC_OPT_SGD 2
 #define CREC_OPT_ADAGRAD 3
+/* TF1-exact Adam with the traffic of the lazy step, for tables too large to sweep every step (BASELINE configs[4]:
+ * a TF1 sweep of 10 M x 1 M x 128 is 16.9 GB per batch).  TF1 decays m, v and moves var on EVERY row at every step
+ * (SURVEY a7); here a row carries the step at which its state was last brought up to date and replays the steps it sat
+ * out whenever a batch touches it -- before its values are used -- and, for all rows, in crec_bpr_adam_flush.
+ * Only through crec_bpr_train_epoch_deferred. */
+#define CREC_ADAM_DEFERRED 4
 
 typedef struct crec_ctx crec_ctx;
 
@@ -145,6 +151,18 @@ typedef struct {
  * train_model's return value is mean(loss_per_batch) (:61).  B <= 8192. */
 int crec_bpr_train_epoch(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, const int32_t *u, const int32_t *i,
                          const int32_t *j, int64_t N, int32_t B, float *loss_per_batch, void *stream);
+
+/* adam_mode CREC_ADAM_DEFERRED: lastP [U], lastQ [I] int32 [dev], zero-initialised by the caller, hold the step at which
+ * each row's (var, m, v) are current.  After an epoch the tables are NOT what TF1's would be until crec_bpr_adam_flush
+ * has replayed the outstanding steps of every row: call it before evaluating, checkpointing or reading the tables
+ * (replaces nothing in the reference: there every sess.run leaves all rows current). */
+typedef struct {
+    int32_t *lastP, *lastQ;
+} crec_bpr_deferred;
+int crec_bpr_train_epoch_deferred(crec_ctx *ctx, const crec_bpr_tables *t, const crec_bpr_deferred *df, crec_adam *opt,
+                                  const int32_t *u, const int32_t *i, const int32_t *j, int64_t N, int32_t B,
+                                  float *loss_per_batch, void *stream);
+int crec_bpr_adam_flush(crec_ctx *ctx, const crec_bpr_tables *t, const crec_bpr_deferred *df, const crec_adam *opt, void *stream);
 
 /* ---- pointwise NCF family: GMF / MLP / NeuMF (device) --------------------------------------------
  * replaces, per batch, sess.run([self.train, self.loss], {u_idx, i_idx, y}) (model/RankingRecommender.py:52-58)

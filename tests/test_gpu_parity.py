@@ -463,3 +463,52 @@ def test_model_class_with_sgd_and_adagrad(sess, tmp_path):
         oavg, _ = oracle.train_model_py(om, nb, ou, oi, oj, 256)
         assert avg == pytest.approx(oavg, rel=1e-5)
         np.testing.assert_allclose(m.Q.cpu().numpy(), om.Q, rtol=2e-6, atol=2e-6)
+
+
+@pytest.mark.parametrize("d", [32, 128])
+def test_bpr_deferred_adam_equals_tf1(sess, d):
+    """adam_mode deferred (rows replay the steps they sat out when touched, all rows at flush) against the TF1 sweep of every
+    row at every step: the fused tf1 kernel and the oracle, on the S-ml100k epoch (BASELINE config C1 shape)."""
+    data = synthetic("S-ml100k")
+    P0, Q0 = _tables(3, data.user_nums, data.item_nums, d)
+    sess.ctx.seed(2)
+    u, i, j = (sess.to_dev(a) for a in sess.ctx.sample_pairwise(data.train_csr, data.item_nums, 4))
+    n = 12 * 2048 + 100
+    st_d = runtime.BprState(sess, P0, Q0, lr=1e-3, reg=0.01, adam_mode="deferred")
+    st_t = runtime.BprState(sess, P0, Q0, lr=1e-3, reg=0.01, adam_mode="tf1")
+    l_d = torch.cat([st_d.train_epoch(u[:n // 2], i[:n // 2], j[:n // 2], 2048), st_d.train_epoch(u[n // 2:n], i[n // 2:n], j[n // 2:n], 2048)])
+    l_t = torch.cat([st_t.train_epoch(u[:n // 2], i[:n // 2], j[:n // 2], 2048), st_t.train_epoch(u[n // 2:n], i[n // 2:n], j[n // 2:n], 2048)])
+    np.testing.assert_allclose(l_d.cpu().numpy(), l_t.cpu().numpy(), rtol=1e-5)
+    # before the flush the untouched rows lag behind; after it every row is where TF1 has it
+    assert not np.allclose(st_d.P.cpu().numpy(), st_t.P.cpu().numpy(), rtol=0, atol=2e-6)
+    st_d.flush()
+    for name in ("P", "Q", "mP", "mQ"):
+        np.testing.assert_allclose(getattr(st_d, name).cpu().numpy(), getattr(st_t, name).cpu().numpy(), rtol=0, atol=2e-6, err_msg=name)
+    for name in ("vP", "vQ"):
+        np.testing.assert_allclose(getattr(st_d, name).cpu().numpy(), getattr(st_t, name).cpu().numpy(), rtol=1e-4, atol=1e-12, err_msg=name)
+    assert int(st_d.lastP.min()) == int(st_d.lastQ.min()) == st_d.adam.step == st_t.adam.step
+
+
+def test_bpr_deferred_adam_long_gaps_against_oracle(sess):
+    """Rows that sit out more than CREC_REPLAY_MAX = 1024 steps (m has underflowed: the rest of the gap is v *= beta2^n),
+    rows touched again after a long gap, and rows never touched, against the oracle's TF1 sweep: 1 500 steps of B = 4."""
+    g = np.random.Generator(np.random.PCG64(17))
+    U, I, d, B, steps = 60, 50, 8, 4, 1500
+    P0, Q0 = _tables(9, U, I, d, 0.1)
+    u = g.integers(10, U, steps * B).astype(np.int32)  # users 0..9 only at the very beginning and the very end
+    u[:B] = np.arange(B)
+    u[-B:] = np.arange(B)
+    i = g.integers(5, I, steps * B).astype(np.int32)   # items 0..4 never
+    j = g.integers(5, I, steps * B).astype(np.int32)
+    i[:B] = 5 + np.arange(B)
+    st = runtime.BprState(sess, P0, Q0, lr=1e-2, reg=0.01, adam_mode="deferred")
+    om = oracle.BprModel(P0, Q0, lr=1e-2, reg=0.01, adam_mode=0)
+    loss = st.train_epoch(sess.to_dev(u), sess.to_dev(i), sess.to_dev(j), B).cpu().numpy()
+    oloss = np.array([om.step(u[b * B:(b + 1) * B], i[b * B:(b + 1) * B], j[b * B:(b + 1) * B]) for b in range(steps)])
+    np.testing.assert_allclose(loss, oloss, rtol=2e-5)
+    st.flush()
+    for name in ("P", "Q"):  # 1 500 steps of lr = 1e-2: the fp32 noise of the running state is what the bound covers
+        np.testing.assert_allclose(getattr(st, name).cpu().numpy(), getattr(om, name), rtol=0, atol=2e-4, err_msg=name)
+    np.testing.assert_allclose(st.Q.cpu().numpy()[:5], Q0[:5], rtol=0, atol=0)  # never touched: m = v = 0, nothing moves
+    for name in ("vP", "vQ"):
+        np.testing.assert_allclose(getattr(st, name).cpu().numpy(), getattr(om, name), rtol=2e-3, atol=1e-12, err_msg=name)
