@@ -46,11 +46,12 @@ class Param(C.Structure):
 
 
 NCF_GMF, NCF_MLP, NCF_NEUMF = 0, 1, 2
+LOSS_CROSS_ENTROPY, LOSS_SQUARE = 0, 1
 
 
 class Ncf(C.Structure):
     _fields_ = [("kind", C.c_int32), ("P_gmf", Param), ("Q_gmf", Param), ("P_mlp", Param), ("Q_mlp", Param),
-                ("n_layers", C.c_int32), ("small", Param), ("reg_gmf", C.c_float), ("reg_mlp", C.c_float)]
+                ("n_layers", C.c_int32), ("small", Param), ("reg_gmf", C.c_float), ("reg_mlp", C.c_float), ("loss_func", C.c_int32)]
 
 
 class Fm(C.Structure):

@@ -230,10 +230,13 @@ __global__ __launch_bounds__(NT) void ncf_tile(NcfDev m, const int32_t *__restri
         if (sub == 0) {
             const bool ok = r < nr;
             const float z = zg + zm, lab = yl[r];
-            e[r] = ok ? sigmoidf_(z) - lab : 0.f;
+            // d loss / d logit: sigmoid(z) - y for the cross-entropy, 2 (z - y) for the square loss (utils/tools.py:74-75)
+            e[r] = !ok ? 0.f : (m.loss == CREC_LOSS_SQUARE ? 2.0f * (z - lab) : sigmoidf_(z) - lab);
             if (ok) {
-                // sigmoid_cross_entropy_with_logits (utils/tools.py:68-69) + the l2 terms of the gathered rows
-                const float ls = (z > 0.f ? z : 0.f) - z * lab + log1pf(expf(-fabsf(z)));
+                // sigmoid_cross_entropy_with_logits (utils/tools.py:68-69) | squared_difference(y, logits) (:74-75)
+                // + the l2 terms of the gathered rows
+                const float ls = m.loss == CREC_LOSS_SQUARE ? (lab - z) * (lab - z)
+                                                            : (z > 0.f ? z : 0.f) - z * lab + log1pf(expf(-fabsf(z)));
                 loss_inst[r0 + r] = ls + m.reg_g * (0.5f * ng) + m.reg_m * (0.5f * nm);
             }
         }

@@ -11,6 +11,7 @@ struct NcfDev {
     int dg, n_layers, L0;
     int w_off[MAX_LAYERS], b_off[MAX_LAYERS], h_off, n_small;
     float reg_g, reg_m;
+    int loss; // CREC_LOSS_*: sigmoid cross-entropy | square (utils/tools.py:66-76)
     long long *dbg; // -DNCF_STAMPS builds only: per-phase clock stamps of one tile (tools/ncf_variants.sh)
 };
 
@@ -23,6 +24,8 @@ inline int ncf_describe(crec_ctx *ctx, const crec_ncf *mdl, NcfDev *d)
     d->kind = mdl->kind;
     d->reg_g = mdl->reg_gmf;
     d->reg_m = mdl->reg_mlp;
+    CREC_REQUIRE(ctx, mdl->loss_func == CREC_LOSS_CROSS_ENTROPY || mdl->loss_func == CREC_LOSS_SQUARE, "loss_func");
+    d->loss = mdl->loss_func;
     int off = 0;
     if (has_g) {
         CREC_REQUIRE(ctx, mdl->P_gmf.var && mdl->Q_gmf.var && mdl->P_gmf.cols == mdl->Q_gmf.cols, "gmf tables");

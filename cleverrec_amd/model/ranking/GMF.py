@@ -16,8 +16,10 @@ class GMF(RankingRecommender):
         self.embed_size = int(configs['embed_size'])
         # the class reads configs['reg'] but the shipped conf defines reg_gmf: accept both
         self.reg = float(configs['reg'] if 'reg' in configs else configs['reg_gmf'])
-        if self.loss_func != 'cross_entropy':
-            raise NotImplementedError("GMF is built with loss_func=cross_entropy (conf/GMF.properties)")
+        # get_loss(self.loss_func, self.y, self.logits) (utils/tools.py:66-76): the two names that can train this graph in the
+        # reference; 'bpr' ignores the logits (no gradient reaches the model), 'hinge' adds margin = None (TypeError)
+        if self.loss_func not in ('cross_entropy', 'square'):
+            raise NotImplementedError("GMF: loss_func=%s cannot train this graph (utils/tools.py:66-76)" % self.loss_func)
         logger.info(' model_params: embed_size=%d, reg=%s' % (self.embed_size, self.reg) + ', ' + self.model_params)
 
     def _create_inputs(self):
@@ -29,7 +31,7 @@ class GMF(RankingRecommender):
         P = init.get('P', None) if 'P' in init else self.initializer([U, d])
         Q = init.get('Q', None) if 'Q' in init else self.initializer([I, d])
         h = init.get('h_gmf', None) if 'h_gmf' in init else self.initializer([d])  # biases use the same initializer (GMF.py:25-26)
-        self.state = NcfState(self.sess, 'GMF', {'P_gmf': P, 'Q_gmf': Q}, [], [], h, self.lr, reg_gmf=self.reg)
+        self.state = NcfState(self.sess, 'GMF', {'P_gmf': P, 'Q_gmf': Q}, [], [], h, self.lr, reg_gmf=self.reg, loss_func=self.loss_func)
         self.P, self.Q, self.h_gmf = self.state.t['P_gmf'], self.state.t['Q_gmf'], self.state.h
 
     def _create_embeddings(self):

@@ -14,6 +14,10 @@ class MLP(RankingRecommender):
         super(MLP, self).__init__(sess, data, configs, logger)
         if self.optimizer != 'Adam':  # SGD / Adagrad are built for the BPR step only (csrc/bpr_train.hip)
             raise NotImplementedError("optimizer=%s: this model's step implements Adam (its shipped conf's choice)" % self.optimizer)
+        # get_loss(self.loss_func, self.y, self.logits) (utils/tools.py:66-76): the two names that can train this graph in the
+        # reference; 'bpr' ignores the logits (no gradient reaches the model), 'hinge' adds margin = None (TypeError)
+        if self.loss_func not in ('cross_entropy', 'square'):
+            raise NotImplementedError("MLP: loss_func=%s cannot train this graph (utils/tools.py:66-76)" % self.loss_func)
         self.layers = parse_list(configs['layers'], int)
         self.reg = float(configs['reg'] if 'reg' in configs else configs['reg_mlp'])
         logger.info(' model_params: layers=%s, reg=%s' % (self.layers, self.reg) + ', ' + self.model_params)
@@ -34,7 +38,7 @@ class MLP(RankingRecommender):
         for k in range(1, len(L)):
             if L[k] != L[k - 1] // 2:
                 raise ValueError("layers=%s: layer k must take the previous layer's output width" % L)
-        self.state = NcfState(self.sess, 'MLP', {'P_mlp': P, 'Q_mlp': Q}, Ws, bs, h, self.lr, reg_mlp=self.reg)
+        self.state = NcfState(self.sess, 'MLP', {'P_mlp': P, 'Q_mlp': Q}, Ws, bs, h, self.lr, reg_mlp=self.reg, loss_func=self.loss_func)
         self.P, self.Q, self.h_mlp = self.state.t['P_mlp'], self.state.t['Q_mlp'], self.state.h
         self.mlp_params = {}
         for k in range(len(L)):

@@ -129,7 +129,10 @@ class NcfState:
 
     KINDS = {"GMF": _lib.NCF_GMF, "MLP": _lib.NCF_MLP, "NeuMF": _lib.NCF_NEUMF}
 
-    def __init__(self, sess, kind, tables, Ws, bs, h, lr, reg_gmf=0.0, reg_mlp=0.0, beta1=0.9, beta2=0.999, eps=1e-8):
+    LOSSES = {"cross_entropy": _lib.LOSS_CROSS_ENTROPY, "square": _lib.LOSS_SQUARE}
+
+    def __init__(self, sess, kind, tables, Ws, bs, h, lr, reg_gmf=0.0, reg_mlp=0.0, beta1=0.9, beta2=0.999, eps=1e-8,
+                 loss_func="cross_entropy"):
         self.sess, self.kind = sess, kind
         f32 = torch.float32
         self.t, self.slots = {}, {}
@@ -157,7 +160,7 @@ class NcfState:
             return _lib.Param(t.data_ptr(), m.data_ptr(), v.data_ptr(), t.shape[0], t.shape[1])
         small = _lib.Param(self.small.data_ptr(), self.small_m.data_ptr(), self.small_v.data_ptr(), 1, self.small.numel())
         self.model = _lib.Ncf(self.KINDS[kind], param("P_gmf"), param("Q_gmf"), param("P_mlp"), param("Q_mlp"), len(Ws), small,
-                              reg_gmf, reg_mlp)
+                              reg_gmf, reg_mlp, self.LOSSES[loss_func])
         self.adam = _lib.Adam(lr, beta1, beta2, eps, 0.0, _lib.ADAM_TF1, beta1, beta2, 0)
 
     def train_epoch(self, u, i, y, batch_size):

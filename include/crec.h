@@ -176,6 +176,12 @@ typedef struct {
     int32_t cols;
 } crec_param;
 
+/* configs['loss_func'] of the pointwise models: 'cross_entropy' = sum sigmoid_cross_entropy_with_logits(y, logits)
+ * (utils/tools.py:68-69), 'square' = sum (y - logits)^2 (:74-75).  The other two names of get_loss cannot train these
+ * graphs in the reference either: 'bpr' ignores the logits (no gradient), 'hinge' adds margin = None (TypeError). */
+#define CREC_LOSS_CROSS_ENTROPY 0
+#define CREC_LOSS_SQUARE 1
+
 #define CREC_NCF_GMF 0
 #define CREC_NCF_MLP 1
 #define CREC_NCF_NEUMF 2
@@ -188,6 +194,7 @@ typedef struct {
     crec_param small;        /* ONE flat block [1, n]: W_0 | b_0 | W_1 | b_1 | ... | h, W_k row-major [w_k, w_k/2];
                                 h = h_gmf [d] (GMF), h_mlp [last] (MLP), h_neumf [d + last] (NeuMF) */
     float reg_gmf, reg_mlp;  /* l2 weights of the gmf / mlp rows (configs 'reg' | 'reg_gmf' | 'reg1', 'reg_mlp' | 'reg2') */
+    int32_t loss_func;       /* CREC_LOSS_*: get_loss(self.loss_func, self.y, self.logits), utils/tools.py:66-76 */
 } crec_ncf;
 
 /* u, i int32 [N], y float [N] [dev]: the shuffled instances of pointwise_ranking_sampler; batches are the

@@ -115,6 +115,13 @@ def _ce_sum(labels, logits):  # utils/tools.py:68-69: reduce_sum(sigmoid_cross_e
     return (torch.clamp(logits, min=0) - logits * labels + torch.log1p(torch.exp(-logits.abs()))).sum()
 
 
+def _pointwise_loss(loss_func, labels, logits):  # get_loss(self.loss_func, self.y, self.logits), utils/tools.py:66-76
+    if loss_func == "square":
+        return ((labels - logits) ** 2).sum()  # reduce_sum(squared_difference(y, logits)), :74-75
+    assert loss_func == "cross_entropy"
+    return _ce_sum(labels, logits)
+
+
 class Model:
     """params (fp32 tensors), kinds, loss(batch) -> scalar.  step(batch) runs one sess.run([train, loss])."""
 
@@ -160,16 +167,16 @@ class Model:
 class GMF(Model):
     """model/ranking/GMF.py:29-57: logit = sum_d pu*qi*h (:42); loss = sum CE + reg*(l2(pu)+l2(qi)) (:48)."""
 
-    def __init__(self, P, Q, h, lr, reg):
+    def __init__(self, P, Q, h, lr, reg, loss_func="cross_entropy"):
         super().__init__({"P": P, "Q": Q, "h_gmf": h}, {"P": "sparse", "Q": "sparse", "h_gmf": "dense"}, lr)
-        self.reg = reg
+        self.reg, self.loss_func = reg, loss_func
 
     def loss(self, w, u, i, y):
         u, i = torch.as_tensor(u, dtype=torch.long), torch.as_tensor(i, dtype=torch.long)
         y = self._float(y)
         pu, qi = gather(w, "P", u), gather(w, "Q", i)
         logits = ((pu * qi) * w["h_gmf"]).sum(1)
-        return _ce_sum(y, logits) + self.reg * (_l2(pu) + _l2(qi))
+        return _pointwise_loss(self.loss_func, y, logits) + self.reg * (_l2(pu) + _l2(qi))
 
     def predict(self, users):  # GMF.py:40,57: sigmoid((pu * Q) . h) for every item
         P, Q, h = (self.params[k] for k in ("P", "Q", "h_gmf"))
@@ -186,7 +193,8 @@ class MLP(Model):
     """model/ranking/MLP.py:31-77: P,Q of width layers[0]//2, W_k [layers[k], layers[k]//2], b_k, h_mlp;
     logit = tower(concat(pu, qi)) . h_mlp (:59); loss = sum CE + reg*(l2(pu)+l2(qi)) (:66)."""
 
-    def __init__(self, P, Q, Ws, bs, h, lr, reg):
+    def __init__(self, P, Q, Ws, bs, h, lr, reg, loss_func="cross_entropy"):
+        self.loss_func = loss_func
         params, kinds = {"P": P, "Q": Q, "h_mlp": h}, {"P": "sparse", "Q": "sparse", "h_mlp": "dense"}
         for k, (W, b) in enumerate(zip(Ws, bs)):
             params["W_%d" % k], params["b_%d" % k] = W, b
@@ -199,7 +207,7 @@ class MLP(Model):
         y = self._float(y)
         pu, qi = gather(w, "P", u), gather(w, "Q", i)
         logits = _tower(torch.cat([pu, qi], 1), w, self.n_layers) @ w["h_mlp"]
-        return _ce_sum(y, logits) + self.reg * (_l2(pu) + _l2(qi))
+        return _pointwise_loss(self.loss_func, y, logits) + self.reg * (_l2(pu) + _l2(qi))
 
 
 class NeuMF(Model):
@@ -207,7 +215,8 @@ class NeuMF(Model):
     loss = sum CE + reg1*(l2(pg)+l2(qg)) + reg2*(l2(pm)+l2(qm)) (:93-94).  h_gmf / h_mlp exist as variables but
     receive no gradient."""
 
-    def __init__(self, Pg, Qg, Pm, Qm, Ws, bs, h, lr, reg1, reg2):
+    def __init__(self, Pg, Qg, Pm, Qm, Ws, bs, h, lr, reg1, reg2, loss_func="cross_entropy"):
+        self.loss_func = loss_func
         params = {"P_gmf": Pg, "Q_gmf": Qg, "P_mlp": Pm, "Q_mlp": Qm, "h_neumf": h}
         kinds = {"P_gmf": "sparse", "Q_gmf": "sparse", "P_mlp": "sparse", "Q_mlp": "sparse", "h_neumf": "dense"}
         for k, (W, b) in enumerate(zip(Ws, bs)):
@@ -222,7 +231,7 @@ class NeuMF(Model):
         pg, qg, pm, qm = gather(w, "P_gmf", u), gather(w, "Q_gmf", i), gather(w, "P_mlp", u), gather(w, "Q_mlp", i)
         y_mlp = _tower(torch.cat([pm, qm], 1), w, self.n_layers)
         logits = torch.cat([pg * qg, y_mlp], 1) @ w["h_neumf"]
-        return _ce_sum(y, logits) + self.reg1 * (_l2(pg) + _l2(qg)) + self.reg2 * (_l2(pm) + _l2(qm))
+        return _pointwise_loss(self.loss_func, y, logits) + self.reg1 * (_l2(pg) + _l2(qg)) + self.reg2 * (_l2(pm) + _l2(qm))
 
     def predict(self, users):  # NeuMF.py:66,73,84,105 for every item
         w = self.params

@@ -200,3 +200,30 @@ def test_neumf_full_catalogue_eval(sess, tmp_path):
     H, M, N = oracle.test_model_rs_py(lambda cur: dev.predict(cur), m.test_users, data.ui_train, data.ui_test, [10, 20], 50)
     np.testing.assert_allclose(np.mean(NDCG[0]), np.mean(N[0]), rtol=1e-6)
     np.testing.assert_allclose(np.mean(HR[1]), np.mean(H[1]), rtol=1e-6)
+
+
+@pytest.mark.parametrize("kind", ["GMF", "NeuMF"])
+def test_square_loss_matches_oracle(sess, kind):
+    """loss_func = square: get_loss(.., self.y, self.logits) = sum (y - logits)^2 (utils/tools.py:74-75), the other loss a
+    pointwise graph can train with in the reference."""
+    U, I, B, d, layers = 90, 70, 256, 16, [32, 16]
+    g = np.random.Generator(np.random.PCG64(77))
+    u, i, y = _instances(5, U, I, 2 * B + 40)
+    if kind == "GMF":
+        P, Q, h = _rand(g, U, d), _rand(g, I, d), _rand(g, d, scale=0.5)
+        st = runtime.NcfState(sess, "GMF", {"P_gmf": P, "Q_gmf": Q}, [], [], h, lr=1e-3, reg_gmf=0.01, loss_func="square")
+        om = MT.GMF(P, Q, h, lr=1e-3, reg=0.01, loss_func="square")
+        names = [(st.t["P_gmf"], "P"), (st.t["Q_gmf"], "Q"), (st.h, "h_gmf")]
+    else:
+        Pg, Qg, Pm, Qm = _rand(g, U, d), _rand(g, I, d), _rand(g, U, layers[0] // 2), _rand(g, I, layers[0] // 2)
+        Ws, bs, last = _tower(g, layers[0], len(layers))
+        h = _rand(g, d + last, scale=0.3)
+        st = runtime.NcfState(sess, "NeuMF", {"P_gmf": Pg, "Q_gmf": Qg, "P_mlp": Pm, "Q_mlp": Qm}, Ws, bs, h, lr=1e-3, reg_gmf=1e-2,
+                              reg_mlp=1e-3, loss_func="square")
+        om = MT.NeuMF(Pg, Qg, Pm, Qm, Ws, bs, h, lr=1e-3, reg1=1e-2, reg2=1e-3, loss_func="square")
+        names = [(st.t[k], k) for k in ("P_gmf", "Q_gmf", "P_mlp", "Q_mlp")] + [(st.h, "h_neumf")]
+        names += [(st.W[k], "W_%d" % k) for k in range(len(layers))] + [(st.b[k], "b_%d" % k) for k in range(len(layers))]
+    loss = st.train_epoch(sess.to_dev(u), sess.to_dev(i), sess.to_dev(y), B).cpu().numpy()
+    ol = [om.step(u[b * B:(b + 1) * B], i[b * B:(b + 1) * B], y[b * B:(b + 1) * B]) for b in range(len(loss))]
+    np.testing.assert_allclose(loss, ol, rtol=1e-5)
+    _compare(st, om, names)
