@@ -200,14 +200,125 @@ __device__ __forceinline__ void rows_apply_row(const crec_rows_table &t, const i
     st4_stream(t.v + ro, v);
 }
 
+// The same update with the wave's G = 64/LPR lane groups SIDE BY SIDE, one table row each (rows r0 .. r0+G-1): every
+// lane does Adam arithmetic and a wave moves G rows per round trip instead of one -- the sweep over a table is bound by
+// rounds of waves times a wave's chain of round trips, not by bytes.  A group adds its row's slots in ascending slot
+// order, four contribution rows in flight.  A wave that holds a row with more than SIDE_MAX slots (popular items) takes
+// its rows one after the other in the whole-wave form above instead, where the groups share a row's slots.
+constexpr int SIDE_MAX = 12;
+template <int LPR>
+__device__ __forceinline__ void rows_apply_side(const crec_rows_table &t, const int2 *__restrict__ rowseg,
+                                                const int32_t *__restrict__ order, const float *__restrict__ contrib,
+                                                const float *__restrict__ dense_grad, float *__restrict__ row_out,
+                                                const crec_rows_opt &o, int64_t r0, int chunks)
+{
+    constexpr int G = 64 / LPR;
+    const int lane = threadIdx.x & 63, g = lane / LPR, l = lane % LPR;
+    const int64_t r = r0 + g;
+    const bool valid = r < t.rows;
+    int cnt = 0;
+    if (valid)
+        for (int ch = 0; ch < chunks; ++ch)
+            cnt += rowseg[(int64_t)ch * t.rows + r].y;
+    int wmax = cnt;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int other = __shfl_xor(wmax, off, 64);
+        wmax = other > wmax ? other : wmax;
+    }
+    if (G == 1 || wmax > SIDE_MAX) { // wave-uniform
+        for (int k = 0; k < G; ++k)
+            rows_apply_row<LPR>(t, rowseg, order, contrib, dense_grad, row_out, o, r0 + k, chunks);
+        return;
+    }
+    const int d = t.d;
+    const bool act = valid && 4 * l < d;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cnt == 0 && o.kind == ROWS_SPARSE_LAZY)
+        return;
+    const int64_t ro = r * d + 4 * l;
+    const float4 var = act ? ld4(t.var + ro) : zero;
+    float4 m = act ? ld4(t.m + ro) : zero, v = act ? ld4(t.v + ro) : zero;
+    float4 acc = zero;
+    if (act) {
+        for (int ch = 0; ch < chunks; ++ch) { // chunk by chunk = ascending slot order
+            const int2 rs = rowseg[(int64_t)ch * t.rows + r];
+            for (int k = rs.x; k < rs.x + rs.y; k += 4) {
+                float4 c[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    c[e] = k + e < rs.x + rs.y ? ld4(contrib + (int64_t)order[k + e] * d + 4 * l) : zero;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (k + e < rs.x + rs.y) {
+                        acc.x = acc.x + (c[e].x + o.reg_occ * var.x);
+                        acc.y = acc.y + (c[e].y + o.reg_occ * var.y);
+                        acc.z = acc.z + (c[e].z + o.reg_occ * var.z);
+                        acc.w = acc.w + (c[e].w + o.reg_occ * var.w);
+                    }
+            }
+        }
+    }
+    float4 dg = zero;
+    if (o.cov_coef != 0.f) { // CML covariance term, see rows_apply_row
+        float4 xc = zero;
+        if (act) {
+            const float4 mu = ld4(dense_grad + 4 * l);
+            xc = make_float4(var.x - mu.x, var.y - mu.y, var.z - mu.z, var.w - mu.w);
+        }
+        float sr = (xc.x + xc.y) + (xc.z + xc.w), sq = (xc.x * xc.x + xc.y * xc.y) + (xc.z * xc.z + xc.w * xc.w);
+#pragma unroll
+        for (int off = LPR >> 1; off > 0; off >>= 1) {
+            sr += __shfl_xor(sr, off, 64);
+            sq += __shfl_xor(sq, off, 64);
+        }
+        dg = make_float4(o.cov_coef * (sr - xc.x), o.cov_coef * (sr - xc.y), o.cov_coef * (sr - xc.z), o.cov_coef * (sr - xc.w));
+        if (row_out && valid && l == 0)
+            row_out[r] = sr * sr - sq;
+    } else if (dense_grad && act) {
+        dg = ld4(dense_grad + ro);
+    }
+    if (o.row_norm) {
+        float sq = (var.x * var.x + var.y * var.y) + (var.z * var.z + var.w * var.w);
+#pragma unroll
+        for (int off = LPR >> 1; off > 0; off >>= 1)
+            sq += __shfl_xor(sq, off, 64);
+        if (row_out && valid && l == 0)
+            row_out[r] = sq;
+    }
+    if (!act)
+        return;
+    float4 nv = var;
+    const float omb1 = 1.0f - o.beta1, omb2 = 1.0f - o.beta2;
+    const auto upd = [&](float g_, float d_, float var_, float &m_, float &v_, float &n_) {
+        if (o.kind == ROWS_DENSE) {
+            const float gg = (g_ + d_) + o.dense_reg * var_;
+            m_ = m_ + (gg - m_) * omb1;
+            v_ = v_ + (gg * gg - v_) * omb2;
+            n_ = var_ - (m_ * o.lr_t) / (sqrtf(v_) + o.eps);
+        } else {
+            m_ = m_ * o.beta1 + g_ * omb1;
+            v_ = v_ * o.beta2 + (g_ * g_) * omb2;
+            n_ = var_ - (o.lr_t * m_) / (sqrtf(v_) + o.eps);
+        }
+    };
+    upd(acc.x, dg.x, var.x, m.x, v.x, nv.x);
+    upd(acc.y, dg.y, var.y, m.y, v.y, nv.y);
+    upd(acc.z, dg.z, var.z, m.z, v.z, nv.z);
+    upd(acc.w, dg.w, var.w, m.w, v.w, nv.w);
+    st4_stream(t.var + ro, nv);
+    st4_stream(t.m + ro, m);
+    st4_stream(t.v + ro, v);
+}
+
 template <int LPR>
 __global__ __launch_bounds__(256) void rows_apply(crec_rows_table t, const int2 *__restrict__ rowseg,
                                                   const int32_t *__restrict__ order, const float *__restrict__ contrib,
                                                   const float *__restrict__ dense_grad, float *__restrict__ row_out,
                                                   crec_rows_opt o, int chunks)
 {
-    rows_apply_row<LPR>(t, rowseg, order, contrib, dense_grad, row_out, o,
-                        (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), chunks);
+    rows_apply_side<LPR>(t, rowseg, order, contrib, dense_grad, row_out, o,
+                         ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (64 / LPR), chunks);
 }
 
 // dense ApplyAdam of a small parameter vector (h, W_k, b_k, w0) from partial sums:
@@ -299,8 +410,8 @@ template <int LPR> __global__ __launch_bounds__(256) void apply_all(crec_apply_s
         }
     if (k < a.n_tables) {
         const crec_rows_job &j = a.tables[k];
-        rows_apply_row<LPR>(j.t, j.rowseg, j.order, j.contrib, j.dense_grad, j.row_out, j.o,
-                            (int64_t)(bi - first) * 4 + (threadIdx.x >> 6), j.chunks > 1 ? j.chunks : 1);
+        rows_apply_side<LPR>(j.t, j.rowseg, j.order, j.contrib, j.dense_grad, j.row_out, j.o,
+                             ((int64_t)(bi - first) * 4 + (threadIdx.x >> 6)) * (64 / LPR), j.chunks > 1 ? j.chunks : 1);
     } else if (bi < a.scalar_end) {
         scalar_rows_block(a.scalar, bi - first);
     } else {
@@ -348,7 +459,7 @@ int crec_rows_apply(crec_ctx *ctx, const crec_rows_table &t, const crec_rows_ind
         lpr <<= 1;
     const int2 *rs = ix.rowseg + batch * ix.chunks * ix.rows;
     const int32_t *ord = ix.order + batch * ix.per_batch;
-    const dim3 grid((unsigned)crec_ceil_div(t.rows, 4)), block(256);
+    const dim3 grid((unsigned)crec_ceil_div(t.rows, 4 * (64 / lpr))), block(256); // a wave owns 64 / lpr rows
     crec_prof_begin(ctx, CREC_K_ROWS_APPLY, st);
 #define CREC_RA(L)                                                                                   \
     case L:                                                                                          \
@@ -388,7 +499,7 @@ int crec_apply_all(crec_ctx *ctx, crec_apply_set &a, hipStream_t st)
             l <<= 1;
         CREC_REQUIRE(ctx, lpr == 0 || l == lpr, "apply set: tables of one launch must share the row width class");
         lpr = l;
-        blocks += (int)crec_ceil_div(a.tables[k].t.rows, 4);
+        blocks += (int)crec_ceil_div(a.tables[k].t.rows, 4 * (64 / l)); // a wave owns 64 / l rows (rows_apply_side)
         a.block_end[k] = blocks;
     }
     if (a.scalar.rows > 0)

@@ -78,7 +78,7 @@ class BprState:
         n = int(u.numel())
         nb = -(-n // batch_size)
         loss = s.empty((nb,), torch.float32)
-        if self.deferred is not None:
+        if getattr(self, 'deferred', None) is not None:
             s.ctx.check(s.lib.crec_bpr_train_epoch_deferred(s.ctx.h, C.byref(self.tables), C.byref(self.deferred), C.byref(self.adam),
                                                             s.ptr(u), s.ptr(i), s.ptr(j), n, int(batch_size), s.ptr(loss), s.stream_ptr()))
             return loss
@@ -89,7 +89,7 @@ class BprState:
     def flush(self):
         """adam_mode 'deferred': replay the steps every row sat out (crec_bpr_adam_flush) -- before evaluating, saving or
         reading the tables.  A no-op in the other modes."""
-        if self.deferred is not None:
+        if getattr(self, 'deferred', None) is not None:
             s = self.sess
             s.ctx.check(s.lib.crec_bpr_adam_flush(s.ctx.h, C.byref(self.tables), C.byref(self.deferred), C.byref(self.adam), s.stream_ptr()))
 
