@@ -206,6 +206,9 @@ __device__ __forceinline__ void rows_apply_row(const crec_rows_table &t, const i
 // order, four contribution rows in flight.  A wave that holds a row with more than SIDE_MAX slots (popular items) takes
 // its rows one after the other in the whole-wave form above instead, where the groups share a row's slots.
 constexpr int SIDE_MAX = 12;
+// measured (tools/bench_models.py): side by side wins at d = 32 (FM C4: 19.2 -> 16.7 us/step, eight rows per wave) and
+// loses 3-10 % at d = 64 / 128 (NeuMF C3, GMF, CML: four / two rows per wave), where a wave per row stays
+constexpr int rows_per_wave(int lpr) { return lpr <= 8 ? 64 / lpr : 1; }
 template <int LPR>
 __device__ __forceinline__ void rows_apply_side(const crec_rows_table &t, const int2 *__restrict__ rowseg,
                                                 const int32_t *__restrict__ order, const float *__restrict__ contrib,
@@ -317,8 +320,11 @@ __global__ __launch_bounds__(256) void rows_apply(crec_rows_table t, const int2 
                                                   const float *__restrict__ dense_grad, float *__restrict__ row_out,
                                                   crec_rows_opt o, int chunks)
 {
-    rows_apply_side<LPR>(t, rowseg, order, contrib, dense_grad, row_out, o,
-                         ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (64 / LPR), chunks);
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (rows_per_wave(LPR) > 1)
+        rows_apply_side<LPR>(t, rowseg, order, contrib, dense_grad, row_out, o, wave * (64 / LPR), chunks);
+    else
+        rows_apply_row<LPR>(t, rowseg, order, contrib, dense_grad, row_out, o, wave, chunks);
 }
 
 // dense ApplyAdam of a small parameter vector (h, W_k, b_k, w0) from partial sums:
@@ -410,8 +416,12 @@ template <int LPR> __global__ __launch_bounds__(256) void apply_all(crec_apply_s
         }
     if (k < a.n_tables) {
         const crec_rows_job &j = a.tables[k];
-        rows_apply_side<LPR>(j.t, j.rowseg, j.order, j.contrib, j.dense_grad, j.row_out, j.o,
-                             ((int64_t)(bi - first) * 4 + (threadIdx.x >> 6)) * (64 / LPR), j.chunks > 1 ? j.chunks : 1);
+        const int64_t wave = (int64_t)(bi - first) * 4 + (threadIdx.x >> 6);
+        if (rows_per_wave(LPR) > 1)
+            rows_apply_side<LPR>(j.t, j.rowseg, j.order, j.contrib, j.dense_grad, j.row_out, j.o, wave * (64 / LPR),
+                                 j.chunks > 1 ? j.chunks : 1);
+        else
+            rows_apply_row<LPR>(j.t, j.rowseg, j.order, j.contrib, j.dense_grad, j.row_out, j.o, wave, j.chunks > 1 ? j.chunks : 1);
     } else if (bi < a.scalar_end) {
         scalar_rows_block(a.scalar, bi - first);
     } else {
@@ -459,7 +469,7 @@ int crec_rows_apply(crec_ctx *ctx, const crec_rows_table &t, const crec_rows_ind
         lpr <<= 1;
     const int2 *rs = ix.rowseg + batch * ix.chunks * ix.rows;
     const int32_t *ord = ix.order + batch * ix.per_batch;
-    const dim3 grid((unsigned)crec_ceil_div(t.rows, 4 * (64 / lpr))), block(256); // a wave owns 64 / lpr rows
+    const dim3 grid((unsigned)crec_ceil_div(t.rows, 4 * rows_per_wave(lpr))), block(256);
     crec_prof_begin(ctx, CREC_K_ROWS_APPLY, st);
 #define CREC_RA(L)                                                                                   \
     case L:                                                                                          \
@@ -499,7 +509,7 @@ int crec_apply_all(crec_ctx *ctx, crec_apply_set &a, hipStream_t st)
             l <<= 1;
         CREC_REQUIRE(ctx, lpr == 0 || l == lpr, "apply set: tables of one launch must share the row width class");
         lpr = l;
-        blocks += (int)crec_ceil_div(a.tables[k].t.rows, 4 * (64 / l)); // a wave owns 64 / l rows (rows_apply_side)
+        blocks += (int)crec_ceil_div(a.tables[k].t.rows, 4 * rows_per_wave(l));
         a.block_end[k] = blocks;
     }
     if (a.scalar.rows > 0)
