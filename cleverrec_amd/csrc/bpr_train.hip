@@ -103,8 +103,9 @@ __device__ __forceinline__ void crec_mark(int slot, int dep) // the time at whic
 #endif
 #define CREC_LAZY_WAVES(MODE) ((MODE) == 2 ? CREC_LAZY_ITEM_WAVES : 4)
 #ifndef CREC_LAZY_DEEP
-#define CREC_LAZY_DEEP 11 // contribution / partial rows in flight in a finisher's sum: 126 VGPRs, four waves per SIMD (12: 132 VGPRs,
-                          // three; measured 8 / 11 / 12 / 16 x CH 16 / 24 / 32 on S-big: all within 2 %, tools/lazy_variants.sh)
+#define CREC_LAZY_DEEP 8 // contribution / partial rows in flight in a finisher's sum.  The d = 128 workgroup is 1024 threads, i.e. a
+                         // hard limit of 128 VGPRs: 11 in flight spill three registers; 8 / 11 / 12 / 16 measured within 2 % of each other
+                         // (tools/lazy_variants.sh)
 #endif
 #ifndef CREC_FUSED_WT
 #define CREC_FUSED_WT 0 // 1: the launch-per-step tf1 kernel writes its tables with write-through (sc1) stores
@@ -129,7 +130,9 @@ struct IndexWs {
     // lazy mode: the order in which the triple pass takes the batch positions -- triples of heavy item rows first, then
     // those of other multi-occurrence item rows, then the rest: a multi-occurrence row is finished by its LAST
     // contributor, and a heavy row's finish is a chain of dependent round trips that should not start at the very end
-    int32_t *order;                 // [nbc][B]
+    int32_t *order;                 // [nbc][3B] batch position per processing slot, -1 = padding
+    int32_t *nslots;                // [nbc][2]  {processing slots of the batch, of which the heavy rows' blocks}
+    int32_t spw;                    // processing slots per workgroup of the triple pass (a heavy row's blocks are aligned to it)
     int4 *u_hrows, *q_hrows;   // [nbc][HRu|HRq]  {row, first chunk, chunks<<16 | length, rank among unique rows}
     int4 *u_hitems, *q_hitems; // [nbc][HIu|HIq]  {row, segment start, length | heavy row index << 8, chunk index}
     int64_t B, U, I, HRu, HRq, HIu, HIq;
@@ -156,8 +159,12 @@ inline int row_bits(int64_t n_rows)
     return b;
 }
 
+// processing slots per workgroup of bpr_triples_lazy: 32 lane groups; 64 at d = 4, where a group is one lane; 16 above
+// d = 128, where a group is a whole wave (a workgroup has at most 1024 threads)
+inline int lazy_spw(int d) { return d <= 4 ? 64 : (d > 128 ? 16 : 32); }
+
 IndexWs layout_index(void *base, int64_t nbc, int64_t B, int64_t U, int64_t I, bool dense, int CH, int wide_rows = 0,
-                     int wide_total = 0)
+                     int wide_total = 0, int spw = 32)
 {
     IndexWs w{};
     w.B = B;
@@ -195,7 +202,9 @@ IndexWs layout_index(void *base, int64_t nbc, int64_t B, int64_t U, int64_t I, b
     w.u_desc = (int4 *)take(sizeof(int4) * nbc * (dense ? 0 : B));
     w.i_desc = (int4 *)take(sizeof(int4) * nbc * (dense ? 0 : B));
     w.j_desc = (int4 *)take(sizeof(int4) * nbc * (dense ? 0 : B));
-    w.order = (int32_t *)take(sizeof(int32_t) * nbc * (dense ? 0 : B));
+    w.order = (int32_t *)take(sizeof(int32_t) * nbc * (dense ? 0 : 3 * B));
+    w.nslots = (int32_t *)take(sizeof(int32_t) * nbc * (dense ? 0 : 2));
+    w.spw = spw;
     w.wide_rows = dense && wide_total > 0 ? wide_rows : 0;
     w.wide_total = wide_total;
     w.WMu = w.wide_rows ? B / (wide_total + 1) + 1 : 0;
@@ -269,52 +278,113 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
         seg[total] = (uint16_t)n;
     __syncthreads();
 
-    if ((side ? w.I : w.U) == 0) { // lazy mode: the triple pass needs, per batch position and role, where the slot and its
-        int r = rank_first;        // row sit in the sorted order -- and the order to take the positions in
-        uint16_t *wt = (uint16_t *)hist; // [B] occurrences of the triple's busier item row (the sort's counters are free by now)
+    if ((side ? w.I : w.U) == 0) {
+        // lazy mode.  The triple pass (bpr_triples_lazy) needs, per batch position and role, where the slot and its row
+        // sit in the sorted order, and the order to take the positions in.  Item rows with more than CH positive slots
+        // ("heavy-aligned") get whole workgroups of the pass: their i-slot triples are laid out in sorted order in blocks of
+        // SPW processing slots, a row's first block on a block boundary, so that a workgroup holds slots of ONE such row
+        // and can add their contributions in LDS -- one partial per workgroup instead of one contribution row per slot.
+        uint16_t *wt = (uint16_t *)hist; // [B] per position: 0xffff = laid out in a heavy block, else the busier item row's count
+        const int SPW = w.spw;
+        int32_t *ord = w.order + (int64_t)batch * 3 * B;
+        int nhp = 0; // processing slots taken by the heavy rows' blocks
+        if (side == 1) {
+            const int rper = (total + PREP_THREADS - 1) / PREP_THREADS;
+            const int q0 = tid * rper, q1 = (q0 + rper) < total ? (q0 + rper) : total;
+            // a run's i-slots come first (stable sort, i-slices before j-slices): their number by binary search on the slot ids
+            const auto i_slots = [&](int start, int cnt) {
+                int lo = 0, hi = cnt;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if ((int)tag[start + mid] < nb)
+                        lo = mid + 1;
+                    else
+                        hi = mid;
+                }
+                return lo;
+            };
+            int mine = 0;
+            for (int q = q0; q < q1; ++q) {
+                const int start = seg[q], cnt = (int)seg[q + 1] - start;
+                if (cnt > CH) {
+                    const int ci = i_slots(start, cnt);
+                    if (ci > CH)
+                        mine += (ci + SPW - 1) / SPW * SPW;
+                }
+            }
+            int at = crec_sort::block_excl_scan<PREP_THREADS>(mine, scan, &nhp);
+            for (int q = q0; q < q1; ++q) {
+                const int start = seg[q], cnt = (int)seg[q + 1] - start;
+                if (cnt > CH) {
+                    const int ci = i_slots(start, cnt);
+                    if (ci > CH) { // the run's row id stays in rows[start]; the next two entries carry the layout
+                        const int span = (ci + SPW - 1) / SPW * SPW;
+                        rows[start + 1] = 0x80000000u | (uint32_t)at;
+                        rows[start + 2] = (uint32_t)ci;
+                        for (int e = ci; e < span; ++e)
+                            ord[at + e] = -1; // the tail of the row's last block
+                        at += span;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        int ri = rank_first - 1; // index of the run that holds position k
         for (int k = k0; k < k1; ++k) {
-            if (k == 0 || rows[k] != rows[k - 1])
-                ++r;
-            const int start = seg[r - 1], cnt = (int)seg[r] - start;
+            if (k == (int)seg[ri + 1])
+                ++ri;
+            const int start = seg[ri], cnt = (int)seg[ri + 1] - start;
+            const bool aligned = side == 1 && cnt > CH && (rows[start + 1] & 0x80000000u);
+            const int ci = aligned ? (int)rows[start + 2] : 0;
             const int slot = tag[k];
             int4 *dst = side == 0 ? w.u_desc : (slot < nb ? w.i_desc : w.j_desc);
             dst[(int64_t)batch * B + (slot < nb ? slot : slot - nb)] =
-                make_int4((int)(rows[k] | (cnt == 1 ? 0x80000000u : 0u)), k, start, cnt);
-            if (side == 1 && slot < nb)
-                wt[slot] = (uint16_t)(cnt > 0xffff ? 0xffff : cnt);
+                make_int4((int)(rows[start] | (cnt == 1 ? 0x80000000u : 0u)), k, start, cnt | (ci << 16));
+            if (side == 1 && slot < nb) {
+                if (aligned) { // (k - start < ci: an i-slot of a heavy-aligned row)
+                    ord[(int)(rows[start + 1] & 0x7fffffffu) + (k - start)] = slot;
+                    wt[slot] = 0xffff;
+                } else {
+                    wt[slot] = (uint16_t)(cnt > 0xfffe ? 0xfffe : cnt);
+                }
+            }
         }
         if (side == 0)
             return;
         __syncthreads();
-        r = rank_first;
+        ri = rank_first - 1;
         for (int k = k0; k < k1; ++k) { // every position has one i-slot (above) and one j-slot (here): no two writers
-            if (k == 0 || rows[k] != rows[k - 1])
-                ++r;
-            const int cnt = (int)seg[r] - (int)seg[r - 1], slot = tag[k];
-            if (slot >= nb && cnt > (int)wt[slot - nb])
-                wt[slot - nb] = (uint16_t)(cnt > 0xffff ? 0xffff : cnt);
+            if (k == (int)seg[ri + 1])
+                ++ri;
+            const int cnt = (int)seg[ri + 1] - (int)seg[ri], slot = tag[k];
+            if (slot >= nb && wt[slot - nb] != 0xffff && cnt > (int)wt[slot - nb])
+                wt[slot - nb] = (uint16_t)(cnt > 0xfffe ? 0xfffe : cnt);
         }
         __syncthreads();
-        // stable three-way partition of the positions: heavy (> CH), multi (2..CH), single
+        // behind the heavy blocks: the positions whose items occur more than once (their rows are finished by their LAST
+        // contributor: the sooner they start the better), then the rest -- a stable partition
         const int pper = (nb + PREP_THREADS - 1) / PREP_THREADS;
         const int p0 = tid * pper, p1 = (p0 + pper) < nb ? (p0 + pper) : nb;
-        int n_heavy = 0, n_multi = 0;
+        int n_blk = 0, n_multi = 0;
         for (int q = p0; q < p1; ++q) {
-            n_heavy += wt[q] > CH ? 1 : 0;
-            n_multi += (wt[q] >= 2 && wt[q] <= CH) ? 1 : 0;
+            n_blk += wt[q] == 0xffff ? 1 : 0;
+            n_multi += (wt[q] != 0xffff && wt[q] >= 2) ? 1 : 0;
         }
         int tot_pack = 0;
-        const int before = crec_sort::block_excl_scan<PREP_THREADS>((n_heavy << 16) | n_multi, scan, &tot_pack);
-        const int tot_heavy = tot_pack >> 16, tot_multi = tot_pack & 0xffff;
-        int at_h = before >> 16, at_m = tot_heavy + (before & 0xffff), at_s = tot_heavy + tot_multi + (p0 - (before >> 16) - (before & 0xffff));
-        int32_t *ord = w.order + (int64_t)batch * B;
+        const int before = crec_sort::block_excl_scan<PREP_THREADS>((n_blk << 16) | n_multi, scan, &tot_pack);
+        const int tot_blk = tot_pack >> 16, tot_multi = tot_pack & 0xffff;
+        int at_m = nhp + (before & 0xffff), at_s = nhp + tot_multi + (p0 - (before >> 16) - (before & 0xffff));
         for (int q = p0; q < p1; ++q) {
-            if (wt[q] > CH)
-                ord[at_h++] = q;
-            else if (wt[q] >= 2)
+            if (wt[q] == 0xffff)
+                continue;
+            if (wt[q] >= 2)
                 ord[at_m++] = q;
             else
                 ord[at_s++] = q;
+        }
+        if (tid == 0) {
+            w.nslots[batch * 2 + 0] = nhp + (nb - tot_blk);
+            w.nslots[batch * 2 + 1] = nhp;
         }
         return;
     }
@@ -1415,76 +1485,44 @@ __device__ __forceinline__ float4 lazy_sum_rows(const float *base, int n, int64_
     return g;
 }
 
-// Where a slot's ticket counter lives and how many tickets complete it: the row's own counter for a light row (<= CH
-// slots), the counter of the slot's chunk for a heavy row.
+// A slot's ticket: which counter it is drawn on, what the slot weighs and at which total the counter is complete.
+//   heavy-aligned item row (ci > 0: more than CH positive slots, laid out in workgroup blocks by the index kernel): the
+//     row's counter; a block's leader weighs the block's slots, a negative slot weighs one; complete at cnt
+//   light row (cnt <= CH): the row's counter, one per slot, complete at cnt
+//   other rows (user rows with more than CH slots, item rows whose slots are mostly negatives): the counter of the slot's
+//     chunk of CH slots, complete at the chunk's length; the chunk's finisher then draws on the row's counter, one per chunk
 struct LazyTicket {
     int idx, need;
-    bool light;
+    bool chunked;
 };
 __device__ __forceinline__ LazyTicket lazy_ticket_of(int4 desc, int CH)
 {
-    const int k = desc.y, start = desc.z, cnt = desc.w;
+    const int k = desc.y, start = desc.z, cnt = desc.w & 0xffff, ci = desc.w >> 16;
     LazyTicket q;
-    q.light = cnt <= CH;
-    q.idx = q.light ? start : start + (k - start) / CH * CH;
-    q.need = q.light ? cnt : ((cnt - (q.idx - start)) < CH ? (cnt - (q.idx - start)) : CH);
+    q.chunked = ci == 0 && cnt > CH;
+    q.idx = q.chunked ? start + (k - start) / CH * CH : start;
+    q.need = q.chunked ? ((cnt - (q.idx - start)) < CH ? (cnt - (q.idx - start)) : CH) : cnt;
     return q;
 }
 
-// One multi-occurrence row of this group's triple.  The group has published its contribution row, waited for the
-// store, and drawn ticket `tk` on the row's (chunk's) counter.  The last contributor of the row -- of the chunk first,
-// for a heavy row -- forms the sum in sorted order and finishes the row.  Every lane of the group takes the same path.
+// the end of a multi-occurrence row: gradient sum g (l2 terms included) -> the optimizer's update in place; the row-sharded
+// step sends an item row's sum back to its owner instead; deferred Adam first replays the steps the row sat out
 template <int LPR, bool USER, bool DEFER>
-__device__ __forceinline__ void lazy_role_tail(const Tables &t, int d, bool act, int4 desc, int tk, float4 own, float *cbuf,
-                                               float *pbuf, int32_t *row_t, int32_t *chk_t, int CH, const Hyper &h)
+__device__ __forceinline__ void lazy_finish_row(const Tables &t, int d, bool act, int row, float4 own, float4 g, float4 m, float4 v,
+                                                const Hyper &h)
 {
-    const int lane = threadIdx.x & 63, l = lane % LPR, lead = lane - l;
-    const int start = desc.z, cnt = desc.w;
-    const LazyTicket q = lazy_ticket_of(desc, CH);
-    if (tk != q.need - 1)
-        return;
-    const int idx = q.idx, need = q.need;
-    const bool light = q.light;
-    int32_t *ctr = (light ? row_t : chk_t) + idx;
-    asm volatile("" ::: "memory");
-    const int64_t ro = (int64_t)(desc.x & 0x7fffffff) * d + 4 * l;
-    const bool slots = act && (USER || !h.dQ);
-    // the slots are only needed at the very end: asked for now, their round trip hides behind the contributions'
-    float4 m = slots && h.opt != CREC_OPT_SGD ? ld4((USER ? t.mP : t.mQ) + ro) : make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 v = slots && h.opt == 0 ? ld4((USER ? t.vP : t.vQ) + ro) : make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 regrow = make_float4(h.reg * own.x, h.reg * own.y, h.reg * own.z, h.reg * own.w);
-    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (act)
-        g = lazy_sum_rows(cbuf + (int64_t)idx * d + 4 * l, need, d, regrow);
-    if (l == 0)
-        __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next launch
-    if (!light) { // a chunk of a heavy row: publish the partial, then the same game over the row's chunks
-        if (act)
-            st4_agent(pbuf + (int64_t)idx * d + 4 * l, g);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const int parts = (cnt + CH - 1) / CH;
-        int t2 = -1;
-        if (l == 0)
-            t2 = __hip_atomic_fetch_add(row_t + start, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        t2 = __shfl(t2, lead, 64);
-        if (t2 != parts - 1)
-            return;
-        asm volatile("" ::: "memory");
-        if (act)
-            g = lazy_sum_rows(pbuf + (int64_t)start * d + 4 * l, parts, (int64_t)CH * d, make_float4(0.f, 0.f, 0.f, 0.f));
-        if (l == 0)
-            __hip_atomic_store(row_t + start, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    const int l = (threadIdx.x & 63) % LPR;
     if (!act)
         return;
-    if (!USER && h.dQ) { // row-sharded step: the item row's gradient sum goes back to its owner
+    const int64_t ro = (int64_t)row * d + 4 * l;
+    if (!USER && h.dQ) {
         st4(h.dQ + ro, g);
         return;
     }
     float4 nv = own; // deferred mode: `own` is the contributor's caught-up copy of the row; m, v as stored are replayed here
     if (DEFER) {
         float4 scratch = ld4((USER ? t.P : t.Q) + ro);
-        int32_t *last = (USER ? h.lastP : h.lastQ) + (desc.x & 0x7fffffff);
+        int32_t *last = (USER ? h.lastP : h.lastQ) + row;
         adam_replay(scratch, m, v, *last, h.step - 1, h);
         if (l == 0)
             *last = h.step;
@@ -1497,18 +1535,85 @@ __device__ __forceinline__ void lazy_role_tail(const Tables &t, int d, bool act,
         st4((USER ? t.vP : t.vQ) + ro, v);
 }
 
-// bpr_triples_lazy: a lane group per triple; ud / id / jd: the triple's three roles by batch position (IndexWs).
-template <int LPR, bool FULL, bool DEFER>
-__global__ __launch_bounds__(256) void bpr_triples_lazy(Tables t, int d, const int32_t *__restrict__ order,
-                                                        const int4 *__restrict__ ud, const int4 *__restrict__ id,
-                                                        const int4 *__restrict__ jd, int nb, LazyBufs z,
-                                                        float *__restrict__ xb, float *__restrict__ l2b, Hyper h)
+// One multi-occurrence row of this group's triple.  The group has published its contribution (or, as the leader of a heavy
+// block, the block's partial sum) at its slot's sorted position, waited for the store, and drawn a ticket: `old` = the
+// counter before, `weight` = what it added.  Whoever completes the counter forms the row's (chunk's) sum in sorted order
+// and finishes the row.  Every lane of the group takes the same path; nobody waits for anybody.
+template <int LPR, bool USER, bool DEFER>
+__device__ __forceinline__ void lazy_role_tail(const Tables &t, int d, bool act, int4 desc, int old, int weight, float4 own,
+                                               float *cbuf, float *pbuf, int32_t *row_t, int32_t *chk_t, int CH, int SPW,
+                                               const Hyper &h)
 {
-    constexpr int G = 64 / LPR;
-    const int lane = threadIdx.x & 63, g = lane / LPR, l = lane % LPR;
-    const int slot = (int)((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * G + g);
-    const bool valid = slot < nb, act = FULL || 4 * l < d, on = valid && act;
-    const int pos = valid ? order[slot] : 0; // heavy rows' triples first (IndexWs::order)
+    const int lane = threadIdx.x & 63, l = lane % LPR, lead = lane - l;
+    const int start = desc.z, cnt = desc.w & 0xffff, ci = desc.w >> 16;
+    const LazyTicket q = lazy_ticket_of(desc, CH);
+    if (old + weight != q.need)
+        return;
+    asm volatile("" ::: "memory");
+    const int row = desc.x & 0x7fffffff;
+    const int64_t ro = (int64_t)row * d + 4 * l;
+    const bool slots = act && (USER || !h.dQ);
+    // the slots are only needed at the very end: asked for now, their round trip hides behind the contributions'
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 m = slots && h.opt != CREC_OPT_SGD ? ld4((USER ? t.mP : t.mQ) + ro) : zero;
+    float4 v = slots && h.opt == 0 ? ld4((USER ? t.vP : t.vQ) + ro) : zero;
+    const float4 regrow = make_float4(h.reg * own.x, h.reg * own.y, h.reg * own.z, h.reg * own.w);
+    int32_t *ctr = (q.chunked ? chk_t : row_t) + q.idx;
+    float4 g = zero;
+    if (ci > 0) { // heavy-aligned: one partial per block of the row's positive slots (l2 terms inside), then its negative slots
+        if (act) {
+            g = lazy_sum_rows(cbuf + (int64_t)start * d + 4 * l, (ci + SPW - 1) / SPW, (int64_t)SPW * d, zero);
+            add4(g, lazy_sum_rows(cbuf + (int64_t)(start + ci) * d + 4 * l, cnt - ci, d, regrow));
+        }
+    } else if (act) {
+        g = lazy_sum_rows(cbuf + (int64_t)q.idx * d + 4 * l, q.need, d, regrow);
+    }
+    if (l == 0)
+        __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next launch
+    if (q.chunked) { // a chunk of a chunked row: publish the partial, then the same game over the row's chunks
+        if (act)
+            st4_agent(pbuf + (int64_t)q.idx * d + 4 * l, g);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int parts = (cnt + CH - 1) / CH;
+        int t2 = -1;
+        if (l == 0)
+            t2 = __hip_atomic_fetch_add(row_t + start, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t2 = __shfl(t2, lead, 64);
+        if (t2 != parts - 1)
+            return;
+        asm volatile("" ::: "memory");
+        if (act)
+            g = lazy_sum_rows(pbuf + (int64_t)start * d + 4 * l, parts, (int64_t)CH * d, zero);
+        if (l == 0)
+            __hip_atomic_store(row_t + start, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    lazy_finish_row<LPR, USER, DEFER>(t, d, act, row, own, g, m, v, h);
+}
+
+// bpr_triples_lazy: a lane group per processing slot; a workgroup = SPW slots (IndexWs::order, ::nslots); ud / id / jd: the
+// triples' three roles by batch position.
+template <int LPR> struct LazyGeo {
+    static constexpr int SPW = LPR == 1 ? 64 : (LPR == 64 ? 16 : 32), THREADS = SPW * LPR; // = lazy_spw(d)
+};
+
+template <int LPR, bool FULL, bool DEFER>
+__global__ __launch_bounds__(LazyGeo<LPR>::THREADS) void bpr_triples_lazy(Tables t, int d, const int32_t *__restrict__ order,
+                                                                          const int32_t *__restrict__ nslots,
+                                                                          const int4 *__restrict__ ud, const int4 *__restrict__ id,
+                                                                          const int4 *__restrict__ jd, LazyBufs z,
+                                                                          float *__restrict__ xb, float *__restrict__ l2b, Hyper h)
+{
+    constexpr int SPW = LazyGeo<LPR>::SPW;
+    extern __shared__ float4 blk_rows[]; // [SPW][LPR], heavy blocks only
+    const int lane = threadIdx.x & 63, l = lane % LPR, gw = (int)threadIdx.x / LPR;
+    const int slot0 = (int)blockIdx.x * SPW;
+    const int n_slots = nslots[0], n_blk_slots = nslots[1];
+    if (slot0 >= n_slots)
+        return;
+    const bool heavy_block = slot0 < n_blk_slots; // workgroup-uniform: every slot here is a positive slot of ONE heavy-aligned row
+    const int slot = slot0 + gw;
+    const int pos = slot < n_slots ? order[slot] : -1;
+    const bool valid = pos >= 0, act = FULL || 4 * l < d, on = valid && act;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     const int4 none = make_int4((int)0x80000000u, 0, 0, 1); // a dead group: "single" rows, no tails
     const int4 du = valid ? ud[pos] : none, di = valid ? id[pos] : none, dj = valid ? jd[pos] : none;
@@ -1516,6 +1621,7 @@ __global__ __launch_bounds__(256) void bpr_triples_lazy(Tables t, int d, const i
     const int64_t ou = (int64_t)(du.x & 0x7fffffff) * d + 4 * l, oi = (int64_t)(di.x & 0x7fffffff) * d + 4 * l,
                   oj = (int64_t)(dj.x & 0x7fffffff) * d + 4 * l;
     const bool item_adam = h.dQ == nullptr; // the row-sharded step only emits the item rows' gradient sums
+    const bool blk_lead = heavy_block && gw == 0; // may finish the block's row on the spot: wants its slots
     float4 p = zero, qi = zero, qj = zero, mp = zero, vp = zero, mi = zero, vi = zero, mj = zero, vj = zero;
     if (on) { // every address is known: one round of loads
         p = ld4(t.P + ou);
@@ -1526,15 +1632,16 @@ __global__ __launch_bounds__(256) void bpr_triples_lazy(Tables t, int d, const i
             mp = ld4s(t.mP + ou);
         if ((us || DEFER) && has_v)
             vp = ld4s(t.vP + ou);
-        if ((is || DEFER) && item_adam && has_m)
+        if ((is || DEFER || blk_lead) && item_adam && has_m)
             mi = ld4s(t.mQ + oi);
-        if ((is || DEFER) && item_adam && has_v)
+        if ((is || DEFER || blk_lead) && item_adam && has_v)
             vi = ld4s(t.vQ + oi);
         if ((js || DEFER) && item_adam && has_m)
             mj = ld4s(t.mQ + oj);
         if ((js || DEFER) && item_adam && has_v)
             vj = ld4s(t.vQ + oj);
     }
+    float4 mi_raw = mi, vi_raw = vi; // deferred mode: a finisher replays the stored slots itself
     if (DEFER) { // the steps these rows sat out, replayed: from here on p, q_i, q_j are what TF1's tables hold after step - 1
         const int lu = valid ? h.lastP[du.x & 0x7fffffff] : h.step, li = valid ? h.lastQ[di.x & 0x7fffffff] : h.step,
                   lj = valid ? h.lastQ[dj.x & 0x7fffffff] : h.step;
@@ -1562,12 +1669,37 @@ __global__ __launch_bounds__(256) void bpr_triples_lazy(Tables t, int d, const i
     const float ns = -s;
     const float4 cu = make_float4(ns * (qi.x - qj.x), ns * (qi.y - qj.y), ns * (qi.z - qj.z), ns * (qi.w - qj.w));
     const float4 sp = make_float4(s * p.x, s * p.y, s * p.z, s * p.w), nsp = make_float4(-sp.x, -sp.y, -sp.z, -sp.w);
+
+    // 0. a heavy block: the contributions of its slots (all to the same row, l2 terms included) meet in LDS, in a fixed
+    // tree order; the block's leader group carries the sum from here on
+    float4 blk_sum = zero;
+    int blk_n = 0; // the leader's weight: positive slots of the row inside this block
+    if (heavy_block) {
+        blk_rows[gw * LPR + l] = on ? make_float4(nsp.x + h.reg * qi.x, nsp.y + h.reg * qi.y, nsp.z + h.reg * qi.z, nsp.w + h.reg * qi.w)
+                                    : zero;
+        for (int st = 1; st < SPW; st <<= 1) {
+            __syncthreads();
+            if ((gw & (2 * st - 1)) == 0 && gw + st < SPW) {
+                float4 a = blk_rows[gw * LPR + l];
+                add4(a, blk_rows[(gw + st) * LPR + l]);
+                blk_rows[gw * LPR + l] = a;
+            }
+        }
+        if (gw == 0) {
+            blk_sum = blk_rows[l];
+            const int left = (di.w >> 16) - (di.y - di.z); // positive slots from this block's first one to the row's last
+            blk_n = left < SPW ? left : SPW;
+        }
+    }
+    const int i_cnt = di.w & 0xffff;
+    const bool blk_whole = blk_lead && blk_n == i_cnt; // the row lies inside this block: no ticket, no memory round trip
     // 1. the contribution rows of the multi-occurrence roles, first: their completion is what the tickets wait for
+    const bool i_publish = !is && (!heavy_block || (blk_lead && !blk_whole)); // heavy blocks: only the leader speaks for the row
     if (on) {
         if (!us)
             st4_agent(z.ucontrib + (int64_t)du.y * d + 4 * l, cu);
-        if (!is)
-            st4_agent(z.qcontrib + (int64_t)di.y * d + 4 * l, nsp);
+        if (i_publish)
+            st4_agent(z.qcontrib + (int64_t)di.y * d + 4 * l, heavy_block ? blk_sum : nsp);
         if (!js)
             st4_agent(z.qcontrib + (int64_t)dj.y * d + 4 * l, sp);
     }
@@ -1575,18 +1707,19 @@ __global__ __launch_bounds__(256) void bpr_triples_lazy(Tables t, int d, const i
     // agent-scope stores; the wave waits for their completion first -- the same guarantee as a release fence for these
     // buffers, without writing back the whole L2 (the row loads above have long been consumed: only these stores are
     // outstanding)
-    const bool any_multi = __builtin_amdgcn_ballot_w64(!(us && is && js)) != 0; // false for the usual wave on large tables
+    const bool any_multi = __builtin_amdgcn_ballot_w64(valid && (!us || i_publish || !js)) != 0; // false for the usual wave on large tables
+    const int wi = heavy_block ? blk_n : 1;
     int tku = -1, tki = -1, tkj = -1;
     if (any_multi) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (valid && l == 0) {
             const LazyTicket qu = lazy_ticket_of(du, z.CH), qi_ = lazy_ticket_of(di, z.CH), qj_ = lazy_ticket_of(dj, z.CH);
             if (!us)
-                tku = __hip_atomic_fetch_add((qu.light ? z.urow_t : z.uchk_t) + qu.idx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (!is)
-                tki = __hip_atomic_fetch_add((qi_.light ? z.qrow_t : z.qchk_t) + qi_.idx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                tku = __hip_atomic_fetch_add((qu.chunked ? z.uchk_t : z.urow_t) + qu.idx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (i_publish)
+                tki = __hip_atomic_fetch_add((qi_.chunked ? z.qchk_t : z.qrow_t) + qi_.idx, wi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (!js)
-                tkj = __hip_atomic_fetch_add((qj_.light ? z.qrow_t : z.qchk_t) + qj_.idx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                tkj = __hip_atomic_fetch_add((qj_.chunked ? z.qchk_t : z.qrow_t) + qj_.idx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     // 3. the rows that occur once are finished here, while the tickets travel
@@ -1630,19 +1763,21 @@ __global__ __launch_bounds__(256) void bpr_triples_lazy(Tables t, int d, const i
             }
         }
     }
+    if (blk_whole && valid) // a heavy-aligned row that fits its block: finished from LDS, nothing published
+        lazy_finish_row<LPR, false, DEFER>(t, d, act, di.x & 0x7fffffff, qi, blk_sum, mi_raw, vi_raw, h);
     if (!any_multi)
         return;
-    // 4. whoever drew the last ticket of a row (chunk) finishes it
+    // 4. whoever completes a row's (chunk's) counter finishes it
     const int lead = lane - l;
     tku = __shfl(tku, lead, 64);
     tki = __shfl(tki, lead, 64);
     tkj = __shfl(tkj, lead, 64);
     if (valid && !us)
-        lazy_role_tail<LPR, true, DEFER>(t, d, act, du, tku, p, z.ucontrib, z.upart, z.urow_t, z.uchk_t, z.CH, h);
-    if (valid && !is)
-        lazy_role_tail<LPR, false, DEFER>(t, d, act, di, tki, qi, z.qcontrib, z.qpart, z.qrow_t, z.qchk_t, z.CH, h);
+        lazy_role_tail<LPR, true, DEFER>(t, d, act, du, tku, 1, p, z.ucontrib, z.upart, z.urow_t, z.uchk_t, z.CH, SPW, h);
+    if (valid && i_publish)
+        lazy_role_tail<LPR, false, DEFER>(t, d, act, di, tki, wi, qi, z.qcontrib, z.qpart, z.qrow_t, z.qchk_t, z.CH, SPW, h);
     if (valid && !js)
-        lazy_role_tail<LPR, false, DEFER>(t, d, act, dj, tkj, qj, z.qcontrib, z.qpart, z.qrow_t, z.qchk_t, z.CH, h);
+        lazy_role_tail<LPR, false, DEFER>(t, d, act, dj, tkj, 1, qj, z.qcontrib, z.qpart, z.qrow_t, z.qchk_t, z.CH, SPW, h);
 }
 
 // deferred mode: every row of a table brought up to the state after step h.step (before evaluation / a checkpoint);
@@ -1809,17 +1944,21 @@ template <int LPR, bool FULL> void launch_fused(const StepArgs &a, const IndexWs
 
 template <int LPR, bool FULL> void launch_lazy(const StepArgs &a, const IndexWs &w, int64_t b, const int32_t *hn)
 {
-    constexpr int G = 64 / LPR;
+    constexpr int SPW = LazyGeo<LPR>::SPW, THREADS = LazyGeo<LPR>::THREADS;
     (void)hn;
+    // processing slots of a batch: its triples plus the padding of the heavy rows' blocks (< 2 per triple: a heavy row has
+    // more than CH = 16+ positive slots and pads fewer than SPW); workgroups beyond the batch's count leave at once
+    const dim3 grid((unsigned)crec_ceil_div(3 * (int64_t)a.nb_cur, SPW)), block(THREADS);
+    const size_t lds = sizeof(float4) * THREADS;
     crec_prof_begin(a.ctx, CREC_K_USER_SIDE, a.st);
     if (a.h.lr_tab)
-        CREC_KLAUNCH(a.ctx, (bpr_triples_lazy<LPR, FULL, true>), dim3((unsigned)crec_ceil_div(a.nb_cur, 4 * G)), dim3(256), 0, a.st, a.cur,
-                     a.d, (const int32_t *)(w.order + b * w.B), (const int4 *)(w.u_desc + b * w.B), (const int4 *)(w.i_desc + b * w.B),
-                     (const int4 *)(w.j_desc + b * w.B), (int)a.nb_cur, a.lazy, a.xb, a.rowterm, a.h);
+        CREC_KLAUNCH(a.ctx, (bpr_triples_lazy<LPR, FULL, true>), grid, block, lds, a.st, a.cur, a.d,
+                     (const int32_t *)(w.order + b * 3 * w.B), (const int32_t *)(w.nslots + b * 2), (const int4 *)(w.u_desc + b * w.B),
+                     (const int4 *)(w.i_desc + b * w.B), (const int4 *)(w.j_desc + b * w.B), a.lazy, a.xb, a.rowterm, a.h);
     else
-        CREC_KLAUNCH(a.ctx, (bpr_triples_lazy<LPR, FULL, false>), dim3((unsigned)crec_ceil_div(a.nb_cur, 4 * G)), dim3(256), 0, a.st, a.cur,
-                     a.d, (const int32_t *)(w.order + b * w.B), (const int4 *)(w.u_desc + b * w.B), (const int4 *)(w.i_desc + b * w.B),
-                     (const int4 *)(w.j_desc + b * w.B), (int)a.nb_cur, a.lazy, a.xb, a.rowterm, a.h);
+        CREC_KLAUNCH(a.ctx, (bpr_triples_lazy<LPR, FULL, false>), grid, block, lds, a.st, a.cur, a.d,
+                     (const int32_t *)(w.order + b * 3 * w.B), (const int32_t *)(w.nslots + b * 2), (const int4 *)(w.u_desc + b * w.B),
+                     (const int4 *)(w.i_desc + b * w.B), (const int4 *)(w.j_desc + b * w.B), a.lazy, a.xb, a.rowterm, a.h);
     crec_prof_end(a.ctx, a.st);
 }
 
@@ -2064,7 +2203,7 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
     for (int64_t b0 = 0; b0 < nb; b0 += chunk) {
         const int64_t nbc = (nb - b0) < chunk ? (nb - b0) : chunk;
         const int64_t t0 = b0 * B, n_chunk = (N - t0) < nbc * B ? (N - t0) : nbc * B;
-        IndexWs w = layout_index(ctx->idx_ws.ptr, nbc, B, t->U, t->I, dense, CH, wide_rows, wide_total);
+        IndexWs w = layout_index(ctx->idx_ws.ptr, nbc, B, t->U, t->I, dense, CH, wide_rows, wide_total, lazy_spw(t->d));
         crec_prof_begin(ctx, CREC_K_INDEX, st);
         CREC_KLAUNCH(ctx, bpr_index_batches, dim3((unsigned)(2 * nbc)), dim3(PREP_THREADS), lds, st, u + t0, i + t0,
                            j + t0, n_chunk, B, cap, w);
@@ -2402,7 +2541,7 @@ int sharded_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, int64_t I_global
         hipLaunchKernelGGL(shard_owner_index, dim3((unsigned)nbc), dim3(SHARD_THREADS), shard_lds_bytes(cap_srv), st,
                            (const int32_t *)v.ids_recv, (const int64_t *)p.srv_base, (const int32_t *)p.srv_cnt, G, cap_srv,
                            cap_srv, row_bits(S), v.srv_rows, v.order, v.urows, v.useg, v.n_urows);
-        IndexWs w = layout_index(ctx->idx_ws.ptr, nbc, B, t->U, IC, false, CH);
+        IndexWs w = layout_index(ctx->idx_ws.ptr, nbc, B, t->U, IC, false, CH, 0, 0, lazy_spw(d));
         crec_prof_begin(ctx, CREC_K_INDEX, st);
         CREC_KLAUNCH(ctx, bpr_index_batches, dim3((unsigned)(2 * nbc)), dim3(PREP_THREADS), lds_idx, st, u + t0,
                      (const int32_t *)p.ci, (const int32_t *)p.cj, n_chunk, B, cap_idx, w);
