@@ -130,9 +130,9 @@ struct IndexWs {
     // lazy mode: the order in which the triple pass takes the batch positions -- triples of heavy item rows first, then
     // those of other multi-occurrence item rows, then the rest: a multi-occurrence row is finished by its LAST
     // contributor, and a heavy row's finish is a chain of dependent round trips that should not start at the very end
-    int32_t *order;                 // [nbc][3B] batch position per processing slot, -1 = padding
-    int32_t *nslots;                // [nbc][2]  {processing slots of the batch, of which the heavy rows' blocks}
-    int32_t spw;                    // processing slots per workgroup of the triple pass (a heavy row's blocks are aligned to it)
+    int32_t *order;                 // [nbc][B] batch position per processing slot
+    int32_t *nslots;                // [nbc][2]  {triples of the batch, of which in the item-sorted front region}
+    int32_t spw;                    // processing slots per workgroup of the triple pass
     int4 *u_hrows, *q_hrows;   // [nbc][HRu|HRq]  {row, first chunk, chunks<<16 | length, rank among unique rows}
     int4 *u_hitems, *q_hitems; // [nbc][HIu|HIq]  {row, segment start, length | heavy row index << 8, chunk index}
     int64_t B, U, I, HRu, HRq, HIu, HIq;
@@ -202,7 +202,7 @@ IndexWs layout_index(void *base, int64_t nbc, int64_t B, int64_t U, int64_t I, b
     w.u_desc = (int4 *)take(sizeof(int4) * nbc * (dense ? 0 : B));
     w.i_desc = (int4 *)take(sizeof(int4) * nbc * (dense ? 0 : B));
     w.j_desc = (int4 *)take(sizeof(int4) * nbc * (dense ? 0 : B));
-    w.order = (int32_t *)take(sizeof(int32_t) * nbc * (dense ? 0 : 3 * B));
+    w.order = (int32_t *)take(sizeof(int32_t) * nbc * (dense ? 0 : B));
     w.nslots = (int32_t *)take(sizeof(int32_t) * nbc * (dense ? 0 : 2));
     w.spw = spw;
     w.wide_rows = dense && wide_total > 0 ? wide_rows : 0;
@@ -280,14 +280,15 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
 
     if ((side ? w.I : w.U) == 0) {
         // lazy mode.  The triple pass (bpr_triples_lazy) needs, per batch position and role, where the slot and its row
-        // sit in the sorted order, and the order to take the positions in.  Item rows with more than CH positive slots
-        // ("heavy-aligned") get whole workgroups of the pass: their i-slot triples are laid out in sorted order in blocks of
-        // SPW processing slots, a row's first block on a block boundary, so that a workgroup holds slots of ONE such row
-        // and can add their contributions in LDS -- one partial per workgroup instead of one contribution row per slot.
-        uint16_t *wt = (uint16_t *)hist; // [B] per position: 0xffff = laid out in a heavy block, else the busier item row's count
+        // sit in the sorted order, and the order to take the positions in.  The triples whose POSITIVE item occurs more
+        // than once as a positive come first, sorted by item: the positive slots of such a row are consecutive processing
+        // slots, so the workgroups of the pass (SPW slots each) can add a row's contributions in LDS -- a row that lies
+        // inside one workgroup is finished there without any memory round trip, a longer one leaves one partial per
+        // workgroup it crosses instead of one contribution row per slot.
+        uint16_t *wt = (uint16_t *)hist; // [B] per position: 0xffff = in the item-sorted front region, else the busier item row's count
         const int SPW = w.spw;
-        int32_t *ord = w.order + (int64_t)batch * 3 * B;
-        int nhp = 0; // processing slots taken by the heavy rows' blocks
+        int32_t *ord = w.order + (int64_t)batch * B;
+        int n_front = 0; // triples in the front region
         if (side == 1) {
             const int rper = (total + PREP_THREADS - 1) / PREP_THREADS;
             const int q0 = tid * rper, q1 = (q0 + rper) < total ? (q0 + rper) : total;
@@ -306,24 +307,19 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
             int mine = 0;
             for (int q = q0; q < q1; ++q) {
                 const int start = seg[q], cnt = (int)seg[q + 1] - start;
-                if (cnt > CH) {
+                if (cnt >= 2) {
                     const int ci = i_slots(start, cnt);
-                    if (ci > CH)
-                        mine += (ci + SPW - 1) / SPW * SPW;
+                    mine += ci >= 2 ? ci : 0;
                 }
             }
-            int at = crec_sort::block_excl_scan<PREP_THREADS>(mine, scan, &nhp);
+            int at = crec_sort::block_excl_scan<PREP_THREADS>(mine, scan, &n_front);
             for (int q = q0; q < q1; ++q) {
                 const int start = seg[q], cnt = (int)seg[q + 1] - start;
-                if (cnt > CH) {
+                if (cnt >= 2) {
                     const int ci = i_slots(start, cnt);
-                    if (ci > CH) { // the run's row id stays in rows[start]; the next two entries carry the layout
-                        const int span = (ci + SPW - 1) / SPW * SPW;
-                        rows[start + 1] = 0x80000000u | (uint32_t)at;
-                        rows[start + 2] = (uint32_t)ci;
-                        for (int e = ci; e < span; ++e)
-                            ord[at + e] = -1; // the tail of the row's last block
-                        at += span;
+                    if (ci >= 2) { // the run's row id stays in rows[start]; the next entry carries {positive slots, first processing slot}
+                        rows[start + 1] = 0x80000000u | ((uint32_t)ci << 14) | (uint32_t)at;
+                        at += ci;
                     }
                 }
             }
@@ -334,15 +330,17 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
             if (k == (int)seg[ri + 1])
                 ++ri;
             const int start = seg[ri], cnt = (int)seg[ri + 1] - start;
-            const bool aligned = side == 1 && cnt > CH && (rows[start + 1] & 0x80000000u);
-            const int ci = aligned ? (int)rows[start + 2] : 0;
+            const uint32_t lay = (side == 1 && cnt >= 2) ? rows[start + 1] : 0u;
+            const bool front = (lay & 0x80000000u) != 0;
+            const int ci = front ? (int)((lay >> 14) & 0x3fffu) : 0, first = (int)(lay & 0x3fffu);
             const int slot = tag[k];
             int4 *dst = side == 0 ? w.u_desc : (slot < nb ? w.i_desc : w.j_desc);
+            // y: the slot's sorted position, and (front rows) where in its workgroup the row's first positive slot sits
             dst[(int64_t)batch * B + (slot < nb ? slot : slot - nb)] =
-                make_int4((int)(rows[start] | (cnt == 1 ? 0x80000000u : 0u)), k, start, cnt | (ci << 16));
+                make_int4((int)(rows[start] | (cnt == 1 ? 0x80000000u : 0u)), k | (front ? (first % SPW) << 16 : 0), start, cnt | (ci << 16));
             if (side == 1 && slot < nb) {
-                if (aligned) { // (k - start < ci: an i-slot of a heavy-aligned row)
-                    ord[(int)(rows[start + 1] & 0x7fffffffu) + (k - start)] = slot;
+                if (front) { // (k - start < ci: a positive slot of a front row)
+                    ord[first + (k - start)] = slot;
                     wt[slot] = 0xffff;
                 } else {
                     wt[slot] = (uint16_t)(cnt > 0xfffe ? 0xfffe : cnt);
@@ -361,7 +359,7 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
                 wt[slot - nb] = (uint16_t)(cnt > 0xfffe ? 0xfffe : cnt);
         }
         __syncthreads();
-        // behind the heavy blocks: the positions whose items occur more than once (their rows are finished by their LAST
+        // behind the front region: the positions with another multi-occurrence item row (finished by their LAST
         // contributor: the sooner they start the better), then the rest -- a stable partition
         const int pper = (nb + PREP_THREADS - 1) / PREP_THREADS;
         const int p0 = tid * pper, p1 = (p0 + pper) < nb ? (p0 + pper) : nb;
@@ -372,8 +370,8 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
         }
         int tot_pack = 0;
         const int before = crec_sort::block_excl_scan<PREP_THREADS>((n_blk << 16) | n_multi, scan, &tot_pack);
-        const int tot_blk = tot_pack >> 16, tot_multi = tot_pack & 0xffff;
-        int at_m = nhp + (before & 0xffff), at_s = nhp + tot_multi + (p0 - (before >> 16) - (before & 0xffff));
+        const int tot_multi = tot_pack & 0xffff;
+        int at_m = n_front + (before & 0xffff), at_s = n_front + tot_multi + (p0 - (before >> 16) - (before & 0xffff));
         for (int q = p0; q < p1; ++q) {
             if (wt[q] == 0xffff)
                 continue;
@@ -383,8 +381,8 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
                 ord[at_s++] = q;
         }
         if (tid == 0) {
-            w.nslots[batch * 2 + 0] = nhp + (nb - tot_blk);
-            w.nslots[batch * 2 + 1] = nhp;
+            w.nslots[batch * 2 + 0] = nb;
+            w.nslots[batch * 2 + 1] = n_front;
         }
         return;
     }
@@ -1486,8 +1484,9 @@ __device__ __forceinline__ float4 lazy_sum_rows(const float *base, int n, int64_
 }
 
 // A slot's ticket: which counter it is drawn on, what the slot weighs and at which total the counter is complete.
-//   heavy-aligned item row (ci > 0: more than CH positive slots, laid out in workgroup blocks by the index kernel): the
-//     row's counter; a block's leader weighs the block's slots, a negative slot weighs one; complete at cnt
+//   front item row (ci > 0: two or more positive slots, consecutive processing slots in the item-sorted front region): the
+//     row's counter; the leader of a piece (the row's slots inside one workgroup) weighs the piece, a negative slot weighs
+//     one; complete at cnt
 //   light row (cnt <= CH): the row's counter, one per slot, complete at cnt
 //   other rows (user rows with more than CH slots, item rows whose slots are mostly negatives): the counter of the slot's
 //     chunk of CH slots, complete at the chunk's length; the chunk's finisher then draws on the row's counter, one per chunk
@@ -1497,7 +1496,7 @@ struct LazyTicket {
 };
 __device__ __forceinline__ LazyTicket lazy_ticket_of(int4 desc, int CH)
 {
-    const int k = desc.y, start = desc.z, cnt = desc.w & 0xffff, ci = desc.w >> 16;
+    const int k = desc.y & 0xffff, start = desc.z, cnt = desc.w & 0xffff, ci = desc.w >> 16;
     LazyTicket q;
     q.chunked = ci == 0 && cnt > CH;
     q.idx = q.chunked ? start + (k - start) / CH * CH : start;
@@ -1560,9 +1559,12 @@ __device__ __forceinline__ void lazy_role_tail(const Tables &t, int d, bool act,
     const float4 regrow = make_float4(h.reg * own.x, h.reg * own.y, h.reg * own.z, h.reg * own.w);
     int32_t *ctr = (q.chunked ? chk_t : row_t) + q.idx;
     float4 g = zero;
-    if (ci > 0) { // heavy-aligned: one partial per block of the row's positive slots (l2 terms inside), then its negative slots
+    if (ci > 0) { // a front row: one partial per piece of its positive slots (l2 terms inside) -- the first piece ends at the
+        // workgroup boundary behind the row's first slot, the others are whole workgroups --, then its negative slots
         if (act) {
-            g = lazy_sum_rows(cbuf + (int64_t)start * d + 4 * l, (ci + SPW - 1) / SPW, (int64_t)SPW * d, zero);
+            const int room = SPW - (desc.y >> 16), len1 = ci < room ? ci : room;
+            g = lazy_sum_rows(cbuf + (int64_t)start * d + 4 * l, 1, 0, zero);
+            add4(g, lazy_sum_rows(cbuf + (int64_t)(start + len1) * d + 4 * l, (ci - len1 + SPW - 1) / SPW, (int64_t)SPW * d, zero));
             add4(g, lazy_sum_rows(cbuf + (int64_t)(start + ci) * d + 4 * l, cnt - ci, d, regrow));
         }
     } else if (act) {
@@ -1604,16 +1606,17 @@ __global__ __launch_bounds__(LazyGeo<LPR>::THREADS) void bpr_triples_lazy(Tables
                                                                           float *__restrict__ xb, float *__restrict__ l2b, Hyper h)
 {
     constexpr int SPW = LazyGeo<LPR>::SPW;
-    extern __shared__ float4 blk_rows[]; // [SPW][LPR], heavy blocks only
+    extern __shared__ float4 blk_rows[]; // [SPW][LPR], workgroups of the front region only
     const int lane = threadIdx.x & 63, l = lane % LPR, gw = (int)threadIdx.x / LPR;
     const int slot0 = (int)blockIdx.x * SPW;
-    const int n_slots = nslots[0], n_blk_slots = nslots[1];
+    const int n_slots = nslots[0], n_blk_slots = nslots[1]; // triples of the batch, of which in the front region
     if (slot0 >= n_slots)
         return;
-    const bool heavy_block = slot0 < n_blk_slots; // workgroup-uniform: every slot here is a positive slot of ONE heavy-aligned row
+    const bool front_block = slot0 < n_blk_slots; // workgroup-uniform: slots of the item-sorted front region in this workgroup
     const int slot = slot0 + gw;
     const int pos = slot < n_slots ? order[slot] : -1;
     const bool valid = pos >= 0, act = FULL || 4 * l < d, on = valid && act;
+    const bool front = valid && slot < n_blk_slots; // this slot's positive item row has its positive slots right here, in a row
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     const int4 none = make_int4((int)0x80000000u, 0, 0, 1); // a dead group: "single" rows, no tails
     const int4 du = valid ? ud[pos] : none, di = valid ? id[pos] : none, dj = valid ? jd[pos] : none;
@@ -1621,7 +1624,12 @@ __global__ __launch_bounds__(LazyGeo<LPR>::THREADS) void bpr_triples_lazy(Tables
     const int64_t ou = (int64_t)(du.x & 0x7fffffff) * d + 4 * l, oi = (int64_t)(di.x & 0x7fffffff) * d + 4 * l,
                   oj = (int64_t)(dj.x & 0x7fffffff) * d + 4 * l;
     const bool item_adam = h.dQ == nullptr; // the row-sharded step only emits the item rows' gradient sums
-    const bool blk_lead = heavy_block && gw == 0; // may finish the block's row on the spot: wants its slots
+    // front region: the piece of this slot's row inside this workgroup starts at the row's first slot or at the workgroup's;
+    // the group of that slot leads the piece.  A piece that is the whole row is finished on the spot: its leader wants the slots
+    const int i_k = di.y & 0xffff, i_posr = i_k - di.z, i_ci = di.w >> 16, i_cnt = di.w & 0xffff;
+    const bool blk_lead = front && (gw == 0 || i_posr == 0);
+    const int blk_n = blk_lead ? ((i_ci - i_posr) < (SPW - gw) ? (i_ci - i_posr) : (SPW - gw)) : 0; // the piece's slots = the leader's weight
+    const bool blk_whole = blk_lead && blk_n == i_cnt; // the row lies inside this workgroup: no ticket, no memory round trip
     float4 p = zero, qi = zero, qj = zero, mp = zero, vp = zero, mi = zero, vi = zero, mj = zero, vj = zero;
     if (on) { // every address is known: one round of loads
         p = ld4(t.P + ou);
@@ -1632,9 +1640,9 @@ __global__ __launch_bounds__(LazyGeo<LPR>::THREADS) void bpr_triples_lazy(Tables
             mp = ld4s(t.mP + ou);
         if ((us || DEFER) && has_v)
             vp = ld4s(t.vP + ou);
-        if ((is || DEFER || blk_lead) && item_adam && has_m)
+        if ((is || DEFER || blk_whole) && item_adam && has_m)
             mi = ld4s(t.mQ + oi);
-        if ((is || DEFER || blk_lead) && item_adam && has_v)
+        if ((is || DEFER || blk_whole) && item_adam && has_v)
             vi = ld4s(t.vQ + oi);
         if ((js || DEFER) && item_adam && has_m)
             mj = ld4s(t.mQ + oj);
@@ -1670,45 +1678,32 @@ __global__ __launch_bounds__(LazyGeo<LPR>::THREADS) void bpr_triples_lazy(Tables
     const float4 cu = make_float4(ns * (qi.x - qj.x), ns * (qi.y - qj.y), ns * (qi.z - qj.z), ns * (qi.w - qj.w));
     const float4 sp = make_float4(s * p.x, s * p.y, s * p.z, s * p.w), nsp = make_float4(-sp.x, -sp.y, -sp.z, -sp.w);
 
-    // 0. a heavy block: the contributions of its slots (all to the same row, l2 terms included) meet in LDS, in a fixed
-    // tree order; the block's leader group carries the sum from here on
+    // 0. front region: the contributions of a row's positive slots (l2 terms included) meet in LDS; the piece's leader adds
+    // them in slot (= batch) order and carries the sum from here on
     float4 blk_sum = zero;
-    int blk_n = 0; // the leader's weight: positive slots of the row inside this block
-    if (heavy_block) {
-        blk_rows[gw * LPR + l] = on ? make_float4(nsp.x + h.reg * qi.x, nsp.y + h.reg * qi.y, nsp.z + h.reg * qi.z, nsp.w + h.reg * qi.w)
-                                    : zero;
-        for (int st = 1; st < SPW; st <<= 1) {
-            __syncthreads();
-            if ((gw & (2 * st - 1)) == 0 && gw + st < SPW) {
-                float4 a = blk_rows[gw * LPR + l];
-                add4(a, blk_rows[(gw + st) * LPR + l]);
-                blk_rows[gw * LPR + l] = a;
-            }
-        }
-        if (gw == 0) {
-            blk_sum = blk_rows[l];
-            const int left = (di.w >> 16) - (di.y - di.z); // positive slots from this block's first one to the row's last
-            blk_n = left < SPW ? left : SPW;
-        }
+    if (front_block) {
+        blk_rows[gw * LPR + l] = (front && act) ? make_float4(nsp.x + h.reg * qi.x, nsp.y + h.reg * qi.y, nsp.z + h.reg * qi.z, nsp.w + h.reg * qi.w)
+                                                : zero;
+        __syncthreads();
+        for (int e = 0; e < blk_n; ++e)
+            add4(blk_sum, blk_rows[(gw + e) * LPR + l]);
     }
-    const int i_cnt = di.w & 0xffff;
-    const bool blk_whole = blk_lead && blk_n == i_cnt; // the row lies inside this block: no ticket, no memory round trip
     // 1. the contribution rows of the multi-occurrence roles, first: their completion is what the tickets wait for
-    const bool i_publish = !is && (!heavy_block || (blk_lead && !blk_whole)); // heavy blocks: only the leader speaks for the row
+    const bool i_publish = !is && (!front || (blk_lead && !blk_whole)); // front region: only a piece's leader speaks for the row
     if (on) {
         if (!us)
-            st4_agent(z.ucontrib + (int64_t)du.y * d + 4 * l, cu);
+            st4_agent(z.ucontrib + (int64_t)(du.y & 0xffff) * d + 4 * l, cu);
         if (i_publish)
-            st4_agent(z.qcontrib + (int64_t)di.y * d + 4 * l, heavy_block ? blk_sum : nsp);
+            st4_agent(z.qcontrib + (int64_t)i_k * d + 4 * l, front ? blk_sum : nsp);
         if (!js)
-            st4_agent(z.qcontrib + (int64_t)dj.y * d + 4 * l, sp);
+            st4_agent(z.qcontrib + (int64_t)(dj.y & 0xffff) * d + 4 * l, sp);
     }
     // 2. the tickets of all three roles at once (one round trip, not three).  The contribution rows travel with
     // agent-scope stores; the wave waits for their completion first -- the same guarantee as a release fence for these
     // buffers, without writing back the whole L2 (the row loads above have long been consumed: only these stores are
     // outstanding)
     const bool any_multi = __builtin_amdgcn_ballot_w64(valid && (!us || i_publish || !js)) != 0; // false for the usual wave on large tables
-    const int wi = heavy_block ? blk_n : 1;
+    const int wi = front ? blk_n : 1;
     int tku = -1, tki = -1, tkj = -1;
     if (any_multi) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1763,7 +1758,7 @@ __global__ __launch_bounds__(LazyGeo<LPR>::THREADS) void bpr_triples_lazy(Tables
             }
         }
     }
-    if (blk_whole && valid) // a heavy-aligned row that fits its block: finished from LDS, nothing published
+    if (blk_whole) // a front row that lies inside this workgroup: finished from LDS, nothing published
         lazy_finish_row<LPR, false, DEFER>(t, d, act, di.x & 0x7fffffff, qi, blk_sum, mi_raw, vi_raw, h);
     if (!any_multi)
         return;
@@ -1946,18 +1941,16 @@ template <int LPR, bool FULL> void launch_lazy(const StepArgs &a, const IndexWs 
 {
     constexpr int SPW = LazyGeo<LPR>::SPW, THREADS = LazyGeo<LPR>::THREADS;
     (void)hn;
-    // processing slots of a batch: its triples plus the padding of the heavy rows' blocks (< 2 per triple: a heavy row has
-    // more than CH = 16+ positive slots and pads fewer than SPW); workgroups beyond the batch's count leave at once
-    const dim3 grid((unsigned)crec_ceil_div(3 * (int64_t)a.nb_cur, SPW)), block(THREADS);
+    const dim3 grid((unsigned)crec_ceil_div((int64_t)a.nb_cur, SPW)), block(THREADS);
     const size_t lds = sizeof(float4) * THREADS;
     crec_prof_begin(a.ctx, CREC_K_USER_SIDE, a.st);
     if (a.h.lr_tab)
         CREC_KLAUNCH(a.ctx, (bpr_triples_lazy<LPR, FULL, true>), grid, block, lds, a.st, a.cur, a.d,
-                     (const int32_t *)(w.order + b * 3 * w.B), (const int32_t *)(w.nslots + b * 2), (const int4 *)(w.u_desc + b * w.B),
+                     (const int32_t *)(w.order + b * w.B), (const int32_t *)(w.nslots + b * 2), (const int4 *)(w.u_desc + b * w.B),
                      (const int4 *)(w.i_desc + b * w.B), (const int4 *)(w.j_desc + b * w.B), a.lazy, a.xb, a.rowterm, a.h);
     else
         CREC_KLAUNCH(a.ctx, (bpr_triples_lazy<LPR, FULL, false>), grid, block, lds, a.st, a.cur, a.d,
-                     (const int32_t *)(w.order + b * 3 * w.B), (const int32_t *)(w.nslots + b * 2), (const int4 *)(w.u_desc + b * w.B),
+                     (const int32_t *)(w.order + b * w.B), (const int32_t *)(w.nslots + b * 2), (const int4 *)(w.u_desc + b * w.B),
                      (const int4 *)(w.i_desc + b * w.B), (const int4 *)(w.j_desc + b * w.B), a.lazy, a.xb, a.rowterm, a.h);
     crec_prof_end(a.ctx, a.st);
 }
