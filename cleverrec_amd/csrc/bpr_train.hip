@@ -126,7 +126,10 @@ struct IndexWs {
     // lazy mode: per batch position and role (user, positive, negative) {row | single << 31, k, start, cnt}: the row
     // id (bit 31: it occurs once in the batch), the slot's position k in the side's sorted order, the row's segment
     // [start, start + cnt) there.  These are the lazy step's whole index: nothing else is written in lazy mode.
-    int4 *u_desc, *i_desc, *j_desc; // [nbc][B]
+    int4 *u_desc, *i_desc, *j_desc; // [nbc][B]; u_desc by batch position, i_desc / j_desc by PROCESSING SLOT (see order)
+    int4 *i_tmp, *j_tmp;            // [nbc][B] scratch of the index kernel (the item descriptors by batch position)
+    int2 *slot_pu;                  // [nbc][B] by processing slot: {batch position, user row}: with i_desc / j_desc everything the
+                                    // triple pass needs to address its rows comes from ONE round of coalesced loads
     // lazy mode: the order in which the triple pass takes the batch positions -- triples of heavy item rows first, then
     // those of other multi-occurrence item rows, then the rest: a multi-occurrence row is finished by its LAST
     // contributor, and a heavy row's finish is a chain of dependent round trips that should not start at the very end
@@ -203,6 +206,9 @@ IndexWs layout_index(void *base, int64_t nbc, int64_t B, int64_t U, int64_t I, b
     w.i_desc = (int4 *)take(sizeof(int4) * nbc * (dense ? 0 : B));
     w.j_desc = (int4 *)take(sizeof(int4) * nbc * (dense ? 0 : B));
     w.order = (int32_t *)take(sizeof(int32_t) * nbc * (dense ? 0 : B));
+    w.slot_pu = (int2 *)take(sizeof(int2) * nbc * (dense ? 0 : B));
+    w.i_tmp = (int4 *)take(sizeof(int4) * nbc * (dense ? 0 : B));
+    w.j_tmp = (int4 *)take(sizeof(int4) * nbc * (dense ? 0 : B));
     w.nslots = (int32_t *)take(sizeof(int32_t) * nbc * (dense ? 0 : 2));
     w.spw = spw;
     w.wide_rows = dense && wide_total > 0 ? wide_rows : 0;
@@ -334,9 +340,11 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
             const bool front = (lay & 0x80000000u) != 0;
             const int ci = front ? (int)((lay >> 14) & 0x3fffu) : 0, first = (int)(lay & 0x3fffu);
             const int slot = tag[k];
+            // y: the slot's sorted position, and (front rows) where in its workgroup the row's first positive slot sits.
+            // The item side's descriptors are written by batch position here and moved to processing-slot order below
             int4 *dst = side == 0 ? w.u_desc : (slot < nb ? w.i_desc : w.j_desc);
-            // y: the slot's sorted position, and (front rows) where in its workgroup the row's first positive slot sits
-            dst[(int64_t)batch * B + (slot < nb ? slot : slot - nb)] =
+            int4 *dst_tmp = side == 0 ? dst : (slot < nb ? w.i_tmp : w.j_tmp);
+            dst_tmp[(int64_t)batch * B + (slot < nb ? slot : slot - nb)] =
                 make_int4((int)(rows[start] | (cnt == 1 ? 0x80000000u : 0u)), k | (front ? (first % SPW) << 16 : 0), start, cnt | (ci << 16));
             if (side == 1 && slot < nb) {
                 if (front) { // (k - start < ci: a positive slot of a front row)
@@ -383,6 +391,15 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
         if (tid == 0) {
             w.nslots[batch * 2 + 0] = nb;
             w.nslots[batch * 2 + 1] = n_front;
+        }
+        // the order is complete (this workgroup wrote all of it): the item descriptors and {position, user} by processing slot
+        __threadfence_block();
+        __syncthreads();
+        for (int sl = tid; sl < nb; sl += PREP_THREADS) {
+            const int pos = ord[sl];
+            w.slot_pu[(int64_t)batch * B + sl] = make_int2(pos, u[t0 + pos]);
+            w.i_desc[(int64_t)batch * B + sl] = w.i_tmp[(int64_t)batch * B + pos];
+            w.j_desc[(int64_t)batch * B + sl] = w.j_tmp[(int64_t)batch * B + pos];
         }
         return;
     }
@@ -1599,7 +1616,7 @@ template <int LPR> struct LazyGeo {
 };
 
 template <int LPR, bool FULL, bool DEFER>
-__global__ __launch_bounds__(LazyGeo<LPR>::THREADS) void bpr_triples_lazy(Tables t, int d, const int32_t *__restrict__ order,
+__global__ __launch_bounds__(LazyGeo<LPR>::THREADS) void bpr_triples_lazy(Tables t, int d, const int2 *__restrict__ slot_pu, int n_slots,
                                                                           const int32_t *__restrict__ nslots,
                                                                           const int4 *__restrict__ ud, const int4 *__restrict__ id,
                                                                           const int4 *__restrict__ jd, LazyBufs z,
@@ -1609,19 +1626,22 @@ __global__ __launch_bounds__(LazyGeo<LPR>::THREADS) void bpr_triples_lazy(Tables
     extern __shared__ float4 blk_rows[]; // [SPW][LPR], workgroups of the front region only
     const int lane = threadIdx.x & 63, l = lane % LPR, gw = (int)threadIdx.x / LPR;
     const int slot0 = (int)blockIdx.x * SPW;
-    const int n_slots = nslots[0], n_blk_slots = nslots[1]; // triples of the batch, of which in the front region
-    if (slot0 >= n_slots)
-        return;
-    const bool front_block = slot0 < n_blk_slots; // workgroup-uniform: slots of the item-sorted front region in this workgroup
+    // ONE round of coalesced loads, by processing slot, gives every address of the next round: {position, user row} and the
+    // two item descriptors.  (n_slots = the batch's triples comes from the host; the size of the front region and the
+    // user's own descriptor -- needed only where the user occurs more than once -- arrive alongside.)
+    const int n_blk_slots = nslots[1];
     const int slot = slot0 + gw;
-    const int pos = slot < n_slots ? order[slot] : -1;
-    const bool valid = pos >= 0, act = FULL || 4 * l < d, on = valid && act;
-    const bool front = valid && slot < n_blk_slots; // this slot's positive item row has its positive slots right here, in a row
+    const bool valid = slot < n_slots, act = FULL || 4 * l < d, on = valid && act;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     const int4 none = make_int4((int)0x80000000u, 0, 0, 1); // a dead group: "single" rows, no tails
-    const int4 du = valid ? ud[pos] : none, di = valid ? id[pos] : none, dj = valid ? jd[pos] : none;
-    const bool us = du.x < 0, is = di.x < 0, js = dj.x < 0;
-    const int64_t ou = (int64_t)(du.x & 0x7fffffff) * d + 4 * l, oi = (int64_t)(di.x & 0x7fffffff) * d + 4 * l,
+    const int2 pu = valid ? slot_pu[slot] : make_int2(0, 0);
+    const int4 di = valid ? id[slot] : none, dj = valid ? jd[slot] : none;
+    const int pos = pu.x;
+    const bool front_block = slot0 < n_blk_slots; // workgroup-uniform: slots of the item-sorted front region in this workgroup
+    const bool front = valid && slot < n_blk_slots; // this slot's positive item row has its positive slots right here, in a row
+    const int4 du = valid ? ud[pos] : none; // (a second, dependent load: off the critical path of the row loads below)
+    const bool is = di.x < 0, js = dj.x < 0;
+    const int64_t ou = (int64_t)pu.y * d + 4 * l, oi = (int64_t)(di.x & 0x7fffffff) * d + 4 * l,
                   oj = (int64_t)(dj.x & 0x7fffffff) * d + 4 * l;
     const bool item_adam = h.dQ == nullptr; // the row-sharded step only emits the item rows' gradient sums
     // front region: the piece of this slot's row inside this workgroup starts at the row's first slot or at the workgroup's;
@@ -1636,9 +1656,11 @@ __global__ __launch_bounds__(LazyGeo<LPR>::THREADS) void bpr_triples_lazy(Tables
         qi = ld4(t.Q + oi);
         qj = ld4(t.Q + oj);
         const bool has_m = h.opt != CREC_OPT_SGD, has_v = h.opt == 0; // the slots this optimizer keeps
-        if ((us || DEFER) && has_m) // deferred mode: every row is brought up to date before its values are used
+        // the user's slots are asked for without waiting for its descriptor (is the user row single?): wasted only for users
+        // that occur more than once.  (Deferred mode: every row is brought up to date before its values are used.)
+        if (has_m)
             mp = ld4s(t.mP + ou);
-        if ((us || DEFER) && has_v)
+        if (has_v)
             vp = ld4s(t.vP + ou);
         if ((is || DEFER || blk_whole) && item_adam && has_m)
             mi = ld4s(t.mQ + oi);
@@ -1649,9 +1671,10 @@ __global__ __launch_bounds__(LazyGeo<LPR>::THREADS) void bpr_triples_lazy(Tables
         if ((js || DEFER) && item_adam && has_v)
             vj = ld4s(t.vQ + oj);
     }
+    const bool us = du.x < 0; // the user row occurs once in the batch
     float4 mi_raw = mi, vi_raw = vi; // deferred mode: a finisher replays the stored slots itself
     if (DEFER) { // the steps these rows sat out, replayed: from here on p, q_i, q_j are what TF1's tables hold after step - 1
-        const int lu = valid ? h.lastP[du.x & 0x7fffffff] : h.step, li = valid ? h.lastQ[di.x & 0x7fffffff] : h.step,
+        const int lu = valid ? h.lastP[pu.y] : h.step, li = valid ? h.lastQ[di.x & 0x7fffffff] : h.step,
                   lj = valid ? h.lastQ[dj.x & 0x7fffffff] : h.step;
         adam_replay(p, mp, vp, lu, h.step - 1, h);
         adam_replay(qi, mi, vi, li, h.step - 1, h);
@@ -1946,11 +1969,11 @@ template <int LPR, bool FULL> void launch_lazy(const StepArgs &a, const IndexWs 
     crec_prof_begin(a.ctx, CREC_K_USER_SIDE, a.st);
     if (a.h.lr_tab)
         CREC_KLAUNCH(a.ctx, (bpr_triples_lazy<LPR, FULL, true>), grid, block, lds, a.st, a.cur, a.d,
-                     (const int32_t *)(w.order + b * w.B), (const int32_t *)(w.nslots + b * 2), (const int4 *)(w.u_desc + b * w.B),
+                     (const int2 *)(w.slot_pu + b * w.B), (int)a.nb_cur, (const int32_t *)(w.nslots + b * 2), (const int4 *)(w.u_desc + b * w.B),
                      (const int4 *)(w.i_desc + b * w.B), (const int4 *)(w.j_desc + b * w.B), a.lazy, a.xb, a.rowterm, a.h);
     else
         CREC_KLAUNCH(a.ctx, (bpr_triples_lazy<LPR, FULL, false>), grid, block, lds, a.st, a.cur, a.d,
-                     (const int32_t *)(w.order + b * w.B), (const int32_t *)(w.nslots + b * 2), (const int4 *)(w.u_desc + b * w.B),
+                     (const int2 *)(w.slot_pu + b * w.B), (int)a.nb_cur, (const int32_t *)(w.nslots + b * 2), (const int4 *)(w.u_desc + b * w.B),
                      (const int4 *)(w.i_desc + b * w.B), (const int4 *)(w.j_desc + b * w.B), a.lazy, a.xb, a.rowterm, a.h);
     crec_prof_end(a.ctx, a.st);
 }
