@@ -102,6 +102,9 @@ __device__ __forceinline__ void crec_mark(int slot, int dep) // the time at whic
 #define CREC_LAZY_ITEM_WAVES 4 // 5 (96 VGPRs, 12 bytes of scratch) measured the same: 10.8 us
 #endif
 #define CREC_LAZY_WAVES(MODE) ((MODE) == 2 ? CREC_LAZY_ITEM_WAVES : 4)
+#ifndef CREC_LAZY_ABL
+#define CREC_LAZY_ABL 0 // timing ablations of bpr_triples_lazy (wrong results): 1 no finishers, 2 no publishing / tickets either,
+#endif                  // 4 no LDS piece sums
 #ifndef CREC_LAZY_DEEP
 #define CREC_LAZY_DEEP 8 // contribution / partial rows in flight in a finisher's sum.  The d = 128 workgroup is 1024 threads, i.e. a
                          // hard limit of 128 VGPRs: 11 in flight spill three registers; 8 / 11 / 12 / 16 measured within 2 % of each other
@@ -601,6 +604,14 @@ __device__ __forceinline__ void st4_wt(float *base, int64_t off, float4 v)
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000);
     const crec_u4v x = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
     __builtin_amdgcn_raw_buffer_store_b128(x, r, (int)(off * 4), 0, 16 /* sc1 */);
+}
+// the matching 16-byte load: agent scope (sc1), served where the XCDs meet -- one instruction instead of the four 4-byte
+// atomic loads of ld4_agent.  base: wave-uniform; off: float index (< 2^29)
+__device__ __forceinline__ float4 ld4_sc1(const float *base, int64_t off)
+{
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, 0x7fffffff, 0x00020000);
+    const crec_u4v x = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(off * 4), 0, 16 /* sc1 */);
+    return make_float4(__uint_as_float(x.x), __uint_as_float(x.y), __uint_as_float(x.z), __uint_as_float(x.w));
 }
 __device__ __forceinline__ float4 ld4s(const float *p) // streamed slot input (m, v: read once)
 {
@@ -1483,7 +1494,7 @@ struct LazyBufs {
 
 // sum of n rows base[0], base[stride], ... in that order, each plus `add` (reg * row, or zero); agent-scope loads
 // (the rows were published by other waves, possibly on another XCD), eight in flight
-__device__ __forceinline__ float4 lazy_sum_rows(const float *base, int n, int64_t stride, float4 add)
+__device__ __forceinline__ float4 lazy_sum_rows(const float *buf, int64_t off, int n, int64_t stride, float4 add)
 {
     constexpr int DEEP = CREC_LAZY_DEEP;
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1491,11 +1502,35 @@ __device__ __forceinline__ float4 lazy_sum_rows(const float *base, int n, int64_
         float4 c[DEEP];
 #pragma unroll
         for (int e = 0; e < DEEP; ++e)
-            c[e] = k0 + e < n ? ld4_agent(base + (int64_t)(k0 + e) * stride) : make_float4(0.f, 0.f, 0.f, 0.f);
+            c[e] = k0 + e < n ? ld4_sc1(buf, off + (int64_t)(k0 + e) * stride) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int e = 0; e < DEEP; ++e)
             if (k0 + e < n)
                 add4(g, make_float4(c[e].x + add.x, c[e].y + add.y, c[e].z + add.z, c[e].w + add.w));
+    }
+    return g;
+}
+
+// the sum of a front row: the partials of its pieces (l2 terms inside) -- the first piece ends at the workgroup boundary
+// behind the row's first slot, the others are whole workgroups --, then its negative slots' contributions (+ reg*row each),
+// all in ONE list of loads, in that order
+__device__ __forceinline__ float4 lazy_sum_front(const float *buf, int d, int l, int start, int ci, int cnt, int hmod, int SPW, float4 regrow)
+{
+    constexpr int DEEP = CREC_LAZY_DEEP;
+    const int room = SPW - hmod, len1 = ci < room ? ci : room, np = 1 + (ci - len1 + SPW - 1) / SPW, n = np + (cnt - ci);
+    const auto at = [&](int e) { return e == 0 ? start : (e < np ? start + len1 + (e - 1) * SPW : start + ci + (e - np)); };
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k0 = 0; k0 < n; k0 += DEEP) {
+        float4 c[DEEP];
+#pragma unroll
+        for (int e = 0; e < DEEP; ++e)
+            c[e] = k0 + e < n ? ld4_sc1(buf, (int64_t)at(k0 + e) * d + 4 * l) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int e = 0; e < DEEP; ++e)
+            if (k0 + e < n) {
+                const float w = k0 + e >= np ? 1.0f : 0.0f; // w * regrow is exact
+                add4(g, make_float4(c[e].x + w * regrow.x, c[e].y + w * regrow.y, c[e].z + w * regrow.z, c[e].w + w * regrow.w));
+            }
     }
     return g;
 }
@@ -1578,20 +1613,16 @@ __device__ __forceinline__ void lazy_role_tail(const Tables &t, int d, bool act,
     float4 g = zero;
     if (ci > 0) { // a front row: one partial per piece of its positive slots (l2 terms inside) -- the first piece ends at the
         // workgroup boundary behind the row's first slot, the others are whole workgroups --, then its negative slots
-        if (act) {
-            const int room = SPW - (desc.y >> 16), len1 = ci < room ? ci : room;
-            g = lazy_sum_rows(cbuf + (int64_t)start * d + 4 * l, 1, 0, zero);
-            add4(g, lazy_sum_rows(cbuf + (int64_t)(start + len1) * d + 4 * l, (ci - len1 + SPW - 1) / SPW, (int64_t)SPW * d, zero));
-            add4(g, lazy_sum_rows(cbuf + (int64_t)(start + ci) * d + 4 * l, cnt - ci, d, regrow));
-        }
+        if (act)
+            g = lazy_sum_front(cbuf, d, l, start, ci, cnt, desc.y >> 16, SPW, regrow);
     } else if (act) {
-        g = lazy_sum_rows(cbuf + (int64_t)q.idx * d + 4 * l, q.need, d, regrow);
+        g = lazy_sum_rows(cbuf, (int64_t)q.idx * d + 4 * l, q.need, d, regrow);
     }
     if (l == 0)
         __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next launch
     if (q.chunked) { // a chunk of a chunked row: publish the partial, then the same game over the row's chunks
         if (act)
-            st4_agent(pbuf + (int64_t)q.idx * d + 4 * l, g);
+            st4_wt(pbuf, (int64_t)q.idx * d + 4 * l, g);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const int parts = (cnt + CH - 1) / CH;
         int t2 = -1;
@@ -1602,7 +1633,7 @@ __device__ __forceinline__ void lazy_role_tail(const Tables &t, int d, bool act,
             return;
         asm volatile("" ::: "memory");
         if (act)
-            g = lazy_sum_rows(pbuf + (int64_t)start * d + 4 * l, parts, (int64_t)CH * d, zero);
+            g = lazy_sum_rows(pbuf, (int64_t)start * d + 4 * l, parts, (int64_t)CH * d, zero);
         if (l == 0)
             __hip_atomic_store(row_t + start, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -1704,7 +1735,7 @@ __global__ __launch_bounds__(LazyGeo<LPR>::THREADS) void bpr_triples_lazy(Tables
     // 0. front region: the contributions of a row's positive slots (l2 terms included) meet in LDS; the piece's leader adds
     // them in slot (= batch) order and carries the sum from here on
     float4 blk_sum = zero;
-    if (front_block) {
+    if (front_block && !(CREC_LAZY_ABL & 4)) {
         blk_rows[gw * LPR + l] = (front && act) ? make_float4(nsp.x + h.reg * qi.x, nsp.y + h.reg * qi.y, nsp.z + h.reg * qi.z, nsp.w + h.reg * qi.w)
                                                 : zero;
         __syncthreads();
@@ -1713,19 +1744,19 @@ __global__ __launch_bounds__(LazyGeo<LPR>::THREADS) void bpr_triples_lazy(Tables
     }
     // 1. the contribution rows of the multi-occurrence roles, first: their completion is what the tickets wait for
     const bool i_publish = !is && (!front || (blk_lead && !blk_whole)); // front region: only a piece's leader speaks for the row
-    if (on) {
+    if (on && !(CREC_LAZY_ABL & 2)) {
         if (!us)
-            st4_agent(z.ucontrib + (int64_t)(du.y & 0xffff) * d + 4 * l, cu);
+            st4_wt(z.ucontrib, (int64_t)(du.y & 0xffff) * d + 4 * l, cu);
         if (i_publish)
-            st4_agent(z.qcontrib + (int64_t)i_k * d + 4 * l, front ? blk_sum : nsp);
+            st4_wt(z.qcontrib, (int64_t)i_k * d + 4 * l, front ? blk_sum : nsp);
         if (!js)
-            st4_agent(z.qcontrib + (int64_t)(dj.y & 0xffff) * d + 4 * l, sp);
+            st4_wt(z.qcontrib, (int64_t)(dj.y & 0xffff) * d + 4 * l, sp);
     }
     // 2. the tickets of all three roles at once (one round trip, not three).  The contribution rows travel with
     // agent-scope stores; the wave waits for their completion first -- the same guarantee as a release fence for these
     // buffers, without writing back the whole L2 (the row loads above have long been consumed: only these stores are
     // outstanding)
-    const bool any_multi = __builtin_amdgcn_ballot_w64(valid && (!us || i_publish || !js)) != 0; // false for the usual wave on large tables
+    const bool any_multi = !(CREC_LAZY_ABL & 2) && __builtin_amdgcn_ballot_w64(valid && (!us || i_publish || !js)) != 0; // false for the usual wave on large tables
     const int wi = front ? blk_n : 1;
     int tku = -1, tki = -1, tkj = -1;
     if (any_multi) {
@@ -1783,7 +1814,7 @@ __global__ __launch_bounds__(LazyGeo<LPR>::THREADS) void bpr_triples_lazy(Tables
     }
     if (blk_whole) // a front row that lies inside this workgroup: finished from LDS, nothing published
         lazy_finish_row<LPR, false, DEFER>(t, d, act, di.x & 0x7fffffff, qi, blk_sum, mi_raw, vi_raw, h);
-    if (!any_multi)
+    if (!any_multi || (CREC_LAZY_ABL & 1))
         return;
     // 4. whoever completes a row's (chunk's) counter finishes it
     const int lead = lane - l;
