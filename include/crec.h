@@ -75,7 +75,7 @@ int crec_ctx_set_option(crec_ctx *ctx, const char *name, int64_t value);
 /* ---- measurement: per-kernel time from HIP events recorded on the launch stream ------------
  * While enabled, every kernel launch of this ctx is bracketed by two events and each API call
  * ends with a stream synchronise (so do not time whole-job throughput with it on).
- * kernel_class: 0 bpr_index_batches, 1 bpr_step_fused, 2 bpr_triples_lazy, 3 bpr_rows_lazy,
+ * kernel_class: 0 bpr_index_batches, 1 bpr_step_fused, 2 bpr_triples_lazy, 3 (unused),
  *               4 bpr_reduce_loss, 5 eval_sweep, 6 eval_merge, 7 rank_metrics, 8 (unused), 9 bpr_adam_dense,
  *               10 rows_index_batches, 11 rows_apply, 12 small_adam_dense, 13 ncf_tile, 14 fm_instances, 15 cml_instances,
  *               16 ncf_pair_logits, 17 shard_plan_batches, 18 shard_serve_rows, 19 shard_owner_apply.

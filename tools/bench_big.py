@@ -58,7 +58,7 @@ def run(users=10_000_000, items=1_000_000, dim=128, steps=300, warmup=30, batch=
     sess.ctx.profile(False)
 
     # row multiplicities per batch (sampled): unique touched rows for the 28d Adam term, and which kernel owns a row --
-    # rows that occur once are finished by bpr_triples_lazy, the others by bpr_rows_lazy
+    # rows that occur once are finished in the triple pass's main line, the others by their last contributor
     uq_u = uq_q = single_u = single_q = multi_slots_q = multi_slots_u = 0
     sample = range(0, steps, max(1, steps // 16))
     for b in sample:
@@ -75,22 +75,19 @@ def run(users=10_000_000, items=1_000_000, dim=128, steps=300, warmup=30, batch=
     multi_slots_u, multi_slots_q = multi_slots_u / len(sample), multi_slots_q / len(sample)
     d = dim
     # (24d + 12) B per triple (3 ids, 3 row reads, 3 gradient rows) + 28d B per unique touched row (Adam).
-    # The triple pass owns the ids, the row reads, the gradient rows and the Adam traffic of the single-occurrence
-    # rows; the rows kernel owns the gradient rows (= the stored contribution rows it sums) and the Adam of the rest
-    alg_triples = batch * (12 * d + 12) + (single_u + single_q) * (4 * d + 28 * d)
-    alg_rows = (multi_slots_u + multi_slots_q) * 4 * d + (uq_u - single_u + uq_q - single_q) * 28 * d
+    # The step is ONE launch (bpr_triples_lazy): it owns all of it.
+    alg_step = batch * (24 * d + 12) + (uq_u + uq_q) * 28 * d
     us = prof["bpr_triples_lazy"][0] / prof["bpr_triples_lazy"][1] * 1e3
-    it = prof["bpr_rows_lazy"][0] / max(prof["bpr_rows_lazy"][1], 1) * 1e3
     out = {
         "workload": "S-big: %d users x %d items, d=%d fp32, batch %d, lazy Adam, Zipf(1.0) positives" % (users, items, dim, batch),
         "state_GB": (users + items) * dim * 4 * 3 / 1e9,
         "triples_per_s": steps * batch / dt, "us_per_step": dt / steps * 1e6,
         "unique_user_rows_per_batch": uq_u, "unique_item_rows_per_batch": uq_q,
         "single_occurrence_rows_per_batch": {"users": single_u, "items": single_q},
-        "bpr_triples_lazy": {"avg_us": us, "algorithmic_bytes": alg_triples, "GBs": alg_triples / us / 1e3, "frac_of_8TBs": alg_triples / us / 1e3 / 8000},
-        "bpr_rows_lazy": {"avg_us": it, "algorithmic_bytes": alg_rows, "GBs": alg_rows / max(it, 1e-9) / 1e3, "frac_of_8TBs": alg_rows / max(it, 1e-9) / 1e3 / 8000},
-        "step_algorithmic_bytes": batch * (24 * d + 12) + (uq_u + uq_q) * 28 * d,
-        "step_algorithmic_GBs": (batch * (24 * d + 12) + (uq_u + uq_q) * 28 * d) / (dt / steps) / 1e9,
+        "slots_of_multi_occurrence_rows_per_batch": {"users": multi_slots_u, "items": multi_slots_q},
+        "bpr_triples_lazy": {"avg_us": us, "algorithmic_bytes": alg_step, "GBs": alg_step / us / 1e3, "frac_of_8TBs": alg_step / us / 1e3 / 8000},
+        "step_algorithmic_bytes": alg_step,
+        "step_algorithmic_GBs": alg_step / (dt / steps) / 1e9,
         "bpr_index_batches_us_per_step": prof["bpr_index_batches"][0] * 1e3 / steps,
         "loss_first_last": [float(loss[0]), float(loss[-1])],
     }

@@ -14,5 +14,5 @@ for v in "$@"; do
   CREC_LIB=$out/libcrec.so python bench.py --cpu-steps 0 --no-big 2>/dev/null | python -c "
 import json,sys; d=json.load(sys.stdin); print('$tag vgpr $vg occ $occ', round(d['value']/1e6,1), 'Mtr/s', round(d['ms_per_step']*1e3,2), 'us/step', {k:round(v['avg_us'],2) for k,v in d['kernels'].items() if k!='bpr_index_batches'})"
   if [ -n "$BIG" ]; then CREC_LIB=$out/libcrec.so python tools/bench_big.py --steps 200 2>/dev/null | python -c "
-import json,sys; d=json.load(sys.stdin); print('   big $tag', round(d['triples_per_s']/1e6,1), 'Mtr/s', round(d['us_per_step'],1), 'us/step user', round(d['bpr_triples_lazy']['avg_us'],1), 'item', round(d['bpr_rows_lazy']['avg_us'],1), 'alg GB/s', round(d['step_algorithmic_GBs']))"; fi
+import json,sys; d=json.load(sys.stdin); print('   big $tag', round(d['triples_per_s']/1e6,1), 'Mtr/s', round(d['us_per_step'],1), 'us/step user', round(d['bpr_triples_lazy']['avg_us'],1), 'alg GB/s', round(d['step_algorithmic_GBs']))"; fi
 done
