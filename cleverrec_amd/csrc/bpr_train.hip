@@ -167,7 +167,10 @@ inline int row_bits(int64_t n_rows)
 
 // processing slots per workgroup of bpr_triples_lazy: 32 lane groups; 64 at d = 4, where a group is one lane; 16 above
 // d = 128, where a group is a whole wave (a workgroup has at most 1024 threads)
-inline int lazy_spw(int d) { return d <= 4 ? 64 : (d > 128 ? 16 : 32); }
+#ifndef CREC_LAZY_SPW
+#define CREC_LAZY_SPW 16 // slots per workgroup at 4 < d <= 128: S-big kernel 19.5 / 17.7 / 18.6 us at 8 / 16 / 32 (tools/lazy_variants.sh)
+#endif
+inline int lazy_spw(int d) { return d <= 4 ? 64 : (d > 128 ? 16 : (d > 64 && CREC_LAZY_SPW > 32 ? 32 : CREC_LAZY_SPW)); }
 
 IndexWs layout_index(void *base, int64_t nbc, int64_t B, int64_t U, int64_t I, bool dense, int CH, int wide_rows = 0,
                      int wide_total = 0, int spw = 32)
@@ -1643,7 +1646,8 @@ __device__ __forceinline__ void lazy_role_tail(const Tables &t, int d, bool act,
 // bpr_triples_lazy: a lane group per processing slot; a workgroup = SPW slots (IndexWs::order, ::nslots); ud / id / jd: the
 // triples' three roles by batch position.
 template <int LPR> struct LazyGeo {
-    static constexpr int SPW = LPR == 1 ? 64 : (LPR == 64 ? 16 : 32), THREADS = SPW * LPR; // = lazy_spw(d)
+    static constexpr int SPW = LPR == 1 ? 64 : (LPR == 64 ? 16 : (LPR == 32 && CREC_LAZY_SPW > 32 ? 32 : CREC_LAZY_SPW)),
+                         THREADS = SPW * LPR; // = lazy_spw(d)
 };
 
 template <int LPR, bool FULL, bool DEFER>
