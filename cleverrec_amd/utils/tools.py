@@ -71,7 +71,9 @@ def get_initializer(init_method, stddev=None, generator=None):
             lim = math.sqrt(6.0 / (fi + fo))
             return torch.empty(shape).uniform_(-lim, lim, generator=g)
         if init_method == "xavier_normal":
-            sd = math.sqrt(2.0 / (fi + fo))
+            # tf.contrib.layers.xavier_initializer(uniform=False) = variance_scaling_initializer(factor=1, FAN_AVG):
+            # truncated_normal(0, sqrt(1.3 * factor / n)), n = (fan_in + fan_out) / 2 -- the 1.3 makes up for the truncation
+            sd = math.sqrt(1.3 * 2.0 / (fi + fo))
             return torch.nn.init.trunc_normal_(torch.empty(shape), 0.0, sd, -2 * sd, 2 * sd, generator=g)
         raise ValueError("init_method=%r" % init_method)
     return f

@@ -233,3 +233,35 @@ def test_properties_outside_the_built_shapes_are_refused_up_front():
     with pytest.raises(ValueError):
         config.validate(dict(base, embed_size="256"), extra_width=4)  # CML widens its rows by 4 columns for evaluation
     config.validate(dict(base, embed_size="[32,64]"))  # a grid list (main_tuning.py) is validated per run
+
+
+def test_initializers_have_the_reference_distributions():
+    """get_initializer (utils/tools.py:51-63) -> the TF1 initializers' distributions: normal N(0, s^2); tnormal = the parent
+    normal N(0, s^2) cut at 2 s (std 0.8796 s); uniform U(-s, s); xavier = Glorot-uniform, limit sqrt(6 / (fan_in + fan_out));
+    xavier_normal = truncated normal of parent std sqrt(1.3 * 2 / (fan_in + fan_out)) (tf.contrib's variance_scaling, FAN_AVG).
+    TF's Philox stream itself is not reproducible (and the reference never seeds it): moments and supports are what can match."""
+    import math
+    import torch
+    from cleverrec_amd.utils.tools import get_initializer
+    g = lambda: torch.Generator().manual_seed(7)
+    n, d, s = 4000, 64, 0.05
+    x = get_initializer("normal", s, g())([n, d]).double()
+    assert abs(float(x.mean())) < 4 * s / math.sqrt(n * d) and abs(float(x.std()) / s - 1) < 0.01
+    x = get_initializer("tnormal", s, g())([n, d]).double()
+    assert float(x.abs().max()) <= 2 * s and abs(float(x.std()) / (0.8796 * s) - 1) < 0.01
+    x = get_initializer("uniform", s, g())([n, d]).double()
+    assert float(x.abs().max()) <= s and abs(float(x.std()) / (s / math.sqrt(3)) - 1) < 0.01
+    lim = math.sqrt(6.0 / (n + d))
+    for name in ("xavier", "xavier_uniform"):  # the shipped NCF confs say xavier_uniform, which the reference does not handle (SURVEY 2.3)
+        x = get_initializer(name, s, g())([n, d]).double()
+        assert float(x.abs().max()) <= lim and abs(float(x.std()) / (lim / math.sqrt(3)) - 1) < 0.01
+    sd = math.sqrt(1.3 * 2.0 / (n + d))
+    x = get_initializer("xavier_normal", s, g())([n, d]).double()
+    assert float(x.abs().max()) <= 2 * sd and abs(float(x.std()) / (0.8796 * sd) - 1) < 0.01
+    # a vector (biases, h) takes fan_in = fan_out = its length; the same generator state gives the same tensor
+    x = get_initializer("xavier", s, g())([d]).double()
+    assert float(x.abs().max()) <= math.sqrt(6.0 / (2 * d))
+    assert torch.equal(get_initializer("normal", s, g())([8, 4]), get_initializer("normal", s, g())([8, 4]))
+    assert get_initializer("normal", s)([3, 5]).dtype == torch.float32
+    with pytest.raises(ValueError):
+        get_initializer("he_uniform", s)([2, 2])  # conf/SBPR.properties mentions it in a comment; the reference returns None and fails
