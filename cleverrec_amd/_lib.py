@@ -79,6 +79,7 @@ _SIGNATURES = {
     "crec_sample_pairwise": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, C.c_int, _vp, _vp, _vp, C.POINTER(_i64)]),
     "crec_sample_pointwise": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, C.c_int, _vp, _vp, _vp, C.POINTER(_i64)]),
     "crec_sample_cml": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, C.c_int, _vp, _vp, _vp, C.POINTER(_i64)]),
+    "crec_sample_sbpr": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i64)]),
     "crec_sample_negatives_device": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
     "crec_bpr_train_epoch": (C.c_int, [_vp, C.POINTER(BprTables), C.POINTER(Adam), _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "crec_bpr_train_epoch_deferred": (C.c_int, [_vp, C.POINTER(BprTables), C.POINTER(BprDeferred), C.POINTER(Adam), _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
@@ -222,6 +223,20 @@ class Context:
         y = self.alloc(max(cap, 1), np.float32)
         n, u, i = self._sample(self.lib.crec_sample_pointwise, csr, item_nums, neg_ratio, cap, y)
         return u[:n], i[:n], y[:n]
+
+    def sample_sbpr(self, csr, item_nums, neg_ratio, spu_csr):
+        """ranking_sampler_sbpr: spu_csr = (spu_ptr int64 [n_users+1], spu_items int32, spu_suk int32), rows parallel to csr's."""
+        keys, ptr, items = csr
+        spu_ptr, spu_items, spu_suk = spu_csr
+        cap = int(ptr[-1]) * neg_ratio
+        u, i, k, j = (self.alloc(max(cap, 1), np.int32) for _ in range(4))
+        suk = self.alloc(max(cap, 1), np.float32)
+        n = C.c_int64()
+        self.check(self.lib.crec_sample_sbpr(self.h, _np(ptr), _np(items), len(keys), _np(keys), int(item_nums), int(neg_ratio),
+                                             _np(spu_ptr), _np(spu_items), _np(spu_suk), _np(u), _np(i), _np(k), _np(j), _np(suk),
+                                             C.byref(n)))
+        n = n.value
+        return u[:n], i[:n], k[:n], j[:n], suk[:n]
 
     def sample_cml(self, csr, item_nums, neg_ratio):
         cap = int(csr[1][-1])

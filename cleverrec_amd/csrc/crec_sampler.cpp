@@ -385,6 +385,81 @@ int crec_sample_pointwise(crec_ctx *ctx, const int64_t *ptr, const int32_t *item
     return CREC_OK;
 }
 
+// ranking_sampler_sbpr (utils/sampler.py:102-141).  Users without an SPu list are skipped (:106-107); per positive and
+// repetition: s = randint(len(spu)) (no word drawn when the list has one entry), then neg = randint(item_nums) redrawn
+// while it is a train item or an SPu item of the user (:113-119; no distinctness among the repetitions); the social
+// coefficient of the drawn item is a property of (user, item) and comes precomputed (spu_suk); then one permutation.
+int crec_sample_sbpr(crec_ctx *ctx, const int64_t *ptr, const int32_t *items, int64_t n_users, const int32_t *user_ids,
+                     int32_t item_nums, int neg_ratio, const int64_t *spu_ptr, const int32_t *spu_items, const int32_t *spu_suk,
+                     int32_t *u, int32_t *i, int32_t *i_s, int32_t *i_neg, float *suk, int64_t *n_out)
+{
+    if (!ctx)
+        return CREC_EINVAL;
+    Csr c{ptr, items, n_users, user_ids, item_nums};
+    if (int rc = check_csr(ctx, c, neg_ratio, u, i, i_neg, n_out))
+        return rc;
+    CREC_REQUIRE(ctx, spu_ptr && i_s && suk && (spu_ptr[n_users] == 0 || (spu_items && spu_suk)), "null argument");
+    int64_t n = 0;
+    for (int64_t k = 0; k < n_users; ++k) {
+        CREC_REQUIRE(ctx, spu_ptr[k + 1] >= spu_ptr[k], "spu_ptr not monotone at %lld", (long long)k);
+        if (spu_ptr[k + 1] > spu_ptr[k])
+            n += (ptr[k + 1] - ptr[k]) * neg_ratio;
+    }
+    for (int64_t e = 0; e < spu_ptr[n_users]; ++e)
+        CREC_REQUIRE(ctx, spu_items[e] >= 0 && spu_items[e] < item_nums, "SPu item %d out of range", spu_items[e]);
+    CREC_REQUIRE(ctx, n <= 0xffffffffLL, "epoch too large for a 32-bit permutation");
+    auto stamp = alloc<int32_t>(item_nums, true);
+    auto edge = alloc<int32_t>(n);   // instance -> position of its positive in `items`
+    auto soc = alloc<int32_t>(n);    // instance -> position of its social item in spu_items
+    auto neg = alloc<int32_t>(n);
+    auto perm = alloc<uint32_t>(n);
+    auto eu = edge_users(c);
+    if (!stamp || !edge || !soc || !neg || !perm || !eu)
+        return crec_fail(ctx, CREC_ENOMEM, "host allocation failed");
+    const uint32_t max = (uint32_t)(item_nums - 1), mask = mask_of(max);
+    int64_t out = 0;
+    for (int64_t k = 0; k < n_users; ++k) {
+        const int64_t ns = spu_ptr[k + 1] - spu_ptr[k];
+        if (ns == 0)
+            continue; // `if u not in SPu: continue`
+        const int32_t tag = (int32_t)(k + 1);
+        int64_t uniq = 0;
+        for (int64_t e = ptr[k]; e < ptr[k + 1]; ++e) {
+            uniq += (stamp[items[e]] != tag);
+            stamp[items[e]] = tag; // tru
+        }
+        for (int64_t e = spu_ptr[k]; e < spu_ptr[k + 1]; ++e) {
+            uniq += (stamp[spu_items[e]] != tag);
+            stamp[spu_items[e]] = tag; // spu
+        }
+        if (ptr[k + 1] > ptr[k] && uniq >= item_nums)
+            return crec_fail(ctx, CREC_EINVAL, "a user's train and social items cover the catalogue: no negative exists");
+        const uint32_t smax = (uint32_t)(ns - 1), smask = mask_of(smax);
+        for (int64_t e = ptr[k]; e < ptr[k + 1]; ++e) {
+            for (int t = 0; t < neg_ratio; ++t) {
+                edge[out] = (int32_t)e;
+                soc[out] = (int32_t)(spu_ptr[k] + draw(ctx->rng, smax, smask));
+                int32_t j;
+                do {
+                    j = (int32_t)draw(ctx->rng, max, mask);
+                } while (stamp[j] == tag);
+                neg[out] = j;
+                ++out;
+            }
+        }
+    }
+    const int32_t *edgep = edge.get(), *socp = soc.get(), *negp = neg.get(), *eup = eu.get();
+    shuffled_apply(ctx->rng, n, perm.get(), [=](int64_t k, uint32_t sidx) { // sampler.py:132-138
+        u[k] = eup[edgep[sidx]];
+        i[k] = items[edgep[sidx]];
+        i_s[k] = spu_items[socp[sidx]];
+        i_neg[k] = negp[sidx];
+        suk[k] = (float)spu_suk[socp[sidx]];
+    });
+    *n_out = n;
+    return CREC_OK;
+}
+
 int crec_sample_cml(crec_ctx *ctx, const int64_t *ptr, const int32_t *items, int64_t n_users, const int32_t *user_ids,
                     int32_t item_nums, int neg_ratio, int32_t *u, int32_t *i, int32_t *neg_out, int64_t *n_out)
 {

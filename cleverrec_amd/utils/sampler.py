@@ -49,6 +49,21 @@ def _with_numpy_stream(fn):
     return out
 
 
+def ranking_sampler_sbpr(data, SPu, neg_ratio, batch_size, is_suk=True):
+    """utils/sampler.py:102-141 -> (train_batches, u, i, i_s, i_neg[, suk]).  SPu: utils/tools.get_SPu(data) (list order matters)."""
+    from .tools import spu_csr
+    cache = getattr(data, "_spu_csr", None)
+    if cache is None or cache[0] is not SPu:
+        cache = (SPu, spu_csr(data, SPu))
+        try:
+            data._spu_csr = cache
+        except AttributeError:
+            pass
+    u, i, k, j, suk = _with_numpy_stream(lambda c: c.sample_sbpr(_csr(data), data.item_nums, neg_ratio, cache[1]))
+    nb = math.ceil(len(u) / batch_size)
+    return (nb, u, i, k, j, suk) if is_suk else (nb, u, i, k, j)
+
+
 _KINDS = {"pairwise": "sample_pairwise", "pointwise": "sample_pointwise", "cml": "sample_cml"}
 
 

@@ -77,3 +77,42 @@ def get_initializer(init_method, stddev=None, generator=None):
             return torch.nn.init.trunc_normal_(torch.empty(shape), 0.0, sd, -2 * sd, 2 * sd, generator=g)
         raise ValueError("init_method=%r" % init_method)
     return f
+
+
+def get_SPu(data):
+    """utils/tools.py:116-127: per user the items its friends consumed and it did not, as a LIST -- in the order CPython
+    iterates the set the reference builds, because ranking_sampler_sbpr indexes that list with the drawn position
+    (utils/sampler.py:114-116).  The set arithmetic is therefore the reference's, operation for operation (the
+    difference is taken after every friend, which changes the order elements enter the set)."""
+    SPu = {}
+    for u in data.ui_train:
+        u_s_items = set()
+        if u in data.user_friends:
+            for friend in data.user_friends[u]:
+                if friend not in data.ui_train:
+                    continue
+                u_s_items = u_s_items.union(set(data.ui_train[friend])).difference(set(data.ui_train[u]))
+            if u_s_items:
+                SPu[u] = list(u_s_items)
+    return SPu
+
+
+def spu_csr(data, SPu):
+    """(spu_ptr, spu_items, spu_suk) for crec_sample_sbpr: the SPu lists as rows parallel to ui_train's iteration order,
+    and per entry the social coefficient suk = the number of the user's friends (with training items) who consumed it
+    (utils/sampler.py:122-129)."""
+    import numpy as np
+    ptr, items, suk = [0], [], []
+    sets = {}
+    for u in data.ui_train:
+        lst = SPu.get(u, [])
+        friends = [f for f in data.user_friends.get(u, []) if f in data.ui_train]
+        for f in friends:
+            if f not in sets:
+                sets[f] = set(data.ui_train[f])
+        for it in lst:
+            items.append(it)
+            suk.append(sum(1 for f in friends if it in sets[f]))  # a friend listed twice counts twice, as in the reference's loop
+        ptr.append(len(items))
+    return (np.asarray(ptr, np.int64), np.asarray(items if items else [0], np.int32)[:len(items)],
+            np.asarray(suk if suk else [0], np.int32)[:len(suk)])

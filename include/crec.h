@@ -111,6 +111,17 @@ int crec_sample_pointwise(crec_ctx *ctx, const int64_t *ptr, const int32_t *item
 int crec_sample_cml(crec_ctx *ctx, const int64_t *ptr, const int32_t *items, int64_t n_users, const int32_t *user_ids,
                     int32_t item_nums, int neg_ratio, int32_t *u, int32_t *i, int32_t *neg, int64_t *n_out);
 
+/* SBPR's sampler (utils/sampler.py:102-141): per training positive of a user that has social items
+ * (SPu = items the user's friends consumed and the user did not, utils/tools.py:116-127) and repetition: a social item
+ * drawn from the user's SPu list, then a negative outside train and SPu items; spu_ptr / spu_items: the SPu lists as a CSR
+ * parallel to the ui_train CSR (users without SPu: empty rows, skipped like `if u not in SPu: continue`), IN THE
+ * REFERENCE'S LIST ORDER (the index of the drawn element is what the stream decides); spu_suk: per SPu entry the number
+ * of the user's friends who consumed it (the social coefficient suk, :122-129, a property of (user, item)).
+ * Capacity n_pos*neg_ratio each; suk as float (the dtype of the `suk` placeholder, SBPR.py:26). */
+int crec_sample_sbpr(crec_ctx *ctx, const int64_t *ptr, const int32_t *items, int64_t n_users, const int32_t *user_ids,
+                     int32_t item_nums, int neg_ratio, const int64_t *spu_ptr, const int32_t *spu_items, const int32_t *spu_suk,
+                     int32_t *u, int32_t *i, int32_t *i_s, int32_t *i_neg, float *suk, int64_t *n_out);
+
 /* ---- device-side negative sampling (optional; NOT stream-compatible with the reference) --------------
  * Same acceptance rule as utils/sampler.py:18-31,50-66,82-93 -- neg_ratio items per training positive, uniform over
  * the catalogue, redrawn while seen by the user or already in the positive's group -- but drawn from a counter-based

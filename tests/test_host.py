@@ -265,3 +265,28 @@ def test_initializers_have_the_reference_distributions():
     assert get_initializer("normal", s)([3, 5]).dtype == torch.float32
     with pytest.raises(ValueError):
         get_initializer("he_uniform", s)([2, 2])  # conf/SBPR.properties mentions it in a comment; the reference returns None and fails
+
+
+@pytest.mark.parametrize("name", ["sampler_sbpr", "sampler_sbpr_tiny"])
+def test_sbpr_sampler_matches_reference_stream(golden_dir, name):
+    """get_SPu + ranking_sampler_sbpr (utils/tools.py:116-127, utils/sampler.py:102-141) against vectors generated by the
+    reference itself: the SPu lists in the reference's list order, the five shuffled columns, and where np.random stands."""
+    from cleverrec_amd.utils.tools import get_SPu
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+
+    class D:
+        pass
+    d = D()
+    rows = lambda k, p, v: {int(key): v[p[n]:p[n + 1]].tolist() for n, key in enumerate(k)}
+    d.ui_train = rows(g["keys"], g["ptr"], g["items"])
+    d.user_friends = rows(g["f_keys"], g["f_ptr"], g["f_items"])
+    d.item_nums = int(g["item_nums"])
+    SPu = get_SPu(d)
+    assert SPu == rows(g["spu_keys"], g["spu_ptr"], g["spu_items"])  # same users, same LIST order
+    assert list(SPu.keys()) == [int(k) for k in g["spu_keys"]]
+    np.random.seed(int(g["seed"]))
+    nb, u, i, i_s, i_neg, suk = S.ranking_sampler_sbpr(d, SPu, int(g["neg_ratio"]), int(g["batch"]))
+    assert nb == int(g["batches"])
+    for got, want in ((u, "u"), (i, "i"), (i_s, "i_s"), (i_neg, "i_neg"), (suk, "suk")):
+        assert np.array_equal(np.asarray(got).astype(np.int64), g[want]), want
+    assert int(np.random.randint(2 ** 30)) == int(g["next"])

@@ -84,6 +84,35 @@ def sampler_case(sampler, name, ui, item_nums, seed, neg_ratio, batch):
     return name, out
 
 
+def sbpr_case(sampler, seed=5, n_users=60, n_items=80, neg_ratio=3, batch=64):
+    """ranking_sampler_sbpr (utils/sampler.py:102-141) with get_SPu (utils/tools.py:116-127) on a synthetic trust graph:
+    inputs (ui_train, user_friends), the reference's SPu lists IN THEIR LIST ORDER (a Python set turned into a list),
+    the five shuffled columns and the next np.random draw."""
+    import utils.tools as tools
+    g = np.random.Generator(np.random.PCG64(seed))
+    ui = synth_ui(seed, n_users, n_items, 2, 9, skip_every=7)
+    friends = {}
+    for u in range(n_users):
+        if u % 5 == 4:
+            continue  # users without friends
+        k = int(g.integers(1, 6))
+        friends[u] = [int(x) for x in g.choice(n_users, size=k, replace=False) if int(x) != u]
+        if not friends[u]:
+            del friends[u]
+    d = Data()
+    d.ui_train, d.item_nums, d.user_friends = ui, n_items, friends
+    SPu = tools.get_SPu(d)
+    np.random.seed(seed)
+    nb, u, i, i_s, i_neg, suk = sampler.ranking_sampler_sbpr(d, SPu, neg_ratio, batch)
+    nxt = np.random.randint(2 ** 30)
+    keys, ptr, items = csr(ui)
+    fk, fp, fi = csr(friends)
+    sk, sp, si = csr(SPu)
+    return dict(keys=keys, ptr=ptr, items=items, item_nums=n_items, f_keys=fk, f_ptr=fp, f_items=fi, spu_keys=sk, spu_ptr=sp,
+                spu_items=si, seed=seed, neg_ratio=neg_ratio, batch=batch, batches=nb, u=u.astype(np.int64), i=i.astype(np.int64),
+                i_s=i_s.astype(np.int64), i_neg=i_neg.astype(np.int64), suk=suk.astype(np.int64), next=nxt)
+
+
 def metrics_cases(metrics, n=400):
     g = np.random.Generator(np.random.PCG64(7))
     cases = [([5], [1, 5, 3], 3), ([5, 8, 9], [9, 2, 5, 7, 1, 0, 3, 4, 6, 10], 10), ([1, 2], [7, 8], 2),
@@ -251,6 +280,8 @@ def main():
     ]
     for name, out in cases:
         np.savez_compressed(os.path.join(a.out, "sampler_%s.npz" % name), **out)
+    np.savez_compressed(os.path.join(a.out, "sampler_sbpr.npz"), **sbpr_case(sampler))
+    np.savez_compressed(os.path.join(a.out, "sampler_sbpr_tiny.npz"), **sbpr_case(sampler, seed=11, n_users=9, n_items=40, neg_ratio=2, batch=8))
     with open(os.path.join(a.out, "metrics.json"), "w") as f:
         json.dump(metrics_cases(metrics), f)
     np.savez_compressed(os.path.join(a.out, "preprocess_syn.npz"), **preprocess_case(a.ref))
