@@ -58,6 +58,10 @@ class Fm(C.Structure):
     _fields_ = [("w0", Param), ("wi", Param), ("vif", Param), ("reg", C.c_float)]
 
 
+class Sbpr(C.Structure):
+    _fields_ = [("P", Param), ("Q", Param), ("bias", Param), ("reg", C.c_float)]
+
+
 class Cml(C.Structure):
     _fields_ = [("P", Param), ("Q", Param), ("reg", C.c_float), ("margin", C.c_float)]
 
@@ -93,6 +97,7 @@ _SIGNATURES = {
     "crec_fm_predict": (C.c_int, [_vp, C.POINTER(Fm), _vp, _vp, _i64, _i32, _vp, _vp]),
     "crec_rmse_mae": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "crec_cml_train_epoch": (C.c_int, [_vp, C.POINTER(Cml), C.POINTER(Adam), _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
+    "crec_sbpr_train_epoch": (C.c_int, [_vp, C.POINTER(Sbpr), C.POINTER(Adam), _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "crec_cml_eval_tables": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp]),
     "crec_bpr_train_epoch_dp": (C.c_int, [_vp, C.POINTER(BprTables), C.POINTER(Adam), _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "crec_comm_unique_id": (C.c_int, [_vp, _vp]),

@@ -27,6 +27,7 @@ SOURCES = {
     "ncf.hip": ["-ffp-contract=off"],
     "fm.hip": ["-ffp-contract=off"],
     "cml.hip": ["-ffp-contract=off"],
+    "sbpr.hip": ["-ffp-contract=off"],
     "ncf_eval.hip": [],
 }
 

@@ -59,6 +59,7 @@ struct crec_scalar_job { // a [rows] vector treated as a one-column table (FM's 
     const float *contrib; // [slots]
     float *sq_out;
     crec_rows_opt o;
+    int32_t chunks; // index chunks of this batch (0 is read as 1): rowseg is [chunks][rows]
 };
 
 constexpr int CREC_APPLY_MAX_TABLES = 4;

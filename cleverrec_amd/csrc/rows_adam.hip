@@ -382,10 +382,12 @@ __device__ __forceinline__ void scalar_rows_block(const crec_scalar_job &j, int 
     const int64_t r = (int64_t)blk * 256 + threadIdx.x;
     if (r >= j.rows)
         return;
-    const int2 rs = j.rowseg[r];
     float g = 0.f;
-    for (int k = rs.x; k < rs.x + rs.y; ++k)
-        g = g + j.contrib[j.order[k]];
+    for (int ch = 0; ch < (j.chunks > 1 ? j.chunks : 1); ++ch) { // chunk by chunk = ascending slot order
+        const int2 rs = j.rowseg[(int64_t)ch * j.rows + r];
+        for (int k = rs.x; k < rs.x + rs.y; ++k)
+            g = g + j.contrib[j.order[k]];
+    }
     const float w = j.var[r];
     if (j.sq_out)
         j.sq_out[r] = w * w;

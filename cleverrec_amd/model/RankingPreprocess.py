@@ -50,8 +50,15 @@ class RankingPreprocess(RankingData):
         user_map, item_map = re_index(user_set_), re_index(item_set_)
         ratings.u_id = ratings.u_id.map(lambda x: user_map[x])
         ratings.i_id = ratings.i_id.map(lambda x: item_map[x])
-        if 'social_file' in c:
-            raise NotImplementedError('social_file: the trust graph serves SBPR/SAMN-type models, outside this core')
+        if 'social_file' in c:  # the trust graph (RankingPreprocess.py:49-57): pairs whose both ends survived the filters, re-indexed
+            trusts = pd.read_csv(os.path.join(self.file_path, c['social_file']), sep=c['data.sep'], header=0, names=['u_id', 'v_id'],
+                                 usecols=[0, 1])
+            trusts = trusts[trusts.u_id.isin(user_set_) & trusts.v_id.isin(user_set_)]
+            trusts.u_id = trusts.u_id.map(lambda x: user_map[x])
+            trusts.v_id = trusts.v_id.map(lambda x: user_map[x])
+            self.user_friends = trusts.groupby('u_id').v_id.apply(list).to_dict()
+            if c['recommender'] == 'SAMN':
+                raise NotImplementedError('SAMN pads user_friends to a fixed width (RankingPreprocess.py:59-67): outside this core')
         return ratings, set(ratings.i_id.unique())
 
     @staticmethod

@@ -253,6 +253,33 @@ class CmlState:
         return Pa, Qa
 
 
+class SbprState:
+    """P, Q, bias of model/ranking/SBPR.py:31-37 with Adam slots in HBM (crec_sbpr)."""
+
+    def __init__(self, sess, P0, Q0, bias0, lr, reg, beta1=0.9, beta2=0.999, eps=1e-8):
+        self.sess = sess
+        f32 = torch.float32
+        self.P, self.Q = sess.to_dev(P0, f32).contiguous(), sess.to_dev(Q0, f32).contiguous()
+        self.bias = sess.to_dev(np.asarray(bias0, dtype=np.float32).reshape(-1), f32)
+        self.slots = {k: (torch.zeros_like(t), torch.zeros_like(t)) for k, t in (("P", self.P), ("Q", self.Q), ("bias", self.bias))}
+
+        def par(name, t, rows, cols):
+            m, v = self.slots[name]
+            return _lib.Param(t.data_ptr(), m.data_ptr(), v.data_ptr(), rows, cols)
+        self.model = _lib.Sbpr(par("P", self.P, self.P.shape[0], self.P.shape[1]), par("Q", self.Q, self.Q.shape[0], self.Q.shape[1]),
+                               par("bias", self.bias, self.bias.numel(), 1), reg)
+        self.adam = _lib.Adam(lr, beta1, beta2, eps, 0.0, _lib.ADAM_TF1, beta1, beta2, 0)
+
+    def train_epoch(self, u, i, k, j, suk, batch_size):
+        """u, i, k, j int32 [N], suk fp32 [N] (device) -> per-batch losses (device fp32)."""
+        s = self.sess
+        n = int(u.numel())
+        loss = s.empty((-(-n // batch_size),), torch.float32)
+        s.ctx.check(s.lib.crec_sbpr_train_epoch(s.ctx.h, C.byref(self.model), C.byref(self.adam), s.ptr(u), s.ptr(i), s.ptr(k),
+                                                s.ptr(j), s.ptr(suk), n, int(batch_size), s.ptr(loss), s.stream_ptr()))
+        return loss
+
+
 def ncf_scores(sess, state, users):
     """crec_ncf_scores -> logits [Bt, I] (device fp32); pre_scores = sigmoid(logits) ranks identically."""
     Bt = int(users.numel())

@@ -273,6 +273,20 @@ int crec_cml_train_epoch(crec_ctx *ctx, const crec_cml *model, crec_adam *opt, c
 int crec_cml_eval_tables(crec_ctx *ctx, const float *P, const float *Q, int64_t U, int64_t I, int32_t d, int32_t clip_users,
                          float *P_aug, float *Q_aug, void *stream);
 
+/* ---- Social BPR (device) -------------------------------------------------------------------
+ * replaces sess.run([self.train, self.loss], {u_idx, i_idx, i_s_idx, i_neg_idx, suk}) (train_model_sbpr,
+ * model/RankingRecommender.py:101-116) on the graph of model/ranking/SBPR.py:31-55: scores p.q + bias, two log-sigmoid
+ * terms ((x_ui - x_uk)/suk and x_uk - x_uj), l2 on the gathered rows and biases, AdamOptimizer on IndexedSlices (P
+ * 'sbpr_params/P', Q, and bias [item_nums + 1]: every row decays and moves each step).  u, i, k (social item), j int32 [N],
+ * suk float [N] from crec_sample_sbpr; B <= 8192.  rs-evaluation is BPR's (pre_scores = u_embed @ Q^T, SBPR.py:57-61). */
+typedef struct {
+    crec_param P, Q, bias; /* bias: rows >= Q.rows, cols = 1 */
+    float reg;
+} crec_sbpr;
+int crec_sbpr_train_epoch(crec_ctx *ctx, const crec_sbpr *model, crec_adam *opt, const int32_t *u, const int32_t *i,
+                          const int32_t *k, const int32_t *j, const float *suk, int64_t N, int32_t B, float *loss_per_batch,
+                          void *stream);
+
 /* ---- data-parallel training over RCCL (one process per GPU of one node) -----------------------
  * The path shards with one real exchange: gradients of the same Q row must be summed over all ranks'
  * triples before Adam.  Users (rows of P, their slots, their triples) are sharded over ranks, Q and its

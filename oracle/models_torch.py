@@ -283,6 +283,27 @@ class CML(Model):
         return ((P[int(u)][None, :] - Q[torch.as_tensor(np.asarray(items), dtype=torch.long)]) ** 2).sum(1).numpy()
 
 
+class SBPR(Model):
+    """model/ranking/SBPR.py:31-55: x = p.q + bias; loss = sum -log sigmoid((x_ui - x_uk)/suk) + sum -log sigmoid(x_uk - x_uj)
+    + reg*(l2 of the four gathered rows and the three gathered biases).  All three variables are reached through tf.gather:
+    IndexedSlices Adam (every row swept)."""
+
+    def __init__(self, P, Q, bias, lr, reg):
+        super().__init__({"P": P, "Q": Q, "bias": bias}, {"P": "sparse", "Q": "sparse", "bias": "sparse"}, lr)
+        self.reg = reg
+
+    def loss(self, w, u, i, k, j, suk):
+        u, i, k, j = (torch.as_tensor(np.asarray(x), dtype=torch.long) for x in (u, i, k, j))
+        suk = self._float(suk)
+        pu = gather(w, "P", u)
+        qi, qk, qj = gather(w, "Q", i), gather(w, "Q", k), gather(w, "Q", j)
+        bi, bk, bj = gather(w, "bias", i), gather(w, "bias", k), gather(w, "bias", j)
+        xi, xk, xj = (pu * qi).sum(1) + bi, (pu * qk).sum(1) + bk, (pu * qj).sum(1) + bj
+        sp = torch.nn.functional.softplus
+        return sp(-(xi - xk) / suk).sum() + sp(-(xk - xj)).sum() + \
+            self.reg * (_l2(pu) + _l2(qi) + _l2(qk) + _l2(qj) + _l2(bi) + _l2(bk) + _l2(bj))
+
+
 class FM(Model):
     """model/rating/FM.py:20-53: y = w0 + sum_f wi[x_f] + 0.5*sum_k[(sum_f x v)^2 - sum_f x^2 v^2] (the linear
     term ignores x_value, :35,49); loss = sum (y - y_pre)^2 + reg*(l2(wi) + l2(vif)) over the FULL tables (:52)

@@ -1,0 +1,70 @@
+"""Social BPR (model/ranking/SBPR.py) on the GPU against the torch-autograd restatement of its graph with TF1 Adam on
+IndexedSlices (oracle/models_torch.py); index streams from the reference-pinned sampler (tests/test_host.py)."""
+import logging
+
+import numpy as np
+import pytest
+
+import oracle
+from oracle import models_torch as MT
+from cleverrec_amd import runtime
+from cleverrec_amd.data import RankingData
+from _adam_close import assert_adam_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sess():
+    s = runtime.Session(0)
+    yield s
+    s.close()
+
+
+@pytest.mark.parametrize("d,B", [(16, 200), (128, 512)])
+def test_sbpr_steps_match_oracle(sess, d, B):
+    g = np.random.Generator(np.random.PCG64(d))
+    U, I, N = 80, 60, 2 * B + 37  # a ragged last batch; 3 * B item slots > 2048: several index chunks at B = 512... and one at 200
+    P, Q = (g.standard_normal((U, d)) * 0.1).astype(np.float32), (g.standard_normal((I, d)) * 0.1).astype(np.float32)
+    bias = (g.standard_normal(I + 1) * 0.05).astype(np.float32)
+    u, i, k, j = (g.integers(0, n, N).astype(np.int32) for n in (U, I, I, I))
+    suk = g.integers(1, 4, N).astype(np.float32)
+    st = runtime.SbprState(sess, P, Q, bias, lr=1e-3, reg=0.05)
+    om = MT.SBPR(P, Q, bias, lr=1e-3, reg=0.05)
+    loss = st.train_epoch(*(sess.to_dev(x) for x in (u, i, k, j, suk)), B).cpu().numpy()
+    ol = [om.step(*(x[b * B:(b + 1) * B] for x in (u, i, k, j, suk))) for b in range(len(loss))]
+    np.testing.assert_allclose(loss, ol, rtol=1e-5)
+    for name, dev in (("P", st.P), ("Q", st.Q), ("bias", st.bias)):
+        assert_adam_close(om, name, dev, *st.slots[name])
+
+
+def test_sbpr_class_surface(sess, tmp_path):
+    """SBPR(sess, data, configs, logger): get_SPu, train_model_sbpr on the np.random stream, rs evaluation (u_embed @ Q^T)."""
+    from cleverrec_amd.model.ranking.SBPR import SBPR
+    g = np.random.Generator(np.random.PCG64(3))
+    U, I, d = 90, 120, 32
+    ui_train = {uu: [int(x) for x in g.choice(I, size=int(g.integers(3, 12)), replace=False)] for uu in range(U)}
+    ui_test = {uu: [int(x) for x in g.choice(I, size=2, replace=False)] for uu in range(0, U, 2)}
+    data = RankingData(U, I, ui_train, ui_test)
+    data.user_friends = {uu: [int(x) for x in g.choice(U, size=int(g.integers(1, 5)), replace=False) if int(x) != uu]
+                         for uu in range(U) if uu % 4 != 3}
+    configs = {"recommender": "SBPR", "epoches": "1", "batch_size": "256", "test.batch_size": "64", "lr": "0.001",
+               "test.neg_samples": "0", "is_pairwise": "True", "init_method": "normal", "stddev": "0.01", "loss_func": "bpr",
+               "optimizer": "Adam", "saved_dir": str(tmp_path), "test.interval": "1", "topk": "[10,20]", "neg_ratio": "3",
+               "embed_size": str(d), "reg": "0.05", "data.split_way": "rs"}
+    m = SBPR(sess, data, configs, logging.getLogger("t"))
+    init = {"P": (g.standard_normal((U, d)) * 0.1).astype(np.float32), "Q": (g.standard_normal((I, d)) * 0.1).astype(np.float32)}
+    m.build_model(init)
+    om = MT.SBPR(init["P"], init["Q"], np.zeros(I + 1, np.float32), lr=1e-3, reg=0.05)
+    from cleverrec_amd.utils import sampler as S
+    np.random.seed(7)
+    avg = m.train_model()
+    np.random.seed(7)
+    nb, u, i, k, j, suk = S.ranking_sampler_sbpr(data, m.SPu, 3, 256)
+    tot = sum(om.step(*(x[b * 256:(b + 1) * 256] for x in (u, i, k, j, suk))) for b in range(nb))
+    assert avg == pytest.approx(tot / nb, rel=1e-5)
+    HR, MRR, NDCG = m.test_model_rs()
+    Pn, Qn = m.P.cpu().numpy(), m.Q.cpu().numpy()
+    H, M, N = oracle.test_model_rs_py(lambda cur: oracle.scores(Pn, Qn, cur, 1), m.test_users, data.ui_train, data.ui_test, [10, 20], 64)
+    np.testing.assert_allclose(np.mean(NDCG[0]), np.mean(N[0]), rtol=1e-12)
+    np.testing.assert_allclose(np.mean(HR[1]), np.mean(H[1]), rtol=1e-12)
