@@ -35,6 +35,27 @@ def test_preprocess_matches_reference_on_synthetic_csv(golden_dir, tmp_path):
         assert np.array_equal(mine, g[ref]), ref
 
 
+def test_preprocess_with_trust_file_matches_reference(golden_dir, tmp_path):
+    """social_file (RankingPreprocess.py:49-57): trust pairs whose both ends survive the rating filters, re-indexed, grouped
+    into user_friends in file order -- against the reference's own output on a synthetic ratings + trusts pair."""
+    g = np.load(os.path.join(golden_dir, "preprocess_social.npz"))
+    d = tmp_path / "syn"
+    d.mkdir()
+    with open(d / "ratings.csv", "w") as f:
+        for a, b in zip(g["csv_u"], g["csv_i"]):
+            f.write("%d,%d\n" % (a, b))
+    with open(d / "trusts.csv", "w") as f:
+        for a, b in zip(g["trust_u"], g["trust_v"]):
+            f.write("%d,%d\n" % (a, b))
+    cfg = dict(_cfg(tmp_path, "syn", "ratings.csv", ","), social_file="trusts.csv", recommender="SBPR")
+    np.random.seed(int(g["seed"]))
+    data = RankingPreprocess(cfg, logging.getLogger("t"))
+    for mine, ref in zip(data.train_csr, ("train_keys", "train_ptr", "train_items")):
+        assert np.array_equal(mine, g[ref]), ref
+    want = {int(k): g["f_items"][g["f_ptr"][n]:g["f_ptr"][n + 1]].tolist() for n, k in enumerate(g["f_keys"])}
+    assert data.user_friends == want and list(data.user_friends.keys()) == list(want.keys())
+
+
 def test_ml100k_anchor_preprocess_and_samplers(golden_dir):
     root = "/root/reference/dataset"
     if not os.path.exists(os.path.join(root, "ml-100k", "u.data")):

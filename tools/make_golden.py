@@ -133,9 +133,10 @@ def metrics_cases(metrics, n=400):
     return {"ranking": out, "rmse_mae": {"y": [1, 2, 3], "y_pre": [1.5, 2, 1], "rmse": rm[0], "mae": rm[1]}}
 
 
-def preprocess_case(ref, seed=0):
+def preprocess_case(ref, seed=0, social=False):
     """RankingPreprocess on a synthetic UI csv (first row is swallowed as a header,
-    SURVEY 2.3) -> the `data` protocol the hot path consumes."""
+    SURVEY 2.3) -> the `data` protocol the hot path consumes.  social: plus a trust file (RankingPreprocess.py:49-57):
+    pairs over a wider id range than the ratings', so that the invalid-user filter and the re-indexing are exercised."""
     from model.RankingPreprocess import RankingPreprocess
     g = np.random.Generator(np.random.PCG64(11))
     rows = set()
@@ -152,11 +153,23 @@ def preprocess_case(ref, seed=0):
            "data.split_by_time": "False", "data.user_min": "0", "data.item_min": "5", "test.neg_samples": "0",
            "recommender": "BPR"}
     logger = logging.getLogger("golden")
+    extra = {}
+    if social:
+        pairs = [(int(g.integers(90, 280)), int(g.integers(90, 280))) for _ in range(900)]
+        with open(os.path.join(tmp, "syn", "trusts.csv"), "w") as f:
+            for a, b in pairs:
+                f.write("%d,%d\n" % (a, b))
+        cfg["social_file"] = "trusts.csv"
+        cfg["recommender"] = "SBPR"
+        extra.update(trust_u=np.array([p[0] for p in pairs], dtype=np.int64), trust_v=np.array([p[1] for p in pairs], dtype=np.int64))
     np.random.seed(seed)
     d = RankingPreprocess(cfg, logger)
     tk, tp, ti = csr(d.ui_train)
     sk, sp, si = csr(d.ui_test)
-    return {"csv_u": np.array([r[0] for r in rows], dtype=np.int64), "csv_i": np.array([r[1] for r in rows], dtype=np.int64),
+    if social:
+        fk, fp, fi = csr(d.user_friends)
+        extra.update(f_keys=fk, f_ptr=fp, f_items=fi)
+    return {**extra, "csv_u": np.array([r[0] for r in rows], dtype=np.int64), "csv_i": np.array([r[1] for r in rows], dtype=np.int64),
             "seed": seed, "user_nums": d.user_nums, "item_nums": d.item_nums, "train_keys": tk, "train_ptr": tp,
             "train_items": ti, "test_keys": sk, "test_ptr": sp, "test_items": si}
 
@@ -285,6 +298,7 @@ def main():
     with open(os.path.join(a.out, "metrics.json"), "w") as f:
         json.dump(metrics_cases(metrics), f)
     np.savez_compressed(os.path.join(a.out, "preprocess_syn.npz"), **preprocess_case(a.ref))
+    np.savez_compressed(os.path.join(a.out, "preprocess_social.npz"), **preprocess_case(a.ref, social=True))
     np.savez_compressed(os.path.join(a.out, "rating_syn.npz"), **rating_case(a.ref))
     with open(os.path.join(a.out, "libfm_syn.json"), "w") as f:
         json.dump(libfm_case(a.ref), f)
