@@ -33,7 +33,7 @@ def main():
         d = int(g.choice([4, 8, 12, 16, 32, 64, 128, 256]))
         B = int(g.choice([1, 7, 64, 333, 1000, 2048, 6144, 8192]))
         nr = int(g.integers(1, 5))
-        mode = str(g.choice(["tf1", "lazy"]))
+        mode = str(g.choice(["tf1", "lazy", "lazy", "sgd", "adagrad"]))  # lazy twice: the one-launch triple pass is this round's new kernel
         deg_hi = max(2, min(I - nr - 1, int(g.integers(2, 40))))
         ui_train = {u: [int(x) for x in g.choice(I, size=int(g.integers(1, deg_hi + 1)), replace=False)] for u in range(U) if g.random() < 0.9}
         if not ui_train:
@@ -43,7 +43,7 @@ def main():
         P0 = (g.standard_normal((U, d)) * scale).astype(np.float32)
         Q0 = (g.standard_normal((I, d)) * scale).astype(np.float32)
         st = runtime.BprState(sess, P0, Q0, lr=1e-3, reg=0.01, adam_mode=mode)
-        om = oracle.BprModel(P0, Q0, lr=1e-3, reg=0.01, adam_mode={"tf1": 0, "lazy": 1}[mode])
+        om = oracle.BprModel(P0, Q0, lr=1e-3, reg=0.01, adam_mode={"tf1": 0, "lazy": 1, "sgd": 2, "adagrad": 3}[mode])
         seed = int(g.integers(0, 2 ** 31))
         sess.ctx.seed(seed)
         rng = oracle.Rng(seed)
