@@ -147,6 +147,7 @@ int crec_ctx_create(int device, crec_ctx **out)
     ctx->knob_wide_round = env_int("CREC_WIDE_ROUND", 0);
     ctx->knob_eval_shape = env_int("CREC_EVAL_SHAPE", 0);
     ctx->knob_eval_no_bitmap = env_int("CREC_EVAL_NO_BITMAP", 0);
+    ctx->knob_ncf_generic = env_int("CREC_NCF_GENERIC", 0);
     if (device >= 0) {
         int n = 0;
         hipError_t e = hipGetDeviceCount(&n);
@@ -218,6 +219,8 @@ int crec_ctx_set_option(crec_ctx *ctx, const char *name, int64_t value)
         ctx->knob_eval_shape = (int)value;
     else if (n == "eval_no_bitmap")
         ctx->knob_eval_no_bitmap = (int)value;
+    else if (n == "ncf_generic")
+        ctx->knob_ncf_generic = (int)value;
     else
         return crec_fail(ctx, CREC_EINVAL, "unknown option '%s'", name);
     return CREC_OK;

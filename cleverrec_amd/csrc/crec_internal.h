@@ -105,6 +105,7 @@ struct crec_ctx {
     int knob_wide_round = 0;     // experiment: pad the wide groups' workgroups to a multiple of this (0: chunk maximum)
     int knob_eval_shape = 0;     // 4 / 8: force an eval_sweep workgroup shape where legal (0: choose)
     int knob_eval_no_bitmap = 0; // 1: seen filter by binary search even where the bitmaps would fit
+    int knob_ncf_generic = 0;    // 1: the generic ncf_tile even for the shapes that have a specialised one (tests)
 };
 
 int crec_fail(crec_ctx *ctx, int code, const char *fmt, ...);

@@ -31,6 +31,9 @@ constexpr int T = NCF_T;     // instances per tile
 constexpr int NT = NCF_NT;   // threads per workgroup
 constexpr int NW = NT / 64;  // waves per workgroup
 constexpr int RW = T / NW;   // tile rows owned by one wave in the row-wise phases
+#ifndef NCF_GRID_DIV
+#define NCF_GRID_DIV 1 // tiles per workgroup (grid-stride): timing experiments
+#endif
 
 __device__ inline float sigmoidf_(float z) { return 1.0f / (1.0f + expf(-z)); }
 
@@ -47,14 +50,48 @@ __device__ __forceinline__ float wave_sum(float v)
 // e / label / (u, i) per instance, the small vectors [b_0 | .. | b_{L-1} | h], and the weights of every layer.
 // Nothing in the phases below reads a parameter from global memory: with one workgroup per CU every such load
 // would be an exposed round trip.
+//
+// Shape-specialised: <L0C, LC, DGC> = (layers[0], number of layers, GMF width) fixed at compile time, or L0C < 0 = read
+// from NcfDev.  With one 32-instance tile per workgroup every phase's code runs ONCE per launch, and the generic
+// kernel spends most of a tile on bookkeeping around its few MFMAs -- offsets of the LDS arrays, block -> (row, column)
+// divisions, loop control (stamped: forward pass 10.4 k cycles, 8.5 k of them with the MFMAs removed).  With the
+// shape fixed all of that folds into immediates.
+template <int LC, class F> __device__ __forceinline__ void layers_up(int L, F f)
+{
+    if constexpr (LC >= 0) {
+        if constexpr (LC > 0) f(0);
+        if constexpr (LC > 1) f(1);
+        if constexpr (LC > 2) f(2);
+        if constexpr (LC > 3) f(3);
+    } else {
+        for (int k = 0; k < L; ++k)
+            f(k);
+    }
+}
+template <int LC, class F> __device__ __forceinline__ void layers_down(int L, F f)
+{
+    if constexpr (LC >= 0) {
+        if constexpr (LC > 3) f(3);
+        if constexpr (LC > 2) f(2);
+        if constexpr (LC > 1) f(1);
+        if constexpr (LC > 0) f(0);
+    } else {
+        for (int k = L - 1; k >= 0; --k)
+            f(k);
+    }
+}
+
+template <int L0C, int LC, int DGC>
 __global__ __launch_bounds__(NT) void ncf_tile(NcfDev m, const int32_t *__restrict__ u, const int32_t *__restrict__ i,
                                                const float *__restrict__ y, int nb, float *__restrict__ c_pg,
                                                float *__restrict__ c_qg, float *__restrict__ c_pm,
                                                float *__restrict__ c_qm, float *__restrict__ loss_inst,
                                                float *__restrict__ partial)
 {
+    constexpr bool FIXED = L0C >= 0;
+    constexpr int LCC = FIXED ? LC : -1;
     extern __shared__ float lds[];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63; // wave: scalar
 #ifdef NCF_STAMPS // debug builds: core-clock and 100 MHz stamps of tile 7 at the phase boundaries
     int stamp_n = 0;
 #define STAMP()                                                          \
@@ -73,12 +110,13 @@ __global__ __launch_bounds__(NT) void ncf_tile(NcfDev m, const int32_t *__restri
     STAMP();
     const int r0 = tile * T;
     const int nr = (nb - r0) < T ? (nb - r0) : T;
-    const bool has_g = m.kind != 1, has_m = m.kind != 0;
-    const int dg = has_g ? m.dg : 0, L = has_m ? m.n_layers : 0, hm = m.L0 / 2, ldg = dg + 1;
+    const bool has_g = FIXED ? DGC > 0 : m.kind != 1, has_m = FIXED ? LC > 0 : m.kind != 0;
+    const int L0 = FIXED ? L0C : m.L0;
+    const int dg = FIXED ? DGC : (has_g ? m.dg : 0), L = FIXED ? LC : (has_m ? m.n_layers : 0), hm = L0 / 2, ldg = dg + 1;
 
     // carve LDS (ncf_tile_lds_floats below mirrors this).  Widths halve exactly (ncf_describe), so the offsets
     // are closed-form scalar arithmetic: no pointer tables (they would live in scratch)
-    const auto width_of = [&](int k) { return has_m ? (m.L0 >> k) : 0; };
+    const auto width_of = [&](int k) { return has_m ? (L0 >> k) : 0; };
     const auto off_of = [&](int k) { // floats before A_k when the A_j are laid out back to back
         int o = 0;
         for (int j = 0; j < k; ++j)
@@ -97,6 +135,14 @@ __global__ __launch_bounds__(NT) void ncf_tile(NcfDev m, const int32_t *__restri
             o += width_of(j + 1);
         return o;
     };
+    const auto fw_of = [&](int k) { // flat offset of W_k in the parameter block [W_0 | b_0 | ... | h]; fw_of(L) = h's
+        int o = 0;
+        for (int j = 0; j < k; ++j)
+            o += width_of(j) * width_of(j + 1) + width_of(j + 1);
+        return o;
+    };
+    const auto fb_of = [&](int k) { return fw_of(k) + width_of(k) * width_of(k + 1); };
+    const int h_off = fw_of(L);
     const int last = has_m ? width_of(L) : 0;
     float *const A_base = lds;
     float *const D_base = lds + off_of(L + 1) - off_of(1); // D_k sits where an (L+1+k)-th activation would
@@ -110,41 +156,107 @@ __global__ __launch_bounds__(NT) void ncf_tile(NcfDev m, const int32_t *__restri
     float *const G_q = p;
     p += T * ldg;
     float *const e = p, *const yl = p + T;
-    int *const su = (int *)(p + 2 * T), *const si = su + T;
-    float *const b_base = (float *)(si + T);
+    float *const b_base = p + 4 * T; // (2T floats free: the layout is shared with ncf_tile_lds_floats)
     float *const hl = b_base + boff_of(L); // GMF: h_gmf[dg]; MLP: h_mlp[last]; NeuMF: h_neumf[dg + last]
     float *const W_base = hl + dg + last;
 #define WL_(k) (W_base + woff_of(k))
 #define BL_(k) (b_base + boff_of(k))
 
-    if (tid < T) {
-        const bool ok = tid < nr;
-        su[tid] = ok ? u[r0 + tid] : 0;
-        si[tid] = ok ? i[r0 + tid] : 0;
-        yl[tid] = ok ? y[r0 + tid] : 0.f;
+    // ---- prologue: everything the tile needs from memory in TWO dependent round trips (indices -> rows), the parameter
+    // block travelling beside them.  (One load loop per layer and vector, each followed by its LDS writes, was seven
+    // round trips back to back: 4.3 us of a 26 us tile.)
+    const float yv = tid < nr ? y[r0 + (tid < T ? tid : 0)] : 0.f; // (threads past T: a valid address, value unused)
+    // a wave owns RW rows of the tile, lanes run along the row.  Their indices: ONE vector load per column (lane l asks for
+    // row l % RW; a branch-free clamp keeps ragged tiles in bounds), handed round as scalars -- wave-uniform scalar loads
+    // would each wait for the one before (stamped: eight dependent trips)
+    const int rl = wave * RW + (lane % RW), rc = rl < nr ? rl : nr - 1;
+    const int myu = u[r0 + rc], myi = i[r0 + rc];
+    // the flat parameter block [W_0 | b_0 | ... | h] -> LDS (weight rows padded by one float): where flat offset o lands
+    // (float index into lds); the walk over the layers is scalar arithmetic, only the compares are per lane
+    const int W_lds = (int)(W_base - lds), b_lds = (int)(b_base - lds), h_lds = (int)(hl - lds);
+    const auto dst_of = [&](int o) {
+        int wo = 0, lw = W_lds, lb = b_lds, w = has_m ? L0 : 0, dst = -1;
+        for (int k = 0; k < L; ++k) {
+            const int kout = w >> 1, nW = w * kout, idx = o - wo;
+            const int row = (kout & (kout - 1)) == 0 ? idx >> __builtin_ctz(kout) : idx / kout;
+            const int dW = lw + row * (kout + 1) + (idx - row * kout), dB = lb + (idx - nW);
+            dst = dst < 0 && idx < nW ? dW : dst;
+            dst = dst < 0 && idx < nW + kout ? dB : dst;
+            wo += nW + kout, lw += w * (kout + 1), lb += kout, w = kout;
+        }
+        return dst < 0 ? h_lds + (o - wo) : dst;
+    };
+    bool quads = (dg & 3) == 0; // a float4 of the block never straddles a weight row or a vector
+    for (int k = 0; k < L; ++k)
+        quads = quads && (W_(k + 1) & 3) == 0;
+    constexpr int SD = 8; // float4 loads of the parameter block in flight per thread
+    const bool vec = ((uintptr_t)m.small & 15) == 0;
+    const int n_small = FIXED ? h_off + dg + last : m.n_small;
+    const int n4 = vec && quads ? n_small >> 2 : 0;
+    float4 w4[SD];
+#pragma unroll
+    for (int e = 0; e < SD; ++e) {
+        const int o4 = e * NT + tid;
+        w4[e] = ((const float4 *)m.small)[o4 < n4 ? o4 : 0]; // never predicated: a skipped load costs the ones behind it their place in the queue (vmcnt)
     }
-    // every parameter on chip for both passes; these loads overlap the index fetch
-    for (int c = tid; c < dg + last; c += NT)
-        hl[c] = m.small[m.h_off + c];
-    for (int k = 0; k < L; ++k) {
-        for (int c = tid; c < W_(k + 1); c += NT)
-            BL_(k)[c] = m.small[m.b_off[k] + c];
-        stage_weights<NT>(WL_(k), m.small + m.w_off[k], W_(k), W_(k + 1));
+    __builtin_amdgcn_sched_barrier(0);
+    int64_t ub[RW], ib[RW];
+    bool ok[RW];
+#pragma unroll
+    for (int rr = 0; rr < RW; ++rr) {
+        ok[rr] = wave * RW + rr < nr;
+        ub[rr] = __builtin_amdgcn_readlane(myu, rr);
+        ib[rr] = __builtin_amdgcn_readlane(myi, rr);
     }
-    __syncthreads();
+    // first 64 columns of every gathered row: asked for as soon as the indices are back, while the parameters travel
+    float gp[RW], gq[RW], ap[RW], aq[RW];
+    // (rows past the batch's end repeat its last row and lanes past a narrow row its last column: always a valid
+    // address, never a branch; what they load is either not stored or multiplied by e = 0 in the backward pass)
+    const int cg = lane < dg ? lane : dg - 1, cm = lane < hm ? lane : hm - 1;
+#pragma unroll
+    for (int rr = 0; rr < RW; ++rr) {
+        if (has_g) {
+            gp[rr] = m.Pg[ub[rr] * dg + cg];
+            gq[rr] = m.Qg[ib[rr] * dg + cg];
+        }
+        if (has_m) {
+            ap[rr] = m.Pm[ub[rr] * hm + cm];
+            aq[rr] = m.Qm[ib[rr] * hm + cm];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (tid < T)
+        yl[tid] = yv;
+#pragma unroll
+    for (int e = 0; e < SD; ++e) {
+        const int o4 = e * NT + tid;
+        if (o4 < n4) {
+            float *dst = lds + dst_of(4 * o4);
+            dst[0] = w4[e].x, dst[1] = w4[e].y, dst[2] = w4[e].z, dst[3] = w4[e].w;
+        }
+    }
+    for (int o4 = SD * NT + tid; o4 < n4; o4 += NT) { // wider towers: the rest of the block
+        const float4 w = ((const float4 *)m.small)[o4];
+        float *dst = lds + dst_of(4 * o4);
+        dst[0] = w.x, dst[1] = w.y, dst[2] = w.z, dst[3] = w.w;
+    }
+    for (int o = 4 * n4 + tid; o < n_small; o += NT) // odd shapes / the block's last floats
+        lds[dst_of(o)] = m.small[o];
     STAMP(); // 1: parameters staged
-    // ---- gathers: a wave owns RW rows, lanes run along the row; all RW rows' loads in flight together ------------
     {
-        int64_t ub[RW], ib[RW];
-        bool ok[RW];
 #pragma unroll
         for (int rr = 0; rr < RW; ++rr) {
             const int r = wave * RW + rr;
-            ok[rr] = r < nr;
-            ub[rr] = su[r];
-            ib[rr] = si[r];
+            if (lane < dg) {
+                G_p[r * ldg + lane] = gp[rr];
+                G_q[r * ldg + lane] = gq[rr];
+            }
+            if (has_m && lane < hm) {
+                A_(0)[r * LD_(0) + lane] = ap[rr];
+                A_(0)[r * LD_(0) + hm + lane] = aq[rr];
+            }
         }
-        for (int c = lane; c < dg; c += 64) {
+        for (int c = 64 + lane; c < dg; c += 64) { // rows wider than a wave
             float tp[RW], tq[RW];
 #pragma unroll
             for (int rr = 0; rr < RW; ++rr) {
@@ -160,7 +272,7 @@ __global__ __launch_bounds__(NT) void ncf_tile(NcfDev m, const int32_t *__restri
         if (has_m) {
             float *A0 = A_(0);
             const int ld0 = LD_(0);
-            for (int c = lane; c < hm; c += 64) {
+            for (int c = 64 + lane; c < hm; c += 64) {
                 float tp[RW], tq[RW];
 #pragma unroll
                 for (int rr = 0; rr < RW; ++rr) {
@@ -177,32 +289,46 @@ __global__ __launch_bounds__(NT) void ncf_tile(NcfDev m, const int32_t *__restri
     }
     STAMP(); // 2: rows gathered
     // ---- tower forward: A[k+1] = relu(A[k] W_k + b_k) --------------------------------------------------------
-    for (int k = 0; k < L; ++k) {
+    layers_up<LCC>(L, [&](int k) __attribute__((always_inline)) {
         const int kin = W_(k), kout = W_(k + 1), ws = kout + 1, lda = LD_(k), ldo = LD_(k + 1);
         const float *b = BL_(k), *Ak = A_(k), *Wl = WL_(k);
         float *An = A_(k + 1);
         __syncthreads(); // A[k] complete
+#if NCF_ABL == 5 // per-wave trace of the forward layers of tile 7: entry and exit of the product
+        if (m.dbg && blockIdx.x == 7 && lane == 0)
+            m.dbg[128 + wave * 16 + 2 * k] = __builtin_amdgcn_s_memtime();
+#endif
         tile_gemm<NW>(
             T, kout, kin, [&](int r, int kk) { return Ak[r * lda + kk]; }, [&](int kk, int c) { return Wl[kk * ws + c]; },
             [&](int r, int c, float s) {
                 s += b[c];
                 An[r * ldo + c] = s > 0.f ? s : 0.f;
             });
-    }
+#if NCF_ABL == 5
+        if (m.dbg && blockIdx.x == 7 && lane == 0)
+            m.dbg[128 + wave * 16 + 2 * k + 1] = __builtin_amdgcn_s_memtime();
+#endif
+#if NCF_ABL == 4
+        STAMP(); // per layer
+#endif
+    });
     __syncthreads();
     STAMP(); // 3..: forward
-    // ---- logit, e, loss: 8 lanes per instance, each over a contiguous eighth of the columns, then a fixed
-    // butterfly over the 8 -----------------------------------------------------------------------------------------
-    if (tid < T * 8) {
-        const int r = tid >> 3, sub = tid & 7;
-        const auto eighth = [&](int n, int &c0, int &c1) {
-            const int cw = (n + 7) >> 3;
+    // ---- logit, e, loss: LPI lanes per instance (every thread of the workgroup), each over a contiguous share of the
+    // columns, four reads in flight, then a fixed butterfly over the LPI -----------------------------------------------
+    constexpr int LPI = NT / T;
+    static_assert(LPI >= 1 && (LPI & (LPI - 1)) == 0 && LPI <= 64, "threads per instance");
+    {
+        const int r = tid / LPI, sub = tid % LPI;
+        const auto share = [&](int n, int &c0, int &c1) {
+            const int cw = (n + LPI - 1) / LPI;
             c0 = sub * cw < n ? sub * cw : n;
             c1 = c0 + cw < n ? c0 + cw : n;
         };
         float zg = 0.f, ng = 0.f, zm = 0.f, nm = 0.f;
         int c0, c1;
-        eighth(dg, c0, c1);
+        share(dg, c0, c1);
+#pragma unroll 4
         for (int c = c0; c < c1; ++c) {
             const float pg = G_p[r * ldg + c], qg = G_q[r * ldg + c];
             zg = zg + (pg * qg) * hl[c];
@@ -211,17 +337,19 @@ __global__ __launch_bounds__(NT) void ncf_tile(NcfDev m, const int32_t *__restri
         if (has_m) {
             const float *AL = A_(L), *A0 = A_(0);
             const int ldl = LD_(L), ld0 = LD_(0);
-            eighth(last, c0, c1);
+            share(last, c0, c1);
+#pragma unroll 4
             for (int c = c0; c < c1; ++c)
                 zm = zm + AL[r * ldl + c] * hl[dg + c];
-            eighth(W_(0), c0, c1);
+            share(W_(0), c0, c1);
+#pragma unroll 8
             for (int c = c0; c < c1; ++c) {
                 const float a = A0[r * ld0 + c];
                 nm = nm + a * a;
             }
         }
 #pragma unroll
-        for (int off = 1; off < 8; off <<= 1) {
+        for (int off = 1; off < LPI; off <<= 1) {
             zg += __shfl_xor(zg, off, 64);
             ng += __shfl_xor(ng, off, 64);
             zm += __shfl_xor(zm, off, 64);
@@ -242,7 +370,7 @@ __global__ __launch_bounds__(NT) void ncf_tile(NcfDev m, const int32_t *__restri
         }
     }
     __syncthreads();
-    float *part = partial + (int64_t)tile * m.n_small;
+    float *part = partial + (int64_t)tile * n_small;
     STAMP(); // logit
     // ---- GMF backward ----------------------------------------------------------------------------------------
     if (has_g) {
@@ -258,24 +386,25 @@ __global__ __launch_bounds__(NT) void ncf_tile(NcfDev m, const int32_t *__restri
                 }
             }
         }
-        for (int c = tid; c < dg; c += NT) { // dL/dh_g (rows past nr carry e = 0)
+        // dL/dh_g (rows past nr carry e = 0): the LAST wave's job, dL/dh_m below the one before's -- side by side
+        for (int c = wave == NW - 1 ? lane : dg; c < dg; c += 64) {
             float s = 0.f;
 #pragma unroll 16
             for (int r = 0; r < T; ++r)
                 s = s + e[r] * (G_p[r * ldg + c] * G_q[r * ldg + c]);
-            part[m.h_off + c] = s;
+            part[h_off + c] = s;
         }
     }
     if (has_m) {
         const float *AL = A_(L);
         float *DL = D_(L);
         const int ldl = LD_(L);
-        for (int c = tid; c < last; c += NT) { // dL/dh_m
+        for (int c = wave == (NW >= 2 ? NW - 2 : 0) ? lane : last; c < last; c += 64) { // dL/dh_m
             float s = 0.f;
 #pragma unroll 16
             for (int r = 0; r < T; ++r)
                 s = s + e[r] * AL[r * ldl + c];
-            part[m.h_off + dg + c] = s;
+            part[h_off + dg + c] = s;
         }
         // D[L] = e * h_m * relu'
         for (int c = lane; c < last; c += 64) {
@@ -287,11 +416,11 @@ __global__ __launch_bounds__(NT) void ncf_tile(NcfDev m, const int32_t *__restri
             }
         }
         STAMP(); // gmf backward, D[L]
-        for (int k = L - 1; k >= 0; --k) {
+        layers_down<LCC>(L, [&](int k) __attribute__((always_inline)) {
             const int kin = W_(k), kout = W_(k + 1), ws = kout + 1, lda = LD_(k), ldd = LD_(k + 1);
             const float *Ak = A_(k), *Dn = D_(k + 1), *Wl = WL_(k);
             float *Dk = D_(k);
-            float *pw = part + m.w_off[k];
+            float *pw = part + fw_of(k);
             __syncthreads(); // D[k+1] complete
             // dW_k[kk][c] = sum_r A[k][r][kk] * D[k+1][r][c]   (rows past nr carry D = 0)
             tile_gemm<NW>(
@@ -302,7 +431,7 @@ __global__ __launch_bounds__(NT) void ncf_tile(NcfDev m, const int32_t *__restri
 #pragma unroll 16
                 for (int r = 0; r < T; ++r)
                     s = s + Dn[r * ldd + c];
-                part[m.b_off[k] + c] = s;
+                part[fb_of(k) + c] = s;
             }
             STAMP(); // dW_k
             // delta of the layer below: through its ReLU into D[k] (k > 0), or dL/dX = the contribution rows of the
@@ -326,7 +455,7 @@ __global__ __launch_bounds__(NT) void ncf_tile(NcfDev m, const int32_t *__restri
                         }
                     });
             STAMP(); // dX_k
-        }
+        });
     }
     __syncthreads(); // LDS is reused by the next tile
     }
@@ -424,12 +553,27 @@ extern "C" int crec_ncf_train_epoch(crec_ctx *ctx, const crec_ncf *mdl, crec_ada
     const size_t lds_f = ncf_tile_lds_floats(has_g, has_m, d.dg, d.L0, d.n_layers);
     const size_t lds = lds_f * sizeof(float);
     CREC_REQUIRE(ctx, lds <= 160 * 1024, "model too wide for the on-chip tile (%zu bytes of LDS)", lds);
-    CREC_HIP(ctx, hipFuncSetAttribute((const void *)ncf_tile, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // the shapes of the shipped confs and of BASELINE configs[2] (layers=[128,64,32], embed_size 32 / 64, NeuMF and MLP)
+    // run shape-specialised kernels; everything else the generic one
+    using TileFn = void (*)(NcfDev, const int32_t *, const int32_t *, const float *, int, float *, float *, float *, float *, float *,
+                            float *);
+    TileFn tile_fn = ncf_tile<-1, 0, 0>;
+    if (has_m && d.L0 == 128 && d.n_layers == 3) {
+        if (!has_g)
+            tile_fn = ncf_tile<128, 3, 0>;
+        else if (d.dg == 64)
+            tile_fn = ncf_tile<128, 3, 64>;
+        else if (d.dg == 32)
+            tile_fn = ncf_tile<128, 3, 32>;
+    }
+    if (ctx->knob_ncf_generic)
+        tile_fn = ncf_tile<-1, 0, 0>;
+    CREC_HIP(ctx, hipFuncSetAttribute((const void *)tile_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 
 #ifdef NCF_STAMPS
     long long *dbg = nullptr;
-    CREC_HIP(ctx, hipMalloc(&dbg, 64 * sizeof(long long)));
-    CREC_HIP(ctx, hipMemset(dbg, 0, 64 * sizeof(long long)));
+    CREC_HIP(ctx, hipMalloc(&dbg, 512 * sizeof(long long)));
+    CREC_HIP(ctx, hipMemset(dbg, 0, 512 * sizeof(long long)));
     d.dbg = dbg;
 #endif
     for (int64_t b = 0; b < nb; ++b) {
@@ -442,7 +586,7 @@ extern "C" int crec_ncf_train_epoch(crec_ctx *ctx, const crec_ncf *mdl, crec_ada
         o.beta2 = opt->beta2;
         o.eps = opt->eps;
         crec_prof_begin(ctx, CREC_K_NCF_TILE, st);
-        CREC_KLAUNCH(ctx, ncf_tile, dim3((unsigned)crec_ceil_div(nbt, T)), dim3(NT), lds, st, d, u + t0, i + t0, y + t0, nbt,
+        CREC_KLAUNCH(ctx, tile_fn, dim3((unsigned)crec_ceil_div(crec_ceil_div(nbt, T), NCF_GRID_DIV)), dim3(NT), lds, st, d, u + t0, i + t0, y + t0, nbt,
                            c_pg, c_qg, c_pm, c_qm, loss_inst + t0, partial);
         crec_prof_end(ctx, st);
         // every parameter update of the step in one launch when the tables share a row-width class
@@ -488,11 +632,18 @@ extern "C" int crec_ncf_train_epoch(crec_ctx *ctx, const crec_ncf *mdl, crec_ada
     crec_prof_end(ctx, st);
 #ifdef NCF_STAMPS
     {
-        long long h[64];
+        long long h[512];
         CREC_HIP(ctx, hipStreamSynchronize(st));
         CREC_HIP(ctx, hipMemcpy(h, dbg, sizeof h, hipMemcpyDeviceToHost));
         for (int k = 1; k < 32 && h[2 * k]; ++k)
             fprintf(stderr, "ncf_tile stamp %2d: +%6lld clk  +%5.2f us\n", k, h[2 * k] - h[2 * k - 2], 0.01 * (double)(h[2 * k + 1] - h[2 * k - 1]));
+        if (h[128])
+            for (int w = 0; w < NW; ++w) {
+                fprintf(stderr, "ncf_tile wave %d:", w);
+                for (int j = 0; j < 8 && h[128 + w * 16 + j]; ++j)
+                    fprintf(stderr, " %6lld", h[128 + w * 16 + j] - h[0]);
+                fprintf(stderr, "\n");
+            }
         (void)hipFree(dbg);
     }
 #endif

@@ -66,6 +66,9 @@ inline int ncf_describe(crec_ctx *ctx, const crec_ncf *mdl, NcfDev *d)
 
 // ---- device helpers shared by the training tile (ncf.hip) and the scoring tile (ncf_eval.hip) -----------------
 #ifdef __HIPCC__
+#ifndef NCF_ABL
+#define NCF_ABL 0
+#endif
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 // C[M x N] = A[M x K] * B[K x N] on v_mfma_f32_16x16x4_f32: 16x16 output blocks dealt round-robin to the waves.
@@ -77,26 +80,37 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 // strides that are odd, a half-wave's 32 operand reads fall in 32 different LDS banks whether k runs along the row
 // (A of the forward pass) or down the column (B).  The order of the sum is fixed: chunks ascending, s ascending, q
 // ascending inside the instruction.
+// Two accumulator chains (even / odd steps of a chunk, added once at the end): a dependent MFMA waits for its
+// predecessor's result, and a wave of the training tile has one block at a time -- nothing else to interleave with.
 template <int S, class FA, class FB>
-__device__ __forceinline__ f32x4 gemm_chunk(f32x4 acc, int k0, int mc, int nc, int q, FA fa, FB fb)
+__device__ __forceinline__ void gemm_chunk(f32x4 &acc0, f32x4 &acc1, int k0, int mc, int nc, int q, FA fa, FB fb)
 {
     float a[S], b[S];
 #pragma unroll
     for (int s = 0; s < S; ++s) { // all 2*S operand reads in flight together
+#if NCF_ABL == 2 // timing ablation (wrong results): no operand reads
+        a[s] = (float)(mc + s), b[s] = (float)(nc + k0);
+#else
         a[s] = fa(mc, k0 + s + S * q);
         b[s] = fb(k0 + s + S * q, nc);
+#endif
     }
     __builtin_amdgcn_sched_barrier(0); // keep the reads batched: the scheduler would otherwise pair each with its MFMA
 #pragma unroll
-    for (int s = 0; s < S; ++s)
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc, 0, 0, 0);
-    return acc;
+    for (int s = 0; s < S; s += 2) {
+#if NCF_ABL == 1 // timing ablation (wrong results): no MFMA
+        acc0[0] += a[s] * b[s], acc1[0] += a[s + 1] * b[s + 1];
+#else
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s + 1], b[s + 1], acc1, 0, 0, 0);
+#endif
+    }
 }
 
 template <int NWV, class FA, class FB, class FS>
 __device__ __forceinline__ void tile_gemm(int M, int N, int K, FA fa, FB fb, FS fs)
 {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l16 = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, l16 = lane & 15, q = lane >> 4;
     const int nbn = (N + 15) >> 4, nblk = ((M + 15) >> 4) * nbn;
     for (int blk = wave; blk < nblk; blk += NWV) {
         const int m0 = (blk / nbn) << 4, n0 = (blk % nbn) << 4;
@@ -104,16 +118,16 @@ __device__ __forceinline__ void tile_gemm(int M, int N, int K, FA fa, FB fb, FS 
         // below, so no predicate -- a predicated LDS read costs a branch each
         const int ni = n0 + l16;
         const int mc = (m0 + l16) < M ? (m0 + l16) : M - 1, nc = ni < N ? ni : N - 1;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         int k = 0;
         for (; k + 64 <= K; k += 64)
-            acc = gemm_chunk<16>(acc, k, mc, nc, q, fa, fb);
+            gemm_chunk<16>(acc, acc1, k, mc, nc, q, fa, fb);
         if (k + 32 <= K) {
-            acc = gemm_chunk<8>(acc, k, mc, nc, q, fa, fb);
+            gemm_chunk<8>(acc, acc1, k, mc, nc, q, fa, fb);
             k += 32;
         }
         if (k + 16 <= K) {
-            acc = gemm_chunk<4>(acc, k, mc, nc, q, fa, fb);
+            gemm_chunk<4>(acc, acc1, k, mc, nc, q, fa, fb);
             k += 16;
         }
         for (; k < K; k += 4) { // K tail: columns past the end contribute zeros
@@ -126,7 +140,7 @@ __device__ __forceinline__ void tile_gemm(int M, int N, int K, FA fa, FB fb, FS 
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 if (m0 + q * 4 + j < M)
-                    fs(m0 + q * 4 + j, ni, acc[j]);
+                    fs(m0 + q * 4 + j, ni, acc[j] + acc1[j]);
         }
     }
 }
@@ -156,7 +170,7 @@ __device__ __forceinline__ void gemm_chunk2(f32x4 &acc0, f32x4 &acc1, int k0, in
 template <int NWV, class FA, class FB, class FS>
 __device__ __forceinline__ void tile_gemm_wide(int M, int N, int K, FA fa, FB fb, FS fs)
 {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l16 = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, l16 = lane & 15, q = lane >> 4;
     const int nbn = (N + 31) >> 5, nblk = ((M + 15) >> 4) * nbn;
     for (int blk = wave; blk < nblk; blk += NWV) {
         const int m0 = (blk / nbn) << 4, n0 = (blk % nbn) << 5;

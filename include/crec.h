@@ -69,7 +69,8 @@ const char *crec_last_error(const crec_ctx *ctx);
  *   "wide"          tf1 step: occurrences per row wave above which a whole workgroup takes it (-1 default 16, 0 off)
  *   "wide_round"    experiment: pad the wide groups' workgroups to a multiple of this (0 = the chunk's maximum)
  *   "eval_shape"    4 / 8: force an eval_sweep workgroup shape where legal (0 = choose)
- *   "eval_no_bitmap" 1: seen filter by binary search even where per-user bitmaps would fit */
+ *   "eval_no_bitmap" 1: seen filter by binary search even where per-user bitmaps would fit
+ *   "ncf_generic"    1: the generic NCF tile kernel even for tower shapes that have a shape-specialised one */
 int crec_ctx_set_option(crec_ctx *ctx, const char *name, int64_t value);
 
 /* ---- measurement: per-kernel time from HIP events recorded on the launch stream ------------

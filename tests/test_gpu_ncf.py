@@ -89,9 +89,13 @@ def test_mlp_steps_match_oracle(sess, layers):
     _compare(st, om, names)
 
 
-def test_neumf_config3_shape(sess):
-    """BASELINE config C3: NeuMF, d = 64, layers [128, 64, 32], batch 6144 (catalogue scaled down)."""
-    U, I, B, d, layers = 400, 300, 6144, 64, [128, 64, 32]
+@pytest.mark.parametrize("d,generic", [(64, 0), (32, 0), (64, 1)])
+def test_neumf_config3_shape(sess, d, generic):
+    """BASELINE config C3: NeuMF, d = 64, layers [128, 64, 32], batch 6144 (catalogue scaled down); d = 32 is the
+    shipped conf.  These tower shapes run shape-specialised tile kernels (csrc/ncf.hip); `ncf_generic` keeps the
+    generic kernel under test at the same shape."""
+    U, I, B, layers = 400, 300, 6144, [128, 64, 32]
+    sess.ctx.set_option("ncf_generic", generic)
     g = np.random.Generator(np.random.PCG64(9))
     Pg, Qg, Pm, Qm = _rand(g, U, d), _rand(g, I, d), _rand(g, U, 64), _rand(g, I, 64)
     Ws, bs, last = _tower(g, 128, 3)
@@ -100,7 +104,10 @@ def test_neumf_config3_shape(sess):
     st = runtime.NcfState(sess, "NeuMF", {"P_gmf": Pg, "Q_gmf": Qg, "P_mlp": Pm, "Q_mlp": Qm}, Ws, bs, h, lr=1e-3,
                           reg_gmf=1e-2, reg_mlp=1e-3)
     om = MT.NeuMF(Pg, Qg, Pm, Qm, Ws, bs, h, lr=1e-3, reg1=1e-2, reg2=1e-3)
-    loss = st.train_epoch(sess.to_dev(u), sess.to_dev(i), sess.to_dev(y), B).cpu().numpy()
+    try:
+        loss = st.train_epoch(sess.to_dev(u), sess.to_dev(i), sess.to_dev(y), B).cpu().numpy()
+    finally:
+        sess.ctx.set_option("ncf_generic", 0)
     ol = [om.step(u[b * B:(b + 1) * B], i[b * B:(b + 1) * B], y[b * B:(b + 1) * B]) for b in range(len(loss))]
     np.testing.assert_allclose(loss, ol, rtol=1e-5)
     names = [(st.t[k], k) for k in ("P_gmf", "Q_gmf", "P_mlp", "Q_mlp")] + [(st.h, "h_neumf")]
