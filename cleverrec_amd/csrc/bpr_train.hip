@@ -105,6 +105,9 @@ __device__ __forceinline__ void crec_mark(int slot, int dep) // the time at whic
 #ifndef CREC_LAZY_ABL
 #define CREC_LAZY_ABL 0 // timing ablations of bpr_triples_lazy (wrong results): 1 no finishers, 2 no publishing / tickets either,
 #endif                  // 4 no LDS piece sums
+#ifndef CREC_LAZY_HEADSTART
+#define CREC_LAZY_HEADSTART 6 // x 0.43 us (tools/lazy_variants.sh)
+#endif
 #ifndef CREC_LAZY_DEEP
 #define CREC_LAZY_DEEP 8 // contribution / partial rows in flight in a finisher's sum.  The d = 128 workgroup is 1024 threads, i.e. a
                          // hard limit of 128 VGPRs: 11 in flight spill three registers; 8 / 11 / 12 / 16 measured within 2 % of each other
@@ -1686,6 +1689,17 @@ __global__ __launch_bounds__(LazyGeo<LPR>::THREADS) void bpr_triples_lazy(Tables
     const int blk_n = blk_lead ? ((i_ci - i_posr) < (SPW - gw) ? (i_ci - i_posr) : (SPW - gw)) : 0; // the piece's slots = the leader's weight
     const bool blk_whole = blk_lead && blk_n == i_cnt; // the row lies inside this workgroup: no ticket, no memory round trip
     float4 p = zero, qi = zero, qj = zero, mp = zero, vp = zero, mi = zero, vi = zero, mj = zero, vj = zero;
+#if CREC_LAZY_HEADSTART
+    // A head start for the rows with a tail.  All waves of the launch are resident at once and ask for their rows in the
+    // first microsecond; the memory system then needs the whole body's time to serve them, in no particular order, so a
+    // popular row's finisher -- which needs ALL of the row's pieces published -- starts when the body ends, and its
+    // publish -> ticket -> sum chain is added on top.  Waves none of whose triples takes a ticket therefore wait a
+    // little before asking: the others' rows come back first, and their chains run beside the body instead of after it.
+    // (Only where there is such a front to speak of: S-big 16.46 -> 16.11 us with 6 x 0.43 us, 16.7 / 17.9 with 12 / 16.)
+    if (!front_block && n_slots >= 2048 && 4 * n_blk_slots >= n_slots && __builtin_amdgcn_ballot_w64(valid && (!is || !js)) == 0)
+        for (int k = 0; k < CREC_LAZY_HEADSTART; ++k)
+            __builtin_amdgcn_s_sleep(16); // 16 x 64 clocks = 0.43 us
+#endif
     if (on) { // every address is known: one round of loads
         p = ld4(t.P + ou);
         qi = ld4(t.Q + oi);

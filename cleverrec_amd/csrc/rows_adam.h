@@ -69,7 +69,8 @@ struct crec_apply_set {
     int block_end[CREC_APPLY_MAX_TABLES]; // filled by crec_apply_all
     crec_scalar_job scalar;               // after the tables: 256 rows per block
     int scalar_end;                       // filled by crec_apply_all
-    crec_small_job small;                 // last; small.n == 0: none
+    crec_small_job small;                 // small.n == 0: none; its blocks lead the grid
+    int small_blocks;                     // filled by crec_apply_all
 };
 
 size_t crec_rows_index_bytes(int64_t n_batches, int32_t per_batch, int64_t rows, int32_t chunks = 1);

@@ -403,12 +403,18 @@ __device__ __forceinline__ void scalar_rows_block(const crec_scalar_job &j, int 
 
 // every parameter update of a step in ONE launch: up to CREC_APPLY_MAX_TABLES embedding tables (blocks
 // [block_end[k-1], block_end[k]) sweep table k, four rows per block), then an optional one-column table (256 rows
-// per block) and, last, the small dense vector
+// per block); the small dense vector leads the grid
 // (16 elements per block; same slices, hence the same sums, as small_adam_dense)
 template <int LPR> __global__ __launch_bounds__(256) void apply_all(crec_apply_set a)
 {
     __shared__ float red[SAD_SL * 16];
-    const int bi = blockIdx.x;
+    // the small vector's blocks come FIRST: theirs is the longest chain of the launch (two rounds of strided partial
+    // loads, a reduction, then the update), which then runs beside the table sweep instead of after it
+    if ((int)blockIdx.x < a.small_blocks) {
+        small_adam_block<16>(a.small, blockIdx.x, red);
+        return;
+    }
+    const int bi = (int)blockIdx.x - a.small_blocks;
     int k = 0, first = 0;
 #pragma unroll
     for (int q = 0; q < CREC_APPLY_MAX_TABLES; ++q) // unrolled: a loop indexing block_end[] sent the array to scratch
@@ -424,10 +430,8 @@ template <int LPR> __global__ __launch_bounds__(256) void apply_all(crec_apply_s
                                  j.chunks > 1 ? j.chunks : 1);
         else
             rows_apply_row<LPR>(j.t, j.rowseg, j.order, j.contrib, j.dense_grad, j.row_out, j.o, wave, j.chunks > 1 ? j.chunks : 1);
-    } else if (bi < a.scalar_end) {
-        scalar_rows_block(a.scalar, bi - first);
     } else {
-        small_adam_block<16>(a.small, bi - a.scalar_end, red);
+        scalar_rows_block(a.scalar, bi - first);
     }
 }
 
@@ -517,8 +521,8 @@ int crec_apply_all(crec_ctx *ctx, crec_apply_set &a, hipStream_t st)
     if (a.scalar.rows > 0)
         blocks += (int)crec_ceil_div(a.scalar.rows, 256);
     a.scalar_end = blocks;
-    if (a.small.n > 0)
-        blocks += (int)crec_ceil_div(a.small.n, 16);
+    a.small_blocks = a.small.n > 0 ? (int)crec_ceil_div(a.small.n, 16) : 0;
+    blocks += a.small_blocks;
     if (blocks == 0)
         return CREC_OK;
     if (lpr == 0)
