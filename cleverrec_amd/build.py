@@ -28,6 +28,7 @@ SOURCES = {
     "fm.hip": ["-ffp-contract=off"],
     "cml.hip": ["-ffp-contract=off"],
     "sbpr.hip": ["-ffp-contract=off"],
+    "lrml.hip": ["-ffp-contract=off"],
     "ncf_eval.hip": [],
 }
 

@@ -253,6 +253,47 @@ class CmlState:
         return Pa, Qa
 
 
+class LrmlState:
+    """P, Q, K, M of model/ranking/LRML.py:24-34 with Adam slots in HBM (crec_lrml); K and M are views into ONE flat
+    block [K | M]."""
+
+    def __init__(self, sess, P0, Q0, K0, M0, lr, reg, margin, beta1=0.9, beta2=0.999, eps=1e-8):
+        self.sess = sess
+        f32 = torch.float32
+        self.P, self.Q = sess.to_dev(P0, f32).contiguous(), sess.to_dev(Q0, f32).contiguous()
+        K0, M0 = np.asarray(K0, dtype=np.float32), np.asarray(M0, dtype=np.float32)
+        d, mem = K0.shape
+        if M0.shape != (mem, d) or self.P.shape[1] != d or self.Q.shape[1] != d:
+            raise ValueError("LRML: K [embed_size, mem_size], M [mem_size, embed_size]")
+        self.small = sess.to_dev(np.concatenate([K0.reshape(-1), M0.reshape(-1)]), f32)
+        self.K, self.M = self.small[:d * mem].view(d, mem), self.small[d * mem:].view(mem, d)
+        self.slots = {k: (torch.zeros_like(t), torch.zeros_like(t)) for k, t in (("P", self.P), ("Q", self.Q), ("small", self.small))}
+
+        def par(name, t, rows, cols):
+            m, v = self.slots[name]
+            return _lib.Param(t.data_ptr(), m.data_ptr(), v.data_ptr(), rows, cols)
+        self.model = _lib.Lrml(par("P", self.P, self.P.shape[0], d), par("Q", self.Q, self.Q.shape[0], d),
+                               par("small", self.small, 1, self.small.numel()), mem, reg, margin)
+        self.adam = _lib.Adam(lr, beta1, beta2, eps, 0.0, _lib.ADAM_TF1, beta1, beta2, 0)
+
+    def train_epoch(self, u, i, j, batch_size):
+        """u, i, j int32 [N] (device) -> per-batch summed losses (device fp32)."""
+        s = self.sess
+        n = int(u.numel())
+        loss = s.empty((-(-n // batch_size),), torch.float32)
+        s.ctx.check(s.lib.crec_lrml_train_epoch(s.ctx.h, C.byref(self.model), C.byref(self.adam), s.ptr(u), s.ptr(i), s.ptr(j),
+                                                n, int(batch_size), s.ptr(loss), s.stream_ptr()))
+        return loss
+
+    def scores(self, users):
+        """users int32 [Bt] (device) -> [Bt, I] squared distances (LRML.py:74-76); rank ascending."""
+        s = self.sess
+        Bt = int(users.numel())
+        out = s.empty((Bt, self.Q.shape[0]), torch.float32)
+        s.ctx.check(s.lib.crec_lrml_scores(s.ctx.h, C.byref(self.model), s.ptr(users), Bt, s.ptr(out), s.stream_ptr()))
+        return out
+
+
 class SbprState:
     """P, Q, bias of model/ranking/SBPR.py:31-37 with Adam slots in HBM (crec_sbpr)."""
 

@@ -70,7 +70,7 @@ const char *crec_last_error(const crec_ctx *ctx);
  *   "wide_round"    experiment: pad the wide groups' workgroups to a multiple of this (0 = the chunk's maximum)
  *   "eval_shape"    4 / 8: force an eval_sweep workgroup shape where legal (0 = choose)
  *   "eval_no_bitmap" 1: seen filter by binary search even where per-user bitmaps would fit
- *   "ncf_generic"    1: the generic NCF tile kernel even for tower shapes that have a shape-specialised one */
+ *   "ncf_generic"    1: the generic NCF / LRML tile kernels even for shapes that have a shape-specialised one */
 int crec_ctx_set_option(crec_ctx *ctx, const char *name, int64_t value);
 
 /* ---- measurement: per-kernel time from HIP events recorded on the launch stream ------------
@@ -287,6 +287,25 @@ typedef struct {
 int crec_sbpr_train_epoch(crec_ctx *ctx, const crec_sbpr *model, crec_adam *opt, const int32_t *u, const int32_t *i,
                           const int32_t *k, const int32_t *j, const float *suk, int64_t N, int32_t B, float *loss_per_batch,
                           void *stream);
+
+/* ---- Latent Relational Metric Learning (device) -----------------------------------------------
+ * replaces sess.run([self.train, self.loss], {u_idx, i_idx, j_idx}) (model/RankingRecommender.py:39-47) on the graph of
+ * model/ranking/LRML.py:36-63 -- joint = p_u * q, a = softmax(joint K), r = a M, dist = |p_u + r - q|^2,
+ * loss = sum max(dist_i - dist_j + margin, 0) + reg * l2 of the gathered rows -- with AdamOptimizer (P, Q: IndexedSlices,
+ * every row decays and moves; K [d, mem], M [mem, d]: dense), and sess.run(self.pre_scores) (LRML.py:70-76).
+ *   small: ONE flat block [K | M] (K row-major [d][mem], then M row-major [mem][d]) with its Adam slots, rows * cols =
+ *          2 * d * mem_size.  embed_size a multiple of 4, at most 128; mem_size <= 64; B <= 8192.
+ *   crec_lrml_train_epoch: u, i, j int32 [N] from crec_sample_pairwise; loss_per_batch [ceil(N/B)] summed losses.
+ *   crec_lrml_scores: scores [Bt][I] = the squared distance of every (user, item) pair; rank ascending (cml_like,
+ *          model/RankingRecommender.py:222-223) with crec_topk_scores[_candidates]. */
+typedef struct {
+    crec_param P, Q, small;
+    int32_t mem_size;
+    float reg, margin;
+} crec_lrml;
+int crec_lrml_train_epoch(crec_ctx *ctx, const crec_lrml *model, crec_adam *opt, const int32_t *u, const int32_t *i,
+                          const int32_t *j, int64_t N, int32_t B, float *loss_per_batch, void *stream);
+int crec_lrml_scores(crec_ctx *ctx, const crec_lrml *model, const int32_t *users, int32_t Bt, float *scores, void *stream);
 
 /* ---- data-parallel training over RCCL (one process per GPU of one node) -----------------------
  * The path shards with one real exchange: gradients of the same Q row must be summed over all ranks'

@@ -304,6 +304,53 @@ class SBPR(Model):
             self.reg * (_l2(pu) + _l2(qi) + _l2(qk) + _l2(qj) + _l2(bi) + _l2(bk) + _l2(bj))
 
 
+class LRML(Model):
+    """model/ranking/LRML.py:36-63: joint = p_u * q; a = softmax(joint K); r = a M; dist = |p_u + r - q|^2;
+    loss = sum max(dist_i - dist_j + margin, 0) (utils/tools.py:72-73) + reg*(l2(p_u) + l2(q_i) + l2(q_j)).
+    P, Q are reached through tf.gather (IndexedSlices Adam), K and M are dense variables (ApplyAdam).  _unit_clipping
+    (LRML.py:65-68) is never called and the variables' `regularizer=` never reaches the loss."""
+
+    def __init__(self, P, Q, K, M, lr, reg, margin):
+        super().__init__({"P": P, "Q": Q, "K": K, "M": M}, {"P": "sparse", "Q": "sparse", "K": "dense", "M": "dense"}, lr)
+        self.reg, self.margin = reg, margin
+
+    @staticmethod
+    def _lram(w, pu, q):  # LRML.py:43-52 (training form)
+        att = torch.softmax((pu * q) @ w["K"], dim=1)
+        return att @ w["M"]
+
+    def loss(self, w, u, i, j):
+        u, i, j = (torch.as_tensor(np.asarray(x), dtype=torch.long) for x in (u, i, j))
+        pu, qi, qj = gather(w, "P", u), gather(w, "Q", i), gather(w, "Q", j)
+        fi, fj = pu + self._lram(w, pu, qi) - qi, pu + self._lram(w, pu, qj) - qj
+        di, dj = (fi ** 2).sum(1), (fj ** 2).sum(1)
+        if w.get("_abs") is not None:
+            # rounding scale beyond sum|c_k|: a slot's gradient holds the direct terms +-2g*diff -- for p_u the DIFFERENCE
+            # 2g*(diff_i - diff_j), in which p_u itself cancels -- and what comes back through the memory module, where
+            # the softmax backward a*(dA - <a, dA>) cancels again and K, M mix all d components of 2g*diff into each
+            # one.  Every term is rounded at its own magnitude (~8 ulp: 0.025 * NOISE of it, as in FM below), and that
+            # magnitude is the row's largest |2g*diff| component, not the element's own
+            g2 = 2.0 * (di - dj + self.margin >= 0).double().numpy()[:, None]
+            ai = 0.025 * g2 * np.abs(fi.detach().double().numpy()).max(1, keepdims=True) * np.ones((1, fi.shape[1]))
+            aj = 0.025 * g2 * np.abs(fj.detach().double().numpy()).max(1, keepdims=True) * np.ones((1, fj.shape[1]))
+            a = np.zeros(tuple(w["P"].shape), np.float64)
+            np.add.at(a, u.numpy(), ai + aj)
+            w["_abs"]["P"] = w["_abs"].get("P", 0) + a
+            a = np.zeros(tuple(w["Q"].shape), np.float64)
+            np.add.at(a, i.numpy(), ai)
+            np.add.at(a, j.numpy(), aj)
+            w["_abs"]["Q"] = w["_abs"].get("Q", 0) + a
+        return torch.clamp(di - dj + self.margin, min=0).sum() + self.reg * (_l2(pu) + _l2(qi) + _l2(qj))
+
+    def scores(self, users):
+        """pre_scores of the rs branch (LRML.py:74-76): [len(users), I] squared distances, float64."""
+        w = {k: v.double() for k, v in self.params.items()}
+        pu = w["P"][torch.as_tensor(np.asarray(users), dtype=torch.long)]
+        joint = pu[:, None, :] * w["Q"][None, :, :]
+        r = torch.softmax(joint @ w["K"], dim=2) @ w["M"]
+        return ((pu[:, None, :] + r - w["Q"][None, :, :]) ** 2).sum(2).numpy()
+
+
 class FM(Model):
     """model/rating/FM.py:20-53: y = w0 + sum_f wi[x_f] + 0.5*sum_k[(sum_f x v)^2 - sum_f x^2 v^2] (the linear
     term ignores x_value, :35,49); loss = sum (y - y_pre)^2 + reg*(l2(wi) + l2(vif)) over the FULL tables (:52)

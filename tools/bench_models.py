@@ -3,6 +3,7 @@
   C3  NeuMF on S-ml1m, d=64, layers [128,64,32], batch 6144, neg_ratio 4   -> instances/s
   C4  FM, F=2 one-hot fields (user, U+item), d=32, N = U+I features, batch 6144 -> rows/s
   a11 CML on S-ml1m, d=128, neg_ratio 20, batch 6144                          -> pairs/s
+  f4  LRML on S-ml1m, d=128, mem_size 50, neg_ratio 1, batch 6144            -> triples/s, distance matrix users/s
 Index streams come from the bit-exact host samplers; everything is resident in HBM when timed."""
 import json
 import os
@@ -79,6 +80,22 @@ def main():
     cml = runtime.CmlState(sess, rnd(U, 128), rnd(I, 128), lr=1e-3, reg=10.0, margin=1.0)
     du, di, dn = sess.to_dev(u), sess.to_dev(i), sess.to_dev(neg)
     out["CML"] = dict(timed(lambda: cml.train_epoch(du, di, dn, B), len(u)), unit="pairs")
+
+    # ---- LRML (f4): the shipped conf -- d = 128, 50 memory slots, one negative per positive, hinge
+    sess.ctx.seed(1)
+    u, i, j = sess.ctx.sample_pairwise(data.train_csr, I, 1)
+    lr_ = runtime.LrmlState(sess, rnd(U, 128), rnd(I, 128), rnd(128, 50), rnd(50, 128), lr=1e-3, reg=1e-3, margin=0.2)
+    du, di, dj = sess.to_dev(u), sess.to_dev(i), sess.to_dev(j)
+    out["LRML"] = dict(timed(lambda: lr_.train_epoch(du, di, dj, B), len(u)), unit="triples")
+    users = sess.to_dev(np.arange(1024, dtype=np.int32))
+    lr_.scores(users)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        lr_.scores(users)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 3 * 1e3
+    out["LRML_scores"] = {"users_per_s": 1024 / ms * 1e3, "ms_per_1024_users": ms}
     print(json.dumps(out))
 
 
