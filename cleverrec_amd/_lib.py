@@ -66,6 +66,11 @@ class Lrml(C.Structure):
     _fields_ = [("P", Param), ("Q", Param), ("small", Param), ("mem_size", C.c_int32), ("reg", C.c_float), ("margin", C.c_float)]
 
 
+class Transcf(C.Structure):
+    _fields_ = [("P", Param), ("Q", Param), ("ui_ptr", C.c_void_p), ("ui_items", C.c_void_p), ("iu_ptr", C.c_void_p),
+                ("iu_users", C.c_void_p), ("reg1", C.c_float), ("reg2", C.c_float), ("margin", C.c_float)]
+
+
 class Cml(C.Structure):
     _fields_ = [("P", Param), ("Q", Param), ("reg", C.c_float), ("margin", C.c_float)]
 
@@ -104,6 +109,8 @@ _SIGNATURES = {
     "crec_sbpr_train_epoch": (C.c_int, [_vp, C.POINTER(Sbpr), C.POINTER(Adam), _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "crec_lrml_train_epoch": (C.c_int, [_vp, C.POINTER(Lrml), C.POINTER(Adam), _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "crec_lrml_scores": (C.c_int, [_vp, C.POINTER(Lrml), _vp, _i32, _vp, _vp]),
+    "crec_transcf_train_epoch": (C.c_int, [_vp, C.POINTER(Transcf), C.POINTER(Adam), _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
+    "crec_transcf_scores": (C.c_int, [_vp, C.POINTER(Transcf), _vp, _i32, _i32, _vp, _vp, _vp]),
     "crec_cml_eval_tables": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp]),
     "crec_bpr_train_epoch_dp": (C.c_int, [_vp, C.POINTER(BprTables), C.POINTER(Adam), _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "crec_comm_unique_id": (C.c_int, [_vp, _vp]),

@@ -29,6 +29,7 @@ SOURCES = {
     "cml.hip": ["-ffp-contract=off"],
     "sbpr.hip": ["-ffp-contract=off"],
     "lrml.hip": ["-ffp-contract=off"],
+    "transcf.hip": ["-ffp-contract=off"],
     "ncf_eval.hip": [],
 }
 

@@ -294,6 +294,54 @@ class LrmlState:
         return out
 
 
+class TranscfState:
+    """P, Q of model/ranking/TransCF.py:27-32 with Adam slots and the two neighbourhood CSRs (get_sp_mat) in HBM
+    (crec_transcf)."""
+
+    def __init__(self, sess, P0, Q0, sp_mat, lr, reg1, reg2, margin, beta1=0.9, beta2=0.999, eps=1e-8):
+        self.sess = sess
+        f32 = torch.float32
+        self.P, self.Q = sess.to_dev(P0, f32).contiguous(), sess.to_dev(Q0, f32).contiguous()
+        self.slots = {k: (torch.zeros_like(t), torch.zeros_like(t)) for k, t in (("P", self.P), ("Q", self.Q))}
+        ui_ptr, ui_items, iu_ptr, iu_users = sp_mat
+        U, I = self.P.shape[0], self.Q.shape[0]
+        if len(ui_ptr) != U + 1 or len(iu_ptr) != I + 1 or ui_ptr[-1] != iu_ptr[-1]:
+            raise ValueError("TransCF: ui_ptr [U+1], iu_ptr [I+1] over the same interactions")
+        pad = lambda a: a if len(a) else np.zeros(1, a.dtype)
+        self.csr = tuple(sess.to_dev(np.ascontiguousarray(a)) for a in
+                         (np.asarray(ui_ptr, np.int64), pad(np.asarray(ui_items, np.int32)), np.asarray(iu_ptr, np.int64),
+                          pad(np.asarray(iu_users, np.int32))))
+
+        def par(name, t):
+            m, v = self.slots[name]
+            return _lib.Param(t.data_ptr(), m.data_ptr(), v.data_ptr(), t.shape[0], t.shape[1])
+        self.model = _lib.Transcf(par("P", self.P), par("Q", self.Q), *(c.data_ptr() for c in self.csr), reg1, reg2, margin)
+        self.adam = _lib.Adam(lr, beta1, beta2, eps, 0.0, _lib.ADAM_TF1, beta1, beta2, 0)
+        self._nbr_ws = None
+
+    def train_epoch(self, u, i, j, batch_size):
+        """u, i, j int32 [N] (device) -> per-batch summed losses (device fp32)."""
+        s = self.sess
+        n = int(u.numel())
+        loss = s.empty((-(-n // batch_size),), torch.float32)
+        s.ctx.check(s.lib.crec_transcf_train_epoch(s.ctx.h, C.byref(self.model), C.byref(self.adam), s.ptr(u), s.ptr(i), s.ptr(j),
+                                                   n, int(batch_size), s.ptr(loss), s.stream_ptr()))
+        return loss
+
+    def scores(self, users, clip_users=True):
+        """users int32 [Bt] (device) -> [Bt, I] squared distances (TransCF.py:85-91); rank ascending."""
+        s = self.sess
+        Bt = int(users.numel())
+        U, d = self.P.shape
+        I = self.Q.shape[0]
+        if self._nbr_ws is None:
+            self._nbr_ws = s.empty(((U + I) * d,), torch.float32)
+        out = s.empty((Bt, I), torch.float32)
+        s.ctx.check(s.lib.crec_transcf_scores(s.ctx.h, C.byref(self.model), s.ptr(users), Bt, int(bool(clip_users)),
+                                              s.ptr(self._nbr_ws), s.ptr(out), s.stream_ptr()))
+        return out
+
+
 class SbprState:
     """P, Q, bias of model/ranking/SBPR.py:31-37 with Adam slots in HBM (crec_sbpr)."""
 

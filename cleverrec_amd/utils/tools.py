@@ -116,3 +116,31 @@ def spu_csr(data, SPu):
         ptr.append(len(items))
     return (np.asarray(ptr, np.int64), np.asarray(items if items else [0], np.int32)[:len(items)],
             np.asarray(suk if suk else [0], np.int32)[:len(suk)])
+
+
+def get_sp_mat(data):
+    """utils/tools.py:100-113 (get_sp_mat, TransCF): the row-normalised user-item matrix and its row-normalised transpose as
+    two CSRs instead of tf.SparseTensors: (ui_ptr [U+1] int64, ui_items int32, iu_ptr [I+1] int64, iu_users int32).
+    Row r of the first holds ui_train[r] in list order (every entry weighs 1/len(ui_train[r])); row i of the second the users
+    that hold item i, in ui_train's iteration order (every entry weighs 1/count).  The weights themselves are implied by
+    the row lengths (float32(1.0 / n), the SparseTensor's values) and formed on the device."""
+    import numpy as np
+    U, I = data.user_nums, data.item_nums
+    ui_len = np.zeros(U, dtype=np.int64)
+    for u, items in data.ui_train.items():
+        ui_len[u] = len(items)
+    ui_ptr = np.zeros(U + 1, dtype=np.int64)
+    np.cumsum(ui_len, out=ui_ptr[1:])
+    ui_items = np.empty(int(ui_ptr[-1]), dtype=np.int32)
+    us, its = [], []
+    for u, items in data.ui_train.items():
+        ui_items[ui_ptr[u]:ui_ptr[u + 1]] = np.asarray(items, dtype=np.int32)
+        us.append(np.full(len(items), u, dtype=np.int32))
+        its.append(np.asarray(items, dtype=np.int32))
+    us = np.concatenate(us) if us else np.zeros(0, np.int32)
+    its = np.concatenate(its) if its else np.zeros(0, np.int32)
+    order = np.argsort(its, kind="stable")  # by item, ties in ui_train's iteration order
+    iu_users = np.ascontiguousarray(us[order])
+    iu_ptr = np.zeros(I + 1, dtype=np.int64)
+    np.cumsum(np.bincount(its, minlength=I), out=iu_ptr[1:])
+    return ui_ptr, ui_items, iu_ptr, iu_users

@@ -307,6 +307,30 @@ int crec_lrml_train_epoch(crec_ctx *ctx, const crec_lrml *model, crec_adam *opt,
                           const int32_t *j, int64_t N, int32_t B, float *loss_per_batch, void *stream);
 int crec_lrml_scores(crec_ctx *ctx, const crec_lrml *model, const int32_t *users, int32_t Bt, float *scores, void *stream);
 
+/* ---- Translational Collaborative Filtering (device) -------------------------------------------
+ * replaces sess.run([self.train, self.loss], {u_idx, i_idx, j_idx}) (model/RankingRecommender.py:39-47) on the graph of
+ * model/ranking/TransCF.py:39-77 -- NU = A_ui Q, NI = A_iu P (row-normalised training matrix and its transpose,
+ * utils/tools.py:100-113), dist = |p_u + NU[u] * NI[i] - q_i|^2, hinge on dist_i - dist_j plus the neighbourhood (reg1) and
+ * distance (reg2) regularisers -- with AdamOptimizer; both tables receive dense gradients (the sparse-dense products reach
+ * every row), i.e. the dense ApplyAdam kernel on every row.
+ *   ui_ptr [U+1] / ui_items: a user's training items, by user id; iu_ptr [I+1] / iu_users: an item's training users, by
+ *   item id (device pointers; the same interaction set both ways).  u, i, j int32 [N] from crec_sample_pairwise; B <= 8192.
+ *   crec_transcf_scores: scores [Bt][I] = |a + NU[u] * NI[item] - q_item|^2 with a = clip_1(p_u) (clip_users = 1: the rs
+ *   branch of _predict, TransCF.py:88-91) or p_u (0: the loo / sampled-negatives branch, ui_dist, :86-87); nbr_ws: device
+ *   scratch of (U + I) * d floats (NU, NI of the current tables).  Rank ascending (cml_like) with crec_topk_scores. */
+typedef struct {
+    crec_param P, Q;
+    const int64_t *ui_ptr;
+    const int32_t *ui_items;
+    const int64_t *iu_ptr;
+    const int32_t *iu_users;
+    float reg1, reg2, margin;
+} crec_transcf;
+int crec_transcf_train_epoch(crec_ctx *ctx, const crec_transcf *model, crec_adam *opt, const int32_t *u, const int32_t *i,
+                             const int32_t *j, int64_t N, int32_t B, float *loss_per_batch, void *stream);
+int crec_transcf_scores(crec_ctx *ctx, const crec_transcf *model, const int32_t *users, int32_t Bt, int32_t clip_users,
+                        float *nbr_ws, float *scores, void *stream);
+
 /* ---- data-parallel training over RCCL (one process per GPU of one node) -----------------------
  * The path shards with one real exchange: gradients of the same Q row must be summed over all ranks'
  * triples before Adam.  Users (rows of P, their slots, their triples) are sharded over ranks, Q and its

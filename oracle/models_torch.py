@@ -351,6 +351,56 @@ class LRML(Model):
         return ((pu[:, None, :] + r - w["Q"][None, :, :]) ** 2).sum(2).numpy()
 
 
+class TransCF(Model):
+    """model/ranking/TransCF.py:39-77: NU = A_ui Q, NI = A_iu P (utils/tools.py:100-113); dist = |p_u + NU[u]*NI[i] - q_i|^2;
+    loss = sum max(x + margin, 0) + reg1*(|p_u - NU[u]|^2 + |q_i - NI[i]|^2) + reg2*sum (x + margin)^2, x = dist_i - dist_j.
+    Both tables receive dense gradients (the sparse-dense products), hence the dense ApplyAdam kernel."""
+
+    def __init__(self, P, Q, ui_train, lr, reg1, reg2, margin):
+        super().__init__({"P": P, "Q": Q}, {"P": "dense", "Q": "dense"}, lr)
+        self.reg1, self.reg2, self.margin = reg1, reg2, margin
+        U, I = np.asarray(P).shape[0], np.asarray(Q).shape[0]
+        ui, iu, cnt = [], [], {}
+        for u, items in ui_train.items():
+            for it in items:
+                ui.append((u, it, np.float32(1.0 / len(items))))
+                cnt[it] = cnt.get(it, 0) + 1
+        for u, it, _ in ui:
+            iu.append((it, u, np.float32(1.0 / cnt[it])))
+
+        def sp(trip, shape):
+            idx = torch.tensor([[a for a, _, _ in trip], [b for _, b, _ in trip]], dtype=torch.long)
+            return idx, torch.tensor([float(c) for _, _, c in trip], dtype=f32), shape
+        self._ui, self._iu = sp(ui, (U, I)), sp(iu, (I, U))
+
+    def _nbr(self, w):
+        def mm(spec, dense):
+            idx, val, shape = spec
+            return torch.sparse.mm(torch.sparse_coo_tensor(idx, val.to(dense.dtype), shape), dense)
+        return mm(self._ui, w["Q"]), mm(self._iu, w["P"])
+
+    def loss(self, w, u, i, j):
+        u, i, j = (torch.as_tensor(np.asarray(x), dtype=torch.long) for x in (u, i, j))
+        NU, NI = self._nbr(w)
+        pu, qi, qj = w["P"][u], w["Q"][i], w["Q"][j]
+        nu, ni, nj = NU[u], NI[i], NI[j]
+        di = ((pu + nu * ni - qi) ** 2).sum(1)
+        dj = ((pu + nu * nj - qj) ** 2).sum(1)
+        reg_nbr = ((pu - nu) ** 2).sum() + ((qi - ni) ** 2).sum()
+        reg_dist = ((di + self.margin - dj) ** 2).sum()
+        return torch.clamp(di - dj + self.margin, min=0).sum() + (self.reg1 * reg_nbr + self.reg2 * reg_dist)
+
+    def scores(self, users, clip_users=True):
+        """pre_scores (TransCF.py:85-91): rs branch with clip_1(p_u), loo branch with p_u; [len(users), I], float64."""
+        w = {k: v.double() for k, v in self.params.items()}
+        NU, NI = self._nbr(w)
+        uu = torch.as_tensor(np.asarray(users), dtype=torch.long)
+        a = w["P"][uu]
+        if clip_users:
+            a = a / torch.clamp(a.norm(dim=1, keepdim=True), min=1.0)
+        return ((a[:, None, :] + NU[uu][:, None, :] * NI[None, :, :] - w["Q"][None, :, :]) ** 2).sum(2).numpy()
+
+
 class FM(Model):
     """model/rating/FM.py:20-53: y = w0 + sum_f wi[x_f] + 0.5*sum_k[(sum_f x v)^2 - sum_f x^2 v^2] (the linear
     term ignores x_value, :35,49); loss = sum (y - y_pre)^2 + reg*(l2(wi) + l2(vif)) over the FULL tables (:52)

@@ -21,7 +21,7 @@ def golden_dir():
 
 # The GPU suite runs with -x: the headline path (BPR step, eval, metrics, class surface, data-parallel, LOO) goes
 # first so that a failure in a side model cannot hide it.
-_ORDER = ["test_gpu_parity.py", "test_gpu_sharded.py", "test_gpu_sampler.py", "test_gpu_big.py", "test_gpu_ncf.py", "test_gpu_fm.py", "test_gpu_cml.py", "test_gpu_sbpr.py", "test_gpu_lrml.py"]
+_ORDER = ["test_gpu_parity.py", "test_gpu_sharded.py", "test_gpu_sampler.py", "test_gpu_big.py", "test_gpu_ncf.py", "test_gpu_fm.py", "test_gpu_cml.py", "test_gpu_sbpr.py", "test_gpu_lrml.py", "test_gpu_transcf.py"]
 
 
 def pytest_collection_modifyitems(config, items):
