@@ -152,6 +152,27 @@ def test_world_of_one_matches_plain_lazy_step():
     sess.close()
 
 
+def test_rccl_transport_single_rank_communicator():
+    """The RCCL transport itself (crec_comm_init -> ncclCommInitRank, the grouped ncclSend / ncclRecv all-to-all-v of request
+    lists, rows and gradient rows) on a communicator of ONE rank -- all one GPU can host: every exchange is a send to self
+    through RCCL.  Bit-identical to the same epoch without a communicator."""
+    U, I, B, d = 300, 40, 1024, 32
+    P0, Q0 = _tables(4, U, I, d)
+    streams, ranges = _streams(6, U, I, 1, [2 * B + 100])
+    P, Q, loss, _ = _run_sharded(1, P0, Q0, ranges, streams, B, d, epochs=2)
+    sess = runtime.Session(0)
+    parallel.init_rccl(sess, rank=0, world=1)
+    st = parallel.ShardedBprState(sess, P0, parallel.shard_items(Q0, 0, 1), I, 1e-3, 0.01, 0, 1)
+    u, i, j = (sess.to_dev(x) for x in streams[0])
+    got = np.concatenate([st.train_epoch(u, i, j, B).cpu().numpy() for _ in range(2)])
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(got, loss)
+    np.testing.assert_array_equal(st.P.cpu().numpy(), P)
+    np.testing.assert_array_equal(st.Q.cpu().numpy()[:I], Q)
+    assert st.stats_dict()["rows_served"] > 0
+    sess.close()
+
+
 def test_sharded_c5_row_width_and_batch():
     """BASELINE configs[4] row width and batch (d = 128, B = 6144 per rank) on a scaled-down catalogue, 2 ranks."""
     U, I, B, d = 20000, 5003, 6144, 128

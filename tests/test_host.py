@@ -290,3 +290,29 @@ def test_sbpr_sampler_matches_reference_stream(golden_dir, name):
     for got, want in ((u, "u"), (i, "i"), (i_s, "i_s"), (i_neg, "i_neg"), (suk, "suk")):
         assert np.array_equal(np.asarray(got).astype(np.int64), g[want]), want
     assert int(np.random.randint(2 ** 30)) == int(g["next"])
+
+
+def test_get_sp_mat_matches_reference_lists():
+    """utils/tools.py:100-113 (TransCF): the CSRs of cleverrec_amd.utils.tools.get_sp_mat against the index / value lists the
+    reference's own loops hand to tf.SparseTensor (tests/golden/sp_mat.npz, tools/make_golden.py:sp_mat_case): the same
+    entries, per row in the same order, and weights float32(1 / row length)."""
+    import os
+    from cleverrec_amd.utils.tools import get_sp_mat
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "sp_mat.npz"))
+    keys, ptr, items = z["keys"], z["ptr"], z["items"]
+
+    class D:
+        pass
+    D.user_nums, D.item_nums = int(z["user_nums"]), int(z["item_nums"])
+    D.ui_train = {int(k): [int(x) for x in items[ptr[n]:ptr[n + 1]]] for n, k in enumerate(keys)}
+    ui_ptr, ui_items, iu_ptr, iu_users = get_sp_mat(D)
+    assert list(z["ui_shape"]) == [D.user_nums, D.item_nums] and list(z["iu_shape"]) == [D.item_nums, D.user_nums]
+    for (idx, val, rptr, cols, n_rows) in ((z["ui_indices"], z["ui_values"], ui_ptr, ui_items, D.user_nums),
+                                            (z["iu_indices"], z["iu_values"], iu_ptr, iu_users, D.item_nums)):
+        assert len(rptr) == n_rows + 1 and rptr[-1] == len(idx)
+        for r in range(n_rows):
+            sel = idx[:, 0] == r  # the reference's entries of row r, in list order
+            np.testing.assert_array_equal(cols[rptr[r]:rptr[r + 1]], idx[sel, 1])
+            n = int(rptr[r + 1] - rptr[r])
+            if n:  # the device forms float32(1.0 / n) (csrc/transcf.hip nbr_weight); TF casts the list's float64 the same way
+                np.testing.assert_array_equal(val[sel].astype(np.float32), np.full(n, np.float32(1.0 / n)))

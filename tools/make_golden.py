@@ -113,6 +113,26 @@ def sbpr_case(sampler, seed=5, n_users=60, n_items=80, neg_ratio=3, batch=64):
                 i_s=i_s.astype(np.int64), i_neg=i_neg.astype(np.int64), suk=suk.astype(np.int64), next=nxt)
 
 
+def sp_mat_case(seed=9, n_users=70, n_items=50):
+    """get_sp_mat (utils/tools.py:100-113, TransCF's two neighbourhood matrices): the index / value lists the reference's own
+    loops hand to tf.SparseTensor -- the inert tensorflow module gets a SparseTensor attribute that returns its arguments --
+    for a synthetic ui_train with users without rows and items nobody holds."""
+    import tensorflow as tf
+    import utils.tools as tools
+    tf.SparseTensor = lambda indices, values, dense_shape: (indices, values, dense_shape)
+    try:
+        ui = synth_ui(seed, n_users, n_items, 1, 12, skip_every=9)
+        d = Data()
+        d.ui_train, d.user_nums, d.item_nums = ui, n_users, n_items
+        (ui_idx, ui_val, ui_shape), (iu_idx, iu_val, iu_shape) = tools.get_sp_mat(d)
+    finally:
+        del tf.SparseTensor
+    keys, ptr, items = csr(ui)
+    return dict(keys=keys, ptr=ptr, items=items, user_nums=n_users, item_nums=n_items, ui_indices=np.array(ui_idx, dtype=np.int64),
+                ui_values=np.array(ui_val, dtype=np.float64), ui_shape=np.array(ui_shape), iu_indices=np.array(iu_idx, dtype=np.int64),
+                iu_values=np.array(iu_val, dtype=np.float64), iu_shape=np.array(iu_shape))
+
+
 def metrics_cases(metrics, n=400):
     g = np.random.Generator(np.random.PCG64(7))
     cases = [([5], [1, 5, 3], 3), ([5, 8, 9], [9, 2, 5, 7, 1, 0, 3, 4, 6, 10], 10), ([1, 2], [7, 8], 2),
@@ -297,6 +317,7 @@ def main():
     np.savez_compressed(os.path.join(a.out, "sampler_sbpr_tiny.npz"), **sbpr_case(sampler, seed=11, n_users=9, n_items=40, neg_ratio=2, batch=8))
     with open(os.path.join(a.out, "metrics.json"), "w") as f:
         json.dump(metrics_cases(metrics), f)
+    np.savez_compressed(os.path.join(a.out, "sp_mat.npz"), **sp_mat_case())
     np.savez_compressed(os.path.join(a.out, "preprocess_syn.npz"), **preprocess_case(a.ref))
     np.savez_compressed(os.path.join(a.out, "preprocess_social.npz"), **preprocess_case(a.ref, social=True))
     np.savez_compressed(os.path.join(a.out, "rating_syn.npz"), **rating_case(a.ref))
