@@ -607,18 +607,31 @@ extern "C" int crec_ncf_train_epoch(crec_ctx *ctx, const crec_ncf *mdl, crec_ada
         od.kind = ROWS_DENSE;
         const crec_small_job small{mdl->small.var, mdl->small.m, mdl->small.v, partial, (int)crec_ceil_div(nbt, T), d.n_small,
                                    d.n_small, od};
-        if (has_g) {
+        if (has_g && has_m && d.dg == hm && !ctx->knob_ncf_generic) {
+            // NeuMF with equal widths: a user's P_gmf and P_mlp rows (an item's Q_gmf and Q_mlp rows) share their slots --
+            // one wave updates both (rows_apply_row_pair): half the waves, the index walked once
             job(mdl->P_gmf, U, d.dg, vu, c_pg, mdl->reg_gmf);
+            set.tables[set.n_tables - 1].t2 = crec_rows_table{mdl->P_mlp.var, mdl->P_mlp.m, mdl->P_mlp.v, U, hm};
+            set.tables[set.n_tables - 1].contrib2 = c_pm;
+            set.tables[set.n_tables - 1].reg_occ2 = mdl->reg_mlp;
             job(mdl->Q_gmf, I, d.dg, vi, c_qg, mdl->reg_gmf);
-        }
-        if (has_g && has_m && cls(d.dg) != cls(hm)) { // two width classes: two launches
-            if (int rc = crec_apply_all(ctx, set, st))
-                return rc;
-            set = crec_apply_set{};
-        }
-        if (has_m) {
-            job(mdl->P_mlp, U, hm, vu, c_pm, mdl->reg_mlp);
-            job(mdl->Q_mlp, I, hm, vi, c_qm, mdl->reg_mlp);
+            set.tables[set.n_tables - 1].t2 = crec_rows_table{mdl->Q_mlp.var, mdl->Q_mlp.m, mdl->Q_mlp.v, I, hm};
+            set.tables[set.n_tables - 1].contrib2 = c_qm;
+            set.tables[set.n_tables - 1].reg_occ2 = mdl->reg_mlp;
+        } else {
+            if (has_g) {
+                job(mdl->P_gmf, U, d.dg, vu, c_pg, mdl->reg_gmf);
+                job(mdl->Q_gmf, I, d.dg, vi, c_qg, mdl->reg_gmf);
+            }
+            if (has_g && has_m && cls(d.dg) != cls(hm)) { // two width classes: two launches
+                if (int rc = crec_apply_all(ctx, set, st))
+                    return rc;
+                set = crec_apply_set{};
+            }
+            if (has_m) {
+                job(mdl->P_mlp, U, hm, vu, c_pm, mdl->reg_mlp);
+                job(mdl->Q_mlp, I, hm, vi, c_qm, mdl->reg_mlp);
+            }
         }
         set.small = small;
         if (int rc = crec_apply_all(ctx, set, st))

@@ -40,6 +40,11 @@ struct crec_rows_job {
     const float *dense_grad; // optional (see rows_adam.hip)
     float *row_out;          // optional
     crec_rows_opt o;
+    // optional partner: a second table with the SAME rows, width and slots (rowseg / order), its own contribution rows and
+    // l2 weight, updated by the same wave (rows_apply_row_pair); t2.var == nullptr: none
+    crec_rows_table t2;
+    const float *contrib2;
+    float reg_occ2;
 };
 
 struct crec_small_job { // dense ApplyAdam of a small vector from partial sums

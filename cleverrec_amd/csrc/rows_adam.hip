@@ -200,6 +200,68 @@ __device__ __forceinline__ void rows_apply_row(const crec_rows_table &t, const i
     st4_stream(t.v + ro, v);
 }
 
+// Two tables that share their row ids AND their slots (NeuMF's P_gmf / P_mlp of a user, Q_gmf / Q_mlp of an item: every
+// instance gathers the same row of both) updated by ONE wave: the row's segments and slot ids are walked once, the two
+// contribution rows of a slot travel together -- half the waves, twice the bytes in flight per wave.  TF1 sparse Adam only.
+template <int LPR>
+__device__ __forceinline__ void rows_apply_row_pair(const crec_rows_table &t1, const crec_rows_table &t2, const int2 *__restrict__ rowseg,
+                                                    const int32_t *__restrict__ order, const float *__restrict__ contrib1,
+                                                    const float *__restrict__ contrib2, const crec_rows_opt &o, float reg2, int64_t r,
+                                                    int chunks)
+{
+    constexpr int G = 64 / LPR;
+    const int lane = threadIdx.x & 63, g = lane / LPR, l = lane % LPR;
+    if (r >= t1.rows)
+        return;
+    const int d = t1.d;
+    const bool act = 4 * l < d;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t ro = r * d + 4 * l;
+    const int2 rs0 = rowseg[r];
+    const float4 var1 = act ? ld4(t1.var + ro) : zero, var2 = act ? ld4(t2.var + ro) : zero;
+    float4 m1 = zero, v1 = zero, m2 = zero, v2 = zero;
+    if (g == 0 && act) {
+        m1 = ld4(t1.m + ro), v1 = ld4(t1.v + ro);
+        m2 = ld4(t2.m + ro), v2 = ld4(t2.v + ro);
+    }
+    float4 a1 = zero, a2 = zero;
+    for (int ch = 0; ch < chunks; ++ch) { // chunk by chunk = ascending slot order
+        int2 rs = rs0;
+        if (ch != 0)
+            rs = rowseg[(int64_t)ch * t1.rows + r];
+        for (int k = rs.x + g; k < rs.x + rs.y; k += G) {
+            if (act) {
+                const int64_t so = (int64_t)order[k] * d + 4 * l;
+                const float4 c1 = ld4(contrib1 + so), c2 = ld4(contrib2 + so);
+                a1.x = a1.x + (c1.x + o.reg_occ * var1.x), a1.y = a1.y + (c1.y + o.reg_occ * var1.y);
+                a1.z = a1.z + (c1.z + o.reg_occ * var1.z), a1.w = a1.w + (c1.w + o.reg_occ * var1.w);
+                a2.x = a2.x + (c2.x + reg2 * var2.x), a2.y = a2.y + (c2.y + reg2 * var2.y);
+                a2.z = a2.z + (c2.z + reg2 * var2.z), a2.w = a2.w + (c2.w + reg2 * var2.w);
+            }
+        }
+    }
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1) { // groups hold disjoint slots: add them, lower group first
+        a1.x = a1.x + __shfl_down(a1.x, off, 64), a1.y = a1.y + __shfl_down(a1.y, off, 64);
+        a1.z = a1.z + __shfl_down(a1.z, off, 64), a1.w = a1.w + __shfl_down(a1.w, off, 64);
+        a2.x = a2.x + __shfl_down(a2.x, off, 64), a2.y = a2.y + __shfl_down(a2.y, off, 64);
+        a2.z = a2.z + __shfl_down(a2.z, off, 64), a2.w = a2.w + __shfl_down(a2.w, off, 64);
+    }
+    if (g != 0 || !act)
+        return;
+    const float omb1 = 1.0f - o.beta1, omb2 = 1.0f - o.beta2;
+    const auto upd = [&](float g_, float var_, float &m_, float &v_) {
+        m_ = m_ * o.beta1 + g_ * omb1;
+        v_ = v_ * o.beta2 + (g_ * g_) * omb2;
+        return var_ - (o.lr_t * m_) / (sqrtf(v_) + o.eps);
+    };
+    float4 n1, n2;
+    n1.x = upd(a1.x, var1.x, m1.x, v1.x), n1.y = upd(a1.y, var1.y, m1.y, v1.y), n1.z = upd(a1.z, var1.z, m1.z, v1.z), n1.w = upd(a1.w, var1.w, m1.w, v1.w);
+    n2.x = upd(a2.x, var2.x, m2.x, v2.x), n2.y = upd(a2.y, var2.y, m2.y, v2.y), n2.z = upd(a2.z, var2.z, m2.z, v2.z), n2.w = upd(a2.w, var2.w, m2.w, v2.w);
+    st4_stream(t1.var + ro, n1), st4_stream(t1.m + ro, m1), st4_stream(t1.v + ro, v1);
+    st4_stream(t2.var + ro, n2), st4_stream(t2.m + ro, m2), st4_stream(t2.v + ro, v2);
+}
+
 // The same update with the wave's G = 64/LPR lane groups SIDE BY SIDE, one table row each (rows r0 .. r0+G-1): every
 // lane does Adam arithmetic and a wave moves G rows per round trip instead of one -- the sweep over a table is bound by
 // rounds of waves times a wave's chain of round trips, not by bytes.  A group adds its row's slots in ascending slot
@@ -425,7 +487,9 @@ template <int LPR> __global__ __launch_bounds__(256) void apply_all(crec_apply_s
     if (k < a.n_tables) {
         const crec_rows_job &j = a.tables[k];
         const int64_t wave = (int64_t)(bi - first) * 4 + (threadIdx.x >> 6);
-        if (rows_per_wave(LPR) > 1)
+        if (j.t2.var)
+            rows_apply_row_pair<LPR>(j.t, j.t2, j.rowseg, j.order, j.contrib, j.contrib2, j.o, j.reg_occ2, wave, j.chunks > 1 ? j.chunks : 1);
+        else if (rows_per_wave(LPR) > 1)
             rows_apply_side<LPR>(j.t, j.rowseg, j.order, j.contrib, j.dense_grad, j.row_out, j.o, wave * (64 / LPR),
                                  j.chunks > 1 ? j.chunks : 1);
         else
@@ -515,7 +579,10 @@ int crec_apply_all(crec_ctx *ctx, crec_apply_set &a, hipStream_t st)
             l <<= 1;
         CREC_REQUIRE(ctx, lpr == 0 || l == lpr, "apply set: tables of one launch must share the row width class");
         lpr = l;
-        blocks += (int)crec_ceil_div(a.tables[k].t.rows, 4 * rows_per_wave(l));
+        CREC_REQUIRE(ctx, !a.tables[k].t2.var || (a.tables[k].t2.rows == a.tables[k].t.rows && a.tables[k].t2.d == a.tables[k].t.d &&
+                                                   a.tables[k].o.kind == ROWS_SPARSE_TF1 && !a.tables[k].dense_grad && !a.tables[k].row_out),
+                     "apply set: a paired table shares rows, width and slots with its partner (TF1 sparse Adam only)");
+        blocks += (int)crec_ceil_div(a.tables[k].t.rows, 4 * (a.tables[k].t2.var ? 1 : rows_per_wave(l)));
         a.block_end[k] = blocks;
     }
     if (a.scalar.rows > 0)
