@@ -60,11 +60,11 @@ constexpr int HEAVY = 64;
 
 // sum over k = k0 + gi, k0 + gi + ng, ... < k1 of w_k * table[idx[k]].  ADJ = false: w_k = w_row (the forward products; each
 // term scaled first, as the CPU kernel of tf.sparse_tensor_dense_matmul does).  ADJ = true (the adjoint products): neighbour
-// nb weighs 1 / deg(nb), deg from optr, and neighbours no slot of the batch names hold zero rows and are skipped.
+// nb weighs aw[nb] = 1 / deg(nb) if a slot of the batch names it, else 0 -- its gradient row is zero and is not read
+// (tcf_row_sums leaves aw beside the sums: one 4-byte load per neighbour decides).
 template <bool ADJ>
 __device__ __forceinline__ float4 nbr_sum(const float *__restrict__ table, const int32_t *__restrict__ idx, int64_t k0, int64_t k1, int gi,
-                                          int ng, int d, int l, float w_row, const int64_t *__restrict__ optr,
-                                          const int2 *__restrict__ orowseg, int64_t orows, int ochunks)
+                                          int ng, int d, int l, float w_row, const float *__restrict__ aw)
 {
     constexpr int DEEP = 8;
     float4 acc = f4(0.f, 0.f, 0.f, 0.f);
@@ -78,13 +78,9 @@ __device__ __forceinline__ float4 nbr_sum(const float *__restrict__ table, const
             const int64_t kk = k + (int64_t)e * ng;
             if (kk < k1) {
                 const int nb = idx[kk];
-                if (!ADJ) {
+                w[e] = ADJ ? aw[nb] : w_row;
+                if (!ADJ || w[e] != 0.f)
                     c[e] = ld4(table + (int64_t)nb * d + 4 * l);
-                    w[e] = w_row;
-                } else if (touched(orowseg, orows, ochunks, nb) != 0) {
-                    c[e] = ld4(table + (int64_t)nb * d + 4 * l);
-                    w[e] = nbr_weight((int)(optr[nb + 1] - optr[nb]));
-                }
             }
         }
 #pragma unroll
@@ -135,7 +131,7 @@ __global__ __launch_bounds__(256) void tcf_nbr_rows(float *__restrict__ out, con
     const bool act = 4 * l < d;
     float4 acc = f4(0.f, 0.f, 0.f, 0.f);
     if (act)
-        acc = nbr_sum<false>(table, idx, k0, k1, WG ? (int)threadIdx.x / LPR : 0, WG ? 256 / LPR : 1, d, l, w, nullptr, nullptr, 0, 0);
+        acc = nbr_sum<false>(table, idx, k0, k1, WG ? (int)threadIdx.x / LPR : 0, WG ? 256 / LPR : 1, d, l, w, nullptr);
     if (WG) {
         acc = heavy_reduce<LPR>(acc, red);
         if ((int)threadIdx.x >= LPR)
@@ -186,11 +182,13 @@ __global__ __launch_bounds__(256) void tcf_triples(const float *__restrict__ P, 
     st4(c_ni + s_j, f4(gj.x * nu.x, gj.y * nu.y, gj.z * nu.z, gj.w * nu.w));
 }
 
-// dst_a[r] = sum of ca over row r's slots, dst_b[r] = sum of cb, slot order; rows without slots are zero
+// dst_a[r] = sum of ca over row r's slots, dst_b[r] = sum of cb, slot order; rows without slots are zero.
+// aw[r] = the row's weight in its neighbourhood matrix, 1 / deg(r), if it has slots, else 0 (see nbr_sum)
 template <int LPR>
-__global__ __launch_bounds__(256) void tcf_row_sums(float *__restrict__ dst_a, float *__restrict__ dst_b, const float *__restrict__ ca,
-                                                    const float *__restrict__ cb, const int2 *__restrict__ rowseg,
-                                                    const int32_t *__restrict__ order, int64_t rows, int d, int chunks)
+__global__ __launch_bounds__(256) void tcf_row_sums(float *__restrict__ dst_a, float *__restrict__ dst_b, float *__restrict__ aw,
+                                                    const float *__restrict__ ca, const float *__restrict__ cb,
+                                                    const int2 *__restrict__ rowseg, const int32_t *__restrict__ order,
+                                                    const int64_t *__restrict__ ptr, int64_t rows, int d, int chunks)
 {
     constexpr int G = 64 / LPR, DEEP = 4;
     const int lane = threadIdx.x & 63, g = lane / LPR, l = lane % LPR;
@@ -198,8 +196,10 @@ __global__ __launch_bounds__(256) void tcf_row_sums(float *__restrict__ dst_a, f
     if (r >= rows || 4 * l >= d)
         return;
     float4 a = f4(0.f, 0.f, 0.f, 0.f), b = a;
+    int n_slots = 0;
     for (int ch = 0; ch < chunks; ++ch) {
         const int2 rs = rowseg[(int64_t)ch * rows + r];
+        n_slots += rs.y;
         for (int k = rs.x; k < rs.x + rs.y; k += DEEP) {
             float4 x[DEEP], y[DEEP];
 #pragma unroll
@@ -219,17 +219,19 @@ __global__ __launch_bounds__(256) void tcf_row_sums(float *__restrict__ dst_a, f
     }
     st4(dst_a + r * d + 4 * l, a);
     st4(dst_b + r * d + 4 * l, b);
+    if (l == 0)
+        aw[r] = n_slots ? nbr_weight((int)(ptr[r + 1] - ptr[r])) : 0.f;
 }
 
 // g[r] = direct[r] + sum_k w(idx[k]) * nbr_grad[idx[k]] over row r's neighbours (the adjoint of the OTHER side's product:
-// neighbour nb contributes with ITS weight 1 / deg(nb), deg from optr), then tf.train.AdamOptimizer's dense kernel on the
+// neighbour nb contributes with ITS weight aw[nb]), then tf.train.AdamOptimizer's dense kernel on the
 // row.  WG as in tcf_nbr_rows.
 template <int LPR, bool WG>
 __global__ __launch_bounds__(256) void tcf_grad_adam(float *__restrict__ var, float *__restrict__ m, float *__restrict__ v,
                                                      const float *__restrict__ direct, const float *__restrict__ nbr_grad,
                                                      const int64_t *__restrict__ ptr, const int32_t *__restrict__ idx,
-                                                     const int64_t *__restrict__ optr, const int2 *__restrict__ orowseg, int64_t orows,
-                                                     int ochunks, int64_t rows, int d, float lr_t, float beta1, float beta2, float eps)
+                                                     const float *__restrict__ aw, int64_t rows, int d, float lr_t, float beta1,
+                                                     float beta2, float eps)
 {
     __shared__ float4 red[WG ? 256 : 1];
     constexpr int G = 64 / LPR;
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(256) void tcf_grad_adam(float *__restrict__ var, fl
     const bool act = 4 * l < d;
     float4 acc = f4(0.f, 0.f, 0.f, 0.f);
     if (act)
-        acc = nbr_sum<true>(nbr_grad, idx, k0, k1, WG ? (int)threadIdx.x / LPR : 0, WG ? 256 / LPR : 1, d, l, 0.f, optr, orowseg, orows, ochunks);
+        acc = nbr_sum<true>(nbr_grad, idx, k0, k1, WG ? (int)threadIdx.x / LPR : 0, WG ? 256 / LPR : 1, d, l, 0.f, aw);
     if (WG) {
         acc = heavy_reduce<LPR>(acc, red);
         if ((int)threadIdx.x >= LPR)
@@ -419,7 +421,8 @@ extern "C" int crec_transcf_train_epoch(crec_ctx *ctx, const crec_transcf *m, cr
     const size_t tu = sizeof(float) * (size_t)U * d, ti = sizeof(float) * (size_t)I * d;
     const size_t cu = sizeof(float) * (size_t)B * d, cq = sizeof(float) * (size_t)2 * B * d;
     const size_t sl = sizeof(int32_t) * (size_t)2 * B, li = sizeof(float) * (size_t)N;
-    if (int rc = crec_reserve(ctx, &ctx->idx_ws, up(ixu) + up(ixq) + 3 * up(tu) + 3 * up(ti) + 2 * up(cu) + 2 * up(cq) + up(sl) + up(li)))
+    const size_t awu = sizeof(float) * (size_t)U, awi = sizeof(float) * (size_t)I;
+    if (int rc = crec_reserve(ctx, &ctx->idx_ws, up(ixu) + up(ixq) + 3 * up(tu) + 3 * up(ti) + 2 * up(cu) + 2 * up(cq) + up(sl) + up(li) + up(awu) + up(awi)))
         return rc;
     char *p = (char *)ctx->idx_ws.ptr;
     crec_rows_index_view vu, vq;
@@ -437,6 +440,7 @@ extern "C" int crec_transcf_train_epoch(crec_ctx *ctx, const crec_transcf *m, cr
     float *c_p = take(cu), *c_nu = take(cu), *c_q = take(cq), *c_ni = take(cq);
     int32_t *slots = (int32_t *)take(sl);
     float *loss_inst = take(li);
+    float *aw_u = take(awu), *aw_i = take(awi);
     for (int64_t b = 0; b < nb; ++b) {
         const int64_t t0 = b * B;
         const int nbt = (int)((N - t0) < B ? (N - t0) : B);
@@ -452,18 +456,17 @@ extern "C" int crec_transcf_train_epoch(crec_ctx *ctx, const crec_transcf *m, cr
         const dim3 gu((unsigned)crec_ceil_div(crec_ceil_div(U, G), 4)), gi((unsigned)crec_ceil_div(crec_ceil_div(I, G), 4));
 #define TCF_GA(L, WG, GU, GI)                                                                                                           \
     hipLaunchKernelGGL((tcf_grad_adam<L, WG>), GU, dim3(256), 0, st, m->P.var, m->P.m, m->P.v, (const float *)GPd, (const float *)GNI,    \
-                       m->ui_ptr, m->ui_items, m->iu_ptr, (const int2 *)vq.rowseg, I, vq.chunks, U, d, lr_t, opt->beta1, opt->beta2,     \
-                       opt->eps);                                                                                                       \
+                       m->ui_ptr, m->ui_items, (const float *)aw_i, U, d, lr_t, opt->beta1, opt->beta2, opt->eps);                       \
     hipLaunchKernelGGL((tcf_grad_adam<L, WG>), GI, dim3(256), 0, st, m->Q.var, m->Q.m, m->Q.v, (const float *)GQd, (const float *)GNU,    \
-                       m->iu_ptr, m->iu_users, m->ui_ptr, urs, U, vu.chunks, I, d, lr_t, opt->beta1, opt->beta2, opt->eps)
+                       m->iu_ptr, m->iu_users, (const float *)aw_u, I, d, lr_t, opt->beta1, opt->beta2, opt->eps)
 #define TCF_STEP(L)                                                                                                                      \
     hipLaunchKernelGGL((tcf_triples<L>), gt, dim3(256), 0, st, (const float *)m->P.var, (const float *)m->Q.var, (const float *)NU,        \
                        (const float *)NI, d, u + t0, i + t0, j + t0, nbt, m->reg1, m->reg2, m->margin, c_p, c_nu, c_q, c_ni,              \
                        loss_inst + t0);                                                                                                  \
-    hipLaunchKernelGGL((tcf_row_sums<L>), gu, dim3(256), 0, st, GPd, GNU, (const float *)c_p, (const float *)c_nu, urs, uord, U, d,        \
-                       vu.chunks);                                                                                                       \
-    hipLaunchKernelGGL((tcf_row_sums<L>), gi, dim3(256), 0, st, GQd, GNI, (const float *)c_q, (const float *)c_ni,                         \
-                       (const int2 *)vq.rowseg, (const int32_t *)vq.order, I, d, vq.chunks);                                             \
+    hipLaunchKernelGGL((tcf_row_sums<L>), gu, dim3(256), 0, st, GPd, GNU, aw_u, (const float *)c_p, (const float *)c_nu, urs, uord,        \
+                       m->ui_ptr, U, d, vu.chunks);                                                                                      \
+    hipLaunchKernelGGL((tcf_row_sums<L>), gi, dim3(256), 0, st, GQd, GNI, aw_i, (const float *)c_q, (const float *)c_ni,                   \
+                       (const int2 *)vq.rowseg, (const int32_t *)vq.order, m->iu_ptr, I, d, vq.chunks);                                  \
     TCF_GA(L, false, gu, gi);                                                                                                            \
     TCF_GA(L, true, dim3((unsigned)U), dim3((unsigned)I))
         TCF_LPR_SWITCH(lpr, TCF_STEP)
