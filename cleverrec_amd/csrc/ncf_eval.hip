@@ -46,6 +46,9 @@ __global__ void ncf_first_layer(const float *__restrict__ X, const int32_t *__re
 //   The logit, not its sigmoid, is written (same ranking).
 constexpr int MAXF4 = 4; // float4s of a tile's [TI][width] rows per thread: width <= MAXF4 * 4 * PT / TI = 128
 
+// <L0C, LC, DGC>: the tower shape fixed at compile time (the shipped confs' layers [128, 64, 32]; L0C < 0: from NcfDev), as
+// for the training tile (csrc/ncf.hip): the tile is bound by its bookkeeping instructions, which fold away with the shape
+template <int L0C, int LC, int DGC>
 __global__ __launch_bounds__(PT) void ncf_pair_logits(NcfDev m, const int32_t *__restrict__ users, int Bt, int64_t I,
                                                       const float *__restrict__ Au, const float *__restrict__ Bi,
                                                       float *__restrict__ logits)
@@ -54,10 +57,18 @@ __global__ __launch_bounds__(PT) void ncf_pair_logits(NcfDev m, const int32_t *_
     constexpr int NWV = PT / 64;
     const int tid = threadIdx.x;
     const int64_t u0 = (int64_t)blockIdx.y * TU;
-    const bool has_g = m.kind != 1, has_m = m.kind != 0;
-    const int dg = has_g ? m.dg : 0, ldg = dg + 1;
-    const int w1 = has_m ? m.L0 / 2 : 0, ldb = w1 + 1, L = has_m ? m.n_layers : 0;
-    const auto width_of = [&](int k) { return m.L0 >> k; }; // input width of layer k
+    constexpr bool FIXED = L0C >= 0;
+    const bool has_g = FIXED ? DGC > 0 : m.kind != 1, has_m = FIXED ? LC > 0 : m.kind != 0;
+    const int L0 = FIXED ? L0C : m.L0;
+    const int dg = FIXED ? DGC : (has_g ? m.dg : 0), ldg = dg + 1;
+    const int w1 = has_m ? L0 / 2 : 0, ldb = w1 + 1, L = FIXED ? LC : (has_m ? m.n_layers : 0);
+    const auto width_of = [&](int k) { return L0 >> k; }; // input width of layer k
+    const auto fw_of = [&](int k) { // flat offset of W_k in the parameter block [W_0 | b_0 | ... | h]; fw_of(L) = h's
+        int o = 0;
+        for (int j = 0; j < k; ++j)
+            o += width_of(j) * width_of(j + 1) + width_of(j + 1);
+        return o;
+    };
     const auto woff_of = [&](int k) {                         // floats before W_k among layers 1..
         int o = 0;
         for (int j = 1; j < k; ++j)
@@ -84,16 +95,16 @@ __global__ __launch_bounds__(PT) void ncf_pair_logits(NcfDev m, const int32_t *_
     float *W_base = hl + last;
 
     // ---- once per workgroup: parameters and the users' rows ---------------------------------------------------------
-    const float *h = m.small + m.h_off;
+    const float *h = m.small + (has_m ? fw_of(L) : 0);
     for (int c = tid; c < last; c += PT)
         hl[c] = h[dg + c];
     for (int k = 1; k < L; ++k) {
         for (int c = tid; c < width_of(k + 1); c += PT)
-            b_base[boff_of(k) + c] = m.small[m.b_off[k] + c];
-        stage_weights<PT>(W_base + woff_of(k), m.small + m.w_off[k], width_of(k), width_of(k + 1));
+            b_base[boff_of(k) + c] = m.small[fw_of(k) + width_of(k) * width_of(k + 1) + c];
+        stage_weights<PT>(W_base + woff_of(k), m.small + fw_of(k), width_of(k), width_of(k + 1));
     }
     for (int k = tid; k < TU * dg; k += PT) {
-        const int ul = k / dg, c = k % dg;
+        const int ul = k / (dg > 0 ? dg : 1), c = k % (dg > 0 ? dg : 1);
         ph[k] = u0 + ul < Bt ? m.Pg[(int64_t)users[u0 + ul] * dg + c] * h[c] : 0.f;
     }
     for (int k = tid; k < TU * w1; k += PT)
@@ -357,7 +368,17 @@ int crec_ncf_scores(crec_ctx *ctx, const crec_ncf *mdl, const int32_t *users, in
     }
     lds = sizeof(float) * ncf_pair_lds_floats(d.kind != CREC_NCF_MLP, has_m, d.dg, d.L0, d.n_layers);
     CREC_REQUIRE(ctx, lds <= 160 * 1024, "model too wide for the scoring tile (%zu bytes of LDS)", lds);
-    CREC_HIP(ctx, hipFuncSetAttribute((const void *)ncf_pair_logits, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    using PairFn = void (*)(NcfDev, const int32_t *, int, int64_t, const float *, const float *, float *);
+    PairFn pair_fn = ncf_pair_logits<-1, 0, 0>;
+    if (has_m && d.L0 == 128 && d.n_layers == 3 && !ctx->knob_ncf_generic) {
+        if (d.kind == CREC_NCF_MLP)
+            pair_fn = ncf_pair_logits<128, 3, 0>;
+        else if (d.dg == 64)
+            pair_fn = ncf_pair_logits<128, 3, 64>;
+        else if (d.dg == 32)
+            pair_fn = ncf_pair_logits<128, 3, 32>;
+    }
+    CREC_HIP(ctx, hipFuncSetAttribute((const void *)pair_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     CREC_REQUIRE(ctx, d.L0 / 2 <= MAXF4 * 4 * PT / TI && d.dg <= MAXF4 * 4 * PT / TI,
                  "scoring tile: row widths up to %d", MAXF4 * 4 * PT / TI);
     // a workgroup keeps its TU users and walks the item tiles; enough splits of the catalogue for two workgroups per CU's worth of work
@@ -366,7 +387,7 @@ int crec_ncf_scores(crec_ctx *ctx, const crec_ncf *mdl, const int32_t *users, in
     splits = splits < 1 ? 1 : (splits > n_tiles ? n_tiles : splits);
     const dim3 grid((unsigned)splits, (unsigned)user_tiles);
     crec_prof_begin(ctx, CREC_K_NCF_SCORES, st);
-    CREC_KLAUNCH(ctx, ncf_pair_logits, grid, dim3(PT), lds, st, d, users, (int)Bt, I, (const float *)Au, (const float *)Bi,
+    CREC_KLAUNCH(ctx, pair_fn, grid, dim3(PT), lds, st, d, users, (int)Bt, I, (const float *)Au, (const float *)Bi,
                        logits);
     crec_prof_end(ctx, st);
     CREC_HIP(ctx, hipGetLastError());

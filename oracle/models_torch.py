@@ -209,6 +209,14 @@ class MLP(Model):
         logits = _tower(torch.cat([pu, qi], 1), w, self.n_layers) @ w["h_mlp"]
         return _pointwise_loss(self.loss_func, y, logits) + self.reg * (_l2(pu) + _l2(qi))
 
+    def predict(self, users):  # MLP.py:45-52,71-77 for every item
+        w = self.params
+        out = []
+        for uu in torch.as_tensor(users, dtype=torch.long):
+            x = torch.cat([w["P"][uu].expand(len(w["Q"]), -1), w["Q"]], 1)
+            out.append(torch.sigmoid(_tower(x, w, self.n_layers) @ w["h_mlp"]))
+        return torch.stack(out).numpy()
+
 
 class NeuMF(Model):
     """model/ranking/NeuMF.py:33-105: four tables; logit = concat(pg*qg, tower(concat(pm, qm))) . h_neumf (:84);

@@ -209,6 +209,34 @@ def test_neumf_full_catalogue_eval(sess, tmp_path):
     np.testing.assert_allclose(np.mean(HR[1]), np.mean(H[1]), rtol=1e-6)
 
 
+@pytest.mark.parametrize("kind,d", [("NeuMF", 64), ("NeuMF", 32), ("MLP", 0)])
+def test_scores_at_the_shipped_tower_shape(sess, kind, d):
+    """crec_ncf_scores at layers [128, 64, 32] (shape-specialised ncf_pair_logits, csrc/ncf_eval.hip): against the oracle's
+    predict() and against the generic kernel at the same shape (`ncf_generic`); a catalogue that is not a multiple of the
+    64-item tile, more users than one workgroup's four."""
+    U, I = 37, 333
+    g = np.random.Generator(np.random.PCG64(40 + d))
+    Ws, bs, last = _tower(g, 128, 3)
+    Pm, Qm = _rand(g, U, 64, scale=0.5), _rand(g, I, 64, scale=0.5)
+    if kind == "NeuMF":
+        Pg, Qg, h = _rand(g, U, d, scale=0.5), _rand(g, I, d, scale=0.5), _rand(g, d + last, scale=0.5)
+        st = runtime.NcfState(sess, "NeuMF", {"P_gmf": Pg, "Q_gmf": Qg, "P_mlp": Pm, "Q_mlp": Qm}, Ws, bs, h, lr=1e-3)
+        om = MT.NeuMF(Pg, Qg, Pm, Qm, Ws, bs, h, lr=1e-3, reg1=0.0, reg2=0.0)
+    else:
+        h = _rand(g, last, scale=0.5)
+        st = runtime.NcfState(sess, "MLP", {"P_mlp": Pm, "Q_mlp": Qm}, Ws, bs, h, lr=1e-3)
+        om = MT.MLP(Pm, Qm, Ws, bs, h, lr=1e-3, reg=0.0)
+    users = np.array([0, 36, 5, 5, 17, 2, 9], dtype=np.int32)
+    z = runtime.ncf_scores(sess, st, sess.to_dev(users)).cpu().numpy()
+    sess.ctx.set_option("ncf_generic", 1)
+    try:
+        zg = runtime.ncf_scores(sess, st, sess.to_dev(users)).cpu().numpy()
+    finally:
+        sess.ctx.set_option("ncf_generic", 0)
+    np.testing.assert_allclose(z, zg, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(1.0 / (1.0 + np.exp(-z.astype(np.float64))), om.predict(users), rtol=2e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize("kind", ["GMF", "NeuMF"])
 def test_square_loss_matches_oracle(sess, kind):
     """loss_func = square: get_loss(.., self.y, self.logits) = sum (y - logits)^2 (utils/tools.py:74-75), the other loss a
