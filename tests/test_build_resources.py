@@ -63,3 +63,19 @@ def test_row_apply_kernels_do_not_spill():
     assert ks
     for v in ks:
         assert v["ScratchSize"] == 0 and v["Occupancy"] >= 8, v
+
+
+def test_tile_kernels_fit_their_workgroups():
+    """The on-chip tile kernels run 512-thread workgroups, one per CU (their LDS): two waves per SIMD, i.e. at most 256
+    VGPRs and nothing in scratch -- the first one-round prologue of ncf_tile spilled 1.7 KB per lane without any test
+    noticing.  The shape-specialised instantiations (the shipped tower / the shipped LRML shape) must exist."""
+    res = _resources("ncf.hip", ("-ffp-contract=off",))
+    tiles = {k: v for k, v in res.items() if "ncf_tile" in k}
+    assert any("Li128ELi3ELi64E" in k for k in tiles) and any("Lin1E" in k for k in tiles), list(tiles)
+    for v in tiles.values():
+        assert v["VGPRs"] <= 256 and v["ScratchSize"] == 0 and v["Occupancy"] >= 2, v
+    res = _resources("lrml.hip", ("-ffp-contract=off",))
+    tiles = {k: v for k, v in res.items() if "lrml_tile" in k or "lrml_scores" in k}
+    assert any("Li128ELi50E" in k for k in tiles), list(tiles)
+    for v in tiles.values():
+        assert v["VGPRs"] <= 256 and v["ScratchSize"] == 0 and v["Occupancy"] >= 2, v
