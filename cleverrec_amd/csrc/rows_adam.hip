@@ -467,7 +467,7 @@ __device__ __forceinline__ void scalar_rows_block(const crec_scalar_job &j, int 
 // [block_end[k-1], block_end[k]) sweep table k, four rows per block), then an optional one-column table (256 rows
 // per block); the small dense vector leads the grid
 // (16 elements per block; same slices, hence the same sums, as small_adam_dense)
-template <int LPR> __global__ __launch_bounds__(256) void apply_all(crec_apply_set a)
+template <int LPR> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void apply_all(crec_apply_set a)
 {
     __shared__ float red[SAD_SL * 16];
     // the small vector's blocks come FIRST: theirs is the longest chain of the launch (two rounds of strided partial
