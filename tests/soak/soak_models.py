@@ -129,8 +129,9 @@ def main():
             np.testing.assert_allclose(loss, ol, rtol=5e-5, atol=1e-5)
             for dev, name in ((st.P, "P"), (st.Q, "Q"), (st.K, "K"), (st.M, "M")):
                 close(dev, om.numpy(name), name)
-            users = g.integers(0, U, 5).astype(np.int32)
-            np.testing.assert_allclose(st.scores(sess.to_dev(users)).cpu().numpy(), om.scores(users), rtol=5e-5, atol=1e-6)
+            users = g.integers(0, U, 5).astype(np.int32)  # distances of the DEVICE's parameters (the trajectories may differ by now)
+            dev = MT.LRML(*(t.cpu().numpy() for t in (st.P, st.Q, st.K, st.M)), lr=1e-3, reg=1e-3, margin=0.2)
+            np.testing.assert_allclose(st.scores(sess.to_dev(users)).cpu().numpy(), dev.scores(users), rtol=5e-5, atol=1e-6)
         except AssertionError as e:
             fails += 1
             print("LRML FAIL U=%d I=%d d=%d mem=%d B=%d N=%d: %s" % (U, I, dl, mem, Bl, Nl, str(e).strip().split("\n")[0]))
@@ -154,7 +155,8 @@ def main():
             close(st.P, om.numpy("P"), "P")
             close(st.Q, om.numpy("Q"), "Q")
             users = g.integers(0, U, 11).astype(np.int32)
-            np.testing.assert_allclose(st.scores(sess.to_dev(users)).cpu().numpy(), om.scores(users), rtol=5e-5, atol=1e-6)
+            dev = MT.TransCF(st.P.cpu().numpy(), st.Q.cpu().numpy(), ui_train, lr=1e-3, reg1=0.1, reg2=0.01, margin=0.5)
+            np.testing.assert_allclose(st.scores(sess.to_dev(users)).cpu().numpy(), dev.scores(users), rtol=5e-5, atol=1e-6)
         except AssertionError as e:
             fails += 1
             print("TransCF FAIL U=%d I=%d d=%d B=%d: %s" % (U, I, dt, Bt, str(e).strip().split("\n")[0]))
