@@ -44,6 +44,9 @@
 // Compiled with -ffp-contract=off: each fp32 multiply/add is rounded separately, like the
 // element-wise Eigen kernels TF1 runs (and like the CPU oracle), so the Adam arithmetic is
 // bit-reproducible.
+#include <atomic>
+#include <chrono>
+#include <cstring>
 #include "crec_internal.h"
 #include "block_sort.h"
 #include "crec_comm.h"
@@ -154,6 +157,13 @@ struct IndexWs {
     int32_t *nwide;            // [nbc][2] wide groups per batch {user, item}
     int64_t WMu, WMq;
     size_t bytes;
+    // tf1 mode: the counts the host sizes the chunk's launches with reach it WITHOUT a copy and a stream synchronisation:
+    // every workgroup of the index launch also writes its counts into page-locked, host-coherent memory (same layout as
+    // [hn, nwide + 2 nbc)) and draws a ticket on `done`; the last one raises the flag the host is polling with the launch's
+    // sequence number (null: the host copies)
+    int32_t *host_counts, *done;
+    int32_t *host_flag;
+    int32_t seq, n_back;
 };
 
 constexpr int HN = 8; // per-batch counters the host reads back
@@ -542,6 +552,22 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
         w.nwide[batch * 2 + side] = wide_total_n;
     }
     CREC_IDX_MARK(6);
+    if (w.host_counts && tid == 0) { // the chunk's counts straight into the host's hands (see IndexWs)
+        // No fences (a device- or system-scope fence writes the L2 back: 10+ us at the end of a kernel that has just written
+        // megabytes of records): system-scope stores travel by themselves, the wave waits for their completion, then draws
+        // its ticket; the workgroup that draws the last one raises the flag.
+        int32_t *hc = w.host_counts + batch * HN + side * 2, *hw = w.host_counts + (w.nwide - w.hn) + batch * 2 + side;
+        __hip_atomic_store(hc + 0, (int32_t)(hv_total >> 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(hc + 1, (int32_t)(hv_total & 0xffff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(hw, (int32_t)wide_total_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // slots 6, 7 of a batch's counters are free: this workgroup's stamp, which the host checks before it trusts the rest
+        __hip_atomic_store(w.host_counts + batch * HN + 6 + side, w.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (__hip_atomic_fetch_add(w.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
+            __hip_atomic_store(w.done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next launch
+            __hip_atomic_store(w.host_flag, w.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -2269,29 +2295,65 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
         const int64_t nbc = (nb - b0) < chunk ? (nb - b0) : chunk;
         const int64_t t0 = b0 * B, n_chunk = (N - t0) < nbc * B ? (N - t0) : nbc * B;
         IndexWs w = layout_index(ctx->idx_ws.ptr, nbc, B, t->U, t->I, dense, CH, wide_rows, wide_total, lazy_spw(t->d));
-        crec_prof_begin(ctx, CREC_K_INDEX, st);
-        CREC_KLAUNCH(ctx, bpr_index_batches, dim3((unsigned)(2 * nbc)), dim3(PREP_THREADS), lds, st, u + t0, i + t0,
-                           j + t0, n_chunk, B, cap, w);
-        crec_prof_end(ctx, st);
-        // the chunk's counts come back into page-locked memory: a pageable destination is staged and costs tens of
-        // microseconds per copy, once per epoch -- a tenth of an ml-100k epoch of 45 steps
-        // tf1 mode: the chunk's counts of heavy-row chunks and wide groups size the launches.  One copy for both arrays:
-        // a device-to-host copy costs ~10 us of latency whatever its size.  (Lazy mode has nothing to read back: its
-        // launches are sized by the batch alone, so the whole epoch is enqueued without a host synchronisation.)
         const size_t nw_off = (size_t)(w.nwide - w.hn), n_back = dense ? nw_off + (size_t)nbc * 2 : 0;
-        if (n_back > ctx->pinned_ints) {
+        if (n_back + 64 > ctx->pinned_ints) {
             if (ctx->pinned)
                 CREC_HIP(ctx, hipHostFree(ctx->pinned));
             ctx->pinned = nullptr;
             ctx->pinned_ints = 0;
-            CREC_HIP(ctx, hipHostMalloc((void **)&ctx->pinned, sizeof(int32_t) * n_back * 2, hipHostMallocDefault));
-            ctx->pinned_ints = n_back * 2;
+            ctx->pinned_dev = nullptr;
+            // mapped + coherent: the index kernel's last workgroup writes the counts and the flag here itself
+            CREC_HIP(ctx, hipHostMalloc((void **)&ctx->pinned, sizeof(int32_t) * (n_back * 2 + 64),
+                                        hipHostMallocMapped | hipHostMallocCoherent));
+            ctx->pinned_ints = n_back * 2 + 64;
+            memset(ctx->pinned, 0, sizeof(int32_t) * ctx->pinned_ints);
+            void *dev = nullptr;
+            if (hipHostGetDevicePointer(&dev, ctx->pinned, 0) == hipSuccess)
+                ctx->pinned_dev = (int32_t *)dev;
+            else
+                (void)hipGetLastError();
         }
+        if (!ctx->idx_done) {
+            CREC_HIP(ctx, hipMalloc((void **)&ctx->idx_done, sizeof(int32_t)));
+            CREC_HIP(ctx, hipMemsetAsync(ctx->idx_done, 0, sizeof(int32_t), st));
+        }
+        // the flag sits in the buffer's last cache line, the counts at its start
+        const size_t flag_at = ctx->pinned_ints - 16;
+        const bool zero_copy = dense && ctx->pinned_dev && !ctx->knob_no_zero_copy;
+        w.host_counts = zero_copy ? ctx->pinned_dev : nullptr;
+        w.host_flag = zero_copy ? ctx->pinned_dev + flag_at : nullptr;
+        w.done = ctx->idx_done;
+        w.seq = zero_copy ? ++ctx->idx_seq : 0;
+        w.n_back = (int32_t)n_back;
+        crec_prof_begin(ctx, CREC_K_INDEX, st);
+        CREC_KLAUNCH(ctx, bpr_index_batches, dim3((unsigned)(2 * nbc)), dim3(PREP_THREADS), lds, st, u + t0, i + t0,
+                           j + t0, n_chunk, B, cap, w);
+        crec_prof_end(ctx, st);
+        // tf1 mode: the chunk's counts of heavy-row chunks and wide groups size the launches.  They arrive in page-locked
+        // memory written by the kernel itself (above); the host polls the flag -- a device-to-host copy plus a stream
+        // synchronisation cost ~15 us per call, a tenth of a 20-batch call.  (Lazy mode has nothing to read back: its
+        // launches are sized by the batch alone, so the whole epoch is enqueued without a host synchronisation.)
         const int32_t *hn = ctx->pinned, *nwide = ctx->pinned + nw_off;
         a.nwide = nwide;
         if (dense) {
-            CREC_HIP(ctx, hipMemcpyAsync(ctx->pinned, w.hn, sizeof(int32_t) * n_back, hipMemcpyDeviceToHost, st));
-            CREC_HIP(ctx, hipStreamSynchronize(st));
+            bool have = false;
+            if (zero_copy) {
+                volatile int32_t *flag = ctx->pinned + flag_at;
+                const auto t_give_up = std::chrono::steady_clock::now() + std::chrono::milliseconds(200);
+                unsigned spins = 0;
+                while (!(have = (*flag == w.seq))) {
+                    __builtin_ia32_pause();
+                    if ((++spins & 1023) == 0 && std::chrono::steady_clock::now() > t_give_up)
+                        break; // (a profiler serialising the launch, a device error: fall back to the copy)
+                }
+                std::atomic_thread_fence(std::memory_order_acquire);
+                for (int64_t b = 0; have && b < nbc; ++b) // every workgroup's stamp: its counts are this launch's
+                    have = ctx->pinned[(size_t)b * HN + 6] == w.seq && ctx->pinned[(size_t)b * HN + 7] == w.seq;
+            }
+            if (!have) {
+                CREC_HIP(ctx, hipMemcpyAsync(ctx->pinned, w.hn, sizeof(int32_t) * n_back, hipMemcpyDeviceToHost, st));
+                CREC_HIP(ctx, hipStreamSynchronize(st));
+            }
         }
         a.pad_wide = a.pad_chunks_u = a.pad_chunks_q = 0;
         for (int64_t b = 0; b < (dense ? nbc : 0); ++b) {

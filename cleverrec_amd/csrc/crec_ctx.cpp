@@ -148,6 +148,7 @@ int crec_ctx_create(int device, crec_ctx **out)
     ctx->knob_eval_shape = env_int("CREC_EVAL_SHAPE", 0);
     ctx->knob_eval_no_bitmap = env_int("CREC_EVAL_NO_BITMAP", 0);
     ctx->knob_ncf_generic = env_int("CREC_NCF_GENERIC", 0);
+    ctx->knob_no_zero_copy = env_int("CREC_NO_ZERO_COPY", 0);
     if (device >= 0) {
         int n = 0;
         hipError_t e = hipGetDeviceCount(&n);
@@ -200,6 +201,8 @@ void crec_ctx_destroy(crec_ctx *ctx)
             (void)hipHostFree(ctx->pinned);
         if (ctx->pinned64)
             (void)hipHostFree(ctx->pinned64);
+        if (ctx->idx_done)
+            (void)hipFree(ctx->idx_done);
     }
     delete ctx;
 }
@@ -221,6 +224,8 @@ int crec_ctx_set_option(crec_ctx *ctx, const char *name, int64_t value)
         ctx->knob_eval_no_bitmap = (int)value;
     else if (n == "ncf_generic")
         ctx->knob_ncf_generic = (int)value;
+    else if (n == "no_zero_copy")
+        ctx->knob_no_zero_copy = (int)value;
     else
         return crec_fail(ctx, CREC_EINVAL, "unknown option '%s'", name);
     return CREC_OK;

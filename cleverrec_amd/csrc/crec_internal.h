@@ -94,6 +94,9 @@ struct crec_ctx {
     size_t index_lds_set = 0;   // dynamic LDS limit already granted to bpr_index_batches
     int32_t *pinned = nullptr; // page-locked host buffer for the per-chunk counts read back from the index kernel
     size_t pinned_ints = 0;
+    int32_t *pinned_dev = nullptr; // the same buffer as the device addresses it (null: not mapped, the host copies instead)
+    int32_t *idx_done = nullptr;   // device: ticket counter of the index launch's workgroups
+    int32_t idx_seq = 0;           // sequence number of the last index launch that published its counts itself
     // eval workspace (eval_topk.hip)
     crec_devbuf eval_ws;
     crec_devbuf ks_dev;
@@ -105,6 +108,7 @@ struct crec_ctx {
     int knob_wide_round = 0;     // experiment: pad the wide groups' workgroups to a multiple of this (0: chunk maximum)
     int knob_eval_shape = 0;     // 4 / 8: force an eval_sweep workgroup shape where legal (0: choose)
     int knob_eval_no_bitmap = 0; // 1: seen filter by binary search even where the bitmaps would fit
+    int knob_no_zero_copy = 0;   // 1: the chunk's counts come back by copy + stream synchronisation (tests)
     int knob_ncf_generic = 0;    // 1: the generic ncf_tile even for the shapes that have a specialised one (tests)
 };
 

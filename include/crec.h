@@ -70,7 +70,9 @@ const char *crec_last_error(const crec_ctx *ctx);
  *   "wide_round"    experiment: pad the wide groups' workgroups to a multiple of this (0 = the chunk's maximum)
  *   "eval_shape"    4 / 8: force an eval_sweep workgroup shape where legal (0 = choose)
  *   "eval_no_bitmap" 1: seen filter by binary search even where per-user bitmaps would fit
- *   "ncf_generic"    1: the generic NCF / LRML tile kernels even for shapes that have a shape-specialised one */
+ *   "ncf_generic"    1: the generic NCF / LRML tile kernels even for shapes that have a shape-specialised one
+ *   "no_zero_copy"   1: the tf1 step's per-chunk counts come back by copy + stream synchronisation instead of being written
+ *                    into page-locked memory by the index kernel itself */
 int crec_ctx_set_option(crec_ctx *ctx, const char *name, int64_t value);
 
 /* ---- measurement: per-kernel time from HIP events recorded on the launch stream ------------

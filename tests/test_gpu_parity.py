@@ -512,3 +512,26 @@ def test_bpr_deferred_adam_long_gaps_against_oracle(sess):
     np.testing.assert_allclose(st.Q.cpu().numpy()[:5], Q0[:5], rtol=0, atol=0)  # never touched: m = v = 0, nothing moves
     for name in ("vP", "vQ"):
         np.testing.assert_allclose(getattr(st, name).cpu().numpy(), getattr(om, name), rtol=2e-3, atol=1e-12, err_msg=name)
+
+
+def test_counts_published_by_the_index_kernel_equal_the_copied_ones(sess):
+    """tf1 mode: the per-chunk counts that size the step launches reach the host through page-locked memory written by the
+    index kernel's last workgroup (csrc/bpr_train.hip, IndexWs::host_counts); `no_zero_copy` restores the copy + stream
+    synchronisation.  Same launches either way: bit-identical tables and losses, over several chunks and calls."""
+    U, I, d, B = 500, 60, 32, 512  # a small catalogue: heavy rows and wide groups in every batch
+    g = np.random.Generator(np.random.PCG64(12))
+    P0, Q0 = (g.standard_normal((U, d)) * 0.01).astype(np.float32), (g.standard_normal((I, d)) * 0.01).astype(np.float32)
+    n = 150 * B + 77  # more than one chunk of 64 batches, a ragged tail
+    u, i, j = (g.integers(0, m, n).astype(np.int32) for m in (U, I, I))
+    out = []
+    for flag in (0, 1):
+        sess.ctx.set_option("no_zero_copy", flag)
+        try:
+            st = runtime.BprState(sess, P0, Q0, lr=1e-3, reg=0.01, adam_mode="tf1")
+            du, di, dj = (sess.to_dev(x) for x in (u, i, j))
+            losses = [st.train_epoch(du, di, dj, B).cpu().numpy(), st.train_epoch(du[:5 * B], di[:5 * B], dj[:5 * B], B).cpu().numpy()]
+            out.append((np.concatenate(losses), st.P.cpu().numpy(), st.Q.cpu().numpy(), st.vQ.cpu().numpy()))
+        finally:
+            sess.ctx.set_option("no_zero_copy", 0)
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)
