@@ -337,10 +337,8 @@ int crec_cml_train_epoch(crec_ctx *ctx, const crec_cml *m, crec_adam *opt, const
         crec_rows_opt o{};
         o.kind = ROWS_DENSE;
         o.cov_coef = 2.0f * m->reg / n_rows;
-        o.lr_t = (opt->lr * sqrtf(1.0f - opt->beta2_power)) / (1.0f - opt->beta1_power);
-        o.beta1 = opt->beta1;
-        o.beta2 = opt->beta2;
-        o.eps = opt->eps;
+        if (int rc = crec_rows_optimizer(ctx, opt, &o))
+            return rc;
         const int waves = (int)crec_ceil_div(nbt, G);
         float *li_b = (float *)((char *)loss_inst + (b & 1) * up(li));
         aux.n_inst = (int)crec_ceil_div(waves, 4);

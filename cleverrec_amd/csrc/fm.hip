@@ -294,10 +294,8 @@ int crec_fm_train_epoch(crec_ctx *ctx, const crec_fm *m, crec_adam *opt, const i
         o.kind = ROWS_DENSE;
         o.reg_occ = 0.f;
         o.dense_reg = m->reg;
-        o.lr_t = (opt->lr * sqrtf(1.0f - opt->beta2_power)) / (1.0f - opt->beta1_power);
-        o.beta1 = opt->beta1;
-        o.beta2 = opt->beta2;
-        o.eps = opt->eps;
+        if (int rc = crec_rows_optimizer(ctx, opt, &o))
+            return rc;
         const int waves = (int)crec_ceil_div(nbt, G);
         float *se = (float *)((char *)sq_err + (b & 1) * up(seb));
         crec_prof_begin(ctx, CREC_K_FM_INSTANCES, st);

@@ -336,7 +336,6 @@ extern "C" int crec_lrml_train_epoch(crec_ctx *ctx, const crec_lrml *m, crec_ada
     if (int rc = lrml_check(ctx, m, &d, &mem))
         return rc;
     CREC_REQUIRE(ctx, m->small.m && m->small.v && m->P.m && m->P.v && m->Q.m && m->Q.v, "Adam slots");
-    CREC_REQUIRE(ctx, opt->adam_mode == CREC_ADAM_TF1, "the LRML step implements adam_mode tf1");
     CREC_REQUIRE(ctx, B >= 1 && B <= 8192, "batch_size <= 8192");
     CREC_REQUIRE(ctx, N >= 0 && (N == 0 || (u && i && j && loss_per_batch)), "null argument");
     if (N == 0)
@@ -380,10 +379,8 @@ extern "C" int crec_lrml_train_epoch(crec_ctx *ctx, const crec_lrml *m, crec_ada
         crec_rows_opt o{};
         o.kind = ROWS_SPARSE_TF1;
         o.reg_occ = m->reg;
-        o.lr_t = (opt->lr * sqrtf(1.0f - opt->beta2_power)) / (1.0f - opt->beta1_power);
-        o.beta1 = opt->beta1;
-        o.beta2 = opt->beta2;
-        o.eps = opt->eps;
+        if (int rc = crec_rows_optimizer(ctx, opt, &o))
+            return rc;
         hipLaunchKernelGGL(tile_fn, dim3((unsigned)tiles), dim3(NT), lds, st, (const float *)m->P.var, (const float *)m->Q.var,
                            (const float *)m->small.var, d, mem, u + t0, i + t0, j + t0, nbt, m->reg, m->margin, c_p, c_q, slots,
                            loss_inst + t0, partial);

@@ -516,7 +516,6 @@ extern "C" int crec_ncf_train_epoch(crec_ctx *ctx, const crec_ncf *mdl, crec_ada
     CREC_REQUIRE(ctx, mdl && opt && N >= 0, "null argument");
     CREC_REQUIRE(ctx, N == 0 || (u && i && y && loss_per_batch), "null argument");
     CREC_REQUIRE(ctx, mdl->kind >= CREC_NCF_GMF && mdl->kind <= CREC_NCF_NEUMF, "ncf kind");
-    CREC_REQUIRE(ctx, opt->adam_mode == CREC_ADAM_TF1, "the NCF step implements adam_mode tf1");
     CREC_REQUIRE(ctx, B >= 1 && B <= 16384, "batch_size %d: at most 16384", B);
     const bool has_g = mdl->kind != CREC_NCF_MLP, has_m = mdl->kind != CREC_NCF_GMF;
     NcfDev d{};
@@ -581,10 +580,8 @@ extern "C" int crec_ncf_train_epoch(crec_ctx *ctx, const crec_ncf *mdl, crec_ada
         const int nbt = (int)((N - t0) < B ? (N - t0) : B);
         crec_rows_opt o{};
         o.kind = ROWS_SPARSE_TF1;
-        o.lr_t = (opt->lr * sqrtf(1.0f - opt->beta2_power)) / (1.0f - opt->beta1_power);
-        o.beta1 = opt->beta1;
-        o.beta2 = opt->beta2;
-        o.eps = opt->eps;
+        if (int rc = crec_rows_optimizer(ctx, opt, &o))
+            return rc;
         crec_prof_begin(ctx, CREC_K_NCF_TILE, st);
         CREC_KLAUNCH(ctx, tile_fn, dim3((unsigned)crec_ceil_div(crec_ceil_div(nbt, T), NCF_GRID_DIV)), dim3(NT), lds, st, d, u + t0, i + t0, y + t0, nbt,
                            c_pg, c_qg, c_pm, c_qm, loss_inst + t0, partial);
@@ -607,7 +604,7 @@ extern "C" int crec_ncf_train_epoch(crec_ctx *ctx, const crec_ncf *mdl, crec_ada
         od.kind = ROWS_DENSE;
         const crec_small_job small{mdl->small.var, mdl->small.m, mdl->small.v, partial, (int)crec_ceil_div(nbt, T), d.n_small,
                                    d.n_small, od};
-        if (has_g && has_m && d.dg == hm && !ctx->knob_ncf_generic) {
+        if (has_g && has_m && d.dg == hm && o.opt == 0 && !ctx->knob_ncf_generic) {
             // NeuMF with equal widths: a user's P_gmf and P_mlp rows (an item's Q_gmf and Q_mlp rows) share their slots --
             // one wave updates both (rows_apply_row_pair): half the waves, the index walked once
             job(mdl->P_gmf, U, d.dg, vu, c_pg, mdl->reg_gmf);

@@ -1,5 +1,6 @@
 // Internal interface of rows_adam.hip (not part of the C ABI).
 #pragma once
+#include <cmath>
 #include "crec_internal.h"
 
 enum { ROWS_SPARSE_TF1 = 0, ROWS_SPARSE_LAZY = 1, ROWS_DENSE = 2 };
@@ -17,7 +18,25 @@ struct crec_rows_opt {
     float cov_coef;   // ROWS_DENSE, CML: 2*reg/n of the covariance term; dense_grad then holds the column means
     int row_norm;     // row_out[r] = |row r|^2 of the values before the update (FM's l2 loss term)
     float lr_t, beta1, beta2, eps;
+    int opt;          // 0: Adam; CREC_OPT_SGD, CREC_OPT_ADAGRAD (utils/tools.py:79-87): lr_t then holds the plain learning rate,
+                      // a sparse table's untouched rows stay as they are (scatter_sub / SparseApplyAdagrad on the unique rows),
+                      // Adagrad's accumulator is the m slot (the caller initialises it to 0.1), the v slot is not used
 };
+
+// the step's optimizer out of a crec_adam (adam_mode tf1 = Adam | CREC_OPT_SGD | CREC_OPT_ADAGRAD) into a crec_rows_opt:
+// opt, lr_t (Adam: lr*sqrt(1-b2^t)/(1-b1^t) with the fp32 running powers; else the plain lr), betas, eps
+inline int crec_rows_optimizer(crec_ctx *ctx, const crec_adam *opt, crec_rows_opt *o)
+{
+    const bool adam = opt->adam_mode == CREC_ADAM_TF1;
+    CREC_REQUIRE(ctx, adam || opt->adam_mode == CREC_OPT_SGD || opt->adam_mode == CREC_OPT_ADAGRAD,
+                 "this model's step implements adam_mode tf1 (Adam), CREC_OPT_SGD and CREC_OPT_ADAGRAD");
+    o->opt = adam ? 0 : opt->adam_mode;
+    o->lr_t = adam ? (opt->lr * sqrtf(1.0f - opt->beta2_power)) / (1.0f - opt->beta1_power) : opt->lr;
+    o->beta1 = opt->beta1;
+    o->beta2 = opt->beta2;
+    o->eps = opt->eps;
+    return CREC_OK;
+}
 
 // A batch's slots may be indexed in `chunks` equal runs of slots, each sorted by its own workgroup (a per-step index
 // is then `chunks` short sorts side by side instead of one long one).  A row's slots are visited chunk by chunk, and

@@ -89,6 +89,34 @@ __device__ inline void st4_stream(float *p, float4 v)
     }
 }
 
+// one element under the step's optimizer (get_optimizer, utils/tools.py:79-87).  `dense`: the ApplyAdam form of Adam
+// (dense variables), else the IndexedSlices form; SGD: var -= lr*g; Adagrad: accum += g*g, var -= lr*g/sqrt(accum)
+// (accum in m; the same arithmetic as the BPR step's opt4, csrc/bpr_train.hip)
+__device__ __forceinline__ float opt_elem(const crec_rows_opt &o, bool dense, float g, float var, float &m, float &v)
+{
+    if (o.opt == CREC_OPT_SGD)
+        return var - o.lr_t * g;
+    if (o.opt == CREC_OPT_ADAGRAD) {
+        m = m + g * g;
+        return var - (o.lr_t * g) * __builtin_amdgcn_rsqf(m);
+    }
+    const float omb1 = 1.0f - o.beta1, omb2 = 1.0f - o.beta2;
+    if (dense) {
+        m = m + (g - m) * omb1;
+        v = v + (g * g - v) * omb2;
+        return var - (m * o.lr_t) / (sqrtf(v) + o.eps);
+    }
+    m = m * o.beta1 + g * omb1;
+    v = v * o.beta2 + (g * g) * omb2;
+    return var - (o.lr_t * m) / (sqrtf(v) + o.eps);
+}
+
+// a sparse table's rows no slot names: swept by TF1's Adam (g = 0), left alone by lazy Adam, SGD and Adagrad
+__device__ __forceinline__ bool untouched_stays(const crec_rows_opt &o)
+{
+    return o.kind == ROWS_SPARSE_LAZY || (o.kind == ROWS_SPARSE_TF1 && o.opt != 0);
+}
+
 // one wave per table row; group g of the wave takes slots g, g+G, ... of the row (fixed order),
 // the G partial sums are added in group order
 template <int LPR>
@@ -106,7 +134,7 @@ __device__ __forceinline__ void rows_apply_row(const crec_rows_table &t, const i
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     const int64_t ro = r * d + 4 * l;
     const int2 rs0 = rowseg[r];
-    if (chunks == 1 && rs0.y == 0 && o.kind == ROWS_SPARSE_LAZY)
+    if (chunks == 1 && rs0.y == 0 && untouched_stays(o))
         return;
     const float4 var = act ? ld4(t.var + ro) : zero;
     // the slots are only needed for the update at the end, but asked for here: behind the slot walk their round trip
@@ -133,7 +161,7 @@ __device__ __forceinline__ void rows_apply_row(const crec_rows_table &t, const i
             }
         }
     }
-    if (touched == 0 && o.kind == ROWS_SPARSE_LAZY)
+    if (touched == 0 && untouched_stays(o))
         return;
 #pragma unroll
     for (int off = LPR; off < 64; off <<= 1) { // groups hold disjoint slots: add them, lower group first
@@ -177,19 +205,10 @@ __device__ __forceinline__ void rows_apply_row(const crec_rows_table &t, const i
     if (g != 0 || !act)
         return;
     float4 nv = var;
-    const float omb1 = 1.0f - o.beta1, omb2 = 1.0f - o.beta2;
     // component by component in registers (indexing the float4s through pointers put them in scratch)
     const auto upd = [&](float g_, float d_, float var_, float &m_, float &v_, float &n_) {
-        if (o.kind == ROWS_DENSE) {
-            const float gg = (g_ + d_) + o.dense_reg * var_;
-            m_ = m_ + (gg - m_) * omb1;
-            v_ = v_ + (gg * gg - v_) * omb2;
-            n_ = var_ - (m_ * o.lr_t) / (sqrtf(v_) + o.eps);
-        } else {
-            m_ = m_ * o.beta1 + g_ * omb1;
-            v_ = v_ * o.beta2 + (g_ * g_) * omb2;
-            n_ = var_ - (o.lr_t * m_) / (sqrtf(v_) + o.eps);
-        }
+        const bool dense = o.kind == ROWS_DENSE;
+        n_ = opt_elem(o, dense, dense ? (g_ + d_) + o.dense_reg * var_ : g_, var_, m_, v_);
     };
     upd(acc.x, dg.x, var.x, m.x, v.x, nv.x);
     upd(acc.y, dg.y, var.y, m.y, v.y, nv.y);
@@ -299,7 +318,7 @@ __device__ __forceinline__ void rows_apply_side(const crec_rows_table &t, const 
     const int d = t.d;
     const bool act = valid && 4 * l < d;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (cnt == 0 && o.kind == ROWS_SPARSE_LAZY)
+    if (cnt == 0 && untouched_stays(o))
         return;
     const int64_t ro = r * d + 4 * l;
     const float4 var = act ? ld4(t.var + ro) : zero;
@@ -354,18 +373,9 @@ __device__ __forceinline__ void rows_apply_side(const crec_rows_table &t, const 
     if (!act)
         return;
     float4 nv = var;
-    const float omb1 = 1.0f - o.beta1, omb2 = 1.0f - o.beta2;
     const auto upd = [&](float g_, float d_, float var_, float &m_, float &v_, float &n_) {
-        if (o.kind == ROWS_DENSE) {
-            const float gg = (g_ + d_) + o.dense_reg * var_;
-            m_ = m_ + (gg - m_) * omb1;
-            v_ = v_ + (gg * gg - v_) * omb2;
-            n_ = var_ - (m_ * o.lr_t) / (sqrtf(v_) + o.eps);
-        } else {
-            m_ = m_ * o.beta1 + g_ * omb1;
-            v_ = v_ * o.beta2 + (g_ * g_) * omb2;
-            n_ = var_ - (o.lr_t * m_) / (sqrtf(v_) + o.eps);
-        }
+        const bool dense = o.kind == ROWS_DENSE;
+        n_ = opt_elem(o, dense, dense ? (g_ + d_) + o.dense_reg * var_ : g_, var_, m_, v_);
     };
     upd(acc.x, dg.x, var.x, m.x, v.x, nv.x);
     upd(acc.y, dg.y, var.y, m.y, v.y, nv.y);
@@ -423,13 +433,11 @@ template <int EL> __device__ __forceinline__ void small_adam_block(const crec_sm
 #pragma unroll
     for (int s = 1; s < SAD_SL; ++s)
         g = g + red[s * EL + el];
-    const float omb1 = 1.0f - j.o.beta1, omb2 = 1.0f - j.o.beta2;
     float mm = j.m[e], vv = j.v[e];
-    mm = mm + (g - mm) * omb1;
-    vv = vv + (g * g - vv) * omb2;
+    const float nv = opt_elem(j.o, true, g, j.var[e], mm, vv);
     j.m[e] = mm;
     j.v[e] = vv;
-    j.var[e] = j.var[e] - (mm * j.o.lr_t) / (sqrtf(vv) + j.o.eps);
+    j.var[e] = nv;
 }
 
 __global__ __launch_bounds__(64 * SAD_SL) void small_adam_dense(crec_small_job j)
@@ -454,13 +462,11 @@ __device__ __forceinline__ void scalar_rows_block(const crec_scalar_job &j, int 
     if (j.sq_out)
         j.sq_out[r] = w * w;
     g = g + j.o.dense_reg * w;
-    const float omb1 = 1.0f - j.o.beta1, omb2 = 1.0f - j.o.beta2;
     float mm = j.m[r], vv = j.v[r];
-    mm = mm + (g - mm) * omb1;
-    vv = vv + (g * g - vv) * omb2;
+    const float nv = opt_elem(j.o, true, g, w, mm, vv);
     j.m[r] = mm;
     j.v[r] = vv;
-    j.var[r] = w - (mm * j.o.lr_t) / (sqrtf(vv) + j.o.eps);
+    j.var[r] = nv;
 }
 
 // every parameter update of a step in ONE launch: up to CREC_APPLY_MAX_TABLES embedding tables (blocks
@@ -580,7 +586,7 @@ int crec_apply_all(crec_ctx *ctx, crec_apply_set &a, hipStream_t st)
         CREC_REQUIRE(ctx, lpr == 0 || l == lpr, "apply set: tables of one launch must share the row width class");
         lpr = l;
         CREC_REQUIRE(ctx, !a.tables[k].t2.var || (a.tables[k].t2.rows == a.tables[k].t.rows && a.tables[k].t2.d == a.tables[k].t.d &&
-                                                   a.tables[k].o.kind == ROWS_SPARSE_TF1 && !a.tables[k].dense_grad && !a.tables[k].row_out),
+                                                   a.tables[k].o.kind == ROWS_SPARSE_TF1 && a.tables[k].o.opt == 0 && !a.tables[k].dense_grad && !a.tables[k].row_out),
                      "apply set: a paired table shares rows, width and slots with its partner (TF1 sparse Adam only)");
         blocks += (int)crec_ceil_div(a.tables[k].t.rows, 4 * (a.tables[k].t2.var ? 1 : rows_per_wave(l)));
         a.block_end[k] = blocks;

@@ -161,10 +161,8 @@ extern "C" int crec_sbpr_train_epoch(crec_ctx *ctx, const crec_sbpr *m, crec_ada
         crec_rows_opt o{};
         o.kind = ROWS_SPARSE_TF1;
         o.reg_occ = m->reg;
-        o.lr_t = (opt->lr * sqrtf(1.0f - opt->beta2_power)) / (1.0f - opt->beta1_power);
-        o.beta1 = opt->beta1;
-        o.beta2 = opt->beta2;
-        o.eps = opt->eps;
+        if (int rc = crec_rows_optimizer(ctx, opt, &o))
+            return rc;
         const dim3 grid((unsigned)crec_ceil_div(crec_ceil_div(nbt, G), 4));
 #define CREC_SBPR(L)                                                                                                        \
     case L:                                                                                                                 \

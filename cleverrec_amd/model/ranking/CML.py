@@ -8,8 +8,6 @@ from ..RankingRecommender import RankingRecommender
 class CML(RankingRecommender):
     def __init__(self, sess, data, configs, logger):
         super(CML, self).__init__(sess, data, configs, logger)
-        if self.optimizer != 'Adam':  # SGD / Adagrad are built for the BPR step only (csrc/bpr_train.hip)
-            raise NotImplementedError("optimizer=%s: this model's step implements Adam (its shipped conf's choice)" % self.optimizer)
         self.embed_size, self.reg, self.margin = int(configs['embed_size']), float(configs['reg']), float(configs['margin'])
         logger.info(' model_params: embed_size=%d, reg=%s, margin=%s' % (self.embed_size, self.reg, self.margin) + ', ' + self.model_params)
         self.train_model = self.train_model_cml  # CML.py:16
@@ -21,7 +19,7 @@ class CML(RankingRecommender):
         init = init or {}
         P = init['P'] if 'P' in init else self.initializer([self.data.user_nums, self.embed_size])
         Q = init['Q'] if 'Q' in init else self.initializer([self.data.item_nums, self.embed_size])
-        self.state = CmlState(self.sess, P, Q, self.lr, self.reg, self.margin)
+        self.state = CmlState(self.sess, P, Q, self.lr, self.reg, self.margin, optimizer=self.optimizer)
         self.P, self.Q = self.state.P, self.state.Q
 
     def _create_embeddings(self):

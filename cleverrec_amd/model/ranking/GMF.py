@@ -11,8 +11,6 @@ from ..RankingRecommender import RankingRecommender
 class GMF(RankingRecommender):
     def __init__(self, sess, data, configs, logger):
         super(GMF, self).__init__(sess, data, configs, logger)
-        if self.optimizer != 'Adam':  # SGD / Adagrad are built for the BPR step only (csrc/bpr_train.hip)
-            raise NotImplementedError("optimizer=%s: this model's step implements Adam (its shipped conf's choice)" % self.optimizer)
         self.embed_size = int(configs['embed_size'])
         # the class reads configs['reg'] but the shipped conf defines reg_gmf: accept both
         self.reg = float(configs['reg'] if 'reg' in configs else configs['reg_gmf'])
@@ -31,7 +29,8 @@ class GMF(RankingRecommender):
         P = init.get('P', None) if 'P' in init else self.initializer([U, d])
         Q = init.get('Q', None) if 'Q' in init else self.initializer([I, d])
         h = init.get('h_gmf', None) if 'h_gmf' in init else self.initializer([d])  # biases use the same initializer (GMF.py:25-26)
-        self.state = NcfState(self.sess, 'GMF', {'P_gmf': P, 'Q_gmf': Q}, [], [], h, self.lr, reg_gmf=self.reg, loss_func=self.loss_func)
+        self.state = NcfState(self.sess, 'GMF', {'P_gmf': P, 'Q_gmf': Q}, [], [], h, self.lr, reg_gmf=self.reg, loss_func=self.loss_func,
+                              optimizer=self.optimizer)
         self.P, self.Q, self.h_gmf = self.state.t['P_gmf'], self.state.t['Q_gmf'], self.state.h
 
     def _create_embeddings(self):

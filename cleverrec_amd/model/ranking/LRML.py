@@ -11,8 +11,6 @@ from ..RankingRecommender import RankingRecommender
 class LRML(RankingRecommender):
     def __init__(self, sess, data, configs, logger):
         super(LRML, self).__init__(sess, data, configs, logger)
-        if self.optimizer != 'Adam':  # SGD / Adagrad are built for the BPR step only (csrc/bpr_train.hip)
-            raise NotImplementedError("optimizer=%s: this model's step implements Adam (its shipped conf's choice)" % self.optimizer)
         # get_loss(self.loss_func, ui_dist - uj_dist, margin=self.margin) (LRML.py:63): 'hinge' is the one name that uses the
         # margin; 'bpr' would also run in the reference (margin ignored) but is not what the model is
         if self.loss_func != 'hinge':
@@ -34,7 +32,7 @@ class LRML(RankingRecommender):
         Q = init['Q'] if 'Q' in init else self.initializer([I, d])
         K = init['K'] if 'K' in init else self.initializer([d, mem])
         M = init['M'] if 'M' in init else self.initializer([mem, d])
-        self.state = LrmlState(self.sess, P, Q, K, M, self.lr, self.reg, self.margin)
+        self.state = LrmlState(self.sess, P, Q, K, M, self.lr, self.reg, self.margin, optimizer=self.optimizer)
         self.P, self.Q, self.K, self.M = self.state.P, self.state.Q, self.state.K, self.state.M
 
     def _create_embeddings(self):

@@ -12,8 +12,6 @@ from ..RankingRecommender import RankingRecommender
 class MLP(RankingRecommender):
     def __init__(self, sess, data, configs, logger):
         super(MLP, self).__init__(sess, data, configs, logger)
-        if self.optimizer != 'Adam':  # SGD / Adagrad are built for the BPR step only (csrc/bpr_train.hip)
-            raise NotImplementedError("optimizer=%s: this model's step implements Adam (its shipped conf's choice)" % self.optimizer)
         # get_loss(self.loss_func, self.y, self.logits) (utils/tools.py:66-76): the two names that can train this graph in the
         # reference; 'bpr' ignores the logits (no gradient reaches the model), 'hinge' adds margin = None (TypeError)
         if self.loss_func not in ('cross_entropy', 'square'):
@@ -38,7 +36,8 @@ class MLP(RankingRecommender):
         for k in range(1, len(L)):
             if L[k] != L[k - 1] // 2:
                 raise ValueError("layers=%s: layer k must take the previous layer's output width" % L)
-        self.state = NcfState(self.sess, 'MLP', {'P_mlp': P, 'Q_mlp': Q}, Ws, bs, h, self.lr, reg_mlp=self.reg, loss_func=self.loss_func)
+        self.state = NcfState(self.sess, 'MLP', {'P_mlp': P, 'Q_mlp': Q}, Ws, bs, h, self.lr, reg_mlp=self.reg, loss_func=self.loss_func,
+                              optimizer=self.optimizer)
         self.P, self.Q, self.h_mlp = self.state.t['P_mlp'], self.state.t['Q_mlp'], self.state.h
         self.mlp_params = {}
         for k in range(len(L)):

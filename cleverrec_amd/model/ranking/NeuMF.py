@@ -12,8 +12,6 @@ from ..RankingRecommender import RankingRecommender
 class NeuMF(RankingRecommender):
     def __init__(self, sess, data, configs, logger):
         super(NeuMF, self).__init__(sess, data, configs, logger)
-        if self.optimizer != 'Adam':  # SGD / Adagrad are built for the BPR step only (csrc/bpr_train.hip)
-            raise NotImplementedError("optimizer=%s: this model's step implements Adam (its shipped conf's choice)" % self.optimizer)
         # get_loss(self.loss_func, self.y, self.logits) (utils/tools.py:66-76): the two names that can train this graph in the
         # reference; 'bpr' ignores the logits (no gradient reaches the model), 'hinge' adds margin = None (TypeError)
         if self.loss_func not in ('cross_entropy', 'square'):
@@ -44,7 +42,8 @@ class NeuMF(RankingRecommender):
         Ws = [get('W_%d' % k, [L[k], L[k] // 2]) for k in range(len(L))]
         bs = [get('b_%d' % k, [L[k] // 2]) for k in range(len(L))]
         h = get('h_neumf', [d + L[-1] // 2])  # NeuMF.py:51
-        self.state = NcfState(self.sess, 'NeuMF', tables, Ws, bs, h, self.lr, reg_gmf=self.reg1, reg_mlp=self.reg2, loss_func=self.loss_func)
+        self.state = NcfState(self.sess, 'NeuMF', tables, Ws, bs, h, self.lr, reg_gmf=self.reg1, reg_mlp=self.reg2, loss_func=self.loss_func,
+                              optimizer=self.optimizer)
         self.P_gmf, self.Q_gmf = self.state.t['P_gmf'], self.state.t['Q_gmf']
         self.P_mlp, self.Q_mlp, self.h_neumf = self.state.t['P_mlp'], self.state.t['Q_mlp'], self.state.h
         self.mlp_params = {}

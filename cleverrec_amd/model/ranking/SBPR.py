@@ -13,8 +13,6 @@ from ..RankingRecommender import RankingRecommender
 class SBPR(RankingRecommender):
     def __init__(self, sess, data, configs, logger):
         super(SBPR, self).__init__(sess, data, configs, logger)
-        if self.optimizer != 'Adam':  # SGD / Adagrad are built for the BPR step only (csrc/bpr_train.hip)
-            raise NotImplementedError("optimizer=%s: this model's step implements Adam (its shipped conf's choice)" % self.optimizer)
         if self.loss_func != 'bpr':  # SBPR.py:52 calls get_loss(self.loss_func, x) with one argument: only 'bpr' can run
             raise NotImplementedError("SBPR: loss_func=%s cannot train this graph (utils/tools.py:66-76)" % self.loss_func)
         self.embed_size, self.reg = int(configs['embed_size']), float(configs['reg'])
@@ -31,7 +29,7 @@ class SBPR(RankingRecommender):
         P = init['P'] if 'P' in init else self.initializer([U, d])
         Q = init['Q'] if 'Q' in init else self.initializer([I, d])
         bias = init['bias'] if 'bias' in init else torch.zeros(I + 1)  # tf.zeros(item_nums + 1), SBPR.py:37
-        self.state = SbprState(self.sess, P, Q, bias, self.lr, self.reg)
+        self.state = SbprState(self.sess, P, Q, bias, self.lr, self.reg, optimizer=self.optimizer)
         self.P, self.Q, self.bias = self.state.P, self.state.Q, self.state.bias
 
     def _create_embeddings(self):

@@ -12,7 +12,7 @@ from ..RankingRecommender import RankingRecommender
 class TransCF(RankingRecommender):
     def __init__(self, sess, data, configs, logger):
         super(TransCF, self).__init__(sess, data, configs, logger)
-        if self.optimizer != 'Adam':  # SGD / Adagrad are built for the BPR step only (csrc/bpr_train.hip)
+        if self.optimizer != 'Adam':  # SGD / Adagrad run on the shared row machinery (csrc/rows_adam.hip); this step has its own dense Adam
             raise NotImplementedError("optimizer=%s: this model's step implements Adam (its shipped conf's choice)" % self.optimizer)
         if self.loss_func != 'hinge':  # get_loss(self.loss_func, ui_dist - uj_dist, margin=self.margin) (TransCF.py:57)
             raise NotImplementedError("TransCF: loss_func=%s: the step implements the hinge of the shipped conf (utils/tools.py:72-73)" % self.loss_func)

@@ -9,8 +9,6 @@ from ..RatingRecommender import RatingRecommender
 class FM(RatingRecommender):
     def __init__(self, sess, data, configs, logger):
         super(FM, self).__init__(sess, data, configs, logger)
-        if self.optimizer != 'Adam':  # SGD / Adagrad are built for the BPR step only (csrc/bpr_train.hip)
-            raise NotImplementedError("optimizer=%s: this model's step implements Adam (its shipped conf's choice)" % self.optimizer)
         self.embed_size, self.reg = int(configs['embed_size']), float(configs['reg'])
         if self.loss_func != 'square':
             raise NotImplementedError("FM is built with loss_func=square (conf/FM.properties)")
@@ -25,7 +23,7 @@ class FM(RatingRecommender):
         w0 = init['w0'] if 'w0' in init else np.zeros(1, np.float32)  # FM.py:29
         wi = init['wi'] if 'wi' in init else self.initializer([n])
         vif = init['vif'] if 'vif' in init else self.initializer([n, self.embed_size])
-        self.state = FmState(self.sess, w0, wi, vif, self.lr, self.reg)
+        self.state = FmState(self.sess, w0, wi, vif, self.lr, self.reg, optimizer=self.optimizer)
         self.w0, self.wi, self.vif = self.state.w0, self.state.wi, self.state.vif
 
     def _create_embeddings(self):

@@ -120,6 +120,19 @@ def rank_metrics(sess, topk_ids, users, ks, test_ptr, test_items):
     return out
 
 
+def _optimizer_mode(optimizer):
+    """configs['optimizer'] (utils/tools.py:79-87) -> crec_adam.adam_mode of the models that run on the shared row machinery."""
+    try:
+        return {"adam": _lib.ADAM_TF1, "sgd": _lib.OPT_SGD, "adagrad": _lib.OPT_ADAGRAD}[str(optimizer).lower()]
+    except KeyError:
+        raise ValueError("optimizer=%s: SGD | Adam | Adagrad" % optimizer)
+
+
+def _zeros_slot(t, optimizer):
+    """the m slot of a variable: Adam's first moment (0), or Adagrad's accumulator (initial_accumulator_value = 0.1)"""
+    return torch.full_like(t, 0.1) if str(optimizer).lower() == "adagrad" else torch.zeros_like(t)
+
+
 class NcfState:
     """Variables of GMF / MLP / NeuMF in HBM (crec_ncf): embedding tables + ONE flat block holding
     W_0|b_0|...|h with named views, Adam slots for all, and the optimizer scalars.
@@ -132,17 +145,17 @@ class NcfState:
     LOSSES = {"cross_entropy": _lib.LOSS_CROSS_ENTROPY, "square": _lib.LOSS_SQUARE}
 
     def __init__(self, sess, kind, tables, Ws, bs, h, lr, reg_gmf=0.0, reg_mlp=0.0, beta1=0.9, beta2=0.999, eps=1e-8,
-                 loss_func="cross_entropy"):
+                 loss_func="cross_entropy", optimizer="Adam"):
         self.sess, self.kind = sess, kind
         f32 = torch.float32
         self.t, self.slots = {}, {}
         for k, a in tables.items():
             self.t[k] = sess.to_dev(a, f32).contiguous()
-            self.slots[k] = (torch.zeros_like(self.t[k]), torch.zeros_like(self.t[k]))
+            self.slots[k] = (_zeros_slot(self.t[k], optimizer), torch.zeros_like(self.t[k]))
         flat = [np.asarray(x, dtype=np.float32).reshape(-1) for pair in zip(Ws, bs) for x in pair] + \
                [np.asarray(h, dtype=np.float32).reshape(-1)]
         self.small = sess.to_dev(np.concatenate(flat), f32)
-        self.small_m, self.small_v = torch.zeros_like(self.small), torch.zeros_like(self.small)
+        self.small_m, self.small_v = _zeros_slot(self.small, optimizer), torch.zeros_like(self.small)
         # named views into the flat block
         self.W, self.b, off = [], [], 0
         for W, b in zip(Ws, bs):
@@ -161,7 +174,7 @@ class NcfState:
         small = _lib.Param(self.small.data_ptr(), self.small_m.data_ptr(), self.small_v.data_ptr(), 1, self.small.numel())
         self.model = _lib.Ncf(self.KINDS[kind], param("P_gmf"), param("Q_gmf"), param("P_mlp"), param("Q_mlp"), len(Ws), small,
                               reg_gmf, reg_mlp, self.LOSSES[loss_func])
-        self.adam = _lib.Adam(lr, beta1, beta2, eps, 0.0, _lib.ADAM_TF1, beta1, beta2, 0)
+        self.adam = _lib.Adam(lr, beta1, beta2, eps, 0.0, _optimizer_mode(optimizer), beta1, beta2, 0)
 
     def train_epoch(self, u, i, y, batch_size):
         """u, i int32, y float32 device tensors [N] -> per-batch summed losses (device fp32)."""
@@ -176,20 +189,20 @@ class NcfState:
 class FmState:
     """w0, wi, vif of model/rating/FM.py:27-31 with Adam slots in HBM (crec_fm)."""
 
-    def __init__(self, sess, w0, wi, vif, lr, reg, beta1=0.9, beta2=0.999, eps=1e-8):
+    def __init__(self, sess, w0, wi, vif, lr, reg, beta1=0.9, beta2=0.999, eps=1e-8, optimizer="Adam"):
         self.sess = sess
         f32 = torch.float32
         self.w0 = sess.to_dev(np.asarray(w0, dtype=np.float32).reshape(1), f32)
         self.wi = sess.to_dev(np.asarray(wi, dtype=np.float32).reshape(-1), f32)
         self.vif = sess.to_dev(vif, f32).contiguous()
-        self.slots = {k: (torch.zeros_like(t), torch.zeros_like(t)) for k, t in (("w0", self.w0), ("wi", self.wi), ("vif", self.vif))}
+        self.slots = {k: (_zeros_slot(t, optimizer), torch.zeros_like(t)) for k, t in (("w0", self.w0), ("wi", self.wi), ("vif", self.vif))}
 
         def param(name, t, rows, cols):
             m, v = self.slots[name]
             return _lib.Param(t.data_ptr(), m.data_ptr(), v.data_ptr(), rows, cols)
         self.model = _lib.Fm(param("w0", self.w0, 1, 1), param("wi", self.wi, self.wi.numel(), 1),
                              param("vif", self.vif, self.vif.shape[0], self.vif.shape[1]), reg)
-        self.adam = _lib.Adam(lr, beta1, beta2, eps, 0.0, _lib.ADAM_TF1, beta1, beta2, 0)
+        self.adam = _lib.Adam(lr, beta1, beta2, eps, 0.0, _optimizer_mode(optimizer), beta1, beta2, 0)
 
     def train_epoch(self, x_idx, x_val, y, batch_size):
         """x_idx int32 [N,F], x_val fp32 [N,F], y fp32 [N] (device) -> (pre-update y_pre [N], per-batch losses)."""
@@ -222,15 +235,15 @@ def rmse_mae(sess, y, y_pre):
 class CmlState:
     """P, Q of model/ranking/CML.py:28-32 with Adam slots in HBM (crec_cml)."""
 
-    def __init__(self, sess, P0, Q0, lr, reg, margin, beta1=0.9, beta2=0.999, eps=1e-8):
+    def __init__(self, sess, P0, Q0, lr, reg, margin, beta1=0.9, beta2=0.999, eps=1e-8, optimizer="Adam"):
         self.sess = sess
         f32 = torch.float32
         self.P, self.Q = sess.to_dev(P0, f32).contiguous(), sess.to_dev(Q0, f32).contiguous()
-        self.mP, self.vP = torch.zeros_like(self.P), torch.zeros_like(self.P)
-        self.mQ, self.vQ = torch.zeros_like(self.Q), torch.zeros_like(self.Q)
+        self.mP, self.vP = _zeros_slot(self.P, optimizer), torch.zeros_like(self.P)
+        self.mQ, self.vQ = _zeros_slot(self.Q, optimizer), torch.zeros_like(self.Q)
         par = lambda t, m, v: _lib.Param(t.data_ptr(), m.data_ptr(), v.data_ptr(), t.shape[0], t.shape[1])
         self.model = _lib.Cml(par(self.P, self.mP, self.vP), par(self.Q, self.mQ, self.vQ), reg, margin)
-        self.adam = _lib.Adam(lr, beta1, beta2, eps, 0.0, _lib.ADAM_TF1, beta1, beta2, 0)
+        self.adam = _lib.Adam(lr, beta1, beta2, eps, 0.0, _optimizer_mode(optimizer), beta1, beta2, 0)
 
     def train_epoch(self, u, i, neg, batch_size):
         """u, i int32 [N], neg int32 [N, K] (device) -> per-batch losses (device fp32)."""
@@ -257,7 +270,7 @@ class LrmlState:
     """P, Q, K, M of model/ranking/LRML.py:24-34 with Adam slots in HBM (crec_lrml); K and M are views into ONE flat
     block [K | M]."""
 
-    def __init__(self, sess, P0, Q0, K0, M0, lr, reg, margin, beta1=0.9, beta2=0.999, eps=1e-8):
+    def __init__(self, sess, P0, Q0, K0, M0, lr, reg, margin, beta1=0.9, beta2=0.999, eps=1e-8, optimizer="Adam"):
         self.sess = sess
         f32 = torch.float32
         self.P, self.Q = sess.to_dev(P0, f32).contiguous(), sess.to_dev(Q0, f32).contiguous()
@@ -267,14 +280,14 @@ class LrmlState:
             raise ValueError("LRML: K [embed_size, mem_size], M [mem_size, embed_size]")
         self.small = sess.to_dev(np.concatenate([K0.reshape(-1), M0.reshape(-1)]), f32)
         self.K, self.M = self.small[:d * mem].view(d, mem), self.small[d * mem:].view(mem, d)
-        self.slots = {k: (torch.zeros_like(t), torch.zeros_like(t)) for k, t in (("P", self.P), ("Q", self.Q), ("small", self.small))}
+        self.slots = {k: (_zeros_slot(t, optimizer), torch.zeros_like(t)) for k, t in (("P", self.P), ("Q", self.Q), ("small", self.small))}
 
         def par(name, t, rows, cols):
             m, v = self.slots[name]
             return _lib.Param(t.data_ptr(), m.data_ptr(), v.data_ptr(), rows, cols)
         self.model = _lib.Lrml(par("P", self.P, self.P.shape[0], d), par("Q", self.Q, self.Q.shape[0], d),
                                par("small", self.small, 1, self.small.numel()), mem, reg, margin)
-        self.adam = _lib.Adam(lr, beta1, beta2, eps, 0.0, _lib.ADAM_TF1, beta1, beta2, 0)
+        self.adam = _lib.Adam(lr, beta1, beta2, eps, 0.0, _optimizer_mode(optimizer), beta1, beta2, 0)
 
     def train_epoch(self, u, i, j, batch_size):
         """u, i, j int32 [N] (device) -> per-batch summed losses (device fp32)."""
@@ -345,19 +358,19 @@ class TranscfState:
 class SbprState:
     """P, Q, bias of model/ranking/SBPR.py:31-37 with Adam slots in HBM (crec_sbpr)."""
 
-    def __init__(self, sess, P0, Q0, bias0, lr, reg, beta1=0.9, beta2=0.999, eps=1e-8):
+    def __init__(self, sess, P0, Q0, bias0, lr, reg, beta1=0.9, beta2=0.999, eps=1e-8, optimizer="Adam"):
         self.sess = sess
         f32 = torch.float32
         self.P, self.Q = sess.to_dev(P0, f32).contiguous(), sess.to_dev(Q0, f32).contiguous()
         self.bias = sess.to_dev(np.asarray(bias0, dtype=np.float32).reshape(-1), f32)
-        self.slots = {k: (torch.zeros_like(t), torch.zeros_like(t)) for k, t in (("P", self.P), ("Q", self.Q), ("bias", self.bias))}
+        self.slots = {k: (_zeros_slot(t, optimizer), torch.zeros_like(t)) for k, t in (("P", self.P), ("Q", self.Q), ("bias", self.bias))}
 
         def par(name, t, rows, cols):
             m, v = self.slots[name]
             return _lib.Param(t.data_ptr(), m.data_ptr(), v.data_ptr(), rows, cols)
         self.model = _lib.Sbpr(par("P", self.P, self.P.shape[0], self.P.shape[1]), par("Q", self.Q, self.Q.shape[0], self.Q.shape[1]),
                                par("bias", self.bias, self.bias.numel(), 1), reg)
-        self.adam = _lib.Adam(lr, beta1, beta2, eps, 0.0, _lib.ADAM_TF1, beta1, beta2, 0)
+        self.adam = _lib.Adam(lr, beta1, beta2, eps, 0.0, _optimizer_mode(optimizer), beta1, beta2, 0)
 
     def train_epoch(self, u, i, k, j, suk, batch_size):
         """u, i, k, j int32 [N], suk fp32 [N] (device) -> per-batch losses (device fp32)."""

@@ -61,12 +61,17 @@ def gather(w, key, idx):
 
 
 class TF1Adam:
-    def __init__(self, params, kinds, lr, beta1=0.9, beta2=0.999, eps=1e-8):
-        """params: dict name -> tensor (updated in place); kinds: dict name -> 'sparse' | 'dense'."""
-        self.p, self.kinds = params, kinds
+    def __init__(self, params, kinds, lr, beta1=0.9, beta2=0.999, eps=1e-8, optimizer="Adam"):
+        """params: dict name -> tensor (updated in place); kinds: dict name -> 'sparse' | 'dense'.
+        optimizer (get_optimizer, utils/tools.py:79-87): 'Adam' | 'SGD' (GradientDescentOptimizer: var -= lr*g; an
+        IndexedSlices gradient is scatter_sub on its unique rows, i.e. the same formula with g = 0 elsewhere) | 'Adagrad'
+        (AdagradOptimizer, initial_accumulator_value 0.1 kept in m: accum += g*g; var -= lr*g/sqrt(accum), again g = 0 on
+        the rows a sparse gradient does not name)."""
+        self.p, self.kinds, self.optimizer = params, kinds, optimizer
+        assert optimizer in ("Adam", "SGD", "Adagrad")
         self.lr, self.b1, self.b2, self.eps = (np.float32(x) for x in (lr, beta1, beta2, eps))
         self.b1p, self.b2p = np.float32(beta1), np.float32(beta2)
-        self.m = {k: torch.zeros_like(v) for k, v in params.items()}
+        self.m = {k: torch.full_like(v, 0.1) if optimizer == "Adagrad" else torch.zeros_like(v) for k, v in params.items()}
         self.v = {k: torch.zeros_like(v) for k, v in params.items()}
         # rounding-error envelopes (see the module docstring), float64
         self.tol_m = {k: np.zeros(tuple(v.shape)) for k, v in params.items()}
@@ -78,6 +83,14 @@ class TF1Adam:
         (dense gradients: NOISE * max|g| as the scale of the cancelled terms)."""
         ga = np.abs(g.numpy().astype(np.float64))
         dg = NOISE * (np.asarray(gabs, dtype=np.float64) + ga) if gabs is not None else NOISE * np.maximum(ga, ga.max(initial=0.0))
+        if self.optimizer == "SGD":
+            self.tol_var[k] = self.tol_var[k] + float(self.lr) * dg
+            return
+        if self.optimizer == "Adagrad":  # accum (in m) += g^2; var -= lr*g/sqrt(accum): first-order in dg and in the accumulator's own error
+            acc = self.m[k].numpy().astype(np.float64)
+            self.tol_m[k] = self.tol_m[k] + 2 * ga * dg + dg * dg
+            self.tol_var[k] = self.tol_var[k] + float(self.lr) * (dg / np.sqrt(acc) + 0.5 * ga * self.tol_m[k] / acc ** 1.5) + 2e-7 * float(self.lr) * ga / np.sqrt(acc)
+            return
         b1, b2 = float(self.b1), float(self.b2)
         self.tol_m[k] = b1 * self.tol_m[k] + (1 - b1) * dg
         self.tol_v[k] = b2 * self.tol_v[k] + (1 - b2) * (2 * ga * dg + dg * dg)
@@ -93,7 +106,12 @@ class TF1Adam:
             if g is None:
                 continue  # minimize() skips variables without a gradient
             var, m, v = self.p[k], self.m[k], self.v[k]
-            if self.kinds[k] == "sparse":
+            if self.optimizer == "SGD":
+                var.sub_(float(self.lr) * g)
+            elif self.optimizer == "Adagrad":
+                m.add_(g * g)
+                var.sub_((float(self.lr) * g) / m.sqrt())
+            elif self.kinds[k] == "sparse":
                 m.mul_(float(self.b1)).add_(g * float(omb1))
                 v.mul_(float(self.b2)).add_((g * g) * float(omb2))
                 var.sub_((float(lr_t) * m) / (v.sqrt() + float(self.eps)))
@@ -125,9 +143,9 @@ def _pointwise_loss(loss_func, labels, logits):  # get_loss(self.loss_func, self
 class Model:
     """params (fp32 tensors), kinds, loss(batch) -> scalar.  step(batch) runs one sess.run([train, loss])."""
 
-    def __init__(self, params, kinds, lr):
+    def __init__(self, params, kinds, lr, optimizer="Adam"):
         self.params = {k: torch.tensor(np.array(v, dtype=np.float32)) for k, v in params.items()}
-        self.opt = TF1Adam(self.params, kinds, lr)
+        self.opt = TF1Adam(self.params, kinds, lr, optimizer=optimizer)
 
     def step(self, *batch):
         nt = torch.get_num_threads()
@@ -167,8 +185,8 @@ class Model:
 class GMF(Model):
     """model/ranking/GMF.py:29-57: logit = sum_d pu*qi*h (:42); loss = sum CE + reg*(l2(pu)+l2(qi)) (:48)."""
 
-    def __init__(self, P, Q, h, lr, reg, loss_func="cross_entropy"):
-        super().__init__({"P": P, "Q": Q, "h_gmf": h}, {"P": "sparse", "Q": "sparse", "h_gmf": "dense"}, lr)
+    def __init__(self, P, Q, h, lr, reg, loss_func="cross_entropy", optimizer="Adam"):
+        super().__init__({"P": P, "Q": Q, "h_gmf": h}, {"P": "sparse", "Q": "sparse", "h_gmf": "dense"}, lr, optimizer)
         self.reg, self.loss_func = reg, loss_func
 
     def loss(self, w, u, i, y):
@@ -193,13 +211,13 @@ class MLP(Model):
     """model/ranking/MLP.py:31-77: P,Q of width layers[0]//2, W_k [layers[k], layers[k]//2], b_k, h_mlp;
     logit = tower(concat(pu, qi)) . h_mlp (:59); loss = sum CE + reg*(l2(pu)+l2(qi)) (:66)."""
 
-    def __init__(self, P, Q, Ws, bs, h, lr, reg, loss_func="cross_entropy"):
+    def __init__(self, P, Q, Ws, bs, h, lr, reg, loss_func="cross_entropy", optimizer="Adam"):
         self.loss_func = loss_func
         params, kinds = {"P": P, "Q": Q, "h_mlp": h}, {"P": "sparse", "Q": "sparse", "h_mlp": "dense"}
         for k, (W, b) in enumerate(zip(Ws, bs)):
             params["W_%d" % k], params["b_%d" % k] = W, b
             kinds["W_%d" % k] = kinds["b_%d" % k] = "dense"
-        super().__init__(params, kinds, lr)
+        super().__init__(params, kinds, lr, optimizer)
         self.reg, self.n_layers = reg, len(Ws)
 
     def loss(self, w, u, i, y):
@@ -223,14 +241,14 @@ class NeuMF(Model):
     loss = sum CE + reg1*(l2(pg)+l2(qg)) + reg2*(l2(pm)+l2(qm)) (:93-94).  h_gmf / h_mlp exist as variables but
     receive no gradient."""
 
-    def __init__(self, Pg, Qg, Pm, Qm, Ws, bs, h, lr, reg1, reg2, loss_func="cross_entropy"):
+    def __init__(self, Pg, Qg, Pm, Qm, Ws, bs, h, lr, reg1, reg2, loss_func="cross_entropy", optimizer="Adam"):
         self.loss_func = loss_func
         params = {"P_gmf": Pg, "Q_gmf": Qg, "P_mlp": Pm, "Q_mlp": Qm, "h_neumf": h}
         kinds = {"P_gmf": "sparse", "Q_gmf": "sparse", "P_mlp": "sparse", "Q_mlp": "sparse", "h_neumf": "dense"}
         for k, (W, b) in enumerate(zip(Ws, bs)):
             params["W_%d" % k], params["b_%d" % k] = W, b
             kinds["W_%d" % k] = kinds["b_%d" % k] = "dense"
-        super().__init__(params, kinds, lr)
+        super().__init__(params, kinds, lr, optimizer)
         self.reg1, self.reg2, self.n_layers = reg1, reg2, len(Ws)
 
     def loss(self, w, u, i, y):
@@ -258,8 +276,8 @@ class CML(Model):
     gradient (:45-53), + reg * sum offdiag(cov([Q;P])) (:63-70).  Both tables get dense gradients (the
     covariance term reads the full tables) -> dense Adam."""
 
-    def __init__(self, P, Q, lr, reg, margin, item_nums):
-        super().__init__({"P": P, "Q": Q}, {"P": "dense", "Q": "dense"}, lr)
+    def __init__(self, P, Q, lr, reg, margin, item_nums, optimizer="Adam"):
+        super().__init__({"P": P, "Q": Q}, {"P": "dense", "Q": "dense"}, lr, optimizer)
         self.reg, self.margin, self.item_nums = reg, margin, item_nums
 
     def loss(self, w, u, i, neg):
@@ -296,8 +314,8 @@ class SBPR(Model):
     + reg*(l2 of the four gathered rows and the three gathered biases).  All three variables are reached through tf.gather:
     IndexedSlices Adam (every row swept)."""
 
-    def __init__(self, P, Q, bias, lr, reg):
-        super().__init__({"P": P, "Q": Q, "bias": bias}, {"P": "sparse", "Q": "sparse", "bias": "sparse"}, lr)
+    def __init__(self, P, Q, bias, lr, reg, optimizer="Adam"):
+        super().__init__({"P": P, "Q": Q, "bias": bias}, {"P": "sparse", "Q": "sparse", "bias": "sparse"}, lr, optimizer)
         self.reg = reg
 
     def loss(self, w, u, i, k, j, suk):
@@ -318,8 +336,8 @@ class LRML(Model):
     P, Q are reached through tf.gather (IndexedSlices Adam), K and M are dense variables (ApplyAdam).  _unit_clipping
     (LRML.py:65-68) is never called and the variables' `regularizer=` never reaches the loss."""
 
-    def __init__(self, P, Q, K, M, lr, reg, margin):
-        super().__init__({"P": P, "Q": Q, "K": K, "M": M}, {"P": "sparse", "Q": "sparse", "K": "dense", "M": "dense"}, lr)
+    def __init__(self, P, Q, K, M, lr, reg, margin, optimizer="Adam"):
+        super().__init__({"P": P, "Q": Q, "K": K, "M": M}, {"P": "sparse", "Q": "sparse", "K": "dense", "M": "dense"}, lr, optimizer)
         self.reg, self.margin = reg, margin
 
     @staticmethod
@@ -414,8 +432,8 @@ class FM(Model):
     term ignores x_value, :35,49); loss = sum (y - y_pre)^2 + reg*(l2(wi) + l2(vif)) over the FULL tables (:52)
     -> dense Adam for wi and vif; w0 dense."""
 
-    def __init__(self, w0, wi, vif, lr, reg):
-        super().__init__({"w0": w0, "wi": wi, "vif": vif}, {"w0": "dense", "wi": "dense", "vif": "dense"}, lr)
+    def __init__(self, w0, wi, vif, lr, reg, optimizer="Adam"):
+        super().__init__({"w0": w0, "wi": wi, "vif": vif}, {"w0": "dense", "wi": "dense", "vif": "dense"}, lr, optimizer)
         self.reg = reg
 
     def y_pre(self, w, x_idx, x_val):

@@ -107,3 +107,27 @@ def test_cml_loo_uses_unclipped_user_rows(sess, tmp_path):
     clipped = lambda u, items: om.predict([u])[0][np.asarray(items)]
     Hc, _, Nc = oracle.test_model_loo_py(clipped, m.test_users, data.ui_test, neg_samples, [5, 10], 16, ascending=True)
     assert not np.allclose(N[1], Nc[1])
+
+
+@pytest.mark.parametrize("optimizer", ["SGD", "Adagrad"])
+def test_cml_sgd_and_adagrad_match_oracle(sess, optimizer):
+    """configs['optimizer'] = SGD | Adagrad on the CML graph (utils/tools.py:79-87); both tables are dense variables (the
+    covariance term)."""
+    from oracle import models_torch as MT
+    g = np.random.Generator(np.random.PCG64(23))
+    U, I, d, K, B = 60, 45, 16, 5, 100
+    N = 2 * B + 17
+    P, Q = (g.standard_normal((U, d)) * 0.3).astype(np.float32), (g.standard_normal((I, d)) * 0.3).astype(np.float32)
+    u, i = g.integers(0, U, N).astype(np.int32), g.integers(0, I, N).astype(np.int32)
+    neg = g.integers(0, I, (N, K)).astype(np.int32)
+    lr = 0.01
+    st = runtime.CmlState(sess, P, Q, lr=lr, reg=10.0, margin=1.0, optimizer=optimizer)
+    om = MT.CML(P, Q, lr=lr, reg=10.0, margin=1.0, item_nums=I, optimizer=optimizer)
+    loss = st.train_epoch(sess.to_dev(u), sess.to_dev(i), sess.to_dev(neg), B).cpu().numpy()
+    ol = [om.step(u[b * B:(b + 1) * B], i[b * B:(b + 1) * B], neg[b * B:(b + 1) * B]) for b in range(len(loss))]
+    np.testing.assert_allclose(loss, ol, rtol=5e-5)
+    for dev, name in ((st.P, "P"), (st.Q, "Q")):
+        ref = om.numpy(name)
+        tol = om.bounds(name)[0] + 1e-6 * np.abs(ref) + 2e-7
+        assert (np.abs(dev.cpu().numpy() - ref) <= tol).all(), name
+    assert np.abs(st.Q.cpu().numpy() - Q).max() > 1e-3

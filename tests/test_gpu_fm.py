@@ -91,3 +91,28 @@ def test_fm_class_surface(sess, tmp_path):
     yp = om.y_pre(w, data.X_idx_t, data.X_value_t).numpy()
     r3, m3 = cal_rmse_mae(data.y_t.astype(np.float64), yp.astype(np.float64))
     assert rt == pytest.approx(r3, rel=1e-4) and mt == pytest.approx(m3, rel=1e-4)
+
+
+@pytest.mark.parametrize("optimizer", ["SGD", "Adagrad"])
+def test_fm_sgd_and_adagrad_match_oracle(sess, optimizer):
+    """configs['optimizer'] = SGD | Adagrad on the FM graph (utils/tools.py:79-87): all three variables are dense (the l2
+    term reads the full tables), so every row moves every step."""
+    from oracle import models_torch as MT
+    g = np.random.Generator(np.random.PCG64(17))
+    nf, d, F, B = 120, 16, 3, 128
+    N = 2 * B + 30
+    w0, wi, vif = np.array([0.1], np.float32), (g.standard_normal(nf) * 0.1).astype(np.float32), (g.standard_normal((nf, d)) * 0.1).astype(np.float32)
+    x_idx = g.integers(0, nf, (N, F)).astype(np.int32)
+    x_val = np.where(g.random((N, F)) < 0.7, 1.0, g.random((N, F)) * 2).astype(np.float32)
+    y = g.integers(1, 6, N).astype(np.float32)
+    lr = 0.01
+    st = runtime.FmState(sess, w0, wi, vif, lr=lr, reg=1e-3, optimizer=optimizer)
+    om = MT.FM(w0.reshape(()), wi, vif, lr=lr, reg=1e-3, optimizer=optimizer)
+    y_pre, loss = st.train_epoch(sess.to_dev(x_idx), sess.to_dev(x_val), sess.to_dev(y), B)
+    ol = [om.step(x_idx[b * B:(b + 1) * B], x_val[b * B:(b + 1) * B], y[b * B:(b + 1) * B]) for b in range(len(loss))]
+    np.testing.assert_allclose(loss.cpu().numpy(), ol, rtol=2e-5)
+    for dev, name in ((st.w0, "w0"), (st.wi, "wi"), (st.vif, "vif")):
+        ref = om.numpy(name)
+        tol = om.bounds(name)[0] + 1e-6 * np.abs(ref) + 1e-7
+        assert (np.abs(dev.cpu().numpy().reshape(ref.shape) - ref) <= tol).all(), name
+    assert np.abs(st.wi.cpu().numpy() - wi).max() > 1e-3

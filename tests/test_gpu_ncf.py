@@ -262,3 +262,44 @@ def test_square_loss_matches_oracle(sess, kind):
     ol = [om.step(u[b * B:(b + 1) * B], i[b * B:(b + 1) * B], y[b * B:(b + 1) * B]) for b in range(len(loss))]
     np.testing.assert_allclose(loss, ol, rtol=1e-5)
     _compare(st, om, names)
+
+
+@pytest.mark.parametrize("optimizer", ["SGD", "Adagrad"])
+@pytest.mark.parametrize("kind", ["GMF", "NeuMF"])
+def test_sgd_and_adagrad_match_oracle(sess, kind, optimizer):
+    """get_optimizer(configs['optimizer'], lr) (utils/tools.py:79-87) on the NCF graphs: GradientDescentOptimizer and
+    AdagradOptimizer (accumulator 0.1, kept in the m slots) on the shared row machinery (csrc/rows_adam.hip) -- a sparse
+    table's untouched rows stay as they are; the tower's dense variables take the dense forms.  lr large enough that three
+    steps move the parameters well beyond the comparison's resolution."""
+    U, I, B, d, layers = 90, 70, 256, 16, [32, 16]
+    g = np.random.Generator(np.random.PCG64(31))
+    u, i, y = _instances(6, U, I, 2 * B + 40)
+    lr = 0.05
+    if kind == "GMF":
+        P, Q, h = _rand(g, U, d), _rand(g, I, d), _rand(g, d, scale=0.5)
+        st = runtime.NcfState(sess, "GMF", {"P_gmf": P, "Q_gmf": Q}, [], [], h, lr=lr, reg_gmf=0.01, optimizer=optimizer)
+        om = MT.GMF(P, Q, h, lr=lr, reg=0.01, optimizer=optimizer)
+        names = [(st.t["P_gmf"], "P"), (st.t["Q_gmf"], "Q"), (st.h, "h_gmf")]
+    else:
+        Pg, Qg, Pm, Qm = _rand(g, U, d), _rand(g, I, d), _rand(g, U, layers[0] // 2), _rand(g, I, layers[0] // 2)
+        Ws, bs, last = _tower(g, layers[0], len(layers))
+        h = _rand(g, d + last, scale=0.3)
+        st = runtime.NcfState(sess, "NeuMF", {"P_gmf": Pg, "Q_gmf": Qg, "P_mlp": Pm, "Q_mlp": Qm}, Ws, bs, h, lr=lr,
+                              reg_gmf=1e-2, reg_mlp=1e-3, optimizer=optimizer)
+        om = MT.NeuMF(Pg, Qg, Pm, Qm, Ws, bs, h, lr=lr, reg1=1e-2, reg2=1e-3, optimizer=optimizer)
+        names = [(st.t[k], k) for k in ("P_gmf", "Q_gmf", "P_mlp", "Q_mlp")] + [(st.h, "h_neumf")]
+        names += [(st.W[k], "W_%d" % k) for k in range(len(layers))] + [(st.b[k], "b_%d" % k) for k in range(len(layers))]
+    loss = st.train_epoch(sess.to_dev(u), sess.to_dev(i), sess.to_dev(y), B).cpu().numpy()
+    ol = [om.step(u[b * B:(b + 1) * B], i[b * B:(b + 1) * B], y[b * B:(b + 1) * B]) for b in range(len(loss))]
+    np.testing.assert_allclose(loss, ol, rtol=1e-5)
+    for dev, name in names:
+        ref = om.numpy(name)
+        tol = om.bounds(name)[0] + 1e-6 * np.abs(ref) + 1e-7
+        assert (np.abs(dev.cpu().numpy().reshape(ref.shape) - ref) <= tol).all(), name
+    assert np.abs(st.h.cpu().numpy() - h).max() > 1e-3  # the steps did move the parameters
+    # untouched rows of a sparse table are bit-for-bit what they were
+    t0 = {"GMF": ("P_gmf", "P"), "NeuMF": ("P_gmf", "P_gmf")}[kind]
+    untouched = np.setdiff1d(np.arange(U), u)
+    if len(untouched):
+        init = (P if kind == "GMF" else Pg)[untouched]
+        assert np.array_equal(st.t[t0[0]].cpu().numpy()[untouched], init)
