@@ -645,6 +645,31 @@ __device__ __forceinline__ float4 ld4_sc1(const float *base, int64_t off)
     const crec_u4v x = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(off * 4), 0, 16 /* sc1 */);
     return make_float4(__uint_as_float(x.x), __uint_as_float(x.y), __uint_as_float(x.z), __uint_as_float(x.w));
 }
+// the lazy step's published rows (contributions, partials): agent-scope accesses + s_waitcnt, or -- CREC_TICKET_FENCES,
+// the textbook form kept buildable and compared bit for bit under test (tests/test_gpu_fences.py) -- plain accesses
+// bracketed by device-scope fences
+__device__ __forceinline__ void st4_pub(float *base, int64_t off, float4 v)
+{
+    if (CREC_TICKET_FENCES)
+        st4(base + off, v);
+    else
+        st4_wt(base, off, v);
+}
+__device__ __forceinline__ float4 ld4_pub(const float *base, int64_t off) { return CREC_TICKET_FENCES ? ld4(base + off) : ld4_sc1(base, off); }
+__device__ __forceinline__ void pub_release()
+{
+    if (CREC_TICKET_FENCES)
+        __threadfence();
+    else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ void pub_acquire()
+{
+    if (CREC_TICKET_FENCES)
+        __threadfence();
+    else
+        asm volatile("" ::: "memory");
+}
 __device__ __forceinline__ float4 ld4s(const float *p) // streamed slot input (m, v: read once)
 {
     if (CREC_NT & 2) {
@@ -1534,7 +1559,7 @@ __device__ __forceinline__ float4 lazy_sum_rows(const float *buf, int64_t off, i
         float4 c[DEEP];
 #pragma unroll
         for (int e = 0; e < DEEP; ++e)
-            c[e] = k0 + e < n ? ld4_sc1(buf, off + (int64_t)(k0 + e) * stride) : make_float4(0.f, 0.f, 0.f, 0.f);
+            c[e] = k0 + e < n ? ld4_pub(buf, off + (int64_t)(k0 + e) * stride) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int e = 0; e < DEEP; ++e)
             if (k0 + e < n)
@@ -1556,7 +1581,7 @@ __device__ __forceinline__ float4 lazy_sum_front(const float *buf, int d, int l,
         float4 c[DEEP];
 #pragma unroll
         for (int e = 0; e < DEEP; ++e)
-            c[e] = k0 + e < n ? ld4_sc1(buf, (int64_t)at(k0 + e) * d + 4 * l) : make_float4(0.f, 0.f, 0.f, 0.f);
+            c[e] = k0 + e < n ? ld4_pub(buf, (int64_t)at(k0 + e) * d + 4 * l) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int e = 0; e < DEEP; ++e)
             if (k0 + e < n) {
@@ -1632,7 +1657,7 @@ __device__ __forceinline__ void lazy_role_tail(const Tables &t, int d, bool act,
     const LazyTicket q = lazy_ticket_of(desc, CH);
     if (old + weight != q.need)
         return;
-    asm volatile("" ::: "memory");
+    pub_acquire();
     const int row = desc.x & 0x7fffffff;
     const int64_t ro = (int64_t)row * d + 4 * l;
     const bool slots = act && (USER || !h.dQ);
@@ -1654,8 +1679,8 @@ __device__ __forceinline__ void lazy_role_tail(const Tables &t, int d, bool act,
         __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next launch
     if (q.chunked) { // a chunk of a chunked row: publish the partial, then the same game over the row's chunks
         if (act)
-            st4_wt(pbuf, (int64_t)q.idx * d + 4 * l, g);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            st4_pub(pbuf, (int64_t)q.idx * d + 4 * l, g);
+        pub_release();
         const int parts = (cnt + CH - 1) / CH;
         int t2 = -1;
         if (l == 0)
@@ -1663,7 +1688,7 @@ __device__ __forceinline__ void lazy_role_tail(const Tables &t, int d, bool act,
         t2 = __shfl(t2, lead, 64);
         if (t2 != parts - 1)
             return;
-        asm volatile("" ::: "memory");
+        pub_acquire();
         if (act)
             g = lazy_sum_rows(pbuf, (int64_t)start * d + 4 * l, parts, (int64_t)CH * d, zero);
         if (l == 0)
@@ -1790,11 +1815,11 @@ __global__ __launch_bounds__(LazyGeo<LPR>::THREADS) void bpr_triples_lazy(Tables
     const bool i_publish = !is && (!front || (blk_lead && !blk_whole)); // front region: only a piece's leader speaks for the row
     if (on && !(CREC_LAZY_ABL & 2)) {
         if (!us)
-            st4_wt(z.ucontrib, (int64_t)(du.y & 0xffff) * d + 4 * l, cu);
+            st4_pub(z.ucontrib, (int64_t)(du.y & 0xffff) * d + 4 * l, cu);
         if (i_publish)
-            st4_wt(z.qcontrib, (int64_t)i_k * d + 4 * l, front ? blk_sum : nsp);
+            st4_pub(z.qcontrib, (int64_t)i_k * d + 4 * l, front ? blk_sum : nsp);
         if (!js)
-            st4_wt(z.qcontrib, (int64_t)(dj.y & 0xffff) * d + 4 * l, sp);
+            st4_pub(z.qcontrib, (int64_t)(dj.y & 0xffff) * d + 4 * l, sp);
     }
     // 2. the tickets of all three roles at once (one round trip, not three).  The contribution rows travel with
     // agent-scope stores; the wave waits for their completion first -- the same guarantee as a release fence for these
@@ -1804,7 +1829,7 @@ __global__ __launch_bounds__(LazyGeo<LPR>::THREADS) void bpr_triples_lazy(Tables
     const int wi = front ? blk_n : 1;
     int tku = -1, tki = -1, tkj = -1;
     if (any_multi) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        pub_release();
         if (valid && l == 0) {
             const LazyTicket qu = lazy_ticket_of(du, z.CH), qi_ = lazy_ticket_of(di, z.CH), qj_ = lazy_ticket_of(dj, z.CH);
             if (!us)

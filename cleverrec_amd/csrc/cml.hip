@@ -188,7 +188,10 @@ __global__ __launch_bounds__(256) void cml_instances(const float *__restrict__ P
     float dmin = INFINITY;
     int kmin = 0, imp = 0;
     // four negatives' rows in flight per group: the loop is a chain of row fetches otherwise (K is 20 in the shipped conf)
-    constexpr int NB = 4;
+#ifndef CML_NB
+#define CML_NB 4
+#endif
+    constexpr int NB = CML_NB;
     for (int k0 = 0; k0 < K; k0 += NB) { // wave-uniform trip count
         int nk[NB];
         float4 qn[NB];

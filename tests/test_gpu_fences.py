@@ -1,0 +1,58 @@
+"""The ticket paths of csrc/bpr_train.hip (heavy-row chunks of the tf1 step, multi-occurrence rows of the lazy step) publish
+rows with agent-scope accesses + `s_waitcnt vmcnt(0)` + relaxed tickets instead of release / acquire fences -- correct by
+gfx950's memory hierarchy (sc1 stores complete where the XCDs meet), not by the C++ memory model.  The textbook form
+(-DCREC_TICKET_FENCES=1: plain accesses bracketed by device-scope fences) stays buildable; this test builds it on the box and
+requires bit-identical tables and losses on shapes where nearly every row takes a ticket."""
+import glob
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_WORKER = r"""
+import sys, numpy as np
+sys.path.insert(0, %(root)r)
+from cleverrec_amd import runtime
+sess = runtime.Session(0)
+out = {}
+g = np.random.Generator(np.random.PCG64(3))
+for mode, U, I, d, B in (("tf1", 300, 24, 64, 2048), ("lazy", 300, 24, 128, 2048), ("lazy", 5000, 40, 32, 1024)):
+    P0, Q0 = (g.standard_normal((U, d)) * 0.01).astype(np.float32), (g.standard_normal((I, d)) * 0.01).astype(np.float32)
+    n = 5 * B + 123
+    u, i, j = (g.integers(0, m, n).astype(np.int32) for m in (U, I, I))
+    st = runtime.BprState(sess, P0, Q0, lr=1e-3, reg=0.01, adam_mode=mode)
+    loss = st.train_epoch(sess.to_dev(u), sess.to_dev(i), sess.to_dev(j), B).cpu().numpy()
+    key = "%%s_%%d_%%d" %% (mode, U, d)
+    out[key + "_loss"], out[key + "_P"], out[key + "_Q"], out[key + "_vQ"] = loss, st.P.cpu().numpy(), st.Q.cpu().numpy(), st.vQ.cpu().numpy()
+np.savez(sys.argv[1], **out)
+"""
+
+
+def _run(lib, path):
+    env = dict(os.environ)
+    if lib:
+        env["CREC_LIB"] = lib
+    subprocess.run([sys.executable, "-c", _WORKER % {"root": ROOT}, path], check=True, env=env, timeout=300)
+    return np.load(path)
+
+
+def test_fenced_build_is_bit_identical(tmp_path):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    objs = [o for o in glob.glob(os.path.join(ROOT, "cleverrec_amd", "lib", "obj", "*.o")) if os.path.basename(o) != "bpr_train.o"]
+    if not os.path.exists(hipcc) or not objs:
+        pytest.skip("needs hipcc and the built objects of the library")
+    obj, lib = str(tmp_path / "bpr_train.o"), str(tmp_path / "libcrec.so")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-x", "hip", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off",
+                    "-I" + os.path.join(ROOT, "include"), "-DCREC_TICKET_FENCES=1", "-c",
+                    os.path.join(ROOT, "cleverrec_amd", "csrc", "bpr_train.hip"), "-o", obj], check=True, timeout=600)
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-o", lib, *objs, obj, "-L/opt/rocm/lib", "-lrccl"], check=True, timeout=300)
+    a, b = _run(None, str(tmp_path / "default.npz")), _run(lib, str(tmp_path / "fenced.npz"))
+    assert sorted(a.files) == sorted(b.files) and len(a.files) == 12
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k
