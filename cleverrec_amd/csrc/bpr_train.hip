@@ -1943,12 +1943,13 @@ __global__ __launch_bounds__(256) void bpr_adam_dense(float *__restrict__ var, f
 // bpr_reduce_loss: one workgroup per batch, fixed summation order, float64 accumulation.
 //   dense: rowterm[0 .. n_dense).  lazy (n_dense == 0): one l2 term per triple, rowterm[0 .. nb).
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bpr_reduce_loss(const float *__restrict__ ws, int64_t stride, int64_t n_total,
+constexpr int RL_THREADS = 1024; // 6 + 10 terms per thread at ml-1m shape: two rounds of loads (256 threads: eight, 12 -> 7 us per chunk of 20 batches)
+__global__ __launch_bounds__(RL_THREADS) void bpr_reduce_loss(const float *__restrict__ ws, int64_t stride, int64_t n_total,
                                                        int32_t B, int64_t n_dense, const int32_t *__restrict__ n_u,
                                                        const int32_t *__restrict__ n_q, float reg,
                                                        float *__restrict__ loss_per_batch)
 {
-    __shared__ double part[256];
+    __shared__ double part[RL_THREADS];
     const int64_t t0 = (int64_t)blockIdx.x * B;
     const int nb = (int)((n_total - t0) < B ? (n_total - t0) : B);
     const float *xb = ws + blockIdx.x * stride, *rowterm = xb + B;
@@ -1956,18 +1957,16 @@ __global__ __launch_bounds__(256) void bpr_reduce_loss(const float *__restrict__
     // a thread's terms are added in ascending k; the loads of eight of them are issued together (a load per add was a
     // chain of ~60 dependent round trips: 24 us for a chunk of 20 batches)
     const auto sum_f = [](const float *p, int64_t n, auto f, double acc) {
-        int64_t k = threadIdx.x;
-        for (; k + 7 * 256 < n; k += 8 * 256) {
+        for (int64_t k = threadIdx.x; k < n; k += 8 * RL_THREADS) {
             float t[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-                t[e] = p[k + e * 256];
+                t[e] = k + e * RL_THREADS < n ? p[k + e * RL_THREADS] : 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-                acc += (double)f(t[e]);
+                if (k + e * RL_THREADS < n)
+                    acc += (double)f(t[e]);
         }
-        for (; k < n; k += 256)
-            acc += (double)f(p[k]);
         return acc;
     };
     const auto ident = [](float x) { return x; };
@@ -1979,7 +1978,7 @@ __global__ __launch_bounds__(256) void bpr_reduce_loss(const float *__restrict__
     }
     part[threadIdx.x] = s + (double)reg * l2;
     __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
+    for (int off = RL_THREADS / 2; off > 0; off >>= 1) {
         if ((int)threadIdx.x < off)
             part[threadIdx.x] += part[threadIdx.x + off];
         __syncthreads();
@@ -2428,7 +2427,7 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
             opt->step += 1;
         }
         crec_prof_begin(ctx, CREC_K_REDUCE_LOSS, st);
-        CREC_KLAUNCH(ctx, bpr_reduce_loss, dim3((unsigned)nbc), dim3(256), 0, st, (const float *)ctx->loss_ws.ptr,
+        CREC_KLAUNCH(ctx, bpr_reduce_loss, dim3((unsigned)nbc), dim3(RL_THREADS), 0, st, (const float *)ctx->loss_ws.ptr,
                            loss_stride, n_chunk, B, dense ? t->U + t->I : (int64_t)0, (const int32_t *)w.n_u,
                            (const int32_t *)w.n_q, opt->reg, loss_per_batch + b0);
         crec_prof_end(ctx, st);
@@ -2750,7 +2749,7 @@ int sharded_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, int64_t I_global
             opt->step += 1;
         }
         crec_prof_begin(ctx, CREC_K_REDUCE_LOSS, st);
-        CREC_KLAUNCH(ctx, bpr_reduce_loss, dim3((unsigned)nbc), dim3(256), 0, st, (const float *)ctx->loss_ws.ptr, loss_stride,
+        CREC_KLAUNCH(ctx, bpr_reduce_loss, dim3((unsigned)nbc), dim3(RL_THREADS), 0, st, (const float *)ctx->loss_ws.ptr, loss_stride,
                      n_chunk, B, (int64_t)0, (const int32_t *)w.n_u, (const int32_t *)w.n_q, opt->reg, loss_per_batch + b0);
         crec_prof_end(ctx, st);
         if (int rc = x->allreduce_sum_f32(ctx, loss_per_batch + b0, (size_t)nbc, st))
