@@ -108,6 +108,9 @@ __device__ __forceinline__ void crec_mark(int slot, int dep) // the time at whic
 #ifndef CREC_LAZY_ABL
 #define CREC_LAZY_ABL 0 // timing ablations of bpr_triples_lazy (wrong results): 1 no finishers, 2 no publishing / tickets either,
 #endif                  // 4 no LDS piece sums
+#ifndef CREC_IDX_RECS
+#define CREC_IDX_RECS 12 // all of a thread's records at B = 6144: one round of gathers instead of three (a 20-batch call 227 -> 219 us)
+#endif
 #ifndef CREC_LAZY_HEADSTART
 #define CREC_LAZY_HEADSTART 6 // x 0.43 us (tools/lazy_variants.sh)
 #endif
@@ -518,19 +521,20 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
     CREC_IDX_MARK(5);
     // occurrence records in sorted order
     int4 *occ_out = side ? w.q_occ + (int64_t)batch * 2 * B : w.u_occ + (int64_t)batch * B;
-    for (int k0r = tid; k0r < n; k0r += 4 * PREP_THREADS) { // four records per thread in flight: the gathers are the cost
-        int pos[4];
-        uint32_t payload[4];
-        int4 rec[4];
+    constexpr int RIF = CREC_IDX_RECS; // records per thread in flight: the gathers are the cost (4: three rounds per item side)
+    for (int k0r = tid; k0r < n; k0r += RIF * PREP_THREADS) {
+        int pos[RIF];
+        uint32_t payload[RIF];
+        int4 rec[RIF];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < RIF; ++e) {
             const int k = k0r + e * PREP_THREADS;
             const int t = k < n ? tag[k] : 0;
             pos[e] = t < nb ? t : t - nb;
             payload[e] = (t < nb ? 0u : 0x80000000u) | (uint32_t)pos[e]; // side flag: the row is the triple's j
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { // the sorted row is one of the three ids: two scattered loads per record, not three
+        for (int e = 0; e < RIF; ++e) { // the sorted row is one of the three ids: two scattered loads per record, not three
             const int k = k0r + e * PREP_THREADS;
             const int row = k < n ? (int)rows[k] : 0;
             if (side == 0)
@@ -541,7 +545,7 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
                 rec[e] = make_int4(u[t0 + pos[e]], row, j[t0 + pos[e]], (int)payload[e]);
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+        for (int e = 0; e < RIF; ++e)
             if (k0r + e * PREP_THREADS < n)
                 occ_out[k0r + e * PREP_THREADS] = rec[e];
     }
