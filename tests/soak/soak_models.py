@@ -41,6 +41,7 @@ def main():
         u, i = g.integers(0, U, N).astype(np.int32), g.integers(0, I, N).astype(np.int32)
         # ---- NCF family -------------------------------------------------------------------------------------------------
         kind = str(g.choice(["GMF", "MLP", "NeuMF"]))
+        optim = str(g.choice(["Adam", "Adam", "SGD", "Adagrad"]))  # get_optimizer (utils/tools.py:79-87)
         dg = int(g.choice([4, 8, 12, 32, 64]))
         n_layers = int(g.integers(1, 5))
         L0 = int(g.choice([8, 16, 24, 40, 64, 128])) if n_layers < 4 else int(g.choice([16, 64, 128]))
@@ -54,18 +55,18 @@ def main():
         try:
             if kind == "GMF":
                 P, Q, h = rnd(U, dg), rnd(I, dg), rnd(dg, scale=0.5)
-                st = runtime.NcfState(sess, "GMF", {"P_gmf": P, "Q_gmf": Q}, [], [], h, lr=1e-3, reg_gmf=0.01)
-                om = MT.GMF(P, Q, h, lr=1e-3, reg=0.01)
+                st = runtime.NcfState(sess, "GMF", {"P_gmf": P, "Q_gmf": Q}, [], [], h, lr=1e-3, reg_gmf=0.01, optimizer=optim)
+                om = MT.GMF(P, Q, h, lr=1e-3, reg=0.01, optimizer=optim)
                 names = [(st.t["P_gmf"], "P"), (st.t["Q_gmf"], "Q"), (st.h, "h_gmf")]
             elif kind == "MLP":
                 P, Q, h = rnd(U, L0 // 2), rnd(I, L0 // 2), rnd(w, scale=0.5)
-                st = runtime.NcfState(sess, "MLP", {"P_mlp": P, "Q_mlp": Q}, Ws, bs, h, lr=1e-3, reg_mlp=0.01)
-                om = MT.MLP(P, Q, Ws, bs, h, lr=1e-3, reg=0.01)
+                st = runtime.NcfState(sess, "MLP", {"P_mlp": P, "Q_mlp": Q}, Ws, bs, h, lr=1e-3, reg_mlp=0.01, optimizer=optim)
+                om = MT.MLP(P, Q, Ws, bs, h, lr=1e-3, reg=0.01, optimizer=optim)
                 names = [(st.t["P_mlp"], "P"), (st.t["Q_mlp"], "Q"), (st.h, "h_mlp")] + [(st.W[k], "W_%d" % k) for k in range(n_layers)]
             else:
                 Pg, Qg, Pm, Qm, h = rnd(U, dg), rnd(I, dg), rnd(U, L0 // 2), rnd(I, L0 // 2), rnd(dg + w, scale=0.3)
-                st = runtime.NcfState(sess, "NeuMF", {"P_gmf": Pg, "Q_gmf": Qg, "P_mlp": Pm, "Q_mlp": Qm}, Ws, bs, h, lr=1e-3, reg_gmf=1e-2, reg_mlp=1e-3)
-                om = MT.NeuMF(Pg, Qg, Pm, Qm, Ws, bs, h, lr=1e-3, reg1=1e-2, reg2=1e-3)
+                st = runtime.NcfState(sess, "NeuMF", {"P_gmf": Pg, "Q_gmf": Qg, "P_mlp": Pm, "Q_mlp": Qm}, Ws, bs, h, lr=1e-3, reg_gmf=1e-2, reg_mlp=1e-3, optimizer=optim)
+                om = MT.NeuMF(Pg, Qg, Pm, Qm, Ws, bs, h, lr=1e-3, reg1=1e-2, reg2=1e-3, optimizer=optim)
                 names = [(st.t[k], k) for k in ("P_gmf", "Q_gmf", "P_mlp", "Q_mlp")] + [(st.h, "h_neumf")] + [(st.W[k], "W_%d" % k) for k in range(n_layers)]
             loss = st.train_epoch(sess.to_dev(u), sess.to_dev(i), sess.to_dev(y), B).cpu().numpy()
             ol = [om.step(u[b * B:(b + 1) * B], i[b * B:(b + 1) * B], y[b * B:(b + 1) * B]) for b in range(len(loss))]
@@ -74,7 +75,7 @@ def main():
                 close(dev, om.numpy(name), name)
         except AssertionError as e:
             fails += 1
-            print("NCF FAIL %s U=%d I=%d B=%d N=%d dg=%d L0=%d layers=%d: %s" % (kind, U, I, B, N, dg, L0, n_layers, str(e).strip().split("\n")[0]))
+            print("NCF FAIL %s %s U=%d I=%d B=%d N=%d dg=%d L0=%d layers=%d: %s" % (kind, optim, U, I, B, N, dg, L0, n_layers, str(e).strip().split("\n")[0]))
         n["ncf"] += 1
         # ---- FM ---------------------------------------------------------------------------------------------------------
         d, F, nf = int(g.choice([4, 8, 20, 32, 64])), int(g.integers(1, 9)), int(g.integers(10, 200))
