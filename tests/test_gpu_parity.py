@@ -535,3 +535,45 @@ def test_counts_published_by_the_index_kernel_equal_the_copied_ones(sess):
             sess.ctx.set_option("no_zero_copy", 0)
     for a, b in zip(out[0], out[1]):
         assert np.array_equal(a, b)
+
+
+def test_csv_to_metrics_pipeline(sess, tmp_path):
+    """f2 + a16 on the GPU box: ratings.csv -> RankingPreprocess (filter, re-index, split, CSR; checked against the
+    reference's own output on the same file, tests/golden/preprocess_syn.npz) -> BPR(sess, data, configs, logger) -> one
+    epoch and the rs evaluation, against the oracle's trainer on the reference's CSR."""
+    import logging
+    from cleverrec_amd.model.RankingPreprocess import RankingPreprocess
+    from cleverrec_amd.model.ranking.BPR import BPR
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "preprocess_syn.npz"))
+    d = tmp_path / "syn"
+    d.mkdir()
+    with open(d / "ratings.csv", "w") as f:
+        for a, b in zip(g["csv_u"], g["csv_i"]):
+            f.write("%d,%d\n" % (a, b))
+    cfg = {"data.root_dir": str(tmp_path), "data.dataset": "syn", "data.file_name": "ratings.csv", "data.sep": ",",
+           "data.format": "UI", "data.split_way": "rs", "data.split_ratio": "[0.7,0.2,0.1]", "data.split_by_time": "False",
+           "data.user_min": "0", "data.item_min": "5", "test.neg_samples": "0", "recommender": "BPR"}
+    np.random.seed(int(g["seed"]))
+    data = RankingPreprocess(cfg, logging.getLogger("t"))
+    for mine, ref in zip(data.train_csr, ("train_keys", "train_ptr", "train_items")):
+        assert np.array_equal(mine, g[ref]), ref
+    configs = dict(cfg, **{"epoches": "1", "batch_size": "256", "test.batch_size": "64", "lr": "0.001", "is_pairwise": "True",
+                           "init_method": "normal", "stddev": "0.01", "loss_func": "bpr", "optimizer": "Adam",
+                           "saved_dir": str(tmp_path), "test.interval": "1", "topk": "[5,10]", "neg_ratio": "4",
+                           "embed_size": "16", "reg": "0.01"})
+    m = BPR(sess, data, configs, logging.getLogger("t"))
+    P0, Q0 = _tables(21, data.user_nums, data.item_nums, 16)
+    m.build_model(P0, Q0)
+    om = oracle.BprModel(P0, Q0, lr=1e-3, reg=0.01)
+    ref_train = {int(k): [int(x) for x in g["train_items"][g["train_ptr"][n]:g["train_ptr"][n + 1]]] for n, k in enumerate(g["train_keys"])}
+    np.random.seed(4)
+    avg = m.train_model()
+    nb, ou, oi, oj = oracle.sample_pairwise(oracle.Rng(4), ref_train, int(g["item_nums"]), 4, 256)
+    oavg, _ = oracle.train_model_py(om, nb, ou, oi, oj, 256)
+    assert avg == pytest.approx(oavg, rel=1e-5)
+    HR, MRR, NDCG = m.test_model_rs()
+    Pn, Qn = m.P.cpu().numpy(), m.Q.cpu().numpy()
+    H, M, N = oracle.test_model_rs_py(lambda cur: oracle.scores(Pn, Qn, cur, 1), m.test_users, data.ui_train, data.ui_test, [5, 10], 64)
+    for kid in range(2):
+        np.testing.assert_allclose(HR[kid], H[kid], rtol=0)
+        np.testing.assert_allclose(NDCG[kid], N[kid], rtol=1e-12)

@@ -1,5 +1,7 @@
 """Device sampler (cleverrec_amd.runtime.DeviceSampler): not stream-compatible with the reference, so it is tested on the
 properties the reference's rule guarantees (utils/sampler.py:18-31,50-66,82-93) and against the host sampler's shapes."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -108,3 +110,58 @@ def test_class_surface_with_device_sampler(sess, tmp_path):
     for _ in range(4):
         l1 = m.train_model()
     assert np.isfinite(l0) and l1 < l0
+
+
+# ---- the bit-exact host samplers ON the GPU box, into the device path ----------------------------------
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_rng_streams_match_numpy_on_the_gpu_box(sess):
+    """a1: the NumPy-legacy MT19937 randint / permutation of the GPU-bound ctx against numpy itself."""
+    ctx = sess.ctx
+    for seed in (0, 123, 2 ** 32 - 1):
+        ctx.seed(seed)
+        np.random.seed(seed)
+        for n in [1, 2, 3, 10, 1349, 3706, 4096, 4097, 2 ** 31, 2 ** 32, 1, 7] * 10:
+            assert ctx.randint(n) == int(np.random.randint(n))
+        for n in (0, 1, 2, 63, 64, 65, 1000, 5000):
+            assert np.array_equal(ctx.permutation(n), np.random.permutation(n))
+
+
+@pytest.mark.parametrize("name", ["toy", "syn200", "dense", "pow2"])
+def test_reference_streams_reach_the_device_path_unchanged(sess, name):
+    """a2-a4: the pairwise / pointwise / CML samplers of the GPU-bound ctx reproduce the reference-generated streams bit for
+    bit (tests/golden/sampler_*.npz, tools/make_golden.py), the columns survive the upload, and a BPR epoch on the pairwise
+    stream equals the oracle's on the reference's own columns."""
+    import oracle
+    g = np.load(os.path.join(GOLDEN, "sampler_%s.npz" % name))
+    csr = (g["keys"], g["ptr"], g["items"])
+    item_nums, seed, nr = int(g["item_nums"]), int(g["seed"]), int(g["neg_ratio"])
+    ctx = sess.ctx
+    ctx.seed(seed)
+    u, i, j = ctx.sample_pairwise(csr, item_nums, nr)
+    assert np.array_equal(u, g["pw_u"]) and np.array_equal(i, g["pw_i"]) and np.array_equal(j, g["pw_j"])
+    assert ctx.randint(2 ** 30) == int(g["pw_next"])
+    ctx.seed(seed)
+    pu, pi, py = ctx.sample_pointwise(csr, item_nums, nr)
+    assert np.array_equal(pu, g["pt_u"]) and np.array_equal(pi, g["pt_i"]) and np.array_equal(py, g["pt_y"])
+    assert ctx.randint(2 ** 30) == int(g["pt_next"])
+    ctx.seed(seed)
+    cu, ci, cneg = ctx.sample_cml(csr, item_nums, nr)
+    assert np.array_equal(cu, g["cml_u"]) and np.array_equal(ci, g["cml_i"]) and np.array_equal(cneg, g["cml_neg"])
+    assert ctx.randint(2 ** 30) == int(g["cml_next"])
+    du, di, dj = (sess.to_dev(x) for x in (u, i, j))
+    assert np.array_equal(du.cpu().numpy(), g["pw_u"]) and np.array_equal(dj.cpu().numpy(), g["pw_j"])
+    # the stream through the step: the device on ITS sampler's columns, the oracle on the reference's
+    U = int(max(int(g["keys"].max()), int(g["pw_u"].max())) + 1)
+    d, B = 16, 64
+    rng = np.random.Generator(np.random.PCG64(1))
+    P0, Q0 = (rng.standard_normal((U, d)) * 0.01).astype(np.float32), (rng.standard_normal((item_nums, d)) * 0.01).astype(np.float32)
+    st = runtime.BprState(sess, P0, Q0, lr=1e-3, reg=0.01, adam_mode="tf1")
+    loss = st.train_epoch(du, di, dj, B).cpu().numpy()
+    om = oracle.BprModel(P0, Q0, lr=1e-3, reg=0.01)
+    ru, ri, rj = (np.asarray(g[k], dtype=np.int32) for k in ("pw_u", "pw_i", "pw_j"))
+    ol = [om.step(ru[b * B:(b + 1) * B], ri[b * B:(b + 1) * B], rj[b * B:(b + 1) * B]) for b in range(len(loss))]
+    np.testing.assert_allclose(loss, ol, rtol=1e-5)
+    np.testing.assert_allclose(st.P.cpu().numpy(), om.P, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(st.Q.cpu().numpy(), om.Q, rtol=0, atol=2e-6)
