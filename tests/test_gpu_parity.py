@@ -577,3 +577,36 @@ def test_csv_to_metrics_pipeline(sess, tmp_path):
     for kid in range(2):
         np.testing.assert_allclose(HR[kid], H[kid], rtol=0)
         np.testing.assert_allclose(NDCG[kid], N[kid], rtol=1e-12)
+
+
+@pytest.mark.parametrize("init_method,expect", [("normal", "normal"), ("tnormal", "tnormal"), ("xavier_normal", "xavier_normal"),
+                                                ("xavier", "xavier")])
+def test_initializers_reach_the_device_tables(sess, tmp_path, init_method, expect):
+    """a9 on the GPU box: BPR(...).build_model() without injected tables draws P, Q with get_initializer(init_method, stddev)
+    (utils/tools.py:51-63) and the rows the step trains are those draws: moments / supports of the DEVICE tables."""
+    import logging
+    import math
+    import torch
+    from cleverrec_amd.model.ranking.BPR import BPR
+    data = _toy_data(3, 3000, 400, 3, 12)
+    s, d = 0.05, 64
+    configs = {"recommender": "BPR", "epoches": "1", "batch_size": "512", "test.batch_size": "64", "lr": "0.001",
+               "test.neg_samples": "0", "is_pairwise": "True", "init_method": init_method, "stddev": str(s), "loss_func": "bpr",
+               "optimizer": "Adam", "saved_dir": str(tmp_path), "test.interval": "1", "topk": "[10]", "neg_ratio": "1",
+               "embed_size": str(d), "reg": "0.01", "data.split_way": "rs"}
+    torch.manual_seed(11)
+    m = BPR(sess, data, configs, logging.getLogger("t"))
+    m.build_model()
+    x = m.P.cpu().double()
+    n = data.user_nums
+    assert m.P.is_cuda and tuple(x.shape) == (n, d) and float(m.state.mP.abs().max()) == 0.0
+    if expect == "normal":
+        assert abs(float(x.mean())) < 5 * s / math.sqrt(n * d) and abs(float(x.std()) / s - 1) < 0.02
+    elif expect == "tnormal":
+        assert float(x.abs().max()) <= 2 * s and abs(float(x.std()) / (0.8796 * s) - 1) < 0.02
+    elif expect == "xavier_normal":
+        sd = math.sqrt(1.3 * 2.0 / (n + d))
+        assert float(x.abs().max()) <= 2 * sd and abs(float(x.std()) / (0.8796 * sd) - 1) < 0.02
+    else:
+        lim = math.sqrt(6.0 / (n + d))
+        assert float(x.abs().max()) <= lim and abs(float(x.std()) / (lim / math.sqrt(3)) - 1) < 0.02
