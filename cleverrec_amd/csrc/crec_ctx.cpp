@@ -53,7 +53,8 @@ void crec_prof_begin(crec_ctx *ctx, int cls, hipStream_t st)
 {
     if (!ctx->prof.on)
         return;
-    crec_profile::rec r{cls, prof_event(ctx), prof_event(ctx), false};
+    crec_profile::rec r{cls, prof_event(ctx), prof_event(ctx), false, ctx->prof.skip_next};
+    ctx->prof.skip_next = false;
     ctx->prof.pending.push_back(r);
     ctx->prof.open = true;
     (void)st;
@@ -91,7 +92,7 @@ int crec_prof_flush(crec_ctx *ctx, hipStream_t st)
     CREC_HIP(ctx, hipStreamSynchronize(st));
     for (auto &r : ctx->prof.pending) {
         float ms = 0.f;
-        if (r.ext && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+        if (r.ext && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess && !r.skip) {
             ctx->prof.total_ms[r.cls] += ms > 0.f ? ms : 0.f;
             ctx->prof.launches[r.cls] += 1;
         }

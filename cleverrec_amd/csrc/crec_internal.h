@@ -56,7 +56,9 @@ struct crec_profile {
         int cls;
         hipEvent_t a, b;
         bool ext; // a / b were handed to hipExtLaunchKernelGGL: they carry the dispatch's own begin / end timestamps
+        bool skip; // launched while its predecessor was still running: its events also span the wait, not counted
     };
+    bool skip_next = false; // the next crec_prof_begin opens such a record
     bool open = false; // between crec_prof_begin and crec_prof_end
     std::vector<rec> pending;
     std::vector<hipEvent_t> pool;
