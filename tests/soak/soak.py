@@ -27,7 +27,11 @@ def main():
     g = np.random.Generator(np.random.PCG64(a.seed))
     t_end = time.time() + 60 * a.minutes
     n_bpr = n_eval = n_samp = fails = 0
+    t_say = time.time() + 60
     while time.time() < t_end:
+        if time.time() > t_say:  # a line a minute: a silent run is taken for a hung one
+            print("soak: %d BPR configs so far, %d failures" % (n_bpr, fails), flush=True)
+            t_say = time.time() + 60
         # ---- a BPR configuration: small catalogues make heavy rows; ragged batch sizes -------------------------------
         U, I = int(g.integers(3, 400)), int(g.integers(6, 300))
         d = int(g.choice([4, 8, 12, 16, 32, 64, 128, 256]))

@@ -34,7 +34,11 @@ def main():
     g = np.random.Generator(np.random.PCG64(a.seed))
     rnd = lambda *s, scale=0.1: (g.standard_normal(s) * scale).astype(np.float32)
     t_end, n, fails = time.time() + 60 * a.minutes, {"ncf": 0, "fm": 0, "cml": 0, "lrml": 0, "transcf": 0}, 0
+    t_say = time.time() + 60
     while time.time() < t_end:
+        if time.time() > t_say:  # a line a minute: a silent run is taken for a hung one
+            print("soak_models: %s so far, %d failures" % (n, fails), flush=True)
+            t_say = time.time() + 60
         U, I = int(g.integers(5, 120)), int(g.integers(5, 90))
         B = int(g.choice([1, 31, 32, 33, 200, 1000]))
         N = int(min(3 * B + g.integers(0, B + 1), 2500))
