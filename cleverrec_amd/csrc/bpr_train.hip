@@ -2331,12 +2331,17 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
             ctx->pinned_ints = 0;
             ctx->pinned_dev = nullptr;
             // mapped + coherent: the index kernel's last workgroup writes the counts and the flag here itself
-            CREC_HIP(ctx, hipHostMalloc((void **)&ctx->pinned, sizeof(int32_t) * (n_back * 2 + 64),
-                                        hipHostMallocMapped | hipHostMallocCoherent));
+            const size_t want = sizeof(int32_t) * (n_back * 2 + 64);
+            bool mapped = hipHostMalloc((void **)&ctx->pinned, want, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
+            if (!mapped) { // no coherent mapping on this system: plain page-locked memory, the counts come back by copy
+                (void)hipGetLastError();
+                ctx->pinned = nullptr;
+                CREC_HIP(ctx, hipHostMalloc((void **)&ctx->pinned, want, hipHostMallocDefault));
+            }
             ctx->pinned_ints = n_back * 2 + 64;
             memset(ctx->pinned, 0, sizeof(int32_t) * ctx->pinned_ints);
             void *dev = nullptr;
-            if (hipHostGetDevicePointer(&dev, ctx->pinned, 0) == hipSuccess)
+            if (mapped && hipHostGetDevicePointer(&dev, ctx->pinned, 0) == hipSuccess)
                 ctx->pinned_dev = (int32_t *)dev;
             else
                 (void)hipGetLastError();
