@@ -21,7 +21,7 @@ def configs(seed):
         d = int(g.choice([4, 8, 12, 16, 32, 64, 128, 256]))
         B = int(g.choice([1, 7, 64, 333, 1000, 2048, 6144, 8192]))
         nr = int(g.integers(1, 5))
-        mode = str(g.choice(["tf1", "lazy"]))
+        mode = str(g.choice(["tf1", "lazy", "lazy", "sgd", "adagrad"]))  # as tests/soak/soak.py draws it
         deg_hi = max(2, min(I - nr - 1, int(g.integers(2, 40))))
         ui_train = {u: [int(x) for x in g.choice(I, size=int(g.integers(1, deg_hi + 1)), replace=False)] for u in range(U) if g.random() < 0.9}
         if not ui_train:
@@ -56,7 +56,7 @@ def main():
     U, I, B, nr = c["U"], c["I"], c["B"], c["nr"]
     data = RankingData(U, I, c["ui_train"], {u: [0] for u in list(c["ui_train"])[:3]})
     st = runtime.BprState(sess, c["P0"], c["Q0"], lr=1e-3, reg=0.01, adam_mode=c["mode"])
-    om = oracle.BprModel(c["P0"], c["Q0"], lr=1e-3, reg=0.01, adam_mode={"tf1": 0, "lazy": 1}[c["mode"]])
+    om = oracle.BprModel(c["P0"], c["Q0"], lr=1e-3, reg=0.01, adam_mode={"tf1": 0, "lazy": 1, "sgd": 2, "adagrad": 3}[c["mode"]])
     sess.ctx.seed(c["seed"])
     rng = oracle.Rng(c["seed"])
     for ep in range(2):
