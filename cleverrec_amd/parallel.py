@@ -68,12 +68,14 @@ class DpBprState(BprState):
         super().__init__(sess, P0, Q0, lr, reg, "tf1")
         self.rank, self.world = init_rccl(sess, rank, world)
 
-    def train_epoch(self, u, i, j, batch_size):
-        """Collective.  u: row ids inside this rank's shard.  Returns per-batch losses summed over ranks."""
+    def train_epoch(self, u, i, j, batch_size, out=None):
+        """Collective.  u: row ids inside this rank's shard.  Returns per-batch losses summed over ranks (in `out` if given)."""
         s = self.sess
         n = int(u.numel())
         nb = -(-n // batch_size)
-        loss = s.empty((nb,), torch.float32)
+        loss = s.empty((nb,), torch.float32) if out is None else out
+        if loss.numel() < nb or loss.dtype != torch.float32 or not loss.is_contiguous():
+            raise ValueError("out: a contiguous float32 device tensor of at least %d elements" % nb)
         s.ctx.check(s.lib.crec_bpr_train_epoch_dp(s.ctx.h, C.byref(self.tables), C.byref(self.adam), s.ptr(u), s.ptr(i),
                                                   s.ptr(j), n, int(batch_size), s.ptr(loss), s.stream_ptr()))
         return loss

@@ -72,12 +72,14 @@ class BprState:
             self.lastQ = torch.zeros(self.Q.shape[0], dtype=torch.int32, device=sess.device)
             self.deferred = _lib.BprDeferred(self.lastP.data_ptr(), self.lastQ.data_ptr())
 
-    def train_epoch(self, u, i, j, batch_size):
-        """u, i, j: int32 device tensors [N].  Returns the per-batch summed losses (device fp32)."""
+    def train_epoch(self, u, i, j, batch_size, out=None):
+        """u, i, j: int32 device tensors [N].  Returns the per-batch summed losses (device fp32; written into `out` if given)."""
         s = self.sess
         n = int(u.numel())
         nb = -(-n // batch_size)
-        loss = s.empty((nb,), torch.float32)
+        loss = s.empty((nb,), torch.float32) if out is None else out
+        if loss.numel() < nb or loss.dtype != torch.float32 or not loss.is_contiguous():
+            raise ValueError("out: a contiguous float32 device tensor of at least %d elements" % nb)
         if getattr(self, 'deferred', None) is not None:
             s.ctx.check(s.lib.crec_bpr_train_epoch_deferred(s.ctx.h, C.byref(self.tables), C.byref(self.deferred), C.byref(self.adam),
                                                             s.ptr(u), s.ptr(i), s.ptr(j), n, int(batch_size), s.ptr(loss), s.stream_ptr()))
