@@ -1,10 +1,10 @@
 // Workgroup-wide primitives of the index kernels (bpr_index_batches, rows_index_batches): an exclusive scan of one
 // int per thread and a STABLE sort of up to 16*NTH (row, tag) pairs held in LDS by row.
 //
-// The sort is a least-significant-digit radix sort, 8 bits per pass, over the key_bits low bits of the row (the
-// caller knows the table size, so ml-1m takes two passes and a 10 M-row table three).  In a pass wave w owns the
+// The sort is a least-significant-digit radix sort, at most 8 bits per pass, over the key_bits low bits of the row (the
+// caller knows the table size, so ml-1m takes two passes of 6 bits and a 10 M-row table three of 8).  In a pass wave w owns the
 // contiguous range [w*chunk, (w+1)*chunk) of the current order and walks it 64 elements at a time; the lanes that
-// hold the same digit find each other with eight ballots (one per digit bit), which gives every element its
+// hold the same digit find each other with one ballot per digit bit, which gives every element its
 // position among its wave's elements of that digit without atomics and in the current order -- that is what makes
 // the pass stable.  Per-wave digit counts are then scanned in (digit, wave) order and every element is written to
 // its final place of the pass.  All elements sit in registers between the read and the write, so one LDS copy of
@@ -70,7 +70,12 @@ __device__ __forceinline__ void block_sort_rows(uint32_t *rows, uint16_t *tag, i
     const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     int *my_hist = hist + wave * HIST_STRIDE;
     __syncthreads(); // the caller's fill of rows / tag
-    for (int shift = 0; shift < key_bits; shift += 8) {
+    // the key's bits are dealt evenly to the passes (12 bits: 6 + 6, not 8 + 4): a pass costs a ballot per digit bit and a
+    // scan over 2^bits counters per wave, so 6 + 6 is twelve ballots and two 64-digit scans where 8 + 4 was sixteen
+    // ballots (the second pass went through all eight) and two 256-digit scans
+    const int passes = (key_bits + 7) / 8, bits = (key_bits + passes - 1) / passes, D = 1 << bits;
+    const uint32_t dmask = (uint32_t)D - 1u;
+    for (int pass = 0, shift = 0; pass < passes; ++pass, shift += bits) {
         uint32_t r[MAXI];
         uint16_t p[MAXI];
         int loc[MAXI];
@@ -84,7 +89,7 @@ __device__ __forceinline__ void block_sort_rows(uint32_t *rows, uint16_t *tag, i
                 p[s] = tag[k];
             }
         }
-        for (int c = lane; c < 256; c += 64)
+        for (int c = lane; c < D; c += 64)
             my_hist[c] = 0;
         // rank inside the wave: LDS operations of one wave execute in order, so the running counter written in
         // round s is the one read in round s+1
@@ -92,13 +97,15 @@ __device__ __forceinline__ void block_sort_rows(uint32_t *rows, uint16_t *tag, i
         for (int s = 0; s < MAXI; ++s) {
             if (s < ns) { // wave-uniform
                 const bool valid = base + s * 64 + lane < n;
-                const uint32_t digit = (r[s] >> shift) & 255u;
+                const uint32_t digit = (r[s] >> shift) & dmask;
                 uint64_t peers = __ballot(valid);
 #pragma unroll
                 for (int b = 0; b < 8; ++b) {
-                    const bool bit = (digit >> b) & 1u;
-                    const uint64_t bal = __ballot(bit);
-                    peers &= bit ? bal : ~bal;
+                    if (b < bits) { // wave-uniform
+                        const bool bit = (digit >> b) & 1u;
+                        const uint64_t bal = __ballot(bit);
+                        peers &= bit ? bal : ~bal;
+                    }
                 }
                 const int before = __popcll(peers & lt_mask), cnt = __popcll(peers);
                 const int run = my_hist[digit];
@@ -108,12 +115,12 @@ __device__ __forceinline__ void block_sort_rows(uint32_t *rows, uint16_t *tag, i
             }
         }
         __syncthreads(); // every element is in registers, every wave's counts are final
-        // exclusive scan of the 256*WAVES counts in (digit, wave) order: four consecutive counts per thread
+        // exclusive scan of the D*WAVES counts in (digit, wave) order: up to four consecutive counts per thread
         int v[4], sum = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int c = 4 * tid + q;
-            v[q] = hist[(c % WAVES) * HIST_STRIDE + c / WAVES];
+            v[q] = c < D * WAVES ? hist[(c % WAVES) * HIST_STRIDE + c / WAVES] : 0;
             sum += v[q];
         }
         int total;
@@ -121,14 +128,15 @@ __device__ __forceinline__ void block_sort_rows(uint32_t *rows, uint16_t *tag, i
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int c = 4 * tid + q;
-            hist[(c % WAVES) * HIST_STRIDE + c / WAVES] = run;
+            if (c < D * WAVES)
+                hist[(c % WAVES) * HIST_STRIDE + c / WAVES] = run;
             run += v[q];
         }
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < MAXI; ++s) {
             if (s < ns && base + s * 64 + lane < n) {
-                const int dst = my_hist[(r[s] >> shift) & 255u] + loc[s];
+                const int dst = my_hist[(r[s] >> shift) & dmask] + loc[s];
                 rows[dst] = r[s];
                 tag[dst] = p[s];
             }
