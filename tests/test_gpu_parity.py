@@ -188,6 +188,68 @@ def test_bpr_is_deterministic_at_full_size(sess):
     np.testing.assert_allclose(outs[0][0][:3], ol, rtol=1e-5)
 
 
+@pytest.mark.parametrize("mode", ["lazy", "tf1", "deferred"])
+def test_bpr_c5_full_size_step_against_the_oracle_on_the_touched_rows(sess, mode):
+    """BASELINE configs[4] at its full size -- 10 M users x 1 M items, d = 128, B = 6144, tables and slots 16.9 GB in HBM
+    (made on the device; the host never holds them).  Only rows a batch has named ever move (lazy: by construction; TF1's
+    dense sweep: a row with m = 0 gets lr_t * 0 / (0 + eps)), so the oracle runs the same batches on the COMPACT problem (the
+    touched rows, ids renumbered in order) and every touched row, its m and its v must agree; every other row of all six
+    arrays must be bit-identical to what it was.  deferred = TF1's numbers with the lazy step's traffic, after flush()."""
+    free = torch.cuda.mem_get_info()[0]
+    if free < 40 << 30:
+        pytest.skip("needs 40 GB of free HBM, %.0f GB free" % (free / 2 ** 30))
+    U, I, d, B, nb = 10_000_000, 1_000_000, 128, 6144, 4
+    dev = sess.device
+    g = torch.Generator(device=dev).manual_seed(5)
+    st = runtime.BprState.__new__(runtime.BprState)
+    st.sess = sess
+    st.P = torch.empty((U, d), dtype=torch.float32, device=dev).normal_(0, 0.01, generator=g)
+    st.Q = torch.empty((I, d), dtype=torch.float32, device=dev).normal_(0, 0.01, generator=g)
+    st.mP, st.vP, st.mQ, st.vQ = (torch.zeros_like(t) for t in (st.P, st.P, st.Q, st.Q))
+    st.tables = _lib.BprTables(*(t.data_ptr() for t in (st.P, st.Q, st.mP, st.vP, st.mQ, st.vQ)), U, I, d)
+    st.adam = _lib.Adam(1e-3, 0.9, 0.999, 1e-8, 0.01, {"lazy": _lib.ADAM_LAZY, "tf1": _lib.ADAM_TF1, "deferred": _lib.ADAM_DEFERRED}[mode],
+                        0.9, 0.999, 0)
+    st.deferred = None
+    if mode == "deferred":
+        st.lastP, st.lastQ = torch.zeros(U, dtype=torch.int32, device=dev), torch.zeros(I, dtype=torch.int32, device=dev)
+        st.deferred = _lib.BprDeferred(st.lastP.data_ptr(), st.lastQ.data_ptr())
+    n = nb * B - 100  # ragged last batch
+    u = torch.randint(0, U, (n,), generator=g, device=dev).to(torch.int32)
+    w = 1.0 / torch.arange(1, I + 1, dtype=torch.float64, device=dev)  # positives Zipf(1): item 0 ~430 times a batch
+    i = torch.searchsorted(torch.cumsum(w / w.sum(), 0), torch.rand(n, generator=g, device=dev, dtype=torch.float64)).clamp_(max=I - 1).to(torch.int32)
+    j = torch.randint(0, I, (n,), generator=g, device=dev).to(torch.int32)
+    u[:7] = torch.tensor([0, U - 1, U - 1, 0, 1 << 23, (1 << 23) - 1, U - 1], dtype=torch.int32)  # the ends of the id range
+    j[:3] = torch.tensor([I - 1, 0, I - 1], dtype=torch.int32)
+    uu, qq = torch.unique(u.long()), torch.unique(torch.cat([i, j]).long())
+    P0c, Q0c = st.P[uu].cpu().numpy(), st.Q[qq].cpu().numpy()
+    P_before, Q_before = st.P.clone(), st.Q.clone()
+    loss = st.train_epoch(u, i, j, B).cpu().numpy()
+    st.flush()
+    # ---- the oracle on the compact problem ----
+    om = oracle.BprModel(P0c, Q0c, lr=1e-3, reg=0.01, adam_mode=1 if mode == "lazy" else 0)
+    cu, ci, cj = (torch.searchsorted(ids, x.long()).to(torch.int32).cpu().numpy() for ids, x in ((uu, u), (qq, i), (qq, j)))
+    _, oloss = oracle.train_model_py(om, nb, cu, ci, cj, B)
+    np.testing.assert_allclose(loss, oloss, rtol=1e-5)
+    for name, ids in (("P", uu), ("Q", qq)):
+        got, gm, gv = (getattr(st, pre + name)[ids].cpu().numpy() for pre in ("", "m", "v"))
+        # m is linear in the gradient: tight.  A weight whose gradient cancels to ~1e-8 (|m| ~ 1e-9, inside Adam's eps) turns the
+        # order of the fp32 additions into a fraction of a step: all but 1e-5 of the elements within 2e-6, none beyond 2 % of a step
+        np.testing.assert_allclose(gm, getattr(om, "m" + name), rtol=1e-5, atol=1e-7, err_msg="m" + name)
+        np.testing.assert_allclose(gv, getattr(om, "v" + name), rtol=2e-3, atol=1e-12, err_msg="v" + name)
+        dw = np.abs(got - getattr(om, name))
+        assert dw.max() <= 2e-5 and (dw > 2e-6).mean() <= 1e-5, "%s: max %.3g, %.3g of the elements beyond 2e-6" % (name, dw.max(), (dw > 2e-6).mean())
+    # ---- nothing else moved: rows outside the batches keep their bits, their slots stay zero ----
+    for name, ids, before in (("P", uu, P_before), ("Q", qq, Q_before)):
+        touched = torch.zeros(before.shape[0], dtype=torch.bool, device=dev)
+        touched[ids] = True
+        moved = (getattr(st, name) != before).any(dim=1)
+        assert not bool((moved & ~touched).any()), name + ": a row outside the batches changed"
+        assert bool(moved[ids].all()), name + ": a touched row kept its value"
+        del moved
+        for pre in ("m", "v"):
+            assert not bool(((getattr(st, pre + name) != 0).any(dim=1) & ~touched).any()), pre + name + ": a slot row outside the batches is not zero"
+
+
 def test_bpr_argument_checks(sess):
     P0, Q0 = _tables(0, 10, 10, 6)  # d = 6 is not a multiple of 4
     st = runtime.BprState(sess, P0, Q0, 1e-3, 0.01)
