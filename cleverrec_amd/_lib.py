@@ -62,6 +62,10 @@ class Sbpr(C.Structure):
     _fields_ = [("P", Param), ("Q", Param), ("bias", Param), ("reg", C.c_float)]
 
 
+class Cune(C.Structure):
+    _fields_ = [("P", Param), ("Q", Param), ("bias", Param), ("s", Param), ("reg", C.c_float)]
+
+
 class Lrml(C.Structure):
     _fields_ = [("P", Param), ("Q", Param), ("small", Param), ("mem_size", C.c_int32), ("reg", C.c_float), ("margin", C.c_float)]
 
@@ -107,6 +111,7 @@ _SIGNATURES = {
     "crec_rmse_mae": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "crec_cml_train_epoch": (C.c_int, [_vp, C.POINTER(Cml), C.POINTER(Adam), _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
     "crec_sbpr_train_epoch": (C.c_int, [_vp, C.POINTER(Sbpr), C.POINTER(Adam), _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
+    "crec_cune_train_epoch": (C.c_int, [_vp, C.POINTER(Cune), C.POINTER(Adam), _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "crec_lrml_train_epoch": (C.c_int, [_vp, C.POINTER(Lrml), C.POINTER(Adam), _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "crec_lrml_scores": (C.c_int, [_vp, C.POINTER(Lrml), _vp, _i32, _vp, _vp]),
     "crec_transcf_train_epoch": (C.c_int, [_vp, C.POINTER(Transcf), C.POINTER(Adam), _vp, _vp, _vp, _i64, _i32, _vp, _vp]),

@@ -12,6 +12,12 @@
 // instance: four row gathers, three dots, the two sigmoids, contribution rows for p_u and the three item rows,
 // contribution scalars for the three biases, the item slot ids) -> rows_index_batches over the batch's 3B item slots
 // -> crec_apply_all (P, Q, and bias as a one-column table).  Deterministic, no atomics.
+//
+// CUNE_BPR (model/ranking/CUNE_BPR.py:44-61) is the same step with other arguments of the two log-sigmoids --
+//   loss = sum -log sigmoid(x_ui - x_uk) + sum -log sigmoid((x_uk - x_uj) / (s + 1.0)) + the same l2 terms
+// -- where s is a trainable scalar (tf.Variable(0.0), :42; a dense variable: ApplyAdam).  sbpr_instances<LPR, true> reads
+// s, leaves every instance's ds = sigmoid(-b) * b / (s + 1) (b = the second argument; RealDiv's gradient) in a column, and
+// cune_scalar_step (one workgroup, launched after the tables' apply) sums the column in a fixed order and moves s.
 #include "crec_internal.h"
 #include "rows_adam.h"
 
@@ -41,14 +47,15 @@ template <int LPR> __device__ inline float group_sum(float v)
 }
 
 // grid: ceil(nb / G / 4) blocks of 256; slot layout of the item side per batch: [i-slots | k-slots | j-slots], B each
-template <int LPR>
+template <int LPR, bool CUNE>
 __global__ __launch_bounds__(256) void sbpr_instances(const float *__restrict__ P, const float *__restrict__ Q,
                                                       const float *__restrict__ bias, int d, const int32_t *__restrict__ u,
                                                       const int32_t *__restrict__ i, const int32_t *__restrict__ k,
                                                       const int32_t *__restrict__ j, const float *__restrict__ suk, int nb,
                                                       int B, float reg, float *__restrict__ c_p, float *__restrict__ c_q,
                                                       float *__restrict__ c_b, int32_t *__restrict__ slots,
-                                                      float *__restrict__ loss_inst)
+                                                      float *__restrict__ loss_inst, const float *__restrict__ s_var,
+                                                      float *__restrict__ ds_inst)
 {
     constexpr int G = 64 / LPR;
     const int lane = threadIdx.x & 63, g = lane / LPR, l = lane % LPR;
@@ -56,17 +63,25 @@ __global__ __launch_bounds__(256) void sbpr_instances(const float *__restrict__ 
     const bool valid = r < nb, act = 4 * l < d, on = valid && act;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     const int ru = valid ? u[r] : 0, ri = valid ? i[r] : 0, rk = valid ? k[r] : 0, rj = valid ? j[r] : 0;
-    const float sk = valid ? suk[r] : 1.0f;
+    float sk = 1.0f, den = 1.0f; // SBPR: the first argument is divided by suk; CUNE: the second by s + 1
+    if (CUNE)
+        den = s_var[0] + 1.0f;
+    else if (valid)
+        sk = suk[r];
     const float4 p = on ? ld4(P + (int64_t)ru * d + 4 * l) : zero, qi = on ? ld4(Q + (int64_t)ri * d + 4 * l) : zero,
                  qk = on ? ld4(Q + (int64_t)rk * d + 4 * l) : zero, qj = on ? ld4(Q + (int64_t)rj * d + 4 * l) : zero;
     const float bi = valid ? bias[ri] : 0.f, bk = valid ? bias[rk] : 0.f, bj = valid ? bias[rj] : 0.f;
     const float xi = group_sum<LPR>(dot4(p, qi)) + bi, xk = group_sum<LPR>(dot4(p, qk)) + bk, xj = group_sum<LPR>(dot4(p, qj)) + bj;
     const float np = group_sum<LPR>(dot4(p, p)), ni = group_sum<LPR>(dot4(qi, qi)), nk = group_sum<LPR>(dot4(qk, qk)),
                 nj = group_sum<LPR>(dot4(qj, qj));
-    const float a = (xi - xk) / sk, b = xk - xj;           // SBPR.py:52: tf.divide(ui - uk, suk), uk - uj
+    // SBPR.py:52: tf.divide(ui - uk, suk), uk - uj;  CUNE_BPR.py:58: ui - uk, (uk - uj) / (s + 1.0)
+    const float a = CUNE ? xi - xk : (xi - xk) / sk, b = CUNE ? (xk - xj) / den : xk - xj;
     const float s1 = 1.0f / (1.0f + expf(a)), s2 = 1.0f / (1.0f + expf(b)); // sigmoid(-a), sigmoid(-b)
-    const float gi = -s1 / sk, gk = s1 / sk - s2, gj = s2; // dL/dx_ui, dL/dx_uk, dL/dx_uj
+    const float g1 = CUNE ? s1 : s1 / sk, g2 = CUNE ? s2 / den : s2;
+    const float gi = -g1, gk = g1 - g2, gj = g2; // dL/dx_ui, dL/dx_uk, dL/dx_uj
     if (valid && l == 0) {
+        if (CUNE)
+            ds_inst[r] = (s2 * b) / den; // dL/db = -s2;  d b / d den = -b / den (RealDiv's gradient: grad * (-x / y) / y)
         loss_inst[r] = (tf_softplus(-a) + tf_softplus(-b)) +
                        reg * (((0.5f * np + 0.5f * ni) + (0.5f * nk + 0.5f * nj)) + ((0.5f * (bi * bi) + 0.5f * (bk * bk)) + 0.5f * (bj * bj)));
         slots[r] = ri;
@@ -107,7 +122,43 @@ __global__ __launch_bounds__(256) void sbpr_reduce_loss(const float *__restrict_
         loss_per_batch[blockIdx.x] = (float)part[0];
 }
 
+// CUNE_BPR's `s`: the batch's ds column summed in a fixed order (float64 tree), then the dense update of one element
+__global__ __launch_bounds__(256) void cune_scalar_step(const float *__restrict__ ds_inst, int nb, float *__restrict__ var,
+                                                        float *__restrict__ m, float *__restrict__ v, crec_rows_opt o)
+{
+    __shared__ double part[256];
+    double s = 0.0;
+    for (int r = threadIdx.x; r < nb; r += 256)
+        s += (double)ds_inst[r];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off)
+            part[threadIdx.x] += part[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x != 0)
+        return;
+    const float g = (float)part[0];
+    if (o.opt == CREC_OPT_SGD) { // GradientDescentOptimizer
+        var[0] -= o.lr_t * g;
+    } else if (o.opt == CREC_OPT_ADAGRAD) { // accumulator in m (0.1 at start)
+        const float acc = m[0] + g * g;
+        m[0] = acc;
+        var[0] -= (o.lr_t * g) / sqrtf(acc);
+    } else { // ApplyAdam: m += (g - m)(1 - b1); v += (g^2 - v)(1 - b2); var -= m lr_t / (sqrt(v) + eps)
+        const float mn = m[0] + (g - m[0]) * (1.0f - o.beta1), vn = v[0] + (g * g - v[0]) * (1.0f - o.beta2);
+        m[0] = mn;
+        v[0] = vn;
+        var[0] -= (mn * o.lr_t) / (sqrtf(vn) + o.eps);
+    }
+}
+
 } // namespace
+
+static int sbpr_epoch(crec_ctx *ctx, const crec_sbpr *m, const crec_param *s_par, crec_adam *opt, const int32_t *u,
+                      const int32_t *i, const int32_t *k, const int32_t *j, const float *suk, int64_t N, int32_t B,
+                      float *loss_per_batch, void *stream);
 
 extern "C" int crec_sbpr_train_epoch(crec_ctx *ctx, const crec_sbpr *m, crec_adam *opt, const int32_t *u, const int32_t *i,
                                      const int32_t *k, const int32_t *j, const float *suk, int64_t N, int32_t B,
@@ -115,6 +166,25 @@ extern "C" int crec_sbpr_train_epoch(crec_ctx *ctx, const crec_sbpr *m, crec_ada
 {
     if (!ctx)
         return CREC_EINVAL;
+    CREC_REQUIRE(ctx, N <= 0 || suk, "null argument");
+    return sbpr_epoch(ctx, m, nullptr, opt, u, i, k, j, suk, N, B, loss_per_batch, stream);
+}
+
+extern "C" int crec_cune_train_epoch(crec_ctx *ctx, const crec_cune *m, crec_adam *opt, const int32_t *u, const int32_t *i,
+                                     const int32_t *k, const int32_t *j, int64_t N, int32_t B, float *loss_per_batch, void *stream)
+{
+    if (!ctx)
+        return CREC_EINVAL;
+    CREC_REQUIRE(ctx, m && m->s.var && m->s.m && m->s.v && m->s.rows == 1 && m->s.cols == 1, "CUNE_BPR: s is one float with its two slots");
+    const crec_sbpr tables{m->P, m->Q, m->bias, m->reg};
+    return sbpr_epoch(ctx, &tables, &m->s, opt, u, i, k, j, nullptr, N, B, loss_per_batch, stream);
+}
+
+static int sbpr_epoch(crec_ctx *ctx, const crec_sbpr *m, const crec_param *s_par, crec_adam *opt, const int32_t *u,
+                      const int32_t *i, const int32_t *k, const int32_t *j, const float *suk, int64_t N, int32_t B,
+                      float *loss_per_batch, void *stream)
+{
+    const bool cune = s_par != nullptr;
     CREC_REQUIRE(ctx, ctx->device >= 0, "host-only ctx: no device bound");
     CREC_REQUIRE(ctx, m && opt && m->P.var && m->Q.var && m->bias.var && m->P.cols == m->Q.cols && m->bias.cols == 1 &&
                           m->bias.rows >= m->Q.rows,
@@ -122,7 +192,7 @@ extern "C" int crec_sbpr_train_epoch(crec_ctx *ctx, const crec_sbpr *m, crec_ada
     const int d = m->P.cols;
     CREC_REQUIRE(ctx, d % 4 == 0 && d >= 4 && d <= 256, "embed_size %d: need a multiple of 4 in [4, 256]", d);
     CREC_REQUIRE(ctx, B >= 1 && B <= 8192, "batch_size <= 8192");
-    CREC_REQUIRE(ctx, N >= 0 && (N == 0 || (u && i && k && j && suk && loss_per_batch)), "null argument");
+    CREC_REQUIRE(ctx, N >= 0 && (N == 0 || (u && i && k && j && loss_per_batch)), "null argument");
     if (N == 0)
         return CREC_OK;
     CREC_HIP(ctx, hipSetDevice(ctx->device));
@@ -136,8 +206,8 @@ extern "C" int crec_sbpr_train_epoch(crec_ctx *ctx, const crec_sbpr *m, crec_ada
     const int q_chunks = (int)crec_ceil_div(3 * (int64_t)B, 2048); // item slots: sorted 2048 at a time
     const size_t ixu = crec_rows_index_bytes(nb, B, U), ixq = crec_rows_index_bytes(1, 3 * B, I, q_chunks);
     const size_t cpb = sizeof(float) * (size_t)B * d, cqb = sizeof(float) * (size_t)3 * B * d, cbb = sizeof(float) * (size_t)3 * B;
-    const size_t sl = sizeof(int32_t) * (size_t)3 * B, li = sizeof(float) * (size_t)N;
-    if (int rc = crec_reserve(ctx, &ctx->idx_ws, up(ixu) + up(ixq) + up(cpb) + up(cqb) + up(cbb) + up(sl) + up(li)))
+    const size_t sl = sizeof(int32_t) * (size_t)3 * B, li = sizeof(float) * (size_t)N, dsb = sizeof(float) * (size_t)B;
+    if (int rc = crec_reserve(ctx, &ctx->idx_ws, up(ixu) + up(ixq) + up(cpb) + up(cqb) + up(cbb) + up(sl) + up(li) + up(dsb)))
         return rc;
     char *ws = (char *)ctx->idx_ws.ptr;
     crec_rows_index_view vu, vq;
@@ -155,6 +225,8 @@ extern "C" int crec_sbpr_train_epoch(crec_ctx *ctx, const crec_sbpr *m, crec_ada
     int32_t *slots = (int32_t *)p;
     p += up(sl);
     float *loss_inst = (float *)p;
+    p += up(li);
+    float *ds_inst = (float *)p;
     for (int64_t b = 0; b < nb; ++b) {
         const int64_t t0 = b * B;
         const int nbt = (int)((N - t0) < B ? (N - t0) : B);
@@ -164,11 +236,16 @@ extern "C" int crec_sbpr_train_epoch(crec_ctx *ctx, const crec_sbpr *m, crec_ada
         if (int rc = crec_rows_optimizer(ctx, opt, &o))
             return rc;
         const dim3 grid((unsigned)crec_ceil_div(crec_ceil_div(nbt, G), 4));
+#define CREC_SBPR_LAUNCH(L, C)                                                                                              \
+    hipLaunchKernelGGL((sbpr_instances<L, C>), grid, dim3(256), 0, st, (const float *)m->P.var, (const float *)m->Q.var,    \
+                       (const float *)m->bias.var, d, u + t0, i + t0, k + t0, j + t0, C ? nullptr : suk + t0, nbt, nbt,     \
+                       m->reg, c_p, c_q, c_b, slots, loss_inst + t0, C ? (const float *)s_par->var : nullptr, ds_inst)
 #define CREC_SBPR(L)                                                                                                        \
     case L:                                                                                                                 \
-        hipLaunchKernelGGL((sbpr_instances<L>), grid, dim3(256), 0, st, (const float *)m->P.var, (const float *)m->Q.var,   \
-                           (const float *)m->bias.var, d, u + t0, i + t0, k + t0, j + t0, suk + t0, nbt, nbt, m->reg, c_p,  \
-                           c_q, c_b, slots, loss_inst + t0);                                                                \
+        if (cune)                                                                                                           \
+            CREC_SBPR_LAUNCH(L, true);                                                                                      \
+        else                                                                                                                \
+            CREC_SBPR_LAUNCH(L, false);                                                                                     \
         break;
         switch (lpr) {
             CREC_SBPR(1)
@@ -180,6 +257,7 @@ extern "C" int crec_sbpr_train_epoch(crec_ctx *ctx, const crec_sbpr *m, crec_ada
             CREC_SBPR(64)
         }
 #undef CREC_SBPR
+#undef CREC_SBPR_LAUNCH
         // the batch's item slots are laid out [i | k | j] with stride nbt (not B), so a ragged batch has no holes
         if (int rc = crec_rows_index(ctx, slots, 3 * (int64_t)nbt, 3 * B, I, ixq_ws, &vq, st, q_chunks))
             return rc;
@@ -195,6 +273,9 @@ extern "C" int crec_sbpr_train_epoch(crec_ctx *ctx, const crec_sbpr *m, crec_ada
         set.scalar = crec_scalar_job{m->bias.var, m->bias.m, m->bias.v, I, vq.rowseg, vq.order, c_b, nullptr, ob, vq.chunks};
         if (int rc = crec_apply_all(ctx, set, st))
             return rc;
+        if (cune) // s is read by the batch's instances only: its update can follow the tables'
+            hipLaunchKernelGGL(cune_scalar_step, dim3(1), dim3(256), 0, st, (const float *)ds_inst, nbt, (float *)s_par->var,
+                               (float *)s_par->m, (float *)s_par->v, ob);
         opt->beta1_power = opt->beta1_power * opt->beta1;
         opt->beta2_power = opt->beta2_power * opt->beta2;
         opt->step += 1;

@@ -384,6 +384,26 @@ class SbprState:
         return loss
 
 
+class CuneState(SbprState):
+    """CUNE_BPR's variables (model/ranking/CUNE_BPR.py:33-42): SBPR's P, Q, bias plus the trainable scalar s (crec_cune)."""
+
+    def __init__(self, sess, P0, Q0, bias0, s0, lr, reg, beta1=0.9, beta2=0.999, eps=1e-8, optimizer="Adam"):
+        super().__init__(sess, P0, Q0, bias0, lr, reg, beta1, beta2, eps, optimizer)
+        self.s = sess.to_dev(np.asarray(s0, dtype=np.float32).reshape(1), torch.float32)
+        self.slots["s"] = (_zeros_slot(self.s, optimizer), torch.zeros_like(self.s))
+        sb = self.model
+        self.model = _lib.Cune(sb.P, sb.Q, sb.bias, _lib.Param(self.s.data_ptr(), self.slots["s"][0].data_ptr(), self.slots["s"][1].data_ptr(), 1, 1), reg)
+
+    def train_epoch(self, u, i, k, j, batch_size):
+        """u, i, k, j int32 [N] (device) -> per-batch losses (device fp32)."""
+        s = self.sess
+        n = int(u.numel())
+        loss = s.empty((-(-n // batch_size),), torch.float32)
+        s.ctx.check(s.lib.crec_cune_train_epoch(s.ctx.h, C.byref(self.model), C.byref(self.adam), s.ptr(u), s.ptr(i), s.ptr(k), s.ptr(j),
+                                                n, int(batch_size), s.ptr(loss), s.stream_ptr()))
+        return loss
+
+
 def ncf_scores(sess, state, users):
     """crec_ncf_scores -> logits [Bt, I] (device fp32); pre_scores = sigmoid(logits) ranks identically."""
     Bt = int(users.numel())

@@ -290,6 +290,20 @@ int crec_sbpr_train_epoch(crec_ctx *ctx, const crec_sbpr *model, crec_adam *opt,
                           const int32_t *k, const int32_t *j, const float *suk, int64_t N, int32_t B, float *loss_per_batch,
                           void *stream);
 
+/* CUNE_BPR (model/ranking/CUNE_BPR.py:44-61): replaces sess.run([self.train, self.loss], {u_idx, i_idx, i_s_idx,
+ * i_neg_idx}) of train_model_sbpr(is_suk=False) (CUNE_BPR.py:22, model/RankingRecommender.py:101-116).  SBPR's tables and
+ * scores; the two log-sigmoid arguments are x_ui - x_uk and (x_uk - x_uj) / (s + 1.0), with s ('s', tf.Variable(0.0), :42) a
+ * trainable scalar on the dense optimizer path (ApplyAdam).  u, i, k, j from crec_sample_sbpr (its suk column unused: the
+ * stream does not depend on is_suk, utils/sampler.py:102-141).  The friends / SPu lists the sampler needs come from
+ * get_topK_friends_and_SPu (utils/tools.py:130-207), host preprocessing outside this library. */
+typedef struct {
+    crec_param P, Q, bias; /* as crec_sbpr */
+    crec_param s;          /* rows = cols = 1 */
+    float reg;
+} crec_cune;
+int crec_cune_train_epoch(crec_ctx *ctx, const crec_cune *model, crec_adam *opt, const int32_t *u, const int32_t *i,
+                          const int32_t *k, const int32_t *j, int64_t N, int32_t B, float *loss_per_batch, void *stream);
+
 /* ---- Latent Relational Metric Learning (device) -----------------------------------------------
  * replaces sess.run([self.train, self.loss], {u_idx, i_idx, j_idx}) (model/RankingRecommender.py:39-47) on the graph of
  * model/ranking/LRML.py:36-63 -- joint = p_u * q, a = softmax(joint K), r = a M, dist = |p_u + r - q|^2,

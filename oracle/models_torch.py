@@ -330,6 +330,31 @@ class SBPR(Model):
             self.reg * (_l2(pu) + _l2(qi) + _l2(qk) + _l2(qj) + _l2(bi) + _l2(bk) + _l2(bj))
 
 
+class CUNE_BPR(Model):
+    """model/ranking/CUNE_BPR.py:44-61: SBPR's three biased scores; loss = sum -log sigmoid(x_ui - x_uk) + sum -log sigmoid((x_uk -
+    x_uj) / (s + 1.0)) + reg*(l2 of the four gathered rows and the three gathered biases).  `s` (tf.Variable(0.0), :42) is a
+    trainable scalar used directly: dense ApplyAdam; P, Q, bias through tf.gather: IndexedSlices Adam."""
+
+    def __init__(self, P, Q, bias, s, lr, reg, optimizer="Adam"):
+        super().__init__({"P": P, "Q": Q, "bias": bias, "s": np.asarray(s, np.float32).reshape(1)},
+                         {"P": "sparse", "Q": "sparse", "bias": "sparse", "s": "dense"}, lr, optimizer)
+        self.reg = reg
+
+    def loss(self, w, u, i, k, j):
+        u, i, k, j = (torch.as_tensor(np.asarray(x), dtype=torch.long) for x in (u, i, k, j))
+        pu = gather(w, "P", u)
+        qi, qk, qj = gather(w, "Q", i), gather(w, "Q", k), gather(w, "Q", j)
+        bi, bk, bj = gather(w, "bias", i), gather(w, "bias", k), gather(w, "bias", j)
+        xi, xk, xj = (pu * qi).sum(1) + bi, (pu * qk).sum(1) + bk, (pu * qj).sum(1) + bj
+        sp = torch.nn.functional.softplus
+        if w.get("_abs") is not None:  # s sums B terms of either sign (Model.bounds): the rounding scale is sum|ds_r|
+            with torch.no_grad():
+                b = (xk - xj) / (w["s"] + 1.0)
+                w["_abs"]["s"] = w["_abs"].get("s", 0) + (torch.sigmoid(-b) * b.abs() / (w["s"] + 1.0).abs()).sum().reshape(1)
+        return sp(-(xi - xk)).sum() + sp(-(xk - xj) / (w["s"] + 1.0)).sum() + \
+            self.reg * (_l2(pu) + _l2(qi) + _l2(qk) + _l2(qj) + _l2(bi) + _l2(bk) + _l2(bj))
+
+
 class LRML(Model):
     """model/ranking/LRML.py:36-63: joint = p_u * q; a = softmax(joint K); r = a M; dist = |p_u + r - q|^2;
     loss = sum max(dist_i - dist_j + margin, 0) (utils/tools.py:72-73) + reg*(l2(p_u) + l2(q_i) + l2(q_j)).

@@ -68,3 +68,60 @@ def test_sbpr_class_surface(sess, tmp_path):
     H, M, N = oracle.test_model_rs_py(lambda cur: oracle.scores(Pn, Qn, cur, 1), m.test_users, data.ui_train, data.ui_test, [10, 20], 64)
     np.testing.assert_allclose(np.mean(NDCG[0]), np.mean(N[0]), rtol=1e-12)
     np.testing.assert_allclose(np.mean(HR[1]), np.mean(H[1]), rtol=1e-12)
+
+
+@pytest.mark.parametrize("optimizer", ["Adam", "SGD", "Adagrad"])
+@pytest.mark.parametrize("d,B", [(16, 200), (128, 512)])
+def test_cune_steps_match_oracle(sess, d, B, optimizer):
+    """CUNE_BPR.py:44-61: SBPR's scores, the second log-sigmoid's argument divided by the trainable scalar s + 1."""
+    g = np.random.Generator(np.random.PCG64(d + 1))
+    U, I, N = 80, 60, 3 * B + 37
+    P, Q = (g.standard_normal((U, d)) * 0.1).astype(np.float32), (g.standard_normal((I, d)) * 0.1).astype(np.float32)
+    bias = (g.standard_normal(I + 1) * 0.05).astype(np.float32)
+    u, i, k, j = (g.integers(0, n, N).astype(np.int32) for n in (U, I, I, I))
+    st = runtime.CuneState(sess, P, Q, bias, 0.25, lr=1e-3, reg=0.05, optimizer=optimizer)
+    om = MT.CUNE_BPR(P, Q, bias, 0.25, lr=1e-3, reg=0.05, optimizer=optimizer)
+    loss = st.train_epoch(*(sess.to_dev(x) for x in (u, i, k, j)), B).cpu().numpy()
+    ol = [om.step(*(x[b * B:(b + 1) * B] for x in (u, i, k, j))) for b in range(len(loss))]
+    np.testing.assert_allclose(loss, ol, rtol=1e-5)
+    for name, dev in (("P", st.P), ("Q", st.Q), ("bias", st.bias), ("s", st.s)):
+        assert_adam_close(om, name, dev, *st.slots[name])
+    assert float(st.s.cpu()[0]) != pytest.approx(0.25, abs=1e-6)  # s is trained
+
+
+def test_cune_class_surface(sess, tmp_path):
+    """CUNE_BPR(sess, data, configs, logger): network -> walks -> vectors -> friends -> SPu on the host, train_model_sbpr(is_suk=False)
+    on the np.random stream, rs evaluation (u_embed @ Q^T), checkpoint names."""
+    import torch
+    from cleverrec_amd.model.ranking.CUNE_BPR import CUNE_BPR
+    from cleverrec_amd.utils import sampler as S
+    g = np.random.Generator(np.random.PCG64(5))
+    U, I, d = 60, 90, 32
+    ui_train = {uu: [int(x) for x in g.choice(I, size=int(g.integers(3, 10)), replace=False)] for uu in range(U) if uu % 9 != 8}
+    ui_test = {uu: [int(x) for x in g.choice(I, size=2, replace=False)] for uu in range(0, U, 2) if uu in ui_train}
+    data = RankingData(U, I, ui_train, ui_test)
+    configs = {"recommender": "CUNE_BPR", "epoches": "1", "batch_size": "256", "test.batch_size": "64", "lr": "0.001",
+               "test.neg_samples": "0", "is_pairwise": "True", "init_method": "normal", "stddev": "0.01", "loss_func": "bpr",
+               "optimizer": "Adam", "saved_dir": str(tmp_path), "test.interval": "1", "topk": "[10,20]", "neg_ratio": "3",
+               "embed_size": str(d), "reg": "0.05", "data.split_way": "rs", "walk_count": "3", "walk_length": "6", "walk_dim": "8",
+               "window_size": "3", "topk_f": "4"}
+    np.random.seed(11)
+    m = CUNE_BPR(sess, data, configs, logging.getLogger("t"))
+    assert m.SPu and all(len(f) == 4 and uu not in f for uu, f in data.user_friends.items())
+    for uu, lst in m.SPu.items():  # items of the latent friends the user does not hold
+        assert not set(lst) & set(ui_train[uu]) and set(lst) <= set().union(*(ui_train[f] for f in data.user_friends[uu]))
+    init = {"P": (g.standard_normal((U, d)) * 0.1).astype(np.float32), "Q": (g.standard_normal((I, d)) * 0.1).astype(np.float32)}
+    m.build_model(init)
+    om = MT.CUNE_BPR(init["P"], init["Q"], np.zeros(I + 1, np.float32), 0.0, lr=1e-3, reg=0.05)
+    np.random.seed(7)
+    avg = m.train_model()
+    np.random.seed(7)
+    nb, u, i, k, j = S.ranking_sampler_sbpr(data, m.SPu, 3, 256, is_suk=False)
+    tot = sum(om.step(*(x[b * 256:(b + 1) * 256] for x in (u, i, k, j))) for b in range(nb))
+    assert avg == pytest.approx(tot / nb, rel=1e-5)
+    assert float(m.s.cpu()[0]) == pytest.approx(float(om.numpy("s")[0]), abs=2e-6)
+    HR, MRR, NDCG = m.test_model_rs()
+    Pn, Qn = m.P.cpu().numpy(), m.Q.cpu().numpy()
+    H, M, N = oracle.test_model_rs_py(lambda cur: oracle.scores(Pn, Qn, cur, 1), m.test_users, data.ui_train, data.ui_test, [10, 20], 64)
+    np.testing.assert_allclose(np.mean(NDCG[0]), np.mean(N[0]), rtol=1e-12)
+    assert sorted(torch.load(m.save())) == ["cune_params/P", "cune_params/Q", "cune_params/bias"]

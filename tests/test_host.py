@@ -316,3 +316,94 @@ def test_get_sp_mat_matches_reference_lists():
             n = int(rptr[r + 1] - rptr[r])
             if n:  # the device forms float32(1.0 / n) (csrc/transcf.hip nbr_weight); TF casts the list's float64 the same way
                 np.testing.assert_array_equal(val[sel].astype(np.float32), np.full(n, np.float32(1.0 / n)))
+
+
+def _cune_toy(seed=3, U=40, I=30):
+    from cleverrec_amd.data import RankingData
+    g = np.random.Generator(np.random.PCG64(seed))
+    ui_train = {u: [int(x) for x in g.choice(I, size=int(g.integers(1, 7)), replace=False)] for u in range(U) if u % 11 != 10}
+    ui_train[U - 1] = [I - 1]  # a user sharing nothing with anybody stays outside the network (item I-1 removed from the others)
+    for u in ui_train:
+        if u != U - 1:
+            ui_train[u] = [x for x in ui_train[u] if x != I - 1] or [0]
+    return RankingData(U, I, ui_train, {0: [1]})
+
+
+def test_cunet_is_the_pairwise_intersection_network():
+    """utils/tools.py:132-141 by its definition (U^2 set intersections) against the sparse product of utils/tools.cunet."""
+    from cleverrec_amd.utils.tools import cunet
+    data = _cune_toy()
+    nbr_weight, draw_list = cunet(data)
+    exp_w, exp_l = {}, {}
+    for u1 in data.ui_train:
+        for u2 in data.ui_train:
+            w = len(set(data.ui_train[u1]) & set(data.ui_train[u2])) if u1 != u2 else 0
+            if w > 0:
+                exp_w.setdefault(u1, {})[u2] = w
+                exp_l.setdefault(u1, []).extend([u2] * w)
+    assert list(nbr_weight) == list(exp_w) and max(data.ui_train) not in nbr_weight
+    for u in exp_w:
+        assert list(nbr_weight[u].items()) == list(exp_w[u].items())  # same neighbours, weights AND order
+        assert draw_list[u].tolist() == exp_l[u]
+
+
+def test_deep_walks_follow_the_network_and_the_numpy_stream():
+    from cleverrec_amd.utils.tools import cunet, deep_walks
+    data = _cune_toy()
+    nbr_weight, draw_list = cunet(data)
+    np.random.seed(5)
+    walks = deep_walks(nbr_weight, draw_list, walk_count=4, walk_length=7)
+    after = np.random.randint(1 << 30)
+    np.random.seed(5)
+    again = deep_walks(nbr_weight, draw_list, 4, 7)
+    assert walks == again and np.random.randint(1 << 30) == after  # a function of the np.random state, which it advances
+    assert len(walks) == 4 * len(draw_list) and all(len(w) == 7 for w in walks)
+    starts = sorted(int(w[0]) for w in walks)
+    assert starts == sorted(list(draw_list) * 4)
+    for w in walks:
+        for a, b in zip(w, w[1:]):
+            assert int(b) in nbr_weight[int(a)]
+    # the first step of a user's first walk: its heaviest neighbour, the first of equals in set order
+    first = {}
+    np.random.seed(5)
+    for w in deep_walks(nbr_weight, draw_list, 1, 2)[:]:
+        first[int(w[0])] = int(w[1])
+    u0 = next(iter(draw_list))
+    assert nbr_weight[u0][first[u0]] == max(nbr_weight[u0].values())
+
+
+def test_topk_friends_and_spu():
+    """get_topK_friends_and_SPu (utils/tools.py:130-207) end to end on a toy set: friends by cosine similarity of the walk
+    vectors (checked against the vectors the function saw), SPu by the set arithmetic of get_SPu."""
+    from cleverrec_amd.utils import tools as T
+    data = _cune_toy()
+    seen = {}
+    orig = T.walk_embeddings
+
+    def spy(walks, size, window, **kw):
+        seen["vec"] = orig(walks, size, window, **kw)
+        return seen["vec"]
+    T.walk_embeddings = spy
+    try:
+        np.random.seed(2)
+        friends, SPu = T.get_topK_friends_and_SPu(data, 5, 8, 12, 3, 3)
+    finally:
+        T.walk_embeddings = orig
+    vec = seen["vec"]
+    assert all(v.shape == (12,) and np.isfinite(v).all() for v in vec.values())
+    users = list(friends)
+    for u in users[:10]:
+        sims = {v: float(vec[str(u)] @ vec[str(v)] / (np.linalg.norm(vec[str(u)]) * np.linalg.norm(vec[str(v)]))) for v in users if v != u}
+        best = sorted(sims.values(), reverse=True)[:3]
+        assert len(friends[u]) == 3 and u not in friends[u]
+        np.testing.assert_allclose([sims[f] for f in friends[u]], best, rtol=1e-5)
+    assert SPu == T.get_SPu(data, friends)
+    # users that walk together end up closer than users that never meet: the vectors carry the network
+    nbr_weight, _ = T.cunet(data)
+    close, far = [], []
+    for u in users:
+        for v in users:
+            if u < v:
+                c = float(vec[str(u)] @ vec[str(v)] / (np.linalg.norm(vec[str(u)]) * np.linalg.norm(vec[str(v)])))
+                (close if v in nbr_weight[u] and nbr_weight[u][v] >= 2 else far).append(c)
+    assert np.mean(close) > np.mean(far)
