@@ -38,7 +38,7 @@ def main():
     sess = runtime.Session(0)
     g = np.random.Generator(np.random.PCG64(a.seed))
     rnd = lambda *s, scale=0.1: (g.standard_normal(s) * scale).astype(np.float32)
-    t_end, n, fails = time.time() + 60 * a.minutes, {"ncf": 0, "fm": 0, "cml": 0, "lrml": 0, "transcf": 0}, 0
+    t_end, n, fails = time.time() + 60 * a.minutes, {"ncf": 0, "fm": 0, "cml": 0, "sbpr": 0, "lrml": 0, "transcf": 0}, 0
     t_say = time.time() + 60
     while time.time() < t_end:
         if time.time() > t_say:  # a line a minute: a silent run is taken for a hung one
@@ -131,13 +131,41 @@ def main():
             om = MT.CML(P, Q, lr=1e-3, reg=10.0, margin=1.0, item_nums=I)
             loss = st.train_epoch(sess.to_dev(uc), sess.to_dev(ic), sess.to_dev(neg), Bc).cpu().numpy()
             ol = [om.step(uc[b * Bc:(b + 1) * Bc], ic[b * Bc:(b + 1) * Bc], neg[b * Bc:(b + 1) * Bc]) for b in range(len(loss))]
-            np.testing.assert_allclose(loss, ol, rtol=5e-5, atol=1e-5)
+            rel = np.abs(loss - np.asarray(ol)) / np.abs(ol)
+            assert np.all(np.abs(loss - np.asarray(ol)) <= 5e-5 * np.abs(ol) + 1e-5), \
+                "loss of batch %d (of %d) off by %.3g relative: %.9g against %.9g" % (int(rel.argmax()), len(ol), rel.max(), loss[rel.argmax()], ol[int(rel.argmax())])
             close(st.P, om.numpy("P"), "P")
             close(st.Q, om.numpy("Q"), "Q")
         except AssertionError as e:
             fails += 1
             print("CML FAIL U=%d I=%d d=%d K=%d B=%d N=%d: %s" % (U, I, dc, K, Bc, Nc, str(e).strip().split("\n")[0]))
         n["cml"] += 1
+        # ---- SBPR / CUNE_BPR (f4): random widths, ragged batches, heavy item rows (3 slots per instance), every optimizer ------
+        ds_ = int(g.choice([4, 12, 16, 32, 64, 128, 256]))
+        Bs = int(g.choice([1, 63, 64, 200, 700, 2048]))
+        Ns = int(min(2 * Bs + g.integers(0, Bs + 1), 4100))
+        us, is_, ks, js = (g.integers(0, m_, Ns).astype(np.int32) for m_ in (U, I, I, I))
+        suk = g.integers(1, 5, Ns).astype(np.float32)
+        cune, opt_s = bool(g.integers(0, 2)), str(g.choice(["Adam", "Adam", "SGD", "Adagrad"]))
+        P, Q, bias, s0 = rnd(U, ds_), rnd(I, ds_), rnd(I + 1, scale=0.05), float(g.uniform(-0.3, 1.0))
+        try:
+            if cune:
+                st = runtime.CuneState(sess, P, Q, bias, s0, lr=1e-3, reg=0.05, optimizer=opt_s)
+                om = MT.CUNE_BPR(P, Q, bias, s0, lr=1e-3, reg=0.05, optimizer=opt_s)
+                cols = (us, is_, ks, js)
+            else:
+                st = runtime.SbprState(sess, P, Q, bias, lr=1e-3, reg=0.05, optimizer=opt_s)
+                om = MT.SBPR(P, Q, bias, lr=1e-3, reg=0.05, optimizer=opt_s)
+                cols = (us, is_, ks, js, suk)
+            loss = st.train_epoch(*(sess.to_dev(x) for x in cols), Bs).cpu().numpy()
+            ol = [om.step(*(x[b * Bs:(b + 1) * Bs] for x in cols)) for b in range(len(loss))]
+            np.testing.assert_allclose(loss, ol, rtol=2e-5, atol=1e-6)
+            for name, dev in (("P", st.P), ("Q", st.Q), ("bias", st.bias)) + ((("s", st.s),) if cune else ()):
+                close(dev, om.numpy(name), name)
+        except AssertionError as e:
+            fails += 1
+            print("%s FAIL %s U=%d I=%d d=%d B=%d N=%d: %s" % ("CUNE" if cune else "SBPR", opt_s, U, I, ds_, Bs, Ns, str(e).strip().split("\n")[0]))
+        n["sbpr"] += 1
         # ---- LRML (f4) ----------------------------------------------------------------------------------------------------
         dl, mem = int(g.choice([4, 16, 20, 32, 128])), int(g.choice([1, 7, 16, 50, 64]))
         Bl = int(g.choice([1, 15, 16, 17, 300, 1100]))
