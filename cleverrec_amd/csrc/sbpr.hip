@@ -122,24 +122,31 @@ __global__ __launch_bounds__(256) void sbpr_reduce_loss(const float *__restrict_
         loss_per_batch[blockIdx.x] = (float)part[0];
 }
 
-// CUNE_BPR's `s`: the batch's ds column summed in a fixed order (float64 tree), then the dense update of one element
-__global__ __launch_bounds__(256) void cune_scalar_step(const float *__restrict__ ds_inst, int nb, float *__restrict__ var,
-                                                        float *__restrict__ m, float *__restrict__ v, crec_rows_opt o)
+// CUNE_BPR's `s`: the batch's ds column summed in a fixed order (float64: per thread, per wave by shuffles, then the 16
+// wave sums in order), then the dense update of one element.  One workgroup of 1024; a thread's <= 8 loads are in flight together.
+__global__ __launch_bounds__(1024) void cune_scalar_step(const float *__restrict__ ds_inst, int nb, float *__restrict__ var,
+                                                         float *__restrict__ m, float *__restrict__ v, crec_rows_opt o)
 {
-    __shared__ double part[256];
-    double s = 0.0;
-    for (int r = threadIdx.x; r < nb; r += 256)
-        s += (double)ds_inst[r];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off)
-            part[threadIdx.x] += part[threadIdx.x + off];
-        __syncthreads();
+    __shared__ double part[16];
+    float x[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { // B <= 8192
+        const int r = (int)threadIdx.x + q * 1024;
+        x[q] = r < nb ? ds_inst[r] : 0.f;
     }
+    double s = (((double)x[0] + (double)x[1]) + ((double)x[2] + (double)x[3])) + (((double)x[4] + (double)x[5]) + ((double)x[6] + (double)x[7]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        s += __shfl_xor(s, off, 64);
+    if ((threadIdx.x & 63) == 0)
+        part[threadIdx.x >> 6] = s;
+    __syncthreads();
     if (threadIdx.x != 0)
         return;
-    const float g = (float)part[0];
+    s = 0.0;
+    for (int w = 0; w < 16; ++w)
+        s += part[w];
+    const float g = (float)s;
     if (o.opt == CREC_OPT_SGD) { // GradientDescentOptimizer
         var[0] -= o.lr_t * g;
     } else if (o.opt == CREC_OPT_ADAGRAD) { // accumulator in m (0.1 at start)
@@ -274,7 +281,7 @@ static int sbpr_epoch(crec_ctx *ctx, const crec_sbpr *m, const crec_param *s_par
         if (int rc = crec_apply_all(ctx, set, st))
             return rc;
         if (cune) // s is read by the batch's instances only: its update can follow the tables'
-            hipLaunchKernelGGL(cune_scalar_step, dim3(1), dim3(256), 0, st, (const float *)ds_inst, nbt, (float *)s_par->var,
+            hipLaunchKernelGGL(cune_scalar_step, dim3(1), dim3(1024), 0, st, (const float *)ds_inst, nbt, (float *)s_par->var,
                                (float *)s_par->m, (float *)s_par->v, ob);
         opt->beta1_power = opt->beta1_power * opt->beta1;
         opt->beta2_power = opt->beta2_power * opt->beta2;

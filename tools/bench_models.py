@@ -114,6 +114,15 @@ def main():
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / 3 * 1e3
     out["TransCF_scores"] = {"users_per_s": 1024 / ms * 1e3, "ms_per_1024_users": ms}
+
+    # ---- SBPR / CUNE_BPR (f4): the shipped confs -- d = 128, B = 6144; social / latent-friend items drawn like positives
+    n = 100 * B
+    us, is_, ks, js = (sess.to_dev(g.integers(0, m, n).astype(np.int32)) for m in (U, I, I, I))
+    suk = sess.to_dev(g.integers(1, 4, n).astype(np.float32))
+    sb = runtime.SbprState(sess, rnd(U, 128), rnd(I, 128), np.zeros(I + 1, np.float32), lr=1e-3, reg=0.05)
+    out["SBPR"] = dict(timed(lambda: sb.train_epoch(us, is_, ks, js, suk, B), n), unit="quadruples")
+    cu = runtime.CuneState(sess, rnd(U, 128), rnd(I, 128), np.zeros(I + 1, np.float32), 0.0, lr=1e-3, reg=0.01)
+    out["CUNE_BPR"] = dict(timed(lambda: cu.train_epoch(us, is_, ks, js, B), n), unit="quadruples")
     print(json.dumps(out))
 
 
