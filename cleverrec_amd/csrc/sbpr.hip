@@ -10,8 +10,9 @@
 //
 // Per batch, three launches on the machinery of rows_adam.hip (like CML / FM): sbpr_instances (a lane group per
 // instance: four row gathers, three dots, the two sigmoids, contribution rows for p_u and the three item rows,
-// contribution scalars for the three biases, the item slot ids) -> rows_index_batches over the batch's 3B item slots
-// -> crec_apply_all (P, Q, and bias as a one-column table).  Deterministic, no atomics.
+// contribution scalars for the three biases) -> crec_apply_all (P, Q, and bias as a one-column table).  The item slots
+// [i | k | j] of a batch are inputs, so their index is not built per step: sbpr_slots lays out the slots of up to 64 batches
+// and ONE rows_index_batches launch sorts them all (the user side's index covers the whole call).  Deterministic, no atomics.
 //
 // CUNE_BPR (model/ranking/CUNE_BPR.py:44-61) is the same step with other arguments of the two log-sigmoids --
 //   loss = sum -log sigmoid(x_ui - x_uk) + sum -log sigmoid((x_uk - x_uj) / (s + 1.0)) + the same l2 terms
@@ -53,8 +54,8 @@ __global__ __launch_bounds__(256) void sbpr_instances(const float *__restrict__ 
                                                       const int32_t *__restrict__ i, const int32_t *__restrict__ k,
                                                       const int32_t *__restrict__ j, const float *__restrict__ suk, int nb,
                                                       int B, float reg, float *__restrict__ c_p, float *__restrict__ c_q,
-                                                      float *__restrict__ c_b, int32_t *__restrict__ slots,
-                                                      float *__restrict__ loss_inst, const float *__restrict__ s_var,
+                                                      float *__restrict__ c_b, float *__restrict__ loss_inst,
+                                                      const float *__restrict__ s_var,
                                                       float *__restrict__ ds_inst)
 {
     constexpr int G = 64 / LPR;
@@ -84,9 +85,6 @@ __global__ __launch_bounds__(256) void sbpr_instances(const float *__restrict__ 
             ds_inst[r] = (s2 * b) / den; // dL/db = -s2;  d b / d den = -b / den (RealDiv's gradient: grad * (-x / y) / y)
         loss_inst[r] = (tf_softplus(-a) + tf_softplus(-b)) +
                        reg * (((0.5f * np + 0.5f * ni) + (0.5f * nk + 0.5f * nj)) + ((0.5f * (bi * bi) + 0.5f * (bk * bk)) + 0.5f * (bj * bj)));
-        slots[r] = ri;
-        slots[B + r] = rk;
-        slots[2 * B + r] = rj;
         c_b[r] = gi + reg * bi; // the bias is a gathered variable too: its l2 term counts once per occurrence
         c_b[B + r] = gk + reg * bk;
         c_b[2 * B + r] = gj + reg * bj;
@@ -99,6 +97,22 @@ __global__ __launch_bounds__(256) void sbpr_instances(const float *__restrict__ 
     st4(c_q + (int64_t)r * d + 4 * l, make_float4(gi * p.x, gi * p.y, gi * p.z, gi * p.w));
     st4(c_q + (int64_t)(B + r) * d + 4 * l, make_float4(gk * p.x, gk * p.y, gk * p.z, gk * p.w));
     st4(c_q + (int64_t)(2 * B + r) * d + 4 * l, make_float4(gj * p.x, gj * p.y, gj * p.z, gj * p.w));
+}
+
+// the item slots of a group of batches, batch after batch: [i | k | j] with stride nbt (the batch's own length: a ragged last
+// batch has no holes, and a batch's slot s is the row of c_q / c_b its instance kernel writes)
+__global__ __launch_bounds__(256) void sbpr_slots(const int32_t *__restrict__ i, const int32_t *__restrict__ k,
+                                                  const int32_t *__restrict__ j, int64_t n, int32_t B, int32_t *__restrict__ slots)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n)
+        return;
+    const int64_t b = t / B, t0 = b * B;
+    const int64_t nbt = (n - t0) < B ? (n - t0) : B;
+    int32_t *dst = slots + 3 * t0 + (t - t0);
+    dst[0] = i[t];
+    dst[nbt] = k[t];
+    dst[2 * nbt] = j[t];
 }
 
 // one block per batch: the batch's instance losses in a fixed order, float64
@@ -211,9 +225,10 @@ static int sbpr_epoch(crec_ctx *ctx, const crec_sbpr *m, const crec_param *s_par
     const int G = 64 / lpr;
     auto up = [](size_t x) { return (x + 255) / 256 * 256; };
     const int q_chunks = (int)crec_ceil_div(3 * (int64_t)B, 2048); // item slots: sorted 2048 at a time
-    const size_t ixu = crec_rows_index_bytes(nb, B, U), ixq = crec_rows_index_bytes(1, 3 * B, I, q_chunks);
+    const int64_t GB = nb < 64 ? nb : 64; // batches per item-side index launch
+    const size_t ixu = crec_rows_index_bytes(nb, B, U), ixq = crec_rows_index_bytes(GB, 3 * B, I, q_chunks);
     const size_t cpb = sizeof(float) * (size_t)B * d, cqb = sizeof(float) * (size_t)3 * B * d, cbb = sizeof(float) * (size_t)3 * B;
-    const size_t sl = sizeof(int32_t) * (size_t)3 * B, li = sizeof(float) * (size_t)N, dsb = sizeof(float) * (size_t)B;
+    const size_t sl = sizeof(int32_t) * (size_t)3 * B * GB, li = sizeof(float) * (size_t)N, dsb = sizeof(float) * (size_t)B;
     if (int rc = crec_reserve(ctx, &ctx->idx_ws, up(ixu) + up(ixq) + up(cpb) + up(cqb) + up(cbb) + up(sl) + up(li) + up(dsb)))
         return rc;
     char *ws = (char *)ctx->idx_ws.ptr;
@@ -235,8 +250,14 @@ static int sbpr_epoch(crec_ctx *ctx, const crec_sbpr *m, const crec_param *s_par
     p += up(li);
     float *ds_inst = (float *)p;
     for (int64_t b = 0; b < nb; ++b) {
-        const int64_t t0 = b * B;
+        const int64_t t0 = b * B, bg = b % GB;
         const int nbt = (int)((N - t0) < B ? (N - t0) : B);
+        if (bg == 0) { // the item-side index of the next GB batches
+            const int64_t ng = (N - t0) < GB * B ? (N - t0) : GB * B;
+            hipLaunchKernelGGL(sbpr_slots, dim3((unsigned)crec_ceil_div(ng, 256)), dim3(256), 0, st, i + t0, k + t0, j + t0, ng, B, slots);
+            if (int rc = crec_rows_index(ctx, slots, 3 * ng, 3 * B, I, ixq_ws, &vq, st, q_chunks))
+                return rc;
+        }
         crec_rows_opt o{};
         o.kind = ROWS_SPARSE_TF1;
         o.reg_occ = m->reg;
@@ -246,7 +267,7 @@ static int sbpr_epoch(crec_ctx *ctx, const crec_sbpr *m, const crec_param *s_par
 #define CREC_SBPR_LAUNCH(L, C)                                                                                              \
     hipLaunchKernelGGL((sbpr_instances<L, C>), grid, dim3(256), 0, st, (const float *)m->P.var, (const float *)m->Q.var,    \
                        (const float *)m->bias.var, d, u + t0, i + t0, k + t0, j + t0, C ? nullptr : suk + t0, nbt, nbt,     \
-                       m->reg, c_p, c_q, c_b, slots, loss_inst + t0, C ? (const float *)s_par->var : nullptr, ds_inst)
+                       m->reg, c_p, c_q, c_b, loss_inst + t0, C ? (const float *)s_par->var : nullptr, ds_inst)
 #define CREC_SBPR(L)                                                                                                        \
     case L:                                                                                                                 \
         if (cune)                                                                                                           \
@@ -265,19 +286,18 @@ static int sbpr_epoch(crec_ctx *ctx, const crec_sbpr *m, const crec_param *s_par
         }
 #undef CREC_SBPR
 #undef CREC_SBPR_LAUNCH
-        // the batch's item slots are laid out [i | k | j] with stride nbt (not B), so a ragged batch has no holes
-        if (int rc = crec_rows_index(ctx, slots, 3 * (int64_t)nbt, 3 * B, I, ixq_ws, &vq, st, q_chunks))
-            return rc;
+        const int2 *q_rowseg = vq.rowseg + bg * vq.chunks * vq.rows;
+        const int32_t *q_order = vq.order + bg * vq.per_batch;
         crec_apply_set set{};
         set.tables[set.n_tables++] = crec_rows_job{crec_rows_table{m->P.var, m->P.m, m->P.v, U, d}, vu.chunks,
                                                    vu.rowseg + b * vu.chunks * vu.rows, vu.order + b * vu.per_batch, c_p, nullptr, nullptr, o};
-        set.tables[set.n_tables++] = crec_rows_job{crec_rows_table{m->Q.var, m->Q.m, m->Q.v, I, d}, vq.chunks, vq.rowseg, vq.order, c_q,
+        set.tables[set.n_tables++] = crec_rows_job{crec_rows_table{m->Q.var, m->Q.m, m->Q.v, I, d}, vq.chunks, q_rowseg, q_order, c_q,
                                                    nullptr, nullptr, o};
         crec_rows_opt ob = o; // the bias: its l2 term is inside the contribution scalars; g = 0 rows still decay and move
         ob.kind = ROWS_DENSE;
         ob.reg_occ = 0.f;
         ob.dense_reg = 0.f;
-        set.scalar = crec_scalar_job{m->bias.var, m->bias.m, m->bias.v, I, vq.rowseg, vq.order, c_b, nullptr, ob, vq.chunks};
+        set.scalar = crec_scalar_job{m->bias.var, m->bias.m, m->bias.v, I, q_rowseg, q_order, c_b, nullptr, ob, vq.chunks};
         if (int rc = crec_apply_all(ctx, set, st))
             return rc;
         if (cune) // s is read by the batch's instances only: its update can follow the tables'

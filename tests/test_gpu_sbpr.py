@@ -38,6 +38,25 @@ def test_sbpr_steps_match_oracle(sess, d, B):
         assert_adam_close(om, name, dev, *st.slots[name])
 
 
+def test_sbpr_more_batches_than_one_item_index_launch_covers(sess):
+    """The item-side index is built for 64 batches at a time (sbpr_slots + one rows_index_batches): 68 batches, the last ragged."""
+    g = np.random.Generator(np.random.PCG64(68))
+    U, I, d, B = 30, 25, 16, 8
+    N = 67 * B + 3
+    P, Q = (g.standard_normal((U, d)) * 0.1).astype(np.float32), (g.standard_normal((I, d)) * 0.1).astype(np.float32)
+    bias = (g.standard_normal(I + 1) * 0.05).astype(np.float32)
+    u, i, k, j = (g.integers(0, n, N).astype(np.int32) for n in (U, I, I, I))
+    suk = g.integers(1, 4, N).astype(np.float32)
+    st = runtime.SbprState(sess, P, Q, bias, lr=1e-3, reg=0.05, optimizer="SGD")  # SGD: 68 steps stay comparable element by element
+    om = MT.SBPR(P, Q, bias, lr=1e-3, reg=0.05, optimizer="SGD")
+    loss = st.train_epoch(*(sess.to_dev(x) for x in (u, i, k, j, suk)), B).cpu().numpy()
+    assert len(loss) == 68
+    ol = [om.step(*(x[b * B:(b + 1) * B] for x in (u, i, k, j, suk))) for b in range(len(loss))]
+    np.testing.assert_allclose(loss, ol, rtol=1e-5)
+    for name, dev in (("P", st.P), ("Q", st.Q), ("bias", st.bias)):
+        assert_adam_close(om, name, dev, *st.slots[name])
+
+
 def test_sbpr_class_surface(sess, tmp_path):
     """SBPR(sess, data, configs, logger): get_SPu, train_model_sbpr on the np.random stream, rs evaluation (u_embed @ Q^T)."""
     from cleverrec_amd.model.ranking.SBPR import SBPR
