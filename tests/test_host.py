@@ -407,3 +407,34 @@ def test_topk_friends_and_spu():
                 c = float(vec[str(u)] @ vec[str(v)] / (np.linalg.norm(vec[str(u)]) * np.linalg.norm(vec[str(v)])))
                 (close if v in nbr_weight[u] and nbr_weight[u][v] >= 2 else far).append(c)
     assert np.mean(close) > np.mean(far)
+
+
+def test_cune_walks_friends_and_spu_match_the_reference_run(golden_dir):
+    """tests/golden/cune.npz: the reference's own get_topK_friends_and_SPu (utils/tools.py:130-207) run by tools/make_golden.py
+    with a recorder in gensim's place: the deep walks (np.random stream, set-iteration tie-breaks, shuffle) bit for bit, the
+    stream position afterwards, and -- given the same stand-in vectors -- the top-K friends in order and the SPu lists in order."""
+    from cleverrec_amd.data import RankingData
+    from cleverrec_amd.utils import tools as T
+    z = np.load(os.path.join(golden_dir, "cune.npz"))
+    ui_train = {int(k): [int(x) for x in z["items"][z["ptr"][n]:z["ptr"][n + 1]]] for n, k in enumerate(z["keys"])}
+    data = RankingData(int(z["user_nums"]), int(z["item_nums"]), ui_train, {})
+    wc, wl, dim, win, topk = (int(x) for x in z["params"])
+    assert list(z["w2v_args"]) == [dim, win, 0, 3]  # size, window, min_count, iter as the reference passes them (:173)
+    got = {}
+
+    def vectors(walks, size, window, **kw):  # tools/make_golden.py: cune_vectors
+        got["walks"] = walks
+        return {t: np.random.Generator(np.random.PCG64([77, int(t)])).standard_normal(size).astype(np.float32) for w in walks for t in w}
+    orig, T.walk_embeddings = T.walk_embeddings, vectors
+    try:
+        np.random.seed(int(z["seed"]))
+        friends, SPu = T.get_topK_friends_and_SPu(data, wc, wl, dim, win, topk)
+        nxt = np.random.randint(2 ** 30)
+    finally:
+        T.walk_embeddings = orig
+    assert np.array_equal(np.array([[int(t) for t in w] for w in got["walks"]]), z["walks"])
+    assert nxt == int(z["next"])
+    ref_friends = {int(k): [int(x) for x in z["f_items"][z["f_ptr"][n]:z["f_ptr"][n + 1]]] for n, k in enumerate(z["f_keys"])}
+    ref_spu = {int(k): [int(x) for x in z["spu_items"][z["spu_ptr"][n]:z["spu_ptr"][n + 1]]] for n, k in enumerate(z["spu_keys"])}
+    assert list(friends) == list(ref_friends) and all(list(friends[u]) == ref_friends[u] for u in friends)
+    assert list(SPu) == list(ref_spu) and all(list(SPu[u]) == ref_spu[u] for u in SPu)

@@ -133,6 +133,47 @@ def sp_mat_case(seed=9, n_users=70, n_items=50):
                 iu_values=np.array(iu_val, dtype=np.float64), iu_shape=np.array(iu_shape))
 
 
+def cune_vectors(tokens, dim, seed=77):
+    """Deterministic stand-in for the word vectors (a function of the token alone, independent of np.random): what the
+    recorder below hands the reference, and what tests/test_host.py hands the repo's own top-K code."""
+    out = {}
+    for t in tokens:
+        g = np.random.Generator(np.random.PCG64([seed, int(t)]))
+        out[t] = g.standard_normal(dim).astype(np.float32)
+    return out
+
+
+def cune_case(seed=13, n_users=45, n_items=35, walk_count=3, walk_length=8, walk_dim=6, window=3, topk_f=4):
+    """get_topK_friends_and_SPu (utils/tools.py:130-207, CUNE_BPR) run by the reference itself: the user network, the deep
+    walks on the np.random stream, the cosine top-K friends and SPu are the reference's own loops.  gensim is absent; the
+    inert gensim.models.word2vec module gets a Word2Vec attribute that RECORDS the walks it is given and answers `.wv[token]`
+    with cune_vectors (so the walks are pinned exactly, and friends / SPu are pinned given those vectors)."""
+    import utils.tools as tools
+    seen = {}
+
+    class Recorder:
+        def __init__(self, walks, size=None, window=None, min_count=None, iter=None):
+            seen["walks"], seen["args"] = [list(w) for w in walks], (size, window, min_count, iter)
+            self.wv = cune_vectors(sorted({t for w in walks for t in w}, key=int), size)
+    tools.word2vec.Word2Vec = Recorder
+    try:
+        ui = synth_ui(seed, n_users, n_items, 1, 6, skip_every=8)
+        d = Data()
+        d.ui_train, d.item_nums, d.user_nums = ui, n_items, n_users
+        np.random.seed(seed)
+        friends, SPu = tools.get_topK_friends_and_SPu(d, walk_count, walk_length, walk_dim, window, topk_f)
+        nxt = np.random.randint(2 ** 30)
+    finally:
+        del tools.word2vec.Word2Vec
+    keys, ptr, items = csr(ui)
+    fk, fp, fi = csr({u: [int(x) for x in f] for u, f in friends.items()})
+    sk, sp, si = csr(SPu)
+    return dict(keys=keys, ptr=ptr, items=items, item_nums=n_items, user_nums=n_users, seed=seed,
+                params=np.array([walk_count, walk_length, walk_dim, window, topk_f]), w2v_args=np.array(seen["args"]),
+                walks=np.array([[int(t) for t in w] for w in seen["walks"]], dtype=np.int64), f_keys=fk, f_ptr=fp, f_items=fi,
+                spu_keys=sk, spu_ptr=sp, spu_items=si, next=nxt)
+
+
 def metrics_cases(metrics, n=400):
     g = np.random.Generator(np.random.PCG64(7))
     cases = [([5], [1, 5, 3], 3), ([5, 8, 9], [9, 2, 5, 7, 1, 0, 3, 4, 6, 10], 10), ([1, 2], [7, 8], 2),
@@ -318,6 +359,7 @@ def main():
     with open(os.path.join(a.out, "metrics.json"), "w") as f:
         json.dump(metrics_cases(metrics), f)
     np.savez_compressed(os.path.join(a.out, "sp_mat.npz"), **sp_mat_case())
+    np.savez_compressed(os.path.join(a.out, "cune.npz"), **cune_case())
     np.savez_compressed(os.path.join(a.out, "preprocess_syn.npz"), **preprocess_case(a.ref))
     np.savez_compressed(os.path.join(a.out, "preprocess_social.npz"), **preprocess_case(a.ref, social=True))
     np.savez_compressed(os.path.join(a.out, "rating_syn.npz"), **rating_case(a.ref))
