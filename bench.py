@@ -181,8 +181,15 @@ def main():
     if not a.no_extras:
         # ---- roofline: per-kernel durations from the HIP events attached to each dispatch.  The data-parallel
         # epoch is collective, so at N > 1 EVERY rank runs these steps; rank 0 reports its own kernels.
+        # The pass is the timed region's workload again, long enough for a stable mean whatever --steps was (a 20-step
+        # pass is ONE call: 19 launches right after the event pool is first filled read 9 us where thousands read 6.3);
+        # a first pass fills the pool and is discarded.
+        k_prof = max(a.steps, 4 * (n_epoch // B))
         sess.ctx.profile(True)
-        run_steps(min(a.steps, n_epoch // B))
+        run_steps(min(k_prof, n_epoch // B))
+        fence()
+        sess.ctx.profile(True)  # resets the sums, keeps the events
+        run_steps(k_prof)
         fence()
         prof = sess.ctx.profile_read()
         sess.ctx.profile(False)
