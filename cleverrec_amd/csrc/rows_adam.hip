@@ -119,6 +119,7 @@ __device__ __forceinline__ bool untouched_stays(const crec_rows_opt &o)
 
 // one wave per table row; group g of the wave takes slots g, g+G, ... of the row (fixed order),
 // the G partial sums are added in group order
+constexpr int SEGS = 2; // row segments (one per chunk of the index) in flight together
 template <int LPR>
 __device__ __forceinline__ void rows_apply_row(const crec_rows_table &t, const int2 *__restrict__ rowseg,
                                                const int32_t *__restrict__ order, const float *__restrict__ contrib,
@@ -146,20 +147,29 @@ __device__ __forceinline__ void rows_apply_row(const crec_rows_table &t, const i
     }
     float4 acc = zero;
     int touched = 0;
-    for (int ch = 0; ch < chunks; ++ch) { // chunk by chunk = ascending slot order
-        int2 rs = rs0; // (a ?: of the two int2 objects selects between addresses and sends rs0 to scratch)
-        if (ch != 0)
-            rs = rowseg[(int64_t)ch * t.rows + r];
+    const auto walk = [&](int2 rs) __attribute__((always_inline)) {
         touched += rs.y;
         for (int k = rs.x + g; k < rs.x + rs.y; k += G) {
             if (act) {
-                const float4 c = ld4(contrib + (int64_t)order[k] * d + 4 * l);
-                acc.x = acc.x + (c.x + o.reg_occ * var.x);
-                acc.y = acc.y + (c.y + o.reg_occ * var.y);
-                acc.z = acc.z + (c.z + o.reg_occ * var.z);
-                acc.w = acc.w + (c.w + o.reg_occ * var.w);
+                const float4 cc = ld4(contrib + (int64_t)order[k] * d + 4 * l);
+                acc.x = acc.x + (cc.x + o.reg_occ * var.x);
+                acc.y = acc.y + (cc.y + o.reg_occ * var.y);
+                acc.z = acc.z + (cc.z + o.reg_occ * var.z);
+                acc.w = acc.w + (cc.w + o.reg_occ * var.w);
             }
         }
+    };
+    walk(rs0);
+    // the other chunks, in ascending slot order; the segments of SEGS chunks are asked for together (one round trip, not one
+    // per chunk: a row with its slots in nine chunks waited nine times before its last contribution)
+    for (int c0 = 1; c0 < chunks; c0 += SEGS) {
+        int2 rsv[SEGS];
+#pragma unroll
+        for (int c = 0; c < SEGS; ++c)
+            rsv[c] = c0 + c < chunks ? rowseg[(int64_t)(c0 + c) * t.rows + r] : make_int2(0, 0);
+#pragma unroll
+        for (int c = 0; c < SEGS; ++c)
+            walk(rsv[c]);
     }
     if (touched == 0 && untouched_stays(o))
         return;
@@ -453,10 +463,28 @@ __device__ __forceinline__ void scalar_rows_block(const crec_scalar_job &j, int 
     if (r >= j.rows)
         return;
     float g = 0.f;
-    for (int ch = 0; ch < (j.chunks > 1 ? j.chunks : 1); ++ch) { // chunk by chunk = ascending slot order
-        const int2 rs = j.rowseg[(int64_t)ch * j.rows + r];
-        for (int k = rs.x; k < rs.x + rs.y; ++k)
-            g = g + j.contrib[j.order[k]];
+    const int chunks = j.chunks > 1 ? j.chunks : 1;
+    for (int c0 = 0; c0 < chunks; c0 += SEGS) { // chunk by chunk = ascending slot order; SEGS segments asked for together
+        int2 rsv[SEGS];
+#pragma unroll
+        for (int c = 0; c < SEGS; ++c)
+            rsv[c] = c0 + c < chunks ? j.rowseg[(int64_t)(c0 + c) * j.rows + r] : make_int2(0, 0);
+#pragma unroll
+        for (int c = 0; c < SEGS; ++c)
+            for (int k = rsv[c].x; k < rsv[c].x + rsv[c].y; k += 4) { // four slots' ids, then their four terms, in flight
+                int id[4];
+                float x[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    id[e] = k + e < rsv[c].x + rsv[c].y ? j.order[k + e] : -1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    x[e] = id[e] >= 0 ? j.contrib[id[e]] : 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (id[e] >= 0)
+                        g = g + x[e];
+            }
     }
     const float w = j.var[r];
     if (j.sq_out)

@@ -224,7 +224,9 @@ static int sbpr_epoch(crec_ctx *ctx, const crec_sbpr *m, const crec_param *s_par
         lpr <<= 1;
     const int G = 64 / lpr;
     auto up = [](size_t x) { return (x + 255) / 256 * 256; };
-    const int q_chunks = (int)crec_ceil_div(3 * (int64_t)B, 2048); // item slots: sorted 2048 at a time
+    // item slots: the index is built ahead for many batches at once, so what counts is the walk of the update launch (a row's
+    // slots chunk by chunk), not the latency of one sort: as few chunks as a workgroup's 16 384 slots allow
+    const int q_chunks = (int)crec_ceil_div(3 * (int64_t)B, 16384);
     const int64_t GB = nb < 64 ? nb : 64; // batches per item-side index launch
     const size_t ixu = crec_rows_index_bytes(nb, B, U), ixq = crec_rows_index_bytes(GB, 3 * B, I, q_chunks);
     const size_t cpb = sizeof(float) * (size_t)B * d, cqb = sizeof(float) * (size_t)3 * B * d, cbb = sizeof(float) * (size_t)3 * B;
