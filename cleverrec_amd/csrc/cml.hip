@@ -294,7 +294,10 @@ int crec_cml_train_epoch(crec_ctx *ctx, const crec_cml *m, crec_adam *opt, const
     const int G = 64 / lpr;
     auto up = [](size_t x) { return (x + 255) / 256 * 256; };
     const int nbP = (int)crec_ceil_div(U, CS_ROWS), nbQ = (int)crec_ceil_div(I, CS_ROWS);
-    const int q_chunks = (int)crec_ceil_div(2 * (int64_t)B, 2048); // item slots: sorted 2048 at a time
+#ifndef CML_CHUNK_SLOTS
+#define CML_CHUNK_SLOTS 2048
+#endif
+    const int q_chunks = (int)crec_ceil_div(2 * (int64_t)B, CML_CHUNK_SLOTS); // item slots: sorted 2048 at a time
     const size_t ixu = crec_rows_index_bytes(nb, B, U), ixq = crec_rows_index_bytes(1, 2 * B, I, q_chunks);
     const size_t cpb = sizeof(float) * (size_t)B * d, cqb = sizeof(float) * (size_t)2 * B * d;
     const size_t sl = sizeof(int32_t) * (size_t)2 * B, li = sizeof(float) * (size_t)B;
