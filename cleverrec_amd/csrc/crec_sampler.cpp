@@ -17,6 +17,7 @@
 
 #include <atomic>
 #include <thread>
+#include <chrono>
 #include <vector>
 
 namespace {
@@ -340,8 +341,11 @@ int crec_sample_pairwise(crec_ctx *ctx, const int64_t *ptr, const int32_t *items
     auto eu = edge_users(c);
     if (!stamp || !neg || !perm || !eu)
         return crec_fail(ctx, CREC_ENOMEM, "host allocation failed");
+    static const bool timing = getenv("CREC_SAMPLER_TIMING") != nullptr; // phase times on stderr (tools/prof_epoch.py)
+    const auto t0 = std::chrono::steady_clock::now();
     if (!draw_negatives(ctx->rng, c, neg_ratio, neg.get(), stamp.get()))
         return crec_fail(ctx, CREC_EINVAL, "a user has fewer than neg_ratio unseen items");
+    const auto t1 = std::chrono::steady_clock::now();
     const int32_t *negp = neg.get(), *eup = eu.get();
     // sampler.py:68 + np.array(x)[s_idx] for the three columns at once
     shuffled_apply(ctx->rng, n, perm.get(), [=](int64_t k, uint32_t sidx) {
@@ -350,6 +354,10 @@ int crec_sample_pairwise(crec_ctx *ctx, const int64_t *ptr, const int32_t *items
         i[k] = items[e];
         j[k] = negp[sidx];
     });
+    if (timing)
+        fprintf(stderr, "crec_sample_pairwise: negatives %.2f ms, shuffle + gather %.2f ms\n",
+                std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
     *n_out = n;
     return CREC_OK;
 }
