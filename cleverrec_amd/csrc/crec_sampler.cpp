@@ -110,17 +110,50 @@ template <typename T> void permutation(crec_mt19937 &r, int64_t n, T *a, std::at
 // shuffle: the legacy shuffle walks k downwards and never touches a position above k again, so perm[k..n) is final
 // as soon as step k is done and can be consumed while the (strictly serial) shuffle is still running.  The RNG
 // stream and the result are exactly those of the serial code.
-template <class Body> void shuffled_apply(crec_mt19937 &r, int64_t n, uint32_t *perm, Body body)
+// n / d for every 32-bit n by one multiplication and two shifts (Granlund-Montgomery, the round-up form): the gather
+// divides every shuffled index by neg_ratio, and a hardware 32-bit division costs 10-30 ns where this costs one.
+struct FastDiv {
+    uint32_t m, s1, s2;
+    explicit FastDiv(uint32_t d)
+    {
+        uint32_t L = 0;
+        while (((uint64_t)1 << L) < d)
+            ++L;
+        m = (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << L) - d)) / d + 1);
+        s1 = L < 1 ? L : 1;
+        s2 = L - s1;
+    }
+    uint32_t div(uint32_t n) const
+    {
+        const uint32_t t = (uint32_t)(((uint64_t)m * n) >> 32);
+        return (t + ((n - t) >> s1)) >> s2;
+    }
+};
+
+// `ahead(sidx)`: prefetches of what body(k, sidx) will read -- the gather's reads are scattered over arrays far larger than
+// the caches, and without them every element waits for its own misses one after the other.
+struct NoAhead {
+    void operator()(uint32_t) const {}
+};
+constexpr int GATHER_AHEAD = 24;
+template <class Body, class Ahead = NoAhead>
+void shuffled_apply(crec_mt19937 &r, int64_t n, uint32_t *perm, Body body, Ahead ahead = Ahead())
 {
     static const int env_threads = getenv("CREC_SAMPLER_THREADS") ? atoi(getenv("CREC_SAMPLER_THREADS")) : -1;
     // one gather worker (+ the swap thread below) keeps up with the RNG thread on the GPU host: 45 -> 34 ms per
     // ml-1m epoch; more workers only add contention
     int workers = env_threads >= 0 ? env_threads : ((int)std::thread::hardware_concurrency() >= 4 ? 1 : 0);
     workers = workers > 8 ? 8 : workers;
+    const auto serial_gather = [&] {
+        for (int64_t k = 0; k < n; ++k) {
+            if (k + GATHER_AHEAD < n)
+                ahead(perm[k + GATHER_AHEAD]);
+            body(k, perm[k]);
+        }
+    };
     if (workers < 1 || n < (1 << 16)) {
         permutation(r, n, perm);
-        for (int64_t k = 0; k < n; ++k)
-            body(k, perm[k]);
+        serial_gather();
         return;
     }
     constexpr int64_t CHUNK = 1 << 14;
@@ -156,8 +189,7 @@ template <class Body> void shuffled_apply(crec_mt19937 &r, int64_t n, uint32_t *
         });
     } catch (...) {
         permutation(r, n, perm);
-        for (int64_t k = 0; k < n; ++k)
-            body(k, perm[k]);
+        serial_gather();
         return;
     }
     const auto gather = [&] { // chunks from the top down, each as soon as the shuffle has passed it
@@ -169,8 +201,10 @@ template <class Body> void shuffled_apply(crec_mt19937 &r, int64_t n, uint32_t *
             while (front.load(std::memory_order_acquire) > lo)
                 std::this_thread::yield();
             for (int64_t k = lo; k < hi; ++k) {
-                if (k + 16 < hi)
-                    __builtin_prefetch(&perm[k + 16], 0, 1);
+                if (k + 2 * GATHER_AHEAD < hi)
+                    __builtin_prefetch(&perm[k + 2 * GATHER_AHEAD], 0, 1);
+                if (k + GATHER_AHEAD < hi)
+                    ahead(perm[k + GATHER_AHEAD]);
                 body(k, perm[k]);
             }
         }
@@ -274,6 +308,17 @@ buf<int32_t> edge_users(const Csr &c)
 
 extern "C" {
 
+// test hook: FastDiv(d).div(n) for n in ns[0 .. count) (tests/test_host.py checks it against the hardware division)
+int crec_debug_fastdiv(uint32_t d, const uint32_t *ns, int64_t count, uint32_t *out)
+{
+    if (d == 0 || !ns || !out)
+        return CREC_EINVAL;
+    const FastDiv f(d);
+    for (int64_t k = 0; k < count; ++k)
+        out[k] = f.div(ns[k]);
+    return CREC_OK;
+}
+
 int crec_rng_seed(crec_ctx *ctx, uint32_t seed)
 {
     if (!ctx)
@@ -348,12 +393,25 @@ int crec_sample_pairwise(crec_ctx *ctx, const int64_t *ptr, const int32_t *items
     const auto t1 = std::chrono::steady_clock::now();
     const int32_t *negp = neg.get(), *eup = eu.get();
     // sampler.py:68 + np.array(x)[s_idx] for the three columns at once
-    shuffled_apply(ctx->rng, n, perm.get(), [=](int64_t k, uint32_t sidx) {
-        const uint32_t e = sidx / (uint32_t)neg_ratio;
-        u[k] = eup[e];
-        i[k] = items[e];
-        j[k] = negp[sidx];
-    });
+    const FastDiv by_ratio((uint32_t)neg_ratio);
+    static const int ahead_mode = getenv("CREC_SAMPLER_AHEAD") ? atoi(getenv("CREC_SAMPLER_AHEAD")) : 0;
+    shuffled_apply(
+        ctx->rng, n, perm.get(),
+        [=](int64_t k, uint32_t sidx) {
+            const uint32_t e = by_ratio.div(sidx);
+            u[k] = eup[e];
+            i[k] = items[e];
+            j[k] = negp[sidx];
+        },
+        [=](uint32_t sidx) {
+            if (ahead_mode >= 1)
+                __builtin_prefetch(&negp[sidx], 0, 0);
+            if (ahead_mode >= 3) {
+                const uint32_t e = by_ratio.div(sidx);
+                __builtin_prefetch(&eup[e], 0, 0);
+                __builtin_prefetch(&items[e], 0, 0);
+            }
+        });
     if (timing)
         fprintf(stderr, "crec_sample_pairwise: negatives %.2f ms, shuffle + gather %.2f ms\n",
                 std::chrono::duration<double, std::milli>(t1 - t0).count(),
@@ -382,13 +440,21 @@ int crec_sample_pointwise(crec_ctx *ctx, const int64_t *ptr, const int32_t *item
     if (!draw_negatives(ctx->rng, c, neg_ratio, neg.get(), stamp.get()))
         return crec_fail(ctx, CREC_EINVAL, "a user has fewer than neg_ratio unseen items");
     const int32_t *negp = neg.get(), *eup = eu.get();
-    shuffled_apply(ctx->rng, n, perm.get(), [=](int64_t k, uint32_t sidx) { // sampler.py:37
-        // instance s = e*(1+neg_ratio) + t: t == 0 the positive, t >= 1 its (t-1)-th negative (sampler.py:18-31)
-        const uint32_t e = sidx / (uint32_t)w, t = sidx - e * (uint32_t)w;
-        u[k] = eup[e];
-        i[k] = t == 0 ? items[e] : negp[(int64_t)e * neg_ratio + (t - 1)];
-        y[k] = t == 0 ? 1.0f : 0.0f;
-    });
+    const FastDiv by_w((uint32_t)w);
+    shuffled_apply(
+        ctx->rng, n, perm.get(),
+        [=](int64_t k, uint32_t sidx) { // sampler.py:37
+            // instance s = e*(1+neg_ratio) + t: t == 0 the positive, t >= 1 its (t-1)-th negative (sampler.py:18-31)
+            const uint32_t e = by_w.div(sidx), t = sidx - e * (uint32_t)w;
+            u[k] = eup[e];
+            i[k] = t == 0 ? items[e] : negp[(int64_t)e * neg_ratio + (t - 1)];
+            y[k] = t == 0 ? 1.0f : 0.0f;
+        },
+        [=](uint32_t sidx) {
+            const uint32_t e = by_w.div(sidx), t = sidx - e * (uint32_t)w;
+            __builtin_prefetch(&eup[e], 0, 0);
+            __builtin_prefetch(t == 0 ? &items[e] : &negp[(int64_t)e * neg_ratio + (t - 1)], 0, 0);
+        });
     *n_out = n;
     return CREC_OK;
 }

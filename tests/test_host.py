@@ -438,3 +438,25 @@ def test_cune_walks_friends_and_spu_match_the_reference_run(golden_dir):
     ref_spu = {int(k): [int(x) for x in z["spu_items"][z["spu_ptr"][n]:z["spu_ptr"][n + 1]]] for n, k in enumerate(z["spu_keys"])}
     assert list(friends) == list(ref_friends) and all(list(friends[u]) == ref_friends[u] for u in friends)
     assert list(SPu) == list(ref_spu) and all(list(SPu[u]) == ref_spu[u] for u in SPu)
+
+
+def test_sampler_fast_division_is_exact():
+    """The gather of every epoch sample divides the shuffled index by neg_ratio with a multiply and two shifts
+    (crec_sampler.cpp: FastDiv); against integer division for every divisor up to 300 and a few large ones, on the edges
+    of the 32-bit range and on random dividends."""
+    import ctypes as C
+    from cleverrec_amd import _lib
+    lib = _lib.load()
+    g = np.random.Generator(np.random.PCG64(3))
+    ns = np.concatenate([np.arange(0, 2000), 2 ** 32 - 1 - np.arange(0, 2000), g.integers(0, 2 ** 32, 20000),
+                         (2 ** np.arange(1, 32))[:, None].repeat(3, 1).ravel() + np.tile([-1, 0, 1], 31)]).astype(np.uint32)
+    out = np.empty_like(ns)
+    for d in list(range(1, 301)) + [1000, 4097, 65535, 65536, 65537, 2 ** 31 - 1, 2 ** 31, 2 ** 31 + 1, 2 ** 32 - 1]:
+        top = (2 ** 32 - 1) // d
+        mult = np.array([max(top - 2, 0) * d, max(top - 1, 0) * d, top * d], dtype=np.uint64)  # the largest multiples of d and their neighbours
+        extra = np.concatenate([np.maximum(mult, 1) - 1, mult, np.minimum(mult + 1, 2 ** 32 - 1)]).astype(np.uint32)
+        for arr in (ns, extra):
+            o = out[:len(arr)]
+            rc = lib.crec_debug_fastdiv(C.c_uint32(d), arr.ctypes.data_as(C.c_void_p), C.c_int64(len(arr)), o.ctypes.data_as(C.c_void_p))
+            assert rc == 0
+            assert np.array_equal(o, (arr.astype(np.uint64) // d).astype(np.uint32)), d
