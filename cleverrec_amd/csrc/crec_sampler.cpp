@@ -116,6 +116,7 @@ struct FastDiv {
     uint32_t m, s1, s2;
     explicit FastDiv(uint32_t d)
     {
+        d = d ? d : 1; // neg_ratio 0: an empty sample, nothing is divided
         uint32_t L = 0;
         while (((uint64_t)1 << L) < d)
             ++L;
