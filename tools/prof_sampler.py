@@ -22,6 +22,8 @@ print("median %%.1f ms for %%d triples" %% (sorted(ts)[len(ts) // 2] * 1e3, len(
 for ahead in os.environ.get("PROF_SAMPLER_AHEADS", "0 1 3").split():
     for th in ("0", "1", "2"):
         env = dict(os.environ, CREC_SAMPLER_THREADS=th, CREC_SAMPLER_TIMING="1", CREC_SAMPLER_AHEAD=ahead)
+        if th not in os.environ.get("PROF_SAMPLER_WORKERS", "0 1 2").split():
+            continue
         r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True)
         lines = [l for l in r.stderr.splitlines() if "crec_sample_pairwise" in l]
         print("prefetch mode", ahead, "workers", th, "|", r.stdout.strip(), "|", lines[-1] if lines else r.stderr[-300:], flush=True)
