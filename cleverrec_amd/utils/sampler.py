@@ -49,8 +49,9 @@ def _with_numpy_stream(fn):
     return out
 
 
-def ranking_sampler_sbpr(data, SPu, neg_ratio, batch_size, is_suk=True):
-    """utils/sampler.py:102-141 -> (train_batches, u, i, i_s, i_neg[, suk]).  SPu: utils/tools.get_SPu(data) (list order matters)."""
+def ranking_sampler_sbpr(data, SPu, neg_ratio, batch_size, is_suk=True, prefetch_next=False):
+    """utils/sampler.py:102-141 -> (train_batches, u, i, i_s, i_neg[, suk]).  SPu: utils/tools.get_SPu(data) (list order matters).
+    prefetch_next (extension): start drawing the next call's sample on a host thread (module docstring)."""
     from .tools import spu_csr
     cache = getattr(data, "_spu_csr", None)
     if cache is None or cache[0] is not SPu:
@@ -59,19 +60,19 @@ def ranking_sampler_sbpr(data, SPu, neg_ratio, batch_size, is_suk=True):
             data._spu_csr = cache
         except AttributeError:
             pass
-    u, i, k, j, suk = _with_numpy_stream(lambda c: c.sample_sbpr(_csr(data), data.item_nums, neg_ratio, cache[1]))
+    u, i, k, j, suk = _sample("sbpr", data, neg_ratio, prefetch_next, extra=(cache[1],), tag=id(SPu))
     nb = math.ceil(len(u) / batch_size)
     return (nb, u, i, k, j, suk) if is_suk else (nb, u, i, k, j)
 
 
-_KINDS = {"pairwise": "sample_pairwise", "pointwise": "sample_pointwise", "cml": "sample_cml"}
+_KINDS = {"pairwise": "sample_pairwise", "pointwise": "sample_pointwise", "cml": "sample_cml", "sbpr": "sample_sbpr"}
 
 
 class _Prefetch:
     """One sample drawn ahead on a host thread from a private copy of the MT19937 state (see the module docstring)."""
 
-    def __init__(self, kind, data, neg_ratio, key, pos):
-        self.sig = (kind, id(data), int(neg_ratio))
+    def __init__(self, kind, data, neg_ratio, key, pos, extra=(), tag=None):
+        self.sig = (kind, id(data), int(neg_ratio), tag)
         self.key, self.pos = np.array(key, dtype=np.uint32, copy=True), int(pos)
         self.out = self.end = self.err = None
         csr, item_nums = _csr(data), data.item_nums
@@ -80,7 +81,7 @@ class _Prefetch:
             try:
                 ctx = _lib.Context(None)  # its own host ctx: the RNG state is per ctx
                 ctx.set_state(self.key, self.pos)
-                self.out = getattr(ctx, _KINDS[kind])(csr, item_nums, neg_ratio)  # ctypes drops the GIL for the call
+                self.out = getattr(ctx, _KINDS[kind])(csr, item_nums, neg_ratio, *extra)  # ctypes drops the GIL for the call
                 self.end = ctx.get_state()
                 ctx.close()
             except Exception as e:  # noqa: BLE001 -- surfaces as a fall-back to the serial path
@@ -96,9 +97,10 @@ _pending = None
 stats = {"prefetch_hits": 0, "prefetch_misses": 0}
 
 
-def _sample(kind, data, neg_ratio, prefetch_next):
+def _sample(kind, data, neg_ratio, prefetch_next, extra=(), tag=None):
+    """extra: further arguments of the ctx method (SBPR: the SPu CSR); tag: what else the sample depends on (id of the SPu dict)."""
     global _pending
-    sig = (kind, id(data), int(neg_ratio))
+    sig = (kind, id(data), int(neg_ratio), tag)
     st = np.random.get_state()
     assert st[0] == "MT19937"
     pf, _pending = _pending, None
@@ -112,10 +114,10 @@ def _sample(kind, data, neg_ratio, prefetch_next):
     if out is None:
         if pf is not None:
             stats["prefetch_misses"] += 1
-        out = _with_numpy_stream(lambda c: getattr(c, _KINDS[kind])(_csr(data), data.item_nums, neg_ratio))
+        out = _with_numpy_stream(lambda c: getattr(c, _KINDS[kind])(_csr(data), data.item_nums, neg_ratio, *extra))
     if prefetch_next:
         st = np.random.get_state()
-        _pending = _Prefetch(kind, data, neg_ratio, st[1], st[2])
+        _pending = _Prefetch(kind, data, neg_ratio, st[1], st[2], extra, tag)
     return out
 
 

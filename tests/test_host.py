@@ -460,3 +460,54 @@ def test_sampler_fast_division_is_exact():
             rc = lib.crec_debug_fastdiv(C.c_uint32(d), arr.ctypes.data_as(C.c_void_p), C.c_int64(len(arr)), o.ctypes.data_as(C.c_void_p))
             assert rc == 0
             assert np.array_equal(o, (arr.astype(np.uint64) // d).astype(np.uint32)), d
+
+
+def test_sbpr_sampler_prefetch_is_stream_exact(golden_dir):
+    """The SBPR / CUNE_BPR sampler drawn ahead on a host thread: the same five columns and the same np.random state as the
+    serial order (first epoch = the reference's own stream, tests/golden/sampler_sbpr.npz), hits when nobody draws between
+    epochs, a miss (and still the serial results) when somebody does or when another SPu dict is passed."""
+    from cleverrec_amd.utils.tools import get_SPu
+    g = np.load(os.path.join(golden_dir, "sampler_sbpr.npz"))
+
+    class D:
+        pass
+    d = D()
+    rows = lambda k, p, v: {int(key): v[p[n]:p[n + 1]].tolist() for n, key in enumerate(k)}
+    d.ui_train, d.user_friends, d.item_nums = rows(g["keys"], g["ptr"], g["items"]), rows(g["f_keys"], g["f_ptr"], g["f_items"]), int(g["item_nums"])
+    SPu = get_SPu(d)
+    seed, nr, B = int(g["seed"]), int(g["neg_ratio"]), int(g["batch"])
+
+    def run(prefetch, disturb):
+        S.drop_prefetch()
+        np.random.seed(seed)
+        outs = []
+        for e in range(4):
+            outs.append(S.ranking_sampler_sbpr(d, SPu, nr, B, is_suk=(e % 2 == 0), prefetch_next=prefetch))
+            if disturb and e == 1:
+                outs.append(np.random.randint(1000))
+        outs.append(np.random.randint(2 ** 30))
+        return outs
+
+    def same(a, b):
+        return all((x == y) if np.isscalar(x) else all(np.array_equal(p, q) for p, q in zip(x, y)) for x, y in zip(a, b))
+    base = run(False, False)
+    assert np.array_equal(np.asarray(base[0][1]).astype(np.int64), g["u"]) and np.array_equal(np.asarray(base[0][4]).astype(np.int64), g["i_neg"])
+    assert len(base[0]) == 6 and len(base[1]) == 5  # is_suk=False drops the suk column, not the draws
+    h0 = dict(S.stats)
+    assert same(run(True, False), base)
+    assert S.stats["prefetch_hits"] - h0["prefetch_hits"] == 3 and S.stats["prefetch_misses"] == h0["prefetch_misses"]
+    dbase = run(False, True)
+    assert same(run(True, True), dbase) and S.stats["prefetch_misses"] - h0["prefetch_misses"] == 1
+    # another SPu dict (same content, another object): the pending sample is not trusted
+    S.drop_prefetch()
+    np.random.seed(seed)
+    first = S.ranking_sampler_sbpr(d, SPu, nr, B, prefetch_next=True)
+    m0 = S.stats["prefetch_misses"]
+    second = S.ranking_sampler_sbpr(d, dict(SPu), nr, B, prefetch_next=False)
+    assert S.stats["prefetch_misses"] == m0 + 1
+    np.random.seed(seed)
+    S.drop_prefetch()
+    a = S.ranking_sampler_sbpr(d, SPu, nr, B)
+    b = S.ranking_sampler_sbpr(d, SPu, nr, B)
+    assert same([first, second], [a, b])
+    S.drop_prefetch()
