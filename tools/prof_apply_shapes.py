@@ -1,3 +1,5 @@
+"""The update launch (apply_all) and the index launches of the SBPR step by HIP events at a few table shapes and batch sizes:
+what is sweep (B = 64: nearly no slots) and what is the slot walk (B = 6144).  python tools/prof_apply_shapes.py"""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
