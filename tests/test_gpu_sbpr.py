@@ -21,7 +21,7 @@ def sess():
     s.close()
 
 
-@pytest.mark.parametrize("d,B", [(16, 200), (128, 512)])
+@pytest.mark.parametrize("d,B", [(16, 200), (128, 512), (8, 5461), (8, 5462), (8, 8192)])  # 3B = 16 383 | 16 386 | 24 576 item slots: one | two | two index chunks
 def test_sbpr_steps_match_oracle(sess, d, B):
     g = np.random.Generator(np.random.PCG64(d))
     U, I, N = 80, 60, 2 * B + 37  # a ragged last batch; 3 * B item slots > 2048: several index chunks at B = 512... and one at 200
