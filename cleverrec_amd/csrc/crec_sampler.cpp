@@ -110,6 +110,51 @@ template <typename T> void permutation(crec_mt19937 &r, int64_t n, T *a, std::at
 // shuffle: the legacy shuffle walks k downwards and never touches a position above k again, so perm[k..n) is final
 // as soon as step k is done and can be consumed while the (strictly serial) shuffle is still running.  The RNG
 // stream and the result are exactly those of the serial code.
+// The epoch-sized work arrays (negatives, permutation, swap targets, edge -> user) come from the ctx's pool: a sampler
+// call takes its buffers in a fixed order and finds last epoch's -- mapped, faulted in, large enough -- instead of
+// asking the allocator for 40 MB and touching 10 000 fresh pages inside the timed phases (on the GPU host that made
+// the negatives phase 12 or 29 ms from call to call).  Outside a PoolScope (there is none) alloc falls back to malloc.
+thread_local crec_host_pool *tl_pool = nullptr;
+struct PoolScope {
+    explicit PoolScope(crec_ctx *ctx)
+    {
+        tl_pool = &ctx->samp_pool;
+        tl_pool->next = 0;
+    }
+    ~PoolScope() { tl_pool = nullptr; }
+};
+template <typename T> struct Free {
+    bool owned = true;
+    void operator()(T *p) const
+    {
+        if (owned)
+            std::free(p);
+    }
+};
+template <typename T> using buf = std::unique_ptr<T[], Free<T>>;
+template <typename T> buf<T> alloc(int64_t n, bool zero = false)
+{
+    size_t bytes = sizeof(T) * (size_t)(n > 0 ? n : 1);
+    if (tl_pool) {
+        try {
+            if ((int)tl_pool->slots.size() <= tl_pool->next)
+                tl_pool->slots.resize((size_t)tl_pool->next + 1, {nullptr, 0});
+        } catch (...) {
+            return buf<T>(nullptr, Free<T>{false});
+        }
+        auto &slot = tl_pool->slots[(size_t)tl_pool->next++];
+        if (slot.second < bytes) {
+            std::free(slot.first);
+            slot.first = std::malloc(bytes);
+            slot.second = slot.first ? bytes : 0;
+        }
+        if (zero && slot.first)
+            std::memset(slot.first, 0, bytes);
+        return buf<T>((T *)slot.first, Free<T>{false});
+    }
+    return buf<T>((T *)(zero ? std::calloc(bytes, 1) : std::malloc(bytes)), Free<T>{true});
+}
+
 // n / d for every 32-bit n by one multiplication and two shifts (Granlund-Montgomery, the round-up form): the gather
 // divides every shuffled index by neg_ratio, and a hardware 32-bit division costs 10-30 ns where this costs one.
 struct FastDiv {
@@ -162,11 +207,13 @@ void shuffled_apply(crec_mt19937 &r, int64_t n, uint32_t *perm, Body body, Ahead
     std::atomic<int64_t> front{n}, next{n_chunks - 1};
     // the shuffle itself in two stages: this thread owns the RNG and only draws the swap targets (they depend on the
     // stream alone), a second thread applies the swaps behind it -- generation and the cache-missing swaps overlap
-    std::vector<uint32_t> target;
+    auto target_buf = alloc<uint32_t>(n);
+    uint32_t *const target = target_buf.get();
     std::atomic<int64_t> drawn{n}; // steps k >= drawn have their target
     std::thread swapper;
     try { // nothing may escape through the C ABI: without memory or threads, do it serially
-        target.resize((size_t)n);
+        if (!target)
+            throw std::bad_alloc();
         swapper = std::thread([&] {
             for (int64_t k = 0; k < n; ++k)
                 perm[k] = (uint32_t)k;
@@ -272,16 +319,6 @@ bool draw_negatives(crec_mt19937 &r, const Csr &c, int neg_ratio, int32_t *neg, 
     return true;
 }
 
-template <typename T> struct Free {
-    void operator()(T *p) const { std::free(p); }
-};
-template <typename T> using buf = std::unique_ptr<T[], Free<T>>;
-template <typename T> buf<T> alloc(int64_t n, bool zero = false)
-{
-    size_t bytes = sizeof(T) * (size_t)(n > 0 ? n : 1);
-    return buf<T>((T *)(zero ? std::calloc(bytes, 1) : std::malloc(bytes)));
-}
-
 int check_csr(crec_ctx *ctx, const Csr &c, int neg_ratio, const void *a, const void *b, const void *d, int64_t *n_out)
 {
     CREC_REQUIRE(ctx, c.ptr && c.user_ids && a && b && d && n_out, "null argument");
@@ -377,6 +414,7 @@ int crec_sample_pairwise(crec_ctx *ctx, const int64_t *ptr, const int32_t *items
     if (!ctx)
         return CREC_EINVAL;
     Csr c{ptr, items, n_users, user_ids, item_nums};
+    const PoolScope pool(ctx); // work arrays: the ctx's, kept between calls
     if (int rc = check_csr(ctx, c, neg_ratio, u, i, j, n_out))
         return rc;
     const int64_t n_pos = ptr[n_users], n = n_pos * neg_ratio;
@@ -428,6 +466,7 @@ int crec_sample_pointwise(crec_ctx *ctx, const int64_t *ptr, const int32_t *item
     if (!ctx)
         return CREC_EINVAL;
     Csr c{ptr, items, n_users, user_ids, item_nums};
+    const PoolScope pool(ctx); // work arrays: the ctx's, kept between calls
     if (int rc = check_csr(ctx, c, neg_ratio, u, i, y, n_out))
         return rc;
     const int64_t n_pos = ptr[n_users], w = 1 + (int64_t)neg_ratio, n = n_pos * w;
@@ -471,6 +510,7 @@ int crec_sample_sbpr(crec_ctx *ctx, const int64_t *ptr, const int32_t *items, in
     if (!ctx)
         return CREC_EINVAL;
     Csr c{ptr, items, n_users, user_ids, item_nums};
+    const PoolScope pool(ctx); // work arrays: the ctx's, kept between calls
     if (int rc = check_csr(ctx, c, neg_ratio, u, i, i_neg, n_out))
         return rc;
     CREC_REQUIRE(ctx, spu_ptr && i_s && suk && (spu_ptr[n_users] == 0 || (spu_items && spu_suk)), "null argument");
@@ -541,6 +581,7 @@ int crec_sample_cml(crec_ctx *ctx, const int64_t *ptr, const int32_t *items, int
     if (!ctx)
         return CREC_EINVAL;
     Csr c{ptr, items, n_users, user_ids, item_nums};
+    const PoolScope pool(ctx); // work arrays: the ctx's, kept between calls
     if (int rc = check_csr(ctx, c, neg_ratio, u, i, neg_out, n_out))
         return rc;
     const int64_t n = ptr[n_users];
