@@ -10,6 +10,8 @@
 //
 // Reference: utils/sampler.py:10-99 (samplers), numpy RandomState (randint / permutation).
 #include <cstdlib>
+#include <sched.h>
+#include <sys/resource.h>
 #include <memory>
 #include <new>
 
@@ -270,8 +272,11 @@ void shuffled_apply(crec_mt19937 &r, int64_t n, uint32_t *perm, Body body, Ahead
             drawn.store(k, std::memory_order_release);
     }
     drawn.store(1, std::memory_order_release);
-    swapper.join();
+    // this thread gathers too as soon as its draws are done -- chunks the swapper has passed -- instead of sleeping in a join
+    // until the swapper is through: a thread that sleeps wakes up wherever the scheduler finds room, and on a shared host the
+    // next call's serial phase then ran 2-4x slower for tens of milliseconds
     gather(); // whatever the workers have not claimed (everything, if there are none)
+    swapper.join();
     for (auto &t : pool)
         t.join();
 }
@@ -426,10 +431,21 @@ int crec_sample_pairwise(crec_ctx *ctx, const int64_t *ptr, const int32_t *items
     if (!stamp || !neg || !perm || !eu)
         return crec_fail(ctx, CREC_ENOMEM, "host allocation failed");
     static const bool timing = getenv("CREC_SAMPLER_TIMING") != nullptr; // phase times on stderr (tools/prof_epoch.py)
+    struct rusage ru0, ru1;
+    const int cpu0 = timing ? sched_getcpu() : -1;
+    if (timing)
+        getrusage(RUSAGE_THREAD, &ru0);
     const auto t0 = std::chrono::steady_clock::now();
     if (!draw_negatives(ctx->rng, c, neg_ratio, neg.get(), stamp.get()))
         return crec_fail(ctx, CREC_EINVAL, "a user has fewer than neg_ratio unseen items");
     const auto t1 = std::chrono::steady_clock::now();
+    if (timing) {
+        getrusage(RUSAGE_THREAD, &ru1);
+        fprintf(stderr, "  negatives phase: cpu %d -> %d, involuntary switches %ld, voluntary %ld, thread cpu time %.2f ms\n", cpu0, sched_getcpu(),
+                ru1.ru_nivcsw - ru0.ru_nivcsw, ru1.ru_nvcsw - ru0.ru_nvcsw,
+                (ru1.ru_utime.tv_sec - ru0.ru_utime.tv_sec) * 1e3 + (ru1.ru_utime.tv_usec - ru0.ru_utime.tv_usec) * 1e-3 +
+                    (ru1.ru_stime.tv_sec - ru0.ru_stime.tv_sec) * 1e3 + (ru1.ru_stime.tv_usec - ru0.ru_stime.tv_usec) * 1e-3);
+    }
     const int32_t *negp = neg.get(), *eup = eu.get();
     // sampler.py:68 + np.array(x)[s_idx] for the three columns at once
     const FastDiv by_ratio((uint32_t)neg_ratio);

@@ -25,7 +25,7 @@ for ahead in os.environ.get("PROF_SAMPLER_AHEADS", "0 1 3").split():
         if th not in os.environ.get("PROF_SAMPLER_WORKERS", "0 1 2").split():
             continue
         r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True)
-        lines = [l for l in r.stderr.splitlines() if "crec_sample_pairwise" in l]
+        lines = [l for l in r.stderr.splitlines() if "crec_sample_pairwise" in l or "negatives phase" in l]
         print("prefetch mode", ahead, "workers", th, "|", r.stdout.strip(), "|", lines[-1] if lines else r.stderr[-300:], flush=True)
         if os.environ.get("PROF_SAMPLER_ALL"):
             for l in lines:
