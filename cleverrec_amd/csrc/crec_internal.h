@@ -6,10 +6,8 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
-#include <cstdlib>
 #include <cstring>
 #include <string>
-#include <utility>
 #include <vector>
 
 #include "../../include/crec.h"
@@ -68,20 +66,8 @@ struct crec_profile {
     int64_t launches[CREC_K_COUNT] = {0};
 };
 
-// host buffers of the samplers, kept from one epoch's call to the next (crec_sampler.cpp: a call takes them in a fixed order)
-struct crec_host_pool {
-    std::vector<std::pair<void *, size_t>> slots;
-    int next = 0;
-    ~crec_host_pool()
-    {
-        for (auto &s : slots)
-            free(s.first);
-    }
-};
-
 struct crec_ctx {
     int device = -1;
-    crec_host_pool samp_pool;
     crec_profile prof;
     char err[512] = {0};
     crec_mt19937 rng;

@@ -112,51 +112,6 @@ template <typename T> void permutation(crec_mt19937 &r, int64_t n, T *a, std::at
 // shuffle: the legacy shuffle walks k downwards and never touches a position above k again, so perm[k..n) is final
 // as soon as step k is done and can be consumed while the (strictly serial) shuffle is still running.  The RNG
 // stream and the result are exactly those of the serial code.
-// The epoch-sized work arrays (negatives, permutation, swap targets, edge -> user) come from the ctx's pool: a sampler
-// call takes its buffers in a fixed order and finds last epoch's -- mapped, faulted in, large enough -- instead of
-// asking the allocator for 40 MB and touching 10 000 fresh pages inside the timed phases (on the GPU host that made
-// the negatives phase 12 or 29 ms from call to call).  Outside a PoolScope (there is none) alloc falls back to malloc.
-thread_local crec_host_pool *tl_pool = nullptr;
-struct PoolScope {
-    explicit PoolScope(crec_ctx *ctx)
-    {
-        tl_pool = &ctx->samp_pool;
-        tl_pool->next = 0;
-    }
-    ~PoolScope() { tl_pool = nullptr; }
-};
-template <typename T> struct Free {
-    bool owned = true;
-    void operator()(T *p) const
-    {
-        if (owned)
-            std::free(p);
-    }
-};
-template <typename T> using buf = std::unique_ptr<T[], Free<T>>;
-template <typename T> buf<T> alloc(int64_t n, bool zero = false)
-{
-    size_t bytes = sizeof(T) * (size_t)(n > 0 ? n : 1);
-    if (tl_pool) {
-        try {
-            if ((int)tl_pool->slots.size() <= tl_pool->next)
-                tl_pool->slots.resize((size_t)tl_pool->next + 1, {nullptr, 0});
-        } catch (...) {
-            return buf<T>(nullptr, Free<T>{false});
-        }
-        auto &slot = tl_pool->slots[(size_t)tl_pool->next++];
-        if (slot.second < bytes) {
-            std::free(slot.first);
-            slot.first = std::malloc(bytes);
-            slot.second = slot.first ? bytes : 0;
-        }
-        if (zero && slot.first)
-            std::memset(slot.first, 0, bytes);
-        return buf<T>((T *)slot.first, Free<T>{false});
-    }
-    return buf<T>((T *)(zero ? std::calloc(bytes, 1) : std::malloc(bytes)), Free<T>{true});
-}
-
 // n / d for every 32-bit n by one multiplication and two shifts (Granlund-Montgomery, the round-up form): the gather
 // divides every shuffled index by neg_ratio, and a hardware 32-bit division costs 10-30 ns where this costs one.
 struct FastDiv {
@@ -209,13 +164,11 @@ void shuffled_apply(crec_mt19937 &r, int64_t n, uint32_t *perm, Body body, Ahead
     std::atomic<int64_t> front{n}, next{n_chunks - 1};
     // the shuffle itself in two stages: this thread owns the RNG and only draws the swap targets (they depend on the
     // stream alone), a second thread applies the swaps behind it -- generation and the cache-missing swaps overlap
-    auto target_buf = alloc<uint32_t>(n);
-    uint32_t *const target = target_buf.get();
+    std::vector<uint32_t> target;
     std::atomic<int64_t> drawn{n}; // steps k >= drawn have their target
     std::thread swapper;
     try { // nothing may escape through the C ABI: without memory or threads, do it serially
-        if (!target)
-            throw std::bad_alloc();
+        target.resize((size_t)n);
         swapper = std::thread([&] {
             for (int64_t k = 0; k < n; ++k)
                 perm[k] = (uint32_t)k;
@@ -272,11 +225,8 @@ void shuffled_apply(crec_mt19937 &r, int64_t n, uint32_t *perm, Body body, Ahead
             drawn.store(k, std::memory_order_release);
     }
     drawn.store(1, std::memory_order_release);
-    // this thread gathers too as soon as its draws are done -- chunks the swapper has passed -- instead of sleeping in a join
-    // until the swapper is through: a thread that sleeps wakes up wherever the scheduler finds room, and on a shared host the
-    // next call's serial phase then ran 2-4x slower for tens of milliseconds
-    gather(); // whatever the workers have not claimed (everything, if there are none)
     swapper.join();
+    gather(); // whatever the workers have not claimed (everything, if there are none)
     for (auto &t : pool)
         t.join();
 }
@@ -322,6 +272,21 @@ bool draw_negatives(crec_mt19937 &r, const Csr &c, int neg_ratio, int32_t *neg, 
         }
     }
     return true;
+}
+
+template <typename T> struct Free {
+    void operator()(T *p) const { std::free(p); }
+};
+template <typename T> using buf = std::unique_ptr<T[], Free<T>>;
+// (Keeping these arrays in the ctx from one epoch to the next was tried: no 40 MB of malloc and first-touch per call -- 120 -> 78 ms
+// per epoch on the build container's Xeon, but prefetched epochs ~33 -> ~55 ms on the GPU host's EPYC in two interleaved A/B runs
+// (tools/sampler_ab.sh; presumably last epoch's lines still sit in the caches of the cores that ran last epoch's threads and this
+// epoch's writes pay for them, where freshly mapped pages have no sharers).  The host is noisy -- the same build gives 28 or 63 ms
+// epochs minutes apart -- so only interleaved runs on one box mean anything.)
+template <typename T> buf<T> alloc(int64_t n, bool zero = false)
+{
+    size_t bytes = sizeof(T) * (size_t)(n > 0 ? n : 1);
+    return buf<T>((T *)(zero ? std::calloc(bytes, 1) : std::malloc(bytes)));
 }
 
 int check_csr(crec_ctx *ctx, const Csr &c, int neg_ratio, const void *a, const void *b, const void *d, int64_t *n_out)
@@ -419,7 +384,6 @@ int crec_sample_pairwise(crec_ctx *ctx, const int64_t *ptr, const int32_t *items
     if (!ctx)
         return CREC_EINVAL;
     Csr c{ptr, items, n_users, user_ids, item_nums};
-    const PoolScope pool(ctx); // work arrays: the ctx's, kept between calls
     if (int rc = check_csr(ctx, c, neg_ratio, u, i, j, n_out))
         return rc;
     const int64_t n_pos = ptr[n_users], n = n_pos * neg_ratio;
@@ -430,7 +394,7 @@ int crec_sample_pairwise(crec_ctx *ctx, const int64_t *ptr, const int32_t *items
     auto eu = edge_users(c);
     if (!stamp || !neg || !perm || !eu)
         return crec_fail(ctx, CREC_ENOMEM, "host allocation failed");
-    static const bool timing = getenv("CREC_SAMPLER_TIMING") != nullptr; // phase times on stderr (tools/prof_epoch.py)
+    static const bool timing = getenv("CREC_SAMPLER_TIMING") != nullptr; // phase times on stderr (tools/prof_sampler.py)
     struct rusage ru0, ru1;
     const int cpu0 = timing ? sched_getcpu() : -1;
     if (timing)
@@ -439,7 +403,7 @@ int crec_sample_pairwise(crec_ctx *ctx, const int64_t *ptr, const int32_t *items
     if (!draw_negatives(ctx->rng, c, neg_ratio, neg.get(), stamp.get()))
         return crec_fail(ctx, CREC_EINVAL, "a user has fewer than neg_ratio unseen items");
     const auto t1 = std::chrono::steady_clock::now();
-    if (timing) {
+    if (timing) { // a slow serial phase with no switches and CPU time = wall time is a slow hardware thread (a busy SMT sibling)
         getrusage(RUSAGE_THREAD, &ru1);
         fprintf(stderr, "  negatives phase: cpu %d -> %d, involuntary switches %ld, voluntary %ld, thread cpu time %.2f ms\n", cpu0, sched_getcpu(),
                 ru1.ru_nivcsw - ru0.ru_nivcsw, ru1.ru_nvcsw - ru0.ru_nvcsw,
@@ -482,7 +446,6 @@ int crec_sample_pointwise(crec_ctx *ctx, const int64_t *ptr, const int32_t *item
     if (!ctx)
         return CREC_EINVAL;
     Csr c{ptr, items, n_users, user_ids, item_nums};
-    const PoolScope pool(ctx); // work arrays: the ctx's, kept between calls
     if (int rc = check_csr(ctx, c, neg_ratio, u, i, y, n_out))
         return rc;
     const int64_t n_pos = ptr[n_users], w = 1 + (int64_t)neg_ratio, n = n_pos * w;
@@ -526,7 +489,6 @@ int crec_sample_sbpr(crec_ctx *ctx, const int64_t *ptr, const int32_t *items, in
     if (!ctx)
         return CREC_EINVAL;
     Csr c{ptr, items, n_users, user_ids, item_nums};
-    const PoolScope pool(ctx); // work arrays: the ctx's, kept between calls
     if (int rc = check_csr(ctx, c, neg_ratio, u, i, i_neg, n_out))
         return rc;
     CREC_REQUIRE(ctx, spu_ptr && i_s && suk && (spu_ptr[n_users] == 0 || (spu_items && spu_suk)), "null argument");
@@ -597,7 +559,6 @@ int crec_sample_cml(crec_ctx *ctx, const int64_t *ptr, const int32_t *items, int
     if (!ctx)
         return CREC_EINVAL;
     Csr c{ptr, items, n_users, user_ids, item_nums};
-    const PoolScope pool(ctx); // work arrays: the ctx's, kept between calls
     if (int rc = check_csr(ctx, c, neg_ratio, u, i, neg_out, n_out))
         return rc;
     const int64_t n = ptr[n_users];

@@ -65,25 +65,6 @@ def ranking_sampler_sbpr(data, SPu, neg_ratio, batch_size, is_suk=True, prefetch
     return (nb, u, i, k, j, suk) if is_suk else (nb, u, i, k, j)
 
 
-_free_ctxs = []  # host ctxs of finished prefetch threads (their work arrays stay mapped: crec_sampler.cpp, PoolScope)
-_free_lock = threading.Lock()
-
-
-def _take_prefetch_ctx():
-    with _free_lock:
-        if _free_ctxs:
-            return _free_ctxs.pop()
-    return _lib.Context(None)
-
-
-def _give_prefetch_ctx(ctx):
-    with _free_lock:
-        if len(_free_ctxs) < 2:
-            _free_ctxs.append(ctx)
-            return
-    ctx.close()
-
-
 _KINDS = {"pairwise": "sample_pairwise", "pointwise": "sample_pointwise", "cml": "sample_cml", "sbpr": "sample_sbpr"}
 
 
@@ -96,17 +77,15 @@ class _Prefetch:
         self.out = self.end = self.err = None
         csr, item_nums = _csr(data), data.item_nums
 
-        ctx = _take_prefetch_ctx()  # its own host ctx (the RNG state and the work arrays are per ctx), reused from epoch to epoch
-
         def work():
             try:
+                ctx = _lib.Context(None)  # its own host ctx: the RNG state is per ctx
                 ctx.set_state(self.key, self.pos)
                 self.out = getattr(ctx, _KINDS[kind])(csr, item_nums, neg_ratio, *extra)  # ctypes drops the GIL for the call
                 self.end = ctx.get_state()
+                ctx.close()
             except Exception as e:  # noqa: BLE001 -- surfaces as a fall-back to the serial path
                 self.err = e
-            finally:
-                _give_prefetch_ctx(ctx)
         self.thread = threading.Thread(target=work, daemon=True)
         self.thread.start()
 
