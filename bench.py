@@ -32,6 +32,74 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 D, B, NEG, LR, REG = 64, 6144, 4, 1e-3, 0.01
 
 
+def launch_ranks(n, argv=None):
+    """`python bench.py --gpus N` without a launcher around it: start N copies of this script, one per GPU, with the
+    environment `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` would give them (RANK, LOCAL_RANK,
+    WORLD_SIZE, MASTER_ADDR = 127.0.0.1, MASTER_PORT = a free port), relay rank 0's JSON line and return non-zero if
+    any rank failed (the others are terminated: a dead peer would leave them blocked in a collective)."""
+    import socket
+    import subprocess
+    argv = list(sys.argv[1:] if argv is None else argv)
+    port = os.environ.get("MASTER_PORT")
+    if port is None:
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = str(so.getsockname()[1])
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    import threading
+    got = []
+    reader = threading.Thread(target=lambda: got.append(procs[0].stdout.read()), daemon=True)  # rank 0 prints one line; EOF at exit
+    reader.start()
+    rc, live = 0, set(range(n))
+    while live:  # a rank that dies takes the run with it: its peers would sit in the rendezvous or a collective for ever
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0:
+                sys.stderr.write("bench.py: rank %d exited with %d\n" % (r, code))
+                if rc == 0:
+                    rc = code if code > 0 else 1
+                    for q in procs:  # exact children of this process, by handle
+                        if q.poll() is None:
+                            q.terminate()
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    line0 = got[0] if got else b""
+    sys.stdout.buffer.write(line0)
+    sys.stdout.flush()
+    return rc
+
+
+def dry_rank(real_stdout):
+    """--dry-launch: what a rank does before it needs a GPU -- read the launcher's environment, join the process group
+    (gloo: the CPU stand-in for RCCL), agree with the peers.  Rank 0 prints one JSON line."""
+    import torch
+    import torch.distributed as dist
+    world, rank, local_rank = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
+    seen = None
+    if os.environ.get("CREC_DRY_FAIL_RANK") == str(rank):  # test hook: a rank that dies before the rendezvous
+        return 3
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.zeros(world, dtype=torch.int64)
+        t[rank] = 1 + local_rank
+        dist.all_reduce(t)
+        seen = t.tolist()
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        os.write(real_stdout, (json.dumps({"dry_launch": True, "world": world, "ranks_seen": seen,
+                                           "master": "%s:%s" % (os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"))}) + "\n").encode())
+    return 0
+
+
 def main():
     # the host driver only supports dmabuf IPC: RCCL between processes needs this before HIP is initialised
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -46,7 +114,19 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=3000, help="steps of the scalar-C CPU baseline sample (0 = skip all CPU legs); 3000 ~ 7 s")
     ap.add_argument("--no-extras", action="store_true", help="skip the roofline/eval/sampler/cpu legs")
     ap.add_argument("--no-big", action="store_true", help="skip the S-big (10M x 1M, d=128) leg")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="launcher rehearsal without a GPU: every rank joins a gloo group, all-reduces its rank and reports its environment")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Started bare (`python bench.py --gpus N`): this process becomes the launcher.  It has not imported torch or
+        # touched HIP and never will -- a process that has initialised the GPU must not be replaced or forked into ranks.
+        os.dup2(real_stdout, 1)
+        os.close(real_stdout)
+        sys.exit(launch_ranks(a.gpus))
+
+    if a.dry_launch:
+        sys.exit(dry_rank(real_stdout))
 
     import torch
     import torch.distributed as dist
