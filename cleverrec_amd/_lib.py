@@ -98,6 +98,12 @@ _SIGNATURES = {
     "crec_sample_cml": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, C.c_int, _vp, _vp, _vp, C.POINTER(_i64)]),
     "crec_sample_sbpr": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i64)]),
     "crec_sample_negatives_device": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
+    "crec_dsampler_create": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, C.POINTER(_vp), _vp]),
+    "crec_dsampler_destroy": (None, [_vp]),
+    "crec_dsampler_sample": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "crec_dsampler_finish": (C.c_int, [_vp, _vp, C.POINTER(_i64), _vp, C.POINTER(_i32)]),
+    "crec_dsampler_stats": (C.c_int, [_vp, _vp]),
+    "crec_debug_mt_jump": (C.c_int, [_vp, C.c_int, _vp]),
     "crec_bpr_train_epoch": (C.c_int, [_vp, C.POINTER(BprTables), C.POINTER(Adam), _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "crec_bpr_train_epoch_deferred": (C.c_int, [_vp, C.POINTER(BprTables), C.POINTER(BprDeferred), C.POINTER(Adam), _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "crec_bpr_adam_flush": (C.c_int, [_vp, C.POINTER(BprTables), C.POINTER(BprDeferred), C.POINTER(Adam), _vp]),
@@ -180,7 +186,7 @@ class Context:
             raise CrecError(rc, self.lib.crec_last_error(self.h).decode())
 
     def set_option(self, name, value):
-        """crec_ctx_set_option: tuning / test knobs ("ch", "wide", "wide_round", "eval_shape", "eval_no_bitmap", "ncf_generic", "no_zero_copy")."""
+        """crec_ctx_set_option: tuning / test knobs ("ch", "wide", "wide_round", "eval_shape", "eval_no_bitmap", "ncf_generic", "no_zero_copy", "dsampler_general")."""
         self.check(self.lib.crec_ctx_set_option(self.h, name.encode(), int(value)))
 
     # ---- measurement ---------------------------------------------------------------------------

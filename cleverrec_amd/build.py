@@ -21,6 +21,8 @@ SOURCES = {
     "crec_comm.cpp": ["-pthread"],
     "crec_sampler.cpp": ["-fno-math-errno", "-pthread"],
     "gpu_sampler.hip": [],
+    "mt_jump.cpp": ["-pthread"],
+    "mt_sampler.hip": [],
     "bpr_train.hip": ["-ffp-contract=off"],
     "eval_topk.hip": [],
     "rows_adam.hip": ["-ffp-contract=off"],

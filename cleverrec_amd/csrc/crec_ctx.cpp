@@ -150,6 +150,7 @@ int crec_ctx_create(int device, crec_ctx **out)
     ctx->knob_eval_no_bitmap = env_int("CREC_EVAL_NO_BITMAP", 0);
     ctx->knob_ncf_generic = env_int("CREC_NCF_GENERIC", 0);
     ctx->knob_no_zero_copy = env_int("CREC_NO_ZERO_COPY", 0);
+    ctx->knob_dsampler_general = env_int("CREC_DSAMPLER_GENERAL", 0);
     if (device >= 0) {
         int n = 0;
         hipError_t e = hipGetDeviceCount(&n);
@@ -227,6 +228,8 @@ int crec_ctx_set_option(crec_ctx *ctx, const char *name, int64_t value)
         ctx->knob_ncf_generic = (int)value;
     else if (n == "no_zero_copy")
         ctx->knob_no_zero_copy = (int)value;
+    else if (n == "dsampler_general")
+        ctx->knob_dsampler_general = (int)value;
     else
         return crec_fail(ctx, CREC_EINVAL, "unknown option '%s'", name);
     return CREC_OK;

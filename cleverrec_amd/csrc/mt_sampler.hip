@@ -1,0 +1,1400 @@
+// The bit-exact epoch samplers ON the device: utils/sampler.py:10-99 (pointwise / pairwise / CML) drawn from NumPy's
+// legacy MT19937 stream, word for word, by kernels.  Same index streams and the same generator state afterwards as the
+// reference (tests/golden/sampler_*.npz, tests/test_gpu_dsampler.py); the host form (crec_sampler.cpp) remains for SBPR
+// and for shapes outside this file's limits.
+//
+// The reference's loop is serial in two places only -- which stream word a draw takes depends on every earlier
+// accept / reject.  Everything else is a filter, a prefix sum or a gather:
+//
+//  0  raw words.  MT19937 is linear over GF(2): the state J words ahead is a fixed XOR-combination (jump polynomial,
+//     mt_jump.h) of the next 19937 states, i.e. of the stream itself.  `mt_base` writes 34 blocks from the input key,
+//     `mt_chains` gives each of up to 128 workgroups its own start block by that combination (LDS, ~10 K XORs per word)
+//     and lets it generate 128 blocks of 624 words: 10.2 M words per super-block, super-blocks chained through one
+//     more jump.  Words stay raw (untempered) in HBM: the final generator state is 624 of them.
+//  1a randint(item_nums) is a masked rejection (`v = word & mask; take v if v <= item_nums - 1`): a pure filter of the
+//     stream -> `cand_*` kernels compact the survivors (count, scan, scatter), keeping each one's stream position.
+//  1b `neg_chain`, ONE workgroup of 1024 threads, walks the users in the reference's order.  A tile of 1024 candidates
+//     is tested against the user's bitmap of training items (LDS, prefetched a few users ahead), an exclusive prefix
+//     sum numbers the accepted ones -- slot s of the user is the s-th accepted candidate since its start --, a repeat
+//     inside a positive's group of neg_ratio (sampler.py:24,59,88 `j in random_j`) cuts the tile right behind the
+//     repeated candidate (consumed, rejected), the user's last slot cuts it there.  One link of the chain per user.
+//  2  `perm_targets`, one workgroup: np.random.permutation(n) is arange + for i = n-1..1: swap(a[i], a[draw in [0,i]]),
+//     the draw again a masked rejection but with a bound that falls with every accepted word.  Thread t of a tile
+//     accepts iff (word & mask) <= i - (#accepted before t): sure for most (compare against i - t and i), the rest
+//     refined with prefix bounds until none is undecided; a tile is cut where i crosses a power of two (mask changes).
+//  3  the permutation itself without executing a swap: position i ends up with what sat at its target before step i,
+//     which is what the most recent earlier step with the same target put there ...: steps sorted by target (rocPRIM
+//     radix sort), one pointer per step to the next step with its target, one per position to the first step that
+//     targets it, and chains of expected length O(log n) (`perm_links`, `perm_gather`).  The gather of the output
+//     columns (np.array(x)[s_idx], sampler.py:38,69,97) is fused into the chase.
+//
+// The generator state after the call (NumPy hands it to whoever draws next) is block b of the raw stream and a position.
+#include "crec_internal.h"
+#include "mt_jump.h"
+
+#include <rocprim/rocprim.hpp>
+
+#include <cmath>
+#include <new>
+
+namespace {
+
+using crec_mtj::MT_M;
+using crec_mtj::MT_N;
+
+constexpr int TILE = 1024;       // threads of the two chain kernels = candidates / words per tile
+constexpr int CBUF = 8192;       // LDS ring of candidates (neg_chain)
+constexpr int UCACHE = 1024;     // users whose CSR bounds sit in LDS at a time
+constexpr int CAND_BLK = 2048;   // raw words per workgroup of the compaction kernels (256 threads x 8)
+constexpr int32_t NONE = -1;
+
+enum { DS_OK = 0, DS_OUT_OF_CANDIDATES = 1, DS_OUT_OF_WORDS = 2, DS_INTERNAL = 3 };
+
+struct DsStatus {
+    int32_t status;
+    int32_t pos_out;     // generator position after the call (0..624)
+    int64_t n_cand;      // candidates the compaction produced
+    int64_t raw_next1;   // stream index (in X) of the first word phase 2 may use
+    int64_t raw_next2;   // ... of the first word nobody used: the generator stands here afterwards
+    int64_t cand_used;
+    int64_t dbg[6];      // tile iterations, shader clocks, 100 MHz ticks of neg_chain and of perm_targets (crec_dsampler_stats)
+    uint32_t key_out[MT_N];
+};
+
+__device__ __forceinline__ uint32_t mt_twist(uint32_t a, uint32_t b, uint32_t c)
+{
+    const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+    return c ^ (y >> 1) ^ ((0u - (y & 1u)) & 0x9908b0dfu);
+}
+
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y)
+{
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+
+__host__ __device__ inline uint32_t mask_of(uint32_t m)
+{
+    m |= m >> 1, m |= m >> 2, m |= m >> 4, m |= m >> 8, m |= m >> 16;
+    return m;
+}
+
+// one refill of the generator, old -> nw (both LDS, 624 words), by the threads [0, nt) of the workgroup, nt >= 227.
+// new[k] needs old[k], old[k+1] and old[k+397] or new[k-227]: three rounds of <= 227 independent words.
+__device__ __forceinline__ void twist_block(const uint32_t *old, uint32_t *nw, int tid)
+{
+    if (tid < MT_N - MT_M)
+        nw[tid] = mt_twist(old[tid], old[tid + 1], old[tid + MT_M]);
+    __syncthreads();
+    if (tid < MT_N - MT_M) {
+        const int k = tid + (MT_N - MT_M);
+        nw[k] = mt_twist(old[k], old[k + 1], nw[k - (MT_N - MT_M)]);
+    }
+    __syncthreads();
+    if (tid < MT_N - 2 * (MT_N - MT_M)) { // k = 454 .. 623
+        const int k = tid + 2 * (MT_N - MT_M);
+        nw[k] = k < MT_N - 1 ? mt_twist(old[k], old[k + 1], nw[k - (MT_N - MT_M)]) : mt_twist(old[MT_N - 1], nw[0], nw[MT_M - 1]);
+    }
+    __syncthreads();
+}
+
+// ---- phase 0 -----------------------------------------------------------------------------------------------------
+// base[0 .. n_blocks*624): the raw stream that starts with the key
+__global__ __launch_bounds__(256) void mt_base(const uint32_t *__restrict__ key, uint32_t *__restrict__ base, int n_blocks)
+{
+    __shared__ uint32_t buf[2][MT_N];
+    const int tid = threadIdx.x;
+    for (int k = tid; k < MT_N; k += 256)
+        base[k] = buf[0][k] = key[k];
+    __syncthreads();
+    for (int b = 1; b < n_blocks; ++b) {
+        const uint32_t *old = buf[(b - 1) & 1];
+        uint32_t *nw = buf[b & 1];
+        twist_block(old, nw, tid);
+        for (int k = tid; k < MT_N; k += 256)
+            base[(size_t)b * MT_N + k] = nw[k];
+    }
+}
+
+constexpr int CHAIN_THREADS = 640; // >= 624: one thread per word of the jumped block
+// workgroup c of the grid: chain c of the super-block.  Chain 0 starts from the key (block 0 of `base`); chain c > 0 from the
+// block jumped to by polynomial c-1.  Chain `n_chains` (if next_key != nullptr) only jumps: its block is the next super-block's key.
+// x: where this super-block's blocks go; blocks_total: how many of them exist (the last chain may be short).
+__global__ __launch_bounds__(CHAIN_THREADS) void mt_chains(const uint32_t *__restrict__ base, const uint32_t *__restrict__ polys,
+                                                           uint32_t *__restrict__ x, int64_t blocks_total, int n_chains,
+                                                           uint32_t *__restrict__ next_key)
+{
+    extern __shared__ uint32_t lds[];
+    constexpr int SPAN = crec_mtj::DEG + MT_N; // words [624, 624 + SPAN) of the base stream
+    uint32_t *stream = lds;                   // SPAN words
+    uint32_t *blk = lds + SPAN;               // 2 x 624
+    uint16_t *bits = (uint16_t *)(blk + 2 * MT_N); // set bits of the polynomial, <= DEG entries
+    __shared__ int n_bits_s;
+    __shared__ int wcount[CHAIN_THREADS / 64];
+    const int tid = threadIdx.x, c = blockIdx.x;
+    const int64_t first = (int64_t)c * crec_mtj::LB;
+    if (c == 0) {
+        for (int k = tid; k < MT_N; k += CHAIN_THREADS)
+            blk[k] = base[k];
+        __syncthreads();
+    } else {
+        for (int k = tid; k < SPAN; k += CHAIN_THREADS)
+            stream[k] = base[MT_N + k];
+        // the polynomial's set bits as a list: thread t owns word t
+        const uint32_t pw = tid < crec_mtj::POLY_WORDS ? polys[(size_t)(c - 1) * crec_mtj::POLY_WORDS + tid] : 0u;
+        const int mine = __popc(pw);
+        // exclusive scan of `mine` over the workgroup
+        int incl = mine;
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o);
+            if (lane >= o)
+                incl += t;
+        }
+        if (lane == 63)
+            wcount[wave] = incl;
+        __syncthreads();
+        int off = 0;
+        for (int w = 0; w < wave; ++w)
+            off += wcount[w];
+        if (tid == CHAIN_THREADS - 1)
+            n_bits_s = off + incl;
+        int at = off + incl - mine;
+        uint32_t m = pw;
+        while (m) {
+            const int k = __ffs(m) - 1;
+            m &= m - 1;
+            bits[at++] = (uint16_t)(32 * tid + k);
+        }
+        __syncthreads();
+        const int nb = n_bits_s;
+        if (tid < MT_N) {
+            uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+            int j = 0;
+            for (; j + 4 <= nb; j += 4) { // four independent LDS reads in flight
+                a0 ^= stream[bits[j] + tid];
+                a1 ^= stream[bits[j + 1] + tid];
+                a2 ^= stream[bits[j + 2] + tid];
+                a3 ^= stream[bits[j + 3] + tid];
+            }
+            for (; j < nb; ++j)
+                a0 ^= stream[bits[j] + tid];
+            blk[tid] = a0 ^ a1 ^ a2 ^ a3;
+        }
+        __syncthreads();
+    }
+    if (c == n_chains) { // the hand-over block only
+        if (tid < MT_N)
+            next_key[tid] = blk[tid];
+        return;
+    }
+    int64_t todo = blocks_total - first;
+    todo = todo > crec_mtj::LB ? crec_mtj::LB : todo;
+    for (int64_t b = 0; b < todo; ++b) {
+        uint32_t *cur = blk + (b & 1) * MT_N;
+        if (tid < MT_N)
+            x[(size_t)(first + b) * MT_N + tid] = cur[tid];
+        if (b + 1 < todo)
+            twist_block(cur, blk + ((b + 1) & 1) * MT_N, tid);
+    }
+}
+
+// ---- block-wide helpers of the chain kernels (1024 threads = 16 waves) ------------------------------------------------
+__device__ __forceinline__ uint32_t lanes_below(uint64_t m)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// exclusive prefix of a per-thread value packed per wave by the caller: `wave_total` (the wave's sum, same in all its lanes).
+// wsum: LDS [16], 16-byte aligned; alternate between two arrays from call to call.  After the barrier every thread reads all
+// sixteen sums (four broadcast reads, one LDS round trip) and adds up the ones below its wave -- a chain of cross-lane
+// shuffles here cost six dependent LDS-crossbar trips per call, and these kernels are nothing but such chains.
+__device__ __forceinline__ void block_offsets(uint32_t wave_total, uint32_t *wsum, int lane, int wave, uint32_t &before_wave, uint32_t &total)
+{
+    if (lane == 0)
+        wsum[wave] = wave_total;
+    __syncthreads();
+    const uint4 *q = (const uint4 *)wsum;
+    const uint4 a = q[0], b = q[1], c = q[2], d = q[3];
+    const uint32_t v[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+    uint32_t bef = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        tot += v[w];
+        bef += w < wave ? v[w] : 0u;
+    }
+    before_wave = bef;
+    total = tot;
+}
+
+// min over the workgroup of one value per wave (the wave's lanes all pass the same value); wmin as wsum above
+__device__ __forceinline__ uint32_t read_min16(const uint32_t *w16)
+{
+    const uint4 *q = (const uint4 *)w16;
+    const uint4 a = q[0], b = q[1], c = q[2], d = q[3];
+    const uint32_t v[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+    uint32_t m = 0xffffffffu;
+#pragma unroll
+    for (int w = 0; w < 16; ++w)
+        m = v[w] < m ? v[w] : m;
+    return m;
+}
+
+__device__ __forceinline__ uint32_t block_min(uint32_t wave_val, uint32_t *wmin, int lane, int wave)
+{
+    if (lane == 0)
+        wmin[wave] = wave_val;
+    __syncthreads();
+    return read_min16(wmin);
+}
+
+// ---- LDS-DMA plumbing of the two walks ---------------------------------------------------------------------------------
+// A walk's inputs (stream words, candidates) are consumed strictly in order, a tile per trip round the loop, and a trip is a
+// few hundred cycles -- shorter than one HBM / Infinity-Cache round trip.  A register prefetch does not help (the compiler
+// waits for the register before the loop closes: the first version spent 1.4-2 us per trip waiting for its loads), so the
+// tiles are brought into an LDS ring by LDS-DMA (`global_load_lds_dword`: no register destination), several tiles ahead,
+// and retired by a counted `s_waitcnt vmcnt(N)` in front of a raw `s_barrier`; the ring is read one phase later
+// (cdna_hip_programming.md, "Read a staged buffer one phase AFTER the wait that retires it").  The statements are inline asm,
+// so the compiler neither counts nor drains them; nothing else in the loops loads from global memory.
+__device__ __forceinline__ void glds_dword(const void *gsrc, uint32_t lds_byte_addr)
+{
+    unsigned keep;
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_byte_addr); // M0: the wave's 256 destination bytes start here
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(dst)
+                 : "memory");
+}
+__device__ __forceinline__ uint32_t lds_addr(const void *p) { return (uint32_t)(uintptr_t)p; }
+template <int N> __device__ __forceinline__ void wait_vm_then_barrier()
+{
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// ---- phase 1a: candidates ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cand_count(const uint32_t *__restrict__ x, int64_t r0, int64_t n_words, uint32_t mask, uint32_t mx,
+                                                  uint32_t *__restrict__ counts)
+{
+    __shared__ uint32_t ws[4];
+    const int64_t at = (int64_t)blockIdx.x * CAND_BLK + (int64_t)threadIdx.x * 8;
+    uint32_t n = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (at + k < n_words)
+            n += (mt_temper(x[r0 + at + k]) & mask) <= mx;
+    for (int o = 32; o >= 1; o >>= 1)
+        n += __shfl_xor(n, o);
+    if ((threadIdx.x & 63) == 0)
+        ws[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        counts[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+// counts -> exclusive offsets (in place), total -> st->n_cand.  One workgroup of 1024 threads.
+__global__ __launch_bounds__(1024) void cand_scan(uint32_t *__restrict__ counts, int n_blocks, DsStatus *__restrict__ st)
+{
+    __shared__ __align__(16) uint32_t wsum[2][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint64_t carry = 0;
+    int par = 0;
+    for (int b0 = 0; b0 < n_blocks; b0 += 1024, par ^= 1) {
+        const uint32_t v = b0 + tid < n_blocks ? counts[b0 + tid] : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(incl, o);
+            if (lane >= o)
+                incl += t;
+        }
+        uint32_t before, total;
+        block_offsets(__shfl(incl, 63), wsum[par], lane, wave, before, total);
+        if (b0 + tid < n_blocks)
+            counts[b0 + tid] = (uint32_t)(carry + before + incl - v); // < 2^32: a compaction never covers more words than that
+        carry += total;
+    }
+    if (tid == 0)
+        st->n_cand = (int64_t)carry;
+}
+
+__global__ __launch_bounds__(256) void cand_scatter(const uint32_t *__restrict__ x, int64_t r0, int64_t n_words, uint32_t mask, uint32_t mx,
+                                                    const uint32_t *__restrict__ offs, int32_t *__restrict__ cand, uint32_t *__restrict__ cand_raw)
+{
+    __shared__ uint32_t ws[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t at = (int64_t)blockIdx.x * CAND_BLK + (int64_t)tid * 8;
+    uint32_t v[8];
+    uint32_t n = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        v[k] = 0xffffffffu;
+        if (at + k < n_words) {
+            const uint32_t t = mt_temper(x[r0 + at + k]) & mask;
+            if (t <= mx) {
+                v[k] = t;
+                ++n;
+            }
+        }
+    }
+    uint32_t incl = n;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o);
+        if (lane >= o)
+            incl += t;
+    }
+    if (lane == 63)
+        ws[wave] = incl;
+    __syncthreads();
+    uint32_t off = offs[blockIdx.x] + incl - n;
+    for (int w = 0; w < wave; ++w)
+        off += ws[w];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (v[k] != 0xffffffffu) {
+            cand[off] = (int32_t)v[k];
+            cand_raw[off] = (uint32_t)(r0 + at + k);
+            ++off;
+        }
+}
+
+// ---- the users' bitmaps of training items (once per data set) -----------------------------------------------------------
+__global__ __launch_bounds__(256) void build_bitmaps(const int64_t *__restrict__ ptr, const int32_t *__restrict__ items, int bw,
+                                                     uint32_t *__restrict__ bm)
+{
+    const int64_t k = blockIdx.x;
+    for (int64_t e = ptr[k] + threadIdx.x; e < ptr[k + 1]; e += 256) {
+        const int32_t it = items[e];
+        atomicOr(&bm[k * bw + (it >> 5)], 1u << (it & 31));
+    }
+}
+
+// ---- phase 1b ------------------------------------------------------------------------------------------------------
+struct NegArgs {
+    const int32_t *cand;
+    const uint32_t *cand_raw;
+    const int64_t *ptr;
+    int64_t n_users;
+    const uint32_t *bitmaps;
+    int bw, nbuf, nr;
+    int32_t *neg;
+    DsStatus *st;
+    int64_t raw_begin;
+};
+
+// PWORDS: bitmap words a thread moves per user (bw <= PWORDS * 1024)
+template <int PWORDS> __global__ __launch_bounds__(TILE) void neg_chain_general(NegArgs a)
+{
+    extern __shared__ uint32_t lds[];
+    uint32_t *bm = lds;                                     // nbuf x bw
+    int32_t *cbuf = (int32_t *)(bm + (((size_t)a.nbuf * a.bw + 1) & ~(size_t)1)); // CBUF
+    int32_t *D = cbuf + CBUF;                               // (nr - 1) + TILE: the accepted of a tile behind the last nr-1 of the tiles before
+    int64_t *uptr = (int64_t *)(D + ((a.nr - 1 + TILE + 1) & ~1)); // UCACHE + 1 (8-byte aligned: the sizes before it are even)
+    __shared__ __align__(16) uint32_t wsum[2][16], wmin[2][16], wneed[2][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nr = a.nr, bw = a.bw, nbuf = a.nbuf, CARRY = a.nr - 1;
+    const int64_t n_cand = a.st->n_cand;
+
+    int64_t filled = 0;
+    for (int f = 0; f < 3; ++f) {
+        const int64_t idx = filled + tid;
+        cbuf[idx & (CBUF - 1)] = idx < n_cand ? a.cand[idx] : 0;
+        filled += TILE;
+    }
+    int64_t kc0 = 0;
+    for (int t = tid; t <= UCACHE; t += TILE)
+        uptr[t] = kc0 + t <= a.n_users ? a.ptr[kc0 + t] : 0;
+    for (int s = 0; s < nbuf; ++s)
+        if (s < a.n_users)
+#pragma unroll
+            for (int j = 0; j < PWORDS; ++j) {
+                const int w = tid + j * TILE;
+                if (w < bw)
+                    bm[(size_t)s * bw + w] = a.bitmaps[(size_t)s * bw + w];
+            }
+    __syncthreads();
+
+    uint32_t pend[PWORDS];
+    int pend_slot = -1;
+    int64_t pos = 0, last = -1, iters = 0;
+    const uint64_t clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+    int par = 0;
+    bool failed = false;
+    for (int64_t k = 0; k < a.n_users && !failed; ++k) {
+        if (k - kc0 >= UCACHE) {
+            __syncthreads();
+            kc0 = k;
+            for (int t = tid; t <= UCACHE; t += TILE)
+                uptr[t] = kc0 + t <= a.n_users ? a.ptr[kc0 + t] : 0;
+            __syncthreads();
+        }
+        const int64_t p0 = uptr[k - kc0], p1 = uptr[k - kc0 + 1];
+        const int64_t need = (p1 - p0) * nr, base = p0 * nr;
+        const uint32_t *ubm = bm + (size_t)(k % nbuf) * bw;
+        int64_t done = 0;
+        while (done < need) {
+            if (pos >= n_cand) { // the compaction was sized too small for this epoch's rejections: the host doubles it and starts over
+                failed = true;
+                break;
+            }
+            const bool do_fill = filled - pos < 3 * TILE && filled < n_cand;
+            int32_t fillv = 0;
+            if (do_fill) {
+                const int64_t idx = filled + tid;
+                fillv = idx < n_cand ? a.cand[idx] : 0;
+            }
+            const int64_t gi = pos + tid;
+            const bool valid = gi < n_cand;
+            const int32_t c = cbuf[gi & (CBUF - 1)];
+            const bool f = valid && !((ubm[c >> 5] >> (c & 31)) & 1u);
+            const uint64_t mf = __ballot(f);
+            uint32_t before, total;
+            block_offsets((uint32_t)__popcll(mf), wsum[par], lane, wave, before, total);
+            const uint32_t p = before + lanes_below(mf);
+            const int64_t rem = need - done; // >= 1
+            const uint32_t dmod = (uint32_t)(done % nr);
+            bool dup = false;
+            if (nr > 1) {
+                if (f)
+                    D[CARRY + p] = c;
+                __syncthreads();
+                if (f && (int64_t)p < rem) {
+                    const int q = (int)((dmod + p) % (uint32_t)nr); // earlier members of this positive's group
+                    for (int jj = 1; jj <= q; ++jj)
+                        dup |= D[CARRY + (int)p - jj] == c;
+                }
+            }
+            // first repeat (with its rank) and the thread that holds the user's last slot
+            const uint64_t md = __ballot(dup), mn = __ballot(f && (int64_t)p == rem - 1);
+            uint32_t wd = 0xffffffffu, wn = 0xffffffffu;
+            if (md) {
+                const int l = __ffsll((unsigned long long)md) - 1;
+                wd = ((uint32_t)(wave * 64 + l) << 11) | __shfl(p, l);
+            }
+            if (mn)
+                wn = (uint32_t)(wave * 64 + __ffsll((unsigned long long)mn) - 1);
+            if (lane == 0)
+                wneed[par][wave] = wn;
+            const uint32_t dmin = block_min(wd, wmin[par], lane, wave); // its barrier also covers wneed
+            const uint32_t t_need = read_min16(wneed[par]);
+            const uint32_t t_dup = dmin == 0xffffffffu ? 0xffffffffu : (dmin >> 11);
+            int cut;
+            int64_t acc;
+            if (t_dup != 0xffffffffu && t_dup <= t_need) { // [0, t_dup) kept; the repeat is consumed and rejected
+                cut = (int)t_dup + 1;
+                acc = dmin & 2047u;
+            } else if (t_need != 0xffffffffu) {
+                cut = (int)t_need + 1;
+                acc = rem;
+            } else {
+                const int64_t left = n_cand - pos;
+                cut = left < TILE ? (int)left : TILE;
+                acc = total;
+            }
+            if (f && tid < cut && (int64_t)p < acc)
+                a.neg[base + done + p] = c;
+            if (nr > 1 && done + acc < need) { // the group in progress may reach back into this tile: keep its last nr-1 accepted
+                int32_t v = 0;
+                if (tid < CARRY)
+                    v = D[acc + tid];
+                __syncthreads();
+                if (tid < CARRY)
+                    D[tid] = v;
+            }
+            if (do_fill) {
+                cbuf[(filled + tid) & (CBUF - 1)] = fillv;
+                filled += TILE;
+            }
+            done += acc;
+            last = pos + cut - 1;
+            pos += cut;
+            par ^= 1;
+            ++iters;
+        }
+        // user k is done: its ring slot takes user k + nbuf.  The words loaded at the previous switch are stored now.
+        __syncthreads();
+        if (pend_slot >= 0)
+#pragma unroll
+            for (int j = 0; j < PWORDS; ++j) {
+                const int w = tid + j * TILE;
+                if (w < bw)
+                    bm[(size_t)pend_slot * bw + w] = pend[j];
+            }
+        pend_slot = -1;
+        if (k + nbuf < a.n_users) {
+#pragma unroll
+            for (int j = 0; j < PWORDS; ++j) {
+                const int w = tid + j * TILE;
+                pend[j] = w < bw ? a.bitmaps[(size_t)(k + nbuf) * bw + w] : 0u;
+            }
+            pend_slot = (int)(k % nbuf);
+        }
+    }
+    if (tid == 0) {
+        a.st->dbg[0] = iters;
+        a.st->dbg[1] = (int64_t)(__builtin_amdgcn_s_memtime() - clk0);
+        a.st->dbg[2] = (int64_t)(__builtin_amdgcn_s_memrealtime() - rt0);
+        a.st->cand_used = pos;
+        a.st->raw_next1 = last >= 0 ? (int64_t)a.cand_raw[last] + 1 : a.raw_begin;
+        if (failed)
+            a.st->status = DS_OUT_OF_CANDIDATES;
+    }
+}
+
+// ---- phase 1b, the form that runs wherever its limits allow (neg_ratio <= 33, item_nums <= 65536): ONE barrier per tile ------
+// Same rules as neg_chain_general above; what changes is how a trip round the loop is organised, because a trip IS the cost
+// (one link of the chain per tile, nothing to overlap it with):
+//  * candidates and the users' bitmaps arrive in LDS rings by LDS-DMA, several tiles / users ahead (plumbing above);
+//  * phase A of a tile (read candidate, test bitmap, ballot; per wave: count, ballot mask, its last nr-1 accepted values)
+//    is published before the trip's only barrier; behind it every thread reads all sixteen counts and knows its rank, the
+//    tile's total and -- by a select on the owning wave's mask -- where the user's last slot falls;
+//  * a repeat inside a positive's group is found by each thread for itself (the earlier members of its group are lanes of
+//    its own wave, the tail of an earlier wave, or the last nr-1 accepted of the tiles before: `carry`), but telling the
+//    other waves would take a second barrier -- so a tile is decided as if it had no repeat, the next tile is started from
+//    that state, and the repeat's position (an LDS atomic min) is looked at behind the NEXT barrier: if there was one, the
+//    state of the tile before is restored, cut right behind the repeat, and the walk goes on from there.  What the undone
+//    trips wrote lies at or behind the repeat's slot and is written again.  Side effects that cannot be undone (a finished
+//    user's ring slot handed to the user nbuf ahead) wait until the tile is confirmed.
+constexpr int NWAIT = 5;            // LDS-DMA operations that may stay in flight across a barrier
+constexpr int CRING = 16384;        // candidate ring
+constexpr int CDEPTH = NWAIT + 1;   // candidate fills ahead of the tile being read
+constexpr int FAST_NBUF = NWAIT + 3; // bitmap ring: a user's bitmap is requested nbuf users ahead; see the wait's comment
+constexpr int FAST_NR_MAX = 33;
+constexpr int FAST_BW_MAX = 2048;
+
+struct NegState {
+    int64_t k, pos, done, need, base;
+    uint32_t dmod;
+};
+
+__device__ __forceinline__ int select64(uint64_t m, int r) // position of the r-th set bit, r = 1 .. popcount(m)
+{
+    int pos = 0;
+    uint32_t lo = (uint32_t)m;
+    int c = __popc(lo);
+    if (r > c) {
+        r -= c;
+        pos = 32;
+        lo = (uint32_t)(m >> 32);
+    }
+#pragma unroll
+    for (int sh = 16; sh >= 1; sh >>= 1) {
+        c = __popc(lo & ((1u << sh) - 1u));
+        if (r > c) {
+            r -= c;
+            pos += sh;
+            lo >>= sh;
+        }
+    }
+    return pos;
+}
+
+__global__ __launch_bounds__(TILE) void neg_chain_fast(NegArgs a)
+{
+    extern __shared__ uint32_t lds[];
+    const int nr = a.nr, NRM = a.nr - 1, bw = a.bw, nbuf = a.nbuf;
+    // ONE shared object, carved: [bitmap ring][candidate ring][masks][counts][repeat words][tails][carry][CSR bounds]
+    // (every piece a whole number of 8-byte units: bw is a multiple of 64, tails + carry are 34 * NRM words)
+    uint32_t *bm = lds;
+    int32_t *cbuf = (int32_t *)(bm + (size_t)nbuf * bw);
+    uint64_t *msk = (uint64_t *)(cbuf + CRING);        // [2][16]
+    uint32_t *cnt = (uint32_t *)(msk + 32);            // [2][16]
+    uint32_t *dupw = cnt + 32;                         // [4]
+    int32_t *tail = (int32_t *)(dupw + 4);             // [2][16][NRM]
+    int32_t *carry = tail + 2 * 16 * NRM;              // [2][NRM]
+    int64_t *uptr = (int64_t *)(carry + 2 * NRM);      // [UCACHE + 1]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t n_cand = a.st->n_cand, n_users = a.n_users;
+    const uint64_t clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+    const uint32_t cbuf_at = lds_addr(cbuf), bm_at = lds_addr(bm);
+
+    int64_t filled = 0;
+    const auto fill = [&]() {
+        int64_t idx = filled + tid;
+        idx = idx < n_cand ? idx : (n_cand > 0 ? n_cand - 1 : 0);
+        glds_dword(a.cand + idx, cbuf_at + (uint32_t)(((filled + wave * 64) & (CRING - 1)) * 4));
+        filled += TILE;
+    };
+    // user u's bitmap -> ring slot u % nbuf; 64 words per wave and instruction.  Past the last user the request is still made
+    // (for the last user's words, into a slot nobody reads any more): the wait below counts on the requests that follow one
+    const auto load_bitmap = [&](int64_t u) {
+        const uint32_t slot_at = bm_at + (uint32_t)((u % nbuf) * bw * 4);
+        const int64_t src = u < n_users ? u : n_users - 1;
+        for (int w0 = wave * 64; w0 < bw; w0 += TILE)
+            glds_dword(a.bitmaps + (size_t)src * bw + w0 + lane, slot_at + (uint32_t)(w0 * 4));
+    };
+    for (int f = 0; f <= CDEPTH; ++f)
+        fill();
+    for (int u = 0; u < nbuf; ++u)
+        load_bitmap(u);
+    int64_t kc0 = 0;
+    for (int t = tid; t <= UCACHE; t += TILE)
+        uptr[t] = kc0 + t <= n_users ? a.ptr[kc0 + t] : 0;
+    if (tid < 4)
+        dupw[tid] = 0xffffffffu;
+    wait_vm_then_barrier<0>();
+
+    NegState st{0, 0, 0, 0, 0, 0u}, sv = st;
+    const auto enter_user = [&]() { // st.k -> the next user with slots to fill; its need and base
+        for (;;) {
+            if (st.k >= n_users) {
+                st.need = 0;
+                return;
+            }
+            if (st.k - kc0 >= UCACHE) { // (ordinary loads: drains the DMA queue; once per 1024 users)
+                lds_barrier();
+                kc0 = st.k;
+                for (int t = tid; t <= UCACHE; t += TILE)
+                    uptr[t] = kc0 + t <= n_users ? a.ptr[kc0 + t] : 0;
+                lds_barrier();
+            }
+            const int64_t p0 = uptr[st.k - kc0], p1 = uptr[st.k - kc0 + 1];
+            if (p1 > p0) {
+                st.need = (p1 - p0) * nr;
+                st.base = p0 * nr;
+                st.done = 0;
+                st.dmod = 0;
+                return;
+            }
+            ++st.k;
+        }
+    };
+    enter_user();
+
+    // per-thread memory of the tile whose repeats are still unknown to the other waves
+    int32_t c = 0, c_prev = 0;
+    bool f = false, f_prev = false;
+    uint32_t p_prev = 0, pw = 0;
+    uint64_t mf = 0;
+    int par = 0, cpar = 0;
+    int64_t kconf = 0, last = -1, iters = 0, redo = 0;
+    uint32_t it = 0;
+    bool failed = false, have_prev = false;
+
+    const auto phase_a = [&]() {
+        if (filled - st.pos < (int64_t)(CDEPTH + 1) * TILE && filled < n_cand)
+            fill();
+        const int64_t gi = st.pos + tid;
+        const bool valid = st.k < n_users && gi < n_cand;
+        c = cbuf[gi & (CRING - 1)];
+        const uint32_t *ubm = bm + (size_t)(st.k % nbuf) * bw;
+        f = valid && !((ubm[(uint32_t)c >> 5] >> (c & 31)) & 1u);
+        mf = __ballot(f);
+        const int cntw = __popcll(mf);
+        pw = lanes_below(mf);
+        if (lane == 0) {
+            cnt[par * 16 + wave] = (uint32_t)cntw;
+            msk[par * 16 + wave] = mf;
+        }
+        if (f && cntw - 1 - (int)pw < NRM) // the wave's last nr-1 accepted, the very last one at [NRM - 1]
+            tail[(par * 16 + wave) * NRM + NRM - 1 - (cntw - 1 - (int)pw)] = c;
+    };
+    // carry for the tile that follows a tile of `acc` accepted (of which thread-local rank / flag / value are given)
+    const auto write_carry = [&](int64_t acc, bool ff, uint32_t pp, int32_t cc, const int32_t *from, int32_t *to) {
+        if (ff && (int64_t)pp < acc && (int64_t)pp >= acc - NRM)
+            to[(int64_t)pp - (acc - NRM)] = cc;
+        if (tid < NRM && acc - NRM + tid < 0)
+            to[tid] = from[tid + acc];
+    };
+
+    phase_a();
+    for (;;) {
+        // The wait: everything but this wave's NWAIT youngest LDS-DMA operations has landed.  The candidates read behind this
+        // barrier were requested CDEPTH fills ago; a bitmap first read behind it was requested nbuf users ago and at least
+        // nbuf - 3 = NWAIT younger bitmap requests of the same waves follow it (requests are issued when a user is confirmed
+        // complete, two tiles behind the walk at most).
+        wait_vm_then_barrier<NWAIT>();
+        const uint32_t dprev = have_prev ? dupw[(it - 1) & 3] : 0xffffffffu;
+        if (dprev != 0xffffffffu) {
+            // the tile before had a repeat at thread t_d (rank p_d): undo, cut right behind it
+            const int64_t acc = dprev & 2047u;
+            const int cut = (int)(dprev >> 11) + 1;
+            st = sv;
+            write_carry(acc, f_prev, p_prev, c_prev, carry + (cpar ^ 1) * NRM, carry + cpar * NRM);
+            if (f_prev && (int64_t)p_prev < acc) // (already written by the undone trip; kept for clarity of the invariant)
+                a.neg[st.base + st.done + p_prev] = c_prev;
+            st.done += acc;
+            st.dmod = (uint32_t)((st.dmod + acc) % nr);
+            last = st.pos + cut - 1;
+            st.pos += cut;
+            have_prev = false; // the redone tile follows a confirmed state
+            ++redo;
+            par ^= 1;
+            ++it;
+            if (tid == 0)
+                dupw[(it + 1) & 3] = 0xffffffffu;
+            phase_a();
+            continue;
+        }
+        // the tile before is confirmed: users it completed hand their ring slots on
+        for (; kconf < st.k; ++kconf)
+            load_bitmap(kconf + nbuf);
+        if (st.k >= n_users)
+            break;
+        if (st.pos >= n_cand) { // the compaction was sized too small for this epoch's rejections: the host doubles it
+            failed = true;
+            break;
+        }
+        // ---- phase B ----
+        const uint4 *q4 = (const uint4 *)(cnt + par * 16);
+        const uint4 qa = q4[0], qb = q4[1], qc = q4[2], qd = q4[3];
+        const uint32_t s[16] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w, qc.x, qc.y, qc.z, qc.w, qd.x, qd.y, qd.z, qd.w};
+        const int64_t rem = st.need - st.done; // >= 1
+        uint32_t before = 0, total = 0;
+        int wt = -1;
+        uint32_t before_wt = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            if (wt < 0 && (int64_t)(total + s[w]) >= rem) {
+                wt = w;
+                before_wt = total;
+            }
+            before += w < wave ? s[w] : 0u;
+            total += s[w];
+        }
+        const uint32_t p = before + pw;
+        int cut;
+        int64_t acc;
+        if (wt >= 0) { // the user's last slot falls into wave wt
+            const uint64_t m = msk[par * 16 + wt];
+            cut = wt * 64 + select64(m, (int)(rem - before_wt)) + 1;
+            acc = rem;
+        } else {
+            const int64_t left = n_cand - st.pos;
+            cut = left < TILE ? (int)left : TILE;
+            acc = total;
+        }
+        // repeats inside a positive's group (sampler.py:24,59,88)
+        if (NRM > 0 && f && (int64_t)p < rem) {
+            const int q = (int)((st.dmod + p) % (uint32_t)nr);
+            uint64_t below = mf & ((1ull << lane) - 1ull);
+            int wq = wave, rr = 0; // once the own wave is used up: rr = -(members still to visit), relative to wave wq's end
+            bool dup = false;
+            for (int jj = 1; jj <= q; ++jj) {
+                int32_t v;
+                if (below) {
+                    const int b = 63 - __clzll((long long)below);
+                    below &= ~(1ull << b);
+                    v = cbuf[(st.pos + wave * 64 + b) & (CRING - 1)];
+                } else {
+                    if (rr == 0) {
+                        rr = -1;
+                        wq = wave - 1;
+                    } else {
+                        --rr;
+                    }
+                    while (wq >= 0 && rr + (int)cnt[par * 16 + wq] < 0) {
+                        rr += (int)cnt[par * 16 + wq];
+                        --wq;
+                    }
+                    v = wq >= 0 ? tail[(par * 16 + wq) * NRM + NRM + rr] : carry[cpar * NRM + NRM + rr];
+                }
+                dup |= v == c;
+            }
+            if (dup)
+                atomicMin(&dupw[it & 3], ((uint32_t)tid << 11) | p);
+        }
+        if (f && tid < cut && (int64_t)p < acc)
+            a.neg[st.base + st.done + p] = c;
+        if (NRM > 0 && st.done + acc < st.need)
+            write_carry(acc, f, p, c, carry + cpar * NRM, carry + (cpar ^ 1) * NRM);
+        cpar ^= 1;
+        // remember the tile until its repeats are known, then move on as if it had none
+        sv = st;
+        c_prev = c, f_prev = f, p_prev = p;
+        have_prev = true;
+        st.done += acc;
+        st.dmod = (uint32_t)((st.dmod + acc) % nr);
+        last = st.pos + cut - 1;
+        st.pos += cut;
+        if (st.done >= st.need) {
+            ++st.k;
+            enter_user();
+        }
+        if (tid == 0)
+            dupw[(it + 2) & 3] = 0xffffffffu; // the word two tiles ahead: its last reader passed a barrier ago
+        par ^= 1;
+        ++it;
+        ++iters;
+        phase_a();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // no LDS-DMA may be in flight when the workgroup ends
+    if (tid == 0) {
+        a.st->dbg[0] = iters + (redo << 32);
+        a.st->dbg[1] = (int64_t)(__builtin_amdgcn_s_memtime() - clk0);
+        a.st->dbg[2] = (int64_t)(__builtin_amdgcn_s_memrealtime() - rt0);
+        a.st->cand_used = st.pos;
+        a.st->raw_next1 = last >= 0 ? (int64_t)a.cand_raw[last] + 1 : a.raw_begin;
+        if (failed)
+            a.st->status = DS_OUT_OF_CANDIDATES;
+    }
+}
+
+// ---- phase 2 -------------------------------------------------------------------------------------------------------
+constexpr int XRING = 16384; // stream words in the LDS ring of perm_targets
+constexpr int XDEPTH = 6;    // fills ahead of the tile being read (the tile's own stores share the queue: about half of them stay in flight)
+struct PermLds {
+    uint32_t ring[XRING];
+    uint32_t wsum[2][16];
+    int cut_at[2];
+};
+
+// tgt[i], i = n-1 .. 1: the swap target of step i of the legacy shuffle.  Also leaves the generator's final state.
+__global__ __launch_bounds__(TILE) void perm_targets(const uint32_t *__restrict__ x, int64_t x_words, int64_t n, uint32_t *__restrict__ tgt,
+                                                     DsStatus *__restrict__ st)
+{
+    __shared__ __align__(16) PermLds L; // ONE shared object (a second one beside an LDS-DMA target can cost a vmcnt(0) per read)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (st->status != DS_OK)
+        return;
+    int64_t w = st->raw_next1;
+    int64_t i = n - 1, iters = 0;
+    int par = 0;
+    bool failed = false;
+    const uint64_t clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+    const uint32_t ring_at = lds_addr(L.ring);
+    int64_t filled = w & ~(int64_t)63; // the ring holds stream words [.., filled); a wave's 64 words never wrap
+    const auto fill = [&]() {
+        int64_t idx = filled + tid;
+        idx = idx < x_words ? idx : x_words - 1;
+        glds_dword(x + idx, ring_at + (uint32_t)(((filled + wave * 64) & (XRING - 1)) * 4));
+        filled += TILE;
+    };
+    for (int f = 0; f <= XDEPTH + 1; ++f)
+        fill();
+    wait_vm_then_barrier<0>();
+    while (i >= 1) {
+        if (w >= x_words) {
+            failed = true;
+            break;
+        }
+        // one tile consumed per trip at most, so one fill per trip keeps filled - w >= (XDEPTH + 1) tiles (+ the 63 words `filled`
+        // may start below w): the next trip's tile ends at or before w + 2 * TILE <= filled - (XDEPTH - 1) * TILE, i.e. before
+        // the XDEPTH - 1 fills that the wait below may leave in flight
+        if (filled - w < (XDEPTH + 1) * TILE + 64)
+            fill();
+        const int64_t left = x_words - w;
+        const int navail = left < TILE ? (int)left : TILE;
+        const uint32_t mask = mask_of((uint32_t)i);
+        const int64_t room = i - (int64_t)(mask >> 1); // steps left before the mask changes: i .. (mask >> 1) + 1
+        const bool valid = tid < navail;
+        const int64_t v = mt_temper(L.ring[(w + tid) & (XRING - 1)]) & mask;
+        bool acc = valid && v <= i - tid; // even if every word before it in the tile is accepted
+        bool amb = valid && !acc && v <= i;
+        uint32_t Lc = 0, tot = 0;
+        for (int round = 0;; ++round) {
+            if (round > TILE + 2) { // every round settles at least the first undecided word: cannot happen
+                failed = true;
+                break;
+            }
+            const uint64_t ma = __ballot(acc), mb = __ballot(amb);
+            if (lane == 0)
+                L.wsum[par][wave] = (uint32_t)__popcll(ma) | ((uint32_t)__popcll(mb) << 16);
+            // all fills but the XDEPTH-1 youngest have landed once every wave is past this barrier: the tile of the NEXT trip
+            wait_vm_then_barrier<XDEPTH - 1>();
+            const uint4 *q = (const uint4 *)L.wsum[par];
+            const uint4 a = q[0], b = q[1], c = q[2], d = q[3];
+            const uint32_t s[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+            uint32_t before = 0, total = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                total += s[k];
+                before += k < wave ? s[k] : 0u;
+            }
+            par ^= 1;
+            Lc = (before & 0xffffu) + lanes_below(ma);
+            tot = total & 0xffffu;
+            if ((total >> 16) == 0)
+                break;
+            if (amb) {
+                const uint32_t U = Lc + (before >> 16) + lanes_below(mb);
+                if (v <= i - (int64_t)U) {
+                    acc = true;
+                    amb = false;
+                } else if (v > i - (int64_t)Lc) {
+                    amb = false;
+                }
+            }
+        }
+        if (failed)
+            break;
+        int e = navail;
+        if ((int64_t)tot >= room) { // cut right behind the room-th accepted word: what follows is judged under the next mask
+            if (acc && (int64_t)Lc == room - 1)
+                L.cut_at[par] = tid + 1;
+            lds_barrier();
+            e = L.cut_at[par];
+            tot = (uint32_t)room;
+        }
+        if (acc && tid < e && Lc < tot)
+            tgt[i - Lc] = (uint32_t)v;
+        i -= tot;
+        w += e;
+        ++iters;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // no LDS-DMA may be in flight when the workgroup ends
+    if (failed) {
+        if (tid == 0)
+            st->status = w >= x_words ? DS_OUT_OF_WORDS : DS_INTERNAL;
+        return;
+    }
+    // RandomState afterwards: `pos` words of block b consumed; a block that is used up stays (pos = 624) until the next draw
+    const int64_t b = (w % MT_N == 0 && w > 0) ? w / MT_N - 1 : w / MT_N;
+    if (tid < MT_N)
+        st->key_out[tid] = x[b * MT_N + tid];
+    if (tid == 0) {
+        st->pos_out = (int32_t)(w - b * MT_N);
+        st->raw_next2 = w;
+        st->dbg[3] = iters;
+        st->dbg[4] = (int64_t)(__builtin_amdgcn_s_memtime() - clk0);
+        st->dbg[5] = (int64_t)(__builtin_amdgcn_s_memrealtime() - rt0);
+    }
+}
+
+// ---- phase 3 -------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void perm_keys(const uint32_t *__restrict__ tgt, int64_t n, uint32_t *__restrict__ key, uint32_t *__restrict__ val,
+                                                 int32_t *__restrict__ head)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n)
+        return;
+    const uint32_t t = i == 0 ? (uint32_t)n : tgt[i];
+    key[i] = (i == 0 || t == (uint32_t)i) ? (uint32_t)n : t; // step 0 does not exist; a self-swap moves nothing
+    val[i] = (uint32_t)i;
+    head[i] = NONE;
+}
+
+// sorted by (target, step): head[p] = first step that targets p, nxt[i] = the next step with step i's target
+__global__ __launch_bounds__(256) void perm_links(const uint32_t *__restrict__ skey, const uint32_t *__restrict__ sval, int64_t n,
+                                                  int32_t *__restrict__ head, int32_t *__restrict__ nxt)
+{
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= n)
+        return;
+    const uint32_t p = skey[q], i = sval[q];
+    if (p >= (uint32_t)n) {
+        nxt[i] = NONE;
+        return;
+    }
+    if (q == 0 || skey[q - 1] != p)
+        head[p] = (int32_t)i;
+    nxt[i] = (q + 1 < n && skey[q + 1] == p) ? (int32_t)sval[q + 1] : NONE;
+}
+
+struct GatherArgs {
+    const uint32_t *tgt;
+    const int32_t *head, *nxt;
+    int64_t n;
+    int kind, nr;
+    const int32_t *edge_user, *items, *neg;
+    int32_t *u, *i;
+    void *third;
+};
+
+// perm[k] by the chase, then row perm[k] of the unshuffled sample (sampler.py:38,69,97)
+__global__ __launch_bounds__(256) void perm_gather(GatherArgs a)
+{
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= a.n)
+        return;
+    int64_t s;
+    const uint32_t t = k == 0 ? 0u : a.tgt[k];
+    int32_t xi = (k == 0 || t == (uint32_t)k) ? (int32_t)k : a.nxt[k];
+    if (xi == NONE) {
+        s = t; // nobody touched the target before step k: it still holds its own index
+    } else {
+        for (int64_t hops = 0; hops < a.n; ++hops) { // the pointers lead to ever larger steps: the bound is never reached
+            const int32_t h = a.head[xi];
+            if (h == NONE)
+                break;
+            xi = h;
+        }
+        s = xi;
+    }
+    const int nr = a.nr;
+    if (a.kind == 0) { // pairwise: row s = (positive s / nr, its (s % nr)-th negative)
+        const int64_t e = s / nr;
+        a.u[k] = a.edge_user[e];
+        a.i[k] = a.items[e];
+        ((int32_t *)a.third)[k] = a.neg[s];
+    } else if (a.kind == 1) { // pointwise: row s = positive e (t == 0, label 1) or its (t-1)-th negative (label 0)
+        const int64_t w = 1 + nr, e = s / w, tt = s - e * w;
+        a.u[k] = a.edge_user[e];
+        a.i[k] = tt == 0 ? a.items[e] : a.neg[e * nr + (tt - 1)];
+        ((float *)a.third)[k] = tt == 0 ? 1.0f : 0.0f;
+    } else { // cml: row s = positive s with its nr negatives
+        a.u[k] = a.edge_user[s];
+        a.i[k] = a.items[s];
+        int32_t *row = (int32_t *)a.third + k * nr;
+        for (int q = 0; q < nr; ++q)
+            row[q] = a.neg[s * nr + q];
+    }
+}
+
+} // namespace
+
+// ---- the object behind the C ABI ---------------------------------------------------------------------------------------
+struct crec_dsampler {
+    int device = -1;
+    int64_t n_users = 0, n_pos = 0;
+    int32_t item_nums = 0;
+    int bw = 0, nbuf = 0, pwords = 1;
+    int64_t max_uniq = 0;
+    double s1 = 0; // sum over users of deg / (item_nums - distinct items): expected candidates per unit of neg_ratio
+    crec_devbuf ptr, items, edge_user, bitmaps, polys;
+    crec_devbuf x, base, next_key, cand, cand_raw, counts, neg, tgt, key, val, skey, sval, head, nxt, sort_tmp, status;
+    DsStatus *status_host = nullptr; // page-locked
+    hipEvent_t done = nullptr;
+    bool pending = false;
+    // the call in flight (for the retry with larger budgets)
+    int kind = 0, nr = 0;
+    uint32_t key_in[MT_N];
+    int32_t pos_in = 0;
+    int32_t *u = nullptr, *i = nullptr;
+    void *third = nullptr;
+    hipStream_t stream = nullptr;
+    double growth = 1.0;
+    int64_t n = 0, raw_next1_in = 0;
+};
+
+namespace {
+
+double harmonic_span(int64_t lo, int64_t hi) // sum_{i=lo}^{hi} 1 / (i + 1)
+{
+    if (hi < lo)
+        return 0;
+    if (hi - lo < 64) {
+        double s = 0;
+        for (int64_t i = lo; i <= hi; ++i)
+            s += 1.0 / (double)(i + 1);
+        return s;
+    }
+    return std::log(((double)hi + 1.5) / ((double)lo + 0.5));
+}
+
+// expected words of np.random.permutation(n): per step i one draw accepted with probability (i + 1) / (mask(i) + 1)
+double expected_shuffle_words(int64_t n)
+{
+    double s = 0;
+    int64_t hi = n - 1;
+    while (hi >= 1) {
+        const uint32_t m = mask_of((uint32_t)hi);
+        const int64_t lo = (int64_t)(m >> 1) + 1;
+        s += ((double)m + 1.0) * harmonic_span(lo, hi);
+        hi = lo - 1;
+    }
+    return s;
+}
+
+int free_bufs(crec_dsampler *s)
+{
+    crec_devbuf *bufs[] = {&s->ptr, &s->items, &s->edge_user, &s->bitmaps, &s->polys, &s->x, &s->base, &s->next_key, &s->cand, &s->cand_raw,
+                           &s->counts, &s->neg, &s->tgt, &s->key, &s->val, &s->skey, &s->sval, &s->head, &s->nxt, &s->sort_tmp, &s->status};
+    for (crec_devbuf *b : bufs)
+        if (b->ptr) {
+            (void)hipFree(b->ptr);
+            b->ptr = nullptr;
+            b->bytes = 0;
+        }
+    if (s->status_host)
+        (void)hipHostFree(s->status_host);
+    if (s->done)
+        (void)hipEventDestroy(s->done);
+    return 0;
+}
+
+// everything of one sample, enqueued on s->stream
+int enqueue(crec_ctx *ctx, crec_dsampler *s)
+{
+    hipStream_t st = s->stream;
+    const int nr = s->nr;
+    const int64_t n_pos = s->n_pos, n = s->n, n_neg = n_pos * nr;
+    const uint32_t mx = (uint32_t)(s->item_nums - 1), mask = mask_of(mx);
+    // budgets: expectation + slack, grown on a retry
+    const double e1 = nr > 0 ? (double)nr * ((double)mask + 1.0) * s->s1 : 0.0;
+    int64_t w1 = nr > 0 ? (int64_t)((e1 * 1.02 + 8.0 * std::sqrt(e1 + 1.0) + 4096.0) * s->growth) : 0;
+    w1 = crec_ceil_div(w1, CAND_BLK) * CAND_BLK;
+    const double e2 = expected_shuffle_words(n);
+    const int64_t w2 = (int64_t)((e2 * 1.02 + 8.0 * std::sqrt(e2 + 1.0) + 4096.0) * s->growth);
+    const int64_t x_blocks = crec_ceil_div((int64_t)s->pos_in + w1 + w2, MT_N) + 1;
+    const int64_t x_words = x_blocks * MT_N;
+    CREC_REQUIRE(ctx, x_words < ((int64_t)1 << 32) && w1 < ((int64_t)1 << 32), "epoch needs more than 2^32 stream words");
+    const int64_t cand_blocks = w1 / CAND_BLK;
+    if (int rc = crec_reserve(ctx, &s->x, (size_t)x_words * 4))
+        return rc;
+    if (int rc = crec_reserve(ctx, &s->cand, (size_t)(w1 + 1) * 4))
+        return rc;
+    if (int rc = crec_reserve(ctx, &s->cand_raw, (size_t)(w1 + 1) * 4))
+        return rc;
+    if (int rc = crec_reserve(ctx, &s->counts, (size_t)(cand_blocks + 1) * 4))
+        return rc;
+    if (int rc = crec_reserve(ctx, &s->neg, (size_t)(n_neg + 1) * 4))
+        return rc;
+    for (crec_devbuf *b : {&s->tgt, &s->key, &s->val, &s->skey, &s->sval, &s->nxt})
+        if (int rc = crec_reserve(ctx, b, (size_t)(n + 1) * 4))
+            return rc;
+    if (int rc = crec_reserve(ctx, &s->head, (size_t)(n + 2) * 4))
+        return rc;
+    unsigned sort_bits = 1;
+    while (sort_bits < 32 && ((uint64_t)1 << sort_bits) <= (uint64_t)n)
+        ++sort_bits;
+    size_t tmp_bytes = 0;
+    if (n > 1) {
+        CREC_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, (const uint32_t *)s->key.ptr, (uint32_t *)s->skey.ptr, (const uint32_t *)s->val.ptr,
+                                                (uint32_t *)s->sval.ptr, (size_t)n, 0u, sort_bits, st));
+        if (int rc = crec_reserve(ctx, &s->sort_tmp, tmp_bytes + 16))
+            return rc;
+    }
+    DsStatus *dst = (DsStatus *)s->status.ptr;
+    CREC_HIP(ctx, hipMemsetAsync(dst, 0, sizeof(DsStatus), st));
+    uint32_t *x = (uint32_t *)s->x.ptr;
+
+    // phase 0: the raw stream, super-block by super-block
+    CREC_HIP(ctx, hipMemcpyAsync(s->next_key.ptr, s->key_in, sizeof(s->key_in), hipMemcpyHostToDevice, st));
+    constexpr int64_t SB_BLOCKS = (int64_t)crec_mtj::T * crec_mtj::LB;
+    const size_t chain_lds = (size_t)(crec_mtj::DEG + MT_N + 2 * MT_N) * 4 + (size_t)crec_mtj::DEG * 2 + 64;
+    CREC_HIP(ctx, hipFuncSetAttribute((const void *)mt_chains, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain_lds));
+    for (int64_t b0 = 0; b0 < x_blocks; b0 += SB_BLOCKS) {
+        const int64_t blocks = (x_blocks - b0) < SB_BLOCKS ? (x_blocks - b0) : SB_BLOCKS;
+        const int n_chains = (int)crec_ceil_div(blocks, crec_mtj::LB);
+        const bool more = b0 + SB_BLOCKS < x_blocks;
+        hipLaunchKernelGGL(mt_base, dim3(1), dim3(256), 0, st, (const uint32_t *)s->next_key.ptr, (uint32_t *)s->base.ptr, crec_mtj::BASE_BLOCKS);
+        hipLaunchKernelGGL(mt_chains, dim3(n_chains + (more ? 1 : 0)), dim3(CHAIN_THREADS), chain_lds, st, (const uint32_t *)s->base.ptr,
+                           (const uint32_t *)s->polys.ptr, x + (size_t)b0 * MT_N, blocks, n_chains, more ? (uint32_t *)s->next_key.ptr : nullptr);
+    }
+    CREC_HIP(ctx, hipGetLastError());
+
+    // phase 1
+    const int64_t r0 = s->pos_in;
+    if (nr > 0 && n_pos > 0) {
+        hipLaunchKernelGGL(cand_count, dim3((unsigned)cand_blocks), dim3(256), 0, st, (const uint32_t *)x, r0, w1, mask, mx, (uint32_t *)s->counts.ptr);
+        hipLaunchKernelGGL(cand_scan, dim3(1), dim3(1024), 0, st, (uint32_t *)s->counts.ptr, (int)cand_blocks, dst);
+        hipLaunchKernelGGL(cand_scatter, dim3((unsigned)cand_blocks), dim3(256), 0, st, (const uint32_t *)x, r0, w1, mask, mx,
+                           (const uint32_t *)s->counts.ptr, (int32_t *)s->cand.ptr, (uint32_t *)s->cand_raw.ptr);
+        NegArgs na{(const int32_t *)s->cand.ptr, (const uint32_t *)s->cand_raw.ptr, (const int64_t *)s->ptr.ptr, s->n_users,
+                   (const uint32_t *)s->bitmaps.ptr, s->bw, s->nbuf, nr, (int32_t *)s->neg.ptr, dst, r0};
+        if (nr <= FAST_NR_MAX && s->bw <= FAST_BW_MAX && !ctx->knob_dsampler_general) {
+            na.nbuf = FAST_NBUF;
+            const size_t lds = ((size_t)FAST_NBUF * s->bw + CRING + 34 * (size_t)(nr - 1) + 32 + 4) * 4 + 32 * 8 + (size_t)(UCACHE + 1) * 8;
+            CREC_HIP(ctx, hipFuncSetAttribute((const void *)neg_chain_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(neg_chain_fast, dim3(1), dim3(TILE), lds, st, na);
+        } else {
+            const size_t lds = ((((size_t)s->nbuf * s->bw + 1) & ~(size_t)1) + CBUF + ((nr - 1 + TILE + 1) & ~1)) * 4 + (size_t)(UCACHE + 1) * 8;
+            if (s->pwords == 1) {
+                CREC_HIP(ctx, hipFuncSetAttribute((const void *)neg_chain_general<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(neg_chain_general<1>, dim3(1), dim3(TILE), lds, st, na);
+            } else {
+                CREC_HIP(ctx, hipFuncSetAttribute((const void *)neg_chain_general<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(neg_chain_general<8>, dim3(1), dim3(TILE), lds, st, na);
+            }
+        }
+    } else {
+        // no draws in phase 1: phase 2 starts where the generator stands
+        s->raw_next1_in = r0; // lives in the object: the copy is asynchronous
+        CREC_HIP(ctx, hipMemcpyAsync(&dst->raw_next1, &s->raw_next1_in, sizeof(int64_t), hipMemcpyHostToDevice, st));
+    }
+    // phase 2 (also leaves the final generator state)
+    hipLaunchKernelGGL(perm_targets, dim3(1), dim3(TILE), 0, st, (const uint32_t *)x, x_words, n, (uint32_t *)s->tgt.ptr, dst);
+    // phase 3
+    if (n > 0) {
+        const unsigned g = (unsigned)crec_ceil_div(n, 256);
+        hipLaunchKernelGGL(perm_keys, dim3(g), dim3(256), 0, st, (const uint32_t *)s->tgt.ptr, n, (uint32_t *)s->key.ptr, (uint32_t *)s->val.ptr,
+                           (int32_t *)s->head.ptr);
+        const uint32_t *skey = (const uint32_t *)s->key.ptr, *sval = (const uint32_t *)s->val.ptr;
+        if (n > 1) {
+            CREC_HIP(ctx, rocprim::radix_sort_pairs(s->sort_tmp.ptr, tmp_bytes, (const uint32_t *)s->key.ptr, (uint32_t *)s->skey.ptr,
+                                                    (const uint32_t *)s->val.ptr, (uint32_t *)s->sval.ptr, (size_t)n, 0u, sort_bits, st));
+            skey = (const uint32_t *)s->skey.ptr;
+            sval = (const uint32_t *)s->sval.ptr;
+        }
+        hipLaunchKernelGGL(perm_links, dim3(g), dim3(256), 0, st, skey, sval, n, (int32_t *)s->head.ptr, (int32_t *)s->nxt.ptr);
+        GatherArgs ga{(const uint32_t *)s->tgt.ptr, (const int32_t *)s->head.ptr, (const int32_t *)s->nxt.ptr, n, s->kind, nr,
+                      (const int32_t *)s->edge_user.ptr, (const int32_t *)s->items.ptr, (const int32_t *)s->neg.ptr, s->u, s->i, s->third};
+        hipLaunchKernelGGL(perm_gather, dim3(g), dim3(256), 0, st, ga);
+    }
+    CREC_HIP(ctx, hipGetLastError());
+    CREC_HIP(ctx, hipMemcpyAsync(s->status_host, dst, sizeof(DsStatus), hipMemcpyDeviceToHost, st));
+    CREC_HIP(ctx, hipEventRecord(s->done, st));
+    s->pending = true;
+    return CREC_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int crec_dsampler_create(crec_ctx *ctx, const int64_t *ptr, const int32_t *items, int64_t n_users, const int32_t *user_ids, int32_t item_nums,
+                         crec_dsampler **out, void *stream)
+{
+    if (!ctx)
+        return CREC_EINVAL;
+    CREC_REQUIRE(ctx, ctx->device >= 0, "host-only ctx: no device bound");
+    CREC_REQUIRE(ctx, ptr && user_ids && out && n_users >= 0 && item_nums >= 1, "null argument / bad sizes");
+    *out = nullptr;
+    const int64_t n_pos = ptr[n_users];
+    CREC_REQUIRE(ctx, items || n_pos == 0, "null items");
+    for (int64_t k = 0; k < n_users; ++k)
+        CREC_REQUIRE(ctx, ptr[k + 1] >= ptr[k], "ptr not monotone at %lld", (long long)k);
+    // what the kernels are built for; anything else stays with the host sampler (crec_sample_*)
+    const int bw = (int)(crec_ceil_div(crec_ceil_div(item_nums, 32), 64) * 64); // words per bitmap row, whole 64-word LDS-DMA pieces
+    if (bw > 8 * TILE || (double)n_users * bw * 4.0 > 2147483648.0)
+        return crec_fail(ctx, CREC_EUNSUPPORTED, "device sampler: item_nums <= 262144 and users x items / 8 <= 2 GiB (use crec_sample_*)");
+    std::vector<int32_t> stamp, eu;
+    try {
+        stamp.assign((size_t)item_nums, 0);
+        eu.resize((size_t)(n_pos > 0 ? n_pos : 1));
+    } catch (...) {
+        return crec_fail(ctx, CREC_ENOMEM, "host allocation failed");
+    }
+    double s1 = 0;
+    int64_t max_uniq = 0;
+    for (int64_t k = 0; k < n_users; ++k) {
+        int64_t uniq = 0;
+        for (int64_t e = ptr[k]; e < ptr[k + 1]; ++e) {
+            CREC_REQUIRE(ctx, items[e] >= 0 && items[e] < item_nums, "item id %d out of range", items[e]);
+            uniq += stamp[items[e]] != (int32_t)(k + 1);
+            stamp[items[e]] = (int32_t)(k + 1);
+            eu[(size_t)e] = user_ids[k];
+        }
+        max_uniq = uniq > max_uniq ? uniq : max_uniq;
+        if (uniq < item_nums)
+            s1 += (double)(ptr[k + 1] - ptr[k]) / (double)(item_nums - uniq);
+    }
+    const char *jerr = nullptr;
+    const uint32_t *tab = crec_mtj::jump_table(&jerr);
+    if (!tab)
+        return crec_fail(ctx, CREC_EINVAL, "%s", jerr ? jerr : "MT19937 jump table unavailable");
+    crec_dsampler *s = new (std::nothrow) crec_dsampler();
+    if (!s)
+        return crec_fail(ctx, CREC_ENOMEM, "host allocation failed");
+    s->device = ctx->device;
+    s->n_users = n_users, s->n_pos = n_pos, s->item_nums = item_nums, s->bw = bw, s->max_uniq = max_uniq, s->s1 = s1;
+    s->pwords = bw <= TILE ? 1 : 8;
+    {
+        const int fit = (int)((96 * 1024) / ((size_t)bw * 4)); // ring of bitmaps: as many users ahead as 96 KB hold, 3 .. 6
+        s->nbuf = fit < 3 ? 3 : (fit > 6 ? 6 : fit);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const auto fail = [&](int rc) {
+        free_bufs(s);
+        delete s;
+        return rc;
+    };
+#define DS_TRY(expr)               \
+    do {                           \
+        if (int rc_ = (expr))      \
+            return fail(rc_);      \
+    } while (0)
+#define DS_HIP(call)                                                                                        \
+    do {                                                                                                    \
+        hipError_t e_ = (call);                                                                             \
+        if (e_ != hipSuccess)                                                                               \
+            return fail(crec_fail(ctx, CREC_EHIP, "%s failed: %s", #call, hipGetErrorString(e_)));          \
+    } while (0)
+    DS_HIP(hipSetDevice(ctx->device));
+    DS_TRY(crec_reserve(ctx, &s->ptr, (size_t)(n_users + 1) * 8));
+    DS_TRY(crec_reserve(ctx, &s->items, (size_t)(n_pos + 1) * 4));
+    DS_TRY(crec_reserve(ctx, &s->edge_user, (size_t)(n_pos + 1) * 4));
+    DS_TRY(crec_reserve(ctx, &s->bitmaps, (size_t)(n_users + 1) * bw * 4));
+    DS_TRY(crec_reserve(ctx, &s->polys, (size_t)crec_mtj::T * crec_mtj::POLY_WORDS * 4));
+    DS_TRY(crec_reserve(ctx, &s->base, (size_t)crec_mtj::BASE_BLOCKS * MT_N * 4));
+    DS_TRY(crec_reserve(ctx, &s->next_key, (size_t)MT_N * 4));
+    DS_TRY(crec_reserve(ctx, &s->status, sizeof(DsStatus)));
+    DS_HIP(hipHostMalloc((void **)&s->status_host, sizeof(DsStatus), hipHostMallocDefault));
+    DS_HIP(hipEventCreateWithFlags(&s->done, hipEventDisableTiming));
+    DS_HIP(hipMemcpyAsync(s->ptr.ptr, ptr, (size_t)(n_users + 1) * 8, hipMemcpyHostToDevice, st));
+    if (n_pos > 0) {
+        DS_HIP(hipMemcpyAsync(s->items.ptr, items, (size_t)n_pos * 4, hipMemcpyHostToDevice, st));
+        DS_HIP(hipMemcpyAsync(s->edge_user.ptr, eu.data(), (size_t)n_pos * 4, hipMemcpyHostToDevice, st));
+    }
+    DS_HIP(hipMemcpyAsync(s->polys.ptr, tab, (size_t)crec_mtj::T * crec_mtj::POLY_WORDS * 4, hipMemcpyHostToDevice, st));
+    DS_HIP(hipMemsetAsync(s->bitmaps.ptr, 0, (size_t)(n_users + 1) * bw * 4, st));
+    if (n_users > 0 && n_pos > 0)
+        hipLaunchKernelGGL(build_bitmaps, dim3((unsigned)n_users), dim3(256), 0, st, (const int64_t *)s->ptr.ptr, (const int32_t *)s->items.ptr, bw,
+                           (uint32_t *)s->bitmaps.ptr);
+    DS_HIP(hipGetLastError());
+    DS_HIP(hipStreamSynchronize(st)); // eu / the caller's arrays may go away
+#undef DS_TRY
+#undef DS_HIP
+    *out = s;
+    return CREC_OK;
+}
+
+void crec_dsampler_destroy(crec_dsampler *s)
+{
+    if (!s)
+        return;
+    if (s->device >= 0) {
+        (void)hipSetDevice(s->device);
+        if (s->pending && s->done)
+            (void)hipEventSynchronize(s->done);
+    }
+    free_bufs(s);
+    delete s;
+}
+
+int crec_dsampler_sample(crec_ctx *ctx, crec_dsampler *s, int kind, int neg_ratio, const uint32_t key[624], int32_t pos, int32_t *u, int32_t *i,
+                         void *third, void *stream)
+{
+    if (!ctx)
+        return CREC_EINVAL;
+    CREC_REQUIRE(ctx, s && key && pos >= 0 && pos <= MT_N, "null sampler / bad MT19937 state");
+    CREC_REQUIRE(ctx, kind >= 0 && kind <= 2 && neg_ratio >= 0 && neg_ratio <= 1024, "kind 0..2, 0 <= neg_ratio <= 1024");
+    CREC_REQUIRE(ctx, !s->pending, "the previous sample has not been finished (crec_dsampler_finish)");
+    const int64_t n = kind == 0 ? s->n_pos * neg_ratio : (kind == 1 ? s->n_pos * (1 + (int64_t)neg_ratio) : s->n_pos);
+    CREC_REQUIRE(ctx, n == 0 || (u && i && third), "null output");
+    CREC_REQUIRE(ctx, n < ((int64_t)1 << 31), "epoch too large for the device sampler");
+    // the reference's rejection loop ends only if every user can supply neg_ratio unseen items (crec_sample_* checks the same)
+    CREC_REQUIRE(ctx, s->n_pos == 0 || neg_ratio == 0 || s->max_uniq + neg_ratio <= s->item_nums, "a user has fewer than neg_ratio unseen items");
+    CREC_HIP(ctx, hipSetDevice(s->device));
+    s->kind = kind, s->nr = neg_ratio, s->pos_in = pos, s->u = u, s->i = i, s->third = third, s->stream = (hipStream_t)stream;
+    s->n = n;
+    s->growth = 1.0;
+    std::memcpy(s->key_in, key, sizeof(s->key_in));
+    return enqueue(ctx, s);
+}
+
+int crec_dsampler_finish(crec_ctx *ctx, crec_dsampler *s, int64_t *n_out, uint32_t key_out[624], int32_t *pos_out)
+{
+    if (!ctx)
+        return CREC_EINVAL;
+    CREC_REQUIRE(ctx, s && n_out && key_out && pos_out, "null argument");
+    CREC_REQUIRE(ctx, s->pending, "no sample in flight");
+    CREC_HIP(ctx, hipSetDevice(s->device));
+    for (int attempt = 0;; ++attempt) {
+        CREC_HIP(ctx, hipEventSynchronize(s->done));
+        s->pending = false;
+        if (s->status_host->status == DS_OK)
+            break;
+        // the stream budget (sized from the expected rejection counts) did not last: again with twice the words
+        CREC_REQUIRE(ctx, s->status_host->status != DS_INTERNAL, "device sampler: internal error (undecided words left in a shuffle tile)");
+        CREC_REQUIRE(ctx, attempt < 6, "device sampler: stream budget exhausted after %d retries (status %d)", attempt, s->status_host->status);
+        s->growth *= 2.0;
+        if (int rc = enqueue(ctx, s))
+            return rc;
+    }
+    *n_out = s->n;
+    std::memcpy(key_out, s->status_host->key_out, sizeof(uint32_t) * MT_N);
+    *pos_out = s->status_host->pos_out;
+    return CREC_OK;
+}
+
+// what the last finished sample consumed: stream words of the negatives phase, of the shuffle, candidates produced / used
+int crec_dsampler_stats(const crec_dsampler *s, int64_t out[10])
+{
+    if (!s || !out || !s->status_host)
+        return CREC_EINVAL;
+    out[0] = s->status_host->raw_next1 - s->pos_in;
+    out[1] = s->status_host->raw_next2 - s->status_host->raw_next1;
+    out[2] = s->status_host->n_cand;
+    out[3] = s->status_host->cand_used;
+    for (int k = 0; k < 6; ++k)
+        out[4 + k] = s->status_host->dbg[k];
+    return CREC_OK;
+}
+
+} // extern "C"

@@ -481,3 +481,105 @@ class DeviceSampler:
         neg = self.negatives(neg_ratio)
         perm = self._perm(self.n_pos)
         return self.edge_user[perm].contiguous(), self.items[perm].contiguous(), neg[perm].contiguous()
+
+
+class MtSampler:
+    """The reference's epoch samplers ON the device, bit for bit (crec_dsampler_*, csrc/mt_sampler.hip): NumPy's MT19937
+    word stream produced by jump-ahead chains, randint's rejection as a compaction, the per-user redraw loop and the
+    shuffle's draws as tile walks, the permutation as a sort + pointer chase.  Same columns, same np.random state
+    afterwards as utils/sampler.py:10-99 -- and the columns never leave HBM.
+
+    next_epoch(kind, neg_ratio) is the drop-in: it reads np.random's state, returns the sample the reference would
+    draw now and leaves np.random where the reference would.  With ahead=True the sample after this one is enqueued
+    on a second stream right away (from the state this one ends in) and runs beside the training steps of this
+    epoch; it is used at the next call only if np.random still stands exactly there."""
+
+    KINDS = {"pairwise": 0, "pointwise": 1, "cml": 2}
+
+    def __init__(self, sess, data):
+        from .data import RankingData
+        if not hasattr(data, "train_csr"):
+            data = RankingData(data.user_nums, data.item_nums, data.ui_train, data.ui_test)
+        keys, ptr, items = data.train_csr
+        keys, ptr = np.ascontiguousarray(keys, np.int32), np.ascontiguousarray(ptr, np.int64)
+        items = np.ascontiguousarray(items if len(items) else np.zeros(1, np.int32), np.int32)
+        self.sess, self.n_pos, self.item_nums = sess, int(ptr[-1]), int(data.item_nums)
+        self.h = C.c_void_p()
+        sess.ctx.check(sess.lib.crec_dsampler_create(sess.ctx.h, _lib._np(ptr), _lib._np(items), len(keys), _lib._np(keys),
+                                                     self.item_nums, C.byref(self.h), sess.stream_ptr()))
+        self.side = torch.cuda.Stream(device=sess.device)
+        self._flight = None  # (kind, neg_ratio, key, pos, (u, i, third), stream) of the sample enqueued and not yet collected
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.sess.lib.crec_dsampler_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _shapes(self, kind, nr):
+        n = {"pairwise": self.n_pos * nr, "pointwise": self.n_pos * (1 + nr), "cml": self.n_pos}[kind]
+        third = (torch.float32, (n,)) if kind == "pointwise" else (torch.int32, (n, nr) if kind == "cml" else (n,))
+        return n, third
+
+    def enqueue(self, kind, neg_ratio, key, pos, stream=None):
+        """start one sample from the generator state (key, pos) on `stream` (default: the current one)"""
+        if self._flight is not None:
+            raise RuntimeError("MtSampler: collect() the sample in flight first")
+        s = self.sess
+        stream = stream or torch.cuda.current_stream(s.device)
+        n, (tdt, tshape) = self._shapes(kind, int(neg_ratio))
+        with torch.cuda.stream(stream):
+            u, i = (torch.empty(max(n, 1), dtype=torch.int32, device=s.device) for _ in range(2))
+            third = torch.empty([max(x, 1) for x in tshape], dtype=tdt, device=s.device)
+            key = np.ascontiguousarray(key, dtype=np.uint32)
+            s.ctx.check(s.lib.crec_dsampler_sample(s.ctx.h, self.h, self.KINDS[kind], int(neg_ratio), _lib._np(key), int(pos),
+                                                   s.ptr(u), s.ptr(i), s.ptr(third), C.c_void_p(stream.cuda_stream)))
+        self._flight = (kind, int(neg_ratio), key.copy(), int(pos), (u, i, third), stream, n, tshape)
+
+    def collect(self):
+        """-> ((u, i, third) device tensors, (key, pos) generator state after the sample); waits for the sample"""
+        kind, nr, _, _, (u, i, third), stream, n, tshape = self._flight
+        s = self.sess
+        n_out, key, pos = C.c_int64(), np.empty(624, dtype=np.uint32), C.c_int32()
+        s.ctx.check(s.lib.crec_dsampler_finish(s.ctx.h, self.h, C.byref(n_out), _lib._np(key), C.byref(pos)))
+        self._flight = None
+        assert n_out.value == n
+        cur = torch.cuda.current_stream(s.device)
+        if stream != cur:  # the sample is complete (finish waited for it); tell the allocator who reads the columns now
+            for t in (u, i, third):
+                t.record_stream(cur)
+        third = third[:n] if kind != "cml" else third[:n, :nr]
+        return (u[:n], i[:n], third), (key, pos.value)
+
+    def stats(self):
+        out = (C.c_int64 * 10)()
+        self.sess.ctx.check(self.sess.lib.crec_dsampler_stats(self.h, out))
+        return dict(words_negatives=out[0], words_shuffle=out[1], candidates=out[2], candidates_used=out[3],
+                    neg_tiles=out[4], neg_clocks=out[5], neg_us=out[6] / 100.0, perm_tiles=out[7], perm_clocks=out[8], perm_us=out[9] / 100.0)
+
+    def sample(self, kind, neg_ratio, key, pos):
+        """one sample from an explicit generator state, synchronously"""
+        self.enqueue(kind, neg_ratio, key, pos)
+        return self.collect()
+
+    def drop(self):
+        if self._flight is not None:
+            self.collect()
+
+    def next_epoch(self, kind, neg_ratio, ahead=True):
+        st = np.random.get_state()
+        assert st[0] == "MT19937"
+        cols = None
+        fl = self._flight
+        if fl is not None:
+            hit = fl[0] == kind and fl[1] == int(neg_ratio) and fl[3] == st[2] and np.array_equal(fl[2], st[1])
+            got = self.collect()
+            if hit:
+                cols, end = got
+        if cols is None:
+            cols, end = self.sample(kind, neg_ratio, st[1], st[2])
+        np.random.set_state(("MT19937", end[0], end[1], st[3], st[4]))  # no normals drawn: the cached gaussian stays
+        if ahead:
+            self.enqueue(kind, neg_ratio, end[0], end[1], stream=self.side)
+        return cols

@@ -125,6 +125,34 @@ int crec_sample_sbpr(crec_ctx *ctx, const int64_t *ptr, const int32_t *items, in
                      int32_t item_nums, int neg_ratio, const int64_t *spu_ptr, const int32_t *spu_items, const int32_t *spu_suk,
                      int32_t *u, int32_t *i, int32_t *i_s, int32_t *i_neg, float *suk, int64_t *n_out);
 
+/* ---- the SAME samplers on the device (bit-exact: stream words, index streams and final generator state) ---------
+ * replaces pairwise_ranking_sampler / pointwise_ranking_sampler / ranking_sampler_cml (utils/sampler.py:46-74, 10-43,
+ * 77-99) as called at the top of every epoch (model/RankingRecommender.py:37,49,92), with the columns left in HBM
+ * where the train step reads them.  The MT19937 word stream itself is produced on the GPU by jump-ahead chains,
+ * randint's masked rejection is a stream compaction, the per-user redraw loop and the shuffle's draws are tile
+ * walks by one workgroup each, the permutation is a sort + pointer chase (csrc/mt_sampler.hip).
+ *   crec_dsampler_create: ui_train as in crec_sample_* [host arrays]; builds the device copy + per-user item bitmaps.
+ *       CREC_EUNSUPPORTED when item_nums > 262144 or users x items / 8 > 2 GiB (the host samplers take those).
+ *   crec_dsampler_sample: ENQUEUES one epoch's sample on `stream` from the generator state (key, pos) =
+ *       np.random.get_state()[1:3].  kind 0 pairwise: u, i, third = j int32 [n_pos*neg_ratio];  1 pointwise: u, i,
+ *       third = y float [n_pos*(1+neg_ratio)];  2 cml: u, i [n_pos], third = neg int32 [n_pos, neg_ratio]  [dev].
+ *   crec_dsampler_finish: waits for it; *n_out instances; (key_out, *pos_out) = the generator state afterwards, to
+ *       be put back with np.random.set_state.  (If the epoch rejected more draws than the stream budget sized from
+ *       the expected rejection rate allowed, the sample is redone with twice the budget -- same result.)
+ *   crec_dsampler_stats: stream words used by the negatives / by the shuffle, candidates produced / used, then tile
+ *       iterations, shader clocks and 100 MHz ticks of the negatives walk and of the shuffle-target walk. */
+typedef struct crec_dsampler crec_dsampler;
+int crec_dsampler_create(crec_ctx *ctx, const int64_t *ptr, const int32_t *items, int64_t n_users, const int32_t *user_ids,
+                         int32_t item_nums, crec_dsampler **out, void *stream);
+void crec_dsampler_destroy(crec_dsampler *s);
+int crec_dsampler_sample(crec_ctx *ctx, crec_dsampler *s, int kind, int neg_ratio, const uint32_t key[624], int32_t pos,
+                         int32_t *u, int32_t *i, void *third, void *stream);
+int crec_dsampler_finish(crec_ctx *ctx, crec_dsampler *s, int64_t *n_out, uint32_t key_out[624], int32_t *pos_out);
+int crec_dsampler_stats(const crec_dsampler *s, int64_t out[10]);
+/* test hook [host]: the block of 624 raw MT19937 words that lies c*128 refills behind `key` (1 <= c <= 128), by the
+ * jump polynomial the device chains use (csrc/mt_jump.cpp) */
+int crec_debug_mt_jump(const uint32_t key[624], int c, uint32_t out_block[624]);
+
 /* ---- device-side negative sampling (optional; NOT stream-compatible with the reference) --------------
  * Same acceptance rule as utils/sampler.py:18-31,50-66,82-93 -- neg_ratio items per training positive, uniform over
  * the catalogue, redrawn while seen by the user or already in the positive's group -- but drawn from a counter-based

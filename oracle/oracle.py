@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "liboracle.so")
 
 __all__ = [
-    "build", "Rng", "to_csr", "dict_from_csr", "sample_pairwise", "sample_pointwise", "sample_cml",
+    "build", "Rng", "to_csr", "dict_from_csr", "sample_pairwise", "sample_pointwise", "sample_cml", "reference_sampler",
     "AdamSchedule", "BprModel", "bpr_step", "scores", "topk", "rank_metrics",
     "cal_ranking_metrics_py", "test_model_rs_py", "train_model_py", "tf_softplus_np", "bpr_dp_local", "adam_dense", "test_model_loo_py", "bpr_shard_local", "adam_rows_lazy", "sharded_steps",
 ]
@@ -142,6 +142,19 @@ def sample_pointwise(rng, ui_train, item_nums, neg_ratio, batch_size):
 def sample_cml(rng, ui_train, item_nums, neg_ratio, batch_size):
     """ranking_sampler_cml (utils/sampler.py:77-99) -> (train_batches, u, i, neg[N, neg_ratio])."""
     return _sample("orc_sample_cml", rng, ui_train, item_nums, neg_ratio, batch_size, 1, np.int64, neg_ratio)
+
+
+def reference_sampler(kind, ui_train, item_nums, neg_ratio):
+    """The three samplers drawing from np.random's GLOBAL state, as the reference does (utils/sampler.py:10-99): reads the
+    state, samples with the C restatement above, leaves np.random where the reference's call would.  -> (u, i, third)."""
+    st = np.random.get_state()
+    rng = Rng()
+    rng.set_state(st[1], st[2])
+    fn = {"pairwise": sample_pairwise, "pointwise": sample_pointwise, "cml": sample_cml}[kind]
+    _, u, i, t = fn(rng, ui_train, item_nums, neg_ratio, 1 << 30)
+    key, pos = rng.get_state()
+    np.random.set_state(("MT19937", key, pos, st[3], st[4]))
+    return u, i, t
 
 
 class AdamSchedule:
