@@ -7,7 +7,7 @@ import os
 
 DEFAULTS = {
     "adam_mode": "tf1",        # tf1 | lazy | deferred  (include/crec.h CREC_ADAM_*)
-    "sampler_mode": "mt19937",  # mt19937: bit-exact host sampler | device: GPU sampler, same rule, own generator
+    "sampler_mode": "mt19937",  # mt19937: the reference's streams, drawn on the device | mt19937_host: by the host form | device: same rule, own generator
 }
 
 

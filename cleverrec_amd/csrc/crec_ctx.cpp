@@ -230,6 +230,8 @@ int crec_ctx_set_option(crec_ctx *ctx, const char *name, int64_t value)
         ctx->knob_no_zero_copy = (int)value;
     else if (n == "dsampler_general")
         ctx->knob_dsampler_general = (int)value;
+    else if (n == "dsampler_budget")
+        ctx->knob_dsampler_budget = (int)value;
     else
         return crec_fail(ctx, CREC_EINVAL, "unknown option '%s'", name);
     return CREC_OK;

@@ -112,6 +112,7 @@ struct crec_ctx {
     int knob_eval_no_bitmap = 0; // 1: seen filter by binary search even where the bitmaps would fit
     int knob_no_zero_copy = 0;   // 1: the chunk's counts come back by copy + stream synchronisation (tests)
     int knob_ncf_generic = 0;    // 1: the generic ncf_tile even for the shapes that have a specialised one (tests)
+    int knob_dsampler_budget = 100; // percent of the device sampler's stream budget to start with (tests: < 100 forces the retry path)
     int knob_dsampler_general = 0; // 1: the device sampler's general negatives walk even where the one-barrier form applies (tests)
 };
 

@@ -384,6 +384,8 @@ struct NegArgs {
     int32_t *neg;
     DsStatus *st;
     int64_t raw_begin;
+    uint32_t cand_cap; // elements allocated behind `cand` (a multiple of 4): the walk's 16-byte requests stay inside
+    uint32_t neg_spare; // index of a spare element behind `neg`: where a lane without a result stores
 };
 
 // PWORDS: bitmap words a thread moves per user (bw <= PWORDS * 1024)
@@ -545,289 +547,235 @@ template <int PWORDS> __global__ __launch_bounds__(TILE) void neg_chain_general(
     }
 }
 
-// ---- phase 1b, the form that runs wherever its limits allow (neg_ratio <= 33, item_nums <= 65536): ONE barrier per tile ------
-// Same rules as neg_chain_general above; what changes is how a trip round the loop is organised, because a trip IS the cost
-// (one link of the chain per tile, nothing to overlap it with):
-//  * candidates and the users' bitmaps arrive in LDS rings by LDS-DMA, several tiles / users ahead (plumbing above);
-//  * phase A of a tile (read candidate, test bitmap, ballot; per wave: count, ballot mask, its last nr-1 accepted values)
-//    is published before the trip's only barrier; behind it every thread reads all sixteen counts and knows its rank, the
-//    tile's total and -- by a select on the owning wave's mask -- where the user's last slot falls;
-//  * a repeat inside a positive's group is found by each thread for itself (the earlier members of its group are lanes of
-//    its own wave, the tail of an earlier wave, or the last nr-1 accepted of the tiles before: `carry`), but telling the
-//    other waves would take a second barrier -- so a tile is decided as if it had no repeat, the next tile is started from
-//    that state, and the repeat's position (an LDS atomic min) is looked at behind the NEXT barrier: if there was one, the
-//    state of the tile before is restored, cut right behind the repeat, and the walk goes on from there.  What the undone
-//    trips wrote lies at or behind the repeat's slot and is written again.  Side effects that cannot be undone (a finished
-//    user's ring slot handed to the user nbuf ahead) wait until the tile is confirmed.
-constexpr int NWAIT = 5;            // LDS-DMA operations that may stay in flight across a barrier
-constexpr int CRING = 16384;        // candidate ring
-constexpr int CDEPTH = NWAIT + 1;   // candidate fills ahead of the tile being read
-constexpr int FAST_NBUF = NWAIT + 3; // bitmap ring: a user's bitmap is requested nbuf users ahead; see the wait's comment
-constexpr int FAST_NR_MAX = 33;
-constexpr int FAST_BW_MAX = 2048;
+// ---- the walks as they run wherever their limits allow: FOUR waves, four tile elements per lane ---------------------------------
+// A trip round a walk's loop is one link of a serial chain, and what a trip costs is the instructions of its longest wave:
+// the first version (1024 threads, one element each) put four waves on every SIMD, each of them executing the trip's uniform
+// bookkeeping -- prefix sums, the cut, the state, the ring management, ~500 instructions -- and measured 3 100 (shuffle
+// targets) and 5 000-9 000 (negatives) cycles per tile with the loads already hidden.  With one wave per SIMD and four
+// elements per lane the bookkeeping runs once per SIMD instead of four times and the element work keeps all lanes busy.
+// Element (wave w, row j, lane l) sits at tile offset w * 256 + j * 64 + l: group g = 4 w + j, sixteen groups in tile order.
+constexpr int WT = 256;             // threads of a walk
+constexpr int NWAIT = 5;            // fills (LDS-DMA requests of 4 KiB) that may be in flight across a barrier
+// what a wave may leave outstanding at a walk's counted wait, in vector-memory operations: a trip issues exactly four stores (one per
+// element row, unconditionally: rows without a result store to a dummy slot) and at most one fill, so the NOPS youngest operations
+// span at least NWAIT trips and hold at most NWAIT fills
+constexpr int NOPS = 5 * NWAIT;
+constexpr int CRING = 16384;        // ring of candidates / stream words
+constexpr int CDEPTH = NWAIT + 1;   // fills ahead of the tile being read
+constexpr int WALK_NBUF = NWAIT + 3; // bitmap ring (see the wait's comment in neg_walk)
+constexpr int WALK_BW_MAX = 2048;   // bitmap words per user the ring takes (item_nums <= 65536)
+constexpr int WALK_NR_MAX = 256;
 
-struct NegState {
-    int64_t k, pos, done, need, base;
-    uint32_t dmod;
-};
-
-__device__ __forceinline__ int select64(uint64_t m, int r) // position of the r-th set bit, r = 1 .. popcount(m)
+// 16 bytes per lane, 1 KiB per wave: LDS destination = lds_byte_addr + 16 * lane
+__device__ __forceinline__ void glds_x4(const void *gsrc, uint32_t lds_byte_addr)
 {
-    int pos = 0;
-    uint32_t lo = (uint32_t)m;
-    int c = __popc(lo);
-    if (r > c) {
-        r -= c;
-        pos = 32;
-        lo = (uint32_t)(m >> 32);
-    }
-#pragma unroll
-    for (int sh = 16; sh >= 1; sh >>= 1) {
-        c = __popc(lo & ((1u << sh) - 1u));
-        if (r > c) {
-            r -= c;
-            pos += sh;
-            lo >>= sh;
-        }
-    }
-    return pos;
+    unsigned keep;
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_byte_addr);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(dst)
+                 : "memory");
 }
 
-__global__ __launch_bounds__(TILE) void neg_chain_fast(NegArgs a)
+// inclusive prefix sum inside every row of 16 lanes (DPP row shifts: no LDS, no cross-lane permutes)
+__device__ __forceinline__ uint32_t row_scan16(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); // row_shr:1, lanes without a source add 0
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    return v;
+}
+
+// ---- phase 1b: the negatives of every positive, users in the reference's order ---------------------------------------------------
+// Rules as in neg_chain_general above (a tile is cut behind the user's last slot or behind the first repeat inside a positive's
+// group); candidates and the users' bitmaps arrive in LDS rings by LDS-DMA several tiles / users ahead.
+template <int NRT> __global__ __launch_bounds__(WT) void neg_walk(NegArgs a)
 {
     extern __shared__ uint32_t lds[];
-    const int nr = a.nr, NRM = a.nr - 1, bw = a.bw, nbuf = a.nbuf;
-    // ONE shared object, carved: [bitmap ring][candidate ring][masks][counts][repeat words][tails][carry][CSR bounds]
-    // (every piece a whole number of 8-byte units: bw is a multiple of 64, tails + carry are 34 * NRM words)
+    const int nr = NRT ? NRT : a.nr, CARRY = nr - 1, bw = a.bw, nbuf = a.nbuf;
+    // ONE shared object: [bitmap ring][candidate ring][D: accepted of the tile behind the last nr-1 of the tiles before][counts][cuts][CSR bounds]
     uint32_t *bm = lds;
     int32_t *cbuf = (int32_t *)(bm + (size_t)nbuf * bw);
-    uint64_t *msk = (uint64_t *)(cbuf + CRING);        // [2][16]
-    uint32_t *cnt = (uint32_t *)(msk + 32);            // [2][16]
-    uint32_t *dupw = cnt + 32;                         // [4]
-    int32_t *tail = (int32_t *)(dupw + 4);             // [2][16][NRM]
-    int32_t *carry = tail + 2 * 16 * NRM;              // [2][NRM]
-    int64_t *uptr = (int64_t *)(carry + 2 * NRM);      // [UCACHE + 1]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t n_cand = a.st->n_cand, n_users = a.n_users;
+    int32_t *D = cbuf + CRING;
+    uint32_t *cnt = (uint32_t *)(D + ((CARRY + TILE + 3) & ~3)); // [2][16]
+    uint32_t *red = cnt + 32;                                    // [2][8]: per wave {first repeat | its rank, thread of the last slot}
+    int64_t *uptr = (int64_t *)(red + 16);                       // [UCACHE + 1]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t n_cand = (uint32_t)a.st->n_cand;
+    const int64_t n_users = a.n_users;
     const uint64_t clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
     const uint32_t cbuf_at = lds_addr(cbuf), bm_at = lds_addr(bm);
 
-    int64_t filled = 0;
-    const auto fill = [&]() {
-        int64_t idx = filled + tid;
-        idx = idx < n_cand ? idx : (n_cand > 0 ? n_cand - 1 : 0);
-        glds_dword(a.cand + idx, cbuf_at + (uint32_t)(((filled + wave * 64) & (CRING - 1)) * 4));
+    uint32_t filled = 0;
+    const auto fill = [&]() { // candidates [filled, filled + 1024) -> ring; one 16-byte request per lane
+        uint32_t idx = filled + wave * 256 + lane * 4;
+        idx = idx + 4 <= a.cand_cap ? idx : a.cand_cap - 4;
+        glds_x4(a.cand + idx, cbuf_at + ((filled + wave * 256) & (CRING - 1)) * 4);
         filled += TILE;
     };
-    // user u's bitmap -> ring slot u % nbuf; 64 words per wave and instruction.  Past the last user the request is still made
-    // (for the last user's words, into a slot nobody reads any more): the wait below counts on the requests that follow one
+    // user u's bitmap -> ring slot u % nbuf, 256 words per wave and request.  Past the last user the request is still made (the
+    // last user's words, into a slot nobody reads any more): the wait below counts on the requests that follow one
     const auto load_bitmap = [&](int64_t u) {
         const uint32_t slot_at = bm_at + (uint32_t)((u % nbuf) * bw * 4);
         const int64_t src = u < n_users ? u : n_users - 1;
-        for (int w0 = wave * 64; w0 < bw; w0 += TILE)
-            glds_dword(a.bitmaps + (size_t)src * bw + w0 + lane, slot_at + (uint32_t)(w0 * 4));
+        for (int w0 = wave * 256; w0 < bw; w0 += 1024)
+            glds_x4(a.bitmaps + (size_t)src * bw + w0 + lane * 4, slot_at + (uint32_t)(w0 * 4));
     };
     for (int f = 0; f <= CDEPTH; ++f)
         fill();
     for (int u = 0; u < nbuf; ++u)
         load_bitmap(u);
     int64_t kc0 = 0;
-    for (int t = tid; t <= UCACHE; t += TILE)
+    for (int t = tid; t <= UCACHE; t += WT)
         uptr[t] = kc0 + t <= n_users ? a.ptr[kc0 + t] : 0;
-    if (tid < 4)
-        dupw[tid] = 0xffffffffu;
     wait_vm_then_barrier<0>();
 
-    NegState st{0, 0, 0, 0, 0, 0u}, sv = st;
-    const auto enter_user = [&]() { // st.k -> the next user with slots to fill; its need and base
-        for (;;) {
-            if (st.k >= n_users) {
-                st.need = 0;
-                return;
+    uint32_t pos = 0, iters = 0;
+    int64_t last = -1;
+    int par = 0;
+    bool failed = false;
+    for (int64_t k = 0; k < n_users && !failed; ++k) {
+        if (k - kc0 >= UCACHE) { // (ordinary loads: drains the DMA queue; once per 1024 users)
+            lds_barrier();
+            kc0 = k;
+            for (int t = tid; t <= UCACHE; t += WT)
+                uptr[t] = kc0 + t <= n_users ? a.ptr[kc0 + t] : 0;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_barrier();
+        }
+        const int64_t p0 = uptr[k - kc0], p1 = uptr[k - kc0 + 1];
+        const uint32_t need = (uint32_t)(p1 - p0) * (uint32_t)nr, base = (uint32_t)p0 * (uint32_t)nr;
+        const uint32_t *ubm = bm + (size_t)(k % nbuf) * bw;
+        uint32_t done = 0, dmod = 0;
+        if (need == 0) // a user without rows makes no trip (no stores to count on): retire everything
+            wait_vm_then_barrier<0>();
+        while (done < need) {
+            if (pos >= n_cand) { // the compaction was sized too small for this epoch's rejections: the host doubles it and starts over
+                failed = true;
+                break;
             }
-            if (st.k - kc0 >= UCACHE) { // (ordinary loads: drains the DMA queue; once per 1024 users)
-                lds_barrier();
-                kc0 = st.k;
-                for (int t = tid; t <= UCACHE; t += TILE)
-                    uptr[t] = kc0 + t <= n_users ? a.ptr[kc0 + t] : 0;
-                lds_barrier();
-            }
-            const int64_t p0 = uptr[st.k - kc0], p1 = uptr[st.k - kc0 + 1];
-            if (p1 > p0) {
-                st.need = (p1 - p0) * nr;
-                st.base = p0 * nr;
-                st.done = 0;
-                st.dmod = 0;
-                return;
-            }
-            ++st.k;
-        }
-    };
-    enter_user();
-
-    // per-thread memory of the tile whose repeats are still unknown to the other waves
-    int32_t c = 0, c_prev = 0;
-    bool f = false, f_prev = false;
-    uint32_t p_prev = 0, pw = 0;
-    uint64_t mf = 0;
-    int par = 0, cpar = 0;
-    int64_t kconf = 0, last = -1, iters = 0, redo = 0;
-    uint32_t it = 0;
-    bool failed = false, have_prev = false;
-
-    const auto phase_a = [&]() {
-        if (filled - st.pos < (int64_t)(CDEPTH + 1) * TILE && filled < n_cand)
-            fill();
-        const int64_t gi = st.pos + tid;
-        const bool valid = st.k < n_users && gi < n_cand;
-        c = cbuf[gi & (CRING - 1)];
-        const uint32_t *ubm = bm + (size_t)(st.k % nbuf) * bw;
-        f = valid && !((ubm[(uint32_t)c >> 5] >> (c & 31)) & 1u);
-        mf = __ballot(f);
-        const int cntw = __popcll(mf);
-        pw = lanes_below(mf);
-        if (lane == 0) {
-            cnt[par * 16 + wave] = (uint32_t)cntw;
-            msk[par * 16 + wave] = mf;
-        }
-        if (f && cntw - 1 - (int)pw < NRM) // the wave's last nr-1 accepted, the very last one at [NRM - 1]
-            tail[(par * 16 + wave) * NRM + NRM - 1 - (cntw - 1 - (int)pw)] = c;
-    };
-    // carry for the tile that follows a tile of `acc` accepted (of which thread-local rank / flag / value are given)
-    const auto write_carry = [&](int64_t acc, bool ff, uint32_t pp, int32_t cc, const int32_t *from, int32_t *to) {
-        if (ff && (int64_t)pp < acc && (int64_t)pp >= acc - NRM)
-            to[(int64_t)pp - (acc - NRM)] = cc;
-        if (tid < NRM && acc - NRM + tid < 0)
-            to[tid] = from[tid + acc];
-    };
-
-    phase_a();
-    for (;;) {
-        // The wait: everything but this wave's NWAIT youngest LDS-DMA operations has landed.  The candidates read behind this
-        // barrier were requested CDEPTH fills ago; a bitmap first read behind it was requested nbuf users ago and at least
-        // nbuf - 3 = NWAIT younger bitmap requests of the same waves follow it (requests are issued when a user is confirmed
-        // complete, two tiles behind the walk at most).
-        wait_vm_then_barrier<NWAIT>();
-        const uint32_t dprev = have_prev ? dupw[(it - 1) & 3] : 0xffffffffu;
-        if (dprev != 0xffffffffu) {
-            // the tile before had a repeat at thread t_d (rank p_d): undo, cut right behind it
-            const int64_t acc = dprev & 2047u;
-            const int cut = (int)(dprev >> 11) + 1;
-            st = sv;
-            write_carry(acc, f_prev, p_prev, c_prev, carry + (cpar ^ 1) * NRM, carry + cpar * NRM);
-            if (f_prev && (int64_t)p_prev < acc) // (already written by the undone trip; kept for clarity of the invariant)
-                a.neg[st.base + st.done + p_prev] = c_prev;
-            st.done += acc;
-            st.dmod = (uint32_t)((st.dmod + acc) % nr);
-            last = st.pos + cut - 1;
-            st.pos += cut;
-            have_prev = false; // the redone tile follows a confirmed state
-            ++redo;
-            par ^= 1;
-            ++it;
-            if (tid == 0)
-                dupw[(it + 1) & 3] = 0xffffffffu;
-            phase_a();
-            continue;
-        }
-        // the tile before is confirmed: users it completed hand their ring slots on
-        for (; kconf < st.k; ++kconf)
-            load_bitmap(kconf + nbuf);
-        if (st.k >= n_users)
-            break;
-        if (st.pos >= n_cand) { // the compaction was sized too small for this epoch's rejections: the host doubles it
-            failed = true;
-            break;
-        }
-        // ---- phase B ----
-        const uint4 *q4 = (const uint4 *)(cnt + par * 16);
-        const uint4 qa = q4[0], qb = q4[1], qc = q4[2], qd = q4[3];
-        const uint32_t s[16] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w, qc.x, qc.y, qc.z, qc.w, qd.x, qd.y, qd.z, qd.w};
-        const int64_t rem = st.need - st.done; // >= 1
-        uint32_t before = 0, total = 0;
-        int wt = -1;
-        uint32_t before_wt = 0;
+            // one tile consumed per trip at most: with one fill per trip filled - pos >= (CDEPTH + 1) tiles, so the NEXT trip's
+            // tile ends before the NWAIT fills that the wait below may leave in flight
+            if (filled - pos < (CDEPTH + 1) * TILE && filled < n_cand)
+                fill();
+            // ---- candidates against the user's bitmap; per group: count of the accepted
+            int32_t c[4];
+            uint32_t pw[4];
+            uint64_t mf[4];
+            const uint32_t t0 = wave * 256 + lane;
 #pragma unroll
-        for (int w = 0; w < 16; ++w) {
-            if (wt < 0 && (int64_t)(total + s[w]) >= rem) {
-                wt = w;
-                before_wt = total;
+            for (int j = 0; j < 4; ++j)
+                c[j] = cbuf[(pos + t0 + j * 64) & (CRING - 1)];
+            uint32_t cw[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool valid = pos + t0 + j * 64 < n_cand;
+                const bool fj = valid && !((ubm[(uint32_t)c[j] >> 5] >> (c[j] & 31)) & 1u);
+                mf[j] = __ballot(fj);
+                cw[j] = (uint32_t)__popcll(mf[j]);
+                pw[j] = lanes_below(mf[j]);
             }
-            before += w < wave ? s[w] : 0u;
-            total += s[w];
-        }
-        const uint32_t p = before + pw;
-        int cut;
-        int64_t acc;
-        if (wt >= 0) { // the user's last slot falls into wave wt
-            const uint64_t m = msk[par * 16 + wt];
-            cut = wt * 64 + select64(m, (int)(rem - before_wt)) + 1;
-            acc = rem;
-        } else {
-            const int64_t left = n_cand - st.pos;
-            cut = left < TILE ? (int)left : TILE;
-            acc = total;
-        }
-        // repeats inside a positive's group (sampler.py:24,59,88)
-        if (NRM > 0 && f && (int64_t)p < rem) {
-            const int q = (int)((st.dmod + p) % (uint32_t)nr);
-            uint64_t below = mf & ((1ull << lane) - 1ull);
-            int wq = wave, rr = 0; // once the own wave is used up: rr = -(members still to visit), relative to wave wq's end
-            bool dup = false;
-            for (int jj = 1; jj <= q; ++jj) {
-                int32_t v;
-                if (below) {
-                    const int b = 63 - __clzll((long long)below);
-                    below &= ~(1ull << b);
-                    v = cbuf[(st.pos + wave * 64 + b) & (CRING - 1)];
-                } else {
-                    if (rr == 0) {
-                        rr = -1;
-                        wq = wave - 1;
-                    } else {
-                        --rr;
+            if (lane == 0)
+                *(uint4 *)(cnt + par * 16 + wave * 4) = make_uint4(cw[0], cw[1], cw[2], cw[3]);
+            // The wait: everything but this wave's NOPS youngest vector-memory operations has completed, which leaves at most NWAIT
+            // fills in flight (the candidates read behind this barrier were requested CDEPTH fills ago).  A bitmap first read behind
+            // it was requested nbuf users ago: the trips of the nbuf - 2 users since (four stores each) and their own bitmap
+            // requests are more than NOPS younger operations.
+            wait_vm_then_barrier<NOPS>();
+            const uint32_t mine = lane < 16 ? cnt[par * 16 + lane] : 0u;
+            const uint32_t incl = row_scan16(mine);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 15);
+            uint32_t p[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                p[j] = (uint32_t)__builtin_amdgcn_readlane((int)(incl - mine), wave * 4 + j) + pw[j];
+            const uint32_t rem = need - done; // >= 1
+            // ---- repeats inside a positive's group (sampler.py:24,59,88): the accepted of the tile in rank order, compare with
+            // the earlier members of the group
+            uint64_t md[4] = {0, 0, 0, 0};
+            if (nr > 1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if ((mf[j] >> lane) & 1)
+                        D[CARRY + p[j]] = c[j];
+                lds_barrier();
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    bool dup = false;
+                    if (((mf[j] >> lane) & 1) && p[j] < rem) {
+                        const int q = NRT == 4 ? (int)((dmod + p[j]) & 3u) : (int)((dmod + p[j]) % (uint32_t)nr);
+                        const int32_t *at = D + CARRY + p[j];
+                        if (NRT == 4) {
+                            const int32_t v1 = at[-1], v2 = at[-2], v3 = at[-3];
+                            dup = (q >= 1 && v1 == c[j]) || (q >= 2 && v2 == c[j]) || (q >= 3 && v3 == c[j]);
+                        } else {
+                            for (int jj = 1; jj <= q; ++jj)
+                                dup |= at[-jj] == c[j];
+                        }
                     }
-                    while (wq >= 0 && rr + (int)cnt[par * 16 + wq] < 0) {
-                        rr += (int)cnt[par * 16 + wq];
-                        --wq;
-                    }
-                    v = wq >= 0 ? tail[(par * 16 + wq) * NRM + NRM + rr] : carry[cpar * NRM + NRM + rr];
+                    md[j] = __ballot(dup);
                 }
-                dup |= v == c;
             }
-            if (dup)
-                atomicMin(&dupw[it & 3], ((uint32_t)tid << 11) | p);
+            // this wave's first repeat (thread << 11 | rank) and the thread that holds the user's last slot
+            uint32_t wd = 0xffffffffu, wn = 0xffffffffu;
+#pragma unroll
+            for (int j = 3; j >= 0; --j) {
+                if (md[j]) {
+                    const int l = __ffsll((unsigned long long)md[j]) - 1;
+                    wd = ((uint32_t)(wave * 256 + j * 64 + l) << 11) | (uint32_t)__builtin_amdgcn_readlane((int)p[j], l);
+                }
+                const uint64_t mn = __ballot(((mf[j] >> lane) & 1) && p[j] == rem - 1);
+                if (mn)
+                    wn = (uint32_t)(wave * 256 + j * 64 + __ffsll((unsigned long long)mn) - 1);
+            }
+            if (lane == 0)
+                *(uint2 *)(red + par * 8 + wave * 2) = make_uint2(wd, wn);
+            lds_barrier();
+            const uint4 ra = *(const uint4 *)(red + par * 8), rb = *(const uint4 *)(red + par * 8 + 4);
+            const uint32_t dmin = min(min(ra.x, ra.z), min(rb.x, rb.z)), t_need = min(min(ra.y, ra.w), min(rb.y, rb.w));
+            const uint32_t t_dup = dmin == 0xffffffffu ? 0xffffffffu : (dmin >> 11);
+            uint32_t cut, acc;
+            if (t_dup != 0xffffffffu && t_dup <= t_need) { // [0, t_dup) kept; the repeat is consumed and rejected
+                cut = t_dup + 1;
+                acc = dmin & 2047u;
+            } else if (t_need != 0xffffffffu) {
+                cut = t_need + 1;
+                acc = rem;
+            } else {
+                const uint32_t left = n_cand - pos;
+                cut = left < TILE ? left : TILE;
+                acc = total;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { // exactly four stores per trip (see NOPS): lanes without a negative write the spare slot behind the array
+                const bool ok = ((mf[j] >> lane) & 1) && t0 + j * 64 < cut && p[j] < acc;
+                a.neg[ok ? base + done + p[j] : a.neg_spare] = c[j];
+            }
+            if (nr > 1 && done + acc < need) { // the group in progress may reach back into this tile: keep its last nr-1 accepted
+                int32_t v = 0;
+                if (tid < CARRY)
+                    v = D[acc + tid];
+                lds_barrier();
+                if (tid < CARRY)
+                    D[tid] = v;
+            }
+            done += acc;
+            dmod = NRT == 4 ? ((dmod + acc) & 3u) : (dmod + acc) % (uint32_t)nr;
+            last = (int64_t)pos + cut - 1;
+            pos += cut;
+            par ^= 1;
+            ++iters;
         }
-        if (f && tid < cut && (int64_t)p < acc)
-            a.neg[st.base + st.done + p] = c;
-        if (NRM > 0 && st.done + acc < st.need)
-            write_carry(acc, f, p, c, carry + cpar * NRM, carry + (cpar ^ 1) * NRM);
-        cpar ^= 1;
-        // remember the tile until its repeats are known, then move on as if it had none
-        sv = st;
-        c_prev = c, f_prev = f, p_prev = p;
-        have_prev = true;
-        st.done += acc;
-        st.dmod = (uint32_t)((st.dmod + acc) % nr);
-        last = st.pos + cut - 1;
-        st.pos += cut;
-        if (st.done >= st.need) {
-            ++st.k;
-            enter_user();
-        }
-        if (tid == 0)
-            dupw[(it + 2) & 3] = 0xffffffffu; // the word two tiles ahead: its last reader passed a barrier ago
-        par ^= 1;
-        ++it;
-        ++iters;
-        phase_a();
+        load_bitmap(k + nbuf); // user k is done: its ring slot takes the user nbuf ahead
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // no LDS-DMA may be in flight when the workgroup ends
     if (tid == 0) {
-        a.st->dbg[0] = iters + (redo << 32);
+        a.st->dbg[0] = iters;
         a.st->dbg[1] = (int64_t)(__builtin_amdgcn_s_memtime() - clk0);
         a.st->dbg[2] = (int64_t)(__builtin_amdgcn_s_memrealtime() - rt0);
-        a.st->cand_used = st.pos;
+        a.st->cand_used = pos;
         a.st->raw_next1 = last >= 0 ? (int64_t)a.cand_raw[last] + 1 : a.raw_begin;
         if (failed)
             a.st->status = DS_OUT_OF_CANDIDATES;
@@ -835,104 +783,123 @@ __global__ __launch_bounds__(TILE) void neg_chain_fast(NegArgs a)
 }
 
 // ---- phase 2 -------------------------------------------------------------------------------------------------------
-constexpr int XRING = 16384; // stream words in the LDS ring of perm_targets
-constexpr int XDEPTH = 6;    // fills ahead of the tile being read (the tile's own stores share the queue: about half of them stay in flight)
 struct PermLds {
-    uint32_t ring[XRING];
-    uint32_t wsum[2][16];
+    uint32_t ring[CRING];
+    uint32_t cnt[2][16];
     int cut_at[2];
 };
 
 // tgt[i], i = n-1 .. 1: the swap target of step i of the legacy shuffle.  Also leaves the generator's final state.
-__global__ __launch_bounds__(TILE) void perm_targets(const uint32_t *__restrict__ x, int64_t x_words, int64_t n, uint32_t *__restrict__ tgt,
-                                                     DsStatus *__restrict__ st)
+__global__ __launch_bounds__(WT) void perm_targets(const uint32_t *__restrict__ x, int64_t x_words64, int64_t n, uint32_t *__restrict__ tgt,
+                                                   DsStatus *__restrict__ st)
 {
     __shared__ __align__(16) PermLds L; // ONE shared object (a second one beside an LDS-DMA target can cost a vmcnt(0) per read)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (st->status != DS_OK)
         return;
-    int64_t w = st->raw_next1;
-    int64_t i = n - 1, iters = 0;
+    const uint32_t x_words = (uint32_t)x_words64;
+    uint32_t w = (uint32_t)st->raw_next1;
+    int32_t i = (int32_t)(n - 1);
+    uint32_t iters = 0;
     int par = 0;
     bool failed = false;
     const uint64_t clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
     const uint32_t ring_at = lds_addr(L.ring);
-    int64_t filled = w & ~(int64_t)63; // the ring holds stream words [.., filled); a wave's 64 words never wrap
+    uint32_t filled = w & ~255u; // the ring holds stream words [.., filled); a wave's 256 words never wrap
     const auto fill = [&]() {
-        int64_t idx = filled + tid;
-        idx = idx < x_words ? idx : x_words - 1;
-        glds_dword(x + idx, ring_at + (uint32_t)(((filled + wave * 64) & (XRING - 1)) * 4));
+        uint32_t idx = filled + wave * 256 + lane * 4;
+        idx = idx + 4 <= x_words ? idx : x_words - 4; // x_words is a multiple of 624: of 4
+        glds_x4(x + idx, ring_at + ((filled + wave * 256) & (CRING - 1)) * 4);
         filled += TILE;
     };
-    for (int f = 0; f <= XDEPTH + 1; ++f)
+    for (int f = 0; f <= CDEPTH + 1; ++f)
         fill();
     wait_vm_then_barrier<0>();
+    const uint32_t t0 = wave * 256 + lane;
     while (i >= 1) {
         if (w >= x_words) {
             failed = true;
             break;
         }
-        // one tile consumed per trip at most, so one fill per trip keeps filled - w >= (XDEPTH + 1) tiles (+ the 63 words `filled`
-        // may start below w): the next trip's tile ends at or before w + 2 * TILE <= filled - (XDEPTH - 1) * TILE, i.e. before
-        // the XDEPTH - 1 fills that the wait below may leave in flight
-        if (filled - w < (XDEPTH + 1) * TILE + 64)
+        // one tile consumed per trip at most, so one fill per trip keeps filled - w >= CDEPTH + 1 tiles (+ the 255 words `filled`
+        // may start below w): the next trip's tile ends before the NWAIT fills that the wait below may leave in flight
+        if (filled - w < (CDEPTH + 1) * TILE + 256)
             fill();
-        const int64_t left = x_words - w;
-        const int navail = left < TILE ? (int)left : TILE;
+        const uint32_t left = x_words - w;
+        const uint32_t navail = left < TILE ? left : TILE;
         const uint32_t mask = mask_of((uint32_t)i);
-        const int64_t room = i - (int64_t)(mask >> 1); // steps left before the mask changes: i .. (mask >> 1) + 1
-        const bool valid = tid < navail;
-        const int64_t v = mt_temper(L.ring[(w + tid) & (XRING - 1)]) & mask;
-        bool acc = valid && v <= i - tid; // even if every word before it in the tile is accepted
-        bool amb = valid && !acc && v <= i;
-        uint32_t Lc = 0, tot = 0;
+        const int32_t room = i - (int32_t)(mask >> 1); // steps left before the mask changes: i .. (mask >> 1) + 1
+        int32_t v[4];
+        bool acc[4], amb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t t = t0 + j * 64;
+            v[j] = (int32_t)(mt_temper(L.ring[(w + t) & (CRING - 1)]) & mask);
+            const bool valid = t < navail;
+            acc[j] = valid && v[j] <= i - (int32_t)t; // even if every word before it in the tile is accepted
+            amb[j] = valid && !acc[j] && v[j] <= i;
+        }
+        uint32_t Lc[4] = {0, 0, 0, 0}, tot = 0;
         for (int round = 0;; ++round) {
             if (round > TILE + 2) { // every round settles at least the first undecided word: cannot happen
                 failed = true;
                 break;
             }
-            const uint64_t ma = __ballot(acc), mb = __ballot(amb);
-            if (lane == 0)
-                L.wsum[par][wave] = (uint32_t)__popcll(ma) | ((uint32_t)__popcll(mb) << 16);
-            // all fills but the XDEPTH-1 youngest have landed once every wave is past this barrier: the tile of the NEXT trip
-            wait_vm_then_barrier<XDEPTH - 1>();
-            const uint4 *q = (const uint4 *)L.wsum[par];
-            const uint4 a = q[0], b = q[1], c = q[2], d = q[3];
-            const uint32_t s[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
-            uint32_t before = 0, total = 0;
+            uint64_t ma[4], mb[4];
+            uint32_t pk[4];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                total += s[k];
-                before += k < wave ? s[k] : 0u;
+            for (int j = 0; j < 4; ++j) {
+                ma[j] = __ballot(acc[j]);
+                mb[j] = __ballot(amb[j]);
+                pk[j] = (uint32_t)__popcll(ma[j]) | ((uint32_t)__popcll(mb[j]) << 16);
             }
+            if (lane == 0)
+                *(uint4 *)(L.cnt[par] + wave * 4) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            wait_vm_then_barrier<NOPS>(); // at most NWAIT fills stay in flight: the tile of the NEXT trip has landed
+            const uint32_t mine = lane < 16 ? L.cnt[par][lane] : 0u;
+            const uint32_t incl = row_scan16(mine);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 15);
             par ^= 1;
-            Lc = (before & 0xffffu) + lanes_below(ma);
+            uint32_t bef[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bef[j] = (uint32_t)__builtin_amdgcn_readlane((int)(incl - mine), wave * 4 + j);
+                Lc[j] = (bef[j] & 0xffffu) + lanes_below(ma[j]);
+            }
             tot = total & 0xffffu;
             if ((total >> 16) == 0)
                 break;
-            if (amb) {
-                const uint32_t U = Lc + (before >> 16) + lanes_below(mb);
-                if (v <= i - (int64_t)U) {
-                    acc = true;
-                    amb = false;
-                } else if (v > i - (int64_t)Lc) {
-                    amb = false;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (amb[j]) {
+                    const uint32_t U = Lc[j] + (bef[j] >> 16) + lanes_below(mb[j]);
+                    if (v[j] <= i - (int32_t)U) {
+                        acc[j] = true;
+                        amb[j] = false;
+                    } else if (v[j] > i - (int32_t)Lc[j]) {
+                        amb[j] = false;
+                    }
                 }
-            }
         }
         if (failed)
             break;
-        int e = navail;
-        if ((int64_t)tot >= room) { // cut right behind the room-th accepted word: what follows is judged under the next mask
-            if (acc && (int64_t)Lc == room - 1)
-                L.cut_at[par] = tid + 1;
+        uint32_t e = navail;
+        if ((int32_t)tot >= room) { // cut right behind the room-th accepted word: what follows is judged under the next mask
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (acc[j] && (int32_t)Lc[j] == room - 1)
+                    L.cut_at[par] = (int)(t0 + j * 64 + 1);
             lds_barrier();
-            e = L.cut_at[par];
+            e = (uint32_t)L.cut_at[par];
             tot = (uint32_t)room;
         }
-        if (acc && tid < e && Lc < tot)
-            tgt[i - Lc] = (uint32_t)v;
-        i -= tot;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { // exactly four stores per trip (see NOPS): lanes without a target write tgt[0], which no step reads
+            const bool ok = acc[j] && t0 + j * 64 < e && Lc[j] < tot;
+            tgt[ok ? i - (int32_t)Lc[j] : 0] = (uint32_t)v[j];
+        }
+        i -= (int32_t)tot;
         w += e;
         ++iters;
     }
@@ -943,9 +910,9 @@ __global__ __launch_bounds__(TILE) void perm_targets(const uint32_t *__restrict_
         return;
     }
     // RandomState afterwards: `pos` words of block b consumed; a block that is used up stays (pos = 624) until the next draw
-    const int64_t b = (w % MT_N == 0 && w > 0) ? w / MT_N - 1 : w / MT_N;
-    if (tid < MT_N)
-        st->key_out[tid] = x[b * MT_N + tid];
+    const uint32_t b = (w % MT_N == 0 && w > 0) ? w / MT_N - 1 : w / MT_N;
+    for (int t = tid; t < MT_N; t += WT)
+        st->key_out[t] = x[(size_t)b * MT_N + t];
     if (tid == 0) {
         st->pos_out = (int32_t)(w - b * MT_N);
         st->raw_next2 = w;
@@ -956,11 +923,13 @@ __global__ __launch_bounds__(TILE) void perm_targets(const uint32_t *__restrict_
 }
 
 // ---- phase 3 -------------------------------------------------------------------------------------------------------
+// (phase 3 reads what the walks wrote: after a walk that ran out of stream -- the host redoes the sample with a larger budget --
+// `tgt` is not fully written, and nothing may be indexed with it)
 __global__ __launch_bounds__(256) void perm_keys(const uint32_t *__restrict__ tgt, int64_t n, uint32_t *__restrict__ key, uint32_t *__restrict__ val,
-                                                 int32_t *__restrict__ head)
+                                                 int32_t *__restrict__ head, const DsStatus *__restrict__ st)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n)
+    if (i >= n || st->status != DS_OK)
         return;
     const uint32_t t = i == 0 ? (uint32_t)n : tgt[i];
     key[i] = (i == 0 || t == (uint32_t)i) ? (uint32_t)n : t; // step 0 does not exist; a self-swap moves nothing
@@ -970,10 +939,10 @@ __global__ __launch_bounds__(256) void perm_keys(const uint32_t *__restrict__ tg
 
 // sorted by (target, step): head[p] = first step that targets p, nxt[i] = the next step with step i's target
 __global__ __launch_bounds__(256) void perm_links(const uint32_t *__restrict__ skey, const uint32_t *__restrict__ sval, int64_t n,
-                                                  int32_t *__restrict__ head, int32_t *__restrict__ nxt)
+                                                  int32_t *__restrict__ head, int32_t *__restrict__ nxt, const DsStatus *__restrict__ st)
 {
     const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (q >= n)
+    if (q >= n || st->status != DS_OK)
         return;
     const uint32_t p = skey[q], i = sval[q];
     if (p >= (uint32_t)n) {
@@ -993,13 +962,14 @@ struct GatherArgs {
     const int32_t *edge_user, *items, *neg;
     int32_t *u, *i;
     void *third;
+    const DsStatus *st;
 };
 
 // perm[k] by the chase, then row perm[k] of the unshuffled sample (sampler.py:38,69,97)
 __global__ __launch_bounds__(256) void perm_gather(GatherArgs a)
 {
     const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (k >= a.n)
+    if (k >= a.n || a.st->status != DS_OK)
         return;
     int64_t s;
     const uint32_t t = k == 0 ? 0u : a.tgt[k];
@@ -1176,12 +1146,18 @@ int enqueue(crec_ctx *ctx, crec_dsampler *s)
         hipLaunchKernelGGL(cand_scatter, dim3((unsigned)cand_blocks), dim3(256), 0, st, (const uint32_t *)x, r0, w1, mask, mx,
                            (const uint32_t *)s->counts.ptr, (int32_t *)s->cand.ptr, (uint32_t *)s->cand_raw.ptr);
         NegArgs na{(const int32_t *)s->cand.ptr, (const uint32_t *)s->cand_raw.ptr, (const int64_t *)s->ptr.ptr, s->n_users,
-                   (const uint32_t *)s->bitmaps.ptr, s->bw, s->nbuf, nr, (int32_t *)s->neg.ptr, dst, r0};
-        if (nr <= FAST_NR_MAX && s->bw <= FAST_BW_MAX && !ctx->knob_dsampler_general) {
-            na.nbuf = FAST_NBUF;
-            const size_t lds = ((size_t)FAST_NBUF * s->bw + CRING + 34 * (size_t)(nr - 1) + 32 + 4) * 4 + 32 * 8 + (size_t)(UCACHE + 1) * 8;
-            CREC_HIP(ctx, hipFuncSetAttribute((const void *)neg_chain_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(neg_chain_fast, dim3(1), dim3(TILE), lds, st, na);
+                   (const uint32_t *)s->bitmaps.ptr, s->bw, s->nbuf, nr, (int32_t *)s->neg.ptr, dst, r0, 0u, (uint32_t)n_neg};
+        na.cand_cap = (uint32_t)(s->cand.bytes / 4) & ~3u;
+        if (nr <= WALK_NR_MAX && s->bw <= WALK_BW_MAX && !ctx->knob_dsampler_general) {
+            na.nbuf = WALK_NBUF;
+            const size_t lds = ((size_t)WALK_NBUF * s->bw + CRING + (size_t)((nr - 1 + TILE + 3) & ~3) + 32 + 16) * 4 + (size_t)(UCACHE + 1) * 8;
+            if (nr == 4) {
+                CREC_HIP(ctx, hipFuncSetAttribute((const void *)neg_walk<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(neg_walk<4>, dim3(1), dim3(WT), lds, st, na);
+            } else {
+                CREC_HIP(ctx, hipFuncSetAttribute((const void *)neg_walk<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(neg_walk<0>, dim3(1), dim3(WT), lds, st, na);
+            }
         } else {
             const size_t lds = ((((size_t)s->nbuf * s->bw + 1) & ~(size_t)1) + CBUF + ((nr - 1 + TILE + 1) & ~1)) * 4 + (size_t)(UCACHE + 1) * 8;
             if (s->pwords == 1) {
@@ -1198,12 +1174,12 @@ int enqueue(crec_ctx *ctx, crec_dsampler *s)
         CREC_HIP(ctx, hipMemcpyAsync(&dst->raw_next1, &s->raw_next1_in, sizeof(int64_t), hipMemcpyHostToDevice, st));
     }
     // phase 2 (also leaves the final generator state)
-    hipLaunchKernelGGL(perm_targets, dim3(1), dim3(TILE), 0, st, (const uint32_t *)x, x_words, n, (uint32_t *)s->tgt.ptr, dst);
+    hipLaunchKernelGGL(perm_targets, dim3(1), dim3(WT), 0, st, (const uint32_t *)x, x_words, n, (uint32_t *)s->tgt.ptr, dst);
     // phase 3
     if (n > 0) {
         const unsigned g = (unsigned)crec_ceil_div(n, 256);
         hipLaunchKernelGGL(perm_keys, dim3(g), dim3(256), 0, st, (const uint32_t *)s->tgt.ptr, n, (uint32_t *)s->key.ptr, (uint32_t *)s->val.ptr,
-                           (int32_t *)s->head.ptr);
+                           (int32_t *)s->head.ptr, (const DsStatus *)dst);
         const uint32_t *skey = (const uint32_t *)s->key.ptr, *sval = (const uint32_t *)s->val.ptr;
         if (n > 1) {
             CREC_HIP(ctx, rocprim::radix_sort_pairs(s->sort_tmp.ptr, tmp_bytes, (const uint32_t *)s->key.ptr, (uint32_t *)s->skey.ptr,
@@ -1211,9 +1187,10 @@ int enqueue(crec_ctx *ctx, crec_dsampler *s)
             skey = (const uint32_t *)s->skey.ptr;
             sval = (const uint32_t *)s->sval.ptr;
         }
-        hipLaunchKernelGGL(perm_links, dim3(g), dim3(256), 0, st, skey, sval, n, (int32_t *)s->head.ptr, (int32_t *)s->nxt.ptr);
+        hipLaunchKernelGGL(perm_links, dim3(g), dim3(256), 0, st, skey, sval, n, (int32_t *)s->head.ptr, (int32_t *)s->nxt.ptr, (const DsStatus *)dst);
         GatherArgs ga{(const uint32_t *)s->tgt.ptr, (const int32_t *)s->head.ptr, (const int32_t *)s->nxt.ptr, n, s->kind, nr,
-                      (const int32_t *)s->edge_user.ptr, (const int32_t *)s->items.ptr, (const int32_t *)s->neg.ptr, s->u, s->i, s->third};
+                      (const int32_t *)s->edge_user.ptr, (const int32_t *)s->items.ptr, (const int32_t *)s->neg.ptr, s->u, s->i, s->third,
+                      (const DsStatus *)dst};
         hipLaunchKernelGGL(perm_gather, dim3(g), dim3(256), 0, st, ga);
     }
     CREC_HIP(ctx, hipGetLastError());
@@ -1240,7 +1217,7 @@ int crec_dsampler_create(crec_ctx *ctx, const int64_t *ptr, const int32_t *items
     for (int64_t k = 0; k < n_users; ++k)
         CREC_REQUIRE(ctx, ptr[k + 1] >= ptr[k], "ptr not monotone at %lld", (long long)k);
     // what the kernels are built for; anything else stays with the host sampler (crec_sample_*)
-    const int bw = (int)(crec_ceil_div(crec_ceil_div(item_nums, 32), 64) * 64); // words per bitmap row, whole 64-word LDS-DMA pieces
+    const int bw = (int)(crec_ceil_div(crec_ceil_div(item_nums, 32), 256) * 256); // words per bitmap row: whole 1 KiB LDS-DMA pieces
     if (bw > 8 * TILE || (double)n_users * bw * 4.0 > 2147483648.0)
         return crec_fail(ctx, CREC_EUNSUPPORTED, "device sampler: item_nums <= 262144 and users x items / 8 <= 2 GiB (use crec_sample_*)");
     std::vector<int32_t> stamp, eu;
@@ -1347,13 +1324,13 @@ int crec_dsampler_sample(crec_ctx *ctx, crec_dsampler *s, int kind, int neg_rati
     CREC_REQUIRE(ctx, !s->pending, "the previous sample has not been finished (crec_dsampler_finish)");
     const int64_t n = kind == 0 ? s->n_pos * neg_ratio : (kind == 1 ? s->n_pos * (1 + (int64_t)neg_ratio) : s->n_pos);
     CREC_REQUIRE(ctx, n == 0 || (u && i && third), "null output");
-    CREC_REQUIRE(ctx, n < ((int64_t)1 << 31), "epoch too large for the device sampler");
+    CREC_REQUIRE(ctx, n < ((int64_t)1 << 31) && s->n_pos * (int64_t)neg_ratio < ((int64_t)1 << 31), "epoch too large for the device sampler");
     // the reference's rejection loop ends only if every user can supply neg_ratio unseen items (crec_sample_* checks the same)
     CREC_REQUIRE(ctx, s->n_pos == 0 || neg_ratio == 0 || s->max_uniq + neg_ratio <= s->item_nums, "a user has fewer than neg_ratio unseen items");
     CREC_HIP(ctx, hipSetDevice(s->device));
     s->kind = kind, s->nr = neg_ratio, s->pos_in = pos, s->u = u, s->i = i, s->third = third, s->stream = (hipStream_t)stream;
     s->n = n;
-    s->growth = 1.0;
+    s->growth = ctx->knob_dsampler_budget > 0 ? ctx->knob_dsampler_budget / 100.0 : 1.0;
     std::memcpy(s->key_in, key, sizeof(s->key_in));
     return enqueue(ctx, s);
 }

@@ -24,15 +24,28 @@ class RankingRecommender(Recommender):
         self.test_users = [int(u) for u in (data.test_users if hasattr(data, 'test_users') else data.ui_test.keys())]
         self.test_batches = math.ceil(len(self.test_users) / self.batch_size_t)
         self._eval_cache = None
-        # extension (not in the reference): `sampler_mode=device` draws the epoch on the GPU with the same acceptance
-        # rule but its own generator -- statistically equivalent, not NumPy-stream compatible; the default
-        # (`mt19937`) is the bit-exact host sampler
-        # extension: draw the next epoch's (bit-exact) sample on a host thread while the GPU runs this one; the index
-        # stream and np.random's state afterwards are unchanged (utils/sampler.py).  `sampler_prefetch=False` turns it off
+        # `sampler_mode` (extension; default mt19937):
+        #   mt19937       the reference's index streams bit for bit -- NumPy's MT19937 words, the rejection loops, the shuffle --
+        #                 drawn ON the device (runtime.MtSampler, csrc/mt_sampler.hip) with the columns left in HBM; shapes outside
+        #                 the kernels' limits (item_nums > 262144) fall to the same stream drawn by the host C++ form
+        #   mt19937_host  the host C++ form (utils/sampler.py), same streams
+        #   device        same acceptance rule on a counter-based generator: statistically equivalent, NOT stream-compatible
+        # `sampler_prefetch` (default True): the NEXT epoch's sample is drawn while the GPU trains on this one (device form: on a
+        # second stream; host form: on a host thread); the streams and np.random's state afterwards are unchanged
         self.sampler_prefetch = str(configs.get('sampler_prefetch', 'True')).lower() not in ('false', '0', 'no')
-        self._dev_sampler = None
-        if str(configs.get('sampler_mode', 'mt19937')).lower() == 'device':
+        self._dev_sampler = self._mt_sampler = None
+        mode = str(configs.get('sampler_mode', 'mt19937')).lower()
+        if mode == 'device':
             self._dev_sampler = runtime.DeviceSampler(sess, data, seed=int(configs.get('seed', 0)))
+        elif mode == 'mt19937':
+            from .._lib import CrecError, EUNSUPPORTED
+            try:
+                self._mt_sampler = runtime.MtSampler(self.sess, data)
+            except CrecError as e:
+                if e.code != EUNSUPPORTED:
+                    raise
+        elif mode != 'mt19937_host':
+            raise ValueError("sampler_mode=%s: mt19937 | mt19937_host | device" % mode)
 
     # -- hooks a model class fills in ---------------------------------------------------------
     def _train_epoch_device(self, u, i, j):
@@ -50,24 +63,45 @@ class RankingRecommender(Recommender):
     # -- one epoch (RankingRecommender.py:33-61) -------------------------------------------------
     def train_model(self):
         s = self.sess
+        pairwise = self.is_pairwise == 'True'
         if self._dev_sampler is not None:
             ds = self._dev_sampler
-            cols = ds.pairwise(self.neg_ratio) if self.is_pairwise == 'True' else ds.pointwise(self.neg_ratio)
+            cols = ds.pairwise(self.neg_ratio) if pairwise else ds.pointwise(self.neg_ratio)
             losses = self._train_epoch_device(*cols)
             return float(losses.double().sum().item()) / int(losses.numel())
-        if self.is_pairwise == 'True':
+        if self._mt_sampler is not None:  # the reference's sample, drawn on the device: nothing crosses PCIe
+            if self.fism_like:
+                raise NotImplementedError("fism_like models are outside this core (SURVEY.md 2.1 #10)")
+            cols = self._mt_sampler.next_epoch("pairwise" if pairwise else "pointwise", self.neg_ratio, ahead=self._ahead())
+            self._epoch_instances = int(cols[0].numel())
+            losses = self._train_epoch_device(*cols)
+            return float(losses.double().sum().item()) / math.ceil(int(cols[0].numel()) / self.batch_size)
+        if pairwise:
             train_ = pairwise_ranking_sampler(self.data, self.neg_ratio, self.batch_size, fism_like=self.fism_like,
-                                              prefetch_next=self.sampler_prefetch)
+                                              prefetch_next=self._ahead())
             u, i, j = (s.to_dev(a) for a in train_[1:4])
             losses = self._train_epoch_device(u, i, j)
         else:  # pointwise: (u, i, label) instances (RankingRecommender.py:48-58)
             train_ = pointwise_ranking_sampler(self.data, self.neg_ratio, self.batch_size, fism_like=self.fism_like,
-                                               prefetch_next=self.sampler_prefetch)
+                                               prefetch_next=self._ahead())
             u, i = s.to_dev(train_[1]), s.to_dev(train_[2])
             y = s.to_dev(np.asarray(train_[3], dtype=np.float32))
             losses = self._train_epoch_device(u, i, y)
+        self._epoch_instances = len(train_[1])
         total_loss = float(losses.double().sum().item())  # total_loss += loss_val over the batches
         return total_loss / train_[0]
+
+    def _ahead(self):
+        """draw the next epoch's sample during this one?  Not on run_model's last epoch: nobody would use it"""
+        return self.sampler_prefetch and not getattr(self, '_last_epoch', False)
+
+    def _samplers_done(self):
+        """end of training: a sample drawn ahead for an epoch that will not come is dropped (np.random is where the last USED sample
+        left it, by construction) and nothing keeps running behind the caller's back"""
+        if self._mt_sampler is not None:
+            self._mt_sampler.drop()
+        from ..utils import sampler as host_sampler
+        host_sampler.drop_prefetch(join=True)
 
     # -- full-catalogue evaluation (RankingRecommender.py:198-247) -------------------------------
     def _eval_inputs(self):
@@ -143,8 +177,13 @@ class RankingRecommender(Recommender):
         best_metrics = {}
         for epoch in range(self.epoches):
             t1 = time.time()
+            self._last_epoch = epoch == self.epoches - 1
             avg_loss = self.train_model()
-            self.logger.info(' epoch %d\n  Training loss: %.4f, time: %s' % (epoch + 1, avg_loss, time.strftime('%H:%M:%S', time.gmtime(time.time() - t1))))
+            dt = time.time() - t1
+            self.logger.info(' epoch %d\n  Training loss: %.4f, time: %s' % (epoch + 1, avg_loss, time.strftime('%H:%M:%S', time.gmtime(dt))))
+            n_inst = getattr(self, '_epoch_instances', None)
+            if n_inst:  # (extension) sampler-inclusive rate of the epoch just run
+                self.logger.info('  %.2f M instances/s (%.1f ms, sampling included)' % (n_inst / max(dt, 1e-9) / 1e6, dt * 1e3))
             t2 = time.time()
             if (epoch + 1) % self.T:
                 continue
@@ -152,7 +191,9 @@ class RankingRecommender(Recommender):
                 HR, MRR, NDCG = self.test_model_loo()
             else:
                 HR, MRR, NDCG = self.test_model_rs()
-            self.logger.info('  Testing time: %s' % time.strftime('%H:%M:%S', time.gmtime(time.time() - t2)))
+            dt2 = time.time() - t2
+            self.logger.info('  Testing time: %s' % time.strftime('%H:%M:%S', time.gmtime(dt2)))
+            self.logger.info('  %.1f k users/s (%.1f ms)' % (len(self.test_users) / max(dt2, 1e-9) / 1e3, dt2 * 1e3))
             best_flag = False
             for id in range(len(self.topk)):
                 hr, mrr, ndcg = np.mean(HR[id]), np.mean(MRR[id]), np.mean(NDCG[id])
@@ -163,6 +204,7 @@ class RankingRecommender(Recommender):
                 if best_flag:
                     best_metrics[id] = (hr, mrr, ndcg)
                     best_epoch = epoch + 1
+        self._samplers_done()
         self.logger.info('best_epoch: %d' % best_epoch)
         for id in range(len(self.topk)):
             if id in best_metrics:  # the reference raises KeyError when NDCG never rose above 0

@@ -1,5 +1,7 @@
 """Collaborative Metric Learning (reference model/ranking/CML.py): same class name, constructor and hooks;
 train_model is rebound to train_model_cml exactly like the reference (CML.py:16)."""
+import math
+
 from ...runtime import CmlState
 from ...utils.sampler import ranking_sampler_cml
 from ..RankingRecommender import RankingRecommender
@@ -45,7 +47,12 @@ class CML(RankingRecommender):
             u, i, neg = self._dev_sampler.cml(self.neg_ratio)
             losses = self.state.train_epoch(u, i, neg, self.batch_size)
             return float(losses.double().sum().item()) / int(losses.numel())
-        train_ = ranking_sampler_cml(self.data, self.neg_ratio, self.batch_size, prefetch_next=self.sampler_prefetch)
+        if self._mt_sampler is not None:  # the reference's sample, drawn on the device
+            u, i, neg = self._mt_sampler.next_epoch("cml", self.neg_ratio, ahead=self._ahead())
+            self._epoch_instances = int(u.numel())
+            losses = self.state.train_epoch(u, i, neg, self.batch_size)
+            return float(losses.double().sum().item()) / math.ceil(int(u.numel()) / self.batch_size)
+        train_ = ranking_sampler_cml(self.data, self.neg_ratio, self.batch_size, prefetch_next=self._ahead())
         s = self.sess
         losses = self.state.train_epoch(s.to_dev(train_[1]), s.to_dev(train_[2]), s.to_dev(train_[3]), self.batch_size)
         return float(losses.double().sum().item()) / train_[0]

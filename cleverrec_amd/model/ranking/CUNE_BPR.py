@@ -44,7 +44,7 @@ class CUNE_BPR(SBPR):
 
     def train_model_cune(self):
         """RankingRecommender.train_model_sbpr(is_suk=False) (model/RankingRecommender.py:101-116)."""
-        train_ = ranking_sampler_sbpr(self.data, self.SPu, self.neg_ratio, self.batch_size, is_suk=False, prefetch_next=self.sampler_prefetch)
+        train_ = ranking_sampler_sbpr(self.data, self.SPu, self.neg_ratio, self.batch_size, is_suk=False, prefetch_next=self._ahead())
         s = self.sess
         losses = self.state.train_epoch(*(s.to_dev(train_[c]) for c in range(1, 5)), self.batch_size)
         return float(losses.double().sum().item()) / train_[0]

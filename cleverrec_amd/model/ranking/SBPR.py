@@ -60,7 +60,7 @@ class SBPR(RankingRecommender):
 
     def train_model_sbpr(self, is_suk=True):
         """RankingRecommender.train_model_sbpr (model/RankingRecommender.py:101-116)."""
-        train_ = ranking_sampler_sbpr(self.data, self.SPu, self.neg_ratio, self.batch_size, is_suk=True, prefetch_next=self.sampler_prefetch)
+        train_ = ranking_sampler_sbpr(self.data, self.SPu, self.neg_ratio, self.batch_size, is_suk=True, prefetch_next=self._ahead())
         s = self.sess
         cols = [s.to_dev(train_[c]) for c in range(1, 6)]
         losses = self.state.train_epoch(*cols, self.batch_size)

@@ -121,10 +121,13 @@ def _sample(kind, data, neg_ratio, prefetch_next, extra=(), tag=None):
     return out
 
 
-def drop_prefetch():
-    """forget a sample drawn ahead (its thread finishes on its own); np.random is untouched by construction"""
+def drop_prefetch(join=False):
+    """forget a sample drawn ahead; np.random is untouched by construction.  join: wait for its host thread (end of
+    training: nothing of the sampler keeps running, or holds the data, behind the caller's back)"""
     global _pending
-    _pending = None
+    pf, _pending = _pending, None
+    if join and pf is not None:
+        pf.thread.join()
 
 
 def pairwise_ranking_sampler(data, neg_ratio, batch_size, fism_like=False, prefetch_next=False):

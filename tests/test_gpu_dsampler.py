@@ -42,9 +42,9 @@ def _np(cols):
     return [c.cpu().numpy() for c in cols]
 
 
-@pytest.fixture(params=[0, 1], ids=["one-barrier-walk", "general-walk"])
+@pytest.fixture(params=[0, 1], ids=["four-wave-walk", "general-walk"])
 def walk(sess, request):
-    """both forms of the negatives walk (csrc/mt_sampler.hip: neg_chain_fast where its limits allow, neg_chain_general)"""
+    """both forms of the negatives walk (csrc/mt_sampler.hip: neg_walk where its limits allow, neg_chain_general)"""
     sess.ctx.set_option("dsampler_general", request.param)
     yield request.param
     sess.ctx.set_option("dsampler_general", 0)
@@ -74,6 +74,22 @@ def test_device_samplers_reproduce_the_reference_streams(sess, walk, name):
     ms.close()
 
 
+def test_a_starved_stream_budget_is_retried_to_the_same_result(sess, walk):
+    """the stream budget is sized from expected rejection counts; when an epoch needs more, the walk reports it and the sample is
+    redone with twice the words -- same columns, same state (here the first budgets are cut to a fifth on purpose)"""
+    g = np.load(os.path.join(GOLDEN, "sampler_syn200.npz"))
+    ms = runtime.MtSampler(sess, _Csr(g["keys"], g["ptr"], g["items"], g["item_nums"]))
+    key, pos = _state(int(g["seed"]))
+    sess.ctx.set_option("dsampler_budget", 20)
+    try:
+        (u, i, j), end = ms.sample("pairwise", int(g["neg_ratio"]), key, pos)
+    finally:
+        sess.ctx.set_option("dsampler_budget", 100)
+    assert np.array_equal(u.cpu().numpy(), g["pw_u"]) and np.array_equal(j.cpu().numpy(), g["pw_j"])
+    assert _next30(*end) == int(g["pw_next"])
+    ms.close()
+
+
 def _population(seed, U, I, lo, hi):
     g = np.random.Generator(np.random.PCG64(seed))
     ui = {}
@@ -95,7 +111,7 @@ def _population(seed, U, I, lo, hi):
     (700, 3000, 1, 2500, 3, 5),    # users that have seen most of the catalogue: thousands of candidates per user
     (1500, 40000, 1, 60, 1, 6),    # bitmap words beyond one per thread (item_nums > 32768), neg_ratio 1
     (3000, 500, 1, 5, 20, 7),      # CML's group of 20 on short lists: several users per tile
-    (900, 70, 1, 60, 33, 8),       # the widest group the one-barrier walk takes; most users cannot fill it twice over
+    (900, 120, 1, 60, 33, 8),      # a wide group (runtime neg_ratio in the four-wave walk); many repeats
     (200, 90000, 1, 9, 40, 9),     # beyond both of its limits: the general walk either way
     (5000, 64, 0, 3, 3, 10),       # empty users (no train rows) in runs, tiny needs
 ])
@@ -160,3 +176,30 @@ def test_ml1m_shape_epoch_and_stream_accounting(sess):
     b = _np(ms.sample("pointwise", 4, key, pos)[0])
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
     ms.close()
+
+
+@pytest.mark.parametrize("model", ["BPR", "GMF", "CML"])
+def test_class_surface_trains_identically_on_either_form(sess, tmp_path, model):
+    """the drop-in classes draw their epochs on the device by default (sampler_mode=mt19937); with the host form of the same
+    stream (mt19937_host) the index streams are the same bit for bit, so the epochs' losses and np.random afterwards are too"""
+    import importlib
+    import logging
+    data = synthetic("S-ml100k")
+    cfg = {"recommender": model, "epoches": "3", "batch_size": "6144", "test.batch_size": "1024", "lr": "0.01", "test.neg_samples": "0",
+           "is_pairwise": "True" if model != "GMF" else "False", "init_method": "normal", "stddev": "0.01",
+           "loss_func": "bpr" if model == "BPR" else "cross_entropy", "optimizer": "Adam", "saved_dir": str(tmp_path), "test.interval": "1",
+           "topk": "[10,20]", "neg_ratio": "4" if model != "CML" else "20", "embed_size": "32", "reg": "0.01", "adam_mode": "tf1",
+           "data.split_way": "rs", "margin": "1.0", "cml_like": "True" if model == "CML" else "False"}
+    cls = getattr(importlib.import_module("cleverrec_amd.model.ranking." + model), model)
+    out = {}
+    for mode in ("mt19937", "mt19937_host"):
+        np.random.seed(77)
+        torch.manual_seed(0)
+        m = cls(sess, data, dict(cfg, sampler_mode=mode), logging.getLogger("t"))
+        assert (m._mt_sampler is not None) == (mode == "mt19937")
+        m.build_model()
+        losses = [m.train_model() for _ in range(3)]
+        m._samplers_done()
+        out[mode] = (losses, np.random.randint(2 ** 30))
+    assert out["mt19937"][1] == out["mt19937_host"][1]
+    np.testing.assert_allclose(out["mt19937"][0], out["mt19937_host"][0], rtol=1e-6)
