@@ -15,7 +15,7 @@ Extra objects in the line:
   cpu_baseline  the CPU oracle (oracle/crec_oracle.c, one core) on a bounded sample of the
                 same workload -- a reported baseline, not the target
   eval          full-catalogue top-20 evaluation of all test users (users/s)
-  sampler       the bit-exact host sampler's rate and the sampler-inclusive epoch rate
+  sampler       the bit-exact device sampler's rate and the measured sampler-inclusive epoch rate (default mode), the host form beside it
 """
 import argparse
 import json
@@ -366,13 +366,47 @@ def main():
                        "gemm_TFLOPs": 2.0 * len(data.test_users) * I * D / te / 1e12, "ndcg@10": float(ndcg[0].mean())}
 
         # ---- sampler ---------------------------------------------------------------------------------
+        # the default of the drop-in classes: the reference's own index stream (NumPy MT19937, bit for bit), drawn ON the
+        # device (runtime.MtSampler, csrc/mt_sampler.hip), the next epoch's sample on a second stream beside this epoch's steps
         epoch_gpu_s = (n_epoch / B) * (dt / a.steps)
-        out["sampler"] = {"mode": "mt19937 bit-exact (host: one RNG thread + swap and gather threads behind it)", "triples_per_s": n_epoch / t_sample,
-                          "epoch_triples": n_epoch, "epoch_inclusive_triples_per_s_serial": n_epoch / (t_sample + epoch_gpu_s),
-                          "epoch_inclusive_triples_per_s_overlapped": n_epoch / max(t_sample, epoch_gpu_s)}
+        ms_dev = runtime.MtSampler(sess, data)
+        key0, pos0 = np.random.RandomState(1).get_state()[1:3]
+        t_dev = []
+        kk, pp = key0, pos0
+        for _ in range(6):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            cols, (kk, pp) = ms_dev.sample("pairwise", NEG, kk, pp)
+            t_dev.append(time.perf_counter() - t0)
+        t_dev_s = sorted(t_dev[1:])[len(t_dev[1:]) // 2]
+        same = bool(np.array_equal(ms_dev.sample("pairwise", NEG, key0, pos0)[0][2][:4096].cpu().numpy(), j[:4096])) if a.gpus == 1 else None
+        np.random.seed(1)
+        t_ep = []
+        for e in range(7):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            cu, ci, cj = ms_dev.next_epoch("pairwise", NEG, ahead=True)
+            st.train_epoch(cu, ci, cj, B)
+            torch.cuda.synchronize()
+            t_ep.append(time.perf_counter() - t0)
+        ms_dev.drop()
+        steady_ep = sorted(t_ep[1:])[len(t_ep[1:]) // 2]
+        stats_dev = ms_dev.stats()
+        out["sampler"] = {"mode": "mt19937 bit-exact, drawn on the device (jump-ahead MT19937 chains, randint as a compaction, negatives / shuffle-target "
+                                  "walks, permutation by sort + pointer chase); the default of the model classes",
+                          "triples_per_s": int(cu.numel()) / t_dev_s, "ms_per_epoch": t_dev_s * 1e3, "epoch_triples": int(cu.numel()),
+                          "epoch_inclusive_triples_per_s": int(cu.numel()) / steady_ep,
+                          "epoch_inclusive_note": "measured: median of 6 epochs of next_epoch() + %d steps, the next epoch's sample drawn on a second stream "
+                                                  "beside the steps; first epoch (nothing drawn ahead) %.1f ms, steady %.1f ms; the sampler alone %.1f ms, the "
+                                                  "steps alone %.1f ms" % (int(cu.numel()) // B, t_ep[0] * 1e3, steady_ep * 1e3, t_dev_s * 1e3, epoch_gpu_s * 1e3),
+                          "epoch_inclusive_triples_per_s_serial": int(cu.numel()) / (t_dev_s + epoch_gpu_s),
+                          "first_4096_negatives_equal_host_sampler": same,
+                          "walks": {k: stats_dev[k] for k in ("neg_tiles", "neg_us", "perm_tiles", "perm_us", "words_negatives", "words_shuffle")}}
+        ms_dev.close()
 
-        # measured, not derived: epochs through the drop-in sampler wrapper with the next epoch's sample drawn ahead on
-        # a host thread (utils/sampler.py; bit-identical stream)
+        # the host form of the same stream (sampler_mode=mt19937_host; SBPR's sampler and catalogues beyond the device form's limits)
+        out["sampler"]["host_form"] = {"triples_per_s": n_epoch / t_sample, "ms_per_epoch": t_sample * 1e3,
+                                       "note": "crec_sample_pairwise: one RNG thread + swap and gather threads behind it"}
         from cleverrec_amd.utils import sampler as S
         S.drop_prefetch()
         np.random.seed(1)
@@ -385,12 +419,11 @@ def main():
             st.train_epoch(sess.to_dev(uu), sess.to_dev(ii), sess.to_dev(jj), B)
             torch.cuda.synchronize()
             t_ep.append(time.perf_counter() - t0)
-        S.drop_prefetch()
+        S.drop_prefetch(join=True)
         steady = sorted(t_ep[1:])[len(t_ep[1:]) // 2]
-        out["sampler"]["epoch_inclusive_triples_per_s"] = len(uu) / steady
-        out["sampler"]["epoch_inclusive_note"] = ("measured: median of 5 epochs (sample -> upload -> %d steps), next epoch's sample prefetched on a host "
-                                                  "thread; first epoch (no prefetch) %.1f ms, steady %.1f ms; bound = min(sampler %.0f M/s, GPU %.0f M/s)"
-                                                  % (len(uu) // B, t_ep[0] * 1e3, steady * 1e3, n_epoch / t_sample / 1e6, value / 1e6))
+        out["sampler"]["host_form"]["epoch_inclusive_triples_per_s"] = len(uu) / steady
+        out["sampler"]["host_form"]["epoch_inclusive_note"] = ("median of 5 epochs (sample -> upload -> steps), next epoch's sample prefetched on a host thread; "
+                                                               "first epoch %.1f ms, steady %.1f ms" % (t_ep[0] * 1e3, steady * 1e3))
 
         # the optional device sampler (same acceptance rule, counter-based generator: not NumPy-stream compatible)
         ds = runtime.DeviceSampler(sess, data, seed=1)
@@ -401,9 +434,10 @@ def main():
             cu, ci, cj = ds.pairwise(NEG)
         torch.cuda.synchronize()
         t_dev = (time.perf_counter() - t0) / 5
-        out["sampler"]["device_mode"] = {"triples_per_s": int(cu.numel()) / t_dev, "ms_per_epoch": t_dev * 1e3,
-                                         "epoch_inclusive_triples_per_s": n_epoch / (t_dev + epoch_gpu_s),
-                                         "note": "crec_sample_negatives_device + device randperm + gathers; opt-in (sampler_mode=device)"}
+        out["sampler"]["counter_based_mode"] = {"triples_per_s": int(cu.numel()) / t_dev, "ms_per_epoch": t_dev * 1e3,
+                                                "epoch_inclusive_triples_per_s": n_epoch / (t_dev + epoch_gpu_s),
+                                                "note": "crec_sample_negatives_device + device randperm + gathers: same acceptance rule, own generator, NOT the "
+                                                        "reference's stream; opt-in (sampler_mode=device)"}
 
         # ---- S-big: the HBM-bound form of the same path (10 M x 1 M, d=128, lazy Adam) ----------------
         if not a.no_big:

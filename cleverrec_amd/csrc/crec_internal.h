@@ -113,7 +113,7 @@ struct crec_ctx {
     int knob_no_zero_copy = 0;   // 1: the chunk's counts come back by copy + stream synchronisation (tests)
     int knob_ncf_generic = 0;    // 1: the generic ncf_tile even for the shapes that have a specialised one (tests)
     int knob_dsampler_budget = 100; // percent of the device sampler's stream budget to start with (tests: < 100 forces the retry path)
-    int knob_dsampler_general = 0; // 1: the device sampler's general negatives walk even where the one-barrier form applies (tests)
+    int knob_dsampler_general = 0; // negatives phase of the device sampler: 0 parallel tables (walk where they do not apply), 2 the four-wave walk, 1 the general walk (tests)
 };
 
 int crec_fail(crec_ctx *ctx, int code, const char *fmt, ...);

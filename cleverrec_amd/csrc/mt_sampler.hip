@@ -48,7 +48,7 @@ constexpr int UCACHE = 1024;     // users whose CSR bounds sit in LDS at a time
 constexpr int CAND_BLK = 2048;   // raw words per workgroup of the compaction kernels (256 threads x 8)
 constexpr int32_t NONE = -1;
 
-enum { DS_OK = 0, DS_OUT_OF_CANDIDATES = 1, DS_OUT_OF_WORDS = 2, DS_INTERNAL = 3 };
+enum { DS_OK = 0, DS_OUT_OF_CANDIDATES = 1, DS_OUT_OF_WORDS = 2, DS_INTERNAL = 3, DS_NEED_WALK = 4 };
 
 struct DsStatus {
     int32_t status;
@@ -57,6 +57,8 @@ struct DsStatus {
     int64_t raw_next1;   // stream index (in X) of the first word phase 2 may use
     int64_t raw_next2;   // ... of the first word nobody used: the generator stands here afterwards
     int64_t cand_used;
+    int32_t why, why_at; // DS_NEED_WALK: what the parallel negatives phase met (1 events, 2 knot of repeats, 3 start outside a window,
+                         // 4 range too short, 5 a user's end does not check) and at which user / segment
     int64_t dbg[6];      // tile iterations, shader clocks, 100 MHz ticks of neg_chain and of perm_targets (crec_dsampler_stats)
     uint32_t key_out[MT_N];
 };
@@ -593,20 +595,21 @@ __device__ __forceinline__ uint32_t row_scan16(uint32_t v)
 template <int NRT> __global__ __launch_bounds__(WT) void neg_walk(NegArgs a)
 {
     extern __shared__ uint32_t lds[];
-    const int nr = NRT ? NRT : a.nr, CARRY = nr - 1, bw = a.bw, nbuf = a.nbuf;
-    // ONE shared object: [bitmap ring][candidate ring][D: accepted of the tile behind the last nr-1 of the tiles before][counts][cuts][CSR bounds]
+    static_assert(WALK_NBUF == 8, "ring slot = user & 7");
+    const int nr = NRT ? NRT : a.nr, CARRY = nr - 1, bw = a.bw;
+    // ONE shared object: [bitmap ring][candidate ring][D: accepted of the tile behind the last nr-1 of the tiles before, one spare][counts][cuts][CSR bounds]
     uint32_t *bm = lds;
-    int32_t *cbuf = (int32_t *)(bm + (size_t)nbuf * bw);
+    int32_t *cbuf = (int32_t *)(bm + (size_t)WALK_NBUF * bw);
     int32_t *D = cbuf + CRING;
-    uint32_t *cnt = (uint32_t *)(D + ((CARRY + TILE + 3) & ~3)); // [2][16]
-    uint32_t *red = cnt + 32;                                    // [2][8]: per wave {first repeat | its rank, thread of the last slot}
-    int64_t *uptr = (int64_t *)(red + 16);                       // [UCACHE + 1]
+    uint32_t *cnt = (uint32_t *)(D + ((CARRY + TILE + 1 + 3) & ~3)); // [2][16]
+    uint32_t *red = cnt + 32;                                        // [2][8]: per wave {first repeat | its rank, thread of the last slot}
+    uint32_t *uptr = red + 16;                                       // [UCACHE + 1]: CSR bounds (< 2^31: checked by the host)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t n_cand = (uint32_t)a.st->n_cand;
-    const int64_t n_users = a.n_users;
+    const uint32_t n_cand = (uint32_t)a.st->n_cand, n_users = (uint32_t)a.n_users;
     const uint64_t clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
     const uint32_t cbuf_at = lds_addr(cbuf), bm_at = lds_addr(bm);
+    const uint32_t d_spare = (uint32_t)(CARRY + TILE); // where lanes without an accepted candidate put theirs
 
     uint32_t filled = 0;
     const auto fill = [&]() { // candidates [filled, filled + 1024) -> ring; one 16-byte request per lane
@@ -615,39 +618,41 @@ template <int NRT> __global__ __launch_bounds__(WT) void neg_walk(NegArgs a)
         glds_x4(a.cand + idx, cbuf_at + ((filled + wave * 256) & (CRING - 1)) * 4);
         filled += TILE;
     };
-    // user u's bitmap -> ring slot u % nbuf, 256 words per wave and request.  Past the last user the request is still made (the
+    // user u's bitmap -> ring slot u & 7, 256 words per wave and request.  Past the last user the request is still made (the
     // last user's words, into a slot nobody reads any more): the wait below counts on the requests that follow one
-    const auto load_bitmap = [&](int64_t u) {
-        const uint32_t slot_at = bm_at + (uint32_t)((u % nbuf) * bw * 4);
-        const int64_t src = u < n_users ? u : n_users - 1;
+    const auto load_bitmap = [&](uint32_t u) {
+        const uint32_t slot_at = bm_at + (u & 7u) * (uint32_t)bw * 4u;
+        const uint32_t src = u < n_users ? u : n_users - 1;
         for (int w0 = wave * 256; w0 < bw; w0 += 1024)
             glds_x4(a.bitmaps + (size_t)src * bw + w0 + lane * 4, slot_at + (uint32_t)(w0 * 4));
     };
+    const auto load_bounds = [&](uint32_t k0) {
+        for (uint32_t t = tid; t <= UCACHE; t += WT)
+            uptr[t] = k0 + t <= n_users ? (uint32_t)a.ptr[k0 + t] : 0u;
+    };
     for (int f = 0; f <= CDEPTH; ++f)
         fill();
-    for (int u = 0; u < nbuf; ++u)
+    for (uint32_t u = 0; u < WALK_NBUF; ++u)
         load_bitmap(u);
-    int64_t kc0 = 0;
-    for (int t = tid; t <= UCACHE; t += WT)
-        uptr[t] = kc0 + t <= n_users ? a.ptr[kc0 + t] : 0;
+    uint32_t kc0 = 0;
+    load_bounds(0);
     wait_vm_then_barrier<0>();
 
     uint32_t pos = 0, iters = 0;
     int64_t last = -1;
     int par = 0;
     bool failed = false;
-    for (int64_t k = 0; k < n_users && !failed; ++k) {
+    const uint32_t t0 = wave * 256 + lane;
+    for (uint32_t k = 0; k < n_users && !failed; ++k) {
         if (k - kc0 >= UCACHE) { // (ordinary loads: drains the DMA queue; once per 1024 users)
             lds_barrier();
             kc0 = k;
-            for (int t = tid; t <= UCACHE; t += WT)
-                uptr[t] = kc0 + t <= n_users ? a.ptr[kc0 + t] : 0;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            load_bounds(k);
             lds_barrier();
         }
-        const int64_t p0 = uptr[k - kc0], p1 = uptr[k - kc0 + 1];
-        const uint32_t need = (uint32_t)(p1 - p0) * (uint32_t)nr, base = (uint32_t)p0 * (uint32_t)nr;
-        const uint32_t *ubm = bm + (size_t)(k % nbuf) * bw;
+        const uint32_t p0 = uptr[k - kc0], p1 = uptr[k - kc0 + 1];
+        const uint32_t need = (p1 - p0) * (uint32_t)nr, base = p0 * (uint32_t)nr;
+        const uint32_t *ubm = bm + (size_t)(k & 7u) * bw;
         uint32_t done = 0, dmod = 0;
         if (need == 0) // a user without rows makes no trip (no stores to count on): retire everything
             wait_vm_then_barrier<0>();
@@ -662,18 +667,15 @@ template <int NRT> __global__ __launch_bounds__(WT) void neg_walk(NegArgs a)
                 fill();
             // ---- candidates against the user's bitmap; per group: count of the accepted
             int32_t c[4];
-            uint32_t pw[4];
+            uint32_t pw[4], cw[4];
             uint64_t mf[4];
-            const uint32_t t0 = wave * 256 + lane;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 c[j] = cbuf[(pos + t0 + j * 64) & (CRING - 1)];
-            uint32_t cw[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const bool valid = pos + t0 + j * 64 < n_cand;
-                const bool fj = valid && !((ubm[(uint32_t)c[j] >> 5] >> (c[j] & 31)) & 1u);
-                mf[j] = __ballot(fj);
+                const uint32_t word = ubm[(uint32_t)c[j] >> 5];
+                mf[j] = __ballot(pos + t0 + j * 64 < n_cand && !((word >> (c[j] & 31)) & 1u));
                 cw[j] = (uint32_t)__popcll(mf[j]);
                 pw[j] = lanes_below(mf[j]);
             }
@@ -688,34 +690,38 @@ template <int NRT> __global__ __launch_bounds__(WT) void neg_walk(NegArgs a)
             const uint32_t incl = row_scan16(mine);
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 15);
             uint32_t p[4];
+            bool f[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j) {
                 p[j] = (uint32_t)__builtin_amdgcn_readlane((int)(incl - mine), wave * 4 + j) + pw[j];
+                f[j] = (mf[j] >> lane) & 1;
+            }
             const uint32_t rem = need - done; // >= 1
-            // ---- repeats inside a positive's group (sampler.py:24,59,88): the accepted of the tile in rank order, compare with
-            // the earlier members of the group
+            // ---- repeats inside a positive's group (sampler.py:24,59,88): the accepted of the tile in rank order (D, behind the
+            // last nr-1 accepted of the tiles before), every one compared with the earlier members of its group.  No branches:
+            // lanes without an accepted candidate write a spare slot and read slots they do not use.
             uint64_t md[4] = {0, 0, 0, 0};
             if (nr > 1) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if ((mf[j] >> lane) & 1)
-                        D[CARRY + p[j]] = c[j];
+                    D[f[j] ? CARRY + p[j] : d_spare] = c[j];
                 lds_barrier();
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    bool dup = false;
-                    if (((mf[j] >> lane) & 1) && p[j] < rem) {
-                        const int q = NRT == 4 ? (int)((dmod + p[j]) & 3u) : (int)((dmod + p[j]) % (uint32_t)nr);
-                        const int32_t *at = D + CARRY + p[j];
-                        if (NRT == 4) {
-                            const int32_t v1 = at[-1], v2 = at[-2], v3 = at[-3];
-                            dup = (q >= 1 && v1 == c[j]) || (q >= 2 && v2 == c[j]) || (q >= 3 && v3 == c[j]);
-                        } else {
-                            for (int jj = 1; jj <= q; ++jj)
-                                dup |= at[-jj] == c[j];
-                        }
+                    const int32_t *at = D + CARRY + p[j];
+                    uint32_t dup; // integer logic throughout: `&&` would make the reads conditional, i.e. branches
+                    if (NRT == 4) {
+                        const int32_t v1 = at[-1], v2 = at[-2], v3 = at[-3];
+                        const uint32_t q = (dmod + p[j]) & 3u;
+                        dup = ((uint32_t)(q >= 1) & (uint32_t)(v1 == c[j])) | ((uint32_t)(q >= 2) & (uint32_t)(v2 == c[j])) |
+                              ((uint32_t)(q >= 3) & (uint32_t)(v3 == c[j]));
+                    } else {
+                        const uint32_t q = (dmod + p[j]) % (uint32_t)nr;
+                        dup = 0;
+                        for (int jj = 1; jj <= CARRY; ++jj) // uniform trip count; the reads beyond q are not used
+                            dup |= (uint32_t)((uint32_t)jj <= q) & (uint32_t)(at[-jj] == c[j]);
                     }
-                    md[j] = __ballot(dup);
+                    md[j] = __ballot((dup & (uint32_t)f[j] & (uint32_t)(p[j] < rem)) != 0);
                 }
             }
             // this wave's first repeat (thread << 11 | rank) and the thread that holds the user's last slot
@@ -726,7 +732,7 @@ template <int NRT> __global__ __launch_bounds__(WT) void neg_walk(NegArgs a)
                     const int l = __ffsll((unsigned long long)md[j]) - 1;
                     wd = ((uint32_t)(wave * 256 + j * 64 + l) << 11) | (uint32_t)__builtin_amdgcn_readlane((int)p[j], l);
                 }
-                const uint64_t mn = __ballot(((mf[j] >> lane) & 1) && p[j] == rem - 1);
+                const uint64_t mn = __ballot(f[j] && p[j] == rem - 1);
                 if (mn)
                     wn = (uint32_t)(wave * 256 + j * 64 + __ffsll((unsigned long long)mn) - 1);
             }
@@ -750,7 +756,7 @@ template <int NRT> __global__ __launch_bounds__(WT) void neg_walk(NegArgs a)
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) { // exactly four stores per trip (see NOPS): lanes without a negative write the spare slot behind the array
-                const bool ok = ((mf[j] >> lane) & 1) && t0 + j * 64 < cut && p[j] < acc;
+                const bool ok = f[j] && t0 + j * 64 < cut && p[j] < acc;
                 a.neg[ok ? base + done + p[j] : a.neg_spare] = c[j];
             }
             if (nr > 1 && done + acc < need) { // the group in progress may reach back into this tile: keep its last nr-1 accepted
@@ -768,7 +774,7 @@ template <int NRT> __global__ __launch_bounds__(WT) void neg_walk(NegArgs a)
             par ^= 1;
             ++iters;
         }
-        load_bitmap(k + nbuf); // user k is done: its ring slot takes the user nbuf ahead
+        load_bitmap(k + WALK_NBUF); // user k is done: its ring slot takes the user nbuf ahead
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // no LDS-DMA may be in flight when the workgroup ends
     if (tid == 0) {
@@ -779,6 +785,335 @@ template <int NRT> __global__ __launch_bounds__(WT) void neg_walk(NegArgs a)
         a.st->raw_next1 = last >= 0 ? (int64_t)a.cand_raw[last] + 1 : a.raw_begin;
         if (failed)
             a.st->status = DS_OUT_OF_CANDIDATES;
+    }
+}
+
+// ---- phase 1b, the PARALLEL form: every user on its own workgroup, the chain reduced to table look-ups ----------------------------
+// The walk above is a chain of ~8 000 dependent tiles on one CU (13 ms at ml-1m shape) because user k+1's first candidate is
+// wherever user k's last slot was filled.  But where that is can be predicted: user k takes need_k / (1 - p_k) candidates on
+// average (p_k = share of the catalogue it has seen) with a known variance, so its start lies within a few hundred candidates
+// of a position known in advance (plan: lo_k, W_k = twice six standard deviations + 64).  So:
+//   neg_tab    (one workgroup per user, all at once) tests the user's bitmap against every candidate it could possibly meet,
+//              and writes, for EVERY start s in the window, where the user would end: T_k[s - lo_k] = E_k(s).  Without repeats
+//              that is a rank look-up (the (rank(s) + need)-th accepted candidate); repeats inside a positive's group are found
+//              as `events` -- two equal accepted candidates at most nr + 1 ranks apart, a property of the candidates alone --
+//              and whether an event is a repeat for a given start (both in one group of nr) is decided per start.
+//   neg_compose  one thread per (segment of 64 users, start in the segment's first window): 64 look-ups -> F_g
+//   neg_chain_starts  one wave: ~100 look-ups through F give every segment's true start, then one thread per segment replays its
+//              users' tables: start[k] for every user.  Nothing here is approximate: a look-up outside a window, a table entry
+//              whose range was too short, or a knot of repeats the event logic does not cover is REPORTED (DS_NEED_WALK) and the
+//              sample is redone by the walk.
+//   neg_emit   (one workgroup per user) the user's negatives from its true start.
+constexpr uint32_t T_INVALID = 0xffffffffu;
+constexpr int TAB_EV = 1024;    // events per user beyond which the sample goes to the walk (tiny catalogues)
+constexpr int TAB_SK = 256;     // repeats per user, likewise
+constexpr int TAB_SEG = 64;     // users per segment
+constexpr int TAB_NR_MAX = 33;
+
+struct TabArgs {
+    const int32_t *cand;
+    const uint32_t *bitmaps;
+    int bw, nr;
+    uint32_t n_users;
+    const uint32_t *lo, *W, *len, *toff, *need, *base; // the plan, per user
+    uint32_t *T;
+    uint32_t *start; // [n_users + 1]
+    DsStatus *st;
+    uint32_t rcap, wcap;
+    int32_t *neg;
+    const uint32_t *cand_raw;
+    int64_t raw_begin;
+};
+
+__device__ __forceinline__ uint32_t wave_scan64(uint32_t v, int lane) // inclusive prefix sum over the wave
+{
+    v = row_scan16(v);
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 15), r1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 31),
+                   r2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 47);
+    const int row = lane >> 4;
+    return v + (row >= 1 ? r0 : 0u) + (row >= 2 ? r1 : 0u) + (row >= 3 ? r2 : 0u);
+}
+
+// exclusive prefix of v over the 256 threads and the total; ws: LDS [8], two alternating halves
+__device__ __forceinline__ uint32_t block_scan256(uint32_t v, uint32_t *ws, int lane, int wave, uint32_t &total)
+{
+    const uint32_t incl = wave_scan64(v, lane);
+    if (lane == 63)
+        ws[wave] = incl;
+    __syncthreads();
+    const uint32_t w0 = ws[0], w1 = ws[1], w2 = ws[2], w3 = ws[3];
+    total = w0 + w1 + w2 + w3;
+    return incl - v + (wave >= 1 ? w0 : 0u) + (wave >= 2 ? w1 : 0u) + (wave >= 3 ? w2 : 0u);
+}
+
+// the accepted candidates of cand[c0 .. c0 + L) for the user whose bitmap is ubm (LDS): apos[r] = offset of the r-th one
+// (r < rcap), rkw[t] = accepted before offset t (t < Wn).  Returns their number.  256 threads.
+__device__ uint32_t build_accepted(const int32_t *__restrict__ cand, uint32_t c0, uint32_t L, const uint32_t *ubm, uint32_t *apos, uint32_t rcap,
+                                   uint32_t *rkw, uint32_t Wn, uint32_t *ws)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t cum = 0;
+    int par = 0;
+    for (uint32_t ch = 0; ch < L; ch += 1024, par ^= 4) {
+        uint32_t f[4], sum = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t t = ch + tid * 4 + j;
+            const int32_t c = t < L ? cand[c0 + t] : 0;
+            f[j] = t < L && !((ubm[(uint32_t)c >> 5] >> (c & 31)) & 1u);
+            sum += f[j];
+        }
+        uint32_t total;
+        uint32_t rb = cum + block_scan256(sum, ws + par, lane, wave, total);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t t = ch + tid * 4 + j;
+            if (t < Wn)
+                rkw[t] = rb;
+            if (f[j] && rb < rcap)
+                apos[rb] = t;
+            rb += f[j];
+        }
+        cum += total;
+    }
+    __syncthreads();
+    return cum;
+}
+
+// events: pairs of equal accepted candidates at most D ranks apart, as (r << 8 | d) in rank order (r the later one, d the distance).
+// vbuf: LDS [256 + 64]; ctl: LDS [2].  Returns the number of events (capped at TAB_EV + 1).
+__device__ uint32_t build_events(const int32_t *__restrict__ cand, uint32_t c0, const uint32_t *apos, uint32_t R, uint32_t D, int32_t *vbuf,
+                                 uint32_t *ev, uint32_t *ws, uint32_t *ctl)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t nev = 0;
+    if (tid == 0)
+        ctl[0] = 0;
+    __syncthreads();
+    for (uint32_t rc = 0; rc < R; rc += 256) {
+        const uint32_t r = rc + tid;
+        vbuf[64 + tid] = r < R ? cand[c0 + apos[r]] : -1;
+        if (tid < 64)
+            vbuf[tid] = rc + tid >= 64 ? cand[c0 + apos[rc + tid - 64]] : -2;
+        __syncthreads();
+        uint32_t cnt = 0;
+        const int32_t mine = vbuf[64 + tid];
+        if (r < R)
+            for (uint32_t d = 1; d <= D; ++d)
+                cnt += r >= d && vbuf[64 + tid - d] == mine;
+        if (cnt)
+            ctl[0] = 1; // benign race: every writer writes 1
+        __syncthreads();
+        if (ctl[0]) { // rare: some candidate of this stretch equals an earlier one close by
+            uint32_t total;
+            uint32_t at = nev + block_scan256(cnt, ws, lane, wave, total);
+            if (r < R)
+                for (uint32_t d = 1; d <= D; ++d)
+                    if (r >= d && vbuf[64 + tid - d] == mine) {
+                        if (at < TAB_EV)
+                            ev[at] = (r << 8) | d;
+                        ++at;
+                    }
+            nev += total;
+            __syncthreads();
+            if (tid == 0)
+                ctl[0] = 0;
+        }
+        __syncthreads();
+        if (nev > TAB_EV)
+            return TAB_EV + 1;
+    }
+    return nev;
+}
+
+// How many of the events are repeats when the user starts at accepted rank rs: walks the events in rank order with the number
+// of repeats so far and the three latest repeated ranks.  An event (rp, r) is a repeat iff rp belongs to this start (rp >= rs),
+// is itself no repeat, and lies in r's group: fewer taken candidates between them than the group holds before r.  Exact while
+// at most two repeats fall inside any stretch of D ranks; anything denser is flagged (cplx) and handled by the walk.
+// rec (LDS, may be null): the repeated ranks, written by lanes with `rec_writer`.
+__device__ __forceinline__ uint32_t eval_skips(const uint32_t *ev, uint32_t nev, uint32_t rs, uint32_t need, uint32_t nr, uint32_t D, bool &cplx,
+                                               uint32_t *rec, bool rec_writer)
+{
+    uint32_t skips = 0;
+    int32_t sk1 = -1, sk2 = -1, sk3 = -1;
+    for (uint32_t e = 0; e < nev; ++e) {
+        const uint32_t r = ev[e] >> 8, d = ev[e] & 255u, rp = r - d;
+        if (rp >= rs && r <= rs + need - 1 + skips && (int32_t)r != sk1) {
+            if (sk3 >= 0 && sk3 >= (int32_t)r - (int32_t)D)
+                cplx = true; // three repeats this close: more could hide outside what is tracked
+            const uint32_t between = (r - rp - 1) - (uint32_t)(sk1 > (int32_t)rp) - (uint32_t)(sk2 > (int32_t)rp);
+            const bool rp_repeat = sk1 == (int32_t)rp || sk2 == (int32_t)rp;
+            const uint32_t q = ((r - rs) - skips) % nr;
+            if (!rp_repeat && between < q) {
+                sk3 = sk2, sk2 = sk1, sk1 = (int32_t)r;
+                if (rec && rec_writer && skips < TAB_SK)
+                    rec[skips] = r;
+                ++skips;
+                if (sk3 >= 0 && sk3 + (int32_t)(D + nr) >= sk1)
+                    cplx = true;
+            }
+        }
+    }
+    return skips;
+}
+
+// LDS of neg_tab / neg_emit: [bitmap row bw][apos rcap][rkw wcap][vbuf 320][ev TAB_EV][rec TAB_SK][ws 8][ctl 4]
+__global__ __launch_bounds__(256) void neg_tab(TabArgs a)
+{
+    extern __shared__ uint32_t lds[];
+    uint32_t *ubm = lds, *apos = ubm + a.bw, *rkw = apos + a.rcap;
+    int32_t *vbuf = (int32_t *)(rkw + a.wcap);
+    uint32_t *ev = (uint32_t *)(vbuf + 320), *ws = ev + TAB_EV + TAB_SK, *ctl = ws + 8;
+    const int tid = threadIdx.x;
+    const uint32_t k = blockIdx.x, lo = a.lo[k], W = a.W[k], need = a.need[k];
+    uint32_t *T = a.T + a.toff[k];
+    const uint32_t n_cand = (uint32_t)a.st->n_cand;
+    if (need == 0) { // no rows: the next user starts where this one would
+        for (uint32_t i = tid; i < W; i += 256)
+            T[i] = lo + i;
+        return;
+    }
+    if (lo >= n_cand) {
+        for (uint32_t i = tid; i < W; i += 256)
+            T[i] = T_INVALID;
+        return;
+    }
+    const uint32_t L = min(a.len[k], n_cand - lo);
+    for (int w = tid; w < a.bw; w += 256)
+        ubm[w] = a.bitmaps[(size_t)k * a.bw + w];
+    __syncthreads();
+    const uint32_t R = min(build_accepted(a.cand, lo, L, ubm, apos, a.rcap, rkw, min(W, L), ws), a.rcap);
+    const uint32_t D = (uint32_t)a.nr + 1;
+    const uint32_t nev = a.nr > 1 ? build_events(a.cand, lo, apos, R, D, vbuf, ev, ws, ctl) : 0u;
+    if (nev > TAB_EV) {
+        if (tid == 0)
+            a.st->status = DS_NEED_WALK, a.st->why = 1, a.st->why_at = (int32_t)k;
+        return;
+    }
+    __syncthreads();
+    bool cplx = false;
+    for (uint32_t i = tid; i < W; i += 256) {
+        uint32_t E = T_INVALID;
+        if (i < L) {
+            const uint32_t rs = rkw[i];
+            const uint32_t tr = rs + need - 1 + (nev ? eval_skips(ev, nev, rs, need, (uint32_t)a.nr, D, cplx, nullptr, false) : 0u);
+            if (tr < R)
+                E = lo + apos[tr] + 1;
+        }
+        T[i] = E;
+    }
+    if (cplx)
+        a.st->status = DS_NEED_WALK, a.st->why = 2, a.st->why_at = (int32_t)k;
+}
+
+// F[foff[g] + i] = where segment g ends when its first user starts at lo[first] + i
+__global__ __launch_bounds__(256) void neg_compose(TabArgs a, const uint32_t *__restrict__ foff, uint32_t *__restrict__ F)
+{
+    const uint32_t g = blockIdx.x, u0 = g * TAB_SEG, u1 = min(u0 + TAB_SEG, a.n_users);
+    const uint32_t i = blockIdx.y * 256 + threadIdx.x;
+    if (i >= a.W[u0])
+        return;
+    uint32_t x = a.lo[u0] + i;
+    for (uint32_t u = u0; u < u1; ++u) {
+        const uint32_t idx = x - a.lo[u];
+        if (idx >= a.W[u]) { // (also x < lo[u]: the difference wraps)
+            x = T_INVALID;
+            break;
+        }
+        x = a.T[a.toff[u] + idx];
+        if (x == T_INVALID)
+            break;
+    }
+    F[foff[g] + i] = x;
+}
+
+// one wave: the segments' true starts through F (lane 0), then every user's through T (a lane per segment)
+constexpr uint32_t TAB_MAXSEG = 8192;
+__global__ __launch_bounds__(64) void neg_chain_starts(TabArgs a, const uint32_t *__restrict__ foff, const uint32_t *__restrict__ F, uint32_t n_seg)
+{
+    __shared__ uint32_t seg_start[TAB_MAXSEG];
+    const int lane = threadIdx.x;
+    if (a.st->status != DS_OK)
+        return;
+    bool bad = false;
+    if (lane == 0) {
+        uint32_t x = 0;
+        for (uint32_t g = 0; g < n_seg; ++g) {
+            seg_start[g] = x;
+            const uint32_t idx = x - a.lo[g * TAB_SEG];
+            if (idx >= a.W[g * TAB_SEG]) {
+                bad = true;
+                a.st->why = 3, a.st->why_at = (int32_t)g;
+                break;
+            }
+            x = F[foff[g] + idx];
+            if (x == T_INVALID) {
+                bad = true;
+                a.st->why = 4, a.st->why_at = (int32_t)g;
+                break;
+            }
+        }
+        if (!bad) {
+            a.start[a.n_users] = x;
+            a.st->cand_used = x;
+            a.st->raw_next1 = x > 0 ? (int64_t)a.cand_raw[x - 1] + 1 : a.raw_begin;
+        }
+    }
+    if (__any(bad)) {
+        if (lane == 0)
+            a.st->status = DS_NEED_WALK;
+        return;
+    }
+    __syncthreads();
+    for (uint32_t g = lane; g < n_seg; g += 64) {
+        uint32_t x = seg_start[g];
+        const uint32_t u1 = min((g + 1) * TAB_SEG, a.n_users);
+        for (uint32_t u = g * TAB_SEG; u < u1; ++u) {
+            a.start[u] = x;
+            x = a.T[a.toff[u] + (x - a.lo[u])]; // inside the window and valid: F said so
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void neg_emit(TabArgs a)
+{
+    extern __shared__ uint32_t lds[];
+    uint32_t *ubm = lds, *apos = ubm + a.bw, *rkw = apos + a.rcap;
+    int32_t *vbuf = (int32_t *)(rkw + a.wcap);
+    uint32_t *ev = (uint32_t *)(vbuf + 320), *rec = ev + TAB_EV, *ws = rec + TAB_SK, *ctl = ws + 8;
+    const int tid = threadIdx.x;
+    if (a.st->status != DS_OK)
+        return;
+    const uint32_t k = blockIdx.x, need = a.need[k], base = a.base[k];
+    if (need == 0)
+        return;
+    const uint32_t s0 = a.start[k], L = a.start[k + 1] - s0;
+    for (int w = tid; w < a.bw; w += 256)
+        ubm[w] = a.bitmaps[(size_t)k * a.bw + w];
+    __syncthreads();
+    const uint32_t R = build_accepted(a.cand, s0, L, ubm, apos, a.rcap, rkw, 0, ws);
+    const uint32_t D = (uint32_t)a.nr + 1;
+    const uint32_t nev = a.nr > 1 && R <= a.rcap ? build_events(a.cand, s0, apos, R, D, vbuf, ev, ws, ctl) : 0u;
+    bool cplx = R > a.rcap || nev > TAB_EV;
+    uint32_t skips = 0;
+    if (!cplx && nev)
+        skips = eval_skips(ev, nev, 0u, need, (uint32_t)a.nr, D, cplx, rec, tid == 0);
+    // the table said this user ends exactly here: its last candidate is its last slot
+    if (cplx || skips > TAB_SK || R != need + skips || apos[R - 1] != L - 1) {
+        if (tid == 0)
+            a.st->status = DS_NEED_WALK, a.st->why = 5, a.st->why_at = (int32_t)k;
+        return;
+    }
+    __syncthreads();
+    for (uint32_t r = tid; r < R; r += 256) {
+        uint32_t before = 0;
+        bool rep = false;
+        for (uint32_t q = 0; q < skips; ++q) {
+            before += rec[q] < r;
+            rep |= rec[q] == r;
+        }
+        if (!rep)
+            a.neg[base + r - before] = a.cand[s0 + apos[r]];
     }
 }
 
@@ -1029,6 +1364,15 @@ struct crec_dsampler {
     hipStream_t stream = nullptr;
     double growth = 1.0;
     int64_t n = 0, raw_next1_in = 0;
+    // the parallel form of the negatives phase: per-user degrees (host), the plan for one neg_ratio, its tables
+    std::vector<int32_t> deg, uniq;
+    int plan_nr = -1;      // the neg_ratio the plan below was made for (-1: none)
+    bool plan_ok = false;  // the plan fits the kernels' limits
+    bool force_walk = false;
+    int64_t walk_fallbacks = 0;
+    int32_t last_why = 0, last_why_at = 0;
+    uint32_t plan_rcap = 0, plan_wcap = 0, plan_nseg = 0, plan_wfirst_max = 0;
+    crec_devbuf p_lo, p_W, p_len, p_toff, p_need, p_base, p_foff, tabT, tabF, p_start;
 };
 
 namespace {
@@ -1063,7 +1407,8 @@ double expected_shuffle_words(int64_t n)
 int free_bufs(crec_dsampler *s)
 {
     crec_devbuf *bufs[] = {&s->ptr, &s->items, &s->edge_user, &s->bitmaps, &s->polys, &s->x, &s->base, &s->next_key, &s->cand, &s->cand_raw,
-                           &s->counts, &s->neg, &s->tgt, &s->key, &s->val, &s->skey, &s->sval, &s->head, &s->nxt, &s->sort_tmp, &s->status};
+                           &s->counts, &s->neg, &s->tgt, &s->key, &s->val, &s->skey, &s->sval, &s->head, &s->nxt, &s->sort_tmp, &s->status,
+                           &s->p_lo, &s->p_W, &s->p_len, &s->p_toff, &s->p_need, &s->p_base, &s->p_foff, &s->tabT, &s->tabF, &s->p_start};
     for (crec_devbuf *b : bufs)
         if (b->ptr) {
             (void)hipFree(b->ptr);
@@ -1075,6 +1420,78 @@ int free_bufs(crec_dsampler *s)
     if (s->done)
         (void)hipEventDestroy(s->done);
     return 0;
+}
+
+// The plan of the parallel negatives phase for one neg_ratio: where every user's start is expected (mean and variance of the
+// candidates the users before it take: need / (1 - p) and need p / (1 - p)^2 for a user that has seen the share p of the
+// catalogue, plus the rare repeats), the window of starts its table covers (+- six standard deviations + 64) and how far its
+// tested range reaches.  Host arithmetic in double, uploaded once per (sampler, neg_ratio).
+int make_plan(crec_ctx *ctx, crec_dsampler *s, int nr, hipStream_t st)
+{
+    if (s->plan_nr == nr)
+        return CREC_OK;
+    s->plan_nr = nr;
+    s->plan_ok = false;
+    const int64_t U = s->n_users;
+    if (nr < 1 || nr > TAB_NR_MAX || s->bw > WALK_BW_MAX || U < 1 || U > (int64_t)TAB_MAXSEG * TAB_SEG)
+        return CREC_OK;
+    std::vector<uint32_t> lo, W, len, toff, need, base, foff;
+    try {
+        lo.resize(U), W.resize(U), len.resize(U), toff.resize(U), need.resize(U), base.resize(U);
+        foff.resize(crec_ceil_div(U, TAB_SEG));
+    } catch (...) {
+        return crec_fail(ctx, CREC_ENOMEM, "host allocation failed");
+    }
+    const double I = (double)s->item_nums;
+    double S = 0, V = 0;
+    uint64_t tsum = 0, fsum = 0, pos_base = 0;
+    uint32_t rcap = 0, wcap = 0, wfirst = 0;
+    for (int64_t k = 0; k < U; ++k) {
+        const double nd = (double)s->deg[k] * nr, unseen = I - (double)s->uniq[k], p = (double)s->uniq[k] / I;
+        const double mu = nd / (1.0 - p) * (1.0 + 0.5 * (nr - 1) / unseen), var = nd * p / ((1.0 - p) * (1.0 - p)) + nd * 0.5 * (nr - 1) / unseen;
+        const double m = 6.0 * std::sqrt(V) + 64.0;
+        const double a = std::floor(S - m), b = std::ceil(S + m);
+        const double l = a < 0 ? 0 : a;
+        const double span = b - l + 1.0 + std::ceil(mu + 6.0 * std::sqrt(var) + 64.0);
+        if (b + span > 4.0e9)
+            return CREC_OK; // beyond 32-bit positions: the walk
+        lo[k] = (uint32_t)l, W[k] = (uint32_t)(b - l + 1.0), len[k] = (uint32_t)span;
+        need[k] = (uint32_t)(s->deg[k] * (int64_t)nr), base[k] = (uint32_t)pos_base;
+        pos_base += need[k];
+        toff[k] = (uint32_t)tsum;
+        tsum += W[k];
+        if (k % TAB_SEG == 0) {
+            foff[k / TAB_SEG] = (uint32_t)fsum;
+            fsum += W[k];
+            wfirst = W[k] > wfirst ? W[k] : wfirst;
+        }
+        rcap = len[k] > rcap ? len[k] : rcap;
+        wcap = W[k] > wcap ? W[k] : wcap;
+        S += mu, V += var;
+    }
+    const size_t lds = ((size_t)s->bw + rcap + wcap + 320 + TAB_EV + TAB_SK + 8 + 4) * 4;
+    if (tsum >= ((uint64_t)1 << 31) || lds > 150 * 1024)
+        return CREC_OK;
+    const auto up = [&](crec_devbuf *b, const std::vector<uint32_t> &v) {
+        if (int rc = crec_reserve(ctx, b, v.size() * 4 + 4))
+            return rc;
+        CREC_HIP(ctx, hipMemcpyAsync(b->ptr, v.data(), v.size() * 4, hipMemcpyHostToDevice, st));
+        return (int)CREC_OK;
+    };
+    for (auto pr : {std::make_pair(&s->p_lo, &lo), std::make_pair(&s->p_W, &W), std::make_pair(&s->p_len, &len), std::make_pair(&s->p_toff, &toff),
+                    std::make_pair(&s->p_need, &need), std::make_pair(&s->p_base, &base), std::make_pair(&s->p_foff, &foff)})
+        if (int rc = up(pr.first, *pr.second))
+            return rc;
+    if (int rc = crec_reserve(ctx, &s->tabT, (size_t)tsum * 4 + 4))
+        return rc;
+    if (int rc = crec_reserve(ctx, &s->tabF, (size_t)fsum * 4 + 4))
+        return rc;
+    if (int rc = crec_reserve(ctx, &s->p_start, (size_t)(U + 1) * 4))
+        return rc;
+    CREC_HIP(ctx, hipStreamSynchronize(st)); // the vectors go away
+    s->plan_rcap = rcap, s->plan_wcap = wcap, s->plan_nseg = (uint32_t)foff.size(), s->plan_wfirst_max = wfirst;
+    s->plan_ok = true;
+    return CREC_OK;
 }
 
 // everything of one sample, enqueued on s->stream
@@ -1148,9 +1565,26 @@ int enqueue(crec_ctx *ctx, crec_dsampler *s)
         NegArgs na{(const int32_t *)s->cand.ptr, (const uint32_t *)s->cand_raw.ptr, (const int64_t *)s->ptr.ptr, s->n_users,
                    (const uint32_t *)s->bitmaps.ptr, s->bw, s->nbuf, nr, (int32_t *)s->neg.ptr, dst, r0, 0u, (uint32_t)n_neg};
         na.cand_cap = (uint32_t)(s->cand.bytes / 4) & ~3u;
-        if (nr <= WALK_NR_MAX && s->bw <= WALK_BW_MAX && !ctx->knob_dsampler_general) {
+        if (int rc = make_plan(ctx, s, nr, st))
+            return rc;
+        if (s->plan_ok && !s->force_walk && ctx->knob_dsampler_general == 0) {
+            // the parallel form: tables of every user over its window of possible starts, then look-ups
+            TabArgs ta{(const int32_t *)s->cand.ptr, (const uint32_t *)s->bitmaps.ptr, s->bw, nr, (uint32_t)s->n_users,
+                       (const uint32_t *)s->p_lo.ptr, (const uint32_t *)s->p_W.ptr, (const uint32_t *)s->p_len.ptr, (const uint32_t *)s->p_toff.ptr,
+                       (const uint32_t *)s->p_need.ptr, (const uint32_t *)s->p_base.ptr, (uint32_t *)s->tabT.ptr, (uint32_t *)s->p_start.ptr, dst,
+                       s->plan_rcap, s->plan_wcap, (int32_t *)s->neg.ptr, (const uint32_t *)s->cand_raw.ptr, r0};
+            const size_t lds = ((size_t)s->bw + s->plan_rcap + s->plan_wcap + 320 + TAB_EV + TAB_SK + 8 + 4) * 4;
+            CREC_HIP(ctx, hipFuncSetAttribute((const void *)neg_tab, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            CREC_HIP(ctx, hipFuncSetAttribute((const void *)neg_emit, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(neg_tab, dim3((unsigned)s->n_users), dim3(256), lds, st, ta);
+            hipLaunchKernelGGL(neg_compose, dim3(s->plan_nseg, (unsigned)crec_ceil_div(s->plan_wfirst_max, 256)), dim3(256), 0, st, ta,
+                               (const uint32_t *)s->p_foff.ptr, (uint32_t *)s->tabF.ptr);
+            hipLaunchKernelGGL(neg_chain_starts, dim3(1), dim3(64), 0, st, ta, (const uint32_t *)s->p_foff.ptr, (const uint32_t *)s->tabF.ptr, s->plan_nseg);
+            hipLaunchKernelGGL(neg_emit, dim3((unsigned)s->n_users), dim3(256), lds, st, ta);
+        } else
+        if (nr <= WALK_NR_MAX && s->bw <= WALK_BW_MAX && ctx->knob_dsampler_general != 1) {
             na.nbuf = WALK_NBUF;
-            const size_t lds = ((size_t)WALK_NBUF * s->bw + CRING + (size_t)((nr - 1 + TILE + 3) & ~3) + 32 + 16) * 4 + (size_t)(UCACHE + 1) * 8;
+            const size_t lds = ((size_t)WALK_NBUF * s->bw + CRING + (size_t)((nr - 1 + TILE + 1 + 3) & ~3) + 32 + 16 + UCACHE + 1) * 4;
             if (nr == 4) {
                 CREC_HIP(ctx, hipFuncSetAttribute((const void *)neg_walk<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 hipLaunchKernelGGL(neg_walk<4>, dim3(1), dim3(WT), lds, st, na);
@@ -1229,6 +1663,12 @@ int crec_dsampler_create(crec_ctx *ctx, const int64_t *ptr, const int32_t *items
     }
     double s1 = 0;
     int64_t max_uniq = 0;
+    std::vector<int32_t> degs, uniqs;
+    try {
+        degs.resize((size_t)n_users), uniqs.resize((size_t)n_users);
+    } catch (...) {
+        return crec_fail(ctx, CREC_ENOMEM, "host allocation failed");
+    }
     for (int64_t k = 0; k < n_users; ++k) {
         int64_t uniq = 0;
         for (int64_t e = ptr[k]; e < ptr[k + 1]; ++e) {
@@ -1238,6 +1678,7 @@ int crec_dsampler_create(crec_ctx *ctx, const int64_t *ptr, const int32_t *items
             eu[(size_t)e] = user_ids[k];
         }
         max_uniq = uniq > max_uniq ? uniq : max_uniq;
+        degs[(size_t)k] = (int32_t)(ptr[k + 1] - ptr[k]), uniqs[(size_t)k] = (int32_t)uniq;
         if (uniq < item_nums)
             s1 += (double)(ptr[k + 1] - ptr[k]) / (double)(item_nums - uniq);
     }
@@ -1251,6 +1692,7 @@ int crec_dsampler_create(crec_ctx *ctx, const int64_t *ptr, const int32_t *items
     s->device = ctx->device;
     s->n_users = n_users, s->n_pos = n_pos, s->item_nums = item_nums, s->bw = bw, s->max_uniq = max_uniq, s->s1 = s1;
     s->pwords = bw <= TILE ? 1 : 8;
+    s->deg.swap(degs), s->uniq.swap(uniqs);
     {
         const int fit = (int)((96 * 1024) / ((size_t)bw * 4)); // ring of bitmaps: as many users ahead as 96 KB hold, 3 .. 6
         s->nbuf = fit < 3 ? 3 : (fit > 6 ? 6 : fit);
@@ -1330,6 +1772,7 @@ int crec_dsampler_sample(crec_ctx *ctx, crec_dsampler *s, int kind, int neg_rati
     CREC_HIP(ctx, hipSetDevice(s->device));
     s->kind = kind, s->nr = neg_ratio, s->pos_in = pos, s->u = u, s->i = i, s->third = third, s->stream = (hipStream_t)stream;
     s->n = n;
+    s->force_walk = false;
     s->growth = ctx->knob_dsampler_budget > 0 ? ctx->knob_dsampler_budget / 100.0 : 1.0;
     std::memcpy(s->key_in, key, sizeof(s->key_in));
     return enqueue(ctx, s);
@@ -1349,6 +1792,14 @@ int crec_dsampler_finish(crec_ctx *ctx, crec_dsampler *s, int64_t *n_out, uint32
             break;
         // the stream budget (sized from the expected rejection counts) did not last: again with twice the words
         CREC_REQUIRE(ctx, s->status_host->status != DS_INTERNAL, "device sampler: internal error (undecided words left in a shuffle tile)");
+        if (s->status_host->status == DS_NEED_WALK && !s->force_walk) { // the parallel negatives phase met something it reports instead of handling
+            s->force_walk = true;
+            ++s->walk_fallbacks;
+            s->last_why = s->status_host->why, s->last_why_at = s->status_host->why_at;
+            if (int rc = enqueue(ctx, s))
+                return rc;
+            continue;
+        }
         CREC_REQUIRE(ctx, attempt < 6, "device sampler: stream budget exhausted after %d retries (status %d)", attempt, s->status_host->status);
         s->growth *= 2.0;
         if (int rc = enqueue(ctx, s))
@@ -1361,7 +1812,7 @@ int crec_dsampler_finish(crec_ctx *ctx, crec_dsampler *s, int64_t *n_out, uint32
 }
 
 // what the last finished sample consumed: stream words of the negatives phase, of the shuffle, candidates produced / used
-int crec_dsampler_stats(const crec_dsampler *s, int64_t out[10])
+int crec_dsampler_stats(const crec_dsampler *s, int64_t out[13])
 {
     if (!s || !out || !s->status_host)
         return CREC_EINVAL;
@@ -1371,6 +1822,8 @@ int crec_dsampler_stats(const crec_dsampler *s, int64_t out[10])
     out[3] = s->status_host->cand_used;
     for (int k = 0; k < 6; ++k)
         out[4 + k] = s->status_host->dbg[k];
+    out[10] = s->walk_fallbacks;
+    out[11] = s->last_why, out[12] = s->last_why_at;
     return CREC_OK;
 }
 

@@ -553,10 +553,10 @@ class MtSampler:
         return (u[:n], i[:n], third), (key, pos.value)
 
     def stats(self):
-        out = (C.c_int64 * 10)()
+        out = (C.c_int64 * 13)()
         self.sess.ctx.check(self.sess.lib.crec_dsampler_stats(self.h, out))
         return dict(words_negatives=out[0], words_shuffle=out[1], candidates=out[2], candidates_used=out[3],
-                    neg_tiles=out[4], neg_clocks=out[5], neg_us=out[6] / 100.0, perm_tiles=out[7], perm_clocks=out[8], perm_us=out[9] / 100.0)
+                    neg_tiles=out[4], neg_clocks=out[5], neg_us=out[6] / 100.0, perm_tiles=out[7], perm_clocks=out[8], perm_us=out[9] / 100.0, walk_fallbacks=out[10], last_fallback=(out[11], out[12]))
 
     def sample(self, kind, neg_ratio, key, pos):
         """one sample from an explicit generator state, synchronously"""

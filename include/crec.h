@@ -140,7 +140,8 @@ int crec_sample_sbpr(crec_ctx *ctx, const int64_t *ptr, const int32_t *items, in
  *       be put back with np.random.set_state.  (If the epoch rejected more draws than the stream budget sized from
  *       the expected rejection rate allowed, the sample is redone with twice the budget -- same result.)
  *   crec_dsampler_stats: stream words used by the negatives / by the shuffle, candidates produced / used, then tile
- *       iterations, shader clocks and 100 MHz ticks of the negatives walk and of the shuffle-target walk. */
+ *       iterations, shader clocks and 100 MHz ticks of the negatives walk and of the shuffle-target walk, then how often the
+ *       parallel negatives phase handed a sample to the walk, and why / where the last time. */
 typedef struct crec_dsampler crec_dsampler;
 int crec_dsampler_create(crec_ctx *ctx, const int64_t *ptr, const int32_t *items, int64_t n_users, const int32_t *user_ids,
                          int32_t item_nums, crec_dsampler **out, void *stream);
@@ -148,7 +149,7 @@ void crec_dsampler_destroy(crec_dsampler *s);
 int crec_dsampler_sample(crec_ctx *ctx, crec_dsampler *s, int kind, int neg_ratio, const uint32_t key[624], int32_t pos,
                          int32_t *u, int32_t *i, void *third, void *stream);
 int crec_dsampler_finish(crec_ctx *ctx, crec_dsampler *s, int64_t *n_out, uint32_t key_out[624], int32_t *pos_out);
-int crec_dsampler_stats(const crec_dsampler *s, int64_t out[10]);
+int crec_dsampler_stats(const crec_dsampler *s, int64_t out[13]);
 /* test hook [host]: the block of 624 raw MT19937 words that lies c*128 refills behind `key` (1 <= c <= 128), by the
  * jump polynomial the device chains use (csrc/mt_jump.cpp) */
 int crec_debug_mt_jump(const uint32_t key[624], int c, uint32_t out_block[624]);

@@ -42,9 +42,10 @@ def _np(cols):
     return [c.cpu().numpy() for c in cols]
 
 
-@pytest.fixture(params=[0, 1], ids=["four-wave-walk", "general-walk"])
+@pytest.fixture(params=[0, 2, 1], ids=["tables", "four-wave-walk", "general-walk"])
 def walk(sess, request):
-    """both forms of the negatives walk (csrc/mt_sampler.hip: neg_walk where its limits allow, neg_chain_general)"""
+    """the three forms of the negatives phase (csrc/mt_sampler.hip): per-user tables + look-ups (with the walk behind it for what
+    it reports instead of handling), the four-wave walk, the general walk"""
     sess.ctx.set_option("dsampler_general", request.param)
     yield request.param
     sess.ctx.set_option("dsampler_general", 0)
@@ -171,6 +172,7 @@ def test_ml1m_shape_epoch_and_stream_accounting(sess):
     assert end[1] == hpos and np.array_equal(end[0], hkey)
     s = ms.stats()
     assert s["candidates_used"] <= s["candidates"] and s["words_negatives"] >= s["candidates_used"] and s["words_shuffle"] >= len(hu) - 1
+    assert s["walk_fallbacks"] == 0  # at this shape the parallel negatives phase handles the whole epoch itself
     # the three kinds from one state, then again: deterministic
     a = _np(ms.sample("pointwise", 4, key, pos)[0])
     b = _np(ms.sample("pointwise", 4, key, pos)[0])

@@ -15,7 +15,7 @@ print("rocprofv3 --kernel-trace --stats -- python3 tools/prof_dsampler.py (S-ml1
 print("%-44s %8s %14s %12s %8s" % ("kernel", "calls", "total_ns", "avg_ns", "pct"))
 for r in rows[:24]:
     n = r["Name"]
-    m = re.search(r"(neg_chain\w*(<\d+>)?|perm_\w+|mt_\w+|cand_\w+|build_bitmaps|radix_sort_onesweep_\w+|__amd_rocclr_\w+)", n)
+    m = re.search(r"(neg_\w+(<\d+>)?|perm_\w+|mt_\w+|cand_\w+|build_bitmaps|radix_sort_onesweep_\w+|__amd_rocclr_\w+)", n)
     name = (m.group(0) if m else n.split("(")[0])[:44]
     print("%-44s %8s %14s %12.1f %8s" % (name, r["Calls"], r["TotalDurationNs"], float(r["AverageNs"]), r["Percentage"]))
 PY
