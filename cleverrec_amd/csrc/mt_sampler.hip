@@ -48,7 +48,7 @@ constexpr int UCACHE = 1024;     // users whose CSR bounds sit in LDS at a time
 constexpr int CAND_BLK = 2048;   // raw words per workgroup of the compaction kernels (256 threads x 8)
 constexpr int32_t NONE = -1;
 
-enum { DS_OK = 0, DS_OUT_OF_CANDIDATES = 1, DS_OUT_OF_WORDS = 2, DS_INTERNAL = 3, DS_NEED_WALK = 4 };
+enum { DS_OK = 0, DS_OUT_OF_CANDIDATES = 1, DS_OUT_OF_WORDS = 2, DS_INTERNAL = 3, DS_NEED_WALK = 4, DS_NEED_SERIAL_SHUFFLE = 5 };
 
 struct DsStatus {
     int32_t status;
@@ -57,6 +57,7 @@ struct DsStatus {
     int64_t raw_next1;   // stream index (in X) of the first word phase 2 may use
     int64_t raw_next2;   // ... of the first word nobody used: the generator stands here afterwards
     int64_t cand_used;
+    int64_t perm_w;      // shuffle: the stream index the next regime / the walk starts at
     int32_t why, why_at; // DS_NEED_WALK: what the parallel negatives phase met (1 events, 2 knot of repeats, 3 start outside a window,
                          // 4 range too short, 5 a user's end does not check) and at which user / segment
     int64_t dbg[6];      // tile iterations, shader clocks, 100 MHz ticks of neg_chain and of perm_targets (crec_dsampler_stats)
@@ -1125,8 +1126,10 @@ struct PermLds {
 };
 
 // tgt[i], i = n-1 .. 1: the swap target of step i of the legacy shuffle.  Also leaves the generator's final state.
-__global__ __launch_bounds__(WT) void perm_targets(const uint32_t *__restrict__ x, int64_t x_words64, int64_t n, uint32_t *__restrict__ tgt,
-                                                   DsStatus *__restrict__ st)
+// i0: the first step this walk takes (n - 1, or below the regimes that perm_round / perm_emit resolved in parallel: then the
+// stream position comes from st->perm_w)
+__global__ __launch_bounds__(WT) void perm_targets(const uint32_t *__restrict__ x, int64_t x_words64, int64_t i0, int after_regimes,
+                                                   uint32_t *__restrict__ tgt, DsStatus *__restrict__ st)
 {
     __shared__ __align__(16) PermLds L; // ONE shared object (a second one beside an LDS-DMA target can cost a vmcnt(0) per read)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1134,8 +1137,8 @@ __global__ __launch_bounds__(WT) void perm_targets(const uint32_t *__restrict__ 
     if (st->status != DS_OK)
         return;
     const uint32_t x_words = (uint32_t)x_words64;
-    uint32_t w = (uint32_t)st->raw_next1;
-    int32_t i = (int32_t)(n - 1);
+    uint32_t w = (uint32_t)(after_regimes ? st->perm_w : st->raw_next1);
+    int32_t i = (int32_t)i0;
     uint32_t iters = 0;
     int par = 0;
     bool failed = false;
@@ -1257,6 +1260,185 @@ __global__ __launch_bounds__(WT) void perm_targets(const uint32_t *__restrict__ 
     }
 }
 
+// ---- phase 2, the large steps in parallel --------------------------------------------------------------------------------------
+// While i stays between two powers of two (a `regime`: one mask, R steps from hi down) word t of the stream is accepted iff
+// (word & mask) <= hi - c_t, c_t = the accepted before it: a threshold that depends on the answer.  Instead of walking, bound
+// c_t from both sides -- accepted-for-sure before t <= c_t <= that + undecided before t -- and decide every word whose two
+// thresholds agree; the undecided thin out like t^n / (n! M^n) from round to round (M = mask + 1 >= 2 R), so eight to ten
+// rounds settle a regime of a million words, each round one launch over all of its words (prefix sums of the round before, per
+// workgroup of 2048 words).  The regimes themselves follow one another (the next one starts where this one's R-th accepted
+// word lies); the steps below 65 536 -- 90 K words in all -- are left to the walk above.  Rounds that find nothing undecided
+// return at once; a regime that is not settled after PR_ROUNDS, or runs out of words, is reported (the walk takes the sample).
+constexpr int PR_BLK = 2048;
+constexpr int PR_ROUNDS = 12;
+constexpr int PR_MIN_STEP = 65536;
+struct PermRegime {
+    int32_t hi, R;
+    uint32_t mask, tmax;
+    int nb, first; // workgroups; first regime of the shuffle (its start is raw_next1)
+};
+
+__device__ __forceinline__ uint32_t regime_start(const DsStatus *st, const PermRegime &g) { return (uint32_t)(g.first ? st->raw_next1 : st->perm_w); }
+
+// cls: 0 undecided, 1 accepted, 2 rejected or behind the regime's end.  blk: [PR_ROUNDS][2][nbmax] accepted / undecided per workgroup.
+__global__ __launch_bounds__(256) void perm_round(const uint32_t *__restrict__ x, uint32_t x_words, PermRegime g, int r, uint8_t *__restrict__ cls,
+                                                  uint32_t *__restrict__ blk, int nbmax, const DsStatus *__restrict__ st)
+{
+    __shared__ uint32_t ws[8], red[12];
+    if (st->status != DS_OK)
+        return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t b = blockIdx.x, w0 = regime_start(st, g);
+    uint32_t L0 = 0, A0 = 0;
+    if (r > 0) {
+        const uint32_t *pa = blk + (size_t)((r - 1) * 2) * nbmax, *pb = pa + nbmax;
+        uint32_t la = 0, lb = 0, all = 0;
+        for (int q = tid; q < g.nb; q += 256) {
+            const uint32_t va = pa[q], vb = pb[q];
+            all += vb;
+            if ((uint32_t)q < b)
+                la += va, lb += vb;
+        }
+        for (int o = 32; o >= 1; o >>= 1)
+            la += __shfl_xor(la, o), lb += __shfl_xor(lb, o), all += __shfl_xor(all, o);
+        if (lane == 0)
+            red[wave] = la, red[4 + wave] = lb, red[8 + wave] = all;
+        __syncthreads();
+        L0 = red[0] + red[1] + red[2] + red[3], A0 = red[4] + red[5] + red[6] + red[7];
+        if (red[8] + red[9] + red[10] + red[11] == 0) { // the round before left nothing undecided: hand its counts on
+            if (tid == 0)
+                blk[(size_t)(r * 2) * nbmax + b] = pa[b], blk[(size_t)(r * 2 + 1) * nbmax + b] = 0;
+            return;
+        }
+    }
+    const uint32_t t0 = b * PR_BLK + tid * 8;
+    int32_t v[8];
+    uint32_t stt[8], sa = 0, sb = 0;
+    uint64_t old = 0;
+    if (r > 0)
+        old = *(const uint64_t *)(cls + t0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t t = t0 + j;
+        const bool valid = t < g.tmax && w0 + t < x_words;
+        v[j] = valid ? (int32_t)(mt_temper(x[w0 + t]) & g.mask) : 0x7fffffff;
+        if (r == 0)
+            stt[j] = !valid || v[j] > g.hi ? 2u : (v[j] <= g.hi - (int32_t)t ? 1u : 0u); // at most t accepted before word t
+        else
+            stt[j] = (uint32_t)(old >> (8 * j)) & 255u;
+        sa += stt[j] == 1u, sb += stt[j] == 0u;
+    }
+    uint32_t na = sa, nu = sb;
+    if (r > 0) {
+        uint32_t total;
+        const uint32_t ex = block_scan256(sa | (sb << 16), ws, lane, wave, total);
+        uint32_t Lt = L0 + (ex & 0xffffu), Ut = Lt + A0 + (ex >> 16);
+        na = 0, nu = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t was = stt[j];
+            if ((int32_t)Lt >= g.R)
+                stt[j] = 2u; // behind the regime's last step
+            else if (was == 0u) {
+                if (v[j] <= g.hi - (int32_t)Ut)
+                    stt[j] = 1u;
+                else if (v[j] > g.hi - (int32_t)Lt)
+                    stt[j] = 2u;
+            }
+            Lt += was == 1u, Ut += was != 2u;
+            na += stt[j] == 1u, nu += stt[j] == 0u;
+        }
+    }
+    uint64_t nw = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        nw |= (uint64_t)stt[j] << (8 * j);
+    *(uint64_t *)(cls + t0) = nw;
+    for (int o = 32; o >= 1; o >>= 1)
+        na += __shfl_xor(na, o), nu += __shfl_xor(nu, o);
+    __syncthreads();
+    if (lane == 0)
+        red[wave] = na, red[4 + wave] = nu;
+    __syncthreads();
+    if (tid == 0) {
+        blk[(size_t)(r * 2) * nbmax + b] = red[0] + red[1] + red[2] + red[3];
+        blk[(size_t)(r * 2 + 1) * nbmax + b] = red[4] + red[5] + red[6] + red[7];
+    }
+}
+
+// after the rounds: per workgroup the accepted words (fin[b]) and whether anything is left undecided (-> the serial shuffle)
+__global__ __launch_bounds__(256) void perm_count(PermRegime g, const uint8_t *__restrict__ cls, uint32_t *__restrict__ fin, DsStatus *__restrict__ st)
+{
+    __shared__ uint32_t red[8];
+    if (st->status != DS_OK)
+        return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t c8 = *(const uint64_t *)(cls + (size_t)blockIdx.x * PR_BLK + tid * 8);
+    uint32_t na = 0, nu = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t c = (uint32_t)(c8 >> (8 * j)) & 255u;
+        na += c == 1u, nu += c == 0u;
+    }
+    for (int o = 32; o >= 1; o >>= 1)
+        na += __shfl_xor(na, o), nu += __shfl_xor(nu, o);
+    if (lane == 0)
+        red[wave] = na, red[4 + wave] = nu;
+    __syncthreads();
+    if (tid == 0) {
+        fin[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+        if (red[4] + red[5] + red[6] + red[7])
+            st->status = DS_NEED_SERIAL_SHUFFLE;
+    }
+}
+
+// tgt[hi - rank] for the regime's accepted words; the word behind the R-th one is where the next regime starts
+__global__ __launch_bounds__(256) void perm_emit(const uint32_t *__restrict__ x, PermRegime g, const uint8_t *__restrict__ cls, const uint32_t *__restrict__ fin,
+                                                 uint32_t *__restrict__ tgt, DsStatus *__restrict__ st)
+{
+    __shared__ uint32_t ws[8], red[8];
+    if (st->status != DS_OK)
+        return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t b = blockIdx.x, w0 = regime_start(st, g);
+    uint32_t la = 0, all = 0;
+    for (int q = tid; q < g.nb; q += 256) {
+        const uint32_t va = fin[q];
+        all += va;
+        if ((uint32_t)q < b)
+            la += va;
+    }
+    for (int o = 32; o >= 1; o >>= 1)
+        la += __shfl_xor(la, o), all += __shfl_xor(all, o);
+    if (lane == 0)
+        red[wave] = la, red[4 + wave] = all;
+    __syncthreads();
+    const uint32_t L0 = red[0] + red[1] + red[2] + red[3], total_acc = red[4] + red[5] + red[6] + red[7];
+    if ((int32_t)total_acc < g.R) { // the words ran out before the regime's last step: a larger budget
+        if (b == 0 && tid == 0)
+            st->status = DS_OUT_OF_WORDS;
+        return;
+    }
+    const uint32_t t0 = b * PR_BLK + tid * 8;
+    const uint64_t c8 = *(const uint64_t *)(cls + t0);
+    uint32_t sa = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        sa += ((uint32_t)(c8 >> (8 * j)) & 255u) == 1u;
+    uint32_t total;
+    uint32_t Lt = L0 + block_scan256(sa, ws, lane, wave, total);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (((uint32_t)(c8 >> (8 * j)) & 255u) == 1u) {
+            if ((int32_t)Lt < g.R) {
+                tgt[g.hi - (int32_t)Lt] = mt_temper(x[w0 + t0 + j]) & g.mask;
+                if ((int32_t)Lt == g.R - 1)
+                    st->perm_w = (int64_t)w0 + t0 + j + 1;
+            }
+            ++Lt;
+        }
+}
+
 // ---- phase 3 -------------------------------------------------------------------------------------------------------
 // (phase 3 reads what the walks wrote: after a walk that ran out of stream -- the host redoes the sample with a larger budget --
 // `tgt` is not fully written, and nothing may be indexed with it)
@@ -1368,11 +1550,11 @@ struct crec_dsampler {
     std::vector<int32_t> deg, uniq;
     int plan_nr = -1;      // the neg_ratio the plan below was made for (-1: none)
     bool plan_ok = false;  // the plan fits the kernels' limits
-    bool force_walk = false;
+    bool force_walk = false, force_serial_shuffle = false;
     int64_t walk_fallbacks = 0;
     int32_t last_why = 0, last_why_at = 0;
     uint32_t plan_rcap = 0, plan_wcap = 0, plan_nseg = 0, plan_wfirst_max = 0;
-    crec_devbuf p_lo, p_W, p_len, p_toff, p_need, p_base, p_foff, tabT, tabF, p_start;
+    crec_devbuf p_lo, p_W, p_len, p_toff, p_need, p_base, p_foff, tabT, tabF, p_start, pr_cls, pr_blk;
 };
 
 namespace {
@@ -1408,7 +1590,8 @@ int free_bufs(crec_dsampler *s)
 {
     crec_devbuf *bufs[] = {&s->ptr, &s->items, &s->edge_user, &s->bitmaps, &s->polys, &s->x, &s->base, &s->next_key, &s->cand, &s->cand_raw,
                            &s->counts, &s->neg, &s->tgt, &s->key, &s->val, &s->skey, &s->sval, &s->head, &s->nxt, &s->sort_tmp, &s->status,
-                           &s->p_lo, &s->p_W, &s->p_len, &s->p_toff, &s->p_need, &s->p_base, &s->p_foff, &s->tabT, &s->tabF, &s->p_start};
+                           &s->p_lo, &s->p_W, &s->p_len, &s->p_toff, &s->p_need, &s->p_base, &s->p_foff, &s->tabT, &s->tabF, &s->p_start,
+                           &s->pr_cls, &s->pr_blk};
     for (crec_devbuf *b : bufs)
         if (b->ptr) {
             (void)hipFree(b->ptr);
@@ -1607,8 +1790,42 @@ int enqueue(crec_ctx *ctx, crec_dsampler *s)
         s->raw_next1_in = r0; // lives in the object: the copy is asynchronous
         CREC_HIP(ctx, hipMemcpyAsync(&dst->raw_next1, &s->raw_next1_in, sizeof(int64_t), hipMemcpyHostToDevice, st));
     }
-    // phase 2 (also leaves the final generator state)
-    hipLaunchKernelGGL(perm_targets, dim3(1), dim3(WT), 0, st, (const uint32_t *)x, x_words, n, (uint32_t *)s->tgt.ptr, dst);
+    // phase 2: the regimes of large steps in parallel, the rest (and the final generator state) by the walk
+    int64_t i0 = n - 1;
+    int after_regimes = 0;
+    if (!s->force_serial_shuffle && ctx->knob_dsampler_general == 0) {
+        std::vector<PermRegime> regs;
+        int64_t hi = n - 1;
+        int nbmax = 0;
+        while (hi >= PR_MIN_STEP) {
+            const uint32_t m = mask_of((uint32_t)hi);
+            const int64_t lo = (int64_t)(m >> 1) + 1, R = hi - lo + 1;
+            // accepted with probability (i + 1) / (m + 1) >= 1/2: 2 R words on average at worst, + eight standard deviations
+            const int64_t tmax = 2 * R + (int64_t)(8.0 * std::sqrt(2.0 * (double)R)) + 512;
+            PermRegime g{(int32_t)hi, (int32_t)R, m, (uint32_t)tmax, (int)crec_ceil_div(tmax, PR_BLK), regs.empty() ? 1 : 0};
+            nbmax = g.nb > nbmax ? g.nb : nbmax;
+            regs.push_back(g);
+            hi = lo - 1;
+        }
+        if (!regs.empty()) {
+            if (int rc = crec_reserve(ctx, &s->pr_cls, (size_t)nbmax * PR_BLK + 64))
+                return rc;
+            if (int rc = crec_reserve(ctx, &s->pr_blk, (size_t)(PR_ROUNDS * 2 + 1) * nbmax * 4 + 64))
+                return rc;
+            uint32_t *blk = (uint32_t *)s->pr_blk.ptr, *fin = blk + (size_t)PR_ROUNDS * 2 * nbmax;
+            for (const PermRegime &g : regs) {
+                for (int r = 0; r < PR_ROUNDS; ++r)
+                    hipLaunchKernelGGL(perm_round, dim3(g.nb), dim3(256), 0, st, (const uint32_t *)x, (uint32_t)x_words, g, r, (uint8_t *)s->pr_cls.ptr, blk,
+                                       nbmax, (const DsStatus *)dst);
+                hipLaunchKernelGGL(perm_count, dim3(g.nb), dim3(256), 0, st, g, (const uint8_t *)s->pr_cls.ptr, fin, dst);
+                hipLaunchKernelGGL(perm_emit, dim3(g.nb), dim3(256), 0, st, (const uint32_t *)x, g, (const uint8_t *)s->pr_cls.ptr, (const uint32_t *)fin,
+                                   (uint32_t *)s->tgt.ptr, dst);
+            }
+            i0 = hi;
+            after_regimes = 1;
+        }
+    }
+    hipLaunchKernelGGL(perm_targets, dim3(1), dim3(WT), 0, st, (const uint32_t *)x, x_words, i0, after_regimes, (uint32_t *)s->tgt.ptr, dst);
     // phase 3
     if (n > 0) {
         const unsigned g = (unsigned)crec_ceil_div(n, 256);
@@ -1772,7 +1989,7 @@ int crec_dsampler_sample(crec_ctx *ctx, crec_dsampler *s, int kind, int neg_rati
     CREC_HIP(ctx, hipSetDevice(s->device));
     s->kind = kind, s->nr = neg_ratio, s->pos_in = pos, s->u = u, s->i = i, s->third = third, s->stream = (hipStream_t)stream;
     s->n = n;
-    s->force_walk = false;
+    s->force_walk = s->force_serial_shuffle = false;
     s->growth = ctx->knob_dsampler_budget > 0 ? ctx->knob_dsampler_budget / 100.0 : 1.0;
     std::memcpy(s->key_in, key, sizeof(s->key_in));
     return enqueue(ctx, s);
@@ -1792,6 +2009,14 @@ int crec_dsampler_finish(crec_ctx *ctx, crec_dsampler *s, int64_t *n_out, uint32
             break;
         // the stream budget (sized from the expected rejection counts) did not last: again with twice the words
         CREC_REQUIRE(ctx, s->status_host->status != DS_INTERNAL, "device sampler: internal error (undecided words left in a shuffle tile)");
+        if (s->status_host->status == DS_NEED_SERIAL_SHUFFLE && !s->force_serial_shuffle) { // a regime not settled within its rounds
+            s->force_serial_shuffle = true;
+            ++s->walk_fallbacks;
+            s->last_why = 6, s->last_why_at = 0;
+            if (int rc = enqueue(ctx, s))
+                return rc;
+            continue;
+        }
         if (s->status_host->status == DS_NEED_WALK && !s->force_walk) { // the parallel negatives phase met something it reports instead of handling
             s->force_walk = true;
             ++s->walk_fallbacks;
