@@ -809,7 +809,7 @@ constexpr uint32_t T_INVALID = 0xffffffffu;
 constexpr int TAB_EV = 1024;    // events per user beyond which the sample goes to the walk (tiny catalogues)
 constexpr int TAB_SK = 256;     // repeats per user, likewise
 constexpr int TAB_SEG = 64;     // users per segment
-constexpr int TAB_NR_MAX = 33;
+constexpr int TAB_NR_MAX = 30; // events look nr + 1 ranks back: one bit each in a 32-bit mask
 
 struct TabArgs {
     const int32_t *cand;
@@ -847,21 +847,26 @@ __device__ __forceinline__ uint32_t block_scan256(uint32_t v, uint32_t *ws, int 
     return incl - v + (wave >= 1 ? w0 : 0u) + (wave >= 2 ? w1 : 0u) + (wave >= 3 ? w2 : 0u);
 }
 
-// the accepted candidates of cand[c0 .. c0 + L) for the user whose bitmap is ubm (LDS): apos[r] = offset of the r-th one
-// (r < rcap), rkw[t] = accepted before offset t (t < Wn).  Returns their number.  256 threads.
-__device__ uint32_t build_accepted(const int32_t *__restrict__ cand, uint32_t c0, uint32_t L, const uint32_t *ubm, uint32_t *apos, uint32_t rcap,
-                                   uint32_t *rkw, uint32_t Wn, uint32_t *ws)
+// the accepted candidates of cand[c0 .. c0 + L) for the user whose bitmap is ubm (LDS): acc[r] = value << 16 | offset of the r-th
+// one (r < rcap; item ids and offsets below 65 536 on this path), rkw[t] = accepted before offset t (t < Wn).  Returns their number.
+__device__ uint32_t build_accepted(const int32_t *__restrict__ cand, uint32_t c0, uint32_t L, const uint32_t *ubm, uint32_t *acc, uint32_t rcap,
+                                   uint16_t *rkw, uint32_t Wn, uint32_t *ws)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t cum = 0;
     int par = 0;
     for (uint32_t ch = 0; ch < L; ch += 1024, par ^= 4) {
         uint32_t f[4], sum = 0;
+        int32_t c[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint32_t t = ch + tid * 4 + j;
-            const int32_t c = t < L ? cand[c0 + t] : 0;
-            f[j] = t < L && !((ubm[(uint32_t)c >> 5] >> (c & 31)) & 1u);
+            c[j] = t < L ? cand[c0 + t] : 0;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t t = ch + tid * 4 + j;
+            f[j] = t < L && !((ubm[(uint32_t)c[j] >> 5] >> (c[j] & 31)) & 1u);
             sum += f[j];
         }
         uint32_t total;
@@ -870,9 +875,9 @@ __device__ uint32_t build_accepted(const int32_t *__restrict__ cand, uint32_t c0
         for (int j = 0; j < 4; ++j) {
             const uint32_t t = ch + tid * 4 + j;
             if (t < Wn)
-                rkw[t] = rb;
+                rkw[t] = (uint16_t)rb;
             if (f[j] && rb < rcap)
-                apos[rb] = t;
+                acc[rb] = ((uint32_t)c[j] << 16) | t;
             rb += f[j];
         }
         cum += total;
@@ -882,49 +887,42 @@ __device__ uint32_t build_accepted(const int32_t *__restrict__ cand, uint32_t c0
 }
 
 // events: pairs of equal accepted candidates at most D ranks apart, as (r << 8 | d) in rank order (r the later one, d the distance).
-// vbuf: LDS [256 + 64]; ctl: LDS [2].  Returns the number of events (capped at TAB_EV + 1).
-__device__ uint32_t build_events(const int32_t *__restrict__ cand, uint32_t c0, const uint32_t *apos, uint32_t R, uint32_t D, int32_t *vbuf,
-                                 uint32_t *ev, uint32_t *ws, uint32_t *ctl)
+// Returns the number of events (capped at TAB_EV + 1).
+__device__ uint32_t build_events(const uint32_t *acc, uint32_t R, uint32_t D, uint32_t *ev, uint32_t *ws)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t nev = 0;
-    if (tid == 0)
-        ctl[0] = 0;
-    __syncthreads();
-    for (uint32_t rc = 0; rc < R; rc += 256) {
-        const uint32_t r = rc + tid;
-        vbuf[64 + tid] = r < R ? cand[c0 + apos[r]] : -1;
-        if (tid < 64)
-            vbuf[tid] = rc + tid >= 64 ? cand[c0 + apos[rc + tid - 64]] : -2;
-        __syncthreads();
-        uint32_t cnt = 0;
-        const int32_t mine = vbuf[64 + tid];
-        if (r < R)
-            for (uint32_t d = 1; d <= D; ++d)
-                cnt += r >= d && vbuf[64 + tid - d] == mine;
-        if (cnt)
-            ctl[0] = 1; // benign race: every writer writes 1
-        __syncthreads();
-        if (ctl[0]) { // rare: some candidate of this stretch equals an earlier one close by
-            uint32_t total;
-            uint32_t at = nev + block_scan256(cnt, ws, lane, wave, total);
-            if (r < R)
-                for (uint32_t d = 1; d <= D; ++d)
-                    if (r >= d && vbuf[64 + tid - d] == mine) {
-                        if (at < TAB_EV)
-                            ev[at] = (r << 8) | d;
-                        ++at;
-                    }
-            nev += total;
-            __syncthreads();
-            if (tid == 0)
-                ctl[0] = 0;
+    int par = 0;
+    for (uint32_t rc = 0; rc < R; rc += 1024, par ^= 4) {
+        uint32_t cnt = 0, hit[4] = {0, 0, 0, 0}; // bit d of hit[j]: the candidate d ranks back equals this one (D <= 31 on this path)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t r = rc + tid * 4 + j;
+            if (r < R) {
+                const uint32_t mine = acc[r] >> 16;
+                for (uint32_t d = 1; d <= D && d <= r; ++d)
+                    hit[j] |= (uint32_t)((acc[r - d] >> 16) == mine) << d;
+                cnt += __popc(hit[j]);
+            }
         }
-        __syncthreads();
+        uint32_t total;
+        uint32_t at = nev + block_scan256(cnt, ws + par, lane, wave, total);
+        if (total) // rare enough: a candidate that equals one close before it
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t r = rc + tid * 4 + j;
+                for (uint32_t h = hit[j]; h; h &= h - 1) {
+                    if (at < TAB_EV)
+                        ev[at] = (r << 8) | (uint32_t)(__ffs(h) - 1);
+                    ++at;
+                }
+            }
+        nev += total;
         if (nev > TAB_EV)
-            return TAB_EV + 1;
+            break;
     }
-    return nev;
+    __syncthreads();
+    return nev > TAB_EV ? TAB_EV + 1 : nev;
 }
 
 // How many of the events are repeats when the user starts at accepted rank rs: walks the events in rank order with the number
@@ -958,15 +956,16 @@ __device__ __forceinline__ uint32_t eval_skips(const uint32_t *ev, uint32_t nev,
     return skips;
 }
 
-// LDS of neg_tab / neg_emit: [bitmap row bw][apos rcap][rkw wcap][vbuf 320][ev TAB_EV][rec TAB_SK][ws 8][ctl 4]
-__global__ __launch_bounds__(256) void neg_tab(TabArgs a)
+// LDS of neg_tab / neg_emit: [bitmap row bw][acc rcap][ev TAB_EV][rec TAB_SK][ws 8][rkw wcap x 16 bit]
+// The users are launched in two classes (`ids`: the users of this launch): the many with short ranges share a CU several at a time,
+// the few long ones get the LDS they need.
+__global__ __launch_bounds__(256) void neg_tab(TabArgs a, const uint32_t *__restrict__ ids, uint32_t rcap, uint32_t wcap)
 {
     extern __shared__ uint32_t lds[];
-    uint32_t *ubm = lds, *apos = ubm + a.bw, *rkw = apos + a.rcap;
-    int32_t *vbuf = (int32_t *)(rkw + a.wcap);
-    uint32_t *ev = (uint32_t *)(vbuf + 320), *ws = ev + TAB_EV + TAB_SK, *ctl = ws + 8;
+    uint32_t *ubm = lds, *acc = ubm + a.bw, *ev = acc + rcap, *ws = ev + TAB_EV + TAB_SK;
+    uint16_t *rkw = (uint16_t *)(ws + 8);
     const int tid = threadIdx.x;
-    const uint32_t k = blockIdx.x, lo = a.lo[k], W = a.W[k], need = a.need[k];
+    const uint32_t k = ids[blockIdx.x], lo = a.lo[k], W = a.W[k], need = a.need[k];
     uint32_t *T = a.T + a.toff[k];
     const uint32_t n_cand = (uint32_t)a.st->n_cand;
     if (need == 0) { // no rows: the next user starts where this one would
@@ -983,15 +982,14 @@ __global__ __launch_bounds__(256) void neg_tab(TabArgs a)
     for (int w = tid; w < a.bw; w += 256)
         ubm[w] = a.bitmaps[(size_t)k * a.bw + w];
     __syncthreads();
-    const uint32_t R = min(build_accepted(a.cand, lo, L, ubm, apos, a.rcap, rkw, min(W, L), ws), a.rcap);
+    const uint32_t R = min(build_accepted(a.cand, lo, L, ubm, acc, rcap, rkw, min(W, L), ws), rcap);
     const uint32_t D = (uint32_t)a.nr + 1;
-    const uint32_t nev = a.nr > 1 ? build_events(a.cand, lo, apos, R, D, vbuf, ev, ws, ctl) : 0u;
+    const uint32_t nev = a.nr > 1 ? build_events(acc, R, D, ev, ws) : 0u;
     if (nev > TAB_EV) {
         if (tid == 0)
             a.st->status = DS_NEED_WALK, a.st->why = 1, a.st->why_at = (int32_t)k;
         return;
     }
-    __syncthreads();
     bool cplx = false;
     for (uint32_t i = tid; i < W; i += 256) {
         uint32_t E = T_INVALID;
@@ -999,7 +997,7 @@ __global__ __launch_bounds__(256) void neg_tab(TabArgs a)
             const uint32_t rs = rkw[i];
             const uint32_t tr = rs + need - 1 + (nev ? eval_skips(ev, nev, rs, need, (uint32_t)a.nr, D, cplx, nullptr, false) : 0u);
             if (tr < R)
-                E = lo + apos[tr] + 1;
+                E = lo + (acc[tr] & 0xffffu) + 1;
         }
         T[i] = E;
     }
@@ -1076,12 +1074,12 @@ __global__ __launch_bounds__(64) void neg_chain_starts(TabArgs a, const uint32_t
     }
 }
 
-__global__ __launch_bounds__(256) void neg_emit(TabArgs a)
+// the users of this launch by their TRUE ranges: ids of the users whose range (start[k+1] - start[k]) is at most / above `split`
+// are not known to the host, so every user is tried by both launches and takes the one its range belongs to
+__global__ __launch_bounds__(256) void neg_emit(TabArgs a, uint32_t rcap, uint32_t min_len, uint32_t max_len)
 {
     extern __shared__ uint32_t lds[];
-    uint32_t *ubm = lds, *apos = ubm + a.bw, *rkw = apos + a.rcap;
-    int32_t *vbuf = (int32_t *)(rkw + a.wcap);
-    uint32_t *ev = (uint32_t *)(vbuf + 320), *rec = ev + TAB_EV, *ws = rec + TAB_SK, *ctl = ws + 8;
+    uint32_t *ubm = lds, *acc = ubm + a.bw, *ev = acc + rcap, *rec = ev + TAB_EV, *ws = rec + TAB_SK;
     const int tid = threadIdx.x;
     if (a.st->status != DS_OK)
         return;
@@ -1089,18 +1087,20 @@ __global__ __launch_bounds__(256) void neg_emit(TabArgs a)
     if (need == 0)
         return;
     const uint32_t s0 = a.start[k], L = a.start[k + 1] - s0;
+    if (L < min_len || L > max_len)
+        return; // the other launch's user
     for (int w = tid; w < a.bw; w += 256)
         ubm[w] = a.bitmaps[(size_t)k * a.bw + w];
     __syncthreads();
-    const uint32_t R = build_accepted(a.cand, s0, L, ubm, apos, a.rcap, rkw, 0, ws);
+    const uint32_t R = build_accepted(a.cand, s0, L, ubm, acc, rcap, nullptr, 0, ws);
     const uint32_t D = (uint32_t)a.nr + 1;
-    const uint32_t nev = a.nr > 1 && R <= a.rcap ? build_events(a.cand, s0, apos, R, D, vbuf, ev, ws, ctl) : 0u;
-    bool cplx = R > a.rcap || nev > TAB_EV;
+    const uint32_t nev = a.nr > 1 && R <= rcap ? build_events(acc, R, D, ev, ws) : 0u;
+    bool cplx = R > rcap || nev > TAB_EV;
     uint32_t skips = 0;
     if (!cplx && nev)
         skips = eval_skips(ev, nev, 0u, need, (uint32_t)a.nr, D, cplx, rec, tid == 0);
     // the table said this user ends exactly here: its last candidate is its last slot
-    if (cplx || skips > TAB_SK || R != need + skips || apos[R - 1] != L - 1) {
+    if (cplx || skips > TAB_SK || R != need + skips || (acc[R - 1] & 0xffffu) != L - 1) {
         if (tid == 0)
             a.st->status = DS_NEED_WALK, a.st->why = 5, a.st->why_at = (int32_t)k;
         return;
@@ -1114,7 +1114,7 @@ __global__ __launch_bounds__(256) void neg_emit(TabArgs a)
             rep |= rec[q] == r;
         }
         if (!rep)
-            a.neg[base + r - before] = a.cand[s0 + apos[r]];
+            a.neg[base + r - before] = (int32_t)(acc[r] >> 16);
     }
 }
 
@@ -1553,8 +1553,8 @@ struct crec_dsampler {
     bool force_walk = false, force_serial_shuffle = false;
     int64_t walk_fallbacks = 0;
     int32_t last_why = 0, last_why_at = 0;
-    uint32_t plan_rcap = 0, plan_wcap = 0, plan_nseg = 0, plan_wfirst_max = 0;
-    crec_devbuf p_lo, p_W, p_len, p_toff, p_need, p_base, p_foff, tabT, tabF, p_start, pr_cls, pr_blk;
+    uint32_t plan_rcap = 0, plan_wcap = 0, plan_nseg = 0, plan_wfirst_max = 0, plan_rcap_a = 0, plan_wcap_a = 0, plan_na = 0, plan_nb = 0;
+    crec_devbuf p_lo, p_W, p_len, p_toff, p_need, p_base, p_foff, p_ids, tabT, tabF, p_start, pr_cls, pr_blk;
 };
 
 namespace {
@@ -1590,7 +1590,7 @@ int free_bufs(crec_dsampler *s)
 {
     crec_devbuf *bufs[] = {&s->ptr, &s->items, &s->edge_user, &s->bitmaps, &s->polys, &s->x, &s->base, &s->next_key, &s->cand, &s->cand_raw,
                            &s->counts, &s->neg, &s->tgt, &s->key, &s->val, &s->skey, &s->sval, &s->head, &s->nxt, &s->sort_tmp, &s->status,
-                           &s->p_lo, &s->p_W, &s->p_len, &s->p_toff, &s->p_need, &s->p_base, &s->p_foff, &s->tabT, &s->tabF, &s->p_start,
+                           &s->p_lo, &s->p_W, &s->p_len, &s->p_toff, &s->p_need, &s->p_base, &s->p_foff, &s->p_ids, &s->tabT, &s->tabF, &s->p_start,
                            &s->pr_cls, &s->pr_blk};
     for (crec_devbuf *b : bufs)
         if (b->ptr) {
@@ -1652,9 +1652,18 @@ int make_plan(crec_ctx *ctx, crec_dsampler *s, int nr, hipStream_t st)
         wcap = W[k] > wcap ? W[k] : wcap;
         S += mu, V += var;
     }
-    const size_t lds = ((size_t)s->bw + rcap + wcap + 320 + TAB_EV + TAB_SK + 8 + 4) * 4;
-    if (tsum >= ((uint64_t)1 << 31) || lds > 150 * 1024)
+    const size_t lds = ((size_t)s->bw + rcap + TAB_EV + TAB_SK + 8) * 4 + (size_t)wcap * 2 + 4;
+    if (tsum >= ((uint64_t)1 << 31) || lds > 150 * 1024 || rcap > 65535 || s->item_nums > 65536)
         return CREC_OK;
+    // class A: ranges of at most 12288 candidates (three workgroups to a CU); class B: the rest
+    std::vector<uint32_t> ids((size_t)U);
+    uint32_t na = 0, nb = 0, rcap_a = 0, wcap_a = 0;
+    for (int64_t k = 0; k < U; ++k)
+        if (len[k] <= 12288)
+            ids[na++] = (uint32_t)k, rcap_a = len[k] > rcap_a ? len[k] : rcap_a, wcap_a = W[k] > wcap_a ? W[k] : wcap_a;
+    for (int64_t k = 0; k < U; ++k)
+        if (len[k] > 12288)
+            ids[na + nb++] = (uint32_t)k;
     const auto up = [&](crec_devbuf *b, const std::vector<uint32_t> &v) {
         if (int rc = crec_reserve(ctx, b, v.size() * 4 + 4))
             return rc;
@@ -1662,7 +1671,7 @@ int make_plan(crec_ctx *ctx, crec_dsampler *s, int nr, hipStream_t st)
         return (int)CREC_OK;
     };
     for (auto pr : {std::make_pair(&s->p_lo, &lo), std::make_pair(&s->p_W, &W), std::make_pair(&s->p_len, &len), std::make_pair(&s->p_toff, &toff),
-                    std::make_pair(&s->p_need, &need), std::make_pair(&s->p_base, &base), std::make_pair(&s->p_foff, &foff)})
+                    std::make_pair(&s->p_need, &need), std::make_pair(&s->p_base, &base), std::make_pair(&s->p_foff, &foff), std::make_pair(&s->p_ids, &ids)})
         if (int rc = up(pr.first, *pr.second))
             return rc;
     if (int rc = crec_reserve(ctx, &s->tabT, (size_t)tsum * 4 + 4))
@@ -1673,6 +1682,7 @@ int make_plan(crec_ctx *ctx, crec_dsampler *s, int nr, hipStream_t st)
         return rc;
     CREC_HIP(ctx, hipStreamSynchronize(st)); // the vectors go away
     s->plan_rcap = rcap, s->plan_wcap = wcap, s->plan_nseg = (uint32_t)foff.size(), s->plan_wfirst_max = wfirst;
+    s->plan_rcap_a = rcap_a, s->plan_wcap_a = wcap_a, s->plan_na = na, s->plan_nb = nb;
     s->plan_ok = true;
     return CREC_OK;
 }
@@ -1756,14 +1766,23 @@ int enqueue(crec_ctx *ctx, crec_dsampler *s)
                        (const uint32_t *)s->p_lo.ptr, (const uint32_t *)s->p_W.ptr, (const uint32_t *)s->p_len.ptr, (const uint32_t *)s->p_toff.ptr,
                        (const uint32_t *)s->p_need.ptr, (const uint32_t *)s->p_base.ptr, (uint32_t *)s->tabT.ptr, (uint32_t *)s->p_start.ptr, dst,
                        s->plan_rcap, s->plan_wcap, (int32_t *)s->neg.ptr, (const uint32_t *)s->cand_raw.ptr, r0};
-            const size_t lds = ((size_t)s->bw + s->plan_rcap + s->plan_wcap + 320 + TAB_EV + TAB_SK + 8 + 4) * 4;
-            CREC_HIP(ctx, hipFuncSetAttribute((const void *)neg_tab, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            CREC_HIP(ctx, hipFuncSetAttribute((const void *)neg_emit, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(neg_tab, dim3((unsigned)s->n_users), dim3(256), lds, st, ta);
+            // two classes of users by the length of their tested ranges: the short ones several workgroups to a CU
+            const auto tab_lds = [&](uint32_t rcap, uint32_t wcap) { return ((size_t)s->bw + rcap + TAB_EV + TAB_SK + 8) * 4 + (size_t)((wcap + 1) & ~1u) * 2; };
+            const size_t lds_a = tab_lds(s->plan_rcap_a, s->plan_wcap_a), lds_b = tab_lds(s->plan_rcap, s->plan_wcap);
+            CREC_HIP(ctx, hipFuncSetAttribute((const void *)neg_tab, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_a > lds_b ? lds_a : lds_b)));
+            if (s->plan_na)
+                hipLaunchKernelGGL(neg_tab, dim3(s->plan_na), dim3(256), lds_a, st, ta, (const uint32_t *)s->p_ids.ptr, s->plan_rcap_a, s->plan_wcap_a);
+            if (s->plan_nb)
+                hipLaunchKernelGGL(neg_tab, dim3(s->plan_nb), dim3(256), lds_b, st, ta, (const uint32_t *)s->p_ids.ptr + s->plan_na, s->plan_rcap, s->plan_wcap);
             hipLaunchKernelGGL(neg_compose, dim3(s->plan_nseg, (unsigned)crec_ceil_div(s->plan_wfirst_max, 256)), dim3(256), 0, st, ta,
                                (const uint32_t *)s->p_foff.ptr, (uint32_t *)s->tabF.ptr);
             hipLaunchKernelGGL(neg_chain_starts, dim3(1), dim3(64), 0, st, ta, (const uint32_t *)s->p_foff.ptr, (const uint32_t *)s->tabF.ptr, s->plan_nseg);
-            hipLaunchKernelGGL(neg_emit, dim3((unsigned)s->n_users), dim3(256), lds, st, ta);
+            // the users' true ranges are far shorter than the tested ones: most take the small launch
+            const uint32_t emit_small = 4096;
+            const auto emit_lds = [&](uint32_t rcap) { return ((size_t)s->bw + rcap + TAB_EV + TAB_SK + 8) * 4; };
+            CREC_HIP(ctx, hipFuncSetAttribute((const void *)neg_emit, hipFuncAttributeMaxDynamicSharedMemorySize, (int)emit_lds(s->plan_rcap)));
+            hipLaunchKernelGGL(neg_emit, dim3((unsigned)s->n_users), dim3(256), emit_lds(emit_small), st, ta, emit_small, 0u, emit_small);
+            hipLaunchKernelGGL(neg_emit, dim3((unsigned)s->n_users), dim3(256), emit_lds(s->plan_rcap), st, ta, s->plan_rcap, emit_small + 1, 0xffffffffu);
         } else
         if (nr <= WALK_NR_MAX && s->bw <= WALK_BW_MAX && ctx->knob_dsampler_general != 1) {
             na.nbuf = WALK_NBUF;
