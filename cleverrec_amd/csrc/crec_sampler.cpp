@@ -1,12 +1,10 @@
 // Host side of the hot path: the NumPy-legacy MT19937 stream and the three epoch samplers,
 // bit-exact with the reference on the same RNG state.
 //
-// Why this part stays on the host: one MT19937 stream feeds data-dependent rejection loops
-// (redraw while j is a seen item or repeats inside the positive's group) and a Fisher-Yates
-// shuffle whose accept test changes every step, so which stream word lands in which slot
-// depends on every earlier accept/reject.  That chain is strictly serial; a single CPU core
-// walks it at a few ns per draw, a GPU lane at tens.  Everything after the draws (expanding
-// u/i, applying the permutation) is a gather and is done here in one fused pass.
+// The host form.  Since round 3 the model classes draw these streams on the device (mt_sampler.hip: same words, same
+// columns, same final state); this file stays as the form that has no limits (any catalogue size), for SBPR's sampler, for
+// `sampler_mode=mt19937_host`, and as the RNG the ctx exposes (crec_rng_*).  One RNG thread walks the rejection loops and the
+// shuffle's draws; the swaps and the gather of the output columns are pipelined behind it on two more threads.
 //
 // Reference: utils/sampler.py:10-99 (samplers), numpy RandomState (randint / permutation).
 #include <cstdlib>

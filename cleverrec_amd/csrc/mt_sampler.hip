@@ -3,8 +3,8 @@
 // reference (tests/golden/sampler_*.npz, tests/test_gpu_dsampler.py); the host form (crec_sampler.cpp) remains for SBPR
 // and for shapes outside this file's limits.
 //
-// The reference's loop is serial in two places only -- which stream word a draw takes depends on every earlier
-// accept / reject.  Everything else is a filter, a prefix sum or a gather:
+// The reference's loop looks serial -- which stream word a draw takes depends on every earlier accept / reject -- but it is a
+// filter, a prefix sum or a gather almost everywhere, and the two real chains have structure:
 //
 //  0  raw words.  MT19937 is linear over GF(2): the state J words ahead is a fixed XOR-combination (jump polynomial,
 //     mt_jump.h) of the next 19937 states, i.e. of the stream itself.  `mt_base` writes 34 blocks from the input key,
@@ -13,15 +13,15 @@
 //     more jump.  Words stay raw (untempered) in HBM: the final generator state is 624 of them.
 //  1a randint(item_nums) is a masked rejection (`v = word & mask; take v if v <= item_nums - 1`): a pure filter of the
 //     stream -> `cand_*` kernels compact the survivors (count, scan, scatter), keeping each one's stream position.
-//  1b `neg_chain`, ONE workgroup of 1024 threads, walks the users in the reference's order.  A tile of 1024 candidates
-//     is tested against the user's bitmap of training items (LDS, prefetched a few users ahead), an exclusive prefix
-//     sum numbers the accepted ones -- slot s of the user is the s-th accepted candidate since its start --, a repeat
-//     inside a positive's group of neg_ratio (sampler.py:24,59,88 `j in random_j`) cuts the tile right behind the
-//     repeated candidate (consumed, rejected), the user's last slot cuts it there.  One link of the chain per user.
-//  2  `perm_targets`, one workgroup: np.random.permutation(n) is arange + for i = n-1..1: swap(a[i], a[draw in [0,i]]),
-//     the draw again a masked rejection but with a bound that falls with every accepted word.  Thread t of a tile
-//     accepts iff (word & mask) <= i - (#accepted before t): sure for most (compare against i - t and i), the rest
-//     refined with prefix bounds until none is undecided; a tile is cut where i crosses a power of two (mask changes).
+//  1b the negatives.  User k+1's first candidate is wherever user k's last slot was filled -- but that place is predictable to
+//     within a few hundred candidates, so `neg_tab` (a workgroup per user, all at once) tabulates the user's end for EVERY
+//     start in its window, `neg_compose` / `neg_chain_starts` chain the tables by look-ups and `neg_emit` writes the negatives
+//     from the true starts.  `neg_walk` (four waves, tiles of 1024 candidates through LDS rings) is the serial form: it takes
+//     what the tables report instead of handling, and catalogues beyond their limits (`neg_chain_general` beyond 65 536 items).
+//  2  np.random.permutation(n) is arange + for i = n-1..1: swap(a[i], a[draw in [0,i]]), the draw again a masked rejection but
+//     with a bound that falls with every accepted word.  While i stays between two powers of two the accepted count is bounded
+//     from both sides and every word whose two thresholds agree is decided, round after round over all words of the regime
+//     (`perm_round`, `perm_count`, `perm_emit`); the steps below 65 536 are walked by one workgroup (`perm_targets`).
 //  3  the permutation itself without executing a swap: position i ends up with what sat at its target before step i,
 //     which is what the most recent earlier step with the same target put there ...: steps sorted by target (rocPRIM
 //     radix sort), one pointer per step to the next step with its target, one per position to the first step that
