@@ -809,7 +809,9 @@ __device__ __forceinline__ void opt4(float4 &var, float4 &m, float4 &v, float4 g
 
 // deferred mode: bring a row's float4 slice from the state after step `last` to the state after step `upto` with the
 // untouched-row update of TF1's sparse Adam.  m falls below the smallest fp32 denormal after < 1024 steps (0.9^1024 =
-// 1e-47 of itself), from where on var no longer moves: the rest of the gap is v *= b2^n.
+// 1e-47 of itself; the entry point refuses beta1 > 0.9), from where on var no longer moves: the rest of the gap is
+// v *= b2^n -- one powf instead of n fp32 multiplications, i.e. v is within a few ulp of the sweep's, not bit-identical, for
+// rows idle longer than 1024 steps.
 constexpr int CREC_REPLAY_MAX = 1024;
 __device__ __forceinline__ void adam_replay(float4 &var, float4 &m, float4 &v, int last, int upto, const Hyper &h)
 {
@@ -2683,11 +2685,33 @@ int sharded_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, int64_t I_global
         }
         max_served = stride > max_served ? stride : max_served;
         stride = (stride + 63) / 64 * 64;
-        CREC_REQUIRE(ctx, stride <= 16 * SHARD_THREADS,
-                     "a batch asks this rank for %lld rows; the owner-side index sorts at most %d per batch in LDS", (long long)stride,
-                     16 * SHARD_THREADS);
-        if (int rc = crec_reserve(ctx, &ctx->shard_ws2, serve_layout(nullptr, nbc, total_srv, stride).bytes))
-            return rc;
+        // What this rank is asked for is data-dependent and differs from rank to rank: a rank that left here alone would leave its
+        // peers blocked in the exchanges below for ever.  So the verdict is collective: every rank contributes whether IT can go
+        // on (one float through the all-reduce the chunk ends with anyway) and all of them fail together.
+        int local_rc = CREC_OK;
+        if (stride > 16 * SHARD_THREADS)
+            local_rc = crec_fail(ctx, CREC_EINVAL, "a batch asks this rank for %lld rows; the owner-side index sorts at most %d per batch in LDS",
+                                 (long long)stride, 16 * SHARD_THREADS);
+        else
+            local_rc = crec_reserve(ctx, &ctx->shard_ws2, serve_layout(nullptr, nbc, total_srv, stride).bytes);
+        if (G > 1) {
+            if (int rc = crec_reserve(ctx, &ctx->shard_flag, 64))
+                local_rc = local_rc ? local_rc : rc;
+            float verdict = local_rc == CREC_OK ? 0.f : 1.f;
+            if (ctx->shard_flag.ptr) {
+                CREC_HIP(ctx, hipMemcpyAsync(ctx->shard_flag.ptr, &verdict, sizeof(float), hipMemcpyHostToDevice, st));
+                CREC_HIP(ctx, hipStreamSynchronize(st));
+                if (int rc = x->allreduce_sum_f32(ctx, (float *)ctx->shard_flag.ptr, 1, st))
+                    return local_rc ? local_rc : rc;
+                CREC_HIP(ctx, hipMemcpyAsync(&verdict, ctx->shard_flag.ptr, sizeof(float), hipMemcpyDeviceToHost, st));
+                CREC_HIP(ctx, hipStreamSynchronize(st));
+            }
+            if (local_rc == CREC_OK && verdict > 0.f)
+                return crec_fail(ctx, CREC_EINVAL, "%d peer rank(s) cannot serve this chunk (more rows asked of one owner than its index sorts per batch, "
+                                                   "or out of memory there): every rank stops here", (int)(verdict + 0.5f));
+        }
+        if (local_rc)
+            return local_rc;
         const ServeWs v = serve_layout(ctx->shard_ws2.ptr, nbc, total_srv, stride);
         CREC_HIP(ctx, hipMemcpyAsync(p.pack_off, h_pack, sizeof(int64_t) * (size_t)nbc * G, hipMemcpyHostToDevice, st));
         CREC_HIP(ctx, hipMemcpyAsync(p.srv_base, h_base, sizeof(int64_t) * (size_t)nbc * G, hipMemcpyHostToDevice, st));
@@ -2807,6 +2831,10 @@ int crec_bpr_train_epoch_deferred(crec_ctx *ctx, const crec_bpr_tables *t, const
     if (!ctx)
         return CREC_EINVAL;
     CREC_REQUIRE(ctx, df != nullptr, "null argument");
+    // the replay of the steps a row sat out stops after CREC_REPLAY_MAX steps, where m has left the fp32 range -- true for beta1 <= 0.9
+    // (0.9^1024 = 1e-47); a slower decay would still carry weight there and the mode would no longer equal the TF1 sweep
+    CREC_REQUIRE(ctx, opt && opt->beta1 <= 0.9000001f, "adam_mode deferred replays at most %d idle steps exactly: beta1 = %g > 0.9 decays too slowly for that (use tf1 or lazy)",
+                 CREC_REPLAY_MAX, opt ? (double)opt->beta1 : 0.0);
     return train_epoch_impl(ctx, t, opt, u, i, j, N, B, loss_per_batch, stream, false, df);
 }
 

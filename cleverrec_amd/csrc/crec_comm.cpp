@@ -76,6 +76,19 @@ struct LocalGroup {
         std::vector<float> host;
     };
     std::vector<Pub> pub;
+    bool step_failed = false; // some rank's part of the exchange in progress failed: every rank reports it (read behind the closing barrier)
+    // a rank that cannot take part any more (its own HIP call failed before a barrier): the others must not wait 120 s for it
+    void give_up()
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        broken = true;
+        cv.notify_all();
+    }
+    void mark_failed()
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        step_failed = true;
+    }
     // false: a rank did not arrive within the time-out (it failed or was never called); the group stays broken
     bool barrier()
     {
@@ -104,7 +117,10 @@ struct LocalXch : crec_xch {
                   const int64_t *rcnt, const int64_t *rdsp, int elem_bytes, hipStream_t st) override
     {
         // everything this rank enqueued so far is done: its receive buffer is free, its send buffer is filled
-        CREC_HIP(ctx, hipStreamSynchronize(st));
+        if (hipStreamSynchronize(st) != hipSuccess) {
+            grp->give_up();
+            return crec_fail(ctx, CREC_EHIP, "local group: hipStreamSynchronize failed before the exchange");
+        }
         grp->pub[rank].recv = recv;
         grp->pub[rank].rcnt = rcnt;
         grp->pub[rank].rdsp = rdsp;
@@ -119,7 +135,9 @@ struct LocalXch : crec_xch {
                                     (size_t)scnt[p] * elem_bytes, hipMemcpyDefault, st) == hipSuccess;
         }
         ok = ok && hipStreamSynchronize(st) == hipSuccess;
-        if (!grp->barrier() || !ok) // every rank's segments have landed everywhere
+        if (!ok)
+            grp->mark_failed(); // a count mismatch is seen by one side only: all ranks return the same verdict
+        if (!grp->barrier() || grp->step_failed) // every rank's segments have landed everywhere
             return crec_fail(ctx, CREC_EHIP, "local group: exchange failed (count mismatch, copy error or a missing rank)");
         return CREC_OK;
     }
@@ -127,16 +145,19 @@ struct LocalXch : crec_xch {
     {
         std::vector<float> &mine = grp->pub[rank].host;
         mine.resize(n);
-        CREC_HIP(ctx, hipMemcpyAsync(mine.data(), buf, n * sizeof(float), hipMemcpyDeviceToHost, st));
-        CREC_HIP(ctx, hipStreamSynchronize(st));
+        if (hipMemcpyAsync(mine.data(), buf, n * sizeof(float), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+            grp->give_up();
+            return crec_fail(ctx, CREC_EHIP, "local group: reading this rank's operand of the all-reduce failed");
+        }
         if (!grp->barrier())
             return crec_fail(ctx, CREC_EHIP, "local group: a rank did not reach the all-reduce");
         std::vector<float> sum(n, 0.f);
         for (int p = 0; p < world; ++p) // rank order: every rank gets the bit-identical sum
             for (size_t k = 0; k < n; ++k)
                 sum[k] = sum[k] + grp->pub[p].host[k];
-        const hipError_t e = hipMemcpy(buf, sum.data(), n * sizeof(float), hipMemcpyHostToDevice);
-        if (!grp->barrier() || e != hipSuccess) // nobody refills its host copy before everybody has read it
+        if (hipMemcpy(buf, sum.data(), n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+            grp->mark_failed();
+        if (!grp->barrier() || grp->step_failed) // nobody refills its host copy before everybody has read it
             return crec_fail(ctx, CREC_EHIP, "local group: all-reduce failed");
         return CREC_OK;
     }

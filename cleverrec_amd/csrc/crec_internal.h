@@ -78,6 +78,7 @@ struct crec_ctx {
     void *comm = nullptr; // ncclComm_t (RCCL), set by crec_comm_init
     int rank = 0, world = 1;
     struct crec_xch *xch = nullptr; // exchange object of the row-sharded path (crec_comm.h): local group, RCCL or world of one
+    crec_devbuf shard_flag;          // one float: the collective can-every-rank-go-on verdict of a chunk
     crec_devbuf shard_ws, shard_ws2; // row-sharded step: plan side (request lists, compact ids, Qc / dQc), serve side
     int64_t *pinned64 = nullptr;    // page-locked host staging of the sharded path's counts
     size_t pinned64_n = 0;

@@ -458,6 +458,7 @@ int crec_sample_pointwise(crec_ctx *ctx, const int64_t *ptr, const int32_t *item
         return crec_fail(ctx, CREC_EINVAL, "a user has fewer than neg_ratio unseen items");
     const int32_t *negp = neg.get(), *eup = eu.get();
     const FastDiv by_w((uint32_t)w);
+    static const int ahead_mode = getenv("CREC_SAMPLER_AHEAD") ? atoi(getenv("CREC_SAMPLER_AHEAD")) : 0;
     shuffled_apply(
         ctx->rng, n, perm.get(),
         [=](int64_t k, uint32_t sidx) { // sampler.py:37
@@ -468,6 +469,8 @@ int crec_sample_pointwise(crec_ctx *ctx, const int64_t *ptr, const int32_t *item
             y[k] = t == 0 ? 1.0f : 0.0f;
         },
         [=](uint32_t sidx) {
+            if (ahead_mode < 1) // the same knob as the pairwise gather (CREC_SAMPLER_AHEAD): off unless asked for
+                return;
             const uint32_t e = by_w.div(sidx), t = sidx - e * (uint32_t)w;
             __builtin_prefetch(&eup[e], 0, 0);
             __builtin_prefetch(t == 0 ? &items[e] : &negp[(int64_t)e * neg_ratio + (t - 1)], 0, 0);

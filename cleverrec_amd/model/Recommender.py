@@ -15,7 +15,11 @@ class Recommender(object):
 
     def _get_common_params(self):
         c = self.configs
-        validate(c, extra_width=4 if c.get('recommender') == 'CML' else 0)  # shapes outside the built kernels: refused here
+        # shapes outside the built kernels are refused here.  Evaluation widens the rows by 4 columns for CML (distances as dot
+        # products) and for SBPR / CUNE_BPR's loo / sampled-negatives branch (the bias column): embed_size must leave room
+        name = c.get('recommender')
+        loo = c.get('data.split_way') == 'loo' or int(c.get('test.neg_samples', 0) or 0) > 0
+        validate(c, extra_width=4 if name == 'CML' or (name in ('SBPR', 'CUNE_BPR') and loo) else 0)
         self.epoches, self.batch_size, self.batch_size_t = int(c['epoches']), int(c['batch_size']), int(c['test.batch_size'])
         self.lr, self.neg_samples = float(c['lr']), int(c['test.neg_samples'])
         # presence flags, as in the reference (Recommender.py:19)

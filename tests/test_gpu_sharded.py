@@ -215,3 +215,46 @@ def test_sharded_eval_matches_reference_loop():
         np.testing.assert_allclose(tot[1, kid] / n, np.mean(M[kid]), rtol=1e-12)
         np.testing.assert_allclose(tot[2, kid] / n, np.mean(N[kid]), rtol=1e-12)
     sess.close()
+
+
+def test_an_owner_that_cannot_serve_fails_every_rank_together():
+    """What an owner is asked for in a batch is data-dependent and rank-local: here rank 0 owns every requested item (all even ids,
+    unique, 2 ranks x 2 x 8192 requests per batch > the 16384 rows its index sorts per batch) while rank 1 is asked for nothing.
+    The verdict is collective: BOTH ranks return the error (nobody is left blocked in an exchange)."""
+    G, B, d = 2, 8192, 16
+    U, I = 64, 2 * 2 * 2 * B + 2
+    P0, Q0 = _tables(1, U, I, d)
+    ranges = [parallel.user_range(U, r, G) for r in range(G)]
+    streams = []
+    for r in range(G):
+        lo, hi = ranges[r]
+        u = (np.arange(B) % (hi - lo)).astype(np.int32)
+        i = (2 * (np.arange(B) + r * 2 * B)).astype(np.int32)  # even ids: owner 0; disjoint between the ranks
+        j = (2 * (np.arange(B) + r * 2 * B + B)).astype(np.int32)
+        streams.append((u, i, j))
+    sessions = [runtime.Session(0) for _ in range(G)]
+    parallel.init_local_group(sessions)
+    errors = [None] * G
+
+    def work(r):
+        torch.cuda.set_device(0)
+        with torch.cuda.stream(torch.cuda.Stream()):
+            s = sessions[r]
+            lo, hi = ranges[r]
+            st = parallel.ShardedBprState(s, P0[lo:hi], parallel.shard_items(Q0, r, G), I, 1e-3, 0.01, r, G)
+            try:
+                st.train_epoch(*(s.to_dev(x) for x in streams[r]), B)
+                torch.cuda.current_stream().synchronize()
+            except Exception as e:  # noqa: BLE001
+                errors[r] = str(e)
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(G)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+    assert not any(t.is_alive() for t in threads), "a rank was left blocked"
+    assert errors[0] and "owner-side index" in errors[0]
+    assert errors[1] and "peer rank" in errors[1]
+    for s in sessions:
+        s.close()
