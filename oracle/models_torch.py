@@ -182,6 +182,29 @@ class Model:
         return self.params[k].numpy()
 
 
+class BPR(Model):
+    """model/ranking/BPR.py:31-44: x = <p_u, q_i> - <p_u, q_j>, loss = -sum(log_sigmoid(x)) + reg * (l2(p_u) + l2(q_i) + l2(q_j)) over
+    the batch with duplicates; both tables reached by gathers (IndexedSlices Adam, swept over every row).  The C oracle
+    (oracle/crec_oracle.c) restates the same step; this one carries the rounding envelope (bounds())."""
+
+    def __init__(self, P, Q, lr, reg, optimizer="Adam"):
+        super().__init__({"P": P, "Q": Q}, {"P": "sparse", "Q": "sparse"}, lr, optimizer)
+        self.reg = reg
+
+    def loss(self, w, u, i, j):
+        u, i, j = (torch.as_tensor(np.asarray(x), dtype=torch.long) for x in (u, i, j))
+        pu, qi, qj = gather(w, "P", u), gather(w, "Q", i), gather(w, "Q", j)
+        x = (pu * qi).sum(1) - (pu * qj).sum(1)
+        return torch.nn.functional.softplus(-x).sum() + self.reg * (_l2(pu) + _l2(qi) + _l2(qj))
+
+    def loss_slack(self, *batch):
+        """how far the loss of this batch may move when every parameter moves inside its rounding envelope (first order):
+        sum |dL/dw| * tol_var -- what two correct fp32 trajectories may differ by after many steps, seen from the loss."""
+        leaves = {k: v.clone().requires_grad_(True) for k, v in self.params.items()}
+        g = torch.autograd.grad(self.loss(dict(leaves), *batch), list(leaves.values()), allow_unused=True)
+        return float(sum((gk.abs().double().numpy() * self.opt.tol_var[k]).sum() for k, gk in zip(leaves, g) if gk is not None))
+
+
 class GMF(Model):
     """model/ranking/GMF.py:29-57: logit = sum_d pu*qi*h (:42); loss = sum CE + reg*(l2(pu)+l2(qi)) (:48)."""
 

@@ -235,7 +235,10 @@ def test_bpr_c5_full_size_step_against_the_oracle_on_the_touched_rows(sess, mode
         # m is linear in the gradient: tight.  A weight whose gradient cancels to ~1e-8 (|m| ~ 1e-9, inside Adam's eps) turns the
         # order of the fp32 additions into a fraction of a step: all but 1e-5 of the elements within 2e-6, none beyond 2 % of a step
         np.testing.assert_allclose(gm, getattr(om, "m" + name), rtol=1e-5, atol=1e-7, err_msg="m" + name)
-        np.testing.assert_allclose(gv, getattr(om, "v" + name), rtol=2e-3, atol=1e-12, err_msg="v" + name)
+        # v accumulates (1 - beta2) g^2: an error dg of the gradient sum moves it by 2 (1 - beta2) |g| dg, small against the
+        # LARGEST v of the table wherever g itself cancels -- within 1e-5 of the element or of that scale
+        ov = getattr(om, "v" + name)
+        assert (np.abs(gv - ov) <= 1e-5 * ov + 1e-5 * ov.max()).all(), "v" + name
         dw = np.abs(got - getattr(om, name))
         assert dw.max() <= 2e-5 and (dw > 2e-6).mean() <= 1e-5, "%s: max %.3g, %.3g of the elements beyond 2e-6" % (name, dw.max(), (dw > 2e-6).mean())
     # ---- nothing else moved: rows outside the batches keep their bits, their slots stay zero ----
@@ -563,17 +566,35 @@ def test_bpr_deferred_adam_long_gaps_against_oracle(sess):
     i = g.integers(5, I, steps * B).astype(np.int32)   # items 0..4 never
     j = g.integers(5, I, steps * B).astype(np.int32)
     i[:B] = 5 + np.arange(B)
+    from oracle import models_torch as MT
+    from _adam_close import assert_adam_close
     st = runtime.BprState(sess, P0, Q0, lr=1e-2, reg=0.01, adam_mode="deferred")
-    om = oracle.BprModel(P0, Q0, lr=1e-2, reg=0.01, adam_mode=0)
+    om = MT.BPR(P0, Q0, lr=1e-2, reg=0.01)  # the TF1 sweep (every row every step) with the rounding envelope
     loss = st.train_epoch(sess.to_dev(u), sess.to_dev(i), sess.to_dev(j), B).cpu().numpy()
-    oloss = np.array([om.step(u[b * B:(b + 1) * B], i[b * B:(b + 1) * B], j[b * B:(b + 1) * B]) for b in range(steps)])
-    np.testing.assert_allclose(loss, oloss, rtol=2e-5)
+    # 1 500 steps of lr = 1e-2 on batches of four: two correct fp32 trajectories drift apart by the accumulated rounding
+    # noise, which the restatement tracks per element (bounds()).  A step's loss may differ by 1e-5 of itself plus what that
+    # drift is worth in the loss (first order: sum |dL/dw| * tol_var); the first steps, before any drift, are held to 1e-5 alone.
+    for b in range(steps):
+        sl = slice(b * B, (b + 1) * B)
+        slack = om.loss_slack(u[sl], i[sl], j[sl])
+        ol = om.step(u[sl], i[sl], j[sl])
+        assert abs(loss[b] - ol) <= 1e-5 * abs(ol) + 2.0 * slack, (b, loss[b], ol, slack)
+        if b < 50:
+            assert abs(loss[b] - ol) <= 1e-5 * abs(ol), (b, loss[b], ol)
     st.flush()
-    for name in ("P", "Q"):  # 1 500 steps of lr = 1e-2: the fp32 noise of the running state is what the bound covers
-        np.testing.assert_allclose(getattr(st, name).cpu().numpy(), getattr(om, name), rtol=0, atol=2e-4, err_msg=name)
+    drift = max(float(om.bounds(k)[0].max()) for k in ("P", "Q"))  # how far a parameter of either trajectory may have wandered
+    for name in ("P", "Q"):
+        assert_adam_close(om, name, getattr(st, name), None, None, lr=1e-2)
+        # m is a running mean of gradient sums -s (q_i - q_j) + reg p (|s| <= 1): besides the rounding of the sums themselves
+        # (tol_m) it inherits the parameters' drift, at most ~2 rows' worth per term; 4 x covers the second-order terms
+        mr = om.opt.m[name].numpy().astype(np.float64)
+        assert (np.abs(getattr(st, "m" + name).cpu().numpy() - mr) <= om.bounds(name)[1] + 1e-6 * np.abs(mr) + 1e-10 + 4 * drift).all(), "m" + name
+    assert drift < 1e-3  # the envelope stays far below the parameters themselves (|P|, |Q| ~ 0.1): it constrains
     np.testing.assert_allclose(st.Q.cpu().numpy()[:5], Q0[:5], rtol=0, atol=0)  # never touched: m = v = 0, nothing moves
-    for name in ("vP", "vQ"):
-        np.testing.assert_allclose(getattr(st, name).cpu().numpy(), getattr(om, name), rtol=2e-3, atol=1e-12, err_msg=name)
+    for name in ("vP", "vQ"):  # beyond 1 024 idle steps v is scaled by one powf instead of n multiplications (a few ulp), on top of its envelope
+        ov = om.opt.v[name[1:]].numpy().astype(np.float64)
+        tol = om.bounds(name[1:])[2] + 1e-5 * ov + 1e-5 * ov.max() + 8 * drift * np.sqrt(ov.max())  # (1 - b2) 2 |g| dg summed over ~1 / (1 - b2) steps
+        assert (np.abs(getattr(st, name).cpu().numpy() - ov) <= tol).all(), name
 
 
 def test_counts_published_by_the_index_kernel_equal_the_copied_ones(sess):

@@ -258,3 +258,24 @@ def test_an_owner_that_cannot_serve_fails_every_rank_together():
     assert errors[1] and "peer rank" in errors[1]
     for s in sessions:
         s.close()
+
+
+def test_sharded_at_a_million_items():
+    """BASELINE configs[4]'s catalogue scale on the item side: 1 000 003 items (odd: the last shard row of rank 1 is padding), d = 128,
+    B = 6144 per rank, 2 ranks.  The oracle runs the same batches on the compact problem of the touched items (exact: an item no
+    batch names takes no part in the row-sharded step); every other row of Q must keep its bits."""
+    U, I, B, d, G = 20000, 1_000_003, 6144, 128, 2
+    P0, Q0 = _tables(12, U, I, d)
+    streams, ranges = _streams(13, U, I, G, [2 * B + 50, 2 * B])
+    P, Q, loss, stats = _run_sharded(G, P0, Q0, ranges, streams, B, d)
+    qq = np.unique(np.concatenate([np.concatenate([i, j]) for _, i, j in streams]))
+    compact = [(u, np.searchsorted(qq, i).astype(np.int32), np.searchsorted(qq, j).astype(np.int32)) for u, i, j in streams]
+    oP, oQ, oloss, _ = oracle.sharded_steps(P0, Q0[qq], ranges, compact, B)
+    np.testing.assert_allclose(loss, oloss, rtol=1e-5)
+    for a, b in ((P, oP), (Q[qq], oQ)):
+        diff = np.abs(a - b)  # (see test_sharded_c5_row_width_and_batch: the odd cancelling gradient sits a fraction of an Adam step away)
+        assert diff.max() <= 2e-5 and (diff > 2e-6).mean() <= 1e-5
+    untouched = np.ones(I, bool)
+    untouched[qq] = False
+    assert np.array_equal(Q[untouched], Q0[untouched])
+    assert sum(s["rows_requested"] for s in stats) == sum(s["rows_served"] for s in stats) > 0
