@@ -61,7 +61,7 @@ def grid(configs):
 # -- not as a CREC_EINVAL from the middle of an epoch.
 LIMITS = {
     "batch_size": 8192,   # a batch's (row, slot) pairs are sorted in LDS: 2 * batch_size <= 16384 pairs
-    "topk": 32,           # the fused evaluation keeps at most 32 candidates per user
+    "topk": 128,          # the fused evaluation ranks 32 candidates per user and pass, up to four passes
     "embed_size": 256,    # table rows are walked as float4 slices by at most 64 lanes
 }
 
@@ -79,5 +79,8 @@ def validate(configs, extra_width=0):
         bad("topk", configs["topk"], "an ascending list of cut-offs in 1..%d" % LIMITS["topk"])
     if "embed_size" in configs and not str(configs["embed_size"]).strip().startswith("["):
         d = int(configs["embed_size"])
-        if d < 4 or d % 4 or d + extra_width > LIMITS["embed_size"]:
-            bad("embed_size", d, "a multiple of 4 in 4..%d" % (LIMITS["embed_size"] - extra_width))
+        # BPR pads its rows to whole float4 slices itself (zero columns stay zero there); the other models' graphs couple the
+        # columns (CML's covariance term, the towers' first layer), so their width has to be a multiple of 4 as given
+        pads = configs.get("recommender") == "BPR"
+        if d < 1 or (d % 4 and not pads) or (d + 3) // 4 * 4 + extra_width > LIMITS["embed_size"]:
+            bad("embed_size", d, ("1..%d" if pads else "a multiple of 4 in 4..%d") % (LIMITS["embed_size"] - extra_width))

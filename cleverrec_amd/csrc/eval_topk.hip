@@ -33,7 +33,8 @@ typedef unsigned long long u64;
 // Candidate slots per user: after a prune at most K stay, and one block can add 32 (one per item lane), so
 // CAP >= K + 32.  Two shapes: 4 waves x CAP 64 (K <= 32), or 8 waves x CAP 56 (K <= 24) -- two waves per SIMD, so that
 // one wave's epilogue, LDS reads and barrier waits fill the other's MFMA gaps -- when its buffers fit the 160 KB of LDS.
-constexpr int K_MAX = 32;
+constexpr int K_MAX = 32;       // candidates the sweep keeps per user and pass
+constexpr int K_LIST_MAX = 128; // the longest list crec_eval_topk ranks (four passes) and crec_rank_metrics reads
 constexpr int cap_of(int NW) { return NW == 8 ? 56 : 64; }
 constexpr int MAX_SPLITS = 16;
 
@@ -71,6 +72,8 @@ struct WaveState {
     int64_t row0;         // bitmap row of this wave's first user
     int words;
     int keep_listed; // 0: drop items found in the user's list (seen filter); 1: keep only those (candidates)
+    const int32_t *excl;  // K > 32, list mode: [rows][excl_stride] the ids the earlier passes have ranked (first n_excl per row)
+    int n_excl, excl_stride;
 };
 
 // Keep the K best unseen entries of user row `ul` (n buffered), sorted best first; returns how many stay.  Whole wave.
@@ -98,6 +101,9 @@ __device__ inline int prune(const WaveState &ws, int ul, int K, int n, const int
             const bool listed = lo < end && seen_items[lo] == item;
             if (listed != (ws.keep_listed != 0))
                 mine = 0;
+            for (int q = 0; q < ws.n_excl; ++q) // the ranks above this pass's (a list longer than 32 is ranked 32 at a time)
+                if (ws.excl[(ws.row0 + ul) * ws.excl_stride + q] == item)
+                    mine = 0;
         }
         if (lane < ws.cap) // a user's buffer may be shorter than the wave
             buf[lane] = mine;
@@ -140,7 +146,8 @@ __global__ __launch_bounds__(NW * 64) void eval_sweep(const float *__restrict__ 
                                                   const int64_t *__restrict__ seen_ptr,
                                                   const int32_t *__restrict__ seen_items, int K, float sign,
                                                   int64_t items_per_split, u64 *__restrict__ part /*[Bt][S][K]*/,
-                                                  const uint32_t *__restrict__ bits, int words)
+                                                  const uint32_t *__restrict__ bits, int words, const int32_t *__restrict__ excl, int n_excl,
+                                                  int excl_stride)
 {
     constexpr int HS = DMAX / 2;          // MFMA steps
     constexpr int LDQ = DMAX + 4;         // padded LDS row (floats)
@@ -162,7 +169,7 @@ __global__ __launch_bounds__(NW * 64) void eval_sweep(const float *__restrict__ 
     const int row = lane & 31, h = lane >> 5;
     // the host packs the filter mode above K: K | keep_listed << 16
     WaveState ws{cand_all + wv * 32 * CAP, cnt_all + wv * 32, clean_all + wv * 32, thr_all + wv * 32, uid_all + wv * 32, CAP, bits,
-                 (int64_t)blockIdx.x * USERS_PER_WG + wv * 32, words, K >> 16};
+                 (int64_t)blockIdx.x * USERS_PER_WG + wv * 32, words, K >> 16, excl, n_excl, excl_stride};
     K &= 0xffff;
 
     const int S = gridDim.y, sp = blockIdx.y;
@@ -390,8 +397,9 @@ __global__ __launch_bounds__(NW * 64) void eval_sweep(const float *__restrict__ 
 }
 
 // one wave per user: rank the S*K keys, best first
+// (out_stride, out_off: a list longer than 32 is ranked 32 at a time, every pass into its columns of the [Bt, out_stride] outputs)
 __global__ __launch_bounds__(64) void eval_merge(const u64 *__restrict__ part, int S, int K, float sign,
-                                                 int32_t *__restrict__ topk_ids, float *__restrict__ topk_scores)
+                                                 int32_t *__restrict__ topk_ids, float *__restrict__ topk_scores, int out_stride, int out_off)
 {
     __shared__ u64 keys[MAX_SPLITS * K_MAX];
     const int lane = threadIdx.x, n = S * K;
@@ -399,8 +407,8 @@ __global__ __launch_bounds__(64) void eval_merge(const u64 *__restrict__ part, i
     for (int k = lane; k < n; k += 64)
         keys[k] = part[user * n + k];
     if (lane < K) {
-        topk_ids[user * K + lane] = -1;
-        topk_scores[user * K + lane] = sign * -INFINITY;
+        topk_ids[user * out_stride + out_off + lane] = -1;
+        topk_scores[user * out_stride + out_off + lane] = sign * -INFINITY;
     }
     __syncthreads();
     for (int k = lane; k < n; k += 64) {
@@ -411,8 +419,8 @@ __global__ __launch_bounds__(64) void eval_merge(const u64 *__restrict__ part, i
         for (int t = 0; t < n; ++t)
             rank += keys[t] > mine;
         if (rank < K) {
-            topk_ids[user * K + rank] = key_item(mine);
-            topk_scores[user * K + rank] = sign * key_score(mine);
+            topk_ids[user * out_stride + out_off + rank] = key_item(mine);
+            topk_scores[user * out_stride + out_off + rank] = sign * key_score(mine);
         }
     }
 }
@@ -436,13 +444,14 @@ __global__ __launch_bounds__(256) void rank_metrics_kernel(const int32_t *__rest
                                                            double *__restrict__ hr, double *__restrict__ mrr,
                                                            double *__restrict__ ndcg)
 {
-    __shared__ int32_t rec_all[4][64];
+    __shared__ int32_t rec_all[4][K_LIST_MAX];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t r = (int64_t)blockIdx.x * 4 + wv;
     if (r >= Bt)
         return;
     int32_t *rec = rec_all[wv];
-    rec[lane] = lane < Kmax ? topk_ids[r * Kmax + lane] : -1; // Kmax <= 32 (crec_eval_topk), checked by the host
+    for (int k = lane; k < K_LIST_MAX; k += 64)
+        rec[k] = k < Kmax ? topk_ids[r * Kmax + k] : -1; // Kmax <= K_LIST_MAX, checked by the host
     __builtin_amdgcn_wave_barrier();
     asm volatile("" ::: "memory");
     const int32_t uu = users[r];
@@ -492,6 +501,24 @@ __global__ __launch_bounds__(256) void list_bitmap(const int32_t *__restrict__ u
     }
 }
 
+// K > 32, bitmap mode: the ids a pass has ranked leave the competition (seen filter: their bit is set like a listed item's;
+// candidates mode: cleared)
+__global__ __launch_bounds__(256) void ranked_out_of_bitmap(const int32_t *__restrict__ ids, int Bt, int stride, int off, int n, int words,
+                                                            int keep_listed, uint32_t *__restrict__ bits)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (int64_t)Bt * n)
+        return;
+    const int64_t r = t / n;
+    const int32_t it = ids[r * stride + off + (int)(t % n)];
+    if (it < 0)
+        return;
+    if (keep_listed)
+        atomicAnd(bits + r * words + (it >> 5), ~(1u << (it & 31)));
+    else
+        atomicOr(bits + r * words + (it >> 5), 1u << (it & 31));
+}
+
 template <int DMAX, int TI, int NW> constexpr size_t sweep_lds()
 {
     return sizeof(float) * 2 * TI * (DMAX + 4) + sizeof(u64) * NW * 32 * cap_of(NW) + sizeof(int) * NW * 32 * 4;
@@ -500,7 +527,7 @@ template <int DMAX, int TI, int NW> constexpr size_t sweep_lds()
 template <int DMAX, int TI, int NW>
 int launch_sweep(crec_ctx *ctx, dim3 grid, hipStream_t st, const float *P, const float *Q, int64_t I, int d,
                  const int32_t *users, int Bt, const int64_t *seen_ptr, const int32_t *seen_items, int K, float sign,
-                 int64_t per_split, u64 *part, const uint32_t *bits, int words)
+                 int64_t per_split, u64 *part, const uint32_t *bits, int words, const int32_t *excl, int n_excl, int excl_stride)
 {
     constexpr size_t lds = sweep_lds<DMAX, TI, NW>();
     static_assert(lds <= 160 * 1024, "eval_sweep shape does not fit the LDS");
@@ -508,7 +535,7 @@ int launch_sweep(crec_ctx *ctx, dim3 grid, hipStream_t st, const float *P, const
                                       (int)lds));
     crec_prof_begin(ctx, CREC_K_EVAL_SWEEP, st);
     CREC_KLAUNCH(ctx, (eval_sweep<DMAX, TI, NW>), grid, dim3(NW * 64), lds, st, P, Q, I, d, users, Bt, seen_ptr, seen_items, K,
-                       sign, per_split, part, bits, words);
+                       sign, per_split, part, bits, words, excl, n_excl, excl_stride);
     crec_prof_end(ctx, st);
     return CREC_OK;
 }
@@ -543,19 +570,23 @@ static int eval_topk_impl(crec_ctx *ctx, const float *P, const float *Q, int64_t
     CREC_REQUIRE(ctx, ctx->device >= 0, "host-only ctx: no device bound");
     CREC_REQUIRE(ctx, P && Q && users && seen_ptr && topk_ids && topk_scores, "null argument");
     CREC_REQUIRE(ctx, d >= 4 && d <= 256 && d % 4 == 0, "embed_size %d: need a multiple of 4 in [4, 256]", d);
-    CREC_REQUIRE(ctx, K >= 1 && K <= K_MAX, "K = %d: this build keeps at most %d per user", K, K_MAX);
+    CREC_REQUIRE(ctx, K >= 1 && K <= K_LIST_MAX, "K = %d: lists of at most %d ids", K, K_LIST_MAX);
     CREC_REQUIRE(ctx, I >= 1 && I < ((int64_t)1 << 31) && Bt >= 0, "bad sizes");
     CREC_REQUIRE(ctx, (((uintptr_t)P | (uintptr_t)Q) & 15) == 0, "table base not 16-byte aligned");
     if (Bt == 0)
         return CREC_OK;
     CREC_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
+    // The sweep keeps at most K_MAX = 32 candidates per user on chip.  A longer list (the reference takes any topk,
+    // Recommender.py:27) is ranked 32 at a time: pass p ranks the best 32 of what the passes before it have not ranked --
+    // their ids join the seen filter (bitmap mode) or are dropped in the prune (list mode) -- into columns [32 p, 32 p + 32).
+    const int Kp = K < K_MAX ? K : K_MAX; // buffers and shapes are sized for the widest pass
 
     // shape: 8 waves per workgroup (two per SIMD) when K and the row width leave room for their buffers (measured:
     // 66 vs 51 % of the MFMA peak at 65536 x 1M x 64, and 0.46 vs 0.67 ms for the ml-1m sweep)
     const int64_t cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
     // option eval_shape = 8 / 4: force a shape where it is legal (tests, tuning; crec_ctx_set_option)
-    const bool wide = K <= cap_of(8) - 32 && d <= 128 && (ctx->knob_eval_shape ? ctx->knob_eval_shape == 8 : Bt > 128);
+    const bool wide = Kp <= cap_of(8) - 32 && d <= 128 && (ctx->knob_eval_shape ? ctx->knob_eval_shape == 8 : Bt > 128);
     const int tile = wide ? (d > 64 ? 32 : 64) : (d > 128 ? 32 : 64);
     const int users_per_wg = (wide ? 8 : 4) * 32;
     const int user_tiles = (int)crec_ceil_div(Bt, users_per_wg);
@@ -569,7 +600,7 @@ static int eval_topk_impl(crec_ctx *ctx, const float *P, const float *Q, int64_t
     // small catalogues: the users' lists as bitmaps, so that a prune tests membership with one load instead of a
     // binary search in global memory (the startup of every (user, split) sweep is prune-bound)
     const int words = (int)crec_ceil_div(I, 32);
-    const size_t part_bytes = (sizeof(u64) * (size_t)Bt * S * K + 255) / 256 * 256;
+    const size_t part_bytes = (sizeof(u64) * (size_t)Bt * S * Kp + 255) / 256 * 256;
     const size_t bits_bytes = sizeof(uint32_t) * (size_t)Bt * words;
     const bool use_bits = bits_bytes <= ((size_t)64 << 20) && !ctx->knob_eval_no_bitmap;
     if (int rc = crec_reserve(ctx, &ctx->eval_ws, part_bytes + (use_bits ? bits_bytes : 0)))
@@ -583,20 +614,28 @@ static int eval_topk_impl(crec_ctx *ctx, const float *P, const float *Q, int64_t
     }
     const float sign = ascending ? -1.0f : 1.0f;
     dim3 grid((unsigned)user_tiles, (unsigned)S);
-    const int kk = K | (keep_listed << 16);
-    int rc;
-#define CREC_SWEEP(DM, TL, W) launch_sweep<DM, TL, W>(ctx, grid, st, P, Q, I, d, users, Bt, seen_ptr, seen_items, kk, sign, per_split, part, bits, words)
-    if (wide)
-        rc = d <= 32 ? CREC_SWEEP(32, 64, 8) : d <= 64 ? CREC_SWEEP(64, 64, 8) : CREC_SWEEP(128, 32, 8);
-    else
-        rc = d <= 32 ? CREC_SWEEP(32, 64, 4) : d <= 64 ? CREC_SWEEP(64, 64, 4) : d <= 128 ? CREC_SWEEP(128, 64, 4) : CREC_SWEEP(256, 32, 4);
+    for (int done = 0; done < K; done += K_MAX) {
+        const int kpass = (K - done) < K_MAX ? (K - done) : K_MAX;
+        const int kk = kpass | (keep_listed << 16);
+        const int32_t *excl = use_bits ? nullptr : topk_ids; // list mode: the columns ranked so far, read by the prune
+        const int n_excl = use_bits ? 0 : done;
+        int rc;
+#define CREC_SWEEP(DM, TL, W) \
+    launch_sweep<DM, TL, W>(ctx, grid, st, P, Q, I, d, users, Bt, seen_ptr, seen_items, kk, sign, per_split, part, bits, words, excl, n_excl, K)
+        if (wide)
+            rc = d <= 32 ? CREC_SWEEP(32, 64, 8) : d <= 64 ? CREC_SWEEP(64, 64, 8) : CREC_SWEEP(128, 32, 8);
+        else
+            rc = d <= 32 ? CREC_SWEEP(32, 64, 4) : d <= 64 ? CREC_SWEEP(64, 64, 4) : d <= 128 ? CREC_SWEEP(128, 64, 4) : CREC_SWEEP(256, 32, 4);
 #undef CREC_SWEEP
-    if (rc)
-        return rc;
-    crec_prof_begin(ctx, CREC_K_EVAL_MERGE, st);
-    CREC_KLAUNCH(ctx, eval_merge, dim3((unsigned)Bt), dim3(64), 0, st, (const u64 *)part, (int)S, (int)K, sign,
-                       topk_ids, topk_scores);
-    crec_prof_end(ctx, st);
+        if (rc)
+            return rc;
+        crec_prof_begin(ctx, CREC_K_EVAL_MERGE, st);
+        CREC_KLAUNCH(ctx, eval_merge, dim3((unsigned)Bt), dim3(64), 0, st, (const u64 *)part, (int)S, kpass, sign, topk_ids, topk_scores, (int)K, done);
+        crec_prof_end(ctx, st);
+        if (use_bits && done + K_MAX < K)
+            hipLaunchKernelGGL(ranked_out_of_bitmap, dim3((unsigned)crec_ceil_div((int64_t)Bt * kpass, 256)), dim3(256), 0, st, (const int32_t *)topk_ids,
+                               (int)Bt, (int)K, done, kpass, words, keep_listed, bits);
+    }
     CREC_HIP(ctx, hipGetLastError());
     return crec_prof_flush(ctx, st);
 }
@@ -609,7 +648,7 @@ extern "C" int crec_rank_metrics(crec_ctx *ctx, const int32_t *topk_ids, const i
         return CREC_EINVAL;
     CREC_REQUIRE(ctx, ctx->device >= 0, "host-only ctx: no device bound");
     CREC_REQUIRE(ctx, topk_ids && users && ks && test_ptr && hr && mrr && ndcg, "null argument");
-    CREC_REQUIRE(ctx, nk >= 1 && nk <= 64 && Bt >= 0 && K >= 1 && K <= 64, "bad sizes (lists of at most 64 ids)");
+    CREC_REQUIRE(ctx, nk >= 1 && nk <= 64 && Bt >= 0 && K >= 1 && K <= K_LIST_MAX, "bad sizes (lists of at most %d ids)", K_LIST_MAX);
     for (int q = 0; q < nk; ++q)
         CREC_REQUIRE(ctx, ks[q] >= 1 && ks[q] <= K, "ks[%d] = %d outside [1, K]", q, ks[q]);
     if (Bt == 0)

@@ -25,7 +25,8 @@ class BPR(RankingRecommender):
         P0 = self.initializer([self.data.user_nums, self.embed_size]) if P0 is None else P0
         Q0 = self.initializer([self.data.item_nums, self.embed_size]) if Q0 is None else Q0
         self.state = BprState(self.sess, P0, Q0, self.lr, self.reg, self.adam_mode)
-        self.P, self.Q = self.state.P, self.state.Q
+        d = self.embed_size  # (the state pads the rows to whole float4 slices; the variables are the reference's [*, embed_size])
+        self.P, self.Q = self.state.P[:, :d], self.state.Q[:, :d]
 
     def _create_embeddings(self):
         pass  # the three embedding_lookups (BPR.py:31-34) happen inside bpr_step_fused / bpr_triples_lazy
@@ -44,7 +45,7 @@ class BPR(RankingRecommender):
         """Variables under the reference's checkpoint names (BPR.py:53-58)."""
         path = path or os.path.join(self.saved_model_dir, self.model, self.model + '.pt')
         self.state.flush()
-        torch.save({'BPR_params/P': self.P.cpu(), 'BPR_params/Q': self.Q.cpu()}, path)
+        torch.save({'BPR_params/P': self.P.cpu().contiguous(), 'BPR_params/Q': self.Q.cpu().contiguous()}, path)
         return path
 
     def build_model(self, P0=None, Q0=None):

@@ -54,6 +54,12 @@ class BprState:
     def __init__(self, sess, P0, Q0, lr, reg, adam_mode="tf1", beta1=0.9, beta2=0.999, eps=1e-8):
         self.sess = sess
         f32 = torch.float32
+        P0, Q0 = np.asarray(P0, dtype=np.float32), np.asarray(Q0, dtype=np.float32)
+        self.d = int(P0.shape[1])
+        pad = (-self.d) % 4
+        if pad:  # rows are walked as float4 slices: a width that is no multiple of 4 gets zero columns, which stay exactly zero
+            # (their gradient -s (q_i - q_j) + reg p is 0, so m = v = 0 and Adam moves them by 0) and add 0 to every dot product
+            P0, Q0 = np.pad(P0, ((0, 0), (0, pad))), np.pad(Q0, ((0, 0), (0, pad)))
         self.P = sess.to_dev(P0, f32).contiguous()
         self.Q = sess.to_dev(Q0, f32).contiguous()
         self.mP, self.vP = torch.zeros_like(self.P), torch.zeros_like(self.P)

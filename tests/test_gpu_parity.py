@@ -254,7 +254,7 @@ def test_bpr_c5_full_size_step_against_the_oracle_on_the_touched_rows(sess, mode
 
 
 def test_bpr_argument_checks(sess):
-    P0, Q0 = _tables(0, 10, 10, 6)  # d = 6 is not a multiple of 4
+    P0, Q0 = _tables(0, 10, 10, 260)  # rows wider than 64 lanes x float4 (a width that is no multiple of 4 is padded by the state)
     st = runtime.BprState(sess, P0, Q0, 1e-3, 0.01)
     z = sess.zeros((8,), torch.int32)
     with pytest.raises(_lib.CrecError, match="embed_size"):
@@ -693,3 +693,52 @@ def test_initializers_reach_the_device_tables(sess, tmp_path, init_method, expec
     else:
         lim = math.sqrt(6.0 / (n + d))
         assert float(x.abs().max()) <= lim and abs(float(x.std()) / (lim / math.sqrt(3)) - 1) < 0.02
+
+
+@pytest.mark.parametrize("K,bitmap", [(50, True), (50, False), (100, True), (128, False), (65, True)])
+def test_topk_lists_longer_than_32(sess, K, bitmap):
+    """topk beyond 32 (the reference takes any list, Recommender.py:27): ranked 32 at a time, every pass with the ranks above it
+    out of the competition -- ids and scores bit-exact against the oracle's full argsort, in both seen-filter paths, and the
+    metrics of the long list against the oracle's cal_ranking_metrics."""
+    g = np.random.Generator(np.random.PCG64(K))
+    U, I, d = 333, 700, 32
+    P, Q = _tables(K, U, I, d)
+    ui_train = {u: [int(x) for x in g.choice(I, size=int(g.integers(1, 600 if u % 9 == 0 else 60)), replace=False)] for u in range(U)}
+    ui_train[0] = list(range(I - 40))  # fewer unseen items than any of the K tried
+    ui_test = {u: [int(x) for x in g.choice(I, size=int(g.integers(1, 8)), replace=False)] for u in range(0, U, 2)}
+    data = RankingData(U, I, ui_train, ui_test)
+    sess.ctx.set_option("eval_no_bitmap", 0 if bitmap else 1)
+    try:
+        users = sess.to_dev(data.test_users)
+        ids, sc = runtime.eval_topk(sess, sess.to_dev(P), sess.to_dev(Q), users, sess.to_dev(data.seen_csr[0]), sess.to_dev(data.seen_csr[1]), K)
+    finally:
+        sess.ctx.set_option("eval_no_bitmap", 0)
+    osc = oracle.scores(P, Q, data.test_users, order=1)
+    oids, oval = oracle.topk(osc, data.test_users, data.seen_csr[0], data.seen_csr[1], K)
+    assert np.array_equal(ids.cpu().numpy(), oids) and np.array_equal(sc.cpu().numpy(), oval)
+    assert (oids[0, 40:] == -1).all() and (oids[0, :40] >= 0).all()  # user 0 has 40 unseen items: the tail of its list is padding
+    ks = [10, min(50, K), K]
+    hr, mrr, ndcg = runtime.rank_metrics(sess, ids, users, ks, sess.to_dev(data.test_csr[0]), sess.to_dev(data.test_csr[1]))
+    ohr, omrr, ondcg = oracle.rank_metrics(oids, data.test_users, ks, data.test_csr[0], data.test_csr[1])
+    np.testing.assert_allclose(hr.cpu().numpy(), ohr, rtol=1e-12)
+    np.testing.assert_allclose(mrr.cpu().numpy(), omrr, rtol=1e-12)
+    np.testing.assert_allclose(ndcg.cpu().numpy(), ondcg, rtol=1e-12)
+
+
+@pytest.mark.parametrize("mode", ["tf1", "lazy"])
+def test_bpr_embed_size_that_is_no_multiple_of_four(sess, mode):
+    """embed_size = 30 (the reference takes any width): the state pads the rows with two zero columns, which stay exactly zero;
+    the 30 real columns, the losses and the ranking equal the oracle's at d = 30."""
+    U, I, d, B = 300, 200, 30, 512
+    g = np.random.Generator(np.random.PCG64(30))
+    P0, Q0 = _tables(30, U, I, d)
+    n = 3 * B + 77
+    u, i, j = g.integers(0, U, n).astype(np.int32), g.integers(0, I, n).astype(np.int32), g.integers(0, I, n).astype(np.int32)
+    st = runtime.BprState(sess, P0, Q0, lr=1e-3, reg=0.01, adam_mode=mode)
+    loss = st.train_epoch(sess.to_dev(u), sess.to_dev(i), sess.to_dev(j), B).cpu().numpy()
+    om = oracle.BprModel(P0, Q0, lr=1e-3, reg=0.01, adam_mode=0 if mode == "tf1" else 1)
+    _, oloss = oracle.train_model_py(om, len(loss), u, i, j, B)
+    np.testing.assert_allclose(loss, oloss, rtol=1e-5)
+    assert st.P.shape[1] == 32 and not st.P[:, 30:].any() and not st.Q[:, 30:].any() and not st.mP[:, 30:].any() and not st.vQ[:, 30:].any()
+    np.testing.assert_allclose(st.P[:, :30].cpu().numpy(), om.P, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(st.Q[:, :30].cpu().numpy(), om.Q, rtol=0, atol=2e-6)

@@ -223,12 +223,16 @@ def test_properties_outside_the_built_shapes_are_refused_up_front():
     from cleverrec_amd import config
     base = {"recommender": "BPR", "batch_size": "6144", "topk": "[10,20]", "embed_size": "64"}
     config.validate(base)
-    for key, val, frag in (("batch_size", "10000", "batch_size = 10000"), ("topk", "[10,20,50]", "topk = [10,20,50]"),
-                           ("embed_size", "300", "embed_size = 300"), ("embed_size", "30", "embed_size = 30"),
-                           ("topk", "[20,10]", "ascending")):
+    for key, val, frag in (("batch_size", "10000", "batch_size = 10000"), ("topk", "[10,20,200]", "topk = [10,20,200]"),
+                           ("embed_size", "300", "embed_size = 300"), ("topk", "[20,10]", "ascending")):
         with pytest.raises(ValueError) as e:
             config.validate(dict(base, **{key: val}))
         assert frag in str(e.value)
+    config.validate(dict(base, topk="[10,50,100]"))  # lists beyond 32 are ranked in passes of 32 (crec_eval_topk)
+    config.validate(dict(base, embed_size="30"))     # BPR pads its rows to whole float4 slices itself
+    with pytest.raises(ValueError) as e:             # the other graphs couple the columns: their width is taken as given
+        config.validate(dict(base, recommender="CML", embed_size="30"))
+    assert "embed_size = 30" in str(e.value)
     config.validate(dict(base, embed_size="252"), extra_width=4)
     with pytest.raises(ValueError):
         config.validate(dict(base, embed_size="256"), extra_width=4)  # CML widens its rows by 4 columns for evaluation
