@@ -17,7 +17,8 @@
 
 namespace {
 
-constexpr int FM_MAX_F = 8; // features per row held in registers
+constexpr int FM_MAX_F = 8;   // features per row held in registers (the shipped data: 2)
+constexpr int FM_WIDE_F = 64; // rows up to this many features: the wide form walks them twice instead of holding them
 
 // loss_b = sum_b (y - y_pre)^2 + reg * 0.5 * (sum rownorm_w + sum rownorm_v), float64, fixed order
 struct FmLossJob { // the loss of one finished step: its squared errors and the row norms its update launch left
@@ -156,6 +157,72 @@ __global__ __launch_bounds__(256) void fm_instances(const float *__restrict__ w0
         w0_partial[wave] = s;
 }
 
+// the same for rows of more than FM_MAX_F features: nothing is held across the row -- the forward pass sums S, SS and the linear
+// term feature by feature in the same order, the backward pass reads the rows again (they are in cache)
+template <int LPR, bool TRAIN>
+__global__ __launch_bounds__(256) void fm_instances_wide(const float *__restrict__ w0, const float *__restrict__ wi,
+                                                         const float *__restrict__ vif, int d, const int32_t *__restrict__ x_idx,
+                                                         const float *__restrict__ x_val, const float *__restrict__ y, int n,
+                                                         int F, float *__restrict__ y_pre, float *__restrict__ c_v,
+                                                         float *__restrict__ c_w, float *__restrict__ sq_err,
+                                                         float *__restrict__ w0_partial, FmLossJob prev)
+{
+    constexpr int G = 64 / LPR;
+    if (TRAIN && prev.out && blockIdx.x == gridDim.x - 1) {
+        fm_reduce_loss_block(prev.sq_err, prev.nb, prev.nw, prev.nv, prev.rows, prev.reg, prev.out);
+        return;
+    }
+    const int lane = threadIdx.x & 63, g = lane / LPR, l = lane % LPR;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t inst = wave * G + g;
+    const bool ok = inst < n, act = 4 * l < d;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 S = zero, SS = zero;
+    float lin = 0.f;
+    if (ok)
+        for (int f = 0; f < F; ++f) {
+            const int xi = x_idx[inst * F + f];
+            const float xv = x_val[inst * F + f], x2 = xv * xv;
+            const float4 v = act ? *reinterpret_cast<const float4 *>(vif + (int64_t)xi * d + 4 * l) : zero;
+            lin = lin + wi[xi];
+            S.x = S.x + xv * v.x, S.y = S.y + xv * v.y, S.z = S.z + xv * v.z, S.w = S.w + xv * v.w;
+            SS.x = SS.x + x2 * (v.x * v.x), SS.y = SS.y + x2 * (v.y * v.y), SS.z = SS.z + x2 * (v.z * v.z), SS.w = SS.w + x2 * (v.w * v.w);
+        }
+    float second = ((S.x * S.x - SS.x) + (S.y * S.y - SS.y)) + ((S.z * S.z - SS.z) + (S.w * S.w - SS.w));
+#pragma unroll
+    for (int off = LPR >> 1; off > 0; off >>= 1)
+        second += __shfl_xor(second, off, 64);
+    const float yp = (w0[0] + lin) + 0.5f * second;
+    if (ok && l == 0)
+        y_pre[inst] = yp;
+    if (!TRAIN)
+        return;
+    const float res = ok ? yp - y[inst] : 0.f;
+    const float gy = 2.0f * res;
+    if (ok) {
+        if (l == 0)
+            sq_err[inst] = res * res;
+        for (int f = 0; f < F; ++f) {
+            if (act) {
+                const int xi = x_idx[inst * F + f];
+                const float xv = x_val[inst * F + f], x2 = xv * xv;
+                const float4 v = *reinterpret_cast<const float4 *>(vif + (int64_t)xi * d + 4 * l);
+                float4 c;
+                c.x = gy * (xv * S.x - x2 * v.x), c.y = gy * (xv * S.y - x2 * v.y), c.z = gy * (xv * S.z - x2 * v.z), c.w = gy * (xv * S.w - x2 * v.w);
+                *reinterpret_cast<float4 *>(c_v + (inst * F + f) * d + 4 * l) = c;
+            }
+            if (l == 0)
+                c_w[inst * F + f] = gy;
+        }
+    }
+    float s = l == 0 ? gy : 0.f;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        s += __shfl_xor(s, off, 64);
+    if (lane == 0)
+        w0_partial[wave] = s;
+}
+
 // utils/metrics.py:22-29 in float64: out = {sqrt(mean (y - y_pre)^2), mean |y - y_pre|}
 __global__ __launch_bounds__(1024) void rmse_mae_kernel(const float *__restrict__ y, const float *__restrict__ yp, int64_t n,
                                                         double *__restrict__ out)
@@ -190,8 +257,12 @@ void launch_instances(crec_ctx *ctx, int lpr, dim3 grid, hipStream_t st, const f
 {
 #define CREC_FM(L)                                                                                                      \
     case L:                                                                                                             \
-        CREC_KLAUNCH(ctx, (fm_instances<L, TRAIN>), grid, dim3(256), 0, st, w0, wi, vif, d, x_idx, x_val, y, n, F, y_pre, \
-                           c_v, c_w, sq_err, w0_partial, prev);                                                         \
+        if (F <= FM_MAX_F)                                                                                              \
+            CREC_KLAUNCH(ctx, (fm_instances<L, TRAIN>), grid, dim3(256), 0, st, w0, wi, vif, d, x_idx, x_val, y, n, F, y_pre, \
+                               c_v, c_w, sq_err, w0_partial, prev);                                                     \
+        else                                                                                                            \
+            CREC_KLAUNCH(ctx, (fm_instances_wide<L, TRAIN>), grid, dim3(256), 0, st, w0, wi, vif, d, x_idx, x_val, y, n, F, y_pre, \
+                               c_v, c_w, sq_err, w0_partial, prev);                                                     \
         break;
     switch (lpr) {
         CREC_FM(1)
@@ -211,7 +282,7 @@ int check_fm(crec_ctx *ctx, const crec_fm *m, int F)
     CREC_REQUIRE(ctx, m->vif.cols % 4 == 0 && m->vif.cols >= 4 && m->vif.cols <= 256,
                  "embed_size %d: need a multiple of 4 in [4, 256]", m->vif.cols);
     CREC_REQUIRE(ctx, m->wi.rows * m->wi.cols == m->vif.rows, "wi and vif must have the same number of features");
-    CREC_REQUIRE(ctx, F >= 1 && F <= FM_MAX_F, "%d features per row: this build holds at most %d", F, FM_MAX_F);
+    CREC_REQUIRE(ctx, F >= 1 && F <= FM_WIDE_F, "%d features per row: this build takes at most %d", F, FM_WIDE_F);
     return CREC_OK;
 }
 

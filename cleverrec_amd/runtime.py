@@ -419,15 +419,52 @@ def ncf_scores(sess, state, users):
     return out
 
 
-def topk_scores(sess, scores, users, seen_ptr, seen_items, K, ascending=False, candidates=False):
-    """crec_topk_scores[_candidates] over a materialised [Bt, I] score matrix -> (ids int32 [Bt,K], scores fp32 [Bt,K])."""
+TOPK_SCORES_MAX_ITEMS = 40000  # crec_topk_scores stages a user's score row in LDS
+_chunk_lists = {}
+
+
+def _topk_scores_call(sess, scores, users, seen_ptr, seen_items, K, ascending, candidates):
     Bt, I = scores.shape
     ids, sc = sess.empty((Bt, K), torch.int32), sess.empty((Bt, K), torch.float32)
     fn = sess.lib.crec_topk_scores_candidates if candidates else sess.lib.crec_topk_scores
     sess.ctx.check(fn(sess.ctx.h, sess.ptr(scores), I, sess.ptr(users), Bt, sess.ptr(seen_ptr),
-                                             sess.ptr(seen_items), int(K), int(bool(ascending)), sess.ptr(ids), sess.ptr(sc),
-                                             sess.stream_ptr()))
+                      sess.ptr(seen_items), int(K), int(bool(ascending)), sess.ptr(ids), sess.ptr(sc),
+                      sess.stream_ptr()))
     return ids, sc
+
+
+def topk_scores(sess, scores, users, seen_ptr, seen_items, K, ascending=False, candidates=False):
+    """crec_topk_scores[_candidates] over a materialised [Bt, I] score matrix -> (ids int32 [Bt,K], scores fp32 [Bt,K]).
+    Catalogues beyond 40 000 items (one score row no longer fits the kernel's LDS stage) are ranked a stretch of the item
+    axis at a time -- the users' lists cut to the stretch -- and the stretches' K best are ranked once more; ties keep going to
+    the lower item id (lower stretch first, and inside a stretch the kernel's own order)."""
+    Bt, I = scores.shape
+    if I <= TOPK_SCORES_MAX_ITEMS:
+        return _topk_scores_call(sess, scores, users, seen_ptr, seen_items, K, ascending, candidates)
+    key = (seen_ptr.data_ptr(), seen_items.data_ptr(), I)
+    if key not in _chunk_lists:  # the lists per stretch, on the host once (CSR by user id, items ascending)
+        ptr, items = seen_ptr.cpu().numpy(), seen_items.cpu().numpy()
+        row = np.repeat(np.arange(len(ptr) - 1), np.diff(ptr))
+        cuts = []
+        for lo in range(0, I, TOPK_SCORES_MAX_ITEMS):
+            hi = min(lo + TOPK_SCORES_MAX_ITEMS, I)
+            m = (items[:len(row)] >= lo) & (items[:len(row)] < hi)
+            p = np.zeros(len(ptr), np.int64)
+            np.cumsum(np.bincount(row[m], minlength=len(ptr) - 1), out=p[1:])
+            it = (items[:len(row)][m] - lo).astype(np.int32)
+            cuts.append((lo, hi, sess.to_dev(p), sess.to_dev(it if len(it) else np.zeros(1, np.int32))))
+        _chunk_lists.clear()
+        _chunk_lists[key] = cuts
+    parts_i, parts_s = [], []
+    for lo, hi, p, it in _chunk_lists[key]:
+        ids, sc = _topk_scores_call(sess, scores[:, lo:hi].contiguous(), users, p, it, K, ascending, candidates)
+        parts_i.append(torch.where(ids >= 0, ids + lo, ids))
+        parts_s.append(sc)
+    cand_ids, cand_sc = torch.cat(parts_i, 1), torch.cat(parts_s, 1).contiguous()  # [Bt, stretches * K], lower ids first among equals
+    none = sess.zeros((int(users.max().item()) + 2,), torch.int64)  # nobody has a list in this round
+    cols, sc = _topk_scores_call(sess, cand_sc, users, none, sess.zeros((1,), torch.int32), K, ascending, False)
+    ids = torch.gather(cand_ids, 1, cols.clamp(min=0).long()).to(torch.int32)
+    return torch.where(cols >= 0, ids, cols), sc
 
 
 class DeviceSampler:

@@ -250,7 +250,7 @@ int crec_ncf_train_epoch(crec_ctx *ctx, const crec_ncf *model, crec_adam *opt, c
  * sigmoid(logits), which ranks identically.  layers[0] <= 256. */
 int crec_ncf_scores(crec_ctx *ctx, const crec_ncf *model, const int32_t *users, int32_t Bt, float *logits, void *stream);
 /* np.argsort + seen filter (model/RankingRecommender.py:221-240) over a materialised score matrix
- * scores [dev] float [Bt, I], I <= 40000; outputs as crec_eval_topk. */
+ * scores [dev] float [Bt, I], I <= 40000 per call (wider matrices: a stretch of the item axis at a time, runtime.topk_scores); outputs as crec_eval_topk. */
 int crec_topk_scores(crec_ctx *ctx, const float *scores, int64_t I, const int32_t *users, int32_t Bt,
                      const int64_t *seen_ptr, const int32_t *seen_items, int32_t K, int32_t ascending, int32_t *topk_ids,
                      float *topk_scores, void *stream);
@@ -270,7 +270,7 @@ int crec_topk_scores_candidates(crec_ctx *ctx, const float *scores, int64_t I, c
  * replaces sess.run([self.train, self.loss, self.y_pre]) / sess.run(self.y_pre) (model/RatingRecommender.py:50,73)
  * on the graph of model/rating/FM.py:20-53, and cal_rmse_mae (utils/metrics.py:22-29).
  *   w0 [1,1] ('fm_params/w0'), wi [N+1,1] ('wi'), vif [N+1,d] ('vif'); reg = configs['reg'].
- *   x_idx int32 [N,F], x_val float [N,F] (is_real_valued), y float [N]; F <= 8; B*F <= 16384.
+ *   x_idx int32 [N,F], x_val float [N,F] (is_real_valued), y float [N]; F <= 64 (beyond 8 the row is walked twice instead of held); B*F <= 16384.
  *   The loss puts l2 on the FULL wi and vif tables (FM.py:52): both take dense ApplyAdam on every row. */
 typedef struct {
     crec_param w0, wi, vif;
@@ -431,7 +431,9 @@ int crec_bpr_train_epoch_sharded(crec_ctx *ctx, const crec_bpr_tables *t, int64_
  *                user's items sorted ascending (empty row = user absent from ui_train)
  *   topk_ids     [dev] int32 [Bt,K], topk_scores [dev] float [Bt,K]: best first; ties by
  *                lower item id; -1 / -inf padding when fewer than K unseen items exist
- *   ascending    0: larger score is better; 1: smaller is better (cml_like, :222-223) */
+ *   ascending    0: larger score is better; 1: smaller is better (cml_like, :222-223)
+ *   K            1 .. 128 (the reference takes any topk, Recommender.py:27); beyond 32 the list is ranked 32 at a time,
+ *                every pass with the ids ranked so far out of the competition (same result as one pass) */
 int crec_eval_topk(crec_ctx *ctx, const float *P, const float *Q, int64_t I, int32_t d, const int32_t *users,
                    int32_t Bt, const int64_t *seen_ptr, const int32_t *seen_items, int32_t K, int32_t ascending,
                    int32_t *topk_ids, float *topk_scores, void *stream);

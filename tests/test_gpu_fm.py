@@ -18,7 +18,7 @@ def sess():
     s.close()
 
 
-@pytest.mark.parametrize("d,F", [(32, 2), (8, 3), (64, 5)])
+@pytest.mark.parametrize("d,F", [(32, 2), (8, 3), (64, 5), (16, 13), (32, 40)])  # beyond 8 features per row: the form that walks them twice
 def test_fm_steps_match_oracle(sess, d, F):
     g = np.random.Generator(np.random.PCG64(d + F))
     n_feat, B, N = 300, 256, 3 * 256 + 100

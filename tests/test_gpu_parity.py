@@ -742,3 +742,21 @@ def test_bpr_embed_size_that_is_no_multiple_of_four(sess, mode):
     assert st.P.shape[1] == 32 and not st.P[:, 30:].any() and not st.Q[:, 30:].any() and not st.mP[:, 30:].any() and not st.vQ[:, 30:].any()
     np.testing.assert_allclose(st.P[:, :30].cpu().numpy(), om.P, rtol=0, atol=2e-6)
     np.testing.assert_allclose(st.Q[:, :30].cpu().numpy(), om.Q, rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("ascending", [False, True])
+def test_topk_of_a_score_matrix_wider_than_the_lds_stage(sess, ascending):
+    """crec_topk_scores (the tower models' and the distance models' ranking step) on 90 001 items: the item axis is ranked a stretch
+    of 40 000 at a time and the stretches' best once more -- ids bit-exact against the oracle's argsort, ties (quantised scores:
+    plenty) to the lower item id"""
+    g = np.random.Generator(np.random.PCG64(4))
+    Bt, I, K = 37, 90001, 20
+    sc = np.round(g.standard_normal((Bt, I)) * 50).astype(np.float32) / 50
+    ptr = np.zeros(Bt + 1, np.int64)
+    rows = [np.sort(g.choice(I, size=int(g.integers(0, 3000)), replace=False)).astype(np.int32) for _ in range(Bt)]
+    np.cumsum([len(r) for r in rows], out=ptr[1:])
+    items = np.concatenate(rows)
+    users = np.arange(Bt, dtype=np.int32)
+    ids, val = runtime.topk_scores(sess, sess.to_dev(sc), sess.to_dev(users), sess.to_dev(ptr), sess.to_dev(items), K, ascending=ascending)
+    oids, oval = oracle.topk(sc, users, ptr, items, K, ascending=ascending)
+    assert np.array_equal(ids.cpu().numpy(), oids) and np.array_equal(val.cpu().numpy(), oval)
