@@ -194,14 +194,14 @@ def main():
     # Nothing may allocate inside the timed region: the library sizes its per-chunk workspaces (index, loss terms,
     # page-locked count buffer) by the number of batches of a call and only ever grows them, so one untimed pass
     # with exactly the calls the timed region will make leaves every buffer at its final size.  Then a time-based
-    # pre-warm (clocks, caches, allocator): at least 0.5 s of the same calls.  Both are reported.
+    # pre-warm (clocks, caches, allocator; and a second of continuous launches a device-side utilisation sampler can see): at least 1 s of the same calls.  Both are reported.
     t_pre = time.perf_counter()
     prewarm_steps = 0
     while True:
         run_steps(a.steps)
         fence()
         prewarm_steps += a.steps
-        more = time.perf_counter() - t_pre < 0.5
+        more = time.perf_counter() - t_pre < 1.0
         if dp:  # the passes are collective: every rank takes rank 0's decision
             flag = torch.tensor([int(more)], dtype=torch.int64, device=sess.device)
             dist.broadcast(flag, src=0)
@@ -466,10 +466,10 @@ def main():
                                              "times), oracle/crec_oracle.c orc_bpr_step (scalar C, tf1 Adam), %.1f s; host has "
                                              "%d cores" % (k, nbe, k / nbe, tc, os.cpu_count())}
             # the reference-STYLE path of SURVEY 8(d): pure-Python sampler loop + vectorised torch-CPU fp32 step (tf1 Adam
-            # sweep) at 1 thread and at all cores, and the argsort / Python-filter evaluation loop -- each on a bounded sample
+            # sweep) at 1, 16 and (at most) 64 threads -- 64: the most a 6144-row operand keeps busy; with all 256 hardware threads of the GPU host one step took 9 s in round 2, and the argsort / Python-filter evaluation loop -- each on a bounded sample
             from oracle import reference_style
             n_all = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-            out["cpu_baseline"]["reference_style"] = reference_style.measure(data, P0, Q0, u, i, j, B, NEG, sorted({1, min(16, n_all), n_all}), budget_s=3.0)
+            out["cpu_baseline"]["reference_style"] = reference_style.measure(data, P0, Q0, u, i, j, B, NEG, sorted({1, min(16, n_all), min(64, n_all)}), budget_s=3.0)
             out["cpu_baseline"]["reference_style"]["note"] = ("TensorFlow 1.x is not installable here: the TF1-CPU path is represented by the same "
                                                               "structure on PyTorch-CPU (oracle/reference_style.py); cores = torch.set_num_threads(n)")
     if rank == 0:

@@ -2322,6 +2322,7 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
         }
     } home{t, &a, &in_shadow, bytesP, bytesQ, st};
     for (int64_t b0 = 0; b0 < nb; b0 += chunk) {
+        const crec_range chunk_range("crec_bpr chunk of batches");
         const int64_t nbc = (nb - b0) < chunk ? (nb - b0) : chunk;
         const int64_t t0 = b0 * B, n_chunk = (N - t0) < nbc * B ? (N - t0) : nbc * B;
         IndexWs w = layout_index(ctx->idx_ws.ptr, nbc, B, t->U, t->I, dense, CH, wide_rows, wide_total, lazy_spw(t->d));
@@ -2621,6 +2622,7 @@ int sharded_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, int64_t I_global
 
     std::vector<int64_t> scnt(G), sdsp(G), rcnt(G), rdsp(G);
     for (int64_t b0 = 0; b0 < nb; b0 += chunk) {
+        const crec_range chunk_range("crec_bpr chunk of batches");
         const int64_t nbc = (nb - b0) < chunk ? (nb - b0) : chunk;
         const int64_t t0 = b0 * B, n_chunk = (N - t0) < nbc * B ? (N - t0) : nbc * B;
         const PlanWs p = plan_layout(ctx->shard_ws.ptr, nbc);

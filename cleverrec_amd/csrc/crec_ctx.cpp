@@ -2,6 +2,8 @@
 #include "crec_internal.h"
 
 #include <cstdlib>
+#include <dlfcn.h>
+#include <mutex>
 
 int crec_fail(crec_ctx *ctx, int code, const char *fmt, ...)
 {
@@ -36,6 +38,43 @@ int crec_reserve(crec_ctx *ctx, crec_devbuf *b, size_t bytes)
 }
 
 static char g_create_err[256] = "no error";
+
+namespace {
+using push_fn = int (*)(const char *);
+using pop_fn = int (*)();
+push_fn g_push = nullptr;
+pop_fn g_pop = nullptr;
+std::once_flag g_roctx_once;
+void load_roctx()
+{
+    const char *v = getenv("CREC_ROCTX");
+    if (!v || !*v || *v == '0')
+        return;
+    for (const char *lib : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so"}) {
+        if (void *h = dlopen(lib, RTLD_NOW | RTLD_LOCAL)) {
+            g_push = (push_fn)dlsym(h, "roctxRangePushA");
+            g_pop = (pop_fn)dlsym(h, "roctxRangePop");
+            if (g_push && g_pop)
+                return;
+            g_push = nullptr, g_pop = nullptr;
+        }
+    }
+}
+} // namespace
+
+crec_range::crec_range(const char *name) : on(false)
+{
+    std::call_once(g_roctx_once, load_roctx);
+    if (g_push && g_pop) {
+        g_push(name);
+        on = true;
+    }
+}
+crec_range::~crec_range()
+{
+    if (on)
+        g_pop();
+}
 
 static hipEvent_t prof_event(crec_ctx *ctx)
 {

@@ -152,3 +152,12 @@ int crec_reserve(crec_ctx *ctx, crec_devbuf *b, size_t bytes);
     } while (0)
 
 static inline int64_t crec_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Named ranges for rocprofv3 --marker-trace around the library's launches (the reference brackets its phases with the `timer`
+// decorator, utils/tools.py:18-28): an epoch's chunks of batches, an evaluation, a sample.  Off unless CREC_ROCTX=1 is in the
+// environment when the first range opens (the roctx library is then loaded with dlopen; without it the ranges are no-ops).
+struct crec_range {
+    explicit crec_range(const char *name);
+    ~crec_range();
+    bool on;
+};

@@ -575,6 +575,7 @@ static int eval_topk_impl(crec_ctx *ctx, const float *P, const float *Q, int64_t
     CREC_REQUIRE(ctx, (((uintptr_t)P | (uintptr_t)Q) & 15) == 0, "table base not 16-byte aligned");
     if (Bt == 0)
         return CREC_OK;
+    const crec_range eval_range(keep_listed ? "crec_eval_topk_candidates" : "crec_eval_topk");
     CREC_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
     // The sweep keeps at most K_MAX = 32 candidates per user on chip.  A longer list (the reference takes any topk,

@@ -1690,6 +1690,7 @@ int make_plan(crec_ctx *ctx, crec_dsampler *s, int nr, hipStream_t st)
 // everything of one sample, enqueued on s->stream
 int enqueue(crec_ctx *ctx, crec_dsampler *s)
 {
+    const crec_range sample_range("crec_dsampler_sample");
     hipStream_t st = s->stream;
     const int nr = s->nr;
     const int64_t n_pos = s->n_pos, n = s->n, n_neg = n_pos * nr;
