@@ -2877,4 +2877,84 @@ int crec_bpr_train_epoch_sharded(crec_ctx *ctx, const crec_bpr_tables *t, int64_
     return sharded_epoch_impl(ctx, t, I_global, opt, u, i, j, N, B, loss_per_batch, stats, stream);
 }
 
+// test hooks: the index kernels of the row-sharded step on ONE batch, to be held against their host form (shard_host.cpp).
+// All array arguments are device pointers except srv_cnt (host).
+int crec_debug_shard_plan(crec_ctx *ctx, const int32_t *i, const int32_t *j, int32_t nb, int32_t G, int64_t I_global, int32_t *req_keys,
+                          int32_t *n_req, int32_t *req_off, int32_t *ci, int32_t *cj, int32_t *ids_send, void *stream)
+{
+    if (!ctx)
+        return CREC_EINVAL;
+    CREC_REQUIRE(ctx, ctx->device >= 0, "host-only ctx: no device bound");
+    CREC_REQUIRE(ctx, i && j && req_keys && n_req && req_off && ci && cj && ids_send, "null argument");
+    CREC_REQUIRE(ctx, nb >= 1 && nb <= MAX_B && G >= 1 && G <= 64 && I_global >= 1, "shape");
+    const int64_t S = crec_ceil_div(I_global, G);
+    CREC_REQUIRE(ctx, (int64_t)G * S < ((int64_t)1 << 31), "item count");
+    CREC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int cap = (2 * nb + 63) / 64 * 64;
+    CREC_HIP(ctx, hipFuncSetAttribute((const void *)shard_plan_batches, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shard_lds_bytes(cap)));
+    hipLaunchKernelGGL(shard_plan_batches, dim3(1), dim3(SHARD_THREADS), shard_lds_bytes(cap), st, i, j, (int64_t)nb, nb, cap, G, S,
+                       row_bits((int64_t)G * S), req_keys, n_req, req_off, ci, cj);
+    std::vector<int32_t> off((size_t)G + 1);
+    CREC_HIP(ctx, hipMemcpyAsync(off.data(), req_off, sizeof(int32_t) * ((size_t)G + 1), hipMemcpyDeviceToHost, st));
+    CREC_HIP(ctx, hipStreamSynchronize(st));
+    std::vector<int64_t> pack((size_t)G);
+    for (int o = 0; o < G; ++o)
+        pack[(size_t)o] = off[(size_t)o]; // one batch: owner o's requests start where its keys start
+    int64_t *d_pack = nullptr;
+    CREC_HIP(ctx, hipMalloc((void **)&d_pack, sizeof(int64_t) * (size_t)G));
+    hipError_t e = hipMemcpyAsync(d_pack, pack.data(), sizeof(int64_t) * (size_t)G, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(shard_pack_ids, dim3(1), dim3(256), 0, st, (const int32_t *)req_keys, (const int32_t *)req_off,
+                           (const int64_t *)d_pack, nb, G, S, ids_send);
+        e = hipStreamSynchronize(st);
+    }
+    (void)hipFree(d_pack);
+    CREC_HIP(ctx, e);
+    CREC_HIP(ctx, hipGetLastError());
+    return CREC_OK;
+}
+
+int crec_debug_shard_owner_index(crec_ctx *ctx, const int32_t *ids_recv, const int32_t *srv_cnt, int32_t G, int64_t S, int32_t *order,
+                                 int32_t *urows, int32_t *useg, int32_t *n_urows, void *stream)
+{
+    if (!ctx)
+        return CREC_EINVAL;
+    CREC_REQUIRE(ctx, ctx->device >= 0, "host-only ctx: no device bound");
+    CREC_REQUIRE(ctx, ids_recv && srv_cnt && order && urows && useg && n_urows, "null argument");
+    CREC_REQUIRE(ctx, G >= 1 && G <= 64 && S >= 1 && S < ((int64_t)1 << 31), "shape");
+    std::vector<int64_t> base((size_t)G);
+    int64_t n = 0;
+    for (int p = 0; p < G; ++p) {
+        CREC_REQUIRE(ctx, srv_cnt[p] >= 0, "negative count");
+        base[(size_t)p] = n;
+        n += srv_cnt[p];
+    }
+    const int64_t stride = (n + 63) / 64 * 64 > 64 ? (n + 63) / 64 * 64 : 64;
+    CREC_REQUIRE(ctx, stride <= 16 * SHARD_THREADS, "the owner-side index sorts at most %d rows per batch", 16 * SHARD_THREADS);
+    CREC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    char *tmp = nullptr;
+    const size_t bytes = 256 + sizeof(int64_t) * (size_t)G + 256 + sizeof(int32_t) * (size_t)G + 256 + sizeof(int32_t) * (size_t)stride;
+    CREC_HIP(ctx, hipMalloc((void **)&tmp, bytes));
+    int64_t *d_base = (int64_t *)tmp;
+    int32_t *d_cnt = (int32_t *)(tmp + align_up(sizeof(int64_t) * (size_t)G, 256));
+    int32_t *d_rows = (int32_t *)((char *)d_cnt + align_up(sizeof(int32_t) * (size_t)G, 256));
+    hipError_t e = hipMemcpyAsync(d_base, base.data(), sizeof(int64_t) * (size_t)G, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(d_cnt, srv_cnt, sizeof(int32_t) * (size_t)G, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void *)shard_owner_index, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shard_lds_bytes((int)stride));
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(shard_owner_index, dim3(1), dim3(SHARD_THREADS), shard_lds_bytes((int)stride), st, ids_recv,
+                           (const int64_t *)d_base, (const int32_t *)d_cnt, G, (int)stride, (int)stride, row_bits(S), d_rows, order, urows,
+                           useg, n_urows);
+        e = hipStreamSynchronize(st);
+    }
+    (void)hipFree(tmp);
+    CREC_HIP(ctx, e);
+    CREC_HIP(ctx, hipGetLastError());
+    return CREC_OK;
+}
+
 } // extern "C"

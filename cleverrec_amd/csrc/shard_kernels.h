@@ -15,6 +15,7 @@
 //   shard_owner_apply    per step: a row's gradient rows, as they came back from the peers, are added in peer order
 //                        and the row takes its lazy Adam update in place.
 #pragma once
+#include "shard_index.h"
 
 constexpr int SHARD_THREADS = 1024;
 
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(SHARD_THREADS) void shard_plan_batches(const int32_
     const int n = 2 * nb;
     for (int k = tid; k < n; k += SHARD_THREADS) {
         const int64_t g = k < nb ? i[t0 + k] : j[t0 + k - nb];
-        rows[k] = (uint32_t)((g % G) * S + g / G);
+        rows[k] = shard_owner_key(g, G, S);
         tag[k] = (uint16_t)k;
     }
     if (tid < 80)
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(SHARD_THREADS) void shard_plan_batches(const int32_
     for (int k = k0; k < k1; ++k) {
         if (k == 0 || rows[k] != rows[k - 1]) {
             keys_out[r] = (int32_t)rows[k];
-            atomicAdd(&per_owner[(int)((int64_t)rows[k] / S)], 1); // counts only: the order of the adds does not matter
+            atomicAdd(&per_owner[shard_key_owner(rows[k], S)], 1); // counts only: the order of the adds does not matter
             ++r;
         }
         const int slot = tag[k]; // every slot learns the rank of its item among the batch's unique items
@@ -95,8 +96,8 @@ __global__ __launch_bounds__(256) void shard_pack_ids(const int32_t *__restrict_
     const int n = off[G];
     for (int q = threadIdx.x; q < n; q += 256) {
         const int64_t key = keys[q];
-        const int o = (int)(key / S);
-        ids_send[pack_off[(int64_t)b * G + o] + (q - off[o])] = (int32_t)(key - o * S);
+        const int o = shard_key_owner(key, S);
+        ids_send[pack_off[(int64_t)b * G + o] + (q - off[o])] = shard_key_row(key, S);
     }
 }
 

@@ -124,6 +124,37 @@ def unshard_items(shards, item_nums):
     return out
 
 
+def plan_batch_host(i, j, world, item_nums):
+    """crec_shard_plan_host: one batch's index work on the host, with the arithmetic and the orders of the device kernels
+    (shard_plan_batches + shard_pack_ids).  -> (req_keys [n_req], req_off [G+1], ci [nb], cj [nb], ids_send [n_req])"""
+    lib = _lib.load()
+    i, j = np.ascontiguousarray(i, np.int32), np.ascontiguousarray(j, np.int32)
+    nb = len(i)
+    keys, ids = np.empty(max(2 * nb, 1), np.int32), np.empty(max(2 * nb, 1), np.int32)
+    off, ci, cj = np.empty(world + 1, np.int32), np.empty(max(nb, 1), np.int32), np.empty(max(nb, 1), np.int32)
+    n = C.c_int32(0)
+    rc = lib.crec_shard_plan_host(_lib._np(i), _lib._np(j), nb, int(world), int(item_nums), _lib._np(keys), C.byref(n), _lib._np(off),
+                                  _lib._np(ci), _lib._np(cj), _lib._np(ids))
+    if rc != _lib.OK:
+        raise _lib.CrecError(rc, "crec_shard_plan_host")
+    return keys[:n.value], off, ci[:nb], cj[:nb], ids[:n.value]
+
+
+def owner_index_host(ids_recv, srv_cnt):
+    """crec_shard_owner_index_host: the rows the peers ask of this owner in one batch (peer after peer) -> (order [n]: the
+    slots sorted by row, peers in rank order within a row; urows [q]; useg [q+1]: where every row's slots start in order)"""
+    lib = _lib.load()
+    ids_recv, srv_cnt = np.ascontiguousarray(ids_recv, np.int32), np.ascontiguousarray(srv_cnt, np.int32)
+    n = int(srv_cnt.sum())
+    order, urows, useg = np.empty(max(n, 1), np.int32), np.empty(max(n, 1), np.int32), np.empty(n + 1, np.int32)
+    q = C.c_int32(0)
+    rc = lib.crec_shard_owner_index_host(_lib._np(ids_recv), _lib._np(srv_cnt), len(srv_cnt), _lib._np(order), _lib._np(urows),
+                                         _lib._np(useg), C.byref(q))
+    if rc != _lib.OK:
+        raise _lib.CrecError(rc, "crec_shard_owner_index_host")
+    return order[:n], urows[:q.value], useg[:q.value + 1]
+
+
 class ShardedBprState(BprState):
     """P0: this rank's user rows; Q_shard: this rank's item shard (shard_items); item_nums: the global catalogue size.
     The communicator (init_rccl / init_local_group; none = a world of one) must exist before the first epoch."""

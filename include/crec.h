@@ -422,6 +422,22 @@ int crec_comm_init_local(crec_ctx **ctxs, int world);
 int crec_bpr_train_epoch_sharded(crec_ctx *ctx, const crec_bpr_tables *t, int64_t I_global, crec_adam *opt, const int32_t *u,
                                  const int32_t *i, const int32_t *j, int64_t N, int32_t B, float *loss_per_batch,
                                  crec_shard_stats *stats, void *stream);
+/* The index work of that step for ONE batch, twice: the host form (csrc/shard_host.cpp: the planner the multi-process CPU
+ * tests run over gloo, all pointers host) and, as test hooks, the device kernels the epoch launches (all pointers device except
+ * srv_cnt) -- the GPU tests hold the second to the first.
+ *   i, j [nb] global item ids -> req_keys [<= 2 nb] the batch's unique owner-major keys (g % G) * S + g / G ascending,
+ *   n_req their number, req_off [G+1] where every owner's keys start, ci / cj [nb] every slot's rank in that list (its row
+ *   of the compact table), ids_send [n_req] the request lists as local row ids, owner after owner.
+ *   ids_recv: the peers' request lists, peer after peer (srv_cnt [G] rows each) -> order [n] the slots sorted by row
+ *   (stable: peers in rank order), urows / useg [n_urows (+1)] the unique rows and where their slots start in `order`. */
+int crec_shard_plan_host(const int32_t *i, const int32_t *j, int32_t nb, int32_t G, int64_t I_global, int32_t *req_keys, int32_t *n_req,
+                         int32_t *req_off, int32_t *ci, int32_t *cj, int32_t *ids_send);
+int crec_shard_owner_index_host(const int32_t *ids_recv, const int32_t *srv_cnt, int32_t G, int32_t *order, int32_t *urows, int32_t *useg,
+                                int32_t *n_urows);
+int crec_debug_shard_plan(crec_ctx *ctx, const int32_t *i, const int32_t *j, int32_t nb, int32_t G, int64_t I_global, int32_t *req_keys,
+                          int32_t *n_req, int32_t *req_off, int32_t *ci, int32_t *cj, int32_t *ids_send, void *stream);
+int crec_debug_shard_owner_index(crec_ctx *ctx, const int32_t *ids_recv, const int32_t *srv_cnt, int32_t G, int64_t S, int32_t *order,
+                                 int32_t *urows, int32_t *useg, int32_t *n_urows, void *stream);
 
 /* ---- full-catalogue evaluation (device) -------------------------------------------------
  * replaces sess.run(self.pre_scores) (BPR._predict rs branch, BPR.py:51) + np.argsort +

@@ -36,18 +36,23 @@ def _a2a(send, scnt, rcnt, width, dtype):
 class ShardedRank:
     """One rank's state: P_local [U_loc, d], Q_shard [S, d] with Adam slots; lr schedule shared by construction."""
 
-    def __init__(self, P_local, Q_shard, item_nums, lr=1e-3, reg=0.01):
+    def __init__(self, P_local, Q_shard, item_nums, lr=1e-3, reg=0.01, planner=None):
         self.G, self.rank = dist.get_world_size(), dist.get_rank()
         self.S = -(-int(item_nums) // self.G)
+        self.item_nums, self.planner = int(item_nums), planner
         self.user = O.BprModel(P_local, np.zeros((1, P_local.shape[1]), np.float32), lr=lr, reg=reg, adam_mode=1)
         self.item = O.BprModel(np.zeros((1, P_local.shape[1]), np.float32), Q_shard, lr=lr, reg=reg, adam_mode=1)
 
     def step(self, u, i, j):
         G, S, d = self.G, self.S, self.user.P.shape[1]
-        keys, off, ci, cj = plan(i, j, G, S)
+        if self.planner is None:
+            keys, off, ci, cj = plan(i, j, G, S)
+            local = (keys - (keys // S) * S).astype(np.int64)
+        else:
+            keys, off, ci, cj, local = self.planner.plan(i, j, G, self.item_nums)
+            off, local = off.astype(np.int64), local.astype(np.int64)
         cnt = np.diff(off)
         srv_cnt = _a2a(cnt, [1] * G, [1] * G, 0, torch.int64)                      # how many rows every peer asks of me
-        local = (keys - (keys // S) * S).astype(np.int64)
         srv_rows = _a2a(local, cnt, srv_cnt, 0, torch.int64)                       # which rows, peer-major
         Qc = _a2a(self.item.Q[srv_rows], srv_cnt, cnt, d, torch.float32)           # forward: my compact table
         lr_t = float(self.item.sched.next(1)[0])
@@ -56,8 +61,16 @@ class ShardedRank:
         dQc, cQ, loss = O.bpr_shard_local(m, u, ci, cj, lr_t)
         grads = _a2a(dQc, cnt, srv_cnt, d, torch.float32)                          # back: one row per (peer, requested row)
         g, touched = np.zeros_like(self.item.Q), np.zeros(len(self.item.Q), np.int32)
+        if self.planner is not None:                                               # the owner's index as the library builds it
+            order, urows, useg = self.planner.owner_index(srv_rows, srv_cnt)
+            for q, row in enumerate(urows):
+                acc = np.zeros(d, np.float32)
+                for k in range(useg[q], useg[q + 1]):                              # slot (= peer) order
+                    acc = acc + grads[order[k]]
+                g[row], touched[row] = acc, 1
+            srv_cnt = []
         at = 0
-        for p in range(G):                                                         # peer order
+        for p in range(len(srv_cnt)):                                              # peer order
             rows = srv_rows[at:at + int(srv_cnt[p])]
             first = touched[rows] == 0
             g[rows[first]] = grads[at:at + int(srv_cnt[p])][first]                 # 0 + x == x exactly

@@ -266,7 +266,7 @@ def test_sharded_at_a_million_items():
     batch names takes no part in the row-sharded step); every other row of Q must keep its bits."""
     U, I, B, d, G = 20000, 1_000_003, 6144, 128, 2
     P0, Q0 = _tables(12, U, I, d)
-    streams, ranges = _streams(13, U, I, G, [2 * B + 50, 2 * B])
+    streams, ranges = _streams(13, U, I, G, [2 * B + 50, 2 * B + 1])  # ragged last batches, both ranks 3 batches (the epoch is collective)
     P, Q, loss, stats = _run_sharded(G, P0, Q0, ranges, streams, B, d)
     qq = np.unique(np.concatenate([np.concatenate([i, j]) for _, i, j in streams]))
     compact = [(u, np.searchsorted(qq, i).astype(np.int32), np.searchsorted(qq, j).astype(np.int32)) for u, i, j in streams]
@@ -279,3 +279,45 @@ def test_sharded_at_a_million_items():
     untouched[qq] = False
     assert np.array_equal(Q[untouched], Q0[untouched])
     assert sum(s["rows_requested"] for s in stats) == sum(s["rows_served"] for s in stats) > 0
+
+
+@pytest.mark.parametrize("G,I,nb", [(1, 53, 64), (2, 53, 64), (4, 1_000_003, 6144), (8, 1_000_003, 8192), (3, 4099, 1), (8, 40, 777)])
+def test_index_kernels_equal_the_host_planner(G, I, nb):
+    """shard_plan_batches + shard_pack_ids and shard_owner_index (what the epoch launches) against csrc/shard_host.cpp (what the
+    multi-process gloo test runs as every rank's planner, tests/test_parallel_cpu.py): bit for bit, every output."""
+    import ctypes as C
+    sess = runtime.Session(0)
+    g = np.random.Generator(np.random.PCG64(G * 1000 + nb))
+    i = np.minimum(g.zipf(1.2, nb) - 1, I - 1).astype(np.int32)
+    j = g.integers(0, I, nb).astype(np.int32)
+    keys, off, ci, cj, ids = parallel.plan_batch_host(i, j, G, I)
+    d_keys, d_ids = sess.zeros(2 * nb, torch.int32), sess.zeros(2 * nb, torch.int32)
+    d_n, d_off = sess.zeros(1, torch.int32), sess.zeros(G + 1, torch.int32)
+    d_ci, d_cj = sess.zeros(nb, torch.int32), sess.zeros(nb, torch.int32)
+    p = sess.ptr
+    d_i, d_j = sess.to_dev(i), sess.to_dev(j)
+    sess.ctx.check(sess.lib.crec_debug_shard_plan(sess.ctx.h, p(d_i), p(d_j), nb, G, I, p(d_keys), p(d_n), p(d_off),
+                                                  p(d_ci), p(d_cj), p(d_ids), sess.stream_ptr()))
+    n = int(d_n.cpu()[0])
+    assert n == len(keys)
+    assert np.array_equal(d_keys.cpu().numpy()[:n], keys) and np.array_equal(d_off.cpu().numpy(), off)
+    assert np.array_equal(d_ci.cpu().numpy(), ci) and np.array_equal(d_cj.cpu().numpy(), cj)
+    assert np.array_equal(d_ids.cpu().numpy()[:n], ids)
+    # the compact ids name the right rows: keys[ci] is the owner-major key of i
+    S = parallel.shard_rows(I, G)
+    assert np.array_equal(keys[ci], (i.astype(np.int64) % G) * S + i // G)
+
+    # owner side: every peer's request list is a sorted list of unique rows of this shard
+    cnt = g.integers(0, min(S, 2 * nb // G) + 1, G).astype(np.int32)
+    recv = np.concatenate([np.sort(g.choice(S, int(c), replace=False)) for c in cnt]).astype(np.int32) if cnt.sum() else np.zeros(0, np.int32)
+    order, urows, useg = parallel.owner_index_host(recv, cnt)
+    tot = int(cnt.sum())
+    d_order, d_urows, d_useg, d_q = (sess.zeros(tot + 64, torch.int32) for _ in range(4))
+    d_recv = sess.to_dev(recv) if tot else d_q
+    sess.ctx.check(sess.lib.crec_debug_shard_owner_index(sess.ctx.h, p(d_recv), cnt.ctypes.data_as(C.c_void_p), G, S,
+                                                         p(d_order), p(d_urows), p(d_useg), p(d_q), sess.stream_ptr()))
+    q = int(d_q.cpu()[0])
+    assert q == len(urows)
+    assert np.array_equal(d_order.cpu().numpy()[:tot], order)
+    assert np.array_equal(d_urows.cpu().numpy()[:q], urows) and np.array_equal(d_useg.cpu().numpy()[:q + 1], useg)
+    sess.close()

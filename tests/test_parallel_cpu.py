@@ -125,7 +125,13 @@ def test_exchange_scheme_two_ranks_gloo():
     assert out.get(timeout=5) == "ok"
 
 
-def _shard_worker(rank, world, port, out):
+class _LibPlanner:
+    """the product's host planner (libcrec.so: csrc/shard_host.cpp, same arithmetic and orders as the device kernels)"""
+    plan = staticmethod(parallel.plan_batch_host)
+    owner_index = staticmethod(parallel.owner_index_host)
+
+
+def _shard_worker(rank, world, port, out, use_lib):
     """The row-sharded exchange (include/crec.h "row-sharded training") as real multi-process all-to-all-v over gloo:
     every rank holds ONLY its user rows and its item shard (oracle/shard_protocol.py); the result must equal, bit for
     bit, the single-process restatement of the sharded arithmetic (oracle.sharded_steps: per-rank sums, then rank
@@ -145,7 +151,8 @@ def _shard_worker(rank, world, port, out):
             streams.append((g.integers(0, hi - lo, n).astype(np.int32), np.minimum(g.zipf(1.5, n) - 1, I - 1).astype(np.int32),
                             g.integers(0, I, n).astype(np.int32)))
         lo, hi = ranges[rank]
-        me = SP.ShardedRank(P0[lo:hi], parallel.shard_items(Q0, rank, world), I, lr=1e-2, reg=0.01)
+        me = SP.ShardedRank(P0[lo:hi], parallel.shard_items(Q0, rank, world), I, lr=1e-2, reg=0.01,
+                            planner=_LibPlanner if use_lib else None)
         u, i, j = streams[rank]
         losses = [me.step(u[b * B:(b + 1) * B], i[b * B:(b + 1) * B], j[b * B:(b + 1) * B]) for b in range(steps)]
         gathered = [None] * world
@@ -168,12 +175,13 @@ def _shard_worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("use_lib", [True, False], ids=["library-planner", "numpy-planner"])
 @pytest.mark.parametrize("world", [2, 4])
-def test_sharded_exchange_protocol_gloo(world):
+def test_sharded_exchange_protocol_gloo(world, use_lib):
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, out)) for r in range(world)]
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, out, use_lib)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
