@@ -128,14 +128,40 @@ def main():
     if a.dry_launch:
         sys.exit(dry_rank(real_stdout))
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # N > 1: which transport carries the exchanges (CREC_TRANSPORT = auto | peer | rccl).  The peer transport (IPC windows, one
+    # kernel per exchange, csrc/crec_peer.hip) is the fast one, but it reads other GPUs' memory from kernels of this process: it is
+    # first proven between THESE GPUs by a canary in child processes (tools/micro/peer_canary.py: every exchange bit for bit, then
+    # timings) -- started before this process touches the GPU.  Only if every rank's canary passed does the run use it; else RCCL.
+    want_transport = os.environ.get("CREC_TRANSPORT", "auto")
+    canary = None
+    if world > 1 and want_transport in ("auto", "peer"):
+        import subprocess
+        env = dict(os.environ, MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29511")) + 1))
+        for form in ("0", "1"):  # written-through system-scope accesses first, then the fence form (csrc/crec_peer.hip)
+            try:
+                cp = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "micro", "peer_canary.py")], env=dict(env, CREC_PEER_FENCES=form, MASTER_PORT=str(int(env["MASTER_PORT"]) + int(form))),
+                                    stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+                canary = {"rc": cp.returncode, "fences": form == "1"}
+                lines = [ln for ln in cp.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+                if lines:
+                    canary.update(json.loads(lines[-1]))
+                if cp.returncode != 0:
+                    canary["stderr_tail"] = cp.stderr.decode(errors="replace")[-400:]
+            except Exception as e:  # noqa: BLE001  (a canary that hangs or cannot start: RCCL it is)
+                canary = {"rc": -1, "error": repr(e)}
+            # every rank's canary belongs to one group and rank 0 of it gathers the verdict: all ranks see the same exit code
+            if canary["rc"] == 0:
+                os.environ["CREC_PEER_FENCES"] = form
+                break
+
     import torch
     import torch.distributed as dist
     from cleverrec_amd import runtime
     from cleverrec_amd.data import synthetic
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     force_dp = os.environ.get("CREC_FORCE_DP") == "1"  # rehearse the N > 1 code path on one GPU
     if world > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -153,10 +179,15 @@ def main():
     P0 = torch.empty(data.user_nums, D).normal_(0, 0.01, generator=torch.Generator().manual_seed(1000 + rank)).numpy()
     Q0 = torch.empty(3706, D).normal_(0, 0.01, generator=torch.Generator().manual_seed(0)).numpy()[:data.item_nums]
     dp = world > 1 or force_dp
+    transport = "rccl"
     if dp:
         from cleverrec_amd.parallel import DpBprState, agree_min
         assert agree_min(data.item_nums) == data.item_nums == -agree_min(-data.item_nums), "replicas need one catalogue"
-        st = DpBprState(sess, P0, Q0, lr=LR, reg=REG)
+        if world > 1 and want_transport != "rccl" and agree_min(1 if canary and canary.get("rc") == 0 else 0) == 1:
+            transport = "peer"
+        elif os.environ.get("CREC_TRANSPORT") == "peer" and world == 1:
+            transport = "peer"  # (one rank: rehearses the code path, like CREC_FORCE_DP)
+        st = DpBprState(sess, P0, Q0, lr=LR, reg=REG, transport=transport)
     else:
         st = runtime.BprState(sess, P0, Q0, lr=LR, reg=REG, adam_mode="tf1")
 
@@ -254,8 +285,13 @@ def main():
         "config": {"workload": "BPR on S-ml1m (6040x3706, 1,000,208 interactions, ml-1m marginals), d=64 fp32, "
                                "batch 6144, neg_ratio 4, Adam tf1 semantics (BASELINE.json configs[1])",
                    "users": data.user_nums, "items": data.item_nums, "embed_size": D, "batch_size": B,
-                   "neg_ratio": NEG, "adam_mode": "tf1", "sharding": "users sharded (one S-ml1m user shard per GPU), Q replicated, 1 RCCL all-reduce of dQ per step" if world > 1 else "none"},
+                   "neg_ratio": NEG, "adam_mode": "tf1", "sharding": ("users sharded (one S-ml1m user shard per GPU), Q replicated, 1 all-reduce of dQ per step over %s"
+                                                     % ("the peer windows (xGMI loads from one kernel per exchange)" if transport == "peer" else "RCCL")) if dp else "none"},
     }
+    if dp:
+        out["transport"] = transport
+        if canary is not None:
+            out["peer_canary"] = canary
 
     prof = None
     if not a.no_extras:

@@ -130,6 +130,14 @@ _SIGNATURES = {
     "crec_comm_init_local": (C.c_int, [C.POINTER(_vp), C.c_int]),
     "crec_bpr_train_epoch_sharded": (C.c_int, [_vp, C.POINTER(BprTables), _i64, C.POINTER(Adam), _vp, _vp, _vp, _i64, _i32, _vp,
                                                C.POINTER(ShardStats), _vp]),
+    "crec_comm_peer_create": (C.c_int, [_vp, _i64, _vp]),
+    "crec_comm_peer_connect": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
+    "crec_comm_peer_connect_local": (C.c_int, [C.POINTER(_vp), C.c_int, _i64]),
+    "crec_comm_set_timeout": (C.c_int, [_vp, C.c_double]),
+    "crec_comm_peer_fences": (C.c_int, [_vp, C.c_int]),
+    "crec_comm_status": (C.c_int, [_vp, _vp]),
+    "crec_debug_alltoallv": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "crec_debug_allreduce": (C.c_int, [_vp, _vp, _i64, _vp]),
     "crec_shard_plan_host": (C.c_int, [_vp, _vp, _i32, _i32, _i64, _vp, C.POINTER(_i32), _vp, _vp, _vp, _vp]),
     "crec_shard_owner_index_host": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, C.POINTER(_i32)]),
     "crec_debug_shard_plan": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -2197,10 +2197,13 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
     CREC_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
     const bool dense = opt->adam_mode == CREC_ADAM_TF1;
-    ncclComm_t comm = (ncclComm_t)ctx->comm;
+    crec_xch *xdp = nullptr; // the data-parallel step's all-reduces go through the ctx's transport (RCCL or the peer windows)
     if (dp) {
-        CREC_REQUIRE(ctx, comm != nullptr, "crec_comm_init has not been called on this ctx");
+        CREC_REQUIRE(ctx, ctx->comm != nullptr || ctx->xch != nullptr, "crec_comm_init (or crec_comm_peer_connect) has not been called on this ctx");
         CREC_REQUIRE(ctx, dense, "the data-parallel step is built for adam_mode tf1");
+        xdp = crec_xch_of(ctx);
+        CREC_REQUIRE(ctx, (int64_t)t->I * t->d * 4 <= xdp->max_bytes(), "the transport's window is too small for the all-reduce of dQ (%lld bytes)",
+                     (long long)t->I * t->d * 4);
     }
     StepFn step = pick_step(t->d, dense);
     const int64_t nb = crec_ceil_div(N, B);
@@ -2424,8 +2427,8 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
                 // the one exchange of the path: per-item gradient sums over all ranks' triples
                 float *dq = (float *)ctx->dq.ptr;
                 const size_t nq = (size_t)t->I * t->d;
-                if (ncclAllReduce(dq, dq, nq, ncclFloat, ncclSum, comm, st) != ncclSuccess)
-                    return crec_fail(ctx, CREC_EHIP, "ncclAllReduce(dQ) failed");
+                if (int rc = xdp->allreduce_sum_f32(ctx, dq, nq, st))
+                    return rc;
                 crec_prof_begin(ctx, CREC_K_ADAM_DENSE, st);
                 const int64_t n4 = (int64_t)nq / 4;
                 const unsigned blocks = (unsigned)(crec_ceil_div(n4, 256) < 2048 ? crec_ceil_div(n4, 256) : 2048);
@@ -2448,9 +2451,12 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
                            loss_stride, n_chunk, B, dense ? t->U + t->I : (int64_t)0, (const int32_t *)w.n_u,
                            (const int32_t *)w.n_q, opt->reg, loss_per_batch + b0);
         crec_prof_end(ctx, st);
-        if (dp && ncclAllReduce(loss_per_batch + b0, loss_per_batch + b0, (size_t)nbc, ncclFloat, ncclSum, comm, st) !=
-                      ncclSuccess)
-            return crec_fail(ctx, CREC_EHIP, "ncclAllReduce(loss) failed");
+        if (dp) {
+            if (int rc = xdp->allreduce_sum_f32(ctx, loss_per_batch + b0, (size_t)nbc, st))
+                return rc;
+            if (int rc = xdp->status(ctx, st)) // (a transport that waits on its peers inside kernels reports a peer that never came here)
+                return rc;
+        }
         CREC_HIP(ctx, hipGetLastError());
         if (int rc = crec_prof_flush(ctx, st))
             return rc;
@@ -2518,6 +2524,12 @@ int sharded_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, int64_t I_global
     int64_t chunk = (int64_t)((size_t)1 << 30) / (int64_t)per_batch;
     chunk = chunk < 1 ? 1 : (chunk > 1024 ? 1024 : chunk);
     chunk = chunk > nb ? nb : chunk;
+    // a transport that stages a rank's payload (the peer windows) bounds what one exchange carries: per step the rows of a batch,
+    // per chunk the request lists of its batches (every rank holds the same B, d and window, so every rank cuts the same chunks)
+    CREC_REQUIRE(ctx, IC * d * 4 + 16 * G <= x->max_bytes(), "the transport's window is too small for a batch's rows (%lld bytes)", (long long)IC * d * 4);
+    if (chunk * (IC * 4 + 4 * G + 16) + 16 * G > x->max_bytes())
+        chunk = (x->max_bytes() - 16 * G) / (IC * 4 + 4 * G + 16);
+    chunk = chunk < 1 ? 1 : chunk;
     if (int rc = crec_reserve(ctx, &ctx->idx_ws, layout_index(nullptr, chunk, B, t->U, IC, false, CH).bytes))
         return rc;
     const int64_t loss_stride = 2 * (int64_t)B; // x_b, then the l2 term of every triple
@@ -2657,6 +2669,8 @@ int sharded_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, int64_t I_global
         if (int rc = x->alltoallv(ctx, p.cnt_send, scnt.data(), sdsp.data(), p.cnt_recv, rcnt.data(), rdsp.data(), 4, st))
             return rc;
         CREC_HIP(ctx, hipMemcpyAsync(h_cnt_recv, p.cnt_recv, sizeof(int32_t) * (size_t)nbc * G, hipMemcpyDeviceToHost, st));
+        if (int rc = x->status(ctx, st)) // the counts steer the host from here on: a peer that never delivered them is an error now
+            return rc;
         CREC_HIP(ctx, hipStreamSynchronize(st));
         // 3. where everything goes: owner-major packing of my requests, peer-major layout of what I serve
         int64_t at = 0, total_srv = 0, stride = 64;
@@ -2793,6 +2807,8 @@ int sharded_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, int64_t I_global
                      n_chunk, B, (int64_t)0, (const int32_t *)w.n_u, (const int32_t *)w.n_q, opt->reg, loss_per_batch + b0);
         crec_prof_end(ctx, st);
         if (int rc = x->allreduce_sum_f32(ctx, loss_per_batch + b0, (size_t)nbc, st))
+            return rc;
+        if (int rc = x->status(ctx, st))
             return rc;
         CREC_HIP(ctx, hipGetLastError());
         if (int rc = crec_prof_flush(ctx, st))

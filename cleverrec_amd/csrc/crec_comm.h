@@ -6,8 +6,11 @@
 // traffic pattern xGMI is good at (a full mesh: every pair of GPUs has its own link, so the G-1 segments of a rank
 // leave on G-1 links at once), unlike a ring all-reduce of a dense table, which is bound by one link.
 //
-// Two transports behind one interface:
+// Three transports behind one interface:
 //   RCCL   one process per GPU (the production layout): grouped ncclSend / ncclRecv on the launch stream.
+//   peer   one process per GPU (or the ctxs of one process): every rank maps every other rank's window (HIP IPC) and ONE kernel
+//          per exchange publishes, waits on flags and reads the peers' segments over xGMI (crec_peer.hip); chosen with
+//          crec_comm_peer_create / _connect -- microseconds per exchange where a grouped send / recv costs tens.
 //   local  the ranks are ctxs of ONE process, each driven by its own host thread (one per GPU of a node, or -- in
 //          the tests -- several ranks on one GPU): device-to-device copies between the ranks' buffers, host barriers.
 // A ctx without a communicator is a world of one: the exchange is a device copy on the stream.
@@ -22,6 +25,10 @@ struct crec_xch {
     virtual int alltoallv(crec_ctx *ctx, const void *send, const int64_t *scnt, const int64_t *sdsp, void *recv,
                           const int64_t *rcnt, const int64_t *rdsp, int elem_bytes, hipStream_t st) = 0;
     virtual int allreduce_sum_f32(crec_ctx *ctx, float *buf, size_t n, hipStream_t st) = 0;
+    // the largest payload a rank may hand to one exchange (the peer transport stages it in half of its window)
+    virtual int64_t max_bytes() const { return INT64_MAX; }
+    // errors a transport only learns about asynchronously (the peer transport's waits give up after a time-out); synchronises st
+    virtual int status(crec_ctx *, hipStream_t) { return CREC_OK; }
 };
 
 // the ctx's exchange object: its local group, else RCCL (crec_comm_init), else the world-of-one copy

@@ -1,0 +1,553 @@
+// Peer transport of the exchange layer (crec_comm.h): the ranks' payloads cross xGMI as plain loads issued by ONE kernel per
+// exchange, through windows every rank maps from every other rank (HIP IPC, one process per GPU; or raw pointers when the
+// ranks are ctxs of one process) -- no proxy thread, no staging through a library's FIFO, no host round trip.
+//
+// Why: the row-sharded step has two dependent exchanges per batch and the replicated-Q step one all-reduce per ~8 us of
+// compute; a grouped ncclSend / ncclRecv costs tens of microseconds whatever it carries, a launch that waits on seven
+// flags and then reads seven segments costs a launch plus one xGMI round trip.  RCCL stays the portable transport (and the
+// one that carries the unique id / handles at start-up); this one is chosen with crec_comm_peer_*.
+//
+// Protocol (pull): every rank owns a WINDOW (device memory, two halves used alternately) and a block of SIGNAL words
+// (uncached device memory, [2 parities][2 phases][PEER_MAX] x 64 bit).  Exchange number n (counted per communicator, the same on every rank
+// because exchanges are collective and stream-ordered) uses half n & 1:
+//   1. copy-in   my segments for all peers -> my window half, back to back (16-byte aligned starts)
+//   2. publish   when the LAST workgroup of the launch has finished its part of the copy (device-scope counter; the window
+//                stores are written through at system scope and waited for, see copy_bytes) it stores {n, segment offset} into signal [n & 1][my rank] of every peer
+//   3. pull      every workgroup waits for signal [n & 1][p] == n of every source p in its OWN signal block (local, uncached),
+//                then reads its share of p's window half at the published offset straight into the receive buffer
+//   all-reduce   same publish; every rank then reads all G operands and adds them in rank order (bit-identical sums
+//                on every rank, which the replicated-Q step relies on)
+// A window half is rewritten at exchange n + 2.  Safe: a peer publishes n + 1 only after its launch n has ended (stream
+// order) -- pull included --, and my launch n + 1 waits for every peer's n + 1 before my launch n + 2 can start.  Nobody
+// waits in step 1-2, so the waits of step 3 always end; they give up after `timeout` (20 s by default: ranks are only
+// loosely in step, a peer may be allocating or planning on its host) and the communicator then reports the error.
+#include "crec_comm.h"
+
+#include <unistd.h>
+
+namespace {
+
+constexpr int PEER_MAX = 16;
+constexpr int PEER_THREADS = 512;
+constexpr int PEER_MAX_BLOCKS = 128; // half a wave slot per SIMD of half the CUs: always resident together, beside whatever else runs
+
+struct PeerArgs {
+    const char *win[PEER_MAX];                  // rank p's window as this process sees it
+    unsigned long long *sig[PEER_MAX];          // rank p's signal block as this process sees it
+    int64_t s_off[PEER_MAX], s_bytes[PEER_MAX]; // my segment for p inside `send`
+    int64_t w_off[PEER_MAX];                    // ... and where it lies inside my window half
+    int64_t r_off[PEER_MAX], r_bytes[PEER_MAX]; // what p sends me, inside `recv`
+};
+
+// Window traffic, two forms.  Default: every store into a window and every load from one is a SYSTEM-scope access (sc0 sc1: written
+// through to memory / served from memory, as the compiler's own system-scope atomics are -- here 16 bytes at a time), so publishing
+// needs no L2 write-back and reading no L2 invalidate: a wave waits for its stores (s_waitcnt vmcnt(0)) before the counter that leads
+// to the flag.  FENCES (crec_comm_set_option "peer_fences", bench: CREC_PEER_FENCES=1): plain accesses bracketed by system-scope
+// release / acquire fences issued by ONE wave per workgroup behind a barrier -- the textbook form, kept selectable at run time; a
+// fence by every wave costs a full L2 write-back each (measured: 250 us for a 5 MB exchange).
+typedef unsigned peer_u4v __attribute__((ext_vector_type(4)));
+constexpr int AUX_SYS = 17; // sc0 | sc1
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void *base)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0x7fffffff, 0x00020000);
+}
+// dst / src: wave-uniform bases (< 2 GiB behind them); WIN_DST / WIN_SRC: which side is a window
+template <bool WIN_DST, bool WIN_SRC>
+__device__ __forceinline__ void copy_bytes(char *dst, const char *src, int64_t bytes, int64_t tid, int64_t nth, bool fences)
+{
+    const __amdgpu_buffer_rsrc_t rd = rsrc_of(dst), rs = rsrc_of(src);
+    if ((((uintptr_t)dst | (uintptr_t)src | (uintptr_t)bytes) & 15) == 0) {
+        const int64_t n = bytes >> 4;
+        for (int64_t k = tid; k < n; k += nth) {
+            peer_u4v v;
+            if (WIN_SRC && !fences)
+                v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(k << 4), 0, AUX_SYS);
+            else
+                v = ((const peer_u4v *)src)[k];
+            if (WIN_DST && !fences)
+                __builtin_amdgcn_raw_buffer_store_b128(v, rd, (int)(k << 4), 0, AUX_SYS);
+            else
+                ((peer_u4v *)dst)[k] = v;
+        }
+    } else { // 4-byte elements
+        const int64_t n = bytes >> 2;
+        for (int64_t k = tid; k < n; k += nth) {
+            unsigned v;
+            if (WIN_SRC && !fences)
+                v = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(k << 2), 0, AUX_SYS);
+            else
+                v = ((const unsigned *)src)[k];
+            if (WIN_DST && !fences)
+                __builtin_amdgcn_raw_buffer_store_b32(v, rd, (int)(k << 2), 0, AUX_SYS);
+            else
+                ((unsigned *)dst)[k] = v;
+        }
+    }
+}
+
+// mode bit 0: all-reduce of n floats (send = recv = the operand), else all-to-all-v; bit 1: FENCES; bit 2: the all-reduce in two shots.  Every workgroup takes its
+// grid-stride share of the copy-in and of every source's segment; at most PEER_MAX_BLOCKS workgroups, so that all of them are
+// resident at once (a workgroup that waits for a peer must not keep one of its own launch -- whose copy-in the peers wait for -- off
+// the machine).
+__global__ __launch_bounds__(PEER_THREADS) void peer_exchange(PeerArgs a, const char *__restrict__ send, char *__restrict__ recv,
+                                                              char *my_half, int64_t half_off, uint32_t seq, int rank, int world, int mode,
+                                                              int64_t n, unsigned long long timeout_ticks, int32_t *ctr, int32_t *err)
+{
+    __shared__ unsigned long long flag_s[PEER_MAX];
+    __shared__ int last_s, bad_s;
+    const bool reduce = mode & 1, fences = mode & 2;
+    const int tid = threadIdx.x, h = (int)(seq & 1u);
+    const int64_t gtid = (int64_t)blockIdx.x * PEER_THREADS + tid, gsz = (int64_t)gridDim.x * PEER_THREADS;
+    // 1. copy-in
+    for (int p = 0; p < (reduce ? 1 : world); ++p)
+        if (a.s_bytes[p] > 0)
+            copy_bytes<true, false>(my_half + a.w_off[p], send + a.s_off[p], a.s_bytes[p], gtid, gsz, fences);
+    // 2. publish, by the workgroup that finishes last
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's window stores are where the peers will read them (write-through form)
+    __syncthreads();
+    if (tid == 0) {
+        if (fences)
+            __threadfence_system(); // release: writes back what the whole workgroup left dirty in L2
+        bad_s = 0;
+        last_s = atomicAdd(ctr, 1) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (last_s) {
+        if (tid == 0) {
+            if (fences)
+                __threadfence_system();
+            *ctr = 0; // the next launch on this stream starts from zero
+        }
+        __syncthreads();
+        if (tid < world)
+            __hip_atomic_store(a.sig[tid] + h * 2 * PEER_MAX + rank, ((unsigned long long)seq << 32) | (unsigned long long)(uint32_t)(a.w_off[reduce ? 0 : tid] >> 4),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    // 3. wait for every source's flag (in this rank's own signal block)
+    if (tid < world) {
+        const unsigned long long *mine = a.sig[rank] + h * 2 * PEER_MAX + tid;
+        const unsigned long long t0 = wall_clock64();
+        unsigned long long v;
+        for (;;) {
+            v = __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if ((uint32_t)(v >> 32) == seq)
+                break;
+            if (wall_clock64() - t0 > timeout_ticks) {
+                bad_s = 1;
+                atomicExch(err, 1 + tid);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        flag_s[tid] = v;
+    }
+    __syncthreads();
+    if (bad_s)
+        return;
+    if (fences) {
+        if (tid == 0)
+            __threadfence_system(); // acquire: nothing stale of the peers' windows is left in this CU's L1 / the L2
+        __syncthreads();
+    }
+    // 4. pull: the peers behind this rank first, this rank's own segment last
+    if (!reduce) {
+        for (int s = 1; s <= world; ++s) {
+            const int p = (rank + s) % world;
+            if (a.r_bytes[p] > 0)
+                copy_bytes<false, true>(recv + a.r_off[p], a.win[p] + half_off + ((int64_t)(uint32_t)flag_s[p] << 4), a.r_bytes[p], gtid, gsz, fences);
+        }
+    } else if (mode & 4) {
+        // two-shot: this rank adds slice `rank` of all operands (rank order) into its window's result area and into `recv`, publishes
+        // it (phase-1 flag), then collects the other slices from their owners: 2 (G-1)/G n floats cross the links instead of (G-1) n
+        const int64_t n4 = n >> 2, per = (n4 + world - 1) / world;
+        const int64_t roff = ((n * 4 + 15) >> 4) << 4; // result area, behind the operand
+        float4 *out = (float4 *)recv;
+        {
+            const int64_t k0 = (int64_t)rank * per, k1 = (k0 + per) < n4 ? (k0 + per) : n4;
+            const __amdgpu_buffer_rsrc_t rr = rsrc_of(my_half + roff);
+            for (int64_t k = k0 + gtid; k < k1; k += gsz) {
+                peer_u4v v[PEER_MAX];
+#pragma unroll
+                for (int p = 0; p < PEER_MAX; ++p)
+                    if (p < world) {
+                        const char *src = a.win[p] + half_off + ((int64_t)(uint32_t)flag_s[p] << 4);
+                        v[p] = fences ? ((const peer_u4v *)src)[k] : __builtin_amdgcn_raw_buffer_load_b128(rsrc_of(src), (int)(k << 4), 0, AUX_SYS);
+                    }
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int p = 0; p < PEER_MAX; ++p)
+                    if (p < world)
+                        acc = make_float4(acc.x + __uint_as_float(v[p].x), acc.y + __uint_as_float(v[p].y), acc.z + __uint_as_float(v[p].z),
+                                          acc.w + __uint_as_float(v[p].w));
+                out[k] = acc;
+                const peer_u4v w = {__float_as_uint(acc.x), __float_as_uint(acc.y), __float_as_uint(acc.z), __float_as_uint(acc.w)};
+                if (fences)
+                    ((peer_u4v *)(my_half + roff))[k - k0] = w;
+                else
+                    __builtin_amdgcn_raw_buffer_store_b128(w, rr, (int)((k - k0) << 4), 0, AUX_SYS);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            if (fences)
+                __threadfence_system();
+            last_s = atomicAdd(ctr + 2, 1) == (int)gridDim.x - 1;
+        }
+        __syncthreads();
+        if (last_s) {
+            if (tid == 0) {
+                if (fences)
+                    __threadfence_system();
+                ctr[2] = 0;
+            }
+            __syncthreads();
+            if (tid < world)
+                __hip_atomic_store(a.sig[tid] + (h * 2 + 1) * PEER_MAX + rank, ((unsigned long long)seq << 32) | (unsigned long long)(uint32_t)(roff >> 4),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if (tid < world) {
+            const unsigned long long *mine = a.sig[rank] + (h * 2 + 1) * PEER_MAX + tid;
+            const unsigned long long t0 = wall_clock64();
+            unsigned long long v;
+            for (;;) {
+                v = __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if ((uint32_t)(v >> 32) == seq)
+                    break;
+                if (wall_clock64() - t0 > timeout_ticks) {
+                    bad_s = 1;
+                    atomicExch(err, 1 + tid);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            flag_s[tid] = v;
+        }
+        __syncthreads();
+        if (bad_s)
+            return;
+        if (fences) {
+            if (tid == 0)
+                __threadfence_system();
+            __syncthreads();
+        }
+        for (int s = 1; s < world; ++s) {
+            const int p = (rank + s) % world;
+            const int64_t k0 = (int64_t)p * per, k1 = (k0 + per) < n4 ? (k0 + per) : n4;
+            if (k0 < k1)
+                copy_bytes<false, true>((char *)(out + k0), a.win[p] + half_off + ((int64_t)(uint32_t)flag_s[p] << 4), (k1 - k0) << 4, gtid, gsz, fences);
+        }
+    } else if ((n & 3) == 0 && ((uintptr_t)recv & 15) == 0) {
+        float4 *out = (float4 *)recv;
+        for (int64_t k = gtid; k < (n >> 2); k += gsz) {
+            peer_u4v v[PEER_MAX];
+#pragma unroll
+            for (int p = 0; p < PEER_MAX; ++p)
+                if (p < world) {
+                    const char *src = a.win[p] + half_off + ((int64_t)(uint32_t)flag_s[p] << 4);
+                    v[p] = fences ? ((const peer_u4v *)src)[k] : __builtin_amdgcn_raw_buffer_load_b128(rsrc_of(src), (int)(k << 4), 0, AUX_SYS);
+                }
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int p = 0; p < PEER_MAX; ++p) // rank order: every rank forms the same sum
+                if (p < world)
+                    acc = make_float4(acc.x + __uint_as_float(v[p].x), acc.y + __uint_as_float(v[p].y), acc.z + __uint_as_float(v[p].z),
+                                      acc.w + __uint_as_float(v[p].w));
+            out[k] = acc;
+        }
+    } else {
+        float *out = (float *)recv;
+        for (int64_t k = gtid; k < n; k += gsz) {
+            float acc = 0.f;
+            for (int p = 0; p < world; ++p) {
+                const char *src = a.win[p] + half_off + ((int64_t)(uint32_t)flag_s[p] << 4);
+                acc = acc + __uint_as_float(fences ? ((const unsigned *)src)[k] : __builtin_amdgcn_raw_buffer_load_b32(rsrc_of(src), (int)(k << 2), 0, AUX_SYS));
+            }
+            out[k] = acc;
+        }
+    }
+}
+
+struct PeerState { // what a rank owns; shared by the ranks of an in-process group through raw pointers
+    char *win = nullptr;
+    unsigned long long *sig = nullptr;
+    int64_t win_bytes = 0;
+    int device = -1;
+};
+
+struct PeerXch : crec_xch {
+    PeerState own;
+    PeerArgs base{};       // win / sig of every rank as mapped here
+    bool opened[PEER_MAX] = {false}; // mapped with hipIpcOpenMemHandle (to be closed)
+    void *opened_win[PEER_MAX] = {nullptr}, *opened_sig[PEER_MAX] = {nullptr};
+    int32_t *ctr = nullptr, *err = nullptr; // device: workgroup counter, error word
+    uint32_t seq = 0;
+    unsigned long long timeout_ticks = 20ull * 100000000ull; // 100 MHz
+    bool connected = false;
+    bool fences = false; // the textbook form of the window traffic (see copy_bytes)
+    bool two_shot = true; // large all-reduces as reduce-scatter + gather (crec_comm_peer_fences bit 1 clears it: tests compare the two)
+
+    ~PeerXch() override
+    {
+        for (int p = 0; p < PEER_MAX; ++p) {
+            if (opened_win[p])
+                (void)hipIpcCloseMemHandle(opened_win[p]);
+            if (opened_sig[p])
+                (void)hipIpcCloseMemHandle(opened_sig[p]);
+        }
+        if (own.win)
+            (void)hipFree(own.win);
+        if (own.sig)
+            (void)hipFree(own.sig);
+        if (ctr)
+            (void)hipFree(ctr);
+    }
+    int64_t max_bytes() const override { return own.win_bytes / 2; }
+    int status(crec_ctx *ctx, hipStream_t st) override
+    {
+        int32_t e = 0;
+        CREC_HIP(ctx, hipMemcpyAsync(&e, err, sizeof(e), hipMemcpyDeviceToHost, st));
+        CREC_HIP(ctx, hipStreamSynchronize(st));
+        if (e)
+            return crec_fail(ctx, CREC_EHIP, "peer transport: rank %d never published an exchange this rank waited for (gave up after %.0f s)",
+                             e - 1, (double)timeout_ticks / 1e8);
+        return CREC_OK;
+    }
+    int launch(crec_ctx *ctx, PeerArgs &a, const void *send, void *recv, int mode, int64_t n, int64_t recv_total, hipStream_t st)
+    {
+        CREC_REQUIRE(ctx, connected, "peer transport: crec_comm_peer_connect has not completed on this ctx");
+        ++seq;
+        if (seq == 0)
+            ++seq;
+        const int64_t half_off = (int64_t)(seq & 1u) * (own.win_bytes / 2);
+        int nb = (int)((recv_total + 16383) / 16384); // 16 KiB of the larger side per workgroup
+        nb = nb < 1 ? 1 : (nb > PEER_MAX_BLOCKS ? PEER_MAX_BLOCKS : nb);
+        hipLaunchKernelGGL(peer_exchange, dim3((unsigned)nb), dim3(PEER_THREADS), 0, st, a, (const char *)send, (char *)recv,
+                           own.win + half_off, half_off, seq, rank, world, mode | (fences ? 2 : 0), n, timeout_ticks, ctr, err);
+        CREC_HIP(ctx, hipGetLastError());
+        return CREC_OK;
+    }
+    int alltoallv(crec_ctx *ctx, const void *send, const int64_t *scnt, const int64_t *sdsp, void *recv, const int64_t *rcnt,
+                  const int64_t *rdsp, int elem_bytes, hipStream_t st) override
+    {
+        CREC_REQUIRE(ctx, elem_bytes == 4, "exchange: 4-byte elements");
+        CREC_REQUIRE(ctx, scnt[rank] == rcnt[rank], "exchange: a rank's segment to itself has two sizes");
+        PeerArgs a = base;
+        int64_t at = 0, rtot = 0;
+        for (int p = 0; p < world; ++p) {
+            CREC_REQUIRE(ctx, scnt[p] >= 0 && rcnt[p] >= 0, "exchange: negative count");
+            a.s_off[p] = sdsp[p] * 4;
+            a.s_bytes[p] = scnt[p] * 4;
+            a.w_off[p] = at;
+            at = (at + scnt[p] * 4 + 15) / 16 * 16;
+            a.r_off[p] = rdsp[p] * 4;
+            a.r_bytes[p] = rcnt[p] * 4;
+            rtot += rcnt[p] * 4;
+        }
+        CREC_REQUIRE(ctx, at <= own.win_bytes / 2, "peer transport: an exchange of %lld bytes does not fit half of the %lld-byte window",
+                     (long long)at, (long long)own.win_bytes);
+        return launch(ctx, a, send, recv, 0, 0, rtot > at ? rtot : at, st);
+    }
+    int allreduce_sum_f32(crec_ctx *ctx, float *buf, size_t n, hipStream_t st) override
+    {
+        if (n == 0)
+            return CREC_OK;
+        CREC_REQUIRE(ctx, (int64_t)n * 4 <= own.win_bytes / 2, "peer transport: an all-reduce of %zu floats does not fit half of the window", n);
+        PeerArgs a = base;
+        a.s_off[0] = 0;
+        a.s_bytes[0] = (int64_t)n * 4;
+        a.w_off[0] = 0;
+        // from three ranks and 64 KiB on, in two shots (every rank adds one slice and the slices are gathered): same sums, same order
+        const int64_t per16 = (((int64_t)n / 4 + world - 1) / world) * 16;
+        const bool two = two_shot && world >= 3 && (n & 3) == 0 && ((uintptr_t)buf & 15) == 0 && (int64_t)n * 4 >= (64 << 10) &&
+                         (((int64_t)n * 4 + 15) / 16 * 16 + per16) <= own.win_bytes / 2;
+        return launch(ctx, a, buf, buf, two ? 5 : 1, (int64_t)n, two ? (int64_t)n * 4 * 2 : (int64_t)n * 4 * world, st);
+    }
+};
+
+struct PeerBlob { // what a rank tells the others (CREC_PEER_BLOB_BYTES)
+    hipIpcMemHandle_t win, sig;
+    int64_t win_bytes;
+    int32_t device, pid;
+    char pad[CREC_PEER_BLOB_BYTES - 2 * sizeof(hipIpcMemHandle_t) - 16];
+};
+static_assert(sizeof(PeerBlob) == CREC_PEER_BLOB_BYTES, "blob size");
+
+int peer_alloc(crec_ctx *ctx, int64_t window_bytes, PeerXch **out)
+{
+    CREC_REQUIRE(ctx, ctx->device >= 0, "host-only ctx: no device bound");
+    CREC_REQUIRE(ctx, ctx->comm == nullptr && ctx->xch == nullptr, "communicator already initialised");
+    CREC_REQUIRE(ctx, window_bytes >= (1 << 16) && window_bytes % 512 == 0, "window_bytes: a multiple of 512, at least 64 KiB");
+    CREC_HIP(ctx, hipSetDevice(ctx->device));
+    PeerXch *x = new PeerXch();
+    x->own.device = ctx->device;
+    x->own.win_bytes = window_bytes;
+    hipError_t e = hipMalloc((void **)&x->own.win, (size_t)window_bytes);
+    if (e == hipSuccess)
+        e = hipExtMallocWithFlags((void **)&x->own.sig, sizeof(unsigned long long) * 4 * PEER_MAX, hipDeviceMallocUncached);
+    if (e == hipSuccess)
+        e = hipMemset(x->own.sig, 0, sizeof(unsigned long long) * 4 * PEER_MAX);
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&x->ctr, 4 * sizeof(int32_t));
+    if (e == hipSuccess)
+        e = hipMemset(x->ctr, 0, 4 * sizeof(int32_t));
+    if (e == hipSuccess)
+        e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        delete x;
+        return crec_fail(ctx, e == hipErrorOutOfMemory ? CREC_ENOMEM : CREC_EHIP, "peer transport: allocating the window failed: %s", hipGetErrorString(e));
+    }
+    x->err = x->ctr + 1;
+    *out = x;
+    return CREC_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int crec_comm_peer_create(crec_ctx *ctx, int64_t window_bytes, void *blob_out)
+{
+    if (!ctx || !blob_out)
+        return CREC_EINVAL;
+    PeerXch *x = nullptr;
+    if (int rc = peer_alloc(ctx, window_bytes, &x))
+        return rc;
+    PeerBlob b;
+    std::memset(&b, 0, sizeof(b));
+    hipError_t e = hipIpcGetMemHandle(&b.win, x->own.win);
+    if (e == hipSuccess)
+        e = hipIpcGetMemHandle(&b.sig, x->own.sig);
+    if (e != hipSuccess) {
+        delete x;
+        return crec_fail(ctx, CREC_EHIP, "peer transport: hipIpcGetMemHandle failed: %s (is HSA_ENABLE_IPC_MODE_LEGACY=0 set?)", hipGetErrorString(e));
+    }
+    b.win_bytes = window_bytes;
+    b.device = ctx->device;
+    b.pid = (int32_t)getpid();
+    std::memcpy(blob_out, &b, sizeof(b));
+    ctx->xch = x; // not connected yet: any exchange before crec_comm_peer_connect is refused
+    return CREC_OK;
+}
+
+int crec_comm_peer_connect(crec_ctx *ctx, int rank, int world, const void *blobs)
+{
+    if (!ctx || !blobs)
+        return CREC_EINVAL;
+    PeerXch *x = dynamic_cast<PeerXch *>(ctx->xch);
+    CREC_REQUIRE(ctx, x != nullptr && !x->connected, "crec_comm_peer_create first (once)");
+    CREC_REQUIRE(ctx, world >= 1 && world <= PEER_MAX && rank >= 0 && rank < world, "peer transport: world 1..%d", PEER_MAX);
+    CREC_HIP(ctx, hipSetDevice(ctx->device));
+    const PeerBlob *b = (const PeerBlob *)blobs;
+    for (int p = 0; p < world; ++p) {
+        CREC_REQUIRE(ctx, b[p].win_bytes == x->own.win_bytes, "peer transport: rank %d has a window of %lld bytes, this rank %lld", p,
+                     (long long)b[p].win_bytes, (long long)x->own.win_bytes);
+        if (p == rank) {
+            x->base.win[p] = x->own.win;
+            x->base.sig[p] = x->own.sig;
+            continue;
+        }
+        CREC_REQUIRE(ctx, b[p].pid != (int32_t)getpid(), "peer transport: rank %d lives in this process (use crec_comm_peer_connect_local)", p);
+        void *w = nullptr, *s = nullptr;
+        CREC_HIP(ctx, hipIpcOpenMemHandle(&w, b[p].win, hipIpcMemLazyEnablePeerAccess));
+        x->opened_win[p] = w;
+        CREC_HIP(ctx, hipIpcOpenMemHandle(&s, b[p].sig, hipIpcMemLazyEnablePeerAccess));
+        x->opened_sig[p] = s;
+        x->base.win[p] = (const char *)w;
+        x->base.sig[p] = (unsigned long long *)s;
+    }
+    x->rank = rank;
+    x->world = world;
+    x->connected = true;
+    ctx->rank = rank;
+    ctx->world = world;
+    return CREC_OK;
+}
+
+int crec_comm_peer_connect_local(crec_ctx **ctxs, int world, int64_t window_bytes)
+{
+    if (!ctxs || world < 1 || world > PEER_MAX)
+        return CREC_EINVAL;
+    std::vector<PeerXch *> xs((size_t)world, nullptr);
+    for (int r = 0; r < world; ++r) {
+        if (!ctxs[r])
+            return CREC_EINVAL;
+        if (int rc = peer_alloc(ctxs[r], window_bytes, &xs[(size_t)r])) {
+            for (int q = 0; q < r; ++q)
+                delete xs[(size_t)q];
+            return rc;
+        }
+    }
+    for (int r = 0; r < world; ++r) {
+        for (int p = 0; p < world; ++p) {
+            if (xs[(size_t)p]->own.device != xs[(size_t)r]->own.device) { // the ranks of one process on several GPUs of a node
+                (void)hipSetDevice(xs[(size_t)r]->own.device);
+                const hipError_t e = hipDeviceEnablePeerAccess(xs[(size_t)p]->own.device, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+                    (void)hipGetLastError();
+            }
+            xs[(size_t)r]->base.win[p] = xs[(size_t)p]->own.win;
+            xs[(size_t)r]->base.sig[p] = xs[(size_t)p]->own.sig;
+        }
+        xs[(size_t)r]->rank = r;
+        xs[(size_t)r]->world = world;
+        xs[(size_t)r]->connected = true;
+        ctxs[r]->xch = xs[(size_t)r];
+        ctxs[r]->rank = r;
+        ctxs[r]->world = world;
+    }
+    (void)hipGetLastError();
+    return CREC_OK;
+}
+
+int crec_comm_peer_fences(crec_ctx *ctx, int on)
+{
+    if (!ctx)
+        return CREC_EINVAL;
+    PeerXch *x = dynamic_cast<PeerXch *>(ctx->xch);
+    CREC_REQUIRE(ctx, x != nullptr, "crec_comm_peer_fences: a peer-transport ctx");
+    x->fences = (on & 1) != 0;
+    x->two_shot = (on & 2) == 0;
+    return CREC_OK;
+}
+
+int crec_comm_set_timeout(crec_ctx *ctx, double seconds)
+{
+    if (!ctx)
+        return CREC_EINVAL;
+    PeerXch *x = dynamic_cast<PeerXch *>(ctx->xch);
+    CREC_REQUIRE(ctx, x != nullptr && seconds > 0 && seconds < 3600, "crec_comm_set_timeout: a peer-transport ctx and 0 < seconds < 3600");
+    x->timeout_ticks = (unsigned long long)(seconds * 1e8);
+    return CREC_OK;
+}
+
+// test / micro-benchmark hooks: one exchange of the ctx's communicator (any transport) on device buffers; counts and
+// displacements in 4-byte elements, host arrays of `world` entries
+int crec_debug_alltoallv(crec_ctx *ctx, const void *send, const int64_t *scnt, const int64_t *sdsp, void *recv, const int64_t *rcnt,
+                         const int64_t *rdsp, void *stream)
+{
+    if (!ctx)
+        return CREC_EINVAL;
+    CREC_REQUIRE(ctx, ctx->device >= 0 && scnt && sdsp && rcnt && rdsp, "null argument");
+    CREC_HIP(ctx, hipSetDevice(ctx->device));
+    return crec_xch_of(ctx)->alltoallv(ctx, send, scnt, sdsp, recv, rcnt, rdsp, 4, (hipStream_t)stream);
+}
+
+int crec_debug_allreduce(crec_ctx *ctx, float *buf, int64_t n, void *stream)
+{
+    if (!ctx)
+        return CREC_EINVAL;
+    CREC_REQUIRE(ctx, ctx->device >= 0 && buf && n >= 0, "null argument");
+    CREC_HIP(ctx, hipSetDevice(ctx->device));
+    return crec_xch_of(ctx)->allreduce_sum_f32(ctx, buf, (size_t)n, (hipStream_t)stream);
+}
+
+int crec_comm_status(crec_ctx *ctx, void *stream)
+{
+    if (!ctx)
+        return CREC_EINVAL;
+    CREC_REQUIRE(ctx, ctx->device >= 0, "host-only ctx: no device bound");
+    return crec_xch_of(ctx)->status(ctx, (hipStream_t)stream);
+}
+
+} // extern "C"

@@ -13,6 +13,7 @@ range-sharded over ranks in both forms, so all P traffic is local
 torch.distributed is used only to ship the RCCL unique id, to agree on the batch count and (evaluation) to gather
 the item shards."""
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -64,9 +65,13 @@ class DpBprState(BprState):
     """BprState whose train_epoch runs the data-parallel step.  P0: this rank's user rows; Q0: the
     replica (must be identical on every rank)."""
 
-    def __init__(self, sess, P0, Q0, lr, reg, rank=None, world=None):
+    def __init__(self, sess, P0, Q0, lr, reg, rank=None, world=None, transport="rccl"):
+        """transport: "rccl" (crec_comm_init), "peer" (the IPC windows of crec_comm_peer_*), None (the ctx has a communicator)"""
         super().__init__(sess, P0, Q0, lr, reg, "tf1")
-        self.rank, self.world = init_rccl(sess, rank, world)
+        if transport is None:
+            self.rank, self.world = rank, world
+        else:
+            self.rank, self.world = (init_peer if transport == "peer" else init_rccl)(sess, rank, world)
 
     def train_epoch(self, u, i, j, batch_size, out=None):
         """Collective.  u: row ids inside this rank's shard.  Returns per-batch losses summed over ranks (in `out` if given)."""
@@ -91,6 +96,35 @@ def init_rccl(sess, rank=None, world=None):
     raw = bytes(uid) if world == 1 else broadcast_bytes(bytes(uid), 0)
     sess.ctx.check(sess.lib.crec_comm_init(sess.ctx.h, rank, world, C.c_char_p(raw)))
     return rank, world
+
+
+PEER_BLOB_BYTES = 192
+
+
+def init_peer(sess, rank=None, world=None, window_bytes=128 << 20):
+    """The peer transport (include/crec.h "Peer transport"): this rank's window is created, torch.distributed ships the IPC
+    handles, every rank maps every other rank's window.  An exchange carries up to window_bytes / 2 per rank."""
+    rank = dist.get_rank() if rank is None else rank
+    world = dist.get_world_size() if world is None else world
+    blob = (C.c_char * PEER_BLOB_BYTES)()
+    sess.ctx.check(sess.lib.crec_comm_peer_create(sess.ctx.h, int(window_bytes), blob))
+    if world == 1:
+        blobs = [bytes(blob)]
+    else:
+        blobs = [None] * world
+        dist.all_gather_object(blobs, bytes(blob))
+    sess.ctx.check(sess.lib.crec_comm_peer_connect(sess.ctx.h, rank, world, C.c_char_p(b"".join(blobs))))
+    if os.environ.get("CREC_PEER_FENCES") == "1":  # the textbook form of the window traffic (csrc/crec_peer.hip)
+        sess.ctx.check(sess.lib.crec_comm_peer_fences(sess.ctx.h, 1))
+    if world > 1:
+        dist.barrier()  # nobody starts an exchange before everybody has mapped everybody
+    return rank, world
+
+
+def init_peer_local(sessions, window_bytes=128 << 20):
+    """crec_comm_peer_connect_local: the peer transport among Sessions of THIS process (rank = position)."""
+    arr = (C.c_void_p * len(sessions))(*[s.ctx.h for s in sessions])
+    sessions[0].ctx.check(sessions[0].lib.crec_comm_peer_connect_local(arr, len(sessions), int(window_bytes)))
 
 
 def init_local_group(sessions):

@@ -422,6 +422,33 @@ int crec_comm_init_local(crec_ctx **ctxs, int world);
 int crec_bpr_train_epoch_sharded(crec_ctx *ctx, const crec_bpr_tables *t, int64_t I_global, crec_adam *opt, const int32_t *u,
                                  const int32_t *i, const int32_t *j, int64_t N, int32_t B, float *loss_per_batch,
                                  crec_shard_stats *stats, void *stream);
+/* Peer transport for both multi-GPU forms (csrc/crec_peer.hip): instead of grouped ncclSend / ncclRecv, every rank maps a window of
+ * every other rank (HIP IPC over xGMI; needs HSA_ENABLE_IPC_MODE_LEGACY=0 on this platform) and ONE kernel per exchange copies the
+ * rank's segments into its own window, publishes them with a flag per peer and reads the peers' segments with plain loads.
+ *   crec_comm_peer_create   allocates this rank's window (two halves used alternately: an exchange may carry window_bytes / 2 per
+ *                           rank) and signal words, returns the CREC_PEER_BLOB_BYTES the OTHER ranks need (ship them with whatever
+ *                           the application has: torch.distributed all_gather in cleverrec_amd/parallel.py)
+ *   crec_comm_peer_connect  blobs = world x CREC_PEER_BLOB_BYTES in rank order; maps the peers.  World <= 16.
+ *   crec_comm_peer_connect_local  the ranks are `world` ctxs of THIS process (tests: several ranks on one GPU; or one thread per GPU)
+ *   crec_comm_set_timeout   how long a rank waits for a peer's flag before the communicator reports an error (default 20 s)
+ *   crec_comm_status        synchronises the stream and reports such an error (the epochs call it once per chunk of batches)
+ * crec_bpr_train_epoch_dp and crec_bpr_train_epoch_sharded then run over it unchanged.  Exchanges are collective and must be
+ * enqueued on ONE stream per ctx.  crec_debug_alltoallv / crec_debug_allreduce: one exchange of the ctx's communicator (any
+ * transport) on device buffers -- counts and displacements in 4-byte elements, host arrays of `world` entries (tests, tools/micro). */
+#define CREC_PEER_BLOB_BYTES 192
+int crec_comm_peer_create(crec_ctx *ctx, int64_t window_bytes, void *blob_out);
+int crec_comm_peer_connect(crec_ctx *ctx, int rank, int world, const void *blobs);
+int crec_comm_peer_connect_local(crec_ctx **ctxs, int world, int64_t window_bytes);
+int crec_comm_set_timeout(crec_ctx *ctx, double seconds);
+/* on & 1: window traffic as plain accesses between system-scope release / acquire fences instead of written-through system-scope
+ * accesses (same results; the two forms are correct against each other).  on & 2: every all-reduce in ONE shot (every rank reads all operands)
+ * instead of two from three ranks and 64 KiB on (a rank adds one slice, the slices are gathered) -- same sums in the same order; THIS
+ * choice must be the same on every rank. */
+int crec_comm_peer_fences(crec_ctx *ctx, int on);
+int crec_comm_status(crec_ctx *ctx, void *stream);
+int crec_debug_alltoallv(crec_ctx *ctx, const void *send, const int64_t *scnt, const int64_t *sdsp, void *recv, const int64_t *rcnt,
+                         const int64_t *rdsp, void *stream);
+int crec_debug_allreduce(crec_ctx *ctx, float *buf, int64_t n, void *stream);
 /* The index work of that step for ONE batch, twice: the host form (csrc/shard_host.cpp: the planner the multi-process CPU
  * tests run over gloo, all pointers host) and, as test hooks, the device kernels the epoch launches (all pointers device except
  * srv_cnt) -- the GPU tests hold the second to the first.

@@ -1,0 +1,114 @@
+"""The peer transport (csrc/crec_peer.hip: IPC windows, one kernel per exchange) on ONE MI355X.
+
+  * ranks as PROCESSES (tests/_peer_worker.py, world 2 and 3 on cuda:0): the real hipIpcGetMemHandle / hipIpcOpenMemHandle
+    path, flags in uncached memory, system-scope fences -- random all-to-all-v rounds and all-reduces bit for bit, then the
+    row-sharded epoch and the replicated-Q epoch of libcrec.so against the oracle, replicas bit-identical;
+  * ranks as threads of this process (crec_comm_peer_connect_local): the same kernels through raw pointers, the sharded
+    epoch against the oracle.
+What one GPU cannot show is the xGMI side (peer memory types, link bandwidth): see DESIGN.md 7."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from cleverrec_amd import parallel, runtime
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_as_processes_over_ipc_windows(world):
+    """(Not more ranks on ONE GPU: a rank's launch waits inside the GPU for its peers' launches, so all ranks' workgroups have to be
+    resident together -- one per CU and rank; four ranks' worth do not fit a CU's registers, and the waits then run into their
+    time-out.  One process per GPU, the production layout, has the CU to itself.)"""
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_peer_worker.py")], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=280))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, "\n----\n".join(e[-1500:] for _, e in outs))
+    line = [ln for ln in outs[0][0].splitlines() if ln.startswith("PEER_RESULT ")]
+    assert line, outs[0][0][-2000:]
+    res = json.loads(line[0][len("PEER_RESULT "):])
+    assert res["exchanges_ok"]
+    sh, dp = res["sharded"], res["dp"]
+    assert sh["loss_ok"] and sh["same_loss_everywhere"] and sh["P_err"] <= 2e-6 and sh["Q_err"] <= 2e-6, sh
+    assert dp["replicas_identical"] and dp["loss_ok"] and dp["P_err"] <= 2e-6 and dp["Q_err"] <= 2e-6, dp
+
+
+def test_ranks_as_threads_sharded_epoch():
+    """(Two ranks only: a rank's kernel waits inside the GPU for its peers' kernels, so every rank needs a hardware queue of its
+    own -- a process has four, shared by all its streams; one process per GPU never meets that limit.)"""
+    G = 2
+    U, I, B, d = 400, 301, 256, 64
+    g = np.random.Generator(np.random.PCG64(3))
+    P0 = (g.standard_normal((U, d)) * 0.01).astype(np.float32)
+    Q0 = (g.standard_normal((I, d)) * 0.01).astype(np.float32)
+    ranges = [parallel.user_range(U, r, G) for r in range(G)]
+    streams = []
+    for r, (lo, hi) in enumerate(ranges):
+        n = 2 * B + [40, 7, 1, 256][r]
+        streams.append((g.integers(0, hi - lo, n).astype(np.int32), np.minimum(g.zipf(1.3, n) - 1, I - 1).astype(np.int32), g.integers(0, I, n).astype(np.int32)))
+    sessions = [runtime.Session(0) for _ in range(G)]
+    parallel.init_peer_local(sessions, window_bytes=8 << 20)
+    for s in sessions:
+        s.ctx.check(s.lib.crec_comm_set_timeout(s.ctx.h, 10.0))
+    result, errors = [None] * G, []
+
+    def work(r):
+        try:
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                s = sessions[r]
+                lo, hi = ranges[r]
+                st = parallel.ShardedBprState(s, P0[lo:hi], parallel.shard_items(Q0, r, G), I, 1e-3, 0.01, r, G)
+                u, i, j = (s.to_dev(x) for x in streams[r])
+                loss = st.train_epoch(u, i, j, B).cpu().numpy()
+                torch.cuda.current_stream().synchronize()
+                result[r] = (st.P.cpu().numpy(), st.Q.cpu().numpy(), loss)
+        except Exception as e:  # noqa: BLE001
+            errors.append((r, e))
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(G)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+    assert not any(t.is_alive() for t in threads), "a rank hung"
+    if errors:
+        raise errors[0][1]
+    P = np.concatenate([x[0] for x in result])
+    Q = parallel.unshard_items([x[1] for x in result], I)
+    oP, oQ, oloss, _ = oracle.sharded_steps(P0, Q0, ranges, streams, B)
+    np.testing.assert_allclose(result[0][2], oloss, rtol=1e-5)
+    for r in range(1, G):
+        assert np.array_equal(result[r][2], result[0][2])
+    np.testing.assert_allclose(P, oP, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(Q, oQ, rtol=0, atol=2e-6)
+    for s in sessions:
+        s.close()
