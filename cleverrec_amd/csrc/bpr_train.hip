@@ -107,7 +107,7 @@ __device__ __forceinline__ void crec_mark(int slot, int dep) // the time at whic
 #define CREC_LAZY_WAVES(MODE) ((MODE) == 2 ? CREC_LAZY_ITEM_WAVES : 4)
 #ifndef CREC_LAZY_ABL
 #define CREC_LAZY_ABL 0 // timing ablations of bpr_triples_lazy (wrong results): 1 no finishers, 2 no publishing / tickets either,
-#endif                  // 4 no LDS piece sums
+#endif                  // 4 no LDS piece sums, 8 no optimizer arithmetic, 16 no loss terms / user descriptor
 #ifndef CREC_IDX_RECS
 #define CREC_IDX_RECS 12 // all of a thread's records at B = 6144: one round of gathers instead of three (a 20-batch call 227 -> 219 us)
 #endif
@@ -785,6 +785,12 @@ __device__ __forceinline__ void adam4(float4 &var, float4 &m, float4 &v, float4 
 //            accum += g*g; var -= lr * g / sqrt(accum)
 __device__ __forceinline__ void opt4(float4 &var, float4 &m, float4 &v, float4 g, const Hyper &h)
 {
+    if (CREC_LAZY_ABL & 8) { // timing ablation: no optimizer arithmetic
+        var = make_float4(var.x + g.x, var.y + g.y, var.z + g.z, var.w + g.w);
+        m = make_float4(m.x + g.x, m.y + g.y, m.z + g.z, m.w + g.w);
+        v = make_float4(v.x + g.x, v.y + g.y, v.z + g.z, v.w + g.w);
+        return;
+    }
     if (h.opt == 0) {
         adam4(var, m, v, g, true, h);
         return;
@@ -1734,7 +1740,7 @@ __global__ __launch_bounds__(LazyGeo<LPR>::THREADS) void bpr_triples_lazy(Tables
     const int pos = pu.x;
     const bool front_block = slot0 < n_blk_slots; // workgroup-uniform: slots of the item-sorted front region in this workgroup
     const bool front = valid && slot < n_blk_slots; // this slot's positive item row has its positive slots right here, in a row
-    const int4 du = valid ? ud[pos] : none; // (a second, dependent load: off the critical path of the row loads below)
+    const int4 du = (valid && !(CREC_LAZY_ABL & 16)) ? ud[pos] : none; // (a second, dependent load: off the critical path of the row loads below)
     const bool is = di.x < 0, js = dj.x < 0;
     const int64_t ou = (int64_t)pu.y * d + 4 * l, oi = (int64_t)(di.x & 0x7fffffff) * d + 4 * l,
                   oj = (int64_t)(dj.x & 0x7fffffff) * d + 4 * l;
@@ -1797,7 +1803,7 @@ __global__ __launch_bounds__(LazyGeo<LPR>::THREADS) void bpr_triples_lazy(Tables
     float x;
     const float s = triple_s<LPR>(dot4(p, qi) - dot4(p, qj), &x);
     const float l2 = (0.5f * group_sum<LPR>(dot4(p, p)) + 0.5f * group_sum<LPR>(dot4(qi, qi))) + 0.5f * group_sum<LPR>(dot4(qj, qj));
-    if (valid && l == 0) {
+    if (valid && l == 0 && !(CREC_LAZY_ABL & 16)) {
         xb[pos] = x; // softplus(-x) is taken in bpr_reduce_loss
         l2b[pos] = l2;
     }
@@ -2631,6 +2637,7 @@ int sharded_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, int64_t I_global
     if (int rc = setup_lazy_bufs(ctx, B, d, CH, st, &a.lazy))
         return rc;
     int64_t sent_ids = 0, sent_rows = 0, sent_grads = 0, n_requested = 0, n_served = 0, max_served = 0;
+    const bool fused = x->next_half() != nullptr && !ctx->knob_shard_unfused; // the peer transport: exchanges fused with serve / apply
 
     std::vector<int64_t> scnt(G), sdsp(G), rcnt(G), rdsp(G);
     for (int64_t b0 = 0; b0 < nb; b0 += chunk) {
@@ -2767,14 +2774,25 @@ int sharded_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, int64_t I_global
                     sent_grads += 4 * rcnt[q];
                 }
             }
-            if (n_srv > 0) {
-                crec_prof_begin(ctx, CREC_K_SHARD_SERVE, st);
-                CREC_KLAUNCH(ctx, shard_serve_rows, dim3((unsigned)crec_ceil_div(n_srv * lpr, 256)), dim3(256), 0, st,
-                             (const float *)t->Q, (const int32_t *)(v.srv_rows + b * stride), (int)n_srv, d, lpr, v.sendrows);
-                crec_prof_end(ctx, st);
+            if (fused) { // peer transport: the rows are served straight into this rank's window, the exchange starts from there
+                if (n_srv > 0) {
+                    crec_prof_begin(ctx, CREC_K_SHARD_SERVE, st);
+                    CREC_KLAUNCH(ctx, shard_serve_rows, dim3((unsigned)crec_ceil_div(n_srv * lpr, 256)), dim3(256), 0, st,
+                                 (const float *)t->Q, (const int32_t *)(v.srv_rows + b * stride), (int)n_srv, d, lpr, (float *)x->next_half());
+                    crec_prof_end(ctx, st);
+                }
+                if (int rc = x->alltoallv_inplace(ctx, scnt.data(), sdsp.data(), p.Qc, rcnt.data(), rdsp.data(), st))
+                    return rc;
+            } else {
+                if (n_srv > 0) {
+                    crec_prof_begin(ctx, CREC_K_SHARD_SERVE, st);
+                    CREC_KLAUNCH(ctx, shard_serve_rows, dim3((unsigned)crec_ceil_div(n_srv * lpr, 256)), dim3(256), 0, st,
+                                 (const float *)t->Q, (const int32_t *)(v.srv_rows + b * stride), (int)n_srv, d, lpr, v.sendrows);
+                    crec_prof_end(ctx, st);
+                }
+                if (int rc = x->alltoallv(ctx, v.sendrows, scnt.data(), sdsp.data(), p.Qc, rcnt.data(), rdsp.data(), 4, st))
+                    return rc;
             }
-            if (int rc = x->alltoallv(ctx, v.sendrows, scnt.data(), sdsp.data(), p.Qc, rcnt.data(), rdsp.data(), 4, st))
-                return rc;
             a.h.opt = 0;
             a.h.lr_tab = nullptr;
             a.h.lr_t = (opt->lr * sqrtf(1.0f - opt->beta2_power)) / (1.0f - opt->beta1_power);
@@ -2782,21 +2800,43 @@ int sharded_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, int64_t I_global
             a.h.beta2 = opt->beta2;
             a.h.eps = opt->eps;
             a.h.reg = opt->reg;
-            a.h.dQ = p.dQc; // the item side emits each compact row's gradient sum (incl. its l2 term) instead of Adam
+            // the item side emits each compact row's gradient sum (incl. its l2 term) instead of Adam -- over the peer transport straight
+            // into this rank's window, where the owners will read it (the layout of the compact table: owner o's rows from req_off[o])
+            a.h.dQ = fused ? (float *)x->next_half() : p.dQc;
             a.xb = (float *)ctx->loss_ws.ptr + b * loss_stride;
             a.nb_cur = (int32_t)((n_chunk - b * B) < B ? (n_chunk - b * B) : B);
             a.rowterm = a.xb + B;
             step(a, w, b, hn + b * HN);
             // back: the gradient row of every item I referenced goes to its owner (the forward sizes, reversed)
-            if (int rc = x->alltoallv(ctx, p.dQc, rcnt.data(), rdsp.data(), v.recvgrads, scnt.data(), sdsp.data(), 4, st))
-                return rc;
-            if (n_srv > 0) {
+            if (fused) { // exchange + owner apply in one launch: the owners read the gradient rows where the step left them
+                crec_peer_view pv;
+                CREC_REQUIRE(ctx, x->begin(&pv), "peer transport: not connected");
+                ShardPeerOffs so{};
+                for (int q = 0; q < G; ++q) {
+                    so.seg_off[q] = rdsp[q] * 4;
+                    so.slot_base[q] = (int32_t)(sdsp[q] / d);
+                }
+                so.slot_base[G] = (int32_t)n_srv;
+                int64_t nblk = crec_ceil_div(n_srv * lpr, PEER_THREADS);
+                // (no copy-in here: workgroup 0 publishes at once, so no workgroup of this launch waits for another one of it and the
+                // grid may exceed what is resident -- a lane group per row, as in shard_owner_apply)
+                nblk = nblk < 1 ? 1 : (nblk > 8 * PEER_MAX_BLOCKS ? 8 * PEER_MAX_BLOCKS : nblk);
                 crec_prof_begin(ctx, CREC_K_SHARD_APPLY, st);
-                CREC_KLAUNCH(ctx, shard_owner_apply, dim3((unsigned)crec_ceil_div(n_srv * lpr, 256)), dim3(256), 0, st, t->Q, t->mQ,
-                             t->vQ, (const int32_t *)(v.urows + b * stride), (const int32_t *)(v.useg + b * (stride + 1)),
-                             (const int32_t *)(v.order + b * stride), (const int32_t *)(v.n_urows + b),
-                             (const float *)v.recvgrads, d, lpr, a.h);
+                CREC_KLAUNCH(ctx, shard_exchange_apply, dim3((unsigned)nblk), dim3(PEER_THREADS), 0, st, pv, so, t->Q, t->mQ, t->vQ,
+                             (const int32_t *)(v.urows + b * stride), (const int32_t *)(v.useg + b * (stride + 1)),
+                             (const int32_t *)(v.order + b * stride), (const int32_t *)(v.n_urows + b), d, lpr, a.h);
                 crec_prof_end(ctx, st);
+            } else {
+                if (int rc = x->alltoallv(ctx, p.dQc, rcnt.data(), rdsp.data(), v.recvgrads, scnt.data(), sdsp.data(), 4, st))
+                    return rc;
+                if (n_srv > 0) {
+                    crec_prof_begin(ctx, CREC_K_SHARD_APPLY, st);
+                    CREC_KLAUNCH(ctx, shard_owner_apply, dim3((unsigned)crec_ceil_div(n_srv * lpr, 256)), dim3(256), 0, st, t->Q, t->mQ,
+                                 t->vQ, (const int32_t *)(v.urows + b * stride), (const int32_t *)(v.useg + b * (stride + 1)),
+                                 (const int32_t *)(v.order + b * stride), (const int32_t *)(v.n_urows + b),
+                                 (const float *)v.recvgrads, d, lpr, a.h);
+                    crec_prof_end(ctx, st);
+                }
             }
             opt->beta1_power = opt->beta1_power * opt->beta1;
             opt->beta2_power = opt->beta2_power * opt->beta2;

@@ -16,6 +16,7 @@
 // A ctx without a communicator is a world of one: the exchange is a device copy on the stream.
 #pragma once
 #include "crec_internal.h"
+#include "crec_peer_dev.h"
 
 struct crec_xch {
     int rank = 0, world = 1;
@@ -27,6 +28,17 @@ struct crec_xch {
     virtual int allreduce_sum_f32(crec_ctx *ctx, float *buf, size_t n, hipStream_t st) = 0;
     // the largest payload a rank may hand to one exchange (the peer transport stages it in half of its window)
     virtual int64_t max_bytes() const { return INT64_MAX; }
+    // Peer transport only (the others: false / nullptr / CREC_EUNSUPPORTED) -- for kernels that take part in an exchange themselves:
+    //   begin      the view of the NEXT exchange; consumes its sequence number: the caller launches exactly one kernel that publishes
+    //              this rank's segments (peer_publish) and waits for the peers' (peer_wait_all), crec_peer_dev.h
+    //   next_half  where a producer kernel may leave the segments of the next exchange (byte offsets = what it will publish)
+    //   alltoallv_inplace  all-to-all-v whose segments a previous kernel left in next_half() at their send displacements
+    virtual bool begin(crec_peer_view *) { return false; }
+    virtual char *next_half() { return nullptr; }
+    virtual int alltoallv_inplace(crec_ctx *ctx, const int64_t *, const int64_t *, void *, const int64_t *, const int64_t *, hipStream_t)
+    {
+        return crec_fail(ctx, CREC_EUNSUPPORTED, "this transport has no window to exchange in place");
+    }
     // errors a transport only learns about asynchronously (the peer transport's waits give up after a time-out); synchronises st
     virtual int status(crec_ctx *, hipStream_t) { return CREC_OK; }
 };

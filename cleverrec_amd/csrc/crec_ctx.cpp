@@ -188,6 +188,7 @@ int crec_ctx_create(int device, crec_ctx **out)
     ctx->knob_eval_shape = env_int("CREC_EVAL_SHAPE", 0);
     ctx->knob_eval_no_bitmap = env_int("CREC_EVAL_NO_BITMAP", 0);
     ctx->knob_ncf_generic = env_int("CREC_NCF_GENERIC", 0);
+    ctx->knob_shard_unfused = env_int("CREC_SHARD_UNFUSED", 0);
     ctx->knob_no_zero_copy = env_int("CREC_NO_ZERO_COPY", 0);
     ctx->knob_dsampler_general = env_int("CREC_DSAMPLER_GENERAL", 0);
     if (device >= 0) {
@@ -268,6 +269,8 @@ int crec_ctx_set_option(crec_ctx *ctx, const char *name, int64_t value)
         ctx->knob_ncf_generic = (int)value;
     else if (n == "no_zero_copy")
         ctx->knob_no_zero_copy = (int)value;
+    else if (n == "shard_unfused")
+        ctx->knob_shard_unfused = (int)value;
     else if (n == "dsampler_general")
         ctx->knob_dsampler_general = (int)value;
     else if (n == "dsampler_budget")

@@ -112,6 +112,7 @@ struct crec_ctx {
     int knob_eval_shape = 0;     // 4 / 8: force an eval_sweep workgroup shape where legal (0: choose)
     int knob_eval_no_bitmap = 0; // 1: seen filter by binary search even where the bitmaps would fit
     int knob_no_zero_copy = 0;   // 1: the chunk's counts come back by copy + stream synchronisation (tests)
+    int knob_shard_unfused = 0;  // 1: the row-sharded step over the peer transport as five launches (serve, exchange, step, exchange, apply) like over RCCL (tests)
     int knob_ncf_generic = 0;    // 1: the generic ncf_tile even for the shapes that have a specialised one (tests)
     int knob_dsampler_budget = 100; // percent of the device sampler's stream budget to start with (tests: < 100 forces the retry path)
     int knob_dsampler_general = 0; // negatives phase of the device sampler: 0 parallel tables (walk where they do not apply), 2 the four-wave walk, 1 the general walk (tests)

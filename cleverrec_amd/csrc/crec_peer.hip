@@ -22,18 +22,13 @@
 // waits in step 1-2, so the waits of step 3 always end; they give up after `timeout` (20 s by default: ranks are only
 // loosely in step, a peer may be allocating or planning on its host) and the communicator then reports the error.
 #include "crec_comm.h"
+#include "crec_peer_dev.h"
 
 #include <unistd.h>
 
 namespace {
 
-constexpr int PEER_MAX = 16;
-constexpr int PEER_THREADS = 512;
-constexpr int PEER_MAX_BLOCKS = 128; // half a wave slot per SIMD of half the CUs: always resident together, beside whatever else runs
-
-struct PeerArgs {
-    const char *win[PEER_MAX];                  // rank p's window as this process sees it
-    unsigned long long *sig[PEER_MAX];          // rank p's signal block as this process sees it
+struct PeerSegs {
     int64_t s_off[PEER_MAX], s_bytes[PEER_MAX]; // my segment for p inside `send`
     int64_t w_off[PEER_MAX];                    // ... and where it lies inside my window half
     int64_t r_off[PEER_MAX], r_bytes[PEER_MAX]; // what p sends me, inside `recv`
@@ -42,119 +37,69 @@ struct PeerArgs {
 // Window traffic, two forms.  Default: every store into a window and every load from one is a SYSTEM-scope access (sc0 sc1: written
 // through to memory / served from memory, as the compiler's own system-scope atomics are -- here 16 bytes at a time), so publishing
 // needs no L2 write-back and reading no L2 invalidate: a wave waits for its stores (s_waitcnt vmcnt(0)) before the counter that leads
-// to the flag.  FENCES (crec_comm_set_option "peer_fences", bench: CREC_PEER_FENCES=1): plain accesses bracketed by system-scope
-// release / acquire fences issued by ONE wave per workgroup behind a barrier -- the textbook form, kept selectable at run time; a
-// fence by every wave costs a full L2 write-back each (measured: 250 us for a 5 MB exchange).
-typedef unsigned peer_u4v __attribute__((ext_vector_type(4)));
-constexpr int AUX_SYS = 17; // sc0 | sc1
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void *base)
-{
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0x7fffffff, 0x00020000);
-}
+// to the flag.  FENCES (crec_comm_peer_fences, bench: CREC_PEER_FENCES=1): plain accesses bracketed by system-scope release /
+// acquire fences issued by ONE wave per workgroup behind a barrier -- the textbook form, kept selectable at run time; a fence by
+// every wave costs a full L2 write-back each (measured: 250 us for a 5 MB exchange).
 // dst / src: wave-uniform bases (< 2 GiB behind them); WIN_DST / WIN_SRC: which side is a window
 template <bool WIN_DST, bool WIN_SRC>
 __device__ __forceinline__ void copy_bytes(char *dst, const char *src, int64_t bytes, int64_t tid, int64_t nth, bool fences)
 {
-    const __amdgpu_buffer_rsrc_t rd = rsrc_of(dst), rs = rsrc_of(src);
     if ((((uintptr_t)dst | (uintptr_t)src | (uintptr_t)bytes) & 15) == 0) {
         const int64_t n = bytes >> 4;
         for (int64_t k = tid; k < n; k += nth) {
-            peer_u4v v;
-            if (WIN_SRC && !fences)
-                v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(k << 4), 0, AUX_SYS);
-            else
-                v = ((const peer_u4v *)src)[k];
-            if (WIN_DST && !fences)
-                __builtin_amdgcn_raw_buffer_store_b128(v, rd, (int)(k << 4), 0, AUX_SYS);
+            const peer_u4v v = WIN_SRC ? peer_ld16(src, k << 4, fences) : ((const peer_u4v *)src)[k];
+            if (WIN_DST)
+                peer_st16(dst, k << 4, v, fences);
             else
                 ((peer_u4v *)dst)[k] = v;
         }
     } else { // 4-byte elements
+        const __amdgpu_buffer_rsrc_t rd = peer_rsrc(dst), rs = peer_rsrc(src);
         const int64_t n = bytes >> 2;
         for (int64_t k = tid; k < n; k += nth) {
             unsigned v;
             if (WIN_SRC && !fences)
-                v = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(k << 2), 0, AUX_SYS);
+                v = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(k << 2), 0, PEER_AUX_SYS);
             else
                 v = ((const unsigned *)src)[k];
             if (WIN_DST && !fences)
-                __builtin_amdgcn_raw_buffer_store_b32(v, rd, (int)(k << 2), 0, AUX_SYS);
+                __builtin_amdgcn_raw_buffer_store_b32(v, rd, (int)(k << 2), 0, PEER_AUX_SYS);
             else
                 ((unsigned *)dst)[k] = v;
         }
     }
 }
 
-// mode bit 0: all-reduce of n floats (send = recv = the operand), else all-to-all-v; bit 1: FENCES; bit 2: the all-reduce in two shots.  Every workgroup takes its
-// grid-stride share of the copy-in and of every source's segment; at most PEER_MAX_BLOCKS workgroups, so that all of them are
-// resident at once (a workgroup that waits for a peer must not keep one of its own launch -- whose copy-in the peers wait for -- off
-// the machine).
-__global__ __launch_bounds__(PEER_THREADS) void peer_exchange(PeerArgs a, const char *__restrict__ send, char *__restrict__ recv,
-                                                              char *my_half, int64_t half_off, uint32_t seq, int rank, int world, int mode,
-                                                              int64_t n, unsigned long long timeout_ticks, int32_t *ctr, int32_t *err)
+// mode bit 0: all-reduce of n floats (send = recv = the operand), else all-to-all-v; bit 2: the all-reduce in two shots; bit 3: the
+// all-to-all-v's segments already lie in this rank's window half (crec_xch::next_half, at their send displacements): no copy-in,
+// workgroup 0 publishes at once -- and since no workgroup of such a launch waits for another one of it, its grid is not bounded.
+// Otherwise every workgroup takes its grid-stride share of the copy-in and of every source's segment, at most PEER_MAX_BLOCKS
+// workgroups, so that all of them are resident at once (a workgroup that waits for a peer must not keep one of its own launch --
+// whose copy-in the peers wait for -- off the machine).
+__global__ __launch_bounds__(PEER_THREADS) void peer_exchange(crec_peer_view v, PeerSegs a, const char *__restrict__ send, char *__restrict__ recv,
+                                                              int mode, int64_t n)
 {
     __shared__ unsigned long long flag_s[PEER_MAX];
     __shared__ int last_s, bad_s;
-    const bool reduce = mode & 1, fences = mode & 2;
-    const int tid = threadIdx.x, h = (int)(seq & 1u);
+    const bool reduce = mode & 1, fences = v.fences != 0;
+    const int tid = threadIdx.x, rank = v.rank, world = v.world;
     const int64_t gtid = (int64_t)blockIdx.x * PEER_THREADS + tid, gsz = (int64_t)gridDim.x * PEER_THREADS;
-    // 1. copy-in
-    for (int p = 0; p < (reduce ? 1 : world); ++p)
-        if (a.s_bytes[p] > 0)
-            copy_bytes<true, false>(my_half + a.w_off[p], send + a.s_off[p], a.s_bytes[p], gtid, gsz, fences);
-    // 2. publish, by the workgroup that finishes last
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's window stores are where the peers will read them (write-through form)
-    __syncthreads();
-    if (tid == 0) {
-        if (fences)
-            __threadfence_system(); // release: writes back what the whole workgroup left dirty in L2
-        bad_s = 0;
-        last_s = atomicAdd(ctr, 1) == (int)gridDim.x - 1;
+    // 1. copy-in (unless a previous kernel left the segments in the window half), 2. publish (by the workgroup that finishes its
+    // part of the copy last; at once where there was nothing to copy), 3. wait for every source's flag
+    if (!(mode & 8)) {
+        for (int p = 0; p < (reduce ? 1 : world); ++p)
+            if (a.s_bytes[p] > 0)
+                copy_bytes<true, false>(v.my_half + a.w_off[p], send + a.s_off[p], a.s_bytes[p], gtid, gsz, fences);
     }
-    __syncthreads();
-    if (last_s) {
-        if (tid == 0) {
-            if (fences)
-                __threadfence_system();
-            *ctr = 0; // the next launch on this stream starts from zero
-        }
-        __syncthreads();
-        if (tid < world)
-            __hip_atomic_store(a.sig[tid] + h * 2 * PEER_MAX + rank, ((unsigned long long)seq << 32) | (unsigned long long)(uint32_t)(a.w_off[reduce ? 0 : tid] >> 4),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    // 3. wait for every source's flag (in this rank's own signal block)
-    if (tid < world) {
-        const unsigned long long *mine = a.sig[rank] + h * 2 * PEER_MAX + tid;
-        const unsigned long long t0 = wall_clock64();
-        unsigned long long v;
-        for (;;) {
-            v = __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if ((uint32_t)(v >> 32) == seq)
-                break;
-            if (wall_clock64() - t0 > timeout_ticks) {
-                bad_s = 1;
-                atomicExch(err, 1 + tid);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(4);
-        }
-        flag_s[tid] = v;
-    }
-    __syncthreads();
-    if (bad_s)
+    peer_publish(v, 0, !(mode & 8), &last_s, [&](int p) { return a.w_off[reduce ? 0 : p]; });
+    if (!peer_wait_all(v, 0, flag_s, &bad_s))
         return;
-    if (fences) {
-        if (tid == 0)
-            __threadfence_system(); // acquire: nothing stale of the peers' windows is left in this CU's L1 / the L2
-        __syncthreads();
-    }
     // 4. pull: the peers behind this rank first, this rank's own segment last
     if (!reduce) {
         for (int s = 1; s <= world; ++s) {
             const int p = (rank + s) % world;
             if (a.r_bytes[p] > 0)
-                copy_bytes<false, true>(recv + a.r_off[p], a.win[p] + half_off + ((int64_t)(uint32_t)flag_s[p] << 4), a.r_bytes[p], gtid, gsz, fences);
+                copy_bytes<false, true>(recv + a.r_off[p], peer_seg(v, p, flag_s[p]), a.r_bytes[p], gtid, gsz, fences);
         }
     } else if (mode & 4) {
         // two-shot: this rank adds slice `rank` of all operands (rank order) into its window's result area and into `recv`, publishes
@@ -164,95 +109,46 @@ __global__ __launch_bounds__(PEER_THREADS) void peer_exchange(PeerArgs a, const 
         float4 *out = (float4 *)recv;
         {
             const int64_t k0 = (int64_t)rank * per, k1 = (k0 + per) < n4 ? (k0 + per) : n4;
-            const __amdgpu_buffer_rsrc_t rr = rsrc_of(my_half + roff);
             for (int64_t k = k0 + gtid; k < k1; k += gsz) {
-                peer_u4v v[PEER_MAX];
+                peer_u4v x[PEER_MAX];
 #pragma unroll
                 for (int p = 0; p < PEER_MAX; ++p)
-                    if (p < world) {
-                        const char *src = a.win[p] + half_off + ((int64_t)(uint32_t)flag_s[p] << 4);
-                        v[p] = fences ? ((const peer_u4v *)src)[k] : __builtin_amdgcn_raw_buffer_load_b128(rsrc_of(src), (int)(k << 4), 0, AUX_SYS);
-                    }
+                    if (p < world)
+                        x[p] = peer_ld16(peer_seg(v, p, flag_s[p]), k << 4, fences);
                 float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int p = 0; p < PEER_MAX; ++p)
                     if (p < world)
-                        acc = make_float4(acc.x + __uint_as_float(v[p].x), acc.y + __uint_as_float(v[p].y), acc.z + __uint_as_float(v[p].z),
-                                          acc.w + __uint_as_float(v[p].w));
+                        acc = make_float4(acc.x + __uint_as_float(x[p].x), acc.y + __uint_as_float(x[p].y), acc.z + __uint_as_float(x[p].z),
+                                          acc.w + __uint_as_float(x[p].w));
                 out[k] = acc;
                 const peer_u4v w = {__float_as_uint(acc.x), __float_as_uint(acc.y), __float_as_uint(acc.z), __float_as_uint(acc.w)};
-                if (fences)
-                    ((peer_u4v *)(my_half + roff))[k - k0] = w;
-                else
-                    __builtin_amdgcn_raw_buffer_store_b128(w, rr, (int)((k - k0) << 4), 0, AUX_SYS);
+                peer_st16(v.my_half + roff, (k - k0) << 4, w, fences);
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            if (fences)
-                __threadfence_system();
-            last_s = atomicAdd(ctr + 2, 1) == (int)gridDim.x - 1;
-        }
-        __syncthreads();
-        if (last_s) {
-            if (tid == 0) {
-                if (fences)
-                    __threadfence_system();
-                ctr[2] = 0;
-            }
-            __syncthreads();
-            if (tid < world)
-                __hip_atomic_store(a.sig[tid] + (h * 2 + 1) * PEER_MAX + rank, ((unsigned long long)seq << 32) | (unsigned long long)(uint32_t)(roff >> 4),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-        if (tid < world) {
-            const unsigned long long *mine = a.sig[rank] + (h * 2 + 1) * PEER_MAX + tid;
-            const unsigned long long t0 = wall_clock64();
-            unsigned long long v;
-            for (;;) {
-                v = __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                if ((uint32_t)(v >> 32) == seq)
-                    break;
-                if (wall_clock64() - t0 > timeout_ticks) {
-                    bad_s = 1;
-                    atomicExch(err, 1 + tid);
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(4);
-            }
-            flag_s[tid] = v;
-        }
-        __syncthreads();
-        if (bad_s)
+        peer_publish(v, 1, true, &last_s, [&](int) { return roff; });
+        if (!peer_wait_all(v, 1, flag_s, &bad_s))
             return;
-        if (fences) {
-            if (tid == 0)
-                __threadfence_system();
-            __syncthreads();
-        }
         for (int s = 1; s < world; ++s) {
             const int p = (rank + s) % world;
             const int64_t k0 = (int64_t)p * per, k1 = (k0 + per) < n4 ? (k0 + per) : n4;
             if (k0 < k1)
-                copy_bytes<false, true>((char *)(out + k0), a.win[p] + half_off + ((int64_t)(uint32_t)flag_s[p] << 4), (k1 - k0) << 4, gtid, gsz, fences);
+                copy_bytes<false, true>((char *)(out + k0), peer_seg(v, p, flag_s[p]), (k1 - k0) << 4, gtid, gsz, fences);
         }
     } else if ((n & 3) == 0 && ((uintptr_t)recv & 15) == 0) {
         float4 *out = (float4 *)recv;
         for (int64_t k = gtid; k < (n >> 2); k += gsz) {
-            peer_u4v v[PEER_MAX];
+            peer_u4v x[PEER_MAX];
 #pragma unroll
             for (int p = 0; p < PEER_MAX; ++p)
-                if (p < world) {
-                    const char *src = a.win[p] + half_off + ((int64_t)(uint32_t)flag_s[p] << 4);
-                    v[p] = fences ? ((const peer_u4v *)src)[k] : __builtin_amdgcn_raw_buffer_load_b128(rsrc_of(src), (int)(k << 4), 0, AUX_SYS);
-                }
+                if (p < world)
+                    x[p] = peer_ld16(peer_seg(v, p, flag_s[p]), k << 4, fences);
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int p = 0; p < PEER_MAX; ++p) // rank order: every rank forms the same sum
                 if (p < world)
-                    acc = make_float4(acc.x + __uint_as_float(v[p].x), acc.y + __uint_as_float(v[p].y), acc.z + __uint_as_float(v[p].z),
-                                      acc.w + __uint_as_float(v[p].w));
+                    acc = make_float4(acc.x + __uint_as_float(x[p].x), acc.y + __uint_as_float(x[p].y), acc.z + __uint_as_float(x[p].z),
+                                      acc.w + __uint_as_float(x[p].w));
             out[k] = acc;
         }
     } else {
@@ -260,8 +156,8 @@ __global__ __launch_bounds__(PEER_THREADS) void peer_exchange(PeerArgs a, const 
         for (int64_t k = gtid; k < n; k += gsz) {
             float acc = 0.f;
             for (int p = 0; p < world; ++p) {
-                const char *src = a.win[p] + half_off + ((int64_t)(uint32_t)flag_s[p] << 4);
-                acc = acc + __uint_as_float(fences ? ((const unsigned *)src)[k] : __builtin_amdgcn_raw_buffer_load_b32(rsrc_of(src), (int)(k << 2), 0, AUX_SYS));
+                const char *src = peer_seg(v, p, flag_s[p]);
+                acc = acc + __uint_as_float(fences ? ((const unsigned *)src)[k] : __builtin_amdgcn_raw_buffer_load_b32(peer_rsrc(src), (int)(k << 2), 0, PEER_AUX_SYS));
             }
             out[k] = acc;
         }
@@ -277,7 +173,7 @@ struct PeerState { // what a rank owns; shared by the ranks of an in-process gro
 
 struct PeerXch : crec_xch {
     PeerState own;
-    PeerArgs base{};       // win / sig of every rank as mapped here
+    crec_peer_view base{}; // win / sig of every rank as mapped here
     bool opened[PEER_MAX] = {false}; // mapped with hipIpcOpenMemHandle (to be closed)
     void *opened_win[PEER_MAX] = {nullptr}, *opened_sig[PEER_MAX] = {nullptr};
     int32_t *ctr = nullptr, *err = nullptr; // device: workgroup counter, error word
@@ -313,26 +209,43 @@ struct PeerXch : crec_xch {
                              e - 1, (double)timeout_ticks / 1e8);
         return CREC_OK;
     }
-    int launch(crec_ctx *ctx, PeerArgs &a, const void *send, void *recv, int mode, int64_t n, int64_t recv_total, hipStream_t st)
+    // the view of the next exchange; consumes its sequence number
+    bool begin(crec_peer_view *v) override
     {
-        CREC_REQUIRE(ctx, connected, "peer transport: crec_comm_peer_connect has not completed on this ctx");
+        if (!connected)
+            return false;
         ++seq;
         if (seq == 0)
             ++seq;
-        const int64_t half_off = (int64_t)(seq & 1u) * (own.win_bytes / 2);
-        int nb = (int)((recv_total + 16383) / 16384); // 16 KiB of the larger side per workgroup
-        nb = nb < 1 ? 1 : (nb > PEER_MAX_BLOCKS ? PEER_MAX_BLOCKS : nb);
-        hipLaunchKernelGGL(peer_exchange, dim3((unsigned)nb), dim3(PEER_THREADS), 0, st, a, (const char *)send, (char *)recv,
-                           own.win + half_off, half_off, seq, rank, world, mode | (fences ? 2 : 0), n, timeout_ticks, ctr, err);
+        *v = base;
+        v->half_off = (int64_t)(seq & 1u) * (own.win_bytes / 2);
+        v->my_half = own.win + v->half_off;
+        v->seq = seq;
+        v->rank = rank;
+        v->world = world;
+        v->fences = fences ? 1 : 0;
+        v->timeout_ticks = timeout_ticks;
+        v->ctr = ctr;
+        v->err = err;
+        return true;
+    }
+    // where a producer kernel may leave the segments of the NEXT exchange (which then skips its copy-in)
+    char *next_half() override { return connected ? own.win + (int64_t)((seq + 1 == 0 ? 1u : seq + 1) & 1u) * (own.win_bytes / 2) : nullptr; }
+    int launch(crec_ctx *ctx, PeerSegs &a, const void *send, void *recv, int mode, int64_t n, int64_t work_bytes, hipStream_t st)
+    {
+        CREC_REQUIRE(ctx, connected, "peer transport: crec_comm_peer_connect has not completed on this ctx");
+        crec_peer_view v;
+        begin(&v);
+        int nb = (int)((work_bytes + 16383) / 16384); // 16 KiB of the larger side per workgroup
+        const int cap = (mode & 8) ? 8 * PEER_MAX_BLOCKS : PEER_MAX_BLOCKS;
+        nb = nb < 1 ? 1 : (nb > cap ? cap : nb);
+        hipLaunchKernelGGL(peer_exchange, dim3((unsigned)nb), dim3(PEER_THREADS), 0, st, v, a, (const char *)send, (char *)recv, mode, n);
         CREC_HIP(ctx, hipGetLastError());
         return CREC_OK;
     }
-    int alltoallv(crec_ctx *ctx, const void *send, const int64_t *scnt, const int64_t *sdsp, void *recv, const int64_t *rcnt,
-                  const int64_t *rdsp, int elem_bytes, hipStream_t st) override
+    int segs(crec_ctx *ctx, PeerSegs &a, const int64_t *scnt, const int64_t *sdsp, const int64_t *rcnt, const int64_t *rdsp, int64_t *work)
     {
-        CREC_REQUIRE(ctx, elem_bytes == 4, "exchange: 4-byte elements");
         CREC_REQUIRE(ctx, scnt[rank] == rcnt[rank], "exchange: a rank's segment to itself has two sizes");
-        PeerArgs a = base;
         int64_t at = 0, rtot = 0;
         for (int p = 0; p < world; ++p) {
             CREC_REQUIRE(ctx, scnt[p] >= 0 && rcnt[p] >= 0, "exchange: negative count");
@@ -346,17 +259,40 @@ struct PeerXch : crec_xch {
         }
         CREC_REQUIRE(ctx, at <= own.win_bytes / 2, "peer transport: an exchange of %lld bytes does not fit half of the %lld-byte window",
                      (long long)at, (long long)own.win_bytes);
-        return launch(ctx, a, send, recv, 0, 0, rtot > at ? rtot : at, st);
+        *work = rtot > at ? rtot : at;
+        return CREC_OK;
+    }
+    int alltoallv(crec_ctx *ctx, const void *send, const int64_t *scnt, const int64_t *sdsp, void *recv, const int64_t *rcnt,
+                  const int64_t *rdsp, int elem_bytes, hipStream_t st) override
+    {
+        CREC_REQUIRE(ctx, elem_bytes == 4, "exchange: 4-byte elements");
+        PeerSegs a{};
+        int64_t work = 0;
+        if (int rc = segs(ctx, a, scnt, sdsp, rcnt, rdsp, &work))
+            return rc;
+        return launch(ctx, a, send, recv, 0, 0, work, st);
+    }
+    // the segments already lie in next_half() at their send displacements (16-byte aligned), written by a previous kernel on st
+    int alltoallv_inplace(crec_ctx *ctx, const int64_t *scnt, const int64_t *sdsp, void *recv, const int64_t *rcnt, const int64_t *rdsp,
+                          hipStream_t st) override
+    {
+        PeerSegs a{};
+        int64_t work = 0;
+        if (int rc = segs(ctx, a, scnt, sdsp, rcnt, rdsp, &work))
+            return rc;
+        for (int p = 0; p < world; ++p) {
+            CREC_REQUIRE(ctx, (a.s_off[p] & 15) == 0 && a.s_off[p] + a.s_bytes[p] <= own.win_bytes / 2, "in-place exchange: 16-byte aligned segments inside the window half");
+            a.w_off[p] = a.s_off[p];
+        }
+        return launch(ctx, a, nullptr, recv, 8, 0, work, st);
     }
     int allreduce_sum_f32(crec_ctx *ctx, float *buf, size_t n, hipStream_t st) override
     {
         if (n == 0)
             return CREC_OK;
         CREC_REQUIRE(ctx, (int64_t)n * 4 <= own.win_bytes / 2, "peer transport: an all-reduce of %zu floats does not fit half of the window", n);
-        PeerArgs a = base;
-        a.s_off[0] = 0;
+        PeerSegs a{};
         a.s_bytes[0] = (int64_t)n * 4;
-        a.w_off[0] = 0;
         // from three ranks and 64 KiB on, in two shots (every rank adds one slice and the slices are gathered): same sums, same order
         const int64_t per16 = (((int64_t)n / 4 + world - 1) / world) * 16;
         const bool two = two_shot && world >= 3 && (n & 3) == 0 && ((uintptr_t)buf & 15) == 0 && (int64_t)n * 4 >= (64 << 10) &&

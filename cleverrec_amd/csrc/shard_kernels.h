@@ -195,3 +195,85 @@ __global__ __launch_bounds__(256) void shard_owner_apply(float *__restrict__ Q, 
     st4(mQ + ro, m);
     st4(vQ + ro, v);
 }
+
+// ---- over the peer transport (crec_peer.hip) the two exchanges of a step fuse with the kernels around them ----------------------------
+//   forward   shard_serve_rows stages the requested rows straight in this rank's window (crec_xch::next_half) and the exchange
+//             (crec_xch::alltoallv_inplace) starts from there: no copy-in, every rank pulls its requests from the owners' windows;
+//   backward  the step kernel leaves the gradient rows of its compact table in this rank's window (crec_xch::next_half: the compact
+//             table's layout, owner o's segment at row req_off[o]); shard_exchange_apply publishes them, waits for the peers, and every
+//             lane group adds its row's gradient rows STRAIGHT FROM THE REQUESTERS' WINDOWS in peer order, then lazy Adam in place.
+// Four launches per step instead of five, and no second copy of rows or gradient rows on either side.
+struct ShardPeerOffs {
+    int64_t seg_off[PEER_MAX];   // bytes: where owner o's segment starts in my gradient rows (= req_off[o] * d * 4)
+    int32_t slot_base[PEER_MAX + 1]; // my serve layout: peer p's slots are [slot_base[p], slot_base[p + 1])
+};
+__global__ __launch_bounds__(PEER_THREADS) void shard_exchange_apply(crec_peer_view pv, ShardPeerOffs so, float *__restrict__ Q, float *__restrict__ mQ,
+                                                                     float *__restrict__ vQ, const int32_t *__restrict__ urows,
+                                                                     const int32_t *__restrict__ useg, const int32_t *__restrict__ order,
+                                                                     const int32_t *__restrict__ n_urows_p, int d, int lpr, Hyper h)
+{
+    __shared__ unsigned long long flag_s[PEER_MAX];
+    __shared__ int last_s, bad_s, base_s[PEER_MAX + 1];
+    if (threadIdx.x <= PEER_MAX)
+        base_s[threadIdx.x] = so.slot_base[threadIdx.x < pv.world ? threadIdx.x : pv.world];
+    peer_publish(pv, 0, false, &last_s, [&](int p) { return so.seg_off[p]; });
+    const int64_t t = (int64_t)blockIdx.x * PEER_THREADS + threadIdx.x, groups = (int64_t)gridDim.x * PEER_THREADS / lpr;
+    const int l = (int)(t % lpr), nq = *n_urows_p;
+    const bool act = 4 * l < d;
+    const bool fences = pv.fences != 0;
+    // the row, its slots and its slot list do not depend on the peers: asked for before the wait (the usual launch has a lane group
+    // per row, so this is all of the owner's own traffic)
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    int64_t q = t / lpr;
+    int64_t ro = q < nq ? (int64_t)urows[q] * d + 4 * l : 0;
+    int k0 = q < nq ? useg[q] : 0, k1 = q < nq ? useg[q + 1] : 0;
+    float4 var = (q < nq && act) ? ld4(Q + ro) : zero4, m = (q < nq && act) ? ld4(mQ + ro) : zero4, v = (q < nq && act) ? ld4(vQ + ro) : zero4;
+    if (!peer_wait_all(pv, 0, flag_s, &bad_s))
+        return;
+    for (; q < nq; q += groups) {
+        if (q != t / lpr) {
+            ro = (int64_t)urows[q] * d + 4 * l;
+            k0 = useg[q];
+            k1 = useg[q + 1];
+            var = act ? ld4(Q + ro) : zero4;
+            m = act ? ld4(mQ + ro) : zero4;
+            v = act ? ld4(vQ + ro) : zero4;
+        }
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        const auto where = [&](int slot) {
+            int p = 0;
+            while (p + 1 < pv.world && slot >= base_s[p + 1])
+                ++p;
+            // requester p keeps the rows it asked of me in the order it asked: the order I serve them in
+            return peer_seg(pv, p, flag_s[p]) + ((int64_t)(slot - base_s[p]) * d + 4 * l) * 4;
+        };
+        if (k1 - k0 == 1) { // the usual row: one requester
+            if (act) {
+                const peer_u4v c = peer_ld16_at(where(order[k0]), fences);
+                g = make_float4(0.f + __uint_as_float(c.x), 0.f + __uint_as_float(c.y), 0.f + __uint_as_float(c.z), 0.f + __uint_as_float(c.w));
+            }
+            k0 = k1;
+        }
+        for (int k = k0; k < k1; k += 8) { // up to eight requesters' rows in flight, added in slot (= peer) order
+            const char *addr[8];
+            peer_u4v c[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                addr[e] = pv.my_half;
+                if (k + e < k1 && act)
+                    addr[e] = where(order[k + e]);
+            }
+            peer_ld16x8(addr, c, fences);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (k + e < k1)
+                    add4(g, make_float4(__uint_as_float(c[e].x), __uint_as_float(c[e].y), __uint_as_float(c[e].z), __uint_as_float(c[e].w)));
+        }
+        if (act) {
+            adam4(var, m, v, g, true, h);
+            st4(Q + ro, var);
+            st4(mQ + ro, m);
+            st4(vQ + ro, v);
+        }
+    }
+}

@@ -125,7 +125,10 @@ def main():
         all_ex = [None] * world
         dist.all_gather_object(all_ex, ex)
         out["exchanges_ok"] = all(all(e) for e in all_ex)
-        out["sharded"] = sharded(sess, rank, world)
+        out["sharded"] = sharded(sess, rank, world)  # exchanges fused with serve / apply (three launches per step)
+        sess.ctx.set_option("shard_unfused", 1)
+        out["sharded_unfused"] = sharded(sess, rank, world)  # the five-launch form over the same transport
+        sess.ctx.set_option("shard_unfused", 0)
         out["dp"] = data_parallel(sess, rank, world)
         dist.barrier()
         sess.close()

@@ -30,8 +30,8 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_ranks_as_processes_over_ipc_windows(world):
+@pytest.mark.parametrize("world,fences", [(2, 0), (3, 0), (2, 1)])
+def test_ranks_as_processes_over_ipc_windows(world, fences):
     """(Not more ranks on ONE GPU: a rank's launch waits inside the GPU for its peers' launches, so all ranks' workgroups have to be
     resident together -- one per CU and rank; four ranks' worth do not fit a CU's registers, and the waits then run into their
     time-out.  One process per GPU, the production layout, has the CU to itself.)"""
@@ -39,7 +39,7 @@ def test_ranks_as_processes_over_ipc_windows(world):
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", CREC_PEER_FENCES=str(fences))
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_peer_worker.py")], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
     outs = []
@@ -56,8 +56,9 @@ def test_ranks_as_processes_over_ipc_windows(world):
     assert line, outs[0][0][-2000:]
     res = json.loads(line[0][len("PEER_RESULT "):])
     assert res["exchanges_ok"]
-    sh, dp = res["sharded"], res["dp"]
-    assert sh["loss_ok"] and sh["same_loss_everywhere"] and sh["P_err"] <= 2e-6 and sh["Q_err"] <= 2e-6, sh
+    dp = res["dp"]
+    for sh in (res["sharded"], res["sharded_unfused"]):
+        assert sh["loss_ok"] and sh["same_loss_everywhere"] and sh["P_err"] <= 2e-6 and sh["Q_err"] <= 2e-6, sh
     assert dp["replicas_identical"] and dp["loss_ok"] and dp["P_err"] <= 2e-6 and dp["Q_err"] <= 2e-6, dp
 
 

@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def run(users=10_000_000, items=1_000_000, dim=128, steps=300, warmup=30, batch=6144, sess=None, seed=0):
+def run(users=10_000_000, items=1_000_000, dim=128, steps=300, warmup=30, batch=6144, sess=None, seed=0, zipf=True):
     import torch
     from cleverrec_amd import _lib, runtime
     sess = sess or runtime.Session(0)
@@ -40,6 +40,8 @@ def run(users=10_000_000, items=1_000_000, dim=128, steps=300, warmup=30, batch=
     w = 1.0 / torch.arange(1, items + 1, dtype=torch.float64, device=dev)
     cdf = torch.cumsum(w / w.sum(), 0)
     i = torch.searchsorted(cdf, torch.rand(n, generator=g, device=dev, dtype=torch.float64)).clamp_(max=items - 1).to(torch.int32)
+    if not zipf:  # experiment: uniform positives (hardly any row occurs twice in a batch: the triple pass's main line alone)
+        i = torch.randint(0, items, (n,), generator=g, device=dev, dtype=torch.int64).to(torch.int32)
     j = torch.randint(0, items, (n,), generator=g, device=dev, dtype=torch.int64).to(torch.int32)
     del cdf, w
 
@@ -109,6 +111,10 @@ def run_sharded(users=10_000_000, items=1_000_000, dim=128, steps=200, warmup=30
     dev = sess.device
     barrier = barrier or torch.cuda.synchronize
     max_reduce = max_reduce or (lambda x: x)
+    transport = "the ctx's communicator" if world > 1 else "none (device copies)"
+    if world == 1 and os.environ.get("CREC_TRANSPORT") == "peer":  # a world of one over the peer windows: what the fused exchange kernels cost by themselves
+        parallel.init_peer(sess, 0, 1, window_bytes=64 << 20)
+        transport = "peer windows, a world of one" + (" (five launches per step)" if os.environ.get("CREC_SHARD_UNFUSED") == "1" else " (exchanges fused with serve / apply)")
     g = torch.Generator(device=dev).manual_seed(seed + 1000 * rank)
     lo, hi = parallel.user_range(users, rank, world)
     S = parallel.shard_rows(items, world)
@@ -149,7 +155,7 @@ def run_sharded(users=10_000_000, items=1_000_000, dim=128, steps=200, warmup=30
     out = {
         "workload": "S-big row-sharded: %d users x %d items over %d rank(s), d=%d fp32, batch %d per rank per step, lazy Adam, "
                     "Zipf(1.0) positives" % (users, items, world, dim, batch),
-        "world": world, "triples_per_s": steps * batch * world / dt, "us_per_step": dt / steps * 1e6, "steps": steps,
+        "world": world, "transport": transport, "triples_per_s": steps * batch * world / dt, "us_per_step": dt / steps * 1e6, "steps": steps,
         "exchange_per_rank_per_step": per_step, "max_rows_served_per_batch": stats["max_rows_served_per_batch"],
         "kernel_avg_us": kern, "loss_first_last": [float(loss[0]), float(loss[-1])],
         "exchange": "per chunk: request lists (all-to-all-v); per step: rows forward, gradient rows back (2 all-to-all-v)",
@@ -166,9 +172,10 @@ if __name__ == "__main__":
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--batch", type=int, default=6144)
+    ap.add_argument("--uniform", action="store_true", help="uniform positives instead of Zipf(1.0): hardly any multi-occurrence rows")
     ap.add_argument("--sharded", action="store_true", help="the row-sharded epoch on a world of one (protocol cost)")
     a = ap.parse_args()
     if a.sharded:
         print(json.dumps(run_sharded(a.users, a.items, a.dim, a.steps, batch=a.batch)))
     else:
-        print(json.dumps(run(a.users, a.items, a.dim, a.steps, batch=a.batch)))
+        print(json.dumps(run(a.users, a.items, a.dim, a.steps, batch=a.batch, zipf=not a.uniform)))

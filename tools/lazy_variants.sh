@@ -9,6 +9,6 @@ for v in "$@"; do
         -c cleverrec_amd/csrc/bpr_train.hip -o $out/bpr_train.o || exit 1
   objs=$(ls $O/*.o | grep -v "/bpr_train.o")
   hipcc --offload-arch=gfx950 -shared -o $out/libcrec.so $objs $out/bpr_train.o -L/opt/rocm/lib -lrccl || exit 1
-  for ch in "$@"; do CREC_LIB=$out/libcrec.so CREC_CH=$ch python tools/bench_big.py --steps 300 2>/dev/null | python -c "
+  for ch in "$@"; do CREC_LIB=$out/libcrec.so CREC_CH=$ch python tools/bench_big.py --steps 300 $CREC_BIG_ARGS 2>/dev/null | python -c "
 import json,sys; d=json.load(sys.stdin); print('deep $deep $CREC_DEFS ch $ch:', round(d['triples_per_s']/1e6,1), 'Mtr/s', round(d['us_per_step'],2), 'us/step kernel', round(d['bpr_triples_lazy']['avg_us'],2), 'us', round(d['step_algorithmic_bytes']/d['bpr_triples_lazy']['avg_us']/1e3/8000,3), 'of 8 TB/s')"; done
 done
