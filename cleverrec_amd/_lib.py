@@ -141,6 +141,7 @@ _SIGNATURES = {
     "crec_shard_plan_host": (C.c_int, [_vp, _vp, _i32, _i32, _i64, _vp, C.POINTER(_i32), _vp, _vp, _vp, _vp]),
     "crec_shard_owner_index_host": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, C.POINTER(_i32)]),
     "crec_debug_shard_plan": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "crec_debug_lazy_index": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "crec_debug_shard_owner_index": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp]),
     "crec_eval_topk": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "crec_rank_metrics": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),

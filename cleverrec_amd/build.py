@@ -26,6 +26,7 @@ SOURCES = {
     "mt_jump.cpp": ["-pthread"],
     "mt_sampler.hip": [],
     "bpr_train.hip": ["-ffp-contract=off"],
+    "index_big.hip": [],
     "eval_topk.hip": [],
     "rows_adam.hip": ["-ffp-contract=off"],
     "ncf.hip": ["-ffp-contract=off"],

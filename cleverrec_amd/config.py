@@ -60,7 +60,9 @@ def grid(configs):
 # .properties file beyond them is refused HERE, when the model object is built, with the key, the value and the limit
 # -- not as a CREC_EINVAL from the middle of an epoch.
 LIMITS = {
-    "batch_size": 8192,   # a batch's (row, slot) pairs are sorted in LDS: 2 * batch_size <= 16384 pairs
+    "batch_size": 8192,   # every model but BPR: a batch's (row, slot) pairs are sorted in LDS, 2 * batch_size <= 16384 pairs
+    "batch_size_bpr": 1 << 19,  # BPR: beyond 8192 the batch's index is built in global memory (csrc/index_big.hip); the limit is
+                                # what the index descriptors' fields hold
     "topk": 128,          # the fused evaluation ranks 32 candidates per user and pass, up to four passes
     "embed_size": 256,    # table rows are walked as float4 slices by at most 64 lanes
 }
@@ -72,8 +74,9 @@ def validate(configs, extra_width=0):
     def bad(key, value, why):
         raise ValueError("%s = %s: %s (this build's limit; see cleverrec_amd/config.py LIMITS and include/crec.h)" % (key, value, why))
     b = int(configs["batch_size"])
-    if not 1 <= b <= LIMITS["batch_size"]:
-        bad("batch_size", b, "batches of 1..%d instances" % LIMITS["batch_size"])
+    b_max = LIMITS["batch_size_bpr" if configs.get("recommender") == "BPR" else "batch_size"]
+    if not 1 <= b <= b_max:
+        bad("batch_size", b, "batches of 1..%d instances" % b_max)
     ks = parse_list(configs["topk"], int)
     if not ks or ks != sorted(ks) or ks[0] < 1 or ks[-1] > LIMITS["topk"]:
         bad("topk", configs["topk"], "an ascending list of cut-offs in 1..%d" % LIMITS["topk"])

@@ -49,6 +49,7 @@
 #include <cstring>
 #include "crec_internal.h"
 #include "block_sort.h"
+#include "lazy_desc.h"
 #include "crec_comm.h"
 
 #include <rccl/rccl.h>
@@ -56,7 +57,7 @@
 namespace {
 
 constexpr int PREP_THREADS = 1024;
-constexpr int MAX_B = 8192;
+constexpr int MAX_B = 8192; // triples per batch bpr_index_batches sorts in LDS; larger batches: index_big.hip (lazy-family steps)
 #ifndef CREC_UNR
 #define CREC_UNR 2
 #endif
@@ -367,7 +368,7 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
             int4 *dst = side == 0 ? w.u_desc : (slot < nb ? w.i_desc : w.j_desc);
             int4 *dst_tmp = side == 0 ? dst : (slot < nb ? w.i_tmp : w.j_tmp);
             dst_tmp[(int64_t)batch * B + (slot < nb ? slot : slot - nb)] =
-                make_int4((int)(rows[start] | (cnt == 1 ? 0x80000000u : 0u)), k | (front ? (first % SPW) << 16 : 0), start, cnt | (ci << 16));
+                lazy_desc_pack(rows[start], cnt == 1, k, start, cnt, ci, front ? first % SPW : 0);
             if (side == 1 && slot < nb) {
                 if (front) { // (k - start < ci: a positive slot of a front row)
                     ord[first + (k - start)] = slot;
@@ -1617,7 +1618,7 @@ struct LazyTicket {
 };
 __device__ __forceinline__ LazyTicket lazy_ticket_of(int4 desc, int CH)
 {
-    const int k = desc.y & 0xffff, start = desc.z, cnt = desc.w & 0xffff, ci = desc.w >> 16;
+    const int k = lazy_desc_k(desc), start = lazy_desc_start(desc), cnt = lazy_desc_cnt(desc), ci = lazy_desc_ci(desc);
     LazyTicket q;
     q.chunked = ci == 0 && cnt > CH;
     q.idx = q.chunked ? start + (k - start) / CH * CH : start;
@@ -1665,7 +1666,7 @@ __device__ __forceinline__ void lazy_role_tail(const Tables &t, int d, bool act,
                                                const Hyper &h)
 {
     const int lane = threadIdx.x & 63, l = lane % LPR, lead = lane - l;
-    const int start = desc.z, cnt = desc.w & 0xffff, ci = desc.w >> 16;
+    const int start = lazy_desc_start(desc), cnt = lazy_desc_cnt(desc), ci = lazy_desc_ci(desc);
     const LazyTicket q = lazy_ticket_of(desc, CH);
     if (old + weight != q.need)
         return;
@@ -1683,7 +1684,7 @@ __device__ __forceinline__ void lazy_role_tail(const Tables &t, int d, bool act,
     if (ci > 0) { // a front row: one partial per piece of its positive slots (l2 terms inside) -- the first piece ends at the
         // workgroup boundary behind the row's first slot, the others are whole workgroups --, then its negative slots
         if (act)
-            g = lazy_sum_front(cbuf, d, l, start, ci, cnt, desc.y >> 16, SPW, regrow);
+            g = lazy_sum_front(cbuf, d, l, start, ci, cnt, lazy_desc_hmod(desc), SPW, regrow);
     } else if (act) {
         g = lazy_sum_rows(cbuf, (int64_t)q.idx * d + 4 * l, q.need, d, regrow);
     }
@@ -1747,7 +1748,7 @@ __global__ __launch_bounds__(LazyGeo<LPR>::THREADS) void bpr_triples_lazy(Tables
     const bool item_adam = h.dQ == nullptr; // the row-sharded step only emits the item rows' gradient sums
     // front region: the piece of this slot's row inside this workgroup starts at the row's first slot or at the workgroup's;
     // the group of that slot leads the piece.  A piece that is the whole row is finished on the spot: its leader wants the slots
-    const int i_k = di.y & 0xffff, i_posr = i_k - di.z, i_ci = di.w >> 16, i_cnt = di.w & 0xffff;
+    const int i_k = lazy_desc_k(di), i_posr = i_k - lazy_desc_start(di), i_ci = lazy_desc_ci(di), i_cnt = lazy_desc_cnt(di);
     const bool blk_lead = front && (gw == 0 || i_posr == 0);
     const int blk_n = blk_lead ? ((i_ci - i_posr) < (SPW - gw) ? (i_ci - i_posr) : (SPW - gw)) : 0; // the piece's slots = the leader's weight
     const bool blk_whole = blk_lead && blk_n == i_cnt; // the row lies inside this workgroup: no ticket, no memory round trip
@@ -1827,11 +1828,11 @@ __global__ __launch_bounds__(LazyGeo<LPR>::THREADS) void bpr_triples_lazy(Tables
     const bool i_publish = !is && (!front || (blk_lead && !blk_whole)); // front region: only a piece's leader speaks for the row
     if (on && !(CREC_LAZY_ABL & 2)) {
         if (!us)
-            st4_pub(z.ucontrib, (int64_t)(du.y & 0xffff) * d + 4 * l, cu);
+            st4_pub(z.ucontrib, (int64_t)lazy_desc_k(du) * d + 4 * l, cu);
         if (i_publish)
             st4_pub(z.qcontrib, (int64_t)i_k * d + 4 * l, front ? blk_sum : nsp);
         if (!js)
-            st4_pub(z.qcontrib, (int64_t)(dj.y & 0xffff) * d + 4 * l, sp);
+            st4_pub(z.qcontrib, (int64_t)lazy_desc_k(dj) * d + 4 * l, sp);
     }
     // 2. the tickets of all three roles at once (one round trip, not three).  The contribution rows travel with
     // agent-scope stores; the wave waits for their completion first -- the same guarantee as a release fence for these
@@ -2189,7 +2190,10 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
     CREC_REQUIRE(ctx, t->P && t->Q && t->mP && t->vP && t->mQ && t->vQ, "null table pointer");
     CREC_REQUIRE(ctx, t->d >= 4 && t->d <= 256 && t->d % 4 == 0, "embed_size %d: need a multiple of 4 in [4, 256]", t->d);
     CREC_REQUIRE(ctx, t->U >= 1 && t->I >= 1 && t->U < ((int64_t)1 << 31) && t->I < ((int64_t)1 << 31), "table rows");
-    CREC_REQUIRE(ctx, B >= 1 && B <= MAX_B, "batch_size %d: this build indexes batches of at most %d in LDS", B, MAX_B);
+    CREC_REQUIRE(ctx, B >= 1 && B <= LAZY_MAX_B, "batch_size %d: batches of 1..%d triples", B, LAZY_MAX_B);
+    CREC_REQUIRE(ctx, B <= MAX_B || opt->adam_mode != CREC_ADAM_TF1,
+                 "batch_size %d with adam_mode tf1: the swept step indexes batches of at most %d in LDS; larger batches run as adam_mode deferred "
+                 "(the same results with sparse traffic), lazy, SGD or Adagrad", B, MAX_B);
     CREC_REQUIRE(ctx, opt->adam_mode == CREC_ADAM_TF1 || opt->adam_mode == CREC_ADAM_LAZY || opt->adam_mode == CREC_OPT_SGD ||
                           opt->adam_mode == CREC_OPT_ADAGRAD || opt->adam_mode == CREC_ADAM_DEFERRED, "adam_mode");
     CREC_REQUIRE(ctx, (opt->adam_mode == CREC_ADAM_DEFERRED) == (df != nullptr),
@@ -2239,6 +2243,10 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
     // chunk the epoch so the inverted indices of a chunk stay under ~1 GiB
     const size_t per_batch = layout_index(nullptr, 1, B, t->U, t->I, dense, CH, wide_rows, wide_total).bytes;
     int64_t chunk = (int64_t)((size_t)1 << 30) / (int64_t)per_batch;
+    // batches beyond the LDS sort (and any batch under the "big_index" option) are indexed in global memory, a chunk at a time
+    const bool big_index = !dense && (B > MAX_B || ctx->knob_big_index);
+    if (big_index && chunk * B > ((int64_t)1 << 22)) // its scratch: ~100 bytes per triple of the chunk
+        chunk = ((int64_t)1 << 22) / B;
     chunk = chunk < 1 ? 1 : (chunk > nb ? nb : chunk);
     if (int rc = crec_reserve(ctx, &ctx->idx_ws, layout_index(nullptr, chunk, B, t->U, t->I, dense, CH, wide_rows, wide_total).bytes))
         return rc;
@@ -2292,7 +2300,7 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
 
     // dynamic LDS of the index kernel
     const int cap = (2 * B + 63) / 64 * 64;
-    const size_t lds = index_lds_bytes(cap);
+    const size_t lds = big_index ? 0 : index_lds_bytes(cap);
     if (lds > ctx->index_lds_set) { // a driver call per epoch otherwise
         CREC_HIP(ctx, hipFuncSetAttribute((const void *)bpr_index_batches, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)lds));
@@ -2370,10 +2378,16 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
         w.done = ctx->idx_done;
         w.seq = zero_copy ? ++ctx->idx_seq : 0;
         w.n_back = (int32_t)n_back;
-        crec_prof_begin(ctx, CREC_K_INDEX, st);
-        CREC_KLAUNCH(ctx, bpr_index_batches, dim3((unsigned)(2 * nbc)), dim3(PREP_THREADS), lds, st, u + t0, i + t0,
-                           j + t0, n_chunk, B, cap, w);
-        crec_prof_end(ctx, st);
+        if (big_index) {
+            const LazyIndexOut o{w.u_desc, w.i_desc, w.j_desc, w.i_tmp, w.j_tmp, w.slot_pu, w.order, w.nslots};
+            if (int rc = crec_lazy_index_big(ctx, u + t0, i + t0, j + t0, n_chunk, B, nbc, w.bits_u, w.bits_q, w.spw, o, st))
+                return rc;
+        } else {
+            crec_prof_begin(ctx, CREC_K_INDEX, st);
+            CREC_KLAUNCH(ctx, bpr_index_batches, dim3((unsigned)(2 * nbc)), dim3(PREP_THREADS), lds, st, u + t0, i + t0,
+                               j + t0, n_chunk, B, cap, w);
+            crec_prof_end(ctx, st);
+        }
         // tf1 mode: the chunk's counts of heavy-row chunks and wide groups size the launches.  They arrive in page-locked
         // memory written by the kernel itself (above); the host polls the flag -- a device-to-host copy plus a stream
         // synchronisation cost ~15 us per call, a tenth of a 20-batch call.  (Lazy mode has nothing to read back: its
@@ -2746,6 +2760,10 @@ int sharded_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, int64_t I_global
             return rc;
         for (int q = 0; q < G; ++q)
             sent_ids += q == me ? 0 : 4 * (scnt[q] + nbc);
+        // the request lists are row ids the kernels below index Q with: a peer that never delivered them (a transport that waits inside
+        // its kernels gives up after its time-out and leaves the receive buffer as it was) must be an error here, not an address
+        if (int rc = x->status(ctx, st))
+            return rc;
         // 5. owner-side index of every batch, then the occurrence index over the compact ids
         const int cap_srv = (int)stride;
         CREC_HIP(ctx, hipFuncSetAttribute((const void *)shard_owner_index, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -3009,6 +3027,46 @@ int crec_debug_shard_owner_index(crec_ctx *ctx, const int32_t *ids_recv, const i
     }
     (void)hipFree(tmp);
     CREC_HIP(ctx, e);
+    CREC_HIP(ctx, hipGetLastError());
+    return CREC_OK;
+}
+
+int crec_debug_lazy_index(crec_ctx *ctx, const int32_t *u, const int32_t *i, const int32_t *j, int64_t N, int32_t B, int64_t U, int64_t I,
+                          int32_t d, int32_t big, int32_t *u_desc, int32_t *i_desc, int32_t *j_desc, int32_t *slot_pu, int32_t *nslots,
+                          void *stream)
+{
+    if (!ctx)
+        return CREC_EINVAL;
+    CREC_REQUIRE(ctx, ctx->device >= 0, "host-only ctx: no device bound");
+    CREC_REQUIRE(ctx, u && i && j && u_desc && i_desc && j_desc && slot_pu && nslots && N >= 1, "null argument");
+    CREC_REQUIRE(ctx, B >= 1 && (big ? B <= LAZY_MAX_B : B <= MAX_B) && U >= 1 && I >= 1 && d >= 4 && d <= 256, "shape");
+    CREC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t nbc = crec_ceil_div(N, B);
+    if (int rc = crec_reserve(ctx, &ctx->idx_ws, layout_index(nullptr, nbc, B, U, I, false, 16).bytes))
+        return rc;
+    const IndexWs w = layout_index(ctx->idx_ws.ptr, nbc, B, U, I, false, 16, 0, 0, lazy_spw(d));
+    CREC_HIP(ctx, hipMemsetAsync(ctx->idx_ws.ptr, 0xff, w.bytes, st)); // (a partial last batch leaves its tail as it is: the same on both sides)
+    if (big) {
+        const LazyIndexOut o{w.u_desc, w.i_desc, w.j_desc, w.i_tmp, w.j_tmp, w.slot_pu, w.order, w.nslots};
+        if (int rc = crec_lazy_index_big(ctx, u, i, j, N, B, nbc, w.bits_u, w.bits_q, w.spw, o, st))
+            return rc;
+    } else {
+        const int cap = (2 * B + 63) / 64 * 64;
+        const size_t lds = index_lds_bytes(cap);
+        if (lds > ctx->index_lds_set) {
+            CREC_HIP(ctx, hipFuncSetAttribute((const void *)bpr_index_batches, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            ctx->index_lds_set = lds;
+        }
+        hipLaunchKernelGGL(bpr_index_batches, dim3((unsigned)(2 * nbc)), dim3(PREP_THREADS), lds, st, u, i, j, N, B, cap, w);
+    }
+    const size_t n = (size_t)nbc * B;
+    CREC_HIP(ctx, hipMemcpyAsync(u_desc, w.u_desc, sizeof(int4) * n, hipMemcpyDeviceToDevice, st));
+    CREC_HIP(ctx, hipMemcpyAsync(i_desc, w.i_desc, sizeof(int4) * n, hipMemcpyDeviceToDevice, st));
+    CREC_HIP(ctx, hipMemcpyAsync(j_desc, w.j_desc, sizeof(int4) * n, hipMemcpyDeviceToDevice, st));
+    CREC_HIP(ctx, hipMemcpyAsync(slot_pu, w.slot_pu, sizeof(int2) * n, hipMemcpyDeviceToDevice, st));
+    CREC_HIP(ctx, hipMemcpyAsync(nslots, w.nslots, sizeof(int32_t) * 2 * (size_t)nbc, hipMemcpyDeviceToDevice, st));
+    CREC_HIP(ctx, hipStreamSynchronize(st));
     CREC_HIP(ctx, hipGetLastError());
     return CREC_OK;
 }

@@ -73,6 +73,7 @@ struct crec_ctx {
     crec_mt19937 rng;
     // BPR training workspace (bpr_train.hip)
     crec_devbuf idx_ws;   // per-batch inverted indices of one chunk of batches
+    crec_devbuf big_ws;   // index_big.hip: sort buffers, run tables and scans of one chunk of large batches
     crec_devbuf contrib;  // lazy mode: contribution rows, heavy-row partials and ticket counters (setup_lazy_bufs)
     crec_devbuf dq;       // data-parallel step: dense per-item gradient sums [I, d]
     void *comm = nullptr; // ncclComm_t (RCCL), set by crec_comm_init
@@ -113,6 +114,7 @@ struct crec_ctx {
     int knob_eval_no_bitmap = 0; // 1: seen filter by binary search even where the bitmaps would fit
     int knob_no_zero_copy = 0;   // 1: the chunk's counts come back by copy + stream synchronisation (tests)
     int knob_shard_unfused = 0;  // 1: the row-sharded step over the peer transport as five launches (serve, exchange, step, exchange, apply) like over RCCL (tests)
+    int knob_big_index = 0;      // 1: the lazy step's index through index_big.hip (global-memory sort) even for batches the LDS sort holds (tests)
     int knob_ncf_generic = 0;    // 1: the generic ncf_tile even for the shapes that have a specialised one (tests)
     int knob_dsampler_budget = 100; // percent of the device sampler's stream budget to start with (tests: < 100 forces the retry path)
     int knob_dsampler_general = 0; // negatives phase of the device sampler: 0 parallel tables (walk where they do not apply), 2 the four-wave walk, 1 the general walk (tests)

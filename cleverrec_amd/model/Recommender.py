@@ -36,6 +36,11 @@ class Recommender(object):
             raise ValueError("optimizer=%s: utils/tools.py get_optimizer knows SGD, Adam, Adagrad" % self.optimizer)
         # 'tf1' (default) | 'lazy' for Adam; SGD / Adagrad update touched rows only, which is their TF1 semantics
         self.adam_mode = {'Adam': c.get('adam_mode', 'tf1'), 'SGD': 'sgd', 'Adagrad': 'adagrad'}[self.optimizer]
+        if name == 'BPR' and self.adam_mode == 'tf1' and self.batch_size > 8192:
+            # the swept TF1 step indexes a batch in LDS (at most 8192 triples); beyond that the same results come from the deferred
+            # form: every row replays the steps it sat out when a batch touches it, indexed in global memory
+            self.adam_mode = 'deferred'
+            self.logger.info(' batch_size=%d > 8192: Adam runs in its deferred form (TF1 results, touched rows only)' % self.batch_size)
         self.saved_model_dir = c['saved_dir']
         self.T = int(c['test.interval'])
         self.topk = parse_list(c['topk'], int)

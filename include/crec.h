@@ -72,7 +72,9 @@ const char *crec_last_error(const crec_ctx *ctx);
  *   "eval_no_bitmap" 1: seen filter by binary search even where per-user bitmaps would fit
  *   "ncf_generic"    1: the generic NCF / LRML tile kernels even for shapes that have a shape-specialised one
  *   "no_zero_copy"   1: the tf1 step's per-chunk counts come back by copy + stream synchronisation instead of being written
- *                    into page-locked memory by the index kernel itself */
+ *                    into page-locked memory by the index kernel itself
+ *   "big_index"      1: the lazy-family steps index their batches through the global-memory sort (index_big.hip, the form batches of
+ *                    more than 8192 triples always take) even where the in-LDS sort would do: same index, bit for bit */
 int crec_ctx_set_option(crec_ctx *ctx, const char *name, int64_t value);
 
 /* ---- measurement: per-kernel time from HIP events recorded on the launch stream ------------
@@ -465,6 +467,13 @@ int crec_debug_shard_plan(crec_ctx *ctx, const int32_t *i, const int32_t *j, int
                           int32_t *n_req, int32_t *req_off, int32_t *ci, int32_t *cj, int32_t *ids_send, void *stream);
 int crec_debug_shard_owner_index(crec_ctx *ctx, const int32_t *ids_recv, const int32_t *srv_cnt, int32_t G, int64_t S, int32_t *order,
                                  int32_t *urows, int32_t *useg, int32_t *n_urows, void *stream);
+/* test hook: the index the lazy-family BPR steps (adam_mode lazy / deferred, SGD, Adagrad) read -- TF1's unique + segment-sum
+ * bookkeeping of a batch (the IndexedSlices aggregation behind model/ranking/BPR.py:31-44) -- of the ceil(N / B) batches of a stream,
+ * built by the in-LDS sort (big = 0; B <= 8192) or by the global-memory sort that larger batches take (big = 1): the two must agree
+ * bit for bit.  All arrays are device pointers; u_desc / i_desc / j_desc int32 [nb][B][4], slot_pu int32 [nb][B][2], nslots int32 [nb][2]. */
+int crec_debug_lazy_index(crec_ctx *ctx, const int32_t *u, const int32_t *i, const int32_t *j, int64_t N, int32_t B, int64_t U, int64_t I,
+                          int32_t d, int32_t big, int32_t *u_desc, int32_t *i_desc, int32_t *j_desc, int32_t *slot_pu, int32_t *nslots,
+                          void *stream);
 
 /* ---- full-catalogue evaluation (device) -------------------------------------------------
  * replaces sess.run(self.pre_scores) (BPR._predict rs branch, BPR.py:51) + np.argsort +

@@ -1,0 +1,166 @@
+"""Batches beyond what a workgroup sorts in LDS (batch_size > 8192; the reference takes any batch_size, model/Recommender.py:17).
+
+  * the index built in global memory (csrc/index_big.hip) equals the in-LDS index (bpr_index_batches) BIT FOR BIT on batches both
+    can build -- descriptors, processing order, front-region sizes;
+  * the BPR step on batches of 16 384 / 20 000 / 40 000 triples against the oracle (lazy and SGD / Adagrad: touched rows only; deferred
+    against the oracle's TF1 sweep), fp32 losses rtol 1e-5, parameters atol 2e-6 as in test_gpu_parity.py;
+  * the `big_index` option on a batch of 6144: the same tables and losses, bit for bit, as the default path.
+Needs an MI355X."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from cleverrec_amd import runtime
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sess():
+    s = runtime.Session(0)
+    yield s
+    s.close()
+
+
+def _stream(seed, n, U, I, zipf=None, item_cap=None):
+    g = np.random.Generator(np.random.PCG64(seed))
+    u = g.integers(0, U, n).astype(np.int32)
+    if zipf:
+        i = np.minimum(g.zipf(zipf, n) - 1, I - 1).astype(np.int32)
+    else:
+        i = g.integers(0, item_cap or I, n).astype(np.int32)
+    j = g.integers(0, item_cap or I, n).astype(np.int32)
+    j = np.where(j == i, (j + 1) % I, j).astype(np.int32)  # (a sampled negative is never the positive)
+    return u, i, j
+
+
+def _index(sess, u, i, j, B, U, I, d, big):
+    n = len(u)
+    nb = -(-n // B)
+    dev = lambda shape: torch.empty(shape, dtype=torch.int32, device=sess.device)  # noqa: E731
+    ud, idd, jd, pu, ns = dev((nb, B, 4)), dev((nb, B, 4)), dev((nb, B, 4)), dev((nb, B, 2)), dev((nb, 2))
+    a = [sess.to_dev(x) for x in (u, i, j)]
+    sess.ctx.check(sess.lib.crec_debug_lazy_index(sess.ctx.h, sess.ptr(a[0]), sess.ptr(a[1]), sess.ptr(a[2]), n, B, U, I, d, int(big),
+                                                  sess.ptr(ud), sess.ptr(idd), sess.ptr(jd), sess.ptr(pu), sess.ptr(ns), sess.stream_ptr()))
+    return [t.cpu().numpy() for t in (ud, idd, jd, pu, ns)]
+
+
+@pytest.mark.parametrize("n,B,U,I,d,kw", [
+    (6144 * 3 + 100, 6144, 100000, 1000000, 128, dict(zipf=1.2)),   # S-big's shape: a Zipf head of popular positives
+    (8192 * 2, 8192, 500, 40, 64, dict()),                          # every row heavy
+    (8192 + 1, 8192, 3, 2, 32, dict()),                             # two items, three users: runs of thousands
+    (250, 100, 50, 30, 16, dict()),                                 # a ragged last batch
+    (7, 1, 5, 5, 4, dict()),                                        # batches of one; d = 4: 64 slots per workgroup
+    (4000, 2000, 6040, 3706, 256, dict(zipf=1.5)),                  # d = 256: 16 slots per workgroup
+    (6144, 6144, 10_000_000, 1_000_000, 128, dict()),               # 24-bit user ids: three radix digits
+])
+def test_big_index_equals_lds_index(sess, n, B, U, I, d, kw):
+    u, i, j = _stream(n + B, n, U, I, **kw)
+    a = _index(sess, u, i, j, B, U, I, d, big=False)
+    b = _index(sess, u, i, j, B, U, I, d, big=True)
+    for name, x, y in zip(("u_desc", "i_desc", "j_desc", "slot_pu", "nslots"), a, b):
+        assert np.array_equal(x, y), "%s differs at %s" % (name, np.argwhere(x != y)[:4].tolist())
+    # and it is an index: every batch position appears once in the processing order
+    nb = -(-n // B)
+    for bt in range(nb):
+        m = min(B, n - bt * B)
+        assert np.array_equal(np.sort(a[3][bt, :m, 0]), np.arange(m))
+        assert a[4][bt, 0] == m
+
+
+def _oracle_steps(P0, Q0, u, i, j, B, lr, reg, mode):
+    om = oracle.BprModel(P0, Q0, lr=lr, reg=reg, adam_mode=mode)
+    nb = -(-len(u) // B)
+    _, ol = oracle.train_model_py(om, nb, u, i, j, B)
+    return om, ol
+
+
+@pytest.mark.parametrize("B,mode", [(16384, "lazy"), (20000, "lazy"), (40000, "lazy"), (16384, "deferred")])
+def test_large_batches_against_the_oracle(sess, B, mode):
+    U, I, d, lr, reg = 5000, 3000, 32, 1e-3, 0.01
+    n = 2 * B + 777
+    u, i, j = _stream(B, n, U, I, zipf=1.3)
+    g = np.random.Generator(np.random.PCG64(5))
+    P0 = (g.standard_normal((U, d)) * 0.01).astype(np.float32)
+    Q0 = (g.standard_normal((I, d)) * 0.01).astype(np.float32)
+    st = runtime.BprState(sess, P0, Q0, lr=lr, reg=reg, adam_mode=mode)
+    loss = st.train_epoch(sess.to_dev(u), sess.to_dev(i), sess.to_dev(j), B).cpu().numpy()
+    st.flush()
+    om, ol = _oracle_steps(P0, Q0, u, i, j, B, lr, reg, {"lazy": 1, "deferred": 0}[mode])
+    np.testing.assert_allclose(loss, ol, rtol=1e-5)
+    for name in ("P", "Q", "mP", "mQ"):
+        np.testing.assert_allclose(getattr(st, name).cpu().numpy(), getattr(om, name), rtol=0, atol=2e-6, err_msg=name)
+    # v = (1 - beta2) g^2 squares the gradient sum; in a batch of tens of thousands the Zipf head's rows add thousands of terms
+    # (in a different order on the two sides) and a sum that partly cancels keeps fewer digits: element-wise 1e-4 where v is of
+    # the table's size, norm-wise 1e-5 below that
+    for name in ("vP", "vQ"):
+        ov = getattr(om, name)
+        np.testing.assert_allclose(getattr(st, name).cpu().numpy(), ov, rtol=1e-4, atol=1e-5 * float(np.abs(ov).max()), err_msg=name)
+
+
+def test_tf1_sweep_refuses_a_large_batch_and_names_the_way_out(sess):
+    U, I, d, B = 100, 80, 16, 9000
+    u, i, j = _stream(1, B, U, I)
+    P0, Q0 = np.zeros((U, d), np.float32), np.zeros((I, d), np.float32)
+    st = runtime.BprState(sess, P0, Q0, lr=1e-3, reg=0.01, adam_mode="tf1")
+    with pytest.raises(Exception, match="deferred"):
+        st.train_epoch(sess.to_dev(u), sess.to_dev(i), sess.to_dev(j), B)
+
+
+@pytest.mark.parametrize("mode", ["lazy", "sgd", "adagrad", "deferred"])
+def test_big_index_option_changes_nothing(mode):
+    U, I, d, B = 20000, 5000, 64, 6144
+    n = 3 * B + 55
+    u, i, j = _stream(9, n, U, I, zipf=1.25)
+    g = np.random.Generator(np.random.PCG64(6))
+    P0 = (g.standard_normal((U, d)) * 0.01).astype(np.float32)
+    Q0 = (g.standard_normal((I, d)) * 0.01).astype(np.float32)
+    out = []
+    for big in (0, 1):
+        s = runtime.Session(0)
+        s.ctx.check(s.lib.crec_ctx_set_option(s.ctx.h, b"big_index", C.c_int64(big)))
+        st = runtime.BprState(s, P0, Q0, lr=1e-3, reg=0.01, adam_mode=mode)
+        loss = st.train_epoch(s.to_dev(u), s.to_dev(i), s.to_dev(j), B).cpu().numpy()
+        st.flush()
+        out.append([loss] + [getattr(st, k).cpu().numpy() for k in ("P", "Q", "mP", "mQ", "vP", "vQ")])
+        s.close()
+    for x, y in zip(*out):
+        assert np.array_equal(x, y)
+
+
+def test_class_surface_takes_a_large_batch(sess, tmp_path):
+    """batch_size = 20000 through the BPR class: validate() lets it through, Adam runs in its deferred form, and the epochs match an
+    oracle run of the reference's protocol with TF1's swept Adam (same np.random sampler stream)."""
+    import logging
+
+    from cleverrec_amd.data import RankingData
+    from cleverrec_amd.model.ranking.BPR import BPR
+    g = np.random.Generator(np.random.PCG64(21))
+    U, I, B = 700, 400, 20000
+    ui_train = {u: [int(x) for x in g.choice(I, size=int(g.integers(10, 50)), replace=False)] for u in range(U)}
+    ui_test = {u: [int(x) for x in g.choice(I, size=2, replace=False)] for u in range(0, U, 3)}
+    data = RankingData(U, I, ui_train, ui_test)
+    configs = {"recommender": "BPR", "epoches": "2", "batch_size": str(B), "test.batch_size": "64", "lr": "0.001",
+               "test.neg_samples": "0", "is_pairwise": "True", "init_method": "normal", "stddev": "0.01",
+               "loss_func": "bpr", "optimizer": "Adam", "saved_dir": str(tmp_path), "test.interval": "1",
+               "topk": "[10,20]", "neg_ratio": "4", "embed_size": "32", "reg": "0.01", "data.split_way": "rs"}
+    m = BPR(sess, data, configs, logging.getLogger("bigbatch"))
+    assert m.adam_mode == "deferred"
+    P0 = (g.standard_normal((U, 32)) * 0.01).astype(np.float32)
+    Q0 = (g.standard_normal((I, 32)) * 0.01).astype(np.float32)
+    m.build_model(P0, Q0)
+    om = oracle.BprModel(P0, Q0, lr=1e-3, reg=0.01)
+    np.random.seed(4)
+    rng = oracle.Rng(4)
+    for _ in range(2):
+        avg = m.train_model()
+        nb, ou, oi, oj = oracle.sample_pairwise(rng, data.ui_train, data.item_nums, 4, B)
+        assert nb >= 3
+        oavg, _ = oracle.train_model_py(om, nb, ou, oi, oj, B)
+        assert avg == pytest.approx(oavg, rel=1e-5)
+    m.state.flush()
+    np.testing.assert_allclose(m.P.cpu().numpy(), om.P, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(m.Q.cpu().numpy(), om.Q, rtol=0, atol=2e-6)

@@ -80,11 +80,15 @@ def test_ranks_as_threads_sharded_epoch():
     for s in sessions:
         s.ctx.check(s.lib.crec_comm_set_timeout(s.ctx.h, 10.0))
     result, errors = [None] * G, []
+    # a rank's kernel waits inside the GPU for its peer's kernel: the two streams must not share a hardware queue.  Streams of
+    # different priorities never do (a queue has one priority); two streams of the same priority may, depending on how many the
+    # process has created before
+    rank_streams = [torch.cuda.Stream(priority=0), torch.cuda.Stream(priority=-1)]
 
     def work(r):
         try:
             torch.cuda.set_device(0)
-            with torch.cuda.stream(torch.cuda.Stream()):
+            with torch.cuda.stream(rank_streams[r]):
                 s = sessions[r]
                 lo, hi = ranges[r]
                 st = parallel.ShardedBprState(s, P0[lo:hi], parallel.shard_items(Q0, r, G), I, 1e-3, 0.01, r, G)
