@@ -481,6 +481,14 @@ def main():
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import bench_big
                 out["synthetic_big"] = bench_big.run(steps=200, sess=sess)
+                # the same step on larger batches (batch_size is the reference's .properties key, any int: model/Recommender.py:17;
+                # beyond 8192 the batch's index is built in global memory, csrc/index_big.hip): a launch long enough that the
+                # dispatch and the multi-occurrence rows' tails no longer show
+                out["synthetic_big"]["larger_batches"] = {}
+                for bb in (32768, 65536):
+                    r = bench_big.run(steps=(1 << 23) // bb, warmup=(1 << 21) // bb, batch=bb, sess=sess)
+                    out["synthetic_big"]["larger_batches"][str(bb)] = {k: r[k] for k in ("triples_per_s", "us_per_step", "bpr_triples_lazy",
+                                                                                          "unique_user_rows_per_batch", "unique_item_rows_per_batch")}
                 out["synthetic_big"]["sharded_world1"] = bench_big.run_sharded(steps=200, sess=sess)  # protocol cost
                 import bench_eval_big
                 out["eval_big"] = bench_eval_big.run(sess=sess, reps=2)  # 65536 users x 1 M items: MFMA utilisation

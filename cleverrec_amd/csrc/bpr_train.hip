@@ -2247,9 +2247,35 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
     const bool big_index = !dense && (B > MAX_B || ctx->knob_big_index);
     if (big_index && chunk * B > ((int64_t)1 << 22)) // its scratch: ~100 bytes per triple of the chunk
         chunk = ((int64_t)1 << 22) / B;
+    if (big_index && chunk > 4096) // ... and 2 KB of digit counters per batch and sort tile
+        chunk = 4096;
     chunk = chunk < 1 ? 1 : (chunk > nb ? nb : chunk);
+    // The chunks' sizes.  The global-memory index does not depend on the tables, so under the "idx_overlap" option chunk c + 1 is
+    // indexed on a side stream while chunk c's steps run (two index buffers); the first chunk's index is then the only one the
+    // steps wait for, so the chunks start small (half a million triples) and double up to `chunk`.  (Off by default: S-big at
+    // B = 65536 on one GPU, 135.1 us per step so against 132.8 in line -- the step kernel is slowed by what the index kernels take.)
+    std::vector<int64_t> chunk_sizes;
+    {
+        int64_t cur = chunk;
+        if (big_index && ctx->knob_idx_overlap) {
+            cur = ((int64_t)1 << 19) / B;
+            cur = cur < 1 ? 1 : (cur > chunk ? chunk : cur);
+        }
+        for (int64_t done = 0; done < nb; done += cur, cur = (2 * cur > chunk ? chunk : 2 * cur))
+            chunk_sizes.push_back((nb - done) < cur ? (nb - done) : cur);
+    }
+    const bool piped = big_index && ctx->knob_idx_overlap && chunk_sizes.size() > 1;
     if (int rc = crec_reserve(ctx, &ctx->idx_ws, layout_index(nullptr, chunk, B, t->U, t->I, dense, CH, wide_rows, wide_total).bytes))
         return rc;
+    if (piped) {
+        if (int rc = crec_reserve(ctx, &ctx->idx_ws2, layout_index(nullptr, chunk, B, t->U, t->I, dense, CH, wide_rows, wide_total).bytes))
+            return rc;
+        if (!ctx->idx_stream) {
+            CREC_HIP(ctx, hipStreamCreateWithFlags(&ctx->idx_stream, hipStreamNonBlocking));
+            for (hipEvent_t &e : ctx->idx_ev)
+                CREC_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+    }
     // per batch: x_b of every triple, then one l2 term per row wave
     const int64_t loss_stride = B + (dense ? t->U + t->I : (int64_t)B); // lazy: x_b, then the l2 term of every triple
     if (int rc = crec_reserve(ctx, &ctx->loss_ws, sizeof(float) * (size_t)chunk * loss_stride))
@@ -2338,11 +2364,18 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
                 (void)run(); // an error return: best effort, the error code of the failing call is what the caller sees
         }
     } home{t, &a, &in_shadow, bytesP, bytesQ, st};
-    for (int64_t b0 = 0; b0 < nb; b0 += chunk) {
+    const auto build_big = [&](const IndexWs &wb, int64_t first, int64_t count, hipStream_t s) {
+        const int64_t tb = first * B, nc = (N - tb) < count * B ? (N - tb) : count * B;
+        const LazyIndexOut o{wb.u_desc, wb.i_desc, wb.j_desc, wb.i_tmp, wb.j_tmp, wb.slot_pu, wb.order, wb.nslots};
+        return crec_lazy_index_big(ctx, u + tb, i + tb, j + tb, nc, B, count, wb.bits_u, wb.bits_q, wb.spw, o, s, chunk);
+    };
+    size_t ci = 0;
+    for (int64_t b0 = 0, nbc = 0; b0 < nb; b0 += nbc, ++ci) {
         const crec_range chunk_range("crec_bpr chunk of batches");
-        const int64_t nbc = (nb - b0) < chunk ? (nb - b0) : chunk;
+        nbc = chunk_sizes[ci];
         const int64_t t0 = b0 * B, n_chunk = (N - t0) < nbc * B ? (N - t0) : nbc * B;
-        IndexWs w = layout_index(ctx->idx_ws.ptr, nbc, B, t->U, t->I, dense, CH, wide_rows, wide_total, lazy_spw(t->d));
+        void *const ws_of[2] = {ctx->idx_ws.ptr, piped ? ctx->idx_ws2.ptr : ctx->idx_ws.ptr};
+        IndexWs w = layout_index(ws_of[ci & 1], nbc, B, t->U, t->I, dense, CH, wide_rows, wide_total, lazy_spw(t->d));
         const size_t nw_off = (size_t)(w.nwide - w.hn), n_back = dense ? nw_off + (size_t)nbc * 2 : 0;
         if (n_back + 64 > ctx->pinned_ints) {
             if (ctx->pinned)
@@ -2378,10 +2411,27 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
         w.done = ctx->idx_done;
         w.seq = zero_copy ? ++ctx->idx_seq : 0;
         w.n_back = (int32_t)n_back;
-        if (big_index) {
-            const LazyIndexOut o{w.u_desc, w.i_desc, w.j_desc, w.i_tmp, w.j_tmp, w.slot_pu, w.order, w.nslots};
-            if (int rc = crec_lazy_index_big(ctx, u + t0, i + t0, j + t0, n_chunk, B, nbc, w.bits_u, w.bits_q, w.spw, o, st))
+        if (big_index && !piped) {
+            if (int rc = build_big(w, b0, nbc, st))
                 return rc;
+        } else if (big_index) {
+            hipStream_t side = ctx->idx_stream;
+            if (ci == 0) { // the side stream starts behind whatever the caller's stream holds (the triples' producer, an earlier epoch's steps)
+                CREC_HIP(ctx, hipEventRecord(ctx->idx_ev[4], st));
+                CREC_HIP(ctx, hipStreamWaitEvent(side, ctx->idx_ev[4], 0));
+                if (int rc = build_big(w, b0, nbc, side))
+                    return rc;
+                CREC_HIP(ctx, hipEventRecord(ctx->idx_ev[0], side));
+            }
+            if (ci + 1 < chunk_sizes.size()) { // the next chunk's index, beside this chunk's steps, into the other buffer
+                const IndexWs wn = layout_index(ws_of[(ci + 1) & 1], chunk_sizes[ci + 1], B, t->U, t->I, dense, CH, wide_rows, wide_total, lazy_spw(t->d));
+                if (ci >= 1) // (that buffer was read by the steps of chunk ci - 1)
+                    CREC_HIP(ctx, hipStreamWaitEvent(side, ctx->idx_ev[2 + ((ci + 1) & 1)], 0));
+                if (int rc = build_big(wn, b0 + nbc, chunk_sizes[ci + 1], side))
+                    return rc;
+                CREC_HIP(ctx, hipEventRecord(ctx->idx_ev[(ci + 1) & 1], side));
+            }
+            CREC_HIP(ctx, hipStreamWaitEvent(st, ctx->idx_ev[ci & 1], 0));
         } else {
             crec_prof_begin(ctx, CREC_K_INDEX, st);
             CREC_KLAUNCH(ctx, bpr_index_batches, dim3((unsigned)(2 * nbc)), dim3(PREP_THREADS), lds, st, u + t0, i + t0,
@@ -2477,6 +2527,8 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
             if (int rc = xdp->status(ctx, st)) // (a transport that waits on its peers inside kernels reports a peer that never came here)
                 return rc;
         }
+        if (piped)
+            CREC_HIP(ctx, hipEventRecord(ctx->idx_ev[2 + (ci & 1)], st));
         CREC_HIP(ctx, hipGetLastError());
         if (int rc = crec_prof_flush(ctx, st))
             return rc;

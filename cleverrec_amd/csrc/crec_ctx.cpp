@@ -190,6 +190,7 @@ int crec_ctx_create(int device, crec_ctx **out)
     ctx->knob_ncf_generic = env_int("CREC_NCF_GENERIC", 0);
     ctx->knob_shard_unfused = env_int("CREC_SHARD_UNFUSED", 0);
     ctx->knob_big_index = env_int("CREC_BIG_INDEX", 0);
+    ctx->knob_idx_overlap = env_int("CREC_IDX_OVERLAP", 0);
     ctx->knob_no_zero_copy = env_int("CREC_NO_ZERO_COPY", 0);
     ctx->knob_dsampler_general = env_int("CREC_DSAMPLER_GENERAL", 0);
     if (device >= 0) {
@@ -229,7 +230,7 @@ void crec_ctx_destroy(crec_ctx *ctx)
         (void)hipSetDevice(ctx->device);
         (void)hipDeviceSynchronize();
         (void)crec_comm_destroy(ctx);
-        crec_devbuf *bufs[] = {&ctx->idx_ws, &ctx->big_ws, &ctx->contrib, &ctx->loss_ws,
+        crec_devbuf *bufs[] = {&ctx->idx_ws, &ctx->idx_ws2, &ctx->big_ws, &ctx->contrib, &ctx->loss_ws,
                                &ctx->misc,   &ctx->eval_ws, &ctx->ks_dev, &ctx->shadow, &ctx->dq, &ctx->shard_ws, &ctx->shard_ws2, &ctx->lr_hist_dev,
                                &ctx->shard_flag};
         for (crec_devbuf *b : bufs)
@@ -241,6 +242,11 @@ void crec_ctx_destroy(crec_ctx *ctx)
         }
         for (hipEvent_t e : ctx->prof.pool)
             (void)hipEventDestroy(e);
+        for (hipEvent_t e : ctx->idx_ev)
+            if (e)
+                (void)hipEventDestroy(e);
+        if (ctx->idx_stream)
+            (void)hipStreamDestroy(ctx->idx_stream);
         if (ctx->pinned)
             (void)hipHostFree(ctx->pinned);
         if (ctx->pinned64)
@@ -274,6 +280,8 @@ int crec_ctx_set_option(crec_ctx *ctx, const char *name, int64_t value)
         ctx->knob_shard_unfused = (int)value;
     else if (n == "big_index")
         ctx->knob_big_index = (int)value;
+    else if (n == "idx_overlap")
+        ctx->knob_idx_overlap = (int)value;
     else if (n == "dsampler_general")
         ctx->knob_dsampler_general = (int)value;
     else if (n == "dsampler_budget")

@@ -74,6 +74,9 @@ struct crec_ctx {
     // BPR training workspace (bpr_train.hip)
     crec_devbuf idx_ws;   // per-batch inverted indices of one chunk of batches
     crec_devbuf big_ws;   // index_big.hip: sort buffers, run tables and scans of one chunk of large batches
+    crec_devbuf idx_ws2;  // ... whose chunks are indexed on a side stream while the previous chunk's steps run: the second index buffer,
+    hipStream_t idx_stream = nullptr; // the side stream, and the events that order the two streams ([0..1] index of a buffer ready,
+    hipEvent_t idx_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // [2..3] steps on a buffer done, [4] the caller's stream on entry)
     crec_devbuf contrib;  // lazy mode: contribution rows, heavy-row partials and ticket counters (setup_lazy_bufs)
     crec_devbuf dq;       // data-parallel step: dense per-item gradient sums [I, d]
     void *comm = nullptr; // ncclComm_t (RCCL), set by crec_comm_init
@@ -114,6 +117,7 @@ struct crec_ctx {
     int knob_eval_no_bitmap = 0; // 1: seen filter by binary search even where the bitmaps would fit
     int knob_no_zero_copy = 0;   // 1: the chunk's counts come back by copy + stream synchronisation (tests)
     int knob_shard_unfused = 0;  // 1: the row-sharded step over the peer transport as five launches (serve, exchange, step, exchange, apply) like over RCCL (tests)
+    int knob_idx_overlap = 0;    // 1: large batches' chunks are indexed a chunk ahead on a side stream, beside the previous chunk's steps
     int knob_big_index = 0;      // 1: the lazy step's index through index_big.hip (global-memory sort) even for batches the LDS sort holds (tests)
     int knob_ncf_generic = 0;    // 1: the generic ncf_tile even for the shapes that have a specialised one (tests)
     int knob_dsampler_budget = 100; // percent of the device sampler's stream budget to start with (tests: < 100 forces the retry path)

@@ -6,7 +6,7 @@
 //
 //   big_fill         (row, slot) pairs of both sides of every batch; per batch a user segment and an item segment (i-slots, then
 //                    j-slots, so that a stable sort leaves a row's occurrences in batch order, positives first)
-//   rocPRIM          segmented stable radix sort by row over the significant bits of a row id
+//   sort_*           segmented stable radix sort by row over the significant bits of a row id, every segment cut into tiles
 //   big_runs         per sorted element: its row's segment [start, start + cnt) (two binary searches, skipped where the
 //                    neighbours already tell), on the item side the row's positive slots `ci` (a third); the user side's
 //                    descriptors are complete here
@@ -42,12 +42,11 @@ struct BigAt {
     int b, side, k, n, nb;
     int64_t seg; // first element of the segment
 };
-__device__ __forceinline__ BigAt big_at(const BigDims &dm, int64_t e)
+__device__ __forceinline__ BigAt big_at(const BigDims &dm, int b, int r) // r: the element's place inside the batch's 3B
 {
     BigAt a;
     const int64_t per = 3 * (int64_t)dm.B;
-    a.b = (int)(e / per);
-    const int r = (int)(e - (int64_t)a.b * per);
+    a.b = b;
     a.nb = dm.nb_of(a.b);
     a.side = r >= dm.B ? 1 : 0;
     a.k = a.side ? r - dm.B : r;
@@ -57,18 +56,13 @@ __device__ __forceinline__ BigAt big_at(const BigDims &dm, int64_t e)
 }
 
 __global__ __launch_bounds__(256) void big_fill(const int32_t *__restrict__ u, const int32_t *__restrict__ i, const int32_t *__restrict__ j,
-                                                BigDims dm, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
-                                                uint32_t *__restrict__ seg_begin, uint32_t *__restrict__ seg_end)
+                                                BigDims dm, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals)
 {
-    const int64_t E = 3 * (int64_t)dm.B * dm.nbc;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
-        const BigAt a = big_at(dm, e);
-        if (e < 2 * (int64_t)dm.nbc) { // segment s = 2 * batch + side
-            const int b = (int)(e >> 1), side = (int)(e & 1), nb = dm.nb_of(b);
-            const int64_t s0 = 3 * (int64_t)dm.B * b + (side ? dm.B : 0);
-            seg_begin[e] = (uint32_t)s0;
-            seg_end[e] = (uint32_t)(s0 + (side ? 2 * nb : nb));
-        }
+    // (the launches over a chunk's elements: grid.y = the batch, grid.x strides over the batch's elements -- no 64-bit divisions)
+    const int b = (int)blockIdx.y;
+    for (int r = (int)(blockIdx.x * blockDim.x + threadIdx.x); r < 3 * dm.B; r += (int)(gridDim.x * blockDim.x)) {
+        const BigAt a = big_at(dm, b, r);
+        const int64_t e = 3 * (int64_t)dm.B * b + r;
         uint32_t key = 0xffffffffu;
         if (a.k < a.n) {
             const int64_t t0 = (int64_t)a.b * dm.B;
@@ -76,6 +70,156 @@ __global__ __launch_bounds__(256) void big_fill(const int32_t *__restrict__ u, c
         }
         keys[e] = key;
         vals[e] = (uint32_t)a.k;
+    }
+}
+
+// ---- the sort: a segmented, stable least-significant-digit radix sort, 8 bits per pass, every segment cut into tiles of
+// SORT_TILE elements so that a pass is three flat launches over ALL tiles of ALL segments (rocPRIM's segmented sort gives a
+// long segment to ONE workgroup: 1.9 ms for a chunk of 64 batches of 65 536 whatever the chunk holds; this one 0.3 ms):
+//   sort_hist     per tile: how many of its elements carry each digit            -> hist[segment][digit][tile]
+//   sort_scan     per segment: exclusive scan in (digit, tile) order = where each tile's elements of a digit go
+//   sort_scatter  per tile: every element's rank among the tile's elements of its digit, IN THE TILE'S ORDER (stable) -- a wave
+//                 owns a contiguous eighth of the tile, the lanes holding the same digit find each other with one ballot per
+//                 digit bit (block_sort.h's scheme), per-wave digit counts are summed in wave order -- and the element moves
+constexpr int SORT_THREADS = 256, SORT_WAVES = SORT_THREADS / 64, SORT_PER_WAVE = 512, SORT_TILE = SORT_WAVES * SORT_PER_WAVE;
+
+struct SortDims {
+    BigDims dm;
+    int tiles_u, tiles_i, tiles_max; // tiles of a user / an item segment (of a full batch)
+    __device__ __forceinline__ void at(int blk, int *b, int *side, int *tile) const
+    {
+        const int per = tiles_u + tiles_i;
+        *b = blk / per;
+        const int r = blk - *b * per;
+        *side = r >= tiles_u ? 1 : 0;
+        *tile = *side ? r - tiles_u : r;
+    }
+};
+
+__global__ __launch_bounds__(SORT_THREADS) void sort_hist(SortDims sd, const uint32_t *__restrict__ keys, int shift, int32_t *__restrict__ hist)
+{
+    __shared__ int cnt[256];
+    int b, side, tile;
+    sd.at((int)blockIdx.x, &b, &side, &tile);
+    const int nb = sd.dm.nb_of(b), n = side ? 2 * nb : nb;
+    const uint32_t *sk = keys + 3 * (int64_t)sd.dm.B * b + (side ? sd.dm.B : 0);
+    cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int k0 = tile * SORT_TILE;
+    for (int k = k0 + (int)threadIdx.x; k < k0 + SORT_TILE && k < n; k += SORT_THREADS)
+        atomicAdd(&cnt[(sk[k] >> shift) & 255u], 1);
+    __syncthreads();
+    hist[((int64_t)(b * 2 + side) * 256 + threadIdx.x) * sd.tiles_max + tile] = cnt[threadIdx.x];
+}
+
+__global__ __launch_bounds__(1024) void sort_scan(SortDims sd, int32_t *__restrict__ hist)
+{
+    __shared__ int wave_sums[1024 / 64 + 2];
+    const int seg = (int)blockIdx.x, side = seg & 1, tiles = side ? sd.tiles_i : sd.tiles_u;
+    int32_t *h = hist + (int64_t)seg * 256 * sd.tiles_max;
+    // the scan runs over (digit, tile < tiles); a thread owns a contiguous span of it
+    const int total = 256 * tiles, per = (total + 1023) / 1024;
+    const int v0 = (int)threadIdx.x * per, v1 = (v0 + per) < total ? (v0 + per) : total;
+    int sum = 0;
+    for (int v = v0; v < v1; ++v)
+        sum += h[(v / tiles) * sd.tiles_max + v % tiles];
+    // (an exclusive scan over the workgroup's threads, as block_sort.h's)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off, 64);
+        if (lane >= off)
+            incl += t;
+    }
+    if (lane == 63)
+        wave_sums[wave] = incl;
+    __syncthreads();
+    if (wave == 0) {
+        int sv = lane < 16 ? wave_sums[lane] : 0, si = sv;
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
+            const int t = __shfl_up(si, off, 64);
+            if (lane >= off)
+                si += t;
+        }
+        if (lane < 16)
+            wave_sums[lane] = si - sv;
+    }
+    __syncthreads();
+    int run = wave_sums[wave] + incl - sum;
+    for (int v = v0; v < v1; ++v) {
+        int32_t *p = h + (v / tiles) * sd.tiles_max + v % tiles;
+        const int c = *p;
+        *p = run;
+        run += c;
+    }
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void sort_scatter(SortDims sd, const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals,
+                                                             int shift, const int32_t *__restrict__ hist, uint32_t *__restrict__ keys_out,
+                                                             uint32_t *__restrict__ vals_out)
+{
+    __shared__ int wcnt[SORT_WAVES][257]; // per wave: running count per digit
+    __shared__ int base[256];             // per digit: where this tile's elements of the digit start in the segment
+    int b, side, tile;
+    sd.at((int)blockIdx.x, &b, &side, &tile);
+    const int nb = sd.dm.nb_of(b), n = side ? 2 * nb : nb;
+    const int64_t seg0 = 3 * (int64_t)sd.dm.B * b + (side ? sd.dm.B : 0);
+    if (tile * SORT_TILE >= n)
+        return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    constexpr int ROUNDS = SORT_PER_WAVE / 64;
+    uint32_t r[ROUNDS], p[ROUNDS];
+    int loc[ROUNDS];
+    const int w0 = tile * SORT_TILE + wave * SORT_PER_WAVE;
+#pragma unroll
+    for (int s = 0; s < ROUNDS; ++s) {
+        const int k = w0 + s * 64 + lane;
+        r[s] = k < n ? keys[seg0 + k] : 0u;
+        p[s] = k < n ? vals[seg0 + k] : 0u;
+    }
+    for (int c = lane; c < 256; c += 64)
+        wcnt[wave][c] = 0;
+    base[tid] = hist[((int64_t)(b * 2 + side) * 256 + tid) * sd.tiles_max + tile];
+    // rank inside the wave: LDS operations of one wave execute in order, so the running counter written in round s is the
+    // one read in round s + 1
+#pragma unroll
+    for (int s = 0; s < ROUNDS; ++s) {
+        const bool valid = w0 + s * 64 + lane < n;
+        const uint32_t digit = (r[s] >> shift) & 255u;
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit) {
+            const bool on = (digit >> bit) & 1u;
+            const uint64_t bal = __ballot(on);
+            peers &= on ? bal : ~bal;
+        }
+        const int before = __popcll(peers & lt_mask), cnt = __popcll(peers);
+        const int run = wcnt[wave][digit];
+        loc[s] = run + before;
+        if (valid && before == 0)
+            wcnt[wave][digit] = run + cnt;
+    }
+    __syncthreads();
+    { // per digit: the waves' counts -> their offsets, in wave order
+        int run = base[tid];
+#pragma unroll
+        for (int w = 0; w < SORT_WAVES; ++w) {
+            const int c = wcnt[w][tid];
+            wcnt[w][tid] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < ROUNDS; ++s) {
+        if (w0 + s * 64 + lane < n) {
+            const int64_t dst = seg0 + wcnt[wave][(r[s] >> shift) & 255u] + loc[s];
+            keys_out[dst] = r[s];
+            vals_out[dst] = p[s];
+        }
     }
 }
 
@@ -97,13 +241,12 @@ __global__ __launch_bounds__(256) void big_runs(BigDims dm, const uint32_t *__re
                                                 int32_t *__restrict__ rstart, int32_t *__restrict__ rcnt, int32_t *__restrict__ rci,
                                                 int32_t *__restrict__ fp, int4 *__restrict__ u_desc)
 {
-    const int64_t E = 3 * (int64_t)dm.B * dm.nbc;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e <= E; e += (int64_t)gridDim.x * blockDim.x) {
-        if (e == E) { // the scan's closing element
-            fp[e] = 0;
-            continue;
-        }
-        const BigAt a = big_at(dm, e);
+    const int b = (int)blockIdx.y;
+    if (b == 0 && blockIdx.x == 0 && threadIdx.x == 0)
+        fp[3 * (int64_t)dm.B * dm.nbc] = 0; // the scan's closing element
+    for (int r = (int)(blockIdx.x * blockDim.x + threadIdx.x); r < 3 * dm.B; r += (int)(gridDim.x * blockDim.x)) {
+        const BigAt a = big_at(dm, b, r);
+        const int64_t e = 3 * (int64_t)dm.B * b + r;
         int front_pos = 0;
         if (a.k < a.n) {
             const uint32_t *sk = keys + a.seg;
@@ -137,11 +280,8 @@ __global__ __launch_bounds__(256) void big_item_desc(BigDims dm, int spw, const 
                                                      int4 *__restrict__ i_tmp, int4 *__restrict__ j_tmp, int32_t *__restrict__ order,
                                                      int32_t *__restrict__ wi, int32_t *__restrict__ wj)
 {
-    const int64_t n_items = 2 * (int64_t)dm.B * dm.nbc;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_items; t += (int64_t)gridDim.x * blockDim.x) {
-        const int b = (int)(t / (2 * dm.B)), k = (int)(t - (int64_t)b * 2 * dm.B), nb = dm.nb_of(b);
-        if (k >= 2 * nb)
-            continue;
+    const int b = (int)blockIdx.y, nb = dm.nb_of(b);
+    for (int k = (int)(blockIdx.x * blockDim.x + threadIdx.x); k < 2 * nb; k += (int)(gridDim.x * blockDim.x)) {
         const int64_t seg = 3 * (int64_t)dm.B * b + dm.B, e = seg + k;
         const int start = rstart[e], cnt = rcnt[e], ci = rci[e];
         const bool front = ci >= 2;
@@ -165,18 +305,18 @@ __global__ __launch_bounds__(256) void big_item_desc(BigDims dm, int spw, const 
 __global__ __launch_bounds__(256) void big_part_flags(BigDims dm, const int32_t *__restrict__ wi, const int32_t *__restrict__ wj,
                                                       unsigned long long *__restrict__ pf)
 {
-    const int64_t n = (int64_t)dm.B * dm.nbc;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t <= n; t += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)blockIdx.y, nb = dm.nb_of(b);
+    if (b == 0 && blockIdx.x == 0 && threadIdx.x == 0)
+        pf[(int64_t)dm.B * dm.nbc] = 0; // the scan's closing element
+    for (int pos = (int)(blockIdx.x * blockDim.x + threadIdx.x); pos < dm.B; pos += (int)(gridDim.x * blockDim.x)) {
+        const int64_t t = (int64_t)b * dm.B + pos;
         unsigned long long f = 0;
-        if (t < n) {
-            const int b = (int)(t / dm.B), pos = (int)(t - (int64_t)b * dm.B);
-            if (pos < dm.nb_of(b)) {
-                const int a = wi[t], c = wj[t];
-                if (a == -1)
-                    f = 1ull << 32;
-                else if ((a > c ? a : c) >= 2)
-                    f = 1ull;
-            }
+        if (pos < nb) {
+            const int a = wi[t], c = wj[t];
+            if (a == -1)
+                f = 1ull << 32;
+            else if ((a > c ? a : c) >= 2)
+                f = 1ull;
         }
         pf[t] = f;
     }
@@ -185,12 +325,9 @@ __global__ __launch_bounds__(256) void big_part_flags(BigDims dm, const int32_t 
 __global__ __launch_bounds__(256) void big_emit_order(BigDims dm, const int32_t *__restrict__ wi, const unsigned long long *__restrict__ pg,
                                                       int32_t *__restrict__ order, int32_t *__restrict__ nslots)
 {
-    const int64_t n = (int64_t)dm.B * dm.nbc;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
-        const int b = (int)(t / dm.B), pos = (int)(t - (int64_t)b * dm.B), nb = dm.nb_of(b);
-        if (pos >= nb)
-            continue;
-        const int64_t t0 = (int64_t)b * dm.B;
+    const int b = (int)blockIdx.y, nb = dm.nb_of(b);
+    for (int pos = (int)(blockIdx.x * blockDim.x + threadIdx.x); pos < nb; pos += (int)(gridDim.x * blockDim.x)) {
+        const int64_t t0 = (int64_t)b * dm.B, t = t0 + pos;
         const unsigned long long base = pg[t0], tot = pg[t0 + nb] - base, before = pg[t] - base, mine = pg[t + 1] - pg[t];
         const int n_front = (int)(tot >> 32), tot_multi = (int)(tot & 0xffffffffull);
         const int bf = (int)(before >> 32), bm = (int)(before & 0xffffffffull);
@@ -212,12 +349,9 @@ __global__ __launch_bounds__(256) void big_gather(BigDims dm, const int32_t *__r
                                                   const int4 *__restrict__ i_tmp, const int4 *__restrict__ j_tmp,
                                                   int2 *__restrict__ slot_pu, int4 *__restrict__ i_desc, int4 *__restrict__ j_desc)
 {
-    const int64_t n = (int64_t)dm.B * dm.nbc;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
-        const int b = (int)(t / dm.B), sl = (int)(t - (int64_t)b * dm.B);
-        if (sl >= dm.nb_of(b))
-            continue;
-        const int64_t t0 = (int64_t)b * dm.B;
+    const int b = (int)blockIdx.y, nb = dm.nb_of(b);
+    for (int sl = (int)(blockIdx.x * blockDim.x + threadIdx.x); sl < nb; sl += (int)(gridDim.x * blockDim.x)) {
+        const int64_t t0 = (int64_t)b * dm.B, t = t0 + sl;
         const int pos = order[t];
         slot_pu[t] = make_int2(pos, u[t0 + pos]);
         i_desc[t] = i_tmp[t0 + pos];
@@ -230,7 +364,7 @@ inline size_t up256(size_t x) { return (x + 255) / 256 * 256; }
 } // namespace
 
 int crec_lazy_index_big(crec_ctx *ctx, const int32_t *u, const int32_t *i, const int32_t *j, int64_t n_chunk, int32_t B, int64_t nbc,
-                        int bits_u, int bits_q, int spw, const LazyIndexOut &out, hipStream_t st)
+                        int bits_u, int bits_q, int spw, const LazyIndexOut &out, hipStream_t st, int64_t reserve_nbc)
 {
     CREC_REQUIRE(ctx, B >= 1 && B <= LAZY_MAX_B, "batch_size %d: the lazy step's descriptors hold batches of at most %d triples", B, LAZY_MAX_B);
     const int64_t E = 3 * (int64_t)B * nbc, NB = (int64_t)B * nbc;
@@ -239,51 +373,87 @@ int crec_lazy_index_big(crec_ctx *ctx, const int32_t *u, const int32_t *i, const
     const int end_bit = bits_u > bits_q ? bits_u : bits_q;
 
     // scratch: keys / vals before and after the sort (the unsorted copies are dead after it and hold the runs' starts and
-    // lengths), positive-slot counts, front flags and their scan, the positions' flags and their scan, segment offsets
-    size_t sort_tmp = 0, scan32_tmp = 0, scan64_tmp = 0;
-    CREC_HIP(ctx, rocprim::segmented_radix_sort_pairs(nullptr, sort_tmp, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr,
-                                                      (uint32_t *)nullptr, (unsigned)E, (unsigned)(2 * nbc), (const uint32_t *)nullptr,
-                                                      (const uint32_t *)nullptr, 0u, (unsigned)end_bit, st));
-    CREC_HIP(ctx, rocprim::exclusive_scan(nullptr, scan32_tmp, (const int32_t *)nullptr, (int32_t *)nullptr, (int32_t)0, (size_t)(E + 1),
-                                          rocprim::plus<int32_t>(), st));
-    CREC_HIP(ctx, rocprim::exclusive_scan(nullptr, scan64_tmp, (const unsigned long long *)nullptr, (unsigned long long *)nullptr, 0ull,
-                                          (size_t)(NB + 1), rocprim::plus<unsigned long long>(), st));
-    size_t tmp_bytes = sort_tmp > scan32_tmp ? sort_tmp : scan32_tmp;
-    tmp_bytes = tmp_bytes > scan64_tmp ? tmp_bytes : scan64_tmp;
-    size_t off = 0;
-    const auto take = [&off](size_t bytes) {
-        const size_t at = off;
-        off += up256(bytes);
-        return at;
+    // lengths), positive-slot counts, front flags and their scan, the positions' flags and their scan, the sort's digit counters
+    struct Lay {
+        size_t k0, v0, k1, v1, ci, fp, fg, wi, wj, pf, pg, hist, tmp, bytes, scan32, scan64;
     };
-    const size_t o_k0 = take(4 * (size_t)(E + 1)), o_v0 = take(4 * (size_t)(E + 1)), o_k1 = take(4 * (size_t)(E + 1)), o_v1 = take(4 * (size_t)(E + 1));
-    const size_t o_ci = take(4 * (size_t)(E + 1)), o_fp = take(4 * (size_t)(E + 1)), o_fg = take(4 * (size_t)(E + 1));
-    const size_t o_wi = take(4 * (size_t)NB), o_wj = take(4 * (size_t)NB), o_pf = take(8 * (size_t)(NB + 1)), o_pg = take(8 * (size_t)(NB + 1));
-    const size_t o_sb = take(4 * (size_t)(2 * nbc)), o_se = take(4 * (size_t)(2 * nbc)), o_tmp = take(tmp_bytes + 256);
-    if (int rc = crec_reserve(ctx, &ctx->big_ws, off))
+    SortDims sd{dm, (int)((B + SORT_TILE - 1) / SORT_TILE), (int)((2 * (int64_t)B + SORT_TILE - 1) / SORT_TILE), 0};
+    sd.tiles_max = sd.tiles_i;
+    const int passes = (end_bit + 7) / 8;
+    const auto layout = [&](int64_t nb_, Lay *L) -> hipError_t {
+        const int64_t E_ = 3 * (int64_t)B * nb_, NB_ = (int64_t)B * nb_;
+        hipError_t e = rocprim::exclusive_scan(nullptr, L->scan32, (const int32_t *)nullptr, (int32_t *)nullptr, (int32_t)0, (size_t)(E_ + 1),
+                                               rocprim::plus<int32_t>(), st);
+        if (e != hipSuccess)
+            return e;
+        e = rocprim::exclusive_scan(nullptr, L->scan64, (const unsigned long long *)nullptr, (unsigned long long *)nullptr, 0ull, (size_t)(NB_ + 1),
+                                    rocprim::plus<unsigned long long>(), st);
+        if (e != hipSuccess)
+            return e;
+        size_t off = 0;
+        const auto take = [&off](size_t bytes) {
+            const size_t at = off;
+            off += up256(bytes);
+            return at;
+        };
+        L->k0 = take(4 * (size_t)(E_ + 1)), L->v0 = take(4 * (size_t)(E_ + 1)), L->k1 = take(4 * (size_t)(E_ + 1)), L->v1 = take(4 * (size_t)(E_ + 1));
+        L->ci = take(4 * (size_t)(E_ + 1)), L->fp = take(4 * (size_t)(E_ + 1)), L->fg = take(4 * (size_t)(E_ + 1));
+        L->wi = take(4 * (size_t)NB_), L->wj = take(4 * (size_t)NB_), L->pf = take(8 * (size_t)(NB_ + 1)), L->pg = take(8 * (size_t)(NB_ + 1));
+        L->hist = take(4 * (size_t)(2 * nb_) * 256 * sd.tiles_max);
+        L->tmp = take((L->scan32 > L->scan64 ? L->scan32 : L->scan64) + 256);
+        L->bytes = off;
+        return hipSuccess;
+    };
+    Lay L{}, Lmax{};
+    CREC_HIP(ctx, layout(nbc, &L));
+    CREC_HIP(ctx, layout(reserve_nbc > nbc ? reserve_nbc : nbc, &Lmax)); // (a caller that pipelines chunks of growing size reserves for the largest up front)
+    if (int rc = crec_reserve(ctx, &ctx->big_ws, Lmax.bytes))
         return rc;
+    size_t scan32_tmp = L.scan32, scan64_tmp = L.scan64;
+    const size_t o_k0 = L.k0, o_v0 = L.v0, o_k1 = L.k1, o_v1 = L.v1, o_ci = L.ci, o_fp = L.fp, o_fg = L.fg, o_wi = L.wi, o_wj = L.wj, o_pf = L.pf,
+                 o_pg = L.pg, o_hist = L.hist, o_tmp = L.tmp;
     char *base = (char *)ctx->big_ws.ptr;
     uint32_t *k0 = (uint32_t *)(base + o_k0), *v0 = (uint32_t *)(base + o_v0), *k1 = (uint32_t *)(base + o_k1), *v1 = (uint32_t *)(base + o_v1);
     int32_t *rstart = (int32_t *)k0, *rcnt = (int32_t *)v0; // (after the sort)
+    int32_t *hist = (int32_t *)(base + o_hist);
     int32_t *rci = (int32_t *)(base + o_ci), *fp = (int32_t *)(base + o_fp), *fg = (int32_t *)(base + o_fg);
     int32_t *wi = (int32_t *)(base + o_wi), *wj = (int32_t *)(base + o_wj);
     unsigned long long *pf = (unsigned long long *)(base + o_pf), *pg = (unsigned long long *)(base + o_pg);
-    uint32_t *sb = (uint32_t *)(base + o_sb), *se = (uint32_t *)(base + o_se);
     void *tmp = base + o_tmp;
 
-    const auto blocks = [](int64_t n) { const int64_t g = (n + 255) / 256; return dim3((unsigned)(g < 1 ? 1 : (g > 65536 ? 65536 : g))); };
-    hipLaunchKernelGGL(big_fill, blocks(E), dim3(256), 0, st, u, i, j, dm, k0, v0, sb, se);
-    CREC_HIP(ctx, rocprim::segmented_radix_sort_pairs(tmp, sort_tmp, (const uint32_t *)k0, k1, (const uint32_t *)v0, v1, (unsigned)E,
-                                                      (unsigned)(2 * nbc), (const uint32_t *)sb, (const uint32_t *)se, 0u, (unsigned)end_bit, st));
-    hipLaunchKernelGGL(big_runs, blocks(E + 1), dim3(256), 0, st, dm, (const uint32_t *)k1, (const uint32_t *)v1, rstart, rcnt, rci, fp, out.u_desc);
+    // grid.y = the batch, grid.x = enough workgroups for `per_batch` elements of it (capped: the kernels stride)
+    const auto blocks = [nbc](int64_t per_batch) {
+        int64_t g = (per_batch + 255) / 256;
+        g = g < 1 ? 1 : (g > 1024 ? 1024 : g);
+        return dim3((unsigned)g, (unsigned)nbc);
+    };
+    {
+        // the passes ping-pong between the two pairs of arrays and must end in (k1, v1): an even number of them starts there
+        const dim3 tiles((unsigned)(nbc * (sd.tiles_u + sd.tiles_i)));
+        uint32_t *ks = (passes & 1) ? k0 : k1, *vs = (passes & 1) ? v0 : v1, *kd = (passes & 1) ? k1 : k0, *vd = (passes & 1) ? v1 : v0;
+        hipLaunchKernelGGL(big_fill, blocks(3 * (int64_t)B), dim3(256), 0, st, u, i, j, dm, ks, vs);
+        for (int pass = 0; pass < passes; ++pass) {
+            hipLaunchKernelGGL(sort_hist, tiles, dim3(SORT_THREADS), 0, st, sd, (const uint32_t *)ks, 8 * pass, hist);
+            hipLaunchKernelGGL(sort_scan, dim3((unsigned)(2 * nbc)), dim3(1024), 0, st, sd, hist);
+            hipLaunchKernelGGL(sort_scatter, tiles, dim3(SORT_THREADS), 0, st, sd, (const uint32_t *)ks, (const uint32_t *)vs, 8 * pass,
+                               (const int32_t *)hist, kd, vd);
+            uint32_t *t = ks;
+            ks = kd;
+            kd = t;
+            t = vs;
+            vs = vd;
+            vd = t;
+        }
+    }
+    hipLaunchKernelGGL(big_runs, blocks(3 * (int64_t)B), dim3(256), 0, st, dm, (const uint32_t *)k1, (const uint32_t *)v1, rstart, rcnt, rci, fp, out.u_desc);
     CREC_HIP(ctx, rocprim::exclusive_scan(tmp, scan32_tmp, (const int32_t *)fp, fg, (int32_t)0, (size_t)(E + 1), rocprim::plus<int32_t>(), st));
-    hipLaunchKernelGGL(big_item_desc, blocks(2 * NB), dim3(256), 0, st, dm, spw, (const uint32_t *)k1, (const uint32_t *)v1, (const int32_t *)rstart,
+    hipLaunchKernelGGL(big_item_desc, blocks(2 * (int64_t)B), dim3(256), 0, st, dm, spw, (const uint32_t *)k1, (const uint32_t *)v1, (const int32_t *)rstart,
                        (const int32_t *)rcnt, (const int32_t *)rci, (const int32_t *)fg, out.i_tmp, out.j_tmp, out.order, wi, wj);
-    hipLaunchKernelGGL(big_part_flags, blocks(NB + 1), dim3(256), 0, st, dm, (const int32_t *)wi, (const int32_t *)wj, pf);
+    hipLaunchKernelGGL(big_part_flags, blocks(B), dim3(256), 0, st, dm, (const int32_t *)wi, (const int32_t *)wj, pf);
     CREC_HIP(ctx, rocprim::exclusive_scan(tmp, scan64_tmp, (const unsigned long long *)pf, pg, 0ull, (size_t)(NB + 1),
                                           rocprim::plus<unsigned long long>(), st));
-    hipLaunchKernelGGL(big_emit_order, blocks(NB), dim3(256), 0, st, dm, (const int32_t *)wi, (const unsigned long long *)pg, out.order, out.nslots);
-    hipLaunchKernelGGL(big_gather, blocks(NB), dim3(256), 0, st, dm, u, (const int32_t *)out.order, (const int4 *)out.i_tmp, (const int4 *)out.j_tmp,
+    hipLaunchKernelGGL(big_emit_order, blocks(B), dim3(256), 0, st, dm, (const int32_t *)wi, (const unsigned long long *)pg, out.order, out.nslots);
+    hipLaunchKernelGGL(big_gather, blocks(B), dim3(256), 0, st, dm, u, (const int32_t *)out.order, (const int4 *)out.i_tmp, (const int4 *)out.j_tmp,
                        out.slot_pu, out.i_desc, out.j_desc);
     CREC_HIP(ctx, hipGetLastError());
     return CREC_OK;

@@ -35,4 +35,4 @@ struct LazyIndexOut {
     int32_t *nslots;                // [nbc][2] {triples of the batch, of which in the item-sorted front region}
 };
 int crec_lazy_index_big(crec_ctx *ctx, const int32_t *u, const int32_t *i, const int32_t *j, int64_t n_chunk, int32_t B, int64_t nbc,
-                        int bits_u, int bits_q, int spw, const LazyIndexOut &out, hipStream_t st);
+                        int bits_u, int bits_q, int spw, const LazyIndexOut &out, hipStream_t st, int64_t reserve_nbc = 0);

@@ -74,7 +74,10 @@ const char *crec_last_error(const crec_ctx *ctx);
  *   "no_zero_copy"   1: the tf1 step's per-chunk counts come back by copy + stream synchronisation instead of being written
  *                    into page-locked memory by the index kernel itself
  *   "big_index"      1: the lazy-family steps index their batches through the global-memory sort (index_big.hip, the form batches of
- *                    more than 8192 triples always take) even where the in-LDS sort would do: same index, bit for bit */
+ *                    more than 8192 triples always take) even where the in-LDS sort would do: same index, bit for bit
+ *   "idx_overlap"    1: that form indexes its chunks of batches a chunk ahead on a side stream, beside the previous chunk's steps
+ *                    (two index buffers), instead of in line on the caller's stream: same results.  Off by default: on one GPU
+ *                    the step kernel slows down by what the index kernels take (measured: 135 against 133 us per step) */
 int crec_ctx_set_option(crec_ctx *ctx, const char *name, int64_t value);
 
 /* ---- measurement: per-kernel time from HIP events recorded on the launch stream ------------

@@ -131,6 +131,31 @@ def test_big_index_option_changes_nothing(mode):
         assert np.array_equal(x, y)
 
 
+def test_chunks_indexed_ahead_on_a_side_stream_change_nothing():
+    """An epoch of several chunks under the `idx_overlap` option: chunk c + 1 is indexed on a side stream beside chunk c's steps (two
+    index buffers, chunks of 32, 64, ... batches here).  Same tables and losses, bit for bit, as with every chunk indexed in line
+    (the default) -- twice in a row, so that the second epoch's first build meets the first epoch's last steps."""
+    U, I, d, B = 30000, 8000, 32, 16384
+    n = 75 * B + 123
+    u, i, j = _stream(4, n, U, I, zipf=1.25)
+    g = np.random.Generator(np.random.PCG64(8))
+    P0 = (g.standard_normal((U, d)) * 0.01).astype(np.float32)
+    Q0 = (g.standard_normal((I, d)) * 0.01).astype(np.float32)
+    out = []
+    for overlap in (1, 0):
+        s = runtime.Session(0)
+        s.ctx.check(s.lib.crec_ctx_set_option(s.ctx.h, b"idx_overlap", C.c_int64(overlap)))
+        st = runtime.BprState(s, P0, Q0, lr=1e-3, reg=0.01, adam_mode="lazy")
+        a = [s.to_dev(x) for x in (u, i, j)]
+        l1 = st.train_epoch(a[0], a[1], a[2], B).cpu().numpy()
+        l2 = st.train_epoch(a[0], a[1], a[2], B).cpu().numpy()
+        out.append([l1, l2] + [getattr(st, k).cpu().numpy() for k in ("P", "Q", "mP", "mQ", "vP", "vQ")])
+        s.close()
+    assert len(out[0][0]) == 76
+    for x, y in zip(*out):
+        assert np.array_equal(x, y)
+
+
 def test_class_surface_takes_a_large_batch(sess, tmp_path):
     """batch_size = 20000 through the BPR class: validate() lets it through, Adam runs in its deferred form, and the epochs match an
     oracle run of the reference's protocol with TF1's swept Adam (same np.random sampler stream)."""
