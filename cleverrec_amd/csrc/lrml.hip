@@ -379,7 +379,7 @@ extern "C" int crec_lrml_train_epoch(crec_ctx *ctx, const crec_lrml *m, crec_ada
         crec_rows_opt o{};
         o.kind = ROWS_SPARSE_TF1;
         o.reg_occ = m->reg;
-        if (int rc = crec_rows_optimizer(ctx, opt, &o))
+        if (int rc = crec_rows_optimizer(ctx, opt, &o, true))
             return rc;
         hipLaunchKernelGGL(tile_fn, dim3((unsigned)tiles), dim3(NT), lds, st, (const float *)m->P.var, (const float *)m->Q.var,
                            (const float *)m->small.var, d, mem, u + t0, i + t0, j + t0, nbt, m->reg, m->margin, c_p, c_q, slots,

@@ -580,7 +580,7 @@ extern "C" int crec_ncf_train_epoch(crec_ctx *ctx, const crec_ncf *mdl, crec_ada
         const int nbt = (int)((N - t0) < B ? (N - t0) : B);
         crec_rows_opt o{};
         o.kind = ROWS_SPARSE_TF1;
-        if (int rc = crec_rows_optimizer(ctx, opt, &o))
+        if (int rc = crec_rows_optimizer(ctx, opt, &o, true))
             return rc;
         crec_prof_begin(ctx, CREC_K_NCF_TILE, st);
         CREC_KLAUNCH(ctx, tile_fn, dim3((unsigned)crec_ceil_div(crec_ceil_div(nbt, T), NCF_GRID_DIV)), dim3(NT), lds, st, d, u + t0, i + t0, y + t0, nbt,
@@ -604,7 +604,7 @@ extern "C" int crec_ncf_train_epoch(crec_ctx *ctx, const crec_ncf *mdl, crec_ada
         od.kind = ROWS_DENSE;
         const crec_small_job small{mdl->small.var, mdl->small.m, mdl->small.v, partial, (int)crec_ceil_div(nbt, T), d.n_small,
                                    d.n_small, od};
-        if (has_g && has_m && d.dg == hm && o.opt == 0 && !ctx->knob_ncf_generic) {
+        if (has_g && has_m && d.dg == hm && o.opt == 0 && o.kind == ROWS_SPARSE_TF1 && !ctx->knob_ncf_generic) {
             // NeuMF with equal widths: a user's P_gmf and P_mlp rows (an item's Q_gmf and Q_mlp rows) share their slots --
             // one wave updates both (rows_apply_row_pair): half the waves, the index walked once
             job(mdl->P_gmf, U, d.dg, vu, c_pg, mdl->reg_gmf);

@@ -24,12 +24,19 @@ struct crec_rows_opt {
 };
 
 // the step's optimizer out of a crec_adam (adam_mode tf1 = Adam | CREC_OPT_SGD | CREC_OPT_ADAGRAD) into a crec_rows_opt:
-// opt, lr_t (Adam: lr*sqrt(1-b2^t)/(1-b1^t) with the fp32 running powers; else the plain lr), betas, eps
-inline int crec_rows_optimizer(crec_ctx *ctx, const crec_adam *opt, crec_rows_opt *o)
+// opt, lr_t (Adam: lr*sqrt(1-b2^t)/(1-b1^t) with the fp32 running powers; else the plain lr), betas, eps.
+// lazy_ok: the model's embedding tables are reached by gathers only and updated as plain row jobs, so adam_mode lazy may turn
+// their kind (preset ROWS_SPARSE_TF1 by the caller) into ROWS_SPARSE_LAZY -- Adam's formula on the rows a batch touches, every
+// other row and its slots left as they are (what BPR's lazy mode does; not TF1's results); dense variables keep ApplyAdam.
+inline int crec_rows_optimizer(crec_ctx *ctx, const crec_adam *opt, crec_rows_opt *o, bool lazy_ok = false)
 {
-    const bool adam = opt->adam_mode == CREC_ADAM_TF1;
+    const bool lazy = lazy_ok && opt->adam_mode == CREC_ADAM_LAZY && o->kind == ROWS_SPARSE_TF1;
+    const bool adam = opt->adam_mode == CREC_ADAM_TF1 || lazy;
     CREC_REQUIRE(ctx, adam || opt->adam_mode == CREC_OPT_SGD || opt->adam_mode == CREC_OPT_ADAGRAD,
-                 "this model's step implements adam_mode tf1 (Adam), CREC_OPT_SGD and CREC_OPT_ADAGRAD");
+                 lazy_ok ? "this model's step implements adam_mode tf1 / lazy (Adam), CREC_OPT_SGD and CREC_OPT_ADAGRAD"
+                         : "this model's step implements adam_mode tf1 (Adam), CREC_OPT_SGD and CREC_OPT_ADAGRAD");
+    if (lazy)
+        o->kind = ROWS_SPARSE_LAZY;
     o->opt = adam ? 0 : opt->adam_mode;
     o->lr_t = adam ? (opt->lr * sqrtf(1.0f - opt->beta2_power)) / (1.0f - opt->beta1_power) : opt->lr;
     o->beta1 = opt->beta1;

@@ -30,7 +30,7 @@ class GMF(RankingRecommender):
         Q = init.get('Q', None) if 'Q' in init else self.initializer([I, d])
         h = init.get('h_gmf', None) if 'h_gmf' in init else self.initializer([d])  # biases use the same initializer (GMF.py:25-26)
         self.state = NcfState(self.sess, 'GMF', {'P_gmf': P, 'Q_gmf': Q}, [], [], h, self.lr, reg_gmf=self.reg, loss_func=self.loss_func,
-                              optimizer=self.optimizer)
+                              optimizer=self.state_optimizer)
         self.P, self.Q, self.h_gmf = self.state.t['P_gmf'], self.state.t['Q_gmf'], self.state.h
 
     def _create_embeddings(self):

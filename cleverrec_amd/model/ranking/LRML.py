@@ -32,7 +32,7 @@ class LRML(RankingRecommender):
         Q = init['Q'] if 'Q' in init else self.initializer([I, d])
         K = init['K'] if 'K' in init else self.initializer([d, mem])
         M = init['M'] if 'M' in init else self.initializer([mem, d])
-        self.state = LrmlState(self.sess, P, Q, K, M, self.lr, self.reg, self.margin, optimizer=self.optimizer)
+        self.state = LrmlState(self.sess, P, Q, K, M, self.lr, self.reg, self.margin, optimizer=self.state_optimizer)
         self.P, self.Q, self.K, self.M = self.state.P, self.state.Q, self.state.K, self.state.M
 
     def _create_embeddings(self):

@@ -37,7 +37,7 @@ class MLP(RankingRecommender):
             if L[k] != L[k - 1] // 2:
                 raise ValueError("layers=%s: layer k must take the previous layer's output width" % L)
         self.state = NcfState(self.sess, 'MLP', {'P_mlp': P, 'Q_mlp': Q}, Ws, bs, h, self.lr, reg_mlp=self.reg, loss_func=self.loss_func,
-                              optimizer=self.optimizer)
+                              optimizer=self.state_optimizer)
         self.P, self.Q, self.h_mlp = self.state.t['P_mlp'], self.state.t['Q_mlp'], self.state.h
         self.mlp_params = {}
         for k in range(len(L)):

