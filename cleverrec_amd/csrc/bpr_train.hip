@@ -2568,8 +2568,11 @@ int sharded_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, int64_t I_global
     CREC_REQUIRE(ctx, N >= 1 && u && i && j && loss_per_batch, "the sharded epoch is collective: every rank passes N >= 1 triples");
     CREC_REQUIRE(ctx, t->P && t->Q && t->mP && t->vP && t->mQ && t->vQ, "null table pointer");
     CREC_REQUIRE(ctx, t->d >= 4 && t->d <= 256 && t->d % 4 == 0, "embed_size %d: need a multiple of 4 in [4, 256]", t->d);
-    CREC_REQUIRE(ctx, B >= 1 && B <= MAX_B, "batch_size %d: this build indexes batches of at most %d in LDS", B, MAX_B);
+    CREC_REQUIRE(ctx, B >= 1 && B <= LAZY_MAX_B, "batch_size %d: batches of 1..%d triples", B, LAZY_MAX_B);
     CREC_REQUIRE(ctx, opt->adam_mode == CREC_ADAM_LAZY, "the row-sharded step is built for adam_mode lazy");
+    // batches beyond the in-LDS sorts take the three index builds of a chunk (plan, owner side, compact-id index) through
+    // index_big.hip's global-memory sort: the same indices, bit for bit, and no cap on the rows one owner serves per batch
+    const bool big = B > MAX_B || ctx->knob_big_index;
     crec_xch *x = crec_xch_of(ctx);
     const int G = x->world, me = x->rank;
     CREC_REQUIRE(ctx, G >= 1 && G <= 64, "world size 1..64");
@@ -2595,6 +2598,9 @@ int sharded_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, int64_t I_global
     const size_t per_batch = layout_index(nullptr, 1, B, t->U, IC, false, CH).bytes;
     int64_t chunk = (int64_t)((size_t)1 << 30) / (int64_t)per_batch;
     chunk = chunk < 1 ? 1 : (chunk > 1024 ? 1024 : chunk);
+    if (big && chunk * B > ((int64_t)1 << 22)) // index_big.hip's scratch: ~100 bytes per triple of the chunk
+        chunk = ((int64_t)1 << 22) / B;
+    chunk = chunk < 1 ? 1 : chunk;
     chunk = chunk > nb ? nb : chunk;
     // a transport that stages a rank's payload (the peer windows) bounds what one exchange carries: per step the rows of a batch,
     // per chunk the request lists of its batches (every rank holds the same B, d and window, so every rank cuts the same chunks)
@@ -2682,10 +2688,11 @@ int sharded_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, int64_t I_global
     }
 
     const int cap_plan = (int)((IC + 63) / 64 * 64);
-    CREC_HIP(ctx, hipFuncSetAttribute((const void *)shard_plan_batches, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)shard_lds_bytes(cap_plan)));
+    if (!big)
+        CREC_HIP(ctx, hipFuncSetAttribute((const void *)shard_plan_batches, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)shard_lds_bytes(cap_plan)));
     const int cap_idx = (2 * B + 63) / 64 * 64;
-    const size_t lds_idx = index_lds_bytes(cap_idx);
+    const size_t lds_idx = big ? 0 : index_lds_bytes(cap_idx);
     if (lds_idx > ctx->index_lds_set) {
         CREC_HIP(ctx, hipFuncSetAttribute((const void *)bpr_index_batches, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_idx));
         ctx->index_lds_set = lds_idx;
@@ -2712,10 +2719,16 @@ int sharded_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, int64_t I_global
         const int64_t t0 = b0 * B, n_chunk = (N - t0) < nbc * B ? (N - t0) : nbc * B;
         const PlanWs p = plan_layout(ctx->shard_ws.ptr, nbc);
         // 1. plan: compact ids and request lists of every batch of the chunk
-        crec_prof_begin(ctx, CREC_K_SHARD_PLAN, st);
-        CREC_KLAUNCH(ctx, shard_plan_batches, dim3((unsigned)nbc), dim3(SHARD_THREADS), shard_lds_bytes(cap_plan), st, i + t0,
-                     j + t0, n_chunk, B, cap_plan, G, S, row_bits((int64_t)G * S), p.req_keys, p.n_req, p.req_off, p.ci, p.cj);
-        crec_prof_end(ctx, st);
+        if (big) {
+            if (int rc = crec_shard_plan_big(ctx, i + t0, j + t0, n_chunk, B, nbc, G, S, row_bits((int64_t)G * S), p.req_keys, p.n_req, p.req_off,
+                                             p.ci, p.cj, st))
+                return rc;
+        } else {
+            crec_prof_begin(ctx, CREC_K_SHARD_PLAN, st);
+            CREC_KLAUNCH(ctx, shard_plan_batches, dim3((unsigned)nbc), dim3(SHARD_THREADS), shard_lds_bytes(cap_plan), st, i + t0,
+                         j + t0, n_chunk, B, cap_plan, G, S, row_bits((int64_t)G * S), p.req_keys, p.n_req, p.req_off, p.ci, p.cj);
+            crec_prof_end(ctx, st);
+        }
         // 2. the per-owner counts -> host; every rank tells every owner how many rows each batch will ask for
         char *hp = (char *)ctx->pinned64;
         const auto htake = [&hp](size_t bytes) {
@@ -2778,7 +2791,7 @@ int sharded_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, int64_t I_global
         // peers blocked in the exchanges below for ever.  So the verdict is collective: every rank contributes whether IT can go
         // on (one float through the all-reduce the chunk ends with anyway) and all of them fail together.
         int local_rc = CREC_OK;
-        if (stride > 16 * SHARD_THREADS)
+        if (!big && stride > 16 * SHARD_THREADS)
             local_rc = crec_fail(ctx, CREC_EINVAL, "a batch asks this rank for %lld rows; the owner-side index sorts at most %d per batch in LDS",
                                  (long long)stride, 16 * SHARD_THREADS);
         else
@@ -2818,16 +2831,25 @@ int sharded_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, int64_t I_global
             return rc;
         // 5. owner-side index of every batch, then the occurrence index over the compact ids
         const int cap_srv = (int)stride;
-        CREC_HIP(ctx, hipFuncSetAttribute((const void *)shard_owner_index, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)shard_lds_bytes(cap_srv)));
-        hipLaunchKernelGGL(shard_owner_index, dim3((unsigned)nbc), dim3(SHARD_THREADS), shard_lds_bytes(cap_srv), st,
-                           (const int32_t *)v.ids_recv, (const int64_t *)p.srv_base, (const int32_t *)p.srv_cnt, G, cap_srv,
-                           cap_srv, row_bits(S), v.srv_rows, v.order, v.urows, v.useg, v.n_urows);
         IndexWs w = layout_index(ctx->idx_ws.ptr, nbc, B, t->U, IC, false, CH, 0, 0, lazy_spw(d));
-        crec_prof_begin(ctx, CREC_K_INDEX, st);
-        CREC_KLAUNCH(ctx, bpr_index_batches, dim3((unsigned)(2 * nbc)), dim3(PREP_THREADS), lds_idx, st, u + t0,
-                     (const int32_t *)p.ci, (const int32_t *)p.cj, n_chunk, B, cap_idx, w);
-        crec_prof_end(ctx, st);
+        if (big) {
+            if (int rc = crec_shard_owner_index_big(ctx, v.ids_recv, p.srv_base, p.srv_cnt, G, nbc, stride, row_bits(S), v.srv_rows, v.order, v.urows,
+                                                    v.useg, v.n_urows, st))
+                return rc;
+            const LazyIndexOut o{w.u_desc, w.i_desc, w.j_desc, w.i_tmp, w.j_tmp, w.slot_pu, w.order, w.nslots};
+            if (int rc = crec_lazy_index_big(ctx, u + t0, p.ci, p.cj, n_chunk, B, nbc, w.bits_u, w.bits_q, w.spw, o, st))
+                return rc;
+        } else {
+            CREC_HIP(ctx, hipFuncSetAttribute((const void *)shard_owner_index, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              (int)shard_lds_bytes(cap_srv)));
+            hipLaunchKernelGGL(shard_owner_index, dim3((unsigned)nbc), dim3(SHARD_THREADS), shard_lds_bytes(cap_srv), st,
+                               (const int32_t *)v.ids_recv, (const int64_t *)p.srv_base, (const int32_t *)p.srv_cnt, G, cap_srv,
+                               cap_srv, row_bits(S), v.srv_rows, v.order, v.urows, v.useg, v.n_urows);
+            crec_prof_begin(ctx, CREC_K_INDEX, st);
+            CREC_KLAUNCH(ctx, bpr_index_batches, dim3((unsigned)(2 * nbc)), dim3(PREP_THREADS), lds_idx, st, u + t0,
+                         (const int32_t *)p.ci, (const int32_t *)p.cj, n_chunk, B, cap_idx, w);
+            crec_prof_end(ctx, st);
+        }
         const int32_t *hn = nullptr; // the lazy step's launches are sized by the batch alone
         a.cur = Tables{t->P, t->mP, t->vP, p.Qc, nullptr, nullptr};
         // 6. the steps

@@ -21,6 +21,7 @@
 // batches both can build); the triple pass does not know which builder ran.
 #include "crec_internal.h"
 #include "lazy_desc.h"
+#include "shard_index.h"
 
 #include <rocprim/rocprim.hpp>
 
@@ -56,8 +57,14 @@ __device__ __forceinline__ BigAt big_at(const BigDims &dm, int b, int r) // r: t
 }
 
 __global__ __launch_bounds__(256) void big_fill(const int32_t *__restrict__ u, const int32_t *__restrict__ i, const int32_t *__restrict__ j,
-                                                BigDims dm, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals)
+                                                BigDims dm, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
+                                                int64_t *__restrict__ seg0, int32_t *__restrict__ segn)
 {
+    if (blockIdx.x == 0 && threadIdx.x < 2) { // segment 2 * batch + side
+        const int b = (int)blockIdx.y, side = (int)threadIdx.x, nb = dm.nb_of(b);
+        seg0[2 * b + side] = 3 * (int64_t)dm.B * b + (side ? dm.B : 0);
+        segn[2 * b + side] = side ? 2 * nb : nb;
+    }
     // (the launches over a chunk's elements: grid.y = the batch, grid.x strides over the batch's elements -- no 64-bit divisions)
     const int b = (int)blockIdx.y;
     for (int r = (int)(blockIdx.x * blockDim.x + threadIdx.x); r < 3 * dm.B; r += (int)(gridDim.x * blockDim.x)) {
@@ -83,46 +90,38 @@ __global__ __launch_bounds__(256) void big_fill(const int32_t *__restrict__ u, c
 //                 digit bit (block_sort.h's scheme), per-wave digit counts are summed in wave order -- and the element moves
 constexpr int SORT_THREADS = 256, SORT_WAVES = SORT_THREADS / 64, SORT_PER_WAVE = 512, SORT_TILE = SORT_WAVES * SORT_PER_WAVE;
 
-struct SortDims {
-    BigDims dm;
-    int tiles_u, tiles_i, tiles_max; // tiles of a user / an item segment (of a full batch)
-    __device__ __forceinline__ void at(int blk, int *b, int *side, int *tile) const
-    {
-        const int per = tiles_u + tiles_i;
-        *b = blk / per;
-        const int r = blk - *b * per;
-        *side = r >= tiles_u ? 1 : 0;
-        *tile = *side ? r - tiles_u : r;
-    }
+// the segments of one sort: segment s holds segn[s] pairs from element seg0[s] on; a launch has a workgroup per (tile, segment)
+struct SegSort {
+    const int64_t *seg0; // [nseg] device
+    const int32_t *segn; // [nseg] device
+    int tiles_max;       // tiles of the longest segment
 };
 
-__global__ __launch_bounds__(SORT_THREADS) void sort_hist(SortDims sd, const uint32_t *__restrict__ keys, int shift, int32_t *__restrict__ hist)
+__global__ __launch_bounds__(SORT_THREADS) void sort_hist(SegSort sd, const uint32_t *__restrict__ keys, int shift, int32_t *__restrict__ hist)
 {
     __shared__ int cnt[256];
-    int b, side, tile;
-    sd.at((int)blockIdx.x, &b, &side, &tile);
-    const int nb = sd.dm.nb_of(b), n = side ? 2 * nb : nb;
-    const uint32_t *sk = keys + 3 * (int64_t)sd.dm.B * b + (side ? sd.dm.B : 0);
+    const int seg = (int)blockIdx.y, tile = (int)blockIdx.x, n = sd.segn[seg];
+    const uint32_t *sk = keys + sd.seg0[seg];
     cnt[threadIdx.x] = 0;
     __syncthreads();
     const int k0 = tile * SORT_TILE;
     for (int k = k0 + (int)threadIdx.x; k < k0 + SORT_TILE && k < n; k += SORT_THREADS)
         atomicAdd(&cnt[(sk[k] >> shift) & 255u], 1);
     __syncthreads();
-    hist[((int64_t)(b * 2 + side) * 256 + threadIdx.x) * sd.tiles_max + tile] = cnt[threadIdx.x];
+    hist[((int64_t)seg * 256 + threadIdx.x) * sd.tiles_max + tile] = cnt[threadIdx.x]; // (a tile behind the segment's end: zeros)
 }
 
-__global__ __launch_bounds__(1024) void sort_scan(SortDims sd, int32_t *__restrict__ hist)
+__global__ __launch_bounds__(1024) void sort_scan(SegSort sd, int32_t *__restrict__ hist)
 {
     __shared__ int wave_sums[1024 / 64 + 2];
-    const int seg = (int)blockIdx.x, side = seg & 1, tiles = side ? sd.tiles_i : sd.tiles_u;
+    const int seg = (int)blockIdx.x;
     int32_t *h = hist + (int64_t)seg * 256 * sd.tiles_max;
-    // the scan runs over (digit, tile < tiles); a thread owns a contiguous span of it
-    const int total = 256 * tiles, per = (total + 1023) / 1024;
+    // the scan runs over (digit, tile), which is how the counters lie in memory; a thread owns a contiguous span of it
+    const int total = 256 * sd.tiles_max, per = (total + 1023) / 1024;
     const int v0 = (int)threadIdx.x * per, v1 = (v0 + per) < total ? (v0 + per) : total;
     int sum = 0;
     for (int v = v0; v < v1; ++v)
-        sum += h[(v / tiles) * sd.tiles_max + v % tiles];
+        sum += h[v];
     // (an exclusive scan over the workgroup's threads, as block_sort.h's)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int incl = sum;
@@ -149,23 +148,20 @@ __global__ __launch_bounds__(1024) void sort_scan(SortDims sd, int32_t *__restri
     __syncthreads();
     int run = wave_sums[wave] + incl - sum;
     for (int v = v0; v < v1; ++v) {
-        int32_t *p = h + (v / tiles) * sd.tiles_max + v % tiles;
-        const int c = *p;
-        *p = run;
+        const int c = h[v];
+        h[v] = run;
         run += c;
     }
 }
 
-__global__ __launch_bounds__(SORT_THREADS) void sort_scatter(SortDims sd, const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals,
+__global__ __launch_bounds__(SORT_THREADS) void sort_scatter(SegSort sd, const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals,
                                                              int shift, const int32_t *__restrict__ hist, uint32_t *__restrict__ keys_out,
                                                              uint32_t *__restrict__ vals_out)
 {
     __shared__ int wcnt[SORT_WAVES][257]; // per wave: running count per digit
     __shared__ int base[256];             // per digit: where this tile's elements of the digit start in the segment
-    int b, side, tile;
-    sd.at((int)blockIdx.x, &b, &side, &tile);
-    const int nb = sd.dm.nb_of(b), n = side ? 2 * nb : nb;
-    const int64_t seg0 = 3 * (int64_t)sd.dm.B * b + (side ? sd.dm.B : 0);
+    const int seg = (int)blockIdx.y, tile = (int)blockIdx.x, n = sd.segn[seg];
+    const int64_t seg0 = sd.seg0[seg];
     if (tile * SORT_TILE >= n)
         return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -182,7 +178,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter(SortDims sd, const 
     }
     for (int c = lane; c < 256; c += 64)
         wcnt[wave][c] = 0;
-    base[tid] = hist[((int64_t)(b * 2 + side) * 256 + tid) * sd.tiles_max + tile];
+    base[tid] = hist[((int64_t)seg * 256 + tid) * sd.tiles_max + tile];
     // rank inside the wave: LDS operations of one wave execute in order, so the running counter written in round s is the
     // one read in round s + 1
 #pragma unroll
@@ -222,6 +218,30 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter(SortDims sd, const 
         }
     }
 }
+
+// (ka, va) -> sorted by the low `bits` bits of the key, every segment by itself, equal keys in their incoming order.  The passes
+// ping-pong between (ka, va) and (kb, vb); *kres / *vres: where the result is.  hist: 256 * tiles_max ints per segment.
+inline void seg_sort(const SegSort &sd, int nseg, int bits, uint32_t *ka, uint32_t *va, uint32_t *kb, uint32_t *vb, int32_t *hist, hipStream_t st,
+                     uint32_t **kres, uint32_t **vres)
+{
+    const dim3 tiles((unsigned)sd.tiles_max, (unsigned)nseg);
+    uint32_t *ks = ka, *vs = va, *kd = kb, *vd = vb;
+    for (int pass = 0; pass < (bits + 7) / 8; ++pass) {
+        hipLaunchKernelGGL(sort_hist, tiles, dim3(SORT_THREADS), 0, st, sd, (const uint32_t *)ks, 8 * pass, hist);
+        hipLaunchKernelGGL(sort_scan, dim3((unsigned)nseg), dim3(1024), 0, st, sd, hist);
+        hipLaunchKernelGGL(sort_scatter, tiles, dim3(SORT_THREADS), 0, st, sd, (const uint32_t *)ks, (const uint32_t *)vs, 8 * pass,
+                           (const int32_t *)hist, kd, vd);
+        uint32_t *t = ks;
+        ks = kd;
+        kd = t;
+        t = vs;
+        vs = vd;
+        vd = t;
+    }
+    *kres = ks;
+    *vres = vs;
+}
+inline int sort_tiles(int64_t longest) { return (int)((longest + SORT_TILE - 1) / SORT_TILE > 0 ? (longest + SORT_TILE - 1) / SORT_TILE : 1); }
 
 // first index in [lo, hi) of the sorted keys that is >= x (UPPER: > x)
 template <bool UPPER> __device__ __forceinline__ int big_bound(const uint32_t *__restrict__ keys, int lo, int hi, uint32_t x)
@@ -359,6 +379,123 @@ __global__ __launch_bounds__(256) void big_gather(BigDims dm, const int32_t *__r
     }
 }
 
+// ---- the row-sharded step's two index builds (shard_kernels.h: shard_plan_batches, shard_owner_index) for batches of any size:
+// the same outputs, bit for bit, from the same sort.  Arrays are flat [nseg][stride]; segment b holds segn[b] valid elements.
+__global__ __launch_bounds__(256) void plan_fill(const int32_t *__restrict__ i, const int32_t *__restrict__ j, BigDims dm, int32_t G, int64_t S,
+                                                 uint32_t *__restrict__ keys, uint32_t *__restrict__ vals, int64_t *__restrict__ seg0,
+                                                 int32_t *__restrict__ segn)
+{
+    const int b = (int)blockIdx.y, nb = dm.nb_of(b);
+    const int64_t t0 = (int64_t)b * dm.B, e0 = 2 * t0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        seg0[b] = e0;
+        segn[b] = 2 * nb;
+    }
+    for (int k = (int)(blockIdx.x * blockDim.x + threadIdx.x); k < 2 * nb; k += (int)(gridDim.x * blockDim.x)) {
+        const int64_t g = k < nb ? i[t0 + k] : j[t0 + k - nb];
+        keys[e0 + k] = shard_owner_key(g, G, S);
+        vals[e0 + k] = (uint32_t)k;
+    }
+}
+
+// heads[e] = 1 where a run of equal keys starts (valid elements only); the element behind the last segment closes the scan
+__global__ __launch_bounds__(256) void flat_heads(const uint32_t *__restrict__ keys, const int32_t *__restrict__ segn, int stride, int nseg,
+                                                  int32_t *__restrict__ heads)
+{
+    const int b = (int)blockIdx.y, n = segn[b];
+    const int64_t e0 = (int64_t)b * stride;
+    if (b == 0 && blockIdx.x == 0 && threadIdx.x == 0)
+        heads[(int64_t)nseg * stride] = 0;
+    for (int k = (int)(blockIdx.x * blockDim.x + threadIdx.x); k < stride; k += (int)(gridDim.x * blockDim.x))
+        heads[e0 + k] = (k < n && (k == 0 || keys[e0 + k] != keys[e0 + k - 1])) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void plan_emit(BigDims dm, int32_t G, int64_t S, const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals,
+                                                 const int32_t *__restrict__ heads, const int32_t *__restrict__ hs, int32_t *__restrict__ req_keys,
+                                                 int32_t *__restrict__ n_req, int32_t *__restrict__ req_off, int32_t *__restrict__ ci,
+                                                 int32_t *__restrict__ cj)
+{
+    const int b = (int)blockIdx.y, nb = dm.nb_of(b), n = 2 * nb;
+    const int64_t t0 = (int64_t)b * dm.B, e0 = 2 * t0;
+    const int base = hs[e0];
+    if (blockIdx.x == 0 && (int)threadIdx.x <= G) { // owner o's requests start at the rank of the first unique key of an owner >= o
+        const int o = (int)threadIdx.x;
+        const int lb = o == G ? n : big_bound<false>(keys + e0, 0, n, (uint32_t)((int64_t)o * S));
+        const int at = hs[e0 + lb] - base;
+        req_off[(int64_t)b * (G + 1) + o] = at;
+        if (o == G)
+            n_req[b] = at;
+    }
+    for (int k = (int)(blockIdx.x * blockDim.x + threadIdx.x); k < n; k += (int)(gridDim.x * blockDim.x)) {
+        const int64_t e = e0 + k;
+        const int h = heads[e], r = hs[e] + h - 1 - base; // the rank of this slot's item among the batch's unique items
+        if (h)
+            req_keys[e0 + r] = (int32_t)keys[e];
+        const int slot = (int)vals[e];
+        if (slot < nb)
+            ci[t0 + slot] = r;
+        else
+            cj[t0 + slot - nb] = r;
+    }
+}
+
+__global__ __launch_bounds__(256) void own_fill(const int32_t *__restrict__ ids_recv, const int64_t *__restrict__ srv_base,
+                                                const int32_t *__restrict__ srv_cnt, int32_t G, int stride, uint32_t *__restrict__ keys,
+                                                uint32_t *__restrict__ vals, int32_t *__restrict__ srv_rows, int64_t *__restrict__ seg0,
+                                                int32_t *__restrict__ segn)
+{
+    __shared__ int pre[66]; // slots of the peers before p
+    const int b = (int)blockIdx.y;
+    if (threadIdx.x == 0) {
+        int at = 0;
+        for (int p = 0; p < G; ++p) {
+            pre[p] = at;
+            at += srv_cnt[(int64_t)b * G + p];
+        }
+        pre[G] = at;
+    }
+    __syncthreads();
+    const int n = pre[G];
+    const int64_t e0 = (int64_t)b * stride;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        seg0[b] = e0;
+        segn[b] = n;
+    }
+    for (int s = (int)(blockIdx.x * blockDim.x + threadIdx.x); s < n; s += (int)(gridDim.x * blockDim.x)) {
+        int p = 0;
+        while (p + 1 < G && s >= pre[p + 1])
+            ++p;
+        const int32_t row = ids_recv[srv_base[(int64_t)b * G + p] + (s - pre[p])];
+        keys[e0 + s] = (uint32_t)row;
+        vals[e0 + s] = (uint32_t)s;
+        srv_rows[e0 + s] = row;
+    }
+}
+
+__global__ __launch_bounds__(256) void own_emit(const int32_t *__restrict__ segn, int stride, const uint32_t *__restrict__ keys,
+                                                const uint32_t *__restrict__ vals, const int32_t *__restrict__ heads, const int32_t *__restrict__ hs,
+                                                int32_t *__restrict__ order, int32_t *__restrict__ urows, int32_t *__restrict__ useg,
+                                                int32_t *__restrict__ n_urows)
+{
+    const int b = (int)blockIdx.y, n = segn[b];
+    const int64_t e0 = (int64_t)b * stride;
+    const int base = hs[e0];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const int total = hs[e0 + n] - base;
+        useg[(int64_t)b * (stride + 1) + total] = n;
+        n_urows[b] = total;
+    }
+    for (int k = (int)(blockIdx.x * blockDim.x + threadIdx.x); k < n; k += (int)(gridDim.x * blockDim.x)) {
+        const int64_t e = e0 + k;
+        if (heads[e]) {
+            const int r = hs[e] - base;
+            urows[e0 + r] = (int32_t)keys[e];
+            useg[(int64_t)b * (stride + 1) + r] = k;
+        }
+        order[e] = (int32_t)vals[e];
+    }
+}
+
 inline size_t up256(size_t x) { return (x + 255) / 256 * 256; }
 
 } // namespace
@@ -375,11 +512,9 @@ int crec_lazy_index_big(crec_ctx *ctx, const int32_t *u, const int32_t *i, const
     // scratch: keys / vals before and after the sort (the unsorted copies are dead after it and hold the runs' starts and
     // lengths), positive-slot counts, front flags and their scan, the positions' flags and their scan, the sort's digit counters
     struct Lay {
-        size_t k0, v0, k1, v1, ci, fp, fg, wi, wj, pf, pg, hist, tmp, bytes, scan32, scan64;
+        size_t k0, v0, k1, v1, ci, fp, fg, wi, wj, pf, pg, hist, seg0, segn, tmp, bytes, scan32, scan64;
     };
-    SortDims sd{dm, (int)((B + SORT_TILE - 1) / SORT_TILE), (int)((2 * (int64_t)B + SORT_TILE - 1) / SORT_TILE), 0};
-    sd.tiles_max = sd.tiles_i;
-    const int passes = (end_bit + 7) / 8;
+    const int tiles_max = sort_tiles(2 * (int64_t)B);
     const auto layout = [&](int64_t nb_, Lay *L) -> hipError_t {
         const int64_t E_ = 3 * (int64_t)B * nb_, NB_ = (int64_t)B * nb_;
         hipError_t e = rocprim::exclusive_scan(nullptr, L->scan32, (const int32_t *)nullptr, (int32_t *)nullptr, (int32_t)0, (size_t)(E_ + 1),
@@ -399,7 +534,8 @@ int crec_lazy_index_big(crec_ctx *ctx, const int32_t *u, const int32_t *i, const
         L->k0 = take(4 * (size_t)(E_ + 1)), L->v0 = take(4 * (size_t)(E_ + 1)), L->k1 = take(4 * (size_t)(E_ + 1)), L->v1 = take(4 * (size_t)(E_ + 1));
         L->ci = take(4 * (size_t)(E_ + 1)), L->fp = take(4 * (size_t)(E_ + 1)), L->fg = take(4 * (size_t)(E_ + 1));
         L->wi = take(4 * (size_t)NB_), L->wj = take(4 * (size_t)NB_), L->pf = take(8 * (size_t)(NB_ + 1)), L->pg = take(8 * (size_t)(NB_ + 1));
-        L->hist = take(4 * (size_t)(2 * nb_) * 256 * sd.tiles_max);
+        L->hist = take(4 * (size_t)(2 * nb_) * 256 * tiles_max);
+        L->seg0 = take(8 * (size_t)(2 * nb_)), L->segn = take(4 * (size_t)(2 * nb_));
         L->tmp = take((L->scan32 > L->scan64 ? L->scan32 : L->scan64) + 256);
         L->bytes = off;
         return hipSuccess;
@@ -413,13 +549,13 @@ int crec_lazy_index_big(crec_ctx *ctx, const int32_t *u, const int32_t *i, const
     const size_t o_k0 = L.k0, o_v0 = L.v0, o_k1 = L.k1, o_v1 = L.v1, o_ci = L.ci, o_fp = L.fp, o_fg = L.fg, o_wi = L.wi, o_wj = L.wj, o_pf = L.pf,
                  o_pg = L.pg, o_hist = L.hist, o_tmp = L.tmp;
     char *base = (char *)ctx->big_ws.ptr;
-    uint32_t *k0 = (uint32_t *)(base + o_k0), *v0 = (uint32_t *)(base + o_v0), *k1 = (uint32_t *)(base + o_k1), *v1 = (uint32_t *)(base + o_v1);
-    int32_t *rstart = (int32_t *)k0, *rcnt = (int32_t *)v0; // (after the sort)
+    uint32_t *ka = (uint32_t *)(base + o_k0), *va = (uint32_t *)(base + o_v0), *kb = (uint32_t *)(base + o_k1), *vb = (uint32_t *)(base + o_v1);
     int32_t *hist = (int32_t *)(base + o_hist);
     int32_t *rci = (int32_t *)(base + o_ci), *fp = (int32_t *)(base + o_fp), *fg = (int32_t *)(base + o_fg);
     int32_t *wi = (int32_t *)(base + o_wi), *wj = (int32_t *)(base + o_wj);
     unsigned long long *pf = (unsigned long long *)(base + o_pf), *pg = (unsigned long long *)(base + o_pg);
     void *tmp = base + o_tmp;
+    SegSort sd{(const int64_t *)(base + L.seg0), (const int32_t *)(base + L.segn), tiles_max};
 
     // grid.y = the batch, grid.x = enough workgroups for `per_batch` elements of it (capped: the kernels stride)
     const auto blocks = [nbc](int64_t per_batch) {
@@ -427,24 +563,11 @@ int crec_lazy_index_big(crec_ctx *ctx, const int32_t *u, const int32_t *i, const
         g = g < 1 ? 1 : (g > 1024 ? 1024 : g);
         return dim3((unsigned)g, (unsigned)nbc);
     };
-    {
-        // the passes ping-pong between the two pairs of arrays and must end in (k1, v1): an even number of them starts there
-        const dim3 tiles((unsigned)(nbc * (sd.tiles_u + sd.tiles_i)));
-        uint32_t *ks = (passes & 1) ? k0 : k1, *vs = (passes & 1) ? v0 : v1, *kd = (passes & 1) ? k1 : k0, *vd = (passes & 1) ? v1 : v0;
-        hipLaunchKernelGGL(big_fill, blocks(3 * (int64_t)B), dim3(256), 0, st, u, i, j, dm, ks, vs);
-        for (int pass = 0; pass < passes; ++pass) {
-            hipLaunchKernelGGL(sort_hist, tiles, dim3(SORT_THREADS), 0, st, sd, (const uint32_t *)ks, 8 * pass, hist);
-            hipLaunchKernelGGL(sort_scan, dim3((unsigned)(2 * nbc)), dim3(1024), 0, st, sd, hist);
-            hipLaunchKernelGGL(sort_scatter, tiles, dim3(SORT_THREADS), 0, st, sd, (const uint32_t *)ks, (const uint32_t *)vs, 8 * pass,
-                               (const int32_t *)hist, kd, vd);
-            uint32_t *t = ks;
-            ks = kd;
-            kd = t;
-            t = vs;
-            vs = vd;
-            vd = t;
-        }
-    }
+    hipLaunchKernelGGL(big_fill, blocks(3 * (int64_t)B), dim3(256), 0, st, u, i, j, dm, ka, va, (int64_t *)(base + L.seg0), (int32_t *)(base + L.segn));
+    uint32_t *k1 = nullptr, *v1 = nullptr;
+    seg_sort(sd, (int)(2 * nbc), end_bit, ka, va, kb, vb, hist, st, &k1, &v1);
+    // (the pair of arrays the sort did not end in is free from here on: the runs' starts and lengths)
+    int32_t *rstart = (int32_t *)(k1 == ka ? kb : ka), *rcnt = (int32_t *)(v1 == va ? vb : va);
     hipLaunchKernelGGL(big_runs, blocks(3 * (int64_t)B), dim3(256), 0, st, dm, (const uint32_t *)k1, (const uint32_t *)v1, rstart, rcnt, rci, fp, out.u_desc);
     CREC_HIP(ctx, rocprim::exclusive_scan(tmp, scan32_tmp, (const int32_t *)fp, fg, (int32_t)0, (size_t)(E + 1), rocprim::plus<int32_t>(), st));
     hipLaunchKernelGGL(big_item_desc, blocks(2 * (int64_t)B), dim3(256), 0, st, dm, spw, (const uint32_t *)k1, (const uint32_t *)v1, (const int32_t *)rstart,
@@ -455,6 +578,89 @@ int crec_lazy_index_big(crec_ctx *ctx, const int32_t *u, const int32_t *i, const
     hipLaunchKernelGGL(big_emit_order, blocks(B), dim3(256), 0, st, dm, (const int32_t *)wi, (const unsigned long long *)pg, out.order, out.nslots);
     hipLaunchKernelGGL(big_gather, blocks(B), dim3(256), 0, st, dm, u, (const int32_t *)out.order, (const int4 *)out.i_tmp, (const int4 *)out.j_tmp,
                        out.slot_pu, out.i_desc, out.j_desc);
+    CREC_HIP(ctx, hipGetLastError());
+    return CREC_OK;
+}
+
+namespace {
+// scratch of the two builds above: two pairs of sort arrays, head flags and their scan, the sort's counters, the segment table
+struct FlatWs {
+    uint32_t *ka, *va, *kb, *vb;
+    int32_t *heads, *hs, *hist, *segn;
+    int64_t *seg0;
+    void *tmp;
+    size_t scan_tmp;
+    int tiles_max;
+};
+int flat_ws(crec_ctx *ctx, int64_t nseg, int64_t stride, hipStream_t st, FlatWs *w)
+{
+    const int64_t N = nseg * stride;
+    CREC_REQUIRE(ctx, N + 1 < ((int64_t)1 << 31) && nseg <= 65535, "chunk of %lld batches of %lld slots: too large for one index build", (long long)nseg,
+                 (long long)stride);
+    w->tiles_max = sort_tiles(stride);
+    w->scan_tmp = 0;
+    CREC_HIP(ctx, rocprim::exclusive_scan(nullptr, w->scan_tmp, (const int32_t *)nullptr, (int32_t *)nullptr, (int32_t)0, (size_t)(N + 1),
+                                          rocprim::plus<int32_t>(), st));
+    size_t off = 0;
+    const auto take = [&off](size_t bytes) {
+        const size_t at = off;
+        off += up256(bytes);
+        return at;
+    };
+    const size_t o_ka = take(4 * (size_t)(N + 1)), o_va = take(4 * (size_t)(N + 1)), o_kb = take(4 * (size_t)(N + 1)), o_vb = take(4 * (size_t)(N + 1));
+    const size_t o_h = take(4 * (size_t)(N + 1)), o_hs = take(4 * (size_t)(N + 1)), o_hist = take(4 * (size_t)nseg * 256 * w->tiles_max);
+    const size_t o_s0 = take(8 * (size_t)nseg), o_sn = take(4 * (size_t)nseg), o_tmp = take(w->scan_tmp + 256);
+    if (int rc = crec_reserve(ctx, &ctx->big_ws, off))
+        return rc;
+    char *base = (char *)ctx->big_ws.ptr;
+    w->ka = (uint32_t *)(base + o_ka), w->va = (uint32_t *)(base + o_va), w->kb = (uint32_t *)(base + o_kb), w->vb = (uint32_t *)(base + o_vb);
+    w->heads = (int32_t *)(base + o_h), w->hs = (int32_t *)(base + o_hs), w->hist = (int32_t *)(base + o_hist);
+    w->seg0 = (int64_t *)(base + o_s0), w->segn = (int32_t *)(base + o_sn), w->tmp = base + o_tmp;
+    return CREC_OK;
+}
+inline dim3 flat_blocks(int64_t per_seg, int64_t nseg)
+{
+    int64_t g = (per_seg + 255) / 256;
+    g = g < 1 ? 1 : (g > 1024 ? 1024 : g);
+    return dim3((unsigned)g, (unsigned)nseg);
+}
+} // namespace
+
+int crec_shard_plan_big(crec_ctx *ctx, const int32_t *i, const int32_t *j, int64_t n_chunk, int32_t B, int64_t nbc, int32_t G, int64_t S, int key_bits,
+                        int32_t *req_keys, int32_t *n_req, int32_t *req_off, int32_t *ci, int32_t *cj, hipStream_t st)
+{
+    CREC_REQUIRE(ctx, B >= 1 && B <= LAZY_MAX_B && nbc >= 1 && G >= 1 && G <= 64, "shape");
+    FlatWs w{};
+    if (int rc = flat_ws(ctx, nbc, 2 * (int64_t)B, st, &w))
+        return rc;
+    const BigDims dm{n_chunk, B, (int32_t)nbc};
+    const int stride = 2 * B;
+    hipLaunchKernelGGL(plan_fill, flat_blocks(stride, nbc), dim3(256), 0, st, i, j, dm, G, S, w.ka, w.va, w.seg0, w.segn);
+    uint32_t *ks = nullptr, *vs = nullptr;
+    seg_sort(SegSort{w.seg0, w.segn, w.tiles_max}, (int)nbc, key_bits, w.ka, w.va, w.kb, w.vb, w.hist, st, &ks, &vs);
+    hipLaunchKernelGGL(flat_heads, flat_blocks(stride, nbc), dim3(256), 0, st, (const uint32_t *)ks, (const int32_t *)w.segn, stride, (int)nbc, w.heads);
+    CREC_HIP(ctx, rocprim::exclusive_scan(w.tmp, w.scan_tmp, (const int32_t *)w.heads, w.hs, (int32_t)0, (size_t)(nbc * stride + 1), rocprim::plus<int32_t>(), st));
+    hipLaunchKernelGGL(plan_emit, flat_blocks(stride, nbc), dim3(256), 0, st, dm, G, S, (const uint32_t *)ks, (const uint32_t *)vs, (const int32_t *)w.heads,
+                       (const int32_t *)w.hs, req_keys, n_req, req_off, ci, cj);
+    CREC_HIP(ctx, hipGetLastError());
+    return CREC_OK;
+}
+
+int crec_shard_owner_index_big(crec_ctx *ctx, const int32_t *ids_recv, const int64_t *srv_base, const int32_t *srv_cnt, int32_t G, int64_t nbc,
+                               int64_t stride, int key_bits, int32_t *srv_rows, int32_t *order, int32_t *urows, int32_t *useg, int32_t *n_urows,
+                               hipStream_t st)
+{
+    CREC_REQUIRE(ctx, nbc >= 1 && G >= 1 && G <= 64 && stride >= 1 && stride <= 2 * (int64_t)LAZY_MAX_B * 64, "shape");
+    FlatWs w{};
+    if (int rc = flat_ws(ctx, nbc, stride, st, &w))
+        return rc;
+    hipLaunchKernelGGL(own_fill, flat_blocks(stride, nbc), dim3(256), 0, st, ids_recv, srv_base, srv_cnt, G, (int)stride, w.ka, w.va, srv_rows, w.seg0, w.segn);
+    uint32_t *ks = nullptr, *vs = nullptr;
+    seg_sort(SegSort{w.seg0, w.segn, w.tiles_max}, (int)nbc, key_bits, w.ka, w.va, w.kb, w.vb, w.hist, st, &ks, &vs);
+    hipLaunchKernelGGL(flat_heads, flat_blocks(stride, nbc), dim3(256), 0, st, (const uint32_t *)ks, (const int32_t *)w.segn, (int)stride, (int)nbc, w.heads);
+    CREC_HIP(ctx, rocprim::exclusive_scan(w.tmp, w.scan_tmp, (const int32_t *)w.heads, w.hs, (int32_t)0, (size_t)(nbc * stride + 1), rocprim::plus<int32_t>(), st));
+    hipLaunchKernelGGL(own_emit, flat_blocks(stride, nbc), dim3(256), 0, st, (const int32_t *)w.segn, (int)stride, (const uint32_t *)ks, (const uint32_t *)vs,
+                       (const int32_t *)w.heads, (const int32_t *)w.hs, order, urows, useg, n_urows);
     CREC_HIP(ctx, hipGetLastError());
     return CREC_OK;
 }

@@ -36,3 +36,11 @@ struct LazyIndexOut {
 };
 int crec_lazy_index_big(crec_ctx *ctx, const int32_t *u, const int32_t *i, const int32_t *j, int64_t n_chunk, int32_t B, int64_t nbc,
                         int bits_u, int bits_q, int spw, const LazyIndexOut &out, hipStream_t st, int64_t reserve_nbc = 0);
+
+// index_big.hip: the row-sharded step's plan and owner-side index (shard_kernels.h: shard_plan_batches, shard_owner_index) for
+// batches beyond what a workgroup sorts in LDS: the same outputs, bit for bit.  All pointers device.
+int crec_shard_plan_big(crec_ctx *ctx, const int32_t *i, const int32_t *j, int64_t n_chunk, int32_t B, int64_t nbc, int32_t G, int64_t S, int key_bits,
+                        int32_t *req_keys, int32_t *n_req, int32_t *req_off, int32_t *ci, int32_t *cj, hipStream_t st);
+int crec_shard_owner_index_big(crec_ctx *ctx, const int32_t *ids_recv, const int64_t *srv_base, const int32_t *srv_cnt, int32_t G, int64_t nbc,
+                               int64_t stride, int key_bits, int32_t *srv_rows, int32_t *order, int32_t *urows, int32_t *useg, int32_t *n_urows,
+                               hipStream_t st);

@@ -40,10 +40,13 @@ def _streams(seed, U, I, G, n_per_rank, zipf=True):
     return out, ranges
 
 
-def _run_sharded(G, P0, Q0, ranges, streams, B, d, lr=1e-3, reg=0.01, epochs=1):
+def _run_sharded(G, P0, Q0, ranges, streams, B, d, lr=1e-3, reg=0.01, epochs=1, options=None):
     """G ranks of a local group on cuda:0 -> (P full, Q full, losses [nb], stats of every rank)"""
     I = len(Q0)
     sessions = [runtime.Session(0) for _ in range(G)]
+    for s in sessions:
+        for k, v in (options or {}).items():
+            s.ctx.set_option(k, v)
     if G > 1:
         parallel.init_local_group(sessions)
     states, result, errors = [None] * G, [None] * G, []
@@ -100,6 +103,41 @@ def test_sharded_matches_oracle(G, d):
         assert stats[0]["bytes_rows_sent"] == 0 and stats[0]["bytes_grads_sent"] == 0
     else:
         assert sum(s["bytes_rows_sent"] for s in stats) == sum(s["bytes_grads_sent"] for s in stats) > 0
+
+
+@pytest.mark.parametrize("G", [1, 2, 4])
+def test_sharded_through_the_global_memory_index(G):
+    """The three index builds of a chunk (plan, owner side, compact-id index) through csrc/index_big.hip -- the form batches beyond
+    8192 triples take -- forced onto batches of 256 (`big_index`): the same tables and losses BIT FOR BIT as the in-LDS builds, and
+    both against the oracle."""
+    U, I, B, d = 400, 301, 256, 16
+    P0, Q0 = _tables(3, U, I, d)
+    n = [2 * B + 40, 2 * B + 7, 2 * B + 1, 3 * B][:G]
+    streams, ranges = _streams(5, U, I, G, n)
+    P, Q, loss, stats = _run_sharded(G, P0, Q0, ranges, streams, B, d, options={"big_index": 1})
+    P1, Q1, loss1, stats1 = _run_sharded(G, P0, Q0, ranges, streams, B, d)
+    assert np.array_equal(P, P1) and np.array_equal(Q, Q1) and np.array_equal(loss, loss1)
+    assert [s["rows_requested"] for s in stats] == [s["rows_requested"] for s in stats1]
+    oP, oQ, oloss, _ = oracle.sharded_steps(P0, Q0, ranges, streams, B)
+    np.testing.assert_allclose(loss, oloss, rtol=1e-5)
+    np.testing.assert_allclose(P, oP, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(Q, oQ, rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("G,B", [(2, 12000), (1, 20000)])
+def test_sharded_batches_beyond_the_lds_sort(G, B):
+    """batch_size > 8192 per rank (what amortises the exchanges' hand-shakes over more triples): ragged last batches, a catalogue
+    no world size divides, a Zipf head that one owner serves thousands of times per batch; against the oracle."""
+    U, I, d = 3000, 2001, 16
+    P0, Q0 = _tables(4, U, I, d)
+    n = [2 * B + 333, 2 * B + 5][:G]  # (every rank the same number of batches: the epoch is collective)
+    streams, ranges = _streams(6, U, I, G, n)
+    P, Q, loss, stats = _run_sharded(G, P0, Q0, ranges, streams, B, d)
+    oP, oQ, oloss, _ = oracle.sharded_steps(P0, Q0, ranges, streams, B)
+    np.testing.assert_allclose(loss, oloss, rtol=1e-5)
+    np.testing.assert_allclose(P, oP, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(Q, oQ, rtol=0, atol=2e-6)
+    assert sum(s["rows_requested"] for s in stats) == sum(s["rows_served"] for s in stats) > 0
 
 
 def test_one_two_four_ranks_agree_on_the_same_global_batches():
