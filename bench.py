@@ -187,7 +187,8 @@ def main():
             transport = "peer"
         elif os.environ.get("CREC_TRANSPORT") == "peer" and world == 1:
             transport = "peer"  # (one rank: rehearses the code path, like CREC_FORCE_DP)
-        st = DpBprState(sess, P0, Q0, lr=LR, reg=REG, transport=transport)
+        # (the window also carries the S-big leg's compact tables: 65536 triples per rank x 2 items x 512 B per half)
+        st = DpBprState(sess, P0, Q0, lr=LR, reg=REG, transport=transport, window_bytes=288 << 20)
     else:
         st = runtime.BprState(sess, P0, Q0, lr=LR, reg=REG, adam_mode="tf1")
 
@@ -374,6 +375,10 @@ def main():
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 return float(tt.item())
             big_sharded = bench_big.run_sharded(steps=200, sess=sess, rank=rank, world=world, barrier=fence, max_reduce=big_max)
+            # the same with 65536 triples per rank and step (batches beyond 8192 are indexed in global memory, csrc/index_big.hip):
+            # the exchanges' hand-shakes and the launches are paid once per ten times the triples
+            big_sharded["larger_batch"] = bench_big.run_sharded(steps=24, batch=65536, sess=sess, rank=rank, world=world, barrier=fence,
+                                                                max_reduce=big_max)
         except Exception as e:  # every rank fails or none: the sizes are the same everywhere
             big_sharded = {"error": repr(e)}
     if rank == 0 and big_sharded is not None:

@@ -65,13 +65,16 @@ class DpBprState(BprState):
     """BprState whose train_epoch runs the data-parallel step.  P0: this rank's user rows; Q0: the
     replica (must be identical on every rank)."""
 
-    def __init__(self, sess, P0, Q0, lr, reg, rank=None, world=None, transport="rccl"):
-        """transport: "rccl" (crec_comm_init), "peer" (the IPC windows of crec_comm_peer_*), None (the ctx has a communicator)"""
+    def __init__(self, sess, P0, Q0, lr, reg, rank=None, world=None, transport="rccl", window_bytes=128 << 20):
+        """transport: "rccl" (crec_comm_init), "peer" (the IPC windows of crec_comm_peer_*; window_bytes: an exchange carries up to half
+        of it per rank), None (the ctx has a communicator)"""
         super().__init__(sess, P0, Q0, lr, reg, "tf1")
         if transport is None:
             self.rank, self.world = rank, world
+        elif transport == "peer":
+            self.rank, self.world = init_peer(sess, rank, world, window_bytes=window_bytes)
         else:
-            self.rank, self.world = (init_peer if transport == "peer" else init_rccl)(sess, rank, world)
+            self.rank, self.world = init_rccl(sess, rank, world)
 
     def train_epoch(self, u, i, j, batch_size, out=None):
         """Collective.  u: row ids inside this rank's shard.  Returns per-batch losses summed over ranks (in `out` if given)."""
