@@ -324,20 +324,24 @@ def main():
         # command, tools/profile.sh; gfx950 FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes).  PMC
         # counters cannot be read from inside the process, so the committed measurement is quoted.
         traffic = None
-        tf = os.path.join(ROOT, "profiles", "round2_traffic.json")
-        if not os.path.exists(tf):
-            tf = os.path.join(ROOT, "profiles", "round1_traffic.json")
+        def newest(name):  # the latest round's committed summary of this workload
+            for r in ("round3", "round2", "round1"):
+                f_ = os.path.join(ROOT, "profiles", "%s_%s" % (r, name))
+                if os.path.exists(f_):
+                    return f_
+            return os.path.join(ROOT, "profiles", "round3_" + name)
+        tf = newest("traffic.json")
         if os.path.exists(tf) and not dp:
             traffic = json.load(open(tf)).get("traffic_bytes_per_launch")
         if dp:
             alg[dom] = B * (24 * D + 12) + 24 * D * U + 4 * D * I  # P swept, dQ written; Q is swept by bpr_adam_dense
         avg_s = prof[dom][0] / prof[dom][1] * 1e-3
         ach = alg[dom] / avg_s / 1e9
-        # the second clock: rocprofv3 --kernel-trace --stats of this workload (tools/profile.sh -> profiles/round2_kernel_stats.txt).
+        # the second clock: rocprofv3 --kernel-trace --stats of this workload (tools/profile.sh -> profiles/round3_kernel_stats.txt).
         # The two disagree by ~15 % (under tracing consecutive dependent dispatches tile the timeline, so its per-dispatch
         # figure is the launch-to-launch period); `frac` is priced on the SLOWER clock, both are reported.
         rp_us = None
-        ks = os.path.join(ROOT, "profiles", "round2_kernel_stats.txt")
+        ks = newest("kernel_stats.txt")
         if os.path.exists(ks) and not dp:
             for line in open(ks):
                 f = line.split()
@@ -354,7 +358,7 @@ def main():
                            "note": "avg_launch_us = mean over the timed launches of the elapsed time between the two HIP events "
                                    "attached to each dispatch (hipExtLaunchKernelGGL start/stop events on the launch stream), i.e. "
                                    "the dispatch's own begin/end timestamps; avg_launch_us_rocprof = the committed rocprofv3 "
-                                   "--kernel-trace --stats average of the same workload (profiles/round2_kernel_stats.txt); achieved and "
+                                   "--kernel-trace --stats average of the same workload (" + os.path.relpath(ks, ROOT) + "); achieved and "
                                    "frac use the larger of the two.  Tables+slots are 7.5 MB (Infinity-Cache resident): the HBM "
                                    "fraction is nominal; S-big (synthetic_big) is the HBM-resident form",
                            "launch_period_us": dt / a.steps * 1e6 - sum(v["avg_us"] * v["launches"] for k, v in kern.items()

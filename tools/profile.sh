@@ -4,7 +4,7 @@
 set -o pipefail
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 OUT=$ROOT/gpurun_out/profiles
-R=${ROUND:-round2}   # file name prefix of the summaries (copy the ones to be judged into profiles/)
+R=${ROUND:-round3}   # file name prefix of the summaries (copy the ones to be judged into profiles/)
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
@@ -17,7 +17,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 print("rocprofv3 --kernel-trace --stats -- python bench.py --steps 1824 --warmup 456 --no-extras")
 print("%-60s %8s %14s %12s %8s" % ("kernel", "calls", "total_ns", "avg_ns", "pct"))
 for r in rows:
-    m = re.search(r"(bpr_\w+|eval_\w+|rank_metrics\w*|shard_\w+|ncf_\w+|fm_\w+|cml_\w+|rows_\w+|apply_all|small_adam\w*|topk_\w+|lrml_\w+|tcf_\w+)(<[^>]*>)?", r["Name"])
+    m = re.search(r"(bpr_\w+|eval_\w+|rank_metrics\w*|shard_\w+|ncf_\w+|fm_\w+|cml_\w+|rows_\w+|apply_all|small_adam\w*|topk_\w+|lrml_\w+|tcf_\w+|sbpr_\w+|cune_\w+|sort_\w+|big_\w+|plan_\w+|own_\w+|flat_heads|peer_\w+)(<[^>]*>)?", r["Name"])
     name = (m.group(0) if m else r["Name"].split("(")[0])[:60]
     print("%-60s %8s %14s %12.1f %8s" % (name, r["Calls"], r["TotalDurationNs"], float(r["AverageNs"]), r["Percentage"]))
 PY
@@ -27,7 +27,7 @@ for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_WAVE_CYCL
   rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$n -- python $ROOT/bench.py --steps 100 --warmup 10 --no-extras > /dev/null 2>&1 || echo "pmc $n failed"
 done
 # the HBM-resident form of the path (S-big) and the catalogue-scale eval: kernel-trace stats only
-for leg in "big tools/bench_big.py --steps 200" "big_sharded tools/bench_big.py --steps 200 --sharded" "eval_big tools/bench_eval_big.py --dim 128" "models tools/bench_models.py"; do
+for leg in "big tools/bench_big.py --steps 200" "bigbatch tools/bench_big.py --batch 65536 --steps 64" "big_sharded tools/bench_big.py --steps 200 --sharded" "bigbatch_sharded tools/bench_big.py --batch 65536 --steps 32 --sharded" "eval_big tools/bench_eval_big.py --dim 128" "models tools/bench_models.py"; do
   set -- $leg; name=$1; shift
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$name -- python $ROOT/$@ > $OUT/${name}_under_trace.json 2>/dev/null
   f=$(find $OUT/trace_$name -name "*kernel_stats.csv" | head -1)
@@ -37,7 +37,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 print("rocprofv3 --kernel-trace --stats -- python " + sys.argv[2])
 print("%-60s %8s %14s %12s %8s" % ("kernel", "calls", "total_ns", "avg_ns", "pct"))
 for r in rows[:26]:
-    m = re.search(r"(bpr_\w+|eval_\w+|rank_metrics\w*|shard_\w+|ncf_\w+|fm_\w+|cml_\w+|rows_\w+|apply_all|small_adam\w*|topk_\w+|lrml_\w+|tcf_\w+)(<[^>]*>)?", r["Name"])
+    m = re.search(r"(bpr_\w+|eval_\w+|rank_metrics\w*|shard_\w+|ncf_\w+|fm_\w+|cml_\w+|rows_\w+|apply_all|small_adam\w*|topk_\w+|lrml_\w+|tcf_\w+|sbpr_\w+|cune_\w+|sort_\w+|big_\w+|plan_\w+|own_\w+|flat_heads|peer_\w+)(<[^>]*>)?", r["Name"])
     name = (m.group(0) if m else r["Name"].split("(")[0])[:60]
     print("%-60s %8s %14s %12.1f %8s" % (name, r["Calls"], r["TotalDurationNs"], float(r["AverageNs"]), r["Percentage"]))
 PY
@@ -46,16 +46,20 @@ done
 # counters for the two secondary legs: HBM-side traffic of the S-big kernels, matrix-core busy cycles of the big eval
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $OUT/pmcbig_$c -- python $ROOT/tools/bench_big.py --steps 60 > /dev/null 2>&1 || echo "pmc big $c failed"
+  rocprofv3 --pmc $c --output-format csv -d $OUT/pmcbigbatch_$c -- python $ROOT/tools/bench_big.py --batch 65536 --steps 32 > /dev/null 2>&1 || echo "pmc bigbatch $c failed"
   rocprofv3 --pmc $c --output-format csv -d $OUT/pmcmodels_$c -- python $ROOT/tools/bench_models.py > /dev/null 2>&1 || echo "pmc models $c failed"
 done
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmceval_MFMA -- python $ROOT/tools/bench_eval_big.py --dim 128 > /dev/null 2>&1 || echo "pmc eval failed"
 cd $ROOT && python tools/pmc_summary.py $OUT/pmc_* > $OUT/pmc_summary.txt
-python tools/pmc_summary.py $OUT/pmcbig_* > $OUT/big_pmc_summary.txt
+python tools/pmc_summary.py $OUT/pmcbig_[FW]* > $OUT/big_pmc_summary.txt
+python tools/pmc_summary.py $OUT/pmcbigbatch_* > $OUT/bigbatch_pmc_summary.txt
 python tools/pmc_summary.py $OUT/pmceval_* > $OUT/eval_big_pmc_summary.txt
 python tools/pmc_summary.py $OUT/pmcmodels_* > $OUT/models_pmc_summary.txt
 python tools/traffic_json.py $OUT/pmc_summary.txt bpr_step_fused > $OUT/traffic.json
-for f in kernel_stats.txt pmc_summary.txt big_kernel_stats.txt big_sharded_kernel_stats.txt big_pmc_summary.txt eval_big_kernel_stats.txt eval_big_pmc_summary.txt models_kernel_stats.txt models_pmc_summary.txt traffic.json; do
+for f in kernel_stats.txt pmc_summary.txt big_kernel_stats.txt bigbatch_kernel_stats.txt bigbatch_pmc_summary.txt bigbatch_sharded_kernel_stats.txt big_sharded_kernel_stats.txt big_pmc_summary.txt eval_big_kernel_stats.txt eval_big_pmc_summary.txt models_kernel_stats.txt models_pmc_summary.txt traffic.json; do
   [ -f $OUT/$f ] && cp $OUT/$f $OUT/${R}_$f
 done
 rm -rf $OUT/trace/*/*kernel_trace.csv
 cat $OUT/kernel_stats.txt $OUT/big_kernel_stats.txt $OUT/big_sharded_kernel_stats.txt $OUT/eval_big_kernel_stats.txt $OUT/models_kernel_stats.txt; cat $OUT/pmc_summary.txt $OUT/big_pmc_summary.txt $OUT/eval_big_pmc_summary.txt $OUT/models_pmc_summary.txt $OUT/traffic.json
+# gpurun merges at most 64 MiB back: the raw counter / trace directories stay on the box, the summaries travel
+rm -rf $OUT/pmc_* $OUT/pmcbig_* $OUT/pmcbigbatch_* $OUT/pmcmodels_* $OUT/pmceval_* $OUT/trace $OUT/trace_*
