@@ -39,9 +39,12 @@ def main():
         # ---- a BPR configuration: small catalogues make heavy rows; ragged batch sizes -------------------------------
         U, I = int(g.integers(3, 400)), int(g.integers(6, 300))
         d = int(g.choice([4, 8, 12, 16, 32, 64, 128, 256]))
-        B = int(g.choice([1, 7, 64, 333, 1000, 2048, 6144, 8192]))
+        B = int(g.choice([1, 7, 64, 333, 1000, 2048, 6144, 8192, 9000, 20000]))
         nr = int(g.integers(1, 5))
         mode = str(g.choice(["tf1", "lazy", "lazy", "sgd", "adagrad"]))  # lazy twice: the one-launch triple pass is this round's new kernel
+        if B > 8192 and mode == "tf1":  # the swept step indexes at most 8192 triples per batch (larger ones: lazy family, csrc/index_big.hip)
+            mode = "lazy"
+        sess.ctx.set_option("big_index", int(g.random() < 0.3))  # the global-memory index also on batches the LDS sort holds
         deg_hi = max(2, min(I - nr - 1, int(g.integers(2, 40))))
         ui_train = {u: [int(x) for x in g.choice(I, size=int(g.integers(1, deg_hi + 1)), replace=False)] for u in range(U) if g.random() < 0.9}
         if not ui_train:
