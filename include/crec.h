@@ -196,7 +196,10 @@ typedef struct {
  * partial), exactly the slicing of RankingRecommender.train_model (:39-47).
  *   u, i, j        [dev] int32 [N]
  *   loss_per_batch [dev] float [ceil(N/B)]: loss_b = sum softplus(-x) + reg*(l2 terms)
- * train_model's return value is mean(loss_per_batch) (:61).  B <= 8192. */
+ * train_model's return value is mean(loss_per_batch) (:61).
+ * B: the reference takes any batch_size (model/Recommender.py:17).  adam_mode tf1: B <= 8192 (a batch's slots are sorted in LDS);
+ * lazy / deferred / SGD / Adagrad: B <= 524288 -- beyond 8192 the batch's index (the unique + segment-sum bookkeeping) is built in
+ * global memory, the same index bit for bit (csrc/index_big.hip).  tf1 beyond 8192: run it as deferred, the same results. */
 int crec_bpr_train_epoch(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, const int32_t *u, const int32_t *i,
                          const int32_t *j, int64_t N, int32_t B, float *loss_per_batch, void *stream);
 
@@ -415,7 +418,9 @@ int crec_bpr_train_epoch_dp(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *
  * a ctx with neither is a world of one.
  *   t->P, slots   [U_local, d]   this rank's user rows; u = row ids inside the shard
  *   t->Q, slots   [>= ceil(I_global / G), d]   this rank's item shard; i, j = GLOBAL item ids
- *   collective: every rank passes the same number of batches ceil(N / B), N >= 1; adam_mode lazy.
+ *   collective: every rank passes the same number of batches ceil(N / B), N >= 1; adam_mode lazy; B <= 524288 (beyond 8192 the
+ *   plan, the owner-side index and the compact-id index are built in global memory; the transport's window must hold a batch's
+ *   compact table, 2 * B * d * 4 bytes per half).
  *   loss_per_batch [dev] receives the sum over ranks.  stats (optional) accumulates what this rank sent to OTHER ranks. */
 typedef struct {
     int64_t bytes_ids_sent, bytes_rows_sent, bytes_grads_sent; /* to other ranks */
