@@ -101,6 +101,53 @@ def test_large_batches_against_the_oracle(sess, B, mode):
         np.testing.assert_allclose(getattr(st, name).cpu().numpy(), ov, rtol=1e-4, atol=1e-5 * float(np.abs(ov).max()), err_msg=name)
 
 
+def test_runs_beyond_sixteen_bits(sess):
+    """A batch of 150 000 triples over 7 users and 5 items: every sorted position, segment start and count beyond 65 535 (the
+    descriptor fields' old width), rows cut into thousands of chunks, a front row whose positive slots span thousands of workgroups.
+    A row's gradient is a sum of 20 000-60 000 terms of both signs, and long stretches of it are ONE running fp32 sum on every side
+    (TF1's segment sum and the C oracle: all of it; here: a front row's tens of thousands of negative slots, a chunked row's
+    thousands of chunk partials), good to N * 6e-8 of sum|terms| at worst: no two fp32 implementations agree on such a row beyond
+    1e-4.  So the first step is held against the float64 value of the same sums -- |delta g| <= 2e-4 * sum|terms| (seen: 4e-5) --,
+    the loss against float64, the step itself to 2e-6 (Adam's m / sqrt(v) does not see the error), and two runs (a ragged second
+    batch included) against each other bit for bit."""
+    U, I, d, B, lr, reg = 7, 5, 8, 150000, 1e-3, 0.01
+    n = B + 1234
+    u, i, j = _stream(12, n, U, I)
+    g = np.random.Generator(np.random.PCG64(13))
+    P0 = (g.standard_normal((U, d)) * 0.01).astype(np.float32)
+    Q0 = (g.standard_normal((I, d)) * 0.01).astype(np.float32)
+    runs = []
+    for _ in range(2):
+        st = runtime.BprState(sess, P0, Q0, lr=lr, reg=reg, adam_mode="lazy")
+        loss = st.train_epoch(sess.to_dev(u), sess.to_dev(i), sess.to_dev(j), B).cpu().numpy()
+        runs.append([loss] + [getattr(st, k).cpu().numpy() for k in ("P", "Q", "mP", "mQ", "vP", "vQ")])
+    for x, y in zip(*runs):
+        assert np.array_equal(x, y)
+    # the first step in float64
+    st = runtime.BprState(sess, P0, Q0, lr=lr, reg=reg, adam_mode="lazy")
+    loss = st.train_epoch(sess.to_dev(u[:B]), sess.to_dev(i[:B]), sess.to_dev(j[:B]), B).cpu().numpy()
+    P, Q = P0.astype(np.float64), Q0.astype(np.float64)
+    p, qi, qj = P[u[:B]], Q[i[:B]], Q[j[:B]]
+    x = (p * qi).sum(1) - (p * qj).sum(1)
+    sg = 1.0 / (1.0 + np.exp(x))  # sigmoid(-x)
+    l64 = np.logaddexp(0.0, -x).sum() + reg * 0.5 * ((p * p).sum() + (qi * qi).sum() + (qj * qj).sum())
+    assert loss[0] == pytest.approx(l64, rel=1e-6)
+    gP, aP, gQ, aQ = np.zeros_like(P), np.zeros_like(P), np.zeros_like(Q), np.zeros_like(Q)
+    cu = -sg[:, None] * (qi - qj) + reg * p
+    np.add.at(gP, u[:B], cu), np.add.at(aP, u[:B], np.abs(cu))
+    for rows, c in ((i[:B], -sg[:, None] * p + reg * qi), (j[:B], sg[:, None] * p + reg * qj)):
+        np.add.at(gQ, rows, c), np.add.at(aQ, rows, np.abs(c))
+    for name, g64, a64, var0 in (("P", gP, aP, P), ("Q", gQ, aQ, Q)):
+        m = getattr(st, "m" + name).cpu().numpy().astype(np.float64)
+        worst = float((np.abs(m - 0.1 * g64) / (0.1 * a64 + 1e-30)).max())
+        assert worst <= 2e-4, "m%s: |delta| up to %.3g of sum|terms|" % (name, worst)
+        v = getattr(st, "v" + name).cpu().numpy().astype(np.float64)
+        np.testing.assert_allclose(v, 1e-3 * g64 * g64, rtol=2 * 2e-4 * float((a64 / np.abs(g64)).max()) + 1e-5, err_msg="v" + name)
+        lr_t = lr * np.sqrt(1 - 0.999) / (1 - 0.9)
+        want = var0 - lr_t * (0.1 * g64) / (np.sqrt(1e-3 * g64 * g64) + 1e-8)
+        np.testing.assert_allclose(getattr(st, name).cpu().numpy(), want, rtol=0, atol=2e-6, err_msg=name)
+
+
 def test_tf1_sweep_refuses_a_large_batch_and_names_the_way_out(sess):
     U, I, d, B = 100, 80, 16, 9000
     u, i, j = _stream(1, B, U, I)
