@@ -61,6 +61,7 @@ def grid(configs):
 # -- not as a CREC_EINVAL from the middle of an epoch.
 LIMITS = {
     "batch_size": 8192,   # every model but BPR: a batch's (row, slot) pairs are sorted in LDS, 2 * batch_size <= 16384 pairs
+    "batch_size_rows": 1 << 18,  # GMF / MLP / NeuMF, FM: a batch's slots are indexed 16 384 at a time, a larger batch in several chunks
     "batch_size_bpr": 1 << 19,  # BPR: beyond 8192 the batch's index is built in global memory (csrc/index_big.hip); the limit is
                                 # what the index descriptors' fields hold
     "topk": 128,          # the fused evaluation ranks 32 candidates per user and pass, up to four passes
@@ -74,7 +75,8 @@ def validate(configs, extra_width=0):
     def bad(key, value, why):
         raise ValueError("%s = %s: %s (this build's limit; see cleverrec_amd/config.py LIMITS and include/crec.h)" % (key, value, why))
     b = int(configs["batch_size"])
-    b_max = LIMITS["batch_size_bpr" if configs.get("recommender") == "BPR" else "batch_size"]
+    name = configs.get("recommender")
+    b_max = LIMITS["batch_size_bpr" if name == "BPR" else ("batch_size_rows" if name in ("GMF", "MLP", "NeuMF", "FM") else "batch_size")]
     if not 1 <= b <= b_max:
         bad("batch_size", b, "batches of 1..%d instances" % b_max)
     ks = parse_list(configs["topk"], int)

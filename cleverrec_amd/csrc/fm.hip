@@ -325,7 +325,9 @@ int crec_fm_train_epoch(crec_ctx *ctx, const crec_fm *m, crec_adam *opt, const i
     if (int rc = check_fm(ctx, m, F))
         return rc;
     CREC_REQUIRE(ctx, opt && N >= 0 && (N == 0 || (x_idx && x_val && y && y_pre && loss_per_batch)), "null argument");
-    CREC_REQUIRE(ctx, B >= 1 && (int64_t)B * F <= 16384, "batch_size * features = %lld: at most 16384", (long long)B * F);
+    // (a batch's B * F slots are indexed 16 384 at a time; more of them in several chunks the update launch walks in order)
+    CREC_REQUIRE(ctx, B >= 1 && (int64_t)B * F <= 1048576, "batch_size * features = %lld: at most 1048576", (long long)B * F);
+    const int ix_chunks = (int)crec_ceil_div((int64_t)B * F, 16384);
     if (N == 0)
         return CREC_OK;
     CREC_HIP(ctx, hipSetDevice(ctx->device));
@@ -337,7 +339,7 @@ int crec_fm_train_epoch(crec_ctx *ctx, const crec_fm *m, crec_adam *opt, const i
         lpr <<= 1;
     const int G = 64 / lpr;
     auto up = [](size_t x) { return (x + 255) / 256 * 256; };
-    const size_t ixb = crec_rows_index_bytes(nb, B * F, rows);
+    const size_t ixb = crec_rows_index_bytes(nb, B * F, rows, ix_chunks);
     const size_t cvb = sizeof(float) * (size_t)B * F * d, cwb = sizeof(float) * (size_t)B * F, seb = sizeof(float) * (size_t)B;
     const int max_waves = (int)crec_ceil_div(B, G);
     const size_t w0b = sizeof(float) * (size_t)max_waves, nrb = sizeof(float) * (size_t)rows;
@@ -345,7 +347,7 @@ int crec_fm_train_epoch(crec_ctx *ctx, const crec_fm *m, crec_adam *opt, const i
         return rc;
     char *ws = (char *)ctx->idx_ws.ptr;
     crec_rows_index_view vx;
-    if (int rc = crec_rows_index(ctx, x_idx, N * F, B * F, rows, ws, &vx, st))
+    if (int rc = crec_rows_index(ctx, x_idx, N * F, B * F, rows, ws, &vx, st, ix_chunks))
         return rc;
     float *c_v = (float *)(ws + up(ixb));
     float *c_w = (float *)((char *)c_v + up(cvb));
@@ -377,10 +379,10 @@ int crec_fm_train_epoch(crec_ctx *ctx, const crec_fm *m, crec_adam *opt, const i
         crec_apply_set set{};
         crec_rows_opt ov = o;
         ov.row_norm = 1;
-        set.tables[set.n_tables++] = crec_rows_job{crec_rows_table{m->vif.var, m->vif.m, m->vif.v, rows, d}, vx.chunks, vx.rowseg + b * vx.rows,
-                                                   vx.order + b * vx.per_batch, c_v, nullptr, nv, ov};
-        set.scalar = crec_scalar_job{m->wi.var, m->wi.m, m->wi.v, rows, vx.rowseg + b * vx.rows, vx.order + b * vx.per_batch,
-                                     c_w, nw, o};
+        set.tables[set.n_tables++] = crec_rows_job{crec_rows_table{m->vif.var, m->vif.m, m->vif.v, rows, d}, vx.chunks,
+                                                   vx.rowseg + b * vx.chunks * vx.rows, vx.order + b * vx.per_batch, c_v, nullptr, nv, ov};
+        set.scalar = crec_scalar_job{m->wi.var, m->wi.m, m->wi.v, rows, vx.rowseg + b * vx.chunks * vx.rows, vx.order + b * vx.per_batch,
+                                     c_w, nw, o, vx.chunks};
         // waves beyond this batch's count were not written: pass the exact count
         set.small = crec_small_job{m->w0.var, m->w0.m, m->w0.v, w0_partial, waves, 1, 1, o};
         if (int rc = crec_apply_all(ctx, set, st))

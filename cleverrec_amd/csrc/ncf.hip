@@ -516,7 +516,10 @@ extern "C" int crec_ncf_train_epoch(crec_ctx *ctx, const crec_ncf *mdl, crec_ada
     CREC_REQUIRE(ctx, mdl && opt && N >= 0, "null argument");
     CREC_REQUIRE(ctx, N == 0 || (u && i && y && loss_per_batch), "null argument");
     CREC_REQUIRE(ctx, mdl->kind >= CREC_NCF_GMF && mdl->kind <= CREC_NCF_NEUMF, "ncf kind");
-    CREC_REQUIRE(ctx, B >= 1 && B <= 16384, "batch_size %d: at most 16384", B);
+    // a batch's slots are indexed 16 384 at a time (one workgroup's sort in LDS); a larger batch in several such chunks, which the
+    // update launch walks one after the other -- still every row's slots in ascending order
+    CREC_REQUIRE(ctx, B >= 1 && B <= 262144, "batch_size %d: at most 262144", B);
+    const int ix_chunks = (int)crec_ceil_div(B, 16384);
     const bool has_g = mdl->kind != CREC_NCF_MLP, has_m = mdl->kind != CREC_NCF_GMF;
     NcfDev d{};
     if (int rc = ncf_describe(ctx, mdl, &d))
@@ -531,7 +534,7 @@ extern "C" int crec_ncf_train_epoch(crec_ctx *ctx, const crec_ncf *mdl, crec_ada
     const int hm = d.L0 / 2;
 
     // workspace: two inverted indices (users, items) for the epoch, contribution rows, partials, losses
-    const size_t ixu = crec_rows_index_bytes(nb, B, U), ixi = crec_rows_index_bytes(nb, B, I);
+    const size_t ixu = crec_rows_index_bytes(nb, B, U, ix_chunks), ixi = crec_rows_index_bytes(nb, B, I, ix_chunks);
     const size_t cb = sizeof(float) * (size_t)B * (2 * d.dg + 2 * hm);
     const size_t pb = sizeof(float) * (size_t)n_tiles * d.n_small, lb = sizeof(float) * (size_t)nb * B;
     auto up = [](size_t x) { return (x + 255) / 256 * 256; };
@@ -539,9 +542,9 @@ extern "C" int crec_ncf_train_epoch(crec_ctx *ctx, const crec_ncf *mdl, crec_ada
         return rc;
     char *ws = (char *)ctx->idx_ws.ptr;
     crec_rows_index_view vu, vi;
-    if (int rc = crec_rows_index(ctx, u, N, B, U, ws, &vu, st))
+    if (int rc = crec_rows_index(ctx, u, N, B, U, ws, &vu, st, ix_chunks))
         return rc;
-    if (int rc = crec_rows_index(ctx, i, N, B, I, ws + up(ixu), &vi, st))
+    if (int rc = crec_rows_index(ctx, i, N, B, I, ws + up(ixu), &vi, st, ix_chunks))
         return rc;
     float *c_pg = (float *)(ws + up(ixu) + up(ixi));
     float *c_qg = c_pg + (size_t)B * d.dg, *c_pm = c_qg + (size_t)B * d.dg, *c_qm = c_pm + (size_t)B * hm;

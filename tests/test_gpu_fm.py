@@ -46,6 +46,27 @@ def test_fm_steps_match_oracle(sess, d, F):
     assert rm == pytest.approx(r2, rel=1e-12) and ma == pytest.approx(m2, rel=1e-12)
 
 
+def test_fm_batch_beyond_one_index_chunk(sess):
+    """batch_size * features beyond the 16 384 slots a workgroup sorts in LDS (the reference takes any batch_size): the batch's index
+    comes in several chunks which the update launch walks in order.  C4's fields, B = 20 000 (40 000 slots: three chunks), two
+    full batches and a ragged one."""
+    g = np.random.Generator(np.random.PCG64(45))
+    U, I, d, B = 3000, 2000, 32, 20000
+    n_feat, N = U + I, 2 * B + 777
+    w0, wi, vif = np.array([0.0], np.float32), (g.standard_normal(n_feat + 1) * 0.01).astype(np.float32), \
+        (g.standard_normal((n_feat + 1, d)) * 0.01).astype(np.float32)
+    x_idx = np.stack([g.integers(0, U, N), U + np.minimum(g.zipf(1.2, N) - 1, I - 1)], 1).astype(np.int32)
+    x_val = np.ones((N, 2), np.float32)
+    y = g.integers(1, 6, N).astype(np.float32)
+    st = runtime.FmState(sess, w0, wi, vif, lr=1e-3, reg=1e-3)
+    om = MT.FM(w0.reshape(()), wi, vif, lr=1e-3, reg=1e-3)
+    y_pre, loss = st.train_epoch(sess.to_dev(x_idx), sess.to_dev(x_val), sess.to_dev(y), B)
+    ol = [om.step(x_idx[b * B:(b + 1) * B], x_val[b * B:(b + 1) * B], y[b * B:(b + 1) * B]) for b in range(len(loss))]
+    np.testing.assert_allclose(loss.cpu().numpy(), ol, rtol=1e-5)
+    for dev, name in ((st.w0, "w0"), (st.wi, "wi"), (st.vif, "vif")):
+        assert_adam_close(om, name, dev, *st.slots[name])
+
+
 def test_fm_at_the_c4_shape(sess):
     """BASELINE configs[3] shape: two one-hot fields (user, U + item), N = 9 746 features, d = 32, B = 6 144 -- one
     epoch of four batches (the last one ragged), every variable under the rounding envelope, losses within 1e-5."""

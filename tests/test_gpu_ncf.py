@@ -361,3 +361,17 @@ def test_lazy_adam_matches_oracle(sess, kind):
     only_first = np.setdiff1d(u[:B], u[B:])  # touched by the first batch and left alone: TF1 goes on moving them, the lazy rule does not
     assert len(only_first) > 5
     assert np.abs(tf1.numpy(okey)[only_first] - om.numpy(okey)[only_first]).max() > 1e-5
+
+
+@pytest.mark.parametrize("kind", ["GMF", "NeuMF"])
+def test_batch_beyond_one_index_chunk(sess, kind):
+    """batch_size = 40 000 (the reference takes any): a batch's user and item slots are indexed 16 384 at a time, three chunks per
+    batch here, which the update launch walks in ascending slot order; two full batches and a ragged one against the torch
+    restatement under its envelope (the paired P_gmf / P_mlp update of NeuMF included)."""
+    U, I, B, d, layers, lr = 2000, 1500, 40000, 16, [32, 16], 1e-3
+    u, i, y = _instances(12, U, I, 2 * B + 4321)
+    st, om, names, _ = _ncf_pair(sess, kind, np.random.Generator(np.random.PCG64(51)), U, I, d, layers, lr, "Adam")
+    loss = st.train_epoch(sess.to_dev(u), sess.to_dev(i), sess.to_dev(y), B).cpu().numpy()
+    ol = [om.step(u[b * B:(b + 1) * B], i[b * B:(b + 1) * B], y[b * B:(b + 1) * B]) for b in range(len(loss))]
+    np.testing.assert_allclose(loss, ol, rtol=1e-5)
+    _compare(st, om, names)
