@@ -86,9 +86,12 @@ __global__ __launch_bounds__(256) void big_fill(const int32_t *__restrict__ u, c
 //   sort_hist     per tile: how many of its elements carry each digit            -> hist[segment][digit][tile]
 //   sort_scan     per segment: exclusive scan in (digit, tile) order = where each tile's elements of a digit go
 //   sort_scatter  per tile: every element's rank among the tile's elements of its digit, IN THE TILE'S ORDER (stable) -- a wave
-//                 owns a contiguous eighth of the tile, the lanes holding the same digit find each other with one ballot per
+//                 owns a contiguous 512 elements of the tile, the lanes holding the same digit find each other with one ballot per
 //                 digit bit (block_sort.h's scheme), per-wave digit counts are summed in wave order -- and the element moves
-constexpr int SORT_THREADS = 256, SORT_WAVES = SORT_THREADS / 64, SORT_PER_WAVE = 512, SORT_TILE = SORT_WAVES * SORT_PER_WAVE;
+#ifndef CREC_SORT_THREADS
+#define CREC_SORT_THREADS 256 // tiles of 2048.  (1024 threads / tiles of 8192, for longer runs in the scatter: sort_scatter 89 -> 132 us, sort_hist 24 -> 37 us per pass over 12.6 M pairs)
+#endif
+constexpr int SORT_THREADS = CREC_SORT_THREADS, SORT_WAVES = SORT_THREADS / 64, SORT_PER_WAVE = 512, SORT_TILE = SORT_WAVES * SORT_PER_WAVE;
 
 // the segments of one sort: segment s holds segn[s] pairs from element seg0[s] on; a launch has a workgroup per (tile, segment)
 struct SegSort {
@@ -102,13 +105,15 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_hist(SegSort sd, const uint
     __shared__ int cnt[256];
     const int seg = (int)blockIdx.y, tile = (int)blockIdx.x, n = sd.segn[seg];
     const uint32_t *sk = keys + sd.seg0[seg];
-    cnt[threadIdx.x] = 0;
+    if (threadIdx.x < 256)
+        cnt[threadIdx.x] = 0;
     __syncthreads();
     const int k0 = tile * SORT_TILE;
     for (int k = k0 + (int)threadIdx.x; k < k0 + SORT_TILE && k < n; k += SORT_THREADS)
         atomicAdd(&cnt[(sk[k] >> shift) & 255u], 1);
     __syncthreads();
-    hist[((int64_t)seg * 256 + threadIdx.x) * sd.tiles_max + tile] = cnt[threadIdx.x]; // (a tile behind the segment's end: zeros)
+    if (threadIdx.x < 256)
+        hist[((int64_t)seg * 256 + threadIdx.x) * sd.tiles_max + tile] = cnt[threadIdx.x]; // (a tile behind the segment's end: zeros)
 }
 
 __global__ __launch_bounds__(1024) void sort_scan(SegSort sd, int32_t *__restrict__ hist)
@@ -178,7 +183,8 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter(SegSort sd, const u
     }
     for (int c = lane; c < 256; c += 64)
         wcnt[wave][c] = 0;
-    base[tid] = hist[((int64_t)seg * 256 + tid) * sd.tiles_max + tile];
+    if (tid < 256)
+        base[tid] = hist[((int64_t)seg * 256 + tid) * sd.tiles_max + tile];
     // rank inside the wave: LDS operations of one wave execute in order, so the running counter written in round s is the
     // one read in round s + 1
 #pragma unroll
@@ -199,7 +205,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter(SegSort sd, const u
             wcnt[wave][digit] = run + cnt;
     }
     __syncthreads();
-    { // per digit: the waves' counts -> their offsets, in wave order
+    if (tid < 256) { // per digit: the waves' counts -> their offsets, in wave order
         int run = base[tid];
 #pragma unroll
         for (int w = 0; w < SORT_WAVES; ++w) {
