@@ -2796,6 +2796,8 @@ int sharded_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, int64_t I_global
                                  (long long)stride, 16 * SHARD_THREADS);
         else
             local_rc = crec_reserve(ctx, &ctx->shard_ws2, serve_layout(nullptr, nbc, total_srv, stride).bytes);
+        if (big && local_rc == CREC_OK) // (the owner-side index' scratch is sized by what THIS rank is asked for: part of the same verdict)
+            local_rc = crec_shard_owner_index_big_reserve(ctx, nbc, stride, st);
         if (G > 1) {
             if (int rc = crec_reserve(ctx, &ctx->shard_flag, 64))
                 local_rc = local_rc ? local_rc : rc;

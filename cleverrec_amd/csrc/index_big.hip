@@ -632,6 +632,14 @@ inline dim3 flat_blocks(int64_t per_seg, int64_t nseg)
 }
 } // namespace
 
+// the scratch of crec_shard_owner_index_big for this shape, reserved ahead (a rank must know that it can serve a chunk BEFORE the
+// ranks agree to go on: what an owner is asked for differs from rank to rank)
+int crec_shard_owner_index_big_reserve(crec_ctx *ctx, int64_t nbc, int64_t stride, hipStream_t st)
+{
+    FlatWs w{};
+    return flat_ws(ctx, nbc, stride, st, &w);
+}
+
 int crec_shard_plan_big(crec_ctx *ctx, const int32_t *i, const int32_t *j, int64_t n_chunk, int32_t B, int64_t nbc, int32_t G, int64_t S, int key_bits,
                         int32_t *req_keys, int32_t *n_req, int32_t *req_off, int32_t *ci, int32_t *cj, hipStream_t st)
 {

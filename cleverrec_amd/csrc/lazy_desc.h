@@ -41,6 +41,7 @@ int crec_lazy_index_big(crec_ctx *ctx, const int32_t *u, const int32_t *i, const
 // batches beyond what a workgroup sorts in LDS: the same outputs, bit for bit.  All pointers device.
 int crec_shard_plan_big(crec_ctx *ctx, const int32_t *i, const int32_t *j, int64_t n_chunk, int32_t B, int64_t nbc, int32_t G, int64_t S, int key_bits,
                         int32_t *req_keys, int32_t *n_req, int32_t *req_off, int32_t *ci, int32_t *cj, hipStream_t st);
+int crec_shard_owner_index_big_reserve(crec_ctx *ctx, int64_t nbc, int64_t stride, hipStream_t st);
 int crec_shard_owner_index_big(crec_ctx *ctx, const int32_t *ids_recv, const int64_t *srv_base, const int32_t *srv_cnt, int32_t G, int64_t nbc,
                                int64_t stride, int key_bits, int32_t *srv_rows, int32_t *order, int32_t *urows, int32_t *useg, int32_t *n_urows,
                                hipStream_t st);
