@@ -60,7 +60,8 @@ def grid(configs):
 # .properties file beyond them is refused HERE, when the model object is built, with the key, the value and the limit
 # -- not as a CREC_EINVAL from the middle of an epoch.
 LIMITS = {
-    "batch_size": 8192,   # every model but BPR: a batch's (row, slot) pairs are sorted in LDS, 2 * batch_size <= 16384 pairs
+    "batch_size": 65536,  # CML, SBPR / CUNE_BPR, LRML, TransCF: the per-step item index comes in at most 64 chunks of 2048 slots
+    "batch_size_fm": 65536,  # FM: batch_size * features per row <= 2^20 slots (the libfm files here have up to 16 features per row)
     "batch_size_rows": 1 << 18,  # GMF / MLP / NeuMF, FM: a batch's slots are indexed 16 384 at a time, a larger batch in several chunks
     "batch_size_bpr": 1 << 19,  # BPR: beyond 8192 the batch's index is built in global memory (csrc/index_big.hip); the limit is
                                 # what the index descriptors' fields hold
@@ -77,6 +78,8 @@ def validate(configs, extra_width=0):
     b = int(configs["batch_size"])
     name = configs.get("recommender")
     b_max = LIMITS["batch_size_bpr" if name == "BPR" else ("batch_size_rows" if name in ("GMF", "MLP", "NeuMF", "FM") else "batch_size")]
+    if name == "FM":
+        b_max = LIMITS["batch_size_fm"]
     if not 1 <= b <= b_max:
         bad("batch_size", b, "batches of 1..%d instances" % b_max)
     ks = parse_list(configs["topk"], int)

@@ -281,7 +281,9 @@ int crec_cml_train_epoch(crec_ctx *ctx, const crec_cml *m, crec_adam *opt, const
     CREC_REQUIRE(ctx, m && opt && m->P.var && m->Q.var && m->P.cols == m->Q.cols, "CML tables");
     const int d = m->P.cols;
     CREC_REQUIRE(ctx, d % 4 == 0 && d >= 4 && d <= 256, "embed_size %d: need a multiple of 4 in [4, 256]", d);
-    CREC_REQUIRE(ctx, K >= 1 && B >= 1 && B <= 8192, "neg_ratio >= 1, batch_size <= 8192");
+    // (user slots are indexed 16 384 at a time, the per-step item index 2048 at a time in at most 64 chunks)
+    CREC_REQUIRE(ctx, K >= 1 && B >= 1 && B <= 65536, "neg_ratio >= 1, batch_size <= 65536");
+    const int u_chunks = (int)crec_ceil_div(B, 16384);
     CREC_REQUIRE(ctx, N >= 0 && (N == 0 || (u && i && neg && loss_per_batch)), "null argument");
     if (N == 0)
         return CREC_OK;
@@ -298,7 +300,7 @@ int crec_cml_train_epoch(crec_ctx *ctx, const crec_cml *m, crec_adam *opt, const
 #define CML_CHUNK_SLOTS 2048
 #endif
     const int q_chunks = (int)crec_ceil_div(2 * (int64_t)B, CML_CHUNK_SLOTS); // item slots: sorted 2048 at a time
-    const size_t ixu = crec_rows_index_bytes(nb, B, U), ixq = crec_rows_index_bytes(1, 2 * B, I, q_chunks);
+    const size_t ixu = crec_rows_index_bytes(nb, B, U, u_chunks), ixq = crec_rows_index_bytes(1, 2 * B, I, q_chunks);
     const size_t cpb = sizeof(float) * (size_t)B * d, cqb = sizeof(float) * (size_t)2 * B * d;
     const size_t sl = sizeof(int32_t) * (size_t)2 * B, li = sizeof(float) * (size_t)B;
     const size_t pp = sizeof(float) * (size_t)(nbP + nbQ) * d, mub = sizeof(float) * 256 + 256;
@@ -308,7 +310,7 @@ int crec_cml_train_epoch(crec_ctx *ctx, const crec_cml *m, crec_adam *opt, const
         return rc;
     char *ws = (char *)ctx->idx_ws.ptr;
     crec_rows_index_view vu, vq;
-    if (int rc = crec_rows_index(ctx, u, N, B, U, ws, &vu, st))
+    if (int rc = crec_rows_index(ctx, u, N, B, U, ws, &vu, st, u_chunks))
         return rc;
     char *p = ws + up(ixu);
     char *ixq_ws = p;

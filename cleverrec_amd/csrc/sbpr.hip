@@ -142,13 +142,17 @@ __global__ __launch_bounds__(1024) void cune_scalar_step(const float *__restrict
                                                          float *__restrict__ m, float *__restrict__ v, crec_rows_opt o)
 {
     __shared__ double part[16];
-    float x[8];
+    double s = 0.0;
+    for (int r0 = 0; r0 < nb; r0 += 8192) { // 8192 terms at a time (one round for the shipped batch: the sums it always had)
+        float x[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) { // B <= 8192
-        const int r = (int)threadIdx.x + q * 1024;
-        x[q] = r < nb ? ds_inst[r] : 0.f;
+        for (int q = 0; q < 8; ++q) {
+            const int r = r0 + (int)threadIdx.x + q * 1024;
+            x[q] = r < nb ? ds_inst[r] : 0.f;
+        }
+        const double sr = (((double)x[0] + (double)x[1]) + ((double)x[2] + (double)x[3])) + (((double)x[4] + (double)x[5]) + ((double)x[6] + (double)x[7]));
+        s = r0 == 0 ? sr : s + sr;
     }
-    double s = (((double)x[0] + (double)x[1]) + ((double)x[2] + (double)x[3])) + (((double)x[4] + (double)x[5]) + ((double)x[6] + (double)x[7]));
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1)
         s += __shfl_xor(s, off, 64);
@@ -212,7 +216,8 @@ static int sbpr_epoch(crec_ctx *ctx, const crec_sbpr *m, const crec_param *s_par
                  "SBPR variables: P [U,d], Q [I,d], bias [>= I, 1]");
     const int d = m->P.cols;
     CREC_REQUIRE(ctx, d % 4 == 0 && d >= 4 && d <= 256, "embed_size %d: need a multiple of 4 in [4, 256]", d);
-    CREC_REQUIRE(ctx, B >= 1 && B <= 8192, "batch_size <= 8192");
+    CREC_REQUIRE(ctx, B >= 1 && B <= 65536, "batch_size <= 65536"); // (a batch's slots are indexed 16 384 at a time)
+    const int u_chunks = (int)crec_ceil_div(B, 16384);
     CREC_REQUIRE(ctx, N >= 0 && (N == 0 || (u && i && k && j && loss_per_batch)), "null argument");
     if (N == 0)
         return CREC_OK;
@@ -228,14 +233,14 @@ static int sbpr_epoch(crec_ctx *ctx, const crec_sbpr *m, const crec_param *s_par
     // slots chunk by chunk), not the latency of one sort: as few chunks as a workgroup's 16 384 slots allow
     const int q_chunks = (int)crec_ceil_div(3 * (int64_t)B, 16384);
     const int64_t GB = nb < 64 ? nb : 64; // batches per item-side index launch
-    const size_t ixu = crec_rows_index_bytes(nb, B, U), ixq = crec_rows_index_bytes(GB, 3 * B, I, q_chunks);
+    const size_t ixu = crec_rows_index_bytes(nb, B, U, u_chunks), ixq = crec_rows_index_bytes(GB, 3 * B, I, q_chunks);
     const size_t cpb = sizeof(float) * (size_t)B * d, cqb = sizeof(float) * (size_t)3 * B * d, cbb = sizeof(float) * (size_t)3 * B;
     const size_t sl = sizeof(int32_t) * (size_t)3 * B * GB, li = sizeof(float) * (size_t)N, dsb = sizeof(float) * (size_t)B;
     if (int rc = crec_reserve(ctx, &ctx->idx_ws, up(ixu) + up(ixq) + up(cpb) + up(cqb) + up(cbb) + up(sl) + up(li) + up(dsb)))
         return rc;
     char *ws = (char *)ctx->idx_ws.ptr;
     crec_rows_index_view vu, vq;
-    if (int rc = crec_rows_index(ctx, u, N, B, U, ws, &vu, st))
+    if (int rc = crec_rows_index(ctx, u, N, B, U, ws, &vu, st, u_chunks))
         return rc;
     char *p = ws + up(ixu);
     char *ixq_ws = p;

@@ -407,7 +407,8 @@ extern "C" int crec_transcf_train_epoch(crec_ctx *ctx, const crec_transcf *m, cr
         return rc;
     CREC_REQUIRE(ctx, m->P.m && m->P.v && m->Q.m && m->Q.v, "Adam slots");
     CREC_REQUIRE(ctx, opt->adam_mode == CREC_ADAM_TF1, "the TransCF step implements adam_mode tf1");
-    CREC_REQUIRE(ctx, B >= 1 && B <= 8192, "batch_size <= 8192");
+    CREC_REQUIRE(ctx, B >= 1 && B <= 65536, "batch_size <= 65536"); // (user slots indexed 16 384 at a time, item slots 2048 at a time in <= 64 chunks)
+    const int u_chunks = (int)crec_ceil_div(B, 16384);
     CREC_REQUIRE(ctx, N >= 0 && (N == 0 || (u && i && j && loss_per_batch)), "null argument");
     if (N == 0)
         return CREC_OK;
@@ -417,7 +418,7 @@ extern "C" int crec_transcf_train_epoch(crec_ctx *ctx, const crec_transcf *m, cr
     const int G = 64 / lpr;
     auto up = [](size_t x) { return (x + 255) / 256 * 256; };
     const int q_chunks = (int)crec_ceil_div(2 * (int64_t)B, 2048); // item slots: sorted 2048 at a time
-    const size_t ixu = crec_rows_index_bytes(nb, B, U), ixq = crec_rows_index_bytes(1, 2 * B, I, q_chunks);
+    const size_t ixu = crec_rows_index_bytes(nb, B, U, u_chunks), ixq = crec_rows_index_bytes(1, 2 * B, I, q_chunks);
     const size_t tu = sizeof(float) * (size_t)U * d, ti = sizeof(float) * (size_t)I * d;
     const size_t cu = sizeof(float) * (size_t)B * d, cq = sizeof(float) * (size_t)2 * B * d;
     const size_t sl = sizeof(int32_t) * (size_t)2 * B, li = sizeof(float) * (size_t)N;
@@ -426,7 +427,7 @@ extern "C" int crec_transcf_train_epoch(crec_ctx *ctx, const crec_transcf *m, cr
         return rc;
     char *p = (char *)ctx->idx_ws.ptr;
     crec_rows_index_view vu, vq;
-    if (int rc = crec_rows_index(ctx, u, N, B, U, p, &vu, st))
+    if (int rc = crec_rows_index(ctx, u, N, B, U, p, &vu, st, u_chunks))
         return rc;
     p += up(ixu);
     char *ixq_ws = p;

@@ -297,7 +297,7 @@ int crec_rmse_mae(crec_ctx *ctx, const float *y, const float *y_pre, int64_t n, 
  * replaces sess.run([self.train, self.loss], {u_idx, i_idx, neg_items}) (model/RankingRecommender.py:90-100)
  * on the graph of model/ranking/CML.py:34-70 (hinge on the closest sampled negative, WARP rank weight,
  * covariance regulariser over [Q;P]).  P ('cml_params/P') and Q take dense ApplyAdam on every row.
- *   u, i int32 [N]; neg int32 [N, K] (ranking_sampler_cml); B <= 8192. */
+ *   u, i int32 [N]; neg int32 [N, K] (ranking_sampler_cml); B <= 65536. */
 typedef struct {
     crec_param P, Q;
     float reg, margin; /* configs['reg'], configs['margin'] */
@@ -318,7 +318,7 @@ int crec_cml_eval_tables(crec_ctx *ctx, const float *P, const float *Q, int64_t 
  * model/RankingRecommender.py:101-116) on the graph of model/ranking/SBPR.py:31-55: scores p.q + bias, two log-sigmoid
  * terms ((x_ui - x_uk)/suk and x_uk - x_uj), l2 on the gathered rows and biases, AdamOptimizer on IndexedSlices (P
  * 'sbpr_params/P', Q, and bias [item_nums + 1]: every row decays and moves each step).  u, i, k (social item), j int32 [N],
- * suk float [N] from crec_sample_sbpr; B <= 8192.  rs-evaluation is BPR's (pre_scores = u_embed @ Q^T, SBPR.py:57-61). */
+ * suk float [N] from crec_sample_sbpr; B <= 65536.  rs-evaluation is BPR's (pre_scores = u_embed @ Q^T, SBPR.py:57-61). */
 typedef struct {
     crec_param P, Q, bias; /* bias: rows >= Q.rows, cols = 1 */
     float reg;
@@ -347,7 +347,7 @@ int crec_cune_train_epoch(crec_ctx *ctx, const crec_cune *model, crec_adam *opt,
  * loss = sum max(dist_i - dist_j + margin, 0) + reg * l2 of the gathered rows -- with AdamOptimizer (P, Q: IndexedSlices,
  * every row decays and moves; K [d, mem], M [mem, d]: dense), and sess.run(self.pre_scores) (LRML.py:70-76).
  *   small: ONE flat block [K | M] (K row-major [d][mem], then M row-major [mem][d]) with its Adam slots, rows * cols =
- *          2 * d * mem_size.  embed_size a multiple of 4, at most 128; mem_size <= 64; B <= 8192.
+ *          2 * d * mem_size.  embed_size a multiple of 4, at most 128; mem_size <= 64; B <= 65536.
  *   crec_lrml_train_epoch: u, i, j int32 [N] from crec_sample_pairwise; loss_per_batch [ceil(N/B)] summed losses.
  *   crec_lrml_scores: scores [Bt][I] = the squared distance of every (user, item) pair; rank ascending (cml_like,
  *          model/RankingRecommender.py:222-223) with crec_topk_scores[_candidates]. */
@@ -367,7 +367,7 @@ int crec_lrml_scores(crec_ctx *ctx, const crec_lrml *model, const int32_t *users
  * distance (reg2) regularisers -- with AdamOptimizer; both tables receive dense gradients (the sparse-dense products reach
  * every row), i.e. the dense ApplyAdam kernel on every row.
  *   ui_ptr [U+1] / ui_items: a user's training items, by user id; iu_ptr [I+1] / iu_users: an item's training users, by
- *   item id (device pointers; the same interaction set both ways).  u, i, j int32 [N] from crec_sample_pairwise; B <= 8192.
+ *   item id (device pointers; the same interaction set both ways).  u, i, j int32 [N] from crec_sample_pairwise; B <= 65536.
  *   crec_transcf_scores: scores [Bt][I] = |a + NU[u] * NI[item] - q_item|^2 with a = clip_1(p_u) (clip_users = 1: the rs
  *   branch of _predict, TransCF.py:88-91) or p_u (0: the loo / sampled-negatives branch, ui_dist, :86-87); nbr_ws: device
  *   scratch of (U + I) * d floats (NU, NI of the current tables).  Rank ascending (cml_like) with crec_topk_scores. */

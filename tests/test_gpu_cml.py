@@ -21,10 +21,10 @@ def sess():
     s.close()
 
 
-@pytest.mark.parametrize("d,K", [(16, 5), (128, 20)])
-def test_cml_steps_match_oracle(sess, d, K):
+@pytest.mark.parametrize("d,K,B", [(16, 5, 200), (128, 20, 200), (16, 3, 20000)])  # 20 000: two chunks of user slots, twenty of item slots
+def test_cml_steps_match_oracle(sess, d, K, B):
     g = np.random.Generator(np.random.PCG64(d))
-    U, I, B, N = 70, 90, 200, 2 * 200 + 50
+    U, I, N = 70, 90, 2 * B + 50
     P = (g.standard_normal((U, d)) * 0.3).astype(np.float32)
     Q = (g.standard_normal((I, d)) * 0.3).astype(np.float32)
     u, i = g.integers(0, U, N).astype(np.int32), g.integers(0, I, N).astype(np.int32)

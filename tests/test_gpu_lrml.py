@@ -37,7 +37,7 @@ def _slots(st, name):
     return st.M, m[d * mem:].view(mem, d), v[d * mem:].view(mem, d)
 
 
-@pytest.mark.parametrize("d,mem,B,generic", [(16, 8, 200, 0), (64, 50, 300, 0), (128, 50, 1100, 0), (128, 50, 300, 1), (20, 64, 97, 0)])
+@pytest.mark.parametrize("d,mem,B,generic", [(16, 8, 200, 0), (64, 50, 300, 0), (128, 50, 1100, 0), (128, 50, 300, 1), (20, 64, 97, 0), (16, 8, 20000, 0)])
 def test_lrml_steps_match_oracle(sess, d, mem, B, generic):
     """two full batches and a ragged one (ragged last tile as well); widths that are not multiples of the 16 x 16 x 4 MFMA
     tile (mem = 50, d = 20); 2 * B item slots > 2048 at B = 1100: several index chunks.  128 x 50 (the shipped conf) runs

@@ -21,7 +21,7 @@ def sess():
     s.close()
 
 
-@pytest.mark.parametrize("d,B", [(16, 200), (128, 512), (8, 5461), (8, 5462), (8, 8192)])  # 3B = 16 383 | 16 386 | 24 576 item slots: one | two | two index chunks
+@pytest.mark.parametrize("d,B", [(16, 200), (128, 512), (8, 5461), (8, 5462), (8, 8192), (8, 20000)])  # 3B = 16 383 | 16 386 | 24 576 | 60 000 item slots: one | two | two | four index chunks (and two of user slots at 20 000)
 def test_sbpr_steps_match_oracle(sess, d, B):
     g = np.random.Generator(np.random.PCG64(d))
     U, I, N = 80, 60, 2 * B + 37  # a ragged last batch; 3 * B item slots > 2048: several index chunks at B = 512... and one at 200
@@ -90,7 +90,7 @@ def test_sbpr_class_surface(sess, tmp_path):
 
 
 @pytest.mark.parametrize("optimizer", ["Adam", "SGD", "Adagrad"])
-@pytest.mark.parametrize("d,B", [(16, 200), (128, 512)])
+@pytest.mark.parametrize("d,B", [(16, 200), (128, 512), (8, 20000)])  # 20 000: the scalar's gradient summed 8192 terms at a time
 def test_cune_steps_match_oracle(sess, d, B, optimizer):
     """CUNE_BPR.py:44-61: SBPR's scores, the second log-sigmoid's argument divided by the trainable scalar s + 1."""
     g = np.random.Generator(np.random.PCG64(d + 1))

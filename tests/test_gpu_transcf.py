@@ -30,7 +30,7 @@ def _data(g, U, I, lo=1, hi=12, holes=(7,)):
     return RankingData(U, I, ui_train, ui_test)
 
 
-@pytest.mark.parametrize("d,B", [(16, 200), (64, 1100), (128, 97)])
+@pytest.mark.parametrize("d,B", [(16, 200), (64, 1100), (128, 97), (16, 20000)])
 def test_transcf_steps_match_oracle(sess, d, B):
     """two full batches and a ragged one; 2 * B item slots > 2048 at B = 1100 (several index chunks); users and items
     without neighbours; triples that name such users."""

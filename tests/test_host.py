@@ -225,8 +225,9 @@ def test_properties_outside_the_built_shapes_are_refused_up_front():
     config.validate(base)
     config.validate(dict(base, batch_size="10000"))  # BPR indexes batches beyond 8192 in global memory (csrc/index_big.hip)
     with pytest.raises(ValueError) as e:            # the other models' steps sort a batch in LDS
-        config.validate(dict(base, recommender="CML", batch_size="10000"))
-    assert "batch_size = 10000" in str(e.value)
+        config.validate(dict(base, recommender="CML", batch_size="100000"))
+    assert "batch_size = 100000" in str(e.value)
+    config.validate(dict(base, recommender="CML", batch_size="10000"))
     config.validate(dict(base, recommender="NeuMF", batch_size="10000"))  # NCF / FM index a batch's slots in several chunks
     for key, val, frag in (("batch_size", "600000", "batch_size = 600000"), ("topk", "[10,20,200]", "topk = [10,20,200]"),
                            ("embed_size", "300", "embed_size = 300"), ("topk", "[20,10]", "ascending")):
