@@ -498,6 +498,25 @@ def main():
                     r = bench_big.run(steps=(1 << 23) // bb, warmup=(1 << 21) // bb, batch=bb, sess=sess)
                     out["synthetic_big"]["larger_batches"][str(bb)] = {k: r[k] for k in ("triples_per_s", "us_per_step", "bpr_triples_lazy",
                                                                                           "unique_user_rows_per_batch", "unique_item_rows_per_batch")}
+                # HBM-side bytes per launch of the step kernel from the committed PMC passes over the same commands (tools/profile.sh:
+                # FETCH_SIZE x 2 + WRITE_SIZE, KiB -> bytes, MI355X_MICROARCH.md's gfx950 correction) -> a roofline object per batch size
+                def lazy_traffic(name):
+                    f_ = newest(name)
+                    vals = {}
+                    if os.path.exists(f_):
+                        for line in open(f_):
+                            t = line.split()
+                            if line.startswith("bpr_triples_lazy") and len(t) >= 5:
+                                vals[t[1]] = float(t[3])
+                    return int((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024) if {"FETCH_SIZE", "WRITE_SIZE"} <= set(vals) else None
+
+                def lazy_roofline(k, traffic):
+                    return {"bound": "hbm", "kernel": "bpr_triples_lazy", "achieved": k["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": k["frac_of_8TBs"], "traffic": traffic, "algorithmic_bytes_per_launch": k["algorithmic_bytes"],
+                            "avg_launch_us": k["avg_us"]}
+                out["synthetic_big"]["roofline"] = lazy_roofline(out["synthetic_big"]["bpr_triples_lazy"], lazy_traffic("big_pmc_summary.txt"))
+                out["synthetic_big"]["larger_batches"]["65536"]["roofline"] = lazy_roofline(
+                    out["synthetic_big"]["larger_batches"]["65536"]["bpr_triples_lazy"], lazy_traffic("bigbatch_pmc_summary.txt"))
                 out["synthetic_big"]["sharded_world1"] = bench_big.run_sharded(steps=200, sess=sess)  # protocol cost
                 import bench_eval_big
                 out["eval_big"] = bench_eval_big.run(sess=sess, reps=2)  # 65536 users x 1 M items: MFMA utilisation
