@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void big_fill(const int32_t *__restrict__ u, c
 
 // ---- the sort: a segmented, stable least-significant-digit radix sort, 8 bits per pass, every segment cut into tiles of
 // SORT_TILE elements so that a pass is three flat launches over ALL tiles of ALL segments (rocPRIM's segmented sort gives a
-// long segment to ONE workgroup: 1.9 ms for a chunk of 64 batches of 65 536 whatever the chunk holds; this one 0.3 ms):
+// long segment to ONE workgroup: 1.9 ms for a chunk of 64 batches of 65 536 whatever the chunk holds; this one 0.44 ms):
 //   sort_hist     per tile: how many of its elements carry each digit            -> hist[segment][digit][tile]
 //   sort_scan     per segment: exclusive scan in (digit, tile) order = where each tile's elements of a digit go
 //   sort_scatter  per tile: every element's rank among the tile's elements of its digit, IN THE TILE'S ORDER (stable) -- a wave
@@ -348,8 +348,8 @@ __global__ __launch_bounds__(256) void big_part_flags(BigDims dm, const int32_t 
     }
 }
 
-__global__ __launch_bounds__(256) void big_emit_order(BigDims dm, const int32_t *__restrict__ wi, const unsigned long long *__restrict__ pg,
-                                                      int32_t *__restrict__ order, int32_t *__restrict__ nslots)
+__global__ __launch_bounds__(256) void big_emit_order(BigDims dm, const unsigned long long *__restrict__ pg, int32_t *__restrict__ order,
+                                                      int32_t *__restrict__ nslots)
 {
     const int b = (int)blockIdx.y, nb = dm.nb_of(b);
     for (int pos = (int)(blockIdx.x * blockDim.x + threadIdx.x); pos < nb; pos += (int)(gridDim.x * blockDim.x)) {
@@ -368,7 +368,6 @@ __global__ __launch_bounds__(256) void big_emit_order(BigDims dm, const int32_t 
         else
             order[t0 + n_front + tot_multi + (pos - bf - bm)] = pos;
     }
-    (void)wi;
 }
 
 __global__ __launch_bounds__(256) void big_gather(BigDims dm, const int32_t *__restrict__ u, const int32_t *__restrict__ order,
@@ -581,7 +580,7 @@ int crec_lazy_index_big(crec_ctx *ctx, const int32_t *u, const int32_t *i, const
     hipLaunchKernelGGL(big_part_flags, blocks(B), dim3(256), 0, st, dm, (const int32_t *)wi, (const int32_t *)wj, pf);
     CREC_HIP(ctx, rocprim::exclusive_scan(tmp, scan64_tmp, (const unsigned long long *)pf, pg, 0ull, (size_t)(NB + 1),
                                           rocprim::plus<unsigned long long>(), st));
-    hipLaunchKernelGGL(big_emit_order, blocks(B), dim3(256), 0, st, dm, (const int32_t *)wi, (const unsigned long long *)pg, out.order, out.nslots);
+    hipLaunchKernelGGL(big_emit_order, blocks(B), dim3(256), 0, st, dm, (const unsigned long long *)pg, out.order, out.nslots);
     hipLaunchKernelGGL(big_gather, blocks(B), dim3(256), 0, st, dm, u, (const int32_t *)out.order, (const int4 *)out.i_tmp, (const int4 *)out.j_tmp,
                        out.slot_pu, out.i_desc, out.j_desc);
     CREC_HIP(ctx, hipGetLastError());
