@@ -2270,11 +2270,9 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
     if (piped) {
         if (int rc = crec_reserve(ctx, &ctx->idx_ws2, layout_index(nullptr, chunk, B, t->U, t->I, dense, CH, wide_rows, wide_total).bytes))
             return rc;
-        if (!ctx->idx_stream) {
-            CREC_HIP(ctx, hipStreamCreateWithFlags(&ctx->idx_stream, hipStreamNonBlocking));
-            for (hipEvent_t &e : ctx->idx_ev)
-                CREC_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        }
+        hipStream_t side_;
+        if (int rc = crec_side_stream(ctx, &side_))
+            return rc;
     }
     // per batch: x_b of every triple, then one l2 term per row wave
     const int64_t loss_stride = B + (dense ? t->U + t->I : (int64_t)B); // lazy: x_b, then the l2 term of every triple

@@ -37,6 +37,17 @@ int crec_reserve(crec_ctx *ctx, crec_devbuf *b, size_t bytes)
     return CREC_OK;
 }
 
+int crec_side_stream(crec_ctx *ctx, hipStream_t *side)
+{
+    if (!ctx->idx_stream) {
+        CREC_HIP(ctx, hipStreamCreateWithFlags(&ctx->idx_stream, hipStreamNonBlocking));
+        for (hipEvent_t &e : ctx->idx_ev)
+            CREC_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    *side = ctx->idx_stream;
+    return CREC_OK;
+}
+
 static char g_create_err[256] = "no error";
 
 namespace {

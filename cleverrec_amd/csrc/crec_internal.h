@@ -143,6 +143,8 @@ bool crec_prof_events(crec_ctx *ctx, hipEvent_t *a, hipEvent_t *b);
     } while (0)
 int crec_prof_flush(crec_ctx *ctx, hipStream_t st);
 int crec_reserve(crec_ctx *ctx, crec_devbuf *b, size_t bytes);
+// the ctx's side stream and its five events (created on first use): work that does not depend on what the caller's stream is busy with
+int crec_side_stream(crec_ctx *ctx, hipStream_t *side);
 
 #define CREC_HIP(ctx, call)                                                                            \
     do {                                                                                               \
