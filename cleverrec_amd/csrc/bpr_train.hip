@@ -3034,15 +3034,21 @@ int crec_debug_shard_plan(crec_ctx *ctx, const int32_t *i, const int32_t *j, int
         return CREC_EINVAL;
     CREC_REQUIRE(ctx, ctx->device >= 0, "host-only ctx: no device bound");
     CREC_REQUIRE(ctx, i && j && req_keys && n_req && req_off && ci && cj && ids_send, "null argument");
-    CREC_REQUIRE(ctx, nb >= 1 && nb <= MAX_B && G >= 1 && G <= 64 && I_global >= 1, "shape");
+    const bool big = nb > MAX_B || ctx->knob_big_index; // (the form batches beyond the in-LDS sort take: index_big.hip)
+    CREC_REQUIRE(ctx, nb >= 1 && nb <= LAZY_MAX_B && G >= 1 && G <= 64 && I_global >= 1, "shape");
     const int64_t S = crec_ceil_div(I_global, G);
     CREC_REQUIRE(ctx, (int64_t)G * S < ((int64_t)1 << 31), "item count");
     CREC_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
     const int cap = (2 * nb + 63) / 64 * 64;
-    CREC_HIP(ctx, hipFuncSetAttribute((const void *)shard_plan_batches, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shard_lds_bytes(cap)));
-    hipLaunchKernelGGL(shard_plan_batches, dim3(1), dim3(SHARD_THREADS), shard_lds_bytes(cap), st, i, j, (int64_t)nb, nb, cap, G, S,
-                       row_bits((int64_t)G * S), req_keys, n_req, req_off, ci, cj);
+    if (big) {
+        if (int rc = crec_shard_plan_big(ctx, i, j, (int64_t)nb, nb, 1, G, S, row_bits((int64_t)G * S), req_keys, n_req, req_off, ci, cj, st))
+            return rc;
+    } else {
+        CREC_HIP(ctx, hipFuncSetAttribute((const void *)shard_plan_batches, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shard_lds_bytes(cap)));
+        hipLaunchKernelGGL(shard_plan_batches, dim3(1), dim3(SHARD_THREADS), shard_lds_bytes(cap), st, i, j, (int64_t)nb, nb, cap, G, S,
+                           row_bits((int64_t)G * S), req_keys, n_req, req_off, ci, cj);
+    }
     std::vector<int32_t> off((size_t)G + 1);
     CREC_HIP(ctx, hipMemcpyAsync(off.data(), req_off, sizeof(int32_t) * ((size_t)G + 1), hipMemcpyDeviceToHost, st));
     CREC_HIP(ctx, hipStreamSynchronize(st));
@@ -3079,7 +3085,7 @@ int crec_debug_shard_owner_index(crec_ctx *ctx, const int32_t *ids_recv, const i
         n += srv_cnt[p];
     }
     const int64_t stride = (n + 63) / 64 * 64 > 64 ? (n + 63) / 64 * 64 : 64;
-    CREC_REQUIRE(ctx, stride <= 16 * SHARD_THREADS, "the owner-side index sorts at most %d rows per batch", 16 * SHARD_THREADS);
+    const bool big = stride > 16 * SHARD_THREADS || ctx->knob_big_index;
     CREC_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
     char *tmp = nullptr;
@@ -3091,15 +3097,24 @@ int crec_debug_shard_owner_index(crec_ctx *ctx, const int32_t *ids_recv, const i
     hipError_t e = hipMemcpyAsync(d_base, base.data(), sizeof(int64_t) * (size_t)G, hipMemcpyHostToDevice, st);
     if (e == hipSuccess)
         e = hipMemcpyAsync(d_cnt, srv_cnt, sizeof(int32_t) * (size_t)G, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void *)shard_owner_index, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shard_lds_bytes((int)stride));
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(shard_owner_index, dim3(1), dim3(SHARD_THREADS), shard_lds_bytes((int)stride), st, ids_recv,
-                           (const int64_t *)d_base, (const int32_t *)d_cnt, G, (int)stride, (int)stride, row_bits(S), d_rows, order, urows,
-                           useg, n_urows);
+    int big_rc = CREC_OK;
+    if (e == hipSuccess && big) {
+        big_rc = crec_shard_owner_index_big(ctx, ids_recv, (const int64_t *)d_base, (const int32_t *)d_cnt, G, 1, stride, row_bits(S), d_rows, order, urows,
+                                            useg, n_urows, st);
         e = hipStreamSynchronize(st);
+    } else {
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void *)shard_owner_index, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shard_lds_bytes((int)stride));
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(shard_owner_index, dim3(1), dim3(SHARD_THREADS), shard_lds_bytes((int)stride), st, ids_recv,
+                               (const int64_t *)d_base, (const int32_t *)d_cnt, G, (int)stride, (int)stride, row_bits(S), d_rows, order, urows,
+                               useg, n_urows);
+            e = hipStreamSynchronize(st);
+        }
     }
     (void)hipFree(tmp);
+    if (big_rc)
+        return big_rc;
     CREC_HIP(ctx, e);
     CREC_HIP(ctx, hipGetLastError());
     return CREC_OK;

@@ -319,12 +319,16 @@ def test_sharded_at_a_million_items():
     assert sum(s["rows_requested"] for s in stats) == sum(s["rows_served"] for s in stats) > 0
 
 
-@pytest.mark.parametrize("G,I,nb", [(1, 53, 64), (2, 53, 64), (4, 1_000_003, 6144), (8, 1_000_003, 8192), (3, 4099, 1), (8, 40, 777)])
-def test_index_kernels_equal_the_host_planner(G, I, nb):
+@pytest.mark.parametrize("big", [0, 1])
+@pytest.mark.parametrize("G,I,nb", [(1, 53, 64), (2, 53, 64), (4, 1_000_003, 6144), (8, 1_000_003, 8192), (3, 4099, 1), (8, 40, 777),
+                                    (4, 1_000_003, 40000)])
+def test_index_kernels_equal_the_host_planner(G, I, nb, big):
     """shard_plan_batches + shard_pack_ids and shard_owner_index (what the epoch launches) against csrc/shard_host.cpp (what the
-    multi-process gloo test runs as every rank's planner, tests/test_parallel_cpu.py): bit for bit, every output."""
+    multi-process gloo test runs as every rank's planner, tests/test_parallel_cpu.py): bit for bit, every output -- by the in-LDS
+    builds and (big = 1; a batch of 40 000 always) by the global-memory builds of csrc/index_big.hip."""
     import ctypes as C
     sess = runtime.Session(0)
+    sess.ctx.set_option("big_index", big)
     g = np.random.Generator(np.random.PCG64(G * 1000 + nb))
     i = np.minimum(g.zipf(1.2, nb) - 1, I - 1).astype(np.int32)
     j = g.integers(0, I, nb).astype(np.int32)
