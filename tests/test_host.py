@@ -521,3 +521,27 @@ def test_sbpr_sampler_prefetch_is_stream_exact(golden_dir):
     b = S.ranking_sampler_sbpr(d, SPu, nr, B)
     assert same([first, second], [a, b])
     S.drop_prefetch()
+
+
+def test_csr_builders_are_vectorised_and_equal_the_row_by_row_definition():
+    """RankingData's CSR forms (samplers' iteration order, seen filter by user id with sorted rows, test rows in list order) and
+    csr_from_dict against the row-by-row definition on random dicts (keys ascending and not, empty rows, absent users)."""
+    g = np.random.Generator(np.random.PCG64(5))
+    for trial in range(25):
+        U, I = int(g.integers(1, 60)), int(g.integers(2, 50))
+        ui = {int(u): [int(x) for x in g.choice(I, size=int(g.integers(0, min(I, 9))), replace=False)]
+              for u in g.permutation(U)[:int(g.integers(1, U + 1))]}
+        if trial % 2:
+            ui = dict(sorted(ui.items()))
+        te = {u: v[::-1][:2] for u, v in ui.items() if v}
+        k, p, it = csr_from_dict(ui)
+        assert list(k) == list(ui.keys()) and all(it[p[n]:p[n + 1]].tolist() == v for n, v in enumerate(ui.values()))
+        for srt in (False, True):
+            k, p, it = csr_from_dict(ui, n_rows=U, sort_rows=srt)
+            for u in range(U):
+                want = ui.get(u, [])
+                assert it[p[u]:p[u + 1]].tolist() == (sorted(want) if srt else want)
+        d = RankingData(U, I, ui, te)
+        for u in range(U):
+            assert d.seen_csr[1][d.seen_csr[0][u]:d.seen_csr[0][u + 1]].tolist() == sorted(ui.get(u, []))
+            assert d.test_csr[1][d.test_csr[0][u]:d.test_csr[0][u + 1]].tolist() == te.get(u, [])
