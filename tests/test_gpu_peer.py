@@ -30,8 +30,8 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,fences", [(2, 0), (3, 0), (2, 1)])
-def test_ranks_as_processes_over_ipc_windows(world, fences):
+@pytest.mark.parametrize("world,fences,big", [(2, 0, 0), (3, 0, 0), (2, 1, 0), (2, 0, 1)])  # big: the epochs' index builds through csrc/index_big.hip
+def test_ranks_as_processes_over_ipc_windows(world, fences, big):
     """(Not more ranks on ONE GPU: a rank's launch waits inside the GPU for its peers' launches, so all ranks' workgroups have to be
     resident together -- one per CU and rank; four ranks' worth do not fit a CU's registers, and the waits then run into their
     time-out.  One process per GPU, the production layout, has the CU to itself.)"""
@@ -39,7 +39,7 @@ def test_ranks_as_processes_over_ipc_windows(world, fences):
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY="0", CREC_PEER_FENCES=str(fences))
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", CREC_PEER_FENCES=str(fences), CREC_BIG_INDEX=str(big))
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_peer_worker.py")], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
     outs = []
