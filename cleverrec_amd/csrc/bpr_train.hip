@@ -245,7 +245,10 @@ IndexWs layout_index(void *base, int64_t nbc, int64_t B, int64_t U, int64_t I, b
 }
 
 // ------------------------------------------------------------------------------------
-// bpr_index_batches: grid = 2*nbc workgroups; block b>>1 = batch, b&1 = side (0 user, 1 item).
+// bpr_index_batches: grid = 2*nbc workgroups; block b>>1 = batch, b&1 = side (0 user, 1 item).  tf1 mode, parts == 2: grid =
+// 4*nbc -- every (batch, side) has TWO workgroups that both sort the side's pairs and then share the phases behind the sort:
+// part 0 writes the heavy rows, the wide groups, the row segments and the counts, part 1 the occurrence records (they need the
+// sorted arrays only).  What a call waits for is one workgroup's latency, and the CUs next door are idle: 46 -> 36 us.
 // Stable radix sort in LDS of the side's (row, slot) pairs (block_sort.h): slots are the triples' positions on the
 // user side, i-slices then j-slices on the item side, so that a row's occurrences come out in batch order, i before j.
 // LDS: rows u32[cap], tag u16[cap], seg u16[cap+64], digit counters, scan scratch (cap = 2B rounded up to 64).
@@ -259,14 +262,16 @@ inline size_t index_lds_bytes(int cap)
 __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t *__restrict__ u,
                                                                   const int32_t *__restrict__ i,
                                                                   const int32_t *__restrict__ j, int64_t n_total,
-                                                                  int32_t B, int32_t cap, IndexWs w)
+                                                                  int32_t B, int32_t cap, IndexWs w, int32_t wg_parts)
 {
     extern __shared__ uint32_t rows[]; // [cap]
     uint16_t *tag = (uint16_t *)(rows + cap);
     uint16_t *seg = tag + cap; // [cap + 64] run starts by rank, closed by n
     int *hist = (int *)(seg + cap + 64);
     int *scan = hist + crec_sort::hist_ints<PREP_THREADS>();
-    const int batch = blockIdx.x >> 1, side = blockIdx.x & 1;
+    const int pair = wg_parts == 2 ? (int)(blockIdx.x >> 1) : (int)blockIdx.x, part = wg_parts == 2 ? (int)(blockIdx.x & 1) : -1;
+    const int batch = pair >> 1, side = pair & 1;
+    const bool do_lists = part != 1, do_records = part != 0; // (wg_parts == 1: one workgroup does both)
     const int tid = threadIdx.x;
     const int64_t t0 = (int64_t)batch * B;
     const int nb = (int)((n_total - t0) < B ? (n_total - t0) : B); // triples in this batch
@@ -439,8 +444,8 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
         if (cnt > CH)
             hv += (1 << 16) + (cnt + CH - 1) / CH;
     }
-    const int hv_before = crec_sort::block_excl_scan<PREP_THREADS>(hv, scan, &hv_total);
-    if (hv) {
+    const int hv_before = do_lists ? crec_sort::block_excl_scan<PREP_THREADS>(hv, scan, &hv_total) : 0;
+    if (hv && do_lists) {
         int hrow = hv_before >> 16, hitem = hv_before & 0xffff;
         for (int q = q0; q < q1; ++q) {
             const int k = seg[q], cnt = (int)seg[q + 1] - k;
@@ -479,7 +484,7 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
     // present rank decides for the group
     uint8_t *wflag = (uint8_t *)hist;
     int wide_total_n = 0;
-    if (WR > 0) {
+    if (WR > 0 && do_lists) {
         __syncthreads();
         for (int q = tid; q < total; q += PREP_THREADS) {
             if (q > 0 && group_of(q - 1) == group_of(q))
@@ -506,7 +511,7 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
     int32_t *rows_out = side ? w.q_rows + (int64_t)batch * 2 * B : w.u_rows + (int64_t)batch * B;
     int32_t *seg_out = side ? w.q_seg + (int64_t)batch * (2 * B + 1) : w.u_seg + (int64_t)batch * (B + 1);
     int2 *rs = side ? w.q_rowseg + (int64_t)batch * w.I : w.u_rowseg + (int64_t)batch * w.U;
-    for (int q = tid; q <= total; q += PREP_THREADS) {
+    for (int q = tid; do_lists && q <= total; q += PREP_THREADS) {
         if (q < total) {
             const int k = seg[q], cnt = (int)seg[q + 1] - k;
             rows_out[q] = (int32_t)(rows[k] | (cnt > CH ? 0x80000000u : 0u));
@@ -523,7 +528,7 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
     // occurrence records in sorted order
     int4 *occ_out = side ? w.q_occ + (int64_t)batch * 2 * B : w.u_occ + (int64_t)batch * B;
     constexpr int RIF = CREC_IDX_RECS; // records per thread in flight: the gathers are the cost (4: three rounds per item side)
-    for (int k0r = tid; k0r < n; k0r += RIF * PREP_THREADS) {
+    for (int k0r = tid; do_records && k0r < n; k0r += RIF * PREP_THREADS) {
         int pos[RIF];
         uint32_t payload[RIF];
         int4 rec[RIF];
@@ -550,6 +555,8 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
             if (k0r + e * PREP_THREADS < n)
                 occ_out[k0r + e * PREP_THREADS] = rec[e];
     }
+    if (!do_lists)
+        return;
     if (tid == 0) {
         (side ? w.n_q : w.n_u)[batch] = total;
         w.hn[batch * HN + side * 2 + 0] = hv_total >> 16;
@@ -568,7 +575,7 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
         // slots 6, 7 of a batch's counters are free: this workgroup's stamp, which the host checks before it trusts the rest
         __hip_atomic_store(w.host_counts + batch * HN + 6 + side, w.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (__hip_atomic_fetch_add(w.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
+        if (__hip_atomic_fetch_add(w.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x / (wg_parts == 2 ? 2 : 1) - 1) {
             __hip_atomic_store(w.done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next launch
             __hip_atomic_store(w.host_flag, w.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
@@ -2432,8 +2439,13 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
             CREC_HIP(ctx, hipStreamWaitEvent(st, ctx->idx_ev[ci & 1], 0));
         } else {
             crec_prof_begin(ctx, CREC_K_INDEX, st);
-            CREC_KLAUNCH(ctx, bpr_index_batches, dim3((unsigned)(2 * nbc)), dim3(PREP_THREADS), lds, st, u + t0, i + t0,
-                               j + t0, n_chunk, B, cap, w);
+            // tf1, a call of few batches: two workgroups per (batch, side) share the phases behind the sort -- as long as all of them
+            // find a CU of their own at once it is the latency of one workgroup that the steps wait for (a 20-batch call: 524 ->
+            // 536-553 M triples/s); an epoch's 455 batches fill the chip anyway, and the second sort is then just more work (810 -> 785 M)
+            const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+            const int idx_parts = dense && !ctx->knob_idx_one_wg && 4 * nbc <= cus ? 2 : 1;
+            CREC_KLAUNCH(ctx, bpr_index_batches, dim3((unsigned)(2 * idx_parts * nbc)), dim3(PREP_THREADS), lds, st, u + t0, i + t0,
+                               j + t0, n_chunk, B, cap, w, idx_parts);
             crec_prof_end(ctx, st);
         }
         // tf1 mode: the chunk's counts of heavy-row chunks and wide groups size the launches.  They arrive in page-locked
@@ -2847,7 +2859,7 @@ int sharded_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, int64_t I_global
                                cap_srv, row_bits(S), v.srv_rows, v.order, v.urows, v.useg, v.n_urows);
             crec_prof_begin(ctx, CREC_K_INDEX, st);
             CREC_KLAUNCH(ctx, bpr_index_batches, dim3((unsigned)(2 * nbc)), dim3(PREP_THREADS), lds_idx, st, u + t0,
-                         (const int32_t *)p.ci, (const int32_t *)p.cj, n_chunk, B, cap_idx, w);
+                         (const int32_t *)p.ci, (const int32_t *)p.cj, n_chunk, B, cap_idx, w, 1);
             crec_prof_end(ctx, st);
         }
         const int32_t *hn = nullptr; // the lazy step's launches are sized by the batch alone
@@ -3147,7 +3159,7 @@ int crec_debug_lazy_index(crec_ctx *ctx, const int32_t *u, const int32_t *i, con
             CREC_HIP(ctx, hipFuncSetAttribute((const void *)bpr_index_batches, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             ctx->index_lds_set = lds;
         }
-        hipLaunchKernelGGL(bpr_index_batches, dim3((unsigned)(2 * nbc)), dim3(PREP_THREADS), lds, st, u, i, j, N, B, cap, w);
+        hipLaunchKernelGGL(bpr_index_batches, dim3((unsigned)(2 * nbc)), dim3(PREP_THREADS), lds, st, u, i, j, N, B, cap, w, 1);
     }
     const size_t n = (size_t)nbc * B;
     CREC_HIP(ctx, hipMemcpyAsync(u_desc, w.u_desc, sizeof(int4) * n, hipMemcpyDeviceToDevice, st));

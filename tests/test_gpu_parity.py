@@ -123,6 +123,29 @@ def test_bpr_heavy_duplicates_and_large_scores(sess):
     _assert_state_close(st, om, atol=5e-5)
 
 
+@pytest.mark.parametrize("U,I,B", [(943, 1349, 6144), (60, 40, 2048)])  # ml-100k's shape (wide groups); a tiny catalogue (heavy rows, chunks)
+def test_index_by_two_workgroups_per_side_changes_nothing(U, I, B):
+    """The tf1 step's per-chunk index is built by two workgroups per (batch, side) that share the phases behind the sort (one the
+    heavy rows / wide groups / row segments / counts, the other the occurrence records); `idx_one_wg` restores the single
+    workgroup: same tables and losses, bit for bit."""
+    g = np.random.Generator(np.random.PCG64(U + B))
+    n = 7 * B + 321
+    u = g.integers(0, U, n).astype(np.int32)
+    i = np.minimum(g.zipf(1.3, n) - 1, I - 1).astype(np.int32)
+    j = g.integers(0, I, n).astype(np.int32)
+    P0, Q0 = _tables(11, U, I, 32)
+    out = []
+    for one in (0, 1):
+        s = runtime.Session(0)
+        s.ctx.set_option("idx_one_wg", one)
+        st = runtime.BprState(s, P0, Q0, lr=1e-3, reg=0.01, adam_mode="tf1")
+        loss = st.train_epoch(s.to_dev(u), s.to_dev(i), s.to_dev(j), B).cpu().numpy()
+        out.append([loss] + [getattr(st, k).cpu().numpy() for k in ("P", "Q", "mP", "mQ", "vP", "vQ")])
+        s.close()
+    for x, y in zip(*out):
+        assert np.array_equal(x, y)
+
+
 @pytest.mark.parametrize("threshold", [1, 8, 24])
 def test_bpr_wide_groups_match_plain_row_waves(sess, threshold):
     """tf1 step with overloaded row waves handed to whole workgroups (option wide = occurrences per row wave above which
