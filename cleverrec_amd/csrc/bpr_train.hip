@@ -2752,6 +2752,7 @@ int sharded_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, int64_t I_global
         int32_t *h_srv_cnt = (int32_t *)htake(sizeof(int32_t) * (size_t)nbc * G);   // [nbc][G]
         int64_t *h_pack = (int64_t *)htake(sizeof(int64_t) * (size_t)nbc * G);      // [nbc][G]
         int64_t *h_base = (int64_t *)htake(sizeof(int64_t) * (size_t)nbc * G);      // [nbc][G]
+        float *h_verdict = (float *)htake(64);                                         // (page-locked like the rest: see crec_peer.hip, err_host)
         CREC_HIP(ctx, hipMemcpyAsync(h_off, p.req_off, sizeof(int32_t) * (size_t)nbc * (G + 1), hipMemcpyDeviceToHost, st));
         CREC_HIP(ctx, hipStreamSynchronize(st));
         for (int o = 0; o < G; ++o)
@@ -2813,12 +2814,13 @@ int sharded_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, int64_t I_global
                 local_rc = local_rc ? local_rc : rc;
             float verdict = local_rc == CREC_OK ? 0.f : 1.f;
             if (ctx->shard_flag.ptr) {
-                CREC_HIP(ctx, hipMemcpyAsync(ctx->shard_flag.ptr, &verdict, sizeof(float), hipMemcpyHostToDevice, st));
-                CREC_HIP(ctx, hipStreamSynchronize(st));
+                *h_verdict = verdict;
+                CREC_HIP(ctx, hipMemcpyAsync(ctx->shard_flag.ptr, h_verdict, sizeof(float), hipMemcpyHostToDevice, st));
                 if (int rc = x->allreduce_sum_f32(ctx, (float *)ctx->shard_flag.ptr, 1, st))
                     return local_rc ? local_rc : rc;
-                CREC_HIP(ctx, hipMemcpyAsync(&verdict, ctx->shard_flag.ptr, sizeof(float), hipMemcpyDeviceToHost, st));
+                CREC_HIP(ctx, hipMemcpyAsync(h_verdict, ctx->shard_flag.ptr, sizeof(float), hipMemcpyDeviceToHost, st));
                 CREC_HIP(ctx, hipStreamSynchronize(st));
+                verdict = *h_verdict;
             }
             if (local_rc == CREC_OK && verdict > 0.f)
                 return crec_fail(ctx, CREC_EINVAL, "%d peer rank(s) cannot serve this chunk (more rows asked of one owner than its index sorts per batch, "

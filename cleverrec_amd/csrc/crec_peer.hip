@@ -177,6 +177,9 @@ struct PeerXch : crec_xch {
     bool opened[PEER_MAX] = {false}; // mapped with hipIpcOpenMemHandle (to be closed)
     void *opened_win[PEER_MAX] = {nullptr}, *opened_sig[PEER_MAX] = {nullptr};
     int32_t *ctr = nullptr, *err = nullptr; // device: workgroup counter, error word
+    int32_t *err_host = nullptr;            // page-locked landing place of the error word (a copy into pageable memory is not
+                                            // stream-ordered alone: the runtime may drain the device's other streams for it -- with the
+                                            // ranks as threads of one process, a peer's kernel that is waiting for THIS rank's next launch)
     uint32_t seq = 0;
     unsigned long long timeout_ticks = 20ull * 100000000ull; // 100 MHz
     bool connected = false;
@@ -197,13 +200,15 @@ struct PeerXch : crec_xch {
             (void)hipFree(own.sig);
         if (ctr)
             (void)hipFree(ctr);
+        if (err_host)
+            (void)hipHostFree(err_host);
     }
     int64_t max_bytes() const override { return own.win_bytes / 2; }
     int status(crec_ctx *ctx, hipStream_t st) override
     {
-        int32_t e = 0;
-        CREC_HIP(ctx, hipMemcpyAsync(&e, err, sizeof(e), hipMemcpyDeviceToHost, st));
+        CREC_HIP(ctx, hipMemcpyAsync(err_host, err, sizeof(int32_t), hipMemcpyDeviceToHost, st));
         CREC_HIP(ctx, hipStreamSynchronize(st));
+        const int32_t e = *err_host;
         if (e)
             return crec_fail(ctx, CREC_EHIP, "peer transport: rank %d never published an exchange this rank waited for (gave up after %.0f s)",
                              e - 1, (double)timeout_ticks / 1e8);
@@ -323,6 +328,8 @@ int peer_alloc(crec_ctx *ctx, int64_t window_bytes, PeerXch **out)
         e = hipExtMallocWithFlags((void **)&x->own.sig, sizeof(unsigned long long) * 4 * PEER_MAX, hipDeviceMallocUncached);
     if (e == hipSuccess)
         e = hipMemset(x->own.sig, 0, sizeof(unsigned long long) * 4 * PEER_MAX);
+    if (e == hipSuccess)
+        e = hipHostMalloc((void **)&x->err_host, 64, hipHostMallocDefault);
     if (e == hipSuccess)
         e = hipMalloc((void **)&x->ctr, 4 * sizeof(int32_t));
     if (e == hipSuccess)

@@ -84,6 +84,10 @@ def test_ranks_as_threads_sharded_epoch():
     # different priorities never do (a queue has one priority); two streams of the same priority may, depending on how many the
     # process has created before
     rank_streams = [torch.cuda.Stream(priority=0), torch.cuda.Stream(priority=-1)]
+    # ... and no rank may copy from pageable host memory (its tables, its triples) while the other's kernel already waits for it:
+    # such a copy drains the device's other streams first -- here the waiting kernel, which waits for THIS rank's next launch.
+    # (One process per GPU has only its own streams to drain.)  So: every rank's buffers first, then the epochs.
+    ready = threading.Barrier(G)
 
     def work(r):
         try:
@@ -93,7 +97,12 @@ def test_ranks_as_threads_sharded_epoch():
                 lo, hi = ranges[r]
                 st = parallel.ShardedBprState(s, P0[lo:hi], parallel.shard_items(Q0, r, G), I, 1e-3, 0.01, r, G)
                 u, i, j = (s.to_dev(x) for x in streams[r])
-                loss = st.train_epoch(u, i, j, B).cpu().numpy()
+                torch.cuda.current_stream().synchronize()
+                ready.wait(60)
+                loss = st.train_epoch(u, i, j, B)
+                torch.cuda.current_stream().synchronize()
+                ready.wait(60)  # (the read-back below is such a copy as well)
+                loss = loss.cpu().numpy()
                 torch.cuda.current_stream().synchronize()
                 result[r] = (st.P.cpu().numpy(), st.Q.cpu().numpy(), loss)
         except Exception as e:  # noqa: BLE001
