@@ -1,3 +1,9 @@
+"""Two ranks of the peer transport as THREADS of one process on one GPU, the row-sharded epoch, again and again (fresh sessions each
+time): which outcomes occur with the ranks' streams at different priorities (`prio`) and at the same one (`same`).  What it showed:
+same-priority streams may share a hardware queue -- a rank's kernel that waits in the GPU for its peer then starves it (symmetric
+time-outs, about one run in four); and (tests/test_gpu_peer.py) a rank that copies from pageable host memory while its peer's kernel
+already waits drains that kernel's stream first.  Both are properties of ranks-as-threads; one process per GPU has neither.
+usage (GPU box): python tools/micro/thread_ranks_stress.py prio|same [iterations]"""
 import os, sys, threading, time
 import numpy as np, torch
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
