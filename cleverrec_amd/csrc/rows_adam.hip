@@ -463,12 +463,16 @@ __device__ __forceinline__ void scalar_rows_block(const crec_scalar_job &j, int 
     if (r >= j.rows)
         return;
     float g = 0.f;
+    int touched = 0;
     const int chunks = j.chunks > 1 ? j.chunks : 1;
     for (int c0 = 0; c0 < chunks; c0 += SEGS) { // chunk by chunk = ascending slot order; SEGS segments asked for together
         int2 rsv[SEGS];
 #pragma unroll
         for (int c = 0; c < SEGS; ++c)
             rsv[c] = c0 + c < chunks ? j.rowseg[(int64_t)(c0 + c) * j.rows + r] : make_int2(0, 0);
+#pragma unroll
+        for (int c = 0; c < SEGS; ++c)
+            touched += rsv[c].y;
 #pragma unroll
         for (int c = 0; c < SEGS; ++c)
             for (int k = rsv[c].x; k < rsv[c].x + rsv[c].y; k += 4) { // four slots' ids, then their four terms, in flight
@@ -486,6 +490,8 @@ __device__ __forceinline__ void scalar_rows_block(const crec_scalar_job &j, int 
                         g = g + x[e];
             }
     }
+    if (touched == 0 && j.o.kind == ROWS_SPARSE_LAZY) // lazy Adam: an element no slot names stays, slots included
+        return;
     const float w = j.var[r];
     if (j.sq_out)
         j.sq_out[r] = w * w;

@@ -268,7 +268,7 @@ static int sbpr_epoch(crec_ctx *ctx, const crec_sbpr *m, const crec_param *s_par
         crec_rows_opt o{};
         o.kind = ROWS_SPARSE_TF1;
         o.reg_occ = m->reg;
-        if (int rc = crec_rows_optimizer(ctx, opt, &o))
+        if (int rc = crec_rows_optimizer(ctx, opt, &o, true))
             return rc;
         const dim3 grid((unsigned)crec_ceil_div(crec_ceil_div(nbt, G), 4));
 #define CREC_SBPR_LAUNCH(L, C)                                                                                              \
@@ -300,8 +300,8 @@ static int sbpr_epoch(crec_ctx *ctx, const crec_sbpr *m, const crec_param *s_par
                                                    vu.rowseg + b * vu.chunks * vu.rows, vu.order + b * vu.per_batch, c_p, nullptr, nullptr, o};
         set.tables[set.n_tables++] = crec_rows_job{crec_rows_table{m->Q.var, m->Q.m, m->Q.v, I, d}, vq.chunks, q_rowseg, q_order, c_q,
                                                    nullptr, nullptr, o};
-        crec_rows_opt ob = o; // the bias: its l2 term is inside the contribution scalars; g = 0 rows still decay and move
-        ob.kind = ROWS_DENSE;
+        crec_rows_opt ob = o; // the bias: its l2 term is inside the contribution scalars; g = 0 rows still decay and move (TF1) or stay (lazy)
+        ob.kind = o.kind == ROWS_SPARSE_LAZY ? ROWS_SPARSE_LAZY : ROWS_DENSE;
         ob.reg_occ = 0.f;
         ob.dense_reg = 0.f;
         set.scalar = crec_scalar_job{m->bias.var, m->bias.m, m->bias.v, I, q_rowseg, q_order, c_b, nullptr, ob, vq.chunks};

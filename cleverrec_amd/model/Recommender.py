@@ -41,7 +41,7 @@ class Recommender(object):
             # form: every row replays the steps it sat out when a batch touches it, indexed in global memory
             self.adam_mode = 'deferred'
             self.logger.info(' batch_size=%d > 8192: Adam runs in its deferred form (TF1 results, touched rows only)' % self.batch_size)
-        # GMF / MLP / NeuMF and LRML take adam_mode=lazy as well: their states call it the optimizer 'LazyAdam'
+        # GMF / MLP / NeuMF, LRML and SBPR / CUNE_BPR take adam_mode=lazy as well: their states call it the optimizer 'LazyAdam'
         self.state_optimizer = 'LazyAdam' if self.optimizer == 'Adam' and self.adam_mode == 'lazy' else self.optimizer
         self.saved_model_dir = c['saved_dir']
         self.T = int(c['test.interval'])

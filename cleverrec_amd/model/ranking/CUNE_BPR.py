@@ -33,7 +33,7 @@ class CUNE_BPR(SBPR):
         P = init['P'] if 'P' in init else self.initializer([U, d])
         Q = init['Q'] if 'Q' in init else self.initializer([I, d])
         bias = init['bias'] if 'bias' in init else torch.zeros(I + 1)  # tf.zeros(item_nums + 1), CUNE_BPR.py:41
-        self.state = CuneState(self.sess, P, Q, bias, init.get('s', 0.0), self.lr, self.reg, optimizer=self.optimizer)  # s = 0.0, :42
+        self.state = CuneState(self.sess, P, Q, bias, init.get('s', 0.0), self.lr, self.reg, optimizer=self.state_optimizer)  # s = 0.0, :42
         self.P, self.Q, self.bias, self.s = self.state.P, self.state.Q, self.state.bias, self.state.s
 
     def save(self, path=None):

@@ -29,7 +29,7 @@ class SBPR(RankingRecommender):
         P = init['P'] if 'P' in init else self.initializer([U, d])
         Q = init['Q'] if 'Q' in init else self.initializer([I, d])
         bias = init['bias'] if 'bias' in init else torch.zeros(I + 1)  # tf.zeros(item_nums + 1), SBPR.py:37
-        self.state = SbprState(self.sess, P, Q, bias, self.lr, self.reg, optimizer=self.optimizer)
+        self.state = SbprState(self.sess, P, Q, bias, self.lr, self.reg, optimizer=self.state_optimizer)
         self.P, self.Q, self.bias = self.state.P, self.state.Q, self.state.bias
 
     def _create_embeddings(self):

@@ -38,6 +38,55 @@ def test_sbpr_steps_match_oracle(sess, d, B):
         assert_adam_close(om, name, dev, *st.slots[name])
 
 
+def _lazy_pair(sess, g, U, I, d, N, cune):
+    P, Q = (g.standard_normal((U, d)) * 0.1).astype(np.float32), (g.standard_normal((I, d)) * 0.1).astype(np.float32)
+    bias = (g.standard_normal(I + 1) * 0.05).astype(np.float32)
+    u, i, k, j = (g.integers(0, n, N).astype(np.int32) for n in (U, I, I, I))
+    suk = g.integers(1, 4, N).astype(np.float32)
+    if cune:
+        st = runtime.CuneState(sess, P, Q, bias, 0.25, lr=1e-3, reg=0.05, optimizer="LazyAdam")
+        om = MT.CUNE_BPR(P, Q, bias, 0.25, lr=1e-3, reg=0.05, optimizer="LazyAdam")
+        return st, om, (u, i, k, j), (P, Q, bias)
+    st = runtime.SbprState(sess, P, Q, bias, lr=1e-3, reg=0.05, optimizer="LazyAdam")
+    om = MT.SBPR(P, Q, bias, lr=1e-3, reg=0.05, optimizer="LazyAdam")
+    return st, om, (u, i, k, j, suk), (P, Q, bias)
+
+
+@pytest.mark.parametrize("cune", [False, True])
+def test_lazy_adam_matches_oracle(sess, cune):
+    """adam_mode=lazy ('LazyAdam') on SBPR / CUNE_BPR: P, Q rows and bias entries a batch names take Adam's formula, every other
+    row / entry and its slots stay bit for bit (CUNE_BPR's scalar s is a dense variable: ApplyAdam as ever).  (a) On the step
+    tests' draw (80 users, 60 items, batches of 200): against the torch restatement with the same rule, under its rounding envelope.
+    (b) On a population four times the batches' reach: what no batch named keeps its bits; what a batch named is within a hundredth
+    of an Adam step on all but a handful of elements (a row touched once has ONE contribution as its gradient, and where -s * (..)
+    cancels against reg * p the first Adam step is anybody's: tests/_adam_close.py's loose rule, without the envelope)."""
+    B = 200
+    st, om, cols, _ = _lazy_pair(sess, np.random.Generator(np.random.PCG64(91 + cune)), 80, 60, 16, 3 * B + 37, cune)
+    loss = st.train_epoch(*(sess.to_dev(x) for x in cols), B).cpu().numpy()
+    ol = [om.step(*(x[b * B:(b + 1) * B] for x in cols)) for b in range(len(loss))]
+    np.testing.assert_allclose(loss, ol, rtol=1e-5)
+    for name, dev in (("P", st.P), ("Q", st.Q), ("bias", st.bias)) + ((("s", st.s),) if cune else ()):
+        assert_adam_close(om, name, dev, *st.slots[name])
+
+    U, I, B = 500, 400, 128
+    st, om, cols, (P, Q, bias) = _lazy_pair(sess, np.random.Generator(np.random.PCG64(93 + cune)), U, I, 32, 3 * B + 19, cune)
+    loss = st.train_epoch(*(sess.to_dev(x) for x in cols), B).cpu().numpy()
+    ol = [om.step(*(x[b * B:(b + 1) * B] for x in cols)) for b in range(len(loss))]
+    np.testing.assert_allclose(loss, ol, rtol=1e-5)
+    for name, dev in (("P", st.P), ("Q", st.Q), ("bias", st.bias)):
+        diff = np.abs(dev.cpu().numpy().reshape(-1) - om.numpy(name).reshape(-1))
+        assert (diff > 1e-5).mean() <= 5e-3 and diff.max() <= 1e-4, "%s: %.3g of the elements beyond 1e-5, max %.3g" % (name, (diff > 1e-5).mean(), diff.max())
+    u, i, k, j = cols[:4]
+    untouched_u = np.setdiff1d(np.arange(U), u)
+    untouched_i = np.setdiff1d(np.arange(I), np.concatenate([i, k, j]))
+    assert len(untouched_u) > 20 and len(untouched_i) > 5
+    assert np.array_equal(st.P.cpu().numpy()[untouched_u], P[untouched_u])
+    assert np.array_equal(st.bias.cpu().numpy().reshape(-1)[untouched_i], bias[untouched_i])
+    for name, rows in (("P", untouched_u), ("Q", untouched_i), ("bias", untouched_i)):
+        m, v = st.slots[name]
+        assert not m.cpu().numpy().reshape(len(m), -1)[rows].any() and not v.cpu().numpy().reshape(len(v), -1)[rows].any(), name
+
+
 def test_sbpr_more_batches_than_one_item_index_launch_covers(sess):
     """The item-side index is built for 64 batches at a time (sbpr_slots + one rows_index_batches): 68 batches, the last ragged."""
     g = np.random.Generator(np.random.PCG64(68))
