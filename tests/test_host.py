@@ -545,3 +545,45 @@ def test_csr_builders_are_vectorised_and_equal_the_row_by_row_definition():
         for u in range(U):
             assert d.seen_csr[1][d.seen_csr[0][u]:d.seen_csr[0][u + 1]].tolist() == sorted(ui.get(u, []))
             assert d.test_csr[1][d.test_csr[0][u]:d.test_csr[0][u + 1]].tolist() == te.get(u, [])
+
+
+def test_lazy_descriptor_fields_round_trip(tmp_path):
+    """csrc/lazy_desc.h: the packed int4 the lazy step reads per (batch position, role) keeps every field at its largest value
+    (batches of 2^19 triples: k, start < 2^20, cnt <= 2^20, ci <= 2^19, hmod < 64) and at random ones -- host build, no GPU."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("needs hipcc")
+    src = tmp_path / "t.hip"
+    src.write_text(r'''
+#include "lazy_desc.h"
+#include <cstdio>
+#include <cstdlib>
+static int check(uint32_t row, bool single, int k, int start, int cnt, int ci, int hmod)
+{
+    const int4 d = lazy_desc_pack(row, single, k, start, cnt, ci, hmod);
+    const bool ok = (uint32_t)(d.x & 0x7fffffff) == row && (d.x < 0) == single && lazy_desc_k(d) == k && lazy_desc_start(d) == start &&
+                    lazy_desc_cnt(d) == cnt && lazy_desc_ci(d) == ci && lazy_desc_hmod(d) == hmod;
+    if (!ok)
+        printf("FAIL row %u single %d k %d start %d cnt %d ci %d hmod %d\n", row, (int)single, k, start, cnt, ci, hmod);
+    return ok ? 0 : 1;
+}
+int main()
+{
+    int bad = 0;
+    bad += check(0x7fffffffu, true, (1 << 20) - 1, (1 << 20) - 1, 1 << 20, 1 << 19, 63);
+    bad += check(0u, false, 0, 0, 1, 0, 0);
+    bad += check(12345u, false, 65536, 65535, 65537, 40000, 15);
+    srand(7);
+    for (int t = 0; t < 200000; ++t)
+        bad += check((uint32_t)rand() & 0x7fffffffu, rand() & 1, rand() % (1 << 20), rand() % (1 << 20), 1 + rand() % (1 << 20), rand() % ((1 << 19) + 1), rand() % 64);
+    printf("bad %d\n", bad);
+    return bad != 0;
+}
+''')
+    exe = str(tmp_path / "t")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-x", "hip", "-O1", "-I" + os.path.join(ROOT, "cleverrec_amd", "csrc"), "-I" + os.path.join(ROOT, "include"),
+                    str(src), "-o", exe], check=True, timeout=600)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "bad 0" in out.stdout, out.stdout[-500:]
