@@ -71,6 +71,29 @@ def test_big_index_equals_lds_index(sess, n, B, U, I, d, kw):
         assert a[4][bt, 0] == m
 
 
+@pytest.mark.parametrize("big", [False, True])
+@pytest.mark.parametrize("n,B,U,I,d", [(3 * 1000 + 77, 1000, 5000, 800, 64),   # a Zipf head: front rows across workgroup boundaries
+                                       (2 * 2048, 2048, 40, 12, 128),         # every row heavy
+                                       (150, 64, 30, 20, 4),                   # d = 4: 64 slots per workgroup
+                                       (700, 700, 100000, 70000, 256)])        # nearly every row single
+def test_device_index_equals_the_cpu_restatement(sess, n, B, U, I, d, big):
+    """Both device builders of the lazy step's index (in-LDS sort, global-memory sort) against oracle/lazy_index.py -- the numpy
+    restatement of TF1's unique + segment-sum bookkeeping in the packed form of csrc/lazy_desc.h -- bit for bit: every descriptor,
+    the processing order, the front-region size."""
+    from oracle import lazy_index
+    u, i, j = _stream(n + d, n, U, I, zipf=1.25)
+    got = _index(sess, u, i, j, B, U, I, d, big=big)
+    spw = 64 if d <= 4 else 16
+    for b in range(-(-n // B)):
+        sl = slice(b * B, min(n, (b + 1) * B))
+        ud, idd, jd, pu, (nb, nf) = lazy_index.batch_index(u[sl], i[sl], j[sl], spw)
+        assert np.array_equal(got[0][b, :nb], ud), "u_desc of batch %d" % b
+        assert np.array_equal(got[1][b, :nb], idd), "i_desc of batch %d" % b
+        assert np.array_equal(got[2][b, :nb], jd), "j_desc of batch %d" % b
+        assert np.array_equal(got[3][b, :nb], pu), "slot_pu of batch %d" % b
+        assert got[4][b].tolist() == [nb, nf]
+
+
 def _oracle_steps(P0, Q0, u, i, j, B, lr, reg, mode):
     om = oracle.BprModel(P0, Q0, lr=lr, reg=reg, adam_mode=mode)
     nb = -(-len(u) // B)
