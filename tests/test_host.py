@@ -587,3 +587,37 @@ int main()
                     str(src), "-o", exe], check=True, timeout=600)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "bad 0" in out.stdout, out.stdout[-500:]
+
+
+def test_lazy_index_restatement_against_plain_counting():
+    """oracle/lazy_index.py (the checker of the device index builders) against plain counting: every slot's row count, its segment,
+    its rank among the row's slots in batch order (positives before negatives), the processing order a permutation with the front
+    rows' positive slots first, row after row."""
+    from collections import Counter
+    from oracle import lazy_index
+    g = np.random.Generator(np.random.PCG64(17))
+    for trial in range(12):
+        nb, U, I, spw = int(g.integers(1, 400)), int(g.integers(2, 60)), int(g.integers(2, 40)), int(g.choice([16, 64]))
+        u, i, j = g.integers(0, U, nb), np.minimum(g.zipf(1.4, nb) - 1, I - 1), g.integers(0, I, nb)
+        ud, idd, jd, pu, (n, nf) = lazy_index.batch_index(u, i, j, spw)
+        assert n == nb and sorted(pu[:, 0].tolist()) == list(range(nb)) and (pu[:, 1] == u[pu[:, 0]]).all()
+        cu, cq, cpos = Counter(u.tolist()), Counter(i.tolist() + j.tolist()), Counter(i.tolist())
+        unpack = lambda d: (int(d[0]) & 0x7fffffff, int(d[0]) < 0, int(d[1]) & 0xfffff, (int(d[1]) >> 20) & 0xfff, int(d[2]) & 0xfffff,  # noqa: E731
+                            int(d[3]) & 0x1fffff, ((int(d[2]) >> 20) & 0xfff) | ((int(d[3]) >> 21) << 12))
+        for pos in range(nb):
+            row, single, k, _, start, cnt, _ = unpack(ud[pos])
+            assert row == u[pos] and cnt == cu[row] and single == (cnt == 1) and k - start == int((u[:pos] == row).sum())
+        front_seen = []
+        for sl in range(nb):
+            pos = int(pu[sl, 0])
+            row, single, k, hmod, start, cnt, ci = unpack(idd[sl])
+            assert row == i[pos] and cnt == cq[row] and k - start == int((i[:pos] == row).sum())
+            assert ci == (cpos[row] if cpos[row] >= 2 else 0)
+            if sl < nf:
+                assert ci >= 2 and hmod == (sl - (k - start)) % spw
+                front_seen.append(row)
+            else:
+                assert ci == 0 and hmod == 0
+            row, single, k, _, start, cnt, cij = unpack(jd[sl])
+            assert row == j[pos] and cnt == cq[row] and k - start == cpos[row] + int((j[:pos] == row).sum())
+        assert front_seen == sorted(front_seen) and nf == sum(c for c in cpos.values() if c >= 2)
