@@ -19,9 +19,12 @@ def configs(seed):
     while True:
         U, I = int(g.integers(3, 400)), int(g.integers(6, 300))
         d = int(g.choice([4, 8, 12, 16, 32, 64, 128, 256]))
-        B = int(g.choice([1, 7, 64, 333, 1000, 2048, 6144, 8192]))
+        B = int(g.choice([1, 7, 64, 333, 1000, 2048, 6144, 8192, 9000, 20000]))
         nr = int(g.integers(1, 5))
         mode = str(g.choice(["tf1", "lazy", "lazy", "sgd", "adagrad"]))  # as tests/soak/soak.py draws it
+        if B > 8192 and mode == "tf1":
+            mode = "lazy"
+        big = int(g.random() < 0.3)
         deg_hi = max(2, min(I - nr - 1, int(g.integers(2, 40))))
         ui_train = {u: [int(x) for x in g.choice(I, size=int(g.integers(1, deg_hi + 1)), replace=False)] for u in range(U) if g.random() < 0.9}
         if not ui_train:
@@ -30,7 +33,7 @@ def configs(seed):
         P0 = (g.standard_normal((U, d)) * scale).astype(np.float32)
         Q0 = (g.standard_normal((I, d)) * scale).astype(np.float32)
         s = int(g.integers(0, 2 ** 31))
-        yield dict(U=U, I=I, d=d, B=B, nr=nr, mode=mode, ui_train=ui_train, scale=scale, P0=P0, Q0=Q0, seed=s)
+        yield dict(U=U, I=I, d=d, B=B, nr=nr, mode=mode, ui_train=ui_train, scale=scale, P0=P0, Q0=Q0, seed=s, big=big)
         g.choice([1, 5, 10, 20, 24, 32])  # the eval part's draws
         g.choice(U, size=int(g.integers(1, U + 1)), replace=False)
         g.integers(0, 2)
@@ -42,17 +45,20 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--target", type=int, required=True)
+    ap.add_argument("--big-index", type=int, default=-1, help="-1: as the soak drew it; 0 / 1: the in-LDS / the global-memory index build")
     a = ap.parse_args()
     for n, c in enumerate(configs(a.seed)):
         if c["seed"] == a.target:
             break
         if n > 200000:
             sys.exit("not found")
-    print("config #%d: U=%d I=%d d=%d B=%d nr=%d mode=%s scale=%g" % (n, c["U"], c["I"], c["d"], c["B"], c["nr"], c["mode"], c["scale"]))
+    big = c["big"] if a.big_index < 0 else a.big_index
+    print("config #%d: U=%d I=%d d=%d B=%d nr=%d mode=%s scale=%g big_index=%d (drawn %d)" % (n, c["U"], c["I"], c["d"], c["B"], c["nr"], c["mode"], c["scale"], big, c["big"]))
     import oracle
     from cleverrec_amd import runtime
     from cleverrec_amd.data import RankingData
     sess = runtime.Session(0)
+    sess.ctx.set_option("big_index", big)
     U, I, B, nr = c["U"], c["I"], c["B"], c["nr"]
     data = RankingData(U, I, c["ui_train"], {u: [0] for u in list(c["ui_train"])[:3]})
     st = runtime.BprState(sess, c["P0"], c["Q0"], lr=1e-3, reg=0.01, adam_mode=c["mode"])
