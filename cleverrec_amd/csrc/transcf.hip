@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void tcf_grad_adam(float *__restrict__ var, fl
                                                      const float *__restrict__ direct, const float *__restrict__ nbr_grad,
                                                      const int64_t *__restrict__ ptr, const int32_t *__restrict__ idx,
                                                      const float *__restrict__ aw, int64_t rows, int d, float lr_t, float beta1,
-                                                     float beta2, float eps)
+                                                     float beta2, float eps, int opt)
 {
     __shared__ float4 red[WG ? 256 : 1];
     constexpr int G = 64 / LPR;
@@ -259,7 +259,15 @@ __global__ __launch_bounds__(256) void tcf_grad_adam(float *__restrict__ var, fl
     const float4 dd = ld4(direct + ro);
     const float4 gg = f4(acc.x + dd.x, acc.y + dd.y, acc.z + dd.z, acc.w + dd.w);
     const float omb1 = 1.0f - beta1, omb2 = 1.0f - beta2;
+    // get_optimizer (utils/tools.py:79-87) on a DENSE gradient: Adam's ApplyAdam; GradientDescentOptimizer var -= lr g; AdagradOptimizer
+    // accum += g^2 (in the m slot, 0.1 at start), var -= lr g / sqrt(accum) -- the arithmetic of rows_adam.hip's opt_elem
     const auto upd = [&](float g_, float var_, float &m_, float &v_) {
+        if (opt == CREC_OPT_SGD)
+            return var_ - lr_t * g_;
+        if (opt == CREC_OPT_ADAGRAD) {
+            m_ = m_ + g_ * g_;
+            return var_ - (lr_t * g_) * __builtin_amdgcn_rsqf(m_);
+        }
         m_ = m_ + (g_ - m_) * omb1;
         v_ = v_ + (g_ * g_ - v_) * omb2;
         return var_ - (m_ * lr_t) / (sqrtf(v_) + eps);
@@ -406,7 +414,9 @@ extern "C" int crec_transcf_train_epoch(crec_ctx *ctx, const crec_transcf *m, cr
     if (int rc = tcf_check(ctx, m, &d, &lpr))
         return rc;
     CREC_REQUIRE(ctx, m->P.m && m->P.v && m->Q.m && m->Q.v, "Adam slots");
-    CREC_REQUIRE(ctx, opt->adam_mode == CREC_ADAM_TF1, "the TransCF step implements adam_mode tf1");
+    CREC_REQUIRE(ctx, opt->adam_mode == CREC_ADAM_TF1 || opt->adam_mode == CREC_OPT_SGD || opt->adam_mode == CREC_OPT_ADAGRAD,
+                 "the TransCF step implements adam_mode tf1 (Adam), CREC_OPT_SGD and CREC_OPT_ADAGRAD");
+    const int opt_kind = opt->adam_mode == CREC_ADAM_TF1 ? 0 : opt->adam_mode;
     CREC_REQUIRE(ctx, B >= 1 && B <= 65536, "batch_size <= 65536"); // (user slots indexed 16 384 at a time, item slots 2048 at a time in <= 64 chunks)
     const int u_chunks = (int)crec_ceil_div(B, 16384);
     CREC_REQUIRE(ctx, N >= 0 && (N == 0 || (u && i && j && loss_per_batch)), "null argument");
@@ -445,7 +455,7 @@ extern "C" int crec_transcf_train_epoch(crec_ctx *ctx, const crec_transcf *m, cr
     for (int64_t b = 0; b < nb; ++b) {
         const int64_t t0 = b * B;
         const int nbt = (int)((N - t0) < B ? (N - t0) : B);
-        const float lr_t = (opt->lr * sqrtf(1.0f - opt->beta2_power)) / (1.0f - opt->beta1_power);
+        const float lr_t = opt_kind ? opt->lr : (opt->lr * sqrtf(1.0f - opt->beta2_power)) / (1.0f - opt->beta1_power);
         hipLaunchKernelGGL(tcf_cat_slots, dim3((unsigned)crec_ceil_div(nbt, 256)), dim3(256), 0, st, i + t0, j + t0, nbt, slots);
         if (int rc = crec_rows_index(ctx, slots, 2 * (int64_t)nbt, 2 * B, I, ixq_ws, &vq, st, q_chunks))
             return rc;
@@ -457,9 +467,9 @@ extern "C" int crec_transcf_train_epoch(crec_ctx *ctx, const crec_transcf *m, cr
         const dim3 gu((unsigned)crec_ceil_div(crec_ceil_div(U, G), 4)), gi((unsigned)crec_ceil_div(crec_ceil_div(I, G), 4));
 #define TCF_GA(L, WG, GU, GI)                                                                                                           \
     hipLaunchKernelGGL((tcf_grad_adam<L, WG>), GU, dim3(256), 0, st, m->P.var, m->P.m, m->P.v, (const float *)GPd, (const float *)GNI,    \
-                       m->ui_ptr, m->ui_items, (const float *)aw_i, U, d, lr_t, opt->beta1, opt->beta2, opt->eps);                       \
+                       m->ui_ptr, m->ui_items, (const float *)aw_i, U, d, lr_t, opt->beta1, opt->beta2, opt->eps, opt_kind);             \
     hipLaunchKernelGGL((tcf_grad_adam<L, WG>), GI, dim3(256), 0, st, m->Q.var, m->Q.m, m->Q.v, (const float *)GQd, (const float *)GNU,    \
-                       m->iu_ptr, m->iu_users, (const float *)aw_u, I, d, lr_t, opt->beta1, opt->beta2, opt->eps)
+                       m->iu_ptr, m->iu_users, (const float *)aw_u, I, d, lr_t, opt->beta1, opt->beta2, opt->eps, opt_kind)
 #define TCF_STEP(L)                                                                                                                      \
     hipLaunchKernelGGL((tcf_triples<L>), gt, dim3(256), 0, st, (const float *)m->P.var, (const float *)m->Q.var, (const float *)NU,        \
                        (const float *)NI, d, u + t0, i + t0, j + t0, nbt, m->reg1, m->reg2, m->margin, c_p, c_nu, c_q, c_ni,              \

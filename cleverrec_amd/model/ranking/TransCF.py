@@ -12,8 +12,6 @@ from ..RankingRecommender import RankingRecommender
 class TransCF(RankingRecommender):
     def __init__(self, sess, data, configs, logger):
         super(TransCF, self).__init__(sess, data, configs, logger)
-        if self.optimizer != 'Adam':  # SGD / Adagrad run on the shared row machinery (csrc/rows_adam.hip); this step has its own dense Adam
-            raise NotImplementedError("optimizer=%s: this model's step implements Adam (its shipped conf's choice)" % self.optimizer)
         if self.loss_func != 'hinge':  # get_loss(self.loss_func, ui_dist - uj_dist, margin=self.margin) (TransCF.py:57)
             raise NotImplementedError("TransCF: loss_func=%s: the step implements the hinge of the shipped conf (utils/tools.py:72-73)" % self.loss_func)
         if self.is_pairwise != 'True':
@@ -34,7 +32,7 @@ class TransCF(RankingRecommender):
         U, I, d = self.data.user_nums, self.data.item_nums, self.embed_size
         P = init['P'] if 'P' in init else self.initializer([U, d])
         Q = init['Q'] if 'Q' in init else self.initializer([I, d])
-        self.state = TranscfState(self.sess, P, Q, self._sp_mat, self.lr, self.reg1, self.reg2, self.margin)
+        self.state = TranscfState(self.sess, P, Q, self._sp_mat, self.lr, self.reg1, self.reg2, self.margin, optimizer=self.optimizer)
         self.P, self.Q = self.state.P, self.state.Q
 
     def _create_embeddings(self):

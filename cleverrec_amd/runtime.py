@@ -320,11 +320,13 @@ class TranscfState:
     """P, Q of model/ranking/TransCF.py:27-32 with Adam slots and the two neighbourhood CSRs (get_sp_mat) in HBM
     (crec_transcf)."""
 
-    def __init__(self, sess, P0, Q0, sp_mat, lr, reg1, reg2, margin, beta1=0.9, beta2=0.999, eps=1e-8):
+    def __init__(self, sess, P0, Q0, sp_mat, lr, reg1, reg2, margin, beta1=0.9, beta2=0.999, eps=1e-8, optimizer="Adam"):
         self.sess = sess
         f32 = torch.float32
         self.P, self.Q = sess.to_dev(P0, f32).contiguous(), sess.to_dev(Q0, f32).contiguous()
-        self.slots = {k: (torch.zeros_like(t), torch.zeros_like(t)) for k, t in (("P", self.P), ("Q", self.Q))}
+        if str(optimizer).lower() == "lazyadam":
+            raise ValueError("TransCF: both tables take dense gradients (the neighbourhood products reach every row): no lazy Adam")
+        self.slots = {k: (_zeros_slot(t, optimizer), torch.zeros_like(t)) for k, t in (("P", self.P), ("Q", self.Q))}
         ui_ptr, ui_items, iu_ptr, iu_users = sp_mat
         U, I = self.P.shape[0], self.Q.shape[0]
         if len(ui_ptr) != U + 1 or len(iu_ptr) != I + 1 or ui_ptr[-1] != iu_ptr[-1]:
@@ -338,7 +340,7 @@ class TranscfState:
             m, v = self.slots[name]
             return _lib.Param(t.data_ptr(), m.data_ptr(), v.data_ptr(), t.shape[0], t.shape[1])
         self.model = _lib.Transcf(par("P", self.P), par("Q", self.Q), *(c.data_ptr() for c in self.csr), reg1, reg2, margin)
-        self.adam = _lib.Adam(lr, beta1, beta2, eps, 0.0, _lib.ADAM_TF1, beta1, beta2, 0)
+        self.adam = _lib.Adam(lr, beta1, beta2, eps, 0.0, _optimizer_mode(optimizer), beta1, beta2, 0)
         self._nbr_ws = None
 
     def train_epoch(self, u, i, j, batch_size):

@@ -445,8 +445,8 @@ class TransCF(Model):
     loss = sum max(x + margin, 0) + reg1*(|p_u - NU[u]|^2 + |q_i - NI[i]|^2) + reg2*sum (x + margin)^2, x = dist_i - dist_j.
     Both tables receive dense gradients (the sparse-dense products), hence the dense ApplyAdam kernel."""
 
-    def __init__(self, P, Q, ui_train, lr, reg1, reg2, margin):
-        super().__init__({"P": P, "Q": Q}, {"P": "dense", "Q": "dense"}, lr)
+    def __init__(self, P, Q, ui_train, lr, reg1, reg2, margin, optimizer="Adam"):
+        super().__init__({"P": P, "Q": Q}, {"P": "dense", "Q": "dense"}, lr, optimizer)
         self.reg1, self.reg2, self.margin = reg1, reg2, margin
         U, I = np.asarray(P).shape[0], np.asarray(Q).shape[0]
         ui, iu, cnt = [], [], {}

@@ -64,6 +64,32 @@ def test_transcf_steps_match_oracle(sess, d, B):
             assert_adam_close(om, name, dev, *st.slots[name])
 
 
+@pytest.mark.parametrize("optimizer", ["SGD", "Adagrad"])
+def test_transcf_sgd_and_adagrad_match_oracle(sess, optimizer):
+    """get_optimizer(configs['optimizer'], lr) (utils/tools.py:79-87) on TransCF's graph: both tables take DENSE gradients (the
+    neighbourhood products reach every row), so GradientDescentOptimizer and AdagradOptimizer (accumulator 0.1, kept in the m slots)
+    move every row every step.  Two full batches and a ragged one in one epoch (SGD / Adagrad do not normalise the gradient: no
+    divergence of trajectories to guard against, unlike Adam's first steps), lr large enough to move the tables well beyond the
+    comparison's resolution."""
+    g = np.random.Generator(np.random.PCG64(71))
+    U, I, d, B = 80, 60, 32, 200
+    N = 2 * B + 37
+    data = _data(g, U, I)
+    P, Q = (g.standard_normal((U, d)) * 0.3).astype(np.float32), (g.standard_normal((I, d)) * 0.3).astype(np.float32)
+    u, i, j = (g.integers(0, n, N).astype(np.int32) for n in (U, I, I))
+    lr = 0.01
+    st = runtime.TranscfState(sess, P, Q, get_sp_mat(data), lr=lr, reg1=0.1, reg2=0.01, margin=0.5, optimizer=optimizer)
+    om = MT.TransCF(P, Q, data.ui_train, lr=lr, reg1=0.1, reg2=0.01, margin=0.5, optimizer=optimizer)
+    loss = st.train_epoch(*(sess.to_dev(x) for x in (u, i, j)), B).cpu().numpy()
+    ol = [om.step(*(x[b * B:(b + 1) * B] for x in (u, i, j))) for b in range(len(loss))]
+    np.testing.assert_allclose(loss, ol, rtol=2e-5)
+    for name, dev in (("P", st.P), ("Q", st.Q)):
+        ref = om.numpy(name)
+        tol = om.bounds(name)[0] + 1e-6 * np.abs(ref) + 1e-7
+        assert (np.abs(dev.cpu().numpy() - ref) <= tol).all(), name
+        assert np.abs(ref - (P if name == "P" else Q)).max() > 1e-3  # the steps did move the table
+
+
 def test_transcf_popular_rows(sess):
     """an item most users hold and a user who holds most items: neighbourhoods longer than one lane group's share (the
     workgroup-per-row launches of csrc/transcf.hip), both in the forward means and in the adjoint sums."""
