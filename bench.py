@@ -107,6 +107,9 @@ def main():
     # there when it initialises) is sent to stderr
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+    if os.environ.get("CREC_BENCH_TRACE_AFTER"):  # diagnosis of a run that does not come back: every thread's Python stack to stderr after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["CREC_BENCH_TRACE_AFTER"]), repeat=False, file=sys.stderr)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=45600)
@@ -131,6 +134,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("CREC_BENCH_ONE_GPU") == "1" and world > 1:  # (the rehearsal on one GPU, below: every rank -- and its canary -- on cuda:0)
+        os.environ["LOCAL_RANK"] = "0"
+        local_rank = 0
+        # a rank's exchange kernel waits inside the GPU for its peers' kernels.  On its own GPU it may fill the chip while it waits (the
+        # fused serve / apply exchanges of the row-sharded step launch up to 1024 workgroups); on ONE shared GPU that starves the very
+        # kernels it waits for.  The five-launch form keeps every waiting launch at 128 workgroups.
+        os.environ.setdefault("CREC_SHARD_UNFUSED", "1")
     # N > 1: which transport carries the exchanges (CREC_TRANSPORT = auto | peer | rccl).  The peer transport (IPC windows, one
     # kernel per exchange, csrc/crec_peer.hip) is the fast one, but it reads other GPUs' memory from kernels of this process: it is
     # first proven between THESE GPUs by a canary in child processes (tools/micro/peer_canary.py: every exchange bit for bit, then
@@ -163,10 +173,19 @@ def main():
     from cleverrec_amd.data import synthetic
 
     force_dp = os.environ.get("CREC_FORCE_DP") == "1"  # rehearse the N > 1 code path on one GPU
+    # CREC_BENCH_ONE_GPU=1: a rehearsal of `--gpus N` on ONE GPU -- every rank on cuda:0, the control plane over gloo (RCCL refuses two
+    # ranks on one device), the data over the peer windows: the whole N > 1 flow of this file between real processes, minus the links
+    one_gpu = os.environ.get("CREC_BENCH_ONE_GPU") == "1" and world > 1
+    if one_gpu:
+        local_rank = 0
+    ctl_dev = "cpu" if one_gpu else None  # where the control plane's little tensors live (None: this rank's GPU)
     if world > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     assert world == a.gpus, "--gpus %d but WORLD_SIZE=%d" % (a.gpus, world)
 
     sess = runtime.Session(local_rank)
@@ -185,6 +204,8 @@ def main():
         assert agree_min(data.item_nums) == data.item_nums == -agree_min(-data.item_nums), "replicas need one catalogue"
         if world > 1 and want_transport != "rccl" and agree_min(1 if canary and canary.get("rc") == 0 else 0) == 1:
             transport = "peer"
+        elif one_gpu:
+            raise SystemExit("CREC_BENCH_ONE_GPU=1 needs the peer transport (its canary failed: %r)" % (canary,))
         elif os.environ.get("CREC_TRANSPORT") == "peer" and world == 1:
             transport = "peer"  # (one rank: rehearses the code path, like CREC_FORCE_DP)
         # (the window also carries the S-big leg's compact tables: 65536 triples per rank x 2 items x 512 B per half)
@@ -235,7 +256,7 @@ def main():
         prewarm_steps += a.steps
         more = time.perf_counter() - t_pre < 1.0
         if dp:  # the passes are collective: every rank takes rank 0's decision
-            flag = torch.tensor([int(more)], dtype=torch.int64, device=sess.device)
+            flag = torch.tensor([int(more)], dtype=torch.int64, device=ctl_dev or sess.device)
             dist.broadcast(flag, src=0)
             more = bool(flag.item())
         if not more:
@@ -246,7 +267,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if dp:
-        tt = torch.tensor([dt], dtype=torch.float64, device=sess.device)
+        tt = torch.tensor([dt], dtype=torch.float64, device=ctl_dev or sess.device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     value = a.steps * B * world / dt
@@ -264,7 +285,7 @@ def main():
             k_st += nb_epoch_
             more = k_st < 8 * nb_epoch_
             if dp:
-                flag = torch.tensor([int(more)], dtype=torch.int64, device=sess.device)
+                flag = torch.tensor([int(more)], dtype=torch.int64, device=ctl_dev or sess.device)
                 dist.broadcast(flag, src=0)
                 more = bool(flag.item())
             if not more:
@@ -272,7 +293,7 @@ def main():
         fence()
         dts = time.perf_counter() - t0
         if dp:
-            tt = torch.tensor([dts], dtype=torch.float64, device=sess.device)
+            tt = torch.tensor([dts], dtype=torch.float64, device=ctl_dev or sess.device)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dts = float(tt.item())
         steady = {"steps": k_st, "ms_per_step": dts / k_st * 1e3, "value": k_st * B * world / dts, "unit": "triples/s",
@@ -375,16 +396,19 @@ def main():
             import bench_big
 
             def big_max(x):
-                tt = torch.tensor([x], dtype=torch.float64, device=sess.device)
+                tt = torch.tensor([x], dtype=torch.float64, device=ctl_dev or sess.device)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 return float(tt.item())
-            big_sharded = bench_big.run_sharded(steps=200, sess=sess, rank=rank, world=world, barrier=fence, max_reduce=big_max)
+            # (the one-GPU rehearsal: two processes' kernels that wait for each other take turns on the one GPU -- a hand-shake costs a
+            # scheduling turn there, so it runs a handful of steps)
+            big_sharded = bench_big.run_sharded(steps=4 if one_gpu else 200, sess=sess, rank=rank, world=world, barrier=fence, max_reduce=big_max)
             # the same with 65536 triples per rank and step (batches beyond 8192 are indexed in global memory, csrc/index_big.hip):
             # the exchanges' hand-shakes and the launches are paid once per ten times the triples
-            big_sharded["larger_batch"] = bench_big.run_sharded(steps=24, batch=65536, sess=sess, rank=rank, world=world, barrier=fence,
+            big_sharded["larger_batch"] = bench_big.run_sharded(steps=2 if one_gpu else 24, batch=65536, sess=sess, rank=rank, world=world, barrier=fence,
                                                                 max_reduce=big_max)
         except Exception as e:  # every rank fails or none: the sizes are the same everywhere
             big_sharded = {"error": repr(e)}
+            print("rank %d: the S-big row-sharded leg failed: %r" % (rank, e), file=sys.stderr, flush=True)
     if rank == 0 and big_sharded is not None:
         out["synthetic_big"] = big_sharded
 

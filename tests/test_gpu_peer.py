@@ -134,3 +134,26 @@ def test_ranks_as_threads_sharded_epoch():
     np.testing.assert_allclose(Q, oQ, rtol=0, atol=2e-6)
     for s in sessions:
         s.close()
+
+
+def test_bench_with_two_ranks_rehearsed_on_one_gpu():
+    """`python bench.py --gpus 2` as the driver starts it, rehearsed on ONE GPU (CREC_BENCH_ONE_GPU=1: every rank on cuda:0, the control
+    plane over gloo, the data over the peer windows): the launcher, the transport's canary, the replicated-Q headline epoch between two
+    processes, the S-big row-sharded legs at 6 144 and at 65 536 triples per rank (the global-memory index builds at a world of two)
+    and rank 0's JSON line -- the whole N > 1 flow of bench.py minus the links."""
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, CREC_BENCH_ONE_GPU="1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    cp = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--cpu-steps", "0"],
+                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=400)
+    assert cp.returncode == 0, cp.stderr[-2000:]
+    lines = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, cp.stdout[-1000:]
+    b = json.loads(lines[0])
+    assert b["n_gpus"] == 2 and b["transport"] == "peer" and b["peer_canary"]["rc"] == 0 and b["value"] > 0
+    sb = b["synthetic_big"]
+    assert "error" not in sb and sb["world"] == 2 and sb["triples_per_s"] > 0
+    assert "error" not in sb["larger_batch"] and sb["larger_batch"]["triples_per_s"] > 0
+    x = sb["exchange_per_rank_per_step"]
+    assert x["bytes_rows_sent"] > 0 and abs(x["bytes_rows_sent"] - x["bytes_grads_sent"]) < 0.02 * x["bytes_rows_sent"]
