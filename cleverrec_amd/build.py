@@ -19,7 +19,7 @@ COMMON = ["-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 SOURCES = {
     "crec_ctx.cpp": [],
     "crec_comm.cpp": ["-pthread"],
-    "crec_peer.hip": [],
+    "crec_peer.hip": ["-ffp-contract=off"],  # (its fused all-reduce + Adam repeats bpr_train.hip's arithmetic bit for bit)
     "shard_host.cpp": [],
     "crec_sampler.cpp": ["-fno-math-errno", "-pthread"],
     "gpu_sampler.hip": [],

@@ -589,6 +589,7 @@ struct Hyper {
     float lr_t, beta1, beta2, eps, reg;
     int opt; // 0 Adam; CREC_OPT_SGD, CREC_OPT_ADAGRAD: the touched-rows-only optimizers of utils/tools.py:79-87
     float *dQ; // data-parallel step: item rows' gradient sums go here ([I,d], every row written) instead of Adam
+    int dq_sys = 0; // dQ is a peer-transport window (< 2 GiB) that other GPUs will read: system-scope (written-through) stores, see st4_dq
     // deferred mode (exact TF1 Adam with the traffic of the lazy step): TF1 decays m, v and moves var on EVERY row at
     // every step; here a row carries the step at which its (var, m, v) were last brought up to date and replays the
     // steps it skipped -- m *= b1, v *= b2, var -= lr_s*m/(sqrt(v)+eps) for s = last+1 .. -- whenever it is touched
@@ -648,6 +649,21 @@ __device__ __forceinline__ void st4_wt(float *base, int64_t off, float4 v)
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000);
     const crec_u4v x = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
     __builtin_amdgcn_raw_buffer_store_b128(x, r, (int)(off * 4), 0, 16 /* sc1 */);
+}
+// A gradient row for an exchange: into a plain buffer, or -- sys -- into this rank's peer-transport window with a SYSTEM-scope
+// (sc0 sc1, written through) store, the form crec_peer.hip's own copy-in uses and its canary proves between the node's GPUs: what
+// the peers read does not depend on which scope the end of this kernel releases at.  base: wave-uniform; off: float index
+__device__ __forceinline__ void st4_dq(float *base, int64_t off, float4 v, bool sys, bool stream)
+{
+    if (sys) {
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000);
+        const crec_u4v x = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+        __builtin_amdgcn_raw_buffer_store_b128(x, r, (int)(off * 4), 0, 17 /* sc0 sc1 */);
+    } else if (stream) {
+        st4s(base + off, v);
+    } else {
+        st4(base + off, v);
+    }
 }
 // the matching 16-byte load: agent scope (sc1), served where the XCDs meet -- one instruction instead of the four 4-byte
 // atomic loads of ld4_agent.  base: wave-uniform; off: float index (< 2^29)
@@ -1237,7 +1253,7 @@ __device__ __forceinline__ void row_finish(const Tables &dst, const Slot &sl, in
         if (l == 0 && (dense || sl.cnt > 0))
             *rowterm_slot = (0.5f * nr) * (float)sl.cnt;
         if (!user && h.dQ) { // the all-reduce + bpr_adam_dense finish this row
-            st4(h.dQ + ro, grad);
+            st4_dq(h.dQ, ro, grad, h.dq_sys, false);
         } else {
             adam4(var, m, v, grad, sl.cnt > 0, h);
             if (WT) {
@@ -1417,7 +1433,7 @@ __device__ __forceinline__ void chunk_wave(const Tables &src, int d, int4 item, 
         if (l == 0 && f.rowterm) // lazy mode keeps its l2 terms per triple
             f.rowterm[f.dense ? sl.row : (int64_t)rec.w] = (0.5f * nr) * (float)cnt;
         if (!user && h.dQ) {
-            st4(h.dQ + ro, grad);
+            st4_dq(h.dQ, ro, grad, h.dq_sys, false);
         } else {
             adam4(var, m, v, grad, true, h);
             if (WT) {
@@ -1644,7 +1660,7 @@ __device__ __forceinline__ void lazy_finish_row(const Tables &t, int d, bool act
         return;
     const int64_t ro = (int64_t)row * d + 4 * l;
     if (!USER && h.dQ) {
-        st4(h.dQ + ro, g);
+        st4_dq(h.dQ, ro, g, h.dq_sys, false);
         return;
     }
     float4 nv = own; // deferred mode: `own` is the contributor's caught-up copy of the row; m, v as stored are replayed here
@@ -1883,7 +1899,7 @@ __global__ __launch_bounds__(LazyGeo<LPR>::THREADS) void bpr_triples_lazy(Tables
                 if (h.opt == 0)
                     st4s(t.vQ + oi, vi);
             } else {
-                st4s(h.dQ + oi, gi);
+                st4_dq(h.dQ, oi, gi, h.dq_sys, true);
             }
         }
         if (js) {
@@ -1897,7 +1913,7 @@ __global__ __launch_bounds__(LazyGeo<LPR>::THREADS) void bpr_triples_lazy(Tables
                 if (h.opt == 0)
                     st4s(t.vQ + oj, vj);
             } else {
-                st4s(h.dQ + oj, gj);
+                st4_dq(h.dQ, oj, gj, h.dq_sys, true);
             }
         }
     }
@@ -2498,12 +2514,22 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
             a.h.beta2 = opt->beta2;
             a.h.eps = opt->eps;
             a.h.reg = opt->reg;
-            a.h.dQ = dp ? (float *)ctx->dq.ptr : nullptr;
+            // (the peer transport: dQ goes straight into this rank's window, and ONE launch exchanges it and updates Q)
+            const bool dp_fused = dp && !ctx->knob_dp_unfused && xdp->has_allreduce_adam((size_t)t->I * t->d);
+            a.h.dQ = dp ? (dp_fused ? (float *)xdp->next_half() : (float *)ctx->dq.ptr) : nullptr;
+            a.h.dq_sys = dp_fused;
             a.xb = (float *)ctx->loss_ws.ptr + b * loss_stride;
             a.nb_cur = (int32_t)((n_chunk - b * B) < B ? (n_chunk - b * B) : B);
             a.rowterm = a.xb + B;
             step(a, w, b, hn + b * HN);
-            if (dp) {
+            if (dp && dp_fused) {
+                const crec_adam_args aa{a.h.lr_t, a.h.beta1, a.h.beta2, a.h.eps};
+                crec_prof_begin(ctx, CREC_K_ADAM_DENSE, st);
+                const int rc = xdp->allreduce_adam(ctx, (size_t)t->I * t->d, t->Q, t->mQ, t->vQ, aa, st);
+                crec_prof_end(ctx, st);
+                if (rc)
+                    return rc;
+            } else if (dp) {
                 // the one exchange of the path: per-item gradient sums over all ranks' triples
                 float *dq = (float *)ctx->dq.ptr;
                 const size_t nq = (size_t)t->I * t->d;
@@ -2884,7 +2910,7 @@ int sharded_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, int64_t I_global
                 if (n_srv > 0) {
                     crec_prof_begin(ctx, CREC_K_SHARD_SERVE, st);
                     CREC_KLAUNCH(ctx, shard_serve_rows, dim3((unsigned)crec_ceil_div(n_srv * lpr, 256)), dim3(256), 0, st,
-                                 (const float *)t->Q, (const int32_t *)(v.srv_rows + b * stride), (int)n_srv, d, lpr, (float *)x->next_half());
+                                 (const float *)t->Q, (const int32_t *)(v.srv_rows + b * stride), (int)n_srv, d, lpr, (float *)x->next_half(), 1);
                     crec_prof_end(ctx, st);
                 }
                 if (int rc = x->alltoallv_inplace(ctx, scnt.data(), sdsp.data(), p.Qc, rcnt.data(), rdsp.data(), st))
@@ -2893,7 +2919,7 @@ int sharded_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, int64_t I_global
                 if (n_srv > 0) {
                     crec_prof_begin(ctx, CREC_K_SHARD_SERVE, st);
                     CREC_KLAUNCH(ctx, shard_serve_rows, dim3((unsigned)crec_ceil_div(n_srv * lpr, 256)), dim3(256), 0, st,
-                                 (const float *)t->Q, (const int32_t *)(v.srv_rows + b * stride), (int)n_srv, d, lpr, v.sendrows);
+                                 (const float *)t->Q, (const int32_t *)(v.srv_rows + b * stride), (int)n_srv, d, lpr, v.sendrows, 0);
                     crec_prof_end(ctx, st);
                 }
                 if (int rc = x->alltoallv(ctx, v.sendrows, scnt.data(), sdsp.data(), p.Qc, rcnt.data(), rdsp.data(), 4, st))
@@ -2909,6 +2935,7 @@ int sharded_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, int64_t I_global
             // the item side emits each compact row's gradient sum (incl. its l2 term) instead of Adam -- over the peer transport straight
             // into this rank's window, where the owners will read it (the layout of the compact table: owner o's rows from req_off[o])
             a.h.dQ = fused ? (float *)x->next_half() : p.dQc;
+            a.h.dq_sys = fused;
             a.xb = (float *)ctx->loss_ws.ptr + b * loss_stride;
             a.nb_cur = (int32_t)((n_chunk - b * B) < B ? (n_chunk - b * B) : B);
             a.rowterm = a.xb + B;

@@ -18,6 +18,11 @@
 #include "crec_internal.h"
 #include "crec_peer_dev.h"
 
+// what TF1's dense Adam needs besides the variable, its slots and the gradient (lr_t = lr sqrt(1 - b2^t) / (1 - b1^t))
+struct crec_adam_args {
+    float lr_t, beta1, beta2, eps;
+};
+
 struct crec_xch {
     int rank = 0, world = 1;
     virtual ~crec_xch() {}
@@ -38,6 +43,14 @@ struct crec_xch {
     virtual int alltoallv_inplace(crec_ctx *ctx, const int64_t *, const int64_t *, void *, const int64_t *, const int64_t *, hipStream_t)
     {
         return crec_fail(ctx, CREC_EUNSUPPORTED, "this transport has no window to exchange in place");
+    }
+    //   allreduce_adam  the replicated-Q step's exchange fused with its update: this rank's operand (n floats, its dQ) lies in next_half();
+    //              ONE launch publishes it, forms the rank-ordered sum of all ranks' operands (bit-identical on every rank) and applies
+    //              TF1's Adam to this rank's replica (Q, m, v) -- no reduced gradient in memory, no separate update launch
+    virtual bool has_allreduce_adam(size_t /*n*/) { return false; }
+    virtual int allreduce_adam(crec_ctx *ctx, size_t, float *, float *, float *, const crec_adam_args &, hipStream_t)
+    {
+        return crec_fail(ctx, CREC_EUNSUPPORTED, "this transport has no fused all-reduce + Adam");
     }
     // errors a transport only learns about asynchronously (the peer transport's waits give up after a time-out); synchronises st
     virtual int status(crec_ctx *, hipStream_t) { return CREC_OK; }

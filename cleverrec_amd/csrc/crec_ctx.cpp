@@ -201,6 +201,7 @@ int crec_ctx_create(int device, crec_ctx **out)
     ctx->knob_ncf_generic = env_int("CREC_NCF_GENERIC", 0);
     ctx->knob_shard_unfused = env_int("CREC_SHARD_UNFUSED", 0);
     ctx->knob_big_index = env_int("CREC_BIG_INDEX", 0);
+    ctx->knob_dp_unfused = env_int("CREC_DP_UNFUSED", 0);
     ctx->knob_idx_one_wg = env_int("CREC_IDX_ONE_WG", 0);
     ctx->knob_idx_overlap = env_int("CREC_IDX_OVERLAP", 0);
     ctx->knob_no_zero_copy = env_int("CREC_NO_ZERO_COPY", 0);
@@ -292,6 +293,8 @@ int crec_ctx_set_option(crec_ctx *ctx, const char *name, int64_t value)
         ctx->knob_shard_unfused = (int)value;
     else if (n == "big_index")
         ctx->knob_big_index = (int)value;
+    else if (n == "dp_unfused")
+        ctx->knob_dp_unfused = (int)value;
     else if (n == "idx_one_wg")
         ctx->knob_idx_one_wg = (int)value;
     else if (n == "idx_overlap")

@@ -164,6 +164,94 @@ __global__ __launch_bounds__(PEER_THREADS) void peer_exchange(crec_peer_view v, 
     }
 }
 
+// ---- the replicated-Q step: all-reduce of the ranks' dQ fused with TF1's Adam on this rank's replica -------------------------------------
+// The operand (n4 float4s) was left in this rank's window half by the step kernel; workgroup 0 publishes at once.  One shot: every
+// rank adds all operands in rank order and updates all of Q.  Two shots (from three ranks on): this rank adds slice `rank`, updates it
+// and leaves the sum in its window's result area; the other slices' sums are read from their owners and applied here -- every
+// replica applies the same sums in the same arithmetic: bit-identical replicas, as with the separate all-reduce + bpr_adam_dense.
+// The arithmetic is bpr_train.hip's adam4 (touched form), compiled like it with -ffp-contract=off.
+__device__ __forceinline__ float peer_adam_quot(float num, float v, float eps)
+{
+#ifdef CREC_EXACT_MATH
+    return num / (sqrtf(v) + eps);
+#else
+    return num * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) + eps);
+#endif
+}
+__device__ __forceinline__ void peer_adam4(float4 *Q, float4 *m, float4 *vv, int64_t k, float4 g, const crec_adam_args &h)
+{
+    float4 var = Q[k], mm = m[k], v2 = vv[k];
+    const float omb1 = 1.0f - h.beta1, omb2 = 1.0f - h.beta2;
+    float *pv = &var.x, *pm = &mm.x, *pw = &v2.x;
+    const float *pg = &g.x;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float mk = pm[c] * h.beta1;
+        float vk = pw[c] * h.beta2;
+        mk = mk + pg[c] * omb1;
+        vk = vk + (pg[c] * pg[c]) * omb2;
+        pm[c] = mk;
+        pw[c] = vk;
+        pv[c] = pv[c] - peer_adam_quot(h.lr_t * mk, vk, h.eps);
+    }
+    Q[k] = var;
+    m[k] = mm;
+    vv[k] = v2;
+}
+__device__ __forceinline__ float4 peer_sum_all(const crec_peer_view &v, const unsigned long long *flag_s, int64_t k, bool fences)
+{
+    peer_u4v x[PEER_MAX];
+#pragma unroll
+    for (int p = 0; p < PEER_MAX; ++p)
+        if (p < v.world)
+            x[p] = peer_ld16(peer_seg(v, p, flag_s[p]), k << 4, fences);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int p = 0; p < PEER_MAX; ++p) // rank order: every rank forms the same sum
+        if (p < v.world)
+            acc = make_float4(acc.x + __uint_as_float(x[p].x), acc.y + __uint_as_float(x[p].y), acc.z + __uint_as_float(x[p].z),
+                              acc.w + __uint_as_float(x[p].w));
+    return acc;
+}
+__global__ __launch_bounds__(PEER_THREADS) void peer_allreduce_adam(crec_peer_view v, int64_t n4, float4 *__restrict__ Q, float4 *__restrict__ m,
+                                                                    float4 *__restrict__ vv, crec_adam_args h, int two_shot)
+{
+    __shared__ unsigned long long flag_s[PEER_MAX];
+    __shared__ int last_s, bad_s;
+    const bool fences = v.fences != 0;
+    const int64_t gtid = (int64_t)blockIdx.x * PEER_THREADS + threadIdx.x, gsz = (int64_t)gridDim.x * PEER_THREADS;
+    peer_publish(v, 0, false, &last_s, [&](int) { return (int64_t)0; });
+    if (!peer_wait_all(v, 0, flag_s, &bad_s))
+        return;
+    if (!two_shot) {
+        for (int64_t k = gtid; k < n4; k += gsz)
+            peer_adam4(Q, m, vv, k, peer_sum_all(v, flag_s, k, fences), h);
+        return;
+    }
+    const int64_t per = (n4 + v.world - 1) / v.world, roff = n4 << 4; // result area, behind the operand
+    {
+        const int64_t k0 = (int64_t)v.rank * per, k1 = (k0 + per) < n4 ? (k0 + per) : n4;
+        for (int64_t k = k0 + gtid; k < k1; k += gsz) {
+            const float4 acc = peer_sum_all(v, flag_s, k, fences);
+            const peer_u4v w = {__float_as_uint(acc.x), __float_as_uint(acc.y), __float_as_uint(acc.z), __float_as_uint(acc.w)};
+            peer_st16(v.my_half + roff, (k - k0) << 4, w, fences);
+            peer_adam4(Q, m, vv, k, acc, h);
+        }
+    }
+    peer_publish(v, 1, true, &last_s, [&](int) { return roff; });
+    if (!peer_wait_all(v, 1, flag_s, &bad_s))
+        return;
+    for (int s = 1; s < v.world; ++s) {
+        const int p = (v.rank + s) % v.world;
+        const int64_t k0 = (int64_t)p * per, k1 = (k0 + per) < n4 ? (k0 + per) : n4;
+        const char *src = peer_seg(v, p, flag_s[p]);
+        for (int64_t k = k0 + gtid; k < k1; k += gsz) {
+            const peer_u4v x = peer_ld16(src, (k - k0) << 4, fences);
+            peer_adam4(Q, m, vv, k, make_float4(__uint_as_float(x.x), __uint_as_float(x.y), __uint_as_float(x.z), __uint_as_float(x.w)), h);
+        }
+    }
+}
+
 struct PeerState { // what a rank owns; shared by the ranks of an in-process group through raw pointers
     char *win = nullptr;
     unsigned long long *sig = nullptr;
@@ -291,6 +379,28 @@ struct PeerXch : crec_xch {
         }
         return launch(ctx, a, nullptr, recv, 8, 0, work, st);
     }
+    // (two shots from three ranks and 64 KiB on, as allreduce_sum_f32; the operand and the result area must fit the window half)
+    bool adam_two_shot(size_t n) const { return two_shot && world >= 3 && (int64_t)n * 4 >= (64 << 10); }
+    bool has_allreduce_adam(size_t n) override
+    {
+        const int64_t per16 = (((int64_t)n / 4 + world - 1) / world) * 16;
+        return connected && n > 0 && (n & 3) == 0 && (int64_t)n * 4 + (adam_two_shot(n) ? per16 : 0) <= own.win_bytes / 2;
+    }
+    int allreduce_adam(crec_ctx *ctx, size_t n, float *Q, float *m, float *v, const crec_adam_args &h, hipStream_t st) override
+    {
+        CREC_REQUIRE(ctx, has_allreduce_adam(n), "peer transport: fused all-reduce + Adam of %zu floats does not fit this communicator", n);
+        CREC_REQUIRE(ctx, (((uintptr_t)Q | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "peer transport: 16-byte aligned tables");
+        crec_peer_view pv;
+        begin(&pv);
+        const bool two = adam_two_shot(n);
+        const int64_t work = two ? (int64_t)n * 4 * 2 : (int64_t)n * 4 * world;
+        int nb = (int)((work + 16383) / 16384);
+        nb = nb < 1 ? 1 : (nb > PEER_MAX_BLOCKS ? PEER_MAX_BLOCKS : nb);
+        hipLaunchKernelGGL(peer_allreduce_adam, dim3((unsigned)nb), dim3(PEER_THREADS), 0, st, pv, (int64_t)(n / 4), (float4 *)Q, (float4 *)m, (float4 *)v,
+                           h, two ? 1 : 0);
+        CREC_HIP(ctx, hipGetLastError());
+        return CREC_OK;
+    }
     int allreduce_sum_f32(crec_ctx *ctx, float *buf, size_t n, hipStream_t st) override
     {
         if (n == 0)
@@ -318,7 +428,8 @@ int peer_alloc(crec_ctx *ctx, int64_t window_bytes, PeerXch **out)
 {
     CREC_REQUIRE(ctx, ctx->device >= 0, "host-only ctx: no device bound");
     CREC_REQUIRE(ctx, ctx->comm == nullptr && ctx->xch == nullptr, "communicator already initialised");
-    CREC_REQUIRE(ctx, window_bytes >= (1 << 16) && window_bytes % 512 == 0, "window_bytes: a multiple of 512, at least 64 KiB");
+    CREC_REQUIRE(ctx, window_bytes >= (1 << 16) && window_bytes % 512 == 0 && window_bytes < ((int64_t)1 << 32),
+                 "window_bytes: a multiple of 512, at least 64 KiB, below 4 GiB (a half is addressed with 32-bit offsets)");
     CREC_HIP(ctx, hipSetDevice(ctx->device));
     PeerXch *x = new PeerXch();
     x->own.device = ctx->device;

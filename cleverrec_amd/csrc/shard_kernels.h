@@ -154,14 +154,14 @@ __global__ __launch_bounds__(SHARD_THREADS) void shard_owner_index(const int32_t
 
 // one group of lpr lanes per served slot: out[slot] = Q[srv_rows[slot]]
 __global__ __launch_bounds__(256) void shard_serve_rows(const float *__restrict__ Q, const int32_t *__restrict__ srv_rows, int n,
-                                                        int d, int lpr, float *__restrict__ out)
+                                                        int d, int lpr, float *__restrict__ out, int sys /* out is a peer window */)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t slot = t / lpr;
     const int l = (int)(t % lpr);
     if (slot >= n || 4 * l >= d)
         return;
-    st4s(out + slot * d + 4 * l, ld4(Q + (int64_t)srv_rows[slot] * d + 4 * l));
+    st4_dq(out, slot * d + 4 * l, ld4(Q + (int64_t)srv_rows[slot] * d + 4 * l), sys != 0, true);
 }
 
 // one group of lpr lanes per unique row of the batch: the row's gradient rows (one per requesting peer, each already

@@ -121,6 +121,7 @@ def init_peer(sess, rank=None, world=None, window_bytes=128 << 20):
         sess.ctx.check(sess.lib.crec_comm_peer_fences(sess.ctx.h, 1))
     if world > 1:
         dist.barrier()  # nobody starts an exchange before everybody has mapped everybody
+    sess.peer_window_bytes = int(window_bytes)
     return rank, world
 
 

@@ -75,6 +75,8 @@ const char *crec_last_error(const crec_ctx *ctx);
  *                    into page-locked memory by the index kernel itself
  *   "idx_one_wg"     1: the tf1 step's per-chunk index with one workgroup per (batch, side) instead of two that share the phases
  *                    behind the sort (same index, bit for bit)
+ *   "dp_unfused"     1: the replicated-Q step over the peer transport as an all-reduce of dQ plus a separate Adam launch instead of
+ *                    one launch that exchanges and updates (same tables, bit for bit)
  *   "big_index"      1: the lazy-family steps index their batches through the global-memory sort (index_big.hip, the form batches of
  *                    more than 8192 triples always take) even where the in-LDS sort would do: same index, bit for bit
  *   "idx_overlap"    1: that form indexes its chunks of batches a chunk ahead on a side stream, beside the previous chunk's steps

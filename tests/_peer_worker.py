@@ -76,9 +76,10 @@ def sharded(sess, rank, world):
             "same_loss_everywhere": all(bool(np.array_equal(x[2], loss)) for x in gathered)}
 
 
-def data_parallel(sess, rank, world):
-    """the replicated-Q step, every rank a process: replicas bit-identical, tables against the oracle's restatement"""
-    U, I, B, d, steps = 300, 140, 512, 64, 4
+def data_parallel(sess, rank, world, I=140):
+    """the replicated-Q step, every rank a process: replicas bit-identical, tables against the oracle's restatement.  Over the peer
+    transport the all-reduce of dQ and the dense Adam are ONE launch (option dp_unfused: two); I = 300: its two-shot form at a world of 3"""
+    U, B, d, steps = 300, 512, 64, 4
     g = np.random.Generator(np.random.PCG64(9))
     P0 = (g.standard_normal((U, d)) * 0.01).astype(np.float32)
     Q0 = (g.standard_normal((I, d)) * 0.01).astype(np.float32)
@@ -108,7 +109,8 @@ def data_parallel(sess, rank, world):
         for m in models:
             oracle.adam_dense(m, dQ, lr_t)
         ol.append(tot)
-    return {"replicas_identical": all(bool(np.array_equal(x[1], gathered[0][1]) and np.array_equal(x[2], gathered[0][2])) for x in gathered),
+    return {"Q": gathered[0][1], "mQ": gathered[0][2],
+            "replicas_identical": all(bool(np.array_equal(x[1], gathered[0][1]) and np.array_equal(x[2], gathered[0][2])) for x in gathered),
             "loss_ok": bool(np.allclose(loss, ol, rtol=1e-5)), "Q_err": float(np.abs(gathered[0][1] - models[0].Q).max()),
             "P_err": float(max(np.abs(x[0] - m.P).max() for x, m in zip(gathered, models)))}
 
@@ -129,7 +131,15 @@ def main():
         sess.ctx.set_option("shard_unfused", 1)
         out["sharded_unfused"] = sharded(sess, rank, world)  # the five-launch form over the same transport
         sess.ctx.set_option("shard_unfused", 0)
-        out["dp"] = data_parallel(sess, rank, world)
+        for name, I_ in (("dp", 140), ("dp_two_shot", 300)):
+            one = data_parallel(sess, rank, world, I_)  # all-reduce + Adam in one launch
+            sess.ctx.set_option("dp_unfused", 1)
+            two = data_parallel(sess, rank, world, I_)
+            sess.ctx.set_option("dp_unfused", 0)
+            if rank == 0:
+                one["same_bits_as_unfused"] = bool(np.array_equal(one.pop("Q"), two.pop("Q")) and np.array_equal(one.pop("mQ"), two.pop("mQ")))
+                one["unfused"] = two
+            out[name] = one
         dist.barrier()
         sess.close()
     finally:

@@ -56,10 +56,12 @@ def test_ranks_as_processes_over_ipc_windows(world, fences, big):
     assert line, outs[0][0][-2000:]
     res = json.loads(line[0][len("PEER_RESULT "):])
     assert res["exchanges_ok"]
-    dp = res["dp"]
     for sh in (res["sharded"], res["sharded_unfused"]):
         assert sh["loss_ok"] and sh["same_loss_everywhere"] and sh["P_err"] <= 2e-6 and sh["Q_err"] <= 2e-6, sh
-    assert dp["replicas_identical"] and dp["loss_ok"] and dp["P_err"] <= 2e-6 and dp["Q_err"] <= 2e-6, dp
+    for name in ("dp", "dp_two_shot"):  # all-reduce + Adam in one launch, the same bits as the all-reduce followed by bpr_adam_dense
+        for dp in (res[name], res[name]["unfused"]):
+            assert dp["replicas_identical"] and dp["loss_ok"] and dp["P_err"] <= 2e-6 and dp["Q_err"] <= 2e-6, (name, dp)
+        assert res[name]["same_bits_as_unfused"], name
 
 
 def test_ranks_as_threads_sharded_epoch():

@@ -113,7 +113,8 @@ def run_sharded(users=10_000_000, items=1_000_000, dim=128, steps=200, warmup=30
     max_reduce = max_reduce or (lambda x: x)
     transport = "the ctx's communicator" if world > 1 else "none (device copies)"
     if world == 1 and os.environ.get("CREC_TRANSPORT") == "peer":  # a world of one over the peer windows: what the fused exchange kernels cost by themselves
-        parallel.init_peer(sess, 0, 1, window_bytes=max(64 << 20, -(-(2 * (2 * batch * dim * 4 + 4096)) // (1 << 20)) * (1 << 20)))  # two halves, each a batch's compact table
+        if not getattr(sess, "peer_window_bytes", 0):  # (bench.py's rehearsal of the N > 1 path has connected this ctx already)
+            parallel.init_peer(sess, 0, 1, window_bytes=max(64 << 20, -(-(2 * (2 * batch * dim * 4 + 4096)) // (1 << 20)) * (1 << 20)))  # two halves, each a batch's compact table
         transport = "peer windows, a world of one" + (" (five launches per step)" if os.environ.get("CREC_SHARD_UNFUSED") == "1" else " (exchanges fused with serve / apply)")
     g = torch.Generator(device=dev).manual_seed(seed + 1000 * rank)
     lo, hi = parallel.user_range(users, rank, world)
