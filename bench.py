@@ -267,6 +267,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if dp:
+        st.synchronize()  # (the epochs report an exchange that gave up on a peer late, without draining the stream: ask now)
         tt = torch.tensor([dt], dtype=torch.float64, device=ctl_dev or sess.device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -355,7 +356,7 @@ def main():
         if os.path.exists(tf) and not dp:
             traffic = json.load(open(tf)).get("traffic_bytes_per_launch")
         if dp:
-            alg[dom] = B * (24 * D + 12) + 24 * D * U + 4 * D * I  # P swept, dQ written; Q is swept by bpr_adam_dense
+            alg[dom] = B * (24 * D + 12) + 24 * D * U + 4 * D * I  # P swept, dQ written; Q is swept by bpr_adam_dense / peer_allreduce_adam
         avg_s = prof[dom][0] / prof[dom][1] * 1e-3
         ach = alg[dom] / avg_s / 1e9
         # the second clock: rocprofv3 --kernel-trace --stats of this workload (tools/profile.sh -> profiles/round3_kernel_stats.txt).

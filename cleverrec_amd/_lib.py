@@ -205,7 +205,7 @@ class Context:
     # ---- measurement ---------------------------------------------------------------------------
     KERNELS = ("bpr_index_batches", "bpr_step_fused", "bpr_triples_lazy", "unused3", "bpr_reduce_loss", "eval_sweep",
                "eval_merge", "rank_metrics", "unused8", "bpr_adam_dense", "rows_index_batches", "rows_apply", "small_adam_dense", "ncf_tile", "fm_instances", "cml_instances", "ncf_pair_logits",
-               "shard_plan_batches", "shard_serve_rows", "shard_owner_apply")
+               "shard_plan_batches", "shard_serve_rows", "shard_owner_apply", "peer_allreduce_adam")
 
     def profile(self, on):
         self.check(self.lib.crec_profile_enable(self.h, int(bool(on))))

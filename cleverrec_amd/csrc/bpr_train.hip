@@ -2524,7 +2524,7 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
             step(a, w, b, hn + b * HN);
             if (dp && dp_fused) {
                 const crec_adam_args aa{a.h.lr_t, a.h.beta1, a.h.beta2, a.h.eps};
-                crec_prof_begin(ctx, CREC_K_ADAM_DENSE, st);
+                crec_prof_begin(ctx, CREC_K_PEER_ADAM, st);
                 const int rc = xdp->allreduce_adam(ctx, (size_t)t->I * t->d, t->Q, t->mQ, t->vQ, aa, st);
                 crec_prof_end(ctx, st);
                 if (rc)
@@ -2560,7 +2560,10 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
         if (dp) {
             if (int rc = xdp->allreduce_sum_f32(ctx, loss_per_batch + b0, (size_t)nbc, st))
                 return rc;
-            if (int rc = xdp->status(ctx, st)) // (a transport that waits on its peers inside kernels reports a peer that never came here)
+            // (a transport that waits on its peers inside kernels reports a peer that never came; without draining the stream: a
+            // time-out -- after which the tables are no longer the replicas' common state -- is reported by the NEXT chunk's check, the
+            // next call's, or crec_comm_status)
+            if (int rc = xdp->status_deferred(ctx, st))
                 return rc;
         }
         if (piped)

@@ -54,6 +54,9 @@ struct crec_xch {
     }
     // errors a transport only learns about asynchronously (the peer transport's waits give up after a time-out); synchronises st
     virtual int status(crec_ctx *, hipStream_t) { return CREC_OK; }
+    // the same without waiting: the error word is sent to the host BEHIND the work enqueued so far and the call reports what earlier
+    // such checks have brought back -- a time-out shows up one check late (or at the next status), the stream is never drained
+    virtual int status_deferred(crec_ctx *ctx, hipStream_t st) { return status(ctx, st); }
 };
 
 // the ctx's exchange object: its local group, else RCCL (crec_comm_init), else the world-of-one copy

@@ -47,6 +47,7 @@ enum crec_kernel_class {
     CREC_K_SHARD_PLAN,
     CREC_K_SHARD_SERVE,
     CREC_K_SHARD_APPLY,
+    CREC_K_PEER_ADAM, // peer_allreduce_adam: the replicated-Q step's exchange + dense Adam
     CREC_K_COUNT
 };
 

@@ -178,11 +178,14 @@ __device__ __forceinline__ float peer_adam_quot(float num, float v, float eps)
     return num * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) + eps);
 #endif
 }
-__device__ __forceinline__ void peer_adam4(float4 *Q, float4 *m, float4 *vv, int64_t k, float4 g, const crec_adam_args &h)
+struct PeerRow4 {
+    float4 var, m, v;
+};
+__device__ __forceinline__ PeerRow4 peer_row_load(const float4 *Q, const float4 *m, const float4 *vv, int64_t k) { return PeerRow4{Q[k], m[k], vv[k]}; }
+__device__ __forceinline__ void peer_adam4(float4 *Q, float4 *m, float4 *vv, int64_t k, PeerRow4 r, float4 g, const crec_adam_args &h)
 {
-    float4 var = Q[k], mm = m[k], v2 = vv[k];
     const float omb1 = 1.0f - h.beta1, omb2 = 1.0f - h.beta2;
-    float *pv = &var.x, *pm = &mm.x, *pw = &v2.x;
+    float *pv = &r.var.x, *pm = &r.m.x, *pw = &r.v.x;
     const float *pg = &g.x;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -194,9 +197,9 @@ __device__ __forceinline__ void peer_adam4(float4 *Q, float4 *m, float4 *vv, int
         pw[c] = vk;
         pv[c] = pv[c] - peer_adam_quot(h.lr_t * mk, vk, h.eps);
     }
-    Q[k] = var;
-    m[k] = mm;
-    vv[k] = v2;
+    Q[k] = r.var;
+    m[k] = r.m;
+    vv[k] = r.v;
 }
 __device__ __forceinline__ float4 peer_sum_all(const crec_peer_view &v, const unsigned long long *flag_s, int64_t k, bool fences)
 {
@@ -213,6 +216,8 @@ __device__ __forceinline__ float4 peer_sum_all(const crec_peer_view &v, const un
                               acc.w + __uint_as_float(x[p].w));
     return acc;
 }
+// (a thread's first row of Q, m, v is requested BEFORE the wait for the peers' flags: it does not depend on them, and at ml-1m
+// shape -- one or two float4s per thread -- that is most of the table traffic)
 __global__ __launch_bounds__(PEER_THREADS) void peer_allreduce_adam(crec_peer_view v, int64_t n4, float4 *__restrict__ Q, float4 *__restrict__ m,
                                                                     float4 *__restrict__ vv, crec_adam_args h, int two_shot)
 {
@@ -220,34 +225,39 @@ __global__ __launch_bounds__(PEER_THREADS) void peer_allreduce_adam(crec_peer_vi
     __shared__ int last_s, bad_s;
     const bool fences = v.fences != 0;
     const int64_t gtid = (int64_t)blockIdx.x * PEER_THREADS + threadIdx.x, gsz = (int64_t)gridDim.x * PEER_THREADS;
+    const int64_t per = two_shot ? (n4 + v.world - 1) / v.world : n4;
+    const int64_t m0 = two_shot ? (int64_t)v.rank * per : 0, m1 = (m0 + per) < n4 ? (m0 + per) : n4; // the rows this rank sums itself
+    PeerRow4 first{};
+    if (m0 + gtid < m1)
+        first = peer_row_load(Q, m, vv, m0 + gtid);
     peer_publish(v, 0, false, &last_s, [&](int) { return (int64_t)0; });
     if (!peer_wait_all(v, 0, flag_s, &bad_s))
         return;
-    if (!two_shot) {
-        for (int64_t k = gtid; k < n4; k += gsz)
-            peer_adam4(Q, m, vv, k, peer_sum_all(v, flag_s, k, fences), h);
-        return;
-    }
-    const int64_t per = (n4 + v.world - 1) / v.world, roff = n4 << 4; // result area, behind the operand
-    {
-        const int64_t k0 = (int64_t)v.rank * per, k1 = (k0 + per) < n4 ? (k0 + per) : n4;
-        for (int64_t k = k0 + gtid; k < k1; k += gsz) {
-            const float4 acc = peer_sum_all(v, flag_s, k, fences);
+    const int64_t roff = n4 << 4; // two shots: the result area, behind the operand
+    for (int64_t k = m0 + gtid; k < m1; k += gsz) {
+        const float4 acc = peer_sum_all(v, flag_s, k, fences);
+        if (two_shot) {
             const peer_u4v w = {__float_as_uint(acc.x), __float_as_uint(acc.y), __float_as_uint(acc.z), __float_as_uint(acc.w)};
-            peer_st16(v.my_half + roff, (k - k0) << 4, w, fences);
-            peer_adam4(Q, m, vv, k, acc, h);
+            peer_st16(v.my_half + roff, (k - m0) << 4, w, fences);
         }
+        peer_adam4(Q, m, vv, k, k == m0 + gtid ? first : peer_row_load(Q, m, vv, k), acc, h);
     }
+    if (!two_shot)
+        return;
     peer_publish(v, 1, true, &last_s, [&](int) { return roff; });
     if (!peer_wait_all(v, 1, flag_s, &bad_s))
         return;
-    for (int s = 1; s < v.world; ++s) {
-        const int p = (v.rank + s) % v.world;
-        const int64_t k0 = (int64_t)p * per, k1 = (k0 + per) < n4 ? (k0 + per) : n4;
-        const char *src = peer_seg(v, p, flag_s[p]);
-        for (int64_t k = k0 + gtid; k < k1; k += gsz) {
-            const peer_u4v x = peer_ld16(src, (k - k0) << 4, fences);
-            peer_adam4(Q, m, vv, k, make_float4(__uint_as_float(x.x), __uint_as_float(x.y), __uint_as_float(x.z), __uint_as_float(x.w)), h);
+    // the other ranks' slices, all at once: slice lengths padded to whole waves, so that a wave reads from ONE peer (the window base
+    // of a 16-byte access is wave-uniform) and every thread of the launch has a row of some slice
+    const int64_t per_w = (per + 63) & ~(int64_t)63, tot = (int64_t)(v.world - 1) * per_w;
+    for (int64_t t = gtid; t < tot; t += gsz) {
+        const int sl = __builtin_amdgcn_readfirstlane((int)(t / per_w));
+        const int p = (v.rank + 1 + sl) % v.world;
+        const int64_t off = t - (int64_t)sl * per_w, k = (int64_t)p * per + off;
+        if (off < per && k < n4) {
+            const PeerRow4 r = peer_row_load(Q, m, vv, k);
+            const peer_u4v x = peer_ld16(peer_seg(v, p, flag_s[p]), off << 4, fences);
+            peer_adam4(Q, m, vv, k, r, make_float4(__uint_as_float(x.x), __uint_as_float(x.y), __uint_as_float(x.z), __uint_as_float(x.w)), h);
         }
     }
 }
@@ -300,6 +310,15 @@ struct PeerXch : crec_xch {
         if (e)
             return crec_fail(ctx, CREC_EHIP, "peer transport: rank %d never published an exchange this rank waited for (gave up after %.0f s)",
                              e - 1, (double)timeout_ticks / 1e8);
+        return CREC_OK;
+    }
+    int status_deferred(crec_ctx *ctx, hipStream_t st) override
+    {
+        const int32_t e = *(volatile int32_t *)err_host; // what earlier checks have brought back
+        if (e)
+            return crec_fail(ctx, CREC_EHIP, "peer transport: rank %d never published an exchange this rank waited for (gave up after %.0f s)",
+                             e - 1, (double)timeout_ticks / 1e8);
+        CREC_HIP(ctx, hipMemcpyAsync(err_host, err, sizeof(int32_t), hipMemcpyDeviceToHost, st));
         return CREC_OK;
     }
     // the view of the next exchange; consumes its sequence number
@@ -393,11 +412,12 @@ struct PeerXch : crec_xch {
         crec_peer_view pv;
         begin(&pv);
         const bool two = adam_two_shot(n);
-        const int64_t work = two ? (int64_t)n * 4 * 2 : (int64_t)n * 4 * world;
-        int nb = (int)((work + 16383) / 16384);
-        nb = nb < 1 ? 1 : (nb > PEER_MAX_BLOCKS ? PEER_MAX_BLOCKS : nb);
-        hipLaunchKernelGGL(peer_allreduce_adam, dim3((unsigned)nb), dim3(PEER_THREADS), 0, st, pv, (int64_t)(n / 4), (float4 *)Q, (float4 *)m, (float4 *)v,
-                           h, two ? 1 : 0);
+        // a float4 of the table per thread; two shots: every workgroup waits for the peers' slices, which wait for ALL of this launch's
+        // workgroups -- so they must be resident together (PEER_MAX_BLOCKS); one shot: no workgroup waits for one of its own launch
+        int64_t nb = ((int64_t)n / 4 + PEER_THREADS - 1) / PEER_THREADS;
+        nb = nb < 1 ? 1 : (nb > (two ? PEER_MAX_BLOCKS : 1024) ? (two ? PEER_MAX_BLOCKS : 1024) : nb);
+        CREC_KLAUNCH(ctx, peer_allreduce_adam, dim3((unsigned)nb), dim3(PEER_THREADS), 0, st, pv, (int64_t)(n / 4), (float4 *)Q, (float4 *)m, (float4 *)v, h,
+                     two ? 1 : 0);
         CREC_HIP(ctx, hipGetLastError());
         return CREC_OK;
     }

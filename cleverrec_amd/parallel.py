@@ -88,6 +88,12 @@ class DpBprState(BprState):
                                                   s.ptr(j), n, int(batch_size), s.ptr(loss), s.stream_ptr()))
         return loss
 
+    def synchronize(self):
+        """Waits for the enqueued epochs and raises if an exchange gave up on a peer (crec_comm_status): train_epoch itself never
+        drains the stream, it reports such a time-out one chunk or one call late."""
+        s = self.sess
+        s.ctx.check(s.lib.crec_comm_status(s.ctx.h, s.stream_ptr()))
+
 
 def init_rccl(sess, rank=None, world=None):
     """crec_comm_init on this rank's ctx: rank 0 creates the RCCL unique id, torch.distributed ships it."""

@@ -90,7 +90,8 @@ int crec_ctx_set_option(crec_ctx *ctx, const char *name, int64_t value);
  * kernel_class: 0 bpr_index_batches, 1 bpr_step_fused, 2 bpr_triples_lazy, 3 (unused),
  *               4 bpr_reduce_loss, 5 eval_sweep, 6 eval_merge, 7 rank_metrics, 8 (unused), 9 bpr_adam_dense,
  *               10 rows_index_batches, 11 rows_apply, 12 small_adam_dense, 13 ncf_tile, 14 fm_instances, 15 cml_instances,
- *               16 ncf_pair_logits, 17 shard_plan_batches, 18 shard_serve_rows, 19 shard_owner_apply.
+ *               16 ncf_pair_logits, 17 shard_plan_batches, 18 shard_serve_rows, 19 shard_owner_apply,
+ *               20 peer_allreduce_adam.
  * enable(.., 1) also clears the accumulated totals. */
 int crec_profile_enable(crec_ctx *ctx, int on);
 int crec_profile_read(const crec_ctx *ctx, int kernel_class, double *total_ms, int64_t *launches);
@@ -445,7 +446,11 @@ int crec_bpr_train_epoch_sharded(crec_ctx *ctx, const crec_bpr_tables *t, int64_
  *   crec_comm_peer_connect  blobs = world x CREC_PEER_BLOB_BYTES in rank order; maps the peers.  World <= 16.
  *   crec_comm_peer_connect_local  the ranks are `world` ctxs of THIS process (tests: several ranks on one GPU; or one thread per GPU)
  *   crec_comm_set_timeout   how long a rank waits for a peer's flag before the communicator reports an error (default 20 s)
- *   crec_comm_status        synchronises the stream and reports such an error (the epochs call it once per chunk of batches)
+ *   crec_comm_status        synchronises the stream and reports such an error.  crec_bpr_train_epoch_sharded checks once per chunk
+ *                           of batches (it reads counts on the host there anyway); crec_bpr_train_epoch_dp never drains the
+ *                           stream: it sends the error word to the host behind each chunk and reports what earlier chunks or
+ *                           calls brought back -- call crec_comm_status after the last epoch (cleverrec_amd/parallel.py does, in
+ *                           DpBprState.synchronize)
  * crec_bpr_train_epoch_dp and crec_bpr_train_epoch_sharded then run over it unchanged.  Exchanges are collective and must be
  * enqueued on ONE stream per ctx.  crec_debug_alltoallv / crec_debug_allreduce: one exchange of the ctx's communicator (any
  * transport) on device buffers -- counts and displacements in 4-byte elements, host arrays of `world` entries (tests, tools/micro). */

@@ -90,7 +90,7 @@ def data_parallel(sess, rank, world, I=140):
     st = parallel.DpBprState(sess, P0[lo:hi], Q0, lr=1e-3, reg=0.01, rank=rank, world=world, transport=None)
     u, i, j = (sess.to_dev(x) for x in streams[rank])
     loss = st.train_epoch(u, i, j, B).cpu().numpy()
-    torch.cuda.synchronize()
+    st.synchronize()
     gathered = [None] * world
     dist.all_gather_object(gathered, (st.P.cpu().numpy(), st.Q.cpu().numpy(), st.mQ.cpu().numpy(), loss))
     if rank:
