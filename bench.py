@@ -150,6 +150,10 @@ def main():
     if world > 1 and want_transport in ("auto", "peer"):
         import subprocess
         env = dict(os.environ, MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29511")) + 1))
+        # started by torch.distributed.run, this rank is told to find its store at the launcher's agent (MASTER_PORT): the canaries
+        # form a group of their OWN on the next ports, whose rank 0 must host its store itself
+        for k in [k for k in env if k.startswith("TORCHELASTIC_") or k.startswith("TORCH_NCCL_ASYNC")]:
+            env.pop(k)
         for form in ("0", "1"):  # written-through system-scope accesses first, then the fence form (csrc/crec_peer.hip)
             try:
                 cp = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "micro", "peer_canary.py")], env=dict(env, CREC_PEER_FENCES=form, MASTER_PORT=str(int(env["MASTER_PORT"]) + int(form))),

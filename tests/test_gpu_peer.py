@@ -138,8 +138,11 @@ def test_ranks_as_threads_sharded_epoch():
         s.close()
 
 
-def test_bench_with_two_ranks_rehearsed_on_one_gpu():
-    """`python bench.py --gpus 2` as the driver starts it, rehearsed on ONE GPU (CREC_BENCH_ONE_GPU=1: every rank on cuda:0, the control
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_bench_with_two_ranks_rehearsed_on_one_gpu(launcher):
+    """`python bench.py --gpus 2` (bench.py starts its ranks) and the driver's own line, `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 ...` (whose workers are told to use the launcher's
+    store: the canaries' group must not inherit that), rehearsed on ONE GPU (CREC_BENCH_ONE_GPU=1: every rank on cuda:0, the control
     plane over gloo, the data over the peer windows): the launcher, the transport's canary, the replicated-Q headline epoch between two
     processes, the S-big row-sharded legs at 6 144 and at 65 536 triples per rank (the global-memory index builds at a world of two)
     and rank 0's JSON line -- the whole N > 1 flow of bench.py minus the links."""
@@ -147,8 +150,10 @@ def test_bench_with_two_ranks_rehearsed_on_one_gpu():
     env = dict(os.environ, CREC_BENCH_ONE_GPU="1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
-    cp = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--cpu-steps", "0"],
-                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=400)
+    args = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--cpu-steps", "0"]
+    if launcher == "torchrun":
+        args = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", env.pop("MASTER_PORT")] + args
+    cp = subprocess.run([sys.executable] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=400)
     assert cp.returncode == 0, cp.stderr[-2000:]
     lines = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, cp.stdout[-1000:]

@@ -43,6 +43,7 @@ def rank_main():
     sys.path.insert(0, ROOT)
     from cleverrec_amd import parallel, runtime
     rank, world, local = (int(os.environ[k]) for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"))
+    os.environ.pop("TORCHELASTIC_USE_AGENT_STORE", None)  # (a canary started from a torchrun worker: this group's rank 0 hosts the store)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     ok, res = True, {"world": world}
     try:
