@@ -1,0 +1,38 @@
+"""CML step alone (S-ml1m, d = 128, 20 negatives, batch 6144): microseconds per step and per kernel (ctx profile).
+Env: CREC_ROWS_FLAT=0 (the row update walks its slots chunk by chunk of the index)."""
+import json, os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+
+def main():
+    import numpy as np
+    import torch
+    from cleverrec_amd import runtime
+    from cleverrec_amd.data import synthetic
+    sess = runtime.Session(0)
+    data = synthetic("S-ml1m")
+    U, I, B = data.user_nums, data.item_nums, 6144
+    g = np.random.Generator(np.random.PCG64(0))
+    rnd = lambda *s: (g.standard_normal(s) * 0.05).astype(np.float32)
+    sess.ctx.seed(1)
+    u, i, neg = sess.ctx.sample_cml(data.train_csr, I, 20)
+    cml = runtime.CmlState(sess, rnd(U, 128), rnd(I, 128), lr=1e-3, reg=10.0, margin=1.0)
+    du, di, dn = sess.to_dev(u), sess.to_dev(i), sess.to_dev(neg)
+    fn = lambda: cml.train_epoch(du, di, dn, B)
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 3
+    steps = -(-len(u) // B)
+    sess.ctx.profile(True)
+    fn()
+    torch.cuda.synchronize()
+    prof = {k: round(ms / n * 1e3, 2) for k, (ms, n) in sess.ctx.profile_read().items() if n}
+    sess.ctx.profile(False)
+    print(json.dumps({"rows_flat": os.environ.get("CREC_ROWS_FLAT", "1"), "us_per_step": round(dt / steps * 1e6, 2), "kernels_us": prof}))
+
+
+main()
