@@ -1,5 +1,5 @@
 """CML step alone (S-ml1m, d = 128, 20 negatives, batch 6144): microseconds per step and per kernel (ctx profile).
-Env: CREC_ROWS_FLAT=0 (the row update walks its slots chunk by chunk of the index)."""
+Env: CML_USERS=n folds the user ids onto n table rows."""
 import json, os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
@@ -16,6 +16,9 @@ def main():
     rnd = lambda *s: (g.standard_normal(s) * 0.05).astype(np.float32)
     sess.ctx.seed(1)
     u, i, neg = sess.ctx.sample_cml(data.train_csr, I, 20)
+    if os.environ.get("CML_USERS"):  # fewer table rows (user ids folded): how the update launch's time depends on its number of row waves
+        U = int(os.environ["CML_USERS"])
+        u = (u % U).astype(u.dtype)
     cml = runtime.CmlState(sess, rnd(U, 128), rnd(I, 128), lr=1e-3, reg=10.0, margin=1.0)
     du, di, dn = sess.to_dev(u), sess.to_dev(i), sess.to_dev(neg)
     fn = lambda: cml.train_epoch(du, di, dn, B)
@@ -32,7 +35,7 @@ def main():
     torch.cuda.synchronize()
     prof = {k: round(ms / n * 1e3, 2) for k, (ms, n) in sess.ctx.profile_read().items() if n}
     sess.ctx.profile(False)
-    print(json.dumps({"rows_flat": os.environ.get("CREC_ROWS_FLAT", "1"), "us_per_step": round(dt / steps * 1e6, 2), "kernels_us": prof}))
+    print(json.dumps({"users": U, "us_per_step": round(dt / steps * 1e6, 2), "kernels_us": prof}))
 
 
 main()
