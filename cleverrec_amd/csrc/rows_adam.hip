@@ -612,6 +612,10 @@ int crec_small_adam_dense(crec_ctx *ctx, float *var, float *m, float *v, const f
 int crec_apply_all(crec_ctx *ctx, crec_apply_set &a, hipStream_t st)
 {
     CREC_REQUIRE(ctx, a.n_tables >= 0 && a.n_tables <= CREC_APPLY_MAX_TABLES, "apply set: too many tables");
+    // timing diagnosis only (tools/time_cml.py): CREC_APPLY_SKIP=k leaves table k of every update launch out
+    static const int skip = getenv("CREC_APPLY_SKIP") ? atoi(getenv("CREC_APPLY_SKIP")) : -1;
+    if (skip >= 0 && skip < a.n_tables)
+        a.tables[skip].t.rows = 0;
     int lpr = 0, blocks = 0;
     for (int k = 0; k < a.n_tables; ++k) {
         int l = 1;

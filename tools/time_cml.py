@@ -35,7 +35,15 @@ def main():
     torch.cuda.synchronize()
     prof = {k: round(ms / n * 1e3, 2) for k, (ms, n) in sess.ctx.profile_read().items() if n}
     sess.ctx.profile(False)
-    print(json.dumps({"users": U, "us_per_step": round(dt / steps * 1e6, 2), "kernels_us": prof}))
+    # how many slots the batch's heaviest item rows hold: positives + the chosen (nearest) negatives, from the tables as they are now
+    P, Q = cml.P.cpu().numpy(), cml.Q.cpu().numpy()
+    ub, ib, nb_ = u[:B].astype(np.int64), i[:B].astype(np.int64), neg[:B].astype(np.int64)
+    dist = ((P[ub][:, None, :] - Q[nb_]) ** 2).sum(-1)
+    kmin = nb_[np.arange(B), dist.argmin(1)]
+    cnt = np.bincount(np.concatenate([ib, kmin]), minlength=I)
+    heavy = {"max_slots_per_item_row": int(cnt.max()), "rows_over_12": int((cnt > 12).sum()), "rows_over_64": int((cnt > 64).sum()),
+             "max_chosen_negative": int(np.bincount(kmin, minlength=I).max())}
+    print(json.dumps({"item_rows": heavy, "users": U, "us_per_step": round(dt / steps * 1e6, 2), "kernels_us": prof}))
 
 
 main()
