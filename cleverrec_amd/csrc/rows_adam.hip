@@ -117,6 +117,34 @@ __device__ __forceinline__ bool untouched_stays(const crec_rows_opt &o)
     return o.kind == ROWS_SPARSE_LAZY || (o.kind == ROWS_SPARSE_TF1 && o.opt != 0);
 }
 
+#ifdef CREC_ROWS_STAMPS // debug build (tools/rows_stamps.sh): every wave of apply_all records when it began and ended and when its
+                        // loads arrived; [wave][8] = {begin, end, slots of the row, 0, marks 0..3}, 100 MHz clock
+__device__ unsigned long long rows_stamps[8 * 16384];
+extern "C" int crec_debug_rows_stamps(unsigned long long *out, size_t n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rows_stamps), n * sizeof(unsigned long long));
+}
+__device__ __forceinline__ void rows_mark(int slot, int dep, bool wait) // the time at which `dep` is available to the wave
+{
+    if (wait)
+        asm volatile("" ::"v"(dep));
+    const unsigned long long t = wall_clock64();
+    const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if ((threadIdx.x & 63) == 0 && w < 16384)
+        rows_stamps[8 * w + slot] = t;
+}
+#define ROWS_MARK(slot, dep) rows_mark(slot, dep, true)
+#define ROWS_NOTE(slot, val)                                                                  \
+    do {                                                                                      \
+        const int w_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);                   \
+        if ((threadIdx.x & 63) == 0 && w_ < 16384)                                            \
+            rows_stamps[8 * w_ + slot] = (unsigned long long)(val);                           \
+    } while (0)
+#else
+#define ROWS_MARK(slot, dep)
+#define ROWS_NOTE(slot, val)
+#endif
+
 // one wave per table row; group g of the wave takes slots g, g+G, ... of the row (fixed order),
 // the G partial sums are added in group order
 constexpr int SEGS = 2; // row segments (one per chunk of the index) in flight together
@@ -135,6 +163,7 @@ __device__ __forceinline__ void rows_apply_row(const crec_rows_table &t, const i
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     const int64_t ro = r * d + 4 * l;
     const int2 rs0 = rowseg[r];
+    ROWS_MARK(4, rs0.y); // the first segment has arrived
     if (chunks == 1 && rs0.y == 0 && untouched_stays(o))
         return;
     const float4 var = act ? ld4(t.var + ro) : zero;
@@ -171,8 +200,11 @@ __device__ __forceinline__ void rows_apply_row(const crec_rows_table &t, const i
         for (int c = 0; c < SEGS; ++c)
             walk(rsv[c]);
     }
+    ROWS_MARK(5, __float_as_int(acc.x) ^ touched); // every slot walked
+    ROWS_NOTE(2, touched);
     if (touched == 0 && untouched_stays(o))
         return;
+    ROWS_MARK(6, __float_as_int(var.x)); // the row itself has arrived (asked for before the walk)
 #pragma unroll
     for (int off = LPR; off < 64; off <<= 1) { // groups hold disjoint slots: add them, lower group first
         const float x = __shfl_down(acc.x, off, 64), y = __shfl_down(acc.y, off, 64);
@@ -224,6 +256,7 @@ __device__ __forceinline__ void rows_apply_row(const crec_rows_table &t, const i
     upd(acc.y, dg.y, var.y, m.y, v.y, nv.y);
     upd(acc.z, dg.z, var.z, m.z, v.z, nv.z);
     upd(acc.w, dg.w, var.w, m.w, v.w, nv.w);
+    ROWS_MARK(7, __float_as_int(nv.x) ^ __float_as_int(m.x)); // m, v arrived, the optimizer done
     st4_stream(t.var + ro, nv);
     st4_stream(t.m + ro, m);
     st4_stream(t.v + ro, v);
@@ -510,6 +543,16 @@ __device__ __forceinline__ void scalar_rows_block(const crec_scalar_job &j, int 
 template <int LPR> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void apply_all(crec_apply_set a)
 {
     __shared__ float red[SAD_SL * 16];
+#ifdef CREC_ROWS_STAMPS
+    rows_mark(0, 0, false);
+    struct End {
+        __device__ ~End()
+        {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            rows_mark(1, 0, false);
+        }
+    } end_;
+#endif
     // the small vector's blocks come FIRST: theirs is the longest chain of the launch (two rounds of strided partial
     // loads, a reduction, then the update), which then runs beside the table sweep instead of after it
     if ((int)blockIdx.x < a.small_blocks) {
