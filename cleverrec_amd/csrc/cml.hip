@@ -371,11 +371,12 @@ int crec_cml_train_epoch(crec_ctx *ctx, const crec_cml *m, crec_adam *opt, const
         crec_prof_end(ctx, st);
         if (int rc = crec_rows_index(ctx, slots, 2 * (int64_t)nbt, 2 * B, I, ixq_ws, &vq, st, q_chunks))
             return rc;
+        // (the item table first: its popular rows' waves are the launch's longest and must not begin in its second round of waves)
         crec_apply_set set{};
-        set.tables[set.n_tables++] = crec_rows_job{crec_rows_table{m->P.var, m->P.m, m->P.v, U, d}, vu.chunks,
-                                                   vu.rowseg + b * vu.chunks * vu.rows, vu.order + b * vu.per_batch, c_p, mu, rowP, o};
         set.tables[set.n_tables++] = crec_rows_job{crec_rows_table{m->Q.var, m->Q.m, m->Q.v, I, d}, vq.chunks, vq.rowseg, vq.order,
                                                    c_q, mu, rowQ, o};
+        set.tables[set.n_tables++] = crec_rows_job{crec_rows_table{m->P.var, m->P.m, m->P.v, U, d}, vu.chunks,
+                                                   vu.rowseg + b * vu.chunks * vu.rows, vu.order + b * vu.per_batch, c_p, mu, rowP, o};
         if (int rc = crec_apply_all(ctx, set, st))
             return rc;
         aux.prev_inst = li_b, aux.prev_n = nbt, aux.out = loss_per_batch + b;

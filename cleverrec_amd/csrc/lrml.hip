@@ -388,11 +388,11 @@ extern "C" int crec_lrml_train_epoch(crec_ctx *ctx, const crec_lrml *m, crec_ada
         // the batch's item slots are laid out [i | j] with stride nbt (not B), so a ragged batch has no holes
         if (int rc = crec_rows_index(ctx, slots, 2 * (int64_t)nbt, 2 * B, I, ixq_ws, &vq, st, q_chunks))
             return rc;
-        crec_apply_set set{};
-        set.tables[set.n_tables++] = crec_rows_job{crec_rows_table{m->P.var, m->P.m, m->P.v, U, d}, vu.chunks,
-                                                   vu.rowseg + b * vu.chunks * vu.rows, vu.order + b * vu.per_batch, c_p, nullptr, nullptr, o};
+        crec_apply_set set{}; // (the item table first: its popular rows' waves are the launch's longest)
         set.tables[set.n_tables++] = crec_rows_job{crec_rows_table{m->Q.var, m->Q.m, m->Q.v, I, d}, vq.chunks, vq.rowseg, vq.order, c_q,
                                                    nullptr, nullptr, o};
+        set.tables[set.n_tables++] = crec_rows_job{crec_rows_table{m->P.var, m->P.m, m->P.v, U, d}, vu.chunks,
+                                                   vu.rowseg + b * vu.chunks * vu.rows, vu.order + b * vu.per_batch, c_p, nullptr, nullptr, o};
         crec_rows_opt od = o; // K, M: dense variables, plain ApplyAdam on the summed tile partials
         od.kind = ROWS_DENSE;
         od.reg_occ = 0.f;

@@ -148,7 +148,7 @@ __device__ __forceinline__ void rows_mark(int slot, int dep, bool wait) // the t
 // one wave per table row; group g of the wave takes slots g, g+G, ... of the row (fixed order),
 // the G partial sums are added in group order
 constexpr int SEGS = 2; // row segments (one per chunk of the index) in flight together
-template <int LPR>
+template <int LPR, bool CHUNKED = false>
 __device__ __forceinline__ void rows_apply_row(const crec_rows_table &t, const int2 *__restrict__ rowseg,
                                                const int32_t *__restrict__ order, const float *__restrict__ contrib,
                                                const float *__restrict__ dense_grad, float *__restrict__ row_out,
@@ -163,6 +163,13 @@ __device__ __forceinline__ void rows_apply_row(const crec_rows_table &t, const i
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     const int64_t ro = r * d + 4 * l;
     const int2 rs0 = rowseg[r];
+    // CML's column means are the same 4 * d bytes for every row and only needed at the end -- where, left to the compiler, their
+    // load sinks to and becomes one more round trip of every wave's chain (stamps: 1.7-2.2 us between the row and the optimizer).
+    // Asked for beside the first segment and held.
+    float4 mu = zero;
+    if (o.cov_coef != 0.f && act)
+        mu = ld4(dense_grad + 4 * l);
+    asm volatile("" ::"v"(mu.x));
     ROWS_MARK(4, rs0.y); // the first segment has arrived
     if (chunks == 1 && rs0.y == 0 && untouched_stays(o))
         return;
@@ -176,7 +183,7 @@ __device__ __forceinline__ void rows_apply_row(const crec_rows_table &t, const i
     }
     float4 acc = zero;
     int touched = 0;
-    const auto walk = [&](int2 rs) __attribute__((always_inline)) {
+    const auto walk1 = [&](int2 rs) __attribute__((always_inline)) { // a per-epoch index (one chunk): most rows hold a slot or two
         touched += rs.y;
         for (int k = rs.x + g; k < rs.x + rs.y; k += G) {
             if (act) {
@@ -188,7 +195,38 @@ __device__ __forceinline__ void rows_apply_row(const crec_rows_table &t, const i
             }
         }
     };
-    walk(rs0);
+    // A per-step index (several chunks: the item tables of CML / LRML / SBPR, whose popular rows hold tens of slots): WALK slots of a
+    // group at a time, their ids, then their contribution rows, in flight together -- such a row's walk is the longest chain of
+    // the launch (stamps: 11.6 us for the item rows with more than 32 slots one slot at a time, 10.2 three at a time).
+    constexpr int WALK = 3;
+    const auto walk = [&](int2 rs) __attribute__((always_inline)) {
+        touched += rs.y;
+        const int end = rs.x + rs.y;
+        for (int k = rs.x + g; k < end; k += WALK * G) {
+            if (act) {
+                int sl[WALK];
+                float4 cc[WALK];
+#pragma unroll
+                for (int e = 0; e < WALK; ++e)
+                    sl[e] = k + e * G < end ? order[k + e * G] : 0;
+#pragma unroll
+                for (int e = 0; e < WALK; ++e)
+                    cc[e] = k + e * G < end ? ld4(contrib + (int64_t)sl[e] * d + 4 * l) : zero;
+#pragma unroll
+                for (int e = 0; e < WALK; ++e)
+                    if (k + e * G < end) {
+                        acc.x = acc.x + (cc[e].x + o.reg_occ * var.x);
+                        acc.y = acc.y + (cc[e].y + o.reg_occ * var.y);
+                        acc.z = acc.z + (cc[e].z + o.reg_occ * var.z);
+                        acc.w = acc.w + (cc[e].w + o.reg_occ * var.w);
+                    }
+            }
+        }
+    };
+    if (!CHUNKED || chunks == 1) // (CHUNKED: the launch was built for a set with a per-step index; the other launches do not carry the second walk)
+        walk1(rs0);
+    else
+        walk(rs0);
     // the other chunks, in ascending slot order; the segments of SEGS chunks are asked for together (one round trip, not one
     // per chunk: a row with its slots in nine chunks waited nine times before its last contribution)
     for (int c0 = 1; c0 < chunks; c0 += SEGS) {
@@ -197,8 +235,12 @@ __device__ __forceinline__ void rows_apply_row(const crec_rows_table &t, const i
         for (int c = 0; c < SEGS; ++c)
             rsv[c] = c0 + c < chunks ? rowseg[(int64_t)(c0 + c) * t.rows + r] : make_int2(0, 0);
 #pragma unroll
-        for (int c = 0; c < SEGS; ++c)
-            walk(rsv[c]);
+        for (int c = 0; c < SEGS; ++c) {
+            if (CHUNKED)
+                walk(rsv[c]);
+            else
+                walk1(rsv[c]);
+        }
     }
     ROWS_MARK(5, __float_as_int(acc.x) ^ touched); // every slot walked
     ROWS_NOTE(2, touched);
@@ -220,10 +262,8 @@ __device__ __forceinline__ void rows_apply_row(const crec_rows_table &t, const i
     float4 dg = zero;
     if (o.cov_coef != 0.f) {
         float4 xc = zero;
-        if (act) {
-            const float4 mu = ld4(dense_grad + 4 * l);
+        if (act)
             xc = make_float4(var.x - mu.x, var.y - mu.y, var.z - mu.z, var.w - mu.w);
-        }
         float sr = (xc.x + xc.y) + (xc.z + xc.w), sq = (xc.x * xc.x + xc.y * xc.y) + (xc.z * xc.z + xc.w * xc.w);
 #pragma unroll
         for (int off = LPR >> 1; off > 0; off >>= 1) {
@@ -540,7 +580,7 @@ __device__ __forceinline__ void scalar_rows_block(const crec_scalar_job &j, int 
 // [block_end[k-1], block_end[k]) sweep table k, four rows per block), then an optional one-column table (256 rows
 // per block); the small dense vector leads the grid
 // (16 elements per block; same slices, hence the same sums, as small_adam_dense)
-template <int LPR> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void apply_all(crec_apply_set a)
+template <int LPR, bool CHUNKED> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void apply_all(crec_apply_set a)
 {
     __shared__ float red[SAD_SL * 16];
 #ifdef CREC_ROWS_STAMPS
@@ -576,7 +616,7 @@ template <int LPR> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves
             rows_apply_side<LPR>(j.t, j.rowseg, j.order, j.contrib, j.dense_grad, j.row_out, j.o, wave * (64 / LPR),
                                  j.chunks > 1 ? j.chunks : 1);
         else
-            rows_apply_row<LPR>(j.t, j.rowseg, j.order, j.contrib, j.dense_grad, j.row_out, j.o, wave, j.chunks > 1 ? j.chunks : 1);
+            rows_apply_row<LPR, CHUNKED>(j.t, j.rowseg, j.order, j.contrib, j.dense_grad, j.row_out, j.o, wave, j.chunks > 1 ? j.chunks : 1);
     } else {
         scalar_rows_block(a.scalar, bi - first);
     }
@@ -660,7 +700,9 @@ int crec_apply_all(crec_ctx *ctx, crec_apply_set &a, hipStream_t st)
     if (skip >= 0 && skip < a.n_tables)
         a.tables[skip].t.rows = 0;
     int lpr = 0, blocks = 0;
+    bool chunked = false; // some table of the set comes with a per-step index in several chunks (rows_apply_row's second walk)
     for (int k = 0; k < a.n_tables; ++k) {
+        chunked = chunked || (a.tables[k].chunks > 1 && !a.tables[k].t2.var && a.tables[k].t.rows > 0);
         int l = 1;
         while (l * 4 < a.tables[k].t.d)
             l <<= 1;
@@ -684,7 +726,10 @@ int crec_apply_all(crec_ctx *ctx, crec_apply_set &a, hipStream_t st)
     crec_prof_begin(ctx, CREC_K_ROWS_APPLY, st);
 #define CREC_AA(L)                                                                  \
     case L:                                                                         \
-        CREC_KLAUNCH(ctx, (apply_all<L>), dim3((unsigned)blocks), dim3(256), 0, st, a); \
+        if (chunked)                                                                \
+            CREC_KLAUNCH(ctx, (apply_all<L, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);  \
+        else                                                                        \
+            CREC_KLAUNCH(ctx, (apply_all<L, false>), dim3((unsigned)blocks), dim3(256), 0, st, a); \
         break;
     switch (lpr) {
         CREC_AA(1)

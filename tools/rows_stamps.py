@@ -29,9 +29,11 @@ def main():
     rc = sess.lib.crec_debug_rows_stamps(raw.ctypes.data_as(C.c_void_p), C.c_size_t(n))
     assert rc == 0, rc
     st = raw.reshape(-1, 8).astype(np.int64)
-    t0 = st[:U + I, 0].min()
+    t0 = st[:U + I + 4, 0][st[:U + I + 4, 0] > 0].min()
     us = lambda x: (x - t0) / 100.0
-    for name, lo, hi in (("user table (6040 rows, per-epoch index, 1 chunk)", 0, U), ("item table (3706 rows, per-step index, 6 chunks)", U, U + I)):
+    # (the item table's blocks lead the grid, four rows per block: the user table's waves start at the next multiple of four)
+    i_end = -(-I // 4) * 4
+    for name, lo, hi in (("item table (3706 rows, per-step index, 6 chunks)", 0, I), ("user table (6040 rows, per-epoch index, 1 chunk)", i_end, i_end + U)):
         s = st[lo:hi]
         beg, end, slots = us(s[:, 0]), us(s[:, 1]), s[:, 2]
         dur = end - beg
