@@ -182,17 +182,46 @@ __global__ __launch_bounds__(256) void cml_instances(const float *__restrict__ P
     const bool ok = inst < n, act = 4 * l < d;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     const int uu = ok ? u[inst] : 0, ii = ok ? i[inst] : 0;
+    // (K <= LPR, the shipped shape: lane l of the group asks for the instance's l-th negative id here, beside the rows of u and i --
+    // one coalesced load instead of a round trip of id loads in front of every batch of negative rows)
+    const bool ids_up_front = K <= LPR;
+    const int my_nk = (ids_up_front && ok && l < K) ? neg[inst * K + l] : 0;
     const float4 p = (ok && act) ? ld4(P + (int64_t)uu * d + 4 * l) : zero;
     const float4 qi = (ok && act) ? ld4(Q + (int64_t)ii * d + 4 * l) : zero;
     const float d_ui = gsum<LPR>(sqdist4(p, qi));
     float dmin = INFINITY;
     int kmin = 0, imp = 0;
+    if (ids_up_front) {
+        // ten negatives' rows in flight per group (the launch is 3 072 waves at batch 6144: registers are not what it lacks)
+        constexpr int NF = 10;
+        for (int k0 = 0; k0 < K; k0 += NF) { // wave-uniform trip count
+            int nk[NF];
+            float4 qn[NF];
+#pragma unroll
+            for (int e = 0; e < NF; ++e)
+                nk[e] = __shfl(my_nk, g * LPR + ((k0 + e) < K ? (k0 + e) : 0), 64);
+#pragma unroll
+            for (int e = 0; e < NF; ++e)
+                qn[e] = (ok && act && k0 + e < K) ? ld4(Q + (int64_t)nk[e] * d + 4 * l) : zero;
+#pragma unroll
+            for (int e = 0; e < NF; ++e) {
+                if (k0 + e < K) { // wave-uniform
+                    const float dn = gsum<LPR>(sqdist4(p, qn[e]));
+                    if (dn < dmin) { // first minimum wins
+                        dmin = dn;
+                        kmin = nk[e];
+                    }
+                    imp += (d_ui + margin - dn) > 0.f;
+                }
+            }
+        }
+    }
     // four negatives' rows in flight per group: the loop is a chain of row fetches otherwise (K is 20 in the shipped conf)
 #ifndef CML_NB
 #define CML_NB 4
 #endif
     constexpr int NB = CML_NB;
-    for (int k0 = 0; k0 < K; k0 += NB) { // wave-uniform trip count
+    for (int k0 = 0; k0 < K && !ids_up_front; k0 += NB) { // wave-uniform trip count
         int nk[NB];
         float4 qn[NB];
 #pragma unroll
