@@ -27,6 +27,7 @@ for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_WAVE_CYCL
   rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$n -- python $ROOT/bench.py --steps 100 --warmup 10 --no-extras > /dev/null 2>&1 || echo "pmc $n failed"
 done
 # the HBM-resident form of the path (S-big) and the catalogue-scale eval: kernel-trace stats only
+if [ -z "$HEADLINE_ONLY" ]; then  # HEADLINE_ONLY=1: only the headline workload's kernel stats, counters and traffic.json
 for leg in "big tools/bench_big.py --steps 200" "bigbatch tools/bench_big.py --batch 65536 --steps 64" "big_sharded tools/bench_big.py --steps 200 --sharded" "bigbatch_sharded tools/bench_big.py --batch 65536 --steps 32 --sharded" "eval_big tools/bench_eval_big.py --dim 128" "models tools/bench_models.py"; do
   set -- $leg; name=$1; shift
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$name -- python $ROOT/$@ > $OUT/${name}_under_trace.json 2>/dev/null
@@ -50,11 +51,14 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $OUT/pmcmodels_$c -- python $ROOT/tools/bench_models.py > /dev/null 2>&1 || echo "pmc models $c failed"
 done
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmceval_MFMA -- python $ROOT/tools/bench_eval_big.py --dim 128 > /dev/null 2>&1 || echo "pmc eval failed"
+fi
 cd $ROOT && python tools/pmc_summary.py $OUT/pmc_* > $OUT/pmc_summary.txt
+if [ -z "$HEADLINE_ONLY" ]; then
 python tools/pmc_summary.py $OUT/pmcbig_[FW]* > $OUT/big_pmc_summary.txt
 python tools/pmc_summary.py $OUT/pmcbigbatch_* > $OUT/bigbatch_pmc_summary.txt
 python tools/pmc_summary.py $OUT/pmceval_* > $OUT/eval_big_pmc_summary.txt
 python tools/pmc_summary.py $OUT/pmcmodels_* > $OUT/models_pmc_summary.txt
+fi
 python tools/traffic_json.py $OUT/pmc_summary.txt bpr_step_fused > $OUT/traffic.json
 for f in kernel_stats.txt pmc_summary.txt big_kernel_stats.txt bigbatch_kernel_stats.txt bigbatch_pmc_summary.txt bigbatch_sharded_kernel_stats.txt big_sharded_kernel_stats.txt big_pmc_summary.txt eval_big_kernel_stats.txt eval_big_pmc_summary.txt models_kernel_stats.txt models_pmc_summary.txt traffic.json; do
   [ -f $OUT/$f ] && cp $OUT/$f $OUT/${R}_$f
