@@ -163,13 +163,6 @@ __device__ __forceinline__ void rows_apply_row(const crec_rows_table &t, const i
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     const int64_t ro = r * d + 4 * l;
     const int2 rs0 = rowseg[r];
-    // CML's column means are the same 4 * d bytes for every row and only needed at the end -- where, left to the compiler, their
-    // load sinks to and becomes one more round trip of every wave's chain (stamps: 1.7-2.2 us between the row and the optimizer).
-    // Asked for beside the first segment and held.
-    float4 mu = zero;
-    if (o.cov_coef != 0.f && act)
-        mu = ld4(dense_grad + 4 * l);
-    asm volatile("" ::"v"(mu.x));
     ROWS_MARK(4, rs0.y); // the first segment has arrived
     if (chunks == 1 && rs0.y == 0 && untouched_stays(o))
         return;
@@ -262,8 +255,10 @@ __device__ __forceinline__ void rows_apply_row(const crec_rows_table &t, const i
     float4 dg = zero;
     if (o.cov_coef != 0.f) {
         float4 xc = zero;
-        if (act)
+        if (act) {
+            const float4 mu = ld4(dense_grad + 4 * l);
             xc = make_float4(var.x - mu.x, var.y - mu.y, var.z - mu.z, var.w - mu.w);
+        }
         float sr = (xc.x + xc.y) + (xc.z + xc.w), sq = (xc.x * xc.x + xc.y * xc.y) + (xc.z * xc.z + xc.w * xc.w);
 #pragma unroll
         for (int off = LPR >> 1; off > 0; off >>= 1) {

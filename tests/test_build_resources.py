@@ -59,10 +59,14 @@ def test_row_apply_kernels_do_not_spill():
     """rows_apply / apply_all once kept an int2 and block_end[] in scratch (a ?: between two objects selects between
     addresses): 16 bytes per lane of private memory on every wave of the models' update launches."""
     res = _resources("rows_adam.hip", ("-ffp-contract=off",))
-    ks = [v for k, v in res.items() if "apply_all" in k or "rows_applyI" in k]
+    ks = {k: v for k, v in res.items() if "apply_all" in k or "rows_applyI" in k}
     assert ks
-    for v in ks:
-        assert v["ScratchSize"] == 0 and v["Occupancy"] >= 8, v
+    for k, v in ks.items():
+        # apply_all<LPR, true>: the instantiation for sets behind a per-step (chunked) index carries a second walk -- three slots of a
+        # group in flight -- and keeps 32 bytes per lane in scratch under the 64-register cap; measured WITH them it is the faster
+        # launch (CML's update 21.9 -> 16.2 us, DESIGN 9.5): they are bounded here, not forbidden
+        chunked = "apply_all" in k and "ELb1E" in k
+        assert v["ScratchSize"] <= (32 if chunked else 0) and v["Occupancy"] >= 8, (k, v)
 
 
 def test_tile_kernels_fit_their_workgroups():
