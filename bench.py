@@ -214,6 +214,11 @@ def main():
             transport = "peer"  # (one rank: rehearses the code path, like CREC_FORCE_DP)
         # (the window also carries the S-big leg's compact tables: 65536 triples per rank x 2 items x 512 B per half)
         st = DpBprState(sess, P0, Q0, lr=LR, reg=REG, transport=transport, window_bytes=288 << 20)
+        if transport == "peer":
+            # a rank's exchange kernel gives up on a peer after this long (then the run fails with the transport's error instead of
+            # hanging): the ranks of a bench are only loosely in step -- one may still be filling the S-big leg's tables (GBs of
+            # normal_()) when another already waits for it -- so well above the library's 20 s
+            sess.ctx.check(sess.lib.crec_comm_set_timeout(sess.ctx.h, 120.0))
     else:
         st = runtime.BprState(sess, P0, Q0, lr=LR, reg=REG, adam_mode="tf1")
 
