@@ -138,6 +138,7 @@ def run_sharded(users=10_000_000, items=1_000_000, dim=128, steps=200, warmup=30
     i = torch.searchsorted(cdf, torch.rand(n, generator=g, device=dev, dtype=torch.float64)).clamp_(max=items - 1).to(torch.int32)
     j = torch.randint(0, items, (n,), generator=g, device=dev, dtype=torch.int64).to(torch.int32)
     del cdf, w
+    barrier()  # (every rank has filled its tables and drawn its triples: nobody's exchange kernel waits through a peer's set-up)
     st.train_epoch(u, i, j, batch)  # same call shape as the timed one: every workspace reaches its final size
     barrier()
     st.stats = _lib.ShardStats()
