@@ -88,6 +88,7 @@ _SIGNATURES = {
     "crec_ctx_set_option": (C.c_int, [_vp, C.c_char_p, _i64]),
     "crec_profile_enable": (C.c_int, [_vp, C.c_int]),
     "crec_profile_read": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(_i64)]),
+    "crec_profile_read_units": (C.c_int, [_vp, C.c_int, C.POINTER(_i64)]),
     "crec_rng_seed": (C.c_int, [_vp, C.c_uint32]),
     "crec_rng_set_state": (C.c_int, [_vp, _vp, _i32]),
     "crec_rng_get_state": (C.c_int, [_vp, _vp, C.POINTER(_i32)]),
@@ -199,11 +200,11 @@ class Context:
             raise CrecError(rc, self.lib.crec_last_error(self.h).decode())
 
     def set_option(self, name, value):
-        """crec_ctx_set_option: tuning / test knobs ("ch", "wide", "wide_round", "eval_shape", "eval_no_bitmap", "ncf_generic", "no_zero_copy", "shard_unfused", "dsampler_general", "dsampler_budget")."""
+        """crec_ctx_set_option: tuning / test knobs ("ch", "wide", "wide_round", "eval_shape", "eval_no_bitmap", "ncf_generic", "no_zero_copy", "shard_unfused", "dsampler_general", "dsampler_budget", "flow", "flow_steps")."""
         self.check(self.lib.crec_ctx_set_option(self.h, name.encode(), int(value)))
 
     # ---- measurement ---------------------------------------------------------------------------
-    KERNELS = ("bpr_index_batches", "bpr_step_fused", "bpr_triples_lazy", "unused3", "bpr_reduce_loss", "eval_sweep",
+    KERNELS = ("bpr_index_batches", "bpr_step_fused", "bpr_triples_lazy", "bpr_steps_flow", "bpr_reduce_loss", "eval_sweep",
                "eval_merge", "rank_metrics", "unused8", "bpr_adam_dense", "rows_index_batches", "rows_apply", "small_adam_dense", "ncf_tile", "fm_instances", "cml_instances", "ncf_pair_logits",
                "shard_plan_batches", "shard_serve_rows", "shard_owner_apply", "peer_allreduce_adam")
 
@@ -218,6 +219,12 @@ class Context:
             self.check(self.lib.crec_profile_read(self.h, k, C.byref(ms), C.byref(n)))
             out[name] = (ms.value, n.value)
         return out
+
+    def profile_units(self, name):
+        """work units of the counted launches of `name` (bpr_steps_flow: steps; every other kernel: one per launch)"""
+        n = C.c_int64()
+        self.check(self.lib.crec_profile_read_units(self.h, self.KERNELS.index(name), C.byref(n)))
+        return n.value
 
     # ---- RNG ----------------------------------------------------------------------------------
     def seed(self, s):

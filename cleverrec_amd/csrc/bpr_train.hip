@@ -73,6 +73,9 @@ constexpr bool PIPELINED = CREC_PIPE;   // two trips in flight
 #ifndef CREC_ABL
 #define CREC_ABL 0
 #endif
+#ifndef CREC_FLOW_STAMP_STEP
+#define CREC_FLOW_STAMP_STEP 30
+#endif
 #ifdef CREC_STAMPS // debug build: every wave of bpr_step_fused records when it started and ended and when its loads
                    // arrived (tools/wave_stamps.sh); [wave][8] = {begin, end, shader clocks, xcd, marks 0..3}, 100 MHz clock
 __device__ unsigned long long crec_stamps[8 * 16384];
@@ -168,7 +171,24 @@ struct IndexWs {
     int32_t *host_counts, *done;
     int32_t *host_flag;
     int32_t seq, n_back;
+    // bpr_steps_flow: rows are sorted (and u_rowseg / q_rowseg indexed) by POSITION instead of by id -- row r of a side sits in
+    // workgroup r mod nwg, slot r div nwg, position (r mod nwg) * rpb + r div nwg (rpb rows per workgroup, a power of two) --
+    // so U / I above are the position counts nwg * rpb.  nwg == 0: positions are row ids (every other step)
+    int32_t flow_nwg_u, flow_nwg_q, flow_rpb;
+    uint32_t flow_magic_u, flow_magic_q; // floor(2^32 / nwg): the division by nwg as a multiplication + one fix-up
 };
+
+// row id -> position under the row dealing of bpr_steps_flow
+__device__ __forceinline__ uint32_t flow_pos_of(uint32_t row, uint32_t nwg, uint32_t magic, uint32_t rpb)
+{
+    uint32_t q = __umulhi(row, magic), rem = row - q * nwg;
+    if (rem >= nwg) {
+        ++q;
+        rem -= nwg;
+    }
+    return rem * rpb + q;
+}
+__device__ __forceinline__ uint32_t flow_row_of(uint32_t pos, uint32_t nwg, uint32_t rpb) { return (pos & (rpb - 1)) * nwg + pos / rpb; }
 
 constexpr int HN = 8; // per-batch counters the host reads back
 
@@ -190,10 +210,19 @@ inline int row_bits(int64_t n_rows)
 inline int lazy_spw(int d) { return d <= 4 ? 64 : (d > 128 ? 16 : (d > 64 && CREC_LAZY_SPW > 32 ? 32 : CREC_LAZY_SPW)); }
 
 IndexWs layout_index(void *base, int64_t nbc, int64_t B, int64_t U, int64_t I, bool dense, int CH, int wide_rows = 0,
-                     int wide_total = 0, int spw = 32)
+                     int wide_total = 0, int spw = 32, int flow_rpb = 0)
 {
     IndexWs w{};
     w.B = B;
+    if (dense && flow_rpb > 0) { // positions instead of row ids (IndexWs::flow_*)
+        w.flow_rpb = flow_rpb;
+        w.flow_nwg_u = (int32_t)((U + flow_rpb - 1) / flow_rpb);
+        w.flow_nwg_q = (int32_t)((I + flow_rpb - 1) / flow_rpb);
+        w.flow_magic_u = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)w.flow_nwg_u > 0xffffffffull ? 0xffffffffull : ((uint64_t)1 << 32) / (uint64_t)w.flow_nwg_u);
+        w.flow_magic_q = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)w.flow_nwg_q > 0xffffffffull ? 0xffffffffull : ((uint64_t)1 << 32) / (uint64_t)w.flow_nwg_q);
+        U = (int64_t)w.flow_nwg_u * flow_rpb;
+        I = (int64_t)w.flow_nwg_q * flow_rpb;
+    }
     w.U = dense ? U : 0;
     w.I = dense ? I : 0;
     w.CH = CH;
@@ -278,8 +307,11 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
     const int n = side ? 2 * nb : nb;
     const int CH = w.CH;
 
+    const uint32_t fl_nwg = (uint32_t)(side ? w.flow_nwg_q : w.flow_nwg_u), fl_magic = side ? w.flow_magic_q : w.flow_magic_u,
+                   fl_rpb = (uint32_t)w.flow_rpb;
     for (int k = tid; k < n; k += PREP_THREADS) {
-        rows[k] = (uint32_t)(side == 0 ? u[t0 + k] : (k < nb ? i[t0 + k] : j[t0 + k - nb]));
+        const uint32_t r = (uint32_t)(side == 0 ? u[t0 + k] : (k < nb ? i[t0 + k] : j[t0 + k - nb]));
+        rows[k] = fl_nwg ? flow_pos_of(r, fl_nwg, fl_magic, fl_rpb) : r;
         tag[k] = (uint16_t)k;
     }
 #ifdef CREC_STAMPS // phase times of workgroups 0 (user side) and 1 (item side) of the launch: crec_stamps[16000*8 + ...]
@@ -542,7 +574,7 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
 #pragma unroll
         for (int e = 0; e < RIF; ++e) { // the sorted row is one of the three ids: two scattered loads per record, not three
             const int k = k0r + e * PREP_THREADS;
-            const int row = k < n ? (int)rows[k] : 0;
+            const int row = k < n ? (int)(fl_nwg ? flow_row_of(rows[k], fl_nwg, fl_rpb) : rows[k]) : 0;
             if (side == 0)
                 rec[e] = make_int4(row, i[t0 + pos[e]], j[t0 + pos[e]], (int)payload[e]);
             else if ((int)payload[e] < 0)
@@ -991,9 +1023,21 @@ template <int R> struct WaveCtx {
     bool act;
     int e[R]; // wave-uniform segment ends of the slots
     float reg;
+    // bpr_steps_flow: the gathered rows are versions other waves of this launch publish (served where the XCDs meet, validated
+    // against the sentinel); `err`: the launch's give-up flag
+    bool hist = false;
+    int32_t *err = nullptr;
 };
 
-template <int LPR, int RW, int MODE>
+// one gathered float4 of the row `row` of `base`: a plain load, or (FLOW, a published version) an agent-scope one
+template <bool FLOW> __device__ __forceinline__ float4 ld4_row(const float *base, int64_t off, bool hist)
+{
+    if (FLOW && hist)
+        return ld4_sc1(base, off);
+    return ld4(base + off);
+}
+
+template <int LPR, int RW, int MODE, bool FLOW = false>
 __device__ __forceinline__ void trip_issue(Trip &tr, const WaveCtx<Geo<LPR, RW>::R> &w, const int4 &mine, int c0, int nc,
                                            int n_sub, int t0)
 {
@@ -1011,18 +1055,19 @@ __device__ __forceinline__ void trip_issue(Trip &tr, const WaveCtx<Geo<LPR, RW>:
             s += k >= w.e[q];
         tr.slot[t] = s;
         tr.a[t] = tr.b[t] = zero;
-        // FULL: a dead slot's record is all zeros -> row 0, a harmless load, so no exec-mask branch is needed
-        if (Geo<LPR, RW>::FULL || (tr.has[t] && w.act)) {
+        // FULL: a dead slot's record is all zeros -> row 0, a harmless load, so no exec-mask branch is needed.  (FLOW: row 0's
+        // version may still hold the sentinel, a NaN, and 0 * NaN would poison the slot sums: dead slots load nothing)
+        if ((Geo<LPR, RW>::FULL && !FLOW) || (tr.has[t] && w.act)) {
             if (CREC_ABL & 1) {
                 tr.a[t] = ld4(w.Q + (int64_t)(tr.rec[t].y & 3) * w.d + 4 * w.l);
                 tr.b[t] = ld4(w.Q + (int64_t)(tr.rec[t].z & 3) * w.d + 4 * w.l);
             } else if (MODE == 0) {
-                tr.a[t] = ld4(w.Q + (int64_t)tr.rec[t].y * w.d + 4 * w.l);
-                tr.b[t] = ld4(w.Q + (int64_t)tr.rec[t].z * w.d + 4 * w.l);
+                tr.a[t] = ld4_row<FLOW>(w.Q, (int64_t)tr.rec[t].y * w.d + 4 * w.l, w.hist);
+                tr.b[t] = ld4_row<FLOW>(w.Q, (int64_t)tr.rec[t].z * w.d + 4 * w.l, w.hist);
             } else if (MODE == 1) {
-                tr.a[t] = ld4(w.P + (int64_t)tr.rec[t].x * w.d + 4 * w.l);
+                tr.a[t] = ld4_row<FLOW>(w.P, (int64_t)tr.rec[t].x * w.d + 4 * w.l, w.hist);
                 const int other = tr.rec[t].w < 0 ? tr.rec[t].y : tr.rec[t].z;
-                tr.b[t] = ld4(w.Q + (int64_t)other * w.d + 4 * w.l);
+                tr.b[t] = ld4_row<FLOW>(w.Q, (int64_t)other * w.d + 4 * w.l, w.hist);
             } else {
                 tr.a[t] = ld4(w.contrib + (int64_t)(tr.rec[t].w & 0x7fffffff) * w.d + 4 * w.l);
             }
@@ -1082,10 +1127,65 @@ __device__ __forceinline__ void trip_consume(const Trip &tr, const WaveCtx<Geo<L
     }
 }
 
+// bpr_steps_flow: a row version that has not been published yet reads as the sentinel (every 4-byte word of it, so nothing
+// rests on how wide a store lands at once); a published word is never the sentinel (flow_publish)
+constexpr uint32_t FLOW_SENT = 0xffffffffu;
+constexpr unsigned FLOW_SPIN_CHECK = 1u << 12, FLOW_SPIN_LIMIT = 1u << 23; // polls between looks at the give-up flag; polls (each at
+                                                                           // least a memory round trip) before a wave gives up itself
+__device__ __forceinline__ bool flow_unset(float4 v)
+{
+    // (all four words: nothing rests on how wide a store lands at once; integer logic, no short-circuit branches)
+    return ((int)(__float_as_uint(v.x) == FLOW_SENT) | (int)(__float_as_uint(v.y) == FLOW_SENT) | (int)(__float_as_uint(v.z) == FLOW_SENT) |
+            (int)(__float_as_uint(v.w) == FLOW_SENT)) != 0;
+}
+// the trip's gathered rows are there: lanes that read the sentinel ask again until their rows' owners have published.  Every
+// wave leaves this loop: when the rows arrive, when another wave has raised the give-up flag, or after FLOW_SPIN_LIMIT polls
+template <int LPR, int RW, int MODE>
+__device__ __forceinline__ void flow_validate(Trip &tr, const WaveCtx<Geo<LPR, RW>::R> &w)
+{
+    if (!w.hist || !w.err) // (no flag: the timing ablation that does not wait)
+        return;
+    unsigned spins = 0;
+    for (;;) {
+        bool bad[UNR], any = false;
+#pragma unroll
+        for (int t = 0; t < UNR; ++t) {
+            bad[t] = tr.has[t] && w.act && (flow_unset(tr.a[t]) || flow_unset(tr.b[t]));
+            any |= bad[t];
+        }
+        if (__ballot(any) == 0)
+            return;
+        __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+        for (int t = 0; t < UNR; ++t) {
+            if (bad[t]) {
+                if (MODE == 0) {
+                    tr.a[t] = ld4_sc1(w.Q, (int64_t)tr.rec[t].y * w.d + 4 * w.l);
+                    tr.b[t] = ld4_sc1(w.Q, (int64_t)tr.rec[t].z * w.d + 4 * w.l);
+                } else {
+                    tr.a[t] = ld4_sc1(w.P, (int64_t)tr.rec[t].x * w.d + 4 * w.l);
+                    const int other = tr.rec[t].w < 0 ? tr.rec[t].y : tr.rec[t].z;
+                    tr.b[t] = ld4_sc1(w.Q, (int64_t)other * w.d + 4 * w.l);
+                }
+            }
+        }
+        if ((++spins & (FLOW_SPIN_CHECK - 1)) == 0) {
+            const bool stop = spins >= FLOW_SPIN_LIMIT || __hip_atomic_load(w.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+            if (stop) {
+                if ((threadIdx.x & 63) == 0)
+                    __hip_atomic_store(w.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+        }
+    }
+}
+
 // walk the occurrence records [k_begin, k_end) of this wave
-template <int LPR, int RW, int MODE, bool STORE_CONTRIB>
+// (FLOW: `pre` holds the records [pf, pf + 64) of `occ`, asked for a step ahead; a chunk inside that window is taken from there)
+template <int LPR, int RW, int MODE, bool STORE_CONTRIB, bool FLOW = false>
 __device__ __forceinline__ void walk_range(const WaveCtx<Geo<LPR, RW>::R> &w, float4 var, AccArr<LPR, RW> &acc,
-                                           const int4 *__restrict__ occ, int k_begin, int k_end)
+                                           const int4 *__restrict__ occ, int k_begin, int k_end, int4 pre = make_int4(0, 0, 0, 0),
+                                           int pf = 0x7fffffff)
 {
     constexpr int G = Geo<LPR, RW>::G;
     const int lane = threadIdx.x & 63;
@@ -1093,7 +1193,11 @@ __device__ __forceinline__ void walk_range(const WaveCtx<Geo<LPR, RW>::R> &w, fl
         k_end = k_begin + 16;
     for (int c0 = k_begin; c0 < k_end; c0 += 64) {
         const int nc = (k_end - c0) < 64 ? (k_end - c0) : 64;
-        const int4 mine = lane < nc ? occ[c0 + lane] : make_int4(0, 0, 0, 0);
+        int4 mine;
+        if (FLOW && c0 >= pf && c0 - pf + nc <= 64)
+            mine = shfl4(pre, (lane + (c0 - pf)) & 63);
+        else
+            mine = lane < nc ? occ[c0 + lane] : make_int4(0, 0, 0, 0);
 #ifndef CREC_STAMP_VAR
         if (c0 == k_begin)
             crec_mark(1, mine.x); // the first chunk of records has arrived
@@ -1101,32 +1205,38 @@ __device__ __forceinline__ void walk_range(const WaveCtx<Geo<LPR, RW>::R> &w, fl
         const int n_sub = (nc + G - 1) / G;
         if (PIPELINED) {
             Trip ta, tb;
-            trip_issue<LPR, RW, MODE>(ta, w, mine, c0, nc, n_sub, 0);
+            trip_issue<LPR, RW, MODE, FLOW>(ta, w, mine, c0, nc, n_sub, 0);
             for (int t0 = 0; t0 < n_sub; t0 += 2 * UNR) {
                 if (t0 + UNR < n_sub)
-                    trip_issue<LPR, RW, MODE>(tb, w, mine, c0, nc, n_sub, t0 + UNR);
+                    trip_issue<LPR, RW, MODE, FLOW>(tb, w, mine, c0, nc, n_sub, t0 + UNR);
+                if (FLOW)
+                    flow_validate<LPR, RW, MODE>(ta, w);
                 trip_consume<LPR, RW, MODE, STORE_CONTRIB>(ta, w, var, acc);
                 if (t0 + UNR >= n_sub)
                     break;
                 if (t0 + 2 * UNR < n_sub)
-                    trip_issue<LPR, RW, MODE>(ta, w, mine, c0, nc, n_sub, t0 + 2 * UNR);
+                    trip_issue<LPR, RW, MODE, FLOW>(ta, w, mine, c0, nc, n_sub, t0 + 2 * UNR);
+                if (FLOW)
+                    flow_validate<LPR, RW, MODE>(tb, w);
                 trip_consume<LPR, RW, MODE, STORE_CONTRIB>(tb, w, var, acc);
             }
         } else {
             for (int t0 = 0; t0 < n_sub; t0 += UNR) {
                 Trip ta;
-                trip_issue<LPR, RW, MODE>(ta, w, mine, c0, nc, n_sub, t0);
+                trip_issue<LPR, RW, MODE, FLOW>(ta, w, mine, c0, nc, n_sub, t0);
+                if (FLOW)
+                    flow_validate<LPR, RW, MODE>(ta, w);
                 trip_consume<LPR, RW, MODE, STORE_CONTRIB>(ta, w, var, acc);
             }
         }
     }
 }
 
-template <int LPR, int RW, int MODE, bool STORE_CONTRIB>
+template <int LPR, int RW, int MODE, bool STORE_CONTRIB, bool FLOW = false>
 __device__ __forceinline__ float4 slots_grad(float4 var, const Slot &sl, int n_valid, const float *__restrict__ P,
                                     const float *__restrict__ Q, int d, const int4 *__restrict__ occ,
                                     float *__restrict__ contrib, float *__restrict__ xb, const Hyper &h, int part = 0,
-                                    int nparts = 1)
+                                    int nparts = 1, bool hist = false, int32_t *err = nullptr)
 {
     constexpr int R = Geo<LPR, RW>::R;
     const int lane = threadIdx.x & 63;
@@ -1140,6 +1250,8 @@ __device__ __forceinline__ float4 slots_grad(float4 var, const Slot &sl, int n_v
     w.l = lane % LPR;
     w.act = Geo<LPR, RW>::FULL ? true : 4 * w.l < d;
     w.reg = h.reg;
+    w.hist = hist;
+    w.err = err;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     int st[R], cn[R]; // wave-uniform copies of the slots' segments
 #pragma unroll
@@ -1178,7 +1290,7 @@ __device__ __forceinline__ float4 slots_grad(float4 var, const Slot &sl, int n_v
     }
     if (!any_heavy) { // the usual case: the slots' segments are one contiguous range
         if (last > first)
-            walk_range<LPR, RW, MODE, STORE_CONTRIB>(w, var, acc, occ, first, last);
+            walk_range<LPR, RW, MODE, STORE_CONTRIB, FLOW>(w, var, acc, occ, first, last);
     } else { // a heavy slot sits in the middle: walk the other slots one by one
 #pragma unroll 1
         for (int s = 0; s < n_valid; ++s) {
@@ -1189,7 +1301,7 @@ __device__ __forceinline__ float4 slots_grad(float4 var, const Slot &sl, int n_v
                 c = s == q ? cn[q] : c;
             }
             if (c > 0)
-                walk_range<LPR, RW, MODE, STORE_CONTRIB>(w, var, acc, occ, b, b + c);
+                walk_range<LPR, RW, MODE, STORE_CONTRIB, FLOW>(w, var, acc, occ, b, b + c);
         }
     }
     return reduce_to_owner<LPR, RW>(acc);
@@ -1572,6 +1684,255 @@ __global__ __launch_bounds__(CREC_FUSED_BLOCK) void bpr_step_fused(Tables src, T
 #ifdef CREC_STAMPS
     stamp_end(0);
 #endif
+}
+
+// ------------------------------------------------------------------------------------
+// tf1 mode, ALL steps of a chunk in one launch: bpr_steps_flow (round 4).
+//
+// bpr_step_fused is bound by what surrounds its waves -- a dispatch per step, every row read from and written to memory per
+// step, three dependent round trips per row wave -- not by bytes.  Here a lane group OWNS a table row for up to
+// FLOW_MAX_STEPS consecutive steps and keeps the row and its Adam slots in registers; what the other waves need of it, the row's
+// values after step k, it publishes once per step into a version history (hist[k][row], written through to where the XCDs
+// meet), and its own gathers of step k + 1 read that version of the rows they need.  There is no barrier and no flag: an
+// unpublished slot holds a sentinel in every word, a gather that reads the sentinel asks again (flow_validate), so the steps of
+// different rows overlap as far as the batches' own dependences allow -- a dataflow execution of exactly the sequential
+// arithmetic (the same walk, the same sums in the same order as a launch per step with this row-to-wave assignment).
+//   * rows are dealt to workgroups round-robin (row r: workgroup r mod NWG, slot r div NWG), so that neighbouring popular
+//     rows do not share a wave; the index kernel sorts by that position (IndexWs::flow_*), which keeps a wave's records
+//     contiguous exactly as in bpr_step_fused
+//   * every wave of the launch must be resident (the host checks the occupancy before it takes this path); a wave waits only
+//     for rows whose owners are resident and never wait for IT within the same step, and every wait gives up after
+//     FLOW_SPIN_LIMIT polls or when another wave has given up (FlowArgs::err, reported by the host as an error)
+//   * two histories alternate between launches: a launch fills one and puts the sentinel back into the slots the launch
+//     before it filled in the other (each owner its own rows, one slot per step), so no memset sits between launches
+// ------------------------------------------------------------------------------------
+constexpr int FLOW_MAX_STEPS = 64;
+struct FlowArgs {
+    const int2 *u_rowseg, *q_rowseg; // [C][Upos], [C][Ipos]: {segment start, length} by POSITION (workgroup * rows per workgroup + slot)
+    const int4 *u_occ, *q_occ;       // [C][B], [C][2B]
+    int64_t Upos, Ipos, B;
+    int nwg_u, nwg_q;                // workgroups per side = the modulus of the row dealing
+    int C;                           // steps of this launch
+    float *histP, *histQ;            // [C - 1][U * d], [C - 1][I * d]: the versions after steps 1 .. C - 1, all sentinel on entry
+    float *nextP, *nextQ;            // the other history: slots [0, dirty_next) get the sentinel back
+    int dirty_next;
+    int64_t hP, hQ;                  // floats per version
+    float *loss_ws;                  // per step: x_b [B], then the row terms [U + I] (by row id)
+    int64_t loss_stride;
+    int32_t *err;
+    int abl; // timing ablations (option flow_abl; WRONG results): 1 gathers do not wait for their versions, 2 gathers read the tables
+             // (plain loads) instead of the versions, 4 nothing is published or reset
+    float lr_t[FLOW_MAX_STEPS];
+};
+
+__device__ __forceinline__ float4 flow_publishable(float4 v) // a NaN that happens to carry the sentinel's bits becomes the canonical one
+{
+    const auto fix = [](float x) { return __float_as_uint(x) == FLOW_SENT ? __uint_as_float(0x7fc00000u) : x; };
+    return make_float4(fix(v.x), fix(v.y), fix(v.z), fix(v.w));
+}
+
+#ifndef CREC_FLOW_WAVES
+#define CREC_FLOW_WAVES 3 // waves per SIMD bpr_steps_flow is compiled for: all of its waves must be resident at once
+#endif
+#ifndef CREC_FLOW_HEAVY
+#define CREC_FLOW_HEAVY 8 // a slot with more occurrences in the batch is walked by the whole workgroup
+#endif
+// One wave of bpr_steps_flow.  Slot q of the workgroup (q = wave * R + lane group) holds row q * nwg + j.  Per step:
+//   * the segments of ALL the workgroup's slots sit in lanes 0 .. RPB - 1 (asked for two steps ahead), the wave's first 64
+//     records in `pre` (asked for a step ahead): the step's only dependent round trip is the gathers themselves
+//   * light slots: the wave walks its own slots' records as bpr_step_fused does (runs of consecutive light slots)
+//   * heavy slots (more than CREC_FLOW_HEAVY occurrences): the owner puts the row into LDS, all waves of the workgroup walk a
+//     quarter of the slot's records each (slots_grad with R = 1: the same split as wide_group), the four partials meet in LDS
+//     and the owner adds them in wave order -- a fixed order given the slot's count.  Two barriers, and only in steps where the
+//     workgroup has a heavy slot (the same decision in every wave: it is a function of the segments)
+template <int LPR, int MODE, bool FULL>
+__device__ __forceinline__ void flow_wave(const Tables &src, const Tables &dst, int d, int64_t U, int64_t n_rows, int j, int nwg,
+                                          const int2 *__restrict__ rowseg, int64_t pos_stride, const int4 *__restrict__ occ,
+                                          int64_t occ_stride, float *hist_own, float *next_own, int64_t h_own, const FlowArgs &f,
+                                          const Hyper &h, float4 *__restrict__ lds)
+{
+    constexpr int RW = ROWS_PER_WAVE | (FULL ? 0x100 : 0), RW1 = 1 | (FULL ? 0x100 : 0), R = Geo<LPR, RW>::R;
+    constexpr int WPB = CREC_FUSED_BLOCK / 64, RPB = R * WPB;
+    constexpr bool user = MODE == 0;
+    const int lane = threadIdx.x & 63, g = lane / LPR, l = lane % LPR;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    float4 *hvar = lds, *hpart = lds + RPB * LPR; // [RPB][LPR], [RPB][WPB][LPR]
+    // the wave's rows ascend with g, so the valid ones are a prefix (a wave without rows still helps with heavy slots)
+    int n_valid = 0;
+#pragma unroll
+    for (int q = 0; q < R; ++q)
+        n_valid += ((int64_t)(wv * R + q) * nwg + j < n_rows) ? 1 : 0;
+    const int gs = g < n_valid ? g : 0;
+    const int64_t row = (int64_t)(wv * R + gs) * nwg + j;
+    const bool act = FULL || 4 * l < d;
+    const bool owner = g < R && g < n_valid && act;
+    const int64_t ro = row * d + 4 * l;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 var = zero, m = zero, v = zero;
+    if (owner) {
+        var = ld4((user ? src.P : src.Q) + ro);
+        m = ld4s((user ? src.mP : src.mQ) + ro);
+        v = ld4s((user ? src.vP : src.vQ) + ro);
+    }
+    const int q_reset = (f.dirty_next + f.C - 1) / f.C; // slots of the other history this wave resets per step
+    const crec_f4v sent = {__uint_as_float(FLOW_SENT), __uint_as_float(FLOW_SENT), __uint_as_float(FLOW_SENT), __uint_as_float(FLOW_SENT)};
+    const int2 *seg_at = rowseg + (int64_t)j * RPB + (lane < RPB ? lane : RPB - 1);
+    const int last_own = wv * R + (n_valid > 0 ? n_valid - 1 : 0);
+    const auto own_range = [&](int2 seg, int &first, int &last) { // the records of the wave's own slots
+        first = __builtin_amdgcn_readlane(seg.x, wv * R);
+        last = n_valid > 0 ? __builtin_amdgcn_readlane(seg.x, last_own) + __builtin_amdgcn_readlane(seg.y, last_own) : first;
+    };
+    int2 seg_cur = seg_at[0], seg_nxt = f.C > 1 ? seg_at[pos_stride] : make_int2(0, 0);
+    int pf_cur, pl_cur;
+    own_range(seg_cur, pf_cur, pl_cur);
+    int4 pre_cur = lane < pl_cur - pf_cur ? occ[pf_cur + lane] : make_int4(0, 0, 0, 0);
+#ifdef CREC_STAMPS // tools/flow_stamps.py: phase times of every wave in one step of the launch ([wave][8], 100 MHz clock)
+    const int stamp_wave = blockIdx.x * WPB + wv;
+#define CREC_FLOW_MARK(slot, dep)                                                                                     \
+    do {                                                                                                              \
+        asm volatile("" ::"v"(dep));                                                                                  \
+        if (k == CREC_FLOW_STAMP_STEP && lane == 0 && stamp_wave < 16000)                                             \
+            crec_stamps[8 * stamp_wave + (slot)] = wall_clock64();                                                    \
+    } while (0)
+#else
+#define CREC_FLOW_MARK(slot, dep)
+#endif
+    for (int k = 0; k < f.C; ++k) {
+        const int4 *occ_k = occ + (int64_t)k * occ_stride;
+        CREC_FLOW_MARK(0, 0);
+        // nothing below depends on another wave: the segments of step k + 2 and the records of step k + 1
+        int2 seg_nn = make_int2(0, 0);
+        if (k + 2 < f.C)
+            seg_nn = seg_at[(int64_t)(k + 2) * pos_stride];
+        int pf_nxt = 0, pl_nxt = 0;
+        int4 pre_nxt = make_int4(0, 0, 0, 0);
+        if (k + 1 < f.C) {
+            own_range(seg_nxt, pf_nxt, pl_nxt);
+            if (lane < pl_nxt - pf_nxt)
+                pre_nxt = occ_k[occ_stride + pf_nxt + lane];
+        }
+        const bool hist = k > 0 && !(f.abl & 2);
+        const float *Pk = hist ? f.histP + (int64_t)(k - 1) * f.hP : src.P;
+        const float *Qk = hist ? f.histQ + (int64_t)(k - 1) * f.hQ : src.Q;
+        float *xb = f.loss_ws + (int64_t)k * f.loss_stride;
+        int32_t *err = (f.abl & 1) ? nullptr : f.err;
+        Hyper hk = h;
+        hk.lr_t = f.lr_t[k];
+        // heavy slots of the workgroup (bit q: slot q)
+        const uint64_t hmask = (f.abl & 8) ? 0ull : __ballot(lane < RPB && seg_cur.y > CREC_FLOW_HEAVY);
+        const int cnt_own = g < n_valid ? __shfl(seg_cur.y, wv * R + gs, 64) : 0;
+        const bool heavy_own = ((hmask >> (wv * R + gs)) & 1ull) != 0;
+        // ---- light slots: the wave's own walk
+        WaveCtx<R> w;
+        w.P = Pk, w.Q = Qk, w.contrib = nullptr, w.xb = xb, w.d = d, w.g = g, w.l = l, w.act = act, w.reg = hk.reg, w.hist = hist, w.err = err;
+        AccArr<LPR, RW> acc;
+        // runs of consecutive light slots (their records are contiguous): at most (R + 1) / 2 of them
+        constexpr int NRUN = (R + 1) / 2;
+        int run_b[NRUN], run_e[NRUN], n_run = 0;
+#pragma unroll
+        for (int r_ = 0; r_ < NRUN; ++r_)
+            run_b[r_] = run_e[r_] = 0;
+        {
+            int rb = -1, re = 0;
+#pragma unroll
+            for (int s_ = 0; s_ < R; ++s_) {
+                acc[s_] = zero;
+                const int st_s = __builtin_amdgcn_readlane(seg_cur.x, wv * R + s_);
+                const int cn_s = s_ < n_valid ? __builtin_amdgcn_readlane(seg_cur.y, wv * R + s_) : 0;
+                w.e[s_] = s_ < n_valid ? st_s + cn_s : 0x7fffffff;
+                const bool light = s_ < n_valid && ((hmask >> (wv * R + s_)) & 1ull) == 0;
+                if (light) {
+                    rb = rb < 0 ? st_s : rb;
+                    re = st_s + cn_s;
+                }
+                if ((!light || s_ == R - 1) && rb >= 0) {
+                    if (re > rb) {
+#pragma unroll
+                        for (int r_ = 0; r_ < NRUN; ++r_)
+                            if (r_ == n_run)
+                                run_b[r_] = rb, run_e[r_] = re;
+                        ++n_run;
+                    }
+                    rb = -1;
+                }
+            }
+        }
+#pragma unroll 1
+        for (int r_ = 0; r_ < n_run; ++r_) {
+            int rb = run_b[0], re = run_e[0];
+#pragma unroll
+            for (int q_ = 1; q_ < NRUN; ++q_)
+                if (q_ == r_)
+                    rb = run_b[q_], re = run_e[q_];
+            walk_range<LPR, RW, MODE, false, true>(w, var, acc, occ_k, rb, re, pre_cur, pf_cur);
+        }
+        float4 grad = reduce_to_owner<LPR, RW>(acc);
+        CREC_FLOW_MARK(1, __float_as_int(grad.x));
+        // ---- heavy slots: the whole workgroup
+        if (hmask != 0) {
+            if (owner && heavy_own)
+                hvar[(wv * R + g) * LPR + l] = var;
+            __syncthreads();
+            for (uint64_t mm = hmask; mm != 0; mm &= mm - 1) {
+                const int q = __builtin_amdgcn_readfirstlane(__builtin_ctzll(mm));
+                Slot hs;
+                hs.row = 0;
+                hs.start = __builtin_amdgcn_readlane(seg_cur.x, q);
+                hs.cnt = __builtin_amdgcn_readlane(seg_cur.y, q);
+                const float4 own = act ? hvar[q * LPR + l] : zero;
+                const float4 part = slots_grad<LPR, RW1, MODE, false, true>(own, hs, 1, Pk, Qk, d, occ_k, nullptr, xb, hk, wv, WPB, hist, err);
+                if (g == 0 && act)
+                    hpart[(q * WPB + wv) * LPR + l] = part;
+            }
+            __syncthreads();
+            if (owner && heavy_own) {
+                const float4 *pp = hpart + (wv * R + g) * WPB * LPR + l;
+                grad = pp[0];
+#pragma unroll
+                for (int p_ = 1; p_ < WPB; ++p_) // wave order: the sum does not depend on timing
+                    add4(grad, pp[p_ * LPR]);
+            }
+        }
+        CREC_FLOW_MARK(2, __float_as_int(grad.x));
+#ifdef CREC_STAMPS
+        if (k == CREC_FLOW_STAMP_STEP && lane == 0 && stamp_wave < 16000)
+            crec_stamps[8 * stamp_wave + 5] = ((unsigned long long)(unsigned)(pl_cur - pf_cur) << 32) | (unsigned)__popcll(hmask) | (user ? 0x100u : 0u);
+#endif
+        const float nr = group_sum<LPR>(dot4(var, var));
+        if (owner) {
+            if (l == 0)
+                xb[f.B + (user ? 0 : U) + row] = (0.5f * nr) * (float)cnt_own;
+            adam4(var, m, v, grad, cnt_own > 0, hk);
+            if (k + 1 < f.C) {
+                if (!(f.abl & 4))
+                    st4_wt(hist_own + (int64_t)k * h_own, ro, flow_publishable(var));
+            } else {
+                st4s((user ? dst.P : dst.Q) + ro, var);
+                st4s((user ? dst.mP : dst.mQ) + ro, m);
+                st4s((user ? dst.vP : dst.vQ) + ro, v);
+            }
+            for (int sr = k * q_reset; sr < (k + 1) * q_reset && sr < f.dirty_next && !(f.abl & 4); ++sr)
+                __builtin_nontemporal_store(sent, reinterpret_cast<crec_f4v *>(next_own + (int64_t)sr * h_own + ro));
+        }
+        CREC_FLOW_MARK(3, __float_as_int(var.x));
+        seg_cur = seg_nxt;
+        seg_nxt = seg_nn;
+        pre_cur = pre_nxt;
+        pf_cur = pf_nxt;
+        pl_cur = pl_nxt;
+    }
+}
+
+template <int LPR, bool FULL>
+__global__ __launch_bounds__(CREC_FUSED_BLOCK) __attribute__((amdgpu_waves_per_eu(CREC_FLOW_WAVES, CREC_FLOW_WAVES))) void bpr_steps_flow(Tables src, Tables dst, int d, int64_t U, int64_t I, FlowArgs f, Hyper h)
+{
+    constexpr int R = Geo<LPR, ROWS_PER_WAVE>::R, WPB = CREC_FUSED_BLOCK / 64;
+    __shared__ float4 flow_lds[R * WPB * LPR * (1 + WPB)];
+    if ((int)blockIdx.x < f.nwg_u)
+        flow_wave<LPR, 0, FULL>(src, dst, d, U, U, (int)blockIdx.x, f.nwg_u, f.u_rowseg, f.Upos, f.u_occ, f.B, f.histP, f.nextP, f.hP, f, h, flow_lds);
+    else
+        flow_wave<LPR, 1, FULL>(src, dst, d, U, I, (int)blockIdx.x - f.nwg_u, f.nwg_q, f.q_rowseg, f.Ipos, f.q_occ, 2 * f.B, f.histQ,
+                                f.nextQ, f.hQ, f, h, flow_lds);
 }
 
 // ------------------------------------------------------------------------------------
@@ -2141,6 +2502,43 @@ int setup_lazy_bufs(crec_ctx *ctx, int64_t B, int d, int CH, hipStream_t st, Laz
 
 using StepFn = void (*)(const StepArgs &, const IndexWs &, int64_t, const int32_t *);
 
+// bpr_steps_flow<LPR, FULL>: the launch, and the workgroups of it one CU holds at a time
+struct FlowKernel {
+    void (*launch)(crec_ctx *, unsigned grid, hipStream_t, const Tables &, const Tables &, int, int64_t, int64_t, const FlowArgs &, const Hyper &);
+    const void *fn;
+    int rows_per_wg, lpr_log2, full;
+};
+template <int LPR, bool FULL>
+void launch_flow(crec_ctx *ctx, unsigned grid, hipStream_t st, const Tables &src, const Tables &dst, int d, int64_t U, int64_t I,
+                 const FlowArgs &f, const Hyper &h)
+{
+    CREC_KLAUNCH(ctx, (bpr_steps_flow<LPR, FULL>), dim3(grid), dim3(CREC_FUSED_BLOCK), 0, st, src, dst, d, U, I, f, h);
+}
+FlowKernel pick_flow(int d)
+{
+    int lpr = 1, lg = 0;
+    while (lpr * 4 < d)
+        lpr <<= 1, ++lg;
+    const bool full = d == 4 * lpr;
+#define CREC_PICK(L)                                                                                                              \
+    case L:                                                                                                                       \
+        return full ? FlowKernel{launch_flow<L, true>, (const void *)bpr_steps_flow<L, true>,                                     \
+                                 Geo<L, ROWS_PER_WAVE>::R * (CREC_FUSED_BLOCK / 64), lg, 1}                                        \
+                    : FlowKernel{launch_flow<L, false>, (const void *)bpr_steps_flow<L, false>,                                   \
+                                 Geo<L, ROWS_PER_WAVE>::R * (CREC_FUSED_BLOCK / 64), lg, 0};
+    switch (lpr) {
+        CREC_PICK(1)
+        CREC_PICK(2)
+        CREC_PICK(4)
+        CREC_PICK(8)
+        CREC_PICK(16)
+        CREC_PICK(32)
+        CREC_PICK(64)
+    }
+#undef CREC_PICK
+    return FlowKernel{nullptr, nullptr, 0, 0, 0};
+}
+
 StepFn pick_step(int d, bool dense)
 {
     int lpr = 1;
@@ -2261,10 +2659,80 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
             lpr <<= 1;
         wide_rows = 64 / lpr < ROWS_PER_WAVE ? 64 / lpr : ROWS_PER_WAVE;
     }
-    const int wide_total = (!dense || wide_rows < 2) ? 0 : (ctx->knob_wide >= 0 ? ctx->knob_wide : 16);
+    int wide_total = (!dense || wide_rows < 2) ? 0 : (ctx->knob_wide >= 0 ? ctx->knob_wide : 16);
+
+    // tf1 mode, all steps of a chunk in ONE launch (bpr_steps_flow) where every wave of it is resident at once and the version
+    // histories stay under 1 GiB; else (and for the data-parallel step, whose item rows leave the launch every step) a launch per step
+    if (ctx->flow_err && *(volatile int32_t *)ctx->flow_err != 0) { // (the flag lives in page-locked memory the kernel writes itself)
+        *(volatile int32_t *)ctx->flow_err = 0;
+        ctx->flow_hist_at = nullptr; // whatever the histories hold now: sentinel again before the next use
+        return crec_fail(ctx, CREC_EHIP, "an earlier bpr_steps_flow launch gave up waiting for a row version (a wave of it never ran or the "
+                                         "device faulted): the tables that call left are not valid");
+    }
+    FlowKernel fk{};
+    int flow_cmax = 0; // steps per launch; 0: bpr_step_fused, a launch per step
+    int CH_idx = CH;   // what the index kernel cuts heavy rows at
+    const int64_t hP = (int64_t)t->U * t->d, hQ = (int64_t)t->I * t->d;
+    if (dense && !dp && ctx->knob_flow > 0) { // (opt-in: measured SLOWER than a launch per step so far)
+        fk = pick_flow(t->d);
+        const int64_t grid = crec_ceil_div(t->U, fk.rows_per_wg) + crec_ceil_div(t->I, fk.rows_per_wg);
+        int &bpc = ctx->flow_blocks_per_cu[fk.lpr_log2][fk.full];
+        if (bpc == 0) {
+            int nbk = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, fk.fn, CREC_FUSED_BLOCK, 0) != hipSuccess) {
+                (void)hipGetLastError();
+                nbk = 0;
+            }
+            bpc = nbk > 0 ? nbk : -1;
+        }
+        const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+        if (!ctx->flow_err) {
+            void *dev = nullptr;
+            if (hipHostMalloc((void **)&ctx->flow_err, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
+                hipHostGetDevicePointer(&dev, ctx->flow_err, 0) == hipSuccess) {
+                *ctx->flow_err = 0;
+                ctx->flow_err_dev = (int32_t *)dev;
+            } else {
+                (void)hipGetLastError();
+                if (ctx->flow_err)
+                    (void)hipHostFree(ctx->flow_err);
+                ctx->flow_err = nullptr;
+            }
+        }
+        if (bpc > 0 && grid <= (int64_t)bpc * cus && ctx->flow_err_dev && hP * 4 < ((int64_t)1 << 31) && hQ * 4 < ((int64_t)1 << 31)) {
+            int64_t cmax = FLOW_MAX_STEPS;
+            while (cmax > 1 && 2 * (cmax - 1) * (hP + hQ) * 4 > ((int64_t)1 << 30))
+                cmax /= 2;
+            if (ctx->knob_flow_steps > 0)
+                cmax = ctx->knob_flow_steps < cmax ? ctx->knob_flow_steps : cmax;
+            if (cmax >= 8 || ctx->knob_flow_steps > 0)
+                flow_cmax = (int)cmax;
+        }
+    }
+    const int flow_rpb = flow_cmax ? fk.rows_per_wg : 0;
+    if (flow_cmax) { // its waves walk whatever their rows hold: no heavy-row chunks, no wide groups, nothing for the host to read back
+        CH_idx = 0x3fffffff;
+        wide_total = 0;
+    }
+    if (flow_cmax > 1) {
+        const int64_t slots = flow_cmax - 1;
+        const size_t bytes = sizeof(float) * (size_t)(2 * slots * (hP + hQ));
+        if (int rc = crec_reserve(ctx, &ctx->flow_hist, bytes))
+            return rc;
+        if (ctx->flow_hist_at != ctx->flow_hist.ptr || ctx->flow_key[0] != flow_cmax || ctx->flow_key[1] != hP || ctx->flow_key[2] != hQ) {
+            CREC_HIP(ctx, hipMemsetAsync(ctx->flow_hist.ptr, 0xff, bytes, (hipStream_t)stream)); // the sentinel in every word
+            ctx->flow_hist_at = ctx->flow_hist.ptr;
+            ctx->flow_key[0] = flow_cmax, ctx->flow_key[1] = hP, ctx->flow_key[2] = hQ;
+            ctx->flow_dirty[0] = ctx->flow_dirty[1] = 0;
+            ctx->flow_cur = 0;
+        }
+    }
+    const auto layout = [&](void *base, int64_t nbc_, int spw_ = 32) {
+        return layout_index(base, nbc_, B, t->U, t->I, dense, CH_idx, wide_rows, wide_total, spw_, flow_rpb);
+    };
 
     // chunk the epoch so the inverted indices of a chunk stay under ~1 GiB
-    const size_t per_batch = layout_index(nullptr, 1, B, t->U, t->I, dense, CH, wide_rows, wide_total).bytes;
+    const size_t per_batch = layout(nullptr, 1).bytes;
     int64_t chunk = (int64_t)((size_t)1 << 30) / (int64_t)per_batch;
     // batches beyond the LDS sort (and any batch under the "big_index" option) are indexed in global memory, a chunk at a time
     const bool big_index = !dense && (B > MAX_B || ctx->knob_big_index);
@@ -2288,10 +2756,10 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
             chunk_sizes.push_back((nb - done) < cur ? (nb - done) : cur);
     }
     const bool piped = big_index && ctx->knob_idx_overlap && chunk_sizes.size() > 1;
-    if (int rc = crec_reserve(ctx, &ctx->idx_ws, layout_index(nullptr, chunk, B, t->U, t->I, dense, CH, wide_rows, wide_total).bytes))
+    if (int rc = crec_reserve(ctx, &ctx->idx_ws, layout(nullptr, chunk).bytes))
         return rc;
     if (piped) {
-        if (int rc = crec_reserve(ctx, &ctx->idx_ws2, layout_index(nullptr, chunk, B, t->U, t->I, dense, CH, wide_rows, wide_total).bytes))
+        if (int rc = crec_reserve(ctx, &ctx->idx_ws2, layout(nullptr, chunk).bytes))
             return rc;
         hipStream_t side_;
         if (int rc = crec_side_stream(ctx, &side_))
@@ -2301,7 +2769,7 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
     const int64_t loss_stride = B + (dense ? t->U + t->I : (int64_t)B); // lazy: x_b, then the l2 term of every triple
     if (int rc = crec_reserve(ctx, &ctx->loss_ws, sizeof(float) * (size_t)chunk * loss_stride))
         return rc;
-    const IndexWs w0 = layout_index(nullptr, 1, B, t->U, t->I, dense, CH, wide_rows, wide_total);
+    const IndexWs w0 = layout(nullptr, 1);
     // heavy rows: chunk partials, then one ticket counter per heavy row (zeroed here, re-zeroed by the finishing wave)
     const size_t part_bytes = align_up(sizeof(float) * (size_t)(w0.HIu + w0.HIq) * t->d, 256);
     const size_t ticket_bytes = sizeof(int32_t) * (size_t)(w0.HRu + w0.HRq);
@@ -2396,7 +2864,7 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
         nbc = chunk_sizes[ci];
         const int64_t t0 = b0 * B, n_chunk = (N - t0) < nbc * B ? (N - t0) : nbc * B;
         void *const ws_of[2] = {ctx->idx_ws.ptr, piped ? ctx->idx_ws2.ptr : ctx->idx_ws.ptr};
-        IndexWs w = layout_index(ws_of[ci & 1], nbc, B, t->U, t->I, dense, CH, wide_rows, wide_total, lazy_spw(t->d));
+        IndexWs w = layout(ws_of[ci & 1], nbc, lazy_spw(t->d));
         const size_t nw_off = (size_t)(w.nwide - w.hn), n_back = dense ? nw_off + (size_t)nbc * 2 : 0;
         if (n_back + 64 > ctx->pinned_ints) {
             if (ctx->pinned)
@@ -2426,7 +2894,7 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
         }
         // the flag sits in the buffer's last cache line, the counts at its start
         const size_t flag_at = ctx->pinned_ints - 16;
-        const bool zero_copy = dense && ctx->pinned_dev && !ctx->knob_no_zero_copy;
+        const bool zero_copy = dense && !flow_cmax && ctx->pinned_dev && !ctx->knob_no_zero_copy;
         w.host_counts = zero_copy ? ctx->pinned_dev : nullptr;
         w.host_flag = zero_copy ? ctx->pinned_dev + flag_at : nullptr;
         w.done = ctx->idx_done;
@@ -2445,7 +2913,7 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
                 CREC_HIP(ctx, hipEventRecord(ctx->idx_ev[0], side));
             }
             if (ci + 1 < chunk_sizes.size()) { // the next chunk's index, beside this chunk's steps, into the other buffer
-                const IndexWs wn = layout_index(ws_of[(ci + 1) & 1], chunk_sizes[ci + 1], B, t->U, t->I, dense, CH, wide_rows, wide_total, lazy_spw(t->d));
+                const IndexWs wn = layout(ws_of[(ci + 1) & 1], chunk_sizes[ci + 1], lazy_spw(t->d));
                 if (ci >= 1) // (that buffer was read by the steps of chunk ci - 1)
                     CREC_HIP(ctx, hipStreamWaitEvent(side, ctx->idx_ev[2 + ((ci + 1) & 1)], 0));
                 if (int rc = build_big(wn, b0 + nbc, chunk_sizes[ci + 1], side))
@@ -2470,7 +2938,7 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
         // launches are sized by the batch alone, so the whole epoch is enqueued without a host synchronisation.)
         const int32_t *hn = ctx->pinned, *nwide = ctx->pinned + nw_off;
         a.nwide = nwide;
-        if (dense) {
+        if (dense && !flow_cmax) {
             bool have = false;
             if (zero_copy) {
                 volatile int32_t *flag = ctx->pinned + flag_at;
@@ -2496,13 +2964,66 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
             }
         }
         a.pad_wide = a.pad_chunks_u = a.pad_chunks_q = 0;
-        for (int64_t b = 0; b < (dense ? nbc : 0); ++b) {
+        for (int64_t b = 0; b < (dense && !flow_cmax ? nbc : 0); ++b) {
             const int nw = nwide[(size_t)b * 2] + nwide[(size_t)b * 2 + 1];
             a.pad_wide = nw > a.pad_wide ? nw : a.pad_wide;
             a.pad_chunks_u = hn[(size_t)b * HN + 1] > a.pad_chunks_u ? hn[(size_t)b * HN + 1] : a.pad_chunks_u;
             a.pad_chunks_q = hn[(size_t)b * HN + 3] > a.pad_chunks_q ? hn[(size_t)b * HN + 3] : a.pad_chunks_q;
         }
-        for (int64_t b = 0; b < nbc; ++b) {
+        for (int64_t b = 0; flow_cmax && b < nbc;) { // bpr_steps_flow: up to flow_cmax steps per launch
+            const int C = (int)((nbc - b) < flow_cmax ? (nbc - b) : flow_cmax);
+            FlowArgs f{};
+            f.u_rowseg = w.u_rowseg + b * w.U;
+            f.q_rowseg = w.q_rowseg + b * w.I;
+            f.u_occ = w.u_occ + b * w.B;
+            f.q_occ = w.q_occ + b * 2 * w.B;
+            f.Upos = w.U, f.Ipos = w.I, f.B = B;
+            f.nwg_u = w.flow_nwg_u, f.nwg_q = w.flow_nwg_q;
+            f.C = C;
+            f.hP = hP, f.hQ = hQ;
+            const int64_t slots = ctx->flow_hist_at ? ctx->flow_key[0] - 1 : 0;
+            const int cur = ctx->flow_cur;
+            if (slots > 0) {
+                float *base = (float *)ctx->flow_hist.ptr;
+                f.histP = base + (int64_t)cur * slots * (hP + hQ);
+                f.histQ = f.histP + slots * hP;
+                f.nextP = base + (int64_t)(1 - cur) * slots * (hP + hQ);
+                f.nextQ = f.nextP + slots * hP;
+                f.dirty_next = ctx->flow_dirty[1 - cur];
+            }
+            f.loss_ws = (float *)ctx->loss_ws.ptr + b * loss_stride;
+            f.loss_stride = loss_stride;
+            f.err = ctx->flow_err_dev;
+            f.abl = ctx->knob_flow_abl;
+            for (int k = 0; k < C; ++k) { // lr_t of every step of the launch (fp32 running powers, as below)
+                f.lr_t[k] = (opt->lr * sqrtf(1.0f - opt->beta2_power)) / (1.0f - opt->beta1_power);
+                opt->beta1_power = opt->beta1_power * opt->beta1;
+                opt->beta2_power = opt->beta2_power * opt->beta2;
+                opt->step += 1;
+            }
+            a.h = Hyper{};
+            a.h.lr_t = f.lr_t[0];
+            a.h.beta1 = opt->beta1;
+            a.h.beta2 = opt->beta2;
+            a.h.eps = opt->eps;
+            a.h.reg = opt->reg;
+            ctx->prof.next_units = C;
+            crec_prof_begin(ctx, CREC_K_STEPS_FLOW, st);
+            fk.launch(ctx, (unsigned)(w.flow_nwg_u + w.flow_nwg_q), st, a.cur, a.other, a.d, a.U, a.I, f, a.h);
+            crec_prof_end(ctx, st);
+            ctx->prof.next_units = 1;
+            if (slots > 0) {
+                ctx->flow_dirty[cur] = C - 1;  // versions 1 .. C - 1 of this launch
+                ctx->flow_dirty[1 - cur] = 0;  // (put back to the sentinel by this launch)
+                ctx->flow_cur = 1 - cur;
+            }
+            Tables tmp = a.cur;
+            a.cur = a.other;
+            a.other = tmp;
+            in_shadow = !in_shadow;
+            b += C;
+        }
+        for (int64_t b = 0; !flow_cmax && b < nbc; ++b) {
             // lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t) with fp32 running powers (TF1 _prepare/_finish); SGD / Adagrad: lr
             a.h.opt = (opt->adam_mode == CREC_OPT_SGD || opt->adam_mode == CREC_OPT_ADAGRAD) ? opt->adam_mode : 0;
             a.h.lr_tab = lr_tab; // deferred mode (else null)
@@ -2838,6 +3359,13 @@ int sharded_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, int64_t I_global
             local_rc = crec_reserve(ctx, &ctx->shard_ws2, serve_layout(nullptr, nbc, total_srv, stride).bytes);
         if (big && local_rc == CREC_OK) // (the owner-side index' scratch is sized by what THIS rank is asked for: part of the same verdict)
             local_rc = crec_shard_owner_index_big_reserve(ctx, nbc, stride, st);
+        // ... and what it is asked for must fit a half of the transport's window: the rows it serves are staged there (next_half) and the
+        // gradient rows it receives travel through it.  n_srv reaches G * IC under skew, beyond the IC * d * 4 checked up front; a rank
+        // that found out alone -- inside alltoallv_inplace, after shard_serve_rows had already written past the half its peers are still
+        // pulling from -- would leave them waiting for the time-out
+        if (local_rc == CREC_OK && stride * d * 4 + 16 * G > x->max_bytes())
+            local_rc = crec_fail(ctx, CREC_EINVAL, "a batch asks this rank for %lld rows = %lld bytes; a half of the transport's window holds %lld",
+                                 (long long)stride, (long long)stride * d * 4, (long long)x->max_bytes());
         if (G > 1) {
             if (int rc = crec_reserve(ctx, &ctx->shard_flag, 64))
                 local_rc = local_rc ? local_rc : rc;
@@ -2852,8 +3380,8 @@ int sharded_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, int64_t I_global
                 verdict = *h_verdict;
             }
             if (local_rc == CREC_OK && verdict > 0.f)
-                return crec_fail(ctx, CREC_EINVAL, "%d peer rank(s) cannot serve this chunk (more rows asked of one owner than its index sorts per batch, "
-                                                   "or out of memory there): every rank stops here", (int)(verdict + 0.5f));
+                return crec_fail(ctx, CREC_EINVAL, "%d peer rank(s) cannot serve this chunk (more rows asked of one owner than its index sorts per batch "
+                                                   "or than a half of its transport window holds, or out of memory there): every rank stops here", (int)(verdict + 0.5f));
         }
         if (local_rc)
             return local_rc;

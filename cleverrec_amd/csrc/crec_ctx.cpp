@@ -103,8 +103,9 @@ void crec_prof_begin(crec_ctx *ctx, int cls, hipStream_t st)
 {
     if (!ctx->prof.on)
         return;
-    crec_profile::rec r{cls, prof_event(ctx), prof_event(ctx), false, ctx->prof.skip_next};
+    crec_profile::rec r{cls, prof_event(ctx), prof_event(ctx), false, ctx->prof.skip_next, ctx->prof.next_units};
     ctx->prof.skip_next = false;
+    ctx->prof.next_units = 1;
     ctx->prof.pending.push_back(r);
     ctx->prof.open = true;
     (void)st;
@@ -145,6 +146,7 @@ int crec_prof_flush(crec_ctx *ctx, hipStream_t st)
         if (r.ext && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess && !r.skip) {
             ctx->prof.total_ms[r.cls] += ms > 0.f ? ms : 0.f;
             ctx->prof.launches[r.cls] += 1;
+            ctx->prof.units[r.cls] += r.units;
         }
         ctx->prof.pool.push_back(r.a);
         ctx->prof.pool.push_back(r.b);
@@ -164,6 +166,7 @@ int crec_profile_enable(crec_ctx *ctx, int on)
     for (int k = 0; k < CREC_K_COUNT; ++k) {
         ctx->prof.total_ms[k] = 0;
         ctx->prof.launches[k] = 0;
+        ctx->prof.units[k] = 0;
     }
     return CREC_OK;
 }
@@ -174,6 +177,14 @@ int crec_profile_read(const crec_ctx *ctx, int kernel_class, double *total_ms, i
         return CREC_EINVAL;
     *total_ms = ctx->prof.total_ms[kernel_class];
     *launches = ctx->prof.launches[kernel_class];
+    return CREC_OK;
+}
+
+int crec_profile_read_units(const crec_ctx *ctx, int kernel_class, int64_t *units)
+{
+    if (!ctx || kernel_class < 0 || kernel_class >= CREC_K_COUNT || !units)
+        return CREC_EINVAL;
+    *units = ctx->prof.units[kernel_class];
     return CREC_OK;
 }
 
@@ -206,6 +217,8 @@ int crec_ctx_create(int device, crec_ctx **out)
     ctx->knob_idx_overlap = env_int("CREC_IDX_OVERLAP", 0);
     ctx->knob_no_zero_copy = env_int("CREC_NO_ZERO_COPY", 0);
     ctx->knob_dsampler_general = env_int("CREC_DSAMPLER_GENERAL", 0);
+    ctx->knob_flow = env_int("CREC_FLOW", 0);
+    ctx->knob_flow_steps = env_int("CREC_FLOW_STEPS", 0);
     if (device >= 0) {
         int n = 0;
         hipError_t e = hipGetDeviceCount(&n);
@@ -245,7 +258,7 @@ void crec_ctx_destroy(crec_ctx *ctx)
         (void)crec_comm_destroy(ctx);
         crec_devbuf *bufs[] = {&ctx->idx_ws, &ctx->idx_ws2, &ctx->big_ws, &ctx->contrib, &ctx->loss_ws,
                                &ctx->misc,   &ctx->eval_ws, &ctx->ks_dev, &ctx->shadow, &ctx->dq, &ctx->shard_ws, &ctx->shard_ws2, &ctx->lr_hist_dev,
-                               &ctx->shard_flag};
+                               &ctx->shard_flag, &ctx->flow_hist};
         for (crec_devbuf *b : bufs)
             if (b->ptr)
                 (void)hipFree(b->ptr);
@@ -264,6 +277,8 @@ void crec_ctx_destroy(crec_ctx *ctx)
             (void)hipHostFree(ctx->pinned);
         if (ctx->pinned64)
             (void)hipHostFree(ctx->pinned64);
+        if (ctx->flow_err)
+            (void)hipHostFree(ctx->flow_err);
         if (ctx->idx_done)
             (void)hipFree(ctx->idx_done);
     }
@@ -299,6 +314,12 @@ int crec_ctx_set_option(crec_ctx *ctx, const char *name, int64_t value)
         ctx->knob_idx_one_wg = (int)value;
     else if (n == "idx_overlap")
         ctx->knob_idx_overlap = (int)value;
+    else if (n == "flow")
+        ctx->knob_flow = (int)value;
+    else if (n == "flow_abl")
+        ctx->knob_flow_abl = (int)value;
+    else if (n == "flow_steps")
+        ctx->knob_flow_steps = (int)value;
     else if (n == "dsampler_general")
         ctx->knob_dsampler_general = (int)value;
     else if (n == "dsampler_budget")

@@ -30,7 +30,7 @@ enum crec_kernel_class {
     CREC_K_INDEX = 0,
     CREC_K_STEP_FUSED,
     CREC_K_USER_SIDE,
-    CREC_K_ITEM_SIDE,
+    CREC_K_STEPS_FLOW, // bpr_steps_flow: up to 64 tf1 steps per launch (`units` counts the steps)
     CREC_K_REDUCE_LOSS,
     CREC_K_EVAL_SWEEP,
     CREC_K_EVAL_MERGE,
@@ -58,13 +58,16 @@ struct crec_profile {
         hipEvent_t a, b;
         bool ext; // a / b were handed to hipExtLaunchKernelGGL: they carry the dispatch's own begin / end timestamps
         bool skip; // launched while its predecessor was still running: its events also span the wait, not counted
+        int64_t units; // see crec_profile::units
     };
+    int64_t next_units = 1; // units of the next crec_prof_begin
     bool skip_next = false; // the next crec_prof_begin opens such a record
     bool open = false; // between crec_prof_begin and crec_prof_end
     std::vector<rec> pending;
     std::vector<hipEvent_t> pool;
     double total_ms[CREC_K_COUNT] = {0};
     int64_t launches[CREC_K_COUNT] = {0};
+    int64_t units[CREC_K_COUNT] = {0}; // work units of the counted launches where a launch holds a varying number (steps of bpr_steps_flow)
 };
 
 struct crec_ctx {
@@ -124,6 +127,17 @@ struct crec_ctx {
     int knob_big_index = 0;      // 1: the lazy step's index through index_big.hip (global-memory sort) even for batches the LDS sort holds (tests)
     int knob_ncf_generic = 0;    // 1: the generic ncf_tile even for the shapes that have a specialised one (tests)
     int knob_dsampler_budget = 100; // percent of the device sampler's stream budget to start with (tests: < 100 forces the retry path)
+    int knob_flow = 0;           // tf1 step: 1 all steps of a chunk in one dataflow launch where the shape allows (bpr_steps_flow), 0 (default) a launch per step
+    int knob_flow_abl = 0;       // timing ablations of bpr_steps_flow (FlowArgs::abl; wrong results)
+    int knob_flow_steps = 0;     // steps per bpr_steps_flow launch (0: up to 64; 1: a launch per step through the same kernel -- no version history, tests)
+    // bpr_steps_flow: the two version histories (alternating between launches), what they are laid out for, how many slots of each
+    // hold published rows (the rest holds the sentinel), which one the next launch fills; the give-up flag (page-locked, mapped)
+    crec_devbuf flow_hist;
+    void *flow_hist_at = nullptr;
+    int64_t flow_key[3] = {0, 0, 0}; // {steps per history + 1, floats per P version, floats per Q version}
+    int flow_dirty[2] = {0, 0}, flow_cur = 0;
+    int32_t *flow_err = nullptr, *flow_err_dev = nullptr;
+    int flow_blocks_per_cu[8][2] = {{0}}; // occupancy of bpr_steps_flow<LPR, FULL> by (log2 LPR, FULL); 0: not asked yet
     int knob_dsampler_general = 0; // negatives phase of the device sampler: 0 parallel tables (walk where they do not apply), 2 the four-wave walk, 1 the general walk (tests)
 };
 

@@ -327,8 +327,8 @@ struct PeerXch : crec_xch {
         if (!connected)
             return false;
         ++seq;
-        if (seq == 0)
-            ++seq;
+        if (seq == 0) // 0 is "no exchange yet".  The wrap keeps the parity alternating (0xffffffff is odd, so the next one is 2, not 1):
+            seq = 2;  // two consecutive exchanges never share a window half and a pair of signal slots
         *v = base;
         v->half_off = (int64_t)(seq & 1u) * (own.win_bytes / 2);
         v->my_half = own.win + v->half_off;
@@ -342,7 +342,7 @@ struct PeerXch : crec_xch {
         return true;
     }
     // where a producer kernel may leave the segments of the NEXT exchange (which then skips its copy-in)
-    char *next_half() override { return connected ? own.win + (int64_t)((seq + 1 == 0 ? 1u : seq + 1) & 1u) * (own.win_bytes / 2) : nullptr; }
+    char *next_half() override { return connected ? own.win + (int64_t)((seq + 1 == 0 ? 2u : seq + 1) & 1u) * (own.win_bytes / 2) : nullptr; }
     int launch(crec_ctx *ctx, PeerSegs &a, const void *send, void *recv, int mode, int64_t n, int64_t work_bytes, hipStream_t st)
     {
         CREC_REQUIRE(ctx, connected, "peer transport: crec_comm_peer_connect has not completed on this ctx");

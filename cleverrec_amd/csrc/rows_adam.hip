@@ -690,10 +690,12 @@ int crec_small_adam_dense(crec_ctx *ctx, float *var, float *m, float *v, const f
 int crec_apply_all(crec_ctx *ctx, crec_apply_set &a, hipStream_t st)
 {
     CREC_REQUIRE(ctx, a.n_tables >= 0 && a.n_tables <= CREC_APPLY_MAX_TABLES, "apply set: too many tables");
-    // timing diagnosis only (tools/time_cml.py): CREC_APPLY_SKIP=k leaves table k of every update launch out
+#ifdef CREC_ROWS_STAMPS // timing diagnosis only, debug builds (tools/rows_stamps.sh, tools/time_cml.py): CREC_APPLY_SKIP=k leaves table k of
+                        // every update launch out.  Never in the shipped library: a stray environment variable must not change training
     static const int skip = getenv("CREC_APPLY_SKIP") ? atoi(getenv("CREC_APPLY_SKIP")) : -1;
     if (skip >= 0 && skip < a.n_tables)
         a.tables[skip].t.rows = 0;
+#endif
     int lpr = 0, blocks = 0;
     bool chunked = false; // some table of the set comes with a per-step index in several chunks (rows_apply_row's second walk)
     for (int k = 0; k < a.n_tables; ++k) {

@@ -444,8 +444,10 @@ def topk_scores(sess, scores, users, seen_ptr, seen_items, K, ascending=False, c
     Bt, I = scores.shape
     if I <= TOPK_SCORES_MAX_ITEMS:
         return _topk_scores_call(sess, scores, users, seen_ptr, seen_items, K, ascending, candidates)
-    key = (seen_ptr.data_ptr(), seen_items.data_ptr(), I)
-    if key not in _chunk_lists:  # the lists per stretch, on the host once (CSR by user id, items ascending)
+    # the cache holds the tensors themselves and compares identity: addresses alone come back (the caching allocator hands a freed
+    # block to the next dataset of a grid search), and a stale cut would filter the wrong items
+    held = _chunk_lists.get("lists")
+    if held is None or held[0] is not seen_ptr or held[1] is not seen_items or held[2] != I:  # the lists per stretch, on the host once (CSR by user id, items ascending)
         ptr, items = seen_ptr.cpu().numpy(), seen_items.cpu().numpy()
         row = np.repeat(np.arange(len(ptr) - 1), np.diff(ptr))
         cuts = []
@@ -457,14 +459,14 @@ def topk_scores(sess, scores, users, seen_ptr, seen_items, K, ascending=False, c
             it = (items[:len(row)][m] - lo).astype(np.int32)
             cuts.append((lo, hi, sess.to_dev(p), sess.to_dev(it if len(it) else np.zeros(1, np.int32))))
         _chunk_lists.clear()
-        _chunk_lists[key] = cuts
+        _chunk_lists["lists"] = (seen_ptr, seen_items, I, cuts)
     parts_i, parts_s = [], []
-    for lo, hi, p, it in _chunk_lists[key]:
+    for lo, hi, p, it in _chunk_lists["lists"][3]:
         ids, sc = _topk_scores_call(sess, scores[:, lo:hi].contiguous(), users, p, it, K, ascending, candidates)
         parts_i.append(torch.where(ids >= 0, ids + lo, ids))
         parts_s.append(sc)
     cand_ids, cand_sc = torch.cat(parts_i, 1), torch.cat(parts_s, 1).contiguous()  # [Bt, stretches * K], lower ids first among equals
-    none = sess.zeros((int(users.max().item()) + 2,), torch.int64)  # nobody has a list in this round
+    none = sess.zeros((len(seen_ptr),), torch.int64)  # nobody has a list in this round (sized by the CSR: no read-back of users.max())
     cols, sc = _topk_scores_call(sess, cand_sc, users, none, sess.zeros((1,), torch.int32), K, ascending, False)
     ids = torch.gather(cand_ids, 1, cols.clamp(min=0).long()).to(torch.int32)
     return torch.where(cols >= 0, ids, cols), sc

@@ -77,6 +77,12 @@ const char *crec_last_error(const crec_ctx *ctx);
  *                    behind the sort (same index, bit for bit)
  *   "dp_unfused"     1: the replicated-Q step over the peer transport as an all-reduce of dQ plus a separate Adam launch instead of
  *                    one launch that exchanges and updates (same tables, bit for bit)
+ *   "flow"           tf1 step (replaces the per-batch sess.run of model/RankingRecommender.py:39-47): 1 all steps of a chunk of
+ *                    batches in ONE dataflow launch (bpr_steps_flow: rows and Adam slots stay in registers, a version of every row is
+ *                    published per step) where every wave of it is resident at once, 0 (default) a launch per step (bpr_step_fused).
+ *                    The two assign rows to waves differently: same results up to fp32 summation order.  Experimental: correct
+ *                    (bit-identical to itself launched step by step) and, as measured in round 4, slower than the default
+ *   "flow_steps"     steps per bpr_steps_flow launch (0 = up to 64; 1 = a launch per step through the same kernel: bit-identical)
  *   "big_index"      1: the lazy-family steps index their batches through the global-memory sort (index_big.hip, the form batches of
  *                    more than 8192 triples always take) even where the in-LDS sort would do: same index, bit for bit
  *   "idx_overlap"    1: that form indexes its chunks of batches a chunk ahead on a side stream, beside the previous chunk's steps
@@ -87,7 +93,8 @@ int crec_ctx_set_option(crec_ctx *ctx, const char *name, int64_t value);
 /* ---- measurement: per-kernel time from HIP events recorded on the launch stream ------------
  * While enabled, every kernel launch of this ctx is bracketed by two events and each API call
  * ends with a stream synchronise (so do not time whole-job throughput with it on).
- * kernel_class: 0 bpr_index_batches, 1 bpr_step_fused, 2 bpr_triples_lazy, 3 (unused),
+ * kernel_class: 0 bpr_index_batches, 1 bpr_step_fused, 2 bpr_triples_lazy, 3 bpr_steps_flow (a launch holds up to 64 steps:
+ *               crec_profile_read_units gives the steps of the counted launches),
  *               4 bpr_reduce_loss, 5 eval_sweep, 6 eval_merge, 7 rank_metrics, 8 (unused), 9 bpr_adam_dense,
  *               10 rows_index_batches, 11 rows_apply, 12 small_adam_dense, 13 ncf_tile, 14 fm_instances, 15 cml_instances,
  *               16 ncf_pair_logits, 17 shard_plan_batches, 18 shard_serve_rows, 19 shard_owner_apply,
@@ -95,6 +102,7 @@ int crec_ctx_set_option(crec_ctx *ctx, const char *name, int64_t value);
  * enable(.., 1) also clears the accumulated totals. */
 int crec_profile_enable(crec_ctx *ctx, int on);
 int crec_profile_read(const crec_ctx *ctx, int kernel_class, double *total_ms, int64_t *launches);
+int crec_profile_read_units(const crec_ctx *ctx, int kernel_class, int64_t *units);
 
 /* ---- RNG: the NumPy legacy global MT19937 stream the samplers draw from -------------
  * replaces np.random.seed / get_state / set_state as used around utils/sampler.py. */

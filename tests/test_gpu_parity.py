@@ -52,11 +52,19 @@ def _run_both(sess, data, d, B, epochs, mode, neg_ratio=4, seed=1, scale=0.01, l
     return st, om, np.concatenate(losses), np.concatenate(olosses)
 
 
+def _assert_v_close(got, ov, name):
+    """v accumulates (1 - beta2) g^2: an error dg of a gradient sum moves it by 2 (1 - beta2) |g| dg, which is small against the
+    LARGEST v of the table wherever g itself cancels -- every element within 1e-5 (north_star's bound) of itself or of that scale"""
+    bad = np.abs(got - ov) > 1e-5 * ov + 1e-5 * ov.max()
+    assert not bad.any(), "%s: %d of %d elements beyond 1e-5 (of the element or of the table's largest v); worst %.3g" % (
+        name, int(bad.sum()), bad.size, float((np.abs(got - ov) / (ov + ov.max())).max()))
+
+
 def _assert_state_close(st, om, atol):
     for name in ("P", "Q", "mP", "mQ"):
         np.testing.assert_allclose(getattr(st, name).cpu().numpy(), getattr(om, name), rtol=0, atol=atol, err_msg=name)
     for name in ("vP", "vQ"):
-        np.testing.assert_allclose(getattr(st, name).cpu().numpy(), getattr(om, name), rtol=1e-4, atol=1e-12, err_msg=name)
+        _assert_v_close(getattr(st, name).cpu().numpy(), getattr(om, name), name)
 
 
 @pytest.mark.parametrize("mode", ["tf1", "lazy"])
@@ -209,6 +217,40 @@ def test_bpr_is_deterministic_at_full_size(sess):
     un, inn, jn = (t[:3 * 6144].cpu().numpy() for t in (u, i, j))
     _, ol = oracle.train_model_py(om, 3, un, inn, jn, 6144)
     np.testing.assert_allclose(outs[0][0][:3], ol, rtol=1e-5)
+
+
+def test_bpr_c2_full_epoch_against_the_oracles(sess):
+    """BASELINE configs[1] as one whole epoch: S-ml1m, d = 64, batch 6144, tf1 Adam, every batch of the sampled epoch (455 full
+    ones and the ragged last) -- the per-batch losses against the C oracle (RankingRecommender.py:39-47 + BPR.py:31-44 +
+    tools.py:83-84 restated in oracle/crec_oracle.c) to 1e-5, and the tables and both Adam slots after the LAST step against the
+    torch restatement under the rounding envelope it propagates through all 456 steps (tests/_adam_close.py; the flat bounds of
+    the short tests are for tens of steps: fp32 rounding noise of 1e-9 per step grows over an epoch, tools/drift.py)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _adam_close import assert_adam_close
+    from oracle import models_torch as MT
+    data = synthetic("S-ml1m")
+    B = 6144
+    P0, Q0 = _tables(3, data.user_nums, data.item_nums, 64)
+    sess.ctx.seed(1)
+    u, i, j = sess.ctx.sample_pairwise(data.train_csr, data.item_nums, 4)
+    nb = -(-len(u) // B)
+    assert nb >= 450 and len(u) % B != 0
+    st = runtime.BprState(sess, P0, Q0, lr=1e-3, reg=0.01, adam_mode="tf1")
+    loss = st.train_epoch(sess.to_dev(u), sess.to_dev(i), sess.to_dev(j), B).cpu().numpy()
+    assert len(loss) == nb and st.adam.step == nb
+    om = oracle.BprModel(P0, Q0, lr=1e-3, reg=0.01, adam_mode=0)
+    _, oloss = oracle.train_model_py(om, nb, u, i, j, B)
+    np.testing.assert_allclose(loss, oloss, rtol=1e-5)
+    mt = MT.BPR(P0, Q0, lr=1e-3, reg=0.01)
+    tl = [mt.step(u[b * B:(b + 1) * B], i[b * B:(b + 1) * B], j[b * B:(b + 1) * B]) for b in range(nb)]
+    np.testing.assert_allclose(loss, tl, rtol=1e-5)
+    report = []
+    assert_adam_close(mt, "P", st.P, st.mP, st.vP, report=report)
+    assert_adam_close(mt, "Q", st.Q, st.mQ, st.vQ, report=report)
+    # ... and the C oracle's tables sit inside the same envelope (two CPU restatements, one GPU kernel: all three agree)
+    assert_adam_close(mt, "P", om.P, om.mP, om.vP)
+    assert_adam_close(mt, "Q", om.Q, om.mQ, om.vQ)
 
 
 @pytest.mark.parametrize("mode", ["lazy", "tf1", "deferred"])
@@ -573,7 +615,7 @@ def test_bpr_deferred_adam_equals_tf1(sess, d):
     for name in ("P", "Q", "mP", "mQ"):
         np.testing.assert_allclose(getattr(st_d, name).cpu().numpy(), getattr(st_t, name).cpu().numpy(), rtol=0, atol=2e-6, err_msg=name)
     for name in ("vP", "vQ"):
-        np.testing.assert_allclose(getattr(st_d, name).cpu().numpy(), getattr(st_t, name).cpu().numpy(), rtol=1e-4, atol=1e-12, err_msg=name)
+        _assert_v_close(getattr(st_d, name).cpu().numpy(), getattr(st_t, name).cpu().numpy(), name)
     assert int(st_d.lastP.min()) == int(st_d.lastQ.min()) == st_d.adam.step == st_t.adam.step
 
 

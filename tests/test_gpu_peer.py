@@ -10,6 +10,7 @@ import json
 import os
 import socket
 import subprocess
+import time
 import sys
 import threading
 
@@ -153,8 +154,11 @@ def test_bench_with_two_ranks_rehearsed_on_one_gpu(launcher):
     args = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--cpu-steps", "0"]
     if launcher == "torchrun":
         args = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", env.pop("MASTER_PORT")] + args
+    t0 = time.perf_counter()
     cp = subprocess.run([sys.executable] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=400)
+    took = time.perf_counter() - t0
     assert cp.returncode == 0, cp.stderr[-2000:]
+    assert took < 90, "the two-rank rehearsal took %.0f s" % took  # (the driver's scaling run has a wall-clock limit per world size)
     lines = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, cp.stdout[-1000:]
     b = json.loads(lines[0])
@@ -164,3 +168,43 @@ def test_bench_with_two_ranks_rehearsed_on_one_gpu(launcher):
     assert "error" not in sb["larger_batch"] and sb["larger_batch"]["triples_per_s"] > 0
     x = sb["exchange_per_rank_per_step"]
     assert x["bytes_rows_sent"] > 0 and abs(x["bytes_rows_sent"] - x["bytes_grads_sent"]) < 0.02 * x["bytes_rows_sent"]
+    assert b["leg_seconds"]["canary"] < 45 and "leg_errors" not in b
+
+
+def test_bench_with_a_failed_canary_still_prints_its_line():
+    """A node whose GPUs cannot map each other's windows (forced: CREC_CANARY_FORCE_FAIL=1): both canary forms fail at once, the
+    failure is on stderr and in the line; on a real node the run would go on over RCCL -- on ONE shared GPU RCCL cannot carry two
+    ranks, so the headline fails, and rank 0 STILL prints exactly one line that says so, with a non-zero exit code."""
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, CREC_BENCH_ONE_GPU="1", CREC_CANARY_FORCE_FAIL="1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    cp = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--cpu-steps", "0"], env=env,
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=200)
+    assert cp.returncode != 0
+    lines = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, cp.stdout[-1000:]
+    b = json.loads(lines[0])
+    assert b["value"] is None and "canary" in b["error"] and b["peer_canary"]["rc"] != 0
+    assert "canary" in cp.stderr and "failed" in cp.stderr
+
+
+def test_bench_over_rccl_at_a_world_of_one():
+    """The fall-back transport end to end: CREC_TRANSPORT=rccl with the N > 1 code path forced at a world of one (CREC_FORCE_DP=1) --
+    the replicated-Q headline epoch with RCCL's all-reduce in the loop and both S-big row-sharded legs through grouped
+    ncclSend / ncclRecv on a one-rank communicator."""
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, CREC_TRANSPORT="rccl", CREC_FORCE_DP="1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    t0 = time.perf_counter()
+    cp = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--cpu-steps", "0"], env=env,
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=400)
+    assert cp.returncode == 0, cp.stderr[-2000:]
+    lines = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, cp.stdout[-1000:]
+    b = json.loads(lines[0])
+    assert b["transport"] == "rccl" and b["value"] > 0 and "leg_errors" not in b, b.get("leg_errors")
+    sb = b["synthetic_big"]
+    assert "error" not in sb and sb["triples_per_s"] > 0 and "error" not in sb["larger_batch"] and sb["larger_batch"]["triples_per_s"] > 0
+    assert time.perf_counter() - t0 < 240
