@@ -705,6 +705,13 @@ __device__ __forceinline__ float4 ld4_sc1(const float *base, int64_t off)
     const crec_u4v x = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(off * 4), 0, 16 /* sc1 */);
     return make_float4(__uint_as_float(x.x), __uint_as_float(x.y), __uint_as_float(x.z), __uint_as_float(x.w));
 }
+// the same load without a scope bit (cached like a plain load; a scalar base and a 32-bit offset instead of a 64-bit address per lane)
+__device__ __forceinline__ float4 ld4_buf(const float *base, int64_t off)
+{
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, 0x7fffffff, 0x00020000);
+    const crec_u4v x = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(off * 4), 0, 0);
+    return make_float4(__uint_as_float(x.x), __uint_as_float(x.y), __uint_as_float(x.z), __uint_as_float(x.w));
+}
 // the lazy step's published rows (contributions, partials): agent-scope accesses + s_waitcnt, or -- CREC_TICKET_FENCES,
 // the textbook form kept buildable and compared bit for bit under test (tests/test_gpu_fences.py) -- plain accesses
 // bracketed by device-scope fences
@@ -1023,21 +1030,9 @@ template <int R> struct WaveCtx {
     bool act;
     int e[R]; // wave-uniform segment ends of the slots
     float reg;
-    // bpr_steps_flow: the gathered rows are versions other waves of this launch publish (served where the XCDs meet, validated
-    // against the sentinel); `err`: the launch's give-up flag
-    bool hist = false;
-    int32_t *err = nullptr;
 };
 
-// one gathered float4 of the row `row` of `base`: a plain load, or (FLOW, a published version) an agent-scope one
-template <bool FLOW> __device__ __forceinline__ float4 ld4_row(const float *base, int64_t off, bool hist)
-{
-    if (FLOW && hist)
-        return ld4_sc1(base, off);
-    return ld4(base + off);
-}
-
-template <int LPR, int RW, int MODE, bool FLOW = false>
+template <int LPR, int RW, int MODE>
 __device__ __forceinline__ void trip_issue(Trip &tr, const WaveCtx<Geo<LPR, RW>::R> &w, const int4 &mine, int c0, int nc,
                                            int n_sub, int t0)
 {
@@ -1055,19 +1050,18 @@ __device__ __forceinline__ void trip_issue(Trip &tr, const WaveCtx<Geo<LPR, RW>:
             s += k >= w.e[q];
         tr.slot[t] = s;
         tr.a[t] = tr.b[t] = zero;
-        // FULL: a dead slot's record is all zeros -> row 0, a harmless load, so no exec-mask branch is needed.  (FLOW: row 0's
-        // version may still hold the sentinel, a NaN, and 0 * NaN would poison the slot sums: dead slots load nothing)
-        if ((Geo<LPR, RW>::FULL && !FLOW) || (tr.has[t] && w.act)) {
+        // FULL: a dead slot's record is all zeros -> row 0, a harmless load, so no exec-mask branch is needed
+        if (Geo<LPR, RW>::FULL || (tr.has[t] && w.act)) {
             if (CREC_ABL & 1) {
                 tr.a[t] = ld4(w.Q + (int64_t)(tr.rec[t].y & 3) * w.d + 4 * w.l);
                 tr.b[t] = ld4(w.Q + (int64_t)(tr.rec[t].z & 3) * w.d + 4 * w.l);
             } else if (MODE == 0) {
-                tr.a[t] = ld4_row<FLOW>(w.Q, (int64_t)tr.rec[t].y * w.d + 4 * w.l, w.hist);
-                tr.b[t] = ld4_row<FLOW>(w.Q, (int64_t)tr.rec[t].z * w.d + 4 * w.l, w.hist);
+                tr.a[t] = ld4(w.Q + (int64_t)tr.rec[t].y * w.d + 4 * w.l);
+                tr.b[t] = ld4(w.Q + (int64_t)tr.rec[t].z * w.d + 4 * w.l);
             } else if (MODE == 1) {
-                tr.a[t] = ld4_row<FLOW>(w.P, (int64_t)tr.rec[t].x * w.d + 4 * w.l, w.hist);
+                tr.a[t] = ld4(w.P + (int64_t)tr.rec[t].x * w.d + 4 * w.l);
                 const int other = tr.rec[t].w < 0 ? tr.rec[t].y : tr.rec[t].z;
-                tr.b[t] = ld4_row<FLOW>(w.Q, (int64_t)other * w.d + 4 * w.l, w.hist);
+                tr.b[t] = ld4(w.Q + (int64_t)other * w.d + 4 * w.l);
             } else {
                 tr.a[t] = ld4(w.contrib + (int64_t)(tr.rec[t].w & 0x7fffffff) * w.d + 4 * w.l);
             }
@@ -1127,65 +1121,10 @@ __device__ __forceinline__ void trip_consume(const Trip &tr, const WaveCtx<Geo<L
     }
 }
 
-// bpr_steps_flow: a row version that has not been published yet reads as the sentinel (every 4-byte word of it, so nothing
-// rests on how wide a store lands at once); a published word is never the sentinel (flow_publish)
-constexpr uint32_t FLOW_SENT = 0xffffffffu;
-constexpr unsigned FLOW_SPIN_CHECK = 1u << 12, FLOW_SPIN_LIMIT = 1u << 23; // polls between looks at the give-up flag; polls (each at
-                                                                           // least a memory round trip) before a wave gives up itself
-__device__ __forceinline__ bool flow_unset(float4 v)
-{
-    // (all four words: nothing rests on how wide a store lands at once; integer logic, no short-circuit branches)
-    return ((int)(__float_as_uint(v.x) == FLOW_SENT) | (int)(__float_as_uint(v.y) == FLOW_SENT) | (int)(__float_as_uint(v.z) == FLOW_SENT) |
-            (int)(__float_as_uint(v.w) == FLOW_SENT)) != 0;
-}
-// the trip's gathered rows are there: lanes that read the sentinel ask again until their rows' owners have published.  Every
-// wave leaves this loop: when the rows arrive, when another wave has raised the give-up flag, or after FLOW_SPIN_LIMIT polls
-template <int LPR, int RW, int MODE>
-__device__ __forceinline__ void flow_validate(Trip &tr, const WaveCtx<Geo<LPR, RW>::R> &w)
-{
-    if (!w.hist || !w.err) // (no flag: the timing ablation that does not wait)
-        return;
-    unsigned spins = 0;
-    for (;;) {
-        bool bad[UNR], any = false;
-#pragma unroll
-        for (int t = 0; t < UNR; ++t) {
-            bad[t] = tr.has[t] && w.act && (flow_unset(tr.a[t]) || flow_unset(tr.b[t]));
-            any |= bad[t];
-        }
-        if (__ballot(any) == 0)
-            return;
-        __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-        for (int t = 0; t < UNR; ++t) {
-            if (bad[t]) {
-                if (MODE == 0) {
-                    tr.a[t] = ld4_sc1(w.Q, (int64_t)tr.rec[t].y * w.d + 4 * w.l);
-                    tr.b[t] = ld4_sc1(w.Q, (int64_t)tr.rec[t].z * w.d + 4 * w.l);
-                } else {
-                    tr.a[t] = ld4_sc1(w.P, (int64_t)tr.rec[t].x * w.d + 4 * w.l);
-                    const int other = tr.rec[t].w < 0 ? tr.rec[t].y : tr.rec[t].z;
-                    tr.b[t] = ld4_sc1(w.Q, (int64_t)other * w.d + 4 * w.l);
-                }
-            }
-        }
-        if ((++spins & (FLOW_SPIN_CHECK - 1)) == 0) {
-            const bool stop = spins >= FLOW_SPIN_LIMIT || __hip_atomic_load(w.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-            if (stop) {
-                if ((threadIdx.x & 63) == 0)
-                    __hip_atomic_store(w.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return;
-            }
-        }
-    }
-}
-
 // walk the occurrence records [k_begin, k_end) of this wave
-// (FLOW: `pre` holds the records [pf, pf + 64) of `occ`, asked for a step ahead; a chunk inside that window is taken from there)
-template <int LPR, int RW, int MODE, bool STORE_CONTRIB, bool FLOW = false>
+template <int LPR, int RW, int MODE, bool STORE_CONTRIB>
 __device__ __forceinline__ void walk_range(const WaveCtx<Geo<LPR, RW>::R> &w, float4 var, AccArr<LPR, RW> &acc,
-                                           const int4 *__restrict__ occ, int k_begin, int k_end, int4 pre = make_int4(0, 0, 0, 0),
-                                           int pf = 0x7fffffff)
+                                           const int4 *__restrict__ occ, int k_begin, int k_end)
 {
     constexpr int G = Geo<LPR, RW>::G;
     const int lane = threadIdx.x & 63;
@@ -1193,11 +1132,7 @@ __device__ __forceinline__ void walk_range(const WaveCtx<Geo<LPR, RW>::R> &w, fl
         k_end = k_begin + 16;
     for (int c0 = k_begin; c0 < k_end; c0 += 64) {
         const int nc = (k_end - c0) < 64 ? (k_end - c0) : 64;
-        int4 mine;
-        if (FLOW && c0 >= pf && c0 - pf + nc <= 64)
-            mine = shfl4(pre, (lane + (c0 - pf)) & 63);
-        else
-            mine = lane < nc ? occ[c0 + lane] : make_int4(0, 0, 0, 0);
+        const int4 mine = lane < nc ? occ[c0 + lane] : make_int4(0, 0, 0, 0);
 #ifndef CREC_STAMP_VAR
         if (c0 == k_begin)
             crec_mark(1, mine.x); // the first chunk of records has arrived
@@ -1205,38 +1140,32 @@ __device__ __forceinline__ void walk_range(const WaveCtx<Geo<LPR, RW>::R> &w, fl
         const int n_sub = (nc + G - 1) / G;
         if (PIPELINED) {
             Trip ta, tb;
-            trip_issue<LPR, RW, MODE, FLOW>(ta, w, mine, c0, nc, n_sub, 0);
+            trip_issue<LPR, RW, MODE>(ta, w, mine, c0, nc, n_sub, 0);
             for (int t0 = 0; t0 < n_sub; t0 += 2 * UNR) {
                 if (t0 + UNR < n_sub)
-                    trip_issue<LPR, RW, MODE, FLOW>(tb, w, mine, c0, nc, n_sub, t0 + UNR);
-                if (FLOW)
-                    flow_validate<LPR, RW, MODE>(ta, w);
+                    trip_issue<LPR, RW, MODE>(tb, w, mine, c0, nc, n_sub, t0 + UNR);
                 trip_consume<LPR, RW, MODE, STORE_CONTRIB>(ta, w, var, acc);
                 if (t0 + UNR >= n_sub)
                     break;
                 if (t0 + 2 * UNR < n_sub)
-                    trip_issue<LPR, RW, MODE, FLOW>(ta, w, mine, c0, nc, n_sub, t0 + 2 * UNR);
-                if (FLOW)
-                    flow_validate<LPR, RW, MODE>(tb, w);
+                    trip_issue<LPR, RW, MODE>(ta, w, mine, c0, nc, n_sub, t0 + 2 * UNR);
                 trip_consume<LPR, RW, MODE, STORE_CONTRIB>(tb, w, var, acc);
             }
         } else {
             for (int t0 = 0; t0 < n_sub; t0 += UNR) {
                 Trip ta;
-                trip_issue<LPR, RW, MODE, FLOW>(ta, w, mine, c0, nc, n_sub, t0);
-                if (FLOW)
-                    flow_validate<LPR, RW, MODE>(ta, w);
+                trip_issue<LPR, RW, MODE>(ta, w, mine, c0, nc, n_sub, t0);
                 trip_consume<LPR, RW, MODE, STORE_CONTRIB>(ta, w, var, acc);
             }
         }
     }
 }
 
-template <int LPR, int RW, int MODE, bool STORE_CONTRIB, bool FLOW = false>
+template <int LPR, int RW, int MODE, bool STORE_CONTRIB>
 __device__ __forceinline__ float4 slots_grad(float4 var, const Slot &sl, int n_valid, const float *__restrict__ P,
                                     const float *__restrict__ Q, int d, const int4 *__restrict__ occ,
                                     float *__restrict__ contrib, float *__restrict__ xb, const Hyper &h, int part = 0,
-                                    int nparts = 1, bool hist = false, int32_t *err = nullptr)
+                                    int nparts = 1)
 {
     constexpr int R = Geo<LPR, RW>::R;
     const int lane = threadIdx.x & 63;
@@ -1250,8 +1179,6 @@ __device__ __forceinline__ float4 slots_grad(float4 var, const Slot &sl, int n_v
     w.l = lane % LPR;
     w.act = Geo<LPR, RW>::FULL ? true : 4 * w.l < d;
     w.reg = h.reg;
-    w.hist = hist;
-    w.err = err;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     int st[R], cn[R]; // wave-uniform copies of the slots' segments
 #pragma unroll
@@ -1290,7 +1217,7 @@ __device__ __forceinline__ float4 slots_grad(float4 var, const Slot &sl, int n_v
     }
     if (!any_heavy) { // the usual case: the slots' segments are one contiguous range
         if (last > first)
-            walk_range<LPR, RW, MODE, STORE_CONTRIB, FLOW>(w, var, acc, occ, first, last);
+            walk_range<LPR, RW, MODE, STORE_CONTRIB>(w, var, acc, occ, first, last);
     } else { // a heavy slot sits in the middle: walk the other slots one by one
 #pragma unroll 1
         for (int s = 0; s < n_valid; ++s) {
@@ -1301,7 +1228,7 @@ __device__ __forceinline__ float4 slots_grad(float4 var, const Slot &sl, int n_v
                 c = s == q ? cn[q] : c;
             }
             if (c > 0)
-                walk_range<LPR, RW, MODE, STORE_CONTRIB, FLOW>(w, var, acc, occ, b, b + c);
+                walk_range<LPR, RW, MODE, STORE_CONTRIB>(w, var, acc, occ, b, b + c);
         }
     }
     return reduce_to_owner<LPR, RW>(acc);
@@ -1687,19 +1614,26 @@ __global__ __launch_bounds__(CREC_FUSED_BLOCK) void bpr_step_fused(Tables src, T
 }
 
 // ------------------------------------------------------------------------------------
-// tf1 mode, ALL steps of a chunk in one launch: bpr_steps_flow (round 4).
+// tf1 mode, ALL steps of a chunk in one launch: bpr_steps_flow (round 4; opt-in, option "flow").
 //
 // bpr_step_fused is bound by what surrounds its waves -- a dispatch per step, every row read from and written to memory per
 // step, three dependent round trips per row wave -- not by bytes.  Here a lane group OWNS a table row for up to
-// FLOW_MAX_STEPS consecutive steps and keeps the row and its Adam slots in registers; what the other waves need of it, the row's
-// values after step k, it publishes once per step into a version history (hist[k][row], written through to where the XCDs
-// meet), and its own gathers of step k + 1 read that version of the rows they need.  There is no barrier and no flag: an
-// unpublished slot holds a sentinel in every word, a gather that reads the sentinel asks again (flow_validate), so the steps of
-// different rows overlap as far as the batches' own dependences allow -- a dataflow execution of exactly the sequential
-// arithmetic (the same walk, the same sums in the same order as a launch per step with this row-to-wave assignment).
+// FLOW_MAX_STEPS consecutive steps and keeps the row and its Adam slots in registers; what the other workgroups need of it, the
+// row's values after step k, it publishes once per step into a version history (hist[k][row], written through to where the
+// XCDs meet), and the gathers of step k + 1 read that version of the rows they need.  There is no device-wide barrier and no flag:
+// an unpublished slot holds a sentinel in every word, a gather that reads the sentinel asks again, so the steps of different rows
+// overlap as far as the batches' own dependences allow -- a dataflow execution of exactly the sequential arithmetic.
 //   * rows are dealt to workgroups round-robin (row r: workgroup r mod NWG, slot r div NWG), so that neighbouring popular
-//     rows do not share a wave; the index kernel sorts by that position (IndexWs::flow_*), which keeps a wave's records
-//     contiguous exactly as in bpr_step_fused
+//     rows do not share a workgroup; the index kernel sorts by that position (IndexWs::flow_*), which makes the records of a
+//     workgroup's rows ONE contiguous range of the sorted list
+//   * a step of a workgroup: (A) its records are dealt to ALL its lane groups, whichever slot they belong to -- the slots' rows
+//     and the records sit in LDS -- each group gathers its records' other rows, forms x, s and the record's contribution row and
+//     leaves it in LDS; (B) every owner adds its slot's contribution rows in record (= batch) order, applies Adam to its
+//     registers, publishes the row and puts it back into LDS for the next step.  Two workgroup barriers per step; every sum has
+//     one order, whatever the timing and however the steps are cut into launches
+//   * what does not depend on other workgroups is asked for ahead: a step's records two steps, its segments four steps before;
+//     every wait for such a load stands BEFORE the step's publishing store (vector memory operations retire in issue order: a
+//     wait behind a written-through store costs the store's round trip)
 //   * every wave of the launch must be resident (the host checks the occupancy before it takes this path); a wave waits only
 //     for rows whose owners are resident and never wait for IT within the same step, and every wait gives up after
 //     FLOW_SPIN_LIMIT polls or when another wave has given up (FlowArgs::err, reported by the host as an error)
@@ -1707,11 +1641,16 @@ __global__ __launch_bounds__(CREC_FUSED_BLOCK) void bpr_step_fused(Tables src, T
 //     before it filled in the other (each owner its own rows, one slot per step), so no memset sits between launches
 // ------------------------------------------------------------------------------------
 constexpr int FLOW_MAX_STEPS = 64;
+constexpr uint32_t FLOW_SENT = 0xffffffffu; // an unpublished row version: this in every 4-byte word (nothing rests on how wide a store
+                                            // lands at once); a published word is never this (flow_publishable)
+constexpr unsigned FLOW_SPIN_CHECK = 1u << 12, FLOW_SPIN_LIMIT = 1u << 23; // polls between looks at the give-up flag; polls (each at
+                                                                           // least a memory round trip) before a wave gives up itself
 struct FlowArgs {
     const int2 *u_rowseg, *q_rowseg; // [C][Upos], [C][Ipos]: {segment start, length} by POSITION (workgroup * rows per workgroup + slot)
     const int4 *u_occ, *q_occ;       // [C][B], [C][2B]
     int64_t Upos, Ipos, B;
     int nwg_u, nwg_q;                // workgroups per side = the modulus of the row dealing
+    uint32_t magic_u, magic_q;       // floor(2^32 / nwg): flow_pos_of
     int C;                           // steps of this launch
     float *histP, *histQ;            // [C - 1][U * d], [C - 1][I * d]: the versions after steps 1 .. C - 1, all sentinel on entry
     float *nextP, *nextQ;            // the other history: slots [0, dirty_next) get the sentinel back
@@ -1725,6 +1664,11 @@ struct FlowArgs {
     float lr_t[FLOW_MAX_STEPS];
 };
 
+__device__ __forceinline__ bool flow_unset(float4 v) // (integer logic, no short-circuit branches)
+{
+    return ((int)(__float_as_uint(v.x) == FLOW_SENT) | (int)(__float_as_uint(v.y) == FLOW_SENT) | (int)(__float_as_uint(v.z) == FLOW_SENT) |
+            (int)(__float_as_uint(v.w) == FLOW_SENT)) != 0;
+}
 __device__ __forceinline__ float4 flow_publishable(float4 v) // a NaN that happens to carry the sentinel's bits becomes the canonical one
 {
     const auto fix = [](float x) { return __float_as_uint(x) == FLOW_SENT ? __uint_as_float(0x7fc00000u) : x; };
@@ -1734,38 +1678,44 @@ __device__ __forceinline__ float4 flow_publishable(float4 v) // a NaN that happe
 #ifndef CREC_FLOW_WAVES
 #define CREC_FLOW_WAVES 3 // waves per SIMD bpr_steps_flow is compiled for: all of its waves must be resident at once
 #endif
-#ifndef CREC_FLOW_HEAVY
-#define CREC_FLOW_HEAVY 8 // a slot with more occurrences in the batch is walked by the whole workgroup
+#ifndef CREC_FLOW_DEEP
+#define CREC_FLOW_DEEP 4 // records a lane group has in flight (two gathered rows each)
 #endif
-// One wave of bpr_steps_flow.  Slot q of the workgroup (q = wave * R + lane group) holds row q * nwg + j.  Per step:
-//   * the segments of ALL the workgroup's slots sit in lanes 0 .. RPB - 1 (asked for two steps ahead), the wave's first 64
-//     records in `pre` (asked for a step ahead): the step's only dependent round trip is the gathers themselves
-//   * light slots: the wave walks its own slots' records as bpr_step_fused does (runs of consecutive light slots)
-//   * heavy slots (more than CREC_FLOW_HEAVY occurrences): the owner puts the row into LDS, all waves of the workgroup walk a
-//     quarter of the slot's records each (slots_grad with R = 1: the same split as wide_group), the four partials meet in LDS
-//     and the owner adds them in wave order -- a fixed order given the slot's count.  Two barriers, and only in steps where the
-//     workgroup has a heavy slot (the same decision in every wave: it is a function of the segments)
+template <int LPR> struct FlowGeo {
+    static constexpr int G = 64 / LPR;                                  // lane groups per wave
+    static constexpr int R = G < ROWS_PER_WAVE ? G : ROWS_PER_WAVE;     // slots (rows) per wave
+    static constexpr int WPB = CREC_FUSED_BLOCK / 64, RPB = R * WPB;    // slots per workgroup
+    static constexpr int NG = G * WPB;                                  // lane groups per workgroup
+    static constexpr int NREC_ = 32768 / (LPR * 16);                    // records per round: 32 KB of contribution rows
+    static constexpr int NREC = NREC_ > 256 ? 256 : NREC_;
+    static constexpr int SEGRING = 5;                                   // steps of segments kept in LDS (asked for four steps ahead)
+    // LDS, in float4 units: the slots' rows, the round's contribution rows, two buffers of records, the ring of segments
+    static constexpr int OFF_VAR = 0, OFF_CON = OFF_VAR + RPB * LPR, OFF_REC = OFF_CON + NREC * LPR, OFF_SEG = OFF_REC + 2 * NREC;
+    static constexpr int LDS_F4 = OFF_SEG + (SEGRING * (RPB + 1) * 2 + 3) / 4 + 1;
+};
+
+// One workgroup of bpr_steps_flow (see the header above).  MODE 0: user rows (records {u, i, j, pos}: gathers q_i, q_j), 1: item rows
+// (gathers p_u and the triple's other item row; bit 31 of pos: the owned row is the triple's j)
 template <int LPR, int MODE, bool FULL>
 __device__ __forceinline__ void flow_wave(const Tables &src, const Tables &dst, int d, int64_t U, int64_t n_rows, int j, int nwg,
-                                          const int2 *__restrict__ rowseg, int64_t pos_stride, const int4 *__restrict__ occ,
-                                          int64_t occ_stride, float *hist_own, float *next_own, int64_t h_own, const FlowArgs &f,
-                                          const Hyper &h, float4 *__restrict__ lds)
+                                          uint32_t magic, const int2 *__restrict__ rowseg, int64_t pos_stride,
+                                          const int4 *__restrict__ occ, int64_t occ_stride, float *hist_own, float *next_own,
+                                          int64_t h_own, const FlowArgs &f, const Hyper &h, float4 *__restrict__ lds)
 {
-    constexpr int RW = ROWS_PER_WAVE | (FULL ? 0x100 : 0), RW1 = 1 | (FULL ? 0x100 : 0), R = Geo<LPR, RW>::R;
-    constexpr int WPB = CREC_FUSED_BLOCK / 64, RPB = R * WPB;
+    using Geo_ = FlowGeo<LPR>;
+    constexpr int G = Geo_::G, R = Geo_::R, RPB = Geo_::RPB, NG = Geo_::NG, NREC = Geo_::NREC, SEGRING = Geo_::SEGRING, DEEP = CREC_FLOW_DEEP;
     constexpr bool user = MODE == 0;
-    const int lane = threadIdx.x & 63, g = lane / LPR, l = lane % LPR;
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    float4 *hvar = lds, *hpart = lds + RPB * LPR; // [RPB][LPR], [RPB][WPB][LPR]
-    // the wave's rows ascend with g, so the valid ones are a prefix (a wave without rows still helps with heavy slots)
-    int n_valid = 0;
-#pragma unroll
-    for (int q = 0; q < R; ++q)
-        n_valid += ((int64_t)(wv * R + q) * nwg + j < n_rows) ? 1 : 0;
-    const int gs = g < n_valid ? g : 0;
-    const int64_t row = (int64_t)(wv * R + gs) * nwg + j;
+    const int tid = threadIdx.x, lane = tid & 63, g = lane / LPR, l = lane % LPR;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int gi = wv * G + g; // this lane group among the workgroup's
+    float4 *l_var = lds + Geo_::OFF_VAR, *l_con = lds + Geo_::OFF_CON;
+    int4 *l_rec = reinterpret_cast<int4 *>(lds + Geo_::OFF_REC);
+    int *l_seg = reinterpret_cast<int *>(lds + Geo_::OFF_SEG); // [SEGRING][RPB + 1][2]: {start, count} per slot; entry RPB: {end of the range, 0}
+    // ownership: slot sw = wv * R + g (g < R) holds row sw * nwg + j
+    const int sw = wv * R + (g < R ? g : 0);
+    const int64_t row = (int64_t)sw * nwg + j;
     const bool act = FULL || 4 * l < d;
-    const bool owner = g < R && g < n_valid && act;
+    const bool owner = g < R && row < n_rows && act;
     const int64_t ro = row * d + 4 * l;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 var = zero, m = zero, v = zero;
@@ -1773,21 +1723,47 @@ __device__ __forceinline__ void flow_wave(const Tables &src, const Tables &dst, 
         var = ld4((user ? src.P : src.Q) + ro);
         m = ld4s((user ? src.mP : src.mQ) + ro);
         v = ld4s((user ? src.vP : src.vQ) + ro);
+        l_var[sw * LPR + l] = var;
     }
-    const int q_reset = (f.dirty_next + f.C - 1) / f.C; // slots of the other history this wave resets per step
+    const int q_reset = (f.dirty_next + f.C - 1) / f.C; // slots of the other history an owner resets per step
     const crec_f4v sent = {__uint_as_float(FLOW_SENT), __uint_as_float(FLOW_SENT), __uint_as_float(FLOW_SENT), __uint_as_float(FLOW_SENT)};
-    const int2 *seg_at = rowseg + (int64_t)j * RPB + (lane < RPB ? lane : RPB - 1);
-    const int last_own = wv * R + (n_valid > 0 ? n_valid - 1 : 0);
-    const auto own_range = [&](int2 seg, int &first, int &last) { // the records of the wave's own slots
-        first = __builtin_amdgcn_readlane(seg.x, wv * R);
-        last = n_valid > 0 ? __builtin_amdgcn_readlane(seg.x, last_own) + __builtin_amdgcn_readlane(seg.y, last_own) : first;
+    // ---- what does not depend on anybody, asked for ahead.  Segments: thread t < RPB holds slot t's {start, count} of steps
+    // k + 3 and k + 4 (two register stages), steps k .. k + 2 sit in the LDS ring; records: thread t holds record t of step k + 2's
+    // first round (one register stage), steps k and k + 1 sit in the two LDS buffers
+    const int2 *seg_at = rowseg + (int64_t)j * RPB + (tid < RPB ? tid : RPB - 1);
+    const auto seg_load = [&](int step) { return step < f.C ? seg_at[(int64_t)step * pos_stride] : make_int2(0, 0); };
+    const auto seg_stage = [&](int step, int2 sg) {
+        if (tid < RPB) {
+            int *e = l_seg + ((step % SEGRING) * (RPB + 1) + tid) * 2;
+            e[0] = sg.x, e[1] = sg.y;
+            if (tid == RPB - 1)
+                e[2] = sg.x + sg.y, e[3] = 0;
+        }
     };
-    int2 seg_cur = seg_at[0], seg_nxt = f.C > 1 ? seg_at[pos_stride] : make_int2(0, 0);
-    int pf_cur, pl_cur;
-    own_range(seg_cur, pf_cur, pl_cur);
-    int4 pre_cur = lane < pl_cur - pf_cur ? occ[pf_cur + lane] : make_int4(0, 0, 0, 0);
+    const auto seg_first = [&](int step) { return l_seg[(step % SEGRING) * (RPB + 1) * 2]; };
+    const auto seg_end = [&](int step) { return l_seg[((step % SEGRING) * (RPB + 1) + RPB) * 2]; };
+    const auto rec_load = [&](int step) { // record tid of the step's range (its first round)
+        int4 r = make_int4(0, 0, 0, 0);
+        if (step < f.C) {
+            const int F = seg_first(step), L = seg_end(step);
+            if (tid < NREC && tid < L - F)
+                r = occ[(int64_t)step * occ_stride + F + tid];
+        }
+        return r;
+    };
+    seg_stage(0, seg_load(0));
+    seg_stage(1, seg_load(1));
+    seg_stage(2, seg_load(2));
+    int2 seg_a = seg_load(3), seg_b = seg_load(4); // steps k + 3, k + 4
+    __syncthreads();
+    if (tid < NREC) {
+        l_rec[tid] = rec_load(0);
+        l_rec[NREC + tid] = rec_load(1);
+    }
+    int4 rec_a = rec_load(2); // step k + 2
+    __syncthreads();
 #ifdef CREC_STAMPS // tools/flow_stamps.py: phase times of every wave in one step of the launch ([wave][8], 100 MHz clock)
-    const int stamp_wave = blockIdx.x * WPB + wv;
+    const int stamp_wave = blockIdx.x * Geo_::WPB + wv;
 #define CREC_FLOW_MARK(slot, dep)                                                                                     \
     do {                                                                                                              \
         asm volatile("" ::"v"(dep));                                                                                  \
@@ -1798,114 +1774,152 @@ __device__ __forceinline__ void flow_wave(const Tables &src, const Tables &dst, 
 #define CREC_FLOW_MARK(slot, dep)
 #endif
     for (int k = 0; k < f.C; ++k) {
-        const int4 *occ_k = occ + (int64_t)k * occ_stride;
         CREC_FLOW_MARK(0, 0);
-        // nothing below depends on another wave: the segments of step k + 2 and the records of step k + 1
-        int2 seg_nn = make_int2(0, 0);
-        if (k + 2 < f.C)
-            seg_nn = seg_at[(int64_t)(k + 2) * pos_stride];
-        int pf_nxt = 0, pl_nxt = 0;
-        int4 pre_nxt = make_int4(0, 0, 0, 0);
-        if (k + 1 < f.C) {
-            own_range(seg_nxt, pf_nxt, pl_nxt);
-            if (lane < pl_nxt - pf_nxt)
-                pre_nxt = occ_k[occ_stride + pf_nxt + lane];
-        }
+        const int4 *occ_k = occ + (int64_t)k * occ_stride;
         const bool hist = k > 0 && !(f.abl & 2);
         const float *Pk = hist ? f.histP + (int64_t)(k - 1) * f.hP : src.P;
         const float *Qk = hist ? f.histQ + (int64_t)(k - 1) * f.hQ : src.Q;
         float *xb = f.loss_ws + (int64_t)k * f.loss_stride;
-        int32_t *err = (f.abl & 1) ? nullptr : f.err;
         Hyper hk = h;
         hk.lr_t = f.lr_t[k];
-        // heavy slots of the workgroup (bit q: slot q)
-        const uint64_t hmask = (f.abl & 8) ? 0ull : __ballot(lane < RPB && seg_cur.y > CREC_FLOW_HEAVY);
-        const int cnt_own = g < n_valid ? __shfl(seg_cur.y, wv * R + gs, 64) : 0;
-        const bool heavy_own = ((hmask >> (wv * R + gs)) & 1ull) != 0;
-        // ---- light slots: the wave's own walk
-        WaveCtx<R> w;
-        w.P = Pk, w.Q = Qk, w.contrib = nullptr, w.xb = xb, w.d = d, w.g = g, w.l = l, w.act = act, w.reg = hk.reg, w.hist = hist, w.err = err;
-        AccArr<LPR, RW> acc;
-        // runs of consecutive light slots (their records are contiguous): at most (R + 1) / 2 of them
-        constexpr int NRUN = (R + 1) / 2;
-        int run_b[NRUN], run_e[NRUN], n_run = 0;
+        const int F = seg_first(k), L = seg_end(k), n_all = L - F; // the workgroup's records of this step
+        const int4 *rec_buf = l_rec + (k & 1) * NREC;
+        float4 grad = zero;
+        const int my_start = l_seg[((k % SEGRING) * (RPB + 1) + sw) * 2] - F, my_cnt = g < R ? l_seg[((k % SEGRING) * (RPB + 1) + sw) * 2 + 1] : 0;
+        for (int r0 = 0; r0 == 0 || r0 < n_all; r0 += NREC) { // rounds of NREC records (one, unless rows are very heavy)
+            const int n_round = (n_all - r0) < NREC ? (n_all - r0) : NREC;
+            if (r0 > 0) { // a further round: its records come straight from memory
+                __syncthreads();
+                if (tid < n_round)
+                    l_rec[(k & 1) * NREC + tid] = occ_k[F + r0 + tid];
+                __syncthreads();
+            }
+            // ---- (A) the round's records, dealt to all lane groups: record q of the round goes to group q mod NG
+            for (int q0 = gi; q0 < n_round; q0 += NG * DEEP) {
+                int4 rec[DEEP];
+                float4 a[DEEP], b[DEEP];
+                bool has[DEEP];
+                // every load of the trip is issued before the first one is waited for: NO per-lane condition around a load (the
+                // compiler would wait for each before the next), dead groups read row 0 and drop it, lanes beyond d read lane 0's slice
+                int64_t oa[DEEP], ob[DEEP];
 #pragma unroll
-        for (int r_ = 0; r_ < NRUN; ++r_)
-            run_b[r_] = run_e[r_] = 0;
-        {
-            int rb = -1, re = 0;
-#pragma unroll
-            for (int s_ = 0; s_ < R; ++s_) {
-                acc[s_] = zero;
-                const int st_s = __builtin_amdgcn_readlane(seg_cur.x, wv * R + s_);
-                const int cn_s = s_ < n_valid ? __builtin_amdgcn_readlane(seg_cur.y, wv * R + s_) : 0;
-                w.e[s_] = s_ < n_valid ? st_s + cn_s : 0x7fffffff;
-                const bool light = s_ < n_valid && ((hmask >> (wv * R + s_)) & 1ull) == 0;
-                if (light) {
-                    rb = rb < 0 ? st_s : rb;
-                    re = st_s + cn_s;
+                for (int t = 0; t < DEEP; ++t) {
+                    const int q = q0 + t * NG;
+                    has[t] = q < n_round;
+                    rec[t] = rec_buf[has[t] ? q : 0];
+                    const int ra = has[t] ? (user ? rec[t].y : rec[t].x) : 0, rb = has[t] ? (user ? rec[t].z : (rec[t].w < 0 ? rec[t].y : rec[t].z)) : 0;
+                    oa[t] = (int64_t)ra * d + (act ? 4 * l : 0);
+                    ob[t] = (int64_t)rb * d + (act ? 4 * l : 0);
                 }
-                if ((!light || s_ == R - 1) && rb >= 0) {
-                    if (re > rb) {
+                const float *ta = user ? Qk : Pk;
+                if (hist) {
 #pragma unroll
-                        for (int r_ = 0; r_ < NRUN; ++r_)
-                            if (r_ == n_run)
-                                run_b[r_] = rb, run_e[r_] = re;
-                        ++n_run;
+                    for (int t = 0; t < DEEP; ++t) {
+                        a[t] = ld4_sc1(ta, oa[t]);
+                        b[t] = ld4_sc1(Qk, ob[t]);
                     }
-                    rb = -1;
+                } else {
+#pragma unroll
+                    for (int t = 0; t < DEEP; ++t) {
+                        a[t] = ld4_buf(ta, oa[t]);
+                        b[t] = ld4_buf(Qk, ob[t]);
+                    }
+                }
+                if (hist && !(f.abl & 1)) { // a trip that read the sentinel somewhere asks again until its rows' owners have published
+                    unsigned spins = 0;
+                    for (;;) {
+                        uint64_t bad[DEEP], any = 0; // per record of the trip: the lanes that read the sentinel (wave-uniform masks)
+#pragma unroll
+                        for (int t = 0; t < DEEP; ++t) {
+                            bad[t] = __ballot(has[t] && act && (flow_unset(a[t]) || flow_unset(b[t])));
+                            any |= bad[t];
+                        }
+                        if (any == 0)
+                            break;
+                        __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                        for (int t = 0; t < DEEP; ++t) { // the records that are not there yet, by every lane (a scalar branch, no per-lane
+                            if (bad[t] != 0) {           // condition around a load; a published row reads the same again)
+                                a[t] = ld4_sc1(ta, oa[t]);
+                                b[t] = ld4_sc1(Qk, ob[t]);
+                            }
+                        }
+                        if ((++spins & (FLOW_SPIN_CHECK - 1)) == 0 &&
+                            (spins >= FLOW_SPIN_LIMIT || __hip_atomic_load(f.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0)) {
+                            if (lane == 0)
+                                __hip_atomic_store(f.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            break;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < DEEP; ++t) { // dead groups and lanes beyond d take part in the arithmetic with zeros
+                    const bool live = has[t] && act;
+                    a[t] = make_float4(live ? a[t].x : 0.f, live ? a[t].y : 0.f, live ? a[t].z : 0.f, live ? a[t].w : 0.f);
+                    b[t] = make_float4(live ? b[t].x : 0.f, live ? b[t].y : 0.f, live ? b[t].z : 0.f, live ? b[t].w : 0.f);
+                }
+#pragma unroll
+                for (int t = 0; t < DEEP; ++t) {
+                    // the record's own row: its slot follows from the row id (the dealing's arithmetic), its values sit in LDS
+                    const uint32_t own_row = (uint32_t)(user ? rec[t].x : (rec[t].w < 0 ? rec[t].z : rec[t].y));
+                    const int osw = (int)(flow_pos_of(own_row, (uint32_t)nwg, magic, (uint32_t)RPB) & (uint32_t)(RPB - 1));
+                    const float4 own = act ? l_var[osw * LPR + l] : zero;
+                    float4 c;
+                    if (user) {
+                        float x;
+                        const float s_ = triple_s<LPR>(dot4(own, a[t]) - dot4(own, b[t]), &x);
+                        if (has[t] && l == 0)
+                            xb[rec[t].w & 0x7fffffff] = x; // softplus(-x) is taken in bpr_reduce_loss
+                        const float ns = -s_;
+                        c.x = ns * (a[t].x - b[t].x) + hk.reg * own.x;
+                        c.y = ns * (a[t].y - b[t].y) + hk.reg * own.y;
+                        c.z = ns * (a[t].z - b[t].z) + hk.reg * own.z;
+                        c.w = ns * (a[t].w - b[t].w) + hk.reg * own.w;
+                    } else {
+                        const float sg = rec[t].w < 0 ? 1.0f : -1.0f; // j-slices get +s*p, i-slices -s*p
+                        float x;
+                        const float s_ = triple_s<LPR>((dot4(a[t], b[t]) - dot4(a[t], own)) * sg, &x);
+                        const float ss = sg * s_;
+                        c.x = ss * a[t].x + hk.reg * own.x;
+                        c.y = ss * a[t].y + hk.reg * own.y;
+                        c.z = ss * a[t].z + hk.reg * own.z;
+                        c.w = ss * a[t].w + hk.reg * own.w;
+                    }
+                    if (has[t] && act)
+                        l_con[(q0 + t * NG) * LPR + l] = c;
                 }
             }
-        }
-#pragma unroll 1
-        for (int r_ = 0; r_ < n_run; ++r_) {
-            int rb = run_b[0], re = run_e[0];
-#pragma unroll
-            for (int q_ = 1; q_ < NRUN; ++q_)
-                if (q_ == r_)
-                    rb = run_b[q_], re = run_e[q_];
-            walk_range<LPR, RW, MODE, false, true>(w, var, acc, occ_k, rb, re, pre_cur, pf_cur);
-        }
-        float4 grad = reduce_to_owner<LPR, RW>(acc);
-        CREC_FLOW_MARK(1, __float_as_int(grad.x));
-        // ---- heavy slots: the whole workgroup
-        if (hmask != 0) {
-            if (owner && heavy_own)
-                hvar[(wv * R + g) * LPR + l] = var;
+            CREC_FLOW_MARK(1, r0);
             __syncthreads();
-            for (uint64_t mm = hmask; mm != 0; mm &= mm - 1) {
-                const int q = __builtin_amdgcn_readfirstlane(__builtin_ctzll(mm));
-                Slot hs;
-                hs.row = 0;
-                hs.start = __builtin_amdgcn_readlane(seg_cur.x, q);
-                hs.cnt = __builtin_amdgcn_readlane(seg_cur.y, q);
-                const float4 own = act ? hvar[q * LPR + l] : zero;
-                const float4 part = slots_grad<LPR, RW1, MODE, false, true>(own, hs, 1, Pk, Qk, d, occ_k, nullptr, xb, hk, wv, WPB, hist, err);
-                if (g == 0 && act)
-                    hpart[(q * WPB + wv) * LPR + l] = part;
+            // the waits for what was asked for a step ago stand HERE, before this step's publishing store: the records of step k + 2
+            // take this step's buffer (nobody reads it any more) and the segments of step k + 3 their ring slot
+            if (r0 + NREC >= n_all) {
+                if (tid < NREC)
+                    l_rec[(k & 1) * NREC + tid] = rec_a;
+                seg_stage(k + 3, seg_a);
+                seg_a = seg_b;
             }
-            __syncthreads();
-            if (owner && heavy_own) {
-                const float4 *pp = hpart + (wv * R + g) * WPB * LPR + l;
-                grad = pp[0];
-#pragma unroll
-                for (int p_ = 1; p_ < WPB; ++p_) // wave order: the sum does not depend on timing
-                    add4(grad, pp[p_ * LPR]);
+            // ---- (B) every owner: its slot's contribution rows of this round, in record order
+            if (owner) {
+                const int lo = my_start > r0 ? my_start : r0, hi = (my_start + my_cnt) < (r0 + n_round) ? (my_start + my_cnt) : (r0 + n_round);
+                for (int q = lo; q < hi; ++q)
+                    add4(grad, l_con[(q - r0) * LPR + l]);
             }
         }
         CREC_FLOW_MARK(2, __float_as_int(grad.x));
 #ifdef CREC_STAMPS
         if (k == CREC_FLOW_STAMP_STEP && lane == 0 && stamp_wave < 16000)
-            crec_stamps[8 * stamp_wave + 5] = ((unsigned long long)(unsigned)(pl_cur - pf_cur) << 32) | (unsigned)__popcll(hmask) | (user ? 0x100u : 0u);
+            crec_stamps[8 * stamp_wave + 5] = ((unsigned long long)(unsigned)n_all << 32) | (user ? 0x100u : 0u);
 #endif
         const float nr = group_sum<LPR>(dot4(var, var));
         if (owner) {
             if (l == 0)
-                xb[f.B + (user ? 0 : U) + row] = (0.5f * nr) * (float)cnt_own;
-            adam4(var, m, v, grad, cnt_own > 0, hk);
+                xb[f.B + (user ? 0 : U) + row] = (0.5f * nr) * (float)my_cnt;
+            adam4(var, m, v, grad, my_cnt > 0, hk);
             if (k + 1 < f.C) {
                 if (!(f.abl & 4))
                     st4_wt(hist_own + (int64_t)k * h_own, ro, flow_publishable(var));
+                l_var[sw * LPR + l] = var;
             } else {
                 st4s((user ? dst.P : dst.Q) + ro, var);
                 st4s((user ? dst.mP : dst.mQ) + ro, m);
@@ -1914,25 +1928,24 @@ __device__ __forceinline__ void flow_wave(const Tables &src, const Tables &dst, 
             for (int sr = k * q_reset; sr < (k + 1) * q_reset && sr < f.dirty_next && !(f.abl & 4); ++sr)
                 __builtin_nontemporal_store(sent, reinterpret_cast<crec_f4v *>(next_own + (int64_t)sr * h_own + ro));
         }
+        // behind the publishing store: what later steps need (their waits stand in front of the NEXT step's publishing store)
+        seg_b = seg_load(k + 5);
+        __syncthreads(); // (the ring slot of step k + 3 and the rows in LDS are complete; this step's records are no longer read)
+        rec_a = rec_load(k + 3);
         CREC_FLOW_MARK(3, __float_as_int(var.x));
-        seg_cur = seg_nxt;
-        seg_nxt = seg_nn;
-        pre_cur = pre_nxt;
-        pf_cur = pf_nxt;
-        pl_cur = pl_nxt;
     }
 }
 
 template <int LPR, bool FULL>
 __global__ __launch_bounds__(CREC_FUSED_BLOCK) __attribute__((amdgpu_waves_per_eu(CREC_FLOW_WAVES, CREC_FLOW_WAVES))) void bpr_steps_flow(Tables src, Tables dst, int d, int64_t U, int64_t I, FlowArgs f, Hyper h)
 {
-    constexpr int R = Geo<LPR, ROWS_PER_WAVE>::R, WPB = CREC_FUSED_BLOCK / 64;
-    __shared__ float4 flow_lds[R * WPB * LPR * (1 + WPB)];
+    __shared__ float4 flow_lds[FlowGeo<LPR>::LDS_F4];
     if ((int)blockIdx.x < f.nwg_u)
-        flow_wave<LPR, 0, FULL>(src, dst, d, U, U, (int)blockIdx.x, f.nwg_u, f.u_rowseg, f.Upos, f.u_occ, f.B, f.histP, f.nextP, f.hP, f, h, flow_lds);
+        flow_wave<LPR, 0, FULL>(src, dst, d, U, U, (int)blockIdx.x, f.nwg_u, f.magic_u, f.u_rowseg, f.Upos, f.u_occ, f.B, f.histP, f.nextP, f.hP, f,
+                                h, flow_lds);
     else
-        flow_wave<LPR, 1, FULL>(src, dst, d, U, I, (int)blockIdx.x - f.nwg_u, f.nwg_q, f.q_rowseg, f.Ipos, f.q_occ, 2 * f.B, f.histQ,
-                                f.nextQ, f.hQ, f, h, flow_lds);
+        flow_wave<LPR, 1, FULL>(src, dst, d, U, I, (int)blockIdx.x - f.nwg_u, f.nwg_q, f.magic_q, f.q_rowseg, f.Ipos, f.q_occ, 2 * f.B,
+                                f.histQ, f.nextQ, f.hQ, f, h, flow_lds);
 }
 
 // ------------------------------------------------------------------------------------
@@ -2523,9 +2536,9 @@ FlowKernel pick_flow(int d)
 #define CREC_PICK(L)                                                                                                              \
     case L:                                                                                                                       \
         return full ? FlowKernel{launch_flow<L, true>, (const void *)bpr_steps_flow<L, true>,                                     \
-                                 Geo<L, ROWS_PER_WAVE>::R * (CREC_FUSED_BLOCK / 64), lg, 1}                                        \
+                                 FlowGeo<L>::RPB, lg, 1}                                                                          \
                     : FlowKernel{launch_flow<L, false>, (const void *)bpr_steps_flow<L, false>,                                   \
-                                 Geo<L, ROWS_PER_WAVE>::R * (CREC_FUSED_BLOCK / 64), lg, 0};
+                                 FlowGeo<L>::RPB, lg, 0};
     switch (lpr) {
         CREC_PICK(1)
         CREC_PICK(2)
@@ -2979,6 +2992,7 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
             f.q_occ = w.q_occ + b * 2 * w.B;
             f.Upos = w.U, f.Ipos = w.I, f.B = B;
             f.nwg_u = w.flow_nwg_u, f.nwg_q = w.flow_nwg_q;
+            f.magic_u = w.flow_magic_u, f.magic_q = w.flow_magic_q;
             f.C = C;
             f.hP = hP, f.hQ = hQ;
             const int64_t slots = ctx->flow_hist_at ? ctx->flow_key[0] - 1 : 0;

@@ -12,7 +12,7 @@ from cleverrec_amd import _lib, runtime  # noqa: E402
 from cleverrec_amd.data import synthetic  # noqa: E402
 
 sess = runtime.Session(0)
-for k, v in (("flow_abl", int(os.environ.get("ABL", "0"))),):
+for k, v in (("flow", 1), ("flow_abl", int(os.environ.get("ABL", "0")))):
     sess.ctx.set_option(k, v)
 data = synthetic("S-ml1m", seed=20240601)
 U, I, B, d, K = int(os.environ.get("USERS", data.user_nums)), data.item_nums, 6144, 64, 64
@@ -39,14 +39,14 @@ print("%d waves stamped; step starts spread over %.2f us (p50 %.2f p90 %.2f), en
 for name, sel in (("user waves", user), ("item waves", ~user)):
     if sel.sum() == 0:
         continue
-    print("%s (%d): step duration p50 %.2f p90 %.2f max %.2f us | light walk p50 %.2f p90 %.2f max %.2f | heavy part p50 %.2f p90 %.2f max %.2f | finish p50 %.2f max %.2f | own records p50 %d max %d, heavy slots in wg p50 %d max %d"
+    print("%s (%d): step duration p50 %.2f p90 %.2f max %.2f us | phase A p50 %.2f p90 %.2f max %.2f | barrier + sums p50 %.2f p90 %.2f max %.2f | finish p50 %.2f max %.2f | workgroup's records p50 %d max %d (%d %d)"
           % (name, sel.sum(), *(np.percentile(dur[sel], q) for q in (50, 90, 100)), *(np.percentile((light - top)[sel], q) for q in (50, 90, 100)),
              *(np.percentile((heavy - light)[sel], q) for q in (50, 90, 100)), *(np.percentile((end - heavy)[sel], q) for q in (50, 100)),
              np.median(recs[sel]), recs[sel].max(), np.median(nheavy[sel]), nheavy[sel].max()))
 order = np.argsort(-dur)[:12]
-print("slowest waves: " + "; ".join("%s recs %d heavy %d: light %.2f heavy %.2f finish %.2f" % ("U" if user[o] else "I", recs[o], nheavy[o], light[o] - top[o], heavy[o] - light[o], end[o] - heavy[o]) for o in order))
+print("slowest waves: " + "; ".join("%s recs %d (%d): A %.2f sums %.2f finish %.2f" % ("U" if user[o] else "I", recs[o], nheavy[o], light[o] - top[o], heavy[o] - light[o], end[o] - heavy[o]) for o in order))
 # light-walk time against the wave's own record count
-for lo, hi in ((0, 1), (1, 5), (5, 9), (9, 17), (17, 33), (33, 1000)):
-    sel = (recs >= lo) & (recs < hi) & (nheavy == 0)
+for lo, hi in ((0, 17), (17, 33), (33, 65), (65, 97), (97, 129), (129, 100000)):
+    sel = (recs >= lo) & (recs < hi)
     if sel.sum():
-        print("  own records [%d, %d), no heavy slot in the workgroup: %d waves, step p50 %.2f us" % (lo, hi, sel.sum(), np.median(dur[sel])))
+        print("  workgroup's records [%d, %d): %d waves, step p50 %.2f max %.2f us, phase A p50 %.2f" % (lo, hi, sel.sum(), np.median(dur[sel]), dur[sel].max(), np.median((light - top)[sel])))
