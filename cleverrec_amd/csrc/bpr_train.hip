@@ -44,9 +44,11 @@
 // Compiled with -ffp-contract=off: each fp32 multiply/add is rounded separately, like the
 // element-wise Eigen kernels TF1 runs (and like the CPU oracle), so the Adam arithmetic is
 // bit-reproducible.
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstring>
+#include <queue>
 #include "crec_internal.h"
 #include "block_sort.h"
 #include "lazy_desc.h"
@@ -174,8 +176,11 @@ struct IndexWs {
     // bpr_steps_flow: rows are sorted (and u_rowseg / q_rowseg indexed) by POSITION instead of by id -- row r of a side sits in
     // workgroup r mod nwg, slot r div nwg, position (r mod nwg) * rpb + r div nwg (rpb rows per workgroup, a power of two) --
     // so U / I above are the position counts nwg * rpb.  nwg == 0: positions are row ids (every other step)
-    int32_t flow_nwg_u, flow_nwg_q, flow_rpb;
+    int32_t flow_nwg_u, flow_nwg_q, flow_rpb_u, flow_rpb_q; // (rows per workgroup by side: item workgroups hold fewer, their rows are busier)
     uint32_t flow_magic_u, flow_magic_q; // floor(2^32 / nwg): the division by nwg as a multiplication + one fix-up
+    // ... or by table (flow_deal_rows: rows dealt by how often they occur, so that the workgroups' record counts are even):
+    // row -> position and position -> row (-1: nobody), per side; null: the arithmetic above
+    const int32_t *flow_pos_u, *flow_pos_q, *flow_row_u, *flow_row_q;
 };
 
 // row id -> position under the row dealing of bpr_steps_flow
@@ -210,18 +215,19 @@ inline int row_bits(int64_t n_rows)
 inline int lazy_spw(int d) { return d <= 4 ? 64 : (d > 128 ? 16 : (d > 64 && CREC_LAZY_SPW > 32 ? 32 : CREC_LAZY_SPW)); }
 
 IndexWs layout_index(void *base, int64_t nbc, int64_t B, int64_t U, int64_t I, bool dense, int CH, int wide_rows = 0,
-                     int wide_total = 0, int spw = 32, int flow_rpb = 0)
+                     int wide_total = 0, int spw = 32, int flow_rpb = 0, int flow_nwg_u = 0, int flow_nwg_q = 0)
 {
     IndexWs w{};
     w.B = B;
-    if (dense && flow_rpb > 0) { // positions instead of row ids (IndexWs::flow_*)
-        w.flow_rpb = flow_rpb;
-        w.flow_nwg_u = (int32_t)((U + flow_rpb - 1) / flow_rpb);
-        w.flow_nwg_q = (int32_t)((I + flow_rpb - 1) / flow_rpb);
+    if (dense && flow_rpb > 0) { // positions instead of row ids (IndexWs::flow_*); flow_rpb = rows per user workgroup | per item workgroup << 8
+        w.flow_rpb_u = flow_rpb & 0xff;
+        w.flow_rpb_q = flow_rpb >> 8;
+        w.flow_nwg_u = flow_nwg_u > 0 ? flow_nwg_u : (int32_t)((U + w.flow_rpb_u - 1) / w.flow_rpb_u); // (the dealing by weight takes a few more)
+        w.flow_nwg_q = flow_nwg_q > 0 ? flow_nwg_q : (int32_t)((I + w.flow_rpb_q - 1) / w.flow_rpb_q);
         w.flow_magic_u = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)w.flow_nwg_u > 0xffffffffull ? 0xffffffffull : ((uint64_t)1 << 32) / (uint64_t)w.flow_nwg_u);
         w.flow_magic_q = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)w.flow_nwg_q > 0xffffffffull ? 0xffffffffull : ((uint64_t)1 << 32) / (uint64_t)w.flow_nwg_q);
-        U = (int64_t)w.flow_nwg_u * flow_rpb;
-        I = (int64_t)w.flow_nwg_q * flow_rpb;
+        U = (int64_t)w.flow_nwg_u * w.flow_rpb_u;
+        I = (int64_t)w.flow_nwg_q * w.flow_rpb_q;
     }
     w.U = dense ? U : 0;
     w.I = dense ? I : 0;
@@ -308,10 +314,11 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
     const int CH = w.CH;
 
     const uint32_t fl_nwg = (uint32_t)(side ? w.flow_nwg_q : w.flow_nwg_u), fl_magic = side ? w.flow_magic_q : w.flow_magic_u,
-                   fl_rpb = (uint32_t)w.flow_rpb;
+                   fl_rpb = (uint32_t)(side ? w.flow_rpb_q : w.flow_rpb_u);
+    const int32_t *fl_pos = side ? w.flow_pos_q : w.flow_pos_u, *fl_row = side ? w.flow_row_q : w.flow_row_u;
     for (int k = tid; k < n; k += PREP_THREADS) {
         const uint32_t r = (uint32_t)(side == 0 ? u[t0 + k] : (k < nb ? i[t0 + k] : j[t0 + k - nb]));
-        rows[k] = fl_nwg ? flow_pos_of(r, fl_nwg, fl_magic, fl_rpb) : r;
+        rows[k] = fl_nwg ? (fl_pos ? (uint32_t)fl_pos[r] : flow_pos_of(r, fl_nwg, fl_magic, fl_rpb)) : r;
         tag[k] = (uint16_t)k;
     }
 #ifdef CREC_STAMPS // phase times of workgroups 0 (user side) and 1 (item side) of the launch: crec_stamps[16000*8 + ...]
@@ -570,11 +577,13 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
             const int t = k < n ? tag[k] : 0;
             pos[e] = t < nb ? t : t - nb;
             payload[e] = (t < nb ? 0u : 0x80000000u) | (uint32_t)pos[e]; // side flag: the row is the triple's j
+            if (fl_nwg && k < n) // bpr_steps_flow: bits 27 .. 30 carry the slot of the record's own row in its workgroup
+                payload[e] |= (rows[k] & (fl_rpb - 1u)) << 27;
         }
 #pragma unroll
         for (int e = 0; e < RIF; ++e) { // the sorted row is one of the three ids: two scattered loads per record, not three
             const int k = k0r + e * PREP_THREADS;
-            const int row = k < n ? (int)(fl_nwg ? flow_row_of(rows[k], fl_nwg, fl_rpb) : rows[k]) : 0;
+            const int row = k < n ? (int)(fl_nwg ? (fl_row ? (uint32_t)fl_row[rows[k]] : flow_row_of(rows[k], fl_nwg, fl_rpb)) : rows[k]) : 0;
             if (side == 0)
                 rec[e] = make_int4(row, i[t0 + pos[e]], j[t0 + pos[e]], (int)payload[e]);
             else if ((int)payload[e] < 0)
@@ -1614,6 +1623,26 @@ __global__ __launch_bounds__(CREC_FUSED_BLOCK) void bpr_step_fused(Tables src, T
 }
 
 // ------------------------------------------------------------------------------------
+// bpr_steps_flow's row dealing by weight.  A step of that kernel lasts as long as its busiest workgroup, and a workgroup's work
+// is the number of records of its rows -- popular items.  flow_count_rows counts a call's occurrences per row; the host deals the
+// rows heaviest first, each to the workgroup with the least work so far that still has a free slot (flow_deal_host; a few per cent
+// more workgroups than the rows need, so that a row as busy as a whole average workgroup ends up nearly alone in its own).  The
+// tables are made ONCE per shape and kept by the ctx; they decide WHERE a row is worked on, never what is computed (a row's
+// contributions are added in batch order wherever it sits): results do not depend on them, bit for bit (tests/test_gpu_flow.py).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void flow_count_rows(const int32_t *__restrict__ u, const int32_t *__restrict__ i,
+                                                       const int32_t *__restrict__ j, int64_t n, int32_t *__restrict__ cu,
+                                                       int32_t *__restrict__ cq)
+{
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
+        atomicAdd(cu + u[k], 1);
+        atomicAdd(cq + i[k], 1);
+        atomicAdd(cq + j[k], 1);
+    }
+}
+constexpr int FLOW_DEAL_MAX = 1 << 16; // rows per side the dealing takes (the ctx keeps the tables; made once per shape, on the host)
+
+// ------------------------------------------------------------------------------------
 // tf1 mode, ALL steps of a chunk in one launch: bpr_steps_flow (round 4; opt-in, option "flow").
 //
 // bpr_step_fused is bound by what surrounds its waves -- a dispatch per step, every row read from and written to memory per
@@ -1650,7 +1679,7 @@ struct FlowArgs {
     const int4 *u_occ, *q_occ;       // [C][B], [C][2B]
     int64_t Upos, Ipos, B;
     int nwg_u, nwg_q;                // workgroups per side = the modulus of the row dealing
-    uint32_t magic_u, magic_q;       // floor(2^32 / nwg): flow_pos_of
+    const int32_t *row_u, *row_q;    // position -> row (-1: nobody) under the dealing by weight; null: row = slot * nwg + workgroup
     int C;                           // steps of this launch
     float *histP, *histQ;            // [C - 1][U * d], [C - 1][I * d]: the versions after steps 1 .. C - 1, all sentinel on entry
     float *nextP, *nextQ;            // the other history: slots [0, dirty_next) get the sentinel back
@@ -1676,17 +1705,21 @@ __device__ __forceinline__ float4 flow_publishable(float4 v) // a NaN that happe
 }
 
 #ifndef CREC_FLOW_WAVES
-#define CREC_FLOW_WAVES 3 // waves per SIMD bpr_steps_flow is compiled for: all of its waves must be resident at once
+#define CREC_FLOW_WAVES 4 // waves per SIMD bpr_steps_flow is compiled for: all of its waves must be resident at once
 #endif
 #ifndef CREC_FLOW_DEEP
 #define CREC_FLOW_DEEP 4 // records a lane group has in flight (two gathered rows each)
 #endif
-template <int LPR> struct FlowGeo {
+#ifndef CREC_FLOW_ITEM_DIV
+#define CREC_FLOW_ITEM_DIV 2 // an item workgroup holds this many times fewer rows than a user workgroup (an item row is ~3x as busy)
+#endif
+template <int LPR, int RDIV> struct FlowGeo {
     static constexpr int G = 64 / LPR;                                  // lane groups per wave
-    static constexpr int R = G < ROWS_PER_WAVE ? G : ROWS_PER_WAVE;     // slots (rows) per wave
+    static constexpr int R0 = G < ROWS_PER_WAVE ? G : ROWS_PER_WAVE;
+    static constexpr int R = R0 / RDIV > 0 ? R0 / RDIV : 1;             // slots (rows) per wave
     static constexpr int WPB = CREC_FUSED_BLOCK / 64, RPB = R * WPB;    // slots per workgroup
     static constexpr int NG = G * WPB;                                  // lane groups per workgroup
-    static constexpr int NREC_ = 32768 / (LPR * 16);                    // records per round: 32 KB of contribution rows
+    static constexpr int NREC_ = 16384 / (LPR * 16);                    // records per round: 16 KB of contribution rows
     static constexpr int NREC = NREC_ > 256 ? 256 : NREC_;
     static constexpr int SEGRING = 5;                                   // steps of segments kept in LDS (asked for four steps ahead)
     // LDS, in float4 units: the slots' rows, the round's contribution rows, two buffers of records, the ring of segments
@@ -1698,11 +1731,11 @@ template <int LPR> struct FlowGeo {
 // (gathers p_u and the triple's other item row; bit 31 of pos: the owned row is the triple's j)
 template <int LPR, int MODE, bool FULL>
 __device__ __forceinline__ void flow_wave(const Tables &src, const Tables &dst, int d, int64_t U, int64_t n_rows, int j, int nwg,
-                                          uint32_t magic, const int2 *__restrict__ rowseg, int64_t pos_stride,
+                                          const int32_t *__restrict__ row_tab, const int2 *__restrict__ rowseg, int64_t pos_stride,
                                           const int4 *__restrict__ occ, int64_t occ_stride, float *hist_own, float *next_own,
                                           int64_t h_own, const FlowArgs &f, const Hyper &h, float4 *__restrict__ lds)
 {
-    using Geo_ = FlowGeo<LPR>;
+    using Geo_ = FlowGeo<LPR, MODE == 1 ? CREC_FLOW_ITEM_DIV : 1>;
     constexpr int G = Geo_::G, R = Geo_::R, RPB = Geo_::RPB, NG = Geo_::NG, NREC = Geo_::NREC, SEGRING = Geo_::SEGRING, DEEP = CREC_FLOW_DEEP;
     constexpr bool user = MODE == 0;
     const int tid = threadIdx.x, lane = tid & 63, g = lane / LPR, l = lane % LPR;
@@ -1711,11 +1744,11 @@ __device__ __forceinline__ void flow_wave(const Tables &src, const Tables &dst, 
     float4 *l_var = lds + Geo_::OFF_VAR, *l_con = lds + Geo_::OFF_CON;
     int4 *l_rec = reinterpret_cast<int4 *>(lds + Geo_::OFF_REC);
     int *l_seg = reinterpret_cast<int *>(lds + Geo_::OFF_SEG); // [SEGRING][RPB + 1][2]: {start, count} per slot; entry RPB: {end of the range, 0}
-    // ownership: slot sw = wv * R + g (g < R) holds row sw * nwg + j
+    // ownership: slot sw = wv * R + g (g < R) holds row sw * nwg + j, or what the dealing by weight put at that position
     const int sw = wv * R + (g < R ? g : 0);
-    const int64_t row = (int64_t)sw * nwg + j;
+    const int64_t row = row_tab ? (int64_t)row_tab[(int64_t)j * RPB + sw] : (int64_t)sw * nwg + j;
     const bool act = FULL || 4 * l < d;
-    const bool owner = g < R && row < n_rows && act;
+    const bool owner = g < R && row >= 0 && row < n_rows && act;
     const int64_t ro = row * d + 4 * l;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 var = zero, m = zero, v = zero;
@@ -1795,10 +1828,14 @@ __device__ __forceinline__ void flow_wave(const Tables &src, const Tables &dst, 
                 __syncthreads();
             }
             // ---- (A) the round's records, dealt to all lane groups: record q of the round goes to group q mod NG
-            for (int q0 = gi; q0 < n_round; q0 += NG * DEEP) {
+            for (int q0 = gi; q0 - g < n_round; q0 += NG * DEEP) { // (a wave goes on while its FIRST group has records: wave-uniform)
                 int4 rec[DEEP];
                 float4 a[DEEP], b[DEEP];
                 bool has[DEEP];
+                // the trip's depth: how many of its DEEP records the wave's first group still has -- wave-uniform, so that a wave with
+                // one record per group (a user workgroup's usual step) does the arithmetic of one record, not of DEEP
+                const int left = n_round - (q0 - g);
+                const int nt = __builtin_amdgcn_readfirstlane(left >= DEEP * NG ? DEEP : (left + NG - 1) / NG);
                 // every load of the trip is issued before the first one is waited for: NO per-lane condition around a load (the
                 // compiler would wait for each before the next), dead groups read row 0 and drop it, lanes beyond d read lane 0's slice
                 int64_t oa[DEEP], ob[DEEP];
@@ -1806,23 +1843,32 @@ __device__ __forceinline__ void flow_wave(const Tables &src, const Tables &dst, 
                 for (int t = 0; t < DEEP; ++t) {
                     const int q = q0 + t * NG;
                     has[t] = q < n_round;
-                    rec[t] = rec_buf[has[t] ? q : 0];
-                    const int ra = has[t] ? (user ? rec[t].y : rec[t].x) : 0, rb = has[t] ? (user ? rec[t].z : (rec[t].w < 0 ? rec[t].y : rec[t].z)) : 0;
-                    oa[t] = (int64_t)ra * d + (act ? 4 * l : 0);
-                    ob[t] = (int64_t)rb * d + (act ? 4 * l : 0);
+                    rec[t] = make_int4(0, 0, 0, 0);
+                    oa[t] = ob[t] = 0;
+                    a[t] = b[t] = zero;
+                    if (t < nt) {
+                        rec[t] = rec_buf[has[t] ? q : 0];
+                        const int ra = has[t] ? (user ? rec[t].y : rec[t].x) : 0, rb = has[t] ? (user ? rec[t].z : (rec[t].w < 0 ? rec[t].y : rec[t].z)) : 0;
+                        oa[t] = (int64_t)ra * d + (act ? 4 * l : 0);
+                        ob[t] = (int64_t)rb * d + (act ? 4 * l : 0);
+                    }
                 }
                 const float *ta = user ? Qk : Pk;
                 if (hist) {
 #pragma unroll
                     for (int t = 0; t < DEEP; ++t) {
-                        a[t] = ld4_sc1(ta, oa[t]);
-                        b[t] = ld4_sc1(Qk, ob[t]);
+                        if (t < nt) {
+                            a[t] = ld4_sc1(ta, oa[t]);
+                            b[t] = ld4_sc1(Qk, ob[t]);
+                        }
                     }
                 } else {
 #pragma unroll
                     for (int t = 0; t < DEEP; ++t) {
-                        a[t] = ld4_buf(ta, oa[t]);
-                        b[t] = ld4_buf(Qk, ob[t]);
+                        if (t < nt) {
+                            a[t] = ld4_buf(ta, oa[t]);
+                            b[t] = ld4_buf(Qk, ob[t]);
+                        }
                     }
                 }
                 if (hist && !(f.abl & 1)) { // a trip that read the sentinel somewhere asks again until its rows' owners have published
@@ -1831,7 +1877,7 @@ __device__ __forceinline__ void flow_wave(const Tables &src, const Tables &dst, 
                         uint64_t bad[DEEP], any = 0; // per record of the trip: the lanes that read the sentinel (wave-uniform masks)
 #pragma unroll
                         for (int t = 0; t < DEEP; ++t) {
-                            bad[t] = __ballot(has[t] && act && (flow_unset(a[t]) || flow_unset(b[t])));
+                            bad[t] = t < nt ? __ballot(has[t] && act && (flow_unset(a[t]) || flow_unset(b[t]))) : 0ull;
                             any |= bad[t];
                         }
                         if (any == 0)
@@ -1853,39 +1899,38 @@ __device__ __forceinline__ void flow_wave(const Tables &src, const Tables &dst, 
                     }
                 }
 #pragma unroll
-                for (int t = 0; t < DEEP; ++t) { // dead groups and lanes beyond d take part in the arithmetic with zeros
-                    const bool live = has[t] && act;
-                    a[t] = make_float4(live ? a[t].x : 0.f, live ? a[t].y : 0.f, live ? a[t].z : 0.f, live ? a[t].w : 0.f);
-                    b[t] = make_float4(live ? b[t].x : 0.f, live ? b[t].y : 0.f, live ? b[t].z : 0.f, live ? b[t].w : 0.f);
-                }
-#pragma unroll
                 for (int t = 0; t < DEEP; ++t) {
-                    // the record's own row: its slot follows from the row id (the dealing's arithmetic), its values sit in LDS
-                    const uint32_t own_row = (uint32_t)(user ? rec[t].x : (rec[t].w < 0 ? rec[t].z : rec[t].y));
-                    const int osw = (int)(flow_pos_of(own_row, (uint32_t)nwg, magic, (uint32_t)RPB) & (uint32_t)(RPB - 1));
+                    if (t >= nt) // (wave-uniform)
+                        continue;
+                    // dead groups and lanes beyond d take part in the arithmetic with zeros
+                    const bool live = has[t] && act;
+                    const float4 at = make_float4(live ? a[t].x : 0.f, live ? a[t].y : 0.f, live ? a[t].z : 0.f, live ? a[t].w : 0.f);
+                    const float4 bt = make_float4(live ? b[t].x : 0.f, live ? b[t].y : 0.f, live ? b[t].z : 0.f, live ? b[t].w : 0.f);
+                    // the record's own row: the index kernel left its slot in bits 27 .. 30 of the record, its values sit in LDS
+                    const int osw = (rec[t].w >> 27) & (RPB - 1);
                     const float4 own = act ? l_var[osw * LPR + l] : zero;
                     float4 c;
                     if (user) {
                         float x;
-                        const float s_ = triple_s<LPR>(dot4(own, a[t]) - dot4(own, b[t]), &x);
+                        const float s_ = triple_s<LPR>(dot4(own, at) - dot4(own, bt), &x);
                         if (has[t] && l == 0)
-                            xb[rec[t].w & 0x7fffffff] = x; // softplus(-x) is taken in bpr_reduce_loss
+                            xb[rec[t].w & 0x07ffffff] = x; // softplus(-x) is taken in bpr_reduce_loss
                         const float ns = -s_;
-                        c.x = ns * (a[t].x - b[t].x) + hk.reg * own.x;
-                        c.y = ns * (a[t].y - b[t].y) + hk.reg * own.y;
-                        c.z = ns * (a[t].z - b[t].z) + hk.reg * own.z;
-                        c.w = ns * (a[t].w - b[t].w) + hk.reg * own.w;
+                        c.x = ns * (at.x - bt.x) + hk.reg * own.x;
+                        c.y = ns * (at.y - bt.y) + hk.reg * own.y;
+                        c.z = ns * (at.z - bt.z) + hk.reg * own.z;
+                        c.w = ns * (at.w - bt.w) + hk.reg * own.w;
                     } else {
                         const float sg = rec[t].w < 0 ? 1.0f : -1.0f; // j-slices get +s*p, i-slices -s*p
                         float x;
-                        const float s_ = triple_s<LPR>((dot4(a[t], b[t]) - dot4(a[t], own)) * sg, &x);
+                        const float s_ = triple_s<LPR>((dot4(at, bt) - dot4(at, own)) * sg, &x);
                         const float ss = sg * s_;
-                        c.x = ss * a[t].x + hk.reg * own.x;
-                        c.y = ss * a[t].y + hk.reg * own.y;
-                        c.z = ss * a[t].z + hk.reg * own.z;
-                        c.w = ss * a[t].w + hk.reg * own.w;
+                        c.x = ss * at.x + hk.reg * own.x;
+                        c.y = ss * at.y + hk.reg * own.y;
+                        c.z = ss * at.z + hk.reg * own.z;
+                        c.w = ss * at.w + hk.reg * own.w;
                     }
-                    if (has[t] && act)
+                    if (live)
                         l_con[(q0 + t * NG) * LPR + l] = c;
                 }
             }
@@ -1902,8 +1947,18 @@ __device__ __forceinline__ void flow_wave(const Tables &src, const Tables &dst, 
             // ---- (B) every owner: its slot's contribution rows of this round, in record order
             if (owner) {
                 const int lo = my_start > r0 ? my_start : r0, hi = (my_start + my_cnt) < (r0 + n_round) ? (my_start + my_cnt) : (r0 + n_round);
-                for (int q = lo; q < hi; ++q)
-                    add4(grad, l_con[(q - r0) * LPR + l]);
+                // (in record order, eight rows asked of LDS at a time: a load per add was a chain of ~100 cycles per record, and a popular
+                // item's forty records made their workgroup the step's last)
+                for (int q = lo; q < hi; q += 8) {
+                    float4 c8[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        c8[e] = l_con[((q + e < hi ? q + e : lo) - r0) * LPR + l];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (q + e < hi)
+                            add4(grad, c8[e]);
+                }
             }
         }
         CREC_FLOW_MARK(2, __float_as_int(grad.x));
@@ -1939,12 +1994,12 @@ __device__ __forceinline__ void flow_wave(const Tables &src, const Tables &dst, 
 template <int LPR, bool FULL>
 __global__ __launch_bounds__(CREC_FUSED_BLOCK) __attribute__((amdgpu_waves_per_eu(CREC_FLOW_WAVES, CREC_FLOW_WAVES))) void bpr_steps_flow(Tables src, Tables dst, int d, int64_t U, int64_t I, FlowArgs f, Hyper h)
 {
-    __shared__ float4 flow_lds[FlowGeo<LPR>::LDS_F4];
+    __shared__ float4 flow_lds[FlowGeo<LPR, 1>::LDS_F4]; // (the user side's layout is the larger one)
     if ((int)blockIdx.x < f.nwg_u)
-        flow_wave<LPR, 0, FULL>(src, dst, d, U, U, (int)blockIdx.x, f.nwg_u, f.magic_u, f.u_rowseg, f.Upos, f.u_occ, f.B, f.histP, f.nextP, f.hP, f,
+        flow_wave<LPR, 0, FULL>(src, dst, d, U, U, (int)blockIdx.x, f.nwg_u, f.row_u, f.u_rowseg, f.Upos, f.u_occ, f.B, f.histP, f.nextP, f.hP, f,
                                 h, flow_lds);
     else
-        flow_wave<LPR, 1, FULL>(src, dst, d, U, I, (int)blockIdx.x - f.nwg_u, f.nwg_q, f.magic_q, f.q_rowseg, f.Ipos, f.q_occ, 2 * f.B,
+        flow_wave<LPR, 1, FULL>(src, dst, d, U, I, (int)blockIdx.x - f.nwg_u, f.nwg_q, f.row_q, f.q_rowseg, f.Ipos, f.q_occ, 2 * f.B,
                                 f.histQ, f.nextQ, f.hQ, f, h, flow_lds);
 }
 
@@ -2515,11 +2570,36 @@ int setup_lazy_bufs(crec_ctx *ctx, int64_t B, int d, int CH, hipStream_t st, Laz
 
 using StepFn = void (*)(const StepArgs &, const IndexWs &, int64_t, const int32_t *);
 
+// rows of one side dealt to nwg workgroups of rpb slots: pos_of[row] = workgroup * rpb + slot, row_of[position] = row or -1
+void flow_deal_host(const int32_t *cnt, int n, int nwg, int rpb, int32_t *pos_of, int32_t *row_of)
+{
+    std::vector<int32_t> order((size_t)n);
+    for (int r = 0; r < n; ++r)
+        order[(size_t)r] = r;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return cnt[a] > cnt[b]; });
+    for (int64_t p_ = 0; p_ < (int64_t)nwg * rpb; ++p_)
+        row_of[p_] = -1;
+    using Entry = std::pair<int64_t, int32_t>; // {work so far, workgroup}: the least-loaded one with a free slot takes the next row
+    std::priority_queue<Entry, std::vector<Entry>, std::greater<Entry>> heap;
+    std::vector<int32_t> used((size_t)nwg, 0);
+    for (int w_ = 0; w_ < nwg; ++w_)
+        heap.push({0, w_});
+    for (int32_t row : order) {
+        const Entry e = heap.top();
+        heap.pop();
+        const int32_t w_ = e.second, slot = used[(size_t)w_]++;
+        pos_of[row] = w_ * rpb + slot;
+        row_of[(int64_t)w_ * rpb + slot] = row;
+        if (used[(size_t)w_] < rpb)
+            heap.push({e.first + cnt[row] + 1, w_}); // (+ 1: a row costs its owner a little even when no record names it)
+    }
+}
+
 // bpr_steps_flow<LPR, FULL>: the launch, and the workgroups of it one CU holds at a time
 struct FlowKernel {
     void (*launch)(crec_ctx *, unsigned grid, hipStream_t, const Tables &, const Tables &, int, int64_t, int64_t, const FlowArgs &, const Hyper &);
     const void *fn;
-    int rows_per_wg, lpr_log2, full;
+    int rpb_u, rpb_q, lpr_log2, full; // rows per user / item workgroup
 };
 template <int LPR, bool FULL>
 void launch_flow(crec_ctx *ctx, unsigned grid, hipStream_t st, const Tables &src, const Tables &dst, int d, int64_t U, int64_t I,
@@ -2536,9 +2616,9 @@ FlowKernel pick_flow(int d)
 #define CREC_PICK(L)                                                                                                              \
     case L:                                                                                                                       \
         return full ? FlowKernel{launch_flow<L, true>, (const void *)bpr_steps_flow<L, true>,                                     \
-                                 FlowGeo<L>::RPB, lg, 1}                                                                          \
+                                 FlowGeo<L, 1>::RPB, FlowGeo<L, CREC_FLOW_ITEM_DIV>::RPB, lg, 1}                                  \
                     : FlowKernel{launch_flow<L, false>, (const void *)bpr_steps_flow<L, false>,                                   \
-                                 FlowGeo<L>::RPB, lg, 0};
+                                 FlowGeo<L, 1>::RPB, FlowGeo<L, CREC_FLOW_ITEM_DIV>::RPB, lg, 0};
     switch (lpr) {
         CREC_PICK(1)
         CREC_PICK(2)
@@ -2549,7 +2629,7 @@ FlowKernel pick_flow(int d)
         CREC_PICK(64)
     }
 #undef CREC_PICK
-    return FlowKernel{nullptr, nullptr, 0, 0, 0};
+    return FlowKernel{nullptr, nullptr, 0, 0, 0, 0};
 }
 
 StepFn pick_step(int d, bool dense)
@@ -2688,7 +2768,7 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
     const int64_t hP = (int64_t)t->U * t->d, hQ = (int64_t)t->I * t->d;
     if (dense && !dp && ctx->knob_flow > 0) { // (opt-in: measured SLOWER than a launch per step so far)
         fk = pick_flow(t->d);
-        const int64_t grid = crec_ceil_div(t->U, fk.rows_per_wg) + crec_ceil_div(t->I, fk.rows_per_wg);
+        const int64_t grid = crec_ceil_div(t->U, fk.rpb_u) + crec_ceil_div(t->I, fk.rpb_q);
         int &bpc = ctx->flow_blocks_per_cu[fk.lpr_log2][fk.full];
         if (bpc == 0) {
             int nbk = 0;
@@ -2722,7 +2802,7 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
                 flow_cmax = (int)cmax;
         }
     }
-    const int flow_rpb = flow_cmax ? fk.rows_per_wg : 0;
+    const int flow_rpb = flow_cmax ? (fk.rpb_u | (fk.rpb_q << 8)) : 0;
     if (flow_cmax) { // its waves walk whatever their rows hold: no heavy-row chunks, no wide groups, nothing for the host to read back
         CH_idx = 0x3fffffff;
         wide_total = 0;
@@ -2740,8 +2820,44 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
             ctx->flow_cur = 0;
         }
     }
+    // the row dealing of bpr_steps_flow by weight: made from this call's triples when the ctx has none for the shape (once: a count
+    // kernel, one read-back, the host's dealing, one upload)
+    const int32_t *deal[4] = {nullptr, nullptr, nullptr, nullptr}; // pos_u, row_u, pos_q, row_q
+    int deal_nwg_u = 0, deal_nwg_q = 0;
+    if (flow_cmax && ctx->knob_flow_deal && t->U <= FLOW_DEAL_MAX && t->I <= FLOW_DEAL_MAX) {
+        const auto more = [](int64_t n_, int rpb_) { const int64_t base_ = crec_ceil_div(n_, rpb_); return (int)(base_ + base_ / 12 + 1); };
+        const int nwg_u = more(t->U, fk.rpb_u), nwg_q = more(t->I, fk.rpb_q);
+        const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+        if ((int64_t)nwg_u + nwg_q <= (int64_t)ctx->flow_blocks_per_cu[fk.lpr_log2][fk.full] * cus) { // (else: the plain dealing, which fits)
+            const size_t n_cnt = align_up((size_t)(t->U + t->I), 64), n_pu = align_up((size_t)t->U, 64), n_ru = align_up((size_t)nwg_u * fk.rpb_u, 64),
+                         n_pq = align_up((size_t)t->I, 64), n_rq = align_up((size_t)nwg_q * fk.rpb_q, 64);
+            const void *before = ctx->flow_deal.ptr;
+            if (int rc = crec_reserve(ctx, &ctx->flow_deal, sizeof(int32_t) * (n_cnt + n_pu + n_ru + n_pq + n_rq)))
+                return rc;
+            int32_t *cnt = (int32_t *)ctx->flow_deal.ptr, *pos_u = cnt + n_cnt, *row_u = pos_u + n_pu, *pos_q = row_u + n_ru, *row_q = pos_q + n_pq;
+            if (ctx->flow_deal.ptr != before || ctx->flow_deal_key[0] != t->U || ctx->flow_deal_key[1] != t->I || ctx->flow_deal_key[2] != flow_rpb) {
+                hipStream_t st_ = (hipStream_t)stream;
+                CREC_HIP(ctx, hipMemsetAsync(cnt, 0, sizeof(int32_t) * n_cnt, st_));
+                const int64_t n_w = N < (int64_t)256 * B ? N : (int64_t)256 * B; // (a few hundred batches say all there is to know)
+                hipLaunchKernelGGL(flow_count_rows, dim3((unsigned)(crec_ceil_div(n_w, 256) < 1024 ? crec_ceil_div(n_w, 256) : 1024)), dim3(256), 0, st_, u,
+                                   i, j, n_w, cnt, cnt + t->U);
+                std::vector<int32_t> h_cnt((size_t)(t->U + t->I)), h_tab(n_pu + n_ru + n_pq + n_rq);
+                CREC_HIP(ctx, hipMemcpyAsync(h_cnt.data(), cnt, sizeof(int32_t) * h_cnt.size(), hipMemcpyDeviceToHost, st_));
+                CREC_HIP(ctx, hipStreamSynchronize(st_));
+                flow_deal_host(h_cnt.data(), (int)t->U, nwg_u, fk.rpb_u, h_tab.data(), h_tab.data() + n_pu);
+                flow_deal_host(h_cnt.data() + t->U, (int)t->I, nwg_q, fk.rpb_q, h_tab.data() + n_pu + n_ru, h_tab.data() + n_pu + n_ru + n_pq);
+                CREC_HIP(ctx, hipMemcpyAsync(pos_u, h_tab.data(), sizeof(int32_t) * h_tab.size(), hipMemcpyHostToDevice, st_));
+                CREC_HIP(ctx, hipStreamSynchronize(st_)); // (h_tab is pageable and goes out of scope)
+                ctx->flow_deal_key[0] = t->U, ctx->flow_deal_key[1] = t->I, ctx->flow_deal_key[2] = flow_rpb;
+            }
+            deal[0] = pos_u, deal[1] = row_u, deal[2] = pos_q, deal[3] = row_q;
+            deal_nwg_u = nwg_u, deal_nwg_q = nwg_q;
+        }
+    }
     const auto layout = [&](void *base, int64_t nbc_, int spw_ = 32) {
-        return layout_index(base, nbc_, B, t->U, t->I, dense, CH_idx, wide_rows, wide_total, spw_, flow_rpb);
+        IndexWs w_ = layout_index(base, nbc_, B, t->U, t->I, dense, CH_idx, wide_rows, wide_total, spw_, flow_rpb, deal_nwg_u, deal_nwg_q);
+        w_.flow_pos_u = deal[0], w_.flow_row_u = deal[1], w_.flow_pos_q = deal[2], w_.flow_row_q = deal[3];
+        return w_;
     };
 
     // chunk the epoch so the inverted indices of a chunk stay under ~1 GiB
@@ -2992,7 +3108,7 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
             f.q_occ = w.q_occ + b * 2 * w.B;
             f.Upos = w.U, f.Ipos = w.I, f.B = B;
             f.nwg_u = w.flow_nwg_u, f.nwg_q = w.flow_nwg_q;
-            f.magic_u = w.flow_magic_u, f.magic_q = w.flow_magic_q;
+            f.row_u = w.flow_row_u, f.row_q = w.flow_row_q;
             f.C = C;
             f.hP = hP, f.hQ = hQ;
             const int64_t slots = ctx->flow_hist_at ? ctx->flow_key[0] - 1 : 0;

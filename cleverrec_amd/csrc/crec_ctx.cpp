@@ -258,7 +258,7 @@ void crec_ctx_destroy(crec_ctx *ctx)
         (void)crec_comm_destroy(ctx);
         crec_devbuf *bufs[] = {&ctx->idx_ws, &ctx->idx_ws2, &ctx->big_ws, &ctx->contrib, &ctx->loss_ws,
                                &ctx->misc,   &ctx->eval_ws, &ctx->ks_dev, &ctx->shadow, &ctx->dq, &ctx->shard_ws, &ctx->shard_ws2, &ctx->lr_hist_dev,
-                               &ctx->shard_flag, &ctx->flow_hist};
+                               &ctx->shard_flag, &ctx->flow_hist, &ctx->flow_deal};
         for (crec_devbuf *b : bufs)
             if (b->ptr)
                 (void)hipFree(b->ptr);
@@ -316,7 +316,10 @@ int crec_ctx_set_option(crec_ctx *ctx, const char *name, int64_t value)
         ctx->knob_idx_overlap = (int)value;
     else if (n == "flow")
         ctx->knob_flow = (int)value;
-    else if (n == "flow_abl")
+    else if (n == "flow_deal") {
+        ctx->knob_flow_deal = (int)value;
+        ctx->flow_deal_key[0] = 0; // (made again at the next call)
+    } else if (n == "flow_abl")
         ctx->knob_flow_abl = (int)value;
     else if (n == "flow_steps")
         ctx->knob_flow_steps = (int)value;

@@ -137,6 +137,10 @@ struct crec_ctx {
     int64_t flow_key[3] = {0, 0, 0}; // {steps per history + 1, floats per P version, floats per Q version}
     int flow_dirty[2] = {0, 0}, flow_cur = 0;
     int32_t *flow_err = nullptr, *flow_err_dev = nullptr;
+    crec_devbuf flow_deal;              // the row dealing by weight: counts, row -> position and position -> row of both sides
+    int64_t flow_deal_key[3] = {0, 0, 0}; // {U, I, rows per workgroup} it was made for (0: none yet)
+    int knob_flow_deal = 1;             // 0: rows dealt round-robin by id (tests: the results do not depend on the dealing)
+    size_t flow_deal_lds_set = 0;
     int flow_blocks_per_cu[8][2] = {{0}}; // occupancy of bpr_steps_flow<LPR, FULL> by (log2 LPR, FULL); 0: not asked yet
     int knob_dsampler_general = 0; // negatives phase of the device sampler: 0 parallel tables (walk where they do not apply), 2 the four-wave walk, 1 the general walk (tests)
 };

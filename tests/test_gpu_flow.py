@@ -52,7 +52,7 @@ def _run(sess, opts, P0, Q0, u, i, j, B, calls=1, lr=1e-3):
         return [np.concatenate(losses)] + [getattr(st, n).cpu().numpy() for n in ("P", "Q", "mP", "mQ", "vP", "vQ")], st
     finally:
         for k in opts:
-            sess.ctx.set_option(k, 0)
+            sess.ctx.set_option(k, {"flow_deal": 1}.get(k, 0))
 
 
 CASES = [
@@ -78,8 +78,8 @@ def test_flow_equals_a_launch_per_step_bit_for_bit(sess, U, I, d, B, nb, zipf):
     b, _ = _run(sess, {"flow_steps": 1}, P0, Q0, u, i, j, B)
     for x, y, name in zip(a, b, ("loss", "P", "Q", "mP", "mQ", "vP", "vQ")):
         assert np.array_equal(x, y), name
-    # ... and however the batches are cut into calls and launches
-    c, _ = _run(sess, {"flow_steps": 7}, P0, Q0, u, i, j, B, calls=3)
+    # ... however the batches are cut into calls and launches, and wherever the rows sit (dealt round-robin by id instead of by weight)
+    c, _ = _run(sess, {"flow_steps": 7, "flow_deal": 0}, P0, Q0, u, i, j, B, calls=3)
     for x, y, name in zip(a, c, ("loss", "P", "Q", "mP", "mQ", "vP", "vQ")):
         assert np.array_equal(x, y), name
 
