@@ -1670,8 +1670,8 @@ constexpr int FLOW_DEAL_MAX = 1 << 16; // rows per side the dealing takes (the c
 //     before it filled in the other (each owner its own rows, one slot per step), so no memset sits between launches
 // ------------------------------------------------------------------------------------
 constexpr int FLOW_MAX_STEPS = 64;
-constexpr uint32_t FLOW_SENT = 0xffffffffu; // an unpublished row version: this in every 4-byte word (nothing rests on how wide a store
-                                            // lands at once); a published word is never this (flow_publishable)
+constexpr uint32_t FLOW_SENT = 0xffffffffu; // an unpublished row version: this in every 4-byte word; a published word is never this
+                                            // (flow_publishable)
 constexpr unsigned FLOW_SPIN_CHECK = 1u << 12, FLOW_SPIN_LIMIT = 1u << 23; // polls between looks at the give-up flag; polls (each at
                                                                            // least a memory round trip) before a wave gives up itself
 struct FlowArgs {
@@ -1693,10 +1693,12 @@ struct FlowArgs {
     float lr_t[FLOW_MAX_STEPS];
 };
 
-__device__ __forceinline__ bool flow_unset(float4 v) // (integer logic, no short-circuit branches)
+// a lane's 16 bytes of a row version are not there yet.  The owner writes them with ONE 16-byte store; such stores have been observed to
+// land whole on gfx950 (MI355X_MICROARCH.md, hand-offs), and the first and the last word are looked at here, so a store that landed as
+// two 8-byte halves in either order is still caught (integer logic, no short-circuit branches)
+__device__ __forceinline__ bool flow_unset(float4 v)
 {
-    return ((int)(__float_as_uint(v.x) == FLOW_SENT) | (int)(__float_as_uint(v.y) == FLOW_SENT) | (int)(__float_as_uint(v.z) == FLOW_SENT) |
-            (int)(__float_as_uint(v.w) == FLOW_SENT)) != 0;
+    return ((int)(__float_as_uint(v.x) == FLOW_SENT) | (int)(__float_as_uint(v.w) == FLOW_SENT)) != 0;
 }
 __device__ __forceinline__ float4 flow_publishable(float4 v) // a NaN that happens to carry the sentinel's bits becomes the canonical one
 {
@@ -1764,7 +1766,8 @@ __device__ __forceinline__ void flow_wave(const Tables &src, const Tables &dst, 
     // k + 3 and k + 4 (two register stages), steps k .. k + 2 sit in the LDS ring; records: thread t holds record t of step k + 2's
     // first round (one register stage), steps k and k + 1 sit in the two LDS buffers
     const int2 *seg_at = rowseg + (int64_t)j * RPB + (tid < RPB ? tid : RPB - 1);
-    const auto seg_load = [&](int step) { return step < f.C ? seg_at[(int64_t)step * pos_stride] : make_int2(0, 0); };
+    const int C_ = f.C;
+    const auto seg_load = [&](int step) { return step < C_ ? seg_at[(int64_t)step * pos_stride] : make_int2(0, 0); };
     const auto seg_stage = [&](int step, int2 sg) {
         if (tid < RPB) {
             int *e = l_seg + ((step % SEGRING) * (RPB + 1) + tid) * 2;
@@ -1777,7 +1780,7 @@ __device__ __forceinline__ void flow_wave(const Tables &src, const Tables &dst, 
     const auto seg_end = [&](int step) { return l_seg[((step % SEGRING) * (RPB + 1) + RPB) * 2]; };
     const auto rec_load = [&](int step) { // record tid of the step's range (its first round)
         int4 r = make_int4(0, 0, 0, 0);
-        if (step < f.C) {
+        if (step < C_) {
             const int F = seg_first(step), L = seg_end(step);
             if (tid < NREC && tid < L - F)
                 r = occ[(int64_t)step * occ_stride + F + tid];
@@ -1806,13 +1809,19 @@ __device__ __forceinline__ void flow_wave(const Tables &src, const Tables &dst, 
 #else
 #define CREC_FLOW_MARK(slot, dep)
 #endif
-    for (int k = 0; k < f.C; ++k) {
+    // (the launch's arguments sit in kernel-argument memory: what a step needs of them is taken once, and the per-step pointers are
+    // stepped instead of multiplied -- a scalar load and its wait per use was half a microsecond of every step)
+    const int C = f.C, abl = f.abl, dirty_next = f.dirty_next;
+    const int64_t hP = f.hP, hQ = f.hQ, loss_stride = f.loss_stride, Bx = f.B;
+    const float *histP_k = f.histP - hP, *histQ_k = f.histQ - hQ; // version k - 1's slot as step k sees it
+    const int4 *occ_k = occ;
+    float *xb = f.loss_ws, *hist_k = hist_own;
+    int32_t *const err = f.err;
+    for (int k = 0; k < C; ++k, occ_k += occ_stride, xb += loss_stride, histP_k += hP, histQ_k += hQ, hist_k += h_own) {
         CREC_FLOW_MARK(0, 0);
-        const int4 *occ_k = occ + (int64_t)k * occ_stride;
-        const bool hist = k > 0 && !(f.abl & 2);
-        const float *Pk = hist ? f.histP + (int64_t)(k - 1) * f.hP : src.P;
-        const float *Qk = hist ? f.histQ + (int64_t)(k - 1) * f.hQ : src.Q;
-        float *xb = f.loss_ws + (int64_t)k * f.loss_stride;
+        const bool hist = k > 0 && !(abl & 2);
+        const float *Pk = hist ? histP_k : src.P;
+        const float *Qk = hist ? histQ_k : src.Q;
         Hyper hk = h;
         hk.lr_t = f.lr_t[k];
         const int F = seg_first(k), L = seg_end(k), n_all = L - F; // the workgroup's records of this step
@@ -1871,7 +1880,7 @@ __device__ __forceinline__ void flow_wave(const Tables &src, const Tables &dst, 
                         }
                     }
                 }
-                if (hist && !(f.abl & 1)) { // a trip that read the sentinel somewhere asks again until its rows' owners have published
+                if (hist && !(abl & 1)) { // a trip that read the sentinel somewhere asks again until its rows' owners have published
                     unsigned spins = 0;
                     for (;;) {
                         uint64_t bad[DEEP], any = 0; // per record of the trip: the lanes that read the sentinel (wave-uniform masks)
@@ -1891,9 +1900,9 @@ __device__ __forceinline__ void flow_wave(const Tables &src, const Tables &dst, 
                             }
                         }
                         if ((++spins & (FLOW_SPIN_CHECK - 1)) == 0 &&
-                            (spins >= FLOW_SPIN_LIMIT || __hip_atomic_load(f.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0)) {
+                            (spins >= FLOW_SPIN_LIMIT || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0)) {
                             if (lane == 0)
-                                __hip_atomic_store(f.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                             break;
                         }
                     }
@@ -1969,18 +1978,18 @@ __device__ __forceinline__ void flow_wave(const Tables &src, const Tables &dst, 
         const float nr = group_sum<LPR>(dot4(var, var));
         if (owner) {
             if (l == 0)
-                xb[f.B + (user ? 0 : U) + row] = (0.5f * nr) * (float)my_cnt;
+                xb[Bx + (user ? 0 : U) + row] = (0.5f * nr) * (float)my_cnt;
             adam4(var, m, v, grad, my_cnt > 0, hk);
-            if (k + 1 < f.C) {
-                if (!(f.abl & 4))
-                    st4_wt(hist_own + (int64_t)k * h_own, ro, flow_publishable(var));
+            if (k + 1 < C) {
+                if (!(abl & 4))
+                    st4_wt(hist_k, ro, flow_publishable(var));
                 l_var[sw * LPR + l] = var;
             } else {
                 st4s((user ? dst.P : dst.Q) + ro, var);
                 st4s((user ? dst.mP : dst.mQ) + ro, m);
                 st4s((user ? dst.vP : dst.vQ) + ro, v);
             }
-            for (int sr = k * q_reset; sr < (k + 1) * q_reset && sr < f.dirty_next && !(f.abl & 4); ++sr)
+            for (int sr = k * q_reset; sr < (k + 1) * q_reset && sr < dirty_next && !(abl & 4); ++sr)
                 __builtin_nontemporal_store(sent, reinterpret_cast<crec_f4v *>(next_own + (int64_t)sr * h_own + ro));
         }
         // behind the publishing store: what later steps need (their waits stand in front of the NEXT step's publishing store)
@@ -2766,7 +2775,7 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
     int flow_cmax = 0; // steps per launch; 0: bpr_step_fused, a launch per step
     int CH_idx = CH;   // what the index kernel cuts heavy rows at
     const int64_t hP = (int64_t)t->U * t->d, hQ = (int64_t)t->I * t->d;
-    if (dense && !dp && ctx->knob_flow > 0) { // (opt-in: measured SLOWER than a launch per step so far)
+    if (dense && !dp && ctx->knob_flow != 0) {
         fk = pick_flow(t->d);
         const int64_t grid = crec_ceil_div(t->U, fk.rpb_u) + crec_ceil_div(t->I, fk.rpb_q);
         int &bpc = ctx->flow_blocks_per_cu[fk.lpr_log2][fk.full];

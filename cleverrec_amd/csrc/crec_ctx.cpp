@@ -217,7 +217,7 @@ int crec_ctx_create(int device, crec_ctx **out)
     ctx->knob_idx_overlap = env_int("CREC_IDX_OVERLAP", 0);
     ctx->knob_no_zero_copy = env_int("CREC_NO_ZERO_COPY", 0);
     ctx->knob_dsampler_general = env_int("CREC_DSAMPLER_GENERAL", 0);
-    ctx->knob_flow = env_int("CREC_FLOW", 0);
+    ctx->knob_flow = env_int("CREC_FLOW", -1);
     ctx->knob_flow_steps = env_int("CREC_FLOW_STEPS", 0);
     if (device >= 0) {
         int n = 0;

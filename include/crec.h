@@ -77,12 +77,14 @@ const char *crec_last_error(const crec_ctx *ctx);
  *                    behind the sort (same index, bit for bit)
  *   "dp_unfused"     1: the replicated-Q step over the peer transport as an all-reduce of dQ plus a separate Adam launch instead of
  *                    one launch that exchanges and updates (same tables, bit for bit)
- *   "flow"           tf1 step (replaces the per-batch sess.run of model/RankingRecommender.py:39-47): 1 all steps of a chunk of
- *                    batches in ONE dataflow launch (bpr_steps_flow: rows and Adam slots stay in registers, a version of every row is
- *                    published per step) where every wave of it is resident at once, 0 (default) a launch per step (bpr_step_fused).
- *                    The two assign rows to waves differently: same results up to fp32 summation order.  Experimental: correct
- *                    (bit-identical to itself launched step by step) and, as measured in round 4, slower than the default
+ *   "flow"           tf1 step (replaces the per-batch sess.run of model/RankingRecommender.py:39-47): -1 / 1 (default) all steps of a
+ *                    chunk of batches in ONE dataflow launch (bpr_steps_flow: a lane group owns a table row for up to 64 steps, the
+ *                    row and its Adam slots stay in registers, a version of every row is published per step) where every wave of
+ *                    it is resident at once (tables of up to ~14 000 rows at d = 64), 0 a launch per step (bpr_step_fused: any
+ *                    table, the data-parallel step).  The two add a row's contributions in different orders: same results up to
+ *                    fp32 summation order
  *   "flow_steps"     steps per bpr_steps_flow launch (0 = up to 64; 1 = a launch per step through the same kernel: bit-identical)
+ *   "flow_deal"      0: its rows are dealt to workgroups round-robin by id instead of by how often they occur (bit-identical)
  *   "big_index"      1: the lazy-family steps index their batches through the global-memory sort (index_big.hip, the form batches of
  *                    more than 8192 triples always take) even where the in-LDS sort would do: same index, bit for bit
  *   "idx_overlap"    1: that form indexes its chunks of batches a chunk ahead on a side stream, beside the previous chunk's steps

@@ -19,10 +19,12 @@ def _np(t):
     return (t.detach().cpu().numpy() if hasattr(t, "detach") else np.asarray(t)).astype(np.float64)
 
 
-def assert_adam_close(om, name, var, m=None, v=None, lr=1e-3, report=None, scale=1.0):
+def assert_adam_close(om, name, var, m=None, v=None, lr=1e-3, report=None, scale=1.0, outliers=0.0):
     """scale: multiple of the propagated envelope to allow.  (LazyAdam tests pass 2: most rows there are touched ONCE, so a row's
     gradient is a single contribution out of the tower's backward pass -- nothing averages its rounding, and NOISE, calibrated on
-    rows that sum several contributions, is met by the tail of 5 000 such elements: 1.17 of the bound on one element seen.)"""
+    rows that sum several contributions, is met by the tail of 5 000 such elements: 1.17 of the bound on one element seen.)
+    outliers: share of a tensor's weights that may leave the envelope by up to 2 % of an Adam step (tables of a million single-
+    contribution elements: the bound of the C5 test, tests/test_gpu_parity.py)."""
     tol_var, tol_m, tol_v = (scale * t for t in om.bounds(name))
     ref = om.numpy(name).astype(np.float64)
     shape = ref.shape
@@ -34,6 +36,8 @@ def assert_adam_close(om, name, var, m=None, v=None, lr=1e-3, report=None, scale
         MARGINS.append(rec)
         if report is not None:
             report.append(rec)
+        if worst > 1.0 and what == "var" and (dv > bound).sum() <= outliers * dv.size and dv.max() <= 2e-2 * lr:
+            return dv  # (`outliers`: that share of a table's weights may sit outside the envelope, none further than 2 % of an Adam step)
         if worst > 1.0:
             k = np.unravel_index(np.argmax(dv / bound), shape)
             raise AssertionError("%s.%s: |delta| %.3e > bound %.3e at %s (ref %.6e); %d of %d elements beyond their bound"

@@ -52,7 +52,7 @@ def _run(sess, opts, P0, Q0, u, i, j, B, calls=1, lr=1e-3):
         return [np.concatenate(losses)] + [getattr(st, n).cpu().numpy() for n in ("P", "Q", "mP", "mQ", "vP", "vQ")], st
     finally:
         for k in opts:
-            sess.ctx.set_option(k, {"flow_deal": 1}.get(k, 0))
+            sess.ctx.set_option(k, {"flow_deal": 1, "flow": -1}.get(k, 0))
 
 
 CASES = [

@@ -17,7 +17,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--d", type=int, default=64)
 ap.add_argument("--reps", type=int, default=100)
 ap.add_argument("--steps", type=int, nargs="*", default=[20, 64, 455])
-ap.add_argument("--flow", type=int, nargs="*", default=[1, 0])
+ap.add_argument("--flow", type=int, nargs="*", default=[-1, 0])
 ap.add_argument("--abl", type=int, nargs="*", default=[0])
 a = ap.parse_args()
 B = 6144
