@@ -340,7 +340,7 @@ def main():
             "config": {"workload": "BPR on S-ml1m (6040x3706, 1,000,208 interactions, ml-1m marginals), d=64 fp32, "
                                    "batch 6144, neg_ratio 4, Adam tf1 semantics (BASELINE.json configs[1])",
                        "users": data.user_nums, "items": data.item_nums, "embed_size": D, "batch_size": B,
-                       "neg_ratio": NEG, "adam_mode": "tf1", "sharding": ("users sharded (one S-ml1m user shard per GPU), Q replicated, 1 all-reduce of dQ per step over %s"
+                       "neg_ratio": NEG, "adam_mode": "tf1", "step_kernel": "bpr_step_fused (a launch per batch)" if dp else "bpr_steps_flow (up to 64 batches per launch) where resident, else bpr_step_fused", "sharding": ("users sharded (one S-ml1m user shard per GPU), Q replicated, 1 all-reduce of dQ per step over %s"
                                                          % ("the peer windows (xGMI loads from one kernel per exchange)" if transport == "peer" else "RCCL")) if dp else "none"},
         }
         if dp:
@@ -374,6 +374,7 @@ def main():
             run_steps(k_prof)
             fence()
             prof = sess.ctx.profile_read()
+            flow_steps = sess.ctx.profile_units("bpr_steps_flow")
             sess.ctx.profile(False)
         except Exception as e:  # noqa: BLE001
             prof = None
@@ -389,27 +390,34 @@ def main():
         for name, (ms, n) in prof.items():
             if n:
                 kern[name] = {"avg_us": ms / n * 1e3, "launches": n}
-        dom = "bpr_step_fused"
+        # the tf1 step runs as ONE dataflow launch per up to 64 batches where every wave of it is resident (bpr_steps_flow, the
+        # default at this shape), else as a launch per batch (bpr_step_fused; always for the data-parallel step)
+        flow = prof.get("bpr_steps_flow", (0, 0))[1] > 0
+        dom = "bpr_steps_flow" if flow else "bpr_step_fused"
+        steps_per_launch = flow_steps / prof[dom][1] if flow else 1.0
+        alg_step = alg["bpr_step_fused"]
         # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes over this same
         # command, tools/profile.sh; gfx950 FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes).  PMC
         # counters cannot be read from inside the process, so the committed measurement is quoted.
         traffic = None
         def newest(name):  # the latest round's committed summary of this workload
-            for r in ("round3", "round2", "round1"):
+            for r in ("round4", "round3", "round2", "round1"):
                 f_ = os.path.join(ROOT, "profiles", "%s_%s" % (r, name))
                 if os.path.exists(f_):
                     return f_
-            return os.path.join(ROOT, "profiles", "round3_" + name)
+            return os.path.join(ROOT, "profiles", "round4_" + name)
         tf = newest("traffic.json")
         if os.path.exists(tf) and not dp:
-            traffic = json.load(open(tf)).get("traffic_bytes_per_launch")
+            tj = json.load(open(tf))
+            if tj.get("kernel", "bpr_step_fused") == dom:
+                traffic = tj.get("traffic_bytes_per_launch")
         if dp:
-            alg[dom] = B * (24 * D + 12) + 24 * D * U + 4 * D * I  # P swept, dQ written; Q is swept by bpr_adam_dense / peer_allreduce_adam
+            alg_step = B * (24 * D + 12) + 24 * D * U + 4 * D * I  # P swept, dQ written; Q is swept by bpr_adam_dense / peer_allreduce_adam
+        alg[dom] = alg_step * steps_per_launch  # algorithmic bytes of an average launch (the launches of an epoch hold 64 .. 7 steps)
         avg_s = prof[dom][0] / prof[dom][1] * 1e-3
         ach = alg[dom] / avg_s / 1e9
-        # the second clock: rocprofv3 --kernel-trace --stats of this workload (tools/profile.sh -> profiles/round3_kernel_stats.txt).
-        # The two disagree by ~15 % (under tracing consecutive dependent dispatches tile the timeline, so its per-dispatch
-        # figure is the launch-to-launch period); `frac` is priced on the SLOWER clock, both are reported.
+        # the second clock: rocprofv3 --kernel-trace --stats of this command (tools/profile.sh -> profiles/roundN_kernel_stats.txt), the
+        # same mix of launches.  `frac` is priced on the SLOWER of the two clocks; both are reported, and `clock` says which it was
         rp_us = None
         ks = newest("kernel_stats.txt")
         if os.path.exists(ks) and not dp:
@@ -424,16 +432,21 @@ def main():
         slow_us = max(avg_s * 1e6, rp_us or 0.0)
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": alg[dom] / slow_us / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": alg[dom] / slow_us / 1e3 / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg[dom],
-                           "avg_launch_us": avg_s * 1e6, "avg_launch_us_rocprof": rp_us, "frac_hip_events": ach / HBM_PEAK_GBS,
+                           "algorithmic_bytes_per_step": alg_step, "steps_per_launch": steps_per_launch,
+                           "avg_launch_us": avg_s * 1e6, "avg_us_per_step": avg_s * 1e6 / steps_per_launch,
+                           "avg_launch_us_rocprof": rp_us, "frac_hip_events": ach / HBM_PEAK_GBS,
+                           "clock": ("rocprofv3 --kernel-trace --stats, committed: " + os.path.relpath(ks, ROOT)) if (rp_us or 0.0) > avg_s * 1e6
+                                    else "HIP events attached to each dispatch, measured in this run",
                            "note": "avg_launch_us = mean over the timed launches of the elapsed time between the two HIP events "
                                    "attached to each dispatch (hipExtLaunchKernelGGL start/stop events on the launch stream), i.e. "
                                    "the dispatch's own begin/end timestamps; avg_launch_us_rocprof = the committed rocprofv3 "
                                    "--kernel-trace --stats average of the same workload (" + os.path.relpath(ks, ROOT) + "); achieved and "
-                                   "frac use the larger of the two.  Tables+slots are 7.5 MB (Infinity-Cache resident): the HBM "
+                                   "frac use the larger of the two.  A bpr_steps_flow launch holds up to 64 steps: its algorithmic bytes "
+                                   "are steps_per_launch x the per-step count.  Tables+slots are 7.5 MB (Infinity-Cache resident): the HBM "
                                    "fraction is nominal; S-big (synthetic_big) is the HBM-resident form",
-                           "launch_period_us": dt / a.steps * 1e6 - sum(v["avg_us"] * v["launches"] for k, v in kern.items()
-                                                                          if k != dom) / max(kern[dom]["launches"], 1)}
-        step_bytes = alg[dom]
+                           "launch_period_us": None if flow else dt / a.steps * 1e6 - sum(v["avg_us"] * v["launches"] for k, v in kern.items()
+                                                                                          if k != dom) / max(kern[dom]["launches"], 1)}
+        step_bytes = alg_step
         out["kernels"] = kern
         out["step_algorithmic_GBs"] = step_bytes / (dt / a.steps) / 1e9
 
@@ -495,7 +508,7 @@ def main():
         try:
             # ---- sampler ---------------------------------------------------------------------------------
             # the default of the drop-in classes: the reference's own index stream (NumPy MT19937, bit for bit), drawn ON the
-            # device (runtime.MtSampler, csrc/mt_sampler.hip), the next epoch's sample on a second stream beside this epoch's steps
+            # device (runtime.MtSampler, csrc/mt_sampler.hip), the next epoch's sample enqueued ahead of this epoch's steps (same stream)
             epoch_gpu_s = (n_epoch / B) * (dt / a.steps)
             ms_dev = runtime.MtSampler(sess, data)
             key0, pos0 = np.random.RandomState(1).get_state()[1:3]
@@ -524,8 +537,8 @@ def main():
                                       "walks, permutation by sort + pointer chase); the default of the model classes",
                               "triples_per_s": int(cu.numel()) / t_dev_s, "ms_per_epoch": t_dev_s * 1e3, "epoch_triples": int(cu.numel()),
                               "epoch_inclusive_triples_per_s": int(cu.numel()) / steady_ep,
-                              "epoch_inclusive_note": "measured: median of 6 epochs of next_epoch() + %d steps, the next epoch's sample drawn on a second stream "
-                                                      "beside the steps; first epoch (nothing drawn ahead) %.1f ms, steady %.1f ms; the sampler alone %.1f ms, the "
+                              "epoch_inclusive_note": "measured: median of 6 epochs of next_epoch() + %d steps, the next epoch's sample enqueued in front of the "
+                                                      "steps on the same stream (the host never waits for it); first epoch %.1f ms, steady %.1f ms; the sampler alone %.1f ms, the "
                                                       "steps alone %.1f ms" % (int(cu.numel()) // B, t_ep[0] * 1e3, steady_ep * 1e3, t_dev_s * 1e3, epoch_gpu_s * 1e3),
                               "epoch_inclusive_triples_per_s_serial": int(cu.numel()) / (t_dev_s + epoch_gpu_s),
                               "first_4096_negatives_equal_host_sampler": same,

@@ -316,10 +316,33 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
     const uint32_t fl_nwg = (uint32_t)(side ? w.flow_nwg_q : w.flow_nwg_u), fl_magic = side ? w.flow_magic_q : w.flow_magic_u,
                    fl_rpb = (uint32_t)(side ? w.flow_rpb_q : w.flow_rpb_u);
     const int32_t *fl_pos = side ? w.flow_pos_q : w.flow_pos_u, *fl_row = side ? w.flow_row_q : w.flow_row_u;
-    for (int k = tid; k < n; k += PREP_THREADS) {
-        const uint32_t r = (uint32_t)(side == 0 ? u[t0 + k] : (k < nb ? i[t0 + k] : j[t0 + k - nb]));
-        rows[k] = fl_nwg ? (fl_pos ? (uint32_t)fl_pos[r] : flow_pos_of(r, fl_nwg, fl_magic, fl_rpb)) : r;
-        tag[k] = (uint16_t)k;
+    if (fl_pos) { // positions by table: a thread's ids first, then its look-ups, each round of loads issued together
+        constexpr int FIF = 6;
+        for (int k0f = tid; k0f < n; k0f += FIF * PREP_THREADS) {
+            uint32_t r[FIF];
+#pragma unroll
+            for (int e = 0; e < FIF; ++e) {
+                const int k = k0f + e * PREP_THREADS;
+                r[e] = k < n ? (uint32_t)(side == 0 ? u[t0 + k] : (k < nb ? i[t0 + k] : j[t0 + k - nb])) : 0u;
+            }
+#pragma unroll
+            for (int e = 0; e < FIF; ++e)
+                r[e] = (uint32_t)fl_pos[r[e]];
+#pragma unroll
+            for (int e = 0; e < FIF; ++e) {
+                const int k = k0f + e * PREP_THREADS;
+                if (k < n) {
+                    rows[k] = r[e];
+                    tag[k] = (uint16_t)k;
+                }
+            }
+        }
+    } else {
+        for (int k = tid; k < n; k += PREP_THREADS) {
+            const uint32_t r = (uint32_t)(side == 0 ? u[t0 + k] : (k < nb ? i[t0 + k] : j[t0 + k - nb]));
+            rows[k] = fl_nwg ? flow_pos_of(r, fl_nwg, fl_magic, fl_rpb) : r;
+            tag[k] = (uint16_t)k;
+        }
     }
 #ifdef CREC_STAMPS // phase times of workgroups 0 (user side) and 1 (item side) of the launch: crec_stamps[16000*8 + ...]
 #define CREC_IDX_MARK(k)                                                           \
@@ -583,7 +606,11 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
 #pragma unroll
         for (int e = 0; e < RIF; ++e) { // the sorted row is one of the three ids: two scattered loads per record, not three
             const int k = k0r + e * PREP_THREADS;
-            const int row = k < n ? (int)(fl_nwg ? (fl_row ? (uint32_t)fl_row[rows[k]] : flow_row_of(rows[k], fl_nwg, fl_rpb)) : rows[k]) : 0;
+            if (fl_row) { // (positions by table: the sorted key is no row id; all three ids come from the stream, independent loads)
+                rec[e] = make_int4(u[t0 + pos[e]], i[t0 + pos[e]], j[t0 + pos[e]], (int)payload[e]);
+                continue;
+            }
+            const int row = k < n ? (int)(fl_nwg ? flow_row_of(rows[k], fl_nwg, fl_rpb) : rows[k]) : 0;
             if (side == 0)
                 rec[e] = make_int4(row, i[t0 + pos[e]], j[t0 + pos[e]], (int)payload[e]);
             else if ((int)payload[e] < 0)
@@ -1672,8 +1699,8 @@ constexpr int FLOW_DEAL_MAX = 1 << 16; // rows per side the dealing takes (the c
 constexpr int FLOW_MAX_STEPS = 64;
 constexpr uint32_t FLOW_SENT = 0xffffffffu; // an unpublished row version: this in every 4-byte word; a published word is never this
                                             // (flow_publishable)
-constexpr unsigned FLOW_SPIN_CHECK = 1u << 12, FLOW_SPIN_LIMIT = 1u << 23; // polls between looks at the give-up flag; polls (each at
-                                                                           // least a memory round trip) before a wave gives up itself
+constexpr unsigned FLOW_SPIN_CHECK = 1u << 8, FLOW_SPIN_LIMIT = 1u << 20; // polls between looks at the give-up flag; polls before a wave gives up
+                                                                           // itself (backed off to ~50 us each: about a minute)
 struct FlowArgs {
     const int2 *u_rowseg, *q_rowseg; // [C][Upos], [C][Ipos]: {segment start, length} by POSITION (workgroup * rows per workgroup + slot)
     const int4 *u_occ, *q_occ;       // [C][B], [C][2B]
@@ -1891,7 +1918,16 @@ __device__ __forceinline__ void flow_wave(const Tables &src, const Tables &dst, 
                         }
                         if (any == 0)
                             break;
-                        __builtin_amdgcn_s_sleep(1);
+                        // back off: a row that is a fraction of a microsecond away is asked for again at once; a wave that has waited
+                        // long is waiting for workgroups that are not on the chip yet (another stream's kernels hold their place), and
+                        // 3 600 waves polling flat out would slow those kernels -- and so its own wait -- a hundredfold
+                        if (spins < 16)
+                            __builtin_amdgcn_s_sleep(1);
+                        else if (spins < 64)
+                            __builtin_amdgcn_s_sleep(16);
+                        else
+                            for (int z = 0; z < (spins < 256 ? 2 : 16); ++z)
+                                __builtin_amdgcn_s_sleep(127);
 #pragma unroll
                         for (int t = 0; t < DEEP; ++t) { // the records that are not there yet, by every lane (a scalar branch, no per-lane
                             if (bad[t] != 0) {           // condition around a load; a published row reads the same again)
@@ -2414,28 +2450,31 @@ __global__ __launch_bounds__(256) void bpr_adam_dense(float *__restrict__ var, f
 }
 
 // ------------------------------------------------------------------------------------
-// bpr_reduce_loss: one workgroup per batch, fixed summation order, float64 accumulation.
+// bpr_reduce_loss: RL_PARTS workgroups per batch, fixed summation order, float64 accumulation.
 //   dense: rowterm[0 .. n_dense).  lazy (n_dense == 0): one l2 term per triple, rowterm[0 .. nb).
+// Part p of a batch sums the p-th quarter of the x_b terms (softplus) and of the row terms; the part that draws the batch's last
+// ticket adds the four partial sums in part order.  (One workgroup per batch -- 6 144 expf + log1pf on ONE CU -- took 10-17 us
+// whatever the number of batches: a tenth of a 20-batch call.)  parts: [batches][RL_PARTS] doubles, tickets: [batches], zero
+// between launches.
 // ------------------------------------------------------------------------------------
-constexpr int RL_THREADS = 1024; // 6 + 10 terms per thread at ml-1m shape: two rounds of loads (256 threads: eight, 12 -> 7 us per chunk of 20 batches)
+constexpr int RL_THREADS = 512, RL_PARTS = 4;
 __global__ __launch_bounds__(RL_THREADS) void bpr_reduce_loss(const float *__restrict__ ws, int64_t stride, int64_t n_total,
                                                        int32_t B, int64_t n_dense, const int32_t *__restrict__ n_u,
-                                                       const int32_t *__restrict__ n_q, float reg,
-                                                       float *__restrict__ loss_per_batch)
+                                                       const int32_t *__restrict__ n_q, float reg, double *__restrict__ parts,
+                                                       int32_t *__restrict__ tickets, float *__restrict__ loss_per_batch)
 {
     __shared__ double part[RL_THREADS];
-    const int64_t t0 = (int64_t)blockIdx.x * B;
+    const int batch = blockIdx.x / RL_PARTS, p = blockIdx.x % RL_PARTS;
+    const int64_t t0 = (int64_t)batch * B;
     const int nb = (int)((n_total - t0) < B ? (n_total - t0) : B);
-    const float *xb = ws + blockIdx.x * stride, *rowterm = xb + B;
-    double s = 0.0, l2 = 0.0;
-    // a thread's terms are added in ascending k; the loads of eight of them are issued together (a load per add was a
-    // chain of ~60 dependent round trips: 24 us for a chunk of 20 batches)
-    const auto sum_f = [](const float *p, int64_t n, auto f, double acc) {
+    const float *xb = ws + batch * stride, *rowterm = xb + B;
+    // a thread's terms are added in ascending k; the loads of eight of them are issued together
+    const auto sum_f = [](const float *q, int64_t n, auto f, double acc) {
         for (int64_t k = threadIdx.x; k < n; k += 8 * RL_THREADS) {
             float t[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-                t[e] = k + e * RL_THREADS < n ? p[k + e * RL_THREADS] : 0.f;
+                t[e] = k + e * RL_THREADS < n ? q[k + e * RL_THREADS] : 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e)
                 if (k + e * RL_THREADS < n)
@@ -2443,13 +2482,16 @@ __global__ __launch_bounds__(RL_THREADS) void bpr_reduce_loss(const float *__res
         }
         return acc;
     };
+    const auto share = [&](int64_t n, int64_t *lo) { // this part's [lo, lo + count) of n terms
+        const int64_t per = (n + RL_PARTS - 1) / RL_PARTS;
+        *lo = per * p < n ? per * p : n;
+        return (*lo + per) < n ? per : n - *lo;
+    };
     const auto ident = [](float x) { return x; };
-    s = sum_f(xb, nb, [](float x) { return tf_softplus(-x); }, 0.0);
-    if (n_dense > 0) {
-        l2 = sum_f(rowterm, n_dense, ident, 0.0);
-    } else { // lazy mode: one l2 term per triple (bpr_triples_lazy), 0.5*(|p_u|^2 + |q_i|^2 + |q_j|^2) as in BPR.py:42-43
-        l2 = sum_f(rowterm, nb, ident, 0.0);
-    }
+    int64_t lo_x, lo_r;
+    const int64_t nx = share(nb, &lo_x), nr = share(n_dense > 0 ? n_dense : (int64_t)nb, &lo_r); // lazy mode: one l2 term per triple
+    const double s = sum_f(xb + lo_x, nx, [](float x) { return tf_softplus(-x); }, 0.0);
+    const double l2 = sum_f(rowterm + lo_r, nr, ident, 0.0);
     part[threadIdx.x] = s + (double)reg * l2;
     __syncthreads();
     for (int off = RL_THREADS / 2; off > 0; off >>= 1) {
@@ -2457,8 +2499,17 @@ __global__ __launch_bounds__(RL_THREADS) void bpr_reduce_loss(const float *__res
             part[threadIdx.x] += part[threadIdx.x + off];
         __syncthreads();
     }
-    if (threadIdx.x == 0)
-        loss_per_batch[blockIdx.x] = (float)part[0];
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(parts + (int64_t)batch * RL_PARTS + p, part[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the agent-scope store has arrived where the other workgroups read)
+        if (__hip_atomic_fetch_add(tickets + batch, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == RL_PARTS - 1) {
+            double tot = 0.0;
+            for (int q = 0; q < RL_PARTS; ++q) // part order: the sum does not depend on which part came last
+                tot += __hip_atomic_load(parts + (int64_t)batch * RL_PARTS + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            loss_per_batch[batch] = (float)tot;
+            __hip_atomic_store(tickets + batch, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next launch
+        }
+    }
 }
 
 #include "shard_kernels.h"
@@ -2578,6 +2629,24 @@ int setup_lazy_bufs(crec_ctx *ctx, int64_t B, int d, int CH, hipStream_t st, Laz
 }
 
 using StepFn = void (*)(const StepArgs &, const IndexWs &, int64_t, const int32_t *);
+
+// bpr_reduce_loss's scratch for `nbc` batches: RL_PARTS partial sums and one ticket per batch (the tickets are cleared when the buffer
+// moves or grows; the kernel leaves them at zero)
+int loss_parts(crec_ctx *ctx, int64_t nbc, hipStream_t st, double **parts, int32_t **tickets)
+{
+    const size_t pbytes = align_up(sizeof(double) * RL_PARTS * (size_t)nbc, 256), tbytes = sizeof(int32_t) * (size_t)nbc;
+    const void *before = ctx->loss_parts.ptr;
+    const size_t had = ctx->loss_parts.bytes;
+    if (int rc = crec_reserve(ctx, &ctx->loss_parts, pbytes + tbytes + 4096))
+        return rc;
+    if (ctx->loss_parts.ptr != before || ctx->loss_parts.bytes != had) // (a fresh buffer)
+        CREC_HIP(ctx, hipMemsetAsync(ctx->loss_parts.ptr, 0, ctx->loss_parts.bytes, st));
+    // (laid out by what the buffer holds, so that the tickets stay where they were cleared while it does not move)
+    const size_t cap = (ctx->loss_parts.bytes - 256) / (sizeof(double) * RL_PARTS + sizeof(int32_t)); // batches it holds (>= nbc)
+    *parts = (double *)ctx->loss_parts.ptr;
+    *tickets = (int32_t *)((char *)ctx->loss_parts.ptr + align_up(sizeof(double) * RL_PARTS * cap, 256));
+    return CREC_OK;
+}
 
 // rows of one side dealt to nwg workgroups of rpb slots: pos_of[row] = workgroup * rpb + slot, row_of[position] = row or -1
 void flow_deal_host(const int32_t *cnt, int n, int nwg, int rpb, int32_t *pos_of, int32_t *row_of)
@@ -3212,10 +3281,14 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
             opt->beta2_power = opt->beta2_power * opt->beta2;
             opt->step += 1;
         }
+        double *l_parts;
+        int32_t *l_tickets;
+        if (int rc = loss_parts(ctx, chunk, st, &l_parts, &l_tickets))
+            return rc;
         crec_prof_begin(ctx, CREC_K_REDUCE_LOSS, st);
-        CREC_KLAUNCH(ctx, bpr_reduce_loss, dim3((unsigned)nbc), dim3(RL_THREADS), 0, st, (const float *)ctx->loss_ws.ptr,
+        CREC_KLAUNCH(ctx, bpr_reduce_loss, dim3((unsigned)(nbc * RL_PARTS)), dim3(RL_THREADS), 0, st, (const float *)ctx->loss_ws.ptr,
                            loss_stride, n_chunk, B, dense ? t->U + t->I : (int64_t)0, (const int32_t *)w.n_u,
-                           (const int32_t *)w.n_q, opt->reg, loss_per_batch + b0);
+                           (const int32_t *)w.n_q, opt->reg, l_parts, l_tickets, loss_per_batch + b0);
         crec_prof_end(ctx, st);
         if (dp) {
             if (int rc = xdp->allreduce_sum_f32(ctx, loss_per_batch + b0, (size_t)nbc, st))
@@ -3645,9 +3718,13 @@ int sharded_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, int64_t I_global
             opt->beta2_power = opt->beta2_power * opt->beta2;
             opt->step += 1;
         }
+        double *l_parts;
+        int32_t *l_tickets;
+        if (int rc = loss_parts(ctx, chunk, st, &l_parts, &l_tickets))
+            return rc;
         crec_prof_begin(ctx, CREC_K_REDUCE_LOSS, st);
-        CREC_KLAUNCH(ctx, bpr_reduce_loss, dim3((unsigned)nbc), dim3(RL_THREADS), 0, st, (const float *)ctx->loss_ws.ptr, loss_stride,
-                     n_chunk, B, (int64_t)0, (const int32_t *)w.n_u, (const int32_t *)w.n_q, opt->reg, loss_per_batch + b0);
+        CREC_KLAUNCH(ctx, bpr_reduce_loss, dim3((unsigned)(nbc * RL_PARTS)), dim3(RL_THREADS), 0, st, (const float *)ctx->loss_ws.ptr, loss_stride,
+                     n_chunk, B, (int64_t)0, (const int32_t *)w.n_u, (const int32_t *)w.n_q, opt->reg, l_parts, l_tickets, loss_per_batch + b0);
         crec_prof_end(ctx, st);
         if (int rc = x->allreduce_sum_f32(ctx, loss_per_batch + b0, (size_t)nbc, st))
             return rc;

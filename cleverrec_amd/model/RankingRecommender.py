@@ -30,8 +30,9 @@ class RankingRecommender(Recommender):
         #                 the kernels' limits (item_nums > 262144) fall to the same stream drawn by the host C++ form
         #   mt19937_host  the host C++ form (utils/sampler.py), same streams
         #   device        same acceptance rule on a counter-based generator: statistically equivalent, NOT stream-compatible
-        # `sampler_prefetch` (default True): the NEXT epoch's sample is drawn while the GPU trains on this one (device form: on a
-        # second stream; host form: on a host thread); the streams and np.random's state afterwards are unchanged
+        # `sampler_prefetch` (default True): the NEXT epoch's sample is drawn ahead (device form: enqueued in front of this epoch's
+        # steps, the host never waits for it; host form: on a host thread while the GPU trains); the streams and np.random's state
+        # afterwards are unchanged
         self.sampler_prefetch = str(configs.get('sampler_prefetch', 'True')).lower() not in ('false', '0', 'no')
         self._dev_sampler = self._mt_sampler = None
         mode = str(configs.get('sampler_mode', 'mt19937')).lower()

@@ -539,8 +539,8 @@ class MtSampler:
 
     next_epoch(kind, neg_ratio) is the drop-in: it reads np.random's state, returns the sample the reference would
     draw now and leaves np.random where the reference would.  With ahead=True the sample after this one is enqueued
-    on a second stream right away (from the state this one ends in) and runs beside the training steps of this
-    epoch; it is used at the next call only if np.random still stands exactly there."""
+    right away (from the state this one ends in, on the caller's stream: it runs in front of this epoch's training steps
+    and the host never waits for it); it is used at the next call only if np.random still stands exactly there."""
 
     KINDS = {"pairwise": 0, "pointwise": 1, "cml": 2}
 
@@ -629,5 +629,10 @@ class MtSampler:
             cols, end = self.sample(kind, neg_ratio, st[1], st[2])
         np.random.set_state(("MT19937", end[0], end[1], st[3], st[4]))  # no normals drawn: the cached gaussian stays
         if ahead:
-            self.enqueue(kind, neg_ratio, end[0], end[1], stream=self.side)
+            # on the CALLER's stream, in front of this epoch's steps -- not beside them.  The host still never waits for a sample, and
+            # the GPU time is the same (an epoch's steps take 2.3 ms since they run as dataflow launches, a sample 2.2 ms: one after the
+            # other 4.5 ms, beside each other they took 4.8); but a bpr_steps_flow launch needs every one of its workgroups on the chip
+            # at once, and beside another stream's kernels with 1024-thread workgroups -- the sampler's walks and sorts -- the two
+            # launches can keep each other's last workgroups off the chip for ever (seen: the launch gave up after its time-out)
+            self.enqueue(kind, neg_ratio, end[0], end[1], stream=None)
         return cols

@@ -4,7 +4,8 @@
 set -o pipefail
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 OUT=$ROOT/gpurun_out/profiles
-R=${ROUND:-round3}   # file name prefix of the summaries (copy the ones to be judged into profiles/)
+R=${ROUND:-round4}
+DOM=${DOM:-bpr_steps_flow}   # the headline's dominant kernel (bpr_step_fused with CREC_FLOW=0)   # file name prefix of the summaries (copy the ones to be judged into profiles/)
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
@@ -21,10 +22,10 @@ for r in rows:
     name = (m.group(0) if m else r["Name"].split("(")[0])[:60]
     print("%-60s %8s %14s %12.1f %8s" % (name, r["Calls"], r["TotalDurationNs"], float(r["AverageNs"]), r["Percentage"]))
 PY
-python $ROOT/tools/trace_steady.py $OUT/trace bpr_step_fused 456 >> $OUT/kernel_stats.txt
+python $ROOT/tools/trace_steady.py $OUT/trace $DOM $([ "$DOM" = bpr_steps_flow ] && echo 8 || echo 456) >> $OUT/kernel_stats.txt
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_SALU"; do
   n=$(echo $c | cut -d" " -f1)
-  rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$n -- python $ROOT/bench.py --steps 100 --warmup 10 --no-extras > /dev/null 2>&1 || echo "pmc $n failed"
+  rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$n -- python $ROOT/bench.py --steps 910 --warmup 455 --no-extras > /dev/null 2>&1 || echo "pmc $n failed"
 done
 # the HBM-resident form of the path (S-big) and the catalogue-scale eval: kernel-trace stats only
 if [ -z "$HEADLINE_ONLY" ]; then  # HEADLINE_ONLY=1: only the headline workload's kernel stats, counters and traffic.json
@@ -59,7 +60,7 @@ python tools/pmc_summary.py $OUT/pmcbigbatch_* > $OUT/bigbatch_pmc_summary.txt
 python tools/pmc_summary.py $OUT/pmceval_* > $OUT/eval_big_pmc_summary.txt
 python tools/pmc_summary.py $OUT/pmcmodels_* > $OUT/models_pmc_summary.txt
 fi
-python tools/traffic_json.py $OUT/pmc_summary.txt bpr_step_fused > $OUT/traffic.json
+python tools/traffic_json.py $OUT/pmc_summary.txt $DOM > $OUT/traffic.json
 for f in kernel_stats.txt pmc_summary.txt big_kernel_stats.txt bigbatch_kernel_stats.txt bigbatch_pmc_summary.txt bigbatch_sharded_kernel_stats.txt big_sharded_kernel_stats.txt big_pmc_summary.txt eval_big_kernel_stats.txt eval_big_pmc_summary.txt models_kernel_stats.txt models_pmc_summary.txt traffic.json; do
   [ -f $OUT/$f ] && cp $OUT/$f $OUT/${R}_$f
 done
