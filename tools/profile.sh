@@ -9,13 +9,13 @@ DOM=${DOM:-bpr_steps_flow}   # the headline's dominant kernel (bpr_step_fused wi
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--steps 1824 --warmup 456 --no-extras"
+ARGS="--steps 1820 --warmup 455 --no-extras"   # whole-epoch calls (455 batches): the launch mix of bench.py's own per-kernel pass
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $ROOT/bench.py $ARGS > $OUT/bench_under_trace.json 2>/dev/null
 f=$(find $OUT/trace -name "*kernel_stats.csv" | head -1)
 python - "$f" > $OUT/kernel_stats.txt <<'PY'
 import csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-print("rocprofv3 --kernel-trace --stats -- python bench.py --steps 1824 --warmup 456 --no-extras")
+print("rocprofv3 --kernel-trace --stats -- python bench.py --steps 1820 --warmup 455 --no-extras")
 print("%-60s %8s %14s %12s %8s" % ("kernel", "calls", "total_ns", "avg_ns", "pct"))
 for r in rows:
     m = re.search(r"(bpr_\w+|eval_\w+|rank_metrics\w*|shard_\w+|ncf_\w+|fm_\w+|cml_\w+|rows_\w+|apply_all|small_adam\w*|topk_\w+|lrml_\w+|tcf_\w+|sbpr_\w+|cune_\w+|sort_\w+|big_\w+|plan_\w+|own_\w+|flat_heads|peer_\w+)(<[^>]*>)?", r["Name"])
