@@ -643,7 +643,7 @@ def main():
                 # sweep) at 1, 16 and (at most) 64 threads -- 64: the most a 6144-row operand keeps busy; with all 256 hardware threads of the GPU host one step took 9 s in round 2, and the argsort / Python-filter evaluation loop -- each on a bounded sample
                 from oracle import reference_style
                 n_all = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-                out["cpu_baseline"]["reference_style"] = reference_style.measure(data, P0, Q0, u, i, j, B, NEG, sorted({1, min(16, n_all), min(64, n_all)}), budget_s=3.0)
+                out["cpu_baseline"]["reference_style"] = reference_style.measure(data, P0, Q0, u, i, j, B, NEG, sorted({1, min(8, n_all), min(16, n_all), min(64, n_all)}), budget_s=3.0)
                 out["cpu_baseline"]["reference_style"]["note"] = ("TensorFlow 1.x is not installable here: the TF1-CPU path is represented by the same "
                                                                   "structure on PyTorch-CPU (oracle/reference_style.py); cores = torch.set_num_threads(n)")
         except Exception as e:  # noqa: BLE001
