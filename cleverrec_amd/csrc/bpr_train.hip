@@ -154,6 +154,15 @@ struct IndexWs {
     int32_t *order;                 // [nbc][B] batch position per processing slot
     int32_t *nslots;                // [nbc][2]  {triples of the batch, of which in the item-sorted front region}
     int32_t spw;                    // processing slots per workgroup of the triple pass
+    // lazy mode, W consecutive batches in ONE launch (option lazy_window; bpr_triples_lazy<.., WIN>): per (batch, side) the sorted
+    // unique rows, their segment starts and a presence filter -- what lazy_window_deps needs to find, for every row a triple
+    // reads, the last EARLIER batch of the window that touches it -- and its result per processing slot
+    int32_t win;                    // 0: off
+    int32_t *wn;                    // [nbc][2] unique rows of the side
+    int32_t *wrow_u, *wst_u;        // [nbc][B]   row / segment start by rank
+    int32_t *wrow_q, *wst_q;        // [nbc][2B]
+    uint32_t *wfilt;                // [nbc][2][WF_WORDS] bit hash(row): the side names a row with this hash (zeroed per chunk)
+    int4 *wdeps;                    // [nbc][B] by processing slot: {user, positive, negative, -}: -1 or batch-in-window << 20 | segment start
     int4 *u_hrows, *q_hrows;   // [nbc][HRu|HRq]  {row, first chunk, chunks<<16 | length, rank among unique rows}
     int4 *u_hitems, *q_hitems; // [nbc][HIu|HIq]  {row, segment start, length | heavy row index << 8, chunk index}
     int64_t B, U, I, HRu, HRq, HIu, HIq;
@@ -196,6 +205,8 @@ __device__ __forceinline__ uint32_t flow_pos_of(uint32_t row, uint32_t nwg, uint
 __device__ __forceinline__ uint32_t flow_row_of(uint32_t pos, uint32_t nwg, uint32_t rpb) { return (pos & (rpb - 1)) * nwg + pos / rpb; }
 
 constexpr int HN = 8; // per-batch counters the host reads back
+constexpr int WF_WORDS = 4096, WF_SHIFT = 15; // lazy_window's presence filter: 2^17 bits per (batch, side)
+__device__ __forceinline__ uint32_t wf_hash(uint32_t row) { return (row * 2654435761u) >> WF_SHIFT; }
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -215,7 +226,7 @@ inline int row_bits(int64_t n_rows)
 inline int lazy_spw(int d) { return d <= 4 ? 64 : (d > 128 ? 16 : (d > 64 && CREC_LAZY_SPW > 32 ? 32 : CREC_LAZY_SPW)); }
 
 IndexWs layout_index(void *base, int64_t nbc, int64_t B, int64_t U, int64_t I, bool dense, int CH, int wide_rows = 0,
-                     int wide_total = 0, int spw = 32, int flow_rpb = 0, int flow_nwg_u = 0, int flow_nwg_q = 0)
+                     int wide_total = 0, int spw = 32, int flow_rpb = 0, int flow_nwg_u = 0, int flow_nwg_q = 0, int win = 0)
 {
     IndexWs w{};
     w.B = B;
@@ -269,6 +280,15 @@ IndexWs layout_index(void *base, int64_t nbc, int64_t B, int64_t U, int64_t I, b
     w.j_tmp = (int4 *)take(sizeof(int4) * nbc * (dense ? 0 : B));
     w.nslots = (int32_t *)take(sizeof(int32_t) * nbc * (dense ? 0 : 2));
     w.spw = spw;
+    w.win = dense ? 0 : win;
+    const int64_t wq = w.win ? 1 : 0;
+    w.wn = (int32_t *)take(sizeof(int32_t) * nbc * 2 * wq);
+    w.wrow_u = (int32_t *)take(sizeof(int32_t) * nbc * B * wq);
+    w.wst_u = (int32_t *)take(sizeof(int32_t) * nbc * B * wq);
+    w.wrow_q = (int32_t *)take(sizeof(int32_t) * nbc * 2 * B * wq);
+    w.wst_q = (int32_t *)take(sizeof(int32_t) * nbc * 2 * B * wq);
+    w.wfilt = (uint32_t *)take(sizeof(uint32_t) * nbc * 2 * WF_WORDS * wq);
+    w.wdeps = (int4 *)take(sizeof(int4) * nbc * B * wq);
     w.wide_rows = dense && wide_total > 0 ? wide_rows : 0;
     w.wide_total = wide_total;
     w.WMu = w.wide_rows ? B / (wide_total + 1) + 1 : 0;
@@ -381,6 +401,21 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
         // slots, so the workgroups of the pass (SPW slots each) can add a row's contributions in LDS -- a row that lies
         // inside one workgroup is finished there without any memory round trip, a longer one leaves one partial per
         // workgroup it crosses instead of one contribution row per slot.
+        if (w.win) { // (lazy_window) the side's unique rows by rank, their segment starts, the presence filter
+            int32_t *wr = side ? w.wrow_q + (int64_t)batch * 2 * B : w.wrow_u + (int64_t)batch * B;
+            int32_t *ws = side ? w.wst_q + (int64_t)batch * 2 * B : w.wst_u + (int64_t)batch * B;
+            uint32_t *wf = w.wfilt + ((int64_t)batch * 2 + side) * WF_WORDS;
+            for (int q = tid; q < total; q += PREP_THREADS) {
+                const uint32_t r = rows[seg[q]];
+                wr[q] = (int32_t)r;
+                ws[q] = (int32_t)seg[q];
+                const uint32_t hs = wf_hash(r);
+                atomicOr(wf + (hs >> 5), 1u << (hs & 31u));
+            }
+            if (tid == 0)
+                w.wn[batch * 2 + side] = total;
+            __syncthreads(); // (the front rows' layout words below overwrite rows[start + 1])
+        }
         uint16_t *wt = (uint16_t *)hist; // [B] per position: 0xffff = in the item-sorted front region, else the busier item row's count
         const int SPW = w.spw;
         int32_t *ord = w.order + (int64_t)batch * B;
@@ -665,6 +700,9 @@ struct Hyper {
     const float *lr_tab;     // lr_s by step s (1-based), device
     int32_t *lastP, *lastQ;  // per row: the step its state is current at
     int32_t step;            // the step being applied
+    // lazy_window: where whoever finishes a row leaves this batch's stamp (by segment start; null: a launch per batch)
+    int32_t *win_done_u = nullptr, *win_done_q = nullptr;
+    int32_t win_stamp = 0;
 };
 
 struct Tables { // one buffer set
@@ -747,6 +785,25 @@ __device__ __forceinline__ float4 ld4_buf(const float *base, int64_t off)
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, 0x7fffffff, 0x00020000);
     const crec_u4v x = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(off * 4), 0, 0);
     return make_float4(__uint_as_float(x.x), __uint_as_float(x.y), __uint_as_float(x.z), __uint_as_float(x.w));
+}
+// 16-byte agent-scope load / written-through store at a full 64-bit address (tables beyond the 2 GiB a buffer offset spans).  Inline
+// assembly: the compiler neither counts these loads nor waits for them -- ld4_sc1g_wait (an s_waitcnt the loaded registers pass
+// through) must stand between the loads and the first use of any of them
+__device__ __forceinline__ crec_f4v ld4_sc1g(const float *p)
+{
+    crec_f4v x;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(x) : "v"(p) : "memory");
+    return x;
+}
+__device__ __forceinline__ void ld4_sc1g_wait(crec_f4v &a, crec_f4v &b, crec_f4v &c, crec_f4v &d_, crec_f4v &e)
+{
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d_), "+v"(e)::"memory");
+}
+__device__ __forceinline__ float4 f4_of(crec_f4v x) { return make_float4(x.x, x.y, x.z, x.w); }
+__device__ __forceinline__ void st4_wtg(float *p, float4 v)
+{
+    const crec_f4v x = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
 }
 // the lazy step's published rows (contributions, partials): agent-scope accesses + s_waitcnt, or -- CREC_TICKET_FENCES,
 // the textbook form kept buildable and compared bit for bit under test (tests/test_gpu_fences.py) -- plain accesses
@@ -2051,6 +2108,64 @@ __global__ __launch_bounds__(CREC_FUSED_BLOCK) __attribute__((amdgpu_waves_per_e
 // ------------------------------------------------------------------------------------
 // lazy mode: touched rows only, in place, one launch
 // ------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------
+// W consecutive batches of the lazy-family step in ONE launch (option lazy_window).  A launch of 6 144 triples is too
+// short for the memory system (a bare gather-update launch of that size takes as long as the whole step); what a longer launch
+// needs in order to stay EXACT is that a triple of batch b reads a row only after the last earlier batch of the window that
+// touches the row has finished it.  lazy_window_deps finds that batch for every row of every triple (per other batch of the
+// window one probe of its presence filter, a binary search in its sorted unique rows where the filter says yes); in the launch,
+// whoever finishes a row writes it through and then leaves a stamp at (batch, side, segment start), and a triple with such a
+// predecessor waits for that stamp before it asks for the row.  Batches are dispatched in order (blockIdx.y), so a wave only ever
+// waits for workgroups dispatched before its own, which never wait for later ones: no residency requirement, no dead-lock.
+// ------------------------------------------------------------------------------------
+constexpr int LAZY_WIN_MAX = 16;
+struct LazyWin {
+    int W;                 // batches of this launch
+    int64_t B;             // triples per batch = the stride of the per-batch index arrays
+    int64_t n_left;        // triples from this launch's first batch to the end of the stream (the last batch may be short)
+    int64_t loss_stride;   // floats between two batches' loss terms
+    int64_t z_stride;      // rows (and counters) between two batches' contribution buffers: 6 B
+    const int4 *deps;      // [W][B] by processing slot (IndexWs::wdeps of the launch's first batch)
+    int32_t *done;         // [LAZY_WIN_MAX][3 B] stamps by (batch in window, segment start; user side first, item side from B)
+    int32_t stamp0;        // the stamp of the launch's first batch (a ctx-wide launch counter: never repeats)
+    int32_t *err;          // give-up flag (page-locked)
+    float lr_t[LAZY_WIN_MAX];
+};
+
+__global__ __launch_bounds__(256) void lazy_window_deps(IndexWs w, int W)
+{
+    const int b = blockIdx.y, slot = blockIdx.x * 256 + threadIdx.x;
+    const int64_t B = w.B;
+    if (slot >= w.nslots[b * 2])
+        return;
+    const int w0 = b - b % W;
+    const int2 pu = w.slot_pu[(int64_t)b * B + slot];
+    const uint32_t rows[3] = {(uint32_t)pu.y, (uint32_t)w.i_desc[(int64_t)b * B + slot].x & 0x7fffffffu,
+                              (uint32_t)w.j_desc[(int64_t)b * B + slot].x & 0x7fffffffu};
+    int dep[3] = {-1, -1, -1};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int side = r ? 1 : 0;
+        const uint32_t row = rows[r], hs = wf_hash(row);
+        for (int bp = b - 1; bp >= w0 && dep[r] < 0; --bp) { // the nearest earlier batch of the window that names the row
+            if (!((w.wfilt[((int64_t)bp * 2 + side) * WF_WORDS + (hs >> 5)] >> (hs & 31u)) & 1u))
+                continue;
+            const int32_t *wr = side ? w.wrow_q + (int64_t)bp * 2 * B : w.wrow_u + (int64_t)bp * B;
+            int lo = 0, hi = w.wn[bp * 2 + side];
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if ((uint32_t)wr[mid] < row)
+                    lo = mid + 1;
+                else
+                    hi = mid;
+            }
+            if (lo < w.wn[bp * 2 + side] && (uint32_t)wr[lo] == row)
+                dep[r] = ((bp - w0) << 20) | (side ? w.wst_q + (int64_t)bp * 2 * B : w.wst_u + (int64_t)bp * B)[lo];
+        }
+    }
+    w.wdeps[(int64_t)b * B + slot] = make_int4(dep[0], dep[1], dep[2], 0);
+}
+
 struct LazyBufs {
     float *ucontrib, *qcontrib; // [B][d], [2B][d] contribution rows by sorted slot position (sign and s_b applied)
     float *upart, *qpart;       // [B][d], [2B][d] partial sums of heavy rows' chunks, at the chunk's first slot position
@@ -2127,9 +2242,26 @@ __device__ __forceinline__ LazyTicket lazy_ticket_of(int4 desc, int CH)
 // step sends an item row's sum back to its owner instead; deferred Adam first replays the steps the row sat out
 template <int LPR, bool USER, bool DEFER>
 __device__ __forceinline__ void lazy_finish_row(const Tables &t, int d, bool act, int row, float4 own, float4 g, float4 m, float4 v,
-                                                const Hyper &h)
+                                                const Hyper &h, int seg_start = 0)
 {
     const int l = (threadIdx.x & 63) % LPR;
+    int32_t *const win_done = USER ? h.win_done_u : h.win_done_q;
+    if (win_done) { // lazy_window: the row written through, then -- once the stores have arrived -- this batch's stamp for the row's
+        if (act) {  // next readers in the window (every lane of the group is here: the wait is the wave's)
+            const int64_t ro = (int64_t)row * d + 4 * l;
+            float4 nv = own;
+            opt4(nv, m, v, g, h);
+            st4_wtg((USER ? t.P : t.Q) + ro, nv);
+            if (h.opt != CREC_OPT_SGD)
+                st4_wtg((USER ? t.mP : t.mQ) + ro, m);
+            if (h.opt == 0)
+                st4_wtg((USER ? t.vP : t.vQ) + ro, v);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (l == 0)
+            __hip_atomic_store(win_done + seg_start, h.win_stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
     if (!act)
         return;
     const int64_t ro = (int64_t)row * d + 4 * l;
@@ -2173,8 +2305,19 @@ __device__ __forceinline__ void lazy_role_tail(const Tables &t, int d, bool act,
     const bool slots = act && (USER || !h.dQ);
     // the slots are only needed at the very end: asked for now, their round trip hides behind the contributions'
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 m = slots && h.opt != CREC_OPT_SGD ? ld4((USER ? t.mP : t.mQ) + ro) : zero;
-    float4 v = slots && h.opt == 0 ? ld4((USER ? t.vP : t.vQ) + ro) : zero;
+    float4 m = zero, v = zero;
+    if ((USER ? h.win_done_u : h.win_done_q) != nullptr) { // lazy_window: every load of a table row is an agent-scope one
+        crec_f4v rm = {0.f, 0.f, 0.f, 0.f}, rv = rm, r2 = rm, r3 = rm, r4 = rm;
+        if (slots && h.opt != CREC_OPT_SGD)
+            rm = ld4_sc1g((USER ? t.mP : t.mQ) + ro);
+        if (slots && h.opt == 0)
+            rv = ld4_sc1g((USER ? t.vP : t.vQ) + ro);
+        ld4_sc1g_wait(rm, rv, r2, r3, r4);
+        m = f4_of(rm), v = f4_of(rv);
+    } else {
+        m = slots && h.opt != CREC_OPT_SGD ? ld4((USER ? t.mP : t.mQ) + ro) : zero;
+        v = slots && h.opt == 0 ? ld4((USER ? t.vP : t.vQ) + ro) : zero;
+    }
     const float4 regrow = make_float4(h.reg * own.x, h.reg * own.y, h.reg * own.z, h.reg * own.w);
     int32_t *ctr = (q.chunked ? chk_t : row_t) + q.idx;
     float4 g = zero;
@@ -2204,7 +2347,7 @@ __device__ __forceinline__ void lazy_role_tail(const Tables &t, int d, bool act,
         if (l == 0)
             __hip_atomic_store(row_t + start, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    lazy_finish_row<LPR, USER, DEFER>(t, d, act, row, own, g, m, v, h);
+    lazy_finish_row<LPR, USER, DEFER>(t, d, act, row, own, g, m, v, h, start);
 }
 
 // bpr_triples_lazy: a lane group per processing slot; a workgroup = SPW slots (IndexWs::order, ::nslots); ud / id / jd: the
@@ -2214,17 +2357,33 @@ template <int LPR> struct LazyGeo {
                          THREADS = SPW * LPR; // = lazy_spw(d)
 };
 
-template <int LPR, bool FULL, bool DEFER>
+template <int LPR, bool FULL, bool DEFER, bool WIN = false>
 __global__ __launch_bounds__(LazyGeo<LPR>::THREADS) void bpr_triples_lazy(Tables t, int d, const int2 *__restrict__ slot_pu, int n_slots,
                                                                           const int32_t *__restrict__ nslots,
                                                                           const int4 *__restrict__ ud, const int4 *__restrict__ id,
                                                                           const int4 *__restrict__ jd, LazyBufs z,
-                                                                          float *__restrict__ xb, float *__restrict__ l2b, Hyper h)
+                                                                          float *__restrict__ xb, float *__restrict__ l2b, Hyper h, LazyWin win)
 {
     constexpr int SPW = LazyGeo<LPR>::SPW;
     extern __shared__ float4 blk_rows[]; // [SPW][LPR], workgroups of the front region only
     const int lane = threadIdx.x & 63, l = lane % LPR, gw = (int)threadIdx.x / LPR;
     const int slot0 = (int)blockIdx.x * SPW;
+    if (WIN) { // batch blockIdx.y of the launch's window: its slices of every per-batch array, its learning rate, its stamp
+        const int wb = blockIdx.y;
+        const int64_t left = win.n_left - (int64_t)wb * win.B;
+        n_slots = (int)(left < win.B ? left : win.B);
+        slot_pu += (int64_t)wb * win.B, ud += (int64_t)wb * win.B, id += (int64_t)wb * win.B, jd += (int64_t)wb * win.B;
+        nslots += wb * 2;
+        xb += (int64_t)wb * win.loss_stride, l2b += (int64_t)wb * win.loss_stride;
+        const int64_t zr = (int64_t)wb * win.z_stride * d, zc = (int64_t)wb * win.z_stride;
+        z.ucontrib += zr, z.qcontrib += zr, z.upart += zr, z.qpart += zr;
+        z.urow_t += zc, z.uchk_t += zc, z.qrow_t += zc, z.qchk_t += zc;
+        win.deps += (int64_t)wb * win.B;
+        h.lr_t = win.lr_t[wb];
+        h.win_done_u = win.done + (int64_t)wb * 3 * win.B;
+        h.win_done_q = h.win_done_u + win.B;
+        h.win_stamp = win.stamp0 + wb;
+    }
     // ONE round of coalesced loads, by processing slot, gives every address of the next round: {position, user row} and the
     // two item descriptors.  (n_slots = the batch's triples comes from the host; the size of the front region and the
     // user's own descriptor -- needed only where the user occurs more than once -- arrive alongside.)
@@ -2250,6 +2409,38 @@ __global__ __launch_bounds__(LazyGeo<LPR>::THREADS) void bpr_triples_lazy(Tables
     const int blk_n = blk_lead ? ((i_ci - i_posr) < (SPW - gw) ? (i_ci - i_posr) : (SPW - gw)) : 0; // the piece's slots = the leader's weight
     const bool blk_whole = blk_lead && blk_n == i_cnt; // the row lies inside this workgroup: no ticket, no memory round trip
     float4 p = zero, qi = zero, qj = zero, mp = zero, vp = zero, mi = zero, vi = zero, mj = zero, vj = zero;
+    if (WIN) { // rows an earlier batch of this launch rewrites: not asked for before that batch's stamp is there
+        const int4 dp = valid ? win.deps[slot] : make_int4(-1, -1, -1, 0);
+        if (__builtin_amdgcn_ballot_w64(valid && (dp.x >= 0 || dp.y >= 0 || dp.z >= 0)) != 0) {
+            unsigned spins = 0;
+            for (;;) {
+                bool pend = false;
+                if (valid && l == 0) {
+                    const int deps3[3] = {dp.x, dp.y, dp.z};
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        if (deps3[r] >= 0) {
+                            const int wbp = deps3[r] >> 20;
+                            const int32_t *f = win.done + (int64_t)wbp * 3 * win.B + (r ? win.B : 0) + (deps3[r] & 0xfffff);
+                            pend |= __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != win.stamp0 + wbp;
+                        }
+                    }
+                }
+                if (__builtin_amdgcn_ballot_w64(pend) == 0)
+                    break;
+                if (spins < 16)
+                    __builtin_amdgcn_s_sleep(2);
+                else
+                    for (int zz = 0; zz < (spins < 256 ? 1 : 16); ++zz)
+                        __builtin_amdgcn_s_sleep(127);
+                if ((++spins & 255u) == 0 && (spins >= (1u << 20) || __hip_atomic_load(win.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0)) {
+                    if (lane == 0)
+                        __hip_atomic_store(win.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+            }
+        }
+    }
 #if CREC_LAZY_HEADSTART
     // A head start for the rows with a tail.  All waves of the launch are resident at once and ask for their rows in the
     // first microsecond; the memory system then needs the whole body's time to serve them, in no particular order, so a
@@ -2261,7 +2452,34 @@ __global__ __launch_bounds__(LazyGeo<LPR>::THREADS) void bpr_triples_lazy(Tables
         for (int k = 0; k < CREC_LAZY_HEADSTART; ++k)
             __builtin_amdgcn_s_sleep(16); // 16 x 64 clocks = 0.43 us
 #endif
-    if (on) { // every address is known: one round of loads
+    if (WIN) { // every load of a table row is an agent-scope one (a row may have been rewritten by another XCD in this very launch)
+        crec_f4v r[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+            r[k] = crec_f4v{0.f, 0.f, 0.f, 0.f};
+        if (on) {
+            const bool has_m = h.opt != CREC_OPT_SGD, has_v = h.opt == 0;
+            r[0] = ld4_sc1g(t.P + ou);
+            r[1] = ld4_sc1g(t.Q + oi);
+            r[2] = ld4_sc1g(t.Q + oj);
+            if (has_m)
+                r[3] = ld4_sc1g(t.mP + ou);
+            if (has_v)
+                r[4] = ld4_sc1g(t.vP + ou);
+            if ((is || blk_whole) && has_m)
+                r[5] = ld4_sc1g(t.mQ + oi);
+            if ((is || blk_whole) && has_v)
+                r[6] = ld4_sc1g(t.vQ + oi);
+            if (js && has_m)
+                r[7] = ld4_sc1g(t.mQ + oj);
+            if (js && has_v)
+                r[8] = ld4_sc1g(t.vQ + oj);
+        }
+        ld4_sc1g_wait(r[0], r[1], r[2], r[3], r[4]);
+        ld4_sc1g_wait(r[5], r[6], r[7], r[8], r[0]);
+        p = f4_of(r[0]), qi = f4_of(r[1]), qj = f4_of(r[2]), mp = f4_of(r[3]), vp = f4_of(r[4]), mi = f4_of(r[5]), vi = f4_of(r[6]),
+        mj = f4_of(r[7]), vj = f4_of(r[8]);
+    } else if (on) { // every address is known: one round of loads
         p = ld4(t.P + ou);
         qi = ld4(t.Q + oi);
         qj = ld4(t.Q + oj);
@@ -2356,22 +2574,38 @@ __global__ __launch_bounds__(LazyGeo<LPR>::THREADS) void bpr_triples_lazy(Tables
             const float4 gp = make_float4(cu.x + h.reg * p.x, cu.y + h.reg * p.y, cu.z + h.reg * p.z, cu.w + h.reg * p.w);
             float4 np = p;
             opt4(np, mp, vp, gp, h);
-            st4s(t.P + ou, np);
-            if (h.opt != CREC_OPT_SGD)
-                st4s(t.mP + ou, mp);
-            if (h.opt == 0)
-                st4s(t.vP + ou, vp);
+            if (WIN) {
+                st4_wtg(t.P + ou, np);
+                if (h.opt != CREC_OPT_SGD)
+                    st4_wtg(t.mP + ou, mp);
+                if (h.opt == 0)
+                    st4_wtg(t.vP + ou, vp);
+            } else {
+                st4s(t.P + ou, np);
+                if (h.opt != CREC_OPT_SGD)
+                    st4s(t.mP + ou, mp);
+                if (h.opt == 0)
+                    st4s(t.vP + ou, vp);
+            }
         }
         if (is) {
             const float4 gi = make_float4(nsp.x + h.reg * qi.x, nsp.y + h.reg * qi.y, nsp.z + h.reg * qi.z, nsp.w + h.reg * qi.w);
             if (item_adam) {
                 float4 nq = qi;
                 opt4(nq, mi, vi, gi, h);
-                st4s(t.Q + oi, nq);
-                if (h.opt != CREC_OPT_SGD)
-                    st4s(t.mQ + oi, mi);
-                if (h.opt == 0)
-                    st4s(t.vQ + oi, vi);
+                if (WIN) {
+                    st4_wtg(t.Q + oi, nq);
+                    if (h.opt != CREC_OPT_SGD)
+                        st4_wtg(t.mQ + oi, mi);
+                    if (h.opt == 0)
+                        st4_wtg(t.vQ + oi, vi);
+                } else {
+                    st4s(t.Q + oi, nq);
+                    if (h.opt != CREC_OPT_SGD)
+                        st4s(t.mQ + oi, mi);
+                    if (h.opt == 0)
+                        st4s(t.vQ + oi, vi);
+                }
             } else {
                 st4_dq(h.dQ, oi, gi, h.dq_sys, true);
             }
@@ -2381,18 +2615,37 @@ __global__ __launch_bounds__(LazyGeo<LPR>::THREADS) void bpr_triples_lazy(Tables
             if (item_adam) {
                 float4 nq = qj;
                 opt4(nq, mj, vj, gj, h);
-                st4s(t.Q + oj, nq);
-                if (h.opt != CREC_OPT_SGD)
-                    st4s(t.mQ + oj, mj);
-                if (h.opt == 0)
-                    st4s(t.vQ + oj, vj);
+                if (WIN) {
+                    st4_wtg(t.Q + oj, nq);
+                    if (h.opt != CREC_OPT_SGD)
+                        st4_wtg(t.mQ + oj, mj);
+                    if (h.opt == 0)
+                        st4_wtg(t.vQ + oj, vj);
+                } else {
+                    st4s(t.Q + oj, nq);
+                    if (h.opt != CREC_OPT_SGD)
+                        st4s(t.mQ + oj, mj);
+                    if (h.opt == 0)
+                        st4s(t.vQ + oj, vj);
+                }
             } else {
                 st4_dq(h.dQ, oj, gj, h.dq_sys, true);
             }
         }
     }
+    if (WIN) { // the rows finished above have arrived: this batch's stamps for their next readers in the window
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (valid && l == 0) {
+            if (us)
+                __hip_atomic_store(h.win_done_u + lazy_desc_start(du), h.win_stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (is)
+                __hip_atomic_store(h.win_done_q + lazy_desc_start(di), h.win_stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (js)
+                __hip_atomic_store(h.win_done_q + lazy_desc_start(dj), h.win_stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     if (blk_whole) // a front row that lies inside this workgroup: finished from LDS, nothing published
-        lazy_finish_row<LPR, false, DEFER>(t, d, act, di.x & 0x7fffffff, qi, blk_sum, mi_raw, vi_raw, h);
+        lazy_finish_row<LPR, false, DEFER>(t, d, act, di.x & 0x7fffffff, qi, blk_sum, mi_raw, vi_raw, h, lazy_desc_start(di));
     if (!any_multi || (CREC_LAZY_ABL & 1))
         return;
     // 4. whoever completes a row's (chunk's) counter finishes it
@@ -2594,19 +2847,57 @@ template <int LPR, bool FULL> void launch_lazy(const StepArgs &a, const IndexWs 
     if (a.h.lr_tab)
         CREC_KLAUNCH(a.ctx, (bpr_triples_lazy<LPR, FULL, true>), grid, block, lds, a.st, a.cur, a.d,
                      (const int2 *)(w.slot_pu + b * w.B), (int)a.nb_cur, (const int32_t *)(w.nslots + b * 2), (const int4 *)(w.u_desc + b * w.B),
-                     (const int4 *)(w.i_desc + b * w.B), (const int4 *)(w.j_desc + b * w.B), a.lazy, a.xb, a.rowterm, a.h);
+                     (const int4 *)(w.i_desc + b * w.B), (const int4 *)(w.j_desc + b * w.B), a.lazy, a.xb, a.rowterm, a.h, LazyWin{});
     else
         CREC_KLAUNCH(a.ctx, (bpr_triples_lazy<LPR, FULL, false>), grid, block, lds, a.st, a.cur, a.d,
                      (const int2 *)(w.slot_pu + b * w.B), (int)a.nb_cur, (const int32_t *)(w.nslots + b * 2), (const int4 *)(w.u_desc + b * w.B),
-                     (const int4 *)(w.i_desc + b * w.B), (const int4 *)(w.j_desc + b * w.B), a.lazy, a.xb, a.rowterm, a.h);
+                     (const int4 *)(w.i_desc + b * w.B), (const int4 *)(w.j_desc + b * w.B), a.lazy, a.xb, a.rowterm, a.h, LazyWin{});
     crec_prof_end(a.ctx, a.st);
+}
+
+// lazy_window: the batches [b, b + win.W) of the chunk in one launch (blockIdx.y = the batch)
+template <int LPR, bool FULL> void launch_lazy_window(const StepArgs &a, const IndexWs &w, int64_t b, const LazyWin &win)
+{
+    constexpr int SPW = LazyGeo<LPR>::SPW, THREADS = LazyGeo<LPR>::THREADS;
+    const dim3 grid((unsigned)crec_ceil_div((int64_t)a.B, SPW), (unsigned)win.W), block(THREADS);
+    const size_t lds = sizeof(float4) * THREADS;
+    a.ctx->prof.next_units = win.W;
+    crec_prof_begin(a.ctx, CREC_K_USER_SIDE, a.st);
+    CREC_KLAUNCH(a.ctx, (bpr_triples_lazy<LPR, FULL, false, true>), grid, block, lds, a.st, a.cur, a.d, (const int2 *)(w.slot_pu + b * w.B), 0,
+                 (const int32_t *)(w.nslots + b * 2), (const int4 *)(w.u_desc + b * w.B), (const int4 *)(w.i_desc + b * w.B),
+                 (const int4 *)(w.j_desc + b * w.B), a.lazy, a.xb, a.rowterm, a.h, win);
+    crec_prof_end(a.ctx, a.st);
+    a.ctx->prof.next_units = 1;
+}
+using WinFn = void (*)(const StepArgs &, const IndexWs &, int64_t, const LazyWin &);
+WinFn pick_window(int d)
+{
+    int lpr = 1;
+    while (lpr * 4 < d)
+        lpr <<= 1;
+    const bool full = d == 4 * lpr;
+#define CREC_PICK(L)                                                                 \
+    case L:                                                                          \
+        return full ? launch_lazy_window<L, true> : launch_lazy_window<L, false>;
+    switch (lpr) {
+        CREC_PICK(1)
+        CREC_PICK(2)
+        CREC_PICK(4)
+        CREC_PICK(8)
+        CREC_PICK(16)
+        CREC_PICK(32)
+        CREC_PICK(64)
+    }
+#undef CREC_PICK
+    return nullptr;
 }
 
 // lazy mode: contribution rows and partials by sorted slot position (user side B slots, item side 2B), then the
 // ticket counters, cleared here once -- the kernels leave them at zero
-int setup_lazy_bufs(crec_ctx *ctx, int64_t B, int d, int CH, hipStream_t st, LazyBufs *z)
+int setup_lazy_bufs(crec_ctx *ctx, int64_t B, int d, int CH, hipStream_t st, LazyBufs *z, int nwin = 1)
 {
-    const size_t rows = 6 * (size_t)B, row_bytes = align_up(sizeof(float) * rows * d, 256), ctr_bytes = sizeof(int32_t) * rows;
+    // (lazy_window: nwin batches' buffers back to back, 6 B rows and 6 B counters each; z describes the first batch's)
+    const size_t rows = 6 * (size_t)B * (size_t)nwin, row_bytes = align_up(sizeof(float) * rows * d, 256), ctr_bytes = sizeof(int32_t) * rows;
     if (int rc = crec_reserve(ctx, &ctx->contrib, row_bytes + ctr_bytes))
         return rc;
     float *f = (float *)ctx->contrib.ptr;
@@ -2840,6 +3131,21 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
         return crec_fail(ctx, CREC_EHIP, "an earlier bpr_steps_flow launch gave up waiting for a row version (a wave of it never ran or the "
                                          "device faulted): the tables that call left are not valid");
     }
+    const auto ensure_err = [&]() { // the give-up flag of the launches whose waves wait for each other: page-locked, mapped
+        if (ctx->flow_err)
+            return;
+        void *dev = nullptr;
+        if (hipHostMalloc((void **)&ctx->flow_err, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
+            hipHostGetDevicePointer(&dev, ctx->flow_err, 0) == hipSuccess) {
+            *ctx->flow_err = 0;
+            ctx->flow_err_dev = (int32_t *)dev;
+        } else {
+            (void)hipGetLastError();
+            if (ctx->flow_err)
+                (void)hipHostFree(ctx->flow_err);
+            ctx->flow_err = nullptr;
+        }
+    };
     FlowKernel fk{};
     int flow_cmax = 0; // steps per launch; 0: bpr_step_fused, a launch per step
     int CH_idx = CH;   // what the index kernel cuts heavy rows at
@@ -2857,19 +3163,7 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
             bpc = nbk > 0 ? nbk : -1;
         }
         const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
-        if (!ctx->flow_err) {
-            void *dev = nullptr;
-            if (hipHostMalloc((void **)&ctx->flow_err, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
-                hipHostGetDevicePointer(&dev, ctx->flow_err, 0) == hipSuccess) {
-                *ctx->flow_err = 0;
-                ctx->flow_err_dev = (int32_t *)dev;
-            } else {
-                (void)hipGetLastError();
-                if (ctx->flow_err)
-                    (void)hipHostFree(ctx->flow_err);
-                ctx->flow_err = nullptr;
-            }
-        }
+        ensure_err();
         if (bpc > 0 && grid <= (int64_t)bpc * cus && ctx->flow_err_dev && hP * 4 < ((int64_t)1 << 31) && hQ * 4 < ((int64_t)1 << 31)) {
             int64_t cmax = FLOW_MAX_STEPS;
             while (cmax > 1 && 2 * (cmax - 1) * (hP + hQ) * 4 > ((int64_t)1 << 30))
@@ -2932,8 +3226,16 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
             deal_nwg_u = nwg_u, deal_nwg_q = nwg_q;
         }
     }
+    // lazy-family steps, W consecutive batches per launch (bpr_triples_lazy<.., WIN>): where the batch is indexed in LDS and the step is
+    // neither the deferred form (its replay stamps) nor the row-sharded one
+    int lazy_win = 0;
+    if (!dense && !dp && !df && B <= MAX_B && !ctx->knob_big_index && ctx->knob_lazy_window > 1 && 3 * (int64_t)B < ((int64_t)1 << 20)) {
+        ensure_err();
+        if (ctx->flow_err_dev)
+            lazy_win = ctx->knob_lazy_window < LAZY_WIN_MAX ? ctx->knob_lazy_window : LAZY_WIN_MAX;
+    }
     const auto layout = [&](void *base, int64_t nbc_, int spw_ = 32) {
-        IndexWs w_ = layout_index(base, nbc_, B, t->U, t->I, dense, CH_idx, wide_rows, wide_total, spw_, flow_rpb, deal_nwg_u, deal_nwg_q);
+        IndexWs w_ = layout_index(base, nbc_, B, t->U, t->I, dense, CH_idx, wide_rows, wide_total, spw_, flow_rpb, deal_nwg_u, deal_nwg_q, lazy_win);
         w_.flow_pos_u = deal[0], w_.flow_row_u = deal[1], w_.flow_pos_q = deal[2], w_.flow_row_q = deal[3];
         return w_;
     };
@@ -3016,8 +3318,16 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
                 return rc;
         }
     } else {
-        if (int rc = setup_lazy_bufs(ctx, B, t->d, CH, st, &a.lazy))
+        if (int rc = setup_lazy_bufs(ctx, B, t->d, CH, st, &a.lazy, lazy_win ? lazy_win : 1))
             return rc;
+        if (lazy_win) { // the stamps by (batch in window, segment start): zero once -- a stamp is a ctx-wide launch count and never repeats
+            const size_t bytes = sizeof(int32_t) * (size_t)LAZY_WIN_MAX * 3 * (size_t)B;
+            const void *before = ctx->lazy_done.ptr;
+            if (int rc = crec_reserve(ctx, &ctx->lazy_done, bytes))
+                return rc;
+            if (ctx->lazy_done.ptr != before)
+                CREC_HIP(ctx, hipMemsetAsync(ctx->lazy_done.ptr, 0, ctx->lazy_done.bytes, st));
+        }
     }
 
     // dynamic LDS of the index kernel
@@ -3129,6 +3439,8 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
             }
             CREC_HIP(ctx, hipStreamWaitEvent(st, ctx->idx_ev[ci & 1], 0));
         } else {
+            if (lazy_win) // (the presence filters are OR-ed into)
+                CREC_HIP(ctx, hipMemsetAsync(w.wfilt, 0, sizeof(uint32_t) * (size_t)nbc * 2 * WF_WORDS, st));
             crec_prof_begin(ctx, CREC_K_INDEX, st);
             // tf1, a call of few batches: two workgroups per (batch, side) share the phases behind the sort -- as long as all of them
             // find a CU of their own at once it is the latency of one workgroup that the steps wait for (a 20-batch call: 524 ->
@@ -3138,6 +3450,8 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
             CREC_KLAUNCH(ctx, bpr_index_batches, dim3((unsigned)(2 * idx_parts * nbc)), dim3(PREP_THREADS), lds, st, u + t0, i + t0,
                                j + t0, n_chunk, B, cap, w, idx_parts);
             crec_prof_end(ctx, st);
+            if (lazy_win)
+                hipLaunchKernelGGL(lazy_window_deps, dim3((unsigned)crec_ceil_div(B, 256), (unsigned)nbc), dim3(256), 0, st, w, lazy_win);
         }
         // tf1 mode: the chunk's counts of heavy-row chunks and wide groups size the launches.  They arrive in page-locked
         // memory written by the kernel itself (above); the host polls the flag -- a device-to-host copy plus a stream
@@ -3231,7 +3545,37 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
             in_shadow = !in_shadow;
             b += C;
         }
-        for (int64_t b = 0; !flow_cmax && b < nbc; ++b) {
+        for (int64_t b = 0; lazy_win && b < nbc;) { // W batches per launch (windows are aligned to the chunk's first batch, as lazy_window_deps has them)
+            const int Wc = (int)((nbc - b) < lazy_win ? (nbc - b) : lazy_win);
+            LazyWin wn{};
+            wn.W = Wc;
+            wn.B = B;
+            wn.n_left = n_chunk - b * B;
+            wn.loss_stride = loss_stride;
+            wn.z_stride = 6 * (int64_t)B;
+            wn.deps = w.wdeps + b * B;
+            wn.done = (int32_t *)ctx->lazy_done.ptr;
+            wn.stamp0 = ctx->lazy_stamp + 1;
+            ctx->lazy_stamp += LAZY_WIN_MAX;
+            if (ctx->lazy_stamp > 0x7fff0000)
+                ctx->lazy_stamp = 0; // (old stamps are at least a launch behind: never equal to a fresh one)
+            wn.err = ctx->flow_err_dev;
+            a.h = Hyper{};
+            a.h.opt = (opt->adam_mode == CREC_OPT_SGD || opt->adam_mode == CREC_OPT_ADAGRAD) ? opt->adam_mode : 0;
+            a.h.beta1 = opt->beta1, a.h.beta2 = opt->beta2, a.h.eps = opt->eps, a.h.reg = opt->reg;
+            for (int k = 0; k < Wc; ++k) {
+                wn.lr_t[k] = a.h.opt ? opt->lr : (opt->lr * sqrtf(1.0f - opt->beta2_power)) / (1.0f - opt->beta1_power);
+                opt->beta1_power = opt->beta1_power * opt->beta1;
+                opt->beta2_power = opt->beta2_power * opt->beta2;
+                opt->step += 1;
+            }
+            a.h.lr_t = wn.lr_t[0];
+            a.xb = (float *)ctx->loss_ws.ptr + b * loss_stride;
+            a.rowterm = a.xb + B;
+            pick_window(t->d)(a, w, b, wn);
+            b += Wc;
+        }
+        for (int64_t b = 0; !flow_cmax && !lazy_win && b < nbc; ++b) {
             // lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t) with fp32 running powers (TF1 _prepare/_finish); SGD / Adagrad: lr
             a.h.opt = (opt->adam_mode == CREC_OPT_SGD || opt->adam_mode == CREC_OPT_ADAGRAD) ? opt->adam_mode : 0;
             a.h.lr_tab = lr_tab; // deferred mode (else null)

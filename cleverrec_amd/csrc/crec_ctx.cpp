@@ -219,6 +219,7 @@ int crec_ctx_create(int device, crec_ctx **out)
     ctx->knob_dsampler_general = env_int("CREC_DSAMPLER_GENERAL", 0);
     ctx->knob_flow = env_int("CREC_FLOW", -1);
     ctx->knob_flow_steps = env_int("CREC_FLOW_STEPS", 0);
+    ctx->knob_lazy_window = env_int("CREC_LAZY_WINDOW", 0);
     if (device >= 0) {
         int n = 0;
         hipError_t e = hipGetDeviceCount(&n);
@@ -258,7 +259,7 @@ void crec_ctx_destroy(crec_ctx *ctx)
         (void)crec_comm_destroy(ctx);
         crec_devbuf *bufs[] = {&ctx->idx_ws, &ctx->idx_ws2, &ctx->big_ws, &ctx->contrib, &ctx->loss_ws,
                                &ctx->misc,   &ctx->eval_ws, &ctx->ks_dev, &ctx->shadow, &ctx->dq, &ctx->shard_ws, &ctx->shard_ws2, &ctx->lr_hist_dev,
-                               &ctx->shard_flag, &ctx->flow_hist, &ctx->flow_deal, &ctx->loss_parts};
+                               &ctx->shard_flag, &ctx->flow_hist, &ctx->flow_deal, &ctx->loss_parts, &ctx->lazy_done};
         for (crec_devbuf *b : bufs)
             if (b->ptr)
                 (void)hipFree(b->ptr);
@@ -319,7 +320,9 @@ int crec_ctx_set_option(crec_ctx *ctx, const char *name, int64_t value)
     else if (n == "flow_deal") {
         ctx->knob_flow_deal = (int)value;
         ctx->flow_deal_key[0] = 0; // (made again at the next call)
-    } else if (n == "flow_abl")
+    } else if (n == "lazy_window")
+        ctx->knob_lazy_window = (int)value;
+    else if (n == "flow_abl")
         ctx->knob_flow_abl = (int)value;
     else if (n == "flow_steps")
         ctx->knob_flow_steps = (int)value;
