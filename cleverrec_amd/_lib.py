@@ -200,7 +200,7 @@ class Context:
             raise CrecError(rc, self.lib.crec_last_error(self.h).decode())
 
     def set_option(self, name, value):
-        """crec_ctx_set_option: tuning / test knobs ("ch", "wide", "wide_round", "eval_shape", "eval_no_bitmap", "ncf_generic", "no_zero_copy", "shard_unfused", "dsampler_general", "dsampler_budget", "flow", "flow_steps")."""
+        """crec_ctx_set_option: tuning / test knobs ("ch", "wide", "wide_round", "eval_shape", "eval_no_bitmap", "ncf_generic", "no_zero_copy", "shard_unfused", "dsampler_general", "dsampler_budget", "flow", "flow_steps", "flow_deal", "lazy_window")."""
         self.check(self.lib.crec_ctx_set_option(self.h, name.encode(), int(value)))
 
     # ---- measurement ---------------------------------------------------------------------------

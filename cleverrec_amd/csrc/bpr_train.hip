@@ -703,6 +703,7 @@ struct Hyper {
     // lazy_window: where whoever finishes a row leaves this batch's stamp (by segment start; null: a launch per batch)
     int32_t *win_done_u = nullptr, *win_done_q = nullptr;
     int32_t win_stamp = 0;
+    int win_segs_p = 1, win_segs_q = 1; // 4-GiB segments of the user / item tables (ld4_sc1x)
 };
 
 struct Tables { // one buffer set
@@ -786,24 +787,33 @@ __device__ __forceinline__ float4 ld4_buf(const float *base, int64_t off)
     const crec_u4v x = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(off * 4), 0, 0);
     return make_float4(__uint_as_float(x.x), __uint_as_float(x.y), __uint_as_float(x.z), __uint_as_float(x.w));
 }
-// 16-byte agent-scope load / written-through store at a full 64-bit address (tables beyond the 2 GiB a buffer offset spans).  Inline
-// assembly: the compiler neither counts these loads nor waits for them -- ld4_sc1g_wait (an s_waitcnt the loaded registers pass
-// through) must stand between the loads and the first use of any of them
-__device__ __forceinline__ crec_f4v ld4_sc1g(const float *p)
+// 16-byte agent-scope load / written-through store anywhere in a table of any size: buffer instructions (which the compiler counts
+// and schedules, unlike inline assembly -- whose untracked destination registers it may copy before the data is there) address 4 GiB
+// from a scalar base, so a table beyond that is covered by one descriptor per 4 GiB and every lane uses the one its offset falls
+// into (`segs` = the table's 4-GiB segments, wave-uniform; one pass for all but the largest user tables).  off: float index
+__device__ __forceinline__ float4 ld4_sc1x(const float *base, int64_t off, int segs)
 {
-    crec_f4v x;
-    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(x) : "v"(p) : "memory");
-    return x;
+    const uint64_t byte = (uint64_t)off * 4;
+    crec_u4v x = {0u, 0u, 0u, 0u};
+    for (int sgm = 0; sgm < segs; ++sgm) {
+        if ((int)(byte >> 32) == sgm) {
+            const __amdgpu_buffer_rsrc_t r =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base) + ((int64_t)sgm << 30), 0, (int)0xffffffffu, 0x00020000);
+            x = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(uint32_t)byte, 0, 16 /* sc1 */);
+        }
+    }
+    return make_float4(__uint_as_float(x.x), __uint_as_float(x.y), __uint_as_float(x.z), __uint_as_float(x.w));
 }
-__device__ __forceinline__ void ld4_sc1g_wait(crec_f4v &a, crec_f4v &b, crec_f4v &c, crec_f4v &d_, crec_f4v &e)
+__device__ __forceinline__ void st4_wtx(float *base, int64_t off, float4 v, int segs)
 {
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d_), "+v"(e)::"memory");
-}
-__device__ __forceinline__ float4 f4_of(crec_f4v x) { return make_float4(x.x, x.y, x.z, x.w); }
-__device__ __forceinline__ void st4_wtg(float *p, float4 v)
-{
-    const crec_f4v x = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
+    const uint64_t byte = (uint64_t)off * 4;
+    const crec_u4v x = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    for (int sgm = 0; sgm < segs; ++sgm) {
+        if ((int)(byte >> 32) == sgm) {
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base + ((int64_t)sgm << 30), 0, (int)0xffffffffu, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b128(x, r, (int)(uint32_t)byte, 0, 16 /* sc1 */);
+        }
+    }
 }
 // the lazy step's published rows (contributions, partials): agent-scope accesses + s_waitcnt, or -- CREC_TICKET_FENCES,
 // the textbook form kept buildable and compared bit for bit under test (tests/test_gpu_fences.py) -- plain accesses
@@ -2129,6 +2139,8 @@ struct LazyWin {
     int32_t *done;         // [LAZY_WIN_MAX][3 B] stamps by (batch in window, segment start; user side first, item side from B)
     int32_t stamp0;        // the stamp of the launch's first batch (a ctx-wide launch counter: never repeats)
     int32_t *err;          // give-up flag (page-locked)
+    int segs_p, segs_q;    // 4-GiB segments of a user / item table
+    int abl;               // timing ablations (option flow_abl; WRONG results): 1 nobody waits for a predecessor
     float lr_t[LAZY_WIN_MAX];
 };
 
@@ -2251,11 +2263,12 @@ __device__ __forceinline__ void lazy_finish_row(const Tables &t, int d, bool act
             const int64_t ro = (int64_t)row * d + 4 * l;
             float4 nv = own;
             opt4(nv, m, v, g, h);
-            st4_wtg((USER ? t.P : t.Q) + ro, nv);
+            const int sg = USER ? h.win_segs_p : h.win_segs_q;
+            st4_wtx(USER ? t.P : t.Q, ro, nv, sg);
             if (h.opt != CREC_OPT_SGD)
-                st4_wtg((USER ? t.mP : t.mQ) + ro, m);
+                st4_wtx(USER ? t.mP : t.mQ, ro, m, sg);
             if (h.opt == 0)
-                st4_wtg((USER ? t.vP : t.vQ) + ro, v);
+                st4_wtx(USER ? t.vP : t.vQ, ro, v, sg);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (l == 0)
@@ -2307,13 +2320,11 @@ __device__ __forceinline__ void lazy_role_tail(const Tables &t, int d, bool act,
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 m = zero, v = zero;
     if ((USER ? h.win_done_u : h.win_done_q) != nullptr) { // lazy_window: every load of a table row is an agent-scope one
-        crec_f4v rm = {0.f, 0.f, 0.f, 0.f}, rv = rm, r2 = rm, r3 = rm, r4 = rm;
+        const int sg = USER ? h.win_segs_p : h.win_segs_q;
         if (slots && h.opt != CREC_OPT_SGD)
-            rm = ld4_sc1g((USER ? t.mP : t.mQ) + ro);
+            m = ld4_sc1x(USER ? t.mP : t.mQ, ro, sg);
         if (slots && h.opt == 0)
-            rv = ld4_sc1g((USER ? t.vP : t.vQ) + ro);
-        ld4_sc1g_wait(rm, rv, r2, r3, r4);
-        m = f4_of(rm), v = f4_of(rv);
+            v = ld4_sc1x(USER ? t.vP : t.vQ, ro, sg);
     } else {
         m = slots && h.opt != CREC_OPT_SGD ? ld4((USER ? t.mP : t.mQ) + ro) : zero;
         v = slots && h.opt == 0 ? ld4((USER ? t.vP : t.vQ) + ro) : zero;
@@ -2362,7 +2373,7 @@ __global__ __launch_bounds__(LazyGeo<LPR>::THREADS) void bpr_triples_lazy(Tables
                                                                           const int32_t *__restrict__ nslots,
                                                                           const int4 *__restrict__ ud, const int4 *__restrict__ id,
                                                                           const int4 *__restrict__ jd, LazyBufs z,
-                                                                          float *__restrict__ xb, float *__restrict__ l2b, Hyper h, LazyWin win)
+                                                                          float *__restrict__ xb, float *__restrict__ l2b, Hyper h, const LazyWin win)
 {
     constexpr int SPW = LazyGeo<LPR>::SPW;
     extern __shared__ float4 blk_rows[]; // [SPW][LPR], workgroups of the front region only
@@ -2378,12 +2389,13 @@ __global__ __launch_bounds__(LazyGeo<LPR>::THREADS) void bpr_triples_lazy(Tables
         const int64_t zr = (int64_t)wb * win.z_stride * d, zc = (int64_t)wb * win.z_stride;
         z.ucontrib += zr, z.qcontrib += zr, z.upart += zr, z.qpart += zr;
         z.urow_t += zc, z.uchk_t += zc, z.qrow_t += zc, z.qchk_t += zc;
-        win.deps += (int64_t)wb * win.B;
         h.lr_t = win.lr_t[wb];
-        h.win_done_u = win.done + (int64_t)wb * 3 * win.B;
-        h.win_done_q = h.win_done_u + win.B;
+        h.win_done_u = (win.abl & 2) ? nullptr : win.done + (int64_t)wb * 3 * win.B;
+        h.win_done_q = (win.abl & 2) ? nullptr : h.win_done_u + win.B;
         h.win_stamp = win.stamp0 + wb;
+        h.win_segs_p = win.segs_p, h.win_segs_q = win.segs_q;
     }
+    const bool win_wt = WIN && !(win.abl & 2), win_sc1 = WIN && !(win.abl & 4);
     // ONE round of coalesced loads, by processing slot, gives every address of the next round: {position, user row} and the
     // two item descriptors.  (n_slots = the batch's triples comes from the host; the size of the front region and the
     // user's own descriptor -- needed only where the user occurs more than once -- arrive alongside.)
@@ -2409,9 +2421,11 @@ __global__ __launch_bounds__(LazyGeo<LPR>::THREADS) void bpr_triples_lazy(Tables
     const int blk_n = blk_lead ? ((i_ci - i_posr) < (SPW - gw) ? (i_ci - i_posr) : (SPW - gw)) : 0; // the piece's slots = the leader's weight
     const bool blk_whole = blk_lead && blk_n == i_cnt; // the row lies inside this workgroup: no ticket, no memory round trip
     float4 p = zero, qi = zero, qj = zero, mp = zero, vp = zero, mi = zero, vi = zero, mj = zero, vj = zero;
+    int4 dp = make_int4(-1, -1, -1, 0); // lazy_window: this triple's rows' predecessors in the launch
     if (WIN) { // rows an earlier batch of this launch rewrites: not asked for before that batch's stamp is there
-        const int4 dp = valid ? win.deps[slot] : make_int4(-1, -1, -1, 0);
-        if (__builtin_amdgcn_ballot_w64(valid && (dp.x >= 0 || dp.y >= 0 || dp.z >= 0)) != 0) {
+        if (valid)
+            dp = win.deps[(int64_t)blockIdx.y * win.B + slot]; // (win is never written: it stays in kernel-argument memory)
+        if (!(win.abl & 1) && __builtin_amdgcn_ballot_w64(valid && (dp.x >= 0 || dp.y >= 0 || dp.z >= 0)) != 0) {
             unsigned spins = 0;
             for (;;) {
                 bool pend = false;
@@ -2440,6 +2454,9 @@ __global__ __launch_bounds__(LazyGeo<LPR>::THREADS) void bpr_triples_lazy(Tables
                 }
             }
         }
+        // the row loads below are relaxed atomics like the polls above: nothing but this keeps the compiler from asking for a row
+        // BEFORE its stamp has been seen (the wave issues in program order, and the polls' values are consumed: the hardware keeps it)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 #if CREC_LAZY_HEADSTART
     // A head start for the rows with a tail.  All waves of the launch are resident at once and ask for their rows in the
@@ -2452,33 +2469,26 @@ __global__ __launch_bounds__(LazyGeo<LPR>::THREADS) void bpr_triples_lazy(Tables
         for (int k = 0; k < CREC_LAZY_HEADSTART; ++k)
             __builtin_amdgcn_s_sleep(16); // 16 x 64 clocks = 0.43 us
 #endif
-    if (WIN) { // every load of a table row is an agent-scope one (a row may have been rewritten by another XCD in this very launch)
-        crec_f4v r[9];
-#pragma unroll
-        for (int k = 0; k < 9; ++k)
-            r[k] = crec_f4v{0.f, 0.f, 0.f, 0.f};
+    if (win_sc1) { // every load of a table row is a 16-byte agent-scope one (a row may have been rewritten by another XCD in this launch)
+        const bool has_m = h.opt != CREC_OPT_SGD, has_v = h.opt == 0;
+        const int sp_ = h.win_segs_p, sq_ = h.win_segs_q;
         if (on) {
-            const bool has_m = h.opt != CREC_OPT_SGD, has_v = h.opt == 0;
-            r[0] = ld4_sc1g(t.P + ou);
-            r[1] = ld4_sc1g(t.Q + oi);
-            r[2] = ld4_sc1g(t.Q + oj);
+            p = ld4_sc1x(t.P, ou, sp_);
+            qi = ld4_sc1x(t.Q, oi, sq_);
+            qj = ld4_sc1x(t.Q, oj, sq_);
             if (has_m)
-                r[3] = ld4_sc1g(t.mP + ou);
+                mp = ld4_sc1x(t.mP, ou, sp_);
             if (has_v)
-                r[4] = ld4_sc1g(t.vP + ou);
+                vp = ld4_sc1x(t.vP, ou, sp_);
             if ((is || blk_whole) && has_m)
-                r[5] = ld4_sc1g(t.mQ + oi);
+                mi = ld4_sc1x(t.mQ, oi, sq_);
             if ((is || blk_whole) && has_v)
-                r[6] = ld4_sc1g(t.vQ + oi);
+                vi = ld4_sc1x(t.vQ, oi, sq_);
             if (js && has_m)
-                r[7] = ld4_sc1g(t.mQ + oj);
+                mj = ld4_sc1x(t.mQ, oj, sq_);
             if (js && has_v)
-                r[8] = ld4_sc1g(t.vQ + oj);
+                vj = ld4_sc1x(t.vQ, oj, sq_);
         }
-        ld4_sc1g_wait(r[0], r[1], r[2], r[3], r[4]);
-        ld4_sc1g_wait(r[5], r[6], r[7], r[8], r[0]);
-        p = f4_of(r[0]), qi = f4_of(r[1]), qj = f4_of(r[2]), mp = f4_of(r[3]), vp = f4_of(r[4]), mi = f4_of(r[5]), vi = f4_of(r[6]),
-        mj = f4_of(r[7]), vj = f4_of(r[8]);
     } else if (on) { // every address is known: one round of loads
         p = ld4(t.P + ou);
         qi = ld4(t.Q + oi);
@@ -2574,12 +2584,12 @@ __global__ __launch_bounds__(LazyGeo<LPR>::THREADS) void bpr_triples_lazy(Tables
             const float4 gp = make_float4(cu.x + h.reg * p.x, cu.y + h.reg * p.y, cu.z + h.reg * p.z, cu.w + h.reg * p.w);
             float4 np = p;
             opt4(np, mp, vp, gp, h);
-            if (WIN) {
-                st4_wtg(t.P + ou, np);
+            if (win_wt) {
+                st4_wtx(t.P, ou, np, h.win_segs_p);
                 if (h.opt != CREC_OPT_SGD)
-                    st4_wtg(t.mP + ou, mp);
+                    st4_wtx(t.mP, ou, mp, h.win_segs_p);
                 if (h.opt == 0)
-                    st4_wtg(t.vP + ou, vp);
+                    st4_wtx(t.vP, ou, vp, h.win_segs_p);
             } else {
                 st4s(t.P + ou, np);
                 if (h.opt != CREC_OPT_SGD)
@@ -2593,12 +2603,12 @@ __global__ __launch_bounds__(LazyGeo<LPR>::THREADS) void bpr_triples_lazy(Tables
             if (item_adam) {
                 float4 nq = qi;
                 opt4(nq, mi, vi, gi, h);
-                if (WIN) {
-                    st4_wtg(t.Q + oi, nq);
+                if (win_wt) {
+                    st4_wtx(t.Q, oi, nq, h.win_segs_q);
                     if (h.opt != CREC_OPT_SGD)
-                        st4_wtg(t.mQ + oi, mi);
+                        st4_wtx(t.mQ, oi, mi, h.win_segs_q);
                     if (h.opt == 0)
-                        st4_wtg(t.vQ + oi, vi);
+                        st4_wtx(t.vQ, oi, vi, h.win_segs_q);
                 } else {
                     st4s(t.Q + oi, nq);
                     if (h.opt != CREC_OPT_SGD)
@@ -2615,12 +2625,12 @@ __global__ __launch_bounds__(LazyGeo<LPR>::THREADS) void bpr_triples_lazy(Tables
             if (item_adam) {
                 float4 nq = qj;
                 opt4(nq, mj, vj, gj, h);
-                if (WIN) {
-                    st4_wtg(t.Q + oj, nq);
+                if (win_wt) {
+                    st4_wtx(t.Q, oj, nq, h.win_segs_q);
                     if (h.opt != CREC_OPT_SGD)
-                        st4_wtg(t.mQ + oj, mj);
+                        st4_wtx(t.mQ, oj, mj, h.win_segs_q);
                     if (h.opt == 0)
-                        st4_wtg(t.vQ + oj, vj);
+                        st4_wtx(t.vQ, oj, vj, h.win_segs_q);
                 } else {
                     st4s(t.Q + oj, nq);
                     if (h.opt != CREC_OPT_SGD)
@@ -2633,7 +2643,7 @@ __global__ __launch_bounds__(LazyGeo<LPR>::THREADS) void bpr_triples_lazy(Tables
             }
         }
     }
-    if (WIN) { // the rows finished above have arrived: this batch's stamps for their next readers in the window
+    if (win_wt) { // the rows finished above have arrived: this batch's stamps for their next readers in the window
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (valid && l == 0) {
             if (us)
@@ -3560,6 +3570,8 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
             if (ctx->lazy_stamp > 0x7fff0000)
                 ctx->lazy_stamp = 0; // (old stamps are at least a launch behind: never equal to a fresh one)
             wn.err = ctx->flow_err_dev;
+            wn.abl = ctx->knob_flow_abl;
+            wn.segs_p = (int)((hP * 4 + ((int64_t)1 << 32) - 1) >> 32), wn.segs_q = (int)((hQ * 4 + ((int64_t)1 << 32) - 1) >> 32);
             a.h = Hyper{};
             a.h.opt = (opt->adam_mode == CREC_OPT_SGD || opt->adam_mode == CREC_OPT_ADAGRAD) ? opt->adam_mode : 0;
             a.h.beta1 = opt->beta1, a.h.beta2 = opt->beta2, a.h.eps = opt->eps, a.h.reg = opt->reg;

@@ -39,7 +39,7 @@ def test_bpr_kernels_register_budget():
     res = _resources("bpr_train.hip", ("-ffp-contract=off",))
     fused = [v for k, v in res.items() if "bpr_step_fusedILi16ELb1" in k]
     lazy = [v for k, v in res.items() if "bpr_triples_lazyILi32ELb1" in k]
-    assert fused and len(lazy) == 2  # the plain and the deferred-Adam instantiation
+    assert fused and len(lazy) == 3  # the plain, the deferred-Adam and the window (lazy_window) instantiation
     for v in fused:  # d = 64: four waves per SIMD (3 313 waves of a step at ml-1m shape fit the 4 096 slots at once)
         assert v["VGPRs"] <= 128 and v["ScratchSize"] == 0 and v["Occupancy"] >= 4, v
     for v in lazy:  # d = 128 lazy step (one launch): four waves per SIMD
