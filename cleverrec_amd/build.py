@@ -1,7 +1,7 @@
 """Builds cleverrec_amd/lib/libcrec.so (gfx950 only) with hipcc, in-tree.
 
 hipcc cross-compiles without a GPU, so this runs in the build container; the .so travels
-to the GPU box with the repo snapshot.  `python -m cleverrec_amd.build [--force]`.
+to the GPU box with the repo snapshot.  `python -m cleverrec_amd.build [--force] [--exact]`.
 """
 import os
 import subprocess
@@ -53,9 +53,13 @@ def _stale(out, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    os.makedirs(LIBDIR, exist_ok=True)
-    objdir = os.path.join(LIBDIR, "obj")
+def build(force=False, verbose=False, exact=False):
+    """exact: the -DCREC_EXACT_MATH variant (IEEE division / square root / expf in the optimizers' quotients and the sigmoid) into
+    lib/exact/libcrec.so -- loaded with CREC_LIB=<that path>; the parity suite is run against it once per round (profiles/)."""
+    libdir = os.path.join(LIBDIR, "exact") if exact else LIBDIR
+    lib = os.path.join(libdir, "libcrec.so")
+    os.makedirs(libdir, exist_ok=True)
+    objdir = os.path.join(libdir, "obj")
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(HERE, "..", "include", "crec.h"))
@@ -66,7 +70,7 @@ def build(force=False, verbose=False):
         obj = os.path.join(objdir, src.rsplit(".", 1)[0] + ".o")
         objs.append(obj)
         if force or _stale(obj, [path] + headers + [os.path.abspath(__file__)]):
-            jobs.append([cc, "--offload-arch=" + ARCH, "-x", "hip"] + COMMON + extra + ["-c", path, "-o", obj])
+            jobs.append([cc, "--offload-arch=" + ARCH, "-x", "hip"] + COMMON + extra + (["-DCREC_EXACT_MATH"] if exact else []) + ["-c", path, "-o", obj])
     if jobs:  # translation units are independent: compile up to four at a time
         from concurrent.futures import ThreadPoolExecutor
 
@@ -76,13 +80,13 @@ def build(force=False, verbose=False):
             subprocess.check_call(cmd)
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as pool:
             list(pool.map(run, jobs))
-    if force or _stale(LIB, objs):
-        cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-lrccl"]
+    if force or _stale(lib, objs):
+        cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-o", lib] + objs + ["-L/opt/rocm/lib", "-lrccl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, exact="--exact" in sys.argv))

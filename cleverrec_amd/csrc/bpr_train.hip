@@ -3138,7 +3138,7 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
     if (ctx->flow_err && *(volatile int32_t *)ctx->flow_err != 0) { // (the flag lives in page-locked memory the kernel writes itself)
         *(volatile int32_t *)ctx->flow_err = 0;
         ctx->flow_hist_at = nullptr; // whatever the histories hold now: sentinel again before the next use
-        return crec_fail(ctx, CREC_EHIP, "an earlier bpr_steps_flow launch gave up waiting for a row version (a wave of it never ran or the "
+        return crec_fail(ctx, CREC_EHIP, "an earlier bpr_steps_flow (or lazy_window) launch gave up waiting for a row version (a wave of it never ran or the "
                                          "device faulted): the tables that call left are not valid");
     }
     const auto ensure_err = [&]() { // the give-up flag of the launches whose waves wait for each other: page-locked, mapped

@@ -98,7 +98,11 @@ __device__ __forceinline__ float opt_elem(const crec_rows_opt &o, bool dense, fl
         return var - o.lr_t * g;
     if (o.opt == CREC_OPT_ADAGRAD) {
         m = m + g * g;
+#ifdef CREC_EXACT_MATH
+        return var - (o.lr_t * g) / sqrtf(m);
+#else
         return var - (o.lr_t * g) * __builtin_amdgcn_rsqf(m);
+#endif
     }
     const float omb1 = 1.0f - o.beta1, omb2 = 1.0f - o.beta2;
     if (dense) {

@@ -266,7 +266,11 @@ __global__ __launch_bounds__(256) void tcf_grad_adam(float *__restrict__ var, fl
             return var_ - lr_t * g_;
         if (opt == CREC_OPT_ADAGRAD) {
             m_ = m_ + g_ * g_;
+#ifdef CREC_EXACT_MATH
+            return var_ - (lr_t * g_) / sqrtf(m_);
+#else
             return var_ - (lr_t * g_) * __builtin_amdgcn_rsqf(m_);
+#endif
         }
         m_ = m_ + (g_ - m_) * omb1;
         v_ = v_ + (g_ * g_ - v_) * omb2;

@@ -24,7 +24,10 @@ def assert_adam_close(om, name, var, m=None, v=None, lr=1e-3, report=None, scale
     gradient is a single contribution out of the tower's backward pass -- nothing averages its rounding, and NOISE, calibrated on
     rows that sum several contributions, is met by the tail of 5 000 such elements: 1.17 of the bound on one element seen.)
     outliers: share of a tensor's weights that may leave the envelope by up to 2 % of an Adam step (tables of a million single-
-    contribution elements: the bound of the C5 test, tests/test_gpu_parity.py)."""
+    contribution elements: the bound of the C5 test, tests/test_gpu_parity.py).  The slots' envelopes are tighter than the weights'
+    (2e-4 of a small element of m) and their tail depends on the HOST as well -- the restatement's own fp32 matmuls round differently
+    from one CPU to the next: 2 elements of 386 560 outside three envelopes on one box, 60 on another, the same kernel -- so with
+    `outliers` up to 100 times that share of m (of v) may leave the envelope, none by more than 1e-5 of the tensor's largest |m| (v)."""
     tol_var, tol_m, tol_v = (scale * t for t in om.bounds(name))
     ref = om.numpy(name).astype(np.float64)
     shape = ref.shape
@@ -38,6 +41,8 @@ def assert_adam_close(om, name, var, m=None, v=None, lr=1e-3, report=None, scale
             report.append(rec)
         if worst > 1.0 and what == "var" and (dv > bound).sum() <= outliers * dv.size and dv[dv > bound].max() <= 2e-2 * lr:
             return dv  # (`outliers`: that share of a table's weights may sit outside the envelope, none further than 2 % of an Adam step)
+        if worst > 1.0 and what != "var" and (dv > bound).sum() <= 100 * outliers * dv.size and dv[dv > bound].max() <= 1e-5 * np.abs(refv).max():
+            return dv
         if worst > 1.0:
             k = np.unravel_index(np.argmax(dv / bound), shape)
             raise AssertionError("%s.%s: |delta| %.3e > bound %.3e at %s (ref %.6e); %d of %d elements beyond their bound"

@@ -36,6 +36,7 @@ np.savez(sys.argv[1], **out)
 
 def _run(lib, path):
     env = dict(os.environ)
+    env.pop("CREC_LIB", None)  # (the in-tree default build is the one compared, whatever build the rest of the suite is run against)
     if lib:
         env["CREC_LIB"] = lib
     subprocess.run([sys.executable, "-c", _WORKER % {"root": ROOT}, path], check=True, env=env, timeout=300)

@@ -61,8 +61,16 @@ def _assert_v_close(got, ov, name):
 
 
 def _assert_state_close(st, om, atol):
+    """Weights and m within `atol`; of a table's elements 1e-5 (none below 100 000 elements) may sit further out, up to 10 atol: where a
+    row's gradient cancels to ~0 the fp32 order of its additions decides the sign Adam steps by (the C5 test's rule; seen: one element
+    of 264 000 at 2.6e-6 under -DCREC_EXACT_MATH, none in the default build)."""
     for name in ("P", "Q", "mP", "mQ"):
-        np.testing.assert_allclose(getattr(st, name).cpu().numpy(), getattr(om, name), rtol=0, atol=atol, err_msg=name)
+        dev, ref = getattr(st, name).cpu().numpy().astype(np.float64), np.asarray(getattr(om, name), dtype=np.float64)
+        dlt = np.abs(dev - ref)
+        over = dlt > atol
+        if over.any() and over.sum() <= int(1e-5 * dlt.size) and dlt.max() <= 10 * atol:
+            continue
+        np.testing.assert_allclose(dev, ref, rtol=0, atol=atol, err_msg=name)
     for name in ("vP", "vQ"):
         _assert_v_close(getattr(st, name).cpu().numpy(), getattr(om, name), name)
 
