@@ -85,6 +85,19 @@ extern "C" int crec_debug_stamps(unsigned long long *out, size_t n)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(crec_stamps), n * sizeof(unsigned long long));
 }
+extern "C" int crec_debug_stamps_clear(void)
+{
+    static unsigned long long zeros[8 * 16384];
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(crec_stamps), zeros, sizeof(zeros));
+}
+// lazy_window's timeline (tools/window_stamps.py): per batch of the launch 16 words from crec_stamps[8 * 16000]; "min" events are
+// kept as the maximum of (2^62 - t), the array starts at zero
+constexpr int WIN_T_BASE = 8 * 16000;
+__device__ __forceinline__ void win_t(int wb, int k, bool is_min)
+{
+    const unsigned long long t = wall_clock64();
+    atomicMax(&crec_stamps[WIN_T_BASE + wb * 16 + k], is_min ? (1ull << 62) - t : t);
+}
 __device__ __forceinline__ void crec_mark(int slot, int dep) // the time at which `dep` is available to the wave
 {
 #ifndef CREC_STAMP_MARKS // marks make the wave wait for `dep` where it stands: they perturb what they measure
@@ -98,6 +111,7 @@ __device__ __forceinline__ void crec_mark(int slot, int dep) // the time at whic
 }
 #else
 #define crec_mark(slot, dep)
+#define win_t(wb, k, is_min)
 #endif
 #ifndef CREC_FUSED_BLOCK
 #define CREC_FUSED_BLOCK 256 // threads per workgroup of bpr_step_fused
@@ -124,6 +138,9 @@ __device__ __forceinline__ void crec_mark(int slot, int dep) // the time at whic
 #define CREC_LAZY_DEEP 8 // contribution / partial rows in flight in a finisher's sum.  The d = 128 workgroup is 1024 threads, i.e. a
                          // hard limit of 128 VGPRs: 11 in flight spill three registers; 8 / 11 / 12 / 16 measured within 2 % of each other
                          // (tools/lazy_variants.sh)
+#endif
+#ifndef CREC_WIN_DEEP
+#define CREC_WIN_DEEP 16 // the same in a lazy_window launch, where a popular row's finisher is on the path from batch to batch
 #endif
 #ifndef CREC_FUSED_WT
 #define CREC_FUSED_WT 0 // 1: the launch-per-step tf1 kernel writes its tables with write-through (sc1) stores
@@ -703,7 +720,8 @@ struct Hyper {
     // lazy_window: where whoever finishes a row leaves this batch's stamp (by segment start; null: a launch per batch)
     int32_t *win_done_u = nullptr, *win_done_q = nullptr;
     int32_t win_stamp = 0;
-    int win_segs_p = 1, win_segs_q = 1; // 4-GiB segments of the user / item tables (ld4_sc1x)
+    int win_wb = 0; // (the batch's place in the launch: debug timeline)
+    bool win_fit_p = false, win_fit_q = false; // the user / item tables lie within the 4 GiB one buffer descriptor spans
 };
 
 struct Tables { // one buffer set
@@ -787,33 +805,63 @@ __device__ __forceinline__ float4 ld4_buf(const float *base, int64_t off)
     const crec_u4v x = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(off * 4), 0, 0);
     return make_float4(__uint_as_float(x.x), __uint_as_float(x.y), __uint_as_float(x.z), __uint_as_float(x.w));
 }
-// 16-byte agent-scope load / written-through store anywhere in a table of any size: buffer instructions (which the compiler counts
-// and schedules, unlike inline assembly -- whose untracked destination registers it may copy before the data is there) address 4 GiB
-// from a scalar base, so a table beyond that is covered by one descriptor per 4 GiB and every lane uses the one its offset falls
-// into (`segs` = the table's 4-GiB segments, wave-uniform; one pass for all but the largest user tables).  off: float index
-__device__ __forceinline__ float4 ld4_sc1x(const float *base, int64_t off, int segs)
+// lazy_window's table accesses: 16-byte agent-scope loads / written-through stores at full 64-bit addresses (the user tables of
+// S-big are 5 GB each: beyond what one buffer descriptor spans, and a descriptor per lane costs a waterfall loop per load).  The
+// compiler has no builtin for a global load with the sc1 bit, and it does not track what inline assembly leaves in flight -- a
+// destination register of an assembly load may be copied or reused before the data is there (seen: garbage rows) -- so a round
+// of loads AND its s_waitcnt are ONE assembly statement: nothing is outstanding where the compiler takes over again.
+// win_load9: nine rows' slices at once (the three rows of a triple and their slots), one wait.
+__device__ __forceinline__ void win_load9(const float *const (&a)[9], float4 (&r)[9])
 {
-    const uint64_t byte = (uint64_t)off * 4;
-    crec_u4v x = {0u, 0u, 0u, 0u};
-    for (int sgm = 0; sgm < segs; ++sgm) {
-        if ((int)(byte >> 32) == sgm) {
-            const __amdgpu_buffer_rsrc_t r =
-                __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base) + ((int64_t)sgm << 30), 0, (int)0xffffffffu, 0x00020000);
-            x = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(uint32_t)byte, 0, 16 /* sc1 */);
-        }
-    }
-    return make_float4(__uint_as_float(x.x), __uint_as_float(x.y), __uint_as_float(x.z), __uint_as_float(x.w));
+    crec_f4v x0, x1, x2, x3, x4, x5, x6, x7, x8;
+    asm volatile("global_load_dwordx4 %0, %9, off sc1\n\t"
+                 "global_load_dwordx4 %1, %10, off sc1\n\t"
+                 "global_load_dwordx4 %2, %11, off sc1\n\t"
+                 "global_load_dwordx4 %3, %12, off sc1\n\t"
+                 "global_load_dwordx4 %4, %13, off sc1\n\t"
+                 "global_load_dwordx4 %5, %14, off sc1\n\t"
+                 "global_load_dwordx4 %6, %15, off sc1\n\t"
+                 "global_load_dwordx4 %7, %16, off sc1\n\t"
+                 "global_load_dwordx4 %8, %17, off sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(x4), "=&v"(x5), "=&v"(x6), "=&v"(x7), "=&v"(x8)
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8])
+                 : "memory");
+    r[0] = make_float4(x0.x, x0.y, x0.z, x0.w), r[1] = make_float4(x1.x, x1.y, x1.z, x1.w), r[2] = make_float4(x2.x, x2.y, x2.z, x2.w);
+    r[3] = make_float4(x3.x, x3.y, x3.z, x3.w), r[4] = make_float4(x4.x, x4.y, x4.z, x4.w), r[5] = make_float4(x5.x, x5.y, x5.z, x5.w);
+    r[6] = make_float4(x6.x, x6.y, x6.z, x6.w), r[7] = make_float4(x7.x, x7.y, x7.z, x7.w), r[8] = make_float4(x8.x, x8.y, x8.z, x8.w);
 }
-__device__ __forceinline__ void st4_wtx(float *base, int64_t off, float4 v, int segs)
+// a finisher's two slots (m, v): asked for and waited for in one statement as well
+__device__ __forceinline__ void win_load2(const float *a0, const float *a1, float4 &r0, float4 &r1)
 {
-    const uint64_t byte = (uint64_t)off * 4;
-    const crec_u4v x = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-    for (int sgm = 0; sgm < segs; ++sgm) {
-        if ((int)(byte >> 32) == sgm) {
-            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base + ((int64_t)sgm << 30), 0, (int)0xffffffffu, 0x00020000);
-            __builtin_amdgcn_raw_buffer_store_b128(x, r, (int)(uint32_t)byte, 0, 16 /* sc1 */);
-        }
-    }
+    crec_f4v x0, x1;
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\t"
+                 "global_load_dwordx4 %1, %3, off sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(x0), "=&v"(x1)
+                 : "v"(a0), "v"(a1)
+                 : "memory");
+    r0 = make_float4(x0.x, x0.y, x0.z, x0.w), r1 = make_float4(x1.x, x1.y, x1.z, x1.w);
+}
+// one row's slice and its two slots
+__device__ __forceinline__ void win_load3(const float *a0, const float *a1, const float *a2, float4 &r0, float4 &r1, float4 &r2)
+{
+    crec_f4v x0, x1, x2;
+    asm volatile("global_load_dwordx4 %0, %3, off sc1\n\t"
+                 "global_load_dwordx4 %1, %4, off sc1\n\t"
+                 "global_load_dwordx4 %2, %5, off sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(x0), "=&v"(x1), "=&v"(x2)
+                 : "v"(a0), "v"(a1), "v"(a2)
+                 : "memory");
+    r0 = make_float4(x0.x, x0.y, x0.z, x0.w), r1 = make_float4(x1.x, x1.y, x1.z, x1.w), r2 = make_float4(x2.x, x2.y, x2.z, x2.w);
+}
+// written-through store (the data registers are read when the instruction issues; the caller's s_waitcnt vmcnt(0) in front of its
+// stamp waits for the acknowledgement)
+__device__ __forceinline__ void st4_wtg(float *p, float4 v)
+{
+    const crec_f4v x = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" ::"v"(p), "v"(x) : "memory");
 }
 // the lazy step's published rows (contributions, partials): agent-scope accesses + s_waitcnt, or -- CREC_TICKET_FENCES,
 // the textbook form kept buildable and compared bit for bit under test (tests/test_gpu_fences.py) -- plain accesses
@@ -2139,7 +2187,7 @@ struct LazyWin {
     int32_t *done;         // [LAZY_WIN_MAX][3 B] stamps by (batch in window, segment start; user side first, item side from B)
     int32_t stamp0;        // the stamp of the launch's first batch (a ctx-wide launch counter: never repeats)
     int32_t *err;          // give-up flag (page-locked)
-    int segs_p, segs_q;    // 4-GiB segments of a user / item table
+    bool fit_p, fit_q;     // a user / item table lies within 4 GiB
     int abl;               // timing ablations (option flow_abl; WRONG results): 1 nobody waits for a predecessor
     float lr_t[LAZY_WIN_MAX];
 };
@@ -2204,13 +2252,20 @@ __device__ __forceinline__ float4 lazy_sum_rows(const float *buf, int64_t off, i
     }
     return g;
 }
+// the same with the whole 4 GiB a 32-bit offset spans (lazy_window: a finisher's slots, where the table fits)
+__device__ __forceinline__ float4 ld4_sc1w(const float *base, int64_t off)
+{
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, (int)0xffffffffu, 0x00020000);
+    const crec_u4v x = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(uint32_t)((uint64_t)off * 4), 0, 16 /* sc1 */);
+    return make_float4(__uint_as_float(x.x), __uint_as_float(x.y), __uint_as_float(x.z), __uint_as_float(x.w));
+}
 
 // the sum of a front row: the partials of its pieces (l2 terms inside) -- the first piece ends at the workgroup boundary
 // behind the row's first slot, the others are whole workgroups --, then its negative slots' contributions (+ reg*row each),
 // all in ONE list of loads, in that order
+template <int DEEP = CREC_LAZY_DEEP>
 __device__ __forceinline__ float4 lazy_sum_front(const float *buf, int d, int l, int start, int ci, int cnt, int hmod, int SPW, float4 regrow)
 {
-    constexpr int DEEP = CREC_LAZY_DEEP;
     const int room = SPW - hmod, len1 = ci < room ? ci : room, np = 1 + (ci - len1 + SPW - 1) / SPW, n = np + (cnt - ci);
     const auto at = [&](int e) { return e == 0 ? start : (e < np ? start + len1 + (e - 1) * SPW : start + ci + (e - np)); };
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -2263,16 +2318,20 @@ __device__ __forceinline__ void lazy_finish_row(const Tables &t, int d, bool act
             const int64_t ro = (int64_t)row * d + 4 * l;
             float4 nv = own;
             opt4(nv, m, v, g, h);
-            const int sg = USER ? h.win_segs_p : h.win_segs_q;
-            st4_wtx(USER ? t.P : t.Q, ro, nv, sg);
+            st4_wtg((USER ? t.P : t.Q) + ro, nv);
             if (h.opt != CREC_OPT_SGD)
-                st4_wtx(USER ? t.mP : t.mQ, ro, m, sg);
+                st4_wtg((USER ? t.mP : t.mQ) + ro, m);
             if (h.opt == 0)
-                st4_wtx(USER ? t.vP : t.vQ, ro, v, sg);
+                st4_wtg((USER ? t.vP : t.vQ) + ro, v);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (l == 0)
+        if (l == 0) {
             __hip_atomic_store(win_done + seg_start, h.win_stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((seg_start & 15) == 0)
+                win_t(h.win_wb, 8, false);
+            if (!USER && seg_start == 0)
+                win_t(h.win_wb, 7, false);
+        }
         return;
     }
     if (!act)
@@ -2302,7 +2361,7 @@ __device__ __forceinline__ void lazy_finish_row(const Tables &t, int d, bool act
 // block, the block's partial sum) at its slot's sorted position, waited for the store, and drawn a ticket: `old` = the
 // counter before, `weight` = what it added.  Whoever completes the counter forms the row's (chunk's) sum in sorted order
 // and finishes the row.  Every lane of the group takes the same path; nobody waits for anybody.
-template <int LPR, bool USER, bool DEFER>
+template <int LPR, bool USER, bool DEFER, bool WIN = false>
 __device__ __forceinline__ void lazy_role_tail(const Tables &t, int d, bool act, int4 desc, int old, int weight, float4 own,
                                                float *cbuf, float *pbuf, int32_t *row_t, int32_t *chk_t, int CH, int SPW,
                                                const Hyper &h)
@@ -2310,9 +2369,15 @@ __device__ __forceinline__ void lazy_role_tail(const Tables &t, int d, bool act,
     const int lane = threadIdx.x & 63, l = lane % LPR, lead = lane - l;
     const int start = lazy_desc_start(desc), cnt = lazy_desc_cnt(desc), ci = lazy_desc_ci(desc);
     const LazyTicket q = lazy_ticket_of(desc, CH);
+    if (!USER && start == 0 && l == 0 && (USER ? h.win_done_u : h.win_done_q) != nullptr) {
+        win_t(h.win_wb, 9, true);
+        win_t(h.win_wb, 10, false);
+    }
     if (old + weight != q.need)
         return;
     pub_acquire();
+    if (!USER && start == 0 && l == 0 && (USER ? h.win_done_u : h.win_done_q) != nullptr)
+        win_t(h.win_wb, q.chunked ? 11 : 5, false);
     const int row = desc.x & 0x7fffffff;
     const int64_t ro = (int64_t)row * d + 4 * l;
     const bool slots = act && (USER || !h.dQ);
@@ -2320,11 +2385,18 @@ __device__ __forceinline__ void lazy_role_tail(const Tables &t, int d, bool act,
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 m = zero, v = zero;
     if ((USER ? h.win_done_u : h.win_done_q) != nullptr) { // lazy_window: every load of a table row is an agent-scope one
-        const int sg = USER ? h.win_segs_p : h.win_segs_q;
-        if (slots && h.opt != CREC_OPT_SGD)
-            m = ld4_sc1x(USER ? t.mP : t.mQ, ro, sg);
-        if (slots && h.opt == 0)
-            v = ld4_sc1x(USER ? t.vP : t.vQ, ro, sg);
+        const bool wm = slots && h.opt != CREC_OPT_SGD, wv = slots && h.opt == 0;
+        const float *safe = USER ? t.P : t.Q; // (a lane that wants nothing reads the table's first bytes)
+        if (USER ? h.win_fit_p : h.win_fit_q) { // (a table within a descriptor's reach: loads the compiler tracks, in flight beside the sum below)
+            if (wm)
+                m = ld4_sc1w(USER ? t.mP : t.mQ, ro);
+            if (wv)
+                v = ld4_sc1w(USER ? t.vP : t.vQ, ro);
+        } else {
+            float4 rm, rv;
+            win_load2(wm ? (USER ? t.mP : t.mQ) + ro : safe, wv ? (USER ? t.vP : t.vQ) + ro : safe, rm, rv);
+            m = wm ? rm : zero, v = wv ? rv : zero;
+        }
     } else {
         m = slots && h.opt != CREC_OPT_SGD ? ld4((USER ? t.mP : t.mQ) + ro) : zero;
         v = slots && h.opt == 0 ? ld4((USER ? t.vP : t.vQ) + ro) : zero;
@@ -2335,7 +2407,7 @@ __device__ __forceinline__ void lazy_role_tail(const Tables &t, int d, bool act,
     if (ci > 0) { // a front row: one partial per piece of its positive slots (l2 terms inside) -- the first piece ends at the
         // workgroup boundary behind the row's first slot, the others are whole workgroups --, then its negative slots
         if (act)
-            g = lazy_sum_front(cbuf, d, l, start, ci, cnt, lazy_desc_hmod(desc), SPW, regrow);
+            g = lazy_sum_front<WIN ? CREC_WIN_DEEP : CREC_LAZY_DEEP>(cbuf, d, l, start, ci, cnt, lazy_desc_hmod(desc), SPW, regrow);
     } else if (act) {
         g = lazy_sum_rows(cbuf, (int64_t)q.idx * d + 4 * l, q.need, d, regrow);
     }
@@ -2358,6 +2430,8 @@ __device__ __forceinline__ void lazy_role_tail(const Tables &t, int d, bool act,
         if (l == 0)
             __hip_atomic_store(row_t + start, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (!USER && start == 0 && l == 0 && (USER ? h.win_done_u : h.win_done_q) != nullptr)
+        win_t(h.win_wb, 6, false);
     lazy_finish_row<LPR, USER, DEFER>(t, d, act, row, own, g, m, v, h, start);
 }
 
@@ -2393,7 +2467,10 @@ __global__ __launch_bounds__(LazyGeo<LPR>::THREADS) void bpr_triples_lazy(Tables
         h.win_done_u = (win.abl & 2) ? nullptr : win.done + (int64_t)wb * 3 * win.B;
         h.win_done_q = (win.abl & 2) ? nullptr : h.win_done_u + win.B;
         h.win_stamp = win.stamp0 + wb;
-        h.win_segs_p = win.segs_p, h.win_segs_q = win.segs_q;
+        h.win_wb = wb;
+        h.win_fit_p = win.fit_p, h.win_fit_q = win.fit_q;
+        if (threadIdx.x == 0 && (blockIdx.x & 15) == 0)
+            win_t(wb, 0, true);
     }
     const bool win_wt = WIN && !(win.abl & 2), win_sc1 = WIN && !(win.abl & 4);
     // ONE round of coalesced loads, by processing slot, gives every address of the next round: {position, user row} and the
@@ -2425,7 +2502,25 @@ __global__ __launch_bounds__(LazyGeo<LPR>::THREADS) void bpr_triples_lazy(Tables
     if (WIN) { // rows an earlier batch of this launch rewrites: not asked for before that batch's stamp is there
         if (valid)
             dp = win.deps[(int64_t)blockIdx.y * win.B + slot]; // (win is never written: it stays in kernel-argument memory)
-        if (!(win.abl & 1) && __builtin_amdgcn_ballot_w64(valid && (dp.x >= 0 || dp.y >= 0 || dp.z >= 0)) != 0) {
+        // Every row is asked for at once, BEFORE the wait: most of a triple's rows have no predecessor in the launch (the user's,
+        // the negative item's), and their trip to HBM then runs beside the earlier batches' tails instead of behind them; the
+        // rows that do have one are asked for again once its stamp is there (they come from where the finisher wrote them
+        // through, not from HBM).  A lane that wants nothing from a load reads the item table's first bytes.
+        const bool has_m = h.opt != CREC_OPT_SGD, has_v = h.opt == 0;
+        const bool wi = on && (is || blk_whole), wj = on && js;
+        const bool want[9] = {on, on, on, on && has_m, on && has_v, wi && has_m, wi && has_v, wj && has_m, wj && has_v};
+        const float *const addr[9] = {t.P + ou, t.Q + oi, t.Q + oj, t.mP + ou, t.vP + ou, t.mQ + oi, t.vQ + oi, t.mQ + oj, t.vQ + oj};
+        float4 rows[9];
+        if (win_sc1) {
+            const float *const a1[9] = {want[0] ? addr[0] : t.Q, want[1] ? addr[1] : t.Q, want[2] ? addr[2] : t.Q,
+                                        want[3] ? addr[3] : t.Q, want[4] ? addr[4] : t.Q, want[5] ? addr[5] : t.Q,
+                                        want[6] ? addr[6] : t.Q, want[7] ? addr[7] : t.Q, want[8] ? addr[8] : t.Q};
+            win_load9(a1, rows);
+            if (threadIdx.x == 0 && (blockIdx.x & 15) == 0)
+                win_t(blockIdx.y, 4, false);
+        }
+        const bool any_dep = __builtin_amdgcn_ballot_w64(valid && (dp.x >= 0 || dp.y >= 0 || dp.z >= 0)) != 0;
+        if (!(win.abl & 1) && any_dep) {
             unsigned spins = 0;
             for (;;) {
                 bool pend = false;
@@ -2442,10 +2537,12 @@ __global__ __launch_bounds__(LazyGeo<LPR>::THREADS) void bpr_triples_lazy(Tables
                 }
                 if (__builtin_amdgcn_ballot_w64(pend) == 0)
                     break;
-                if (spins < 16)
-                    __builtin_amdgcn_s_sleep(2);
+                if (spins < 16) // (a predecessor's stamp is usually 5 - 15 us away, and every hop of a popular row's way from batch to batch
+                    __builtin_amdgcn_s_sleep(2); // begins with a poll that sees it: asked again every ~0.5 us, far less often only after 0.5 ms)
+                else if (spins < 1024)
+                    __builtin_amdgcn_s_sleep(12);
                 else
-                    for (int zz = 0; zz < (spins < 256 ? 1 : 16); ++zz)
+                    for (int zz = 0; zz < 16; ++zz)
                         __builtin_amdgcn_s_sleep(127);
                 if ((++spins & 255u) == 0 && (spins >= (1u << 20) || __hip_atomic_load(win.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0)) {
                     if (lane == 0)
@@ -2457,6 +2554,29 @@ __global__ __launch_bounds__(LazyGeo<LPR>::THREADS) void bpr_triples_lazy(Tables
         // the row loads below are relaxed atomics like the polls above: nothing but this keeps the compiler from asking for a row
         // BEFORE its stamp has been seen (the wave issues in program order, and the polls' values are consumed: the hardware keeps it)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (any_dep && threadIdx.x == 0 && (blockIdx.x & 15) == 0) {
+            win_t(blockIdx.y, 2, true);
+            win_t(blockIdx.y, 3, false);
+        }
+        if (win_sc1) {
+            // the rows with a predecessor, as that batch left them: row by row (the positive item's is the usual one), each only where
+            // some triple of the wave has one
+            const int dep3[3] = {dp.x, dp.y, dp.z};
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const bool again = valid && dep3[r] >= 0;
+                if (__builtin_amdgcn_ballot_w64(again) == 0)
+                    continue;
+                const int e0 = r, e1 = 3 + 2 * r, e2 = 4 + 2 * r; // the row, its m, its v
+                float4 f0, f1, f2;
+                win_load3(want[e0] && again ? addr[e0] : t.Q, want[e1] && again ? addr[e1] : t.Q, want[e2] && again ? addr[e2] : t.Q, f0, f1, f2);
+                if (again)
+                    rows[e0] = f0, rows[e1] = f1, rows[e2] = f2;
+            }
+            p = want[0] ? rows[0] : zero, qi = want[1] ? rows[1] : zero, qj = want[2] ? rows[2] : zero;
+            mp = want[3] ? rows[3] : zero, vp = want[4] ? rows[4] : zero, mi = want[5] ? rows[5] : zero;
+            vi = want[6] ? rows[6] : zero, mj = want[7] ? rows[7] : zero, vj = want[8] ? rows[8] : zero;
+        }
     }
 #if CREC_LAZY_HEADSTART
     // A head start for the rows with a tail.  All waves of the launch are resident at once and ask for their rows in the
@@ -2465,30 +2585,12 @@ __global__ __launch_bounds__(LazyGeo<LPR>::THREADS) void bpr_triples_lazy(Tables
     // publish -> ticket -> sum chain is added on top.  Waves none of whose triples takes a ticket therefore wait a
     // little before asking: the others' rows come back first, and their chains run beside the body instead of after it.
     // (Only where there is such a front to speak of: S-big 16.46 -> 16.11 us with 6 x 0.43 us, 16.7 / 17.9 with 12 / 16.)
-    if (!front_block && n_slots >= 2048 && 4 * n_blk_slots >= n_slots && __builtin_amdgcn_ballot_w64(valid && (!is || !js)) == 0)
+    if (!WIN && !front_block && n_slots >= 2048 && 4 * n_blk_slots >= n_slots && __builtin_amdgcn_ballot_w64(valid && (!is || !js)) == 0)
         for (int k = 0; k < CREC_LAZY_HEADSTART; ++k)
             __builtin_amdgcn_s_sleep(16); // 16 x 64 clocks = 0.43 us
 #endif
-    if (win_sc1) { // every load of a table row is a 16-byte agent-scope one (a row may have been rewritten by another XCD in this launch)
-        const bool has_m = h.opt != CREC_OPT_SGD, has_v = h.opt == 0;
-        const int sp_ = h.win_segs_p, sq_ = h.win_segs_q;
-        if (on) {
-            p = ld4_sc1x(t.P, ou, sp_);
-            qi = ld4_sc1x(t.Q, oi, sq_);
-            qj = ld4_sc1x(t.Q, oj, sq_);
-            if (has_m)
-                mp = ld4_sc1x(t.mP, ou, sp_);
-            if (has_v)
-                vp = ld4_sc1x(t.vP, ou, sp_);
-            if ((is || blk_whole) && has_m)
-                mi = ld4_sc1x(t.mQ, oi, sq_);
-            if ((is || blk_whole) && has_v)
-                vi = ld4_sc1x(t.vQ, oi, sq_);
-            if (js && has_m)
-                mj = ld4_sc1x(t.mQ, oj, sq_);
-            if (js && has_v)
-                vj = ld4_sc1x(t.vQ, oj, sq_);
-        }
+    if (win_sc1) {
+        // (asked for above, around the wait for the predecessors' stamps)
     } else if (on) { // every address is known: one round of loads
         p = ld4(t.P + ou);
         qi = ld4(t.Q + oi);
@@ -2585,11 +2687,11 @@ __global__ __launch_bounds__(LazyGeo<LPR>::THREADS) void bpr_triples_lazy(Tables
             float4 np = p;
             opt4(np, mp, vp, gp, h);
             if (win_wt) {
-                st4_wtx(t.P, ou, np, h.win_segs_p);
+                st4_wtg(t.P + ou, np);
                 if (h.opt != CREC_OPT_SGD)
-                    st4_wtx(t.mP, ou, mp, h.win_segs_p);
+                    st4_wtg(t.mP + ou, mp);
                 if (h.opt == 0)
-                    st4_wtx(t.vP, ou, vp, h.win_segs_p);
+                    st4_wtg(t.vP + ou, vp);
             } else {
                 st4s(t.P + ou, np);
                 if (h.opt != CREC_OPT_SGD)
@@ -2604,11 +2706,11 @@ __global__ __launch_bounds__(LazyGeo<LPR>::THREADS) void bpr_triples_lazy(Tables
                 float4 nq = qi;
                 opt4(nq, mi, vi, gi, h);
                 if (win_wt) {
-                    st4_wtx(t.Q, oi, nq, h.win_segs_q);
+                    st4_wtg(t.Q + oi, nq);
                     if (h.opt != CREC_OPT_SGD)
-                        st4_wtx(t.mQ, oi, mi, h.win_segs_q);
+                        st4_wtg(t.mQ + oi, mi);
                     if (h.opt == 0)
-                        st4_wtx(t.vQ, oi, vi, h.win_segs_q);
+                        st4_wtg(t.vQ + oi, vi);
                 } else {
                     st4s(t.Q + oi, nq);
                     if (h.opt != CREC_OPT_SGD)
@@ -2626,11 +2728,11 @@ __global__ __launch_bounds__(LazyGeo<LPR>::THREADS) void bpr_triples_lazy(Tables
                 float4 nq = qj;
                 opt4(nq, mj, vj, gj, h);
                 if (win_wt) {
-                    st4_wtx(t.Q, oj, nq, h.win_segs_q);
+                    st4_wtg(t.Q + oj, nq);
                     if (h.opt != CREC_OPT_SGD)
-                        st4_wtx(t.mQ, oj, mj, h.win_segs_q);
+                        st4_wtg(t.mQ + oj, mj);
                     if (h.opt == 0)
-                        st4_wtx(t.vQ, oj, vj, h.win_segs_q);
+                        st4_wtg(t.vQ + oj, vj);
                 } else {
                     st4s(t.Q + oj, nq);
                     if (h.opt != CREC_OPT_SGD)
@@ -2664,11 +2766,13 @@ __global__ __launch_bounds__(LazyGeo<LPR>::THREADS) void bpr_triples_lazy(Tables
     tki = __shfl(tki, lead, 64);
     tkj = __shfl(tkj, lead, 64);
     if (valid && !us)
-        lazy_role_tail<LPR, true, DEFER>(t, d, act, du, tku, 1, p, z.ucontrib, z.upart, z.urow_t, z.uchk_t, z.CH, SPW, h);
+        lazy_role_tail<LPR, true, DEFER, WIN>(t, d, act, du, tku, 1, p, z.ucontrib, z.upart, z.urow_t, z.uchk_t, z.CH, SPW, h);
     if (valid && i_publish)
-        lazy_role_tail<LPR, false, DEFER>(t, d, act, di, tki, wi, qi, z.qcontrib, z.qpart, z.qrow_t, z.qchk_t, z.CH, SPW, h);
+        lazy_role_tail<LPR, false, DEFER, WIN>(t, d, act, di, tki, wi, qi, z.qcontrib, z.qpart, z.qrow_t, z.qchk_t, z.CH, SPW, h);
     if (valid && !js)
-        lazy_role_tail<LPR, false, DEFER>(t, d, act, dj, tkj, 1, qj, z.qcontrib, z.qpart, z.qrow_t, z.qchk_t, z.CH, SPW, h);
+        lazy_role_tail<LPR, false, DEFER, WIN>(t, d, act, dj, tkj, 1, qj, z.qcontrib, z.qpart, z.qrow_t, z.qchk_t, z.CH, SPW, h);
+    if (WIN && threadIdx.x == 0 && (blockIdx.x & 15) == 0)
+        win_t(blockIdx.y, 1, false);
 }
 
 // deferred mode: every row of a table brought up to the state after step h.step (before evaluation / a checkpoint);
@@ -3239,10 +3343,20 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
     // lazy-family steps, W consecutive batches per launch (bpr_triples_lazy<.., WIN>): where the batch is indexed in LDS and the step is
     // neither the deferred form (its replay stamps) nor the row-sharded one
     int lazy_win = 0;
-    if (!dense && !dp && !df && B <= MAX_B && !ctx->knob_big_index && ctx->knob_lazy_window > 1 && 3 * (int64_t)B < ((int64_t)1 << 20)) {
-        ensure_err();
-        if (ctx->flow_err_dev)
-            lazy_win = ctx->knob_lazy_window < LAZY_WIN_MAX ? ctx->knob_lazy_window : LAZY_WIN_MAX;
+    if (!dense && !dp && !df && B <= MAX_B && !ctx->knob_big_index && ctx->knob_lazy_window != 0 && ctx->knob_lazy_window != 1 &&
+        3 * (int64_t)B < ((int64_t)1 << 20)) {
+        // -1 (the default): 8 batches per launch where the tables dwarf the batch -- a row then seldom has a predecessor in the launch
+        // and the launch is bound by its traffic, not by the popular rows' way from batch to batch (10 M x 1 M rows, d = 128: 18.3 ->
+        // 15.6 us/step, uniform positives 20.8 -> 14.7; 1 M x 100 k: 18.1 -> 16.9; but 100 k x 20 k: 14.8 -> 15.6 and ml-1m's
+        // 6 040 x 3 706: 18.1 -> 21.0, where every row recurs in every batch; d = 32: neither; tools/time_window.py)
+        int want = ctx->knob_lazy_window;
+        if (want < 0)
+            want = (t->d >= 64 && (int64_t)t->I >= 16 * (int64_t)B && (int64_t)t->U >= 16 * (int64_t)B && nb >= 4) ? 8 : 0;
+        if (want > 1) {
+            ensure_err();
+            if (ctx->flow_err_dev)
+                lazy_win = want < LAZY_WIN_MAX ? want : LAZY_WIN_MAX;
+        }
     }
     const auto layout = [&](void *base, int64_t nbc_, int spw_ = 32) {
         IndexWs w_ = layout_index(base, nbc_, B, t->U, t->I, dense, CH_idx, wide_rows, wide_total, spw_, flow_rpb, deal_nwg_u, deal_nwg_q, lazy_win);
@@ -3571,7 +3685,7 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
                 ctx->lazy_stamp = 0; // (old stamps are at least a launch behind: never equal to a fresh one)
             wn.err = ctx->flow_err_dev;
             wn.abl = ctx->knob_flow_abl;
-            wn.segs_p = (int)((hP * 4 + ((int64_t)1 << 32) - 1) >> 32), wn.segs_q = (int)((hQ * 4 + ((int64_t)1 << 32) - 1) >> 32);
+            wn.fit_p = hP * 4 <= (int64_t)0xfffffff0, wn.fit_q = hQ * 4 <= (int64_t)0xfffffff0;
             a.h = Hyper{};
             a.h.opt = (opt->adam_mode == CREC_OPT_SGD || opt->adam_mode == CREC_OPT_ADAGRAD) ? opt->adam_mode : 0;
             a.h.beta1 = opt->beta1, a.h.beta2 = opt->beta2, a.h.eps = opt->eps, a.h.reg = opt->reg;

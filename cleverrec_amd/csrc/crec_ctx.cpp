@@ -219,7 +219,7 @@ int crec_ctx_create(int device, crec_ctx **out)
     ctx->knob_dsampler_general = env_int("CREC_DSAMPLER_GENERAL", 0);
     ctx->knob_flow = env_int("CREC_FLOW", -1);
     ctx->knob_flow_steps = env_int("CREC_FLOW_STEPS", 0);
-    ctx->knob_lazy_window = env_int("CREC_LAZY_WINDOW", 0);
+    ctx->knob_lazy_window = env_int("CREC_LAZY_WINDOW", -1);
     ctx->knob_flow_abl = env_int("CREC_FLOW_ABL", 0);
     if (device >= 0) {
         int n = 0;

@@ -129,7 +129,7 @@ struct crec_ctx {
     int knob_ncf_generic = 0;    // 1: the generic ncf_tile even for the shapes that have a specialised one (tests)
     int knob_dsampler_budget = 100; // percent of the device sampler's stream budget to start with (tests: < 100 forces the retry path)
     int knob_flow = -1;          // tf1 step: -1 / 1 all steps of a chunk in one dataflow launch where the shape allows (bpr_steps_flow), 0 a launch per step
-    int knob_lazy_window = 0;    // lazy-family steps: W > 1 consecutive batches per launch (bpr_triples_lazy<.., WIN>), 0 / 1 a launch per batch
+    int knob_lazy_window = -1;   // lazy-family steps: W > 1 consecutive batches per launch (bpr_triples_lazy<.., WIN>), 0 / 1 a launch per batch, -1 by table size
     crec_devbuf lazy_done;       // lazy_window: the finishers' stamps
     int32_t lazy_stamp = 0;      // ... and the ctx-wide launch count they are drawn from
     int knob_flow_abl = 0;       // timing ablations of bpr_steps_flow (FlowArgs::abl; wrong results)

@@ -85,10 +85,11 @@ const char *crec_last_error(const crec_ctx *ctx);
  *                    fp32 summation order
  *   "flow_steps"     steps per bpr_steps_flow launch (0 = up to 64; 1 = a launch per step through the same kernel: bit-identical)
  *   "flow_deal"      0: its rows are dealt to workgroups round-robin by id instead of by how often they occur (bit-identical)
- *   "lazy_window"    lazy Adam (CREC_ADAM_LAZY / _DEFERRED off): W = 2..16 consecutive batches of bpr_triples_lazy per launch, a row's
- *                    readers waiting for the batch before them that wrote it (bit-identical to 0 = a launch per batch, the default;
- *                    env CREC_LAZY_WINDOW).  Pays where few rows recur from batch to batch (S-big with uniform positives: 22.9 ->
- *                    16.1 us/step at W = 8), not where the same hot rows chain every batch (Zipf(1.0) positives: 20.2 -> 21.8)
+ *   "lazy_window"    lazy Adam (CREC_ADAM_LAZY, LDS-indexed batches, not the row-sharded step): W = 2..16 consecutive batches of
+ *                    bpr_triples_lazy per launch, a row's readers waiting for the batch before them that wrote it (bit-identical to
+ *                    0 = a launch per batch).  -1 (default; env CREC_LAZY_WINDOW): 8 where both tables hold >= 16 batches' worth of
+ *                    rows and d >= 64 (S-big: 18.3 -> 15.6 us/step, uniform positives 20.8 -> 14.7), else 0 (small catalogues, where
+ *                    every row recurs from batch to batch and the launch is bound by the rows' way through it: ml-1m +16 %)
  *   "flow_abl"       timing ablations of bpr_steps_flow / the window (results are WRONG; tools/ only)
  *   "big_index"      1: the lazy-family steps index their batches through the global-memory sort (index_big.hip, the form batches of
  *                    more than 8192 triples always take) even where the in-LDS sort would do: same index, bit for bit

@@ -37,7 +37,7 @@ def _run(sess, W, mode, U, I, d, B, u, i, j, calls=1):
         losses = [st.train_epoch(du[a:b], di[a:b], dj[a:b], B).cpu().numpy() for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
         return [np.concatenate(losses)] + [getattr(st, n).cpu().numpy() for n in ("P", "Q", "mP", "mQ", "vP", "vQ")]
     finally:
-        sess.ctx.set_option("lazy_window", 0)
+        sess.ctx.set_option("lazy_window", -1)
 
 
 CASES = [
@@ -62,3 +62,64 @@ def test_window_equals_a_launch_per_batch_bit_for_bit(sess, U, I, d, B, nb, zipf
         got = _run(sess, W, mode, U, I, d, B, u, i, j, calls)
         for x, y, name in zip(ref, got, ("loss", "P", "Q", "mP", "mQ", "vP", "vQ")):
             assert np.array_equal(x, y), "W = %d: %s" % (W, name)
+
+
+def test_window_is_the_default_where_the_tables_dwarf_the_batch(sess):
+    """lazy_window = -1 (the default): 8 batches per launch where both tables hold >= 16 batches' worth of rows and d >= 64 -- seen in
+    the launch brackets' unit counts -- and a launch per batch elsewhere; the same bits either way."""
+    for (U, I, d, B, nb), windows in (((200_000, 20_000, 64, 1024, 21), True), ((200_000, 20_000, 64, 2048, 9), False),
+                                      ((200_000, 20_000, 32, 1024, 9), False)):
+        u, i, j = _stream(5, U, I, nb * B + 77, 1.1)
+        ref = _run(sess, 0, "lazy", U, I, d, B, u, i, j)
+        sess.ctx.profile(True)
+        try:
+            got = _run(sess, -1, "lazy", U, I, d, B, u, i, j)
+            launches = sess.ctx.profile_read()["bpr_triples_lazy"][1]
+            units = sess.ctx.profile_units("bpr_triples_lazy")
+        finally:
+            sess.ctx.profile(False)
+        assert units > 0 and (units > launches) == windows, (U, I, d, B, units, launches)
+        for x, y, name in zip(ref, got, ("loss", "P", "Q", "mP", "mQ", "vP", "vQ")):
+            assert np.array_equal(x, y), name
+
+
+def test_window_rows_beyond_a_buffer_descriptors_reach(sess):
+    """User tables of 4.6 GB each (9 M x 128 fp32): rows beyond the 4 GiB a buffer descriptor addresses go through the window's
+    64-bit assembly loads / stores, finishers' slots included -- users at the table's end that occur several times per batch and in
+    consecutive batches.  Against a launch per batch: bit for bit (compared on the device)."""
+    import torch
+    from cleverrec_amd import _lib
+    if torch.cuda.mem_get_info()[0] < 40 << 30:
+        pytest.skip("needs 40 GB of device memory")
+    U, I, d, B, nb = 9_000_000, 300_000, 128, 2048, 13
+    dev = sess.device
+    g = torch.Generator(device=dev).manual_seed(3)
+    P0 = torch.empty((U, d), dtype=torch.float32, device=dev).normal_(0, 0.01, generator=g)
+    Q0 = torch.empty((I, d), dtype=torch.float32, device=dev).normal_(0, 0.01, generator=g)
+    n = nb * B + 99
+    u = (U - 1 - torch.randint(0, 700, (n,), generator=g, device=dev)).to(torch.int32)
+    u[::3] = torch.randint(0, U, (len(u[::3]),), generator=g, device=dev).to(torch.int32)  # (and cold users anywhere)
+    hi, ii, ji = _stream(11, U, I, n, 1.1)
+    i, j = sess.to_dev(ii), sess.to_dev(ji)
+
+    def run(W):
+        sess.ctx.set_option("lazy_window", W)
+        try:
+            st = runtime.BprState.__new__(runtime.BprState)
+            st.sess = sess
+            st.P, st.Q = P0.clone(), Q0.clone()
+            st.mP, st.vP, st.mQ, st.vQ = torch.zeros_like(st.P), torch.zeros_like(st.P), torch.zeros_like(st.Q), torch.zeros_like(st.Q)
+            st.tables = _lib.BprTables(*(t.data_ptr() for t in (st.P, st.Q, st.mP, st.vP, st.mQ, st.vQ)), U, I, d)
+            st.adam = _lib.Adam(1e-3, 0.9, 0.999, 1e-8, 0.01, _lib.ADAM_LAZY, 0.9, 0.999, 0)
+            loss = st.train_epoch(u, i, j, B)
+            torch.cuda.synchronize()
+            return st, loss
+        finally:
+            sess.ctx.set_option("lazy_window", -1)
+
+    ref, ref_loss = run(0)
+    assert float((ref.P[U - 700:] != P0[U - 700:]).float().mean()) > 0.9  # (the end of the table did move)
+    got, loss = run(8)
+    assert torch.equal(loss, ref_loss)
+    for name in ("P", "Q", "mP", "mQ", "vP", "vQ"):
+        assert torch.equal(getattr(got, name), getattr(ref, name)), name

@@ -57,6 +57,7 @@ def run(users=10_000_000, items=1_000_000, dim=128, steps=300, warmup=30, batch=
     st.train_epoch(u[nw:], i[nw:], j[nw:], batch)
     torch.cuda.synchronize()
     prof = sess.ctx.profile_read()
+    batches_per_launch = sess.ctx.profile_units("bpr_triples_lazy") / max(1, prof["bpr_triples_lazy"][1])  # (option lazy_window: W batches per launch)
     sess.ctx.profile(False)
 
     # row multiplicities per batch (sampled): unique touched rows for the 28d Adam term, and which kernel owns a row --
@@ -79,7 +80,7 @@ def run(users=10_000_000, items=1_000_000, dim=128, steps=300, warmup=30, batch=
     # (24d + 12) B per triple (3 ids, 3 row reads, 3 gradient rows) + 28d B per unique touched row (Adam).
     # The step is ONE launch (bpr_triples_lazy): it owns all of it.
     alg_step = batch * (24 * d + 12) + (uq_u + uq_q) * 28 * d
-    us = prof["bpr_triples_lazy"][0] / prof["bpr_triples_lazy"][1] * 1e3
+    us = prof["bpr_triples_lazy"][0] / prof["bpr_triples_lazy"][1] * 1e3 / batches_per_launch  # per batch
     out = {
         "workload": "S-big: %d users x %d items, d=%d fp32, batch %d, lazy Adam, Zipf(1.0) positives" % (users, items, dim, batch),
         "state_GB": (users + items) * dim * 4 * 3 / 1e9,
@@ -87,7 +88,7 @@ def run(users=10_000_000, items=1_000_000, dim=128, steps=300, warmup=30, batch=
         "unique_user_rows_per_batch": uq_u, "unique_item_rows_per_batch": uq_q,
         "single_occurrence_rows_per_batch": {"users": single_u, "items": single_q},
         "slots_of_multi_occurrence_rows_per_batch": {"users": multi_slots_u, "items": multi_slots_q},
-        "bpr_triples_lazy": {"avg_us": us, "algorithmic_bytes": alg_step, "GBs": alg_step / us / 1e3, "frac_of_8TBs": alg_step / us / 1e3 / 8000},
+        "bpr_triples_lazy": {"avg_us": us, "batches_per_launch": batches_per_launch, "algorithmic_bytes": alg_step, "GBs": alg_step / us / 1e3, "frac_of_8TBs": alg_step / us / 1e3 / 8000},
         "step_algorithmic_bytes": alg_step,
         "step_algorithmic_GBs": alg_step / (dt / steps) / 1e9,
         "bpr_index_batches_us_per_step": prof.get("bpr_index_batches", (0.0, 0))[0] * 1e3 / steps,  # (0: batches beyond 8192 are indexed by index_big.hip, outside these brackets)
