@@ -140,7 +140,8 @@ __device__ __forceinline__ void crec_mark(int slot, int dep) // the time at whic
                          // (tools/lazy_variants.sh)
 #endif
 #ifndef CREC_WIN_DEEP
-#define CREC_WIN_DEEP 16 // the same in a lazy_window launch, where a popular row's finisher is on the path from batch to batch
+#define CREC_WIN_DEEP 12 // the same in a lazy_window launch, where a popular row's finisher is on the path from batch to batch (its
+                         // workgroups are up to 1024 threads: 12 fit the 128 VGPRs that leaves, 14 spill)
 #endif
 #ifndef CREC_FUSED_WT
 #define CREC_FUSED_WT 0 // 1: the launch-per-step tf1 kernel writes its tables with write-through (sc1) stores
@@ -240,7 +241,19 @@ inline int row_bits(int64_t n_rows)
 #ifndef CREC_LAZY_SPW
 #define CREC_LAZY_SPW 16 // slots per workgroup at 4 < d <= 128: S-big kernel 19.5 / 17.7 / 18.6 us at 8 / 16 / 32 (tools/lazy_variants.sh)
 #endif
-inline int lazy_spw(int d) { return d <= 4 ? 64 : (d > 128 ? 16 : (d > 64 && CREC_LAZY_SPW > 32 ? 32 : CREC_LAZY_SPW)); }
+// Batches of 4096 triples and more: 32 where the lane group is 8 .. 32 lanes (workgroups of up to 1024 threads) -- a popular item's
+// positive slots then make half as many pieces, and its finisher sums them in one round of loads less: under lazy_window, where that
+// finisher is on the path from batch to batch, S-big 13.0 -> 12.5 us per batch, ml-1m's catalogue at d = 128 20.9 -> 17.0 us per
+// step; a launch per batch is as fast or faster so from 4096 triples (ml-1m d = 64: 14.1 -> 13.4), slower below (B = 2048: 11.9 ->
+// 15.2).  The geometry depends on (d, B) only, never on the window: the pieces are part of the order the sums are formed in.
+inline int lazy_spw(int d, int64_t B = 0)
+{
+    if (d <= 4)
+        return 64;
+    if (d > 128)
+        return 16;
+    return (B >= 4096 && d > 16) ? 32 : (d > 64 && CREC_LAZY_SPW > 32 ? 32 : CREC_LAZY_SPW);
+}
 
 IndexWs layout_index(void *base, int64_t nbc, int64_t B, int64_t U, int64_t I, bool dense, int CH, int wide_rows = 0,
                      int wide_total = 0, int spw = 32, int flow_rpb = 0, int flow_nwg_u = 0, int flow_nwg_q = 0, int win = 0)
@@ -2437,19 +2450,19 @@ __device__ __forceinline__ void lazy_role_tail(const Tables &t, int d, bool act,
 
 // bpr_triples_lazy: a lane group per processing slot; a workgroup = SPW slots (IndexWs::order, ::nslots); ud / id / jd: the
 // triples' three roles by batch position.
-template <int LPR> struct LazyGeo {
-    static constexpr int SPW = LPR == 1 ? 64 : (LPR == 64 ? 16 : (LPR == 32 && CREC_LAZY_SPW > 32 ? 32 : CREC_LAZY_SPW)),
-                         THREADS = SPW * LPR; // = lazy_spw(d)
+template <int LPR, bool BIG = false> struct LazyGeo { // BIG: the geometry of batches >= 4096 triples (lazy_spw)
+    static constexpr int SPW = LPR == 1 ? 64 : (LPR == 64 ? 16 : (BIG && LPR >= 8 ? 32 : (LPR == 32 && CREC_LAZY_SPW > 32 ? 32 : CREC_LAZY_SPW))),
+                         THREADS = SPW * LPR; // = lazy_spw(d, B)
 };
 
-template <int LPR, bool FULL, bool DEFER, bool WIN = false>
-__global__ __launch_bounds__(LazyGeo<LPR>::THREADS) void bpr_triples_lazy(Tables t, int d, const int2 *__restrict__ slot_pu, int n_slots,
+template <int LPR, bool FULL, bool DEFER, bool WIN = false, bool BIG = false>
+__global__ __launch_bounds__((LazyGeo<LPR, BIG>::THREADS)) void bpr_triples_lazy(Tables t, int d, const int2 *__restrict__ slot_pu, int n_slots,
                                                                           const int32_t *__restrict__ nslots,
                                                                           const int4 *__restrict__ ud, const int4 *__restrict__ id,
                                                                           const int4 *__restrict__ jd, LazyBufs z,
                                                                           float *__restrict__ xb, float *__restrict__ l2b, Hyper h, const LazyWin win)
 {
-    constexpr int SPW = LazyGeo<LPR>::SPW;
+    constexpr int SPW = LazyGeo<LPR, BIG>::SPW;
     extern __shared__ float4 blk_rows[]; // [SPW][LPR], workgroups of the front region only
     const int lane = threadIdx.x & 63, l = lane % LPR, gw = (int)threadIdx.x / LPR;
     const int slot0 = (int)blockIdx.x * SPW;
@@ -2951,37 +2964,54 @@ template <int LPR, bool FULL> void launch_fused(const StepArgs &a, const IndexWs
     crec_prof_end(a.ctx, a.st);
 }
 
-template <int LPR, bool FULL> void launch_lazy(const StepArgs &a, const IndexWs &w, int64_t b, const int32_t *hn)
+template <int LPR, bool FULL, bool BIG> void launch_lazy_geo(const StepArgs &a, const IndexWs &w, int64_t b)
 {
-    constexpr int SPW = LazyGeo<LPR>::SPW, THREADS = LazyGeo<LPR>::THREADS;
-    (void)hn;
+    constexpr int SPW = LazyGeo<LPR, BIG>::SPW, THREADS = LazyGeo<LPR, BIG>::THREADS;
     const dim3 grid((unsigned)crec_ceil_div((int64_t)a.nb_cur, SPW)), block(THREADS);
     const size_t lds = sizeof(float4) * THREADS;
     crec_prof_begin(a.ctx, CREC_K_USER_SIDE, a.st);
     if (a.h.lr_tab)
-        CREC_KLAUNCH(a.ctx, (bpr_triples_lazy<LPR, FULL, true>), grid, block, lds, a.st, a.cur, a.d,
+        CREC_KLAUNCH(a.ctx, (bpr_triples_lazy<LPR, FULL, true, false, BIG>), grid, block, lds, a.st, a.cur, a.d,
                      (const int2 *)(w.slot_pu + b * w.B), (int)a.nb_cur, (const int32_t *)(w.nslots + b * 2), (const int4 *)(w.u_desc + b * w.B),
                      (const int4 *)(w.i_desc + b * w.B), (const int4 *)(w.j_desc + b * w.B), a.lazy, a.xb, a.rowterm, a.h, LazyWin{});
     else
-        CREC_KLAUNCH(a.ctx, (bpr_triples_lazy<LPR, FULL, false>), grid, block, lds, a.st, a.cur, a.d,
+        CREC_KLAUNCH(a.ctx, (bpr_triples_lazy<LPR, FULL, false, false, BIG>), grid, block, lds, a.st, a.cur, a.d,
                      (const int2 *)(w.slot_pu + b * w.B), (int)a.nb_cur, (const int32_t *)(w.nslots + b * 2), (const int4 *)(w.u_desc + b * w.B),
                      (const int4 *)(w.i_desc + b * w.B), (const int4 *)(w.j_desc + b * w.B), a.lazy, a.xb, a.rowterm, a.h, LazyWin{});
     crec_prof_end(a.ctx, a.st);
 }
+// (the index was laid out for w.spw slots per workgroup: the kernel of that geometry)
+template <int LPR, bool FULL> void launch_lazy(const StepArgs &a, const IndexWs &w, int64_t b, const int32_t *hn)
+{
+    (void)hn;
+    if constexpr (LazyGeo<LPR, true>::SPW != LazyGeo<LPR, false>::SPW) {
+        if (w.spw == LazyGeo<LPR, true>::SPW)
+            return launch_lazy_geo<LPR, FULL, true>(a, w, b);
+    }
+    launch_lazy_geo<LPR, FULL, false>(a, w, b);
+}
 
 // lazy_window: the batches [b, b + win.W) of the chunk in one launch (blockIdx.y = the batch)
-template <int LPR, bool FULL> void launch_lazy_window(const StepArgs &a, const IndexWs &w, int64_t b, const LazyWin &win)
+template <int LPR, bool FULL, bool BIG> void launch_lazy_window_geo(const StepArgs &a, const IndexWs &w, int64_t b, const LazyWin &win)
 {
-    constexpr int SPW = LazyGeo<LPR>::SPW, THREADS = LazyGeo<LPR>::THREADS;
+    constexpr int SPW = LazyGeo<LPR, BIG>::SPW, THREADS = LazyGeo<LPR, BIG>::THREADS;
     const dim3 grid((unsigned)crec_ceil_div((int64_t)a.B, SPW), (unsigned)win.W), block(THREADS);
     const size_t lds = sizeof(float4) * THREADS;
     a.ctx->prof.next_units = win.W;
     crec_prof_begin(a.ctx, CREC_K_USER_SIDE, a.st);
-    CREC_KLAUNCH(a.ctx, (bpr_triples_lazy<LPR, FULL, false, true>), grid, block, lds, a.st, a.cur, a.d, (const int2 *)(w.slot_pu + b * w.B), 0,
+    CREC_KLAUNCH(a.ctx, (bpr_triples_lazy<LPR, FULL, false, true, BIG>), grid, block, lds, a.st, a.cur, a.d, (const int2 *)(w.slot_pu + b * w.B), 0,
                  (const int32_t *)(w.nslots + b * 2), (const int4 *)(w.u_desc + b * w.B), (const int4 *)(w.i_desc + b * w.B),
                  (const int4 *)(w.j_desc + b * w.B), a.lazy, a.xb, a.rowterm, a.h, win);
     crec_prof_end(a.ctx, a.st);
     a.ctx->prof.next_units = 1;
+}
+template <int LPR, bool FULL> void launch_lazy_window(const StepArgs &a, const IndexWs &w, int64_t b, const LazyWin &win)
+{
+    if constexpr (LazyGeo<LPR, true>::SPW != LazyGeo<LPR, false>::SPW) {
+        if (w.spw == LazyGeo<LPR, true>::SPW)
+            return launch_lazy_window_geo<LPR, FULL, true>(a, w, b, win);
+    }
+    launch_lazy_window_geo<LPR, FULL, false>(a, w, b, win);
 }
 using WinFn = void (*)(const StepArgs &, const IndexWs &, int64_t, const LazyWin &);
 WinFn pick_window(int d)
@@ -3378,17 +3408,22 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
     // indexed on a side stream while chunk c's steps run (two index buffers); the first chunk's index is then the only one the
     // steps wait for, so the chunks start small (half a million triples) and double up to `chunk`.  (Off by default: S-big at
     // B = 65536 on one GPU, 135.1 us per step so against 132.8 in line -- the step kernel is slowed by what the index kernels take.)
+    // The lazy family's LDS-built index (and lazy_window's dependencies) can go the same way -- nothing of it is read back by the host
+    // and its steps wait for nobody dispatched later, so an index kernel beside them is safe (not so beside bpr_steps_flow, whose
+    // waves wait for each other and must all be resident) -- and gains as little: S-big 15.7 us per step so against 15.65 in line,
+    // the window launch 14.3 us per batch instead of 13.0 (the index's workgroups take the CUs the steps would have used).
+    const bool want_pipe = ctx->knob_idx_overlap == 1 && (big_index || (!dense && !dp));
     std::vector<int64_t> chunk_sizes;
     {
         int64_t cur = chunk;
-        if (big_index && ctx->knob_idx_overlap) {
+        if (want_pipe) {
             cur = ((int64_t)1 << 19) / B;
             cur = cur < 1 ? 1 : (cur > chunk ? chunk : cur);
         }
         for (int64_t done = 0; done < nb; done += cur, cur = (2 * cur > chunk ? chunk : 2 * cur))
             chunk_sizes.push_back((nb - done) < cur ? (nb - done) : cur);
     }
-    const bool piped = big_index && ctx->knob_idx_overlap && chunk_sizes.size() > 1;
+    const bool piped = want_pipe && chunk_sizes.size() > 1;
     if (int rc = crec_reserve(ctx, &ctx->idx_ws, layout(nullptr, chunk).bytes))
         return rc;
     if (piped) {
@@ -3454,15 +3489,6 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
         }
     }
 
-    // dynamic LDS of the index kernel
-    const int cap = (2 * B + 63) / 64 * 64;
-    const size_t lds = big_index ? 0 : index_lds_bytes(cap);
-    if (lds > ctx->index_lds_set) { // a driver call per epoch otherwise
-        CREC_HIP(ctx, hipFuncSetAttribute((const void *)bpr_index_batches, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)lds));
-        ctx->index_lds_set = lds;
-    }
-
     bool in_shadow = false; // tf1: which buffer set holds the current tables
     // Whatever way this function is left -- also through one of the error returns below -- the caller's buffers must hold
     // the newest tables: after an odd number of completed steps they live in the ctx's second buffer set
@@ -3499,13 +3525,41 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
         const LazyIndexOut o{wb.u_desc, wb.i_desc, wb.j_desc, wb.i_tmp, wb.j_tmp, wb.slot_pu, wb.order, wb.nslots};
         return crec_lazy_index_big(ctx, u + tb, i + tb, j + tb, nc, B, count, wb.bits_u, wb.bits_q, wb.spw, o, s, chunk);
     };
+    // dynamic LDS of the index kernel
+    const int cap = (2 * B + 63) / 64 * 64;
+    const size_t lds = big_index ? 0 : index_lds_bytes(cap);
+    if (lds > ctx->index_lds_set) { // a driver call per epoch otherwise
+        CREC_HIP(ctx, hipFuncSetAttribute((const void *)bpr_index_batches, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)lds));
+        ctx->index_lds_set = lds;
+    }
+    const auto build_lds = [&](const IndexWs &wb, int64_t first, int64_t count, hipStream_t s) -> int {
+        const int64_t tb = first * B, nc = (N - tb) < count * B ? (N - tb) : count * B;
+        if (lazy_win) // (the presence filters are OR-ed into)
+            CREC_HIP(ctx, hipMemsetAsync(wb.wfilt, 0, sizeof(uint32_t) * (size_t)count * 2 * WF_WORDS, s));
+        crec_prof_begin(ctx, CREC_K_INDEX, s);
+        // tf1, a call of few batches: two workgroups per (batch, side) share the phases behind the sort -- as long as all of them
+        // find a CU of their own at once it is the latency of one workgroup that the steps wait for (a 20-batch call: 524 ->
+        // 536-553 M triples/s); an epoch's 455 batches fill the chip anyway, and the second sort is then just more work (810 -> 785 M)
+        const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+        const int idx_parts = dense && !ctx->knob_idx_one_wg && 4 * count <= cus ? 2 : 1;
+        CREC_KLAUNCH(ctx, bpr_index_batches, dim3((unsigned)(2 * idx_parts * count)), dim3(PREP_THREADS), lds, s, u + tb, i + tb,
+                           j + tb, nc, B, cap, wb, idx_parts);
+        crec_prof_end(ctx, s);
+        if (lazy_win)
+            hipLaunchKernelGGL(lazy_window_deps, dim3((unsigned)crec_ceil_div(B, 256), (unsigned)count), dim3(256), 0, s, wb, lazy_win);
+        return CREC_OK;
+    };
+    const auto build_any = [&](const IndexWs &wb, int64_t first, int64_t count, hipStream_t s) -> int {
+        return big_index ? build_big(wb, first, count, s) : build_lds(wb, first, count, s);
+    };
     size_t ci = 0;
     for (int64_t b0 = 0, nbc = 0; b0 < nb; b0 += nbc, ++ci) {
         const crec_range chunk_range("crec_bpr chunk of batches");
         nbc = chunk_sizes[ci];
         const int64_t t0 = b0 * B, n_chunk = (N - t0) < nbc * B ? (N - t0) : nbc * B;
         void *const ws_of[2] = {ctx->idx_ws.ptr, piped ? ctx->idx_ws2.ptr : ctx->idx_ws.ptr};
-        IndexWs w = layout(ws_of[ci & 1], nbc, lazy_spw(t->d));
+        IndexWs w = layout(ws_of[ci & 1], nbc, lazy_spw(t->d, B));
         const size_t nw_off = (size_t)(w.nwide - w.hn), n_back = dense ? nw_off + (size_t)nbc * 2 : 0;
         if (n_back + 64 > ctx->pinned_ints) {
             if (ctx->pinned)
@@ -3541,41 +3595,28 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
         w.done = ctx->idx_done;
         w.seq = zero_copy ? ++ctx->idx_seq : 0;
         w.n_back = (int32_t)n_back;
-        if (big_index && !piped) {
-            if (int rc = build_big(w, b0, nbc, st))
+        if (!piped) {
+            if (int rc = build_any(w, b0, nbc, st))
                 return rc;
-        } else if (big_index) {
+        } else {
             hipStream_t side = ctx->idx_stream;
             if (ci == 0) { // the side stream starts behind whatever the caller's stream holds (the triples' producer, an earlier epoch's steps)
                 CREC_HIP(ctx, hipEventRecord(ctx->idx_ev[4], st));
                 CREC_HIP(ctx, hipStreamWaitEvent(side, ctx->idx_ev[4], 0));
-                if (int rc = build_big(w, b0, nbc, side))
+                if (int rc = build_any(w, b0, nbc, side))
                     return rc;
                 CREC_HIP(ctx, hipEventRecord(ctx->idx_ev[0], side));
             }
             if (ci + 1 < chunk_sizes.size()) { // the next chunk's index, beside this chunk's steps, into the other buffer
-                const IndexWs wn = layout(ws_of[(ci + 1) & 1], chunk_sizes[ci + 1], lazy_spw(t->d));
+                IndexWs wn = layout(ws_of[(ci + 1) & 1], chunk_sizes[ci + 1], lazy_spw(t->d, B));
+                wn.done = ctx->idx_done; // (no counts go back to the host on these paths)
                 if (ci >= 1) // (that buffer was read by the steps of chunk ci - 1)
                     CREC_HIP(ctx, hipStreamWaitEvent(side, ctx->idx_ev[2 + ((ci + 1) & 1)], 0));
-                if (int rc = build_big(wn, b0 + nbc, chunk_sizes[ci + 1], side))
+                if (int rc = build_any(wn, b0 + nbc, chunk_sizes[ci + 1], side))
                     return rc;
                 CREC_HIP(ctx, hipEventRecord(ctx->idx_ev[(ci + 1) & 1], side));
             }
             CREC_HIP(ctx, hipStreamWaitEvent(st, ctx->idx_ev[ci & 1], 0));
-        } else {
-            if (lazy_win) // (the presence filters are OR-ed into)
-                CREC_HIP(ctx, hipMemsetAsync(w.wfilt, 0, sizeof(uint32_t) * (size_t)nbc * 2 * WF_WORDS, st));
-            crec_prof_begin(ctx, CREC_K_INDEX, st);
-            // tf1, a call of few batches: two workgroups per (batch, side) share the phases behind the sort -- as long as all of them
-            // find a CU of their own at once it is the latency of one workgroup that the steps wait for (a 20-batch call: 524 ->
-            // 536-553 M triples/s); an epoch's 455 batches fill the chip anyway, and the second sort is then just more work (810 -> 785 M)
-            const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
-            const int idx_parts = dense && !ctx->knob_idx_one_wg && 4 * nbc <= cus ? 2 : 1;
-            CREC_KLAUNCH(ctx, bpr_index_batches, dim3((unsigned)(2 * idx_parts * nbc)), dim3(PREP_THREADS), lds, st, u + t0, i + t0,
-                               j + t0, n_chunk, B, cap, w, idx_parts);
-            crec_prof_end(ctx, st);
-            if (lazy_win)
-                hipLaunchKernelGGL(lazy_window_deps, dim3((unsigned)crec_ceil_div(B, 256), (unsigned)nbc), dim3(256), 0, st, w, lazy_win);
         }
         // tf1 mode: the chunk's counts of heavy-row chunks and wide groups size the launches.  They arrive in page-locked
         // memory written by the kernel itself (above); the host polls the flag -- a device-to-host copy plus a stream

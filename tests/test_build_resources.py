@@ -38,14 +38,15 @@ def _resources(src, extra=()):
 def test_bpr_kernels_register_budget():
     res = _resources("bpr_train.hip", ("-ffp-contract=off",))
     fused = [v for k, v in res.items() if "bpr_step_fusedILi16ELb1" in k]
-    lazy = [v for k, v in res.items() if "bpr_triples_lazyILi32ELb1" in k and "ELb1EEEv" not in k]
-    window = [v for k, v in res.items() if "bpr_triples_lazyILi32ELb1ELb0ELb1EEEv" in k]
-    assert fused and len(lazy) == 2 and len(window) == 1  # the plain and the deferred-Adam instantiation; the lazy_window one
+    # bpr_triples_lazy<32, FULL = true, DEFER, WIN, BIG>: d = 128; BIG = the 1024-thread geometry of batches >= 4096 triples
+    lazy = [v for k, v in res.items() if "bpr_triples_lazyILi32ELb1ELb0ELb0" in k or "bpr_triples_lazyILi32ELb1ELb1ELb0" in k]
+    window = [v for k, v in res.items() if "bpr_triples_lazyILi32ELb1ELb0ELb1" in k]
+    assert fused and len(lazy) == 4 and len(window) == 2  # plain / deferred Adam x two geometries; lazy_window x two geometries
     for v in fused:  # d = 64: four waves per SIMD (3 313 waves of a step at ml-1m shape fit the 4 096 slots at once)
         assert v["VGPRs"] <= 128 and v["ScratchSize"] == 0 and v["Occupancy"] >= 4, v
     for v in lazy:  # d = 128 lazy step (one launch): four waves per SIMD
         assert v["VGPRs"] <= 128 and v["ScratchSize"] == 0 and v["Occupancy"] >= 4, v
-    for v in window:  # sixteen partial rows in flight in a popular row's finisher (CREC_WIN_DEEP): three waves per SIMD, measured the faster
+    for v in window:  # twelve partial rows in flight in a popular row's finisher (CREC_WIN_DEEP): no spills in the 1024-thread geometry
         assert v["VGPRs"] <= 144 and v["ScratchSize"] == 0 and v["Occupancy"] >= 3, v
 
 
