@@ -176,6 +176,7 @@ struct IndexWs {
     // unique rows, their segment starts and a presence filter -- what lazy_window_deps needs to find, for every row a triple
     // reads, the last EARLIER batch of the window that touches it -- and its result per processing slot
     int32_t win;                    // 0: off
+    int32_t ids16;                  // 1: the batch's three id streams are kept in LDS as 16-bit ids (after the sort's counters): the records come from there
     int32_t *wn;                    // [nbc][2] unique rows of the side
     int32_t *wrow_u, *wst_u;        // [nbc][B]   row / segment start by rank
     int32_t *wrow_q, *wst_q;        // [nbc][2B]
@@ -338,10 +339,10 @@ IndexWs layout_index(void *base, int64_t nbc, int64_t B, int64_t U, int64_t I, b
 // user side, i-slices then j-slices on the item side, so that a row's occurrences come out in batch order, i before j.
 // LDS: rows u32[cap], tag u16[cap], seg u16[cap+64], digit counters, scan scratch (cap = 2B rounded up to 64).
 // ------------------------------------------------------------------------------------
-inline size_t index_lds_bytes(int cap)
+inline size_t index_lds_bytes(int cap, int64_t ids16_B = 0)
 {
     return sizeof(uint32_t) * cap + sizeof(uint16_t) * (2 * (size_t)cap + 64) +
-           sizeof(int) * (crec_sort::hist_ints<PREP_THREADS>() + crec_sort::scan_ints<PREP_THREADS>());
+           sizeof(int) * (crec_sort::hist_ints<PREP_THREADS>() + crec_sort::scan_ints<PREP_THREADS>()) + sizeof(uint16_t) * 3 * (size_t)ids16_B;
 }
 
 __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t *__restrict__ u,
@@ -354,6 +355,7 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
     uint16_t *seg = tag + cap; // [cap + 64] run starts by rank, closed by n
     int *hist = (int *)(seg + cap + 64);
     int *scan = hist + crec_sort::hist_ints<PREP_THREADS>();
+    uint16_t *ids = (uint16_t *)(scan + crec_sort::scan_ints<PREP_THREADS>()); // [3][B] when w.ids16
     const int pair = wg_parts == 2 ? (int)(blockIdx.x >> 1) : (int)blockIdx.x, part = wg_parts == 2 ? (int)(blockIdx.x & 1) : -1;
     const int batch = pair >> 1, side = pair & 1;
     const bool do_lists = part != 1, do_records = part != 0; // (wg_parts == 1: one workgroup does both)
@@ -362,6 +364,15 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
     const int nb = (int)((n_total - t0) < B ? (n_total - t0) : B); // triples in this batch
     const int n = side ? 2 * nb : nb;
     const int CH = w.CH;
+    // The occurrence records name all three ids of a slot's triple: 2 x 12 288 x 3 scattered loads from the streams took the item
+    // side's records workgroup 15.6 us of its 48 (one CU's address path); with catalogues below 65 536 rows the batch's streams are
+    // read once, coalesced, into LDS as 16-bit ids and the records are put together from there
+    if (w.ids16 && do_records)
+        for (int k = tid; k < nb; k += PREP_THREADS) {
+            ids[k] = (uint16_t)u[t0 + k];
+            ids[B + k] = (uint16_t)i[t0 + k];
+            ids[2 * B + k] = (uint16_t)j[t0 + k];
+        }
 
     const uint32_t fl_nwg = (uint32_t)(side ? w.flow_nwg_q : w.flow_nwg_u), fl_magic = side ? w.flow_magic_q : w.flow_magic_u,
                    fl_rpb = (uint32_t)(side ? w.flow_rpb_q : w.flow_rpb_u);
@@ -394,12 +405,12 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
             tag[k] = (uint16_t)k;
         }
     }
-#ifdef CREC_STAMPS // phase times of workgroups 0 (user side) and 1 (item side) of the launch: crec_stamps[16000*8 + ...]
+#ifdef CREC_STAMPS // phase times of workgroups 0 .. 3 of the launch (batch 0: user / item side, or with two workgroups per side: user lists, user records, item lists, item records): crec_stamps[16000*8 + ...]
 #define CREC_IDX_MARK(k)                                                           \
     do {                                                                           \
         __syncthreads();                                                           \
-        if (tid == 0 && blockIdx.x < 2)                                            \
-            crec_stamps[8 * (16000 + 2 * (k) + blockIdx.x)] = wall_clock64();      \
+        if (tid == 0 && blockIdx.x < 4)                                            \
+            crec_stamps[8 * (16000 + 4 * (k) + blockIdx.x)] = wall_clock64();      \
     } while (0)
 #else
 #define CREC_IDX_MARK(k)
@@ -671,6 +682,10 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
 #pragma unroll
         for (int e = 0; e < RIF; ++e) { // the sorted row is one of the three ids: two scattered loads per record, not three
             const int k = k0r + e * PREP_THREADS;
+            if (w.ids16) {
+                rec[e] = make_int4((int)ids[pos[e]], (int)ids[B + pos[e]], (int)ids[2 * B + pos[e]], (int)payload[e]);
+                continue;
+            }
             if (fl_row) { // (positions by table: the sorted key is no row id; all three ids come from the stream, independent loads)
                 rec[e] = make_int4(u[t0 + pos[e]], i[t0 + pos[e]], j[t0 + pos[e]], (int)payload[e]);
                 continue;
@@ -688,6 +703,7 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
             if (k0r + e * PREP_THREADS < n)
                 occ_out[k0r + e * PREP_THREADS] = rec[e];
     }
+    CREC_IDX_MARK(6);
     if (!do_lists)
         return;
     if (tid == 0) {
@@ -696,7 +712,6 @@ __global__ __launch_bounds__(PREP_THREADS) void bpr_index_batches(const int32_t 
         w.hn[batch * HN + side * 2 + 1] = hv_total & 0xffff;
         w.nwide[batch * 2 + side] = wide_total_n;
     }
-    CREC_IDX_MARK(6);
     if (w.host_counts && tid == 0) { // the chunk's counts straight into the host's hands (see IndexWs)
         // No fences (a device- or system-scope fence writes the L2 back: 10+ us at the end of a kernel that has just written
         // megabytes of records): system-scope stores travel by themselves, the wave waits for their completion, then draws
@@ -2788,6 +2803,23 @@ __global__ __launch_bounds__((LazyGeo<LPR, BIG>::THREADS)) void bpr_triples_lazy
         win_t(blockIdx.y, 1, false);
 }
 
+// the tables of the second buffer set back into the caller's (an odd number of tf1 launches): up to six copies in one launch
+// (rows are multiples of four floats, the buffers 16-byte aligned)
+struct CopyTables {
+    float4 *dst[6];
+    const float4 *src[6];
+    int64_t n4[6];
+};
+__global__ __launch_bounds__(256) void copy_tables(const CopyTables c)
+{
+    const int k = blockIdx.y;
+    float4 *__restrict__ dst = c.dst[k];
+    const float4 *__restrict__ src = c.src[k];
+    const int64_t n = c.n4[k];
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < n; o += (int64_t)gridDim.x * 256)
+        dst[o] = src[o];
+}
+
 // deferred mode: every row of a table brought up to the state after step h.step (before evaluation / a checkpoint);
 // a lane group per row
 __global__ __launch_bounds__(256) void bpr_adam_flush(float *__restrict__ var, float *__restrict__ m, float *__restrict__ v,
@@ -3503,15 +3535,21 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
             if (!*in_shadow)
                 return (int)hipSuccess;
             const Tables &s = a->cur;
-            int e = (int)hipMemcpyAsync(t->P, s.P, bytesP, hipMemcpyDeviceToDevice, st);
-            e |= (int)hipMemcpyAsync(t->mP, s.mP, bytesP, hipMemcpyDeviceToDevice, st);
-            e |= (int)hipMemcpyAsync(t->vP, s.vP, bytesP, hipMemcpyDeviceToDevice, st);
-            if (s.Q != t->Q) {
-                e |= (int)hipMemcpyAsync(t->Q, s.Q, bytesQ, hipMemcpyDeviceToDevice, st);
-                e |= (int)hipMemcpyAsync(t->mQ, s.mQ, bytesQ, hipMemcpyDeviceToDevice, st);
-                e |= (int)hipMemcpyAsync(t->vQ, s.vQ, bytesQ, hipMemcpyDeviceToDevice, st);
+            // ONE launch for the six tables: six device copies of 1.5 / 0.9 MB each took 4.9 us apiece behind a 20-batch call
+            // (29 of its 177 us)
+            CopyTables c{};
+            const bool q_too = s.Q != t->Q;
+            float *const dst[6] = {t->P, t->mP, t->vP, t->Q, t->mQ, t->vQ};
+            const float *const src[6] = {s.P, s.mP, s.vP, s.Q, s.mQ, s.vQ};
+            int64_t most = 0;
+            for (int k = 0; k < (q_too ? 6 : 3); ++k) {
+                c.dst[k] = reinterpret_cast<float4 *>(dst[k]), c.src[k] = reinterpret_cast<const float4 *>(src[k]);
+                c.n4[k] = (int64_t)((k < 3 ? bytesP : bytesQ) / sizeof(float4));
+                most = c.n4[k] > most ? c.n4[k] : most;
             }
-            return e;
+            const unsigned bx = (unsigned)(crec_ceil_div(most, 256) < 256 ? crec_ceil_div(most, 256) : 256);
+            hipLaunchKernelGGL(copy_tables, dim3(bx ? bx : 1, q_too ? 6u : 3u), dim3(256), 0, st, c);
+            return (int)hipGetLastError();
         }
         bool done = false;
         ~BringHome()
@@ -3527,7 +3565,9 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
     };
     // dynamic LDS of the index kernel
     const int cap = (2 * B + 63) / 64 * 64;
-    const size_t lds = big_index ? 0 : index_lds_bytes(cap);
+    // (tf1: the ids in LDS where the catalogues fit 16 bits and the workgroup's LDS the three streams: B <= 6 144)
+    const bool ids16 = dense && !big_index && t->U < 65536 && t->I < 65536 && index_lds_bytes(cap, B) <= (size_t)160 * 1024 && !ctx->knob_idx_no_ids16;
+    const size_t lds = big_index ? 0 : index_lds_bytes(cap, ids16 ? B : 0);
     if (lds > ctx->index_lds_set) { // a driver call per epoch otherwise
         CREC_HIP(ctx, hipFuncSetAttribute((const void *)bpr_index_batches, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)lds));
@@ -3543,8 +3583,10 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
         // 536-553 M triples/s); an epoch's 455 batches fill the chip anyway, and the second sort is then just more work (810 -> 785 M)
         const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
         const int idx_parts = dense && !ctx->knob_idx_one_wg && 4 * count <= cus ? 2 : 1;
+        IndexWs wk = wb;
+        wk.ids16 = ids16 ? 1 : 0;
         CREC_KLAUNCH(ctx, bpr_index_batches, dim3((unsigned)(2 * idx_parts * count)), dim3(PREP_THREADS), lds, s, u + tb, i + tb,
-                           j + tb, nc, B, cap, wb, idx_parts);
+                           j + tb, nc, B, cap, wk, idx_parts);
         crec_prof_end(ctx, s);
         if (lazy_win)
             hipLaunchKernelGGL(lazy_window_deps, dim3((unsigned)crec_ceil_div(B, 256), (unsigned)count), dim3(256), 0, s, wb, lazy_win);

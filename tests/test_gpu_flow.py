@@ -135,3 +135,17 @@ def test_tables_too_tall_for_resident_waves_take_the_launch_per_step_path(sess):
     finally:
         sess.ctx.profile(False)
     assert prof["bpr_steps_flow"][1] == 0 and prof["bpr_step_fused"][1] >= 4  # (the chunk's first step is launched beside the index kernel: not counted)
+
+
+@pytest.mark.parametrize("flow", [1, 0])
+@pytest.mark.parametrize("U,I,d,B,nb", [(6040, 3706, 64, 6144, 20), (943, 1349, 32, 4096, 90), (300, 200, 16, 1000, 7)])
+def test_records_from_lds_ids_are_the_gathered_records(sess, flow, U, I, d, B, nb):
+    """tf1 index: with both catalogues below 65 536 rows a batch's three id streams are kept in LDS as 16-bit ids and the occurrence
+    records are put together from there (option idx_no_ids16 = 1: gathered from the streams as before).  Same records, so the same
+    bits -- for the dataflow launch and the launch per step, few batches per call (two workgroups per side) and many."""
+    u, i, j = _stream(3 * U + B, U, I, nb * B + 17)
+    P0, Q0 = _tables(U, U, I, d)
+    ref, _ = _run(sess, {"flow": flow, "idx_no_ids16": 1}, P0, Q0, u, i, j, B)
+    got, _ = _run(sess, {"flow": flow}, P0, Q0, u, i, j, B)
+    for x, y, name in zip(ref, got, ("loss", "P", "Q", "mP", "mQ", "vP", "vQ")):
+        assert np.array_equal(x, y), name

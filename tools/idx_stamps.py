@@ -22,7 +22,7 @@ du, di, dj = sess.to_dev(u), sess.to_dev(i), sess.to_dev(j)
 st = runtime.BprState(sess, P0, Q0, lr=1e-3, reg=0.01, adam_mode="tf1")
 n = K * B
 names = ["load", "sort", "run starts", "heavy rows", "wide groups", "rowseg + ranks", "records"]
-acc = np.zeros((2, 6))
+acc = np.zeros((4, 6))
 reps = 50
 for r in range(reps + 10):
     st.train_epoch(du[:n], di[:n], dj[:n], B)
@@ -31,7 +31,8 @@ for r in range(reps + 10):
         continue
     buf = (ctypes.c_ulonglong * (8 * 16384))()
     assert sess.lib.crec_debug_stamps(buf, ctypes.c_size_t(8 * 16384)) == 0
-    a = np.frombuffer(buf, dtype=np.uint64).reshape(16384, 8)[16000:16014, 0].astype(np.int64).reshape(7, 2)
+    a = np.frombuffer(buf, dtype=np.uint64).reshape(16384, 8)[16000:16028, 0].astype(np.int64).reshape(7, 4)
     acc += np.diff(a, axis=0).T / 100.0
-for side, nm in enumerate(("user side", "item side")):
-    print(nm, " ".join("%s %.2f" % (names[k + 1], acc[side, k] / reps) for k in range(6)), "| total %.2f us" % (acc[side].sum() / reps))
+# (a 20-batch call has two workgroups per (batch, side): the lists' and the records')
+for wg, nm in enumerate(("user side, lists  ", "user side, records", "item side, lists  ", "item side, records")):
+    print(nm, " ".join("%s %.2f" % (names[k + 1], acc[wg, k] / reps) for k in range(6)), "| total %.2f us" % (acc[wg].sum() / reps))
