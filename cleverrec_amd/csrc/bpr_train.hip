@@ -3251,8 +3251,8 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
     CREC_REQUIRE(ctx, t->U >= 1 && t->I >= 1 && t->U < ((int64_t)1 << 31) && t->I < ((int64_t)1 << 31), "table rows");
     CREC_REQUIRE(ctx, B >= 1 && B <= LAZY_MAX_B, "batch_size %d: batches of 1..%d triples", B, LAZY_MAX_B);
     CREC_REQUIRE(ctx, B <= MAX_B || opt->adam_mode != CREC_ADAM_TF1,
-                 "batch_size %d with adam_mode tf1: the swept step indexes batches of at most %d in LDS; larger batches run as adam_mode deferred "
-                 "(the same results with sparse traffic), lazy, SGD or Adagrad", B, MAX_B);
+                 "batch_size %d with adam_mode tf1 and beta1 > 0.9: batches beyond %d run as deferred Adam, which replays idle steps exactly only for "
+                 "beta1 <= 0.9 (or the data-parallel step: batches of at most %d); use lazy, SGD or Adagrad", B, MAX_B, MAX_B);
     CREC_REQUIRE(ctx, opt->adam_mode == CREC_ADAM_TF1 || opt->adam_mode == CREC_ADAM_LAZY || opt->adam_mode == CREC_OPT_SGD ||
                           opt->adam_mode == CREC_OPT_ADAGRAD || opt->adam_mode == CREC_ADAM_DEFERRED, "adam_mode");
     CREC_REQUIRE(ctx, (opt->adam_mode == CREC_ADAM_DEFERRED) == (df != nullptr),
@@ -4305,6 +4305,27 @@ extern "C" {
 int crec_bpr_train_epoch(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, const int32_t *u, const int32_t *i,
                          const int32_t *j, int64_t N, int32_t B, float *loss_per_batch, void *stream)
 {
+    // tf1 beyond the in-LDS index (model/Recommender.py:17 takes any batch_size): the call runs as deferred Adam -- every row current
+    // at the call's first step, the touched rows replaying the steps they sat out -- and ends with the flush, so the caller's tables
+    // are TF1's after every call, as they are after every sess.run (one whole-table sweep per call instead of one per step)
+    if (ctx && t && opt && opt->adam_mode == CREC_ADAM_TF1 && B > MAX_B && B <= LAZY_MAX_B && opt->beta1 <= 0.9000001f && N > 0 && t->U > 0 &&
+        t->I > 0 && ctx->device >= 0) {
+        CREC_HIP(ctx, hipSetDevice(ctx->device));
+        hipStream_t st = (hipStream_t)stream;
+        if (int rc = crec_reserve(ctx, &ctx->tf1_last, sizeof(int32_t) * ((size_t)t->U + (size_t)t->I)))
+            return rc;
+        crec_bpr_deferred df{(int32_t *)ctx->tf1_last.ptr, (int32_t *)ctx->tf1_last.ptr + t->U};
+        CREC_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)ctx->tf1_last.ptr, (int)opt->step, (size_t)t->U + (size_t)t->I, st));
+        crec_adam o2 = *opt;
+        o2.adam_mode = CREC_ADAM_DEFERRED;
+        if (int rc = train_epoch_impl(ctx, t, &o2, u, i, j, N, B, loss_per_batch, stream, false, &df))
+            return rc;
+        if (int rc = crec_bpr_adam_flush(ctx, t, &df, &o2, stream))
+            return rc;
+        o2.adam_mode = opt->adam_mode;
+        *opt = o2;
+        return CREC_OK;
+    }
     return train_epoch_impl(ctx, t, opt, u, i, j, N, B, loss_per_batch, stream, false);
 }
 

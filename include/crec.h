@@ -218,9 +218,10 @@ typedef struct {
  *   u, i, j        [dev] int32 [N]
  *   loss_per_batch [dev] float [ceil(N/B)]: loss_b = sum softplus(-x) + reg*(l2 terms)
  * train_model's return value is mean(loss_per_batch) (:61).
- * B: the reference takes any batch_size (model/Recommender.py:17).  adam_mode tf1: B <= 8192 (a batch's slots are sorted in LDS);
- * lazy / deferred / SGD / Adagrad: B <= 524288 -- beyond 8192 the batch's index (the unique + segment-sum bookkeeping) is built in
- * global memory, the same index bit for bit (csrc/index_big.hip).  tf1 beyond 8192: run it as deferred, the same results. */
+ * B: the reference takes any batch_size (model/Recommender.py:17): 1 .. 524288 here.  Beyond 8192 the batch's index (the unique +
+ * segment-sum bookkeeping) is built in global memory, the same index bit for bit (csrc/index_big.hip); adam_mode tf1 then runs the call
+ * as deferred Adam with the flush at its end -- TF1's tables after every call, one whole-table sweep per call instead of one per step
+ * (beta1 <= 0.9; refused above that, as crec_bpr_train_epoch_deferred is). */
 int crec_bpr_train_epoch(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, const int32_t *u, const int32_t *i,
                          const int32_t *j, int64_t N, int32_t B, float *loss_per_batch, void *stream);
 

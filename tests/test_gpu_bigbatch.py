@@ -171,12 +171,41 @@ def test_runs_beyond_sixteen_bits(sess):
         np.testing.assert_allclose(getattr(st, name).cpu().numpy(), want, rtol=0, atol=2e-6, err_msg=name)
 
 
-def test_tf1_sweep_refuses_a_large_batch_and_names_the_way_out(sess):
+def test_tf1_beyond_8192_is_tf1(sess):
+    """model/Recommender.py:17 takes any batch_size.  adam_mode tf1 with batches beyond the in-LDS index runs each call as deferred
+    Adam and ends it with the flush (crec_bpr_train_epoch): the tables after a call are TF1's -- against the oracle's TF1 sweep at the
+    suite's bounds, and bit for bit what the explicit deferred calls + flush give; two consecutive calls (the second starts from
+    rows that are all current, whatever the first left)."""
+    U, I, d, B = 900, 700, 16, 9000
+    u, i, j = _stream(1, 5 * B + 123, U, I, zipf=1.3)
+    g = np.random.Generator(np.random.PCG64(3))
+    P0, Q0 = (g.standard_normal((U, d)) * 0.01).astype(np.float32), (g.standard_normal((I, d)) * 0.01).astype(np.float32)
+    cut = 2 * B
+    du, di, dj = sess.to_dev(u), sess.to_dev(i), sess.to_dev(j)
+    out = {}
+    for mode in ("tf1", "deferred"):
+        st = runtime.BprState(sess, P0, Q0, lr=1e-3, reg=0.01, adam_mode=mode)
+        loss = [st.train_epoch(du[:cut], di[:cut], dj[:cut], B).cpu().numpy()]
+        st.flush()
+        loss.append(st.train_epoch(du[cut:], di[cut:], dj[cut:], B).cpu().numpy())
+        st.flush()
+        out[mode] = [np.concatenate(loss)] + [getattr(st, k).cpu().numpy() for k in ("P", "Q", "mP", "mQ", "vP", "vQ")]
+        assert st.adam.step == 6
+    for x, y, name in zip(out["tf1"], out["deferred"], ("loss", "P", "Q", "mP", "mQ", "vP", "vQ")):
+        assert np.array_equal(x, y), name
+    om, ol = _oracle_steps(P0, Q0, u, i, j, B, 1e-3, 0.01, 0)
+    np.testing.assert_allclose(out["tf1"][0], ol, rtol=1e-5)
+    for dev, name in zip(out["tf1"][1:5], ("P", "Q", "mP", "mQ")):
+        np.testing.assert_allclose(dev, getattr(om, name), rtol=0, atol=2e-6, err_msg=name)
+
+
+def test_tf1_beyond_8192_with_a_slow_beta1_is_refused(sess):
+    """(deferred Adam replays idle steps exactly only for beta1 <= 0.9: the refusal names the modes that do run)"""
     U, I, d, B = 100, 80, 16, 9000
     u, i, j = _stream(1, B, U, I)
     P0, Q0 = np.zeros((U, d), np.float32), np.zeros((I, d), np.float32)
-    st = runtime.BprState(sess, P0, Q0, lr=1e-3, reg=0.01, adam_mode="tf1")
-    with pytest.raises(Exception, match="deferred"):
+    st = runtime.BprState(sess, P0, Q0, lr=1e-3, reg=0.01, adam_mode="tf1", beta1=0.95)
+    with pytest.raises(Exception, match="beta1"):
         st.train_epoch(sess.to_dev(u), sess.to_dev(i), sess.to_dev(j), B)
 
 
