@@ -611,9 +611,15 @@ def main():
                     return int((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024) if {"FETCH_SIZE", "WRITE_SIZE"} <= set(vals) else None
 
                 def lazy_roofline(k, traffic):
+                    # (option lazy_window: a launch holds batches_per_launch batches; bytes, traffic and time are per batch here, and
+                    # frac_hbm_side prices what the counters saw instead of the algorithmic count)
+                    bpl = k.get("batches_per_launch", 1.0)
+                    per_batch = None if traffic is None else int(traffic / bpl)
                     return {"bound": "hbm", "kernel": "bpr_triples_lazy", "achieved": k["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": k["frac_of_8TBs"], "traffic": traffic, "algorithmic_bytes_per_launch": k["algorithmic_bytes"],
-                            "avg_launch_us": k["avg_us"]}
+                            "frac": k["frac_of_8TBs"], "traffic": per_batch, "algorithmic_bytes_per_launch": k["algorithmic_bytes"] * bpl,
+                            "algorithmic_bytes_per_batch": k["algorithmic_bytes"], "batches_per_launch": bpl,
+                            "avg_launch_us": k["avg_us"] * bpl, "avg_us_per_batch": k["avg_us"],
+                            "frac_hbm_side": None if per_batch is None else per_batch / (k["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS}
                 out["synthetic_big"]["roofline"] = lazy_roofline(out["synthetic_big"]["bpr_triples_lazy"], lazy_traffic("big_pmc_summary.txt"))
                 out["synthetic_big"]["larger_batches"]["65536"]["roofline"] = lazy_roofline(
                     out["synthetic_big"]["larger_batches"]["65536"]["bpr_triples_lazy"], lazy_traffic("bigbatch_pmc_summary.txt"))
