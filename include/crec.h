@@ -90,6 +90,8 @@ const char *crec_last_error(const crec_ctx *ctx);
  *                    0 = a launch per batch).  -1 (default; env CREC_LAZY_WINDOW): 8 where both tables hold >= 16 batches' worth of
  *                    rows and d >= 64 (S-big: 18.3 -> 15.6 us/step, uniform positives 20.8 -> 14.7), else 0 (small catalogues, where
  *                    every row recurs from batch to batch and the launch is bound by the rows' way through it: ml-1m +16 %)
+ *   "idx_no_ids16"   1: the tf1 index gathers its occurrence records' ids from the streams instead of from the 16-bit copies it keeps in LDS
+ *                    where both catalogues are below 65 536 rows (the same records)
  *   "flow_abl"       timing ablations of bpr_steps_flow / the window (results are WRONG; tools/ only)
  *   "big_index"      1: the lazy-family steps index their batches through the global-memory sort (index_big.hip, the form batches of
  *                    more than 8192 triples always take) even where the in-LDS sort would do: same index, bit for bit

@@ -18,7 +18,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 print("rocprofv3 --kernel-trace --stats -- python bench.py --steps 1820 --warmup 455 --no-extras")
 print("%-60s %8s %14s %12s %8s" % ("kernel", "calls", "total_ns", "avg_ns", "pct"))
 for r in rows:
-    m = re.search(r"(bpr_\w+|eval_\w+|rank_metrics\w*|shard_\w+|ncf_\w+|fm_\w+|cml_\w+|rows_\w+|apply_all|small_adam\w*|topk_\w+|lrml_\w+|tcf_\w+|sbpr_\w+|cune_\w+|sort_\w+|big_\w+|plan_\w+|own_\w+|flat_heads|peer_\w+)(<[^>]*>)?", r["Name"])
+    m = re.search(r"(bpr_\w+|lazy_\w+|copy_tables|eval_\w+|rank_metrics\w*|shard_\w+|ncf_\w+|fm_\w+|cml_\w+|rows_\w+|apply_all|small_adam\w*|topk_\w+|lrml_\w+|tcf_\w+|sbpr_\w+|cune_\w+|sort_\w+|big_\w+|plan_\w+|own_\w+|flat_heads|peer_\w+)(<[^>]*>)?", r["Name"])
     name = (m.group(0) if m else r["Name"].split("(")[0])[:60]
     print("%-60s %8s %14s %12.1f %8s" % (name, r["Calls"], r["TotalDurationNs"], float(r["AverageNs"]), r["Percentage"]))
 PY
@@ -39,7 +39,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 print("rocprofv3 --kernel-trace --stats -- python " + sys.argv[2])
 print("%-60s %8s %14s %12s %8s" % ("kernel", "calls", "total_ns", "avg_ns", "pct"))
 for r in rows[:26]:
-    m = re.search(r"(bpr_\w+|eval_\w+|rank_metrics\w*|shard_\w+|ncf_\w+|fm_\w+|cml_\w+|rows_\w+|apply_all|small_adam\w*|topk_\w+|lrml_\w+|tcf_\w+|sbpr_\w+|cune_\w+|sort_\w+|big_\w+|plan_\w+|own_\w+|flat_heads|peer_\w+)(<[^>]*>)?", r["Name"])
+    m = re.search(r"(bpr_\w+|lazy_\w+|copy_tables|eval_\w+|rank_metrics\w*|shard_\w+|ncf_\w+|fm_\w+|cml_\w+|rows_\w+|apply_all|small_adam\w*|topk_\w+|lrml_\w+|tcf_\w+|sbpr_\w+|cune_\w+|sort_\w+|big_\w+|plan_\w+|own_\w+|flat_heads|peer_\w+)(<[^>]*>)?", r["Name"])
     name = (m.group(0) if m else r["Name"].split("(")[0])[:60]
     print("%-60s %8s %14s %12.1f %8s" % (name, r["Calls"], r["TotalDurationNs"], float(r["AverageNs"]), r["Percentage"]))
 PY
