@@ -2231,13 +2231,27 @@ __global__ __launch_bounds__(256) void lazy_window_deps(IndexWs w, int W)
     const uint32_t rows[3] = {(uint32_t)pu.y, (uint32_t)w.i_desc[(int64_t)b * B + slot].x & 0x7fffffffu,
                               (uint32_t)w.j_desc[(int64_t)b * B + slot].x & 0x7fffffffu};
     int dep[3] = {-1, -1, -1};
+    // the filters of all earlier batches of the window are probed at once (b and w0 are the workgroup's: the same trip count for every
+    // lane), nearest batch first in the mask; only a set bit costs a binary search (one in eleven of them a false alarm)
+    uint32_t hs[3], may[3] = {0u, 0u, 0u};
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+        hs[r] = wf_hash(rows[r]);
+    for (int bp = b - 1, k = 0; bp >= w0; --bp, ++k) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const uint32_t word = w.wfilt[((int64_t)bp * 2 + (r ? 1 : 0)) * WF_WORDS + (hs[r] >> 5)];
+            may[r] |= ((word >> (hs[r] & 31u)) & 1u) << k;
+        }
+    }
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         const int side = r ? 1 : 0;
-        const uint32_t row = rows[r], hs = wf_hash(row);
-        for (int bp = b - 1; bp >= w0 && dep[r] < 0; --bp) { // the nearest earlier batch of the window that names the row
-            if (!((w.wfilt[((int64_t)bp * 2 + side) * WF_WORDS + (hs >> 5)] >> (hs & 31u)) & 1u))
-                continue;
+        const uint32_t row = rows[r];
+        while (may[r] != 0u && dep[r] < 0) { // the nearest earlier batch of the window that names the row
+            const int k = __builtin_ctz(may[r]);
+            may[r] &= may[r] - 1u;
+            const int bp = b - 1 - k;
             const int32_t *wr = side ? w.wrow_q + (int64_t)bp * 2 * B : w.wrow_u + (int64_t)bp * B;
             int lo = 0, hi = w.wn[bp * 2 + side];
             while (lo < hi) {
