@@ -65,10 +65,10 @@ def test_window_equals_a_launch_per_batch_bit_for_bit(sess, U, I, d, B, nb, zipf
 
 
 def test_window_is_the_default_where_the_tables_dwarf_the_batch(sess):
-    """lazy_window = -1 (the default): 8 batches per launch where both tables hold >= 16 batches' worth of rows and d >= 64 -- seen in
+    """lazy_window = -1 (the default): 8 batches per launch where both tables hold >= 3 batches' worth of rows and d >= 32 -- seen in
     the launch brackets' unit counts -- and a launch per batch elsewhere; the same bits either way."""
-    for (U, I, d, B, nb), windows in (((200_000, 20_000, 64, 1024, 21), True), ((200_000, 20_000, 64, 2048, 9), False),
-                                      ((200_000, 20_000, 32, 1024, 9), False)):
+    for (U, I, d, B, nb), windows in (((200_000, 20_000, 64, 1024, 21), True), ((200_000, 5_000, 64, 2048, 9), False),
+                                      ((200_000, 20_000, 16, 1024, 9), False), ((200_000, 20_000, 32, 6144, 5), True)):
         u, i, j = _stream(5, U, I, nb * B + 77, 1.1)
         ref = _run(sess, 0, "lazy", U, I, d, B, u, i, j)
         sess.ctx.profile(True)
