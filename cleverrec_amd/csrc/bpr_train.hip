@@ -242,18 +242,24 @@ inline int row_bits(int64_t n_rows)
 #ifndef CREC_LAZY_SPW
 #define CREC_LAZY_SPW 16 // slots per workgroup at 4 < d <= 128: S-big kernel 19.5 / 17.7 / 18.6 us at 8 / 16 / 32 (tools/lazy_variants.sh)
 #endif
-// Batches of 4096 triples and more: 32 where the lane group is 8 .. 32 lanes (workgroups of up to 1024 threads) -- a popular item's
+// Batches of 4096 .. 8192 triples: 32 where the lane group is 8 .. 32 lanes (workgroups of up to 1024 threads) -- a popular item's
 // positive slots then make half as many pieces, and its finisher sums them in one round of loads less: under lazy_window, where that
 // finisher is on the path from batch to batch, S-big 13.0 -> 12.5 us per batch, ml-1m's catalogue at d = 128 20.9 -> 17.0 us per
 // step; a launch per batch is as fast or faster so from 4096 triples (ml-1m d = 64: 14.1 -> 13.4), slower below (B = 2048: 11.9 ->
 // 15.2).  The geometry depends on (d, B) only, never on the window: the pieces are part of the order the sums are formed in.
+#ifndef CREC_LAZY_BIG_B
+#define CREC_LAZY_BIG_B 4096
+#endif
+#ifndef CREC_LAZY_BIG_B_MAX
+#define CREC_LAZY_BIG_B_MAX 8192 // (beyond the LDS-indexed batches the 512-thread geometry is the faster one: 58.0 against 63.5 us at 32 768, 108.3 / 111.7 at 65 536; tools/spw_bigbatch.sh)
+#endif
 inline int lazy_spw(int d, int64_t B = 0)
 {
     if (d <= 4)
         return 64;
     if (d > 128)
         return 16;
-    return (B >= 4096 && d > 16) ? 32 : (d > 64 && CREC_LAZY_SPW > 32 ? 32 : CREC_LAZY_SPW);
+    return (B >= CREC_LAZY_BIG_B && B <= CREC_LAZY_BIG_B_MAX && d > 16) ? 32 : (d > 64 && CREC_LAZY_SPW > 32 ? 32 : CREC_LAZY_SPW);
 }
 
 IndexWs layout_index(void *base, int64_t nbc, int64_t B, int64_t U, int64_t I, bool dense, int CH, int wide_rows = 0,
