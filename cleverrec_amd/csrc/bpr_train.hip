@@ -140,8 +140,8 @@ __device__ __forceinline__ void crec_mark(int slot, int dep) // the time at whic
                          // (tools/lazy_variants.sh)
 #endif
 #ifndef CREC_WIN_DEEP
-#define CREC_WIN_DEEP 12 // the same in a lazy_window launch, where a popular row's finisher is on the path from batch to batch (its
-                         // workgroups are up to 1024 threads: 12 fit the 128 VGPRs that leaves, 14 spill)
+#define CREC_WIN_DEEP 10 // the same in a lazy_window launch, for the front rows that keep their tickets (negative slots too); twelve spill in the
+                         // 1024-thread geometry now that lazy_poll_front sits beside it
 #endif
 #ifndef CREC_FUSED_WT
 #define CREC_FUSED_WT 0 // 1: the launch-per-step tf1 kernel writes its tables with write-through (sc1) stores
@@ -2221,6 +2221,7 @@ struct LazyWin {
     int32_t *done;         // [LAZY_WIN_MAX][3 B] stamps by (batch in window, segment start; user side first, item side from B)
     int32_t stamp0;        // the stamp of the launch's first batch (a ctx-wide launch counter: never repeats)
     int32_t *err;          // give-up flag (page-locked)
+    float *wpart;          // [W][2 B][d] polled partials of front rows (see lazy_poll_front), all bits set where nothing waits; null: tickets only
     bool fit_p, fit_q;     // a user / item table lies within 4 GiB
     int abl;               // timing ablations (option flow_abl; WRONG results): 1 nobody waits for a predecessor
     float lr_t[LAZY_WIN_MAX];
@@ -2483,6 +2484,77 @@ __device__ __forceinline__ void lazy_role_tail(const Tables &t, int d, bool act,
     lazy_finish_row<LPR, USER, DEFER>(t, d, act, row, own, g, m, v, h, start);
 }
 
+// lazy_window, a front row without negative slots (every slot of the row is one of its pieces' positive slots): no tickets.  The
+// leaders of all pieces but the last leave their partial in `wpart` (at the piece's first sorted position; the buffer holds all bits
+// set wherever no partial waits) and go; the LAST piece's leader -- in the workgroup dispatched last among the row's -- asks for the
+// others' partials until none of them is the sentinel, adds them in piece order and its own at the end (the order lazy_sum_front adds
+// them in), finishes the row and hands the entries back as sentinels.  Two trips through the fabric fewer on the row's way from
+// batch to batch than publish -> acknowledgement -> ticket -> sum: the hottest row's chain is what bounds a window launch.
+// It waits only for workgroups dispatched before its own, which wait for nobody dispatched later.
+template <int LPR, bool DEFER>
+__device__ __forceinline__ void lazy_poll_front(const Tables &t, int d, bool act, int4 desc, float4 own_row, float4 own_sum, float *wpart,
+                                                int SPW, const Hyper &h, int32_t *err)
+{
+    constexpr int DEEP = 8; // (twelve spill in the 1024-thread geometry)
+    const int lane = threadIdx.x & 63, l = lane % LPR;
+    const int start = lazy_desc_start(desc), ci = lazy_desc_ci(desc), hmod = lazy_desc_hmod(desc);
+    const int room = SPW - hmod, len1 = ci < room ? ci : room, np = 1 + (ci - len1 + SPW - 1) / SPW, n = np - 1; // the others' partials
+    const auto at = [&](int e) { return e == 0 ? start : start + len1 + (e - 1) * SPW; };
+    const int row = desc.x & 0x7fffffff;
+    const int64_t ro = (int64_t)row * d + 4 * l;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool slots = act;
+    float4 m = zero, v = zero;
+    { // the row's slots: asked for now, in flight beside the wait for the partials
+        const bool wm = slots && h.opt != CREC_OPT_SGD, wv = slots && h.opt == 0;
+        if (h.win_fit_q) {
+            if (wm)
+                m = ld4_sc1w(t.mQ, ro);
+            if (wv)
+                v = ld4_sc1w(t.vQ, ro);
+        } else {
+            float4 rm, rv;
+            win_load2(wm ? t.mQ + ro : t.Q, wv ? t.vQ + ro : t.Q, rm, rv);
+            m = wm ? rm : zero, v = wv ? rv : zero;
+        }
+    }
+    // the lanes of this group (the wave's other group may be elsewhere): the group's lanes agree on "all here" by ballot
+    const uint64_t gmask = LPR == 64 ? ~0ull : (((1ull << LPR) - 1ull) << (lane - l));
+    float4 g = zero;
+    unsigned spins = 0;
+    for (int k0 = 0; k0 < n; k0 += DEEP) {
+        float4 c[DEEP];
+        for (;;) {
+            bool missing = false;
+#pragma unroll
+            for (int e = 0; e < DEEP; ++e)
+                c[e] = (act && k0 + e < n) ? ld4_pub(wpart, (int64_t)at(k0 + e) * d + 4 * l) : zero;
+#pragma unroll
+            for (int e = 0; e < DEEP; ++e)
+                missing |= act && k0 + e < n && __float_as_uint(c[e].x) == 0xffffffffu;
+            if ((__builtin_amdgcn_ballot_w64(missing) & gmask) == 0)
+                break;
+            __builtin_amdgcn_s_sleep(2);
+            if ((++spins & 255u) == 0 && (spins >= (1u << 20) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0)) {
+                if (l == 0)
+                    __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < DEEP; ++e)
+            if (k0 + e < n)
+                add4(g, c[e]);
+    }
+    add4(g, own_sum);
+    if (act) { // the entries go back to "nothing waits" (nobody asks for them again in this launch; the next launch starts after this one's end)
+        const float4 sent = make_float4(__uint_as_float(0xffffffffu), __uint_as_float(0xffffffffu), __uint_as_float(0xffffffffu), __uint_as_float(0xffffffffu));
+        for (int e = 0; e < n; ++e)
+            st4_pub(wpart, (int64_t)at(e) * d + 4 * l, sent);
+    }
+    lazy_finish_row<LPR, false, DEFER>(t, d, act, row, own_row, g, m, v, h, start);
+}
+
 // bpr_triples_lazy: a lane group per processing slot; a workgroup = SPW slots (IndexWs::order, ::nslots); ud / id / jd: the
 // triples' three roles by batch position.
 template <int LPR, bool BIG = false> struct LazyGeo { // BIG: the geometry of batches >= 4096 triples (lazy_spw)
@@ -2700,12 +2772,17 @@ __global__ __launch_bounds__((LazyGeo<LPR, BIG>::THREADS)) void bpr_triples_lazy
             add4(blk_sum, blk_rows[(gw + e) * LPR + l]);
     }
     // 1. the contribution rows of the multi-occurrence roles, first: their completion is what the tickets wait for
-    const bool i_publish = !is && (!front || (blk_lead && !blk_whole)); // front region: only a piece's leader speaks for the row
+    // lazy_window: a front row all of whose slots are positive ones goes without tickets (lazy_poll_front)
+    const bool i_poll = WIN && win.wpart != nullptr && blk_lead && !blk_whole && i_cnt == i_ci;
+    const bool i_poll_last = i_poll && i_posr + blk_n == i_ci; // the piece that reaches the row's end: its leader finishes the row
+    const bool i_publish = !is && !i_poll && (!front || (blk_lead && !blk_whole)); // front region: only a piece's leader speaks for the row
     if (on && !(CREC_LAZY_ABL & 2)) {
         if (!us)
             st4_pub(z.ucontrib, (int64_t)lazy_desc_k(du) * d + 4 * l, cu);
         if (i_publish)
             st4_pub(z.qcontrib, (int64_t)i_k * d + 4 * l, front ? blk_sum : nsp);
+        if (i_poll && !i_poll_last)
+            st4_pub(win.wpart + (int64_t)blockIdx.y * 2 * win.B * d, (int64_t)i_k * d + 4 * l, blk_sum);
         if (!js)
             st4_pub(z.qcontrib, (int64_t)lazy_desc_k(dj) * d + 4 * l, sp);
     }
@@ -2806,6 +2883,8 @@ __global__ __launch_bounds__((LazyGeo<LPR, BIG>::THREADS)) void bpr_triples_lazy
     }
     if (blk_whole) // a front row that lies inside this workgroup: finished from LDS, nothing published
         lazy_finish_row<LPR, false, DEFER>(t, d, act, di.x & 0x7fffffff, qi, blk_sum, mi_raw, vi_raw, h, lazy_desc_start(di));
+    if (WIN && i_poll_last)
+        lazy_poll_front<LPR, DEFER>(t, d, act, di, qi, blk_sum, win.wpart + (int64_t)blockIdx.y * 2 * win.B * d, SPW, h, win.err);
     if (!any_multi || (CREC_LAZY_ABL & 1))
         return;
     // 4. whoever completes a row's (chunk's) counter finishes it
@@ -3324,6 +3403,7 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
     if (ctx->flow_err && *(volatile int32_t *)ctx->flow_err != 0) { // (the flag lives in page-locked memory the kernel writes itself)
         *(volatile int32_t *)ctx->flow_err = 0;
         ctx->flow_hist_at = nullptr; // whatever the histories hold now: sentinel again before the next use
+        ctx->lazy_wpart_dirty = true;  // (and lazy_window's polled partials)
         return crec_fail(ctx, CREC_EHIP, "an earlier bpr_steps_flow (or lazy_window) launch gave up waiting for a row version (a wave of it never ran or the "
                                          "device faulted): the tables that call left are not valid");
     }
@@ -3539,6 +3619,16 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
                 return rc;
             if (ctx->lazy_done.ptr != before)
                 CREC_HIP(ctx, hipMemsetAsync(ctx->lazy_done.ptr, 0, ctx->lazy_done.bytes, st));
+            // the polled partials of front rows (lazy_poll_front): all bits set = nothing waits; whoever takes a partial puts that back
+            const size_t pbytes = sizeof(float) * (size_t)lazy_win * 2 * (size_t)B * (size_t)t->d;
+            const void *pbefore = ctx->lazy_wpart.ptr;
+            const size_t phad = ctx->lazy_wpart.bytes;
+            if (int rc = crec_reserve(ctx, &ctx->lazy_wpart, pbytes))
+                return rc;
+            if (ctx->lazy_wpart.ptr != pbefore || ctx->lazy_wpart.bytes != phad || ctx->lazy_wpart_dirty) {
+                CREC_HIP(ctx, hipMemsetAsync(ctx->lazy_wpart.ptr, 0xff, ctx->lazy_wpart.bytes, st));
+                ctx->lazy_wpart_dirty = false;
+            }
         }
     }
 
@@ -3789,6 +3879,7 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
                 ctx->lazy_stamp = 0; // (old stamps are at least a launch behind: never equal to a fresh one)
             wn.err = ctx->flow_err_dev;
             wn.abl = ctx->knob_flow_abl;
+            wn.wpart = (wn.abl & 8) ? nullptr : (float *)ctx->lazy_wpart.ptr;
             wn.fit_p = hP * 4 <= (int64_t)0xfffffff0, wn.fit_q = hQ * 4 <= (int64_t)0xfffffff0;
             a.h = Hyper{};
             a.h.opt = (opt->adam_mode == CREC_OPT_SGD || opt->adam_mode == CREC_OPT_ADAGRAD) ? opt->adam_mode : 0;

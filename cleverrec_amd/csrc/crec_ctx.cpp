@@ -260,7 +260,7 @@ void crec_ctx_destroy(crec_ctx *ctx)
         (void)crec_comm_destroy(ctx);
         crec_devbuf *bufs[] = {&ctx->idx_ws, &ctx->idx_ws2, &ctx->big_ws, &ctx->contrib, &ctx->loss_ws,
                                &ctx->misc,   &ctx->eval_ws, &ctx->ks_dev, &ctx->shadow, &ctx->dq, &ctx->shard_ws, &ctx->shard_ws2, &ctx->lr_hist_dev,
-                               &ctx->shard_flag, &ctx->flow_hist, &ctx->flow_deal, &ctx->loss_parts, &ctx->lazy_done, &ctx->tf1_last};
+                               &ctx->shard_flag, &ctx->flow_hist, &ctx->flow_deal, &ctx->loss_parts, &ctx->lazy_done, &ctx->tf1_last, &ctx->lazy_wpart};
         for (crec_devbuf *b : bufs)
             if (b->ptr)
                 (void)hipFree(b->ptr);

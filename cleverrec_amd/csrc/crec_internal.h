@@ -93,6 +93,8 @@ struct crec_ctx {
     crec_devbuf shadow;   // second buffer set of the tf1-mode ping-pong: P, mP, vP, Q, mQ, vQ
     crec_devbuf loss_ws;  // per-triple loss terms of one chunk
     crec_devbuf loss_parts; // bpr_reduce_loss: partial sums and tickets per batch
+    crec_devbuf lazy_wpart; // lazy_window: polled partials of front rows, all bits set between launches
+    bool lazy_wpart_dirty = false; // (a launch gave up: entries may hold partials nobody took)
     crec_devbuf tf1_last;   // tf1 beyond 8192 triples per batch (run as deferred Adam + flush): the rows' last-step stamps of the call
     crec_devbuf misc;     // heavy-row partials + ticket counters
     char *tickets_at = nullptr; // where the counters were last cleared (they are re-zeroed by the kernels after use)
