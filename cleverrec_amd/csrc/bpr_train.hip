@@ -3507,14 +3507,15 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
     int lazy_win = 0;
     if (!dense && !dp && !df && B <= MAX_B && !ctx->knob_big_index && ctx->knob_lazy_window != 0 && ctx->knob_lazy_window != 1 &&
         3 * (int64_t)B < ((int64_t)1 << 20)) {
-        // -1 (the default): 8 batches per launch where the tables outgrow the batch -- a row then seldom has a predecessor in the launch
-        // and the launch is bound by its traffic, not by the popular rows' way from batch to batch.  us per step, a launch per batch /
-        // 8 per launch (tools/time_window.py): 10 M x 1 M rows, d = 128: 18.7 / 14.4 (uniform positives 21.3 / 14.0; 16 per launch
-        // 14.0 / 14.9), d = 32: 12.3 / 11.5; 1 M x 100 k: 18.4 / 15.5; 100 k x 20 k, d = 64: 14.7 / 13.4; but ml-1m's 6 040 x 3 706,
-        // where every row recurs in every batch: d = 64 13.9 / 15.7, d = 128 17.6 / 17.0
+        // -1 (the default): 12 batches per launch where the tables outgrow the batch -- a row then seldom has a predecessor in the
+        // launch and the launch is bound by its traffic, not by the popular rows' way from batch to batch.  us per step, a launch per
+        // batch / 8 / 12 per launch (tools/time_window.py): 10 M x 1 M rows, d = 128: 18.6 / 13.9 / 13.4 (uniform positives 21.4 /
+        // 14.8 / 13.7; B = 2048: 12.1 / 8.4 / 8.1), d = 32: 12.2 / 9.6 / 9.8; 1 M x 100 k: 17.9 / 14.6 / 14.3 (B = 1024: 10.6 /
+        // 7.2 / 6.8); 100 k x 20 k, d = 64: 13.7 / 13.0 / 13.0; but ml-1m's 6 040 x 3 706, where every row recurs in every batch:
+        // d = 64 13.7 / 15.7 / 15.7 (d = 128: 17.6 / 17.0 / 16.9)
         int want = ctx->knob_lazy_window;
         if (want < 0)
-            want = (t->d >= 32 && (int64_t)t->I >= 3 * (int64_t)B && (int64_t)t->U >= 3 * (int64_t)B && nb >= 4) ? 8 : 0;
+            want = (t->d >= 32 && (int64_t)t->I >= 3 * (int64_t)B && (int64_t)t->U >= 3 * (int64_t)B && nb >= 4) ? 12 : 0;
         if (want > 1) {
             ensure_err();
             if (ctx->flow_err_dev)

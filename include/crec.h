@@ -87,8 +87,8 @@ const char *crec_last_error(const crec_ctx *ctx);
  *   "flow_deal"      0: its rows are dealt to workgroups round-robin by id instead of by how often they occur (bit-identical)
  *   "lazy_window"    lazy Adam (CREC_ADAM_LAZY, LDS-indexed batches, not the row-sharded step): W = 2..16 consecutive batches of
  *                    bpr_triples_lazy per launch, a row's readers waiting for the batch before them that wrote it (bit-identical to
- *                    0 = a launch per batch).  -1 (default; env CREC_LAZY_WINDOW): 8 where both tables hold >= 3 batches' worth of
- *                    rows and d >= 32 (S-big: 18.7 -> 14.4 us/step, uniform positives 21.3 -> 14.0), else 0 (small catalogues, where
+ *                    0 = a launch per batch).  -1 (default; env CREC_LAZY_WINDOW): 12 where both tables hold >= 3 batches' worth of
+ *                    rows and d >= 32 (S-big: 18.6 -> 13.4 us/step, uniform positives 21.4 -> 13.7), else 0 (small catalogues, where
  *                    every row recurs from batch to batch and the launch is bound by the rows' way through it: ml-1m +13 %)
  *   "idx_no_ids16"   1: the tf1 index gathers its occurrence records' ids from the streams instead of from the 16-bit copies it keeps in LDS
  *                    where both catalogues are below 65 536 rows (the same records)

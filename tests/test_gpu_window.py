@@ -58,14 +58,14 @@ CASES = [
 def test_window_equals_a_launch_per_batch_bit_for_bit(sess, U, I, d, B, nb, zipf, mode):
     u, i, j = _stream(U + d + B, U, I, nb * B + B // 3 + 1, zipf)
     ref = _run(sess, 0, mode, U, I, d, B, u, i, j)
-    for W, calls in ((2, 1), (4, 2), (8, 1), (16, 3)):
+    for W, calls in ((2, 1), (4, 2), (8, 1), (12, 2), (16, 3)):
         got = _run(sess, W, mode, U, I, d, B, u, i, j, calls)
         for x, y, name in zip(ref, got, ("loss", "P", "Q", "mP", "mQ", "vP", "vQ")):
             assert np.array_equal(x, y), "W = %d: %s" % (W, name)
 
 
 def test_window_is_the_default_where_the_tables_dwarf_the_batch(sess):
-    """lazy_window = -1 (the default): 8 batches per launch where both tables hold >= 3 batches' worth of rows and d >= 32 -- seen in
+    """lazy_window = -1 (the default): 12 batches per launch where both tables hold >= 3 batches' worth of rows and d >= 32 -- seen in
     the launch brackets' unit counts -- and a launch per batch elsewhere; the same bits either way."""
     for (U, I, d, B, nb), windows in (((200_000, 20_000, 64, 1024, 21), True), ((200_000, 5_000, 64, 2048, 9), False),
                                       ((200_000, 20_000, 16, 1024, 9), False), ((200_000, 20_000, 32, 6144, 5), True)):

@@ -49,7 +49,7 @@ while time.time() < t_end:
     d = int(g.choice([4, 8, 16, 20, 32, 64, 100, 128, 256]))
     B = int(g.choice([64, 256, 1000, 2048, 4096, 6144, 8192]))
     nb = int(g.integers(2, 40))
-    W = int(g.choice([2, 3, 4, 8, 16]))
+    W = int(g.choice([2, 3, 4, 8, 12, 16]))
     mode = str(g.choice(["lazy", "lazy", "sgd", "adagrad"]))
     zipf = float(g.choice([1.05, 1.2, 1.5, 0.0]))
     tail = int(g.integers(0, B))
