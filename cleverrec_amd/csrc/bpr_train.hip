@@ -2221,7 +2221,6 @@ struct LazyWin {
     int32_t *done;         // [LAZY_WIN_MAX][3 B] stamps by (batch in window, segment start; user side first, item side from B)
     int32_t stamp0;        // the stamp of the launch's first batch (a ctx-wide launch counter: never repeats)
     int32_t *err;          // give-up flag (page-locked)
-    float *wpart;          // [W][2 B][d] polled partials of front rows (see lazy_poll_front), all bits set where nothing waits; null: tickets only
     bool fit_p, fit_q;     // a user / item table lies within 4 GiB
     int abl;               // timing ablations (option flow_abl; WRONG results): 1 nobody waits for a predecessor
     float lr_t[LAZY_WIN_MAX];
@@ -2281,6 +2280,8 @@ struct LazyBufs {
     int32_t *urow_t, *uchk_t;   // [B] ticket counters by segment start / chunk start, zero between launches
     int32_t *qrow_t, *qchk_t;   // [2B]
     int32_t CH;                 // slots per chunk of a heavy row
+    float *wpart;               // [2B][d] polled partials of front rows without negative slots (lazy_poll_front): all bits set where nothing waits; null: tickets only
+    int32_t *err;               // give-up flag of a wait inside the launch (page-locked)
 };
 
 // sum of n rows base[0], base[stride], ... in that order, each plus `add` (reg * row, or zero); agent-scope loads
@@ -2507,7 +2508,12 @@ __device__ __forceinline__ void lazy_poll_front(const Tables &t, int d, bool act
     float4 m = zero, v = zero;
     { // the row's slots: asked for now, in flight beside the wait for the partials
         const bool wm = slots && h.opt != CREC_OPT_SGD, wv = slots && h.opt == 0;
-        if (h.win_fit_q) {
+        if (h.win_done_q == nullptr) { // a launch per batch: nobody rewrites a row inside the launch
+            if (wm)
+                m = ld4(t.mQ + ro);
+            if (wv)
+                v = ld4(t.vQ + ro);
+        } else if (h.win_fit_q) {
             if (wm)
                 m = ld4_sc1w(t.mQ, ro);
             if (wv)
@@ -2582,6 +2588,8 @@ __global__ __launch_bounds__((LazyGeo<LPR, BIG>::THREADS)) void bpr_triples_lazy
         xb += (int64_t)wb * win.loss_stride, l2b += (int64_t)wb * win.loss_stride;
         const int64_t zr = (int64_t)wb * win.z_stride * d, zc = (int64_t)wb * win.z_stride;
         z.ucontrib += zr, z.qcontrib += zr, z.upart += zr, z.qpart += zr;
+        if (z.wpart)
+            z.wpart += (int64_t)wb * 2 * win.B * d;
         z.urow_t += zc, z.uchk_t += zc, z.qrow_t += zc, z.qchk_t += zc;
         h.lr_t = win.lr_t[wb];
         h.win_done_u = (win.abl & 2) ? nullptr : win.done + (int64_t)wb * 3 * win.B;
@@ -2773,7 +2781,7 @@ __global__ __launch_bounds__((LazyGeo<LPR, BIG>::THREADS)) void bpr_triples_lazy
     }
     // 1. the contribution rows of the multi-occurrence roles, first: their completion is what the tickets wait for
     // lazy_window: a front row all of whose slots are positive ones goes without tickets (lazy_poll_front)
-    const bool i_poll = WIN && win.wpart != nullptr && blk_lead && !blk_whole && i_cnt == i_ci;
+    const bool i_poll = !DEFER && z.wpart != nullptr && !h.dQ && blk_lead && !blk_whole && i_cnt == i_ci;
     const bool i_poll_last = i_poll && i_posr + blk_n == i_ci; // the piece that reaches the row's end: its leader finishes the row
     const bool i_publish = !is && !i_poll && (!front || (blk_lead && !blk_whole)); // front region: only a piece's leader speaks for the row
     if (on && !(CREC_LAZY_ABL & 2)) {
@@ -2782,7 +2790,7 @@ __global__ __launch_bounds__((LazyGeo<LPR, BIG>::THREADS)) void bpr_triples_lazy
         if (i_publish)
             st4_pub(z.qcontrib, (int64_t)i_k * d + 4 * l, front ? blk_sum : nsp);
         if (i_poll && !i_poll_last)
-            st4_pub(win.wpart + (int64_t)blockIdx.y * 2 * win.B * d, (int64_t)i_k * d + 4 * l, blk_sum);
+            st4_pub(z.wpart, (int64_t)i_k * d + 4 * l, blk_sum);
         if (!js)
             st4_pub(z.qcontrib, (int64_t)lazy_desc_k(dj) * d + 4 * l, sp);
     }
@@ -2883,8 +2891,8 @@ __global__ __launch_bounds__((LazyGeo<LPR, BIG>::THREADS)) void bpr_triples_lazy
     }
     if (blk_whole) // a front row that lies inside this workgroup: finished from LDS, nothing published
         lazy_finish_row<LPR, false, DEFER>(t, d, act, di.x & 0x7fffffff, qi, blk_sum, mi_raw, vi_raw, h, lazy_desc_start(di));
-    if (WIN && i_poll_last)
-        lazy_poll_front<LPR, DEFER>(t, d, act, di, qi, blk_sum, win.wpart + (int64_t)blockIdx.y * 2 * win.B * d, SPW, h, win.err);
+    if (i_poll_last)
+        lazy_poll_front<LPR, DEFER>(t, d, act, di, qi, blk_sum, z.wpart, SPW, h, z.err);
     if (!any_multi || (CREC_LAZY_ABL & 1))
         return;
     // 4. whoever completes a row's (chunk's) counter finishes it
@@ -3186,6 +3194,7 @@ int setup_lazy_bufs(crec_ctx *ctx, int64_t B, int d, int CH, hipStream_t st, Laz
     z->qrow_t = c + 2 * B;
     z->qchk_t = c + 4 * B;
     z->CH = CH;
+    z->wpart = nullptr, z->err = nullptr; // (set by the callers that use lazy_poll_front)
     if (ctx->lazy_tickets_at != (char *)c || ctx->lazy_tickets_bytes != ctr_bytes) {
         CREC_HIP(ctx, hipMemsetAsync(c, 0, ctr_bytes, st));
         ctx->lazy_tickets_at = (char *)c;
@@ -3620,8 +3629,14 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
                 return rc;
             if (ctx->lazy_done.ptr != before)
                 CREC_HIP(ctx, hipMemsetAsync(ctx->lazy_done.ptr, 0, ctx->lazy_done.bytes, st));
-            // the polled partials of front rows (lazy_poll_front): all bits set = nothing waits; whoever takes a partial puts that back
-            const size_t pbytes = sizeof(float) * (size_t)lazy_win * 2 * (size_t)B * (size_t)t->d;
+        }
+        a.lazy.wpart = nullptr, a.lazy.err = nullptr;
+        if (lazy_win && !(ctx->knob_flow_abl & 8)) {
+            // the polled partials of front rows (lazy_poll_front): all bits set = nothing waits; whoever takes a partial puts that back.
+            // (Window launches only.  A launch per batch loses by it -- ml-1m's catalogue 13.7 -> 14.8 us per step, S-big 18.6 -> 19.1:
+            // all its waves start together, and a finisher that waits holds its place while the body is still under way.)
+            ensure_err();
+            const size_t pbytes = sizeof(float) * (size_t)(lazy_win ? lazy_win : 1) * 2 * (size_t)B * (size_t)t->d;
             const void *pbefore = ctx->lazy_wpart.ptr;
             const size_t phad = ctx->lazy_wpart.bytes;
             if (int rc = crec_reserve(ctx, &ctx->lazy_wpart, pbytes))
@@ -3630,6 +3645,8 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
                 CREC_HIP(ctx, hipMemsetAsync(ctx->lazy_wpart.ptr, 0xff, ctx->lazy_wpart.bytes, st));
                 ctx->lazy_wpart_dirty = false;
             }
+            if (ctx->flow_err_dev)
+                a.lazy.wpart = (float *)ctx->lazy_wpart.ptr, a.lazy.err = ctx->flow_err_dev;
         }
     }
 
@@ -3880,7 +3897,6 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
                 ctx->lazy_stamp = 0; // (old stamps are at least a launch behind: never equal to a fresh one)
             wn.err = ctx->flow_err_dev;
             wn.abl = ctx->knob_flow_abl;
-            wn.wpart = (wn.abl & 8) ? nullptr : (float *)ctx->lazy_wpart.ptr;
             wn.fit_p = hP * 4 <= (int64_t)0xfffffff0, wn.fit_q = hQ * 4 <= (int64_t)0xfffffff0;
             a.h = Hyper{};
             a.h.opt = (opt->adam_mode == CREC_OPT_SGD || opt->adam_mode == CREC_OPT_ADAGRAD) ? opt->adam_mode : 0;
