@@ -2781,7 +2781,7 @@ __global__ __launch_bounds__((LazyGeo<LPR, BIG>::THREADS)) void bpr_triples_lazy
     }
     // 1. the contribution rows of the multi-occurrence roles, first: their completion is what the tickets wait for
     // lazy_window: a front row all of whose slots are positive ones goes without tickets (lazy_poll_front)
-    const bool i_poll = !DEFER && z.wpart != nullptr && !h.dQ && blk_lead && !blk_whole && i_cnt == i_ci;
+    const bool i_poll = WIN && !DEFER && z.wpart != nullptr && !h.dQ && blk_lead && !blk_whole && i_cnt == i_ci; // (compile-time off outside window launches)
     const bool i_poll_last = i_poll && i_posr + blk_n == i_ci; // the piece that reaches the row's end: its leader finishes the row
     const bool i_publish = !is && !i_poll && (!front || (blk_lead && !blk_whole)); // front region: only a piece's leader speaks for the row
     if (on && !(CREC_LAZY_ABL & 2)) {
@@ -2891,7 +2891,7 @@ __global__ __launch_bounds__((LazyGeo<LPR, BIG>::THREADS)) void bpr_triples_lazy
     }
     if (blk_whole) // a front row that lies inside this workgroup: finished from LDS, nothing published
         lazy_finish_row<LPR, false, DEFER>(t, d, act, di.x & 0x7fffffff, qi, blk_sum, mi_raw, vi_raw, h, lazy_desc_start(di));
-    if (i_poll_last)
+    if (WIN && i_poll_last)
         lazy_poll_front<LPR, DEFER>(t, d, act, di, qi, blk_sum, z.wpart, SPW, h, z.err);
     if (!any_multi || (CREC_LAZY_ABL & 1))
         return;
