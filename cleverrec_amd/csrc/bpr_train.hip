@@ -4437,8 +4437,13 @@ int crec_bpr_train_epoch(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt
     // tf1 beyond the in-LDS index (model/Recommender.py:17 takes any batch_size): the call runs as deferred Adam -- every row current
     // at the call's first step, the touched rows replaying the steps they sat out -- and ends with the flush, so the caller's tables
     // are TF1's after every call, as they are after every sess.run (one whole-table sweep per call instead of one per step)
-    if (ctx && t && opt && opt->adam_mode == CREC_ADAM_TF1 && B > MAX_B && B <= LAZY_MAX_B && opt->beta1 <= 0.9000001f && N > 0 && t->U > 0 &&
-        t->I > 0 && ctx->device >= 0) {
+    // The same form where the sweep itself is what a step costs: tables whose rows and slots make 64 MB and more (24 d (U + I) bytes
+    // per step at the memory system's rate: 12 us upwards, against the 14-18 us of a touched-rows step whatever the tables' size).
+    // us per step, swept / so (tools/time_tf1_vs_deferred.py, d = 64): 20 k x 10 k rows 19.9 / 19.0, 50 k x 20 k 30.2 / 23.2,
+    // 138 k x 27 k 56.5 / 30.5 (d = 128: 93.8 / 36.5), 500 k x 100 k 172.7 / 47.3.  Option "tf1_sweep" = 1 keeps the sweep.
+    const bool big_tables = ctx && t && 24.0 * t->d * ((double)t->U + (double)t->I) >= 64.0 * 1024 * 1024 && !ctx->knob_tf1_sweep;
+    if (ctx && t && opt && opt->adam_mode == CREC_ADAM_TF1 && (B > MAX_B || big_tables) && B <= LAZY_MAX_B && opt->beta1 <= 0.9000001f && N > 0 &&
+        t->U > 0 && t->I > 0 && ctx->device >= 0) {
         CREC_HIP(ctx, hipSetDevice(ctx->device));
         hipStream_t st = (hipStream_t)stream;
         if (int rc = crec_reserve(ctx, &ctx->tf1_last, sizeof(int32_t) * ((size_t)t->U + (size_t)t->I)))

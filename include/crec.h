@@ -90,6 +90,7 @@ const char *crec_last_error(const crec_ctx *ctx);
  *                    0 = a launch per batch).  -1 (default; env CREC_LAZY_WINDOW): 12 where both tables hold >= 3 batches' worth of
  *                    rows and d >= 32 (S-big: 18.6 -> 13.4 us/step, uniform positives 21.4 -> 13.7), else 0 (small catalogues, where
  *                    every row recurs from batch to batch and the launch is bound by the rows' way through it: ml-1m +13 %)
+ *   "tf1_sweep"      1: adam_mode tf1 sweeps every row at every step whatever the tables' size (see crec_bpr_train_epoch)
  *   "idx_no_ids16"   1: the tf1 index gathers its occurrence records' ids from the streams instead of from the 16-bit copies it keeps in LDS
  *                    where both catalogues are below 65 536 rows (the same records)
  *   "flow_abl"       timing ablations of bpr_steps_flow / the window (results are WRONG; tools/ only)
@@ -223,7 +224,9 @@ typedef struct {
  * B: the reference takes any batch_size (model/Recommender.py:17): 1 .. 524288 here.  Beyond 8192 the batch's index (the unique +
  * segment-sum bookkeeping) is built in global memory, the same index bit for bit (csrc/index_big.hip); adam_mode tf1 then runs the call
  * as deferred Adam with the flush at its end -- TF1's tables after every call, one whole-table sweep per call instead of one per step
- * (beta1 <= 0.9; refused above that, as crec_bpr_train_epoch_deferred is). */
+ * (beta1 <= 0.9; refused above that, as crec_bpr_train_epoch_deferred is).  Tables whose rows and slots make 64 MB and more take the
+ * same form at any batch size (a sweep per step would cost more than the step: 138 k x 27 k rows, d = 64: 56 -> 31 us per step;
+ * beta1 > 0.9 keeps the sweep); option "tf1_sweep" = 1 sweeps regardless. */
 int crec_bpr_train_epoch(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, const int32_t *u, const int32_t *i,
                          const int32_t *j, int64_t N, int32_t B, float *loss_per_batch, void *stream);
 

@@ -288,3 +288,36 @@ def test_class_surface_takes_a_large_batch(sess, tmp_path):
     m.state.flush()
     np.testing.assert_allclose(m.P.cpu().numpy(), om.P, rtol=0, atol=2e-6)
     np.testing.assert_allclose(m.Q.cpu().numpy(), om.Q, rtol=0, atol=2e-6)
+
+
+def test_tf1_on_large_tables_runs_as_deferred_and_is_tf1(sess):
+    """Tables whose rows and slots make 64 MB and more: crec_bpr_train_epoch runs adam_mode tf1 as deferred Adam + the flush at the
+    end of the call (a sweep per step would cost more than the step).  Against the sweep itself (option tf1_sweep = 1) on the same
+    stream: losses to 1e-5, tables and m to 2e-6, v norm-wise 1e-5 -- two consecutive calls; and the launches are the touched-rows
+    step's, not the sweep's."""
+    U, I, d, B = 150_000, 30_000, 64, 2048
+    u, i, j = _stream(5, 7 * B + 99, U, I, zipf=1.2)
+    g = np.random.Generator(np.random.PCG64(8))
+    P0, Q0 = (g.standard_normal((U, d)) * 0.01).astype(np.float32), (g.standard_normal((I, d)) * 0.01).astype(np.float32)
+    du, di, dj = sess.to_dev(u), sess.to_dev(i), sess.to_dev(j)
+    cut = 3 * B
+    out = {}
+    for sweep in (1, 0):
+        sess.ctx.set_option("tf1_sweep", sweep)
+        sess.ctx.profile(True)
+        try:
+            st = runtime.BprState(sess, P0, Q0, lr=1e-3, reg=0.01, adam_mode="tf1")
+            loss = np.concatenate([st.train_epoch(du[:cut], di[:cut], dj[:cut], B).cpu().numpy(), st.train_epoch(du[cut:], di[cut:], dj[cut:], B).cpu().numpy()])
+            prof = sess.ctx.profile_read()
+        finally:
+            sess.ctx.profile(False)
+            sess.ctx.set_option("tf1_sweep", 0)
+        out[sweep] = [loss] + [getattr(st, k).cpu().numpy() for k in ("P", "Q", "mP", "mQ", "vP", "vQ")]
+        lazy, fused = prof.get("bpr_triples_lazy", (0, 0))[1], prof.get("bpr_step_fused", (0, 0))[1] + prof.get("bpr_steps_flow", (0, 0))[1]
+        assert (lazy == 0 and fused > 0) if sweep else (lazy > 0 and fused == 0), (sweep, prof)
+        assert st.adam.step == 8
+    np.testing.assert_allclose(out[0][0], out[1][0], rtol=1e-5)
+    for a, b, name in zip(out[0][1:5], out[1][1:5], ("P", "Q", "mP", "mQ")):
+        np.testing.assert_allclose(a, b, rtol=0, atol=2e-6, err_msg=name)
+    for a, b, name in zip(out[0][5:], out[1][5:], ("vP", "vQ")):
+        assert np.abs(a.astype(np.float64) - b).max() <= 1e-5 * np.abs(b).max(), name

@@ -130,7 +130,7 @@ def test_tables_too_tall_for_resident_waves_take_the_launch_per_step_path(sess):
     P0, Q0 = _tables(5, U, I, d)
     sess.ctx.profile(True)
     try:
-        a, _ = _run(sess, {}, P0, Q0, u, i, j, B)
+        a, _ = _run(sess, {"tf1_sweep": 1}, P0, Q0, u, i, j, B)  # (77 MB of rows and slots: swept only on request)
         prof = sess.ctx.profile_read()
     finally:
         sess.ctx.profile(False)
