@@ -2220,6 +2220,7 @@ struct LazyWin {
     const int4 *deps;      // [W][B] by processing slot (IndexWs::wdeps of the launch's first batch)
     int32_t *done;         // [LAZY_WIN_MAX][3 B] stamps by (batch in window, segment start; user side first, item side from B)
     int32_t stamp0;        // the stamp of the launch's first batch (a ctx-wide launch counter: never repeats)
+    int32_t step0;         // deferred Adam: the optimizer step of the launch's first batch
     int32_t *err;          // give-up flag (page-locked)
     bool fit_p, fit_q;     // a user / item table lies within 4 GiB
     int abl;               // timing ablations (option flow_abl; WRONG results): 1 nobody waits for a predecessor
@@ -2367,6 +2368,13 @@ __device__ __forceinline__ void lazy_finish_row(const Tables &t, int d, bool act
         if (act) {  // next readers in the window (every lane of the group is here: the wait is the wave's)
             const int64_t ro = (int64_t)row * d + 4 * l;
             float4 nv = own;
+            if (DEFER) { // m, v as stored: the steps the row sat out (var plays no part in their replay: any copy of the row will do)
+                float4 scratch = own;
+                int32_t *last = (USER ? h.lastP : h.lastQ) + row;
+                adam_replay(scratch, m, v, __hip_atomic_load(last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), h.step - 1, h);
+                if (l == 0)
+                    __hip_atomic_store(last, h.step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             opt4(nv, m, v, g, h);
             st4_wtg((USER ? t.P : t.Q) + ro, nv);
             if (h.opt != CREC_OPT_SGD)
@@ -2592,6 +2600,8 @@ __global__ __launch_bounds__((LazyGeo<LPR, BIG>::THREADS)) void bpr_triples_lazy
             z.wpart += (int64_t)wb * 2 * win.B * d;
         z.urow_t += zc, z.uchk_t += zc, z.qrow_t += zc, z.qchk_t += zc;
         h.lr_t = win.lr_t[wb];
+        if (DEFER)
+            h.step = win.step0 + wb;
         h.win_done_u = (win.abl & 2) ? nullptr : win.done + (int64_t)wb * 3 * win.B;
         h.win_done_q = (win.abl & 2) ? nullptr : h.win_done_u + win.B;
         h.win_stamp = win.stamp0 + wb;
@@ -2635,7 +2645,7 @@ __global__ __launch_bounds__((LazyGeo<LPR, BIG>::THREADS)) void bpr_triples_lazy
         // rows that do have one are asked for again once its stamp is there (they come from where the finisher wrote them
         // through, not from HBM).  A lane that wants nothing from a load reads the item table's first bytes.
         const bool has_m = h.opt != CREC_OPT_SGD, has_v = h.opt == 0;
-        const bool wi = on && (is || blk_whole), wj = on && js;
+        const bool wi = on && (is || blk_whole || DEFER), wj = on && (js || DEFER); // (deferred: every row is brought up to date before it is used)
         const bool want[9] = {on, on, on, on && has_m, on && has_v, wi && has_m, wi && has_v, wj && has_m, wj && has_v};
         const float *const addr[9] = {t.P + ou, t.Q + oi, t.Q + oj, t.mP + ou, t.vP + ou, t.mQ + oi, t.vQ + oi, t.mQ + oj, t.vQ + oj};
         float4 rows[9];
@@ -2742,18 +2752,27 @@ __global__ __launch_bounds__((LazyGeo<LPR, BIG>::THREADS)) void bpr_triples_lazy
     const bool us = du.x < 0; // the user row occurs once in the batch
     float4 mi_raw = mi, vi_raw = vi; // deferred mode: a finisher replays the stored slots itself
     if (DEFER) { // the steps these rows sat out, replayed: from here on p, q_i, q_j are what TF1's tables hold after step - 1
-        const int lu = valid ? h.lastP[pu.y] : h.step, li = valid ? h.lastQ[di.x & 0x7fffffff] : h.step,
-                  lj = valid ? h.lastQ[dj.x & 0x7fffffff] : h.step;
+        // (lazy_window: a row's stamp may have been left by an earlier batch of this launch on another XCD -- read where the XCDs meet,
+        // behind the wait for that batch's mark above; written through below, in front of this batch's own mark)
+        const auto last_of = [&](const int32_t *p_) { return WIN ? __hip_atomic_load(p_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p_; };
+        const int lu = valid ? last_of(h.lastP + pu.y) : h.step, li = valid ? last_of(h.lastQ + (di.x & 0x7fffffff)) : h.step,
+                  lj = valid ? last_of(h.lastQ + (dj.x & 0x7fffffff)) : h.step;
         adam_replay(p, mp, vp, lu, h.step - 1, h);
         adam_replay(qi, mi, vi, li, h.step - 1, h);
         adam_replay(qj, mj, vj, lj, h.step - 1, h);
         if (on && l == 0) { // the single-occurrence rows are finished below
+            const auto set_last = [&](int32_t *p_) {
+                if (WIN)
+                    __hip_atomic_store(p_, h.step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else
+                    *p_ = h.step;
+            };
             if (us)
-                h.lastP[du.x & 0x7fffffff] = h.step;
+                set_last(h.lastP + (du.x & 0x7fffffff));
             if (is)
-                h.lastQ[di.x & 0x7fffffff] = h.step;
+                set_last(h.lastQ + (di.x & 0x7fffffff));
             if (js)
-                h.lastQ[dj.x & 0x7fffffff] = h.step;
+                set_last(h.lastQ + (dj.x & 0x7fffffff));
         }
     }
     float x;
@@ -3138,7 +3157,12 @@ template <int LPR, bool FULL, bool BIG> void launch_lazy_window_geo(const StepAr
     const size_t lds = sizeof(float4) * THREADS;
     a.ctx->prof.next_units = win.W;
     crec_prof_begin(a.ctx, CREC_K_USER_SIDE, a.st);
-    CREC_KLAUNCH(a.ctx, (bpr_triples_lazy<LPR, FULL, false, true, BIG>), grid, block, lds, a.st, a.cur, a.d, (const int2 *)(w.slot_pu + b * w.B), 0,
+    if (a.h.lr_tab)
+        CREC_KLAUNCH(a.ctx, (bpr_triples_lazy<LPR, FULL, true, true, BIG>), grid, block, lds, a.st, a.cur, a.d, (const int2 *)(w.slot_pu + b * w.B), 0,
+                     (const int32_t *)(w.nslots + b * 2), (const int4 *)(w.u_desc + b * w.B), (const int4 *)(w.i_desc + b * w.B),
+                     (const int4 *)(w.j_desc + b * w.B), a.lazy, a.xb, a.rowterm, a.h, win);
+    else
+        CREC_KLAUNCH(a.ctx, (bpr_triples_lazy<LPR, FULL, false, true, BIG>), grid, block, lds, a.st, a.cur, a.d, (const int2 *)(w.slot_pu + b * w.B), 0,
                  (const int32_t *)(w.nslots + b * 2), (const int4 *)(w.u_desc + b * w.B), (const int4 *)(w.i_desc + b * w.B),
                  (const int4 *)(w.j_desc + b * w.B), a.lazy, a.xb, a.rowterm, a.h, win);
     crec_prof_end(a.ctx, a.st);
@@ -3512,9 +3536,9 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
         }
     }
     // lazy-family steps, W consecutive batches per launch (bpr_triples_lazy<.., WIN>): where the batch is indexed in LDS and the step is
-    // neither the deferred form (its replay stamps) nor the row-sharded one
+    // not the row-sharded one (deferred Adam's per-row step stamps travel like the rows: read where the XCDs meet, written through)
     int lazy_win = 0;
-    if (!dense && !dp && !df && B <= MAX_B && !ctx->knob_big_index && ctx->knob_lazy_window != 0 && ctx->knob_lazy_window != 1 &&
+    if (!dense && !dp && B <= MAX_B && !ctx->knob_big_index && ctx->knob_lazy_window != 0 && ctx->knob_lazy_window != 1 &&
         3 * (int64_t)B < ((int64_t)1 << 20)) {
         // -1 (the default): 12 batches per launch where the tables outgrow the batch -- a row then seldom has a predecessor in the
         // launch and the launch is bound by its traffic, not by the popular rows' way from batch to batch.  us per step, a launch per
@@ -3524,7 +3548,12 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
         // d = 64 13.7 / 15.7 / 15.7 (d = 128: 17.6 / 17.0 / 16.9)
         int want = ctx->knob_lazy_window;
         if (want < 0)
-            want = (t->d >= 32 && (int64_t)t->I >= 3 * (int64_t)B && (int64_t)t->U >= 3 * (int64_t)B && nb >= 4) ? 12 : 0;
+        {
+            // (deferred Adam: a row's replay sits on its way from batch to batch as well -- from 16 batches' worth of rows only:
+            // 50 k x 20 k rows 23.2 -> 26.4 us per step under the window, 500 k x 100 k 47.3 -> 45.6)
+            const int64_t need = (df ? 16 : 3) * (int64_t)B;
+            want = (t->d >= 32 && (int64_t)t->I >= need && (int64_t)t->U >= need && nb >= 4) ? 12 : 0;
+        }
         if (want > 1) {
             ensure_err();
             if (ctx->flow_err_dev)
@@ -3901,6 +3930,11 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
             a.h = Hyper{};
             a.h.opt = (opt->adam_mode == CREC_OPT_SGD || opt->adam_mode == CREC_OPT_ADAGRAD) ? opt->adam_mode : 0;
             a.h.beta1 = opt->beta1, a.h.beta2 = opt->beta2, a.h.eps = opt->eps, a.h.reg = opt->reg;
+            a.h.lr_tab = lr_tab; // deferred mode (else null)
+            a.h.lastP = df ? df->lastP : nullptr;
+            a.h.lastQ = df ? df->lastQ : nullptr;
+            wn.step0 = (int32_t)(opt->step + 1);
+            a.h.step = wn.step0;
             for (int k = 0; k < Wc; ++k) {
                 wn.lr_t[k] = a.h.opt ? opt->lr : (opt->lr * sqrtf(1.0f - opt->beta2_power)) / (1.0f - opt->beta1_power);
                 opt->beta1_power = opt->beta1_power * opt->beta1;

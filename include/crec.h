@@ -85,7 +85,7 @@ const char *crec_last_error(const crec_ctx *ctx);
  *                    fp32 summation order
  *   "flow_steps"     steps per bpr_steps_flow launch (0 = up to 64; 1 = a launch per step through the same kernel: bit-identical)
  *   "flow_deal"      0: its rows are dealt to workgroups round-robin by id instead of by how often they occur (bit-identical)
- *   "lazy_window"    lazy Adam (CREC_ADAM_LAZY, LDS-indexed batches, not the row-sharded step): W = 2..16 consecutive batches of
+ *   "lazy_window"    touched-rows steps (lazy / deferred Adam, SGD, Adagrad; LDS-indexed batches, not the row-sharded step): W = 2..16 consecutive batches of
  *                    bpr_triples_lazy per launch, a row's readers waiting for the batch before them that wrote it (bit-identical to
  *                    0 = a launch per batch).  -1 (default; env CREC_LAZY_WINDOW): 12 where both tables hold >= 3 batches' worth of
  *                    rows and d >= 32 (S-big: 18.6 -> 13.4 us/step, uniform positives 21.4 -> 13.7), else 0 (small catalogues, where

@@ -35,6 +35,7 @@ def _run(sess, W, mode, U, I, d, B, u, i, j, calls=1):
         cuts = [round(c * nb / calls) * B for c in range(calls)] + [len(u)]
         du, di, dj = (sess.to_dev(x) for x in (u, i, j))
         losses = [st.train_epoch(du[a:b], di[a:b], dj[a:b], B).cpu().numpy() for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+        st.flush()  # (deferred Adam: every row brought up to the last step; a no-op otherwise)
         return [np.concatenate(losses)] + [getattr(st, n).cpu().numpy() for n in ("P", "Q", "mP", "mQ", "vP", "vQ")]
     finally:
         sess.ctx.set_option("lazy_window", -1)
@@ -51,6 +52,9 @@ CASES = [
     (5_000, 1_000, 64, 700, 17, 1.2, "sgd"),
     (5_000, 1_000, 64, 700, 17, 1.2, "adagrad"),
     (100_000, 50_000, 256, 1000, 7, 1.1, "lazy"),
+    (200_000, 20_000, 64, 2048, 23, 1.1, "deferred"),  # TF1-exact Adam by replay: the rows' step stamps travel with them
+    (300, 200, 32, 512, 40, 1.3, "deferred"),          # every row hot: short replays, every stamp rewritten in every batch
+    (60_000, 900, 128, 4096, 9, 1.2, "deferred"),
 ]
 
 

@@ -36,6 +36,7 @@ def run(W, mode, P0, Q0, u, i, j, B, calls, busy):
                 for _ in range(4):
                     y = x @ x  # noqa: F841
         losses = [st.train_epoch(du[p:q], di[p:q], dj[p:q], B).cpu().numpy() for p, q in zip(cuts[:-1], cuts[1:]) if q > p]
+        st.flush()
         torch.cuda.synchronize()
         return [np.concatenate(losses)] + [getattr(st, n).cpu().numpy() for n in ("P", "Q", "mP", "mQ", "vP", "vQ")]
     finally:
@@ -50,7 +51,7 @@ while time.time() < t_end:
     B = int(g.choice([64, 256, 1000, 2048, 4096, 6144, 8192]))
     nb = int(g.integers(2, 40))
     W = int(g.choice([2, 3, 4, 8, 12, 16]))
-    mode = str(g.choice(["lazy", "lazy", "sgd", "adagrad"]))
+    mode = str(g.choice(["lazy", "lazy", "sgd", "adagrad", "deferred"]))
     zipf = float(g.choice([1.05, 1.2, 1.5, 0.0]))
     tail = int(g.integers(0, B))
     nn = nb * B + tail
