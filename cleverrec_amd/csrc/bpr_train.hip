@@ -1065,7 +1065,7 @@ __device__ __forceinline__ void opt4(float4 &var, float4 &m, float4 &v, float4 g
 // untouched-row update of TF1's sparse Adam.  m falls below the smallest fp32 denormal after < 1024 steps (0.9^1024 =
 // 1e-47 of itself; the entry point refuses beta1 > 0.9), from where on var no longer moves: the rest of the gap is
 // v *= b2^n -- one powf instead of n fp32 multiplications, i.e. v is within a few ulp of the sweep's, not bit-identical, for
-// rows idle longer than 1024 steps.
+// rows idle longer than 1024 steps (and m, v likewise from the step at which var has stopped moving: adam_replay).
 constexpr int CREC_REPLAY_MAX = 1024;
 __device__ __forceinline__ void adam_replay(float4 &var, float4 &m, float4 &v, int last, int upto, const Hyper &h)
 {
@@ -1077,9 +1077,10 @@ __device__ __forceinline__ void adam_replay(float4 &var, float4 &m, float4 &v, i
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     // var -= lr_s m_s / (sqrt(v_s) + eps) shrinks by 0.9 / sqrt(0.999) per idle step (lr_s grows by less than 0.1 % per step): once a
     // step leaves every lane's var as it was, no later one moves it either, and only m *= b1, v *= b2 remain -- the same two
-    // multiplications adam4 does, without its square root, quotient and lr_s: the same bits.  Rows idle for ~700 steps (the steady state of
-    // a 4 M x 400 k table; tools/time_deferred_replay.py): 571 -> 347 us per step, under lazy_window 354 -> 185; runs shorter than
-    // ~250 steps pay 10-25 % for the test.  The exit is the wave's: lanes of other rows may still be moving.
+    // multiplications adam4 does, taken in closed form.  Rows idle for ~700 steps (the steady state of a 4 M x 400 k table;
+    // tools/time_deferred_replay.py): 571 us per step with every step replayed in full, 347 with the multiplications one by one, 264 in
+    // closed form (under lazy_window 354 / 185 / 142); runs shorter than ~250 steps pay 10-25 % for the test.  The exit is the wave's:
+    // lanes of other rows may still be moving.
     int k = 0;
     for (; k < nr; ++k) {
         hs.lr_t = h.lr_tab[last + 1 + k];
@@ -1091,9 +1092,10 @@ __device__ __forceinline__ void adam_replay(float4 &var, float4 &m, float4 &v, i
             break;
         }
     }
-    for (; k < nr; ++k) {
-        m = make_float4(m.x * h.beta1, m.y * h.beta1, m.z * h.beta1, m.w * h.beta1);
-        v = make_float4(v.x * h.beta2, v.y * h.beta2, v.z * h.beta2, v.w * h.beta2);
+    if (k < nr) { // the rest of the gap in closed form: m, v within a few ulp of the multiplications one by one (as beyond CREC_REPLAY_MAX below)
+        const float fm = powf(h.beta1, (float)(nr - k)), fv = powf(h.beta2, (float)(nr - k));
+        m = make_float4(m.x * fm, m.y * fm, m.z * fm, m.w * fm);
+        v = make_float4(v.x * fv, v.y * fv, v.z * fv, v.w * fv);
     }
     if (n > nr) {
         const float f = powf(h.beta2, (float)(n - nr));
