@@ -890,12 +890,14 @@ __device__ __forceinline__ void win_load3(const float *a0, const float *a1, cons
                  : "memory");
     r0 = make_float4(x0.x, x0.y, x0.z, x0.w), r1 = make_float4(x1.x, x1.y, x1.z, x1.w), r2 = make_float4(x2.x, x2.y, x2.z, x2.w);
 }
-// written-through store (the data registers are read when the instruction issues; the caller's s_waitcnt vmcnt(0) in front of its
-// stamp waits for the acknowledgement)
+// written-through store (the caller's s_waitcnt vmcnt(0) in front of its stamp waits for the acknowledgement).  s_nop 1: on
+// gfx940 and later a store of more than 8 bytes needs TWO wait states before a VALU instruction may write its data registers
+// again, and the compiler's hazard bookkeeping does not look inside an assembly statement (seen in round 4 with the same
+// statement in tcf_triples: store data lost to the next row's arithmetic; crec_store.h)
 __device__ __forceinline__ void st4_wtg(float *p, float4 v)
 {
     const crec_f4v x = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" ::"v"(p), "v"(x) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
 }
 // the lazy step's published rows (contributions, partials): agent-scope accesses + s_waitcnt, or -- CREC_TICKET_FENCES,
 // the textbook form kept buildable and compared bit for bit under test (tests/test_gpu_fences.py) -- plain accesses

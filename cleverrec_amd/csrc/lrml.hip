@@ -21,6 +21,7 @@
 //   crec_apply_all  P, Q (TF1 sparse Adam over every row) and [K | M] (tile partials summed in fixed slices, dense Adam).
 // Deterministic: fixed summation orders, no atomics.
 #include "crec_internal.h"
+#include "crec_store.h"
 #include "rows_adam.h"
 #include "ncf_common.h"
 
@@ -210,10 +211,10 @@ __global__ __launch_bounds__(NT) void lrml_tile(const float *__restrict__ P, con
     // dK[c][s] = sum_r joint[r][c] * dlogits[r][s];  dM[s][c] = sum_r a[r][s] * dR[r][c]   (this tile's share)
     tile_gemm<NW>(
         d, mem, T, [&](int c, int r) { return J[r * ld + c]; }, [&](int r, int s) { return Dl[r * lm + s]; },
-        [&](int c, int s, float v) { part[c * mem + s] = v; });
+        [&](int c, int s, float v) { st_out(part + c * mem + s, v); });
     tile_gemm<NW>(
         mem, d, T, [&](int s, int r) { return At[r * lm + s]; }, [&](int r, int c) { return ev[r] * R[r * ld + c]; },
-        [&](int s, int c, float v) { part[d * mem + s * d + c] = v; });
+        [&](int s, int c, float v) { st_out(part + d * mem + s * d + c, v); });
     __syncthreads();
     // ---- contribution rows (without the l2 term: the update adds reg * row per occurrence) --------------------------
     //   d/dq   = dJ * p_u - dR          d/dp_u = (dJ_i * q_i + dR_i) + (dJ_j * q_j + dR_j)
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(NT) void lrml_tile(const float *__restrict__ P, con
         if (t < nr) {
             float *dst = c_q + (int64_t)((r < TT ? 0 : nb) + t0 + t) * d;
             for (int c = lane; c < d; c += 64)
-                dst[c] = DJ[r * ld + c] * Pu[t * ld + c] - ev[r] * R[r * ld + c];
+                st_out(dst + c, DJ[r * ld + c] * Pu[t * ld + c] - ev[r] * R[r * ld + c]);
         }
     }
     for (int rr = 0; rr < TT / NW; ++rr) {
@@ -230,8 +231,8 @@ __global__ __launch_bounds__(NT) void lrml_tile(const float *__restrict__ P, con
         if (t < nr) {
             float *dst = c_p + (int64_t)(t0 + t) * d;
             for (int c = lane; c < d; c += 64)
-                dst[c] = (DJ[t * ld + c] * Qx[t * ld + c] + ev[t] * R[t * ld + c]) +
-                         (DJ[(TT + t) * ld + c] * Qx[(TT + t) * ld + c] + ev[TT + t] * R[(TT + t) * ld + c]);
+                st_out(dst + c, (DJ[t * ld + c] * Qx[t * ld + c] + ev[t] * R[t * ld + c]) +
+                                    (DJ[(TT + t) * ld + c] * Qx[(TT + t) * ld + c] + ev[TT + t] * R[(TT + t) * ld + c]));
         }
     }
 }

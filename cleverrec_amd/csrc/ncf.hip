@@ -16,6 +16,7 @@
 //                   row; the small parameters: tile partials added in 16 fixed slices, TF1 dense ApplyAdam.
 // Everything is deterministic (fixed summation orders, no atomics).
 #include "crec_internal.h"
+#include "crec_store.h"
 #include "rows_adam.h"
 #include "ncf_common.h"
 
@@ -33,6 +34,16 @@ constexpr int NW = NT / 64;  // waves per workgroup
 constexpr int RW = T / NW;   // tile rows owned by one wave in the row-wise phases
 #ifndef NCF_GRID_DIV
 #define NCF_GRID_DIV 1 // tiles per workgroup (grid-stride): timing experiments
+#endif
+
+#ifndef NCF_PIPE
+#define NCF_PIPE 1 // dW_k / dX_0 products with the next block's operand reads in flight (tile_gemm_pipe)
+#endif
+#ifndef NCF_DH_LATE
+#define NCF_DH_LATE 1 // dL/dh reductions beside the last layer's dW product instead of in front of the backward pass
+#endif
+#ifndef NCF_DPP
+#define NCF_DPP 1 // the logit phase's sums over an instance's 16 lanes as DPP row operations
 #endif
 
 __device__ inline float sigmoidf_(float z) { return 1.0f / (1.0f + expf(-z)); }
@@ -81,8 +92,13 @@ template <int LC, class F> __device__ __forceinline__ void layers_down(int L, F 
     }
 }
 
+#ifdef NCF_WPE // timing experiments: cap the registers for NCF_WPE waves per SIMD (two 16-instance tiles per CU)
+#define NCF_OCC __attribute__((amdgpu_waves_per_eu(NCF_WPE, NCF_WPE)))
+#else
+#define NCF_OCC
+#endif
 template <int L0C, int LC, int DGC>
-__global__ __launch_bounds__(NT) void ncf_tile(NcfDev m, const int32_t *__restrict__ u, const int32_t *__restrict__ i,
+__global__ __launch_bounds__(NT) NCF_OCC void ncf_tile(NcfDev m, const int32_t *__restrict__ u, const int32_t *__restrict__ i,
                                                const float *__restrict__ y, int nb, float *__restrict__ c_pg,
                                                float *__restrict__ c_qg, float *__restrict__ c_pm,
                                                float *__restrict__ c_qm, float *__restrict__ loss_inst,
@@ -298,12 +314,16 @@ __global__ __launch_bounds__(NT) void ncf_tile(NcfDev m, const int32_t *__restri
         if (m.dbg && blockIdx.x == 7 && lane == 0)
             m.dbg[128 + wave * 16 + 2 * k] = __builtin_amdgcn_s_memtime();
 #endif
-        tile_gemm<NW>(
-            T, kout, kin, [&](int r, int kk) { return Ak[r * lda + kk]; }, [&](int kk, int c) { return Wl[kk * ws + c]; },
-            [&](int r, int c, float s) {
-                s += b[c];
-                An[r * ldo + c] = s > 0.f ? s : 0.f;
-            });
+        const auto fa_f = [&](int r, int kk) { return Ak[r * lda + kk]; };
+        const auto fb_f = [&](int kk, int c) { return Wl[kk * ws + c]; };
+        const auto fs_f = [&](int r, int c, float s) {
+            s += b[c];
+            An[r * ldo + c] = s > 0.f ? s : 0.f;
+        };
+        if (NCF_PIPE && FIXED && L0C == 128 && k == 0)
+            tile_gemm_2chunk<NW, 16>(T, kout, fa_f, fb_f, fs_f); // K = layers[0] = 128
+        else
+            tile_gemm<NW>(T, kout, kin, fa_f, fb_f, fs_f);
 #if NCF_ABL == 5
         if (m.dbg && blockIdx.x == 7 && lane == 0)
             m.dbg[128 + wave * 16 + 2 * k + 1] = __builtin_amdgcn_s_memtime();
@@ -348,12 +368,16 @@ __global__ __launch_bounds__(NT) void ncf_tile(NcfDev m, const int32_t *__restri
                 nm = nm + a * a;
             }
         }
+        if constexpr (LPI == 16 && NCF_DPP) {
+            zg = row16_sum(zg), ng = row16_sum(ng), zm = row16_sum(zm), nm = row16_sum(nm);
+        } else {
 #pragma unroll
-        for (int off = 1; off < LPI; off <<= 1) {
-            zg += __shfl_xor(zg, off, 64);
-            ng += __shfl_xor(ng, off, 64);
-            zm += __shfl_xor(zm, off, 64);
-            nm += __shfl_xor(nm, off, 64);
+            for (int off = 1; off < LPI; off <<= 1) {
+                zg += __shfl_xor(zg, off, 64);
+                ng += __shfl_xor(ng, off, 64);
+                zm += __shfl_xor(zm, off, 64);
+                nm += __shfl_xor(nm, off, 64);
+            }
         }
         if (sub == 0) {
             const bool ok = r < nr;
@@ -372,6 +396,28 @@ __global__ __launch_bounds__(NT) void ncf_tile(NcfDev m, const int32_t *__restri
     __syncthreads();
     float *part = partial + (int64_t)tile * n_small;
     STAMP(); // logit
+    // dL/dh_g (rows past nr carry e = 0): the LAST wave's job, dL/dh_m the one before's -- side by side.  With a tower they run
+    // beside the last layer's dW product (two or four blocks: most waves have none), not in front of the backward pass.
+    const auto dh_g_job = [&]() __attribute__((always_inline)) {
+        for (int c = wave == NW - 1 ? lane : dg; c < dg; c += 64) {
+            float s = 0.f;
+#pragma unroll 16
+            for (int r = 0; r < T; ++r)
+                s = s + e[r] * (G_p[r * ldg + c] * G_q[r * ldg + c]);
+            st_out(part + h_off + c, s);
+        }
+    };
+    const auto dh_m_job = [&]() __attribute__((always_inline)) {
+        const float *AL = A_(L);
+        const int ldl = LD_(L);
+        for (int c = wave == (NW >= 2 ? NW - 2 : 0) ? lane : last; c < last; c += 64) {
+            float s = 0.f;
+#pragma unroll 16
+            for (int r = 0; r < T; ++r)
+                s = s + e[r] * AL[r * ldl + c];
+            st_out(part + h_off + dg + c, s);
+        }
+    };
     // ---- GMF backward ----------------------------------------------------------------------------------------
     if (has_g) {
         for (int c = lane; c < dg; c += 64) {
@@ -381,31 +427,20 @@ __global__ __launch_bounds__(NT) void ncf_tile(NcfDev m, const int32_t *__restri
                 const int r = wave * RW + rr;
                 if (r < nr) {
                     const float er = e[r];
-                    c_pg[(int64_t)(r0 + r) * dg + c] = er * (G_q[r * ldg + c] * hc);
-                    c_qg[(int64_t)(r0 + r) * dg + c] = er * (G_p[r * ldg + c] * hc);
+                    st_out(c_pg + (int64_t)(r0 + r) * dg + c, er * (G_q[r * ldg + c] * hc));
+                    st_out(c_qg + (int64_t)(r0 + r) * dg + c, er * (G_p[r * ldg + c] * hc));
                 }
             }
         }
-        // dL/dh_g (rows past nr carry e = 0): the LAST wave's job, dL/dh_m below the one before's -- side by side
-        for (int c = wave == NW - 1 ? lane : dg; c < dg; c += 64) {
-            float s = 0.f;
-#pragma unroll 16
-            for (int r = 0; r < T; ++r)
-                s = s + e[r] * (G_p[r * ldg + c] * G_q[r * ldg + c]);
-            part[h_off + c] = s;
-        }
+        if (!has_m || !NCF_DH_LATE)
+            dh_g_job();
     }
     if (has_m) {
         const float *AL = A_(L);
         float *DL = D_(L);
         const int ldl = LD_(L);
-        for (int c = wave == (NW >= 2 ? NW - 2 : 0) ? lane : last; c < last; c += 64) { // dL/dh_m
-            float s = 0.f;
-#pragma unroll 16
-            for (int r = 0; r < T; ++r)
-                s = s + e[r] * AL[r * ldl + c];
-            part[h_off + dg + c] = s;
-        }
+        if (!NCF_DH_LATE)
+            dh_m_job();
         // D[L] = e * h_m * relu'
         for (int c = lane; c < last; c += 64) {
             const float hc = hl[dg + c];
@@ -422,16 +457,25 @@ __global__ __launch_bounds__(NT) void ncf_tile(NcfDev m, const int32_t *__restri
             float *Dk = D_(k);
             float *pw = part + fw_of(k);
             __syncthreads(); // D[k+1] complete
+            if (NCF_DH_LATE && k == L - 1) {
+                if (has_g)
+                    dh_g_job();
+                dh_m_job();
+            }
             // dW_k[kk][c] = sum_r A[k][r][kk] * D[k+1][r][c]   (rows past nr carry D = 0)
-            tile_gemm<NW>(
-                    kin, kout, T, [&](int kk, int r) { return Ak[r * lda + kk]; }, [&](int r, int c) { return Dn[r * ldd + c]; },
-                    [&](int kk, int c, float s) { pw[kk * kout + c] = s; });
+            const auto fa_w = [&](int kk, int r) { return Ak[r * lda + kk]; };
+            const auto fb_w = [&](int r, int c) { return Dn[r * ldd + c]; };
+            const auto fs_w = [&](int kk, int c, float s) { st_out(pw + kk * kout + c, s); };
+            if constexpr (NCF_PIPE && T % 16 == 0 && T <= 64)
+                tile_gemm_pipe<NW, T / 4>(kin, kout, fa_w, fb_w, fs_w);
+            else
+                tile_gemm<NW>(kin, kout, T, fa_w, fb_w, fs_w);
             for (int c = tid; c < kout; c += NT) { // db_k[c] = sum_r D[k+1][r][c]
                 float s = 0.f;
 #pragma unroll 16
                 for (int r = 0; r < T; ++r)
                     s = s + Dn[r * ldd + c];
-                part[fb_of(k) + c] = s;
+                st_out(part + fb_of(k) + c, s);
             }
             STAMP(); // dW_k
             // delta of the layer below: through its ReLU into D[k] (k > 0), or dL/dX = the contribution rows of the
@@ -443,17 +487,22 @@ __global__ __launch_bounds__(NT) void ncf_tile(NcfDev m, const int32_t *__restri
                         const int o = r * lda + kk;
                         Dk[o] = Ak[o] > 0.f ? s : 0.f;
                     });
-            else
-                tile_gemm<NW>(
-                    T, kin, kout, [&](int r, int c) { return Dn[r * ldd + c]; }, [&](int c, int kk) { return Wl[kk * ws + c]; },
-                    [&](int r, int kk, float s) {
-                        if (r < nr) {
-                            if (kk < hm)
-                                c_pm[(int64_t)(r0 + r) * hm + kk] = s;
-                            else
-                                c_qm[(int64_t)(r0 + r) * hm + (kk - hm)] = s;
-                        }
-                    });
+            else {
+                const auto fa_x = [&](int r, int c) { return Dn[r * ldd + c]; };
+                const auto fb_x = [&](int c, int kk) { return Wl[kk * ws + c]; };
+                const auto fs_x = [&](int r, int kk, float s) {
+                    if (r < nr) {
+                        if (kk < hm)
+                            st_out(c_pm + (int64_t)(r0 + r) * hm + kk, s);
+                        else
+                            st_out(c_qm + (int64_t)(r0 + r) * hm + (kk - hm), s);
+                    }
+                };
+                if constexpr (NCF_PIPE && FIXED && L0C == 128)
+                    tile_gemm_pipe<NW, 16>(T, kin, fa_x, fb_x, fs_x); // K = layers[1] = 64
+                else
+                    tile_gemm<NW>(T, kin, kout, fa_x, fb_x, fs_x);
+            }
             STAMP(); // dX_k
         });
     }

@@ -20,6 +20,7 @@
 // s, leaves every instance's ds = sigmoid(-b) * b / (s + 1) (b = the second argument; RealDiv's gradient) in a column, and
 // cune_scalar_step (one workgroup, launched after the tables' apply) sums the column in a fixed order and moves s.
 #include "crec_internal.h"
+#include "crec_store.h"
 #include "rows_adam.h"
 
 namespace {
@@ -92,11 +93,11 @@ __global__ __launch_bounds__(256) void sbpr_instances(const float *__restrict__ 
     if (!on)
         return;
     // contribution rows WITHOUT the l2 term (rows_adam.hip adds reg * row per occurrence)
-    st4(c_p + (int64_t)r * d + 4 * l, make_float4((gi * qi.x + gk * qk.x) + gj * qj.x, (gi * qi.y + gk * qk.y) + gj * qj.y,
+    st4_out(c_p, (int64_t)r * d + 4 * l, make_float4((gi * qi.x + gk * qk.x) + gj * qj.x, (gi * qi.y + gk * qk.y) + gj * qj.y,
                                                   (gi * qi.z + gk * qk.z) + gj * qj.z, (gi * qi.w + gk * qk.w) + gj * qj.w));
-    st4(c_q + (int64_t)r * d + 4 * l, make_float4(gi * p.x, gi * p.y, gi * p.z, gi * p.w));
-    st4(c_q + (int64_t)(B + r) * d + 4 * l, make_float4(gk * p.x, gk * p.y, gk * p.z, gk * p.w));
-    st4(c_q + (int64_t)(2 * B + r) * d + 4 * l, make_float4(gj * p.x, gj * p.y, gj * p.z, gj * p.w));
+    st4_out(c_q, (int64_t)r * d + 4 * l, make_float4(gi * p.x, gi * p.y, gi * p.z, gi * p.w));
+    st4_out(c_q, (int64_t)(B + r) * d + 4 * l, make_float4(gk * p.x, gk * p.y, gk * p.z, gk * p.w));
+    st4_out(c_q, (int64_t)(2 * B + r) * d + 4 * l, make_float4(gj * p.x, gj * p.y, gj * p.z, gj * p.w));
 }
 
 // the item slots of a group of batches, batch after batch: [i | k | j] with stride nbt (the batch's own length: a ragged last
