@@ -55,6 +55,7 @@
 #include "crec_comm.h"
 
 #include <rccl/rccl.h>
+typedef unsigned crec_u4v __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -802,7 +803,6 @@ __device__ __forceinline__ void st4s(float *p, float4 v)
 }
 // write-through (agent-scope, sc1) 16-byte store: the line does not stay dirty in this XCD's L2, so a later device-wide
 // barrier needs no L2 write-back to publish it.  base: wave-uniform table pointer; off: float index (< 2^29)
-typedef unsigned crec_u4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void st4_wt(float *base, int64_t off, float4 v)
 {
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000);

@@ -36,9 +36,6 @@ constexpr int RW = T / NW;   // tile rows owned by one wave in the row-wise phas
 #define NCF_GRID_DIV 1 // tiles per workgroup (grid-stride): timing experiments
 #endif
 
-#ifndef NCF_PIPE
-#define NCF_PIPE 1 // dW_k / dX_0 products with the next block's operand reads in flight (tile_gemm_pipe)
-#endif
 #ifndef NCF_DH_LATE
 #define NCF_DH_LATE 1 // dL/dh reductions beside the last layer's dW product instead of in front of the backward pass
 #endif
@@ -320,10 +317,7 @@ __global__ __launch_bounds__(NT) NCF_OCC void ncf_tile(NcfDev m, const int32_t *
             s += b[c];
             An[r * ldo + c] = s > 0.f ? s : 0.f;
         };
-        if (NCF_PIPE && FIXED && L0C == 128 && k == 0)
-            tile_gemm_2chunk<NW, 16>(T, kout, fa_f, fb_f, fs_f); // K = layers[0] = 128
-        else
-            tile_gemm<NW>(T, kout, kin, fa_f, fb_f, fs_f);
+        tile_gemm<NW>(T, kout, kin, fa_f, fb_f, fs_f);
 #if NCF_ABL == 5
         if (m.dbg && blockIdx.x == 7 && lane == 0)
             m.dbg[128 + wave * 16 + 2 * k + 1] = __builtin_amdgcn_s_memtime();
@@ -466,10 +460,7 @@ __global__ __launch_bounds__(NT) NCF_OCC void ncf_tile(NcfDev m, const int32_t *
             const auto fa_w = [&](int kk, int r) { return Ak[r * lda + kk]; };
             const auto fb_w = [&](int r, int c) { return Dn[r * ldd + c]; };
             const auto fs_w = [&](int kk, int c, float s) { st_out(pw + kk * kout + c, s); };
-            if constexpr (NCF_PIPE && T % 16 == 0 && T <= 64)
-                tile_gemm_pipe<NW, T / 4>(kin, kout, fa_w, fb_w, fs_w);
-            else
-                tile_gemm<NW>(kin, kout, T, fa_w, fb_w, fs_w);
+            tile_gemm<NW>(kin, kout, T, fa_w, fb_w, fs_w);
             for (int c = tid; c < kout; c += NT) { // db_k[c] = sum_r D[k+1][r][c]
                 float s = 0.f;
 #pragma unroll 16
@@ -498,10 +489,7 @@ __global__ __launch_bounds__(NT) NCF_OCC void ncf_tile(NcfDev m, const int32_t *
                             st_out(c_qm + (int64_t)(r0 + r) * hm + (kk - hm), s);
                     }
                 };
-                if constexpr (NCF_PIPE && FIXED && L0C == 128)
-                    tile_gemm_pipe<NW, 16>(T, kin, fa_x, fb_x, fs_x); // K = layers[1] = 64
-                else
-                    tile_gemm<NW>(T, kin, kout, fa_x, fb_x, fs_x);
+                tile_gemm<NW>(T, kin, kout, fa_x, fb_x, fs_x);
             }
             STAMP(); // dX_k
         });

@@ -145,104 +145,6 @@ __device__ __forceinline__ void tile_gemm(int M, int N, int K, FA fa, FB fb, FS 
     }
 }
 
-// The same product for K == 4 * S exactly (one chunk per output block) with the block loop software-pipelined: the operand
-// reads of a wave's NEXT block are in flight while the MFMAs of the current one issue -- a wave with several short blocks
-// (dW_0: four blocks of 8 MFMAs) otherwise waits one LDS round trip per block.  Same summation order as tile_gemm.
-template <int NWV, int S, class FA, class FB, class FS>
-__device__ __forceinline__ void tile_gemm_pipe(int M, int N, FA fa, FB fb, FS fs)
-{
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, l16 = lane & 15, q = lane >> 4;
-    const int nbn = (N + 15) >> 4, nblk = ((M + 15) >> 4) * nbn;
-    const auto load = [&](float(&a)[S], float(&b)[S], int blk) __attribute__((always_inline)) {
-        const int m0 = (blk / nbn) << 4, n0 = (blk % nbn) << 4;
-        const int mc = (m0 + l16) < M ? (m0 + l16) : M - 1, nc = (n0 + l16) < N ? (n0 + l16) : N - 1;
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            a[s] = fa(mc, s + S * q);
-            b[s] = fb(s + S * q, nc);
-        }
-    };
-    const auto run = [&](const float(&a)[S], const float(&b)[S], int blk) __attribute__((always_inline)) {
-        const int m0 = (blk / nbn) << 4, n0 = (blk % nbn) << 4, ni = n0 + l16;
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < S; s += 2) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s + 1], b[s + 1], acc1, 0, 0, 0);
-        }
-        if (ni < N) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (m0 + q * 4 + j < M)
-                    fs(m0 + q * 4 + j, ni, acc0[j] + acc1[j]);
-        }
-    };
-    float a0[S], b0[S], a1[S], b1[S];
-    int blk = wave;
-    if (blk >= nblk)
-        return;
-    load(a0, b0, blk);
-    for (;;) {
-        const int nxt = blk + NWV;
-        if (nxt < nblk)
-            load(a1, b1, nxt);
-        __builtin_amdgcn_sched_barrier(0);
-        run(a0, b0, blk);
-        if (nxt >= nblk)
-            break;
-        blk = nxt + NWV;
-        if (blk < nblk)
-            load(a0, b0, blk);
-        __builtin_amdgcn_sched_barrier(0);
-        run(a1, b1, nxt);
-        if (blk >= nblk)
-            break;
-    }
-}
-
-// The same product for K == 8 * S exactly (two chunks per output block): BOTH chunks' operand reads are in flight before the
-// first MFMA issues, so the second chunk's LDS round trip hides behind the first chunk's MFMAs (layer 0 of the forward pass:
-// K = 128, one block per wave).  Same summation order as tile_gemm.
-template <int NWV, int S, class FA, class FB, class FS>
-__device__ __forceinline__ void tile_gemm_2chunk(int M, int N, FA fa, FB fb, FS fs)
-{
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, l16 = lane & 15, q = lane >> 4;
-    const int nbn = (N + 15) >> 4, nblk = ((M + 15) >> 4) * nbn;
-    for (int blk = wave; blk < nblk; blk += NWV) {
-        const int m0 = (blk / nbn) << 4, n0 = (blk % nbn) << 4, ni = n0 + l16;
-        const int mc = (m0 + l16) < M ? (m0 + l16) : M - 1, nc = ni < N ? ni : N - 1;
-        float a0[S], b0[S], a1[S], b1[S];
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            a0[s] = fa(mc, s + S * q);
-            b0[s] = fb(s + S * q, nc);
-        }
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            a1[s] = fa(mc, 4 * S + s + S * q);
-            b1[s] = fb(4 * S + s + S * q, nc);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < S; s += 2) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], b0[s], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s + 1], b0[s + 1], acc1, 0, 0, 0);
-        }
-#pragma unroll
-        for (int s = 0; s < S; s += 2) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], b1[s], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s + 1], b1[s + 1], acc1, 0, 0, 0);
-        }
-        if (ni < N) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (m0 + q * 4 + j < M)
-                    fs(m0 + q * 4 + j, ni, acc0[j] + acc1[j]);
-        }
-    }
-}
-
 // sum over the 16 lanes of a DPP row, the total in every lane: xor 1 and xor 2 inside the quads, then the mirrors of 8 and of 16
 // lanes -- four VALU instructions where four __shfl_xor are four LDS round trips
 template <int CTRL> __device__ __forceinline__ float dpp_f32(float x)
