@@ -2956,15 +2956,16 @@ struct CopyTables {
     const float4 *src[6];
     int64_t n4[6];
 };
-__global__ __launch_bounds__(256) void copy_tables(const CopyTables c)
+// table k's share of workgroup bx of nbx (any number of threads per workgroup)
+__device__ __forceinline__ void copy_tables_block(const CopyTables &c, int k, int bx, int nbx)
 {
-    const int k = blockIdx.y;
     float4 *__restrict__ dst = c.dst[k];
     const float4 *__restrict__ src = c.src[k];
-    const int64_t n = c.n4[k];
-    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < n; o += (int64_t)gridDim.x * 256)
+    const int64_t n = c.n4[k], nt = blockDim.x;
+    for (int64_t o = (int64_t)bx * nt + threadIdx.x; o < n; o += (int64_t)nbx * nt)
         dst[o] = src[o];
 }
+__global__ __launch_bounds__(256) void copy_tables(const CopyTables c) { copy_tables_block(c, blockIdx.y, blockIdx.x, gridDim.x); }
 
 // deferred mode: every row of a table brought up to the state after step h.step (before evaluation / a checkpoint);
 // a lane group per row
@@ -3016,13 +3017,26 @@ __global__ __launch_bounds__(256) void bpr_adam_dense(float *__restrict__ var, f
 // between launches.
 // ------------------------------------------------------------------------------------
 constexpr int RL_THREADS = 512, RL_PARTS = 4;
-__global__ __launch_bounds__(RL_THREADS) void bpr_reduce_loss(const float *__restrict__ ws, int64_t stride, int64_t n_total,
-                                                       int32_t B, int64_t n_dense, const int32_t *__restrict__ n_u,
-                                                       const int32_t *__restrict__ n_q, float reg, double *__restrict__ parts,
-                                                       int32_t *__restrict__ tickets, float *__restrict__ loss_per_batch)
+struct ReduceLoss {
+    const float *ws;
+    int64_t stride, n_total;
+    int32_t B;
+    int64_t n_dense;
+    float reg;
+    double *parts;
+    int32_t *tickets;
+    float *loss_per_batch;
+};
+__device__ __forceinline__ void reduce_loss_block(const ReduceLoss &a, int blk, double *part)
 {
-    __shared__ double part[RL_THREADS];
-    const int batch = blockIdx.x / RL_PARTS, p = blockIdx.x % RL_PARTS;
+    const float *__restrict__ ws = a.ws;
+    const int64_t stride = a.stride, n_total = a.n_total, n_dense = a.n_dense;
+    const int32_t B = a.B;
+    const float reg = a.reg;
+    double *__restrict__ parts = a.parts;
+    int32_t *__restrict__ tickets = a.tickets;
+    float *__restrict__ loss_per_batch = a.loss_per_batch;
+    const int batch = blk / RL_PARTS, p = blk % RL_PARTS;
     const int64_t t0 = (int64_t)batch * B;
     const int nb = (int)((n_total - t0) < B ? (n_total - t0) : B);
     const float *xb = ws + batch * stride, *rowterm = xb + B;
@@ -3068,6 +3082,28 @@ __global__ __launch_bounds__(RL_THREADS) void bpr_reduce_loss(const float *__res
             __hip_atomic_store(tickets + batch, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next launch
         }
     }
+}
+__global__ __launch_bounds__(RL_THREADS) void bpr_reduce_loss(const float *__restrict__ ws, int64_t stride, int64_t n_total,
+                                                       int32_t B, int64_t n_dense, const int32_t *__restrict__ n_u,
+                                                       const int32_t *__restrict__ n_q, float reg, double *__restrict__ parts,
+                                                       int32_t *__restrict__ tickets, float *__restrict__ loss_per_batch)
+{
+    __shared__ double part[RL_THREADS];
+    reduce_loss_block(ReduceLoss{ws, stride, n_total, B, n_dense, reg, parts, tickets, loss_per_batch}, blockIdx.x, part);
+}
+// The tail of a call that ends in the second buffer set: the last chunk's loss reduction and the tables' way home are
+// independent of each other and both wait for the last step -- ONE launch (the reduction's workgroups first, then
+// TAIL_COPY_BX workgroups per table) instead of two: a launch boundary less behind a 20-batch call.
+constexpr int TAIL_COPY_BX = 32;
+__global__ __launch_bounds__(RL_THREADS) void bpr_call_tail(const ReduceLoss rl, int n_loss_blocks, const CopyTables c)
+{
+    __shared__ double part[RL_THREADS];
+    if ((int)blockIdx.x < n_loss_blocks) {
+        reduce_loss_block(rl, blockIdx.x, part);
+        return;
+    }
+    const int cb = (int)blockIdx.x - n_loss_blocks;
+    copy_tables_block(c, cb / TAIL_COPY_BX, cb % TAIL_COPY_BX, TAIL_COPY_BX);
 }
 
 #include "shard_kernels.h"
@@ -3708,25 +3744,35 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
         const bool *in_shadow;
         size_t bytesP, bytesQ;
         hipStream_t st;
-        int run() const
+        // the copies that bring the current tables home (0 when they are at home): the tables' description and how many
+        int describe(CopyTables *c, int64_t *most) const
         {
             if (!*in_shadow)
-                return (int)hipSuccess;
+                return 0;
             const Tables &s = a->cur;
-            // ONE launch for the six tables: six device copies of 1.5 / 0.9 MB each took 4.9 us apiece behind a 20-batch call
-            // (29 of its 177 us)
-            CopyTables c{};
             const bool q_too = s.Q != t->Q;
             float *const dst[6] = {t->P, t->mP, t->vP, t->Q, t->mQ, t->vQ};
             const float *const src[6] = {s.P, s.mP, s.vP, s.Q, s.mQ, s.vQ};
-            int64_t most = 0;
+            *c = CopyTables{};
+            *most = 0;
             for (int k = 0; k < (q_too ? 6 : 3); ++k) {
-                c.dst[k] = reinterpret_cast<float4 *>(dst[k]), c.src[k] = reinterpret_cast<const float4 *>(src[k]);
-                c.n4[k] = (int64_t)((k < 3 ? bytesP : bytesQ) / sizeof(float4));
-                most = c.n4[k] > most ? c.n4[k] : most;
+                c->dst[k] = reinterpret_cast<float4 *>(dst[k]), c->src[k] = reinterpret_cast<const float4 *>(src[k]);
+                c->n4[k] = (int64_t)((k < 3 ? bytesP : bytesQ) / sizeof(float4));
+                *most = c->n4[k] > *most ? c->n4[k] : *most;
             }
+            return q_too ? 6 : 3;
+        }
+        int run() const
+        {
+            // ONE launch for the six tables: six device copies of 1.5 / 0.9 MB each took 4.9 us apiece behind a 20-batch call
+            // (29 of its 177 us)
+            CopyTables c{};
+            int64_t most = 0;
+            const int n = describe(&c, &most);
+            if (n == 0)
+                return (int)hipSuccess;
             const unsigned bx = (unsigned)(crec_ceil_div(most, 256) < 256 ? crec_ceil_div(most, 256) : 256);
-            hipLaunchKernelGGL(copy_tables, dim3(bx ? bx : 1, q_too ? 6u : 3u), dim3(256), 0, st, c);
+            hipLaunchKernelGGL(copy_tables, dim3(bx ? bx : 1, (unsigned)n), dim3(256), 0, st, c);
             return (int)hipGetLastError();
         }
         bool done = false;
@@ -4021,10 +4067,23 @@ int train_epoch_impl(crec_ctx *ctx, const crec_bpr_tables *t, crec_adam *opt, co
         int32_t *l_tickets;
         if (int rc = loss_parts(ctx, chunk, st, &l_parts, &l_tickets))
             return rc;
+        // the call's last chunk, its tables in the second buffer set: their way home rides in the reduction's launch
+        CopyTables home_c{};
+        int64_t home_most = 0;
+        const int home_n = b0 + nbc >= nb && !ctx->knob_no_call_tail ? home.describe(&home_c, &home_most) : 0;
         crec_prof_begin(ctx, CREC_K_REDUCE_LOSS, st);
-        CREC_KLAUNCH(ctx, bpr_reduce_loss, dim3((unsigned)(nbc * RL_PARTS)), dim3(RL_THREADS), 0, st, (const float *)ctx->loss_ws.ptr,
-                           loss_stride, n_chunk, B, dense ? t->U + t->I : (int64_t)0, (const int32_t *)w.n_u,
-                           (const int32_t *)w.n_q, opt->reg, l_parts, l_tickets, loss_per_batch + b0);
+        if (home_n > 0) {
+            const ReduceLoss rl{(const float *)ctx->loss_ws.ptr, loss_stride, n_chunk, B, dense ? t->U + t->I : (int64_t)0, opt->reg, l_parts,
+                                l_tickets, loss_per_batch + b0};
+            CREC_KLAUNCH(ctx, bpr_call_tail, dim3((unsigned)(nbc * RL_PARTS + home_n * TAIL_COPY_BX)), dim3(RL_THREADS), 0, st, rl,
+                         (int)(nbc * RL_PARTS), home_c);
+            if (hipPeekAtLastError() == hipSuccess)
+                in_shadow = false; // (a launch that failed leaves the copy owed: BringHome runs it on the error return below)
+        } else {
+            CREC_KLAUNCH(ctx, bpr_reduce_loss, dim3((unsigned)(nbc * RL_PARTS)), dim3(RL_THREADS), 0, st, (const float *)ctx->loss_ws.ptr,
+                         loss_stride, n_chunk, B, dense ? t->U + t->I : (int64_t)0, (const int32_t *)w.n_u, (const int32_t *)w.n_q,
+                         opt->reg, l_parts, l_tickets, loss_per_batch + b0);
+        }
         crec_prof_end(ctx, st);
         if (dp) {
             if (int rc = xdp->allreduce_sum_f32(ctx, loss_per_batch + b0, (size_t)nbc, st))

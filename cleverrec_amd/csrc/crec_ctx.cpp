@@ -327,6 +327,8 @@ int crec_ctx_set_option(crec_ctx *ctx, const char *name, int64_t value)
         ctx->knob_flow_abl = (int)value;
     else if (n == "tf1_sweep")
         ctx->knob_tf1_sweep = (int)value;
+    else if (n == "no_call_tail")
+        ctx->knob_no_call_tail = (int)value;
     else if (n == "idx_no_ids16")
         ctx->knob_idx_no_ids16 = (int)value;
     else if (n == "flow_steps")

@@ -125,6 +125,7 @@ struct crec_ctx {
     int knob_eval_no_bitmap = 0; // 1: seen filter by binary search even where the bitmaps would fit
     int knob_no_zero_copy = 0;   // 1: the chunk's counts come back by copy + stream synchronisation (tests)
     int knob_shard_unfused = 0;  // 1: the row-sharded step over the peer transport as five launches (serve, exchange, step, exchange, apply) like over RCCL (tests)
+    int knob_no_call_tail = 0;   // 1: a call that ends in the second buffer set brings its tables home in a launch of its own (default: inside the last chunk's loss reduction launch)
     int knob_tf1_sweep = 0;      // 1: adam_mode tf1 sweeps every row at every step whatever the tables' size (default: tables of 64 MB and more run the call as deferred Adam + flush)
     int knob_idx_no_ids16 = 0;   // 1: the tf1 index gathers its records' ids from the streams (test: the same records as from LDS)
     int knob_idx_overlap = 0;    // 1: chunks of batches are indexed a chunk ahead on a side stream, beside the previous chunk's steps (index_big's, and the lazy family's LDS-built ones)

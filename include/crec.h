@@ -91,6 +91,8 @@ const char *crec_last_error(const crec_ctx *ctx);
  *                    rows and d >= 32 (S-big: 18.6 -> 13.4 us/step, uniform positives 21.4 -> 13.7), else 0 (small catalogues, where
  *                    every row recurs from batch to batch and the launch is bound by the rows' way through it: ml-1m +13 %)
  *   "tf1_sweep"      1: adam_mode tf1 sweeps every row at every step whatever the tables' size (see crec_bpr_train_epoch)
+ *   "no_call_tail"   1: a tf1 call that ends in the ctx's second buffer set copies its tables home in a launch of its own (default 0:
+ *                    the copy rides in the last chunk's loss reduction launch -- a launch boundary less per call; the same tables)
  *   "idx_no_ids16"   1: the tf1 index gathers its occurrence records' ids from the streams instead of from the 16-bit copies it keeps in LDS
  *                    where both catalogues are below 65 536 rows (the same records)
  *   "flow_abl"       timing ablations of bpr_steps_flow / the window (results are WRONG; tools/ only)

@@ -149,3 +149,17 @@ def test_records_from_lds_ids_are_the_gathered_records(sess, flow, U, I, d, B, n
     got, _ = _run(sess, {"flow": flow}, P0, Q0, u, i, j, B)
     for x, y, name in zip(ref, got, ("loss", "P", "Q", "mP", "mQ", "vP", "vQ")):
         assert np.array_equal(x, y), name
+
+
+@pytest.mark.parametrize("flow", [1, 0])
+@pytest.mark.parametrize("U,I,d,B,nb", [(6040, 3706, 64, 6144, 20), (6040, 3706, 64, 6144, 67), (333, 777, 20, 1000, 11), (150, 90, 16, 256, 5)])
+def test_tables_brought_home_inside_the_loss_reduction_launch_are_the_same_tables(sess, flow, U, I, d, B, nb):
+    """A call that ends in the ctx's second buffer set brings its tables home inside the last chunk's loss reduction launch
+    (bpr_call_tail); option no_call_tail = 1 keeps the copy a launch of its own.  Same tables, slots and losses, bit for bit, over
+    calls of odd and even length, with either step kernel (RankingRecommender.py:39-47: the caller's tables after every call)."""
+    u, i, j = _stream(U + nb, U, I, nb * B + B // 5 + 1)
+    P0, Q0 = _tables(4, U, I, d)
+    a, _ = _run(sess, {"flow": flow}, P0, Q0, u, i, j, B, calls=3)
+    b, _ = _run(sess, {"flow": flow, "no_call_tail": 1}, P0, Q0, u, i, j, B, calls=3)
+    for x, y, name in zip(a, b, ("loss", "P", "Q", "mP", "mQ", "vP", "vQ")):
+        assert np.array_equal(x, y), name

@@ -30,6 +30,7 @@ sess.ctx.seed(1)
 u, i, j = (sess.to_dev(x) for x in sess.ctx.sample_pairwise(data.train_csr, data.item_nums, 4))
 for flow, abl in [(f_, a_) for f_ in a.flow for a_ in (a.abl if f_ != 0 else [0])]:
     sess.ctx.set_option("flow", flow)
+    sess.ctx.set_option("no_call_tail", int(os.environ.get("CREC_NO_CALL_TAIL", "0")))  # tools/time_call_tail.sh
     sess.ctx.set_option("flow_abl", abl)
     st = runtime.BprState(sess, P0, Q0, lr=1e-3, reg=0.01, adam_mode="tf1")
     for steps in a.steps:
