@@ -10,7 +10,8 @@
 //                   as 16x16x4 fp32 MFMA products between LDS buffers (tile_gemm, ncf_common.h); GMF product, logit,
 //                   e = sigmoid(logit) - y, loss term.  Writes per-instance contribution rows for the embedding
 //                   tables (dL/drow without the l2 term; layer 0's dL/dX goes straight out) and per-tile partial
-//                   gradients of the small dense parameters (W_k, b_k, h).
+//                   gradients of the small dense parameters (W_k, b_k, h) -- all of them written THROUGH the L2
+//                   (crec_store.h): left dirty there they were written back at the kernel's end, 4 us per launch.
 //   crec_apply_all  (rows_adam.hip) every parameter update in one launch: per embedding table, contribution rows
 //                   summed per table row in batch order (+ reg * row per occurrence), TF1 sparse Adam over every
 //                   row; the small parameters: tile partials added in 16 fixed slices, TF1 dense ApplyAdam.
